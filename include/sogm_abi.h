@@ -1,0 +1,310 @@
+/*
+ * sogm_abi.h — the extern "C" drop-in boundary of the MI355X-native SOGM replan hot path.
+ *
+ * The reference (siyuanwu99/pred-occ-planner) has no FFI/plugin layer: plan_manager links the
+ * map / search / corridor / optimiser class libraries directly (plan_manager/CMakeLists.txt:15-32)
+ * and calls them through shared_ptr members (plan_manager/include/plan_manager/baseline.h:155-158).
+ * The drop-in boundary is therefore (i) the C++ facade classes in
+ * the headers under pred-occ-planner_amd/host/, which keep the reference method names, and (ii) this C ABI,
+ * which those facades (and the Python ctypes host) forward to.  Each entry point cites the
+ * reference interface it replaces.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no torch / Eigen / ROS types;
+ *   - every array argument marked "dev" is a DEVICE pointer (HBM resident), "host" a host pointer;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream);
+ *   - all calls are asynchronous on `stream` unless documented otherwise;
+ *   - return value: 0 = SOGM_OK, negative = sogm_status error; no exceptions cross the boundary;
+ *   - one context per thread (thread-compatible, not thread-safe), like the reference objects;
+ *   - there is NO CPU fallback: without a HIP device every compute call returns SOGM_ERR_NO_DEVICE.
+ */
+#ifndef SOGM_ABI_H
+#define SOGM_ABI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------------------------ */
+/* status                                                                                      */
+/* ------------------------------------------------------------------------------------------ */
+typedef enum sogm_status {
+  SOGM_OK              = 0,
+  SOGM_ERR_INVALID_ARG = -1,
+  SOGM_ERR_NO_DEVICE   = -2, /* no HIP device / HIP runtime error at create time             */
+  SOGM_ERR_HIP         = -3, /* a HIP call failed; see sogm_last_error()                     */
+  SOGM_ERR_CAPACITY    = -4, /* an output buffer / pool was too small                        */
+  SOGM_ERR_STATE       = -5  /* call order violated (e.g. query before any update)           */
+} sogm_status;
+
+/* ------------------------------------------------------------------------------------------ */
+/* plain-data records                                                                          */
+/* ------------------------------------------------------------------------------------------ */
+
+/* Which reference map class the context reproduces. */
+enum {
+  SOGM_MAP_FAKE     = 0, /* FakeParticleRiskVoxel  plan_env/src/fake_particle_risk_voxel.cpp     */
+  SOGM_MAP_RISKBASE = 1  /* RiskBase               plan_env/src/risk_base.cpp                    */
+};
+
+/*
+ * Grid + map parameters.  The reference fixes L,W,H,T with macros
+ * (plan_env/include/plan_env/map_parameters.h:5-13); here they are runtime values.
+ * Field defaults (reference):  66,66,20,6, 0.15, time_resolution 0.2 (map.cpp:30),
+ * risk_threshold 0.2 (map.cpp:35), clearance 0.3 (map.cpp:36; sim_fake.yaml:71 -> 0.45),
+ * ceiling 2.0 / ground -1.0 (map.cpp:37-38; sim_fake.yaml:68-69 -> 3.0 / -0.01),
+ * region threshold 1.2, decays 0.2 (risk_base.cpp:21-23).
+ */
+typedef struct SogmSpec {
+  int32_t L, W, H, T;
+  float   resolution;
+  float   time_resolution;
+  float   risk_threshold;
+  float   clearance;
+  float   ground_height;
+  float   ceiling_height;
+  float   risk_threshold_region;
+  float   risk_thres_reg_decay;
+  float   risk_thres_vox_decay;
+  int32_t map_kind; /* SOGM_MAP_FAKE | SOGM_MAP_RISKBASE */
+} SogmSpec;
+
+/* Ground-truth obstacle record, field-for-field `struct Cylinder`
+ * (plan_env/include/plan_env/fake_particle_risk_voxel.h:31-44). type 3 = cylinder, 2 = ring. */
+typedef struct SogmCylinder {
+  int32_t type;
+  int32_t _pad;
+  double  x, y, z, w, h, vx, vy, qw, qx, qy, qz;
+} SogmCylinder;
+
+/*
+ * One shared trajectory = the payload of traj_utils/msg/BezierTraj.msg:1-9 as stored by
+ * ParticleATC::trajectoryCallback (traj_coordinator/src/particles.cpp:131-191) in
+ * SwarmParticleTraj (traj_coordinator/include/traj_coordinator/particle.hpp:30-37).
+ * Fixed size so that one RCCL all-gather moves the whole swarm's records.
+ * n_pieces == 0 means "no trajectory received from this drone".
+ * cpts: piece-major, 5 control points per piece, xyz-minor (row k = piece*5 + j).
+ */
+#define SOGM_MAX_PIECES 16
+typedef struct SogmTrajRecord {
+  int32_t drone_id;
+  int32_t n_pieces;
+  double  time_start; /* absolute seconds (traj_msg->start_time) */
+  double  duration[SOGM_MAX_PIECES];
+  double  cpts[SOGM_MAX_PIECES * 5 * 3];
+} SogmTrajRecord;
+
+/* Search parameters = FakeRiskHybridAstar::setParam (path_searching/src/fake_risk_hybrid_a_star.cpp:62-82),
+ * values from plan_manager/config/sim_fake.yaml:15-29. */
+typedef struct SogmAstarParams {
+  double  max_tau;
+  double  max_vel;
+  double  max_acc;
+  double  w_time;
+  double  horizon;
+  double  lambda_heu;
+  double  resolution;      /* search/resolution_astar */
+  double  time_resolution; /* search/time_resolution  */
+  int32_t allocate_num;
+  int32_t check_num;
+  int32_t tolerance; /* search/tolerance, default 1 */
+  int32_t _pad;
+} SogmAstarParams;
+
+/* Planner parameters = BaselineParameters (plan_manager/include/plan_manager/baseline.h:45-94). */
+typedef struct SogmPlannerParams {
+  double  corridor_tau;
+  double  init_range;
+  double  shrink_size;
+  double  opt_max_vel;
+  double  opt_max_acc;
+  int32_t fake_planner; /* 1 = FakeBaselinePlanner rules (baseline_fake.cpp), 0 = BaselinePlanner */
+  int32_t firi_iterations; /* 2 at baseline.cpp:352 */
+  int32_t pc_capacity;     /* max obstacle points per corridor box */
+  int32_t max_faces;       /* max faces kept per polytope */
+} SogmPlannerParams;
+
+/* QP solver settings = OSQP v0.6 defaults as used through IOSQP (traj_opt/include/iosqp.hpp:40-115,
+ * traj_opt/src/bezier_optimizer.cpp:269); adaptive rho is disabled (fixed KKT factor). */
+typedef struct SogmQpSettings {
+  double  rho;
+  double  sigma;
+  double  alpha;
+  double  eps_abs;
+  double  eps_rel;
+  int32_t max_iter;
+  int32_t check_termination;
+  int32_t scaling_iters;
+  int32_t _pad;
+} SogmQpSettings;
+
+typedef struct sogm_ctx sogm_ctx;
+
+/* ------------------------------------------------------------------------------------------ */
+/* library                                                                                     */
+/* ------------------------------------------------------------------------------------------ */
+/* ABI version of this header; bumps on any signature change. */
+int         sogm_abi_version(void);
+/* Text of the last HIP error seen by this thread ("" if none). */
+const char *sogm_last_error(void);
+/* Number of visible HIP devices (0 without a GPU; never fails). */
+int         sogm_device_count(void);
+
+/* ------------------------------------------------------------------------------------------ */
+/* map context:  MapBase::init / RiskBase::init / FakeParticleRiskVoxel::init                   */
+/*   (plan_env/src/map.cpp:42-105, risk_base.cpp:15-58, fake_particle_risk_voxel.cpp:20-73)    */
+/* ------------------------------------------------------------------------------------------ */
+/* Allocates the batched SOGM  sogm[n_agents][T][H][W][L]  (fp32, time-major slabs) on `device`. */
+int  sogm_create(const SogmSpec *spec, int n_agents, int device, sogm_ctx **out);
+void sogm_destroy(sogm_ctx *ctx);
+/* Bytes of HBM held by the grid. */
+int64_t sogm_grid_bytes(const sogm_ctx *ctx);
+/* Device pointer of the grid (layout above). */
+float  *sogm_grid_ptr(sogm_ctx *ctx);
+
+/* Body particles of one drone: ParticleATC::initEgoParticles (particles.cpp:62-87).
+ * host: xyz[n*3] offsets (fp64).  Every drone of the swarm uses the same set. */
+int sogm_set_body_particles(sogm_ctx *ctx, const double *xyz_host, int n);
+
+/* Per-kernel timing with HIP events recorded on the caller's stream around each launch (used by
+ * bench.py for the roofline figure).  Slots: */
+enum {
+  SOGM_PROF_CLEAR = 0, /* k_clear_slabs  (the voxel-update roofline kernel) */
+  SOGM_PROF_STAMP = 1, /* k_stamp_cloud                                      */
+  SOGM_PROF_SPLAT = 2, /* k_splat_neighbours                                 */
+  SOGM_PROF_ASTAR = 3,
+  SOGM_PROF_CORRIDOR = 4,
+  SOGM_PROF_QP = 5,
+  SOGM_PROF_N = 6
+};
+int sogm_set_profiling(sogm_ctx *ctx, int enable);
+/* Synchronises the device, then writes the duration (ms) of the LAST launch of each slot
+ * (negative if that slot has not run since profiling was enabled).  host out_ms[SOGM_PROF_N]. */
+int sogm_profile_read(sogm_ctx *ctx, double *out_ms_host);
+
+/* ------------------------------------------------------------------------------------------ */
+/* SOGM update                                                                                 */
+/* ------------------------------------------------------------------------------------------ */
+/*
+ * FakeParticleRiskVoxel::updateMap (fake_particle_risk_voxel.cpp:80-222) without the neighbour
+ * overlay, for every agent of the batch:
+ *   crop cloud to pose +- range (:88-104), zero the grid (:107-108), mark slice 0 (:111-116),
+ *   for each occupied voxel look up the GT velocity (:127-154) and stamp slices 1..T-1 (:155-160).
+ * dev  cloud_xyz     [n_points*3] fp32, world frame
+ * dev  cloud_range   [n_agents*2] int32 {begin,end} point indices seen by each agent
+ * dev  cylinders     [n_cyl]      SogmCylinder          (shared GT state, may be NULL if n_cyl==0)
+ * dev  poses         [n_agents*3] fp32  map centre (MapBase::pose_)
+ * dev  stamps        [n_agents]   fp64  last_update_time_ (absolute seconds)
+ */
+int sogm_update_gt(sogm_ctx *ctx, const float *cloud_xyz, const int32_t *cloud_range,
+                   const SogmCylinder *cylinders, int n_cyl, const float *poses,
+                   const double *stamps, void *stream);
+
+/*
+ * Neighbour overlay: RiskBase::addOtherAgents (risk_base.cpp:136-168) ==
+ * fake_particle_risk_voxel.cpp:178-218, through ParticleATC::getParticlesWithRisk
+ * (particles.cpp:346-422, replan_risk_rate == 0 branch) and addParticlesToRiskMap
+ * (risk_base.cpp:199-208).  Uses the poses/stamps of the last update.
+ * dev  records  [n_records] SogmTrajRecord  (the swarm's latest trajectories)
+ * dev  ego_ids  [n_agents]  int32           drone_id of each batch agent (skipped as "ego")
+ */
+int sogm_project_neighbours(sogm_ctx *ctx, const SogmTrajRecord *records, int n_records,
+                            const int32_t *ego_ids, void *stream);
+
+/*
+ * RiskBase::futureRiskCallback (risk_base.cpp:60-80): adopt an externally produced SOGM.
+ * dev  grid_vt  [n_agents][V][T] fp32 in the REFERENCE layout (voxel-major); transposed into slabs.
+ */
+int sogm_set_future_risk(sogm_ctx *ctx, const float *grid_vt, const float *poses,
+                         const double *stamps, void *stream);
+
+/* Copy agent `a`'s grid to host in the reference layout risk_maps_[V][T] (map.h:52). Synchronous. */
+int sogm_download_reference_layout(sogm_ctx *ctx, int agent, float *out_vt_host);
+
+/* ------------------------------------------------------------------------------------------ */
+/* queries                                                                                     */
+/* ------------------------------------------------------------------------------------------ */
+/*
+ * getClearOcccupancy(pos, double dt)  — fake_particle_risk_voxel.cpp:309-346 / risk_base.cpp:228-260.
+ * dev agent_idx[n_q] int32, dev pos_xyz[n_q*3] fp64 (world), dev t[n_q] fp64 (seconds after the map
+ * stamp; if t_is_index != 0 the value is an integer slice index, the (pos,int) overload).
+ * dev out[n_q] int8: 0 free, 1 occupied, -1 out of bound.
+ */
+int sogm_query_clear(sogm_ctx *ctx, const int32_t *agent_idx, const double *pos_xyz,
+                     const double *t, int t_is_index, int n_q, int8_t *out, void *stream);
+
+/*
+ * getObstaclePoints(points, t_start, t_end, lc, hc) — map.cpp:480-518 (fake map) /
+ * risk_base.cpp:295-337 (RiskBase, decayed threshold).  One box per entry, points appended in the
+ * reference's z,y,x,slice order.
+ * dev agent_idx[n_b], box_lo[n_b*3], box_hi[n_b*3], t0[n_b], t1[n_b] (absolute seconds);
+ * dev out_pts[n_b*cap*3] fp64, dev out_counts[n_b] int32 (true count; > cap means truncated).
+ */
+int sogm_obstacle_points(sogm_ctx *ctx, const int32_t *agent_idx, const double *box_lo,
+                         const double *box_hi, const double *t0, const double *t1, int n_b,
+                         double *out_pts, int32_t *out_counts, int cap, void *stream);
+
+/* ------------------------------------------------------------------------------------------ */
+/* planner context: search + corridors + QP, batched over the same agents as the map            */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct sogm_planner sogm_planner;
+
+/* FakeBaselinePlanner::init / BaselinePlanner::init (baseline_fake.cpp:18-51, baseline.cpp:15-43). */
+int  sogm_planner_create(sogm_ctx *map, const SogmAstarParams *astar, const SogmPlannerParams *pp,
+                         const SogmQpSettings *qp, sogm_planner **out);
+void sogm_planner_destroy(sogm_planner *p);
+
+/*
+ * FakeRiskHybridAstar::reset + search (fake_risk_hybrid_a_star.cpp:84-426), then
+ * getPathWithVel(corridor_tau) (:663-694), for every agent.  The `init=true` search is retried with
+ * `init=false` when it returns NO_PATH, as baseline_fake.cpp:284-291 does.
+ * dev start_pva [n_agents*9] fp64 rows pos,vel,acc;  dev goal [n_agents*3] fp64;
+ * dev t_start   [n_agents]   fp64 absolute trajectory start time (traj_start_time_)
+ * dev out_ret   [n_agents]   int32 ASTAR_RET (dyn_a_star.h:15)
+ * dev out_route [n_agents*route_cap*6] fp64, dev out_route_len [n_agents] int32
+ * dev out_stats [n_agents*4] int32 {use_node_num, iter_num, n_path_nodes, searches_run}
+ * dev out_trace [n_agents*trace_cap] int32 or NULL: pool id of every popped node, in order.
+ */
+int sogm_astar_search(sogm_planner *p, const double *start_pva, const double *goal,
+                      const double *t_start, int32_t *out_ret, double *out_route,
+                      int32_t *out_route_len, int route_cap, int32_t *out_stats,
+                      int32_t *out_trace, int trace_cap, void *stream);
+
+/*
+ * Corridor generation for given routes: baseline_fake.cpp:300-412 — per segment local box,
+ * getObstaclePoints, firi::firi (sfc_gen/firi.hpp:238-365), ShrinkCorridor, validity LP;
+ * adjacent-intersection LPs; goal reachability.  Polytopes are rows h0 x + h1 y + h2 z + h3 <= 0.
+ * dev out_polys  [n_agents*SOGM_MAX_PIECES*max_faces*4] fp64
+ * dev out_nfaces [n_agents*SOGM_MAX_PIECES] int32,  dev out_npoly [n_agents] int32
+ * dev out_goal   [n_agents*6] fp64 local goal pos,vel
+ */
+int sogm_corridor_generate(sogm_planner *p, const double *start_pva, const double *t_start,
+                           const double *route, const int32_t *route_len, int route_cap,
+                           double *out_polys, int32_t *out_nfaces, int32_t *out_npoly,
+                           double *out_goal, void *stream);
+
+/*
+ * BezierOpt::setup + optimize (traj_opt/src/bezier_optimizer.cpp:27-285) for every agent.
+ * dev out_cpts [n_agents*SOGM_MAX_PIECES*15] fp64, dev out_status [n_agents] int32 (OSQP status_val:
+ * 1 solved, -2 max iter, -3 primal infeasible ...), dev out_iters [n_agents] int32.
+ */
+int sogm_bezier_qp_solve(sogm_planner *p, const double *start_pva, const double *goal_pv,
+                         const double *polys, const int32_t *nfaces, const int32_t *npoly,
+                         double *out_cpts, int32_t *out_status, int32_t *out_iters, void *stream);
+
+/*
+ * One full FakeBaselinePlanner::replan (baseline_fake.cpp:266-472, minus isSafeAfterOpt) for every
+ * agent: search -> corridors -> QP, stream-ordered, no host round trip.  On success writes the
+ * agent's SogmTrajRecord (time_start = t_start) into out_records; on failure writes n_pieces = 0.
+ * dev out_ok [n_agents] int32 (1 = replan() returned true).
+ */
+int sogm_replan(sogm_planner *p, const double *start_pva, const double *goal,
+                const double *t_start, const int32_t *drone_ids, SogmTrajRecord *out_records,
+                int32_t *out_ok, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SOGM_ABI_H */

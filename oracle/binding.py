@@ -1,0 +1,128 @@
+"""ctypes binding of oracle/liboracle.so.  TEST INFRASTRUCTURE ONLY: imported by tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg — never by the product package."""
+import ctypes as C
+import importlib
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_HERE)
+if _ROOT not in sys.path:
+    sys.path.insert(0, _ROOT)
+_abi = importlib.import_module("pred-occ-planner_amd._abi")
+
+LIB_PATH = os.path.join(_HERE, "liboracle.so")
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+
+
+_lib = None
+_dp = C.POINTER(C.c_double)
+_fp = C.POINTER(C.c_float)
+_ip = C.POINTER(C.c_int)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            build()
+        _lib = C.CDLL(LIB_PATH)
+        for name in ("orc_bezier_max_rate", "orc_linprog"):
+            if hasattr(_lib, name):
+                getattr(_lib, name).restype = C.c_double
+    return _lib
+
+
+def dptr(a):
+    return a.ctypes.data_as(_dp)
+
+
+def fptr(a):
+    return a.ctypes.data_as(_fp)
+
+
+def iptr(a):
+    return a.ctypes.data_as(_ip)
+
+
+# ---------------------------------------------------------------- Bernstein
+def bezier_eval(durations, cpts, t, derivative=0):
+    d = np.ascontiguousarray(durations, np.float64)
+    c = np.ascontiguousarray(cpts, np.float64)
+    out = np.zeros(3)
+    lib().orc_bezier_eval(dptr(d), dptr(c), len(d), C.c_double(t), derivative, dptr(out))
+    return out
+
+
+def piece_eval(cpts, t0, tf, t, derivative=0):
+    c = np.ascontiguousarray(cpts, np.float64)
+    out = np.zeros(3)
+    lib().orc_piece_eval(dptr(c), C.c_double(t0), C.c_double(tf), C.c_double(t), derivative, dptr(out))
+    return out
+
+
+def derivative_ctrl_pts(pts):
+    p = np.ascontiguousarray(pts, np.float64)
+    out = np.zeros((p.shape[0] - 1, 3))
+    lib().orc_derivative_ctrl_pts(dptr(p), p.shape[0], dptr(out))
+    return out
+
+
+def bezier_max_rate(durations, cpts, derivative):
+    d = np.ascontiguousarray(durations, np.float64)
+    c = np.ascontiguousarray(cpts, np.float64)
+    return float(lib().orc_bezier_max_rate(dptr(d), dptr(c), len(d), derivative))
+
+
+def bernstein_coeff():
+    A = np.zeros(25)
+    lib().orc_bernstein_coeff(dptr(A))
+    return A.reshape(5, 5)
+
+
+# ---------------------------------------------------------------- map
+def ego_particles(size):
+    out = np.zeros((512, 3))
+    n = lib().orc_ego_particles(C.c_double(size[0]), C.c_double(size[1]), C.c_double(size[2]), dptr(out), 512)
+    return out[:n].copy()
+
+
+def update_gt(spec, cloud, cyl_struct, n_cyl, pose):
+    V = spec.L * spec.W * spec.H
+    grid = np.zeros((V, spec.T), dtype=np.float32)
+    cloud = np.ascontiguousarray(cloud, np.float32)
+    pose = np.ascontiguousarray(pose, np.float32)
+    lib().orc_update_gt(C.byref(spec), fptr(cloud), cloud.shape[0], cyl_struct, n_cyl, fptr(pose), fptr(grid))
+    return grid
+
+
+def project_neighbours(spec, grid, records, n_rec, ego_id, body, pose, stamp):
+    pose = np.ascontiguousarray(pose, np.float32)
+    body = np.ascontiguousarray(body, np.float64)
+    lib().orc_project_neighbours(C.byref(spec), records, n_rec, int(ego_id), dptr(body), body.shape[0],
+                                 fptr(pose), C.c_double(stamp), fptr(grid))
+    return grid
+
+
+def query_clear(spec, grid, pose, pos, t, t_is_index=False):
+    pose = np.ascontiguousarray(pose, np.float32)
+    pos = np.ascontiguousarray(pos, np.float64)
+    if t_is_index:
+        return lib().orc_query_clear_idx(C.byref(spec), fptr(grid), fptr(pose), dptr(pos), int(t))
+    return lib().orc_query_clear_time(C.byref(spec), fptr(grid), fptr(pose), dptr(pos), C.c_double(t))
+
+
+def obstacle_points(spec, grid, pose, stamp, t0, t1, lc, hc, cap=4096):
+    pose = np.ascontiguousarray(pose, np.float32)
+    lc = np.ascontiguousarray(lc, np.float64)
+    hc = np.ascontiguousarray(hc, np.float64)
+    out = np.zeros((cap, 3))
+    n = lib().orc_obstacle_points(C.byref(spec), fptr(grid), fptr(pose), C.c_double(stamp), C.c_double(t0),
+                                  C.c_double(t1), dptr(lc), dptr(hc), dptr(out), cap)
+    return out[:min(n, cap)].copy(), n

@@ -1,0 +1,121 @@
+/*
+ * oracle.h — CPU restatement of the reference's replan hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library;
+ * the product (pred-occ-planner_amd/) never links, imports or calls it.
+ *
+ * Parity status: the reference cannot be compiled here (Eigen, ROS, PCL, OSQP absent, no network),
+ * so the restatement is pinned against the reference's own known-answer tests
+ * (traj_utils/test/test_bernstein.cpp, traj_opt/test/test_bezier_opt.cpp — see tests/golden/) and is
+ * otherwise "parity unpinned": each function cites the reference file:line it follows.
+ *
+ * Plain C++17, no third-party code, compiled with -O2 -ffp-contract=off so that fp32/fp64
+ * arithmetic is evaluated exactly as written (no FMA contraction).
+ */
+#ifndef ORACLE_H
+#define ORACLE_H
+
+#include <stdint.h>
+
+#include "../include/sogm_abi.h" /* plain-data record definitions only */
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- a5: Bernstein / Bezier (traj_utils/src/bernstein.cpp:25-59, bernstein.hpp:164-187) ---- */
+/* derivative: 0 pos, 1 vel, 2 acc.  durations[M], cpts[M*5*3].  t is relative to trajectory start. */
+void orc_bezier_eval(const double *durations, const double *cpts, int M, double t, int derivative,
+                     double out[3]);
+/* single piece on [t0, tf] (BernsteinPiece(cpts, t0, tf)) */
+void orc_piece_eval(const double *cpts5x3, double t0, double tf, double t, int derivative,
+                    double out[3]);
+/* getVelCtrlPts / getAccCtrlPts (bernstein.cpp:128-137): in n_in x 3 -> out (n_in-1) x 3 */
+void orc_derivative_ctrl_pts(const double *in, int n_in, double *out);
+/* Bezier::getMaxVelRate / getMaxAccRate (bernstein.cpp:155-218) */
+double orc_bezier_max_rate(const double *durations, const double *cpts, int M, int derivative);
+/* 5x5 coefficient matrix (bernstein.cpp:96-126), row-major */
+void orc_bernstein_coeff(double A[25]);
+
+/* ---- a1: index math (plan_env/include/plan_env/map.h:153-215) ---- */
+int  orc_is_in_range_f(const SogmSpec *s, const float p[3]);
+int  orc_voxel_index_f(const SogmSpec *s, const float p[3]);
+void orc_voxel_position(const SogmSpec *s, const float pose[3], int index, float out[3]);
+int  orc_inf_step(const SogmSpec *s);
+void orc_ranges(const SogmSpec *s, float out[3]);
+
+/* ---- a4: body particles (traj_coordinator/src/particles.cpp:62-75) ---- */
+/* returns count; writes up to cap*3 doubles */
+int orc_ego_particles(double sx, double sy, double sz, double *out, int cap);
+
+/* ---- a2: FakeParticleRiskVoxel::updateMap without overlay (fake_particle_risk_voxel.cpp:80-170) */
+/* grid_vt: [V][T] fp32, reference layout */
+void orc_update_gt(const SogmSpec *s, const float *cloud_xyz, int n_points,
+                   const SogmCylinder *cyl, int n_cyl, const float pose[3], float *grid_vt);
+
+/* ---- a3: neighbour overlay (risk_base.cpp:136-168,199-208; particles.cpp:316-422) ---- */
+void orc_project_neighbours(const SogmSpec *s, const SogmTrajRecord *records, int n_records,
+                            int ego_id, const double *body_xyz, int n_body, const float pose[3],
+                            double stamp, float *grid_vt);
+
+/* ---- a8: getClearOcccupancy ---- */
+int orc_query_clear_idx(const SogmSpec *s, const float *grid_vt, const float pose[3],
+                        const double pos[3], int t);
+int orc_query_clear_time(const SogmSpec *s, const float *grid_vt, const float pose[3],
+                         const double pos[3], double dt);
+
+/* ---- a10: getObstaclePoints(pts, t0, t1, lc, hc) ---- */
+/* returns the true count; writes at most cap points */
+int orc_obstacle_points(const SogmSpec *s, const float *grid_vt, const float pose[3],
+                        double stamp, double t_start, double t_end, const double lc[3],
+                        const double hc[3], double *out_pts, int cap);
+
+/* ---- a9: hybrid A* (path_searching/src/fake_risk_hybrid_a_star.cpp) ---- */
+/* returns ASTAR_RET of the final search; route: n x 6; stats {use_node_num, iter_num, n_path_nodes,
+ * searches_run}; trace: popped pool ids (may be NULL) */
+int orc_astar_search(const SogmSpec *s, const SogmAstarParams *ap, const float *grid_vt,
+                     const float pose[3], const double start_pva[9], const double goal[3],
+                     double t_after_map, double corridor_tau, double *out_route,
+                     int *out_route_len, int route_cap, int out_stats[4], int *out_trace,
+                     int trace_cap, int *out_trace_len);
+
+/* ---- a12: Seidel LP  min c^T x s.t. A x <= b  (traj_utils/include/traj_utils/sdlp.hpp:709-787) */
+/* d in {3,4}; A row-major m x d; returns minimum, +inf infeasible, -inf unbounded */
+double orc_linprog(int d, const double *c, const double *A, const double *b, int m, double *x);
+
+/* ---- a11: FIRI + MVIE (plan_manager/include/sfc_gen/firi.hpp) ---- */
+/* bd: 6x4 row-major; pc: n x 3; hpoly out: up to max_faces x 4; returns number of faces or -1 */
+int orc_firi(const double *bd, int n_bd, const double *pc, int n_pc, const double a[3],
+             const double b[3], int iterations, double *hpoly, int max_faces, double r[3]);
+int orc_mvie(const double *hpoly, int m, double R[9], double p[3], double r[3]);
+
+/* ---- a13/a16: corridor stage of replan (baseline_fake.cpp:300-412 / baseline.cpp:296-403) ---- */
+int orc_corridor_generate(const SogmSpec *s, const SogmPlannerParams *pp, const float *grid_vt,
+                          const float pose[3], double stamp, const double start_pva[9],
+                          double t_start, const double *route, int route_len, double *out_polys,
+                          int *out_nfaces, double out_goal[6]);
+
+/* ---- a14/a15: BezierOpt QP ---- */
+/* assembly only: dense Q (n x n), A (m x n), l, u; returns m; n = 15*M */
+int orc_qp_assemble(const double start[9], const double goal[9], const double *t_alloc, int M,
+                    const double *polys, const int *nfaces, int max_faces, double vmax,
+                    double amax, double *Q, double *A, double *l, double *u, int m_cap);
+/* full solve; returns OSQP-style status_val */
+int orc_qp_solve(const double start[9], const double goal[9], const double *t_alloc, int M,
+                 const double *polys, const int *nfaces, int max_faces, double vmax, double amax,
+                 const SogmQpSettings *qs, double *x_out, int *iters_out);
+/* generic OSQP-algorithm solve of a dense-described QP (for cross-checks) */
+int orc_osqp_dense(const double *P, const double *q, const double *A, const double *l,
+                   const double *u, int n, int m, const SogmQpSettings *qs, double *x, double *y,
+                   int *iters_out);
+
+/* ---- a16: full replan for one agent ---- */
+int orc_replan(const SogmSpec *s, const SogmAstarParams *ap, const SogmPlannerParams *pp,
+               const SogmQpSettings *qs, const float *grid_vt, const float pose[3], double stamp,
+               const double start_pva[9], const double goal[3], double t_start, int drone_id,
+               SogmTrajRecord *out_record, int stage_fail[1]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

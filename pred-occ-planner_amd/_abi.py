@@ -1,0 +1,136 @@
+"""ctypes binding of include/sogm_abi.h (the C-ABI drop-in boundary).
+
+The HIP library is REQUIRED: importing this module without ``libsogm_hip.so`` raises — there is no
+CPU fallback in the product path.  Plain-data records mirror the C structs field for field.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsogm_hip.so")
+
+SOGM_MAX_PIECES = 16
+SOGM_MAP_FAKE = 0
+SOGM_MAP_RISKBASE = 1
+
+SOGM_OK = 0
+SOGM_ERR_INVALID_ARG = -1
+SOGM_ERR_NO_DEVICE = -2
+SOGM_ERR_HIP = -3
+SOGM_ERR_CAPACITY = -4
+SOGM_ERR_STATE = -5
+PROF_CLEAR, PROF_STAMP, PROF_SPLAT, PROF_ASTAR, PROF_CORRIDOR, PROF_QP, PROF_N = range(7)
+
+# ASTAR_RET (path_searching/include/path_searching/dyn_a_star.h:15)
+ASTAR_NO_PATH, ASTAR_INIT_ERR, ASTAR_SEARCH_ERR, ASTAR_REACH_HORIZON, ASTAR_REACH_END, ASTAR_NEAR_END = range(6)
+
+
+class SogmSpec(C.Structure):
+    _fields_ = [("L", C.c_int32), ("W", C.c_int32), ("H", C.c_int32), ("T", C.c_int32),
+                ("resolution", C.c_float), ("time_resolution", C.c_float),
+                ("risk_threshold", C.c_float), ("clearance", C.c_float),
+                ("ground_height", C.c_float), ("ceiling_height", C.c_float),
+                ("risk_threshold_region", C.c_float), ("risk_thres_reg_decay", C.c_float),
+                ("risk_thres_vox_decay", C.c_float), ("map_kind", C.c_int32)]
+
+
+class SogmCylinder(C.Structure):
+    _fields_ = [("type", C.c_int32), ("_pad", C.c_int32)] + [
+        (k, C.c_double) for k in ("x", "y", "z", "w", "h", "vx", "vy", "qw", "qx", "qy", "qz")]
+
+
+class SogmTrajRecord(C.Structure):
+    _fields_ = [("drone_id", C.c_int32), ("n_pieces", C.c_int32), ("time_start", C.c_double),
+                ("duration", C.c_double * SOGM_MAX_PIECES),
+                ("cpts", C.c_double * (SOGM_MAX_PIECES * 15))]
+
+
+class SogmAstarParams(C.Structure):
+    _fields_ = [("max_tau", C.c_double), ("max_vel", C.c_double), ("max_acc", C.c_double),
+                ("w_time", C.c_double), ("horizon", C.c_double), ("lambda_heu", C.c_double),
+                ("resolution", C.c_double), ("time_resolution", C.c_double),
+                ("allocate_num", C.c_int32), ("check_num", C.c_int32), ("tolerance", C.c_int32),
+                ("_pad", C.c_int32)]
+
+
+class SogmPlannerParams(C.Structure):
+    _fields_ = [("corridor_tau", C.c_double), ("init_range", C.c_double),
+                ("shrink_size", C.c_double), ("opt_max_vel", C.c_double),
+                ("opt_max_acc", C.c_double), ("fake_planner", C.c_int32),
+                ("firi_iterations", C.c_int32), ("pc_capacity", C.c_int32),
+                ("max_faces", C.c_int32)]
+
+
+class SogmQpSettings(C.Structure):
+    _fields_ = [("rho", C.c_double), ("sigma", C.c_double), ("alpha", C.c_double),
+                ("eps_abs", C.c_double), ("eps_rel", C.c_double), ("max_iter", C.c_int32),
+                ("check_termination", C.c_int32), ("scaling_iters", C.c_int32),
+                ("_pad", C.c_int32)]
+
+
+TRAJ_RECORD_BYTES = C.sizeof(SogmTrajRecord)  # 2064
+CYLINDER_BYTES = C.sizeof(SogmCylinder)  # 96
+
+_vp = C.c_void_p
+_i = C.c_int
+
+# name -> (restype, argtypes); every symbol include/sogm_abi.h declares
+PROTOTYPES = {
+    "sogm_abi_version": (_i, []),
+    "sogm_last_error": (C.c_char_p, []),
+    "sogm_device_count": (_i, []),
+    "sogm_create": (_i, [C.POINTER(SogmSpec), _i, _i, C.POINTER(_vp)]),
+    "sogm_destroy": (None, [_vp]),
+    "sogm_grid_bytes": (C.c_int64, [_vp]),
+    "sogm_grid_ptr": (_vp, [_vp]),
+    "sogm_set_body_particles": (_i, [_vp, C.POINTER(C.c_double), _i]),
+    "sogm_set_profiling": (_i, [_vp, _i]),
+    "sogm_profile_read": (_i, [_vp, C.POINTER(C.c_double)]),
+    "sogm_update_gt": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
+    "sogm_project_neighbours": (_i, [_vp, _vp, _i, _vp, _vp]),
+    "sogm_set_future_risk": (_i, [_vp, _vp, _vp, _vp, _vp]),
+    "sogm_download_reference_layout": (_i, [_vp, _i, _vp]),
+    "sogm_query_clear": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
+    "sogm_obstacle_points": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp]),
+    "sogm_planner_create": (_i, [_vp, C.POINTER(SogmAstarParams), C.POINTER(SogmPlannerParams),
+                                 C.POINTER(SogmQpSettings), C.POINTER(_vp)]),
+    "sogm_planner_destroy": (None, [_vp]),
+    "sogm_astar_search": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp]),
+    "sogm_corridor_generate": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
+    "sogm_bezier_qp_solve": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "sogm_replan": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+}
+
+
+class SogmError(RuntimeError):
+    pass
+
+
+def load_library(path=LIB_PATH):
+    """Load libsogm_hip.so and bind every ABI symbol.  Raises if the extension is missing."""
+    if not os.path.exists(path):
+        raise SogmError(
+            f"HIP extension not built: {path} is missing. Run `python -c 'import __graft_entry__ as g; "
+            "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    lib = C.CDLL(path)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = load_library()
+    return _lib
+
+
+def check(rc, what):
+    if rc != SOGM_OK:
+        msg = lib().sogm_last_error()
+        raise SogmError(f"{what} failed: status {rc} ({msg.decode() if msg else ''})")

@@ -1,0 +1,236 @@
+// sogm_device.hpp — device-side grid geometry, context layout and small helpers shared by the
+// HIP translation units.  gfx950 only; compiled with -ffp-contract=off so that every fp32/fp64
+// expression is evaluated exactly as written (voxel indices must be bit-exact).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/sogm_abi.h"
+
+namespace sogm {
+
+// Geometry of one agent's SOGM.  Device layout is time-major slabs:
+//     grid[agent][t][z][y][x]      (fp32)
+// so one (agent, t) slice is V contiguous floats and x is the fastest axis — the reference's
+// risk_maps_[V][T] (plan_env/include/plan_env/map.h:52) is voxel-major.
+struct GridGeom {
+  int   L, W, H, T;
+  int   V;            // L*W*H
+  float res;          // VOXEL_RESOLUTION
+  float rx, ry, rz;   // local_update_range_* = (N/2) * res in fp32 (risk_base.cpp:26-28)
+  float dt;           // map/time_resolution
+  float risk_threshold;
+  float clearance;
+  float ground, ceiling;
+  float thr_region, decay_region, decay_voxel;
+  int   inf_step;     // (int)(clearance / res) in fp32 (risk_base.cpp:31)
+  int   map_kind;
+
+  // map.h:153-157 — strict inequalities
+  __host__ __device__ inline bool in_range(float x, float y, float z) const {
+    return x > -rx && x < rx && y > -ry && y < ry && z > -rz && z < rz;
+  }
+  // map.h:159-162
+  __host__ __device__ inline bool in_range(int x, int y, int z) const {
+    return x >= 0 && x < L && y >= 0 && y < W && z >= 0 && z < H;
+  }
+  // map.h:169-174 — fp32 add, fp32 divide, truncation
+  __host__ __device__ inline int voxel_of(float x, float y, float z) const {
+    const int ix = (int)((x + rx) / res);
+    const int iy = (int)((y + ry) / res);
+    const int iz = (int)((z + rz) / res);
+    return iz * L * W + iy * L + ix;
+  }
+  // map.h:186-194 — voxel corner in the world frame
+  __host__ __device__ inline void corner_of(int index, const float *pose, float &ox, float &oy,
+                                            float &oz) const {
+    const int x = index % L;
+    const int y = (index / L) % W;
+    const int z = index / (L * W);
+    ox          = ((float)x * res - rx) + pose[0];
+    oy          = ((float)y * res - ry) + pose[1];
+    oz          = ((float)z * res - rz) + pose[2];
+  }
+};
+
+inline GridGeom make_geom(const SogmSpec &s) {
+  GridGeom g;
+  g.L              = s.L;
+  g.W              = s.W;
+  g.H              = s.H;
+  g.T              = s.T;
+  g.V              = s.L * s.W * s.H;
+  g.res            = s.resolution;
+  g.rx             = (float)(s.L / 2) * s.resolution;
+  g.ry             = (float)(s.W / 2) * s.resolution;
+  g.rz             = (float)(s.H / 2) * s.resolution;
+  g.dt             = s.time_resolution;
+  g.risk_threshold = s.risk_threshold;
+  g.clearance      = s.clearance;
+  g.ground         = s.ground_height;
+  g.ceiling        = s.ceiling_height;
+  g.thr_region     = s.risk_threshold_region;
+  g.decay_region   = s.risk_thres_reg_decay;
+  g.decay_voxel    = s.risk_thres_vox_decay;
+  g.inf_step       = (int)(s.clearance / s.resolution);
+  g.map_kind       = s.map_kind;
+  return g;
+}
+
+// Read-only view of the batched map handed to every kernel that queries it.
+struct MapView {
+  GridGeom      g;
+  const float  *grid;    // [A][T][V]
+  const float  *poses;   // [A][3]
+  const double *stamps;  // [A]
+  int           n_agents;
+
+  __device__ inline const float *slab(int agent, int t) const {
+    return grid + ((size_t)agent * g.T + t) * (size_t)g.V;
+  }
+};
+
+// getClearOcccupancy(pos, int t): fake_particle_risk_voxel.cpp:309-331 / risk_base.cpp:228-251.
+// Summation order = inflate-kernel build order (x, y, z nested) so the fp32 running sum and its
+// early exit are identical to the reference.
+__device__ inline int query_clear_idx(const MapView &m, int agent, double px, double py, double pz,
+                                      int t) {
+  const GridGeom &g = m.g;
+  if (g.map_kind == SOGM_MAP_FAKE) {
+    if (pz < (double)g.ground || pz > (double)g.ceiling) return -1;
+  } else {
+    if (pz < (double)g.ground) return 1;
+    if (pz > (double)g.ceiling) return 1;
+  }
+  const float *pose = m.poses + agent * 3;
+  const float  fx = (float)px - pose[0], fy = (float)py - pose[1], fz = (float)pz - pose[2];
+  const int    ix = (int)((fx + g.rx) / g.res);
+  const int    iy = (int)((fy + g.ry) / g.res);
+  const int    iz = (int)((fz + g.rz) / g.res);
+  if (!g.in_range(ix, iy, iz)) return -1;
+  const float *sl  = m.slab(agent, t);
+  const int    s   = g.inf_step;
+  const int    zs  = g.map_kind == SOGM_MAP_FAKE ? 0 : s;  // fake map: z loop degenerates (:41)
+  const float  thr = g.map_kind == SOGM_MAP_FAKE ? g.risk_threshold
+                                                 : g.thr_region - (float)t * g.decay_region;
+  float        sum = 0.0F;
+  for (int x = -s; x <= s; ++x) {
+    const int qx = ix + x;
+    for (int y = -s; y <= s; ++y) {
+      const int qy = iy + y;
+      for (int z = -zs; z <= zs; ++z) {
+        const int qz = iz + z;
+        if (!g.in_range(qx, qy, qz)) continue;
+        sum += sl[(size_t)qz * g.L * g.W + (size_t)qy * g.L + qx];
+        if (sum > thr) return 1;
+      }
+    }
+  }
+  return 0;
+}
+
+// getClearOcccupancy(pos, double dt): slice = floor(dt / time_resolution) clamped to T-1
+// (fake_particle_risk_voxel.cpp:341-346).  Negative slices (UB in the reference) clamp to 0.
+__device__ inline int query_clear_time(const MapView &m, int agent, double px, double py,
+                                       double pz, double dt) {
+  int tf = (int)floor(dt / (double)m.g.dt);
+  tf     = tf > (m.g.T - 1) ? m.g.T - 1 : tf;
+  tf     = tf < 0 ? 0 : tf;
+  return query_clear_idx(m, agent, px, py, pz, tf);
+}
+
+// Bezier::getPos (traj_utils/src/bernstein.cpp:25-34, bernstein.hpp:164-178):
+// p(t) = C^T * A4 * [1, s, s^2, s^3, s^4],  s = (t - t0) / (tf - t0), evaluated left to right.
+__device__ inline void bezier_pos(const SogmTrajRecord &r, double t, double out[3]) {
+  int    piece = r.n_pieces - 1;
+  double tt    = t;
+  for (int i = 0; i < r.n_pieces; ++i) {
+    tt -= r.duration[i];
+    if (tt < 0) {
+      piece = i;
+      break;
+    }
+  }
+  double t0 = 0;
+  for (int k = 0; k < piece; ++k) t0 += r.duration[k];
+  const double tf  = t0 + r.duration[piece];
+  const double dur = tf - t0;
+  const double s   = (t - t0) / dur;
+  double       S[5];
+  S[0] = 1.0;
+  S[1] = s;
+  S[2] = s * s;
+  S[3] = s * s * s;
+  S[4] = (s * s) * (s * s);
+  const double A[5][5] = {{1, -4, 6, -4, 1},
+                          {0, 4, -12, 12, -4},
+                          {0, 0, 6, -12, 6},
+                          {0, 0, 0, 4, -4},
+                          {0, 0, 0, 0, 1}};
+  const double *c = r.cpts + piece * 15;
+  for (int d = 0; d < 3; ++d) {
+    double acc = 0.0;
+    for (int j = 0; j < 5; ++j) {
+      double b = 0.0;
+      for (int i = 0; i < 5; ++i) b += c[i * 3 + d] * A[i][j];
+      acc += b * S[j];
+    }
+    out[d] = acc;
+  }
+}
+
+}  // namespace sogm
+
+// ---- context (opaque in the C ABI) ----
+struct sogm_ctx {
+  SogmSpec       spec;
+  sogm::GridGeom geom;
+  int            n_agents;
+  int            device;
+  float         *d_grid;    // [A][T][V]
+  float         *d_poses;   // [A][3]
+  double        *d_stamps;  // [A]
+  double        *d_body;    // [n_body][3]
+  int            n_body;
+  int            updated;
+  float         *d_scratch_vt;  // [V][T] staging for download / upload
+  int            profiling;
+  hipEvent_t     ev[SOGM_PROF_N][2];
+  int            ev_used[SOGM_PROF_N];
+};
+
+namespace sogm {
+// RAII-free helper: record the begin/end events of profiling slot `slot` on `st`.
+inline void prof_begin(sogm_ctx *c, int slot, hipStream_t st) {
+  if (c->profiling) (void)hipEventRecord(c->ev[slot][0], st);
+}
+inline void prof_end(sogm_ctx *c, int slot, hipStream_t st) {
+  if (c->profiling) {
+    (void)hipEventRecord(c->ev[slot][1], st);
+    c->ev_used[slot] = 1;
+  }
+}
+}  // namespace sogm
+
+namespace sogm {
+inline MapView view_of(const sogm_ctx *c) {
+  MapView m;
+  m.g        = c->geom;
+  m.grid     = c->d_grid;
+  m.poses    = c->d_poses;
+  m.stamps   = c->d_stamps;
+  m.n_agents = c->n_agents;
+  return m;
+}
+void set_error(const char *what, hipError_t e);
+}  // namespace sogm
+
+#define SOGM_HIP_CHECK(expr)                    \
+  do {                                          \
+    hipError_t _e = (expr);                     \
+    if (_e != hipSuccess) {                     \
+      sogm::set_error(#expr, _e);               \
+      return SOGM_ERR_HIP;                      \
+    }                                           \
+  } while (0)

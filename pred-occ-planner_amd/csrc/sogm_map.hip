@@ -1,0 +1,536 @@
+// sogm_map.hip — batched SOGM build + queries for gfx950 (MI355X), behind include/sogm_abi.h.
+//
+// Kernels (all HBM-bound integer / fp32 work — no MFMA anywhere on this path):
+//   k_clear_slabs        zero sogm[A][T][V]: 16-B coalesced streaming stores, grid-stride.
+//                        This IS the voxel-update roofline kernel: B = V*T*4 bytes per agent-update.
+//   k_stamp_cloud        per (agent, cloud point): crop, slice-0 mark, GT-velocity lookup (cylinders
+//                        staged in LDS), T-1 advected marks.   fake_particle_risk_voxel.cpp:88-161
+//   k_splat_neighbours   per (agent, record, slice): Bezier sample (fp64) + body particles,
+//                        float atomic add.                      risk_base.cpp:136-168,199-208
+//   k_query_clear        batched getClearOcccupancy.            fake_particle_risk_voxel.cpp:309-346
+//   k_obstacle_points    one workgroup per corridor box, order-preserving block-scan compaction.
+//                                                               map.cpp:480-518 / risk_base.cpp:295-337
+//   k_slabs_to_vt / k_vt_to_slabs   layout converters for parity I/O and futureRiskCallback.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "sogm_device.hpp"
+
+namespace sogm {
+
+static thread_local char g_err[512] = {0};
+void set_error(const char *what, hipError_t e) {
+  std::snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+}
+
+// ------------------------------------------------------------------------------------------------
+// clear
+// ------------------------------------------------------------------------------------------------
+// Pure streaming store.  One float4 (16 B) per lane per iteration -> 1 KiB per wave-instruction,
+// fully coalesced; 4 independent stores in flight per lane per trip.  The grid is sized to
+// ~8 workgroups per CU and strides over the buffer.
+typedef float vfloat4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void k_clear_slabs(vfloat4 *__restrict__ p, size_t n_vec4,
+                                                     float *__restrict__ tail, int n_tail) {
+  const size_t  stride = (size_t)gridDim.x * blockDim.x;
+  size_t        i      = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const vfloat4 z      = {0.f, 0.f, 0.f, 0.f};
+  for (; i + 3 * stride < n_vec4; i += 4 * stride) {
+    __builtin_nontemporal_store(z, p + i);
+    __builtin_nontemporal_store(z, p + i + stride);
+    __builtin_nontemporal_store(z, p + i + 2 * stride);
+    __builtin_nontemporal_store(z, p + i + 3 * stride);
+  }
+  for (; i < n_vec4; i += stride) __builtin_nontemporal_store(z, p + i);
+  if (blockIdx.x == 0 && (int)threadIdx.x < n_tail) tail[threadIdx.x] = 0.f;
+}
+
+// ------------------------------------------------------------------------------------------------
+// stamp: cloud -> slice 0, GT velocity -> slices 1..T-1
+// ------------------------------------------------------------------------------------------------
+#define SOGM_MAX_CYL_LDS 1024
+
+__global__ __launch_bounds__(256) void k_stamp_cloud(GridGeom g, float *__restrict__ grid,
+                                                     const float *__restrict__ cloud,
+                                                     const int32_t *__restrict__ cloud_range,
+                                                     const SogmCylinder *__restrict__ cyl,
+                                                     int n_cyl, const float *__restrict__ poses) {
+  // cylinders as {x, y, w + clearance (fp64), vx, vy} — staged once per workgroup
+  __shared__ double s_w[SOGM_MAX_CYL_LDS];
+  __shared__ float  s_xyv[SOGM_MAX_CYL_LDS][4];
+  __shared__ int    s_type[SOGM_MAX_CYL_LDS];
+  const int         n_lds = n_cyl < SOGM_MAX_CYL_LDS ? n_cyl : SOGM_MAX_CYL_LDS;
+  for (int c = threadIdx.x; c < n_lds; c += blockDim.x) {
+    s_w[c]      = cyl[c].w + (double)g.clearance;
+    s_xyv[c][0] = (float)cyl[c].x;
+    s_xyv[c][1] = (float)cyl[c].y;
+    s_xyv[c][2] = (float)cyl[c].vx;
+    s_xyv[c][3] = (float)cyl[c].vy;
+    s_type[c]   = cyl[c].type;
+  }
+  __syncthreads();
+
+  const int    agent = blockIdx.y;
+  const int    begin = cloud_range[agent * 2], end = cloud_range[agent * 2 + 1];
+  const float *pose  = poses + agent * 3;
+  const float  p0 = pose[0], p1 = pose[1], p2 = pose[2];
+  // PassThrough limits (fake_particle_risk_voxel.cpp:88-104), fp32
+  const float lox = p0 - g.rx, hix = p0 + g.rx;
+  const float loy = p1 - g.ry, hiy = p1 + g.ry;
+  const float loz = p2 - g.rz, hiz = p2 + g.rz;
+  float      *base = grid + (size_t)agent * g.T * (size_t)g.V;
+
+  for (int i = begin + blockIdx.x * blockDim.x + threadIdx.x; i < end;
+       i += gridDim.x * blockDim.x) {
+    const float px = cloud[i * 3], py = cloud[i * 3 + 1], pz = cloud[i * 3 + 2];
+    if (!(px >= lox && px <= hix && py >= loy && py <= hiy && pz >= loz && pz <= hiz)) continue;
+    const float x = px - p0, y = py - p1, z = pz - p2;
+    if (!g.in_range(x, y, z)) continue;
+    const int v = g.voxel_of(x, y, z);
+    base[v]     = 1.0F;  // slice 0 (:114)
+    // The reference then sweeps the occupied voxels of slice 0 (:121-125); every cloud point in
+    // range marks exactly one such voxel and the future marks depend only on the voxel, so the
+    // per-point form produces the same set of (idempotent) stores.
+    float cx, cy, cz;
+    g.corner_of(v, pose, cx, cy, cz);
+    float vx = 0.f, vy = 0.f;
+    for (int c = 0; c < n_cyl; ++c) {
+      int    type;
+      float  ox, oy, wx, wy;
+      double wlim;
+      if (c < n_lds) {
+        type = s_type[c];
+        ox   = s_xyv[c][0];
+        oy   = s_xyv[c][1];
+        wx   = s_xyv[c][2];
+        wy   = s_xyv[c][3];
+        wlim = s_w[c];
+      } else {
+        type = cyl[c].type;
+        ox   = (float)cyl[c].x;
+        oy   = (float)cyl[c].y;
+        wx   = (float)cyl[c].vx;
+        wy   = (float)cyl[c].vy;
+        wlim = cyl[c].w + (double)g.clearance;
+      }
+      if (type != 3) continue;  // ring obstacles (type 2) are not produced by the synthetic scenes
+      const float dx = cx - ox, dy = cy - oy, dz = cz - cz;
+      const float dist = sqrtf(dx * dx + dy * dy + dz * dz);
+      if ((double)dist <= wlim) {
+        vx = wx;
+        vy = wy;
+        break;
+      }
+    }
+    for (int k = 1; k < g.T; ++k) {
+      const float fx = (cx + (vx * g.dt) * (float)k) - p0;
+      const float fy = (cy + (vy * g.dt) * (float)k) - p1;
+      const float fz = (cz + (0.0F * g.dt) * (float)k) - p2;
+      if (g.in_range(fx, fy, fz)) base[(size_t)k * g.V + g.voxel_of(fx, fy, fz)] = 1.0F;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// neighbour overlay
+// ------------------------------------------------------------------------------------------------
+// One lane per (agent, record, slice).  The reference's is_swarm_traj_valid chain
+// (risk_base.cpp:154-159) collapses to: record contributes at slice t  iff
+//     time_start < t_abs(0)  and  t_abs(s) < time_end for every s <= t
+// and t_abs is increasing, i.e.  time_start < t_abs(0) && t_abs(t) < time_end.
+__global__ __launch_bounds__(256) void k_splat_neighbours(
+    GridGeom g, float *__restrict__ grid, const SogmTrajRecord *__restrict__ rec, int n_rec,
+    const int32_t *__restrict__ ego_ids, const float *__restrict__ poses,
+    const double *__restrict__ stamps, const double *__restrict__ body, int n_body, int n_agents) {
+  const long long gid   = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long total = (long long)n_agents * n_rec * g.T;
+  if (gid >= total) return;
+  const int t     = (int)(gid % g.T);
+  const int r     = (int)((gid / g.T) % n_rec);
+  const int agent = (int)(gid / ((long long)g.T * n_rec));
+
+  const SogmTrajRecord &R = rec[r];
+  if (R.n_pieces <= 0 || R.drone_id == ego_ids[agent]) return;
+  double time_end = R.time_start;
+  for (int k = 0; k < R.n_pieces; ++k) time_end += R.duration[k];
+  const double stamp = stamps[agent];
+  const double t0    = stamp + (double)(g.dt * (float)0);
+  const double tt    = stamp + (double)(g.dt * (float)t);
+  if (!(R.time_start < t0 && time_end > t0)) return;  // chain broken at slice 0
+  if (!(R.time_start < tt && time_end > tt)) return;
+
+  double p[3];
+  bezier_pos(R, tt - R.time_start, p);
+  const float *pose = poses + agent * 3;
+  const double q0 = (double)pose[0], q1 = (double)pose[1], q2 = (double)pose[2];
+  float       *slab = grid + ((size_t)agent * g.T + t) * (size_t)g.V;
+  for (int e = 0; e < n_body; ++e) {
+    const float fx = (float)((p[0] + body[e * 3 + 0]) - q0);
+    const float fy = (float)((p[1] + body[e * 3 + 1]) - q1);
+    const float fz = (float)((p[2] + body[e * 3 + 2]) - q2);
+    if (!g.in_range(fx, fy, fz)) continue;
+    // += 1.0f per body particle; sums of 1.0 are exact in fp32, so the order is immaterial
+    __hip_atomic_fetch_add(slab + g.voxel_of(fx, fy, fz), 1.0F, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// queries
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_query_clear(MapView m, const int32_t *__restrict__ agent,
+                                                     const double *__restrict__ pos,
+                                                     const double *__restrict__ t, int t_is_index,
+                                                     int n, int8_t *__restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int a = agent[i];
+  int       r;
+  if (t_is_index) {
+    r = query_clear_idx(m, a, pos[i * 3], pos[i * 3 + 1], pos[i * 3 + 2], (int)t[i]);
+  } else {
+    r = query_clear_time(m, a, pos[i * 3], pos[i * 3 + 1], pos[i * 3 + 2], t[i]);
+  }
+  out[i] = (int8_t)r;
+}
+
+// Order-preserving extraction.  Cells of the box are visited in the reference's z,y,x order, 256
+// cells per trip; each lane counts the slices of its cell that exceed the threshold, a block-wide
+// exclusive scan turns counts into output offsets, so the emitted sequence is exactly the
+// reference's (FIRI's greedy selection breaks ties by point order).
+__global__ __launch_bounds__(256) void k_obstacle_points(
+    MapView m, const int32_t *__restrict__ agent_idx, const double *__restrict__ box_lo,
+    const double *__restrict__ box_hi, const double *__restrict__ t0v,
+    const double *__restrict__ t1v, double *__restrict__ out_pts, int32_t *__restrict__ out_cnt,
+    int cap) {
+  __shared__ int s_wave[4];
+  __shared__ int s_base;
+  const GridGeom &g     = m.g;
+  const int       b     = blockIdx.x;
+  const int       agent = agent_idx[b];
+  const float    *pose  = m.poses + agent * 3;
+  const double    stamp = m.stamps[agent];
+  const double    tr    = (double)g.dt;
+  int             js    = (int)floor((t0v[b] - stamp) / tr);
+  int             je    = (int)ceil((t1v[b] - stamp) / tr);
+  js                    = js < 0 ? 0 : js;
+  js                    = js > g.T ? g.T : js;
+  je                    = je > g.T ? g.T : je;
+  je                    = je < 0 ? 0 : je;
+  if (je > g.T - 1) je = g.T - 1;  // slices >= T do not exist (reference reads one past the end)
+  int lx = (int)((box_lo[b * 3 + 0] - pose[0] + g.rx) / g.res);
+  int ly = (int)((box_lo[b * 3 + 1] - pose[1] + g.ry) / g.res);
+  int lz = (int)((box_lo[b * 3 + 2] - pose[2] + g.rz) / g.res);
+  int hx = (int)((box_hi[b * 3 + 0] - pose[0] + g.rx) / g.res);
+  int hy = (int)((box_hi[b * 3 + 1] - pose[1] + g.ry) / g.res);
+  int hz = (int)((box_hi[b * 3 + 2] - pose[2] + g.rz) / g.res);
+  hx     = min(hx, g.L - 1);
+  hy     = min(hy, g.W - 1);
+  hz     = min(hz, g.H - 1);
+  lx     = max(lx, 0);
+  ly     = max(ly, 0);
+  lz     = max(lz, 0);
+  const int nx = hx - lx + 1, ny = hy - ly + 1, nz = hz - lz + 1;
+  if (threadIdx.x == 0) s_base = 0;
+  __syncthreads();
+  if (nx <= 0 || ny <= 0 || nz <= 0 || js > je) {
+    if (threadIdx.x == 0) out_cnt[b] = 0;
+    return;
+  }
+  const int    cells = nx * ny * nz;
+  const float *grid0 = m.slab(agent, 0);
+  double      *outp  = out_pts + (size_t)b * cap * 3;
+  const int    lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+
+  for (int c0 = 0; c0 < cells; c0 += blockDim.x) {
+    const int c    = c0 + threadIdx.x;
+    int       cnt  = 0;
+    unsigned  mask = 0;  // bit j-js set when slice j exceeds
+    int       vi   = 0;
+    if (c < cells) {
+      const int x = lx + c % nx;
+      const int y = ly + (c / nx) % ny;
+      const int z = lz + c / (nx * ny);
+      vi          = x + y * g.L + z * g.L * g.W;
+      for (int j = js; j <= je; ++j) {
+        const float thr =
+            g.map_kind == SOGM_MAP_FAKE ? g.risk_threshold : g.risk_threshold - g.decay_voxel * (float)j;
+        if (grid0[(size_t)j * g.V + vi] > thr) {
+          ++cnt;
+          mask |= 1u << (j - js);
+        }
+      }
+    }
+    // wave-level inclusive scan (64 lanes), then 4-wave combine through LDS
+    int incl = cnt;
+    for (int d = 1; d < 64; d <<= 1) {
+      const int up = __shfl_up(incl, d, 64);
+      if (lane >= d) incl += up;
+    }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    int wave_off = 0, total = 0;
+    for (int w = 0; w < 4; ++w) {
+      const int v = s_wave[w];
+      if (w < wave) wave_off += v;
+      total += v;
+    }
+    const int base = s_base;
+    int       off  = base + wave_off + incl - cnt;
+    if (cnt) {
+      float fx, fy, fz;
+      g.corner_of(vi, pose, fx, fy, fz);
+      for (int j = 0; j < 32 && (mask >> j); ++j) {
+        if ((mask >> j) & 1u) {
+          if (off < cap) {
+            outp[off * 3 + 0] = (double)fx;
+            outp[off * 3 + 1] = (double)fy;
+            outp[off * 3 + 2] = (double)fz;
+          }
+          ++off;
+        }
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) s_base = base + total;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out_cnt[b] = s_base;
+}
+
+// ------------------------------------------------------------------------------------------------
+// layout converters ([T][V] slabs <-> reference [V][T])
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_slabs_to_vt(const float *__restrict__ slabs, int V, int T,
+                                                     float *__restrict__ vt) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= V) return;
+  for (int t = 0; t < T; ++t) vt[(size_t)v * T + t] = slabs[(size_t)t * V + v];
+}
+__global__ __launch_bounds__(256) void k_vt_to_slabs(const float *__restrict__ vt, int V, int T,
+                                                     float *__restrict__ slabs) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= V) return;
+  for (int t = 0; t < T; ++t) slabs[(size_t)t * V + v] = vt[(size_t)v * T + t];
+}
+
+}  // namespace sogm
+
+using namespace sogm;
+
+// ================================================================================================
+// C ABI
+// ================================================================================================
+extern "C" {
+
+int sogm_abi_version(void) { return 1; }
+const char *sogm_last_error(void) { return sogm::g_err; }
+
+int sogm_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int sogm_create(const SogmSpec *spec, int n_agents, int device, sogm_ctx **out) {
+  if (!spec || !out || n_agents <= 0) return SOGM_ERR_INVALID_ARG;
+  if (spec->L <= 0 || spec->W <= 0 || spec->H <= 0 || spec->T <= 0 || spec->T > 32 ||
+      !(spec->resolution > 0.f) || !(spec->time_resolution > 0.f))
+    return SOGM_ERR_INVALID_ARG;
+  if (spec->map_kind != SOGM_MAP_FAKE && spec->map_kind != SOGM_MAP_RISKBASE)
+    return SOGM_ERR_INVALID_ARG;
+  *out = nullptr;
+  if (sogm_device_count() <= device || device < 0) {
+    std::snprintf(sogm::g_err, sizeof(sogm::g_err), "no HIP device %d", device);
+    return SOGM_ERR_NO_DEVICE;
+  }
+  if (hipSetDevice(device) != hipSuccess) return SOGM_ERR_NO_DEVICE;
+  sogm_ctx *c = new (std::nothrow) sogm_ctx();
+  if (!c) return SOGM_ERR_INVALID_ARG;
+  std::memset(c, 0, sizeof(*c));
+  c->spec          = *spec;
+  c->geom          = make_geom(*spec);
+  c->n_agents      = n_agents;
+  c->device        = device;
+  const size_t n   = (size_t)n_agents * spec->T * (size_t)c->geom.V;
+  hipError_t   e   = hipMalloc(&c->d_grid, n * sizeof(float));
+  if (e == hipSuccess) e = hipMalloc(&c->d_poses, sizeof(float) * 3 * n_agents);
+  if (e == hipSuccess) e = hipMalloc(&c->d_stamps, sizeof(double) * n_agents);
+  if (e == hipSuccess) e = hipMalloc(&c->d_scratch_vt, sizeof(float) * (size_t)c->geom.V * spec->T);
+  if (e == hipSuccess) e = hipMemset(c->d_poses, 0, sizeof(float) * 3 * n_agents);
+  if (e == hipSuccess) e = hipMemset(c->d_stamps, 0, sizeof(double) * n_agents);
+  for (int k = 0; k < SOGM_PROF_N && e == hipSuccess; ++k) {
+    e = hipEventCreate(&c->ev[k][0]);
+    if (e == hipSuccess) e = hipEventCreate(&c->ev[k][1]);
+  }
+  if (e != hipSuccess) {
+    sogm::set_error("sogm_create", e);
+    sogm_destroy(c);
+    return SOGM_ERR_HIP;
+  }
+  *out = c;
+  return SOGM_OK;
+}
+
+void sogm_destroy(sogm_ctx *c) {
+  if (!c) return;
+  if (c->d_grid) (void)hipFree(c->d_grid);
+  if (c->d_poses) (void)hipFree(c->d_poses);
+  if (c->d_stamps) (void)hipFree(c->d_stamps);
+  if (c->d_body) (void)hipFree(c->d_body);
+  if (c->d_scratch_vt) (void)hipFree(c->d_scratch_vt);
+  for (int k = 0; k < SOGM_PROF_N; ++k) {
+    if (c->ev[k][0]) (void)hipEventDestroy(c->ev[k][0]);
+    if (c->ev[k][1]) (void)hipEventDestroy(c->ev[k][1]);
+  }
+  delete c;
+}
+
+int64_t sogm_grid_bytes(const sogm_ctx *c) {
+  return c ? (int64_t)c->n_agents * c->spec.T * (int64_t)c->geom.V * 4 : 0;
+}
+float *sogm_grid_ptr(sogm_ctx *c) { return c ? c->d_grid : nullptr; }
+
+int sogm_set_profiling(sogm_ctx *c, int enable) {
+  if (!c) return SOGM_ERR_INVALID_ARG;
+  c->profiling = enable ? 1 : 0;
+  for (int k = 0; k < SOGM_PROF_N; ++k) c->ev_used[k] = 0;
+  return SOGM_OK;
+}
+
+int sogm_profile_read(sogm_ctx *c, double *out_ms) {
+  if (!c || !out_ms) return SOGM_ERR_INVALID_ARG;
+  SOGM_HIP_CHECK(hipDeviceSynchronize());
+  for (int k = 0; k < SOGM_PROF_N; ++k) {
+    out_ms[k] = -1.0;
+    if (!c->ev_used[k]) continue;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, c->ev[k][0], c->ev[k][1]) == hipSuccess) out_ms[k] = (double)ms;
+  }
+  return SOGM_OK;
+}
+
+int sogm_set_body_particles(sogm_ctx *c, const double *xyz, int n) {
+  if (!c || !xyz || n <= 0) return SOGM_ERR_INVALID_ARG;
+  if (c->d_body) (void)hipFree(c->d_body);
+  c->d_body = nullptr;
+  SOGM_HIP_CHECK(hipMalloc(&c->d_body, sizeof(double) * 3 * n));
+  SOGM_HIP_CHECK(hipMemcpy(c->d_body, xyz, sizeof(double) * 3 * n, hipMemcpyHostToDevice));
+  c->n_body = n;
+  return SOGM_OK;
+}
+
+static int clear_grid(sogm_ctx *c, hipStream_t st) {
+  const size_t n    = (size_t)c->n_agents * c->spec.T * (size_t)c->geom.V;
+  const size_t nv4  = n / 4;
+  const int    tail = (int)(n - nv4 * 4);
+  size_t       want = (nv4 + 255) / 256;
+  const int    nblk = (int)(want < 1 ? 1 : (want > 2048 ? 2048 : want));
+  prof_begin(c, SOGM_PROF_CLEAR, st);
+  hipLaunchKernelGGL(k_clear_slabs, dim3(nblk), dim3(256), 0, st, (vfloat4 *)c->d_grid, nv4,
+                     c->d_grid + nv4 * 4, tail);
+  prof_end(c, SOGM_PROF_CLEAR, st);
+  SOGM_HIP_CHECK(hipGetLastError());
+  return SOGM_OK;
+}
+
+int sogm_update_gt(sogm_ctx *c, const float *cloud_xyz, const int32_t *cloud_range,
+                   const SogmCylinder *cylinders, int n_cyl, const float *poses,
+                   const double *stamps, void *stream) {
+  if (!c || !cloud_xyz || !cloud_range || !poses || !stamps || n_cyl < 0 ||
+      (n_cyl > 0 && !cylinders))
+    return SOGM_ERR_INVALID_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  SOGM_HIP_CHECK(hipMemcpyAsync(c->d_poses, poses, sizeof(float) * 3 * c->n_agents,
+                                hipMemcpyDeviceToDevice, st));
+  SOGM_HIP_CHECK(hipMemcpyAsync(c->d_stamps, stamps, sizeof(double) * c->n_agents,
+                                hipMemcpyDeviceToDevice, st));
+  int rc = clear_grid(c, st);
+  if (rc) return rc;
+  // 32 workgroups of 256 lanes per agent stride over that agent's cloud range
+  prof_begin(c, SOGM_PROF_STAMP, st);
+  hipLaunchKernelGGL(k_stamp_cloud, dim3(32, c->n_agents), dim3(256), 0, st, c->geom, c->d_grid,
+                     cloud_xyz, cloud_range, cylinders, n_cyl, c->d_poses);
+  prof_end(c, SOGM_PROF_STAMP, st);
+  SOGM_HIP_CHECK(hipGetLastError());
+  c->updated = 1;
+  return SOGM_OK;
+}
+
+int sogm_project_neighbours(sogm_ctx *c, const SogmTrajRecord *records, int n_records,
+                            const int32_t *ego_ids, void *stream) {
+  if (!c || n_records < 0 || (n_records > 0 && !records) || !ego_ids) return SOGM_ERR_INVALID_ARG;
+  if (!c->updated) return SOGM_ERR_STATE;
+  if (!c->d_body || c->n_body <= 0) return SOGM_ERR_STATE;
+  if (n_records == 0) return SOGM_OK;
+  const long long total = (long long)c->n_agents * n_records * c->spec.T;
+  const int       nblk  = (int)((total + 255) / 256);
+  prof_begin(c, SOGM_PROF_SPLAT, (hipStream_t)stream);
+  hipLaunchKernelGGL(k_splat_neighbours, dim3(nblk), dim3(256), 0, (hipStream_t)stream, c->geom,
+                     c->d_grid, records, n_records, ego_ids, c->d_poses, c->d_stamps, c->d_body,
+                     c->n_body, c->n_agents);
+  prof_end(c, SOGM_PROF_SPLAT, (hipStream_t)stream);
+  SOGM_HIP_CHECK(hipGetLastError());
+  return SOGM_OK;
+}
+
+int sogm_set_future_risk(sogm_ctx *c, const float *grid_vt, const float *poses,
+                         const double *stamps, void *stream) {
+  if (!c || !grid_vt || !poses || !stamps) return SOGM_ERR_INVALID_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  SOGM_HIP_CHECK(hipMemcpyAsync(c->d_poses, poses, sizeof(float) * 3 * c->n_agents,
+                                hipMemcpyDeviceToDevice, st));
+  SOGM_HIP_CHECK(hipMemcpyAsync(c->d_stamps, stamps, sizeof(double) * c->n_agents,
+                                hipMemcpyDeviceToDevice, st));
+  const int    V = c->geom.V, T = c->spec.T;
+  const size_t per = (size_t)V * T;
+  for (int a = 0; a < c->n_agents; ++a) {
+    hipLaunchKernelGGL(k_vt_to_slabs, dim3((V + 255) / 256), dim3(256), 0, st, grid_vt + a * per,
+                       V, T, c->d_grid + a * per);
+  }
+  SOGM_HIP_CHECK(hipGetLastError());
+  c->updated = 1;
+  return SOGM_OK;
+}
+
+int sogm_download_reference_layout(sogm_ctx *c, int agent, float *out) {
+  if (!c || !out || agent < 0 || agent >= c->n_agents) return SOGM_ERR_INVALID_ARG;
+  const int    V = c->geom.V, T = c->spec.T;
+  const size_t per = (size_t)V * T;
+  SOGM_HIP_CHECK(hipDeviceSynchronize());
+  hipLaunchKernelGGL(k_slabs_to_vt, dim3((V + 255) / 256), dim3(256), 0, 0,
+                     c->d_grid + (size_t)agent * per, V, T, c->d_scratch_vt);
+  SOGM_HIP_CHECK(hipGetLastError());
+  SOGM_HIP_CHECK(hipMemcpy(out, c->d_scratch_vt, per * sizeof(float), hipMemcpyDeviceToHost));
+  return SOGM_OK;
+}
+
+int sogm_query_clear(sogm_ctx *c, const int32_t *agent_idx, const double *pos_xyz, const double *t,
+                     int t_is_index, int n_q, int8_t *out, void *stream) {
+  if (!c || !agent_idx || !pos_xyz || !t || !out || n_q < 0) return SOGM_ERR_INVALID_ARG;
+  if (!c->updated) return SOGM_ERR_STATE;
+  if (n_q == 0) return SOGM_OK;
+  hipLaunchKernelGGL(k_query_clear, dim3((n_q + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                     view_of(c), agent_idx, pos_xyz, t, t_is_index, n_q, out);
+  SOGM_HIP_CHECK(hipGetLastError());
+  return SOGM_OK;
+}
+
+int sogm_obstacle_points(sogm_ctx *c, const int32_t *agent_idx, const double *box_lo,
+                         const double *box_hi, const double *t0, const double *t1, int n_b,
+                         double *out_pts, int32_t *out_counts, int cap, void *stream) {
+  if (!c || !agent_idx || !box_lo || !box_hi || !t0 || !t1 || !out_pts || !out_counts ||
+      n_b < 0 || cap <= 0)
+    return SOGM_ERR_INVALID_ARG;
+  if (!c->updated) return SOGM_ERR_STATE;
+  if (n_b == 0) return SOGM_OK;
+  hipLaunchKernelGGL(k_obstacle_points, dim3(n_b), dim3(256), 0, (hipStream_t)stream, view_of(c),
+                     agent_idx, box_lo, box_hi, t0, t1, out_pts, out_counts, cap);
+  SOGM_HIP_CHECK(hipGetLastError());
+  return SOGM_OK;
+}
+
+}  // extern "C"

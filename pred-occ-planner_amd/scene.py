@@ -1,0 +1,165 @@
+"""Deterministic synthetic scenes (SURVEY.md §8 d).
+
+The reference's obstacle generator (`map_generator dynamic_forest_seq`,
+plan_manager/launch/simulator/simulator_fake.launch:19-53) lives in an absent submodule, so the
+build owns the scene.  Parameters follow that launch file: obstacle radius U[0.5, 1.0] m, height 4 m,
+speed U[0, 0.1] m/s, cloud lattice 0.10 m; agents on a circle with antipodal goals as in
+plan_manager/launch/sim_fkpcp_4_case_4.launch:21-89.  Everything is a pure function of the seed
+(splitmix64 -> uniform), numpy only — no torch, no GPU.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+
+from ._abi import SOGM_MAX_PIECES, SogmCylinder, SogmTrajRecord
+
+_M64 = (1 << 64) - 1
+
+
+class SplitMix64:
+    def __init__(self, seed):
+        self.s = seed & _M64
+
+    def next_u64(self):
+        self.s = (self.s + 0x9E3779B97F4A7C15) & _M64
+        z = self.s
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & _M64
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & _M64
+        return z ^ (z >> 31)
+
+    def uniform(self, lo=0.0, hi=1.0):
+        return lo + (hi - lo) * ((self.next_u64() >> 11) * (1.0 / (1 << 53)))
+
+
+def body_particles(size=(0.4, 0.4, 0.45)):
+    """ParticleATC::initEgoParticles (traj_coordinator/src/particles.cpp:62-75): fp64 loops, STEP 0.15."""
+    step = 0.15
+    out = []
+    x = -size[0] / 2
+    while x <= size[0] / 2:
+        y = -size[1] / 2
+        while y <= size[1] / 2:
+            z = -size[2] / 2
+            while z <= size[2] / 2:
+                out.append((x, y, z))
+                z += step
+            y += step
+        x += step
+    return np.asarray(out, dtype=np.float64)
+
+
+def cylinders_to_struct(cyl):
+    """(n, 5) float64 rows {x, y, w, vx, vy} -> ctypes array of SogmCylinder (type 3, height 4)."""
+    arr = (SogmCylinder * max(len(cyl), 1))()
+    for i, (x, y, w, vx, vy) in enumerate(cyl):
+        c = arr[i]
+        c.type = 3
+        c.x, c.y, c.z, c.w, c.h = x, y, 2.0, w, 4.0
+        c.vx, c.vy = vx, vy
+        c.qw, c.qx, c.qy, c.qz = 1.0, 0.0, 0.0, 0.0
+    return arr
+
+
+def make_scene(n_agents, half_range, seed, moving=True, n_cyl=None, circle_radius=None,
+               tick_time=100.0):
+    """Returns a dict of numpy arrays.
+
+    half_range: map half extent in metres (grid L/2 * 0.15) — used to size the field so every
+    agent's window is populated.
+    """
+    rng = SplitMix64(seed)
+    # agents evenly on a circle, >= 1.5 m apart, antipodal goals, z = 1
+    if circle_radius is None:
+        circle_radius = max(8.0, 1.5 * n_agents / (2.0 * math.pi))
+    field = circle_radius + 2.0  # obstacle field half size
+    if n_cyl is None:
+        n_cyl = max(20, int(round(20.0 * (2 * field) ** 2 / 256.0)))  # 20 per 16x16 m
+    starts = np.zeros((n_agents, 3))
+    goals = np.zeros((n_agents, 3))
+    for a in range(n_agents):
+        th = 2.0 * math.pi * a / n_agents + math.pi
+        starts[a] = (circle_radius * math.cos(th), circle_radius * math.sin(th), 1.0)
+        goals[a] = (-starts[a, 0], -starts[a, 1], 1.0)
+    if n_agents == 1:
+        starts[0] = (-8.0, 0.0, 1.0)
+        goals[0] = (8.0, 0.0, 1.0)
+
+    cyl = []
+    guard = 0
+    while len(cyl) < n_cyl and guard < 100000:
+        guard += 1
+        x = rng.uniform(-field, field)
+        y = rng.uniform(-field, field)
+        w = rng.uniform(0.5, 1.0)
+        speed = rng.uniform(0.0, 0.1) * (10.0 if moving else 0.0)  # up to 1 m/s when moving
+        head = rng.uniform(0.0, 2.0 * math.pi)
+        # keep 1 m (+ radius) clear around every start/goal
+        d_s = np.hypot(starts[:, 0] - x, starts[:, 1] - y).min()
+        d_g = np.hypot(goals[:, 0] - x, goals[:, 1] - y).min()
+        if min(d_s, d_g) < 1.0 + w + 0.6:
+            continue
+        cyl.append((x, y, w, speed * math.cos(head), speed * math.sin(head)))
+    cyl = np.asarray(cyl, dtype=np.float64).reshape(-1, 5)
+
+    # cloud: cylinder shells on a 0.10 m lattice, z in [0, 4)
+    pts = []
+    zs = np.arange(0, 40) * 0.1
+    for (x, y, w, _, _) in cyl:
+        r = w * 0.5
+        k0x, k1x = int(math.floor((x - r) / 0.1)), int(math.ceil((x + r) / 0.1))
+        k0y, k1y = int(math.floor((y - r) / 0.1)), int(math.ceil((y + r) / 0.1))
+        gx, gy = np.meshgrid(np.arange(k0x, k1x + 1) * 0.1, np.arange(k0y, k1y + 1) * 0.1,
+                             indexing="ij")
+        d = np.hypot(gx - x, gy - y)
+        m = (d <= r) & (d > r - 0.15)
+        sx, sy = gx[m], gy[m]
+        if sx.size == 0:
+            continue
+        col = np.stack([np.repeat(sx, zs.size), np.repeat(sy, zs.size),
+                        np.tile(zs, sx.size)], axis=1)
+        pts.append(col)
+    cloud = (np.concatenate(pts, axis=0) if pts else np.zeros((0, 3))).astype(np.float32)
+
+    return {
+        "n_agents": n_agents,
+        "cloud": np.ascontiguousarray(cloud),
+        "cylinders": cyl,
+        "starts": starts,
+        "goals": goals,
+        "poses": starts.astype(np.float32).copy(),
+        "stamps": np.full((n_agents,), tick_time, dtype=np.float64),
+        "ego_ids": np.arange(n_agents, dtype=np.int32),
+        "circle_radius": circle_radius,
+    }
+
+
+def straight_records(scene, speed=1.0, t_start=None, n_pieces=6, piece_dur=0.3):
+    """Constant-velocity Bezier trajectories start->goal for every agent (neighbour overlay input
+    before any replan has produced real ones).  Returns a ctypes array of SogmTrajRecord."""
+    A = scene["n_agents"]
+    recs = (SogmTrajRecord * A)()
+    for a in range(A):
+        r = recs[a]
+        r.drone_id = int(scene["ego_ids"][a])
+        r.n_pieces = n_pieces
+        r.time_start = float(scene["stamps"][a] - 0.05 if t_start is None else t_start)
+        d = scene["goals"][a] - scene["starts"][a]
+        n = np.linalg.norm(d)
+        u = d / n if n > 0 else d
+        for p in range(n_pieces):
+            r.duration[p] = piece_dur
+            for j in range(5):
+                s = (p + j / 4.0) * piece_dur * speed
+                for k in range(3):
+                    r.cpts[(p * 5 + j) * 3 + k] = scene["starts"][a][k] + u[k] * s
+    return recs
+
+
+def records_to_numpy(recs):
+    """ctypes SogmTrajRecord array -> uint8 numpy buffer (for upload)."""
+    return np.frombuffer(bytes(recs), dtype=np.uint8).copy()
+
+
+def struct_to_numpy(arr):
+    return np.frombuffer(bytes(arr), dtype=np.uint8).copy()

@@ -1,0 +1,142 @@
+"""Host-side mirror of the reference map classes for a BATCH of agents, over the C ABI.
+
+Method names follow the reference (`updateMap`, `getClearOcccupancy` [sic], `getObstaclePoints`,
+`getMapTime`, `getMapCenter`, `setCoordinator`-style neighbour overlay) —
+plan_env/include/plan_env/fake_particle_risk_voxel.h:49-107, risk_base.h:33-110.  PyTorch is used
+only as plumbing: device buffers and the current HIP stream.  All compute runs in libsogm_hip.so.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _abi
+from ._abi import check, lib
+from .scene import body_particles, struct_to_numpy
+
+
+def _dev(x, dtype=None, device="cuda"):
+    """numpy/ctypes -> device tensor (uint8 for structs)."""
+    if isinstance(x, torch.Tensor):
+        return x.to(device)
+    if not isinstance(x, np.ndarray):
+        x = struct_to_numpy(x)
+    if dtype is not None:
+        x = np.ascontiguousarray(x, dtype=dtype)
+    return torch.from_numpy(np.ascontiguousarray(x)).to(device)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class SogmMap:
+    """Batched FakeParticleRiskVoxel / RiskBase.  One instance = n_agents maps on one GPU."""
+
+    def __init__(self, spec, n_agents, device=0, drone_size=(0.4, 0.4, 0.45)):
+        self.spec = spec
+        self.n_agents = n_agents
+        self.device = device
+        self._ctx = C.c_void_p()
+        torch.cuda.set_device(device)
+        check(lib().sogm_create(C.byref(spec), n_agents, device, C.byref(self._ctx)), "sogm_create")
+        self.body = body_particles(drone_size)
+        check(lib().sogm_set_body_particles(
+            self._ctx, self.body.ctypes.data_as(C.POINTER(C.c_double)), len(self.body)),
+            "sogm_set_body_particles")
+        self.V = spec.L * spec.W * spec.H
+        self._keep = []  # tensors referenced by in-flight calls
+
+    # ---- lifetime ----
+    def close(self):
+        if self._ctx:
+            torch.cuda.synchronize()
+            lib().sogm_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def ctx(self):
+        return self._ctx
+
+    def grid_bytes(self):
+        return int(lib().sogm_grid_bytes(self._ctx))
+
+    # ---- profiling (HIP events around each kernel, on the caller's stream) ----
+    def set_profiling(self, on=True):
+        check(lib().sogm_set_profiling(self._ctx, 1 if on else 0), "sogm_set_profiling")
+
+    def profile_read(self):
+        out = (C.c_double * _abi.PROF_N)()
+        check(lib().sogm_profile_read(self._ctx, out), "sogm_profile_read")
+        return list(out)
+
+    # ---- update ----
+    def updateMap(self, cloud, cloud_range, cylinders, n_cyl, poses, stamps):
+        """FakeParticleRiskVoxel::updateMap for every agent (device tensors)."""
+        self._poses, self._stamps = poses, stamps
+        check(lib().sogm_update_gt(self._ctx, cloud.data_ptr(), cloud_range.data_ptr(),
+                                   cylinders.data_ptr() if n_cyl else None, n_cyl,
+                                   poses.data_ptr(), stamps.data_ptr(), _stream()),
+              "sogm_update_gt")
+
+    def addOtherAgents(self, records, n_records, ego_ids):
+        """RiskBase::addOtherAgents / fake_particle_risk_voxel.cpp:178-218."""
+        check(lib().sogm_project_neighbours(self._ctx, records.data_ptr(), n_records,
+                                            ego_ids.data_ptr(), _stream()),
+              "sogm_project_neighbours")
+
+    def futureRiskCallback(self, grid_vt, poses, stamps):
+        check(lib().sogm_set_future_risk(self._ctx, grid_vt.data_ptr(), poses.data_ptr(),
+                                         stamps.data_ptr(), _stream()), "sogm_set_future_risk")
+
+    # ---- readback ----
+    def download(self, agent):
+        """risk_maps_[V][T] of one agent (reference layout), numpy float32."""
+        out = np.empty((self.V, self.spec.T), dtype=np.float32)
+        check(lib().sogm_download_reference_layout(self._ctx, agent, out.ctypes.data),
+              "sogm_download_reference_layout")
+        return out
+
+    # ---- queries ----
+    def getClearOcccupancy(self, agent_idx, pos, t, t_is_index=False):
+        """Batched getClearOcccupancy; agent_idx int32[n], pos float64[n,3], t float64[n]."""
+        n = int(agent_idx.numel())
+        out = torch.empty((n,), dtype=torch.int8, device=agent_idx.device)
+        check(lib().sogm_query_clear(self._ctx, agent_idx.data_ptr(), pos.data_ptr(),
+                                     t.data_ptr(), 1 if t_is_index else 0, n, out.data_ptr(),
+                                     _stream()), "sogm_query_clear")
+        return out
+
+    def getObstaclePoints(self, agent_idx, box_lo, box_hi, t0, t1, cap=4096):
+        n = int(agent_idx.numel())
+        pts = torch.empty((n, cap, 3), dtype=torch.float64, device=agent_idx.device)
+        cnt = torch.empty((n,), dtype=torch.int32, device=agent_idx.device)
+        check(lib().sogm_obstacle_points(self._ctx, agent_idx.data_ptr(), box_lo.data_ptr(),
+                                         box_hi.data_ptr(), t0.data_ptr(), t1.data_ptr(), n,
+                                         pts.data_ptr(), cnt.data_ptr(), cap, _stream()),
+              "sogm_obstacle_points")
+        return pts, cnt
+
+
+def upload_scene(scene, device="cuda"):
+    """numpy scene -> dict of device tensors in the ABI's layouts."""
+    from .scene import cylinders_to_struct
+    A = scene["n_agents"]
+    n_pts = scene["cloud"].shape[0]
+    cyl = cylinders_to_struct(scene["cylinders"])
+    rng = np.tile(np.asarray([[0, n_pts]], dtype=np.int32), (A, 1))
+    return {
+        "cloud": _dev(scene["cloud"] if n_pts else np.zeros((1, 3), np.float32), np.float32, device),
+        "cloud_range": _dev(rng, np.int32, device),
+        "cylinders": _dev(cyl, None, device),
+        "n_cyl": int(len(scene["cylinders"])),
+        "poses": _dev(scene["poses"], np.float32, device),
+        "stamps": _dev(scene["stamps"], np.float64, device),
+        "ego_ids": _dev(scene["ego_ids"], np.int32, device),
+    }
