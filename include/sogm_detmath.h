@@ -1,0 +1,156 @@
+/*
+ * sogm_detmath.h — deterministic fp64 cbrt / cos / acos built only from IEEE-754 correctly rounded
+ * operations (+ - * / sqrt) and exact exponent manipulation.
+ *
+ * Why: the hybrid A* heuristic (path_searching/src/fake_risk_hybrid_a_star.cpp:525-587) calls
+ * cbrt/acos/cos.  glibc and the ROCm device library round these differently in the last ulp, and
+ * the north_star demands bit-exact A* expansions between the CPU oracle and the HIP path.  Both
+ * sides therefore evaluate these three functions with this one header (plain C++, no algorithm
+ * from the reference in it); tests/test_detmath.py bounds their error against libm.
+ * Compile with -ffp-contract=off on both sides.
+ */
+#ifndef SOGM_DETMATH_H
+#define SOGM_DETMATH_H
+
+#include <stdint.h>
+#include <string.h>
+
+#if defined(__HIPCC__)
+#define SOGM_HD __host__ __device__ inline
+#else
+#define SOGM_HD inline
+#endif
+
+namespace sogm_det {
+
+SOGM_HD double sqrt_rn(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __dsqrt_rn(x);
+#else
+  return __builtin_sqrt(x);
+#endif
+}
+
+SOGM_HD uint64_t bits_of(double x) {
+  uint64_t u;
+  memcpy(&u, &x, 8);
+  return u;
+}
+SOGM_HD double from_bits(uint64_t u) {
+  double x;
+  memcpy(&x, &u, 8);
+  return x;
+}
+
+/* x * 2^k for normal results, exact */
+SOGM_HD double scale2(double x, int k) { return x * from_bits((uint64_t)(1023 + k) << 52); }
+
+SOGM_HD double fabs_(double x) { return x < 0 ? -x : x; }
+
+/* cube root: exponent split + fixed Newton iterations on the mantissa */
+SOGM_HD double cbrt(double x) {
+  if (x == 0.0 || x != x) return x;
+  const bool neg = x < 0;
+  double     a   = neg ? -x : x;
+  uint64_t   u   = bits_of(a);
+  int        e   = (int)(u >> 52) & 0x7ff;
+  if (e == 0x7ff) return x; /* inf */
+  int shift = 0;
+  if (e == 0) { /* subnormal: scale up by 2^54 (multiple of 3) */
+    a     = a * 18014398509481984.0;
+    u     = bits_of(a);
+    e     = (int)(u >> 52) & 0x7ff;
+    shift = -18;
+  }
+  int    ex = e - 1023;                                 /* a = m * 2^ex, m in [1,2) */
+  int    q  = ex >= 0 ? ex / 3 : -((-ex + 2) / 3);      /* floor(ex / 3) */
+  int    r  = ex - 3 * q;                               /* 0,1,2 */
+  double m  = from_bits((u & 0x000fffffffffffffULL) | ((uint64_t)(1023 + r) << 52)); /* [1,8) */
+  /* initial guess: linear fit on [1,8), then fixed Newton steps y <- y - (y^3 - m) / (3 y^2) */
+  double y = 0.7 + 0.16 * m;
+  for (int i = 0; i < 7; ++i) {
+    const double y2 = y * y;
+    y               = y - (y2 * y - m) / (3.0 * y2);
+  }
+  y = scale2(y, q + shift);
+  return neg ? -y : y;
+}
+
+/* sin and cos on |r| <= pi/4 (Taylor, fixed Horner order) */
+SOGM_HD double sin_k(double r) {
+  const double z = r * r;
+  double       p = -7.6471637318198164759e-13;         /* -1/15! */
+  p              = p * z + 1.6059043836821614599e-10;  /*  1/13! */
+  p              = p * z + -2.5052108385441718775e-08; /* -1/11! */
+  p              = p * z + 2.7557319223985890653e-06;  /*  1/9!  */
+  p              = p * z + -1.9841269841269841270e-04; /* -1/7!  */
+  p              = p * z + 8.3333333333333333333e-03;  /*  1/5!  */
+  p              = p * z + -1.6666666666666666667e-01; /* -1/3!  */
+  return r + r * (z * p);
+}
+SOGM_HD double cos_k(double r) {
+  const double z = r * r;
+  double       p = 4.7794773323873852974e-14;          /*  1/16! */
+  p              = p * z + -1.1470745597729724714e-11; /* -1/14! */
+  p              = p * z + 2.0876756987868098979e-09;  /*  1/12! */
+  p              = p * z + -2.7557319223985890653e-07; /* -1/10! */
+  p              = p * z + 2.4801587301587301587e-05;  /*  1/8!  */
+  p              = p * z + -1.3888888888888888889e-03; /* -1/6!  */
+  p              = p * z + 4.1666666666666666667e-02;  /*  1/4!  */
+  return 1.0 - 0.5 * z + z * (z * p);
+}
+
+/* cos for |x| < ~1e5 (three-term Cody-Waite reduction by pi/2) */
+SOGM_HD double cos(double x) {
+  const double a       = fabs_(x);
+  const double kf      = (double)(long long)(a * 0.63661977236758134308 + 0.5);
+  const double PIO2_HI = 1.57079632673412561417e+00;
+  const double PIO2_LO = 6.07710050650619224932e-11;
+  const double PIO2_LL = 2.02226624879595063154e-21;
+  double       r       = a - kf * PIO2_HI;
+  r                    = r - kf * PIO2_LO;
+  r                    = r - kf * PIO2_LL;
+  const int k          = (int)((long long)kf & 3);
+  switch (k) {
+    case 0: return cos_k(r);
+    case 1: return -sin_k(r);
+    case 2: return -cos_k(r);
+    default: return sin_k(r);
+  }
+}
+
+/* asin on [0, ~0.51]: odd Taylor series, 26 terms, Horner in z = x^2 */
+SOGM_HD double asin_small(double x) {
+  const double z = x * x;
+  /* c_n = (2n)! / (4^n (n!)^2 (2n+1)) by the recurrence c_n = c_{n-1} (2n-1)^2 / (2n (2n+1)) */
+  double c[26];
+  c[0] = 1.0;
+  for (int n = 1; n < 26; ++n) {
+    const double tn = (double)(2 * n - 1);
+    c[n]            = c[n - 1] * (tn * tn) / ((double)(2 * n) * (double)(2 * n + 1));
+  }
+  double p = c[25];
+  for (int n = 24; n >= 0; --n) p = p * z + c[n];
+  return x * p;
+}
+
+SOGM_HD double acos(double x) {
+  const double PI      = 3.14159265358979311600e+00;
+  const double PIO2_HI = 1.57079632679489655800e+00;
+  const double PIO2_LO = 6.12323399573676603587e-17;
+  if (x != x) return x;
+  if (x >= 1.0) return 0.0;
+  if (x <= -1.0) return PI;
+  const double a = fabs_(x);
+  if (a <= 0.5) {
+    const double s = asin_small(a);
+    return x >= 0 ? (PIO2_HI - (s - PIO2_LO)) : (PIO2_HI + (s + PIO2_LO));
+  }
+  /* acos(a) = 2 asin(sqrt((1-a)/2)) for a in (0.5, 1) */
+  const double t = sqrt_rn((1.0 - a) * 0.5);
+  const double s = 2.0 * asin_small(t);
+  return x >= 0 ? s : (PI - s);
+}
+
+}  // namespace sogm_det
+#endif

@@ -126,3 +126,26 @@ def obstacle_points(spec, grid, pose, stamp, t0, t1, lc, hc, cap=4096):
     n = lib().orc_obstacle_points(C.byref(spec), fptr(grid), fptr(pose), C.c_double(stamp), C.c_double(t0),
                                   C.c_double(t1), dptr(lc), dptr(hc), dptr(out), cap)
     return out[:min(n, cap)].copy(), n
+
+
+# ---------------------------------------------------------------- A*
+def astar_use_libm(on):
+    lib().orc_astar_use_libm(1 if on else 0)
+
+
+def astar_search(spec, ap, grid, pose, start_pva, goal, t_after_map, corridor_tau=0.3, route_cap=64,
+                 trace_cap=20000):
+    pose = np.ascontiguousarray(pose, np.float32)
+    s = np.ascontiguousarray(start_pva, np.float64).reshape(9)
+    g = np.ascontiguousarray(goal, np.float64)
+    route = np.zeros((route_cap, 6))
+    n = C.c_int(0)
+    stats = (C.c_int * 4)()
+    trace = np.zeros(trace_cap, np.int32)
+    ntr = C.c_int(0)
+    ret = lib().orc_astar_search(C.byref(spec), C.byref(ap), fptr(grid), fptr(pose), dptr(s), dptr(g),
+                                 C.c_double(t_after_map), C.c_double(corridor_tau), dptr(route), C.byref(n),
+                                 route_cap, stats, trace.ctypes.data_as(C.POINTER(C.c_int32)), trace_cap,
+                                 C.byref(ntr))
+    return {"ret": ret, "route": route[:n.value].copy(), "stats": list(stats),
+            "trace": trace[:min(ntr.value, trace_cap)].copy(), "trace_len": ntr.value}

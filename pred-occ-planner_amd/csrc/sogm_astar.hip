@@ -1,0 +1,647 @@
+// sogm_astar.hip — batched 4-D (x,y,z,t) kinodynamic hybrid A* on the SOGM, one workgroup per agent.
+//
+// Reference: FakeRiskHybridAstar (path_searching/src/fake_risk_hybrid_a_star.cpp:84-426,428-587,
+// 663-694,795-836; node/hash/heap types path_node.h:37-97, grid_node.h:10-51).
+//
+// Mapping to CDNA4: the search itself is a serial program (best-first pop, ordered merge of the
+// children into the hash table / heap), so one lane ("the master", lane 0) runs it.  What is
+// parallel is the expansion: the 5x5x3 = 75 motion primitives of a node are evaluated by the 64
+// lanes of the wave at once — state transition, voxel/time index, velocity gate, the K-cell SOGM
+// collision gather and the quartic-root heuristic — and handed to the master through LDS.  The
+// results consumed by the master are pure functions of (node, primitive), so evaluating them eagerly
+// for children the reference would have skipped changes nothing.  Everything is gather / latency
+// bound against an L2-resident working window of the SOGM; there is no dense contraction (no MFMA).
+//
+// Bit-exactness contract (north_star): expansions are bit-identical to the CPU oracle.  fp64
+// arithmetic is written in the same operation order, compiled with -ffp-contract=off;
+// cbrt/acos/cos come from include/sogm_detmath.h on both sides; the open list reproduces
+// libstdc++'s push_heap/pop_heap (std::priority_queue) including its behaviour when f-scores are
+// edited in place; the closed/open hash keeps the reference's insert-does-not-overwrite semantics
+// and its (int)time vs time_idx key mismatch (:387 vs :271).
+#include <hip/hip_runtime.h>
+
+#include "../../include/sogm_detmath.h"
+#include "sogm_planner.hpp"
+
+namespace sogm {
+
+namespace {
+
+enum { IN_CLOSE_SET = 1, IN_OPEN_SET = 2, NOT_EXPAND = 3 };
+enum { NO_PATH = 0, INIT_ERR, SEARCH_ERR, REACH_HORIZON, REACH_END, NEAR_END };
+
+__device__ inline double dot3(const double *a, const double *b) {
+  return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2];
+}
+
+// stateTransit (:812-824): phi * x0 + [0.5 tau^2 u ; tau u]
+__device__ inline void state_transit(const double *s0, double *s1, const double *um, double tau) {
+  const double h = 0.5 * (tau * tau);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    s1[i]     = (s0[i] + tau * s0[i + 3]) + h * um[i];
+    s1[i + 3] = s0[i + 3] + tau * um[i];
+  }
+}
+
+// cubic / quartic (:525-587)
+__device__ inline int cubic(double a, double b, double c, double d, double *out) {
+  const double a2 = b / a, a1 = c / a, a0 = d / a;
+  const double Q = (3 * a1 - a2 * a2) / 9;
+  const double R = (9 * a1 * a2 - 27 * a0 - 2 * a2 * a2 * a2) / 54;
+  const double D = Q * Q * Q + R * R;
+  if (D > 0) {
+    const double S = sogm_det::cbrt(R + sogm_det::sqrt_rn(D));
+    const double T = sogm_det::cbrt(R - sogm_det::sqrt_rn(D));
+    out[0]         = -a2 / 3 + (S + T);
+    return 1;
+  } else if (D == 0) {
+    const double S = sogm_det::cbrt(R);
+    out[0]         = -a2 / 3 + S + S;
+    out[1]         = -a2 / 3 - S;
+    return 2;
+  } else {
+    const double PI    = 3.14159265358979323846;
+    const double theta = sogm_det::acos(R / sogm_det::sqrt_rn(-Q * Q * Q));
+    out[0]             = 2 * sogm_det::sqrt_rn(-Q) * sogm_det::cos(theta / 3) - a2 / 3;
+    out[1]             = 2 * sogm_det::sqrt_rn(-Q) * sogm_det::cos((theta + 2 * PI) / 3) - a2 / 3;
+    out[2]             = 2 * sogm_det::sqrt_rn(-Q) * sogm_det::cos((theta + 4 * PI) / 3) - a2 / 3;
+    return 3;
+  }
+}
+
+__device__ inline int quartic(double a, double b, double c, double d, double e, double *out) {
+  const double a3 = b / a, a2 = c / a, a1 = d / a, a0 = e / a;
+  double       ys[3];
+  cubic(1, -a2, a1 * a3 - 4 * a0, 4 * a2 * a0 - a1 * a1 - a3 * a3 * a0, ys);
+  const double y1 = ys[0];
+  const double r  = a3 * a3 / 4 - a2 + y1;
+  if (r < 0) return 0;
+  const double R = sogm_det::sqrt_rn(r);
+  double       D, E;
+  if (R != 0) {
+    D = sogm_det::sqrt_rn(0.75 * a3 * a3 - R * R - 2 * a2 +
+                          0.25 * (4 * a3 * a2 - 8 * a1 - a3 * a3 * a3) / R);
+    E = sogm_det::sqrt_rn(0.75 * a3 * a3 - R * R - 2 * a2 -
+                          0.25 * (4 * a3 * a2 - 8 * a1 - a3 * a3 * a3) / R);
+  } else {
+    D = sogm_det::sqrt_rn(0.75 * a3 * a3 - 2 * a2 + 2 * sogm_det::sqrt_rn(y1 * y1 - 4 * a0));
+    E = sogm_det::sqrt_rn(0.75 * a3 * a3 - 2 * a2 - 2 * sogm_det::sqrt_rn(y1 * y1 - 4 * a0));
+  }
+  int n = 0;
+  if (!(D != D)) {
+    out[n++] = -a3 / 4 + R / 2 + D / 2;
+    out[n++] = -a3 / 4 + R / 2 - D / 2;
+  }
+  if (!(E != E)) {
+    out[n++] = -a3 / 4 - R / 2 + E / 2;
+    out[n++] = -a3 / 4 - R / 2 - E / 2;
+  }
+  return n;
+}
+
+// estimateHeuristic (:428-468)
+__device__ inline double estimate_heuristic(const SogmAstarParams &ap, const double *x1,
+                                            const double *x2, double &optimal_time) {
+  double dp[3], v0[3], v1[3], vs[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    dp[i] = x2[i] - x1[i];
+    v0[i] = x1[i + 3];
+    v1[i] = x2[i + 3];
+    vs[i] = v0[i] + v1[i];
+  }
+  const double c1 = -36 * dot3(dp, dp);
+  const double c2 = 24 * dot3(vs, dp);
+  const double c3 = -4 * (dot3(v0, v0) + dot3(v0, v1) + dot3(v1, v1));
+  const double c4 = 0;
+  const double c5 = ap.w_time;
+  double       ts[5];
+  int          n     = quartic(c5, c4, c3, c2, c1, ts);
+  const double v_max = ap.max_vel * 0.5;
+  double       linf  = 0;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const double d = sogm_det::fabs_(x1[i] - x2[i]);
+    linf           = d > linf ? d : linf;
+  }
+  const double t_bar = linf / v_max;
+  ts[n++]            = t_bar;
+  double cost = 100000000, t_d = t_bar;
+  for (int i = 0; i < n; ++i) {
+    const double t = ts[i];
+    if (t < t_bar) continue;
+    const double c = -c1 / (3 * t * t * t) - c2 / (2 * t * t) - c3 / t + ap.w_time * t;
+    if (c < cost) {
+      cost = c;
+      t_d  = t;
+    }
+  }
+  optimal_time             = t_d;
+  const double tie_breaker = 1.0 + 1.0 / 10000;
+  return 1.0 * (1 + tie_breaker) * cost;
+}
+
+// ---- per-agent search state in global memory ---------------------------------------------------
+struct __attribute__((aligned(16))) Node {
+  double state[6];
+  double input[3];
+  double duration;
+  double time;
+  double g, f;
+  int    index[3];
+  int    time_idx;
+  int    parent;
+  int    node_state;
+};  // 128 B
+
+struct Work {
+  Node *pool;      // [allocate_num]
+  int  *heap;      // [allocate_num]
+  int4 *hkeys;     // [hash_cap]
+  int  *hvals;     // [hash_cap], -1 = empty
+  int   hash_cap;  // power of two
+};
+
+__device__ inline unsigned hash4(int a, int b, int c, int d) {
+  unsigned h = 0x9e3779b9u;
+  h ^= (unsigned)a + 0x9e3779b9u + (h << 6) + (h >> 2);
+  h ^= (unsigned)b + 0x9e3779b9u + (h << 6) + (h >> 2);
+  h ^= (unsigned)c + 0x9e3779b9u + (h << 6) + (h >> 2);
+  h ^= (unsigned)d + 0x9e3779b9u + (h << 6) + (h >> 2);
+  return h;
+}
+// NodeHashTable::find (path_node.h:86-89)
+__device__ inline int hash_find(const Work &w, int a, int b, int c, int d) {
+  unsigned s = hash4(a, b, c, d) & (w.hash_cap - 1);
+  while (true) {
+    const int v = w.hvals[s];
+    if (v < 0) return -1;
+    const int4 k = w.hkeys[s];
+    if (k.x == a && k.y == b && k.z == c && k.w == d) return v;
+    s = (s + 1) & (w.hash_cap - 1);
+  }
+}
+// NodeHashTable::insert (path_node.h:79-82): unordered_map::insert keeps an existing entry
+__device__ inline void hash_insert(const Work &w, int a, int b, int c, int d, int val) {
+  unsigned s = hash4(a, b, c, d) & (w.hash_cap - 1);
+  while (true) {
+    const int v = w.hvals[s];
+    if (v < 0) {
+      w.hkeys[s] = make_int4(a, b, c, d);
+      w.hvals[s] = val;
+      return;
+    }
+    const int4 k = w.hkeys[s];
+    if (k.x == a && k.y == b && k.z == c && k.w == d) return;
+    s = (s + 1) & (w.hash_cap - 1);
+  }
+}
+
+// libstdc++ std::push_heap / std::pop_heap with NodeComparator (f(a) > f(b)), restated.
+__device__ inline bool heap_cmp(const Node *pool, int a, int b) { return pool[a].f > pool[b].f; }
+__device__ inline void heap_push_up(const Node *pool, int *h, int hole, int top, int value) {
+  int parent = (hole - 1) / 2;
+  while (hole > top && heap_cmp(pool, h[parent], value)) {
+    h[hole] = h[parent];
+    hole    = parent;
+    parent  = (hole - 1) / 2;
+  }
+  h[hole] = value;
+}
+__device__ inline void heap_push(const Node *pool, int *h, int &n, int value) {
+  h[n] = value;
+  ++n;
+  heap_push_up(pool, h, n - 1, 0, value);
+}
+__device__ inline void heap_pop(const Node *pool, int *h, int &n) {
+  if (n > 1) {
+    // __pop_heap(first, last-1, last-1): value = *(last-1); *(last-1) = *first; adjust(first,0,len-1)
+    const int value = h[n - 1];
+    h[n - 1]        = h[0];
+    const int len   = n - 1;
+    int       hole  = 0;
+    int       child = 0;
+    while (child < (len - 1) / 2) {
+      child = 2 * (child + 1);
+      if (heap_cmp(pool, h[child], h[child - 1])) child--;
+      h[hole] = h[child];
+      hole    = child;
+    }
+    if ((len & 1) == 0 && child == (len - 2) / 2) {
+      child   = 2 * (child + 1);
+      h[hole] = h[child - 1];
+      hole    = child - 1;
+    }
+    heap_push_up(pool, h, hole, 0, value);
+  }
+  --n;
+}
+
+// candidate child handed from the lanes to the master through LDS
+struct Cand {
+  double state[6];
+  double g, f;
+  int    id[3];
+  int    t_id;
+  int    flags;  // bit0: velocity ok, bit1: not same (voxel,time) as parent, bit2: occupied
+};
+
+#define ASTAR_MAX_INPUTS 128
+
+__device__ inline void pos_to_index(const double *p, const double *center, double inv_res,
+                                    int *out) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i) out[i] = (int)floor((p[i] - center[i]) * inv_res);
+}
+
+}  // namespace
+
+// One workgroup (one wave of 64 lanes) per agent.
+__global__ __launch_bounds__(64) void k_astar(
+    MapView m, SogmAstarParams ap, double corridor_tau, AstarWorkspace wsp,
+    const double *__restrict__ start_pva, const double *__restrict__ goal,
+    const double *__restrict__ t_start, int32_t *__restrict__ out_ret,
+    double *__restrict__ out_route, int32_t *__restrict__ out_route_len, int route_cap,
+    int32_t *__restrict__ out_stats, int32_t *__restrict__ out_trace, int trace_cap) {
+  const int agent = blockIdx.x;
+  const int lane  = threadIdx.x;
+
+  __shared__ double s_inputs[ASTAR_MAX_INPUTS][3];
+  __shared__ int    s_n_inputs;
+  __shared__ Cand   s_cand[ASTAR_MAX_INPUTS];
+  __shared__ double s_cur_state[6];
+  __shared__ double s_cur_time, s_cur_g;
+  __shared__ int    s_cur_index[3], s_cur_tidx;
+  __shared__ int    s_n_active;   // number of primitives of this expansion (0 = stop)
+  __shared__ int    s_first;      // 1 = "init" expansion (single input = start acc)
+  __shared__ int    s_tmp[ASTAR_MAX_INPUTS];
+
+  Work w;
+  w.pool     = (Node *)(wsp.pool + (size_t)agent * wsp.pool_stride);
+  w.heap     = wsp.heap + (size_t)agent * ap.allocate_num;
+  w.hkeys    = (int4 *)wsp.hkeys + (size_t)agent * wsp.hash_cap;
+  w.hvals    = wsp.hvals + (size_t)agent * wsp.hash_cap;
+  w.hash_cap = wsp.hash_cap;
+
+  const double *pva = start_pva + agent * 9;
+  double        start_pt[3] = {pva[0], pva[1], pva[2]};
+  double        start_v[3]  = {pva[3], pva[4], pva[5]};
+  double        start_a[3]  = {pva[6], pva[7], pva[8]};
+  double        end_state[6] = {goal[agent * 3], goal[agent * 3 + 1], goal[agent * 3 + 2], 0, 0, 0};
+  const float  *pose      = m.poses + agent * 3;
+  const double  center[3] = {(double)pose[0], (double)pose[1], (double)pose[2]};
+  const double  inv_res   = 1.0 / ap.resolution;
+  const double  inv_tres  = 1.0 / ap.time_resolution;
+  // baseline_fake.cpp:282: t_after_map = traj_start_time_ - map_->getMapTime()
+  const double time_start  = t_start[agent] - m.stamps[agent];
+  const double time_origin = time_start;
+
+  // motion primitive table (:245-250), generated with the reference's accumulating fp64 loops
+  if (lane == 0) {
+    int          n  = 0;
+    const double ma = ap.max_acc, res = 1 / 2.0;
+    for (double ax = -ma; ax <= ma + 1e-3; ax += ma * res)
+      for (double ay = -ma; ay <= ma + 1e-3; ay += ma * res)
+        for (double az = -0.5 * ma; az <= 0.5 * ma + 1e-3; az += ma * res) {
+          if (n < ASTAR_MAX_INPUTS) {
+            s_inputs[n][0] = ax;
+            s_inputs[n][1] = ay;
+            s_inputs[n][2] = az;
+          }
+          ++n;
+        }
+    s_n_inputs = n < ASTAR_MAX_INPUTS ? n : ASTAR_MAX_INPUTS;
+  }
+
+  int end_index[3];
+  pos_to_index(end_state, center, inv_res, end_index);
+
+  // master-only state
+  int  use_node_num = 0, iter_num = 0, heap_n = 0, n_trace = 0;
+  int  ret = NO_PATH, searches = 0, terminal = -1;
+  bool is_shot_succ = false;
+
+  for (int attempt = 0; attempt < 2; ++attempt) {  // baseline_fake.cpp:284-291
+    // reset(): clear the hash table (all lanes), node states are rewritten on allocation
+    for (int i = lane; i < w.hash_cap; i += 64) w.hvals[i] = -1;
+    __syncthreads();
+    bool done = false;
+    if (lane == 0) {
+      use_node_num = 0;
+      iter_num     = 0;
+      heap_n       = 0;
+      is_shot_succ = false;
+      terminal     = -1;
+      ++searches;
+      Node &n0  = w.pool[0];
+      n0.parent = -1;
+      for (int i = 0; i < 3; ++i) {
+        n0.state[i]     = start_pt[i];
+        n0.state[i + 3] = start_v[i];
+      }
+      pos_to_index(start_pt, center, inv_res, n0.index);
+      n0.g = 0.0;
+      double ttg;
+      n0.f          = ap.lambda_heu * estimate_heuristic(ap, n0.state, end_state, ttg);
+      n0.node_state = IN_OPEN_SET;
+      heap_push(w.pool, w.heap, heap_n, 0);
+      use_node_num += 1;
+      n0.time     = time_start;
+      n0.time_idx = (int)floor((time_start - time_origin) * inv_tres);
+      hash_insert(w, n0.index[0], n0.index[1], n0.index[2], n0.time_idx, 0);
+      s_first = attempt == 0 ? 1 : 0;
+    }
+    int cur = -1;
+    while (!done) {
+      // ---------------- master: pop / terminate ----------------
+      if (lane == 0) {
+        s_n_active = 0;
+        if (heap_n == 0) {
+          ret = NO_PATH;  // open set empty (:419-422)
+        } else {
+          cur         = w.heap[0];
+          Node &cn    = w.pool[cur];
+          double d3[3] = {cn.state[0] - start_pt[0], cn.state[1] - start_pt[1],
+                          cn.state[2] - start_pt[2]};
+          const bool reach_horizon = sogm_det::sqrt_rn(dot3(d3, d3)) >= ap.horizon;
+          const bool near_end      = abs(cn.index[0] - end_index[0]) <= ap.tolerance &&
+                                abs(cn.index[1] - end_index[1]) <= ap.tolerance &&
+                                abs(cn.index[2] - end_index[2]) <= ap.tolerance;
+          const bool exceed_time = cn.time >= ap.max_tau;
+          bool       stop        = false;
+          if (reach_horizon || near_end || exceed_time) {
+            terminal = cur;
+            if (near_end) {
+              // estimateHeuristic + computeShotTraj (:470-523); only feasibility is consumed
+              double t_d;
+              estimate_heuristic(ap, cn.state, end_state, t_d);
+              double a[3], b[3], c[3], d[3];
+              for (int i = 0; i < 3; ++i) {
+                const double p0 = cn.state[i], dp = end_state[i] - p0, v0 = cn.state[i + 3],
+                             v1 = end_state[i + 3], dv = v1 - v0;
+                a[i] = 1.0 / 6.0 *
+                       (-12.0 / (t_d * t_d * t_d) * (dp - v0 * t_d) + 6 / (t_d * t_d) * dv);
+                b[i] = 0.5 * (6.0 / (t_d * t_d) * (dp - v0 * t_d) - 2 / t_d * dv);
+                c[i] = v0;
+                d[i] = p0;
+              }
+              const double t_delta = t_d / 10;
+              bool         ok      = true;
+              for (double time = t_delta; time <= t_d; time += t_delta) {
+                const double t1 = time, t2 = time * time, t3 = (time * time) * time;
+                double       co[3];
+                for (int dim = 0; dim < 3; ++dim)
+                  co[dim] = ((d[dim] * 1.0 + c[dim] * t1) + b[dim] * t2) + a[dim] * t3;
+                if (query_clear_time(m, agent, co[0], co[1], co[2], time) != 0) {
+                  ok = false;
+                  break;
+                }
+              }
+              if (ok) is_shot_succ = true;
+            }
+          }
+          if (reach_horizon) {
+            ret  = is_shot_succ ? REACH_END : REACH_HORIZON;
+            stop = true;
+          } else if (near_end) {
+            ret  = is_shot_succ ? REACH_END : (cn.parent >= 0 ? NEAR_END : NO_PATH);
+            stop = true;
+          } else if (exceed_time) {
+            ret  = REACH_HORIZON;
+            stop = true;
+          }
+          if (!stop) {
+            heap_pop(w.pool, w.heap, heap_n);
+            cn.node_state = IN_CLOSE_SET;
+            iter_num += 1;
+            if (out_trace && n_trace < trace_cap) out_trace[(size_t)agent * trace_cap + n_trace] = cur;
+            ++n_trace;
+            for (int i = 0; i < 6; ++i) s_cur_state[i] = cn.state[i];
+            s_cur_time = cn.time;
+            s_cur_g    = cn.g;
+            for (int i = 0; i < 3; ++i) s_cur_index[i] = cn.index[i];
+            s_cur_tidx = cn.time_idx;
+            s_n_active = s_first ? 1 : s_n_inputs;
+          }
+        }
+      }
+      __syncthreads();
+      const int n_act = s_n_active;
+      if (n_act == 0) {
+        done = true;
+        break;
+      }
+      // ---------------- all lanes: evaluate the primitives ----------------
+      const bool first = s_first != 0;
+      for (int i = lane; i < n_act; i += 64) {
+        double um[3];
+        if (first) {
+          um[0] = start_a[0];
+          um[1] = start_a[1];
+          um[2] = start_a[2];
+        } else {
+          um[0] = s_inputs[i][0];
+          um[1] = s_inputs[i][1];
+          um[2] = s_inputs[i][2];
+        }
+        const double tau = ap.time_resolution;
+        double       cs[6], ps[6];
+        for (int q = 0; q < 6; ++q) cs[q] = s_cur_state[q];
+        state_transit(cs, ps, um, tau);
+        const double pro_t = s_cur_time + tau;
+        Cand        &c     = s_cand[i];
+        pos_to_index(ps, center, inv_res, c.id);
+        c.t_id    = (int)floor((pro_t - time_origin) * inv_tres);
+        int flags = 0;
+        if (!(fabs(ps[3]) > ap.max_vel || fabs(ps[4]) > ap.max_vel || fabs(ps[5]) > ap.max_vel))
+          flags |= 1;
+        const bool same = c.id[0] == s_cur_index[0] && c.id[1] == s_cur_index[1] &&
+                          c.id[2] == s_cur_index[2] && (c.t_id - s_cur_tidx) == 0;
+        if (!same) flags |= 2;
+        if ((flags & 3) == 3) {
+          // collision gate (:296-331)
+          for (int k = 1; k <= ap.check_num; ++k) {
+            const double dt = tau * (double)k / (double)ap.check_num;
+            double       xt[6];
+            state_transit(cs, xt, um, dt);
+            if (query_clear_time(m, agent, xt[0], xt[1], xt[2], s_cur_time + dt) != 0) {
+              flags |= 4;
+              break;
+            }
+          }
+          if (!(flags & 4)) {
+            double       ttg;
+            const double usq = (um[0] * um[0] + um[1] * um[1]) + um[2] * um[2];
+            c.g              = (usq + ap.w_time) * tau + s_cur_g;
+            c.f = c.g + ap.lambda_heu * estimate_heuristic(ap, ps, end_state, ttg);
+          }
+        }
+        for (int q = 0; q < 6; ++q) c.state[q] = ps[q];
+        c.flags = flags;
+      }
+      __syncthreads();
+      // ---------------- master: ordered merge (:255-414) ----------------
+      if (lane == 0) {
+        int        n_tmp = 0;
+        const bool was_first = s_first != 0;
+        s_first    = 0;  // init_search = false after the first expansion (:243)
+        for (int i = 0; i < n_act && !done; ++i) {
+          const Cand &c = s_cand[i];
+          int pro_node  = hash_find(w, c.id[0], c.id[1], c.id[2], c.t_id);
+          if (pro_node >= 0 && w.pool[pro_node].node_state == IN_CLOSE_SET) continue;
+          if (!(c.flags & 1)) continue;
+          if (!(c.flags & 2)) continue;
+          if (c.flags & 4) continue;
+          const double tau = ap.time_resolution;
+          double       um[3];
+          if (was_first) {
+            um[0] = start_a[0];
+            um[1] = start_a[1];
+            um[2] = start_a[2];
+          } else {
+            um[0] = s_inputs[i][0];
+            um[1] = s_inputs[i][1];
+            um[2] = s_inputs[i][2];
+          }
+          bool prune = false;
+          for (int j = 0; j < n_tmp; ++j) {
+            Node &en = w.pool[s_tmp[j]];
+            if (c.id[0] == en.index[0] && c.id[1] == en.index[1] && c.id[2] == en.index[2] &&
+                c.t_id == en.time_idx) {
+              prune = true;
+              if (c.f < en.f) {
+                en.f = c.f;
+                en.g = c.g;
+                for (int q = 0; q < 6; ++q) en.state[q] = c.state[q];
+                for (int q = 0; q < 3; ++q) en.input[q] = um[q];
+                en.duration = tau;
+                en.time     = s_cur_time + tau;
+              }
+              break;
+            }
+          }
+          if (prune) continue;
+          if (pro_node < 0) {
+            pro_node = use_node_num;
+            Node &pn = w.pool[pro_node];
+            for (int q = 0; q < 3; ++q) pn.index[q] = c.id[q];
+            for (int q = 0; q < 6; ++q) pn.state[q] = c.state[q];
+            pn.f = c.f;
+            pn.g = c.g;
+            for (int q = 0; q < 3; ++q) pn.input[q] = um[q];
+            pn.duration   = tau;
+            pn.parent     = cur;
+            pn.node_state = IN_OPEN_SET;
+            pn.time       = s_cur_time + tau;
+            pn.time_idx   = (int)floor((pn.time - time_origin) * inv_tres);
+            heap_push(w.pool, w.heap, heap_n, pro_node);
+            hash_insert(w, c.id[0], c.id[1], c.id[2], (int)pn.time, pro_node);  // :387 quirk
+            s_tmp[n_tmp++] = pro_node;
+            use_node_num += 1;
+            if (use_node_num == ap.allocate_num) {  // "run out of memory" (:393-396)
+              ret  = NO_PATH;
+              done = true;
+            }
+          } else if (w.pool[pro_node].node_state == IN_OPEN_SET) {
+            Node &pn = w.pool[pro_node];
+            if (c.g < pn.g) {
+              for (int q = 0; q < 6; ++q) pn.state[q] = c.state[q];
+              pn.f = c.f;
+              pn.g = c.g;
+              for (int q = 0; q < 3; ++q) pn.input[q] = um[q];
+              pn.duration = tau;
+              pn.parent   = cur;
+              pn.time     = s_cur_time + tau;
+            }
+          } else {
+            ret  = SEARCH_ERR;
+            done = true;
+          }
+        }
+        s_n_active = done ? -1 : 1;
+      }
+      __syncthreads();
+      if (s_n_active < 0) done = true;
+      __syncthreads();
+    }
+    // broadcast the verdict of this attempt
+    if (lane == 0) s_tmp[0] = ret;
+    __syncthreads();
+    const int r = s_tmp[0];
+    __syncthreads();
+    if (r != NO_PATH) break;
+  }
+
+  // ---------------- master: getPathWithVel(corridor_tau) (:663-694) ----------------
+  if (lane == 0) {
+    int n = 0;
+    if (ret != NO_PATH && ret != SEARCH_ERR && terminal >= 0) {
+      double *route = out_route + (size_t)agent * route_cap * 6;
+      // walk back from the terminal node; points are produced last-to-first, then reversed
+      int    node     = terminal;
+      double t_node   = 0, t_sample = corridor_tau;
+      for (int q = 0; q < 6; ++q) route[q] = w.pool[node].state[q];
+      n = 1;
+      while (w.pool[node].parent >= 0) {
+        const Node  &nd       = w.pool[node];
+        const double duration = nd.duration;
+        const Node  &par      = w.pool[nd.parent];
+        t_node                = duration;
+        while (true) {
+          if (t_sample > t_node) {
+            node = nd.parent;
+            t_sample -= t_node;
+            break;
+          }
+          t_node -= t_sample;
+          double xt[6];
+          state_transit(par.state, xt, nd.input, t_node);
+          if (n < route_cap)
+            for (int q = 0; q < 6; ++q) route[n * 6 + q] = xt[q];
+          ++n;
+          t_sample = corridor_tau;
+        }
+      }
+      const int kept = n < route_cap ? n : route_cap;
+      for (int i = 0; i < kept / 2; ++i)
+        for (int q = 0; q < 6; ++q) {
+          const double tmp            = route[i * 6 + q];
+          route[i * 6 + q]            = route[(kept - 1 - i) * 6 + q];
+          route[(kept - 1 - i) * 6 + q] = tmp;
+        }
+    }
+    // number of nodes on the retrieved path (retrievePath :826-836)
+    int n_path = 0;
+    if (terminal >= 0) {
+      int c = terminal;
+      n_path = 1;
+      while (w.pool[c].parent >= 0) {
+        c = w.pool[c].parent;
+        ++n_path;
+      }
+    }
+    out_ret[agent]           = ret;
+    out_route_len[agent]     = n;
+    out_stats[agent * 4 + 0] = use_node_num;
+    out_stats[agent * 4 + 1] = iter_num;
+    out_stats[agent * 4 + 2] = n_path;
+    out_stats[agent * 4 + 3] = searches;
+    if (out_trace && n_trace < trace_cap) out_trace[(size_t)agent * trace_cap + n_trace] = -1;
+  }
+}
+
+size_t astar_node_bytes() { return sizeof(Node); }
+
+int launch_astar(const MapView &m, const SogmAstarParams &ap, double corridor_tau,
+                 const AstarWorkspace &wsp, int n_agents, const double *start_pva,
+                 const double *goal, const double *t_start, int32_t *out_ret, double *out_route,
+                 int32_t *out_route_len, int route_cap, int32_t *out_stats, int32_t *out_trace,
+                 int trace_cap, hipStream_t st) {
+  hipLaunchKernelGGL(k_astar, dim3(n_agents), dim3(64), 0, st, m, ap, corridor_tau, wsp,
+                     start_pva, goal, t_start, out_ret, out_route, out_route_len, route_cap,
+                     out_stats, out_trace, trace_cap);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+}  // namespace sogm

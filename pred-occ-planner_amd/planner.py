@@ -1,0 +1,105 @@
+"""Host-side mirror of the planner classes for a batch of agents (over the C ABI).
+
+`SogmPlanner` plays the role of FakeBaselinePlanner / BaselinePlanner
+(plan_manager/src/baseline_fake.cpp, baseline.cpp): `search` = FakeRiskHybridAstar::search +
+getPathWithVel, `generateCorridors` = the FIRI corridor stage, `optimize` = BezierOpt::setup +
+optimize, `replan` = the whole BaselinePlanner::replan.  PyTorch only provides device buffers and
+the stream; all compute is in libsogm_hip.so.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _abi
+from ._abi import SOGM_MAX_PIECES, check, lib
+from .sogm import _dev, _stream
+
+
+class SogmPlanner:
+    def __init__(self, sogm_map, astar_params, planner_params, qp_settings):
+        self.map = sogm_map
+        self.ap, self.pp, self.qs = astar_params, planner_params, qp_settings
+        self.A = sogm_map.n_agents
+        self._p = C.c_void_p()
+        check(lib().sogm_planner_create(sogm_map.ctx, C.byref(astar_params), C.byref(planner_params),
+                                        C.byref(qp_settings), C.byref(self._p)), "sogm_planner_create")
+
+    def close(self):
+        if self._p:
+            torch.cuda.synchronize()
+            lib().sogm_planner_destroy(self._p)
+            self._p = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- FakeRiskHybridAstar::search + getPathWithVel ----
+    def search(self, start_pva, goal, t_start, route_cap=64, trace_cap=0):
+        A, dev = self.A, start_pva.device
+        out = {
+            "ret": torch.zeros((A,), dtype=torch.int32, device=dev),
+            "route": torch.zeros((A, route_cap, 6), dtype=torch.float64, device=dev),
+            "route_len": torch.zeros((A,), dtype=torch.int32, device=dev),
+            "stats": torch.zeros((A, 4), dtype=torch.int32, device=dev),
+            "trace": torch.full((A, max(trace_cap, 1)), -1, dtype=torch.int32, device=dev),
+        }
+        check(lib().sogm_astar_search(self._p, start_pva.data_ptr(), goal.data_ptr(), t_start.data_ptr(),
+                                      out["ret"].data_ptr(), out["route"].data_ptr(),
+                                      out["route_len"].data_ptr(), route_cap, out["stats"].data_ptr(),
+                                      out["trace"].data_ptr() if trace_cap else None, trace_cap, _stream()),
+              "sogm_astar_search")
+        return out
+
+    # ---- corridor stage ----
+    def generateCorridors(self, start_pva, t_start, route, route_len):
+        A, dev = self.A, start_pva.device
+        mf = self.pp.max_faces
+        out = {
+            "polys": torch.zeros((A, SOGM_MAX_PIECES, mf, 4), dtype=torch.float64, device=dev),
+            "nfaces": torch.zeros((A, SOGM_MAX_PIECES), dtype=torch.int32, device=dev),
+            "npoly": torch.zeros((A,), dtype=torch.int32, device=dev),
+            "goal": torch.zeros((A, 6), dtype=torch.float64, device=dev),
+        }
+        check(lib().sogm_corridor_generate(self._p, start_pva.data_ptr(), t_start.data_ptr(),
+                                           route.data_ptr(), route_len.data_ptr(), int(route.shape[1]),
+                                           out["polys"].data_ptr(), out["nfaces"].data_ptr(),
+                                           out["npoly"].data_ptr(), out["goal"].data_ptr(), _stream()),
+              "sogm_corridor_generate")
+        return out
+
+    # ---- BezierOpt::setup + optimize ----
+    def optimize(self, start_pva, goal_pv, polys, nfaces, npoly):
+        A, dev = self.A, start_pva.device
+        out = {
+            "cpts": torch.zeros((A, SOGM_MAX_PIECES * 15), dtype=torch.float64, device=dev),
+            "status": torch.zeros((A,), dtype=torch.int32, device=dev),
+            "iters": torch.zeros((A,), dtype=torch.int32, device=dev),
+        }
+        check(lib().sogm_bezier_qp_solve(self._p, start_pva.data_ptr(), goal_pv.data_ptr(),
+                                         polys.data_ptr(), nfaces.data_ptr(), npoly.data_ptr(),
+                                         out["cpts"].data_ptr(), out["status"].data_ptr(),
+                                         out["iters"].data_ptr(), _stream()), "sogm_bezier_qp_solve")
+        return out
+
+    # ---- BaselinePlanner::replan ----
+    def replan(self, start_pva, goal, t_start, drone_ids, out_records=None, out_ok=None):
+        A, dev = self.A, start_pva.device
+        if out_records is None:
+            out_records = torch.zeros((A, _abi.TRAJ_RECORD_BYTES), dtype=torch.uint8, device=dev)
+        if out_ok is None:
+            out_ok = torch.zeros((A,), dtype=torch.int32, device=dev)
+        check(lib().sogm_replan(self._p, start_pva.data_ptr(), goal.data_ptr(), t_start.data_ptr(),
+                                drone_ids.data_ptr(), out_records.data_ptr(), out_ok.data_ptr(), _stream()),
+              "sogm_replan")
+        return out_records, out_ok
+
+
+def records_from_bytes(buf):
+    """uint8 numpy [A, 2064] -> ctypes array of SogmTrajRecord."""
+    n = buf.shape[0]
+    arr = (_abi.SogmTrajRecord * n).from_buffer_copy(np.ascontiguousarray(buf).tobytes())
+    return arr
