@@ -127,7 +127,9 @@ typedef struct SogmPlannerParams {
 } SogmPlannerParams;
 
 /* QP solver settings = OSQP v0.6 defaults as used through IOSQP (traj_opt/include/iosqp.hpp:40-115,
- * traj_opt/src/bezier_optimizer.cpp:269); adaptive rho is disabled (fixed KKT factor). */
+ * traj_opt/src/bezier_optimizer.cpp:269).  adaptive_rho_interval: 0 = fixed rho (one KKT factor
+ * for the whole solve); k > 0 = OSQP's adaptive rho evaluated every k iterations (OSQP's
+ * wall-clock-derived interval lands on its check_termination multiple, 25, for problems this size). */
 typedef struct SogmQpSettings {
   double  rho;
   double  sigma;
@@ -137,7 +139,7 @@ typedef struct SogmQpSettings {
   int32_t max_iter;
   int32_t check_termination;
   int32_t scaling_iters;
-  int32_t _pad;
+  int32_t adaptive_rho_interval;
 } SogmQpSettings;
 
 typedef struct sogm_ctx sogm_ctx;

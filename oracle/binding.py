@@ -149,3 +149,112 @@ def astar_search(spec, ap, grid, pose, start_pva, goal, t_after_map, corridor_ta
                                  C.byref(ntr))
     return {"ret": ret, "route": route[:n.value].copy(), "stats": list(stats),
             "trace": trace[:min(ntr.value, trace_cap)].copy(), "trace_len": ntr.value}
+
+
+# ---------------------------------------------------------------- LP
+def linprog(c, A, b):
+    c = np.ascontiguousarray(c, np.float64)
+    A = np.ascontiguousarray(A, np.float64)
+    b = np.ascontiguousarray(b, np.float64)
+    d = len(c)
+    x = np.zeros(d)
+    v = lib().orc_linprog(d, dptr(c), dptr(A), dptr(b), A.shape[0], dptr(x))
+    return float(v), x
+
+
+# ---------------------------------------------------------------- FIRI / corridors
+def firi(bd, pc, a, b, iterations=2, max_faces=64):
+    bd = np.ascontiguousarray(bd, np.float64)
+    pc = np.ascontiguousarray(pc, np.float64).reshape(-1, 3)
+    a = np.ascontiguousarray(a, np.float64)
+    b = np.ascontiguousarray(b, np.float64)
+    hp = np.zeros((max_faces, 4))
+    r = np.ones(3)
+    n = lib().orc_firi(dptr(bd), bd.shape[0], dptr(pc), pc.shape[0], dptr(a), dptr(b), iterations,
+                       dptr(hp), max_faces, dptr(r))
+    return (hp[:max(n, 0)].copy() if n <= max_faces else hp.copy()), n, r
+
+
+def mvie(hpoly, R, p, r):
+    h = np.ascontiguousarray(hpoly, np.float64)
+    R = np.ascontiguousarray(R, np.float64).copy()
+    p = np.ascontiguousarray(p, np.float64).copy()
+    r = np.ascontiguousarray(r, np.float64).copy()
+    ok = lib().orc_mvie(dptr(h), h.shape[0], dptr(R), dptr(p), dptr(r))
+    return ok, R, p, r
+
+
+def corridor_generate(spec, pp, grid, pose, stamp, start_pva, t_start, route):
+    pose = np.ascontiguousarray(pose, np.float32)
+    s = np.ascontiguousarray(start_pva, np.float64).reshape(9)
+    route = np.ascontiguousarray(route, np.float64)
+    MP = _abi.SOGM_MAX_PIECES
+    polys = np.zeros((MP, pp.max_faces, 4))
+    nf = np.zeros(MP, np.int32)
+    goal = np.zeros(6)
+    n = lib().orc_corridor_generate(C.byref(spec), C.byref(pp), fptr(grid), fptr(pose), C.c_double(stamp),
+                                    dptr(s), C.c_double(t_start), dptr(route), route.shape[0], dptr(polys),
+                                    nf.ctypes.data_as(C.POINTER(C.c_int32)), dptr(goal))
+    return {"npoly": n, "polys": polys, "nfaces": nf, "goal": goal}
+
+
+# ---------------------------------------------------------------- QP
+def qp_assemble(start, goal, t_alloc, polys, nfaces, max_faces, vmax, amax, m_cap=8192):
+    s = np.ascontiguousarray(start, np.float64).reshape(9)
+    g = np.ascontiguousarray(goal, np.float64).reshape(9)
+    t = np.ascontiguousarray(t_alloc, np.float64)
+    M = len(t)
+    n = 15 * M
+    polys = np.ascontiguousarray(polys, np.float64)
+    nf = np.ascontiguousarray(nfaces, np.int32)
+    Q = np.zeros((n, n))
+    A = np.zeros((m_cap, n))
+    l = np.zeros(m_cap)
+    u = np.zeros(m_cap)
+    m = lib().orc_qp_assemble(dptr(s), dptr(g), dptr(t), M, dptr(polys), nf.ctypes.data_as(C.POINTER(C.c_int32)),
+                              max_faces, C.c_double(vmax), C.c_double(amax), dptr(Q), dptr(A), dptr(l), dptr(u),
+                              m_cap)
+    A = A.reshape(-1)[:m * n].reshape(m, n).copy()
+    return Q, A, l[:m].copy(), u[:m].copy()
+
+
+def qp_solve(start, goal, t_alloc, polys, nfaces, max_faces, vmax, amax, qs):
+    s = np.ascontiguousarray(start, np.float64).reshape(9)
+    g = np.ascontiguousarray(goal, np.float64).reshape(9)
+    t = np.ascontiguousarray(t_alloc, np.float64)
+    M = len(t)
+    polys = np.ascontiguousarray(polys, np.float64)
+    nf = np.ascontiguousarray(nfaces, np.int32)
+    x = np.zeros(15 * M)
+    it = C.c_int(0)
+    st = lib().orc_qp_solve(dptr(s), dptr(g), dptr(t), M, dptr(polys), nf.ctypes.data_as(C.POINTER(C.c_int32)),
+                            max_faces, C.c_double(vmax), C.c_double(amax), C.byref(qs), dptr(x), C.byref(it))
+    return st, x, it.value
+
+
+def osqp_dense(P, q, A, l, u, qs):
+    P = np.ascontiguousarray(P, np.float64)
+    A = np.ascontiguousarray(A, np.float64)
+    q = np.ascontiguousarray(q, np.float64)
+    l = np.ascontiguousarray(l, np.float64)
+    u = np.ascontiguousarray(u, np.float64)
+    n, m = P.shape[0], A.shape[0]
+    x = np.zeros(n)
+    y = np.zeros(m)
+    it = C.c_int(0)
+    st = lib().orc_osqp_dense(dptr(P), dptr(q), dptr(A), dptr(l), dptr(u), n, m, C.byref(qs), dptr(x), dptr(y),
+                              C.byref(it))
+    return st, x, y, it.value
+
+
+# ---------------------------------------------------------------- full replan
+def replan(spec, ap, pp, qs, grid, pose, stamp, start_pva, goal, t_start, drone_id=0):
+    pose = np.ascontiguousarray(pose, np.float32)
+    s = np.ascontiguousarray(start_pva, np.float64).reshape(9)
+    g = np.ascontiguousarray(goal, np.float64)
+    rec = _abi.SogmTrajRecord()
+    stage = (C.c_int * 1)()
+    ok = lib().orc_replan(C.byref(spec), C.byref(ap), C.byref(pp), C.byref(qs), fptr(grid), fptr(pose),
+                          C.c_double(stamp), dptr(s), dptr(g), C.c_double(t_start), int(drone_id),
+                          C.byref(rec), stage)
+    return ok, rec, stage[0]

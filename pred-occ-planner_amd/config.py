@@ -66,7 +66,7 @@ def make_planner_params(fake=True):
 
 
 def make_qp_settings():
-    """OSQP v0.6 defaults with eps 1e-3 (bezier_optimizer.cpp:269); adaptive rho off."""
+    """OSQP v0.6 defaults with eps 1e-3 (bezier_optimizer.cpp:269); adaptive rho every 25 iterations."""
     q = SogmQpSettings()
     q.rho = 0.1
     q.sigma = 1e-6
@@ -76,6 +76,7 @@ def make_qp_settings():
     q.max_iter = 4000
     q.check_termination = 25
     q.scaling_iters = 10
+    q.adaptive_rho_interval = 25
     return q
 
 
