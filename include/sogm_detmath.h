@@ -152,5 +152,46 @@ SOGM_HD double acos(double x) {
   return x >= 0 ? s : (PI - s);
 }
 
+/* natural log for finite x > 0: x = m 2^e, m in [sqrt(1/2), sqrt(2)); log m = 2 atanh((m-1)/(m+1)) */
+SOGM_HD double log(double x) {
+  if (!(x > 0.0)) return x == 0.0 ? -1.0 / 0.0 : (x - x) / (x - x);
+  uint64_t u = bits_of(x);
+  int      e = (int)(u >> 52) & 0x7ff;
+  if (e == 0x7ff) return x;
+  int adj = 0;
+  if (e == 0) {
+    x   = x * 18014398509481984.0; /* 2^54 */
+    u   = bits_of(x);
+    e   = (int)(u >> 52) & 0x7ff;
+    adj = -54;
+  }
+  int    ex = e - 1023 + adj;
+  double m  = from_bits((u & 0x000fffffffffffffULL) | ((uint64_t)1023 << 52)); /* [1,2) */
+  if (m > 1.41421356237309514547) {
+    m  = m * 0.5;
+    ex = ex + 1;
+  }
+  const double s = (m - 1.0) / (m + 1.0);
+  const double z = s * s;
+  double       p = 1.0 / 27.0;
+  p              = p * z + 1.0 / 25.0;
+  p              = p * z + 1.0 / 23.0;
+  p              = p * z + 1.0 / 21.0;
+  p              = p * z + 1.0 / 19.0;
+  p              = p * z + 1.0 / 17.0;
+  p              = p * z + 1.0 / 15.0;
+  p              = p * z + 1.0 / 13.0;
+  p              = p * z + 1.0 / 11.0;
+  p              = p * z + 1.0 / 9.0;
+  p              = p * z + 1.0 / 7.0;
+  p              = p * z + 1.0 / 5.0;
+  p              = p * z + 1.0 / 3.0;
+  const double lm    = 2.0 * (s + s * (z * p));
+  const double LN2_H = 6.93147180369123816490e-01;
+  const double LN2_L = 1.90821492927058770002e-10;
+  const double ef    = (double)ex;
+  return ef * LN2_H + (lm + ef * LN2_L);
+}
+
 }  // namespace sogm_det
 #endif

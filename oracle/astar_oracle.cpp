@@ -27,9 +27,11 @@
 #include "../include/sogm_detmath.h"
 #include "oracle.h"
 
+int orc_g_use_libm = 0;  // shared with corridor_oracle.cpp
+
 namespace {
 
-int g_use_libm = 0;
+#define g_use_libm orc_g_use_libm
 
 double f_cbrt(double x) { return g_use_libm ? std::cbrt(x) : sogm_det::cbrt(x); }
 double f_acos(double x) { return g_use_libm ? std::acos(x) : sogm_det::acos(x); }
@@ -421,7 +423,7 @@ struct Search {
 
 extern "C" {
 
-void orc_astar_use_libm(int on) { g_use_libm = on; }
+void orc_astar_use_libm(int on) { orc_g_use_libm = on; }
 
 int orc_astar_search(const SogmSpec *s, const SogmAstarParams *ap, const float *grid,
                      const float pose[3], const double start_pva[9], const double goal[3],

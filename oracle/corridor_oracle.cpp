@@ -16,7 +16,10 @@
 #include <cstring>
 #include <vector>
 
+#include "../include/sogm_detmath.h"
 #include "oracle.h"
+
+extern int orc_g_use_libm;
 
 double orc_linprog3(const double *c, const double *A, const double *b, int m, double *x);
 double orc_linprog4(const double *c, const double *A, const double *b, int m, double *x);
@@ -99,7 +102,11 @@ double costMVIE(const MvieData &D, const double x[9], double g[9]) {
     gdrtd[j] *= D.penaltyWt;
     gdcde[j] *= D.penaltyWt;
   }
-  cost -= std::log(L[0][0]) + std::log(L[1][1]) + std::log(L[2][2]);
+  // log via include/sogm_detmath.h (<= 2 ulp from libm) so the HIP side can match bit for bit
+  if (orc_g_use_libm)
+    cost -= std::log(L[0][0]) + std::log(L[1][1]) + std::log(L[2][2]);
+  else
+    cost -= sogm_det::log(L[0][0]) + sogm_det::log(L[1][1]) + sogm_det::log(L[2][2]);
   gdrtd[0] -= 1.0 / L[0][0];
   gdrtd[1] -= 1.0 / L[1][1];
   gdrtd[2] -= 1.0 / L[2][2];
@@ -513,6 +520,7 @@ int firi(const double *bd, int M, const double *pc, int N, const double a[3], co
         }
       ++nH;
     }
+    if (nH > 128) return -2;  // capacity of the HIP side's plane buffer (FIRI_MAX_H); treated as failure
     poly.assign((size_t)nH * 4, 0.0);
     for (int i = 0; i < nH; ++i) {
       const double *fh = &forwardH[(size_t)i * 4];
@@ -622,12 +630,14 @@ int orc_corridor_generate(const SogmSpec *s, const SogmPlannerParams *pp, const 
     const double t1 = t_start + i * pp->corridor_tau;
     const double t2 = t_start + (i + 1) * pp->corridor_tau;
     int n = orc_obstacle_points(s, grid, pose, stamp, t1, t2, llc, lhc, pc.data(), pp->pc_capacity);
-    if (n > pp->pc_capacity) n = pp->pc_capacity;
+    // capacity limits (not in the reference, which grows its vectors): a corridor whose point list
+    // or face list would be truncated is unsafe, so it is treated as invalid (loop breaks)
+    if (n > pp->pc_capacity) break;
     std::vector<double> hp((size_t)MF * 4, 0.0);
     double              r[3] = {1, 1, 1};
     int nf = firi(bd, 6, pc.data(), n, w0, w1, pp->firi_iterations, hp.data(), MF, r);
+    if (nf == -2 || nf > MF) break;  // capacity exceeded -> invalid
     if (nf < 0) nf = 0;  // seed outside bd: hPoly stays empty (firi's return value is ignored)
-    if (nf > MF) nf = MF;
     // ShrinkCorridor(hPoly, path)
     const double path[3] = {w1[0] - w0[0], w1[1] - w0[1], w1[2] - w0[2]};
     for (int f = 0; f < nf; ++f) {
