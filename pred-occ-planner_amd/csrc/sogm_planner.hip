@@ -9,6 +9,66 @@
 
 using namespace sogm;
 
+// Per-piece min-jerk cost  QM = p2j^T [[I/3, I/6],[I/6, I/3]] p2j  with p2j = a2j v2a p2v
+// (traj_opt/src/bezier_optimizer.cpp:64-111; N = 4, DIM = 3).  Host-side, once per planner.
+static void min_jerk_block(double *QM /*15x15*/) {
+  // derivative-of-control-points operators act per dimension: rows (i,d), cols (j,d)
+  auto diff = [](int rows, double scale, double *out, int cols) {
+    for (int i = 0; i < rows * cols; ++i) out[i] = 0.0;
+    for (int i = 0; i < rows / 3; ++i)
+      for (int d = 0; d < 3; ++d) {
+        out[(i * 3 + d) * cols + i * 3 + d]       = -scale;
+        out[(i * 3 + d) * cols + (i + 1) * 3 + d] = scale;
+      }
+  };
+  double p2v[12 * 15], v2a[9 * 12], a2j[6 * 9], p2a[9 * 15], p2j[6 * 15], W[6 * 6], T[6 * 15];
+  diff(12, 4, p2v, 15);
+  diff(9, 3, v2a, 12);
+  diff(6, 2, a2j, 9);
+  auto mul = [](const double *A, const double *B, double *C, int r, int k, int c) {
+    for (int i = 0; i < r; ++i)
+      for (int j = 0; j < c; ++j) {
+        double s = 0;
+        for (int q = 0; q < k; ++q) s += A[i * k + q] * B[q * c + j];
+        C[i * c + j] = s;
+      }
+  };
+  mul(v2a, p2v, p2a, 9, 12, 15);
+  mul(a2j, p2a, p2j, 6, 9, 15);
+  for (int i = 0; i < 36; ++i) W[i] = 0.0;
+  for (int d = 0; d < 3; ++d) {
+    W[d * 6 + d]           = 1.0 / 3;
+    W[d * 6 + 3 + d]       = 1.0 / 6;
+    W[(3 + d) * 6 + d]     = 1.0 / 6;
+    W[(3 + d) * 6 + 3 + d] = 1.0 / 3;
+  }
+  mul(W, p2j, T, 6, 6, 15);
+  for (int i = 0; i < 15; ++i)
+    for (int j = 0; j < 15; ++j) {
+      double s = 0;
+      for (int q = 0; q < 6; ++q) s += p2j[q * 15 + i] * T[q * 15 + j];
+      QM[i * 15 + j] = s;
+    }
+}
+
+// BezierTraj record of a successful replan (plan_manager/src/plan_manager.cpp:364-399 publishes
+// duration[] and cpts[]); n_pieces = 0 marks "replan() returned false".
+__global__ void k_pack_records(int A, double corridor_tau, const int32_t *ret, const int32_t *npoly,
+                               const int32_t *status, const double *cpts, const double *t_start,
+                               const int32_t *drone_ids, SogmTrajRecord *out, int32_t *ok) {
+  const int a = blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= A) return;
+  SogmTrajRecord &r = out[a];
+  const bool good   = ret[a] != 0 && npoly[a] > 0 && (status[a] == 1 || status[a] == 2);
+  r.drone_id        = drone_ids[a];
+  r.time_start      = t_start[a];
+  r.n_pieces        = good ? npoly[a] : 0;
+  for (int i = 0; i < SOGM_MAX_PIECES; ++i) r.duration[i] = (good && i < npoly[a]) ? corridor_tau : 0.0;
+  for (int i = 0; i < SOGM_MAX_PIECES * 15; ++i)
+    r.cpts[i] = (good && i < npoly[a] * 15) ? cpts[(size_t)a * SOGM_MAX_PIECES * 15 + i] : 0.0;
+  ok[a] = good ? 1 : 0;
+}
+
 extern "C" {
 
 int sogm_planner_create(sogm_ctx *map, const SogmAstarParams *astar, const SogmPlannerParams *pp,
@@ -55,6 +115,22 @@ int sogm_planner_create(sogm_ctx *map, const SogmAstarParams *astar, const SogmP
     if (e == hipSuccess) e = hipMalloc((void **)&p->cw.seg_nfaces, sizeof(int32_t) * slots);
     if (e == hipSuccess) e = hipMalloc((void **)&p->cw.seg_state, sizeof(int32_t) * slots);
     if (e == hipSuccess) e = hipMalloc((void **)&p->cw.seg_npts, sizeof(int32_t) * slots);
+    // QP scratch: rows = 9(M+1) + 21M + 5 * sum(faces) at M = SOGM_MAX_PIECES
+    const int mcap = 9 * (SOGM_MAX_PIECES + 1) + 21 * SOGM_MAX_PIECES + 5 * pp->max_faces * SOGM_MAX_PIECES;
+    p->qw.m_cap    = mcap;
+    if (e == hipSuccess) e = hipMalloc((void **)&p->qw.ell_col, sizeof(int) * (size_t)A * mcap * 6);
+    if (e == hipSuccess) e = hipMalloc((void **)&p->qw.ell_val, sizeof(double) * (size_t)A * mcap * 6);
+    if (e == hipSuccess) e = hipMalloc((void **)&p->qw.mvec, sizeof(double) * (size_t)A * mcap * 10);
+    if (e == hipSuccess) e = hipMalloc((void **)&p->qw.csc_ptr, sizeof(int) * (size_t)A * (15 * SOGM_MAX_PIECES + 1));
+    if (e == hipSuccess) e = hipMalloc((void **)&p->qw.csc_idx, sizeof(int) * (size_t)A * mcap * 6);
+    min_jerk_block(p->qc.QM);
+    if (e == hipSuccess) e = hipMalloc((void **)&p->d_polys, sizeof(double) * slots * pp->max_faces * 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&p->d_goal, sizeof(double) * 6 * A);
+    if (e == hipSuccess) e = hipMalloc((void **)&p->d_cpts, sizeof(double) * slots * 15);
+    if (e == hipSuccess) e = hipMalloc((void **)&p->d_nfaces, sizeof(int32_t) * slots);
+    if (e == hipSuccess) e = hipMalloc((void **)&p->d_npoly, sizeof(int32_t) * A);
+    if (e == hipSuccess) e = hipMalloc((void **)&p->d_status, sizeof(int32_t) * A);
+    if (e == hipSuccess) e = hipMalloc((void **)&p->d_iters, sizeof(int32_t) * A);
   }
   if (e != hipSuccess) {
     sogm::set_error("sogm_planner_create", e);
@@ -69,7 +145,9 @@ void sogm_planner_destroy(sogm_planner *p) {
   void *ptrs[] = {p->aw.pool, p->aw.heap, p->aw.hkeys, p->aw.hvals,
                   p->d_ret,   p->d_route_len, p->d_stats, p->d_route,
                   p->cw.pc,   p->cw.fpc,  p->cw.tang, p->cw.distr, p->cw.polys,
-                  p->cw.seg_nfaces, p->cw.seg_state, p->cw.seg_npts};
+                  p->cw.seg_nfaces, p->cw.seg_state, p->cw.seg_npts,
+                  p->qw.ell_col, p->qw.ell_val, p->qw.mvec, p->qw.csc_ptr, p->qw.csc_idx,
+                  p->d_polys, p->d_goal, p->d_cpts, p->d_nfaces, p->d_npoly, p->d_status, p->d_iters};
   for (void *q : ptrs)
     if (q) (void)hipFree(q);
   delete p;
@@ -115,12 +193,42 @@ int sogm_corridor_generate(sogm_planner *p, const double *start_pva, const doubl
   }
   return SOGM_OK;
 }
-int sogm_bezier_qp_solve(sogm_planner *, const double *, const double *, const double *,
-                         const int32_t *, const int32_t *, double *, int32_t *, int32_t *, void *) {
-  return SOGM_ERR_STATE;
+int sogm_bezier_qp_solve(sogm_planner *p, const double *start_pva, const double *goal_pv,
+                         const double *polys, const int32_t *nfaces, const int32_t *npoly,
+                         double *out_cpts, int32_t *out_status, int32_t *out_iters, void *stream) {
+  if (!p || !start_pva || !goal_pv || !polys || !nfaces || !npoly || !out_cpts || !out_status ||
+      !out_iters)
+    return SOGM_ERR_INVALID_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  prof_begin(p->map, SOGM_PROF_QP, st);
+  int rc = launch_qp(p->pp, p->qs, p->qw, p->qc, p->map->n_agents, start_pva, goal_pv, polys,
+                     nfaces, npoly, out_cpts, out_status, out_iters, st);
+  prof_end(p->map, SOGM_PROF_QP, st);
+  if (rc) {
+    sogm::set_error("k_qp", hipGetLastError());
+    return SOGM_ERR_HIP;
+  }
+  return SOGM_OK;
 }
-int sogm_replan(sogm_planner *, const double *, const double *, const double *, const int32_t *,
-                SogmTrajRecord *, int32_t *, void *) {
-  return SOGM_ERR_STATE;
+int sogm_replan(sogm_planner *p, const double *start_pva, const double *goal,
+                const double *t_start, const int32_t *drone_ids, SogmTrajRecord *out_records,
+                int32_t *out_ok, void *stream) {
+  if (!p || !start_pva || !goal || !t_start || !drone_ids || !out_records || !out_ok)
+    return SOGM_ERR_INVALID_ARG;
+  int rc = sogm_astar_search(p, start_pva, goal, t_start, p->d_ret, p->d_route, p->d_route_len,
+                             p->route_cap, p->d_stats, nullptr, 0, stream);
+  if (rc) return rc;
+  rc = sogm_corridor_generate(p, start_pva, t_start, p->d_route, p->d_route_len, p->route_cap,
+                              p->d_polys, p->d_nfaces, p->d_npoly, p->d_goal, stream);
+  if (rc) return rc;
+  rc = sogm_bezier_qp_solve(p, start_pva, p->d_goal, p->d_polys, p->d_nfaces, p->d_npoly,
+                            p->d_cpts, p->d_status, p->d_iters, stream);
+  if (rc) return rc;
+  const int A = p->map->n_agents;
+  hipLaunchKernelGGL(k_pack_records, dim3((A + 63) / 64), dim3(64), 0, (hipStream_t)stream, A,
+                     p->pp.corridor_tau, p->d_ret, p->d_npoly, p->d_status, p->d_cpts, t_start,
+                     drone_ids, out_records, out_ok);
+  SOGM_HIP_CHECK(hipGetLastError());
+  return SOGM_OK;
 }
 }

@@ -33,6 +33,23 @@ int launch_corridor(const MapView &m, const SogmPlannerParams &pp, const Corrido
                     double *out_polys, int32_t *out_nfaces, int32_t *out_npoly, double *out_goal,
                     hipStream_t st);
 
+// Per-agent QP scratch in HBM (m-sized vectors, ELL rows of A, row-sorted CSC index).
+struct QpWorkspace {
+  int    *ell_col;  // [A][m_cap][6]
+  double *ell_val;  // [A][m_cap][6]
+  double *mvec;     // [A][10][m_cap]  l,u,rho,E,z,zp,zt,y,w,dy
+  int    *csc_ptr;  // [A][15*SOGM_MAX_PIECES+1]
+  int    *csc_idx;  // [A][m_cap*6]
+  int     m_cap;
+};
+struct QpConst {
+  double QM[225];  // per-piece min-jerk cost block (bezier_optimizer.cpp:96-111)
+};
+int launch_qp(const SogmPlannerParams &pp, const SogmQpSettings &qs, const QpWorkspace &ws,
+              const QpConst &qc, int n_agents, const double *start_pva, const double *goal_pv,
+              const double *polys, const int32_t *nfaces, const int32_t *npoly, double *out_cpts,
+              int32_t *out_status, int32_t *out_iters, hipStream_t st);
+
 size_t astar_node_bytes();
 int    launch_astar(const MapView &m, const SogmAstarParams &ap, double corridor_tau,
                     const AstarWorkspace &wsp, int n_agents, const double *start_pva,
@@ -49,8 +66,12 @@ struct sogm_planner {
   SogmQpSettings       qs;
   sogm::AstarWorkspace aw;
   sogm::CorridorWorkspace cw;
+  sogm::QpWorkspace qw;
+  sogm::QpConst qc;
   // internal buffers used by sogm_replan (device)
   int32_t *d_ret, *d_route_len, *d_stats;
   double  *d_route;
   int      route_cap;
+  double  *d_polys, *d_goal, *d_cpts;
+  int32_t *d_nfaces, *d_npoly, *d_status, *d_iters;
 };
