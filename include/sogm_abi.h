@@ -225,6 +225,17 @@ int sogm_set_future_risk(sogm_ctx *ctx, const float *grid_vt, const float *poses
 /* Copy agent `a`'s grid to host in the reference layout risk_maps_[V][T] (map.h:52). Synchronous. */
 int sogm_download_reference_layout(sogm_ctx *ctx, int agent, float *out_vt_host);
 
+/*
+ * Bezier::getPos / getVel / getAcc (traj_utils/include/traj_utils/bernstein.hpp:174-187,
+ * traj_utils/src/bernstein.cpp:25-59) for a batch of shared trajectories:
+ * out_pva[i] = {pos, vel, acc} of records[i] at absolute time t[i] (clamped to the trajectory's
+ * span, as FiniteStateMachine does when it samples the replan start state,
+ * plan_manager/src/plan_manager.cpp:169-175).  out_valid[i] = 0 when the record holds no trajectory.
+ * dev records[n], dev t[n] fp64, dev out_pva[n*9] fp64, dev out_valid[n] int32.
+ */
+int sogm_traj_eval(const SogmTrajRecord *records, int n, const double *t, double *out_pva,
+                   int32_t *out_valid, void *stream);
+
 /* ------------------------------------------------------------------------------------------ */
 /* queries                                                                                     */
 /* ------------------------------------------------------------------------------------------ */

@@ -90,6 +90,7 @@ PROTOTYPES = {
     "sogm_project_neighbours": (_i, [_vp, _vp, _i, _vp, _vp]),
     "sogm_set_future_risk": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "sogm_download_reference_layout": (_i, [_vp, _i, _vp]),
+    "sogm_traj_eval": (_i, [_vp, _i, _vp, _vp, _vp, _vp]),
     "sogm_query_clear": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     "sogm_obstacle_points": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp]),
     "sogm_planner_create": (_i, [_vp, C.POINTER(SogmAstarParams), C.POINTER(SogmPlannerParams),

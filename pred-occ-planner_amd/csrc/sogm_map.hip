@@ -317,6 +317,57 @@ __global__ __launch_bounds__(256) void k_vt_to_slabs(const float *__restrict__ v
   for (int t = 0; t < T; ++t) slabs[(size_t)t * V + v] = vt[(size_t)v * T + t];
 }
 
+// Bezier pos / vel / acc of a trajectory record at an absolute time (bernstein.cpp:25-59)
+__global__ __launch_bounds__(64) void k_traj_eval(const SogmTrajRecord *__restrict__ rec, int n,
+                                                  const double *__restrict__ t,
+                                                  double *__restrict__ out, int32_t *__restrict__ ok) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const SogmTrajRecord &r = rec[i];
+  if (r.n_pieces <= 0) {
+    ok[i] = 0;
+    for (int k = 0; k < 9; ++k) out[i * 9 + k] = 0.0;
+    return;
+  }
+  double total = 0;
+  for (int k = 0; k < r.n_pieces; ++k) total += r.duration[k];
+  double tt = t[i] - r.time_start;
+  tt        = tt < 0 ? 0 : (tt > total ? total : tt);
+  // locatePiece (bernstein.hpp:164-172)
+  int    piece = r.n_pieces - 1;
+  double rem   = tt;
+  for (int k = 0; k < r.n_pieces; ++k) {
+    rem -= r.duration[k];
+    if (rem < 0) {
+      piece = k;
+      break;
+    }
+  }
+  double t0 = 0;
+  for (int k = 0; k < piece; ++k) t0 += r.duration[k];
+  const double tf = t0 + r.duration[piece], dur = tf - t0, s = (tt - t0) / dur;
+  const double A[5][5] = {{1, -4, 6, -4, 1}, {0, 4, -12, 12, -4}, {0, 0, 6, -12, 6},
+                          {0, 0, 0, 4, -4},  {0, 0, 0, 0, 1}};
+  const double S0[5] = {1, s, s * s, s * s * s, (s * s) * (s * s)};
+  const double S1[5] = {0, 1, 2 * s, 3 * (s * s), 4 * (s * s * s)};
+  const double S2[5] = {0, 0, 2, 6 * s, 12 * (s * s)};
+  const double *c    = r.cpts + piece * 15;
+  for (int d = 0; d < 3; ++d) {
+    double p = 0, v = 0, a = 0;
+    for (int j = 0; j < 5; ++j) {
+      double b = 0;
+      for (int q = 0; q < 5; ++q) b += c[q * 3 + d] * A[q][j];
+      p += b * S0[j];
+      v += b * S1[j];
+      a += b * S2[j];
+    }
+    out[i * 9 + d]     = p;
+    out[i * 9 + 3 + d] = v / dur;
+    out[i * 9 + 6 + d] = a / (dur * dur);
+  }
+  ok[i] = 1;
+}
+
 }  // namespace sogm
 
 using namespace sogm;
@@ -505,6 +556,16 @@ int sogm_download_reference_layout(sogm_ctx *c, int agent, float *out) {
                      c->d_grid + (size_t)agent * per, V, T, c->d_scratch_vt);
   SOGM_HIP_CHECK(hipGetLastError());
   SOGM_HIP_CHECK(hipMemcpy(out, c->d_scratch_vt, per * sizeof(float), hipMemcpyDeviceToHost));
+  return SOGM_OK;
+}
+
+int sogm_traj_eval(const SogmTrajRecord *records, int n, const double *t, double *out_pva,
+                   int32_t *out_valid, void *stream) {
+  if (!records || !t || !out_pva || !out_valid || n < 0) return SOGM_ERR_INVALID_ARG;
+  if (n == 0) return SOGM_OK;
+  hipLaunchKernelGGL(k_traj_eval, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, records, n,
+                     t, out_pva, out_valid);
+  SOGM_HIP_CHECK(hipGetLastError());
   return SOGM_OK;
 }
 

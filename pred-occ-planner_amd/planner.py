@@ -103,3 +103,14 @@ def records_from_bytes(buf):
     n = buf.shape[0]
     arr = (_abi.SogmTrajRecord * n).from_buffer_copy(np.ascontiguousarray(buf).tobytes())
     return arr
+
+
+def traj_eval(records, t):
+    """Bezier::getPos/getVel/getAcc for a batch of records (device uint8 [n, 2064]) at absolute times
+    t (device float64 [n]).  Returns (pva [n, 9], valid [n])."""
+    n = int(t.numel())
+    pva = torch.empty((n, 9), dtype=torch.float64, device=t.device)
+    ok = torch.empty((n,), dtype=torch.int32, device=t.device)
+    check(lib().sogm_traj_eval(records.data_ptr(), n, t.data_ptr(), pva.data_ptr(), ok.data_ptr(), _stream()),
+          "sogm_traj_eval")
+    return pva, ok
