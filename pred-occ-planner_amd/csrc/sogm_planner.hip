@@ -118,6 +118,7 @@ int sogm_planner_create(sogm_ctx *map, const SogmAstarParams *astar, const SogmP
     // QP scratch: rows = 9(M+1) + 21M + 5 * sum(faces) at M = SOGM_MAX_PIECES
     const int mcap = 9 * (SOGM_MAX_PIECES + 1) + 21 * SOGM_MAX_PIECES + 5 * pp->max_faces * SOGM_MAX_PIECES;
     p->qw.m_cap    = mcap;
+    p->qw.dyn_lds_bytes = 144 * 1024;  // 160 KiB/CU minus k_qp's ~14 KiB of static LDS
     if (e == hipSuccess) e = hipMalloc((void **)&p->qw.ell_col, sizeof(int) * (size_t)A * mcap * 6);
     if (e == hipSuccess) e = hipMalloc((void **)&p->qw.ell_val, sizeof(double) * (size_t)A * mcap * 6);
     if (e == hipSuccess) e = hipMalloc((void **)&p->qw.mvec, sizeof(double) * (size_t)A * mcap * 10);

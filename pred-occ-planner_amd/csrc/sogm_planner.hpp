@@ -41,6 +41,7 @@ struct QpWorkspace {
   int    *csc_ptr;  // [A][15*SOGM_MAX_PIECES+1]
   int    *csc_idx;  // [A][m_cap*6]
   int     m_cap;
+  int     dyn_lds_bytes;  // dynamic LDS per workgroup of k_qp
 };
 struct QpConst {
   double QM[225];  // per-piece min-jerk cost block (bezier_optimizer.cpp:96-111)

@@ -94,14 +94,17 @@ __global__ __launch_bounds__(256) void k_qp(SogmPlannerParams pp, SogmQpSettings
   const int MF = pp.max_faces;
   const int n  = 15 * M;
 
-  __shared__ double s_Kb[QP_NMAX * (QP_BW + 1)];  // 34.5 KB
-  __shared__ double s_P[SOGM_MAX_PIECES * 225];   // 28.8 KB
+  extern __shared__ __attribute__((aligned(16))) char qp_smem[];
+  double *s_Kb = (double *)qp_smem;            // [n][18]  K band / Cholesky factor
+  double *s_P  = s_Kb + (size_t)n * (QP_BW + 1);  // [M][225] scaled cost blocks
+  __shared__ double s_ginv[QP_NMAX];
   __shared__ double s_x[QP_NMAX], s_xp[QP_NMAX], s_xt[QP_NMAX], s_D[QP_NMAX], s_Dt[QP_NMAX];
   __shared__ double s_cn[QP_NMAX];  // column norms / scratch
   __shared__ double s_red[4];
   __shared__ double s_sc[8];
   __shared__ int    s_off[SOGM_MAX_PIECES + 1];
   __shared__ int    s_cnt[QP_NMAX + 1];
+  __shared__ int    s_cptr[QP_NMAX + 1];
   __shared__ int    s_flag;
 
   // ---- problem dimensions
@@ -114,7 +117,7 @@ __global__ __launch_bounds__(256) void k_qp(SogmPlannerParams pp, SogmQpSettings
     s_off[M] = acc;
   }
   __syncthreads();
-  const int R1 = 3 * (M + 1), R2 = 6 * (M + 1), R3 = 9 * (M + 1), R4 = R3 + 12 * M,
+  const int R1 = 3 * (M + 1), R3 = 9 * (M + 1), R4 = R3 + 12 * M,
             R5 = R4 + 9 * M;
   const int m = R5 + s_off[M];
   Prob      pb;
@@ -122,22 +125,42 @@ __global__ __launch_bounds__(256) void k_qp(SogmPlannerParams pp, SogmQpSettings
   pb.m = m;
   pb.M = M;
   {
-    const size_t mc = ws.m_cap;
-    pb.ecol   = ws.ell_col + (size_t)agent * mc * QP_ELL;
-    pb.eval   = ws.ell_val + (size_t)agent * mc * QP_ELL;
-    double *v = ws.mvec + (size_t)agent * mc * 10;
-    pb.l = v;
-    pb.u = v + mc;
-    pb.rho = v + 2 * mc;
-    pb.E = v + 3 * mc;
-    pb.z = v + 4 * mc;
-    pb.zp = v + 5 * mc;
-    pb.zt = v + 6 * mc;
-    pb.y = v + 7 * mc;
-    pb.w = v + 8 * mc;
-    pb.dy = v + 9 * mc;
-    pb.cptr = ws.csc_ptr + (size_t)agent * (QP_NMAX + 1);
-    pb.cidx = ws.csc_idx + (size_t)agent * mc * QP_ELL;
+    // Row data (8 m-vectors, ELL rows, CSC index) live in LDS when they fit next to K and P —
+    // the common case (m ~ 600) — and in per-agent HBM scratch otherwise (same code, flat pointers).
+    const size_t head  = ((size_t)n * (QP_BW + 1) + (size_t)M * 225) * sizeof(double);
+    const size_t perow = 8 * sizeof(double) + QP_ELL * (sizeof(double) + 2 * sizeof(int));
+    const size_t need  = head + (size_t)m * perow + 64;
+    const size_t mc    = ws.m_cap;
+    double      *v;
+    if (need <= (size_t)ws.dyn_lds_bytes) {
+      v         = (double *)(qp_smem + head);
+      pb.eval   = v + 8 * (size_t)m;
+      pb.ecol   = (int *)(pb.eval + (size_t)m * QP_ELL);
+      pb.cidx   = pb.ecol + (size_t)m * QP_ELL;
+      pb.l = v;
+      pb.u = v + m;
+      pb.rho = v + 2 * (size_t)m;
+      pb.E = v + 3 * (size_t)m;
+      pb.z = v + 4 * (size_t)m;
+      pb.y = v + 5 * (size_t)m;
+      pb.w = v + 6 * (size_t)m;
+      pb.dy = v + 7 * (size_t)m;
+    } else {
+      pb.ecol = ws.ell_col + (size_t)agent * mc * QP_ELL;
+      pb.eval = ws.ell_val + (size_t)agent * mc * QP_ELL;
+      v       = ws.mvec + (size_t)agent * mc * 10;
+      pb.l = v;
+      pb.u = v + mc;
+      pb.rho = v + 2 * mc;
+      pb.E = v + 3 * mc;
+      pb.z = v + 4 * mc;
+      pb.y = v + 5 * mc;
+      pb.w = v + 6 * mc;
+      pb.dy = v + 7 * mc;
+      pb.cidx = ws.csc_idx + (size_t)agent * mc * QP_ELL;
+    }
+    pb.zp = pb.zt = nullptr;
+    pb.cptr = s_cptr;
   }
   const double *sp   = start_pva + agent * 9;
   const double *gp   = goal_pv + agent * 6;
@@ -406,31 +429,31 @@ __global__ __launch_bounds__(256) void k_qp(SogmPlannerParams pp, SogmQpSettings
     if (tid == 0) s_flag = 1;
     __syncthreads();
     if (wave == 0) {
+      // right-looking banded Cholesky: column j is scaled, then the 17x17 trailing triangle is
+      // updated by all 64 lanes (153 pair updates, <= 3 per lane); no reductions on the chain
       for (int j = 0; j < n; ++j) {
-        // d = K[j][j] - sum_k G[j][k]^2
-        double part = 0.0;
-        {
-          const int k = j - 1 - lane;
-          if (lane < QP_BW && k >= 0) {
-            const double g = KB(s_Kb, j, k);
-            part           = g * g;
-          }
-        }
-        part     = wave_sum(part);
-        double d = KB(s_Kb, j, j) - part;
-        if (!(d > 0)) {
+        const double djj = KB(s_Kb, j, j);
+        if (!(djj > 0)) {
           if (lane == 0) s_flag = 0;
           break;
         }
-        d = sogm_det::sqrt_rn(d);
-        if (lane == 0) KB(s_Kb, j, j) = d;
-        // rows i = j+1 .. j+BW : one lane each
-        const int i = j + 1 + lane;
-        if (lane < QP_BW && i < n) {
-          double s = KB(s_Kb, i, j);
-          for (int k = (i - QP_BW > 0 ? i - QP_BW : 0); k < j; ++k)
-            s -= KB(s_Kb, i, k) * KB(s_Kb, j, k);
-          KB(s_Kb, i, j) = s / d;
+        const double d = sogm_det::sqrt_rn(djj), inv = 1.0 / d;
+        if (lane == 0) {
+          KB(s_Kb, j, j) = d;
+          s_ginv[j]      = inv;
+        }
+        if (lane >= 1 && lane <= QP_BW && j + lane < n) KB(s_Kb, j + lane, j) = KB(s_Kb, j + lane, j) * inv;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        for (int e = lane; e < (QP_BW * (QP_BW + 1)) / 2; e += 64) {
+          // e -> (a, b) with 1 <= b <= a <= 17 (row-major lower triangle)
+          int a = 1, rem = e;
+          while (rem >= a) {
+            rem -= a;
+            ++a;
+          }
+          const int b = rem + 1;
+          if (j + a < n) KB(s_Kb, j + a, j + b) -= KB(s_Kb, j + a, j) * KB(s_Kb, j + b, j);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         __builtin_amdgcn_wave_barrier();
@@ -442,21 +465,17 @@ __global__ __launch_bounds__(256) void k_qp(SogmPlannerParams pp, SogmQpSettings
   // solve K xt = xt in place (wave 0), banded forward / backward substitution
   auto solveK = [&]() {
     if (wave == 0) {
-      for (int i = 0; i < n; ++i) {
-        double part = 0.0;
-        const int k = i - 1 - lane;
-        if (lane < QP_BW && k >= 0) part = KB(s_Kb, i, k) * s_xt[k];
-        part = wave_sum(part);
-        if (lane == 0) s_xt[i] = (s_xt[i] - part) / KB(s_Kb, i, i);
+      for (int j = 0; j < n; ++j) {  // G y = b
+        const double xj = s_xt[j] * s_ginv[j];
+        if (lane == 0) s_xt[j] = xj;
+        if (lane >= 1 && lane <= QP_BW && j + lane < n) s_xt[j + lane] -= KB(s_Kb, j + lane, j) * xj;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         __builtin_amdgcn_wave_barrier();
       }
-      for (int i = n - 1; i >= 0; --i) {
-        double part = 0.0;
-        const int k = i + 1 + lane;
-        if (lane < QP_BW && k < n) part = KB(s_Kb, k, i) * s_xt[k];
-        part = wave_sum(part);
-        if (lane == 0) s_xt[i] = (s_xt[i] - part) / KB(s_Kb, i, i);
+      for (int j = n - 1; j >= 0; --j) {  // G^T x = y
+        const double xj = s_xt[j] * s_ginv[j];
+        if (lane == 0) s_xt[j] = xj;
+        if (lane >= 1 && lane <= QP_BW && j - lane >= 0) s_xt[j - lane] -= KB(s_Kb, j, j - lane) * xj;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         __builtin_amdgcn_wave_barrier();
       }
@@ -521,11 +540,7 @@ __global__ __launch_bounds__(256) void k_qp(SogmPlannerParams pp, SogmQpSettings
   if (chol_ok) {
     for (iter = 1; iter <= qs.max_iter; ++iter) {
       for (int j = tid; j < n; j += 256) s_xp[j] = s_x[j];
-      for (int r = tid; r < m; r += 256) {
-        const double zr = pb.z[r];
-        pb.zp[r]        = zr;
-        pb.w[r]         = pb.rho[r] * zr - pb.y[r];
-      }
+      for (int r = tid; r < m; r += 256) pb.w[r] = pb.rho[r] * pb.z[r] - pb.y[r];
       __syncthreads();
       for (int j = tid; j < n; j += 256) {
         double s = qs.sigma * s_xp[j];  // q == 0
@@ -545,7 +560,7 @@ __global__ __launch_bounds__(256) void k_qp(SogmPlannerParams pp, SogmQpSettings
           if (c >= 0) s += pb.eval[(size_t)r * QP_ELL + k] * s_xt[c];
         }
         const double rho = pb.rho[r], yr = pb.y[r];
-        const double zr  = alpha * s + (1.0 - alpha) * pb.zp[r];
+        const double zr  = alpha * s + (1.0 - alpha) * pb.z[r];
         double       v   = zr + yr / rho;
         const double lo = pb.l[r], hi = pb.u[r];
         v               = v < lo ? lo : (v > hi ? hi : v);
@@ -652,8 +667,14 @@ int launch_qp(const SogmPlannerParams &pp, const SogmQpSettings &qs, const QpWor
               const QpConst &qc, int n_agents, const double *start_pva, const double *goal_pv,
               const double *polys, const int32_t *nfaces, const int32_t *npoly, double *out_cpts,
               int32_t *out_status, int32_t *out_iters, hipStream_t st) {
-  hipLaunchKernelGGL(k_qp, dim3(n_agents), dim3(256), 0, st, pp, qs, ws, qc, start_pva, goal_pv,
-                     polys, nfaces, npoly, out_cpts, out_status, out_iters);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void *)k_qp, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              ws.dyn_lds_bytes);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k_qp, dim3(n_agents), dim3(256), ws.dyn_lds_bytes, st, pp, qs, ws, qc, start_pva,
+                     goal_pv, polys, nfaces, npoly, out_cpts, out_status, out_iters);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
