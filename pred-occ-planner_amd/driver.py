@@ -22,6 +22,28 @@ TICK_PERIOD = 0.1        # fsm/replan_duration (sim_fake.yaml:7)
 REPLAN_START_TIME = 0.02  # fsm/replan_start_time (sim_fake.yaml:8)
 
 
+def shard_bounds(rank, world, agents_per_rank):
+    """Contiguous block of agents owned by `rank` (agents are the sharding axis, SURVEY §8 e)."""
+    return rank * agents_per_rank, (rank + 1) * agents_per_rank
+
+
+def exchange_records(own, all_records, dist, world):
+    """The trajectory broadcast of the reference (/broadcast_traj, plan_manager.cpp:364-399 ->
+    particles.cpp:131-191) as ONE all-gather of fixed-size records.  `own` [A_loc, 2064] uint8,
+    `all_records` [A_loc * world, 2064] uint8.  Backend nccl == RCCL on ROCm; gloo on CPU tests."""
+    if world > 1:
+        dist.all_gather_into_tensor(all_records, own.contiguous())
+    else:
+        all_records.copy_(own)
+    return all_records
+
+
+def merge_latest(new, old, ok):
+    """latest-wins per drone (particles.cpp:179-190); a failed replan keeps the previous trajectory
+    (the FSM keeps executing it, plan_manager.cpp:176-196)."""
+    return torch.where(ok.bool().unsqueeze(1), new, old)
+
+
 class SwarmTick:
     def __init__(self, grid="cfg2", agents_per_rank=None, rank=0, world=1, device=0, seed=0x5069,
                  spec=None, scene=None, dist=None):
@@ -31,7 +53,7 @@ class SwarmTick:
         self.A_tot = self.A_loc * world
         half = (self.spec.L // 2) * 0.15
         self.scene = scene if scene is not None else scene_mod.make_scene(self.A_tot, half, seed=seed)
-        lo, hi = rank * self.A_loc, (rank + 1) * self.A_loc
+        lo, hi = shard_bounds(rank, world, self.A_loc)
         loc = dict(self.scene)
         loc["n_agents"] = self.A_loc
         for k in ("starts", "goals", "poses", "stamps", "ego_ids"):
@@ -70,10 +92,7 @@ class SwarmTick:
         self.map.addOtherAgents(self.all, self.A_tot, self.dev["ego_ids"])
         self.planner.replan(pva.contiguous(), self.goals, t_start, self.dev["ego_ids"], self.new, self.ok)
         # latest-wins; a failed replan keeps executing the previous trajectory
-        self.own = torch.where(self.ok.bool().unsqueeze(1), self.new, self.own)
-        if self.world > 1:
-            self.dist.all_gather_into_tensor(self.all, self.own)
-        else:
-            self.all.copy_(self.own)
+        self.own = merge_latest(self.new, self.own, self.ok)
+        exchange_records(self.own, self.all, self.dist, self.world)
         self.tick += 1
         return self.ok

@@ -1,0 +1,160 @@
+// sogm_facade.hpp — host C++ facade that keeps the reference's class surface and forwards to the
+// C ABI (include/sogm_abi.h).  Header-only, C++17, no Eigen / ROS: vectors are std::array<double,3>
+// (an Eigen::Vector3d's storage is layout-compatible: pass v.data()).
+//
+// One facade object is a VIEW of one agent inside a batched context, so that a plan_manager-style
+// caller written against
+//     map_->getClearOcccupancy(pos, t) / getObstaclePoints(...)      (risk_base.h:84-105)
+//     a_star_->search(...) / getPathWithVel(dt)                      (risk_hybrid_a_star.h:96-121)
+//     firi::firi(...)                                                (sfc_gen/firi.hpp:238)
+//     traj_optimizer_->setup(...) / optimize() / getOptBezier(...)   (bezier_optimizer.hpp:57-88)
+// links against this instead (plan_manager/include/plan_manager/baseline.h:155-158 holds exactly
+// these four pointers).  The batched entry points are what a multi-agent service calls directly;
+// the per-agent methods below stage one agent's arguments through small device buffers and are
+// meant for drop-in use and testing, not for throughput.
+#pragma once
+
+#include <hip/hip_runtime_api.h>
+
+#include <array>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/sogm_abi.h"
+
+namespace sogm_host {
+
+using Vec3 = std::array<double, 3>;
+using State6 = std::array<double, 6>;
+
+inline void check(int rc, const char *what) {
+  if (rc != SOGM_OK)
+    throw std::runtime_error(std::string(what) + " failed: " + std::to_string(rc) + " " + sogm_last_error());
+}
+
+template <typename T>
+class DevBuf {  // tiny RAII device buffer
+ public:
+  explicit DevBuf(size_t n = 0) { resize(n); }
+  ~DevBuf() { if (p_) (void)hipFree(p_); }
+  DevBuf(const DevBuf &) = delete;
+  DevBuf &operator=(const DevBuf &) = delete;
+  void resize(size_t n) {
+    if (n <= n_) return;
+    if (p_) (void)hipFree(p_);
+    if (hipMalloc((void **)&p_, n * sizeof(T)) != hipSuccess) throw std::bad_alloc();
+    n_ = n;
+  }
+  void put(const T *h, size_t n) { resize(n); (void)hipMemcpy(p_, h, n * sizeof(T), hipMemcpyHostToDevice); }
+  void get(T *h, size_t n) const { (void)hipMemcpy(h, p_, n * sizeof(T), hipMemcpyDeviceToHost); }
+  T *data() { return p_; }
+
+ private:
+  T     *p_ = nullptr;
+  size_t n_ = 0;
+};
+
+// ---- RiskMap / SOGM : RiskBase + FakeParticleRiskVoxel surface --------------------------------------
+class RiskMap {
+ public:
+  RiskMap(const SogmSpec &spec, int n_agents, int device = 0) : n_(n_agents) {
+    check(sogm_create(&spec, n_agents, device, &ctx_), "sogm_create");
+  }
+  ~RiskMap() { sogm_destroy(ctx_); }
+  sogm_ctx *ctx() { return ctx_; }
+  int       agents() const { return n_; }
+
+  // ParticleATC::initEgoParticles + setCoordinator (risk_base.h:62-65)
+  void setCoordinator(const std::vector<Vec3> &body_particles) {
+    check(sogm_set_body_particles(ctx_, body_particles[0].data(), (int)body_particles.size()), "set_body");
+  }
+  // SOGM::update — FakeParticleRiskVoxel::updateMap for the whole batch (device pointers)
+  void update(const float *cloud_xyz, const int32_t *cloud_range, const SogmCylinder *cyl, int n_cyl,
+              const float *poses, const double *stamps, hipStream_t st = nullptr) {
+    check(sogm_update_gt(ctx_, cloud_xyz, cloud_range, cyl, n_cyl, poses, stamps, st), "sogm_update_gt");
+  }
+  // RiskBase::addOtherAgents
+  void addOtherAgents(const SogmTrajRecord *records, int n, const int32_t *ego_ids, hipStream_t st = nullptr) {
+    check(sogm_project_neighbours(ctx_, records, n, ego_ids, st), "sogm_project_neighbours");
+  }
+  // int getClearOcccupancy(const Vector3d& pos, double dt) const  -> 0 free / 1 occupied / -1 out
+  int getClearOcccupancy(int agent, const Vec3 &pos, double dt) {
+    int32_t a = agent; int8_t r = 0;
+    a_.put(&a, 1); p_.put(pos.data(), 3); t_.put(&dt, 1); o_.resize(1);
+    check(sogm_query_clear(ctx_, a_.data(), p_.data(), t_.data(), 0, 1, o_.data(), nullptr), "sogm_query_clear");
+    o_.get(&r, 1);
+    return r;
+  }
+  int getClearOcccupancy(int agent, const Vec3 &pos, int t_index) {
+    int32_t a = agent; int8_t r = 0; double t = t_index;
+    a_.put(&a, 1); p_.put(pos.data(), 3); t_.put(&t, 1); o_.resize(1);
+    check(sogm_query_clear(ctx_, a_.data(), p_.data(), t_.data(), 1, 1, o_.data(), nullptr), "sogm_query_clear");
+    o_.get(&r, 1);
+    return r;
+  }
+  // void getObstaclePoints(std::vector<Vector3d>&, double t0, double t1, const Vector3d& lc, const Vector3d& hc)
+  void getObstaclePoints(int agent, std::vector<Vec3> &points, double t0, double t1, const Vec3 &lc,
+                         const Vec3 &hc, int cap = 4096) {
+    int32_t a = agent, n = 0;
+    a_.put(&a, 1); p_.put(lc.data(), 3); q_.put(hc.data(), 3); t_.put(&t0, 1); u_.put(&t1, 1);
+    pts_.resize((size_t)cap * 3); cnt_.resize(1);
+    check(sogm_obstacle_points(ctx_, a_.data(), p_.data(), q_.data(), t_.data(), u_.data(), 1, pts_.data(),
+                               cnt_.data(), cap, nullptr), "sogm_obstacle_points");
+    cnt_.get(&n, 1);
+    if (n > cap) n = cap;
+    std::vector<double> h((size_t)n * 3);
+    pts_.get(h.data(), h.size());
+    for (int i = 0; i < n; ++i) points.push_back({h[i * 3], h[i * 3 + 1], h[i * 3 + 2]});
+  }
+
+ private:
+  sogm_ctx       *ctx_ = nullptr;
+  int             n_;
+  DevBuf<int32_t> a_, cnt_;
+  DevBuf<double>  p_, q_, t_, u_, pts_;
+  DevBuf<int8_t>  o_;
+};
+
+// ---- planner: search (KinodynamicAstar-style), CorridorGen, PolyTrajOptimizer, replan ---------------
+class Planner {
+ public:
+  Planner(RiskMap &map, const SogmAstarParams &ap, const SogmPlannerParams &pp, const SogmQpSettings &qs)
+      : map_(map), pp_(pp) {
+    check(sogm_planner_create(map.ctx(), &ap, &pp, &qs, &p_), "sogm_planner_create");
+  }
+  ~Planner() { sogm_planner_destroy(p_); }
+  sogm_planner *handle() { return p_; }
+
+  // ASTAR_RET search(start_p, start_v, start_a, end_p, ...) + getPathWithVel(corridor_tau) — batched
+  void search(const double *start_pva, const double *goal, const double *t_start, int32_t *ret, double *route,
+              int32_t *route_len, int route_cap, int32_t *stats, hipStream_t st = nullptr) {
+    check(sogm_astar_search(p_, start_pva, goal, t_start, ret, route, route_len, route_cap, stats, nullptr, 0, st),
+          "sogm_astar_search");
+  }
+  // CorridorGen: getObstaclePoints + firi::firi + ShrinkCorridor + validity/intersection/goal LPs — batched
+  void generateCorridors(const double *start_pva, const double *t_start, const double *route,
+                         const int32_t *route_len, int route_cap, double *polys, int32_t *nfaces, int32_t *npoly,
+                         double *goal_pv, hipStream_t st = nullptr) {
+    check(sogm_corridor_generate(p_, start_pva, t_start, route, route_len, route_cap, polys, nfaces, npoly,
+                                 goal_pv, st), "sogm_corridor_generate");
+  }
+  // PolyTrajOptimizer::optimize == BezierOpt::setup + optimize — batched
+  void optimize(const double *start_pva, const double *goal_pv, const double *polys, const int32_t *nfaces,
+                const int32_t *npoly, double *cpts, int32_t *status, int32_t *iters, hipStream_t st = nullptr) {
+    check(sogm_bezier_qp_solve(p_, start_pva, goal_pv, polys, nfaces, npoly, cpts, status, iters, st),
+          "sogm_bezier_qp_solve");
+  }
+  // bool BaselinePlanner::replan(t, start_pos, start_vel, start_acc, goal_pos) — batched
+  void replan(const double *start_pva, const double *goal, const double *t_start, const int32_t *drone_ids,
+              SogmTrajRecord *records, int32_t *ok, hipStream_t st = nullptr) {
+    check(sogm_replan(p_, start_pva, goal, t_start, drone_ids, records, ok, st), "sogm_replan");
+  }
+
+ private:
+  RiskMap          &map_;
+  SogmPlannerParams pp_;
+  sogm_planner     *p_ = nullptr;
+};
+
+}  // namespace sogm_host

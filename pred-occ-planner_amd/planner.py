@@ -114,3 +114,27 @@ def traj_eval(records, t):
     check(lib().sogm_traj_eval(records.data_ptr(), n, t.data_ptr(), pva.data_ptr(), ok.data_ptr(), _stream()),
           "sogm_traj_eval")
     return pva, ok
+
+
+def smoke_check(pop, sogm, orc, spec, sc, dev, m):
+    """Used by __graft_entry__.smoke(): one replan of the tiny scene vs the oracle."""
+    A = sc["n_agents"]
+    ap, pp, qs = pop.config.make_astar_params(), pop.config.make_planner_params(True), pop.config.make_qp_settings()
+    P = SogmPlanner(m, ap, pp, qs)
+    pva = np.concatenate([sc["starts"], np.zeros((A, 6))], axis=1)
+    t_start = sc["stamps"] + 0.02
+    rec_d, ok_d = P.replan(_dev(pva, np.float64), _dev(sc["goals"], np.float64), _dev(t_start, np.float64),
+                           dev["ego_ids"])
+    got = records_from_bytes(rec_d.cpu().numpy())
+    ok = ok_d.cpu().numpy()
+    cyl = pop.scene.cylinders_to_struct(sc["cylinders"])
+    recs = pop.scene.straight_records(sc)
+    for a in range(A):
+        g = orc.update_gt(spec, sc["cloud"], cyl, dev["n_cyl"], sc["poses"][a])
+        orc.project_neighbours(spec, g, recs, A, a, m.body, sc["poses"][a], sc["stamps"][a])
+        w_ok, w, _ = orc.replan(spec, ap, pp, qs, g, sc["poses"][a], sc["stamps"][a], pva[a], sc["goals"][a],
+                                t_start[a], a)
+        assert ok[a] == w_ok and got[a].n_pieces == w.n_pieces, "replan outcome differs from the oracle"
+        k = w.n_pieces * 15
+        assert np.allclose(np.array(got[a].cpts[:k]), np.array(w.cpts[:k]), atol=1e-4, rtol=0)
+    P.close()
