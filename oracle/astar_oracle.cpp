@@ -192,7 +192,9 @@ struct Search {
       d[i] = p0;
     }
     const double t_delta = t_d / 10;
-    for (double time = t_delta; time <= t_d; time += t_delta) {
+    // guard: t_d == 0 (node exactly on the goal) makes the reference's loop spin forever
+    int guard = 0;
+    for (double time = t_delta; time <= t_d && guard < 64; time += t_delta, ++guard) {
       // coord = d + c t + b t^2 + a t^3 ; powers as products (pow(t,3) restated as (t*t)*t)
       const double t1 = time, t2 = time * time, t3 = (time * time) * time;
       double       coord[3];

@@ -388,7 +388,8 @@ __global__ __launch_bounds__(64) void k_astar(
               }
               const double t_delta = t_d / 10;
               bool         ok      = true;
-              for (double time = t_delta; time <= t_d; time += t_delta) {
+              int          guard   = 0;  // t_d == 0 would spin forever in the reference
+              for (double time = t_delta; time <= t_d && guard < 64; time += t_delta, ++guard) {
                 const double t1 = time, t2 = time * time, t3 = (time * time) * time;
                 double       co[3];
                 for (int dim = 0; dim < 3; ++dim)

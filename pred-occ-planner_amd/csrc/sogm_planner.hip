@@ -115,15 +115,10 @@ int sogm_planner_create(sogm_ctx *map, const SogmAstarParams *astar, const SogmP
     if (e == hipSuccess) e = hipMalloc((void **)&p->cw.seg_nfaces, sizeof(int32_t) * slots);
     if (e == hipSuccess) e = hipMalloc((void **)&p->cw.seg_state, sizeof(int32_t) * slots);
     if (e == hipSuccess) e = hipMalloc((void **)&p->cw.seg_npts, sizeof(int32_t) * slots);
-    // QP scratch: rows = 9(M+1) + 21M + 5 * sum(faces) at M = SOGM_MAX_PIECES
-    const int mcap = 9 * (SOGM_MAX_PIECES + 1) + 21 * SOGM_MAX_PIECES + 5 * pp->max_faces * SOGM_MAX_PIECES;
-    p->qw.m_cap    = mcap;
-    p->qw.dyn_lds_bytes = 144 * 1024;  // 160 KiB/CU minus k_qp's ~14 KiB of static LDS
-    if (e == hipSuccess) e = hipMalloc((void **)&p->qw.ell_col, sizeof(int) * (size_t)A * mcap * 6);
-    if (e == hipSuccess) e = hipMalloc((void **)&p->qw.ell_val, sizeof(double) * (size_t)A * mcap * 6);
-    if (e == hipSuccess) e = hipMalloc((void **)&p->qw.mvec, sizeof(double) * (size_t)A * mcap * 10);
-    if (e == hipSuccess) e = hipMalloc((void **)&p->qw.csc_ptr, sizeof(int) * (size_t)A * (15 * SOGM_MAX_PIECES + 1));
-    if (e == hipSuccess) e = hipMalloc((void **)&p->qw.csc_idx, sizeof(int) * (size_t)A * mcap * 6);
+    // QP row storage fallback (rows normally live in LDS)
+    p->qw.scratch_stride = qp_scratch_bytes_per_agent(pp->max_faces);
+    p->qw.dyn_lds_bytes  = 144 * 1024;  // 160 KiB/CU minus k_qp's ~14 KiB of static LDS
+    if (e == hipSuccess) e = hipMalloc((void **)&p->qw.scratch, p->qw.scratch_stride * (size_t)A);
     min_jerk_block(p->qc.QM);
     if (e == hipSuccess) e = hipMalloc((void **)&p->d_polys, sizeof(double) * slots * pp->max_faces * 4);
     if (e == hipSuccess) e = hipMalloc((void **)&p->d_goal, sizeof(double) * 6 * A);
@@ -147,7 +142,7 @@ void sogm_planner_destroy(sogm_planner *p) {
                   p->d_ret,   p->d_route_len, p->d_stats, p->d_route,
                   p->cw.pc,   p->cw.fpc,  p->cw.tang, p->cw.distr, p->cw.polys,
                   p->cw.seg_nfaces, p->cw.seg_state, p->cw.seg_npts,
-                  p->qw.ell_col, p->qw.ell_val, p->qw.mvec, p->qw.csc_ptr, p->qw.csc_idx,
+                  p->qw.scratch,
                   p->d_polys, p->d_goal, p->d_cpts, p->d_nfaces, p->d_npoly, p->d_status, p->d_iters};
   for (void *q : ptrs)
     if (q) (void)hipFree(q);

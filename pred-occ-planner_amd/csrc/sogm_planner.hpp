@@ -33,16 +33,13 @@ int launch_corridor(const MapView &m, const SogmPlannerParams &pp, const Corrido
                     double *out_polys, int32_t *out_nfaces, int32_t *out_npoly, double *out_goal,
                     hipStream_t st);
 
-// Per-agent QP scratch in HBM (m-sized vectors, ELL rows of A, row-sorted CSC index).
+// Per-agent QP row storage in HBM, used only when a problem's rows do not fit in LDS.
 struct QpWorkspace {
-  int    *ell_col;  // [A][m_cap][6]
-  double *ell_val;  // [A][m_cap][6]
-  double *mvec;     // [A][10][m_cap]  l,u,rho,E,z,zp,zt,y,w,dy
-  int    *csc_ptr;  // [A][15*SOGM_MAX_PIECES+1]
-  int    *csc_idx;  // [A][m_cap*6]
-  int     m_cap;
-  int     dyn_lds_bytes;  // dynamic LDS per workgroup of k_qp
+  char  *scratch;         // [A][scratch_stride]
+  size_t scratch_stride;  // bytes per agent (rows at M = SOGM_MAX_PIECES, max_faces faces)
+  int    dyn_lds_bytes;   // dynamic LDS per workgroup of k_qp
 };
+size_t qp_scratch_bytes_per_agent(int max_faces);
 struct QpConst {
   double QM[225];  // per-piece min-jerk cost block (bezier_optimizer.cpp:96-111)
 };

@@ -4,20 +4,28 @@
 // through IOSQP (traj_opt/include/iosqp.hpp:40-115) into OSQP (external, v0.6 API, not vendored).
 // The solver restates the published OSQP algorithm exactly as oracle/qp_oracle.cpp does.
 //
-// Mapping to CDNA4: one workgroup (256 lanes = 4 waves) per agent; problems are tiny
-// (n = 15 M <= 240 variables, m ~ 5e2..5.6e3 rows with <= 6 non-zeros each) and strictly
-// latency-bound, so the point is to keep the whole iteration on-chip and off the host:
-//   * A is built directly in ELL form (row-parallel) plus a row-sorted CSC index for A^T products;
-//   * P is block diagonal (one 15x15 min-jerk block per piece) and lives in LDS;
-//   * K = P + sigma I + A^T diag(rho) A is block-banded (half bandwidth 17: continuity rows couple
-//     the last 3 control points of a piece with the first 3 of the next) — stored as an n x 18 band
-//     in LDS, factored by a banded Cholesky on one wave, re-factored only when rho changes;
-//   * per iteration: CSC column sums (A^T w), banded forward/back substitution (wave 0, shuffle
-//     reductions), ELL row products (A x), element-wise updates; residual norms are wavefront
+// Mapping to CDNA4: one workgroup (256 lanes = 4 waves) per agent.  The problems are tiny
+// (n = 15 M <= 240 variables, m ~ 5e2..5.6e3 rows) and strictly latency-bound — an ADMM chain of
+// a few hundred dependent iterations — so the design goal is that one iteration never leaves the
+// CU and has a short critical path:
+//   * rows are split by structure.  "General" rows (continuity, velocity / acceleration boxes:
+//     9(M+1) + 21M rows, <= 6 non-zeros) are kept in ELL form plus a row-sorted CSC index for
+//     A^T products.  "Safety" rows (5 per corridor face: h . c_k <= -h3 for each control point k)
+//     dominate m and have implicit structure — row (piece i, face j, point k) touches exactly the
+//     3 coordinates of point k — so they store only 3 coefficients and are addressed directly:
+//     no column indices, no CSC, and A^T w for a column is a stride-5 walk over that piece's faces;
+//   * P is block diagonal (one 15x15 min-jerk block per piece), K = P + sigma I + A^T diag(rho) A is
+//     banded (half bandwidth 17): an n x 18 band in LDS, banded Cholesky on one wave
+//     (right-looking, no reductions on the dependency chain), re-factored only when rho changes;
+//   * all row data sits in LDS (up to 144 KB dynamic) when it fits — the common case — and in a
+//     per-agent HBM scratch otherwise (same code through flat pointers);
+//   * an iteration is 3 barriers: [A^T w per column] | [banded solve, wave 0] | [x, then per row
+//     z~ = A x~, projection, dual update]; residual norms (every 25 iterations) are wavefront
 //     shuffle reductions combined through LDS.
-// No dense contraction anywhere -> no MFMA.  m-sized vectors stay in per-agent HBM scratch
-// (L2-resident, ~0.4 MB).
+// No dense contraction anywhere -> no MFMA.
 #include <hip/hip_runtime.h>
+
+#include <cstdlib>
 
 #include "../../include/sogm_detmath.h"
 #include "sogm_planner.hpp"
@@ -25,7 +33,7 @@
 namespace sogm {
 namespace {
 
-#define QP_BW 17                 // half bandwidth of K
+#define QP_BW 17  // half bandwidth of K
 #define QP_NMAX (15 * SOGM_MAX_PIECES)
 #define QP_ELL 6
 
@@ -40,7 +48,6 @@ __device__ inline double limit_scaling(double v) {
   v = v > MAX_SCALING ? MAX_SCALING : v;
   return v;
 }
-
 __device__ inline double wave_max(double v) {
   for (int d = 32; d >= 1; d >>= 1) v = dmax(v, __shfl_xor(v, d, 64));
   return v;
@@ -49,7 +56,6 @@ __device__ inline double wave_sum(double v) {
   for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
   return v;
 }
-// block-wide max over 256 lanes; every lane gets the result.  s_red: 4 doubles.
 __device__ inline double block_max(double v, double *s_red) {
   v = wave_max(v);
   __syncthreads();
@@ -58,19 +64,65 @@ __device__ inline double block_max(double v, double *s_red) {
   return dmax(dmax(s_red[0], s_red[1]), dmax(s_red[2], s_red[3]));
 }
 
-struct Prob {
-  int            n, m, M;
-  int           *ecol;  // [m][6]
-  double        *eval;  // [m][6]
-  double        *l, *u, *rho, *E, *z, *zp, *zt, *y, *w, *dy;
-  int           *cptr;  // [n+1]
-  int           *cidx;  // [nnz]  row * 8 + slot, sorted by row inside a column
+// Row storage (LDS or HBM scratch)
+struct Rows {
+  // general rows [0, G)
+  double *gval;  // [G][6]
+  double *gl, *gu, *grho, *gE, *gz, *gy, *gdy;
+  int    *gcol;  // [G][6]
+  int    *cidx;  // CSC entries over general rows: row * 8 + slot, row-sorted inside a column
+  // safety rows [0, S):  s = off_i + 5 * face + k ; columns i*15 + k*3 + {0,1,2}
+  double *sval;  // [S][3]
+  double *su, *sE, *sz, *sy, *sdy;
+  double *sw;   // [S] rho z - y (refreshed by the row update, consumed by the next A^T product)
+  int    *sc0;  // [S] first column of the row's control point
 };
 
-// ---- K band helpers: Kb[i * 18 + (i - j)], 0 <= i - j <= 17
+__host__ __device__ inline size_t rows_bytes(int G, int S) {
+  return (size_t)G * (QP_ELL * 8 + 7 * 8 + QP_ELL * 4 + QP_ELL * 4) + (size_t)S * (3 * 8 + 6 * 8 + 4) + 64;
+}
+__device__ inline void carve_rows(Rows &R, char *base, int G, int S) {
+  double *d = (double *)base;
+  R.gval = d;  d += (size_t)G * QP_ELL;
+  R.gl = d;    d += G;
+  R.gu = d;    d += G;
+  R.grho = d;  d += G;
+  R.gE = d;    d += G;
+  R.gz = d;    d += G;
+  R.gy = d;    d += G;
+  R.gdy = d;   d += G;
+  R.sval = d;  d += (size_t)S * 3;
+  R.su = d;    d += S;
+  R.sE = d;    d += S;
+  R.sz = d;    d += S;
+  R.sy = d;    d += S;
+  R.sdy = d;   d += S;
+  R.sw = d;    d += S;
+  int *q = (int *)d;
+  R.gcol = q;  q += (size_t)G * QP_ELL;
+  R.sc0 = q;   q += S;
+  R.cidx = q;
+}
+
+// value of the lane selected by a DPP quad permute (0xB1: lane ^ 1, 0x4E: lane ^ 2)
+template <int CTRL>
+__device__ inline double dpp_quad_t(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo     = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xF, 0xF, true);
+  hi     = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+#define dpp_quad(v, ctrl) dpp_quad_t<ctrl>(v)
+
 __device__ inline double &KB(double *Kb, int i, int j) { return Kb[i * (QP_BW + 1) + (i - j)]; }
 
 }  // namespace
+
+size_t qp_scratch_bytes_per_agent(int max_faces) {
+  const int G = 9 * (SOGM_MAX_PIECES + 1) + 21 * SOGM_MAX_PIECES;
+  const int S = 5 * max_faces * SOGM_MAX_PIECES;
+  return (rows_bytes(G, S) + 255) & ~(size_t)255;
+}
 
 __global__ __launch_bounds__(256) void k_qp(SogmPlannerParams pp, SogmQpSettings qs, QpWorkspace ws,
                                             QpConst qc, const double *__restrict__ start_pva,
@@ -80,7 +132,7 @@ __global__ __launch_bounds__(256) void k_qp(SogmPlannerParams pp, SogmQpSettings
                                             const int32_t *__restrict__ npoly,
                                             double *__restrict__ out_cpts,
                                             int32_t *__restrict__ out_status,
-                                            int32_t *__restrict__ out_iters) {
+                                            int32_t *__restrict__ out_iters, int ablate) {
   const int agent = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int M = npoly[agent];
@@ -95,90 +147,61 @@ __global__ __launch_bounds__(256) void k_qp(SogmPlannerParams pp, SogmQpSettings
   const int n  = 15 * M;
 
   extern __shared__ __attribute__((aligned(16))) char qp_smem[];
-  double *s_Kb = (double *)qp_smem;            // [n][18]  K band / Cholesky factor
+  double *s_Kb = (double *)qp_smem;               // [n][18]  K band / Cholesky factor
   double *s_P  = s_Kb + (size_t)n * (QP_BW + 1);  // [M][225] scaled cost blocks
+  // Block form of the factor for the per-iteration solve (M <= 8): K is block tridiagonal in 15x15
+  // piece blocks (the profile of the continuity rows), so G = chol(K) is block bidiagonal.
+  const bool use_blocks = M <= 8;
+  double    *s_Ginv     = s_P + (size_t)M * 225;     // [M][225] inverse of the diagonal block of G
+  double    *s_Goff     = s_Ginv + (size_t)M * 225;  // [M][225] G(block i, block i-1)
   __shared__ double s_ginv[QP_NMAX];
-  __shared__ double s_x[QP_NMAX], s_xp[QP_NMAX], s_xt[QP_NMAX], s_D[QP_NMAX], s_Dt[QP_NMAX];
-  __shared__ double s_cn[QP_NMAX];  // column norms / scratch
+  __shared__ double s_x[QP_NMAX], s_xt[QP_NMAX], s_D[QP_NMAX], s_Dt[QP_NMAX];
+  __shared__ double s_cn[QP_NMAX];
   __shared__ double s_red[4];
   __shared__ double s_sc[8];
-  __shared__ int    s_off[SOGM_MAX_PIECES + 1];
+  __shared__ int    s_off[SOGM_MAX_PIECES + 1];  // safety-row offset of each piece
+  __shared__ int    s_nf[SOGM_MAX_PIECES];
   __shared__ int    s_cnt[QP_NMAX + 1];
   __shared__ int    s_cptr[QP_NMAX + 1];
   __shared__ int    s_flag;
 
-  // ---- problem dimensions
   if (tid == 0) {
     int acc = 0;
     for (int i = 0; i < M; ++i) {
-      s_off[i] = acc;
-      acc += 5 * nfaces[agent * SOGM_MAX_PIECES + i];
+      const int f = nfaces[agent * SOGM_MAX_PIECES + i];
+      s_off[i]    = acc;
+      s_nf[i]     = f;
+      acc += 5 * f;
     }
     s_off[M] = acc;
   }
   __syncthreads();
-  const int R1 = 3 * (M + 1), R3 = 9 * (M + 1), R4 = R3 + 12 * M,
-            R5 = R4 + 9 * M;
-  const int m = R5 + s_off[M];
-  Prob      pb;
-  pb.n = n;
-  pb.m = m;
-  pb.M = M;
-  {
-    // Row data (8 m-vectors, ELL rows, CSC index) live in LDS when they fit next to K and P —
-    // the common case (m ~ 600) — and in per-agent HBM scratch otherwise (same code, flat pointers).
-    const size_t head  = ((size_t)n * (QP_BW + 1) + (size_t)M * 225) * sizeof(double);
-    const size_t perow = 8 * sizeof(double) + QP_ELL * (sizeof(double) + 2 * sizeof(int));
-    const size_t need  = head + (size_t)m * perow + 64;
-    const size_t mc    = ws.m_cap;
-    double      *v;
-    if (need <= (size_t)ws.dyn_lds_bytes) {
-      v         = (double *)(qp_smem + head);
-      pb.eval   = v + 8 * (size_t)m;
-      pb.ecol   = (int *)(pb.eval + (size_t)m * QP_ELL);
-      pb.cidx   = pb.ecol + (size_t)m * QP_ELL;
-      pb.l = v;
-      pb.u = v + m;
-      pb.rho = v + 2 * (size_t)m;
-      pb.E = v + 3 * (size_t)m;
-      pb.z = v + 4 * (size_t)m;
-      pb.y = v + 5 * (size_t)m;
-      pb.w = v + 6 * (size_t)m;
-      pb.dy = v + 7 * (size_t)m;
-    } else {
-      pb.ecol = ws.ell_col + (size_t)agent * mc * QP_ELL;
-      pb.eval = ws.ell_val + (size_t)agent * mc * QP_ELL;
-      v       = ws.mvec + (size_t)agent * mc * 10;
-      pb.l = v;
-      pb.u = v + mc;
-      pb.rho = v + 2 * mc;
-      pb.E = v + 3 * mc;
-      pb.z = v + 4 * mc;
-      pb.y = v + 5 * mc;
-      pb.w = v + 6 * mc;
-      pb.dy = v + 7 * mc;
-      pb.cidx = ws.csc_idx + (size_t)agent * mc * QP_ELL;
-    }
-    pb.zp = pb.zt = nullptr;
-    pb.cptr = s_cptr;
-  }
+  const int R1 = 3 * (M + 1), R3 = 9 * (M + 1), R4 = R3 + 12 * M, G = R4 + 9 * M;
+  const int S = s_off[M];
+  const size_t head =
+      ((size_t)n * (QP_BW + 1) + (size_t)M * 225 * (use_blocks ? 3 : 1)) * sizeof(double);
+  const bool rows_in_lds = head + rows_bytes(G, S) <= (size_t)ws.dyn_lds_bytes;
+  // The solver body is instantiated twice (forced inline): once with every row pointer derived from
+  // the LDS array — so the compiler emits ds_read/ds_write instead of flat accesses — and once for
+  // the HBM-scratch fallback.
+  auto body = [&](const Rows &R) __attribute__((always_inline)) {
   const double *sp   = start_pva + agent * 9;
   const double *gp   = goal_pv + agent * 6;
   const double  tau  = pp.corridor_tau;  // time_alloc: every piece = corridor_tau (baseline.cpp:411)
   const double  vmax = pp.opt_max_vel, amax = pp.opt_max_acc;
 
-  // ---- 1. assembly of A, l, u in ELL (bezier_optimizer.cpp:113-260), one lane per row
-  for (int r = tid; r < m; r += 256) {
+  // ---- 1. assembly (bezier_optimizer.cpp:113-260): general rows in ELL, one lane per row
+  for (int r = tid; r < G; r += 256) {
     int    col[QP_ELL];
     double val[QP_ELL];
     for (int k = 0; k < QP_ELL; ++k) {
       col[k] = -1;
       val[k] = 0.0;
     }
-    double lo = 0.0, hi = 0.0;
+    double       lo = 0.0, hi = 0.0;
     const double p2a[3] = {12, -24, 12};
     if (r < R3) {
-      const int kind = r / R1;       // 0 pos, 1 vel, 2 acc
+      const int kind = r / R1;  // 0 pos, 1 vel, 2 acc
       const int rr   = r - kind * R1;
       const int gidx = rr / 3, d = rr % 3;  // 0 = start, 1..M-1 = knots, M = end
       if (kind == 0) {
@@ -250,7 +273,7 @@ __global__ __launch_bounds__(256) void k_qp(SogmPlannerParams pp, SogmQpSettings
       val[1] = 4;
       hi     = vmax * 1.0 * tau;
       lo     = -vmax * 1.0 * tau;
-    } else if (r < R5) {
+    } else {
       const int rr = r - R4, i = rr / 9, j = (rr % 9) / 3, d = rr % 3;
       for (int k = 0; k < 3; ++k) {
         col[k] = i * 15 + j * 3 + k * 3 + d;
@@ -258,30 +281,32 @@ __global__ __launch_bounds__(256) void k_qp(SogmPlannerParams pp, SogmQpSettings
       }
       hi = amax * 1.0 * tau * tau;
       lo = -amax * 1.0 * tau * tau;
-    } else {
-      const int rr = r - R5;
-      int       i  = 0;
-      while (i + 1 < M && rr >= s_off[i + 1]) ++i;
-      const int     q = rr - s_off[i], face = q / 5, k = q % 5;
-      const double *h = polys + (((size_t)agent * SOGM_MAX_PIECES + i) * MF + face) * 4;
-      for (int d = 0; d < 3; ++d) {
-        col[d] = i * 15 + k * 3 + d;
-        val[d] = h[d];
-      }
-      hi = -h[3];
-      lo = -OSQP_INFTY;
     }
     for (int k = 0; k < QP_ELL; ++k) {
-      // explicit zeros are not structural non-zeros (sparseView() drops them, :264-265)
-      if (col[k] >= 0 && val[k] == 0.0) col[k] = -1;
-      pb.ecol[(size_t)r * QP_ELL + k] = col[k];
-      pb.eval[(size_t)r * QP_ELL + k] = val[k];
+      R.gcol[(size_t)r * QP_ELL + k] = col[k];
+      R.gval[(size_t)r * QP_ELL + k] = val[k];
     }
-    pb.l[r] = lo;
-    pb.u[r] = hi;
-    pb.E[r] = 1.0;
-    pb.z[r] = 0.0;
-    pb.y[r] = 0.0;
+    R.gl[r] = lo;
+    R.gu[r] = hi;
+    R.gE[r] = 1.0;
+    R.gz[r] = 0.0;
+    R.gy[r] = 0.0;
+  }
+  // safety rows: one lane per row (explicit zero coefficients simply stay zero)
+  for (int s = tid; s < S; s += 256) {
+    int i = 0;
+    while (i + 1 < M && s >= s_off[i + 1]) ++i;
+    const int     q = s - s_off[i], face = q / 5;
+    const double *h = polys + (((size_t)agent * SOGM_MAX_PIECES + i) * MF + face) * 4;
+    R.sval[(size_t)s * 3 + 0] = h[0];
+    R.sval[(size_t)s * 3 + 1] = h[1];
+    R.sval[(size_t)s * 3 + 2] = h[2];
+    R.su[s] = -h[3];
+    R.sE[s] = 1.0;
+    R.sz[s] = 0.0;
+    R.sy[s] = 0.0;
+    R.sw[s] = 0.0;
+    R.sc0[s] = i * 15 + (q % 5) * 3;
   }
   for (int i = tid; i < M * 225; i += 256) s_P[i] = qc.QM[i % 225];
   for (int j = tid; j < n; j += 256) {
@@ -291,45 +316,51 @@ __global__ __launch_bounds__(256) void k_qp(SogmPlannerParams pp, SogmQpSettings
   for (int j = tid; j <= n; j += 256) s_cnt[j] = 0;
   __syncthreads();
 
-  // ---- 2. CSC index of A (row-sorted inside each column)
-  for (int r = tid; r < m; r += 256)
+  // ---- 2. CSC index of the general rows (row-sorted inside each column)
+  for (int r = tid; r < G; r += 256)
     for (int k = 0; k < QP_ELL; ++k) {
-      const int c = pb.ecol[(size_t)r * QP_ELL + k];
+      const int c = R.gcol[(size_t)r * QP_ELL + k];
       if (c >= 0) atomicAdd(&s_cnt[c], 1);
     }
   __syncthreads();
   if (tid == 0) {
     int acc = 0;
     for (int j = 0; j < n; ++j) {
-      pb.cptr[j] = acc;
+      s_cptr[j] = acc;
       acc += s_cnt[j];
       s_cnt[j] = 0;
     }
-    pb.cptr[n] = acc;
+    s_cptr[n] = acc;
   }
   __syncthreads();
-  for (int r = tid; r < m; r += 256)
+  for (int r = tid; r < G; r += 256)
     for (int k = 0; k < QP_ELL; ++k) {
-      const int c = pb.ecol[(size_t)r * QP_ELL + k];
+      const int c = R.gcol[(size_t)r * QP_ELL + k];
       if (c >= 0) {
-        const int pos            = atomicAdd(&s_cnt[c], 1);
-        pb.cidx[pb.cptr[c] + pos] = r * 8 + k;
+        const int pos           = atomicAdd(&s_cnt[c], 1);
+        R.cidx[s_cptr[c] + pos] = r * 8 + k;
       }
     }
   __syncthreads();
-  for (int j = tid; j < n; j += 256) {  // insertion sort of each column's entries by row
-    const int b = pb.cptr[j], e = pb.cptr[j + 1];
+  for (int j = tid; j < n; j += 256) {
+    const int b = s_cptr[j], e = s_cptr[j + 1];
     for (int a = b + 1; a < e; ++a) {
-      const int v = pb.cidx[a];
+      const int v = R.cidx[a];
       int       q = a - 1;
-      while (q >= b && pb.cidx[q] > v) {
-        pb.cidx[q + 1] = pb.cidx[q];
+      while (q >= b && R.cidx[q] > v) {
+        R.cidx[q + 1] = R.cidx[q];
         --q;
       }
-      pb.cidx[q + 1] = v;
+      R.cidx[q + 1] = v;
     }
   }
   __syncthreads();
+
+  // column j = (piece pi, point pk, dim pd): its safety rows are s_off[pi] + 5 * face + pk
+#define COL_DECODE(j)                                                   \
+  const int pi = (j) / 15, pk = ((j) % 15) / 3, pd = (j) % 3;           \
+  const int sbase = s_off[pi] + pk, nface = s_nf[pi];                   \
+  (void)pd;
 
   // ---- 3. Ruiz equilibration with cost scaling (OSQP scale_data)
   double c_scale = 1.0;
@@ -339,23 +370,38 @@ __global__ __launch_bounds__(256) void k_qp(SogmPlannerParams pp, SogmQpSettings
       const double *Pb = s_P + (j / 15) * 225;
       const int     jj = j % 15;
       for (int i = 0; i < 15; ++i) mx = dmax(mx, dabs(Pb[i * 15 + jj]));
-      for (int a = pb.cptr[j]; a < pb.cptr[j + 1]; ++a) {
-        const int e = pb.cidx[a];
-        mx          = dmax(mx, dabs(pb.eval[(size_t)(e >> 3) * QP_ELL + (e & 7)]));
+      for (int a = s_cptr[j]; a < s_cptr[j + 1]; ++a) {
+        const int e = R.cidx[a];
+        mx          = dmax(mx, dabs(R.gval[(size_t)(e >> 3) * QP_ELL + (e & 7)]));
       }
+      COL_DECODE(j)
+      for (int f = 0; f < nface; ++f) mx = dmax(mx, dabs(R.sval[(size_t)(sbase + 5 * f) * 3 + pd]));
       s_Dt[j] = 1.0 / sogm_det::sqrt_rn(limit_scaling(mx));
     }
     __syncthreads();
-    for (int r = tid; r < m; r += 256) {
+    for (int r = tid; r < G; r += 256) {
       double mx = 0;
       for (int k = 0; k < QP_ELL; ++k)
-        if (pb.ecol[(size_t)r * QP_ELL + k] >= 0) mx = dmax(mx, dabs(pb.eval[(size_t)r * QP_ELL + k]));
+        if (R.gcol[(size_t)r * QP_ELL + k] >= 0) mx = dmax(mx, dabs(R.gval[(size_t)r * QP_ELL + k]));
       const double et = 1.0 / sogm_det::sqrt_rn(limit_scaling(mx));
       for (int k = 0; k < QP_ELL; ++k) {
-        const int c = pb.ecol[(size_t)r * QP_ELL + k];
-        if (c >= 0) pb.eval[(size_t)r * QP_ELL + k] *= et * s_Dt[c];
+        const int c = R.gcol[(size_t)r * QP_ELL + k];
+        if (c >= 0) R.gval[(size_t)r * QP_ELL + k] *= et * s_Dt[c];
       }
-      pb.E[r] *= et;
+      R.gE[r] *= et;
+    }
+    for (int s = tid; s < S; s += 256) {
+      int i = 0;
+      while (i + 1 < M && s >= s_off[i + 1]) ++i;
+      const int    k  = (s - s_off[i]) % 5;
+      double      *v  = R.sval + (size_t)s * 3;
+      const double mx = dmax(dmax(dabs(v[0]), dabs(v[1])), dabs(v[2]));
+      const double et = 1.0 / sogm_det::sqrt_rn(limit_scaling(mx));
+      const int    c0 = i * 15 + k * 3;
+      v[0] *= et * s_Dt[c0];
+      v[1] *= et * s_Dt[c0 + 1];
+      v[2] *= et * s_Dt[c0 + 2];
+      R.sE[s] *= et;
     }
     for (int i = tid; i < M * 225; i += 256) {
       const int b = i / 225, rr = (i % 225) / 15, cc = i % 15;
@@ -375,8 +421,7 @@ __global__ __launch_bounds__(256) void k_qp(SogmPlannerParams pp, SogmQpSettings
       double mean = 0;
       for (int j = 0; j < n; ++j) mean += s_cn[j];
       double c_temp = mean / n;
-      double nq     = limit_scaling(0.0);  // q == 0
-      c_temp        = dmax(c_temp, nq);
+      c_temp        = dmax(c_temp, limit_scaling(0.0));  // ||q||inf = 0 -> 1.0
       c_temp        = limit_scaling(c_temp);
       s_sc[0]       = 1.0 / c_temp;
     }
@@ -386,18 +431,19 @@ __global__ __launch_bounds__(256) void k_qp(SogmPlannerParams pp, SogmQpSettings
     c_scale *= ct;
     __syncthreads();
   }
-  for (int r = tid; r < m; r += 256) {
-    pb.l[r] *= pb.E[r];
-    pb.u[r] *= pb.E[r];
+  for (int r = tid; r < G; r += 256) {
+    R.gl[r] *= R.gE[r];
+    R.gu[r] *= R.gE[r];
   }
+  for (int s = tid; s < S; s += 256) R.su[s] *= R.sE[s];
   const double cinv = 1.0 / c_scale;
   __syncthreads();
 
-  // ---- helpers as lambdas over the shared state -------------------------------------------------
-  double rho_cur = qs.rho;
-  auto set_rho = [&]() {
-    for (int r = tid; r < m; r += 256) {
-      const double lo = pb.l[r], hi = pb.u[r];
+  // ---- helpers -----------------------------------------------------------------------------------
+  double rho_cur = qs.rho;  // safety rows are one-sided inequalities: their rho is rho_cur itself
+  auto   set_rho = [&]() {
+    for (int r = tid; r < G; r += 256) {
+      const double lo = R.gl[r], hi = R.gu[r];
       double       v;
       if (lo < -OSQP_INFTY * MIN_SCALING && hi > OSQP_INFTY * MIN_SCALING)
         v = RHO_MIN;
@@ -405,11 +451,13 @@ __global__ __launch_bounds__(256) void k_qp(SogmPlannerParams pp, SogmQpSettings
         v = RHO_EQ_OVER_RHO_INEQ * rho_cur;
       else
         v = rho_cur;
-      pb.rho[r] = v;
+      R.grho[r] = v;
     }
+    for (int s = tid; s < S; s += 256) R.sw[s] = rho_cur * R.sz[s] - R.sy[s];
     __syncthreads();
   };
-  // K band = P + sigma I + A^T diag(rho) A, then banded Cholesky in place (lower)
+  // K band = P + sigma I + A^T diag(rho) A (rows in global row order: general, then safety),
+  // then banded Cholesky in place
   auto factor = [&]() -> bool {
     for (int e = tid; e < n * (QP_BW + 1); e += 256) {
       const int i = e / (QP_BW + 1), dlt = e % (QP_BW + 1), j = i - dlt;
@@ -417,11 +465,19 @@ __global__ __launch_bounds__(256) void k_qp(SogmPlannerParams pp, SogmQpSettings
       if (j >= 0) {
         if (i / 15 == j / 15) s = s_P[(i / 15) * 225 + (i % 15) * 15 + (j % 15)];
         if (i == j) s += qs.sigma;
-        for (int a = pb.cptr[i]; a < pb.cptr[i + 1]; ++a) {
-          const int    en = pb.cidx[a], r = en >> 3;
-          const double vi = pb.eval[(size_t)r * QP_ELL + (en & 7)];
+        for (int a = s_cptr[i]; a < s_cptr[i + 1]; ++a) {
+          const int    en = R.cidx[a], r = en >> 3;
+          const double vi = R.gval[(size_t)r * QP_ELL + (en & 7)];
           for (int k = 0; k < QP_ELL; ++k)
-            if (pb.ecol[(size_t)r * QP_ELL + k] == j) s += vi * pb.rho[r] * pb.eval[(size_t)r * QP_ELL + k];
+            if (R.gcol[(size_t)r * QP_ELL + k] == j) s += vi * R.grho[r] * R.gval[(size_t)r * QP_ELL + k];
+        }
+        if (i / 3 == j / 3) {  // same control point: safety rows couple its 3 coordinates
+          COL_DECODE(i)
+          const int jd = j % 3;
+          for (int f = 0; f < nface; ++f) {
+            const double *v = R.sval + (size_t)(sbase + 5 * f) * 3;
+            s += v[pd] * rho_cur * v[jd];
+          }
         }
       }
       s_Kb[e] = s;
@@ -429,8 +485,6 @@ __global__ __launch_bounds__(256) void k_qp(SogmPlannerParams pp, SogmQpSettings
     if (tid == 0) s_flag = 1;
     __syncthreads();
     if (wave == 0) {
-      // right-looking banded Cholesky: column j is scaled, then the 17x17 trailing triangle is
-      // updated by all 64 lanes (153 pair updates, <= 3 per lane); no reductions on the chain
       for (int j = 0; j < n; ++j) {
         const double djj = KB(s_Kb, j, j);
         if (!(djj > 0)) {
@@ -446,7 +500,6 @@ __global__ __launch_bounds__(256) void k_qp(SogmPlannerParams pp, SogmQpSettings
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         __builtin_amdgcn_wave_barrier();
         for (int e = lane; e < (QP_BW * (QP_BW + 1)) / 2; e += 64) {
-          // e -> (a, b) with 1 <= b <= a <= 17 (row-major lower triangle)
           int a = 1, rem = e;
           while (rem >= a) {
             rem -= a;
@@ -460,11 +513,123 @@ __global__ __launch_bounds__(256) void k_qp(SogmPlannerParams pp, SogmQpSettings
       }
     }
     __syncthreads();
+    if (use_blocks && s_flag) {
+      for (int e = tid; e < M * 225; e += 256) {
+        const int b = e / 225, r = (e % 225) / 15, c = e % 15;
+        const int row = b * 15 + r, col = (b - 1) * 15 + c;
+        s_Goff[e] = (b > 0 && row - col <= QP_BW) ? KB(s_Kb, row, col) : 0.0;
+        s_Ginv[e] = 0.0;
+      }
+      __syncthreads();
+      // column c of inv(Gd_b): forward substitution, one lane per (block, column)
+      for (int e = tid; e < M * 15; e += 256) {
+        const int b = e / 15, c = e % 15, o = b * 15;
+        double    v[15];
+        for (int r = 0; r < 15; ++r) v[r] = 0.0;
+        v[c] = s_ginv[o + c];
+        for (int r = c + 1; r < 15; ++r) {
+          double acc = 0.0;
+          for (int k = c; k < r; ++k) acc += KB(s_Kb, o + r, o + k) * v[k];
+          v[r] = -acc * s_ginv[o + r];
+        }
+        for (int r = c; r < 15; ++r) s_Ginv[b * 225 + r * 15 + c] = v[r];
+      }
+      __syncthreads();
+      // Fold the two matvecs of a block step into one:  y_b = Ginv_b rhs_b - W_b y_{b-1},
+      // x_b = Ginv_b^T y_b - Z_b x_{b+1}  with  W_b = Ginv_b G(b,b-1),  Z_b = Ginv_b^T G(b+1,b)^T.
+      // W goes into the (now idle) band storage, Z replaces G(b, b-1) in place.
+      double wv[8], zv[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int e = tid + q * 256;
+        wv[q] = zv[q] = 0.0;
+        if (e < M * 225) {
+          const int b = e / 225, r = (e % 225) / 15, c = e % 15;
+          if (b > 0) {
+            double acc = 0.0;
+            for (int k = 0; k <= r; ++k) acc += s_Ginv[b * 225 + r * 15 + k] * s_Goff[b * 225 + k * 15 + c];
+            wv[q] = acc;
+          }
+          if (b < M - 1) {
+            double acc = 0.0;
+            for (int k = r; k < 15; ++k) acc += s_Ginv[b * 225 + k * 15 + r] * s_Goff[(b + 1) * 225 + c * 15 + k];
+            zv[q] = acc;
+          }
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int e = tid + q * 256;
+        if (e < M * 225) {
+          s_Kb[e]   = wv[q];  // W
+          s_Goff[e] = zv[q];  // Z
+        }
+      }
+      __syncthreads();
+    }
     return s_flag != 0;
   };
-  // solve K xt = xt in place (wave 0), banded forward / backward substitution
   auto solveK = [&]() {
-    if (wave == 0) {
+    if (use_blocks) {
+      const double *s_W = s_Kb, *s_Z = s_Goff;
+      // u = blockdiag(Ginv) rhs  — independent of the chain, all lanes
+      for (int j = tid; j < n; j += 256) {
+        const int     b = j / 15, r = j % 15;
+        const double *Gi = s_Ginv + b * 225 + r * 15;
+        double        acc = 0.0;
+        for (int c = 0; c <= r; ++c) acc += Gi[c] * s_xt[b * 15 + c];
+        s_cn[j] = acc;
+      }
+      __syncthreads();
+      // lane = (row r, part p): 4 lanes share one row's dot product; the previous block's result
+      // stays in registers (ds_bpermute gathers issued together, DPP quad reduction).
+      const int  r = lane >> 2, p = lane & 3;
+      const bool act = r < 15;
+      if (wave == 0) {
+        double prev = 0.0;
+        for (int b = 0; b < M; ++b) {  // y_b = u_b - W_b y_{b-1};  W_b is zero left of column 6
+          const double *Wr = s_W + b * 225 + r * 15;
+          const bool    on = act && b > 0;
+          const double  g0 = on ? Wr[6 + p] : 0.0, g1 = on ? Wr[10 + p] : 0.0,
+                       g2 = (on && p == 0) ? Wr[14] : 0.0;
+          const double u  = act ? s_cn[b * 15 + r] : 0.0;
+          const double y0 = __shfl(prev, (6 + p) * 4, 64), y1 = __shfl(prev, (10 + p) * 4, 64),
+                       y2 = __shfl(prev, 14 * 4, 64);
+          double acc = (g0 * y0 + g1 * y1) + g2 * y2;
+          acc += dpp_quad(acc, 0xB1);
+          acc += dpp_quad(acc, 0x4E);
+          prev = u - acc;
+          if (act && p == 0) s_xt[b * 15 + r] = prev;
+        }
+      }
+      __syncthreads();
+      // v = blockdiag(Ginv^T) y
+      for (int j = tid; j < n; j += 256) {
+        const int     b = j / 15, r = j % 15;
+        const double *Gi = s_Ginv + b * 225 + r;
+        double        acc = 0.0;
+        for (int c = r; c < 15; ++c) acc += Gi[c * 15] * s_xt[b * 15 + c];
+        s_cn[j] = acc;
+      }
+      __syncthreads();
+      if (wave == 0) {
+        double prev = 0.0;
+        for (int b = M - 1; b >= 0; --b) {  // x_b = v_b - Z_b x_{b+1};  Z_b is zero right of column 8
+          const double *Zr = s_Z + b * 225 + r * 15;
+          const bool    on = act && b < M - 1;
+          const double  g0 = on ? Zr[p] : 0.0, g1 = on ? Zr[4 + p] : 0.0, g2 = (on && p == 0) ? Zr[8] : 0.0;
+          const double  v  = act ? s_cn[b * 15 + r] : 0.0;
+          const double  x0 = __shfl(prev, p * 4, 64), x1 = __shfl(prev, (4 + p) * 4, 64),
+                       x2 = __shfl(prev, 8 * 4, 64);
+          double acc = (g0 * x0 + g1 * x1) + g2 * x2;
+          acc += dpp_quad(acc, 0xB1);
+          acc += dpp_quad(acc, 0x4E);
+          prev = v - acc;
+          if (act && p == 0) s_xt[b * 15 + r] = prev;
+        }
+      }
+    } else if (wave == 0) {
       for (int j = 0; j < n; ++j) {  // G y = b
         const double xj = s_xt[j] * s_ginv[j];
         if (lane == 0) s_xt[j] = xj;
@@ -482,30 +647,55 @@ __global__ __launch_bounds__(256) void k_qp(SogmPlannerParams pp, SogmQpSettings
     }
     __syncthreads();
   };
+  // (A^T y)_j : general rows first, then safety rows (global row order)
+  auto col_sum_y = [&](int j) -> double {
+    double a = 0;
+    for (int q = s_cptr[j]; q < s_cptr[j + 1]; ++q) {
+      const int en = R.cidx[q], r = en >> 3;
+      a += R.gval[(size_t)r * QP_ELL + (en & 7)] * R.gy[r];
+    }
+    COL_DECODE(j)
+    for (int f = 0; f < nface; ++f) {
+      const int s = sbase + 5 * f;
+      a += R.sval[(size_t)s * 3 + pd] * R.sy[s];
+    }
+    return a;
+  };
   // residual norms (unscaled), results in s_sc: 0 pr, 1 nAx, 2 nz, 3 dr, 4 nPx, 5 nAty, 6 nq(=0)
   auto residuals = [&]() {
     double pr = 0, nAx = 0, nz = 0;
-    for (int r = tid; r < m; r += 256) {
+    for (int r = tid; r < G; r += 256) {
       double s = 0;
       for (int k = 0; k < QP_ELL; ++k) {
-        const int c = pb.ecol[(size_t)r * QP_ELL + k];
-        if (c >= 0) s += pb.eval[(size_t)r * QP_ELL + k] * s_x[c];
+        const int c = R.gcol[(size_t)r * QP_ELL + k];
+        if (c >= 0) s += R.gval[(size_t)r * QP_ELL + k] * s_x[c];
       }
-      const double e = pb.E[r];
-      pr             = dmax(pr, dabs((s - pb.z[r]) / e));
+      const double e = R.gE[r];
+      pr             = dmax(pr, dabs((s - R.gz[r]) / e));
       nAx            = dmax(nAx, dabs(s / e));
-      nz             = dmax(nz, dabs(pb.z[r] / e));
+      nz             = dmax(nz, dabs(R.gz[r] / e));
+    }
+    for (int s = tid; s < S; s += 256) {
+      int i = 0;
+      while (i + 1 < M && s >= s_off[i + 1]) ++i;
+      const int     c0 = i * 15 + ((s - s_off[i]) % 5) * 3;
+      const double *v  = R.sval + (size_t)s * 3;
+      double        ax = 0;
+      ax += v[0] * s_x[c0];
+      ax += v[1] * s_x[c0 + 1];
+      ax += v[2] * s_x[c0 + 2];
+      const double e = R.sE[s];
+      pr             = dmax(pr, dabs((ax - R.sz[s]) / e));
+      nAx            = dmax(nAx, dabs(ax / e));
+      nz             = dmax(nz, dabs(R.sz[s] / e));
     }
     double dr = 0, nPx = 0, nAty = 0;
     for (int j = tid; j < n; j += 256) {
-      double        s  = 0, a = 0;
+      double        s  = 0;
       const double *Pb = s_P + (j / 15) * 225 + (j % 15) * 15;
       const int     b0 = (j / 15) * 15;
       for (int k = 0; k < 15; ++k) s += Pb[k] * s_x[b0 + k];
-      for (int q = pb.cptr[j]; q < pb.cptr[j + 1]; ++q) {
-        const int en = pb.cidx[q], r = en >> 3;
-        a += pb.eval[(size_t)r * QP_ELL + (en & 7)] * pb.y[r];
-      }
+      const double a  = col_sum_y(j);
       const double dj = s_D[j];
       dr              = dmax(dr, dabs((s + a) / dj));
       nPx             = dmax(nPx, dabs(s / dj));
@@ -539,36 +729,63 @@ __global__ __launch_bounds__(256) void k_qp(SogmPlannerParams pp, SogmQpSettings
   const double alpha = qs.alpha;
   if (chol_ok) {
     for (iter = 1; iter <= qs.max_iter; ++iter) {
-      for (int j = tid; j < n; j += 256) s_xp[j] = s_x[j];
-      for (int r = tid; r < m; r += 256) pb.w[r] = pb.rho[r] * pb.z[r] - pb.y[r];
-      __syncthreads();
+      // (a) rhs_j = sigma x_j - q_j + sum_rows A[r][j] (rho_r z_r - y_r)
+      if (!(ablate & 1))
       for (int j = tid; j < n; j += 256) {
-        double s = qs.sigma * s_xp[j];  // q == 0
-        for (int q = pb.cptr[j]; q < pb.cptr[j + 1]; ++q) {
-          const int en = pb.cidx[q], r = en >> 3;
-          s += pb.eval[(size_t)r * QP_ELL + (en & 7)] * pb.w[r];
+        double s = qs.sigma * s_x[j];  // q == 0
+        for (int q = s_cptr[j]; q < s_cptr[j + 1]; ++q) {
+          const int en = R.cidx[q], r = en >> 3;
+          s += R.gval[(size_t)r * QP_ELL + (en & 7)] * (R.grho[r] * R.gz[r] - R.gy[r]);
+        }
+        COL_DECODE(j)
+        for (int f = 0; f < nface; ++f) {
+          const int sr = sbase + 5 * f;
+          s += R.sval[(size_t)sr * 3 + pd] * R.sw[sr];
         }
         s_xt[j] = s;
       }
       __syncthreads();
-      solveK();
-      for (int j = tid; j < n; j += 256) s_x[j] = alpha * s_xt[j] + (1.0 - alpha) * s_xp[j];
-      for (int r = tid; r < m; r += 256) {
+      // (b) x~ = K^-1 rhs
+      if (!(ablate & 2)) solveK();
+      // (c) rows: z~ = A x~ ; z = proj(alpha z~ + (1-alpha) z + y/rho) ; y += rho (.. - z)
+      if (!(ablate & 4))
+      for (int r = tid; r < G; r += 256) {
         double s = 0;
         for (int k = 0; k < QP_ELL; ++k) {
-          const int c = pb.ecol[(size_t)r * QP_ELL + k];
-          if (c >= 0) s += pb.eval[(size_t)r * QP_ELL + k] * s_xt[c];
+          const int c = R.gcol[(size_t)r * QP_ELL + k];
+          if (c >= 0) s += R.gval[(size_t)r * QP_ELL + k] * s_xt[c];
         }
-        const double rho = pb.rho[r], yr = pb.y[r];
-        const double zr  = alpha * s + (1.0 - alpha) * pb.z[r];
+        const double rho = R.grho[r], yr = R.gy[r];
+        const double zr  = alpha * s + (1.0 - alpha) * R.gz[r];
         double       v   = zr + yr / rho;
-        const double lo = pb.l[r], hi = pb.u[r];
+        const double lo = R.gl[r], hi = R.gu[r];
         v               = v < lo ? lo : (v > hi ? hi : v);
-        pb.z[r]         = v;
+        R.gz[r]         = v;
         const double d  = rho * (zr - v);
-        pb.dy[r]        = d;
-        pb.y[r]         = yr + d;
+        R.gdy[r]        = d;
+        R.gy[r]         = yr + d;
       }
+      if (!(ablate & 8))
+      for (int s = tid; s < S; s += 256) {
+        const int     c0 = R.sc0[s];
+        const double *vv = R.sval + (size_t)s * 3;
+        double        ax = 0;
+        ax += vv[0] * s_xt[c0];
+        ax += vv[1] * s_xt[c0 + 1];
+        ax += vv[2] * s_xt[c0 + 2];
+        const double yr = R.sy[s];
+        const double zr = alpha * ax + (1.0 - alpha) * R.sz[s];
+        double       v  = zr + yr / rho_cur;
+        const double hi = R.su[s];
+        v               = v > hi ? hi : v;  // l = -OSQP_INFTY
+        R.sz[s]         = v;
+        const double d  = rho_cur * (zr - v);
+        R.sdy[s]        = d;
+        const double yn = yr + d;
+        R.sy[s]         = yn;
+        R.sw[s]         = rho_cur * v - yn;
+      }
+      for (int j = tid; j < n; j += 256) s_x[j] = alpha * s_xt[j] + (1.0 - alpha) * s_x[j];
       __syncthreads();
       const bool do_adapt = qs.adaptive_rho_interval > 0 && iter % qs.adaptive_rho_interval == 0;
       const bool do_check = qs.check_termination > 0 && iter % qs.check_termination == 0;
@@ -601,23 +818,28 @@ __global__ __launch_bounds__(256) void k_qp(SogmPlannerParams pp, SogmQpSettings
         // primal infeasibility certificate (eps_prim_inf = 1e-4), as in the oracle
         const double eps_inf = 1e-4;
         double       ndy     = 0;
-        for (int r = tid; r < m; r += 256) ndy = dmax(ndy, dabs(pb.E[r] * pb.dy[r]));
+        for (int r = tid; r < G; r += 256) ndy = dmax(ndy, dabs(R.gE[r] * R.gdy[r]));
+        for (int s = tid; s < S; s += 256) ndy = dmax(ndy, dabs(R.sE[s] * R.sdy[s]));
         ndy = block_max(ndy, s_red);
         __syncthreads();
         if (!p_ok && ndy > eps_inf) {
-          // lhs = sum u max(d,0) + l min(d,0); +inf when an infinite bound is pushed
           double lhs = 0;
           int    bad = 0;
-          for (int r = tid; r < m; r += 256) {
-            const double d = pb.dy[r] / ndy;
-            if (pb.u[r] < OSQP_INFTY * MIN_SCALING)
-              lhs += pb.u[r] * (d > 0 ? d : 0);
+          for (int r = tid; r < G; r += 256) {
+            const double d = R.gdy[r] / ndy;
+            if (R.gu[r] < OSQP_INFTY * MIN_SCALING)
+              lhs += R.gu[r] * (d > 0 ? d : 0);
             else if (d > eps_inf)
               bad = 1;
-            if (pb.l[r] > -OSQP_INFTY * MIN_SCALING)
-              lhs += pb.l[r] * (d < 0 ? d : 0);
+            if (R.gl[r] > -OSQP_INFTY * MIN_SCALING)
+              lhs += R.gl[r] * (d < 0 ? d : 0);
             else if (d < -eps_inf)
               bad = 1;
+          }
+          for (int s = tid; s < S; s += 256) {
+            const double d = R.sdy[s] / ndy;
+            lhs += R.su[s] * (d > 0 ? d : 0);
+            if (d < -eps_inf) bad = 1;  // l = -inf pushed
           }
           lhs = wave_sum(lhs);
           __syncthreads();
@@ -628,12 +850,17 @@ __global__ __launch_bounds__(256) void k_qp(SogmPlannerParams pp, SogmQpSettings
           if (!anybad && lhs < -eps_inf) {
             double na = 0;
             for (int j = tid; j < n; j += 256) {
-              double s = 0;
-              for (int q = pb.cptr[j]; q < pb.cptr[j + 1]; ++q) {
-                const int en = pb.cidx[q], r = en >> 3;
-                s += pb.eval[(size_t)r * QP_ELL + (en & 7)] * (pb.dy[r] / ndy);
+              double a = 0;
+              for (int q = s_cptr[j]; q < s_cptr[j + 1]; ++q) {
+                const int en = R.cidx[q], r = en >> 3;
+                a += R.gval[(size_t)r * QP_ELL + (en & 7)] * (R.gdy[r] / ndy);
               }
-              na = dmax(na, dabs(s / s_D[j]));
+              COL_DECODE(j)
+              for (int f = 0; f < nface; ++f) {
+                const int sr = sbase + 5 * f;
+                a += R.sval[(size_t)sr * 3 + pd] * (R.sdy[sr] / ndy);
+              }
+              na = dmax(na, dabs(a / s_D[j]));
             }
             na = block_max(na, s_red);
             __syncthreads();
@@ -661,6 +888,16 @@ __global__ __launch_bounds__(256) void k_qp(SogmPlannerParams pp, SogmQpSettings
     out_status[agent] = status;
     out_iters[agent]  = iter;
   }
+  };  // body
+  if (rows_in_lds) {
+    Rows R;
+    carve_rows(R, qp_smem + head, G, S);
+    body(R);
+  } else {
+    Rows R;
+    carve_rows(R, ws.scratch + (size_t)agent * ws.scratch_stride, G, S);
+    body(R);
+  }
 }
 
 int launch_qp(const SogmPlannerParams &pp, const SogmQpSettings &qs, const QpWorkspace &ws,
@@ -673,8 +910,14 @@ int launch_qp(const SogmPlannerParams &pp, const SogmQpSettings &qs, const QpWor
                               ws.dyn_lds_bytes);
     attr_set = true;
   }
+  // SOGM_QP_ABLATE (profiling aid only): bit0 skip A^T w, bit1 skip the solve, bit2/3 skip row updates
+  static int ablate = -1;
+  if (ablate < 0) {
+    const char *e = getenv("SOGM_QP_ABLATE");
+    ablate        = e ? atoi(e) : 0;
+  }
   hipLaunchKernelGGL(k_qp, dim3(n_agents), dim3(256), ws.dyn_lds_bytes, st, pp, qs, ws, qc, start_pva,
-                     goal_pv, polys, nfaces, npoly, out_cpts, out_status, out_iters);
+                     goal_pv, polys, nfaces, npoly, out_cpts, out_status, out_iters, ablate);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

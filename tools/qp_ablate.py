@@ -1,0 +1,30 @@
+"""Profiling aid: fixed-iteration QP timing with phases ablated (SOGM_QP_ABLATE bitmask)."""
+import importlib, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+pop = importlib.import_module("pred-occ-planner_amd")
+driver = importlib.import_module("pred-occ-planner_amd.driver")
+planner = importlib.import_module("pred-occ-planner_amd.planner")
+A = 128
+sw = driver.SwarmTick("cfg2", A)
+sw.map.set_profiling(True)
+P = sw.planner
+stamp = sw.t0 + sw.tick * driver.TICK_PERIOD
+stamps = torch.full((A,), stamp, dtype=torch.float64, device="cuda")
+t_start = stamps + driver.REPLAN_START_TIME
+pva, valid = planner.traj_eval(sw.own, t_start)
+pva = torch.where(valid.bool().unsqueeze(1), pva, sw.hover).contiguous()
+poses = pva[:, :3].to(torch.float32).contiguous()
+sw.map.updateMap(sw.dev["cloud"], sw.dev["cloud_range"], sw.dev["cylinders"], sw.dev["n_cyl"], poses, stamps)
+sw.map.addOtherAgents(sw.all, A, sw.dev["ego_ids"])
+s = P.search(pva, sw.goals, t_start)
+c = P.generateCorridors(pva, t_start, s["route"], s["route_len"])
+qs = pop.config.make_qp_settings()
+qs.max_iter = 1000
+qs.check_termination = 0
+qs.adaptive_rho_interval = 0
+P2 = planner.SogmPlanner(sw.map, pop.config.make_astar_params(), pop.config.make_planner_params(True), qs)
+for _ in range(2):
+    q = P2.optimize(pva, c["goal"], c["polys"], c["nfaces"], c["npoly"])
+    ms = sw.map.profile_read()
+print("ablate", os.environ.get("SOGM_QP_ABLATE", "0"), "qp ms for 1000 fixed iterations:", round(ms[5], 3), "-> us/iter", round(ms[5], 3))
