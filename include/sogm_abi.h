@@ -186,6 +186,15 @@ int sogm_set_profiling(sogm_ctx *ctx, int enable);
  * (negative if that slot has not run since profiling was enabled).  host out_ms[SOGM_PROF_N]. */
 int sogm_profile_read(sogm_ctx *ctx, double *out_ms_host);
 
+/*
+ * Tick pipelining: with overlap enabled, sogm_replan() launches the NEXT update's grid clear on an
+ * internal side stream as soon as its corridor stage has finished reading the SOGM (the QP stage
+ * does not touch the grid), so the HBM-bound clear runs under the latency-bound QP.  The next
+ * sogm_update_gt() then waits for that clear instead of issuing its own.  While a pre-clear is
+ * pending the map counts as "not updated": queries return SOGM_ERR_STATE until the next update.
+ */
+int sogm_set_overlap_clear(sogm_ctx *ctx, int enable);
+
 /* ------------------------------------------------------------------------------------------ */
 /* SOGM update                                                                                 */
 /* ------------------------------------------------------------------------------------------ */

@@ -84,6 +84,7 @@ PROTOTYPES = {
     "sogm_grid_bytes": (C.c_int64, [_vp]),
     "sogm_grid_ptr": (_vp, [_vp]),
     "sogm_set_body_particles": (_i, [_vp, C.POINTER(C.c_double), _i]),
+    "sogm_set_overlap_clear": (_i, [_vp, _i]),
     "sogm_set_profiling": (_i, [_vp, _i]),
     "sogm_profile_read": (_i, [_vp, C.POINTER(C.c_double)]),
     "sogm_update_gt": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),

@@ -195,6 +195,10 @@ struct sogm_ctx {
   int            n_body;
   int            updated;
   float         *d_scratch_vt;  // [V][T] staging for download / upload
+  int            overlap;     // tick pipelining enabled
+  int            precleared;  // a side-stream clear for the next update is in flight
+  hipStream_t    side;
+  hipEvent_t     ev_grid_free, ev_cleared;
   int            profiling;
   hipEvent_t     ev[SOGM_PROF_N][2];
   int            ev_used[SOGM_PROF_N];
@@ -224,6 +228,7 @@ inline MapView view_of(const sogm_ctx *c) {
   return m;
 }
 void set_error(const char *what, hipError_t e);
+int  launch_clear(sogm_ctx *c, hipStream_t st);
 }  // namespace sogm
 
 #define SOGM_HIP_CHECK(expr)                    \

@@ -368,6 +368,20 @@ __global__ __launch_bounds__(64) void k_traj_eval(const SogmTrajRecord *__restri
   ok[i] = 1;
 }
 
+int launch_clear(sogm_ctx *c, hipStream_t st) {
+  const size_t n    = (size_t)c->n_agents * c->spec.T * (size_t)c->geom.V;
+  const size_t nv4  = n / 4;
+  const int    tail = (int)(n - nv4 * 4);
+  size_t       want = (nv4 + 255) / 256;
+  const int    nblk = (int)(want < 1 ? 1 : (want > 2048 ? 2048 : want));
+  prof_begin(c, SOGM_PROF_CLEAR, st);
+  hipLaunchKernelGGL(k_clear_slabs, dim3(nblk), dim3(256), 0, st, (vfloat4 *)c->d_grid, nv4,
+                     c->d_grid + nv4 * 4, tail);
+  prof_end(c, SOGM_PROF_CLEAR, st);
+  SOGM_HIP_CHECK(hipGetLastError());
+  return SOGM_OK;
+}
+
 }  // namespace sogm
 
 using namespace sogm;
@@ -413,6 +427,9 @@ int sogm_create(const SogmSpec *spec, int n_agents, int device, sogm_ctx **out) 
   if (e == hipSuccess) e = hipMalloc(&c->d_scratch_vt, sizeof(float) * (size_t)c->geom.V * spec->T);
   if (e == hipSuccess) e = hipMemset(c->d_poses, 0, sizeof(float) * 3 * n_agents);
   if (e == hipSuccess) e = hipMemset(c->d_stamps, 0, sizeof(double) * n_agents);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_grid_free, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_cleared, hipEventDisableTiming);
   for (int k = 0; k < SOGM_PROF_N && e == hipSuccess; ++k) {
     e = hipEventCreate(&c->ev[k][0]);
     if (e == hipSuccess) e = hipEventCreate(&c->ev[k][1]);
@@ -433,6 +450,12 @@ void sogm_destroy(sogm_ctx *c) {
   if (c->d_stamps) (void)hipFree(c->d_stamps);
   if (c->d_body) (void)hipFree(c->d_body);
   if (c->d_scratch_vt) (void)hipFree(c->d_scratch_vt);
+  if (c->side) {
+    (void)hipStreamSynchronize(c->side);
+    (void)hipStreamDestroy(c->side);
+  }
+  if (c->ev_grid_free) (void)hipEventDestroy(c->ev_grid_free);
+  if (c->ev_cleared) (void)hipEventDestroy(c->ev_cleared);
   for (int k = 0; k < SOGM_PROF_N; ++k) {
     if (c->ev[k][0]) (void)hipEventDestroy(c->ev[k][0]);
     if (c->ev[k][1]) (void)hipEventDestroy(c->ev[k][1]);
@@ -444,6 +467,12 @@ int64_t sogm_grid_bytes(const sogm_ctx *c) {
   return c ? (int64_t)c->n_agents * c->spec.T * (int64_t)c->geom.V * 4 : 0;
 }
 float *sogm_grid_ptr(sogm_ctx *c) { return c ? c->d_grid : nullptr; }
+
+int sogm_set_overlap_clear(sogm_ctx *c, int enable) {
+  if (!c) return SOGM_ERR_INVALID_ARG;
+  c->overlap = enable ? 1 : 0;
+  return SOGM_OK;
+}
 
 int sogm_set_profiling(sogm_ctx *c, int enable) {
   if (!c) return SOGM_ERR_INVALID_ARG;
@@ -474,19 +503,7 @@ int sogm_set_body_particles(sogm_ctx *c, const double *xyz, int n) {
   return SOGM_OK;
 }
 
-static int clear_grid(sogm_ctx *c, hipStream_t st) {
-  const size_t n    = (size_t)c->n_agents * c->spec.T * (size_t)c->geom.V;
-  const size_t nv4  = n / 4;
-  const int    tail = (int)(n - nv4 * 4);
-  size_t       want = (nv4 + 255) / 256;
-  const int    nblk = (int)(want < 1 ? 1 : (want > 2048 ? 2048 : want));
-  prof_begin(c, SOGM_PROF_CLEAR, st);
-  hipLaunchKernelGGL(k_clear_slabs, dim3(nblk), dim3(256), 0, st, (vfloat4 *)c->d_grid, nv4,
-                     c->d_grid + nv4 * 4, tail);
-  prof_end(c, SOGM_PROF_CLEAR, st);
-  SOGM_HIP_CHECK(hipGetLastError());
-  return SOGM_OK;
-}
+static int clear_grid(sogm_ctx *c, hipStream_t st) { return sogm::launch_clear(c, st); }
 
 int sogm_update_gt(sogm_ctx *c, const float *cloud_xyz, const int32_t *cloud_range,
                    const SogmCylinder *cylinders, int n_cyl, const float *poses,
@@ -499,8 +516,14 @@ int sogm_update_gt(sogm_ctx *c, const float *cloud_xyz, const int32_t *cloud_ran
                                 hipMemcpyDeviceToDevice, st));
   SOGM_HIP_CHECK(hipMemcpyAsync(c->d_stamps, stamps, sizeof(double) * c->n_agents,
                                 hipMemcpyDeviceToDevice, st));
-  int rc = clear_grid(c, st);
-  if (rc) return rc;
+  if (c->precleared) {
+    // the grid was already cleared on the side stream during the previous tick's QP stage
+    SOGM_HIP_CHECK(hipStreamWaitEvent(st, c->ev_cleared, 0));
+    c->precleared = 0;
+  } else {
+    int rc = clear_grid(c, st);
+    if (rc) return rc;
+  }
   // 32 workgroups of 256 lanes per agent stride over that agent's cloud range
   prof_begin(c, SOGM_PROF_STAMP, st);
   hipLaunchKernelGGL(k_stamp_cloud, dim3(32, c->n_agents), dim3(256), 0, st, c->geom, c->d_grid,
@@ -536,6 +559,10 @@ int sogm_set_future_risk(sogm_ctx *c, const float *grid_vt, const float *poses,
                                 hipMemcpyDeviceToDevice, st));
   SOGM_HIP_CHECK(hipMemcpyAsync(c->d_stamps, stamps, sizeof(double) * c->n_agents,
                                 hipMemcpyDeviceToDevice, st));
+  if (c->precleared) {
+    SOGM_HIP_CHECK(hipStreamWaitEvent(st, c->ev_cleared, 0));
+    c->precleared = 0;
+  }
   const int    V = c->geom.V, T = c->spec.T;
   const size_t per = (size_t)V * T;
   for (int a = 0; a < c->n_agents; ++a) {

@@ -217,6 +217,18 @@ int sogm_replan(sogm_planner *p, const double *start_pva, const double *goal,
   rc = sogm_corridor_generate(p, start_pva, t_start, p->d_route, p->d_route_len, p->route_cap,
                               p->d_polys, p->d_nfaces, p->d_npoly, p->d_goal, stream);
   if (rc) return rc;
+  if (p->map->overlap) {
+    // the corridor stage was the last reader of the SOGM in this tick: clear it for the next
+    // update on the side stream, under the QP stage
+    sogm_ctx *c = p->map;
+    SOGM_HIP_CHECK(hipEventRecord(c->ev_grid_free, (hipStream_t)stream));
+    SOGM_HIP_CHECK(hipStreamWaitEvent(c->side, c->ev_grid_free, 0));
+    rc = sogm::launch_clear(c, c->side);
+    if (rc) return rc;
+    SOGM_HIP_CHECK(hipEventRecord(c->ev_cleared, c->side));
+    c->precleared = 1;
+    c->updated    = 0;
+  }
   rc = sogm_bezier_qp_solve(p, start_pva, p->d_goal, p->d_polys, p->d_nfaces, p->d_npoly,
                             p->d_cpts, p->d_status, p->d_iters, stream);
   if (rc) return rc;

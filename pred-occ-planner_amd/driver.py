@@ -46,7 +46,7 @@ def merge_latest(new, old, ok):
 
 class SwarmTick:
     def __init__(self, grid="cfg2", agents_per_rank=None, rank=0, world=1, device=0, seed=0x5069,
-                 spec=None, scene=None, dist=None):
+                 spec=None, scene=None, dist=None, overlap_clear=True):
         self.rank, self.world, self.dist = rank, world, dist
         self.spec = spec if spec is not None else config.make_spec(grid)
         self.A_loc = agents_per_rank if agents_per_rank is not None else config.AGENTS.get(grid, 4)
@@ -61,6 +61,7 @@ class SwarmTick:
         torch.cuda.set_device(device)
         self.dev = upload_scene(loc)
         self.map = SogmMap(self.spec, self.A_loc, device)
+        self.map.set_overlap_clear(overlap_clear)
         self.planner = SogmPlanner(self.map, config.make_astar_params(), config.make_planner_params(True),
                                    config.make_qp_settings())
         d = "cuda"

@@ -67,6 +67,10 @@ class SogmMap:
     def grid_bytes(self):
         return int(lib().sogm_grid_bytes(self._ctx))
 
+    def set_overlap_clear(self, on=True):
+        """Tick pipelining: replan() pre-clears the grid for the next update under its QP stage."""
+        check(lib().sogm_set_overlap_clear(self._ctx, 1 if on else 0), "sogm_set_overlap_clear")
+
     # ---- profiling (HIP events around each kernel, on the caller's stream) ----
     def set_profiling(self, on=True):
         check(lib().sogm_set_profiling(self._ctx, 1 if on else 0), "sogm_set_profiling")
