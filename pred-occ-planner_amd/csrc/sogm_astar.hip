@@ -142,7 +142,16 @@ __device__ inline double estimate_heuristic(const SogmAstarParams &ap, const dou
   return 1.0 * (1 + tie_breaker) * cost;
 }
 
-// ---- per-agent search state in global memory ---------------------------------------------------
+// ---- per-agent search state ---------------------------------------------------------------------
+// Node records live in HBM (128 B each, written once per new node, re-read only on the final path).
+// What the serial master loop touches on its critical path is on-chip:
+//   * the open list (binary heap of node ids) and an f-score mirror are in LDS;
+//   * the closed/open hash is probed by all lanes in parallel BEFORE the ordered merge (an entry
+//     inserted during an expansion can never change that expansion's outcome: a later child that
+//     would find it is in the same (voxel, time index) as the inserting child and is therefore
+//     pruned by the same-parent rule first, :345-362) and filled by all lanes in parallel AFTER it;
+//   * each hash slot is one 64-bit word {13-bit x, y, z, 9-bit t, 14-bit node id} claimed by CAS,
+//     so a probe is a single load and concurrent inserts need no lock.
 struct __attribute__((aligned(16))) Node {
   double state[6];
   double input[3];
@@ -155,66 +164,63 @@ struct __attribute__((aligned(16))) Node {
   int    node_state;
 };  // 128 B
 
-struct Work {
-  Node *pool;      // [allocate_num]
-  int  *heap;      // [allocate_num]
-  int4 *hkeys;     // [hash_cap]
-  int  *hvals;     // [hash_cap], -1 = empty
-  int   hash_cap;  // power of two
-};
+#define ASTAR_POOL_MAX 10240  // LDS f mirror: 80 KB
+#define HASH_EMPTY 0xFFFFFFFFFFFFFFFFull
 
-__device__ inline unsigned hash4(int a, int b, int c, int d) {
-  unsigned h = 0x9e3779b9u;
-  h ^= (unsigned)a + 0x9e3779b9u + (h << 6) + (h >> 2);
-  h ^= (unsigned)b + 0x9e3779b9u + (h << 6) + (h >> 2);
-  h ^= (unsigned)c + 0x9e3779b9u + (h << 6) + (h >> 2);
-  h ^= (unsigned)d + 0x9e3779b9u + (h << 6) + (h >> 2);
-  return h;
+__device__ inline bool pack_ok(int a, int b, int c, int t) {
+  return a >= -4096 && a < 4096 && b >= -4096 && b < 4096 && c >= -4096 && c < 4096 && t >= -256 && t < 256;
+}
+__device__ inline unsigned long long pack_key(int a, int b, int c, int t) {
+  return ((unsigned long long)(a + 4096) << 49) | ((unsigned long long)(b + 4096) << 36) |
+         ((unsigned long long)(c + 4096) << 23) | ((unsigned long long)(t + 256) << 14);
+}
+__device__ inline unsigned hash_of(unsigned long long k) {
+  k ^= k >> 33;
+  k *= 0xff51afd7ed558ccdull;
+  k ^= k >> 33;
+  return (unsigned)k;
 }
 // NodeHashTable::find (path_node.h:86-89)
-__device__ inline int hash_find(const Work &w, int a, int b, int c, int d) {
-  unsigned s = hash4(a, b, c, d) & (w.hash_cap - 1);
+__device__ inline int hash_find(const unsigned long long *tab, int cap, unsigned long long key) {
+  unsigned s = hash_of(key) & (cap - 1);
   while (true) {
-    const int v = w.hvals[s];
-    if (v < 0) return -1;
-    const int4 k = w.hkeys[s];
-    if (k.x == a && k.y == b && k.z == c && k.w == d) return v;
-    s = (s + 1) & (w.hash_cap - 1);
+    const unsigned long long v = __hip_atomic_load(tab + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (v == HASH_EMPTY) return -1;
+    if ((v & ~0x3FFFull) == key) return (int)(v & 0x3FFF);
+    s = (s + 1) & (cap - 1);
   }
 }
 // NodeHashTable::insert (path_node.h:79-82): unordered_map::insert keeps an existing entry
-__device__ inline void hash_insert(const Work &w, int a, int b, int c, int d, int val) {
-  unsigned s = hash4(a, b, c, d) & (w.hash_cap - 1);
+__device__ inline void hash_insert(unsigned long long *tab, int cap, unsigned long long key, int val) {
+  unsigned s = hash_of(key) & (cap - 1);
   while (true) {
-    const int v = w.hvals[s];
-    if (v < 0) {
-      w.hkeys[s] = make_int4(a, b, c, d);
-      w.hvals[s] = val;
+    unsigned long long expect = HASH_EMPTY;
+    if (__hip_atomic_compare_exchange_strong(tab + s, &expect, key | (unsigned long long)val,
+                                             __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                             __HIP_MEMORY_SCOPE_AGENT))
       return;
-    }
-    const int4 k = w.hkeys[s];
-    if (k.x == a && k.y == b && k.z == c && k.w == d) return;
-    s = (s + 1) & (w.hash_cap - 1);
+    if ((expect & ~0x3FFFull) == key) return;
+    s = (s + 1) & (cap - 1);
   }
 }
 
-// libstdc++ std::push_heap / std::pop_heap with NodeComparator (f(a) > f(b)), restated.
-__device__ inline bool heap_cmp(const Node *pool, int a, int b) { return pool[a].f > pool[b].f; }
-__device__ inline void heap_push_up(const Node *pool, int *h, int hole, int top, int value) {
+// libstdc++ std::push_heap / std::pop_heap with NodeComparator (f(a) > f(b)), restated on an LDS
+// heap of node ids with the f-scores mirrored in LDS.
+__device__ inline void heap_push_up(const double *f, unsigned short *h, int hole, int top, int value) {
   int parent = (hole - 1) / 2;
-  while (hole > top && heap_cmp(pool, h[parent], value)) {
+  while (hole > top && f[h[parent]] > f[value]) {
     h[hole] = h[parent];
     hole    = parent;
     parent  = (hole - 1) / 2;
   }
-  h[hole] = value;
+  h[hole] = (unsigned short)value;
 }
-__device__ inline void heap_push(const Node *pool, int *h, int &n, int value) {
-  h[n] = value;
+__device__ inline void heap_push(const double *f, unsigned short *h, int &n, int value) {
+  h[n] = (unsigned short)value;
   ++n;
-  heap_push_up(pool, h, n - 1, 0, value);
+  heap_push_up(f, h, n - 1, 0, value);
 }
-__device__ inline void heap_pop(const Node *pool, int *h, int &n) {
+__device__ inline void heap_pop(const double *f, unsigned short *h, int &n) {
   if (n > 1) {
     // __pop_heap(first, last-1, last-1): value = *(last-1); *(last-1) = *first; adjust(first,0,len-1)
     const int value = h[n - 1];
@@ -224,7 +230,7 @@ __device__ inline void heap_pop(const Node *pool, int *h, int &n) {
     int       child = 0;
     while (child < (len - 1) / 2) {
       child = 2 * (child + 1);
-      if (heap_cmp(pool, h[child], h[child - 1])) child--;
+      if (f[h[child]] > f[h[child - 1]]) child--;
       h[hole] = h[child];
       hole    = child;
     }
@@ -233,7 +239,7 @@ __device__ inline void heap_pop(const Node *pool, int *h, int &n) {
       h[hole] = h[child - 1];
       hole    = child - 1;
     }
-    heap_push_up(pool, h, hole, 0, value);
+    heap_push_up(f, h, hole, 0, value);
   }
   --n;
 }
@@ -244,7 +250,10 @@ struct Cand {
   double g, f;
   int    id[3];
   int    t_id;
-  int    flags;  // bit0: velocity ok, bit1: not same (voxel,time) as parent, bit2: occupied
+  int    flags;     // bit0 velocity ok, bit1 not same (voxel,time) as parent, bit2 occupied
+  int    found;     // node id found in the hash for (id, t_id), -1 if none
+  int    found_st;  // its node_state
+  int    _pad;
 };
 
 #define ASTAR_MAX_INPUTS 128
@@ -267,22 +276,28 @@ __global__ __launch_bounds__(64) void k_astar(
   const int agent = blockIdx.x;
   const int lane  = threadIdx.x;
 
-  __shared__ double s_inputs[ASTAR_MAX_INPUTS][3];
-  __shared__ int    s_n_inputs;
-  __shared__ Cand   s_cand[ASTAR_MAX_INPUTS];
-  __shared__ double s_cur_state[6];
-  __shared__ double s_cur_time, s_cur_g;
-  __shared__ int    s_cur_index[3], s_cur_tidx;
-  __shared__ int    s_n_active;   // number of primitives of this expansion (0 = stop)
-  __shared__ int    s_first;      // 1 = "init" expansion (single input = start acc)
-  __shared__ int    s_tmp[ASTAR_MAX_INPUTS];
+  __shared__ double         s_f[ASTAR_POOL_MAX];     // f-score mirror of every allocated node
+  __shared__ unsigned short s_heap[ASTAR_POOL_MAX];  // open list
+  __shared__ double         s_inputs[ASTAR_MAX_INPUTS][3];
+  __shared__ int            s_n_inputs;
+  __shared__ Cand           s_cand[ASTAR_MAX_INPUTS];
+  __shared__ double         s_cur_state[6];
+  __shared__ double         s_cur_time, s_cur_g;
+  __shared__ int            s_cur_index[3], s_cur_tidx;
+  __shared__ int            s_n_active;  // primitives of this expansion (0 = stop)
+  __shared__ int            s_first;     // 1 = "init" expansion (single input = start acc)
+  __shared__ int            s_tmp[ASTAR_MAX_INPUTS];     // nodes created by this expansion
+  __shared__ unsigned long long s_ins_key[ASTAR_MAX_INPUTS];  // hash keys to insert for them
+  __shared__ int            s_n_new;
+  __shared__ int            s_ret;
+  __shared__ int            s_leader[ASTAR_MAX_INPUTS];   // first gate-passing child with the same key
+  __shared__ int            s_slot_of[ASTAR_MAX_INPUTS];  // child -> slot of the node it created
+  __shared__ int            s_src[ASTAR_MAX_INPUTS];      // slot -> child whose data the node takes
+  __shared__ int            s_was_first, s_cur_node;
 
-  Work w;
-  w.pool     = (Node *)(wsp.pool + (size_t)agent * wsp.pool_stride);
-  w.heap     = wsp.heap + (size_t)agent * ap.allocate_num;
-  w.hkeys    = (int4 *)wsp.hkeys + (size_t)agent * wsp.hash_cap;
-  w.hvals    = wsp.hvals + (size_t)agent * wsp.hash_cap;
-  w.hash_cap = wsp.hash_cap;
+  Node               *pool = (Node *)(wsp.pool + (size_t)agent * wsp.pool_stride);
+  unsigned long long *htab = (unsigned long long *)wsp.hkeys + (size_t)agent * wsp.hash_cap;
+  const int           hcap = wsp.hash_cap;
 
   const double *pva = start_pva + agent * 9;
   double        start_pt[3] = {pva[0], pva[1], pva[2]};
@@ -323,8 +338,8 @@ __global__ __launch_bounds__(64) void k_astar(
   bool is_shot_succ = false;
 
   for (int attempt = 0; attempt < 2; ++attempt) {  // baseline_fake.cpp:284-291
-    // reset(): clear the hash table (all lanes), node states are rewritten on allocation
-    for (int i = lane; i < w.hash_cap; i += 64) w.hvals[i] = -1;
+    // reset(): clear the hash table (all lanes)
+    for (int i = lane; i < hcap; i += 64) htab[i] = HASH_EMPTY;
     __syncthreads();
     bool done = false;
     if (lane == 0) {
@@ -333,8 +348,9 @@ __global__ __launch_bounds__(64) void k_astar(
       heap_n       = 0;
       is_shot_succ = false;
       terminal     = -1;
+      ret          = NO_PATH;
       ++searches;
-      Node &n0  = w.pool[0];
+      Node &n0  = pool[0];
       n0.parent = -1;
       for (int i = 0; i < 3; ++i) {
         n0.state[i]     = start_pt[i];
@@ -344,14 +360,21 @@ __global__ __launch_bounds__(64) void k_astar(
       n0.g = 0.0;
       double ttg;
       n0.f          = ap.lambda_heu * estimate_heuristic(ap, n0.state, end_state, ttg);
+      s_f[0]        = n0.f;
       n0.node_state = IN_OPEN_SET;
-      heap_push(w.pool, w.heap, heap_n, 0);
+      heap_push(s_f, s_heap, heap_n, 0);
       use_node_num += 1;
       n0.time     = time_start;
       n0.time_idx = (int)floor((time_start - time_origin) * inv_tres);
-      hash_insert(w, n0.index[0], n0.index[1], n0.index[2], n0.time_idx, 0);
+      if (pack_ok(n0.index[0], n0.index[1], n0.index[2], n0.time_idx))
+        hash_insert(htab, hcap, pack_key(n0.index[0], n0.index[1], n0.index[2], n0.time_idx), 0);
+      else
+        ret = SEARCH_ERR;
       s_first = attempt == 0 ? 1 : 0;
+      s_ret   = ret;
     }
+    __syncthreads();
+    if (s_ret == SEARCH_ERR) done = true;
     int cur = -1;
     while (!done) {
       // ---------------- master: pop / terminate ----------------
@@ -360,8 +383,8 @@ __global__ __launch_bounds__(64) void k_astar(
         if (heap_n == 0) {
           ret = NO_PATH;  // open set empty (:419-422)
         } else {
-          cur         = w.heap[0];
-          Node &cn    = w.pool[cur];
+          cur          = s_heap[0];
+          Node &cn     = pool[cur];
           double d3[3] = {cn.state[0] - start_pt[0], cn.state[1] - start_pt[1],
                           cn.state[2] - start_pt[2]};
           const bool reach_horizon = sogm_det::sqrt_rn(dot3(d3, d3)) >= ap.horizon;
@@ -413,7 +436,7 @@ __global__ __launch_bounds__(64) void k_astar(
             stop = true;
           }
           if (!stop) {
-            heap_pop(w.pool, w.heap, heap_n);
+            heap_pop(s_f, s_heap, heap_n);
             cn.node_state = IN_CLOSE_SET;
             iter_num += 1;
             if (out_trace && n_trace < trace_cap) out_trace[(size_t)agent * trace_cap + n_trace] = cur;
@@ -433,7 +456,7 @@ __global__ __launch_bounds__(64) void k_astar(
         done = true;
         break;
       }
-      // ---------------- all lanes: evaluate the primitives ----------------
+      // ---------------- all lanes: evaluate the primitives + probe the hash ----------------
       const bool first = s_first != 0;
       for (int i = lane; i < n_act; i += 64) {
         double um[3];
@@ -460,7 +483,15 @@ __global__ __launch_bounds__(64) void k_astar(
         const bool same = c.id[0] == s_cur_index[0] && c.id[1] == s_cur_index[1] &&
                           c.id[2] == s_cur_index[2] && (c.t_id - s_cur_tidx) == 0;
         if (!same) flags |= 2;
-        if ((flags & 3) == 3) {
+        // closed / open lookup (:271): find(pro_id, pro_t_id)
+        int found = -1, found_st = NOT_EXPAND;
+        if (pack_ok(c.id[0], c.id[1], c.id[2], c.t_id)) {
+          found = hash_find(htab, hcap, pack_key(c.id[0], c.id[1], c.id[2], c.t_id));
+          if (found >= 0) found_st = pool[found].node_state;
+        } else {
+          flags |= 8;  // index outside the packable range
+        }
+        if ((flags & 3) == 3 && !(found >= 0 && found_st == IN_CLOSE_SET)) {
           // collision gate (:296-331)
           for (int k = 1; k <= ap.check_num; ++k) {
             const double dt = tau * (double)k / (double)ap.check_num;
@@ -479,97 +510,137 @@ __global__ __launch_bounds__(64) void k_astar(
           }
         }
         for (int q = 0; q < 6; ++q) c.state[q] = ps[q];
-        c.flags = flags;
+        c.flags    = flags;
+        c.found    = found;
+        c.found_st = found_st;
       }
       __syncthreads();
-      // ---------------- master: ordered merge (:255-414) ----------------
+      // ---------------- all lanes: same-parent duplicate detection (:345-362) ----------------
+      // The reference scans the nodes created so far by this expansion for one in the same
+      // (voxel, time index).  Equivalent and parallel: the "leader" of child i is the first child
+      // j <= i that passes the gates and has the same key; a non-leader is pruned against its leader.
+      for (int i = lane; i < n_act; i += 64) {
+        const Cand &c   = s_cand[i];
+        const bool gate = (c.flags & 7) == 3 && !(c.found >= 0 && c.found_st == IN_CLOSE_SET);
+        int        L    = i;
+        if (gate) {
+          for (int j = 0; j < i; ++j) {
+            const Cand &o = s_cand[j];
+            const bool og = (o.flags & 7) == 3 && !(o.found >= 0 && o.found_st == IN_CLOSE_SET);
+            if (og && o.id[0] == c.id[0] && o.id[1] == c.id[1] && o.id[2] == c.id[2] && j < L) L = j;
+          }
+        }
+        s_leader[i] = gate ? L : -1;
+      }
+      __syncthreads();
+      // ---------------- master: ordered merge (:255-414), decisions only ----------------
+      const double tau    = ap.time_resolution;
+      const double new_t  = s_cur_time + tau;
+      const int    new_ti = (int)floor((new_t - time_origin) * inv_tres);
       if (lane == 0) {
-        int        n_tmp = 0;
+        int        n_tmp     = 0;
         const bool was_first = s_first != 0;
-        s_first    = 0;  // init_search = false after the first expansion (:243)
+        s_first              = 0;  // init_search = false after the first expansion (:243)
+        s_was_first          = was_first ? 1 : 0;
         for (int i = 0; i < n_act && !done; ++i) {
+          const int L = s_leader[i];
+          if (L < 0) continue;  // closed, too fast, same cell as the parent, or in collision
           const Cand &c = s_cand[i];
-          int pro_node  = hash_find(w, c.id[0], c.id[1], c.id[2], c.t_id);
-          if (pro_node >= 0 && w.pool[pro_node].node_state == IN_CLOSE_SET) continue;
-          if (!(c.flags & 1)) continue;
-          if (!(c.flags & 2)) continue;
-          if (c.flags & 4) continue;
-          const double tau = ap.time_resolution;
-          double       um[3];
-          if (was_first) {
-            um[0] = start_a[0];
-            um[1] = start_a[1];
-            um[2] = start_a[2];
-          } else {
-            um[0] = s_inputs[i][0];
-            um[1] = s_inputs[i][1];
-            um[2] = s_inputs[i][2];
+          if (c.flags & 8) {
+            ret  = SEARCH_ERR;
+            done = true;
+            break;
           }
-          bool prune = false;
-          for (int j = 0; j < n_tmp; ++j) {
-            Node &en = w.pool[s_tmp[j]];
-            if (c.id[0] == en.index[0] && c.id[1] == en.index[1] && c.id[2] == en.index[2] &&
-                c.t_id == en.time_idx) {
-              prune = true;
-              if (c.f < en.f) {
-                en.f = c.f;
-                en.g = c.g;
-                for (int q = 0; q < 6; ++q) en.state[q] = c.state[q];
-                for (int q = 0; q < 3; ++q) en.input[q] = um[q];
-                en.duration = tau;
-                en.time     = s_cur_time + tau;
+          if (c.found < 0) {
+            if (L == i) {  // first child in this (voxel, time index): new node
+              const int node = use_node_num;
+              const int slot = n_tmp++;
+              s_slot_of[i]   = slot;
+              s_tmp[slot]    = node;
+              s_src[slot]    = i;
+              s_f[node]      = c.f;
+              heap_push(s_f, s_heap, heap_n, node);
+              if (pack_ok(c.id[0], c.id[1], c.id[2], (int)new_t)) {
+                // :387 quirk — insert(pro_id, pro_node->time, ...): double -> int truncation
+                s_ins_key[slot] = pack_key(c.id[0], c.id[1], c.id[2], (int)new_t);
+              } else {
+                ret  = SEARCH_ERR;
+                done = true;
               }
-              break;
+              use_node_num += 1;
+              if (use_node_num == ap.allocate_num) {  // "run out of memory" (:393-396)
+                ret  = NO_PATH;
+                done = true;
+              }
+            } else {  // pruned against the node its leader created; keep the better of the two
+              const int slot = s_slot_of[L];
+              const int e    = s_tmp[slot];
+              if (c.f < s_f[e]) {
+                s_f[e]      = c.f;
+                s_src[slot] = i;
+              }
             }
-          }
-          if (prune) continue;
-          if (pro_node < 0) {
-            pro_node = use_node_num;
-            Node &pn = w.pool[pro_node];
-            for (int q = 0; q < 3; ++q) pn.index[q] = c.id[q];
-            for (int q = 0; q < 6; ++q) pn.state[q] = c.state[q];
-            pn.f = c.f;
-            pn.g = c.g;
-            for (int q = 0; q < 3; ++q) pn.input[q] = um[q];
-            pn.duration   = tau;
-            pn.parent     = cur;
-            pn.node_state = IN_OPEN_SET;
-            pn.time       = s_cur_time + tau;
-            pn.time_idx   = (int)floor((pn.time - time_origin) * inv_tres);
-            heap_push(w.pool, w.heap, heap_n, pro_node);
-            hash_insert(w, c.id[0], c.id[1], c.id[2], (int)pn.time, pro_node);  // :387 quirk
-            s_tmp[n_tmp++] = pro_node;
-            use_node_num += 1;
-            if (use_node_num == ap.allocate_num) {  // "run out of memory" (:393-396)
-              ret  = NO_PATH;
-              done = true;
-            }
-          } else if (w.pool[pro_node].node_state == IN_OPEN_SET) {
-            Node &pn = w.pool[pro_node];
-            if (c.g < pn.g) {
+          } else if (c.found_st == IN_OPEN_SET) {
+            Node &pn = pool[c.found];
+            if (c.g < pn.g) {  // re-read: an earlier child of this expansion may have updated it
+              double um[3];
+              if (was_first) {
+                um[0] = start_a[0];
+                um[1] = start_a[1];
+                um[2] = start_a[2];
+              } else {
+                um[0] = s_inputs[i][0];
+                um[1] = s_inputs[i][1];
+                um[2] = s_inputs[i][2];
+              }
               for (int q = 0; q < 6; ++q) pn.state[q] = c.state[q];
-              pn.f = c.f;
-              pn.g = c.g;
+              pn.f         = c.f;
+              pn.g         = c.g;
+              s_f[c.found] = c.f;
               for (int q = 0; q < 3; ++q) pn.input[q] = um[q];
               pn.duration = tau;
               pn.parent   = cur;
-              pn.time     = s_cur_time + tau;
+              pn.time     = new_t;
             }
           } else {
             ret  = SEARCH_ERR;
             done = true;
           }
         }
+        s_n_new    = n_tmp;
+        s_cur_node = cur;
         s_n_active = done ? -1 : 1;
       }
       __syncthreads();
+      // ---------------- all lanes: write the new nodes + their hash entries ----------------
+      for (int slot = lane; slot < s_n_new; slot += 64) {
+        const int   i    = s_src[slot];
+        const int   node = s_tmp[slot];
+        const Cand &c    = s_cand[i];
+        Node       &pn   = pool[node];
+        for (int q = 0; q < 3; ++q) pn.index[q] = c.id[q];
+        for (int q = 0; q < 6; ++q) pn.state[q] = c.state[q];
+        pn.f = c.f;
+        pn.g = c.g;
+        if (s_was_first) {
+          for (int q = 0; q < 3; ++q) pn.input[q] = start_a[q];
+        } else {
+          for (int q = 0; q < 3; ++q) pn.input[q] = s_inputs[i][q];
+        }
+        pn.duration   = tau;
+        pn.parent     = s_cur_node;
+        pn.node_state = IN_OPEN_SET;
+        pn.time       = new_t;
+        pn.time_idx   = new_ti;
+        hash_insert(htab, hcap, s_ins_key[slot], node);
+      }
       if (s_n_active < 0) done = true;
       __syncthreads();
     }
     // broadcast the verdict of this attempt
-    if (lane == 0) s_tmp[0] = ret;
+    if (lane == 0) s_ret = ret;
     __syncthreads();
-    const int r = s_tmp[0];
+    const int r = s_ret;
     __syncthreads();
     if (r != NO_PATH) break;
   }
@@ -582,12 +653,12 @@ __global__ __launch_bounds__(64) void k_astar(
       // walk back from the terminal node; points are produced last-to-first, then reversed
       int    node     = terminal;
       double t_node   = 0, t_sample = corridor_tau;
-      for (int q = 0; q < 6; ++q) route[q] = w.pool[node].state[q];
+      for (int q = 0; q < 6; ++q) route[q] = pool[node].state[q];
       n = 1;
-      while (w.pool[node].parent >= 0) {
-        const Node  &nd       = w.pool[node];
+      while (pool[node].parent >= 0) {
+        const Node  &nd       = pool[node];
         const double duration = nd.duration;
-        const Node  &par      = w.pool[nd.parent];
+        const Node  &par      = pool[nd.parent];
         t_node                = duration;
         while (true) {
           if (t_sample > t_node) {
@@ -607,18 +678,18 @@ __global__ __launch_bounds__(64) void k_astar(
       const int kept = n < route_cap ? n : route_cap;
       for (int i = 0; i < kept / 2; ++i)
         for (int q = 0; q < 6; ++q) {
-          const double tmp            = route[i * 6 + q];
-          route[i * 6 + q]            = route[(kept - 1 - i) * 6 + q];
+          const double tmp              = route[i * 6 + q];
+          route[i * 6 + q]              = route[(kept - 1 - i) * 6 + q];
           route[(kept - 1 - i) * 6 + q] = tmp;
         }
     }
     // number of nodes on the retrieved path (retrievePath :826-836)
     int n_path = 0;
     if (terminal >= 0) {
-      int c = terminal;
+      int c  = terminal;
       n_path = 1;
-      while (w.pool[c].parent >= 0) {
-        c = w.pool[c].parent;
+      while (pool[c].parent >= 0) {
+        c = pool[c].parent;
         ++n_path;
       }
     }
@@ -633,6 +704,7 @@ __global__ __launch_bounds__(64) void k_astar(
 }
 
 size_t astar_node_bytes() { return sizeof(Node); }
+int    astar_pool_max() { return ASTAR_POOL_MAX; }
 
 int launch_astar(const MapView &m, const SogmAstarParams &ap, double corridor_tau,
                  const AstarWorkspace &wsp, int n_agents, const double *start_pva,

@@ -196,16 +196,47 @@ __device__ inline bool smoothedL1(double mu, double x, double &f, double &df) {
 }
 
 struct MvieData {
-  int           M;
-  double        smoothEps, penaltyWt;
-  const double *A;  // M x 3
+  int    M;
+  double smoothEps, penaltyWt;
+  // this lane's faces (lane and lane + 64); a face beyond M is flagged off
+  double a0[3], a1[3];
+  bool   on0, on1;
 };
 
-__device__ __noinline__ double costMVIE(const MvieData &D, const double *x, double *g) {
+// 64-lane butterfly sum: every lane ends with the same total; the association order
+// ((l, l^32), (.., ^16), ...) is what oracle/corridor_oracle.cpp::tree_sum64 replays.
+__device__ inline double bfly_sum(double v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+  return v;
+}
+
+// one face's contribution to cost and gradient (firi.hpp:105-122)
+__device__ inline void mvie_face(const double a[3], const double L[3][3], const double *p,
+                                 double smoothEps, double acc[10]) {
+  double AL[3];
+  for (int j = 0; j < 3; ++j) AL[j] = (a[0] * L[0][j] + a[1] * L[1][j]) + a[2] * L[2][j];
+  const double normAL = sogm_det::sqrt_rn((AL[0] * AL[0] + AL[1] * AL[1]) + AL[2] * AL[2]);
+  const double adj[3] = {AL[0] / normAL, AL[1] / normAL, AL[2] / normAL};
+  const double Ap     = (a[0] * p[0] + a[1] * p[1]) + a[2] * p[2];
+  const double viola  = (normAL + Ap) - 1.0;
+  double       c, dc;
+  if (smoothedL1(smoothEps, viola, c, dc)) {
+    acc[0] += c;
+    const double vec[3] = {dc * a[0], dc * a[1], dc * a[2]};
+    for (int j = 0; j < 3; ++j) acc[1 + j] += vec[j];
+    for (int j = 0; j < 3; ++j) acc[4 + j] += adj[j] * vec[j];
+    acc[7] += adj[0] * vec[1];
+    acc[8] += adj[1] * vec[2];
+    acc[9] += adj[0] * vec[2];
+  }
+}
+
+// costMVIE (firi.hpp:74-140), evaluated by the whole wave: one face per lane (two when M > 64),
+// per-lane partial sums, butterfly reduction.  Every lane returns the same cost and gradient.
+__device__ __forceinline__ double costMVIE(const MvieData &D, const double *x, double *g) {
   const double *p = x, *rtd = x + 3, *cde = x + 6;
   double       *gdp = g, *gdrtd = g + 3, *gdcde = g + 6;
-  double        cost = 0;
-  for (int i = 0; i < 9; ++i) g[i] = 0;
   double L[3][3];
   L[0][0] = rtd[0] * rtd[0] + DBL_EPSILON;
   L[0][1] = 0.0;
@@ -216,24 +247,16 @@ __device__ __noinline__ double costMVIE(const MvieData &D, const double *x, doub
   L[2][0] = cde[2];
   L[2][1] = cde[1];
   L[2][2] = rtd[2] * rtd[2] + DBL_EPSILON;
-  for (int i = 0; i < D.M; ++i) {
-    const double *a = D.A + i * 3;
-    double        AL[3];
-    for (int j = 0; j < 3; ++j) AL[j] = (a[0] * L[0][j] + a[1] * L[1][j]) + a[2] * L[2][j];
-    const double normAL = sogm_det::sqrt_rn((AL[0] * AL[0] + AL[1] * AL[1]) + AL[2] * AL[2]);
-    const double adj[3] = {AL[0] / normAL, AL[1] / normAL, AL[2] / normAL};
-    const double Ap     = (a[0] * p[0] + a[1] * p[1]) + a[2] * p[2];
-    const double viola  = (normAL + Ap) - 1.0;
-    double       c, dc;
-    if (smoothedL1(D.smoothEps, viola, c, dc)) {
-      cost += c;
-      const double vec[3] = {dc * a[0], dc * a[1], dc * a[2]};
-      for (int j = 0; j < 3; ++j) gdp[j] += vec[j];
-      for (int j = 0; j < 3; ++j) gdrtd[j] += adj[j] * vec[j];
-      gdcde[0] += adj[0] * vec[1];
-      gdcde[1] += adj[1] * vec[2];
-      gdcde[2] += adj[0] * vec[2];
-    }
+  double acc[10];
+  for (int k = 0; k < 10; ++k) acc[k] = 0.0;
+  if (D.on0) mvie_face(D.a0, L, p, D.smoothEps, acc);
+  if (D.on1) mvie_face(D.a1, L, p, D.smoothEps, acc);
+  for (int k = 0; k < 10; ++k) acc[k] = bfly_sum(acc[k]);
+  double cost = acc[0];
+  for (int j = 0; j < 3; ++j) {
+    gdp[j]   = acc[1 + j];
+    gdrtd[j] = acc[4 + j];
+    gdcde[j] = acc[7 + j];
   }
   cost *= D.penaltyWt;
   for (int j = 0; j < 3; ++j) {
@@ -262,7 +285,7 @@ __device__ inline double ninf9(const double *v) {
   return mx;
 }
 
-__device__ int lineSearchLO(const MvieData &D, double *x, double &f, double *g, double &stp,
+__device__ __forceinline__ int lineSearchLO(const MvieData &D, double *x, double &f, double *g, double &stp,
                             const double *s, const double *xp, const double *gp, double stpmin,
                             double stpmax) {
   const double f_dec = 1.0e-4, s_curv = 0.9, machine_prec = 1.0e-16;
@@ -303,21 +326,31 @@ __device__ int lineSearchLO(const MvieData &D, double *x, double &f, double *g, 
   }
 }
 
-// L-BFGS history lives in LDS: lm[0..18*9) = s, lm[18*9..2*18*9) = y
-__device__ __noinline__ int lbfgsMVIE(const MvieData &D, double *x, double *lm) {
+// L-BFGS (lbfgs.hpp lbfgs_optimize with the parameters of firi.hpp:191-199), executed replicated
+// by every lane of the wave (uniform control flow; only costMVIE is lane-parallel).  Everything that
+// is indexed dynamically lives in LDS with lane 0 as the single writer, so nothing spills to scratch:
+//   lm[0..162) = s history, lm[162..324) = y history, lm[340..358) = alpha, lm[358..376) = y.s
+#define LBFGS_FENCE()                                        \
+  do {                                                       \
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");   \
+    __builtin_amdgcn_wave_barrier();                         \
+  } while (0)
+__device__ __forceinline__ int lbfgsMVIE(const MvieData &D, double *x, double *lm, int *n_iter, int *n_eval) {
   const int    n = 9, m = 18, past = 3;
   const double g_epsilon = 0.0, delta = 1.0e-7, min_step = 1.0e-32, max_step = 1.0e+20,
                cautious = 1.0e-6;
-  double  xp[9], g[9], gp[9], d[9], pf[3];
-  double  lm_alpha[18], lm_ys[18];
-  double *lm_s = lm, *lm_y = lm + m * n;
-  for (int i = 0; i < m; ++i) {
-    lm_alpha[i] = 0;
-    lm_ys[i]    = 0;
+  double       xp[9], g[9], gp[9], d[9];
+  double       pf0 = 0, pf1 = 0, pf2 = 0;  // pf[k % 3]
+  double      *lm_s = lm, *lm_y = lm + m * n, *lm_alpha = lm + 2 * m * n + 16,
+              *lm_ys = lm + 2 * m * n + 16 + m;
+  const bool   writer = (threadIdx.x & 63) == 0;
+  if (writer) {
+    for (int i = 0; i < 2 * m * n; ++i) lm[i] = 0;
+    for (int i = 0; i < 2 * m; ++i) lm_alpha[i] = 0;
   }
-  for (int i = 0; i < 2 * m * n; ++i) lm[i] = 0;
+  LBFGS_FENCE();
   double fx = costMVIE(D, x, g);
-  pf[0]     = fx;
+  pf0       = fx;
   for (int i = 0; i < n; ++i) d[i] = -g[i];
   int          ret;
   const double xn0 = ninf9(x);
@@ -332,6 +365,8 @@ __device__ __noinline__ int lbfgsMVIE(const MvieData &D, double *x, double *lm) 
         gp[i] = g[i];
       }
       const int ls = lineSearchLO(D, x, fx, g, step, d, xp, gp, min_step, max_step);
+      *n_iter += 1;
+      *n_eval += ls > 0 ? ls : 0;
       if (ls < 0) {
         for (int i = 0; i < n; ++i) {
           x[i] = xp[i];
@@ -345,40 +380,55 @@ __device__ __noinline__ int lbfgsMVIE(const MvieData &D, double *x, double *lm) 
         ret = 0;
         break;
       }
+      const int km = k % past;
       if (past <= k) {
         const double afx  = dabs(fx);
-        const double rate = dabs(pf[k % past] - fx) / (1.0 > afx ? 1.0 : afx);
+        const double pfk  = km == 0 ? pf0 : (km == 1 ? pf1 : pf2);
+        const double rate = dabs(pfk - fx) / (1.0 > afx ? 1.0 : afx);
         if (rate < delta) {
           ret = 1;
           break;
         }
       }
-      pf[k % past] = fx;
+      if (km == 0) pf0 = fx;
+      else if (km == 1) pf1 = fx;
+      else pf2 = fx;
       ++k;
       double *se = lm_s + end * n, *ye = lm_y + end * n;
+      double  sv[9], yv[9];
       for (int i = 0; i < n; ++i) {
-        se[i] = x[i] - xp[i];
-        ye[i] = g[i] - gp[i];
+        sv[i] = x[i] - xp[i];
+        yv[i] = g[i] - gp[i];
       }
-      const double ys = dotn9(ye, se);
-      const double yy = dotn9(ye, ye);
-      lm_ys[end]      = ys;
+      const double ys = dotn9(yv, sv);
+      const double yy = dotn9(yv, yv);
+      if (writer) {
+        for (int i = 0; i < n; ++i) {
+          se[i] = sv[i];
+          ye[i] = yv[i];
+        }
+        lm_ys[end] = ys;
+      }
+      LBFGS_FENCE();
       for (int i = 0; i < n; ++i) d[i] = -g[i];
-      const double cau = dotn9(se, se) * sogm_det::sqrt_rn(dotn9(gp, gp)) * cautious;
+      const double cau = dotn9(sv, sv) * sogm_det::sqrt_rn(dotn9(gp, gp)) * cautious;
       if (ys > cau) {
         ++bound;
         bound = m < bound ? m : bound;
         end   = (end + 1) % m;
         int j = end;
         for (int i = 0; i < bound; ++i) {
-          j           = (j + m - 1) % m;
-          lm_alpha[j] = dotn9(lm_s + j * n, d) / lm_ys[j];
-          for (int q = 0; q < n; ++q) d[q] += (-lm_alpha[j]) * lm_y[j * n + q];
+          j                  = (j + m - 1) % m;
+          const double alpha = dotn9(lm_s + j * n, d) / lm_ys[j];
+          if (writer) lm_alpha[j] = alpha;
+          for (int q = 0; q < n; ++q) d[q] += (-alpha) * lm_y[j * n + q];
         }
+        LBFGS_FENCE();
         for (int q = 0; q < n; ++q) d[q] *= ys / yy;
         for (int i = 0; i < bound; ++i) {
           const double beta = dotn9(lm_y + j * n, d) / lm_ys[j];
-          for (int q = 0; q < n; ++q) d[q] += (lm_alpha[j] - beta) * lm_s[j * n + q];
+          const double al   = lm_alpha[j];
+          for (int q = 0; q < n; ++q) d[q] += (al - beta) * lm_s[j * n + q];
           j = (j + 1) % m;
         }
       }
@@ -430,105 +480,136 @@ struct SolverScratch {
   double *lm;       // 2 * 18 * 9
 };
 
-// maxVolInsEllipsoid (firi.hpp:146-236); hPoly: M x 4 in LDS/global; lane 0 only
-__device__ __noinline__ bool maxVolInsEllipsoid(const double *hPoly, int M, double R[3][3], double p[3],
-                                   double r[3], const SolverScratch &sc) {
-  double *Alp = sc.rows;                    // M x 4
-  double *blp = sc.rows + LP_MAX_ROWS * 4;  // M
-  for (int i = 0; i < M; ++i) {
-    const double *h  = hPoly + i * 4;
-    const double  hn = sogm_det::sqrt_rn((h[0] * h[0] + h[1] * h[1]) + h[2] * h[2]);
-    for (int j = 0; j < 3; ++j) Alp[i * 4 + j] = h[j] / hn;
-    Alp[i * 4 + 3] = 1.0;
-    blp[i]         = -h[3] / hn;
+// maxVolInsEllipsoid (firi.hpp:146-236); hPoly: M x 4 in LDS.  Called by the WHOLE wave: the
+// deepest-point LP and the final 3x3 SVD run on lane 0, the L-BFGS runs replicated on all lanes
+// with the cost evaluated one face per lane.  R, p, r are meaningful on lane 0 only.
+__device__ __forceinline__ bool maxVolInsEllipsoid(const double *hPoly, int M, double R[3][3], double p[3],
+                                   double r[3], const SolverScratch &sc, long long *dbg) {
+  const int lane = threadIdx.x & 63;
+  double   *Alp  = sc.rows;                    // M x 4
+  double   *blp  = sc.rows + LP_MAX_ROWS * 4;  // M
+  double   *sh   = sc.lm + 2 * 18 * 9;         // 16 doubles of hand-off space after the history
+  if (lane == 0) {
+    for (int i = 0; i < M; ++i) {
+      const double *h  = hPoly + i * 4;
+      const double  hn = sogm_det::sqrt_rn((h[0] * h[0] + h[1] * h[1]) + h[2] * h[2]);
+      for (int j = 0; j < 3; ++j) Alp[i * 4 + j] = h[j] / hn;
+      Alp[i * 4 + 3] = 1.0;
+      blp[i]         = -h[3] / hn;
+    }
+    const double clp[4] = {0, 0, 0, -1.0};
+    double       xlp[4];
+    const double maxdepth = -linprog<4>(clp, M, Alp, blp, xlp, sc.lp_work, sc.perm);
+    const bool   ok = !(!(maxdepth > 0.0) || maxdepth == INFINITY || maxdepth == -INFINITY);
+    sh[12]          = ok ? 1.0 : 0.0;
+    if (ok) {
+      const double interior[3] = {xlp[0], xlp[1], xlp[2]};
+      // A = Alp / (blp - Alp interior), overwriting Alp's first three columns (stride 4)
+      for (int i = 0; i < M; ++i) {
+        double      *a   = Alp + i * 4;
+        const double den = blp[i] - ((a[0] * interior[0] + a[1] * interior[1]) + a[2] * interior[2]);
+        for (int j = 0; j < 3; ++j) a[j] = a[j] / den;
+      }
+      double Q[3][3], L[3][3];
+      for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+          Q[i][j] = (R[i][0] * (r[0] * r[0]) * R[j][0] + R[i][1] * (r[1] * r[1]) * R[j][1]) +
+                    R[i][2] * (r[2] * r[2]) * R[j][2];
+      // chol3d (firi.hpp:44-55)
+      L[0][0] = sogm_det::sqrt_rn(Q[0][0]);
+      L[1][0] = 0.5 * (Q[0][1] + Q[1][0]) / L[0][0];
+      L[1][1] = sogm_det::sqrt_rn(Q[1][1] - L[1][0] * L[1][0]);
+      L[2][0] = 0.5 * (Q[0][2] + Q[2][0]) / L[0][0];
+      L[2][1] = (0.5 * (Q[1][2] + Q[2][1]) - L[2][0] * L[1][0]) / L[1][1];
+      L[2][2] = sogm_det::sqrt_rn(Q[2][2] - L[2][0] * L[2][0] - L[2][1] * L[2][1]);
+      for (int j = 0; j < 3; ++j) sh[j] = p[j] - interior[j];
+      sh[3] = sogm_det::sqrt_rn(L[0][0]);
+      sh[4] = sogm_det::sqrt_rn(L[1][1]);
+      sh[5] = sogm_det::sqrt_rn(L[2][2]);
+      sh[6] = L[1][0];
+      sh[7] = L[2][1];
+      sh[8] = L[2][0];
+      for (int j = 0; j < 3; ++j) sh[9 + j] = interior[j];
+    }
   }
-  const double clp[4] = {0, 0, 0, -1.0};
-  double       xlp[4];
-  const double maxdepth = -linprog<4>(clp, M, Alp, blp, xlp, sc.lp_work, sc.perm);
-  if (!(maxdepth > 0.0) || maxdepth == INFINITY || maxdepth == -INFINITY) return false;
-  const double interior[3] = {xlp[0], xlp[1], xlp[2]};
-  // A = Alp / (blp - Alp interior), stored in place over Alp's first 3 columns (stride 3)
-  double *A = sc.lp_work;  // reuse LP scratch (LP is finished): M x 3
-  for (int i = 0; i < M; ++i) {
-    const double *a   = Alp + i * 4;
-    const double  den = blp[i] - ((a[0] * interior[0] + a[1] * interior[1]) + a[2] * interior[2]);
-    for (int j = 0; j < 3; ++j) A[i * 3 + j] = a[j] / den;
+  __syncthreads();
+  if (sh[12] == 0.0) {
+    __syncthreads();
+    return false;
   }
   MvieData D;
   D.M         = M;
-  D.A         = A;
   D.smoothEps = 1.0e-2;
   D.penaltyWt = 1.0e+3;
-  double x[9], Q[3][3], L[3][3];
-  for (int i = 0; i < 3; ++i)
-    for (int j = 0; j < 3; ++j)
-      Q[i][j] = (R[i][0] * (r[0] * r[0]) * R[j][0] + R[i][1] * (r[1] * r[1]) * R[j][1]) +
-                R[i][2] * (r[2] * r[2]) * R[j][2];
-  // chol3d (firi.hpp:44-55)
-  L[0][0] = sogm_det::sqrt_rn(Q[0][0]);
-  L[0][1] = 0.0;
-  L[0][2] = 0.0;
-  L[1][0] = 0.5 * (Q[0][1] + Q[1][0]) / L[0][0];
-  L[1][1] = sogm_det::sqrt_rn(Q[1][1] - L[1][0] * L[1][0]);
-  L[1][2] = 0.0;
-  L[2][0] = 0.5 * (Q[0][2] + Q[2][0]) / L[0][0];
-  L[2][1] = (0.5 * (Q[1][2] + Q[2][1]) - L[2][0] * L[1][0]) / L[1][1];
-  L[2][2] = sogm_det::sqrt_rn(Q[2][2] - L[2][0] * L[2][0] - L[2][1] * L[2][1]);
-  for (int j = 0; j < 3; ++j) x[j] = p[j] - interior[j];
-  x[3] = sogm_det::sqrt_rn(L[0][0]);
-  x[4] = sogm_det::sqrt_rn(L[1][1]);
-  x[5] = sogm_det::sqrt_rn(L[2][2]);
-  x[6] = L[1][0];
-  x[7] = L[2][1];
-  x[8] = L[2][0];
-  const int ret = lbfgsMVIE(D, x, sc.lm);
-  for (int j = 0; j < 3; ++j) p[j] = x[j] + interior[j];
-  L[0][0] = x[3] * x[3];
-  L[0][1] = 0.0;
-  L[0][2] = 0.0;
-  L[1][0] = x[6];
-  L[1][1] = x[4] * x[4];
-  L[1][2] = 0.0;
-  L[2][0] = x[8];
-  L[2][1] = x[7];
-  L[2][2] = x[5] * x[5];
-  double S[3][3], V[3][3], w[3];
-  for (int i = 0; i < 3; ++i)
-    for (int j = 0; j < 3; ++j)
-      S[i][j] = (L[i][0] * L[j][0] + L[i][1] * L[j][1]) + L[i][2] * L[j][2];
-  jacobiEig3(S, V, w);
-  int ord[3] = {0, 1, 2};
-  for (int a = 0; a < 2; ++a)
-    for (int b = 0; b < 2 - a; ++b)
-      if (w[ord[b]] < w[ord[b + 1]]) {
-        const int t = ord[b];
-        ord[b]      = ord[b + 1];
-        ord[b + 1]  = t;
-      }
-  double U[3][3], Sg[3];
-  for (int c = 0; c < 3; ++c) {
-    Sg[c] = sogm_det::sqrt_rn(w[ord[c]] > 0 ? w[ord[c]] : 0.0);
-    for (int k = 0; k < 3; ++k) U[k][c] = V[k][ord[c]];
+  D.on0       = lane < M;
+  D.on1       = lane + 64 < M;
+  for (int j = 0; j < 3; ++j) {
+    D.a0[j] = D.on0 ? Alp[lane * 4 + j] : 0.0;
+    D.a1[j] = D.on1 ? Alp[(lane + 64) * 4 + j] : 0.0;
   }
-  const double det = U[0][0] * (U[1][1] * U[2][2] - U[1][2] * U[2][1]) -
-                     U[0][1] * (U[1][0] * U[2][2] - U[1][2] * U[2][0]) +
-                     U[0][2] * (U[1][0] * U[2][1] - U[1][1] * U[2][0]);
-  if (det < 0.0) {
-    for (int k = 0; k < 3; ++k) {
-      R[k][0] = U[k][1];
-      R[k][1] = U[k][0];
-      R[k][2] = U[k][2];
+  double x[9];
+  for (int j = 0; j < 9; ++j) x[j] = sh[j];
+  const double interior[3] = {sh[9], sh[10], sh[11]};
+  __syncthreads();
+  int             n_it = 0, n_ev = 0;
+  const long long tl0 = wall_clock64();
+  const int       ret = lbfgsMVIE(D, x, sc.lm, &n_it, &n_ev);
+  if (dbg && lane == 0) {
+    dbg[3] = n_it;
+    dbg[4] = n_ev;
+    dbg[9] = wall_clock64() - tl0;
+  }
+  if (lane == 0) {
+    double L[3][3];
+    for (int j = 0; j < 3; ++j) p[j] = x[j] + interior[j];
+    L[0][0] = x[3] * x[3];
+    L[0][1] = 0.0;
+    L[0][2] = 0.0;
+    L[1][0] = x[6];
+    L[1][1] = x[4] * x[4];
+    L[1][2] = 0.0;
+    L[2][0] = x[8];
+    L[2][1] = x[7];
+    L[2][2] = x[5] * x[5];
+    double S[3][3], V[3][3], w[3];
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j)
+        S[i][j] = (L[i][0] * L[j][0] + L[i][1] * L[j][1]) + L[i][2] * L[j][2];
+    jacobiEig3(S, V, w);
+    int ord[3] = {0, 1, 2};
+    for (int a = 0; a < 2; ++a)
+      for (int b = 0; b < 2 - a; ++b)
+        if (w[ord[b]] < w[ord[b + 1]]) {
+          const int t = ord[b];
+          ord[b]      = ord[b + 1];
+          ord[b + 1]  = t;
+        }
+    double U[3][3], Sg[3];
+    for (int c = 0; c < 3; ++c) {
+      Sg[c] = sogm_det::sqrt_rn(w[ord[c]] > 0 ? w[ord[c]] : 0.0);
+      for (int k = 0; k < 3; ++k) U[k][c] = V[k][ord[c]];
     }
-    r[0] = Sg[1];
-    r[1] = Sg[0];
-    r[2] = Sg[2];
-  } else {
-    for (int k = 0; k < 3; ++k)
-      for (int c = 0; c < 3; ++c) R[k][c] = U[k][c];
-    r[0] = Sg[0];
-    r[1] = Sg[1];
-    r[2] = Sg[2];
+    const double det = U[0][0] * (U[1][1] * U[2][2] - U[1][2] * U[2][1]) -
+                       U[0][1] * (U[1][0] * U[2][2] - U[1][2] * U[2][0]) +
+                       U[0][2] * (U[1][0] * U[2][1] - U[1][1] * U[2][0]);
+    if (det < 0.0) {
+      for (int k = 0; k < 3; ++k) {
+        R[k][0] = U[k][1];
+        R[k][1] = U[k][0];
+        R[k][2] = U[k][2];
+      }
+      r[0] = Sg[1];
+      r[1] = Sg[0];
+      r[2] = Sg[2];
+    } else {
+      for (int k = 0; k < 3; ++k)
+        for (int c = 0; c < 3; ++c) R[k][c] = U[k][c];
+      r[0] = Sg[0];
+      r[1] = Sg[1];
+      r[2] = Sg[2];
+    }
   }
+  __syncthreads();
   return ret >= 0;
 }
 
@@ -610,8 +691,8 @@ __global__ __launch_bounds__(64) void k_corridor_segment(
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double        *s_lp    = (double *)smem;                    // LP_WORK_DOUBLES
   double        *s_rows  = s_lp + LP_WORK_DOUBLES;            // LP_MAX_ROWS * 5
-  double        *s_lm    = s_rows + LP_MAX_ROWS * 5;          // 324
-  double        *s_fH    = s_lm + 2 * 18 * 9;                 // FIRI_MAX_H * 4
+  double        *s_lm    = s_rows + LP_MAX_ROWS * 5;          // 324 history + 16 hand-off + 36 alpha/ys
+  double        *s_fH    = s_lm + 2 * 18 * 9 + 16 + 36;       // FIRI_MAX_H * 4
   double        *s_poly  = s_fH + FIRI_MAX_H * 4;             // FIRI_MAX_H * 4
   double        *s_small = s_poly + FIRI_MAX_H * 4;           // 96 doubles of shared small state
   int           *s_perm  = (int *)(s_small + 96);             // LP_MAX_ROWS
@@ -642,7 +723,10 @@ __global__ __launch_bounds__(64) void k_corridor_segment(
   double         *tang  = ws.tang + (size_t)slot * cap * 4;
   double         *distR = ws.distr + (size_t)slot * cap;
 
+  long long *dbg = ws.seg_dbg + (size_t)slot * 16;
+  const long long tk0 = wall_clock64();
   if (lane == 0) {
+    for (int k = 0; k < 16; ++k) dbg[k] = 0;
     double w0[3], w1[3];
     for (int k = 0; k < 3; ++k) {
       w0[k] = rt[seg * 6 + k];
@@ -758,6 +842,10 @@ __global__ __launch_bounds__(64) void k_corridor_segment(
   }
   __syncthreads();
 
+  if (lane == 0) {
+    dbg[0] = N;
+    dbg[5] = wall_clock64() - tk0;
+  }
   // ---------------- firi::firi (firi.hpp:238-365) ----------------
   const double epsilon = 1.0e-6;
   const int    M       = 6;
@@ -944,10 +1032,16 @@ __global__ __launch_bounds__(64) void k_corridor_segment(
         for (int k = 0; k < 4; ++k) s_poly[i * 4 + k] = h[k];
       }
       __syncthreads();
-      if (loop == pp.firi_iterations - 1) break;
       if (lane == 0) {
-        const int mm = nH < LP_MAX_ROWS - 8 ? nH : LP_MAX_ROWS - 8;
-        maxVolInsEllipsoid(s_poly, mm, R, p, r, sc);
+        dbg[1 + (loop > 0)] = nH;
+        dbg[6 + 2 * (loop > 0)] = wall_clock64() - tk0;
+      }
+      if (loop == pp.firi_iterations - 1) break;
+      {
+        const int       mm  = nH < LP_MAX_ROWS - 8 ? nH : LP_MAX_ROWS - 8;
+        const long long tm0 = wall_clock64();
+        maxVolInsEllipsoid(s_poly, mm, R, p, r, sc, dbg);
+        if (lane == 0) dbg[7] = wall_clock64() - tm0;
       }
       __syncthreads();
     }
@@ -977,6 +1071,7 @@ __global__ __launch_bounds__(64) void k_corridor_segment(
     ws.seg_nfaces[slot] = nf;
     ws.seg_state[slot]  = overflow ? -3 : (valid ? 1 : 0);
     ws.seg_npts[slot]   = N;
+    dbg[10]             = wall_clock64() - tk0;
   }
 }
 
@@ -1059,7 +1154,7 @@ __global__ __launch_bounds__(64) void k_corridor_finalize(
 }
 
 size_t corridor_segment_lds(int pc_capacity) {
-  return sizeof(double) * (LP_WORK_DOUBLES + LP_MAX_ROWS * 5 + 2 * 18 * 9 + 2 * FIRI_MAX_H * 4 + 96) +
+  return sizeof(double) * (LP_WORK_DOUBLES + LP_MAX_ROWS * 5 + 2 * 18 * 9 + 16 + 36 + 2 * FIRI_MAX_H * 4 + 96) +
          sizeof(int) * (LP_MAX_ROWS + 16) + (size_t)pc_capacity;
 }
 

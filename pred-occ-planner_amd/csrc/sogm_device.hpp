@@ -115,6 +115,28 @@ __device__ inline int query_clear_idx(const MapView &m, int agent, double px, do
   const float  thr = g.map_kind == SOGM_MAP_FAKE ? g.risk_threshold
                                                  : g.thr_region - (float)t * g.decay_region;
   float        sum = 0.0F;
+  if (zs == 0 && s <= 3) {
+    // Common case (fkpcp map, K = (2s+1)^2 <= 49): issue every gather first so the loads overlap,
+    // then replay the reference's running sum and early exit in kernel order (x outer, y inner).
+    float v[49];
+    const int w = 2 * s + 1;
+#pragma unroll
+    for (int k = 0; k < 49; ++k) {
+      v[k] = -1.0F;  // marks "outside the grid" (occupancies are >= 0)
+      if (k < w * w) {
+        const int qx = ix + (k / w - s), qy = iy + (k % w - s);
+        if (g.in_range(qx, qy, iz)) v[k] = sl[(size_t)iz * g.L * g.W + (size_t)qy * g.L + qx];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 49; ++k) {
+      if (k < w * w && v[k] >= 0.0F) {
+        sum += v[k];
+        if (sum > thr) return 1;
+      }
+    }
+    return 0;
+  }
   for (int x = -s; x <= s; ++x) {
     const int qx = ix + x;
     for (int y = -s; y <= s; ++y) {

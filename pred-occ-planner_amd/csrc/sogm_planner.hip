@@ -81,7 +81,7 @@ int sogm_planner_create(sogm_ctx *map, const SogmAstarParams *astar, const SogmP
   p->ap  = *astar;
   p->pp  = *pp;
   p->qs  = *qp;
-  if (astar->allocate_num < 2 || astar->check_num < 1 || !(astar->resolution > 0) ||
+  if (astar->allocate_num < 2 || astar->allocate_num > astar_pool_max() || astar->check_num < 1 || !(astar->resolution > 0) ||
       !(astar->time_resolution > 0)) {
     delete p;
     return SOGM_ERR_INVALID_ARG;
@@ -93,9 +93,7 @@ int sogm_planner_create(sogm_ctx *map, const SogmAstarParams *astar, const SogmP
   p->aw.pool_stride = astar_node_bytes() * (size_t)astar->allocate_num;
   p->route_cap      = 64;
   hipError_t e      = hipMalloc((void **)&p->aw.pool, p->aw.pool_stride * A);
-  if (e == hipSuccess) e = hipMalloc((void **)&p->aw.heap, sizeof(int) * (size_t)astar->allocate_num * A);
-  if (e == hipSuccess) e = hipMalloc(&p->aw.hkeys, 16 * (size_t)hc * A);
-  if (e == hipSuccess) e = hipMalloc((void **)&p->aw.hvals, sizeof(int) * (size_t)hc * A);
+  if (e == hipSuccess) e = hipMalloc(&p->aw.hkeys, 8 * (size_t)hc * A);
   if (e == hipSuccess) e = hipMalloc((void **)&p->d_ret, sizeof(int32_t) * A);
   if (e == hipSuccess) e = hipMalloc((void **)&p->d_route_len, sizeof(int32_t) * A);
   if (e == hipSuccess) e = hipMalloc((void **)&p->d_stats, sizeof(int32_t) * 4 * A);
@@ -115,6 +113,7 @@ int sogm_planner_create(sogm_ctx *map, const SogmAstarParams *astar, const SogmP
     if (e == hipSuccess) e = hipMalloc((void **)&p->cw.seg_nfaces, sizeof(int32_t) * slots);
     if (e == hipSuccess) e = hipMalloc((void **)&p->cw.seg_state, sizeof(int32_t) * slots);
     if (e == hipSuccess) e = hipMalloc((void **)&p->cw.seg_npts, sizeof(int32_t) * slots);
+    if (e == hipSuccess) e = hipMalloc((void **)&p->cw.seg_dbg, sizeof(long long) * 16 * slots);
     // QP row storage fallback (rows normally live in LDS)
     p->qw.scratch_stride = qp_scratch_bytes_per_agent(pp->max_faces);
     p->qw.dyn_lds_bytes  = 144 * 1024;  // 160 KiB/CU minus k_qp's ~14 KiB of static LDS
@@ -138,10 +137,10 @@ int sogm_planner_create(sogm_ctx *map, const SogmAstarParams *astar, const SogmP
 }
 void sogm_planner_destroy(sogm_planner *p) {
   if (!p) return;
-  void *ptrs[] = {p->aw.pool, p->aw.heap, p->aw.hkeys, p->aw.hvals,
+  void *ptrs[] = {p->aw.pool, p->aw.hkeys,
                   p->d_ret,   p->d_route_len, p->d_stats, p->d_route,
                   p->cw.pc,   p->cw.fpc,  p->cw.tang, p->cw.distr, p->cw.polys,
-                  p->cw.seg_nfaces, p->cw.seg_state, p->cw.seg_npts,
+                  p->cw.seg_nfaces, p->cw.seg_state, p->cw.seg_npts, p->cw.seg_dbg,
                   p->qw.scratch,
                   p->d_polys, p->d_goal, p->d_cpts, p->d_nfaces, p->d_npoly, p->d_status, p->d_iters};
   for (void *q : ptrs)
@@ -189,6 +188,16 @@ int sogm_corridor_generate(sogm_planner *p, const double *start_pva, const doubl
   }
   return SOGM_OK;
 }
+// diagnostics (tools/ only): copy the per-segment corridor counters to the host
+int sogm_debug_corridor_stats(sogm_planner *p, long long *out_host) {
+  if (!p || !out_host) return SOGM_ERR_INVALID_ARG;
+  SOGM_HIP_CHECK(hipDeviceSynchronize());
+  SOGM_HIP_CHECK(hipMemcpy(out_host, p->cw.seg_dbg,
+                           sizeof(long long) * 16 * (size_t)p->map->n_agents * SOGM_MAX_PIECES,
+                           hipMemcpyDeviceToHost));
+  return SOGM_OK;
+}
+
 int sogm_bezier_qp_solve(sogm_planner *p, const double *start_pva, const double *goal_pv,
                          const double *polys, const int32_t *nfaces, const int32_t *npoly,
                          double *out_cpts, int32_t *out_status, int32_t *out_iters, void *stream) {

@@ -9,11 +9,10 @@ namespace sogm {
 struct AstarWorkspace {
   char  *pool;         // [A][pool_stride] bytes, Node records
   size_t pool_stride;  // bytes per agent
-  int   *heap;         // [A][allocate_num]
-  void  *hkeys;        // [A][hash_cap] int4
-  int   *hvals;        // [A][hash_cap]
+  void  *hkeys;        // [A][hash_cap] 64-bit slots {x, y, z, t, node id}
   int    hash_cap;     // power of two >= 2 * allocate_num
 };
+int astar_pool_max();
 
 // Per-(agent, segment) corridor scratch in HBM.
 struct CorridorWorkspace {
@@ -25,6 +24,7 @@ struct CorridorWorkspace {
   int32_t *seg_nfaces;  // [A*P]
   int32_t *seg_state;   // [A*P] 1 valid, 0 invalid, -2 no segment, -3 capacity exceeded
   int32_t *seg_npts;    // [A*P]
+  long long *seg_dbg;   // [A*P][16] diagnostics: counts and wall_clock64 ticks (100 MHz) per phase
 };
 
 int launch_corridor(const MapView &m, const SogmPlannerParams &pp, const CorridorWorkspace &ws,

@@ -1,0 +1,37 @@
+"""Diagnostic: per-segment corridor phase timings from the in-kernel counters."""
+import ctypes as C, importlib, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+pop = importlib.import_module("pred-occ-planner_amd")
+driver = importlib.import_module("pred-occ-planner_amd.driver")
+planner = importlib.import_module("pred-occ-planner_amd.planner")
+A = 128
+sw = driver.SwarmTick("cfg2", A, overlap_clear=False)
+for _ in range(3):
+    sw.step()
+sw.map.set_profiling(True)
+P = sw.planner
+stamp = sw.t0 + sw.tick * driver.TICK_PERIOD
+stamps = torch.full((A,), stamp, dtype=torch.float64, device="cuda")
+t_start = stamps + driver.REPLAN_START_TIME
+pva, valid = planner.traj_eval(sw.own, t_start)
+pva = torch.where(valid.bool().unsqueeze(1), pva, sw.hover).contiguous()
+poses = pva[:, :3].to(torch.float32).contiguous()
+sw.map.updateMap(sw.dev["cloud"], sw.dev["cloud_range"], sw.dev["cylinders"], sw.dev["n_cyl"], poses, stamps)
+sw.map.addOtherAgents(sw.all, A, sw.dev["ego_ids"])
+s = P.search(pva, sw.goals, t_start)
+c = P.generateCorridors(pva, t_start, s["route"], s["route_len"])
+ms = sw.map.profile_read()
+lib = pop.lib()
+lib.sogm_debug_corridor_stats.argtypes = [C.c_void_p, C.c_void_p]
+out = np.zeros((A * 16, 16), np.int64)
+lib.sogm_debug_corridor_stats(P._p, out.ctypes.data)
+d = out[out[:, 10] > 0]
+us = lambda t: t / 100.0  # 100 MHz
+print("corridor kernel ms", round(ms[4], 2), "segments", len(d))
+print("N pts: max/mean", d[:, 0].max(), d[:, 0].mean(), " nH0 max/mean", d[:, 1].max(), d[:, 1].mean(), " nH1 max", d[:, 2].max())
+print("lbfgs iters max/mean", d[:, 3].max(), d[:, 3].mean(), " evals max/mean", d[:, 4].max(), d[:, 4].mean())
+for name, col in (("points", 5), ("firi0 done", 6), ("mvie total", 7), ("  lbfgs", 9), ("firi1 done", 8), ("segment total", 10)):
+    print(f"{name:14s} us: max {us(d[:, col].max()):9.1f}  mean {us(d[:, col].mean()):9.1f}  p90 {us(np.percentile(d[:, col], 90)):9.1f}")
+i = np.argmax(d[:, 10])
+print("slowest segment:", d[i])
