@@ -108,13 +108,34 @@ def main():
     n_ok = int(torch.stack(oks).sum().item())
     # per-kernel times of the last tick (HIP events recorded on the launch stream inside the library)
     ms = sw.map.profile_read()
-    # a separate short loop for a per-launch average of the roofline kernel
+    # a separate short loop for per-launch averages: the roofline kernel inside the normal tick
+    # (HIP events on its launch stream), and the planner stages through the single-stage entry
+    # points (inside sogm_replan they run concurrently on per-group streams and cannot be timed
+    # one by one)
+    import numpy as np
+    planner = importlib.import_module("pred-occ-planner_amd.planner")
     clear_ms = []
     for _ in range(min(args.steps, 10)):
         sw.step()
-        clear_ms.append(sw.map.profile_read())
-    import numpy as np
+        ms_tick = sw.map.profile_read()
+        stamps = torch.full((sw.A_loc,), sw.t0 + (sw.tick - 1) * driver.TICK_PERIOD, dtype=torch.float64,
+                            device="cuda")
+        clear_ms.append(ms_tick)
+    # stage pass on the state of the last tick (map must be live: rebuild it without the pre-clear)
+    sw.map.set_overlap_clear(False)
+    stamps = torch.full((sw.A_loc,), sw.t0 + sw.tick * driver.TICK_PERIOD, dtype=torch.float64, device="cuda")
+    t_start = stamps + driver.REPLAN_START_TIME
+    pva, valid = planner.traj_eval(sw.own, t_start)
+    pva = torch.where(valid.bool().unsqueeze(1), pva, sw.hover).contiguous()
+    sw.map.updateMap(sw.dev["cloud"], sw.dev["cloud_range"], sw.dev["cylinders"], sw.dev["n_cyl"],
+                     pva[:, :3].to(torch.float32).contiguous(), stamps)
+    sw.map.addOtherAgents(sw.all, sw.A_tot, sw.dev["ego_ids"])
+    s_ = sw.planner.search(pva, sw.goals, t_start)
+    c_ = sw.planner.generateCorridors(pva, t_start, s_["route"], s_["route_len"])
+    q_ = sw.planner.optimize(pva, c_["goal"], c_["polys"], c_["nfaces"], c_["npoly"])
+    ms_stage = sw.map.profile_read()
     avg = np.mean(np.array(clear_ms), axis=0)
+    avg[3:6] = ms_stage[3:6]
     grid_bytes = sw.map.grid_bytes()  # V * T * 4 bytes x agents of this rank = algorithmic bytes / launch
     achieved = grid_bytes / (avg[0] * 1e-3) / 1e9
     out = {

@@ -122,13 +122,35 @@ SOGM_HD double cos(double x) {
 /* asin on [0, ~0.51]: odd Taylor series, 26 terms, Horner in z = x^2 */
 SOGM_HD double asin_small(double x) {
   const double z = x * x;
-  /* c_n = (2n)! / (4^n (n!)^2 (2n+1)) by the recurrence c_n = c_{n-1} (2n-1)^2 / (2n (2n+1)) */
-  double c[26];
-  c[0] = 1.0;
-  for (int n = 1; n < 26; ++n) {
-    const double tn = (double)(2 * n - 1);
-    c[n]            = c[n - 1] * (tn * tn) / ((double)(2 * n) * (double)(2 * n + 1));
-  }
+  /* c_n = (2n)! / (4^n (n!)^2 (2n+1)), n = 0..25: the doubles produced by the recurrence
+   * c_n = c_{n-1} (2n-1)^2 / (2n (2n+1)) evaluated in IEEE double, written out so that no
+   * divisions run per call (tests/test_detmath.py re-derives them) */
+  const double c[26] = {1.0,
+                        0.16666666666666666,
+                        0.075,
+                        0.044642857142857144,
+                        0.030381944444444444,
+                        0.022372159090909092,
+                        0.017352764423076924,
+                        0.01396484375,
+                        0.011551800896139705,
+                        0.009761609529194078,
+                        0.008390335809616815,
+                        0.0073125258735988454,
+                        0.006447210311889649,
+                        0.005740037670841924,
+                        0.005153309682319905,
+                        0.004660143486915096,
+                        0.004240907093679363,
+                        0.003880964558837669,
+                        0.0035692053938259347,
+                        0.003297059503473485,
+                        0.0030578216492580306,
+                        0.002846178401108942,
+                        0.00265787063820729,
+                        0.0024894486782468836,
+                        0.002338091892111975,
+                        0.0022014739737101384};
   double p = c[25];
   for (int n = 24; n >= 0; --n) p = p * z + c[n];
   return x * p;

@@ -244,19 +244,11 @@ __device__ inline void heap_pop(const double *f, unsigned short *h, int &n) {
   --n;
 }
 
-// candidate child handed from the lanes to the master through LDS
-struct Cand {
-  double state[6];
-  double g, f;
-  int    id[3];
-  int    t_id;
-  int    flags;     // bit0 velocity ok, bit1 not same (voxel,time) as parent, bit2 occupied
-  int    found;     // node id found in the hash for (id, t_id), -1 if none
-  int    found_st;  // its node_state
-  int    _pad;
-};
-
 #define ASTAR_MAX_INPUTS 128
+#define ASTAR_THREADS 128
+
+// per-child action decided in parallel, replayed in child order by the master
+enum { EV_NONE = 0, EV_NEW = 1, EV_DUP = 2, EV_OPEN = 3, EV_ERR = 4 };
 
 __device__ inline void pos_to_index(const double *p, const double *center, double inv_res,
                                     int *out) {
@@ -266,34 +258,38 @@ __device__ inline void pos_to_index(const double *p, const double *center, doubl
 
 }  // namespace
 
-// One workgroup (one wave of 64 lanes) per agent.
-__global__ __launch_bounds__(64) void k_astar(
+// One workgroup (two 64-lane waves) per agent: lane i evaluates motion primitive i.
+__global__ __launch_bounds__(ASTAR_THREADS) void k_astar(
     MapView m, SogmAstarParams ap, double corridor_tau, AstarWorkspace wsp,
     const double *__restrict__ start_pva, const double *__restrict__ goal,
     const double *__restrict__ t_start, int32_t *__restrict__ out_ret,
     double *__restrict__ out_route, int32_t *__restrict__ out_route_len, int route_cap,
-    int32_t *__restrict__ out_stats, int32_t *__restrict__ out_trace, int trace_cap) {
-  const int agent = blockIdx.x;
-  const int lane  = threadIdx.x;
+    int32_t *__restrict__ out_stats, int32_t *__restrict__ out_trace, int trace_cap, int agent0) {
+  const int agent = blockIdx.x + agent0;
+  const int tid   = threadIdx.x;
 
-  __shared__ double         s_f[ASTAR_POOL_MAX];     // f-score mirror of every allocated node
-  __shared__ unsigned short s_heap[ASTAR_POOL_MAX];  // open list
-  __shared__ double         s_inputs[ASTAR_MAX_INPUTS][3];
-  __shared__ int            s_n_inputs;
-  __shared__ Cand           s_cand[ASTAR_MAX_INPUTS];
-  __shared__ double         s_cur_state[6];
-  __shared__ double         s_cur_time, s_cur_g;
-  __shared__ int            s_cur_index[3], s_cur_tidx;
-  __shared__ int            s_n_active;  // primitives of this expansion (0 = stop)
-  __shared__ int            s_first;     // 1 = "init" expansion (single input = start acc)
-  __shared__ int            s_tmp[ASTAR_MAX_INPUTS];     // nodes created by this expansion
-  __shared__ unsigned long long s_ins_key[ASTAR_MAX_INPUTS];  // hash keys to insert for them
-  __shared__ int            s_n_new;
-  __shared__ int            s_ret;
-  __shared__ int            s_leader[ASTAR_MAX_INPUTS];   // first gate-passing child with the same key
-  __shared__ int            s_slot_of[ASTAR_MAX_INPUTS];  // child -> slot of the node it created
-  __shared__ int            s_src[ASTAR_MAX_INPUTS];      // slot -> child whose data the node takes
-  __shared__ int            s_was_first, s_cur_node;
+  __shared__ double             s_f[ASTAR_POOL_MAX];     // f-score mirror of every allocated node
+  __shared__ unsigned short     s_heap[ASTAR_POOL_MAX];  // open list
+  __shared__ double             s_inputs[ASTAR_MAX_INPUTS][3];
+  __shared__ double             s_cstate[ASTAR_MAX_INPUTS][6];  // child states
+  __shared__ double             s_cf[ASTAR_MAX_INPUTS], s_cg[ASTAR_MAX_INPUTS];
+  __shared__ unsigned long long s_key[ASTAR_MAX_INPUTS];  // packed (voxel, time index) of child i
+  __shared__ int                s_found[ASTAR_MAX_INPUTS];
+  __shared__ unsigned char      s_gate[ASTAR_MAX_INPUTS];  // 1 = passes every gate of :272-331
+  __shared__ unsigned char      s_ev[ASTAR_MAX_INPUTS];    // EV_* of child i
+  __shared__ short              s_leader[ASTAR_MAX_INPUTS];  // first gate-passing child with same key
+  __shared__ short              s_rank[ASTAR_MAX_INPUTS];    // #EV_NEW before child i
+  __shared__ int                s_src[ASTAR_MAX_INPUTS];     // leader -> child whose data its node takes
+  __shared__ short              s_events[ASTAR_MAX_INPUTS];  // children with an event, in order
+  __shared__ int                s_n_events, s_n_new_w0, s_n_ev_w0;
+  __shared__ int                s_n_inputs;
+  __shared__ double             s_cur_state[6];
+  __shared__ double             s_cur_time, s_cur_g;
+  __shared__ int                s_cur_index[3], s_cur_tidx;
+  __shared__ int                s_n_active;  // primitives of this expansion (0 = stop, < 0 = abort)
+  __shared__ int                s_first;     // 1 = "init" expansion (single input = start acc)
+  __shared__ int                s_was_first, s_cur_node, s_base_node, s_n_written;
+  __shared__ int                s_ret;
 
   Node               *pool = (Node *)(wsp.pool + (size_t)agent * wsp.pool_stride);
   unsigned long long *htab = (unsigned long long *)wsp.hkeys + (size_t)agent * wsp.hash_cap;
@@ -311,9 +307,10 @@ __global__ __launch_bounds__(64) void k_astar(
   // baseline_fake.cpp:282: t_after_map = traj_start_time_ - map_->getMapTime()
   const double time_start  = t_start[agent] - m.stamps[agent];
   const double time_origin = time_start;
+  const double tau         = ap.time_resolution;
 
   // motion primitive table (:245-250), generated with the reference's accumulating fp64 loops
-  if (lane == 0) {
+  if (tid == 0) {
     int          n  = 0;
     const double ma = ap.max_acc, res = 1 / 2.0;
     for (double ax = -ma; ax <= ma + 1e-3; ax += ma * res)
@@ -336,13 +333,15 @@ __global__ __launch_bounds__(64) void k_astar(
   int  use_node_num = 0, iter_num = 0, heap_n = 0, n_trace = 0;
   int  ret = NO_PATH, searches = 0, terminal = -1;
   bool is_shot_succ = false;
+  long long tk[6] = {0, 0, 0, 0, 0, 0};  // wall_clock64 ticks (100 MHz): pop, eval, dup, merge, write, n_exp
+  long long tmark = 0;
 
   for (int attempt = 0; attempt < 2; ++attempt) {  // baseline_fake.cpp:284-291
     // reset(): clear the hash table (all lanes)
-    for (int i = lane; i < hcap; i += 64) htab[i] = HASH_EMPTY;
+    for (int i = tid; i < hcap; i += ASTAR_THREADS) htab[i] = HASH_EMPTY;
     __syncthreads();
     bool done = false;
-    if (lane == 0) {
+    if (tid == 0) {
       use_node_num = 0;
       iter_num     = 0;
       heap_n       = 0;
@@ -378,7 +377,8 @@ __global__ __launch_bounds__(64) void k_astar(
     int cur = -1;
     while (!done) {
       // ---------------- master: pop / terminate ----------------
-      if (lane == 0) {
+      tmark = wall_clock64();
+      if (tid == 0) {
         s_n_active = 0;
         if (heap_n == 0) {
           ret = NO_PATH;  // open set empty (:419-422)
@@ -445,8 +445,12 @@ __global__ __launch_bounds__(64) void k_astar(
             s_cur_time = cn.time;
             s_cur_g    = cn.g;
             for (int i = 0; i < 3; ++i) s_cur_index[i] = cn.index[i];
-            s_cur_tidx = cn.time_idx;
-            s_n_active = s_first ? 1 : s_n_inputs;
+            s_cur_tidx  = cn.time_idx;
+            s_n_active  = s_first ? 1 : s_n_inputs;
+            s_was_first = s_first;
+            s_first     = 0;  // init_search = false after the first expansion (:243)
+            s_cur_node  = cur;
+            s_base_node = use_node_num;
           }
         }
       }
@@ -456,148 +460,173 @@ __global__ __launch_bounds__(64) void k_astar(
         done = true;
         break;
       }
-      // ---------------- all lanes: evaluate the primitives + probe the hash ----------------
-      const bool first = s_first != 0;
-      for (int i = lane; i < n_act; i += 64) {
-        double um[3];
-        if (first) {
-          um[0] = start_a[0];
-          um[1] = start_a[1];
-          um[2] = start_a[2];
-        } else {
-          um[0] = s_inputs[i][0];
-          um[1] = s_inputs[i][1];
-          um[2] = s_inputs[i][2];
-        }
-        const double tau = ap.time_resolution;
-        double       cs[6], ps[6];
-        for (int q = 0; q < 6; ++q) cs[q] = s_cur_state[q];
-        state_transit(cs, ps, um, tau);
-        const double pro_t = s_cur_time + tau;
-        Cand        &c     = s_cand[i];
-        pos_to_index(ps, center, inv_res, c.id);
-        c.t_id    = (int)floor((pro_t - time_origin) * inv_tres);
-        int flags = 0;
-        if (!(fabs(ps[3]) > ap.max_vel || fabs(ps[4]) > ap.max_vel || fabs(ps[5]) > ap.max_vel))
-          flags |= 1;
-        const bool same = c.id[0] == s_cur_index[0] && c.id[1] == s_cur_index[1] &&
-                          c.id[2] == s_cur_index[2] && (c.t_id - s_cur_tidx) == 0;
-        if (!same) flags |= 2;
-        // closed / open lookup (:271): find(pro_id, pro_t_id)
-        int found = -1, found_st = NOT_EXPAND;
-        if (pack_ok(c.id[0], c.id[1], c.id[2], c.t_id)) {
-          found = hash_find(htab, hcap, pack_key(c.id[0], c.id[1], c.id[2], c.t_id));
-          if (found >= 0) found_st = pool[found].node_state;
-        } else {
-          flags |= 8;  // index outside the packable range
-        }
-        if ((flags & 3) == 3 && !(found >= 0 && found_st == IN_CLOSE_SET)) {
-          // collision gate (:296-331)
-          for (int k = 1; k <= ap.check_num; ++k) {
-            const double dt = tau * (double)k / (double)ap.check_num;
-            double       xt[6];
-            state_transit(cs, xt, um, dt);
-            if (query_clear_time(m, agent, xt[0], xt[1], xt[2], s_cur_time + dt) != 0) {
-              flags |= 4;
-              break;
-            }
-          }
-          if (!(flags & 4)) {
-            double       ttg;
-            const double usq = (um[0] * um[0] + um[1] * um[1]) + um[2] * um[2];
-            c.g              = (usq + ap.w_time) * tau + s_cur_g;
-            c.f = c.g + ap.lambda_heu * estimate_heuristic(ap, ps, end_state, ttg);
-          }
-        }
-        for (int q = 0; q < 6; ++q) c.state[q] = ps[q];
-        c.flags    = flags;
-        c.found    = found;
-        c.found_st = found_st;
+      {
+        const long long t2 = wall_clock64();
+        tk[0] += t2 - tmark;
+        tmark = t2;
       }
-      __syncthreads();
-      // ---------------- all lanes: same-parent duplicate detection (:345-362) ----------------
-      // The reference scans the nodes created so far by this expansion for one in the same
-      // (voxel, time index).  Equivalent and parallel: the "leader" of child i is the first child
-      // j <= i that passes the gates and has the same key; a non-leader is pruned against its leader.
-      for (int i = lane; i < n_act; i += 64) {
-        const Cand &c   = s_cand[i];
-        const bool gate = (c.flags & 7) == 3 && !(c.found >= 0 && c.found_st == IN_CLOSE_SET);
-        int        L    = i;
-        if (gate) {
-          for (int j = 0; j < i; ++j) {
-            const Cand &o = s_cand[j];
-            const bool og = (o.flags & 7) == 3 && !(o.found >= 0 && o.found_st == IN_CLOSE_SET);
-            if (og && o.id[0] == c.id[0] && o.id[1] == c.id[1] && o.id[2] == c.id[2] && j < L) L = j;
-          }
-        }
-        s_leader[i] = gate ? L : -1;
-      }
-      __syncthreads();
-      // ---------------- master: ordered merge (:255-414), decisions only ----------------
-      const double tau    = ap.time_resolution;
+      // ---------------- all lanes: evaluate primitive `tid` + probe the hash ----------------
+      const bool   first  = s_was_first != 0;
       const double new_t  = s_cur_time + tau;
       const int    new_ti = (int)floor((new_t - time_origin) * inv_tres);
-      if (lane == 0) {
-        int        n_tmp     = 0;
-        const bool was_first = s_first != 0;
-        s_first              = 0;  // init_search = false after the first expansion (:243)
-        s_was_first          = was_first ? 1 : 0;
-        for (int i = 0; i < n_act && !done; ++i) {
-          const int L = s_leader[i];
-          if (L < 0) continue;  // closed, too fast, same cell as the parent, or in collision
-          const Cand &c = s_cand[i];
-          if (c.flags & 8) {
-            ret  = SEARCH_ERR;
-            done = true;
-            break;
+      {
+        const int i = tid;
+        if (i < n_act) {
+          double um[3];
+          if (first) {
+            um[0] = start_a[0];
+            um[1] = start_a[1];
+            um[2] = start_a[2];
+          } else {
+            um[0] = s_inputs[i][0];
+            um[1] = s_inputs[i][1];
+            um[2] = s_inputs[i][2];
           }
-          if (c.found < 0) {
-            if (L == i) {  // first child in this (voxel, time index): new node
-              const int node = use_node_num;
-              const int slot = n_tmp++;
-              s_slot_of[i]   = slot;
-              s_tmp[slot]    = node;
-              s_src[slot]    = i;
-              s_f[node]      = c.f;
-              heap_push(s_f, s_heap, heap_n, node);
-              if (pack_ok(c.id[0], c.id[1], c.id[2], (int)new_t)) {
-                // :387 quirk — insert(pro_id, pro_node->time, ...): double -> int truncation
-                s_ins_key[slot] = pack_key(c.id[0], c.id[1], c.id[2], (int)new_t);
-              } else {
-                ret  = SEARCH_ERR;
-                done = true;
-              }
-              use_node_num += 1;
-              if (use_node_num == ap.allocate_num) {  // "run out of memory" (:393-396)
-                ret  = NO_PATH;
-                done = true;
-              }
-            } else {  // pruned against the node its leader created; keep the better of the two
-              const int slot = s_slot_of[L];
-              const int e    = s_tmp[slot];
-              if (c.f < s_f[e]) {
-                s_f[e]      = c.f;
-                s_src[slot] = i;
+          double cs[6], ps[6];
+          for (int q = 0; q < 6; ++q) cs[q] = s_cur_state[q];
+          state_transit(cs, ps, um, tau);
+          int id[3];
+          pos_to_index(ps, center, inv_res, id);
+          const int t_id = new_ti;  // timeToIndex(cur->time + tau), the same for every child
+          bool      gate = !(fabs(ps[3]) > ap.max_vel || fabs(ps[4]) > ap.max_vel || fabs(ps[5]) > ap.max_vel);
+          const bool same = id[0] == s_cur_index[0] && id[1] == s_cur_index[1] &&
+                            id[2] == s_cur_index[2] && (t_id - s_cur_tidx) == 0;
+          gate = gate && !same;
+          // closed / open lookup (:271): find(pro_id, pro_t_id)
+          int                found = -1, found_st = NOT_EXPAND, ev = EV_NONE;
+          unsigned long long key   = HASH_EMPTY;
+          const bool packable = pack_ok(id[0], id[1], id[2], t_id) && pack_ok(id[0], id[1], id[2], (int)new_t);
+          if (packable) {
+            key   = pack_key(id[0], id[1], id[2], t_id);
+            found = hash_find(htab, hcap, key);
+            if (found >= 0) found_st = pool[found].node_state;
+          }
+          if (found >= 0 && found_st == IN_CLOSE_SET) gate = false;
+          double cg = 0.0, cf = 0.0;
+          if (gate) {
+            // collision gate (:296-331)
+            for (int k = 1; k <= ap.check_num; ++k) {
+              const double dt = tau * (double)k / (double)ap.check_num;
+              double       xt[6];
+              state_transit(cs, xt, um, dt);
+              if (query_clear_time(m, agent, xt[0], xt[1], xt[2], s_cur_time + dt) != 0) {
+                gate = false;
+                break;
               }
             }
-          } else if (c.found_st == IN_OPEN_SET) {
-            Node &pn = pool[c.found];
-            if (c.g < pn.g) {  // re-read: an earlier child of this expansion may have updated it
-              double um[3];
-              if (was_first) {
-                um[0] = start_a[0];
-                um[1] = start_a[1];
-                um[2] = start_a[2];
-              } else {
-                um[0] = s_inputs[i][0];
-                um[1] = s_inputs[i][1];
-                um[2] = s_inputs[i][2];
+          }
+          if (gate) {
+            double       ttg;
+            const double usq = (um[0] * um[0] + um[1] * um[1]) + um[2] * um[2];
+            cg               = (usq + ap.w_time) * tau + s_cur_g;
+            cf = cg + ap.lambda_heu * estimate_heuristic(ap, ps, end_state, ttg);
+            if (!packable)
+              ev = EV_ERR;  // index outside the packable range
+            else if (found >= 0)
+              ev = found_st == IN_OPEN_SET ? EV_OPEN : EV_ERR;
+          }
+          for (int q = 0; q < 6; ++q) s_cstate[i][q] = ps[q];
+          s_cf[i]    = cf;
+          s_cg[i]    = cg;
+          s_key[i]   = key;
+          s_found[i] = found;
+          s_gate[i]  = gate ? 1 : 0;
+          s_ev[i]    = (unsigned char)ev;
+          s_src[i]   = i;
+        }
+      }
+      __syncthreads();
+      {
+        const long long t2 = wall_clock64();
+        tk[1] += t2 - tmark;
+        tmark = t2;
+      }
+      // ---------------- all lanes: same-parent duplicates (:345-362) and event list ----------------
+      // leader(i) = first gate-passing child with the same key.  A child without a hash hit creates
+      // a node if it is its own leader (EV_NEW); otherwise it is pruned against its leader's node
+      // and replaces that node's data iff its f beats every earlier member of the group (EV_DUP).
+      int my_ev = EV_NONE;
+      if (tid < n_act) {
+        const int i = tid;
+        my_ev       = s_ev[i];
+        if (s_gate[i] && my_ev == EV_NONE) {
+          const unsigned long long key = s_key[i];
+          int                      L   = i;
+          double                   mn  = 0.0;
+          bool                     has = false;
+          for (int j = 0; j < i; ++j) {
+            if (s_gate[j] && s_key[j] == key) {
+              if (!has) {
+                L   = j;
+                mn  = s_cf[j];
+                has = true;
+              } else if (s_cf[j] < mn) {
+                mn = s_cf[j];
               }
-              for (int q = 0; q < 6; ++q) pn.state[q] = c.state[q];
-              pn.f         = c.f;
-              pn.g         = c.g;
-              s_f[c.found] = c.f;
-              for (int q = 0; q < 3; ++q) pn.input[q] = um[q];
+            }
+          }
+          s_leader[i] = (short)L;
+          if (!has) {
+            my_ev = EV_NEW;
+          } else if (s_cf[i] < mn) {
+            my_ev = EV_DUP;
+            atomicMax(&s_src[L], i);  // the last applied replacement wins (= first to reach the min)
+          }
+          s_ev[i] = (unsigned char)my_ev;
+        }
+      }
+      // ranks: number of EV_NEW / of events before child i (two waves)
+      {
+        const int                lane = tid & 63, wave = tid >> 6;
+        const unsigned long long lt   = lane ? (~0ull >> (64 - lane)) : 0ull;
+        const unsigned long long bn   = __ballot(my_ev == EV_NEW);
+        const unsigned long long be   = __ballot(my_ev != EV_NONE);
+        if (wave == 0 && lane == 0) {
+          s_n_new_w0 = __popcll(bn);
+          s_n_ev_w0  = __popcll(be);
+        }
+        __syncthreads();
+        const int rnew = __popcll(bn & lt) + (wave ? s_n_new_w0 : 0);
+        const int rev  = __popcll(be & lt) + (wave ? s_n_ev_w0 : 0);
+        if (tid < n_act) {
+          s_rank[tid] = (short)rnew;
+          if (my_ev != EV_NONE) s_events[rev] = (short)tid;
+        }
+        if (wave == 1 && lane == 0) s_n_events = s_n_ev_w0 + __popcll(be);
+      }
+      __syncthreads();
+      {
+        const long long t2 = wall_clock64();
+        tk[2] += t2 - tmark;
+        tmark = t2;
+      }
+      // ---------------- master: replay the events in child order (:366-414) ----------------
+      if (tid == 0) {
+        const int n_ev = s_n_events;
+        int       n_written = 0;
+        for (int k = 0; k < n_ev && !done; ++k) {
+          const int i  = s_events[k];
+          const int ev = s_ev[i];
+          if (ev == EV_NEW) {
+            const int node = s_base_node + s_rank[i];
+            s_f[node]      = s_cf[i];
+            heap_push(s_f, s_heap, heap_n, node);
+            use_node_num += 1;
+            n_written = s_rank[i] + 1;
+            if (use_node_num == ap.allocate_num) {  // "run out of memory" (:393-396)
+              ret  = NO_PATH;
+              done = true;
+            }
+          } else if (ev == EV_DUP) {
+            s_f[s_base_node + s_rank[s_leader[i]]] = s_cf[i];
+          } else if (ev == EV_OPEN) {
+            Node &pn = pool[s_found[i]];
+            if (s_cg[i] < pn.g) {  // re-read: an earlier child of this expansion may have updated it
+              for (int q = 0; q < 6; ++q) pn.state[q] = s_cstate[i][q];
+              pn.f            = s_cf[i];
+              pn.g            = s_cg[i];
+              s_f[s_found[i]] = s_cf[i];
+              for (int q = 0; q < 3; ++q) pn.input[q] = first ? start_a[q] : s_inputs[i][q];
               pn.duration = tau;
               pn.parent   = cur;
               pn.time     = new_t;
@@ -607,38 +636,46 @@ __global__ __launch_bounds__(64) void k_astar(
             done = true;
           }
         }
-        s_n_new    = n_tmp;
-        s_cur_node = cur;
-        s_n_active = done ? -1 : 1;
+        s_n_written = n_written;
+        s_n_active  = done ? -1 : 1;
       }
       __syncthreads();
+      {
+        const long long t2 = wall_clock64();
+        tk[3] += t2 - tmark;
+        tmark = t2;
+      }
       // ---------------- all lanes: write the new nodes + their hash entries ----------------
-      for (int slot = lane; slot < s_n_new; slot += 64) {
-        const int   i    = s_src[slot];
-        const int   node = s_tmp[slot];
-        const Cand &c    = s_cand[i];
-        Node       &pn   = pool[node];
-        for (int q = 0; q < 3; ++q) pn.index[q] = c.id[q];
-        for (int q = 0; q < 6; ++q) pn.state[q] = c.state[q];
-        pn.f = c.f;
-        pn.g = c.g;
-        if (s_was_first) {
-          for (int q = 0; q < 3; ++q) pn.input[q] = start_a[q];
-        } else {
-          for (int q = 0; q < 3; ++q) pn.input[q] = s_inputs[i][q];
-        }
+      if (tid < n_act && s_ev[tid] == EV_NEW && s_rank[tid] < s_n_written) {
+        const int L    = tid;
+        const int i    = s_src[L];  // child whose data the node ends up with
+        const int node = s_base_node + s_rank[L];
+        Node     &pn   = pool[node];
+        int       id[3];
+        pos_to_index(s_cstate[L], center, inv_res, id);
+        for (int q = 0; q < 3; ++q) pn.index[q] = id[q];
+        for (int q = 0; q < 6; ++q) pn.state[q] = s_cstate[i][q];
+        pn.f = s_cf[i];
+        pn.g = s_cg[i];
+        for (int q = 0; q < 3; ++q) pn.input[q] = first ? start_a[q] : s_inputs[i][q];
         pn.duration   = tau;
         pn.parent     = s_cur_node;
         pn.node_state = IN_OPEN_SET;
         pn.time       = new_t;
         pn.time_idx   = new_ti;
-        hash_insert(htab, hcap, s_ins_key[slot], node);
+        // :387 quirk — insert(pro_id, pro_node->time, ...): double -> int truncation
+        hash_insert(htab, hcap, pack_key(id[0], id[1], id[2], (int)new_t), node);
       }
       if (s_n_active < 0) done = true;
       __syncthreads();
+      {
+        const long long t2 = wall_clock64();
+        tk[4] += t2 - tmark;
+        tk[5] += 1;
+      }
     }
     // broadcast the verdict of this attempt
-    if (lane == 0) s_ret = ret;
+    if (tid == 0) s_ret = ret;
     __syncthreads();
     const int r = s_ret;
     __syncthreads();
@@ -646,7 +683,7 @@ __global__ __launch_bounds__(64) void k_astar(
   }
 
   // ---------------- master: getPathWithVel(corridor_tau) (:663-694) ----------------
-  if (lane == 0) {
+  if (tid == 0) {
     int n = 0;
     if (ret != NO_PATH && ret != SEARCH_ERR && terminal >= 0) {
       double *route = out_route + (size_t)agent * route_cap * 6;
@@ -699,6 +736,8 @@ __global__ __launch_bounds__(64) void k_astar(
     out_stats[agent * 4 + 1] = iter_num;
     out_stats[agent * 4 + 2] = n_path;
     out_stats[agent * 4 + 3] = searches;
+    if (wsp.dbg)
+      for (int k = 0; k < 6; ++k) wsp.dbg[(size_t)agent * 8 + k] = tk[k];
     if (out_trace && n_trace < trace_cap) out_trace[(size_t)agent * trace_cap + n_trace] = -1;
   }
 }
@@ -710,10 +749,10 @@ int launch_astar(const MapView &m, const SogmAstarParams &ap, double corridor_ta
                  const AstarWorkspace &wsp, int n_agents, const double *start_pva,
                  const double *goal, const double *t_start, int32_t *out_ret, double *out_route,
                  int32_t *out_route_len, int route_cap, int32_t *out_stats, int32_t *out_trace,
-                 int trace_cap, hipStream_t st) {
-  hipLaunchKernelGGL(k_astar, dim3(n_agents), dim3(64), 0, st, m, ap, corridor_tau, wsp,
+                 int trace_cap, hipStream_t st, int agent0) {
+  hipLaunchKernelGGL(k_astar, dim3(n_agents), dim3(ASTAR_THREADS), 0, st, m, ap, corridor_tau, wsp,
                      start_pva, goal, t_start, out_ret, out_route, out_route_len, route_cap,
-                     out_stats, out_trace, trace_cap);
+                     out_stats, out_trace, trace_cap, agent0);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

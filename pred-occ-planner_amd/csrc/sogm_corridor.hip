@@ -678,9 +678,9 @@ __device__ inline void wave_argmin(double &v, int &idx) {
 __global__ __launch_bounds__(64) void k_corridor_segment(
     MapView m, SogmPlannerParams pp, CorridorWorkspace ws, const double *__restrict__ start_pva,
     const double *__restrict__ t_start, const double *__restrict__ route,
-    const int32_t *__restrict__ route_len, int route_cap) {
+    const int32_t *__restrict__ route_len, int route_cap, int agent0) {
   const int seg   = blockIdx.x;
-  const int agent = blockIdx.y;
+  const int agent = blockIdx.y + agent0;
   const int lane  = threadIdx.x;
   const int rl    = route_len[agent];
   const int slot  = agent * SOGM_MAX_PIECES + seg;
@@ -1082,8 +1082,8 @@ __global__ __launch_bounds__(64) void k_corridor_finalize(
     SogmPlannerParams pp, CorridorWorkspace ws, const double *__restrict__ start_pva,
     const double *__restrict__ route, const int32_t *__restrict__ route_len, int route_cap,
     double *__restrict__ out_polys, int32_t *__restrict__ out_nfaces,
-    int32_t *__restrict__ out_npoly, double *__restrict__ out_goal) {
-  const int agent = blockIdx.x;
+    int32_t *__restrict__ out_npoly, double *__restrict__ out_goal, int agent0) {
+  const int agent = blockIdx.x + agent0;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double       *s_lp   = (double *)smem;
   double       *s_rows = s_lp + LP_WORK_DOUBLES;
@@ -1162,14 +1162,14 @@ int launch_corridor(const MapView &m, const SogmPlannerParams &pp, const Corrido
                     int n_agents, const double *start_pva, const double *t_start,
                     const double *route, const int32_t *route_len, int route_cap,
                     double *out_polys, int32_t *out_nfaces, int32_t *out_npoly, double *out_goal,
-                    hipStream_t st) {
+                    hipStream_t st, int agent0) {
   const size_t ldsA = corridor_segment_lds(pp.pc_capacity);
   hipLaunchKernelGGL(k_corridor_segment, dim3(SOGM_MAX_PIECES, n_agents), dim3(64), ldsA, st, m,
-                     pp, ws, start_pva, t_start, route, route_len, route_cap);
+                     pp, ws, start_pva, t_start, route, route_len, route_cap, agent0);
   if (hipGetLastError() != hipSuccess) return -1;
   const size_t ldsB = sizeof(double) * (LP_WORK_DOUBLES + LP_MAX_ROWS * 5) + sizeof(int) * LP_MAX_ROWS;
   hipLaunchKernelGGL(k_corridor_finalize, dim3(n_agents), dim3(64), ldsB, st, pp, ws, start_pva,
-                     route, route_len, route_cap, out_polys, out_nfaces, out_npoly, out_goal);
+                     route, route_len, route_cap, out_polys, out_nfaces, out_npoly, out_goal, agent0);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

@@ -2,6 +2,7 @@
 // up one at a time; entry points not yet wired return SOGM_ERR_STATE.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -55,8 +56,8 @@ static void min_jerk_block(double *QM /*15x15*/) {
 // duration[] and cpts[]); n_pieces = 0 marks "replan() returned false".
 __global__ void k_pack_records(int A, double corridor_tau, const int32_t *ret, const int32_t *npoly,
                                const int32_t *status, const double *cpts, const double *t_start,
-                               const int32_t *drone_ids, SogmTrajRecord *out, int32_t *ok) {
-  const int a = blockIdx.x * blockDim.x + threadIdx.x;
+                               const int32_t *drone_ids, SogmTrajRecord *out, int32_t *ok, int agent0) {
+  const int a = blockIdx.x * blockDim.x + threadIdx.x + agent0;
   if (a >= A) return;
   SogmTrajRecord &r = out[a];
   const bool good   = ret[a] != 0 && npoly[a] > 0 && (status[a] == 1 || status[a] == 2);
@@ -94,6 +95,7 @@ int sogm_planner_create(sogm_ctx *map, const SogmAstarParams *astar, const SogmP
   p->route_cap      = 64;
   hipError_t e      = hipMalloc((void **)&p->aw.pool, p->aw.pool_stride * A);
   if (e == hipSuccess) e = hipMalloc(&p->aw.hkeys, 8 * (size_t)hc * A);
+  if (e == hipSuccess) e = hipMalloc((void **)&p->aw.dbg, sizeof(long long) * 8 * A);
   if (e == hipSuccess) e = hipMalloc((void **)&p->d_ret, sizeof(int32_t) * A);
   if (e == hipSuccess) e = hipMalloc((void **)&p->d_route_len, sizeof(int32_t) * A);
   if (e == hipSuccess) e = hipMalloc((void **)&p->d_stats, sizeof(int32_t) * 4 * A);
@@ -127,6 +129,22 @@ int sogm_planner_create(sogm_ctx *map, const SogmAstarParams *astar, const SogmP
     if (e == hipSuccess) e = hipMalloc((void **)&p->d_status, sizeof(int32_t) * A);
     if (e == hipSuccess) e = hipMalloc((void **)&p->d_iters, sizeof(int32_t) * A);
   }
+  // Streams beyond the number of hardware queues (ROCm default GPU_MAX_HW_QUEUES = 4) share a queue
+  // and serialise, so the default is 2 groups; the Python driver raises both (GPU_MAX_HW_QUEUES = 16,
+  // SOGM_GROUPS = 8) before HIP initialises.
+  {
+    const char *eg = getenv("SOGM_GROUPS");
+    int         ng = eg ? atoi(eg) : 2;
+    if (ng < 1) ng = 1;
+    if (ng > SOGM_MAX_GROUPS) ng = SOGM_MAX_GROUPS;
+    p->n_groups = A < ng ? A : ng;
+  }
+  for (int g = 0; g < p->n_groups && e == hipSuccess; ++g) {
+    e = hipStreamCreateWithFlags(&p->gstream[g], hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_corr[g], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_done[g], hipEventDisableTiming);
+  }
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_in, hipEventDisableTiming);
   if (e != hipSuccess) {
     sogm::set_error("sogm_planner_create", e);
     sogm_planner_destroy(p);
@@ -137,7 +155,7 @@ int sogm_planner_create(sogm_ctx *map, const SogmAstarParams *astar, const SogmP
 }
 void sogm_planner_destroy(sogm_planner *p) {
   if (!p) return;
-  void *ptrs[] = {p->aw.pool, p->aw.hkeys,
+  void *ptrs[] = {p->aw.pool, p->aw.hkeys, p->aw.dbg,
                   p->d_ret,   p->d_route_len, p->d_stats, p->d_route,
                   p->cw.pc,   p->cw.fpc,  p->cw.tang, p->cw.distr, p->cw.polys,
                   p->cw.seg_nfaces, p->cw.seg_state, p->cw.seg_npts, p->cw.seg_dbg,
@@ -145,6 +163,15 @@ void sogm_planner_destroy(sogm_planner *p) {
                   p->d_polys, p->d_goal, p->d_cpts, p->d_nfaces, p->d_npoly, p->d_status, p->d_iters};
   for (void *q : ptrs)
     if (q) (void)hipFree(q);
+  for (int g = 0; g < SOGM_MAX_GROUPS; ++g) {
+    if (p->gstream[g]) {
+      (void)hipStreamSynchronize(p->gstream[g]);
+      (void)hipStreamDestroy(p->gstream[g]);
+    }
+    if (p->ev_corr[g]) (void)hipEventDestroy(p->ev_corr[g]);
+    if (p->ev_done[g]) (void)hipEventDestroy(p->ev_done[g]);
+  }
+  if (p->ev_in) (void)hipEventDestroy(p->ev_in);
   delete p;
 }
 
@@ -188,6 +215,15 @@ int sogm_corridor_generate(sogm_planner *p, const double *start_pva, const doubl
   }
   return SOGM_OK;
 }
+// diagnostics (tools/ only): per-agent A* phase ticks
+int sogm_debug_astar_stats(sogm_planner *p, long long *out_host) {
+  if (!p || !out_host) return SOGM_ERR_INVALID_ARG;
+  SOGM_HIP_CHECK(hipDeviceSynchronize());
+  SOGM_HIP_CHECK(hipMemcpy(out_host, p->aw.dbg, sizeof(long long) * 8 * (size_t)p->map->n_agents,
+                           hipMemcpyDeviceToHost));
+  return SOGM_OK;
+}
+
 // diagnostics (tools/ only): copy the per-segment corridor counters to the host
 int sogm_debug_corridor_stats(sogm_planner *p, long long *out_host) {
   if (!p || !out_host) return SOGM_ERR_INVALID_ARG;
@@ -220,32 +256,53 @@ int sogm_replan(sogm_planner *p, const double *start_pva, const double *goal,
                 int32_t *out_ok, void *stream) {
   if (!p || !start_pva || !goal || !t_start || !drone_ids || !out_records || !out_ok)
     return SOGM_ERR_INVALID_ARG;
-  int rc = sogm_astar_search(p, start_pva, goal, t_start, p->d_ret, p->d_route, p->d_route_len,
-                             p->route_cap, p->d_stats, nullptr, 0, stream);
-  if (rc) return rc;
-  rc = sogm_corridor_generate(p, start_pva, t_start, p->d_route, p->d_route_len, p->route_cap,
-                              p->d_polys, p->d_nfaces, p->d_npoly, p->d_goal, stream);
-  if (rc) return rc;
-  if (p->map->overlap) {
-    // the corridor stage was the last reader of the SOGM in this tick: clear it for the next
-    // update on the side stream, under the QP stage
-    sogm_ctx *c = p->map;
-    SOGM_HIP_CHECK(hipEventRecord(c->ev_grid_free, (hipStream_t)stream));
-    SOGM_HIP_CHECK(hipStreamWaitEvent(c->side, c->ev_grid_free, 0));
-    rc = sogm::launch_clear(c, c->side);
+  if (!p->map->updated) return SOGM_ERR_STATE;
+  sogm_ctx   *c    = p->map;
+  hipStream_t main = (hipStream_t)stream;
+  const int   A = c->n_agents, G = p->n_groups;
+  const MapView mv = view_of(c);
+  // fan out: every group stream starts when the caller's stream has produced the inputs
+  SOGM_HIP_CHECK(hipEventRecord(p->ev_in, main));
+  for (int g = 0; g < G; ++g) {
+    const int a0 = (int)((long long)A * g / G), a1 = (int)((long long)A * (g + 1) / G), n = a1 - a0;
+    if (n <= 0) continue;
+    hipStream_t st = p->gstream[g];
+    SOGM_HIP_CHECK(hipStreamWaitEvent(st, p->ev_in, 0));
+    if (launch_astar(mv, p->ap, p->pp.corridor_tau, p->aw, n, start_pva, goal, t_start, p->d_ret,
+                     p->d_route, p->d_route_len, p->route_cap, p->d_stats, nullptr, 0, st, a0) ||
+        launch_corridor(mv, p->pp, p->cw, n, start_pva, t_start, p->d_route, p->d_route_len,
+                        p->route_cap, p->d_polys, p->d_nfaces, p->d_npoly, p->d_goal, st, a0)) {
+      sogm::set_error("sogm_replan launch", hipGetLastError());
+      return SOGM_ERR_HIP;
+    }
+    SOGM_HIP_CHECK(hipEventRecord(p->ev_corr[g], st));
+  }
+  if (c->overlap) {
+    // every group's corridor stage was the last reader of the SOGM in this tick: clear it for the
+    // next update on the side stream, under the QP stage
+    for (int g = 0; g < G; ++g) SOGM_HIP_CHECK(hipStreamWaitEvent(c->side, p->ev_corr[g], 0));
+    int rc = sogm::launch_clear(c, c->side);
     if (rc) return rc;
     SOGM_HIP_CHECK(hipEventRecord(c->ev_cleared, c->side));
     c->precleared = 1;
     c->updated    = 0;
   }
-  rc = sogm_bezier_qp_solve(p, start_pva, p->d_goal, p->d_polys, p->d_nfaces, p->d_npoly,
-                            p->d_cpts, p->d_status, p->d_iters, stream);
-  if (rc) return rc;
-  const int A = p->map->n_agents;
-  hipLaunchKernelGGL(k_pack_records, dim3((A + 63) / 64), dim3(64), 0, (hipStream_t)stream, A,
-                     p->pp.corridor_tau, p->d_ret, p->d_npoly, p->d_status, p->d_cpts, t_start,
-                     drone_ids, out_records, out_ok);
-  SOGM_HIP_CHECK(hipGetLastError());
+  for (int g = 0; g < G; ++g) {
+    const int a0 = (int)((long long)A * g / G), a1 = (int)((long long)A * (g + 1) / G), n = a1 - a0;
+    if (n <= 0) continue;
+    hipStream_t st = p->gstream[g];
+    if (launch_qp(p->pp, p->qs, p->qw, p->qc, n, start_pva, p->d_goal, p->d_polys, p->d_nfaces,
+                  p->d_npoly, p->d_cpts, p->d_status, p->d_iters, st, a0)) {
+      sogm::set_error("sogm_replan launch_qp", hipGetLastError());
+      return SOGM_ERR_HIP;
+    }
+    hipLaunchKernelGGL(k_pack_records, dim3((n + 63) / 64), dim3(64), 0, st, a1, p->pp.corridor_tau,
+                       p->d_ret, p->d_npoly, p->d_status, p->d_cpts, t_start, drone_ids,
+                       out_records, out_ok, a0);
+    SOGM_HIP_CHECK(hipGetLastError());
+    SOGM_HIP_CHECK(hipEventRecord(p->ev_done[g], st));
+    SOGM_HIP_CHECK(hipStreamWaitEvent(main, p->ev_done[g], 0));  // fan in
+  }
   return SOGM_OK;
 }
 }

@@ -11,6 +11,7 @@ struct AstarWorkspace {
   size_t pool_stride;  // bytes per agent
   void  *hkeys;        // [A][hash_cap] 64-bit slots {x, y, z, t, node id}
   int    hash_cap;     // power of two >= 2 * allocate_num
+  long long *dbg;      // [A][8] per-phase wall_clock64 ticks (diagnostics)
 };
 int astar_pool_max();
 
@@ -31,7 +32,7 @@ int launch_corridor(const MapView &m, const SogmPlannerParams &pp, const Corrido
                     int n_agents, const double *start_pva, const double *t_start,
                     const double *route, const int32_t *route_len, int route_cap,
                     double *out_polys, int32_t *out_nfaces, int32_t *out_npoly, double *out_goal,
-                    hipStream_t st);
+                    hipStream_t st, int agent0 = 0);
 
 // Per-agent QP row storage in HBM, used only when a problem's rows do not fit in LDS.
 struct QpWorkspace {
@@ -46,16 +47,18 @@ struct QpConst {
 int launch_qp(const SogmPlannerParams &pp, const SogmQpSettings &qs, const QpWorkspace &ws,
               const QpConst &qc, int n_agents, const double *start_pva, const double *goal_pv,
               const double *polys, const int32_t *nfaces, const int32_t *npoly, double *out_cpts,
-              int32_t *out_status, int32_t *out_iters, hipStream_t st);
+              int32_t *out_status, int32_t *out_iters, hipStream_t st, int agent0 = 0);
 
 size_t astar_node_bytes();
 int    launch_astar(const MapView &m, const SogmAstarParams &ap, double corridor_tau,
                     const AstarWorkspace &wsp, int n_agents, const double *start_pva,
                     const double *goal, const double *t_start, int32_t *out_ret,
                     double *out_route, int32_t *out_route_len, int route_cap, int32_t *out_stats,
-                    int32_t *out_trace, int trace_cap, hipStream_t st);
+                    int32_t *out_trace, int trace_cap, hipStream_t st, int agent0 = 0);
 
 }  // namespace sogm
+
+#define SOGM_MAX_GROUPS 64
 
 struct sogm_planner {
   sogm_ctx            *map;
@@ -72,4 +75,9 @@ struct sogm_planner {
   int      route_cap;
   double  *d_polys, *d_goal, *d_cpts;
   int32_t *d_nfaces, *d_npoly, *d_status, *d_iters;
+  // agent groups: sogm_replan runs each group's search -> corridors -> QP chain on its own stream,
+  // so one slow agent (a long A* search, an infeasible QP) only delays its own group
+  int         n_groups;
+  hipStream_t gstream[SOGM_MAX_GROUPS];
+  hipEvent_t  ev_in, ev_corr[SOGM_MAX_GROUPS], ev_done[SOGM_MAX_GROUPS];
 };

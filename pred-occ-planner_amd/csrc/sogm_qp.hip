@@ -132,8 +132,8 @@ __global__ __launch_bounds__(256) void k_qp(SogmPlannerParams pp, SogmQpSettings
                                             const int32_t *__restrict__ npoly,
                                             double *__restrict__ out_cpts,
                                             int32_t *__restrict__ out_status,
-                                            int32_t *__restrict__ out_iters, int ablate) {
-  const int agent = blockIdx.x;
+                                            int32_t *__restrict__ out_iters, int ablate, int agent0) {
+  const int agent = blockIdx.x + agent0;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int M = npoly[agent];
   if (M <= 0 || M > SOGM_MAX_PIECES) {
@@ -903,7 +903,7 @@ __global__ __launch_bounds__(256) void k_qp(SogmPlannerParams pp, SogmQpSettings
 int launch_qp(const SogmPlannerParams &pp, const SogmQpSettings &qs, const QpWorkspace &ws,
               const QpConst &qc, int n_agents, const double *start_pva, const double *goal_pv,
               const double *polys, const int32_t *nfaces, const int32_t *npoly, double *out_cpts,
-              int32_t *out_status, int32_t *out_iters, hipStream_t st) {
+              int32_t *out_status, int32_t *out_iters, hipStream_t st, int agent0) {
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void *)k_qp, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -917,7 +917,7 @@ int launch_qp(const SogmPlannerParams &pp, const SogmQpSettings &qs, const QpWor
     ablate        = e ? atoi(e) : 0;
   }
   hipLaunchKernelGGL(k_qp, dim3(n_agents), dim3(256), ws.dyn_lds_bytes, st, pp, qs, ws, qc, start_pva,
-                     goal_pv, polys, nfaces, npoly, out_cpts, out_status, out_iters, ablate);
+                     goal_pv, polys, nfaces, npoly, out_cpts, out_status, out_iters, ablate, agent0);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

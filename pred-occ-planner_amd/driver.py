@@ -11,6 +11,13 @@ replaces the ROS broadcast; latest-wins per drone_id, a failed replan keeps the 
 The replan start state is sampled from the agent's own previous trajectory at t_start
 (plan_manager.cpp:169-175); agents without a trajectory hover at their position.
 """
+import os
+
+# sogm_replan runs agent groups on separate HIP streams; streams beyond the number of hardware
+# queues share a queue and serialise, so ask the runtime for more queues before HIP initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+os.environ.setdefault("SOGM_GROUPS", "8")
+
 import numpy as np
 import torch
 
