@@ -28,7 +28,8 @@ def parse():
     ap.add_argument("--grid", default="cfg2")
     ap.add_argument("--agents", type=int, default=None, help="agents per GPU (default: config's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-agents", type=int, default=4, help="cpu_baseline sample size (agents)")
+    ap.add_argument("--cpu-agents", type=float, default=12.0, dest="cpu_agents",
+                    help="cpu_baseline sample: seconds of wall time to spend on the CPU oracle")
     return ap.parse_args()
 
 
@@ -44,8 +45,8 @@ def cpu_baseline(pop, spec, scene, n_agents_sample):
     recs = pop.scene.straight_records(scene)
     body = pop.scene.body_particles()
     A = scene["n_agents"]
-    n = min(n_agents_sample, A)
-    cores = min(n, os.cpu_count() or 1)
+    cores = max(1, min(8, os.cpu_count() or 1, A))  # 640 MB grid per in-flight agent: bound the threads
+    budget_s = float(n_agents_sample)
 
     def one(a):
         g = orc.update_gt(spec, scene["cloud"], cyl, len(scene["cylinders"]), scene["poses"][a])
@@ -55,13 +56,19 @@ def cpu_baseline(pop, spec, scene, n_agents_sample):
                                     scene["goals"][a], scene["stamps"][a] + 0.02, a)
         return ok
 
+    # batches of `cores` agents (one thread each) of tick 0 until ~budget_s seconds of wall time
     t0 = time.time()
+    oks, nxt = [], 0
     with ThreadPoolExecutor(cores) as ex:
-        oks = list(ex.map(one, range(n)))
+        while time.time() - t0 < budget_s and nxt < 4 * A:
+            oks += list(ex.map(one, [(nxt + i) % A for i in range(cores)]))
+            nxt += cores
     dt = time.time() - t0
+    n = len(oks)
     return {"value": n / dt, "unit": "replans/s", "cores": cores, "kind": "port",
-            "sample": f"{n} agents x 1 tick (SOGM update + overlay + A* + corridors + QP) of the same "
-                      f"{spec.L}x{spec.W}x{spec.H}x{spec.T} workload, {sum(oks)}/{n} succeeded, {dt:.1f} s"}
+            "sample": f"{n} agent-replans of tick 0 (SOGM update + overlay + A* + corridors + QP) of the same "
+                      f"{spec.L}x{spec.W}x{spec.H}x{spec.T} workload, {cores} threads, "
+                      f"{sum(oks)}/{n} succeeded, {dt:.1f} s wall"}
 
 
 def main():
@@ -154,7 +161,7 @@ def main():
         "config": {"workload": f"{sw.A_loc} agents/GPU x {world} GPU, {spec.L}x{spec.W}x{spec.H}x{spec.T} SOGM, "
                                "sim_fkpcp-style moving cylinders, batched ADMM QP (BASELINE configs[2] per GPU)",
                    "agents_total": sw.A_tot, "grid": [spec.L, spec.W, spec.H, spec.T],
-                   "cloud_points": int(sw.scene["cloud"].shape[0]), "cylinders": int(len(sw.scene["cylinders"])),
+                   "cloud_points": int(sw.scene["cloud"].shape[0]), "cloud_points_scanned": sw.cloud_points, "cylinders": int(len(sw.scene["cylinders"])),
                    "replans_ok_fraction": n_ok / float(sw.A_loc * args.steps),
                    "parallelism": f"agents sharded x{world}, 1 all-gather/tick"},
         "stage_ms": {"clear": avg[0], "stamp": avg[1], "splat": avg[2], "astar": avg[3], "corridor": avg[4],

@@ -66,7 +66,11 @@ class SwarmTick:
         for k in ("starts", "goals", "poses", "stamps", "ego_ids"):
             loc[k] = self.scene[k][lo:hi]
         torch.cuda.set_device(device)
-        self.dev = upload_scene(loc)
+        # each agent scans only the cloud around it (its sensing neighbourhood): map half range +
+        # the distance it can fly during a run, so per-agent work does not grow with the swarm
+        crop, crange = scene_mod.crop_clouds(self.scene, lo, hi, half + 10.0)
+        self.dev = upload_scene(loc, cloud=crop, cloud_range=crange)
+        self.cloud_points = int(crop.shape[0])
         self.map = SogmMap(self.spec, self.A_loc, device)
         self.map.set_overlap_clear(overlap_clear)
         self.planner = SogmPlanner(self.map, config.make_astar_params(), config.make_planner_params(True),

@@ -72,9 +72,6 @@ def make_scene(n_agents, half_range, seed, moving=True, n_cyl=None, circle_radiu
     # agents evenly on a circle, >= 1.5 m apart, antipodal goals, z = 1
     if circle_radius is None:
         circle_radius = max(8.0, 1.5 * n_agents / (2.0 * math.pi))
-    field = circle_radius + 2.0  # obstacle field half size
-    if n_cyl is None:
-        n_cyl = max(20, int(round(20.0 * (2 * field) ** 2 / 256.0)))  # 20 per 16x16 m
     starts = np.zeros((n_agents, 3))
     goals = np.zeros((n_agents, 3))
     for a in range(n_agents):
@@ -85,19 +82,39 @@ def make_scene(n_agents, half_range, seed, moving=True, n_cyl=None, circle_radiu
         starts[0] = (-8.0, 0.0, 1.0)
         goals[0] = (8.0, 0.0, 1.0)
 
+    # Obstacles where the agents fly during a run: the annulus [R - inner, R + outer] around the
+    # start circle (the whole disk for small swarms), at the launch file's density of 20 per 16x16 m.
+    inner, outer = 30.0, half_range + 2.0
+    r_lo, r_hi = max(circle_radius - inner, 0.0), circle_radius + outer
+    if n_agents == 1:
+        r_lo, r_hi = 0.0, 8.0 + outer
+    if n_cyl is None:
+        n_cyl = max(20, int(round(20.0 * math.pi * (r_hi ** 2 - r_lo ** 2) / 256.0)))
     cyl = []
     guard = 0
-    while len(cyl) < n_cyl and guard < 100000:
+    # spatial hash of starts/goals for the clearance test (keeps generation O(n_cyl))
+    pts_sg = np.concatenate([starts[:, :2], goals[:, :2]], axis=0)
+    cell = 4.0
+    table = {}
+    for q in pts_sg:
+        table.setdefault((int(math.floor(q[0] / cell)), int(math.floor(q[1] / cell))), []).append(q)
+    while len(cyl) < n_cyl and guard < 50 * n_cyl + 1000:
         guard += 1
-        x = rng.uniform(-field, field)
-        y = rng.uniform(-field, field)
+        rho = math.sqrt(rng.uniform(r_lo ** 2, r_hi ** 2))
+        ang = rng.uniform(0.0, 2.0 * math.pi)
+        x, y = rho * math.cos(ang), rho * math.sin(ang)
         w = rng.uniform(0.5, 1.0)
         speed = rng.uniform(0.0, 0.1) * (10.0 if moving else 0.0)  # up to 1 m/s when moving
         head = rng.uniform(0.0, 2.0 * math.pi)
         # keep 1 m (+ radius) clear around every start/goal
-        d_s = np.hypot(starts[:, 0] - x, starts[:, 1] - y).min()
-        d_g = np.hypot(goals[:, 0] - x, goals[:, 1] - y).min()
-        if min(d_s, d_g) < 1.0 + w + 0.6:
+        cx, cy = int(math.floor(x / cell)), int(math.floor(y / cell))
+        near = False
+        for dx in (-1, 0, 1):
+            for dy in (-1, 0, 1):
+                for q in table.get((cx + dx, cy + dy), ()):
+                    if math.hypot(q[0] - x, q[1] - y) < 1.0 + w + 0.6:
+                        near = True
+        if near:
             continue
         cyl.append((x, y, w, speed * math.cos(head), speed * math.sin(head)))
     cyl = np.asarray(cyl, dtype=np.float64).reshape(-1, 5)
@@ -163,3 +180,23 @@ def records_to_numpy(recs):
 
 def struct_to_numpy(arr):
     return np.frombuffer(bytes(arr), dtype=np.uint8).copy()
+
+
+def crop_clouds(scene, lo, hi, half):
+    """Per-agent crop of the global cloud: agent a sees the points within `half` metres (x and y)
+    of its start — the role of the simulator's local sensing radius.  Returns (points, ranges) with
+    the crops concatenated; ranges[a] = (begin, end) in the ABI's cloud_range layout."""
+    cloud = scene["cloud"]
+    order = np.argsort(cloud[:, 0], kind="stable")
+    xs = cloud[order, 0]
+    chunks, ranges, pos = [], [], 0
+    for a in range(lo, hi):
+        cx, cy = scene["starts"][a, 0], scene["starts"][a, 1]
+        i0, i1 = np.searchsorted(xs, cx - half), np.searchsorted(xs, cx + half, side="right")
+        sel = order[i0:i1]
+        sel = np.sort(sel[np.abs(cloud[sel, 1] - cy) <= half])  # keep the global point order
+        chunks.append(cloud[sel])
+        ranges.append((pos, pos + len(sel)))
+        pos += len(sel)
+    pts = np.concatenate(chunks, axis=0) if chunks else np.zeros((0, 3), np.float32)
+    return np.ascontiguousarray(pts, np.float32), np.asarray(ranges, np.int32).reshape(-1, 2)

@@ -128,15 +128,17 @@ class SogmMap:
         return pts, cnt
 
 
-def upload_scene(scene, device="cuda"):
-    """numpy scene -> dict of device tensors in the ABI's layouts."""
+def upload_scene(scene, device="cuda", cloud=None, cloud_range=None):
+    """numpy scene -> dict of device tensors in the ABI's layouts.  By default every agent sees the
+    whole cloud; pass per-agent crops (scene.crop_clouds) to bound each agent's scan."""
     from .scene import cylinders_to_struct
     A = scene["n_agents"]
-    n_pts = scene["cloud"].shape[0]
+    pts = scene["cloud"] if cloud is None else cloud
+    n_pts = pts.shape[0]
     cyl = cylinders_to_struct(scene["cylinders"])
-    rng = np.tile(np.asarray([[0, n_pts]], dtype=np.int32), (A, 1))
+    rng = np.tile(np.asarray([[0, n_pts]], dtype=np.int32), (A, 1)) if cloud_range is None else cloud_range
     return {
-        "cloud": _dev(scene["cloud"] if n_pts else np.zeros((1, 3), np.float32), np.float32, device),
+        "cloud": _dev(pts if n_pts else np.zeros((1, 3), np.float32), np.float32, device),
         "cloud_range": _dev(rng, np.int32, device),
         "cylinders": _dev(cyl, None, device),
         "n_cyl": int(len(scene["cylinders"])),
