@@ -144,6 +144,16 @@ def main():
     avg = np.mean(np.array(clear_ms), axis=0)
     avg[3:6] = ms_stage[3:6]
     grid_bytes = sw.map.grid_bytes()  # V * T * 4 bytes x agents of this rank = algorithmic bytes / launch
+    # HBM traffic of the roofline kernel comes from the committed PMC passes (FETCH_SIZE + WRITE_SIZE,
+    # separate rocprofv3 runs): only valid for the workload they were collected on
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            pmc = json.load(f)
+        if pmc["algorithmic_bytes_per_launch"] == grid_bytes:
+            traffic = pmc["bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
     achieved = grid_bytes / (avg[0] * 1e-3) / 1e9
     out = {
         "metric": "replans/sec (SOGM update + A* + corridors + QP), aggregate over all agents",
@@ -167,7 +177,7 @@ def main():
         "stage_ms": {"clear": avg[0], "stamp": avg[1], "splat": avg[2], "astar": avg[3], "corridor": avg[4],
                      "qp": avg[5]},
         "roofline": {"bound": "hbm", "kernel": "k_clear_slabs (SOGM voxel update)", "achieved": achieved,
-                     "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
+                     "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
                      "bytes_per_launch": grid_bytes, "avg_launch_ms": float(avg[0])},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
