@@ -45,8 +45,11 @@ typedef enum sogm_status {
 
 /* Which reference map class the context reproduces. */
 enum {
-  SOGM_MAP_FAKE     = 0, /* FakeParticleRiskVoxel  plan_env/src/fake_particle_risk_voxel.cpp     */
-  SOGM_MAP_RISKBASE = 1  /* RiskBase               plan_env/src/risk_base.cpp                    */
+  SOGM_MAP_FAKE      = 0, /* FakeParticleRiskVoxel  plan_env/src/fake_particle_risk_voxel.cpp    */
+  SOGM_MAP_RISKBASE  = 1, /* RiskBase               plan_env/src/risk_base.cpp                   */
+  SOGM_MAP_RISKVOXEL = 2  /* RiskVoxel (DSP particle map)  plan_env/src/risk_voxel.cpp: queries
+                             as RiskBase; the neighbour overlay SETS cells to 1.0
+                             (addObstaclesToRiskMap :311-318) instead of adding risk.            */
 };
 
 /*
@@ -244,6 +247,82 @@ int sogm_download_reference_layout(sogm_ctx *ctx, int agent, float *out_vt_host)
  */
 int sogm_traj_eval(const SogmTrajRecord *records, int n, const double *t, double *out_pva,
                    int32_t *out_valid, void *stream);
+
+
+/* ------------------------------------------------------------------------------------------ */
+/* particle-filter SOGM:  dsp_map::DSPMap  (plan_env/include/plan_env/dsp_dynamic.h)            */
+/*   as owned and configured by RiskVoxel (plan_env/src/risk_voxel.cpp:42-50,237-254)          */
+/* ------------------------------------------------------------------------------------------ */
+/* Compile-time constants of the reference (plan_env/include/plan_env/map_parameters.h:5-54) and
+ * the DSPMap settings RiskVoxel::init applies, as runtime values.  The grid (L,W,H,T,resolution)
+ * comes from the SogmSpec of the map context; T = PREDICTION_TIMES. */
+#define SOGM_DSP_MAX_T 16
+typedef struct SogmDspParams {
+  int32_t max_particle_num_voxel; /* MAX_PARTICLE_NUM_VOXEL 7; slots per voxel = 2x (:51)        */
+  int32_t half_fov_h;             /* 43 deg (:22)                                                */
+  int32_t half_fov_v;             /* 29 deg (:24)                                                */
+  int32_t angle_resolution;       /* ANGLE_RESOLUTION 1 (:9)                                     */
+  int32_t newborn_num;            /* setNewBornParticleNumberofEachPoint(20) risk_voxel.cpp:47   */
+  int32_t obs_max_per_pyramid;    /* observation_max_points_num_one_pyramid 100 (:51)            */
+  float   prediction_times[SOGM_DSP_MAX_T]; /* prediction_future_time {0.3 .. 1.8} (:19)         */
+  float   sigma_observation;      /* map/sigma_observation 0.05 (risk_voxel.cpp:20,45)           */
+  float   p_detection;            /* 0.95 (dsp_dynamic.h:135)                                    */
+  float   kappa;                  /* 0.01 (:134)                                                 */
+  float   newborn_weight;         /* setNewBornParticleWeight(0.0001) risk_voxel.cpp:49          */
+  float   obstacle_thickness;     /* obstacle_thickness_for_occlusion 0.3 (map_parameters.h:54)  */
+} SogmDspParams;
+
+typedef struct sogm_dsp sogm_dsp;
+
+/*
+ * DSPMap::DSPMap + setInitParameters (dsp_dynamic.h:118-163,566-632) for every agent of `map`.
+ * The reference fills three 1e7-entry Gaussian tables from a time(0)-seeded engine (:1229-1239)
+ * and draws uniforms from rand(); here the tables are inputs so that runs are reproducible:
+ * host p_gauss[n_gauss] (position noise, N(0, 0.05)), v_gauss[n_gauss] (velocity noise),
+ * rand_tab[n_rand] (values of rand(), 0..RAND_MAX).  The tables are read cyclically.
+ * max_points: capacity of one agent's cloud (5000 in MapBase::filterPointCloud, map.cpp:126).
+ * Particle store per agent: V x 16 slots x 25 B (SoA) — SOGM_ERR_HIP if it does not fit in HBM.
+ */
+int  sogm_dsp_create(sogm_ctx *map, const SogmDspParams *params, const float *p_gauss,
+                     const float *v_gauss, int n_gauss, const int32_t *rand_tab, int n_rand,
+                     int max_points, sogm_dsp **out);
+void sogm_dsp_destroy(sogm_dsp *d);
+
+/*
+ * DSPMap::update (dsp_dynamic.h:165-364) for every agent: observation binning into FOV pyramids,
+ * mapPrediction (:663), mapUpdate (:750), mapAddNewBornParticlesByObservation (:852),
+ * mapOccupancyCalculationAndResample (:993).  Stream-ordered, no host round trip.
+ * dev points  [n_total*3] fp32  sensor-frame points, already voxel-filtered (MapBase::filterPointCloud)
+ * dev labels  [n_total*4] fp32  {vx, vy, vz, intensity} per point = the output of
+ *             velocityEstimationThread (:1487-1678; PCL clustering + Munkres — not restated);
+ *             new-born particles are created in the order the points are given
+ * dev cloud_range [n_agents*2] int32 {begin,end} points of each agent
+ * dev sensor_pos [n_agents*3] fp32, dev sensor_quat [n_agents*4] fp32 (w,x,y,z), dev stamps [n_agents] fp64
+ * dev out_ok  [n_agents] int32: DSPMap::update's return value (0 = rejected odometry, :186-203)
+ */
+int sogm_update_dsp(sogm_dsp *d, const float *points, const float *labels,
+                    const int32_t *cloud_range, const float *sensor_pos, const float *sensor_quat,
+                    const double *stamps, int32_t *out_ok, void *stream);
+
+/*
+ * The map half of RiskVoxel::publishMap (risk_voxel.cpp:138-153): getOccupancyMapWithFutureStatus
+ * (dsp_dynamic.h:445-469) into the SOGM grid of the map context (which also adopts the sensor
+ * position / stamp of the last update as map pose / map time), clearing the future accumulators,
+ * then the zeroing loop over the inflate kernel.  dev out_n_occupied [n_agents] int32 or NULL.
+ * Follow with sogm_project_neighbours() for the overlay (risk_voxel.cpp:161-163).
+ */
+int sogm_dsp_publish(sogm_dsp *d, int32_t *out_n_occupied, void *stream);
+
+/* Parity I/O (synchronous): agent's particle store in the reference layout
+ * voxels_with_particle[V][2*max][9] (slot 8, the update time, is written as 0) and
+ * voxels_objects_number[V][4+T]; counters[16]: {voxel_full, pyramid_full, moved_out, candidates,
+ * p_seq, v_seq, rand_seq, slots_per_voxel, slots_per_pyramid, n_pyramids, unconverged_rounds,
+ * pool_overflow, ...}.  Any pointer may be NULL. */
+int sogm_dsp_download_state(sogm_dsp *d, int agent, float *store_host, float *objnum_host,
+                            int32_t *counters_host);
+/* Observation tables of the last update: nobs[n_pyramids], pc[n_pyramids*obs_max*5], maxlen[n_pyramids] */
+int sogm_dsp_download_observations(sogm_dsp *d, int agent, int32_t *nobs_host, float *pc_host,
+                                   float *maxlen_host);
 
 /* ------------------------------------------------------------------------------------------ */
 /* queries                                                                                     */

@@ -258,3 +258,50 @@ def replan(spec, ap, pp, qs, grid, pose, stamp, start_pva, goal, t_start, drone_
                           C.c_double(stamp), dptr(s), dptr(g), C.c_double(t_start), int(drone_id),
                           C.byref(rec), stage)
     return ok, rec, stage[0]
+
+
+# ---------------------------------------------------------------- particle-filter SOGM (a6)
+class DspOracle:
+    """dsp_map::DSPMap restated (oracle/dsp_oracle.cpp), one agent."""
+
+    def __init__(self, spec, params, tables):
+        pg, vg, rnd = tables
+        L = lib()
+        L.orc_dsp_create.restype = C.c_void_p
+        self.spec, self.params = spec, params
+        self.h = C.c_void_p(L.orc_dsp_create(C.byref(spec), C.byref(params), fptr(pg), fptr(vg), len(pg),
+                                             rnd.ctypes.data_as(C.c_void_p), len(rnd)))
+        self.V = spec.L * spec.W * spec.H
+        self.S = 2 * params.max_particle_num_voxel
+
+    def update(self, points, labels, pos, quat, stamp):
+        pts = np.ascontiguousarray(points, np.float32)
+        lab = np.ascontiguousarray(labels, np.float32)
+        return lib().orc_dsp_update(self.h, len(pts), fptr(pts), fptr(lab), C.c_float(pos[0]), C.c_float(pos[1]),
+                                    C.c_float(pos[2]), C.c_double(stamp), C.c_float(quat[0]), C.c_float(quat[1]),
+                                    C.c_float(quat[2]), C.c_float(quat[3]))
+
+    def publish(self, threshold, inf_step):
+        out = np.zeros((self.V, self.spec.T), np.float32)
+        n = lib().orc_dsp_publish(self.h, fptr(out), C.c_float(threshold), inf_step)
+        return out, n
+
+    def state(self):
+        store = np.zeros((self.V, self.S, 9), np.float32)
+        objnum = np.zeros((self.V, 4 + self.spec.T), np.float32)
+        counters = np.zeros(16, np.int32)
+        lib().orc_dsp_state(self.h, fptr(store), fptr(objnum), counters.ctypes.data_as(C.c_void_p))
+        return store, objnum, counters
+
+    def observations(self, NP):
+        OM = self.params.obs_max_per_pyramid
+        nobs = np.zeros(NP, np.int32)
+        pc = np.zeros((NP, OM, 5), np.float32)
+        ml = np.zeros(NP, np.float32)
+        lib().orc_dsp_observations(self.h, nobs.ctypes.data_as(C.c_void_p), fptr(pc), fptr(ml))
+        return nobs, pc, ml
+
+    def close(self):
+        if self.h:
+            lib().orc_dsp_destroy(self.h)
+            self.h = None

@@ -115,6 +115,16 @@ int orc_replan(const SogmSpec *s, const SogmAstarParams *ap, const SogmPlannerPa
                const double start_pva[9], const double goal[3], double t_start, int drone_id,
                SogmTrajRecord *out_record, int stage_fail[1]);
 
+/* ---- a6: particle-filter SOGM (plan_env/include/plan_env/dsp_dynamic.h), see dsp_oracle.cpp ---- */
+void *orc_dsp_create(const SogmSpec *spec, const SogmDspParams *P, const float *p_gauss,
+                     const float *v_gauss, int n_gauss, const int32_t *rand_tab, int n_rand);
+void  orc_dsp_destroy(void *h);
+int   orc_dsp_update(void *h, int n, const float *pts, const float *labels, float px, float py,
+                     float pz, double stamp, float qw, float qx, float qy, float qz);
+int   orc_dsp_publish(void *h, float *out_vt, float threshold, int inf_step);
+void  orc_dsp_state(void *h, float *store, float *objnum, int *counters);
+void  orc_dsp_observations(void *h, int *nobs, float *pc, float *maxlen);
+
 #ifdef __cplusplus
 }
 #endif

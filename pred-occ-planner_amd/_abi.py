@@ -12,6 +12,8 @@ LIB_PATH = os.path.join(_HERE, "libsogm_hip.so")
 SOGM_MAX_PIECES = 16
 SOGM_MAP_FAKE = 0
 SOGM_MAP_RISKBASE = 1
+SOGM_MAP_RISKVOXEL = 2
+SOGM_DSP_MAX_T = 16
 
 SOGM_OK = 0
 SOGM_ERR_INVALID_ARG = -1
@@ -32,6 +34,15 @@ class SogmSpec(C.Structure):
                 ("ground_height", C.c_float), ("ceiling_height", C.c_float),
                 ("risk_threshold_region", C.c_float), ("risk_thres_reg_decay", C.c_float),
                 ("risk_thres_vox_decay", C.c_float), ("map_kind", C.c_int32)]
+
+
+class SogmDspParams(C.Structure):
+    _fields_ = [("max_particle_num_voxel", C.c_int32), ("half_fov_h", C.c_int32),
+                ("half_fov_v", C.c_int32), ("angle_resolution", C.c_int32),
+                ("newborn_num", C.c_int32), ("obs_max_per_pyramid", C.c_int32),
+                ("prediction_times", C.c_float * SOGM_DSP_MAX_T),
+                ("sigma_observation", C.c_float), ("p_detection", C.c_float), ("kappa", C.c_float),
+                ("newborn_weight", C.c_float), ("obstacle_thickness", C.c_float)]
 
 
 class SogmCylinder(C.Structure):
@@ -101,6 +112,12 @@ PROTOTYPES = {
     "sogm_corridor_generate": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "sogm_bezier_qp_solve": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sogm_replan": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "sogm_dsp_create": (_i, [_vp, C.POINTER(SogmDspParams), _vp, _vp, _i, _vp, _i, _i, C.POINTER(_vp)]),
+    "sogm_dsp_destroy": (None, [_vp]),
+    "sogm_update_dsp": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "sogm_dsp_publish": (_i, [_vp, _vp, _vp]),
+    "sogm_dsp_download_state": (_i, [_vp, _i, _vp, _vp, _vp]),
+    "sogm_dsp_download_observations": (_i, [_vp, _i, _vp, _vp, _vp]),
 }
 
 

@@ -200,3 +200,68 @@ def crop_clouds(scene, lo, hi, half):
         pos += len(sel)
     pts = np.concatenate(chunks, axis=0) if chunks else np.zeros((0, 3), np.float32)
     return np.ascontiguousarray(pts, np.float32), np.asarray(ranges, np.int32).reshape(-1, 2)
+
+
+def quat_yaw(yaw):
+    return np.asarray([math.cos(yaw / 2.0), 0.0, 0.0, math.sin(yaw / 2.0)], np.float32)
+
+
+def make_dsp_sequence(seed, n_updates, half=(4.95, 4.95, 1.5), n_pillars=6, dt=0.1, speed=0.6,
+                      max_points=5000, wall=True):
+    """Synthetic sensor-frame clouds for the particle-filter SOGM (SURVEY.md 8d "depth clouds"):
+    a sensor flying along +x with a slow yaw oscillation past static pillars, one moving pillar
+    (points labelled with its velocity, as velocityEstimationThread would) and one unmatched cluster
+    (label vx = -10000), plus ground points and an optional side wall.  Points lie on a 0.15 m lattice
+    (MapBase::filterPointCloud output), within 5 m and +-60 deg of the optical axis; the FOV test itself
+    is the map's job.  Returns a list of dicts {points [n,3] f32 sensor frame, labels [n,4] f32,
+    pos [3] f32, quat [4] f32 wxyz, stamp f64}."""
+    rng = SplitMix64(seed)
+    pillars = []
+    for i in range(n_pillars):
+        pillars.append([rng.uniform(1.5, 9.0), rng.uniform(-3.0, 3.0), rng.uniform(0.2, 0.45), 0.0, 0.0, 0])
+    pillars.append([4.0, -2.5, 0.3, -0.2, 0.5, 1])    # moving, matched cluster
+    pillars.append([6.0, 2.0, 0.3, 0.0, 0.0, 2])      # unmatched cluster (vx label -10000)
+    out = []
+    zs = np.arange(-8, 9) * 0.15
+    for k in range(n_updates):
+        t = 100.0 + k * dt
+        pos = np.asarray([speed * k * dt, 0.1 * math.sin(0.7 * k * dt), 0.05 * math.sin(0.5 * k * dt)], np.float32)
+        yaw = 0.25 * math.sin(0.9 * k * dt)
+        q = quat_yaw(yaw)
+        cy, sy = math.cos(yaw), math.sin(yaw)
+        pts, lab = [], []
+        for (x0, y0, r, vx, vy, kind) in pillars:
+            cx, cyy = x0 + vx * k * dt, y0 + vy * k * dt
+            for ang in np.arange(0.0, 2 * math.pi, 0.15 / r):
+                wx, wy = cx + r * math.cos(ang), cyy + r * math.sin(ang)
+                # visible half only (normal faces the sensor)
+                if (wx - cx) * (pos[0] - wx) + (wy - cyy) * (pos[1] - wy) <= 0:
+                    continue
+                for z in zs:
+                    pts.append((wx, wy, z))
+                    lab.append((vx, vy, 0.0, 0.5) if kind == 1 else
+                               (-10000.0, -10000.0, -10000.0, 0.7) if kind == 2 else (0.0, 0.0, 0.0, 0.0))
+        for gx in np.arange(0.5, 5.0, 0.3):          # ground strip ahead of the sensor
+            for gy in np.arange(-2.0, 2.01, 0.3):
+                pts.append((pos[0] + gx, gy, -1.2))
+                lab.append((0.0, 0.0, 0.0, 0.0))
+        if wall:                                      # side wall seen at a grazing angle
+            for wx in np.arange(pos[0] + 1.0, pos[0] + 5.0, 0.15):
+                for z in zs[4:13]:
+                    pts.append((wx, 1.6, z))
+                    lab.append((0.0, 0.0, 0.0, 0.0))
+        pts = np.asarray(pts, np.float64).reshape(-1, 3)
+        lab = np.asarray(lab, np.float32).reshape(-1, 4)
+        rel = pts - pos.astype(np.float64)
+        # world-aligned -> sensor frame: rotate by -yaw
+        sx = cy * rel[:, 0] + sy * rel[:, 1]
+        syy = -sy * rel[:, 0] + cy * rel[:, 1]
+        rng_ = np.sqrt(sx * sx + syy * syy + rel[:, 2] ** 2)
+        keep = (rng_ < 5.0) & (sx > 0.2) & (np.abs(np.arctan2(syy, sx)) < math.radians(60.0))
+        sp = np.stack([sx, syy, rel[:, 2]], axis=1)[keep].astype(np.float32)
+        lab = lab[keep]
+        if len(sp) > max_points:
+            sp, lab = sp[:max_points], lab[:max_points]
+        out.append({"points": np.ascontiguousarray(sp), "labels": np.ascontiguousarray(lab), "pos": pos,
+                    "quat": q, "stamp": t})
+    return out
