@@ -249,6 +249,23 @@ int sogm_traj_eval(const SogmTrajRecord *records, int n, const double *t, double
                    int32_t *out_valid, void *stream);
 
 
+/*
+ * MapBase::filterPointCloud (plan_env/src/map.cpp:107-132; duplicate risk_mapping_node.cpp:74-99) for
+ * every agent: pcl::VoxelGrid centroid filter with leaf `filter_res` (one fp32 centroid per occupied
+ * leaf, emitted in ascending leaf index — PCL >= 1.8 applyFilter, third-party), camera->body axis
+ * swap (x = z, y = -x, z = -y), isInRange against the map's local range, stop at `cap` points
+ * (5000 in the reference).  The output feeds sogm_update_dsp as `points`.
+ * dev raw_xyz   [n_total*3] fp32 camera-frame points (non-finite points are skipped)
+ * dev raw_range [n_agents*2] int32 {begin,end}
+ * dev out_xyz   [n_agents*cap*3] fp32,  dev out_count [n_agents] int32 (-1: the cloud's bounding box
+ *               has more leaves than the accumulator array, see sogm_filter_reserve)
+ */
+int sogm_filter_point_cloud(sogm_ctx *ctx, const float *raw_xyz, const int32_t *raw_range,
+                            float filter_res, int cap, float *out_xyz, int32_t *out_count,
+                            void *stream);
+/* Leaf accumulators per agent (default 2^20 = a 15 m cube at 0.15 m); call before the first filter call. */
+int sogm_filter_reserve(sogm_ctx *ctx, int max_cells_per_agent);
+
 /* ------------------------------------------------------------------------------------------ */
 /* particle-filter SOGM:  dsp_map::DSPMap  (plan_env/include/plan_env/dsp_dynamic.h)            */
 /*   as owned and configured by RiskVoxel (plan_env/src/risk_voxel.cpp:42-50,237-254)          */

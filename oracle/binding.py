@@ -305,3 +305,11 @@ class DspOracle:
         if self.h:
             lib().orc_dsp_destroy(self.h)
             self.h = None
+
+
+# ---------------------------------------------------------------- filterPointCloud (a7)
+def filter_point_cloud(spec, raw, filter_res=0.15, cap=5000):
+    raw = np.ascontiguousarray(raw, np.float32)
+    out = np.zeros((cap, 3), np.float32)
+    n = lib().orc_filter_point_cloud(C.byref(spec), fptr(raw), len(raw), C.c_float(filter_res), cap, fptr(out))
+    return out[:n].copy()

@@ -125,6 +125,11 @@ int   orc_dsp_publish(void *h, float *out_vt, float threshold, int inf_step);
 void  orc_dsp_state(void *h, float *store, float *objnum, int *counters);
 void  orc_dsp_observations(void *h, int *nobs, float *pc, float *maxlen);
 
+/* ---- a7: MapBase::filterPointCloud (plan_env/src/map.cpp:107-132) with pcl::VoxelGrid restated ---- */
+/* returns the number of output points (<= cap); out_xyz cap*3 */
+int orc_filter_point_cloud(const SogmSpec *s, const float *raw_xyz, int n, float filter_res, int cap,
+                           float *out_xyz);
+
 #ifdef __cplusplus
 }
 #endif

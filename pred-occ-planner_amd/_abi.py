@@ -112,6 +112,8 @@ PROTOTYPES = {
     "sogm_corridor_generate": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "sogm_bezier_qp_solve": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sogm_replan": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "sogm_filter_point_cloud": (_i, [_vp, _vp, _vp, C.c_float, _i, _vp, _vp, _vp]),
+    "sogm_filter_reserve": (_i, [_vp, _i]),
     "sogm_dsp_create": (_i, [_vp, C.POINTER(SogmDspParams), _vp, _vp, _i, _vp, _i, _i, C.POINTER(_vp)]),
     "sogm_dsp_destroy": (None, [_vp]),
     "sogm_update_dsp": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -221,6 +221,10 @@ struct sogm_ctx {
   int            precleared;  // a side-stream clear for the next update is in flight
   hipStream_t    side;
   hipEvent_t     ev_grid_free, ev_cleared;
+  float         *d_filter_cells;   // filterPointCloud leaf accumulators [A][max_cells][4] (lazy)
+  void          *d_filter_box;
+  int           *d_filter_blocks;
+  int            filter_max_cells;
   int            profiling;
   hipEvent_t     ev[SOGM_PROF_N][2];
   int            ev_used[SOGM_PROF_N];

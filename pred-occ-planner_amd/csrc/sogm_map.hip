@@ -450,6 +450,9 @@ void sogm_destroy(sogm_ctx *c) {
   if (c->d_stamps) (void)hipFree(c->d_stamps);
   if (c->d_body) (void)hipFree(c->d_body);
   if (c->d_scratch_vt) (void)hipFree(c->d_scratch_vt);
+  if (c->d_filter_cells) (void)hipFree(c->d_filter_cells);
+  if (c->d_filter_box) (void)hipFree(c->d_filter_box);
+  if (c->d_filter_blocks) (void)hipFree(c->d_filter_blocks);
   if (c->side) {
     (void)hipStreamSynchronize(c->side);
     (void)hipStreamDestroy(c->side);

@@ -71,6 +71,14 @@ class SogmMap:
         """Tick pipelining: replan() pre-clears the grid for the next update under its QP stage."""
         check(lib().sogm_set_overlap_clear(self._ctx, 1 if on else 0), "sogm_set_overlap_clear")
 
+    def filterPointCloud(self, raw_xyz, raw_range, filter_res=0.15, cap=5000):
+        """MapBase::filterPointCloud (map.cpp:107-132) for every agent: (points [A, cap, 3], counts [A])."""
+        out = torch.empty((self.n_agents, cap, 3), dtype=torch.float32, device=raw_xyz.device)
+        cnt = torch.empty((self.n_agents,), dtype=torch.int32, device=raw_xyz.device)
+        check(lib().sogm_filter_point_cloud(self._ctx, raw_xyz.data_ptr(), raw_range.data_ptr(), filter_res, cap,
+                                            out.data_ptr(), cnt.data_ptr(), _stream()), "sogm_filter_point_cloud")
+        return out, cnt
+
     # ---- profiling (HIP events around each kernel, on the caller's stream) ----
     def set_profiling(self, on=True):
         check(lib().sogm_set_profiling(self._ctx, 1 if on else 0), "sogm_set_profiling")

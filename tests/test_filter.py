@@ -1,0 +1,89 @@
+"""MapBase::filterPointCloud (row a7): oracle known answers on CPU, HIP vs oracle on the GPU."""
+import importlib
+
+import numpy as np
+import pytest
+
+
+def _spec(pop):
+    return pop.config.make_spec("parity")
+
+
+def test_oracle_hand_case(pop, orc):
+    spec = _spec(pop)
+    # camera frame (x right, y down, z forward); leaf 0.15
+    raw = np.asarray([
+        [0.01, 0.02, 1.01], [0.03, 0.04, 1.03], [0.05, 0.00, 1.02],   # one leaf -> centroid
+        [0.40, 0.02, 1.01],                                            # another leaf, larger x index
+        [0.01, 0.02, 6.00],                                            # z forward 6 m -> body x = 6 > 4.95: dropped
+        [np.nan, 0.0, 1.0],                                            # skipped
+    ], np.float32)
+    out = orc.filter_point_cloud(spec, raw)
+    assert out.shape == (2, 3)
+    c = raw[:3].astype(np.float32)
+    cen = np.float32([(c[0, k] + c[1, k] + c[2, k]) / np.float32(3) for k in range(3)])
+    # body frame: x = z, y = -x, z = -y (map.cpp:118-120); leaf order: ascending x index first
+    np.testing.assert_allclose(out[0], [cen[2], -cen[0], -cen[1]], rtol=0, atol=1e-7)
+    np.testing.assert_allclose(out[1], [1.01, -0.40, -0.02], rtol=0, atol=1e-7)
+
+
+def test_oracle_cap_and_order(pop, orc):
+    spec = _spec(pop)
+    rng = np.random.default_rng(5)
+    raw = np.stack([rng.uniform(-4, 4, 20000), rng.uniform(-1.2, 1.2, 20000), rng.uniform(0.3, 4.5, 20000)],
+                   axis=1).astype(np.float32)
+    full = orc.filter_point_cloud(spec, raw, cap=100000)
+    capped = orc.filter_point_cloud(spec, raw, cap=5000)
+    assert len(full) > 5000 and len(capped) == 5000
+    assert np.array_equal(capped, full[:5000])
+    # one output per occupied leaf: leaf index of every centroid is unique, outputs sorted by (z, y, x)
+    # leaf index in the CAMERA frame
+    cam = np.stack([-full[:, 1], -full[:, 2], full[:, 0]], axis=1)
+    ijk = np.floor(cam / np.float32(0.15)).astype(np.int64)
+    key = (ijk[:, 2] * 4096 + ijk[:, 1]) * 4096 + ijk[:, 0]
+    assert np.all(np.diff(key) > 0)
+
+
+def _depth_cloud(seed, n_pix=(480, 640)):
+    """Back-projected synthetic depth image (grid_map.cpp:231-235 formula, fx = fy = 387): a tilted
+    wall, a pillar and a floor; ~0.3 M points, many per 0.15 m leaf."""
+    rng = np.random.default_rng(seed)
+    v, u = np.meshgrid(np.arange(n_pix[0]), np.arange(n_pix[1]), indexing="ij")
+    depth = 3.5 + 0.002 * (u - 320) + rng.normal(0, 0.002, u.shape)
+    pil = np.abs(u - 200 - 40 * (seed % 3)) < 35
+    depth = np.where(pil, 1.6 + rng.normal(0, 0.002, u.shape), depth)
+    floor = v > 400
+    depth = np.where(floor, 1.2 * 387.0 / np.maximum(v - 240, 1), depth)
+    depth = np.clip(depth, 0.3, 4.4)
+    x = (u - 320) * depth / 387.0
+    y = (v - 240) * depth / 387.0
+    return np.stack([x, y, depth], axis=-1).reshape(-1, 3).astype(np.float32)
+
+
+@pytest.mark.gpu
+def test_filter_gpu_matches_oracle(pop, orc):
+    import torch
+    sogm = importlib.import_module("pred-occ-planner_amd.sogm")
+    spec = _spec(pop)
+    clouds = [_depth_cloud(1), _depth_cloud(2)[:150000], np.zeros((0, 3), np.float32), _depth_cloud(3)]
+    clouds[3][::977] = np.nan          # invalid depth pixels
+    clouds[3] = np.concatenate([clouds[3], np.float32([[0.0, 0.0, 9.0], [0.2, 0.1, 9.3]])])  # out of range
+    A = len(clouds)
+    m = sogm.SogmMap(spec, A)
+    ends = np.cumsum([len(c) for c in clouds])
+    rng = np.stack([np.concatenate([[0], ends[:-1]]), ends], axis=1).astype(np.int32)
+    raw = np.concatenate(clouds, axis=0)
+    for rep in range(2):  # second call re-uses the (self-cleaning) leaf accumulators
+        out, cnt = m.filterPointCloud(sogm._dev(raw, np.float32), sogm._dev(rng, np.int32), 0.15, 5000)
+        out, cnt = out.cpu().numpy(), cnt.cpu().numpy()
+        for a in range(A):
+            want = orc.filter_point_cloud(spec, clouds[a], 0.15, 5000)
+            assert cnt[a] == len(want), (a, cnt[a], len(want))
+            # fp32 sums of up to thousands of points per leaf in an unspecified order: 1e-4 (north_star)
+            np.testing.assert_allclose(out[a, :cnt[a]], want, rtol=0, atol=1e-4)
+    # small cap
+    out, cnt = m.filterPointCloud(sogm._dev(raw, np.float32), sogm._dev(rng, np.int32), 0.15, 64)
+    want = orc.filter_point_cloud(spec, clouds[0], 0.15, 64)
+    assert cnt.cpu().numpy()[0] == 64
+    np.testing.assert_allclose(out.cpu().numpy()[0], want, rtol=0, atol=1e-4)
+    m.close()
