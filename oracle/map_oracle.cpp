@@ -298,9 +298,62 @@ void orc_update_gt(const SogmSpec *s, const float *cloud, int n_points, const So
 }
 
 // addOtherAgents (risk_base.cpp:136-168) == fake_particle_risk_voxel.cpp:178-218
+// RiskVoxel::addOtherAgents (risk_voxel.cpp:258-288): getWaypoints directly (particles.cpp:316-344) —
+// body particles while the trajectory runs, its single last point on the slice where it has ended
+// (after which the chain is broken) — and addObstaclesToRiskMap (:311-318) SETS the cell to 1.0.
+static void projectNeighboursRiskVoxel(const SogmSpec *s, const SogmTrajRecord *rec, int n_rec,
+                                       int ego_id, const double *body, int n_body,
+                                       const float pose[3], double stamp, float *grid) {
+  Grid              g(s);
+  const int         T = g.T;
+  std::vector<char> valid(n_rec, 1);
+  for (int t_idx = 0; t_idx < T; ++t_idx) {
+    const double        t = stamp + (double)(s->time_resolution * (float)t_idx);  // :276
+    std::vector<double> pts;
+    for (int i = 0; i < n_rec; ++i) {
+      const SogmTrajRecord &r = rec[i];
+      if (r.drone_id == ego_id || !valid[i]) continue;
+      if (r.n_pieces <= 0) {  // find_if fails -> false (particles.cpp:322)
+        valid[i] = 0;
+        continue;
+      }
+      double time_end = r.time_start;
+      for (int k = 0; k < r.n_pieces; ++k) time_end += r.duration[k];
+      bool ok = false;
+      if (r.time_start < t && time_end > t) {
+        double p[3];
+        bezierEval(r.duration, r.cpts, r.n_pieces, t - r.time_start, 0, p);
+        for (int e = 0; e < n_body; ++e)
+          for (int k = 0; k < 3; ++k) pts.push_back(p[k] + body[e * 3 + k]);
+        ok = true;
+      } else if (r.time_start > t) {
+        ok = true;
+      } else if (time_end < t) {
+        double dur = 0.0, p[3];  // Bezier::getDuration
+        for (int k = 0; k < r.n_pieces; ++k) dur += r.duration[k];
+        bezierEval(r.duration, r.cpts, r.n_pieces, dur, 0, p);
+        for (int k = 0; k < 3; ++k) pts.push_back(p[k]);
+        ok = false;
+      }
+      valid[i] = ok ? 1 : 0;
+    }
+    for (size_t e = 0; e < pts.size() / 3; ++e) {
+      const float fx = (float)(pts[e * 3 + 0] - (double)pose[0]);
+      const float fy = (float)(pts[e * 3 + 1] - (double)pose[1]);
+      const float fz = (float)(pts[e * 3 + 2] - (double)pose[2]);
+      if (!g.inRangeF(fx, fy, fz)) continue;
+      grid[(size_t)g.indexF(fx, fy, fz) * T + t_idx] = 1.0F;
+    }
+  }
+}
+
 void orc_project_neighbours(const SogmSpec *s, const SogmTrajRecord *rec, int n_rec, int ego_id,
                             const double *body, int n_body, const float pose[3], double stamp,
                             float *grid) {
+  if (s->map_kind == SOGM_MAP_RISKVOXEL) {
+    projectNeighboursRiskVoxel(s, rec, n_rec, ego_id, body, n_body, pose, stamp, grid);
+    return;
+  }
   Grid              g(s);
   const int         T = g.T;
   std::vector<char> valid(n_rec, 1);  // is_swarm_traj_valid
@@ -380,7 +433,9 @@ int orc_query_clear_idx(const SogmSpec *s, const float *grid, const float pose[3
           if (sum > s->risk_threshold) return 1;
         } else {
           // risk_base.cpp:249: float - int*float
-          if (sum > s->risk_threshold_region - (float)t * s->risk_thres_reg_decay) return 1;
+          // RiskVoxel (risk_voxel.cpp:426): fixed threshold, no decay
+          const float dec = s->map_kind == SOGM_MAP_RISKVOXEL ? 0.0F : s->risk_thres_reg_decay;
+          if (sum > s->risk_threshold_region - (float)t * dec) return 1;
         }
       }
   return 0;
@@ -429,7 +484,8 @@ int orc_obstacle_points(const SogmSpec *s, const float *grid, const float pose[3
         const int i = x + y * g.L + z * g.L * g.W;
         for (int j = idx_start; j <= idx_end; ++j) {
           if (j >= T) continue;  // deviation: the reference reads slice T (one past the end)
-          const float thr = s->map_kind == SOGM_MAP_FAKE
+          // RiskVoxel inherits MapBase::getObstaclePoints (map.cpp:480-518): fixed threshold
+          const float thr = (s->map_kind == SOGM_MAP_FAKE || s->map_kind == SOGM_MAP_RISKVOXEL)
                                 ? s->risk_threshold
                                 : s->risk_threshold - s->risk_thres_vox_decay * (float)j;
           if (grid[(size_t)i * T + j] > thr) {

@@ -75,6 +75,10 @@ inline GridGeom make_geom(const SogmSpec &s) {
   g.decay_voxel    = s.risk_thres_vox_decay;
   g.inf_step       = (int)(s.clearance / s.resolution);
   g.map_kind       = s.map_kind;
+  // RiskVoxel::getClearOcccupancy (risk_voxel.cpp:399-423) compares the K-cell sum with the fixed
+  // map/risk_threshold_astar: the RiskBase rule with risk_threshold_region = that value and no decay.
+  // It inherits MapBase::getObstaclePoints (map.cpp:480-518): fixed risk_threshold as well.
+  if (s.map_kind == SOGM_MAP_RISKVOXEL) g.decay_region = g.decay_voxel = 0.0f;
   return g;
 }
 

@@ -159,6 +159,36 @@ __global__ __launch_bounds__(256) void k_splat_neighbours(
   const double stamp = stamps[agent];
   const double t0    = stamp + (double)(g.dt * (float)0);
   const double tt    = stamp + (double)(g.dt * (float)t);
+  if (g.map_kind == SOGM_MAP_RISKVOXEL) {
+    // RiskVoxel::addOtherAgents (risk_voxel.cpp:258-288) calls getWaypoints (particles.cpp:316-344)
+    // directly and SETS cells (:311-318).  The record is visited at slice t iff every earlier slice
+    // returned true (running or not yet started); on the slice where it has ended its last point is
+    // stamped once, without body particles.
+    for (int s_ = 0; s_ < t; ++s_) {
+      const double ts = stamp + (double)(g.dt * (float)s_);
+      if (!((R.time_start < ts && time_end > ts) || R.time_start > ts)) return;
+    }
+    const float *pose = poses + agent * 3;
+    const double q0 = (double)pose[0], q1 = (double)pose[1], q2 = (double)pose[2];
+    float       *slab = grid + ((size_t)agent * g.T + t) * (size_t)g.V;
+    double       p[3];
+    if (R.time_start < tt && time_end > tt) {
+      bezier_pos(R, tt - R.time_start, p);
+      for (int e = 0; e < n_body; ++e) {
+        const float fx = (float)((p[0] + body[e * 3 + 0]) - q0);
+        const float fy = (float)((p[1] + body[e * 3 + 1]) - q1);
+        const float fz = (float)((p[2] + body[e * 3 + 2]) - q2);
+        if (g.in_range(fx, fy, fz)) slab[g.voxel_of(fx, fy, fz)] = 1.0F;
+      }
+    } else if (time_end < tt) {
+      double dur = 0.0;
+      for (int k = 0; k < R.n_pieces; ++k) dur += R.duration[k];
+      bezier_pos(R, dur, p);
+      const float fx = (float)(p[0] - q0), fy = (float)(p[1] - q1), fz = (float)(p[2] - q2);
+      if (g.in_range(fx, fy, fz)) slab[g.voxel_of(fx, fy, fz)] = 1.0F;
+    }
+    return;
+  }
   if (!(R.time_start < t0 && time_end > t0)) return;  // chain broken at slice 0
   if (!(R.time_start < tt && time_end > tt)) return;
 
@@ -405,7 +435,8 @@ int sogm_create(const SogmSpec *spec, int n_agents, int device, sogm_ctx **out) 
   if (spec->L <= 0 || spec->W <= 0 || spec->H <= 0 || spec->T <= 0 || spec->T > 32 ||
       !(spec->resolution > 0.f) || !(spec->time_resolution > 0.f))
     return SOGM_ERR_INVALID_ARG;
-  if (spec->map_kind != SOGM_MAP_FAKE && spec->map_kind != SOGM_MAP_RISKBASE)
+  if (spec->map_kind != SOGM_MAP_FAKE && spec->map_kind != SOGM_MAP_RISKBASE &&
+      spec->map_kind != SOGM_MAP_RISKVOXEL)
     return SOGM_ERR_INVALID_ARG;
   *out = nullptr;
   if (sogm_device_count() <= device || device < 0) {

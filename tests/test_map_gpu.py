@@ -65,7 +65,7 @@ def test_ragged_cloud_ranges(pop, orc):
     m.close()
 
 
-@pytest.mark.parametrize("kind", [0, 1])
+@pytest.mark.parametrize("kind", [0, 1, 2])
 def test_query_clear_bit_exact(pop, orc, kind):
     import torch
     sogm, spec, sc, dev, m = _mk(pop, "parity", 4, 21, map_kind=kind)
@@ -89,7 +89,7 @@ def test_query_clear_bit_exact(pop, orc, kind):
     m.close()
 
 
-@pytest.mark.parametrize("kind", [0, 1])
+@pytest.mark.parametrize("kind", [0, 1, 2])
 def test_obstacle_points_identical_sequence(pop, orc, kind):
     import torch
     sogm, spec, sc, dev, m = _mk(pop, "parity", 4, 33, map_kind=kind)
@@ -154,4 +154,36 @@ def test_full_size_properties_cfg2_single_agent(pop, orc):
     ix = ((q + r) / np.float32(0.15)).astype(np.int32)
     idx = np.unique(ix[:, 2] * spec.L * spec.W + ix[:, 1] * spec.L + ix[:, 0])
     assert np.array_equal(np.nonzero(vt[:, 0])[0], idx)
+    m.close()
+
+
+def test_riskvoxel_overlay_sets_cells_and_stamps_last_point(pop, orc):
+    """RiskVoxel::addOtherAgents (risk_voxel.cpp:258-318): cells are SET to 1.0; a neighbour that has
+    not started yet stays in the chain; one whose trajectory ends inside the horizon leaves its last
+    point on that slice and is dropped afterwards; a drone without a record is dropped."""
+    import importlib
+    sogm = importlib.import_module("pred-occ-planner_amd.sogm")
+    A = 6
+    spec = pop.config.make_spec("parity", map_kind=2)
+    sc = pop.scene.make_scene(A, 4.95, seed=0x77, circle_radius=2.5)  # neighbours inside the window
+    dev = sogm.upload_scene(sc)
+    m = sogm.SogmMap(spec, A)
+    m.updateMap(dev["cloud"], dev["cloud_range"], dev["cylinders"], dev["n_cyl"], dev["poses"], dev["stamps"])
+    base = [m.download(a) for a in range(A)]
+    recs = pop.scene.straight_records(sc, speed=1.5)
+    t0 = float(sc["stamps"][0])
+    recs[1].time_start = t0 + 0.3          # starts at slice 2
+    recs[2].time_start = t0 - 1.45         # 1.8 s long -> ends between slices 1 and 2
+    recs[3].n_pieces = 0                   # nothing received from drone 3
+    recs[4].time_start = t0 - 5.0          # ended long ago: last point on slice 0 only
+    m.addOtherAgents(sogm._dev(recs), A, dev["ego_ids"])
+    changed = 0
+    for a in range(A):
+        want = base[a].copy()
+        orc.project_neighbours(spec, want, recs, A, a, m.body, sc["poses"][a], sc["stamps"][a])
+        got = m.download(a)
+        assert np.array_equal(got, want), f"agent {a}: overlay differs in {(got != want).sum()} cells"
+        assert want.max() <= 1.0
+        changed += int((want != base[a]).sum())
+    assert changed > 0
     m.close()
