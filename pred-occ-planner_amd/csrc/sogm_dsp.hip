@@ -40,7 +40,6 @@ namespace sogm {
 enum : uint8_t { F_EMPTY = 0, F_VALID = 1, F_RESAMP = 2, F_MOVED = 3, F_NEW = 4, F_DEPART = 5, F_KILLED = 6 };
 #define DSP_SLOTS 16   // storage slots per voxel (>= SAFE_PARTICLE_NUM_VOXEL)
 #define DSP_ROUNDS 6   // place/pyramid fixed-point rounds issued per update
-#define DSP_MAX_SP 32  // upper bound of SAFE_PARTICLE_NUM_PYRAMID handled
 
 struct DspAgent {  // per-agent scalars (device)
   float  last_p[3];
@@ -84,6 +83,7 @@ struct DspDev {
   int     *vhead;  // [A][V]
   int     *phead;  // [A][NP]
   int     *pyr_list, *pyr_n;  // [A][NP][SP] loc, [A][NP]
+  int     *pyr_key, *pyr_id;  // [A][NP][SP] selection scratch (sweep key, candidate id)
   // new-born scratch
   int   *b_valid, *b_nstatic, *b_vi;  // [A][max_pts]
   float *b_c;                          // [A][max_pts][3]
@@ -119,24 +119,51 @@ __device__ inline int pyramid_of(const float *bh, const float *bv, int nph, int 
   if (!(dot3(x, y, z, bh) >= 0.f && dot3(x, y, z, bh + nph * 3) <= 0.f && dot3(x, y, z, bv) <= 0.f &&
         dot3(x, y, z, bv + npv * 3) >= 0.f))
     return -1;
-  int   h = -1, v = -1;
-  float last = 1.f;
-  for (int i = 0; i < nph; i++) {
-    float t = dot3(x, y, z, bh + (i + 1) * 3);
-    if (last * t <= 0.f) {
-      h = i;
-      break;
+  int h = -1, v = -1;
+  if (fabsf(x) + fabsf(y) + fabsf(z) < 1e-12f) {
+    // degenerate lengths: the products last*t of the reference's scan may underflow — replay it literally
+    float last = 1.f;
+    for (int i = 0; i < nph; i++) {
+      float t = dot3(x, y, z, bh + (i + 1) * 3);
+      if (last * t <= 0.f) {
+        h = i;
+        break;
+      }
+      last = t;
     }
-    last = t;
-  }
-  last = -1.f;
-  for (int j = 0; j < npv; j++) {
-    float t = dot3(x, y, z, bv + (j + 1) * 3);
-    if (last * t <= 0.f) {
-      v = j;
-      break;
+    last = -1.f;
+    for (int j = 0; j < npv; j++) {
+      float t = dot3(x, y, z, bv + (j + 1) * 3);
+      if (last * t <= 0.f) {
+        v = j;
+        break;
+      }
+      last = t;
     }
-    last = t;
+  } else {
+    // The reference scans the boundary planes for the first sign change.  Inside the FOV the dot
+    // products are positive (h) / negative (v) up to the point's pyramid and change sign once (planes
+    // are 1 degree apart, far more than fp32 rounding), so the first index with t <= 0 (h) / t >= 0 (v)
+    // is found by bisection with the same fp32 dot products: ~13 instead of ~70 plane tests.
+    int lo = 0, hi = nph - 1;  // predicate true at nph-1 (ifInPyramidsArea: dot with plane nph <= 0)
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (dot3(x, y, z, bh + (mid + 1) * 3) <= 0.f)
+        hi = mid;
+      else
+        lo = mid + 1;
+    }
+    h  = lo;
+    lo = 0;
+    hi = npv - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (dot3(x, y, z, bv + (mid + 1) * 3) >= 0.f)
+        hi = mid;
+      else
+        lo = mid + 1;
+    }
+    v = lo;
   }
   if (h < 0 || v < 0) return -1;  // "should not happen" in the reference (:1449,1471)
   return h * npv + v;
@@ -301,7 +328,9 @@ __global__ __launch_bounds__(256) void k_dsp_observe(DspDev d, const float *__re
   }
 }
 
-// ---- update: prediction, one thread per slot (:663-748, moveParticle :1295-1372) -----------------
+// ---- update: prediction (:663-748, moveParticle :1295-1372) ------------------------------------------
+// One thread per voxel: a single 16-B load of the slot flags rejects empty voxels (the vast majority);
+// occupied slots are then processed independently of each other.
 __global__ __launch_bounds__(256) void k_dsp_predict(DspDev d) {
   const int a = blockIdx.y;
   DspAgent &s = d.ag[a];
@@ -310,60 +339,98 @@ __global__ __launch_bounds__(256) void k_dsp_predict(DspDev d) {
   for (int i = threadIdx.x; i < (d.nph + 1) * 3; i += 256) s_bh[i] = d.bp_h[(size_t)a * (d.nph + 1) * 3 + i];
   for (int i = threadIdx.x; i < (d.npv + 1) * 3; i += 256) s_bv[i] = d.bp_v[(size_t)a * (d.npv + 1) * 3 + i];
   __syncthreads();
-  const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (gid >= (size_t)d.V * DSP_SLOTS) return;
-  const int    v = (int)(gid / DSP_SLOTS), p = (int)(gid % DSP_SLOTS);
-  const size_t at = (size_t)a * d.V * DSP_SLOTS + gid;
-  const uint8_t c = d.flag[at];
-  if (!(c == F_VALID || c == F_RESAMP)) return;
-  const float ox = s.odom[0], oy = s.odom[1], oz = s.odom[2], dt = s.odom[3];
-  const float vx = d.f[0][at], vy = d.f[1][at];
-  float       px = d.f[2][at], py = d.f[3][at], pz = d.f[4][at];
-  px += dt * vx + ox;
-  py += dt * vy + oy;
-  pz += dt * 0.f + oz;
-  d.f[2][at] = px;
-  d.f[3][at] = py;
-  d.f[4][at] = pz;
-  const int nv = voxel_index(d, px, py, pz);
-  if (nv < 0) {  // moved out (:738-741): the slot frees up at this particle's own turn in the sweep
-    d.flag[at] = F_DEPART;
-    atomicAdd(&s.dbg_out, 1);
-    return;
+  const int    v   = blockIdx.x * 256 + threadIdx.x;
+  const size_t at0 = ((size_t)a * d.V + (v < d.V ? v : 0)) * DSP_SLOTS;
+  uint4        f4  = {0u, 0u, 0u, 0u};
+  if (v < d.V) f4 = *reinterpret_cast<const uint4 *>(d.flag + at0);
+  if (!__any((f4.x | f4.y | f4.z | f4.w) != 0u)) return;  // wave-uniform: whole wave of empty voxels
+  const unsigned w4[4] = {f4.x, f4.y, f4.z, f4.w};
+  const float    ox = s.odom[0], oy = s.odom[1], oz = s.odom[2], dt = s.odom[3];
+  const int      lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // Compact the wave's occupied (voxel, slot) pairs into LDS, then process them 64 at a time: one round
+  // of memory latency per 64 particles instead of one per slot index.
+  __shared__ unsigned short s_list[4][64 * DSP_SLOTS];
+  int n_act = 0;
+#pragma unroll
+  for (int p = 0; p < DSP_SLOTS; ++p) {
+    const uint8_t            c   = (uint8_t)((w4[p >> 2] >> ((p & 3) * 8)) & 0xffu);
+    const bool               act = (c == F_VALID || c == F_RESAMP);
+    const unsigned long long m   = __ballot(act);
+    if (act) s_list[wave][n_act + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)(lane * DSP_SLOTS + p);
+    n_act += __popcll(m);
   }
-  const int pyr = pyramid_of(s_bh, s_bv, d.nph, d.npv, px, py, pz);
-  if (nv == v) {
-    d.flag[at] = F_VALID;
-    if (pyr < 0) return;
-  } else {
-    d.flag[at] = F_DEPART;
+  __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // LDS is in-order per wave; keep the compiler honest
+  const int v0 = v - lane;
+  for (int base = 0; base < n_act; base += 64) {
+    const bool act = base + lane < n_act;
+    const int  e   = act ? s_list[wave][base + lane] : 0;
+    const int  vv = v0 + (e >> 4), p = e & (DSP_SLOTS - 1);
+    const size_t at  = ((size_t)a * d.V + (act ? vv : 0)) * DSP_SLOTS + p;
+    const int    gid = vv * DSP_SLOTS + p;
+    float        vx = 0.f, vy = 0.f, px = 0.f, py = 0.f, pz = 0.f;
+    int          nv = -1, pyr = -1;
+    bool         need = false;
+    if (act) {
+      vx = d.f[0][at];
+      vy = d.f[1][at];
+      px = d.f[2][at];
+      py = d.f[3][at];
+      pz = d.f[4][at];
+      px += dt * vx + ox;
+      py += dt * vy + oy;
+      pz += dt * 0.f + oz;
+      d.f[2][at] = px;
+      d.f[3][at] = py;
+      d.f[4][at] = pz;
+      nv = voxel_index(d, px, py, pz);
+      if (nv < 0) {  // moved out (:738-741): the slot frees up at this particle's own turn in the sweep
+        d.flag[at] = F_DEPART;
+        atomicAdd(&s.dbg_out, 1);
+      } else {
+        pyr = pyramid_of(s_bh, s_bv, d.nph, d.npv, px, py, pz);
+        if (nv == vv) {
+          d.flag[at] = F_VALID;
+          need       = pyr >= 0;
+        } else {
+          d.flag[at] = F_DEPART;
+          need       = true;
+        }
+      }
+    }
+    // one counter bump per wave instead of one same-address atomic per particle
+    const unsigned long long m = __ballot(need);
+    if (!m) continue;
+    int base_c = 0;
+    if (lane == __ffsll((long long)m) - 1) base_c = atomicAdd(&s.cand_cnt, __popcll(m));
+    base_c = __shfl(base_c, __ffsll((long long)m) - 1);
+    if (!need) continue;
+    const int c_i = base_c + __popcll(m & ((1ull << lane) - 1ull));
+    if (c_i >= d.cand_cap) {
+      atomicAdd(&s.err_pool, 1);
+      if (nv != vv) d.flag[at] = F_EMPTY;
+      continue;
+    }
+    const size_t ci = (size_t)a * d.cand_cap + c_i;
+    d.c_key[ci]    = gid;
+    d.c_dest[ci]   = nv;
+    d.c_pyr[ci]    = pyr;
+    d.c_kill[ci]   = 0;
+    if (nv == vv) {
+      d.c_assign[ci] = p;   // stay: slot known
+      d.c_vnext[ci]  = -2;  // marks "stay"
+    } else {
+      d.c_assign[ci] = -1;
+      float *pay     = d.c_pay + ci * 6;
+      pay[0]         = vx;
+      pay[1]         = vy;
+      pay[2]         = px;
+      pay[3]         = py;
+      pay[4]         = pz;
+      pay[5]         = d.f[5][at];
+      d.c_vnext[ci]  = atomicExch(&d.vhead[(size_t)a * d.V + nv], c_i);
+    }
+    if (pyr >= 0) d.c_pnext[ci] = atomicExch(&d.phead[(size_t)a * d.NP + pyr], c_i);
   }
-  const int c_i = atomicAdd(&s.cand_cnt, 1);
-  if (c_i >= d.cand_cap) {
-    atomicAdd(&s.err_pool, 1);
-    if (nv != v) d.flag[at] = F_EMPTY;
-    return;
-  }
-  const size_t ci = (size_t)a * d.cand_cap + c_i;
-  d.c_key[ci]    = (int)gid;
-  d.c_dest[ci]   = nv;
-  d.c_pyr[ci]    = pyr;
-  d.c_kill[ci]   = 0;
-  if (nv == v) {
-    d.c_assign[ci] = p;   // stay: slot known
-    d.c_vnext[ci]  = -2;  // marks "stay"
-  } else {
-    d.c_assign[ci] = -1;
-    float *pay     = d.c_pay + ci * 6;
-    pay[0]         = vx;
-    pay[1]         = vy;
-    pay[2]         = px;
-    pay[3]         = py;
-    pay[4]         = pz;
-    pay[5]         = d.f[5][at];
-    d.c_vnext[ci]  = atomicExch(&d.vhead[(size_t)a * d.V + nv], c_i);
-  }
-  if (pyr >= 0) d.c_pnext[ci] = atomicExch(&d.phead[(size_t)a * d.NP + pyr], c_i);
 }
 
 // ---- update: ordered first-fit of arrivals, one thread per destination voxel ---------------------
@@ -448,8 +515,9 @@ __global__ __launch_bounds__(64) void k_dsp_pyramids(DspDev d, int round) {
     d.pyr_n[(size_t)a * d.NP + q] = 0;
     return;
   }
-  __shared__ int s_key[64][DSP_MAX_SP], s_id[64][DSP_MAX_SP];
-  int *K = s_key[threadIdx.x], *I = s_id[threadIdx.x];
+  // selection scratch in HBM/L2: SAFE_PARTICLE_NUM_PYRAMID grows with the grid (20 at 66x66x20, 218 at
+  // 100^3) while a pyramid rarely holds more than a handful of particles
+  int *K = d.pyr_key + ((size_t)a * d.NP + q) * d.SP, *I = d.pyr_id + ((size_t)a * d.NP + q) * d.SP;
   int  n = 0, placed = 0;
   const int    SP = d.SP;
   const size_t cb = (size_t)a * d.cand_cap;
@@ -491,16 +559,26 @@ __global__ __launch_bounds__(256) void k_dsp_commit_slots(DspDev d) {
   const int a = blockIdx.y;
   DspAgent &s = d.ag[a];
   if (!s.ok) return;
-  const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (gid >= (size_t)d.V * DSP_SLOTS) return;
-  const size_t at = (size_t)a * d.V * DSP_SLOTS + gid;
-  const uint8_t c = d.flag[at];
-  if (c == F_DEPART) d.flag[at] = F_EMPTY;
-  if (c == F_KILLED) {
-    d.flag[at] = F_EMPTY;
-    atomicAdd(&s.dbg_pyr_full, 1);
+  const int v = blockIdx.x * 256 + threadIdx.x;
+  if (v == 0 && s.changed[DSP_ROUNDS - 1] != 0) s.err_unconverged += 1;
+  if (v >= d.V) return;
+  const size_t at0 = ((size_t)a * d.V + v) * DSP_SLOTS;
+  const uint4  f4  = *reinterpret_cast<const uint4 *>(d.flag + at0);
+  // bytes >= 5 are the transient codes F_DEPART / F_KILLED: (b + 3) & 8 is set exactly for 5, 6 (codes <= 6)
+  const unsigned w4[4] = {f4.x, f4.y, f4.z, f4.w};
+  unsigned       any = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) any |= (w4[k] + 0x03030303u) & 0x08080808u;
+  if (!any) return;
+#pragma unroll
+  for (int p = 0; p < DSP_SLOTS; ++p) {
+    const uint8_t c = (uint8_t)((w4[p >> 2] >> ((p & 3) * 8)) & 0xffu);
+    if (c == F_DEPART) d.flag[at0 + p] = F_EMPTY;
+    if (c == F_KILLED) {
+      d.flag[at0 + p] = F_EMPTY;
+      atomicAdd(&s.dbg_pyr_full, 1);
+    }
   }
-  if (gid == 0 && s.changed[DSP_ROUNDS - 1] != 0) s.err_unconverged += 1;
 }
 __global__ __launch_bounds__(256) void k_dsp_commit_movers(DspDev d) {
   const int a = blockIdx.y;
@@ -1012,7 +1090,7 @@ int sogm_dsp_create(sogm_ctx *map, const SogmDspParams *P, const float *p_gauss,
   d.npv = P->half_fov_v * 2 / ar;
   d.NP  = d.nph * d.npv;
   d.SP  = (int)(d.V * P->max_particle_num_voxel + 1e5) / (360 * 180 / ar / ar) * 2;  // SAFE_PARTICLE_NUM_PYRAMID
-  if (d.SP < 1 || d.SP > DSP_MAX_SP) {
+  if (d.SP < 1) {
     delete h;
     return SOGM_ERR_INVALID_ARG;
   }
@@ -1089,6 +1167,8 @@ int sogm_dsp_create(sogm_ctx *map, const SogmDspParams *P, const float *p_gauss,
   bad |= dmalloc(h, &d.phead, A * NP);
   bad |= dmalloc(h, &d.pyr_list, A * NP * d.SP);
   bad |= dmalloc(h, &d.pyr_n, A * NP);
+  bad |= dmalloc(h, &d.pyr_key, A * NP * d.SP);
+  bad |= dmalloc(h, &d.pyr_id, A * NP * d.SP);
   bad |= dmalloc(h, &d.b_valid, A * MP);
   bad |= dmalloc(h, &d.b_nstatic, A * MP);
   bad |= dmalloc(h, &d.b_vi, A * MP);
@@ -1147,7 +1227,6 @@ int sogm_update_dsp(sogm_dsp *h, const float *points, const float *labels, const
   hipStream_t st = (hipStream_t)stream;
   SOGM_HIP_CHECK(hipSetDevice(h->map->device));
   const size_t A = d.A, V = d.V;
-  const dim3   g_slots((unsigned)((V * DSP_SLOTS + 255) / 256), (unsigned)A);
   const dim3   g_vox64((unsigned)((V + 63) / 64), (unsigned)A), g_vox256((unsigned)((V + 255) / 256), (unsigned)A);
   const dim3   g_pyr((unsigned)((d.NP + 63) / 64), (unsigned)A);
   hipLaunchKernelGGL(k_dsp_begin, dim3((unsigned)A), dim3(128), 0, st, d, sensor_pos, sensor_quat, stamps, out_ok);
@@ -1155,12 +1234,12 @@ int sogm_update_dsp(sogm_dsp *h, const float *points, const float *labels, const
   SOGM_HIP_CHECK(hipMemsetAsync(d.phead, 0xFF, A * d.NP * sizeof(int), st));
   hipLaunchKernelGGL(k_dsp_observe, dim3((unsigned)A), dim3(256), 2 * d.NP * sizeof(int), st, d, points, labels,
                      cloud_range);
-  hipLaunchKernelGGL(k_dsp_predict, g_slots, dim3(256), 0, st, d);
+  hipLaunchKernelGGL(k_dsp_predict, g_vox256, dim3(256), 0, st, d);
   for (int r = 0; r < DSP_ROUNDS; ++r) {
     hipLaunchKernelGGL(k_dsp_place, g_vox64, dim3(64), 0, st, d, r);
     hipLaunchKernelGGL(k_dsp_pyramids, g_pyr, dim3(64), 0, st, d, r);
   }
-  hipLaunchKernelGGL(k_dsp_commit_slots, g_slots, dim3(256), 0, st, d);
+  hipLaunchKernelGGL(k_dsp_commit_slots, g_vox256, dim3(256), 0, st, d);
   hipLaunchKernelGGL(k_dsp_commit_movers, dim3((unsigned)((d.cand_cap + 255) / 256), (unsigned)A), dim3(256), 0, st, d);
   hipLaunchKernelGGL(k_dsp_ck, dim3((unsigned)((d.max_pts + 255) / 256), (unsigned)A), dim3(256), 0, st, d);
   hipLaunchKernelGGL(k_dsp_weight, dim3((unsigned)((d.NP * d.SP + 255) / 256), (unsigned)A), dim3(256), 0, st, d);

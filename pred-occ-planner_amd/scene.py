@@ -265,3 +265,21 @@ def make_dsp_sequence(seed, n_updates, half=(4.95, 4.95, 1.5), n_pillars=6, dt=0
         out.append({"points": np.ascontiguousarray(sp), "labels": np.ascontiguousarray(lab), "pos": pos,
                     "quat": q, "stamp": t})
     return out
+
+
+def make_depth_cloud(seed, shape=(480, 640), fx=387.0, max_depth=4.4):
+    """Back-projected synthetic depth image in the CAMERA frame (x right, y down, z forward), pin-hole
+    fx = fy = 387, cx = 320, cy = 240 (SURVEY.md 8d; GridMap::projectDepthImage's formula,
+    plan_env/src/grid_map.cpp:231-235): a tilted wall, a pillar and a floor with 2 mm depth noise.
+    Returns [H*W, 3] float32 — the input of MapBase::filterPointCloud."""
+    rng = np.random.default_rng(seed)
+    v, u = np.meshgrid(np.arange(shape[0]), np.arange(shape[1]), indexing="ij")
+    depth = 3.5 + 0.002 * (u - shape[1] / 2) + rng.normal(0, 0.002, u.shape)
+    pil = np.abs(u - 200 - 40 * (seed % 3)) < 35
+    depth = np.where(pil, 1.6 + rng.normal(0, 0.002, u.shape), depth)
+    floor = v > 0.83 * shape[0]
+    depth = np.where(floor, 1.2 * fx / np.maximum(v - shape[0] / 2, 1), depth)
+    depth = np.clip(depth, 0.3, max_depth)
+    x = (u - shape[1] / 2) * depth / fx
+    y = (v - shape[0] / 2) * depth / fx
+    return np.stack([x, y, depth], axis=-1).reshape(-1, 3).astype(np.float32)

@@ -44,20 +44,9 @@ def test_oracle_cap_and_order(pop, orc):
     assert np.all(np.diff(key) > 0)
 
 
-def _depth_cloud(seed, n_pix=(480, 640)):
-    """Back-projected synthetic depth image (grid_map.cpp:231-235 formula, fx = fy = 387): a tilted
-    wall, a pillar and a floor; ~0.3 M points, many per 0.15 m leaf."""
-    rng = np.random.default_rng(seed)
-    v, u = np.meshgrid(np.arange(n_pix[0]), np.arange(n_pix[1]), indexing="ij")
-    depth = 3.5 + 0.002 * (u - 320) + rng.normal(0, 0.002, u.shape)
-    pil = np.abs(u - 200 - 40 * (seed % 3)) < 35
-    depth = np.where(pil, 1.6 + rng.normal(0, 0.002, u.shape), depth)
-    floor = v > 400
-    depth = np.where(floor, 1.2 * 387.0 / np.maximum(v - 240, 1), depth)
-    depth = np.clip(depth, 0.3, 4.4)
-    x = (u - 320) * depth / 387.0
-    y = (v - 240) * depth / 387.0
-    return np.stack([x, y, depth], axis=-1).reshape(-1, 3).astype(np.float32)
+def _depth_cloud(seed):
+    import importlib
+    return importlib.import_module("pred-occ-planner_amd").scene.make_depth_cloud(seed)
 
 
 @pytest.mark.gpu
