@@ -3,14 +3,19 @@
 // Reference: FakeRiskHybridAstar (path_searching/src/fake_risk_hybrid_a_star.cpp:84-426,428-587,
 // 663-694,795-836; node/hash/heap types path_node.h:37-97, grid_node.h:10-51).
 //
-// Mapping to CDNA4: the search itself is a serial program (best-first pop, ordered merge of the
-// children into the hash table / heap), so one lane ("the master", lane 0) runs it.  What is
-// parallel is the expansion: the 5x5x3 = 75 motion primitives of a node are evaluated by the 64
-// lanes of the wave at once — state transition, voxel/time index, velocity gate, the K-cell SOGM
-// collision gather and the quartic-root heuristic — and handed to the master through LDS.  The
-// results consumed by the master are pure functions of (node, primitive), so evaluating them eagerly
-// for children the reference would have skipped changes nothing.  Everything is gather / latency
-// bound against an L2-resident working window of the SOGM; there is no dense contraction (no MFMA).
+// Mapping to CDNA4: one workgroup of two waves (128 lanes) per agent.  The search is a serial program
+// (best-first pop, ordered merge of the children into hash table / heap), but almost all of its work
+// is not: lane i evaluates motion primitive i of the popped node (75 of the 128 lanes) — state
+// transition, voxel/time index, velocity gate, the K-cell SOGM collision gather, the quartic-root
+// heuristic AND the hash probe of the child's key.  The reference's ordered "first child of a voxel
+// wins, later ones only compare costs" merge is resolved in parallel as well (leader / duplicate
+// detection with a prefix-min over primitives), producing a compact event list (new node / cheaper
+// duplicate / re-open / error) with ballot ranks; one lane replays only those few events against the
+// binary heap (f-scores mirrored in LDS, 16-bit heap slots), all lanes write the new nodes and CAS
+// their keys (x,y,z 13 bit, t 9 bit, id 14 bit packed in 64 bits) into the open-addressing table.
+// The results are pure functions of (node, primitive), so evaluating them eagerly for children the
+// reference would have skipped changes nothing.  Everything is gather / latency bound against an
+// L2-resident working window of the SOGM; there is no dense contraction (no MFMA).
 //
 // Bit-exactness contract (north_star): expansions are bit-identical to the CPU oracle.  fp64
 // arithmetic is written in the same operation order, compiled with -ffp-contract=off;

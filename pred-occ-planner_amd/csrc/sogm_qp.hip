@@ -17,6 +17,9 @@
 //   * P is block diagonal (one 15x15 min-jerk block per piece), K = P + sigma I + A^T diag(rho) A is
 //     banded (half bandwidth 17): an n x 18 band in LDS, banded Cholesky on one wave
 //     (right-looking, no reductions on the dependency chain), re-factored only when rho changes;
+//     the per-iteration triangular solves walk the factor as a block-bidiagonal system held in
+//     registers (15x15 diagonal blocks, coupling folded in once per factorisation), with lane
+//     exchanges by DPP quad permutes / shuffles instead of LDS round trips on the dependency chain;
 //   * all row data sits in LDS (up to 144 KB dynamic) when it fits — the common case — and in a
 //     per-agent HBM scratch otherwise (same code through flat pointers);
 //   * an iteration is 3 barriers: [A^T w per column] | [banded solve, wave 0] | [x, then per row

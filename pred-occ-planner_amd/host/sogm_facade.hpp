@@ -116,6 +116,39 @@ class RiskMap {
   DevBuf<int8_t>  o_;
 };
 
+// ---- DspMap : dsp_map::DSPMap as owned by RiskVoxel (risk_voxel.cpp:42-50,138-153,237-254) ----------
+// One instance serves every agent of a RiskMap created with map_kind = SOGM_MAP_RISKVOXEL.
+class DspMap {
+ public:
+  // DSPMap() + setPredictionVariance / setObservationStdDev / setNewBornParticle* (risk_voxel.cpp:42-49);
+  // the Gaussian and rand() tables the reference seeds from time(0) are supplied by the caller.
+  DspMap(RiskMap &map, const SogmDspParams &p, const std::vector<float> &p_gauss,
+         const std::vector<float> &v_gauss, const std::vector<int32_t> &rand_tab, int max_points = 5000) {
+    check(sogm_dsp_create(map.ctx(), &p, p_gauss.data(), v_gauss.data(), (int)p_gauss.size(), rand_tab.data(),
+                          (int)rand_tab.size(), max_points, &h_), "sogm_dsp_create");
+  }
+  ~DspMap() { sogm_dsp_destroy(h_); }
+  // MapBase::filterPointCloud (map.cpp:107-132) — device pointers, camera-frame cloud in, body-frame out
+  static void filterPointCloud(RiskMap &map, const float *raw_xyz, const int32_t *raw_range, float filter_res,
+                               float *out_xyz, int32_t *out_count, int cap = 5000, hipStream_t st = nullptr) {
+    check(sogm_filter_point_cloud(map.ctx(), raw_xyz, raw_range, filter_res, cap, out_xyz, out_count, st),
+          "sogm_filter_point_cloud");
+  }
+  // int DSPMap::update(n, 3, pts, px, py, pz, stamp, qw, qx, qy, qz) for the whole batch (device pointers)
+  void update(const float *points, const float *labels, const int32_t *cloud_range, const float *sensor_pos,
+              const float *sensor_quat, const double *stamps, int32_t *out_ok, hipStream_t st = nullptr) {
+    check(sogm_update_dsp(h_, points, labels, cloud_range, sensor_pos, sensor_quat, stamps, out_ok, st),
+          "sogm_update_dsp");
+  }
+  // RiskVoxel::publishMap: getOccupancyMapWithFutureStatus -> risk_maps_ (+ RiskMap::addOtherAgents after)
+  void publishMap(int32_t *out_n_occupied = nullptr, hipStream_t st = nullptr) {
+    check(sogm_dsp_publish(h_, out_n_occupied, st), "sogm_dsp_publish");
+  }
+
+ private:
+  sogm_dsp *h_ = nullptr;
+};
+
 // ---- planner: search (KinodynamicAstar-style), CorridorGen, PolyTrajOptimizer, replan ---------------
 class Planner {
  public:
