@@ -444,6 +444,15 @@ __global__ __launch_bounds__(256) void k_qp(SogmPlannerParams pp, SogmQpSettings
 
   // ---- helpers -----------------------------------------------------------------------------------
   double rho_cur = qs.rho;  // safety rows are one-sided inequalities: their rho is rho_cur itself
+  // Register-resident inverse factor (M <= 8).  With X = G^-1 (block lower triangular), lane rho = (bi, rc)
+  // keeps ROW rho of X in slots j <= bi (row part inside block column j), COLUMN rho of X in slots
+  // i' > bi (column part inside block row i') and the diagonal block's column part in slot 8, so the
+  // per-iteration solve x = X^T (X rhs) is two register mat-vecs with no dependency chain at all.
+  // A row/column pair is 135 doubles — more than one lane's VGPR file — so two adjacent lanes share
+  // it: lane h = tid & 1 keeps entries k = 8 h .. 8 h + 7 of every 15-entry part (72 doubles = 144
+  // VGPRs) and the two partial dot products meet through one DPP exchange.
+  double    xr[9][8] = {};
+  const int rho_l = tid >> 1, hh = tid & 1, bi = rho_l / 15, rc = rho_l % 15, k0 = hh * 8;
   auto   set_rho = [&]() {
     for (int r = tid; r < G; r += 256) {
       const double lo = R.gl[r], hi = R.gu[r];
@@ -461,7 +470,7 @@ __global__ __launch_bounds__(256) void k_qp(SogmPlannerParams pp, SogmQpSettings
   };
   // K band = P + sigma I + A^T diag(rho) A (rows in global row order: general, then safety),
   // then banded Cholesky in place
-  auto factor = [&]() -> bool {
+  auto factor = [&]() __attribute__((always_inline)) -> bool {
     for (int e = tid; e < n * (QP_BW + 1); e += 256) {
       const int i = e / (QP_BW + 1), dlt = e % (QP_BW + 1), j = i - dlt;
       double    s = 0.0;
@@ -538,14 +547,12 @@ __global__ __launch_bounds__(256) void k_qp(SogmPlannerParams pp, SogmQpSettings
         for (int r = c; r < 15; ++r) s_Ginv[b * 225 + r * 15 + c] = v[r];
       }
       __syncthreads();
-      // Fold the two matvecs of a block step into one:  y_b = Ginv_b rhs_b - W_b y_{b-1},
-      // x_b = Ginv_b^T y_b - Z_b x_{b+1}  with  W_b = Ginv_b G(b,b-1),  Z_b = Ginv_b^T G(b+1,b)^T.
-      // W goes into the (now idle) band storage, Z replaces G(b, b-1) in place.
-      double wv[8], zv[8];
+      // W_b = Ginv_b G(b, b-1) (into the now idle band storage): X(i, j) = (-W_i) ... (-W_{j+1}) Ginv_j
+      double wv[8];
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
         const int e = tid + q * 256;
-        wv[q] = zv[q] = 0.0;
+        wv[q]       = 0.0;
         if (e < M * 225) {
           const int b = e / 225, r = (e % 225) / 15, c = e % 15;
           if (b > 0) {
@@ -553,84 +560,134 @@ __global__ __launch_bounds__(256) void k_qp(SogmPlannerParams pp, SogmQpSettings
             for (int k = 0; k <= r; ++k) acc += s_Ginv[b * 225 + r * 15 + k] * s_Goff[b * 225 + k * 15 + c];
             wv[q] = acc;
           }
-          if (b < M - 1) {
-            double acc = 0.0;
-            for (int k = r; k < 15; ++k) acc += s_Ginv[b * 225 + k * 15 + r] * s_Goff[(b + 1) * 225 + c * 15 + k];
-            zv[q] = acc;
-          }
         }
       }
       __syncthreads();
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
         const int e = tid + q * 256;
-        if (e < M * 225) {
-          s_Kb[e]   = wv[q];  // W
-          s_Goff[e] = zv[q];  // Z
+        if (e < M * 225) s_Kb[e] = wv[q];
+      }
+      __syncthreads();
+      if (tid < 2 * n) {
+        const double *s_W = s_Kb;
+        // column rho of X, block row by block row:  v <- -W_i' v
+        double v[15];
+#pragma unroll
+        for (int k = 0; k < 15; ++k) v[k] = s_Ginv[bi * 225 + k * 15 + rc];
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) xr[8][kk] = hh ? (kk < 7 ? v[8 + kk] : 0.0) : v[kk];
+#pragma unroll
+        for (int ip = 1; ip < 8; ++ip) {
+          if (ip < M) {
+            const double *Wb = s_W + ip * 225;
+            double        nv[15];
+#pragma unroll
+            for (int r = 0; r < 15; ++r) {
+              double acc = 0.0;
+#pragma unroll
+              for (int k = 0; k < 15; ++k) acc += Wb[r * 15 + k] * v[k];
+              nv[r] = -acc;
+            }
+            if (ip > bi) {
+#pragma unroll
+              for (int r = 0; r < 15; ++r) v[r] = nv[r];
+#pragma unroll
+              for (int kk = 0; kk < 8; ++kk) xr[ip][kk] = hh ? (kk < 7 ? nv[8 + kk] : 0.0) : nv[kk];
+            }
+          }
+        }
+        // row rho of X, block column by block column (right to left):  t <- -t W_j
+        double t[15];
+#pragma unroll
+        for (int k = 0; k < 15; ++k) t[k] = (k == rc) ? 1.0 : 0.0;
+#pragma unroll
+        for (int jb = 7; jb >= 0; --jb) {
+          if (jb < M) {
+            const double *Gj = s_Ginv + jb * 225, *Wj = s_W + jb * 225;
+            double        part[15], nt[15];
+#pragma unroll
+            for (int c = 0; c < 15; ++c) {
+              double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+              for (int k = 0; k < 15; ++k) {
+                a0 += t[k] * Gj[k * 15 + c];
+                a1 += t[k] * Wj[k * 15 + c];
+              }
+              part[c] = a0;
+              nt[c]   = -a1;
+            }
+            if (jb <= bi) {
+#pragma unroll
+              for (int c = 0; c < 15; ++c) t[c] = nt[c];
+#pragma unroll
+              for (int kk = 0; kk < 8; ++kk) xr[jb][kk] = hh ? (kk < 7 ? part[8 + kk] : 0.0) : part[kk];
+            }
+          }
         }
       }
       __syncthreads();
     }
     return s_flag != 0;
   };
-  auto solveK = [&]() {
+  auto solveK = [&]() __attribute__((always_inline)) {
     if (use_blocks) {
-      const double *s_W = s_Kb, *s_Z = s_Goff;
-      // u = blockdiag(Ginv) rhs  — independent of the chain, all lanes
-      for (int j = tid; j < n; j += 256) {
-        const int     b = j / 15, r = j % 15;
-        const double *Gi = s_Ginv + b * 225 + r * 15;
-        double        acc = 0.0;
-        for (int c = 0; c <= r; ++c) acc += Gi[c] * s_xt[b * 15 + c];
-        s_cn[j] = acc;
-      }
-      __syncthreads();
-      // lane = (row r, part p): 4 lanes share one row's dot product; the previous block's result
-      // stays in registers (ds_bpermute gathers issued together, DPP quad reduction).
-      const int  r = lane >> 2, p = lane & 3;
-      const bool act = r < 15;
-      if (wave == 0) {
-        double prev = 0.0;
-        for (int b = 0; b < M; ++b) {  // y_b = u_b - W_b y_{b-1};  W_b is zero left of column 6
-          const double *Wr = s_W + b * 225 + r * 15;
-          const bool    on = act && b > 0;
-          const double  g0 = on ? Wr[6 + p] : 0.0, g1 = on ? Wr[10 + p] : 0.0,
-                       g2 = (on && p == 0) ? Wr[14] : 0.0;
-          const double u  = act ? s_cn[b * 15 + r] : 0.0;
-          const double y0 = __shfl(prev, (6 + p) * 4, 64), y1 = __shfl(prev, (10 + p) * 4, 64),
-                       y2 = __shfl(prev, 14 * 4, 64);
-          double acc = (g0 * y0 + g1 * y1) + g2 * y2;
-          acc += dpp_quad(acc, 0xB1);
-          acc += dpp_quad(acc, 0x4E);
-          prev = u - acc;
-          if (act && p == 0) s_xt[b * 15 + r] = prev;
+      // (fused multiply-adds here: this solve is not on the bit-exact path — the oracle factors K with a
+      // plain banded Cholesky — and every VALU instruction of a 64-lane wave costs 4 cycles)
+      // y = X rhs: row rho of X against the rhs, no chain.  All LDS operands of four blocks are fetched
+      // before any arithmetic (one latency exposure per batch instead of one per block); a block's
+      // partial sum is computed unconditionally and kept or dropped with a select.  Entry 7 of the upper
+      // half is a zero pad whose LDS index is clamped inside the vector.
+      const bool on = tid < 2 * n;
+      int        kx[8];
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) kx[kk] = k0 + kk < 15 ? k0 + kk : 14;
+      {
+        double acc = 0.0;
+#pragma unroll
+        for (int bt = 0; bt < 2; ++bt) {
+          double rv[32];
+#pragma unroll
+          for (int q = 0; q < 32; ++q) {
+            const int jb = bt * 4 + (q >> 3);
+            rv[q]        = s_xt[(jb < M ? jb : 0) * 15 + kx[q & 7]];
+          }
+#pragma unroll
+          for (int b4 = 0; b4 < 4; ++b4) {
+            const int jb   = bt * 4 + b4;
+            double    part = 0.0;
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) part = __builtin_fma(xr[jb][kk], rv[b4 * 8 + kk], part);
+            acc += (on && jb <= bi) ? part : 0.0;
+          }
         }
+        acc += dpp_quad(acc, 0xB1);  // partner lane tid ^ 1
+        if (on && hh == 0) s_cn[rho_l] = acc;
       }
       __syncthreads();
-      // v = blockdiag(Ginv^T) y
-      for (int j = tid; j < n; j += 256) {
-        const int     b = j / 15, r = j % 15;
-        const double *Gi = s_Ginv + b * 225 + r;
-        double        acc = 0.0;
-        for (int c = r; c < 15; ++c) acc += Gi[c * 15] * s_xt[b * 15 + c];
-        s_cn[j] = acc;
-      }
-      __syncthreads();
-      if (wave == 0) {
-        double prev = 0.0;
-        for (int b = M - 1; b >= 0; --b) {  // x_b = v_b - Z_b x_{b+1};  Z_b is zero right of column 8
-          const double *Zr = s_Z + b * 225 + r * 15;
-          const bool    on = act && b < M - 1;
-          const double  g0 = on ? Zr[p] : 0.0, g1 = on ? Zr[4 + p] : 0.0, g2 = (on && p == 0) ? Zr[8] : 0.0;
-          const double  v  = act ? s_cn[b * 15 + r] : 0.0;
-          const double  x0 = __shfl(prev, p * 4, 64), x1 = __shfl(prev, (4 + p) * 4, 64),
-                       x2 = __shfl(prev, 8 * 4, 64);
-          double acc = (g0 * x0 + g1 * x1) + g2 * x2;
-          acc += dpp_quad(acc, 0xB1);
-          acc += dpp_quad(acc, 0x4E);
-          prev = v - acc;
-          if (act && p == 0) s_xt[b * 15 + r] = prev;
+      // x = X^T y: column rho of X against y (slot 0 is never a column part: the diagonal one is slot 8)
+      {
+        double acc = 0.0;
+#pragma unroll
+        for (int bt = 0; bt < 2; ++bt) {
+          double rv[32];
+#pragma unroll
+          for (int q = 0; q < 32; ++q) {
+            const int ip  = bt * 4 + (q >> 3);
+            const int blk = ip == 0 ? bi : (ip < M ? ip : 0);  // batch slot 0 carries the diagonal block
+            rv[q]         = s_cn[(on ? blk : 0) * 15 + kx[q & 7]];
+          }
+#pragma unroll
+          for (int b4 = 0; b4 < 4; ++b4) {
+            const int ip   = bt * 4 + b4;
+            double    part = 0.0;
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) part = __builtin_fma(xr[ip == 0 ? 8 : ip][kk], rv[b4 * 8 + kk], part);
+            acc += (on && (ip == 0 || (ip > bi && ip < M))) ? part : 0.0;
+          }
         }
+        acc += dpp_quad(acc, 0xB1);
+        if (on && hh == 0) s_xt[rho_l] = acc;
       }
     } else if (wave == 0) {
       for (int j = 0; j < n; ++j) {  // G y = b
