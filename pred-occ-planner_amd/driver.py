@@ -38,7 +38,7 @@ def exchange_records(own, all_records, dist, world):
     """The trajectory broadcast of the reference (/broadcast_traj, plan_manager.cpp:364-399 ->
     particles.cpp:131-191) as ONE all-gather of fixed-size records.  `own` [A_loc, 2064] uint8,
     `all_records` [A_loc * world, 2064] uint8.  Backend nccl == RCCL on ROCm; gloo on CPU tests."""
-    if world > 1:
+    if dist is not None and (world > 1 or dist.is_initialized()):
         dist.all_gather_into_tensor(all_records, own.contiguous())
     else:
         all_records.copy_(own)
