@@ -28,6 +28,7 @@ def parse():
     ap.add_argument("--grid", default="cfg2")
     ap.add_argument("--agents", type=int, default=None, help="agents per GPU (default: config's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-deconflict", action="store_true", help="skip isSafeAfterOpt at the end of replan()")
     ap.add_argument("--cpu-agents", type=float, default=12.0, dest="cpu_agents",
                     help="cpu_baseline sample: seconds of wall time to spend on the CPU oracle")
     return ap.parse_args()
@@ -88,7 +89,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
     A_loc = args.agents if args.agents is not None else pop.config.AGENTS[args.grid]
-    sw = driver.SwarmTick(args.grid, A_loc, rank, world, local, dist=dist)
+    sw = driver.SwarmTick(args.grid, A_loc, rank, world, local, dist=dist, deconflict=not args.no_deconflict)
     spec = sw.spec
 
     def barrier():

@@ -413,7 +413,29 @@ int sogm_bezier_qp_solve(sogm_planner *p, const double *start_pva, const double 
                          double *out_cpts, int32_t *out_status, int32_t *out_iters, void *stream);
 
 /*
- * One full FakeBaselinePlanner::replan (baseline_fake.cpp:266-472, minus isSafeAfterOpt) for every
+ * ParticleATC::isSafeAfterOpt (traj_coordinator/src/particles.cpp:223-283) for every agent: the new
+ * trajectory's control points must be linearly separable (separator::Separator::solveModel,
+ * utils/separator/src/separator_glpk.cpp:75-190 — a GLPK feasibility LP, solved here with the
+ * planner's own LP) from the remaining control points of every other agent's active trajectory.
+ * dev cpts [n_agents*SOGM_MAX_PIECES*15] fp64 (sogm_bezier_qp_solve layout), dev npoly [n_agents],
+ * dev records [n_records], dev ego_ids [n_agents], dev t_now [n_agents] fp64 ("ros::Time::now()" of the
+ * check), dev out_safe [n_agents] int32 (1 safe, 0 collides / LP capacity exceeded; agents with
+ * npoly <= 0 report 1).
+ */
+int sogm_safe_after_opt(sogm_planner *p, const double *cpts, const int32_t *npoly,
+                        const SogmTrajRecord *records, int n_records, const int32_t *ego_ids,
+                        const double *t_now, int32_t *out_safe, void *stream);
+/*
+ * Makes sogm_replan() finish like FakeBaselinePlanner::replan does (baseline_fake.cpp:453-460): with
+ * a swarm set, a trajectory that fails isSafeAfterOpt against `records` counts as a failed replan.
+ * The device pointers are read by later sogm_replan() calls; records == NULL switches the check off.
+ */
+int sogm_planner_set_swarm(sogm_planner *p, const SogmTrajRecord *records, int n_records,
+                           const int32_t *ego_ids, const double *t_now);
+
+/*
+ * One full FakeBaselinePlanner::replan (baseline_fake.cpp:266-472; isSafeAfterOpt only when a swarm has
+ * been set with sogm_planner_set_swarm) for every
  * agent: search -> corridors -> QP, stream-ordered, no host round trip.  On success writes the
  * agent's SogmTrajRecord (time_start = t_start) into out_records; on failure writes n_pieces = 0.
  * dev out_ok [n_agents] int32 (1 = replan() returned true).

@@ -313,3 +313,14 @@ def filter_point_cloud(spec, raw, filter_res=0.15, cap=5000):
     out = np.zeros((cap, 3), np.float32)
     n = lib().orc_filter_point_cloud(C.byref(spec), fptr(raw), len(raw), C.c_float(filter_res), cap, fptr(out))
     return out[:n].copy()
+
+
+# ---------------------------------------------------------------- isSafeAfterOpt (f3)
+def separable(A, B):
+    A = np.ascontiguousarray(A, np.float64); B = np.ascontiguousarray(B, np.float64)
+    return int(lib().orc_separable(dptr(A), len(A), dptr(B), len(B)))
+
+
+def safe_after_opt(cpts, M, records, n_records, ego_id, t_now, max_rows=152):
+    c = np.ascontiguousarray(cpts, np.float64)
+    return int(lib().orc_safe_after_opt(dptr(c), M, records, n_records, ego_id, C.c_double(t_now), max_rows))

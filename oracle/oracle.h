@@ -130,6 +130,11 @@ void  orc_dsp_observations(void *h, int *nobs, float *pc, float *maxlen);
 int orc_filter_point_cloud(const SogmSpec *s, const float *raw_xyz, int n, float filter_res, int cap,
                            float *out_xyz);
 
+/* ---- f3: ParticleATC::isSafeAfterOpt (traj_coordinator/src/particles.cpp:223-283) ---- */
+int orc_separable(const double *A, int nA, const double *B, int nB);
+int orc_safe_after_opt(const double *cpts, int M, const SogmTrajRecord *rec, int n_rec, int ego_id,
+                       double t_now, int max_rows);
+
 #ifdef __cplusplus
 }
 #endif

@@ -112,6 +112,8 @@ PROTOTYPES = {
     "sogm_corridor_generate": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "sogm_bezier_qp_solve": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sogm_replan": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "sogm_safe_after_opt": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
+    "sogm_planner_set_swarm": (_i, [_vp, _vp, _i, _vp, _vp]),
     "sogm_filter_point_cloud": (_i, [_vp, _vp, _vp, C.c_float, _i, _vp, _vp, _vp]),
     "sogm_filter_reserve": (_i, [_vp, _i]),
     "sogm_dsp_create": (_i, [_vp, C.POINTER(SogmDspParams), _vp, _vp, _i, _vp, _i, _i, C.POINTER(_vp)]),

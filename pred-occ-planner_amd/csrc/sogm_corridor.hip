@@ -1158,6 +1158,117 @@ size_t corridor_segment_lds(int pc_capacity) {
          sizeof(int) * (LP_MAX_ROWS + 16) + (size_t)pc_capacity;
 }
 
+// ------------------------------------------------------------------------------------------------
+// ParticleATC::isSafeAfterOpt (traj_coordinator/src/particles.cpp:223-283): one workgroup per
+// (other agent's record, ego agent).  Set A = the new trajectory's control points, set B = the record's
+// control points from the piece that contains t_now onwards; separable iff the feasibility LP
+// n.a + d >= 1, n.b + d <= -1 (utils/separator/src/separator_glpk.cpp:75-190, zero objective) has a
+// solution — solved with the same Seidel LP as the corridor checks.
+// ------------------------------------------------------------------------------------------------
+#define DECONFLICT_MAX_ROWS (LP_MAX_ROWS - 8)
+__global__ __launch_bounds__(64) void k_safe_after_opt(const double *__restrict__ cpts,
+                                                       const int32_t *__restrict__ npoly,
+                                                       const SogmTrajRecord *__restrict__ rec, int n_rec,
+                                                       const int32_t *__restrict__ ego_ids,
+                                                       const double *__restrict__ t_now,
+                                                       int32_t *__restrict__ out_safe, int agent0) {
+  extern __shared__ __attribute__((aligned(16))) double s_dyn[];
+  double *s_lp   = s_dyn;                   // LP_WORK_DOUBLES
+  double *s_rows = s_lp + LP_WORK_DOUBLES;  // LP_MAX_ROWS * 5
+  int    *s_perm = (int *)(s_rows + LP_MAX_ROWS * 5);
+  const int a = blockIdx.y + agent0, i = blockIdx.x;
+  const int M = npoly[a];
+  if (M <= 0) return;  // nothing optimised for this agent
+  const SogmTrajRecord &r = rec[i];
+  if (r.n_pieces <= 0 || r.drone_id == ego_ids[a]) return;
+  double time_end = r.time_start;
+  for (int k = 0; k < r.n_pieces; ++k) time_end += r.duration[k];
+  const double now = t_now[a];
+  if (!(r.time_start < now && now < time_end)) return;
+  double t     = now - r.time_start;  // Bezier::locatePiece (bernstein.hpp:164-172)
+  int    piece = r.n_pieces - 1;
+  for (int k = 0; k < r.n_pieces; ++k) {
+    t -= r.duration[k];
+    if (t < 0) {
+      piece = k;
+      break;
+    }
+  }
+  const int nA = 5 * M, nB = (r.n_pieces - piece) * 5;
+  if (nA + nB > DECONFLICT_MAX_ROWS) {  // LP capacity: treated as "not separable" (oracle does the same)
+    if (threadIdx.x == 0) out_safe[a] = 0;
+    return;
+  }
+  double       *A = s_rows, *b = s_rows + LP_MAX_ROWS * 4;
+  const double *ca = cpts + (size_t)a * SOGM_MAX_PIECES * 15, *cb = r.cpts + piece * 15;
+  // Disjoint bounding boxes are separated by an axis-aligned plane (the LP is feasible): most pairs of
+  // a swarm end here without touching the LP.  64-lane min/max over the two point sets.
+  {
+    double lo[6], hi[6];
+    for (int k = 0; k < 6; ++k) {
+      lo[k] = INFINITY;
+      hi[k] = -INFINITY;
+    }
+    for (int q = threadIdx.x; q < nA; q += 64)
+      for (int k = 0; k < 3; ++k) {
+        lo[k] = fmin(lo[k], ca[q * 3 + k]);
+        hi[k] = fmax(hi[k], ca[q * 3 + k]);
+      }
+    for (int q = threadIdx.x; q < nB; q += 64)
+      for (int k = 0; k < 3; ++k) {
+        lo[3 + k] = fmin(lo[3 + k], cb[q * 3 + k]);
+        hi[3 + k] = fmax(hi[3 + k], cb[q * 3 + k]);
+      }
+    bool apart = false;
+    for (int k = 0; k < 6; ++k)
+      for (int d = 32; d >= 1; d >>= 1) {
+        lo[k] = fmin(lo[k], __shfl_xor(lo[k], d, 64));
+        hi[k] = fmax(hi[k], __shfl_xor(hi[k], d, 64));
+      }
+    for (int k = 0; k < 3; ++k) apart = apart || hi[k] < lo[3 + k] || hi[3 + k] < lo[k];
+    if (apart) return;  // wave-uniform
+  }
+  for (int q = threadIdx.x; q < nA + nB; q += 64) {
+    if (q < nA) {
+      A[q * 4 + 0] = -ca[q * 3 + 0];
+      A[q * 4 + 1] = -ca[q * 3 + 1];
+      A[q * 4 + 2] = -ca[q * 3 + 2];
+      A[q * 4 + 3] = -1.0;
+    } else {
+      const int e  = q - nA;
+      A[q * 4 + 0] = cb[e * 3 + 0];
+      A[q * 4 + 1] = cb[e * 3 + 1];
+      A[q * 4 + 2] = cb[e * 3 + 2];
+      A[q * 4 + 3] = 1.0;
+    }
+    b[q] = -1.0;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double c[4] = {0, 0, 0, 0};
+    double       x[4];
+    const double v = linprog<4>(c, nA + nB, A, b, x, s_lp, s_perm);
+    if (v == INFINITY || v == -INFINITY) out_safe[a] = 0;  // plain store: every writer writes 0
+  }
+}
+
+__global__ void k_fill_i32(int32_t *p, int n, int32_t v, int agent0) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[agent0 + i] = v;
+}
+
+int launch_deconflict(int n_agents, const double *cpts, const int32_t *npoly, const SogmTrajRecord *rec,
+                      int n_rec, const int32_t *ego_ids, const double *t_now, int32_t *out_safe,
+                      hipStream_t st, int agent0) {
+  hipLaunchKernelGGL(k_fill_i32, dim3((n_agents + 63) / 64), dim3(64), 0, st, out_safe, n_agents, 1, agent0);
+  if (n_rec > 0) {
+    const size_t lds = sizeof(double) * (LP_WORK_DOUBLES + LP_MAX_ROWS * 5) + sizeof(int) * LP_MAX_ROWS;
+    hipLaunchKernelGGL(k_safe_after_opt, dim3(n_rec, n_agents), dim3(64), lds, st, cpts, npoly, rec, n_rec,
+                       ego_ids, t_now, out_safe, agent0);
+  }
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 int launch_corridor(const MapView &m, const SogmPlannerParams &pp, const CorridorWorkspace &ws,
                     int n_agents, const double *start_pva, const double *t_start,
                     const double *route, const int32_t *route_len, int route_cap,

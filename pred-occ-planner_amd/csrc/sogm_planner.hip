@@ -55,12 +55,15 @@ static void min_jerk_block(double *QM /*15x15*/) {
 // BezierTraj record of a successful replan (plan_manager/src/plan_manager.cpp:364-399 publishes
 // duration[] and cpts[]); n_pieces = 0 marks "replan() returned false".
 __global__ void k_pack_records(int A, double corridor_tau, const int32_t *ret, const int32_t *npoly,
-                               const int32_t *status, const double *cpts, const double *t_start,
-                               const int32_t *drone_ids, SogmTrajRecord *out, int32_t *ok, int agent0) {
+                               const int32_t *status, const int32_t *safe, const double *cpts,
+                               const double *t_start, const int32_t *drone_ids, SogmTrajRecord *out,
+                               int32_t *ok, int agent0) {
   const int a = blockIdx.x * blockDim.x + threadIdx.x + agent0;
   if (a >= A) return;
   SogmTrajRecord &r = out[a];
-  const bool good   = ret[a] != 0 && npoly[a] > 0 && (status[a] == 1 || status[a] == 2);
+  // isSafeAfterOpt false -> replan() returns false (baseline_fake.cpp:455-460)
+  const bool good = ret[a] != 0 && npoly[a] > 0 && (status[a] == 1 || status[a] == 2) &&
+                    (safe == nullptr || safe[a] != 0);
   r.drone_id        = drone_ids[a];
   r.time_start      = t_start[a];
   r.n_pieces        = good ? npoly[a] : 0;
@@ -128,6 +131,7 @@ int sogm_planner_create(sogm_ctx *map, const SogmAstarParams *astar, const SogmP
     if (e == hipSuccess) e = hipMalloc((void **)&p->d_npoly, sizeof(int32_t) * A);
     if (e == hipSuccess) e = hipMalloc((void **)&p->d_status, sizeof(int32_t) * A);
     if (e == hipSuccess) e = hipMalloc((void **)&p->d_iters, sizeof(int32_t) * A);
+    if (e == hipSuccess) e = hipMalloc((void **)&p->d_safe, sizeof(int32_t) * A);
   }
   // Streams beyond the number of hardware queues (ROCm default GPU_MAX_HW_QUEUES = 4) share a queue
   // and serialise, so the default is 2 groups; the Python driver raises both (GPU_MAX_HW_QUEUES = 16,
@@ -160,7 +164,8 @@ void sogm_planner_destroy(sogm_planner *p) {
                   p->cw.pc,   p->cw.fpc,  p->cw.tang, p->cw.distr, p->cw.polys,
                   p->cw.seg_nfaces, p->cw.seg_state, p->cw.seg_npts, p->cw.seg_dbg,
                   p->qw.scratch,
-                  p->d_polys, p->d_goal, p->d_cpts, p->d_nfaces, p->d_npoly, p->d_status, p->d_iters};
+                  p->d_polys, p->d_goal, p->d_cpts, p->d_nfaces, p->d_npoly, p->d_status, p->d_iters,
+                  p->d_safe};
   for (void *q : ptrs)
     if (q) (void)hipFree(q);
   for (int g = 0; g < SOGM_MAX_GROUPS; ++g) {
@@ -251,6 +256,30 @@ int sogm_bezier_qp_solve(sogm_planner *p, const double *start_pva, const double 
   }
   return SOGM_OK;
 }
+int sogm_safe_after_opt(sogm_planner *p, const double *cpts, const int32_t *npoly,
+                        const SogmTrajRecord *records, int n_records, const int32_t *ego_ids,
+                        const double *t_now, int32_t *out_safe, void *stream) {
+  if (!p || !cpts || !npoly || !ego_ids || !t_now || !out_safe || n_records < 0 || (n_records > 0 && !records))
+    return SOGM_ERR_INVALID_ARG;
+  SOGM_HIP_CHECK(hipSetDevice(p->map->device));
+  if (sogm::launch_deconflict(p->map->n_agents, cpts, npoly, records, n_records, ego_ids, t_now, out_safe,
+                              (hipStream_t)stream, 0) != 0) {
+    sogm::set_error("sogm_safe_after_opt", hipGetLastError());
+    return SOGM_ERR_HIP;
+  }
+  return SOGM_OK;
+}
+
+int sogm_planner_set_swarm(sogm_planner *p, const SogmTrajRecord *records, int n_records,
+                           const int32_t *ego_ids, const double *t_now) {
+  if (!p || n_records < 0 || (records && (!ego_ids || !t_now))) return SOGM_ERR_INVALID_ARG;
+  p->swarm     = records;
+  p->n_swarm   = records ? n_records : 0;
+  p->swarm_ego = ego_ids;
+  p->swarm_now = t_now;
+  return SOGM_OK;
+}
+
 int sogm_replan(sogm_planner *p, const double *start_pva, const double *goal,
                 const double *t_start, const int32_t *drone_ids, SogmTrajRecord *out_records,
                 int32_t *out_ok, void *stream) {
@@ -296,9 +325,16 @@ int sogm_replan(sogm_planner *p, const double *start_pva, const double *goal,
       sogm::set_error("sogm_replan launch_qp", hipGetLastError());
       return SOGM_ERR_HIP;
     }
+    if (p->swarm) {
+      if (sogm::launch_deconflict(n, p->d_cpts, p->d_npoly, p->swarm, p->n_swarm, p->swarm_ego, p->swarm_now,
+                                  p->d_safe, st, a0) != 0) {
+        sogm::set_error("sogm_replan launch_deconflict", hipGetLastError());
+        return SOGM_ERR_HIP;
+      }
+    }
     hipLaunchKernelGGL(k_pack_records, dim3((n + 63) / 64), dim3(64), 0, st, a1, p->pp.corridor_tau,
-                       p->d_ret, p->d_npoly, p->d_status, p->d_cpts, t_start, drone_ids,
-                       out_records, out_ok, a0);
+                       p->d_ret, p->d_npoly, p->d_status, p->swarm ? p->d_safe : nullptr, p->d_cpts, t_start,
+                       drone_ids, out_records, out_ok, a0);
     SOGM_HIP_CHECK(hipGetLastError());
     SOGM_HIP_CHECK(hipEventRecord(p->ev_done[g], st));
     SOGM_HIP_CHECK(hipStreamWaitEvent(main, p->ev_done[g], 0));  // fan in

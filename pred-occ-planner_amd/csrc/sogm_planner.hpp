@@ -28,6 +28,10 @@ struct CorridorWorkspace {
   long long *seg_dbg;   // [A*P][16] diagnostics: counts and wall_clock64 ticks (100 MHz) per phase
 };
 
+// ParticleATC::isSafeAfterOpt for agents [agent0, agent0 + n_agents): out_safe[a] = 1 / 0
+int launch_deconflict(int n_agents, const double *cpts, const int32_t *npoly, const SogmTrajRecord *rec,
+                      int n_rec, const int32_t *ego_ids, const double *t_now, int32_t *out_safe,
+                      hipStream_t st, int agent0);
 int launch_corridor(const MapView &m, const SogmPlannerParams &pp, const CorridorWorkspace &ws,
                     int n_agents, const double *start_pva, const double *t_start,
                     const double *route, const int32_t *route_len, int route_cap,
@@ -75,6 +79,12 @@ struct sogm_planner {
   int      route_cap;
   double  *d_polys, *d_goal, *d_cpts;
   int32_t *d_nfaces, *d_npoly, *d_status, *d_iters;
+  // post-optimisation deconfliction (ParticleATC::isSafeAfterOpt); off while swarm == nullptr
+  int32_t              *d_safe;
+  const SogmTrajRecord *swarm;
+  int                   n_swarm;
+  const int32_t        *swarm_ego;
+  const double         *swarm_now;
   // agent groups: sogm_replan runs each group's search -> corridors -> QP chain on its own stream,
   // so one slow agent (a long A* search, an infeasible QP) only delays its own group
   int         n_groups;

@@ -53,7 +53,7 @@ def merge_latest(new, old, ok):
 
 class SwarmTick:
     def __init__(self, grid="cfg2", agents_per_rank=None, rank=0, world=1, device=0, seed=0x5069,
-                 spec=None, scene=None, dist=None, overlap_clear=True):
+                 spec=None, scene=None, dist=None, overlap_clear=True, deconflict=True):
         self.rank, self.world, self.dist = rank, world, dist
         self.spec = spec if spec is not None else config.make_spec(grid)
         self.A_loc = agents_per_rank if agents_per_rank is not None else config.AGENTS.get(grid, 4)
@@ -82,6 +82,11 @@ class SwarmTick:
         self.new = torch.zeros_like(self.own)
         self.ok = torch.zeros((self.A_loc,), dtype=torch.int32, device=d)
         self.all = torch.zeros((self.A_tot, _abi.TRAJ_RECORD_BYTES), dtype=torch.uint8, device=d)
+        # replan() ends with ParticleATC::isSafeAfterOpt against the swarm's latest trajectories
+        # (baseline_fake.cpp:453-460); "now" of the check = the tick's stamp
+        self.now = torch.zeros((self.A_loc,), dtype=torch.float64, device=d)
+        if deconflict:
+            self.planner.setSwarm(self.all, self.A_tot, self.dev["ego_ids"], self.now)
         self.t0 = float(self.scene["stamps"][0])
         self.tick = 0
         self.n_ok_total = 0
@@ -94,6 +99,7 @@ class SwarmTick:
         """One replan tick for every agent of this rank.  Everything is stream-ordered on the GPU."""
         stamp = self.t0 + self.tick * TICK_PERIOD
         stamps = torch.full((self.A_loc,), stamp, dtype=torch.float64, device="cuda")
+        self.now.copy_(stamps)
         t_start = stamps + REPLAN_START_TIME
         pva, valid = traj_eval(self.own, t_start)
         pva = torch.where(valid.bool().unsqueeze(1), pva, self.hover)

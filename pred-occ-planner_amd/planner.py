@@ -85,6 +85,24 @@ class SogmPlanner:
                                          out["iters"].data_ptr(), _stream()), "sogm_bezier_qp_solve")
         return out
 
+    # ---- ParticleATC::isSafeAfterOpt ----
+    def isSafeAfterOpt(self, cpts, npoly, records, n_records, ego_ids, t_now):
+        safe = torch.empty((self.A,), dtype=torch.int32, device=cpts.device)
+        check(lib().sogm_safe_after_opt(self._p, cpts.data_ptr(), npoly.data_ptr(), records.data_ptr(), n_records,
+                                        ego_ids.data_ptr(), t_now.data_ptr(), safe.data_ptr(), _stream()),
+              "sogm_safe_after_opt")
+        return safe
+
+    def setSwarm(self, records, n_records, ego_ids, t_now):
+        """replan() then ends with isSafeAfterOpt against `records` (baseline_fake.cpp:453-460); the tensors
+        are read by later replan() calls and are kept alive here.  records=None switches the check off."""
+        self._swarm = (records, ego_ids, t_now)
+        if records is None:
+            check(lib().sogm_planner_set_swarm(self._p, None, 0, None, None), "sogm_planner_set_swarm")
+        else:
+            check(lib().sogm_planner_set_swarm(self._p, records.data_ptr(), n_records, ego_ids.data_ptr(),
+                                               t_now.data_ptr()), "sogm_planner_set_swarm")
+
     # ---- BaselinePlanner::replan ----
     def replan(self, start_pva, goal, t_start, drone_ids, out_records=None, out_ok=None):
         A, dev = self.A, start_pva.device
