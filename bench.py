@@ -55,6 +55,9 @@ def cpu_baseline(pop, spec, scene, n_agents_sample):
         pva = np.concatenate([scene["starts"][a], np.zeros(6)])
         ok, rec, stage = orc.replan(spec, ap, pp, qs, g, scene["poses"][a], scene["stamps"][a], pva,
                                     scene["goals"][a], scene["stamps"][a] + 0.02, a)
+        if ok:  # isSafeAfterOpt, the last step of replan() (baseline_fake.cpp:453-460)
+            ok = orc.safe_after_opt(np.asarray(rec.cpts[:15 * rec.n_pieces]), rec.n_pieces, recs, A, a,
+                                    float(scene["stamps"][a]))
         return ok
 
     # batches of `cores` agents (one thread each) of tick 0 until ~budget_s seconds of wall time

@@ -58,20 +58,52 @@ __global__ __launch_bounds__(256) void k_stamp_cloud(GridGeom g, float *__restri
                                                      const int32_t *__restrict__ cloud_range,
                                                      const SogmCylinder *__restrict__ cyl,
                                                      int n_cyl, const float *__restrict__ poses) {
-  // cylinders as {x, y, w + clearance (fp64), vx, vy} — staged once per workgroup
+  // Cylinders that can touch this agent's window, in their original order (the reference takes the FIRST
+  // cylinder containing the voxel, :127-154), staged once per workgroup as {x, y, w + clearance (fp64),
+  // vx, vy}.  A voxel corner lies inside the window, so a cylinder further than range + res + (w +
+  // clearance) from the map centre along x or y can never match; culling keeps the per-point loop
+  // independent of the size of the global obstacle field (tens of cylinders instead of thousands).
   __shared__ double s_w[SOGM_MAX_CYL_LDS];
   __shared__ float  s_xyv[SOGM_MAX_CYL_LDS][4];
   __shared__ int    s_type[SOGM_MAX_CYL_LDS];
-  const int         n_lds = n_cyl < SOGM_MAX_CYL_LDS ? n_cyl : SOGM_MAX_CYL_LDS;
-  for (int c = threadIdx.x; c < n_lds; c += blockDim.x) {
-    s_w[c]      = cyl[c].w + (double)g.clearance;
-    s_xyv[c][0] = (float)cyl[c].x;
-    s_xyv[c][1] = (float)cyl[c].y;
-    s_xyv[c][2] = (float)cyl[c].vx;
-    s_xyv[c][3] = (float)cyl[c].vy;
-    s_type[c]   = cyl[c].type;
+  __shared__ int    s_keep, s_wave[4];
+  {
+    const float *pz_ = poses + blockIdx.y * 3;
+    const float  q0 = pz_[0], q1 = pz_[1];
+    if (threadIdx.x == 0) s_keep = 0;
+    __syncthreads();
+    for (int c0 = 0; c0 < n_cyl; c0 += 256) {
+      const int c    = c0 + threadIdx.x;
+      bool      keep = false;
+      double    wl   = 0.0;
+      if (c < n_cyl) {
+        wl = cyl[c].w + (double)g.clearance;
+        const double lim_x = (double)g.rx + (double)g.res + wl + 0.5, lim_y = (double)g.ry + (double)g.res + wl + 0.5;
+        keep = fabs((double)(float)cyl[c].x - (double)q0) <= lim_x && fabs((double)(float)cyl[c].y - (double)q1) <= lim_y;
+      }
+      const unsigned long long m = __ballot(keep);
+      if ((threadIdx.x & 63) == 0) s_wave[threadIdx.x >> 6] = __popcll(m);
+      __syncthreads();
+      int off = s_keep;
+      for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) off += s_wave[w];
+      off += __popcll(m & ((1ull << (threadIdx.x & 63)) - 1ull));
+      if (keep && off < SOGM_MAX_CYL_LDS) {
+        s_w[off]      = wl;
+        s_xyv[off][0] = (float)cyl[c].x;
+        s_xyv[off][1] = (float)cyl[c].y;
+        s_xyv[off][2] = (float)cyl[c].vx;
+        s_xyv[off][3] = (float)cyl[c].vy;
+        s_type[off]   = cyl[c].type;
+      }
+      __syncthreads();
+      if (threadIdx.x == 0) s_keep += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+      __syncthreads();
+    }
   }
-  __syncthreads();
+  // more candidates than LDS slots (never with the shipped scenes): fall back to the full list
+  const bool culled = s_keep <= SOGM_MAX_CYL_LDS;
+  const int  n_lds  = culled ? s_keep : 0;
+  const int  n_loop = culled ? s_keep : n_cyl;
 
   const int    agent = blockIdx.y;
   const int    begin = cloud_range[agent * 2], end = cloud_range[agent * 2 + 1];
@@ -97,7 +129,7 @@ __global__ __launch_bounds__(256) void k_stamp_cloud(GridGeom g, float *__restri
     float cx, cy, cz;
     g.corner_of(v, pose, cx, cy, cz);
     float vx = 0.f, vy = 0.f;
-    for (int c = 0; c < n_cyl; ++c) {
+    for (int c = 0; c < n_loop; ++c) {
       int    type;
       float  ox, oy, wx, wy;
       double wlim;
