@@ -342,6 +342,58 @@ int sogm_dsp_download_observations(sogm_dsp *d, int agent, int32_t *nobs_host, f
                                    float *maxlen_host);
 
 /* ------------------------------------------------------------------------------------------ */
+/* depth-image front end:  GridMap  (plan_env/src/grid_map.cpp, plan_env/src/raycast.cpp)      */
+/*   SURVEY section 8 row f1 — not on the reference's SOGM path today; occupancy grid of its own */
+/* ------------------------------------------------------------------------------------------ */
+/* grid_map/ parameters (GridMap::initMap, grid_map.cpp:15-63).  The reference ships no YAML for them
+ * (defaults are -1): every value is the caller's. */
+typedef struct SogmGridMapParams {
+  double  resolution;
+  double  map_size[3];
+  double  local_update_range[3];
+  double  obstacles_inflation;
+  double  fx, fy, cx, cy;
+  double  depth_filter_maxdist, depth_filter_mindist;
+  double  k_depth_scaling_factor;
+  double  p_hit, p_miss, p_min, p_max, p_occ; /* 0.70 0.35 0.12 0.97 0.80 (:43-47) */
+  double  max_ray_length;
+  double  virtual_ceil_height, ground_height;
+  int32_t use_depth_filter;    /* default true (:35) */
+  int32_t depth_filter_margin;
+  int32_t skip_pixel;
+  int32_t local_map_margin;    /* 1 (:60) */
+  int32_t rows, cols;          /* depth image size (480 x 640) */
+} SogmGridMapParams;
+
+typedef struct sogm_gridmap sogm_gridmap;
+
+/* GridMap::initMap for n_agents independent maps (log-odds buffer fp64 like the reference). */
+int  sogm_gridmap_create(const SogmGridMapParams *params, int n_agents, int device, sogm_gridmap **out);
+void sogm_gridmap_destroy(sogm_gridmap *g);
+/*
+ * depthPoseCallback + updateOccupancyCallback (grid_map.cpp:585-665) for every agent:
+ * projectDepthImage (:210-311), raycastProcess (:313-445: 3-D DDA per pixel from the ray end towards the
+ * camera with the per-frame ray-end / traversed-voxel de-duplication, hit/miss log-odds fusion),
+ * clearAndInflateLocalMap (:469-583).  The de-duplication makes the reference order dependent (a ray
+ * stops at the first voxel an EARLIER ray traversed); it is reproduced exactly by iterating
+ * "first ray to arrive" to its fixed point.
+ * dev depth   [n_agents*rows*cols] uint16 (depth * k_depth_scaling_factor)
+ * dev cam_pos [n_agents*3] fp64, dev cam_rot [n_agents*9] fp64 row-major camera-to-world rotation
+ * dev out_updated [n_agents] int32 or NULL: 0 when the camera is outside the map (:656-662)
+ */
+int sogm_gridmap_update(sogm_gridmap *g, const uint16_t *depth, const double *cam_pos,
+                        const double *cam_rot, int32_t *out_updated, void *stream);
+/* GridMap::getInflateOccupancy (grid_map.h:342-349): dev agent_idx[n], pos[n*3] fp64 -> out[n] int8 {-1,0,1} */
+int sogm_gridmap_query_inflate(sogm_gridmap *g, const int32_t *agent_idx, const double *pos, int n,
+                               int8_t *out, void *stream);
+/* Parity I/O (synchronous): occupancy_buffer_ [nx*ny*nz] fp64, occupancy_buffer_inflate_ int8,
+ * bounds[6] = local_bound_min, local_bound_max, counters[4] = {rays, active rays, rounds used, errors}. */
+int sogm_gridmap_download(sogm_gridmap *g, int agent, double *occupancy_host, int8_t *inflate_host,
+                          int32_t *bounds_host, int32_t *counters_host);
+/* Test hook: sets raycast_num_ (the de-duplication flags are chars and stop matching after frame 127). */
+int sogm_gridmap_force_frame(sogm_gridmap *g, int raycast_num);
+
+/* ------------------------------------------------------------------------------------------ */
 /* queries                                                                                     */
 /* ------------------------------------------------------------------------------------------ */
 /*

@@ -324,3 +324,40 @@ def separable(A, B):
 def safe_after_opt(cpts, M, records, n_records, ego_id, t_now, max_rows=152):
     c = np.ascontiguousarray(cpts, np.float64)
     return int(lib().orc_safe_after_opt(dptr(c), M, records, n_records, ego_id, C.c_double(t_now), max_rows))
+
+
+# ---------------------------------------------------------------- GridMap depth front end (f1)
+class GridMapOracle:
+    def __init__(self, params):
+        L = lib()
+        L.orc_gridmap_create.restype = C.c_void_p
+        self.h = C.c_void_p(L.orc_gridmap_create(C.byref(params)))
+        nv = np.zeros(3, np.int32)
+        L.orc_gridmap_dims(self.h, nv.ctypes.data_as(C.c_void_p))
+        self.nv = [int(x) for x in nv]
+        self.N = self.nv[0] * self.nv[1] * self.nv[2]
+
+    def update(self, depth, cam, R):
+        d = np.ascontiguousarray(depth, np.uint16)
+        c = np.ascontiguousarray(cam, np.float64)
+        r = np.ascontiguousarray(R, np.float64).reshape(9)
+        return int(lib().orc_gridmap_update(self.h, d.ctypes.data_as(C.c_void_p), dptr(c), dptr(r)))
+
+    def force_frame(self, n):
+        lib().orc_gridmap_force_frame(self.h, n)
+
+    def state(self):
+        occ = np.zeros(self.N, np.float64)
+        inf = np.zeros(self.N, np.int8)
+        b = np.zeros(6, np.int32)
+        lib().orc_gridmap_state(self.h, dptr(occ), inf.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p))
+        return occ, inf, b
+
+    def inflate_occupancy(self, pos):
+        p = np.ascontiguousarray(pos, np.float64)
+        return int(lib().orc_gridmap_inflate_occupancy(self.h, dptr(p)))
+
+    def close(self):
+        if self.h:
+            lib().orc_gridmap_destroy(self.h)
+            self.h = None

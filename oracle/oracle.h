@@ -135,6 +135,15 @@ int orc_separable(const double *A, int nA, const double *B, int nB);
 int orc_safe_after_opt(const double *cpts, int M, const SogmTrajRecord *rec, int n_rec, int ego_id,
                        double t_now, int max_rows);
 
+/* ---- f1: GridMap depth front end (plan_env/src/grid_map.cpp:210-583), see gridmap_oracle.cpp ---- */
+void *orc_gridmap_create(const SogmGridMapParams *P);
+void  orc_gridmap_destroy(void *h);
+void  orc_gridmap_dims(void *h, int nv[3]);
+int   orc_gridmap_update(void *h, const uint16_t *depth, const double cam[3], const double R[9]);
+void  orc_gridmap_force_frame(void *h, int raycast_num);
+void  orc_gridmap_state(void *h, double *occ, int8_t *inflate, int bounds[6]);
+int   orc_gridmap_inflate_occupancy(void *h, const double pos[3]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -45,6 +45,17 @@ class SogmDspParams(C.Structure):
                 ("newborn_weight", C.c_float), ("obstacle_thickness", C.c_float)]
 
 
+class SogmGridMapParams(C.Structure):
+    _fields_ = [("resolution", C.c_double), ("map_size", C.c_double * 3), ("local_update_range", C.c_double * 3),
+                ("obstacles_inflation", C.c_double), ("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double),
+                ("cy", C.c_double), ("depth_filter_maxdist", C.c_double), ("depth_filter_mindist", C.c_double),
+                ("k_depth_scaling_factor", C.c_double), ("p_hit", C.c_double), ("p_miss", C.c_double),
+                ("p_min", C.c_double), ("p_max", C.c_double), ("p_occ", C.c_double), ("max_ray_length", C.c_double),
+                ("virtual_ceil_height", C.c_double), ("ground_height", C.c_double),
+                ("use_depth_filter", C.c_int32), ("depth_filter_margin", C.c_int32), ("skip_pixel", C.c_int32),
+                ("local_map_margin", C.c_int32), ("rows", C.c_int32), ("cols", C.c_int32)]
+
+
 class SogmCylinder(C.Structure):
     _fields_ = [("type", C.c_int32), ("_pad", C.c_int32)] + [
         (k, C.c_double) for k in ("x", "y", "z", "w", "h", "vx", "vy", "qw", "qx", "qy", "qz")]
@@ -112,6 +123,12 @@ PROTOTYPES = {
     "sogm_corridor_generate": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "sogm_bezier_qp_solve": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sogm_replan": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "sogm_gridmap_create": (_i, [C.POINTER(SogmGridMapParams), _i, _i, C.POINTER(_vp)]),
+    "sogm_gridmap_destroy": (None, [_vp]),
+    "sogm_gridmap_update": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "sogm_gridmap_query_inflate": (_i, [_vp, _vp, _vp, _i, _vp, _vp]),
+    "sogm_gridmap_download": (_i, [_vp, _i, _vp, _vp, _vp, _vp]),
+    "sogm_gridmap_force_frame": (_i, [_vp, _i]),
     "sogm_safe_after_opt": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "sogm_planner_set_swarm": (_i, [_vp, _vp, _i, _vp, _vp]),
     "sogm_filter_point_cloud": (_i, [_vp, _vp, _vp, C.c_float, _i, _vp, _vp, _vp]),

@@ -149,6 +149,27 @@ class DspMap {
   sogm_dsp *h_ = nullptr;
 };
 
+// ---- GridMap : depth-image occupancy front end (plan_env/src/grid_map.cpp) ------------------------------
+class GridMap {
+ public:
+  GridMap(const SogmGridMapParams &p, int n_agents, int device = 0) {  // GridMap::initMap
+    check(sogm_gridmap_create(&p, n_agents, device, &h_), "sogm_gridmap_create");
+  }
+  ~GridMap() { sogm_gridmap_destroy(h_); }
+  // depthPoseCallback + updateOccupancyCallback for the whole batch (device pointers)
+  void update(const uint16_t *depth, const double *cam_pos, const double *cam_rot, int32_t *out_updated = nullptr,
+              hipStream_t st = nullptr) {
+    check(sogm_gridmap_update(h_, depth, cam_pos, cam_rot, out_updated, st), "sogm_gridmap_update");
+  }
+  // int getInflateOccupancy(Eigen::Vector3d pos) for a batch of device-resident queries
+  void getInflateOccupancy(const int32_t *agent_idx, const double *pos, int n, int8_t *out, hipStream_t st = nullptr) {
+    check(sogm_gridmap_query_inflate(h_, agent_idx, pos, n, out, st), "sogm_gridmap_query_inflate");
+  }
+
+ private:
+  sogm_gridmap *h_ = nullptr;
+};
+
 // ---- planner: search (KinodynamicAstar-style), CorridorGen, PolyTrajOptimizer, replan ---------------
 class Planner {
  public:

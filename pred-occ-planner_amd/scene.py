@@ -283,3 +283,32 @@ def make_depth_cloud(seed, shape=(480, 640), fx=387.0, max_depth=4.4):
     x = (u - shape[1] / 2) * depth / fx
     y = (v - shape[0] / 2) * depth / fx
     return np.stack([x, y, depth], axis=-1).reshape(-1, 3).astype(np.float32)
+
+
+def make_depth_image(seed, shape=(480, 640), fx=387.0, scale=1000.0, holes=True):
+    """uint16 depth image (depth * k_depth_scaling_factor) of the same synthetic view as make_depth_cloud:
+    tilted wall, pillar, floor; optional zero-depth holes and a too-near patch to exercise the depth
+    filter branches of GridMap::projectDepthImage (grid_map.cpp:262-271)."""
+    rng = np.random.default_rng(seed)
+    v, u = np.meshgrid(np.arange(shape[0]), np.arange(shape[1]), indexing="ij")
+    depth = 3.5 + 0.002 * (u - shape[1] / 2) + rng.normal(0, 0.002, u.shape)
+    pil = np.abs(u - 200 - 40 * (seed % 3)) < 35
+    depth = np.where(pil, 1.6 + rng.normal(0, 0.002, u.shape), depth)
+    floor = v > 0.83 * shape[0]
+    depth = np.where(floor, 1.2 * fx / np.maximum(v - shape[0] / 2, 1), depth)
+    far = (u > 0.8 * shape[1]) & (v < 0.3 * shape[0])
+    depth = np.where(far, 7.5, depth)                     # beyond depth_filter_maxdist
+    img = np.clip(depth * scale, 0, 65535).astype(np.uint16)
+    if holes:
+        img[rng.random(img.shape) < 0.01] = 0             # invalid pixels
+        img[20:40, 30:60] = 100                            # 0.1 m: below depth_filter_mindist
+    return img
+
+
+def camera_pose(x, y, z, yaw):
+    """Camera-to-world rotation (row-major 3x3) of a forward-looking camera (x right, y down, z forward)
+    on a body with heading `yaw`, and its position."""
+    c, s = math.cos(yaw), math.sin(yaw)
+    body = np.array([[c, -s, 0.0], [s, c, 0.0], [0.0, 0.0, 1.0]])
+    cam2body = np.array([[0.0, 0.0, 1.0], [-1.0, 0.0, 0.0], [0.0, -1.0, 0.0]])
+    return np.asarray([x, y, z], np.float64), (body @ cam2body).astype(np.float64)
