@@ -406,6 +406,16 @@ int sogm_query_clear(sogm_ctx *ctx, const int32_t *agent_idx, const double *pos_
                      const double *t, int t_is_index, int n_q, int8_t *out, void *stream);
 
 /*
+ * BaselinePlanner::isTrajSafe(T) (plan_manager/src/baseline.cpp:45-68) for every agent: the executed
+ * trajectory records[a] is sampled every 0.1 s from t_now[a] to min(T, duration) and checked with
+ * getClearOcccupancy(pos, t + traj_start - map_time).  The trajectory's own time_start is used where the
+ * reference reads the planner's traj_start_time_ member (identical after a successful replan).
+ * dev records [n_agents], dev t_now [n_agents] fp64, dev out_safe [n_agents] int32 (1 safe).
+ */
+int sogm_traj_safe(sogm_ctx *ctx, const SogmTrajRecord *records, const double *t_now,
+                   double check_duration, int32_t *out_safe, void *stream);
+
+/*
  * getObstaclePoints(points, t_start, t_end, lc, hc) — map.cpp:480-518 (fake map) /
  * risk_base.cpp:295-337 (RiskBase, decayed threshold).  One box per entry, points appended in the
  * reference's z,y,x,slice order.

@@ -361,3 +361,11 @@ class GridMapOracle:
         if self.h:
             lib().orc_gridmap_destroy(self.h)
             self.h = None
+
+
+# ---------------------------------------------------------------- isTrajSafe (f2)
+def traj_safe(spec, grid, pose, map_stamp, record, t_now, T):
+    g = np.ascontiguousarray(grid, np.float32)
+    ps = np.ascontiguousarray(pose, np.float32)
+    return int(lib().orc_traj_safe(C.byref(spec), fptr(g), fptr(ps), C.c_double(map_stamp), C.byref(record),
+                                   C.c_double(t_now), C.c_double(T)))

@@ -504,3 +504,22 @@ int orc_obstacle_points(const SogmSpec *s, const float *grid, const float pose[3
 }
 
 }  // extern "C"
+
+// BaselinePlanner::isTrajSafe (plan_manager/src/baseline.cpp:45-68); traj_start_time_ = r->time_start
+extern "C" int orc_traj_safe(const SogmSpec *s, const float *grid, const float pose[3], double map_stamp,
+                             const SogmTrajRecord *r, double t_now, double T) {
+  if (r->n_pieces <= 0) return 1;
+  double t0 = t_now - r->time_start;
+  if (t0 < 0) t0 = 0;
+  if (t0 > T) return 1;
+  double dur = 0;
+  for (int k = 0; k < r->n_pieces; ++k) dur += r->duration[k];
+  T = T > dur ? dur : T;
+  for (double t = t0; t < T; t += 0.1) {
+    double p[3];
+    bezierEval(r->duration, r->cpts, r->n_pieces, t, 0, p);
+    const double dt = t + r->time_start - map_stamp;
+    if (orc_query_clear_time(s, grid, pose, p, dt) == 1) return 0;
+  }
+  return 1;
+}

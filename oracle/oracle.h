@@ -144,6 +144,10 @@ void  orc_gridmap_force_frame(void *h, int raycast_num);
 void  orc_gridmap_state(void *h, double *occ, int8_t *inflate, int bounds[6]);
 int   orc_gridmap_inflate_occupancy(void *h, const double pos[3]);
 
+/* ---- f2: BaselinePlanner::isTrajSafe (plan_manager/src/baseline.cpp:45-68) ---- */
+int orc_traj_safe(const SogmSpec *s, const float *grid_vt, const float pose[3], double map_stamp,
+                  const SogmTrajRecord *r, double t_now, double T);
+
 #ifdef __cplusplus
 }
 #endif

@@ -129,6 +129,7 @@ PROTOTYPES = {
     "sogm_gridmap_query_inflate": (_i, [_vp, _vp, _vp, _i, _vp, _vp]),
     "sogm_gridmap_download": (_i, [_vp, _i, _vp, _vp, _vp, _vp]),
     "sogm_gridmap_force_frame": (_i, [_vp, _i]),
+    "sogm_traj_safe": (_i, [_vp, _vp, _vp, C.c_double, _vp, _vp]),
     "sogm_safe_after_opt": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "sogm_planner_set_swarm": (_i, [_vp, _vp, _i, _vp, _vp]),
     "sogm_filter_point_cloud": (_i, [_vp, _vp, _vp, C.c_float, _i, _vp, _vp, _vp]),

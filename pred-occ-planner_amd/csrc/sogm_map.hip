@@ -430,6 +430,40 @@ __global__ __launch_bounds__(64) void k_traj_eval(const SogmTrajRecord *__restri
   ok[i] = 1;
 }
 
+// BaselinePlanner::isTrajSafe (plan_manager/src/baseline.cpp:45-68): sample the executed trajectory every
+// 0.1 s from "now" up to min(T, duration) and query the SOGM at the sample's time after the map stamp.
+__global__ __launch_bounds__(64) void k_traj_safe(MapView m, const SogmTrajRecord *__restrict__ rec,
+                                                  const double *__restrict__ t_now, double T,
+                                                  int32_t *__restrict__ out) {
+  const int a = blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= m.n_agents) return;
+  const SogmTrajRecord &r = rec[a];
+  if (r.n_pieces <= 0) {  // nothing is being executed
+    out[a] = 1;
+    return;
+  }
+  double t0 = t_now[a] - r.time_start;
+  if (t0 < 0) t0 = 0;
+  if (t0 > T) {
+    out[a] = 1;
+    return;
+  }
+  double dur = 0;
+  for (int k = 0; k < r.n_pieces; ++k) dur += r.duration[k];
+  T = T > dur ? dur : T;
+  int safe = 1;
+  for (double t = t0; t < T; t += 0.1) {
+    double p[3];
+    bezier_pos(r, t, p);
+    const double dt = t + r.time_start - m.stamps[a];
+    if (query_clear_time(m, a, p[0], p[1], p[2], dt) == 1) {
+      safe = 0;
+      break;
+    }
+  }
+  out[a] = safe;
+}
+
 int launch_clear(sogm_ctx *c, hipStream_t st) {
   const size_t n    = (size_t)c->n_agents * c->spec.T * (size_t)c->geom.V;
   const size_t nv4  = n / 4;
@@ -658,6 +692,16 @@ int sogm_traj_eval(const SogmTrajRecord *records, int n, const double *t, double
   if (n == 0) return SOGM_OK;
   hipLaunchKernelGGL(k_traj_eval, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, records, n,
                      t, out_pva, out_valid);
+  SOGM_HIP_CHECK(hipGetLastError());
+  return SOGM_OK;
+}
+
+int sogm_traj_safe(sogm_ctx *c, const SogmTrajRecord *records, const double *t_now, double check_duration,
+                   int32_t *out_safe, void *stream) {
+  if (!c || !records || !t_now || !out_safe) return SOGM_ERR_INVALID_ARG;
+  if (!c->updated) return SOGM_ERR_STATE;
+  hipLaunchKernelGGL(k_traj_safe, dim3((c->n_agents + 63) / 64), dim3(64), 0, (hipStream_t)stream, view_of(c),
+                     records, t_now, check_duration, out_safe);
   SOGM_HIP_CHECK(hipGetLastError());
   return SOGM_OK;
 }

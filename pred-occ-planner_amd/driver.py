@@ -51,9 +51,72 @@ def merge_latest(new, old, ok):
     return torch.where(ok.bool().unsqueeze(1), new, old)
 
 
+# ---- FiniteStateMachine::FSMCallback, per-agent state machines as tensors ----------------
+FSM_NEW_PLAN, FSM_EXEC_TRAJ, FSM_REPLAN, FSM_GOAL_REACHED = 0, 1, 2, 3
+REPLAN_MAX_FAILURES = 5      # fsm/replan_max_failures (sim_fake.yaml:10)
+COLLI_CHECK_DURATION = 0.2   # fsm/colli_check_duration (sim_fake.yaml:9)
+GOAL_TOLERANCE = 1.0         # fsm/goal_tolerance (sim_fake.yaml:5)
+
+
+def hover_records(drone_ids, start_time, pos):
+    """publishEmptyTrajectory (plan_manager/src/plan_manager.cpp:404-424): one 0.5 s piece whose five control
+    points all sit at the current position.  Returns uint8 [n, 2064] in SogmTrajRecord layout."""
+    n, dev = pos.shape[0], pos.device
+    dur = torch.zeros((n, _abi.SOGM_MAX_PIECES), dtype=torch.float64, device=dev)
+    dur[:, 0] = 0.5
+    cpts = torch.zeros((n, _abi.SOGM_MAX_PIECES * 15), dtype=torch.float64, device=dev)
+    cpts[:, :15] = pos.to(torch.float64).repeat(1, 5)
+    head = torch.stack([drone_ids.to(torch.int32), torch.ones_like(drone_ids, dtype=torch.int32)], dim=1)
+    parts = [head.contiguous().view(torch.uint8).view(n, 8),
+             start_time.to(torch.float64).contiguous().view(torch.uint8).view(n, 8),
+             dur.view(torch.uint8).view(n, -1), cpts.view(torch.uint8).view(n, -1)]
+    return torch.cat(parts, dim=1)
+
+
+def fsm_plan_inputs(status, traj_start, now):
+    """Which agents plan in this FSM tick and from which time (plan_manager.cpp:110-135,165-175):
+    NEW_PLAN plans from `now` once a second, REPLAN from now + replan_start_time."""
+    is_new, is_rep = status == FSM_NEW_PLAN, status == FSM_REPLAN
+    due_new = is_new & ((now - traj_start) > 1.0)
+    t_start = torch.where(is_rep, now + REPLAN_START_TIME, now)
+    return due_new, is_rep, t_start
+
+
+def fsm_apply(status, fail, traj_start, success, now, due_new, is_rep, ok, safe, reached):
+    """State update of one FSMCallback per agent (plan_manager.cpp:92-233) given this tick's replan results.
+    Returns (status, fail, traj_start, success, publish_new, publish_hover, hover_start).  `safe` is isTrajSafe,
+    `reached` isGoalReached; both are only consulted in EXEC_TRAJ."""
+    ok = ok.bool()
+    is_new, is_exec = status == FSM_NEW_PLAN, status == FSM_EXEC_TRAJ
+    # NEW_PLAN (:110-135)
+    traj_start = torch.where(due_new, now, traj_start)
+    success = torch.where(due_new, ok, success.bool())
+    pub_new = due_new & ok
+    pub_hover = due_new & ~ok
+    hover_start = traj_start.clone()
+    st = torch.where(is_new & success, torch.full_like(status, FSM_EXEC_TRAJ), status)
+    # REPLAN (:164-199)
+    t_rep = now + REPLAN_START_TIME
+    traj_start = torch.where(is_rep, t_rep, traj_start)
+    ok_rep = is_rep & ok
+    fail = torch.where(ok_rep, torch.zeros_like(fail), torch.where(is_rep, fail + 1, fail))
+    pub_new = pub_new | ok_rep
+    st = torch.where(ok_rep, torch.full_like(status, FSM_EXEC_TRAJ), st)
+    over = is_rep & ~ok & (fail > REPLAN_MAX_FAILURES)
+    st = torch.where(over, torch.full_like(status, FSM_NEW_PLAN), st)
+    pub_hover = pub_hover | over
+    hover_start = torch.where(over, t_rep, hover_start)
+    traj_start = torch.where(over, now - 1.0, traj_start)  # force a new plan on the next tick
+    # EXEC_TRAJ (:137-162)
+    lapse = is_exec & ((now - traj_start) > TICK_PERIOD)   # fsm/replan_duration
+    st = torch.where(lapse | (is_exec & ~safe.bool()), torch.full_like(status, FSM_REPLAN), st)
+    st = torch.where(is_exec & reached.bool(), torch.full_like(status, FSM_GOAL_REACHED), st)
+    return st, fail, traj_start, success, pub_new, pub_hover, hover_start
+
+
 class SwarmTick:
     def __init__(self, grid="cfg2", agents_per_rank=None, rank=0, world=1, device=0, seed=0x5069,
-                 spec=None, scene=None, dist=None, overlap_clear=True, deconflict=True):
+                 spec=None, scene=None, dist=None, overlap_clear=True, deconflict=True, fsm=False):
         self.rank, self.world, self.dist = rank, world, dist
         self.spec = spec if spec is not None else config.make_spec(grid)
         self.A_loc = agents_per_rank if agents_per_rank is not None else config.AGENTS.get(grid, 4)
@@ -87,6 +150,12 @@ class SwarmTick:
         self.now = torch.zeros((self.A_loc,), dtype=torch.float64, device=d)
         if deconflict:
             self.planner.setSwarm(self.all, self.A_tot, self.dev["ego_ids"], self.now)
+        # optional closed-loop mode: every agent runs the reference's FiniteStateMachine (step_fsm)
+        self.fsm = fsm
+        self.status = torch.full((self.A_loc,), FSM_NEW_PLAN, dtype=torch.int32, device=d)
+        self.fail = torch.zeros((self.A_loc,), dtype=torch.int32, device=d)
+        self.success = torch.zeros((self.A_loc,), dtype=torch.bool, device=d)
+        self.traj_start = torch.full((self.A_loc,), float(self.scene["stamps"][0]) - 2.0, dtype=torch.float64, device=d)
         self.t0 = float(self.scene["stamps"][0])
         self.tick = 0
         self.n_ok_total = 0
@@ -95,8 +164,38 @@ class SwarmTick:
         self.planner.close()
         self.map.close()
 
+    def step_fsm(self):
+        """One FSM tick (plan_manager.cpp:92-233) for every agent: NEW_PLAN / REPLAN agents plan, EXEC_TRAJ
+        agents only check time lapse, isTrajSafe and the goal; failures are counted and after
+        replan_max_failures the agent publishes a hover record and starts over.  Stream-ordered, no host sync."""
+        stamp = self.t0 + self.tick * TICK_PERIOD
+        now = torch.full((self.A_loc,), stamp, dtype=torch.float64, device="cuda")
+        self.now.copy_(now)
+        due_new, is_rep, t_start = fsm_plan_inputs(self.status, self.traj_start, now)
+        pva_now, valid_now = traj_eval(self.own, now)
+        pva_now = torch.where(valid_now.bool().unsqueeze(1), pva_now, self.hover)
+        pva, valid = traj_eval(self.own, t_start)
+        pva = torch.where(valid.bool().unsqueeze(1), pva, self.hover).contiguous()
+        self.hover = torch.cat([pva_now[:, :3], torch.zeros_like(pva_now[:, 3:])], dim=1)
+        self.map.updateMap(self.dev["cloud"], self.dev["cloud_range"], self.dev["cylinders"], self.dev["n_cyl"],
+                           pva_now[:, :3].to(torch.float32).contiguous(), now)
+        self.map.addOtherAgents(self.all, self.A_tot, self.dev["ego_ids"])
+        safe = self.map.isTrajSafe(self.own, now, COLLI_CHECK_DURATION)
+        self.planner.replan(pva, self.goals, t_start, self.dev["ego_ids"], self.new, self.ok)
+        reached = (pva_now[:, :3] - self.goals).norm(dim=1) < GOAL_TOLERANCE
+        ok = self.ok.bool() & (due_new | is_rep)
+        (self.status, self.fail, self.traj_start, self.success, pub_new, pub_hover, hover_start) = fsm_apply(
+            self.status, self.fail, self.traj_start, self.success, now, due_new, is_rep, ok, safe, reached)
+        hover = hover_records(self.dev["ego_ids"], hover_start, pva_now[:, :3])
+        self.own = torch.where(pub_new.unsqueeze(1), self.new, torch.where(pub_hover.unsqueeze(1), hover, self.own))
+        exchange_records(self.own, self.all, self.dist, self.world)
+        self.tick += 1
+        return ok.to(torch.int32)
+
     def step(self):
         """One replan tick for every agent of this rank.  Everything is stream-ordered on the GPU."""
+        if self.fsm:
+            return self.step_fsm()
         stamp = self.t0 + self.tick * TICK_PERIOD
         stamps = torch.full((self.A_loc,), stamp, dtype=torch.float64, device="cuda")
         self.now.copy_(stamps)

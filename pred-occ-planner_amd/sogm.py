@@ -71,6 +71,13 @@ class SogmMap:
         """Tick pipelining: replan() pre-clears the grid for the next update under its QP stage."""
         check(lib().sogm_set_overlap_clear(self._ctx, 1 if on else 0), "sogm_set_overlap_clear")
 
+    def isTrajSafe(self, records, t_now, check_duration):
+        """BaselinePlanner::isTrajSafe for every agent's executed trajectory (device uint8 [A, 2064])."""
+        out = torch.empty((self.n_agents,), dtype=torch.int32, device=t_now.device)
+        check(lib().sogm_traj_safe(self._ctx, records.data_ptr(), t_now.data_ptr(), float(check_duration),
+                                   out.data_ptr(), _stream()), "sogm_traj_safe")
+        return out
+
     def filterPointCloud(self, raw_xyz, raw_range, filter_res=0.15, cap=5000):
         """MapBase::filterPointCloud (map.cpp:107-132) for every agent: (points [A, cap, 3], counts [A])."""
         out = torch.empty((self.n_agents, cap, 3), dtype=torch.float32, device=raw_xyz.device)
