@@ -55,10 +55,72 @@ class DevBuf {  // tiny RAII device buffer
   size_t n_ = 0;
 };
 
+// ---- wire formats -----------------------------------------------------------------------
+// traj_utils/msg/BezierTraj.msg:1-9 as filled by FiniteStateMachine::publishTrajectory
+// (plan_manager/src/plan_manager.cpp:364-399) and read by ParticleATC::trajectoryCallback
+// (traj_coordinator/src/particles.cpp:131-191): float32 durations, geometry_msgs/Point control points.
+struct BezierTrajMsg {
+  int32_t             drone_id = 0, traj_id = 0;
+  double              start_time = 0.0, pub_time = 0.0;  // ros::Time::toSec()
+  uint8_t             order = 4;
+  std::vector<float>  duration;
+  std::vector<Vec3>   cpts;
+};
+// message -> fixed-size record (the all-gather payload).  Returns false when the message does not fit
+// (more than SOGM_MAX_PIECES pieces, order != 4 or an inconsistent control-point count).
+inline bool recordFromMsg(const BezierTrajMsg &m, SogmTrajRecord &r) {
+  const size_t n = m.duration.size();
+  if (m.order != 4 || n > SOGM_MAX_PIECES || m.cpts.size() != 5 * n) return false;
+  r = SogmTrajRecord{};
+  r.drone_id   = m.drone_id;
+  r.n_pieces   = (int32_t)n;
+  r.time_start = m.start_time;
+  for (size_t i = 0; i < n; ++i) r.duration[i] = (double)m.duration[i];  // float32 on the wire
+  for (size_t k = 0; k < 5 * n; ++k)
+    for (int d = 0; d < 3; ++d) r.cpts[k * 3 + d] = m.cpts[k][d];
+  return true;
+}
+inline BezierTrajMsg msgFromRecord(const SogmTrajRecord &r, int32_t traj_id, double pub_time) {
+  BezierTrajMsg m;
+  m.drone_id   = r.drone_id;
+  m.traj_id    = traj_id;
+  m.start_time = r.time_start;
+  m.pub_time   = pub_time;
+  m.order      = 4;
+  for (int i = 0; i < r.n_pieces; ++i) m.duration.push_back((float)r.duration[i]);
+  for (int k = 0; k < 5 * r.n_pieces; ++k) m.cpts.push_back({r.cpts[k * 3], r.cpts[k * 3 + 1], r.cpts[k * 3 + 2]});
+  return m;
+}
+// map/future_risk std_msgs/Float32MultiArray (plan_env/src/risk_mapping_node.cpp:129-145, consumer
+// risk_base.cpp:60-75): data = [V * stride risk values | pose x, y, z | stamp], layout.dim[0].stride = T.
+// Splits one message into the arguments of sogm_set_future_risk (host side; grid returned voxel-major [V][T]).
+inline bool splitFutureRiskMsg(const std::vector<float> &data, int V, int T, int stride, std::vector<float> &grid_vt,
+                               float pose[3], double &stamp) {
+  if (stride < T || data.size() < (size_t)V * stride + 4) return false;
+  grid_vt.resize((size_t)V * T);
+  for (int i = 0; i < V; ++i)
+    for (int j = 0; j < T; ++j) grid_vt[(size_t)i * T + j] = data[(size_t)i * stride + j];
+  // pose and time follow the V * PREDICTION_TIMES block (risk_base.cpp:72 reads index V*T + 3)
+  const size_t o = (size_t)V * T;
+  pose[0] = data[o];
+  pose[1] = data[o + 1];
+  pose[2] = data[o + 2];
+  stamp   = (double)data[o + 3];  // float32 seconds on the wire
+  return true;
+}
+inline std::vector<float> futureRiskMsg(const std::vector<float> &grid_vt, const float pose[3], double stamp) {
+  std::vector<float> d(grid_vt);
+  d.push_back(pose[0]);
+  d.push_back(pose[1]);
+  d.push_back(pose[2]);
+  d.push_back((float)stamp);
+  return d;
+}
+
 // ---- RiskMap / SOGM : RiskBase + FakeParticleRiskVoxel surface --------------------------------------
 class RiskMap {
  public:
-  RiskMap(const SogmSpec &spec, int n_agents, int device = 0) : n_(n_agents) {
+  RiskMap(const SogmSpec &spec, int n_agents, int device = 0) : n_(n_agents), spec_(spec) {
     check(sogm_create(&spec, n_agents, device, &ctx_), "sogm_create");
   }
   ~RiskMap() { sogm_destroy(ctx_); }
@@ -73,6 +135,20 @@ class RiskMap {
   void update(const float *cloud_xyz, const int32_t *cloud_range, const SogmCylinder *cyl, int n_cyl,
               const float *poses, const double *stamps, hipStream_t st = nullptr) {
     check(sogm_update_gt(ctx_, cloud_xyz, cloud_range, cyl, n_cyl, poses, stamps, st), "sogm_update_gt");
+  }
+  // RiskBase::futureRiskCallback for agent 0 of a 1-agent context: adopt one map/future_risk message
+  void futureRiskCallback(const std::vector<float> &msg_data, int stride, hipStream_t st = nullptr) {
+    const SogmSpec sp = spec_;
+    const int      V  = sp.L * sp.W * sp.H;
+    std::vector<float> grid;
+    float  pose[3];
+    double stamp = 0.0;
+    if (n_ != 1 || !splitFutureRiskMsg(msg_data, V, sp.T, stride, grid, pose, stamp))
+      throw std::runtime_error("futureRiskCallback: malformed message");
+    g_.put(grid.data(), grid.size());
+    f_.put(pose, 3);
+    t_.put(&stamp, 1);
+    check(sogm_set_future_risk(ctx_, g_.data(), f_.data(), t_.data(), st), "sogm_set_future_risk");
   }
   // RiskBase::addOtherAgents
   void addOtherAgents(const SogmTrajRecord *records, int n, const int32_t *ego_ids, hipStream_t st = nullptr) {
@@ -111,6 +187,8 @@ class RiskMap {
  private:
   sogm_ctx       *ctx_ = nullptr;
   int             n_;
+  SogmSpec        spec_;
+  DevBuf<float>   g_, f_;
   DevBuf<int32_t> a_, cnt_;
   DevBuf<double>  p_, q_, t_, u_, pts_;
   DevBuf<int8_t>  o_;
