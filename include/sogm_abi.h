@@ -60,6 +60,7 @@ enum {
  * ceiling 2.0 / ground -1.0 (map.cpp:37-38; sim_fake.yaml:68-69 -> 3.0 / -0.01),
  * region threshold 1.2, decays 0.2 (risk_base.cpp:21-23).
  */
+enum { SOGM_STORE_F32 = 0, SOGM_STORE_F16 = 1 };
 typedef struct SogmSpec {
   int32_t L, W, H, T;
   float   resolution;
@@ -71,7 +72,9 @@ typedef struct SogmSpec {
   float   risk_threshold_region;
   float   risk_thres_reg_decay;
   float   risk_thres_vox_decay;
-  int32_t map_kind; /* SOGM_MAP_FAKE | SOGM_MAP_RISKBASE */
+  int32_t map_kind; /* SOGM_MAP_FAKE | SOGM_MAP_RISKBASE | SOGM_MAP_RISKVOXEL */
+  int32_t storage;  /* SOGM_STORE_F32 (reference: float risk_maps_) | SOGM_STORE_F16 (half the HBM
+                       bytes per voxel; marks and neighbour counts up to 2048 stay exact) */
 } SogmSpec;
 
 /* Ground-truth obstacle record, field-for-field `struct Cylinder`
@@ -161,12 +164,13 @@ int         sogm_device_count(void);
 /* map context:  MapBase::init / RiskBase::init / FakeParticleRiskVoxel::init                   */
 /*   (plan_env/src/map.cpp:42-105, risk_base.cpp:15-58, fake_particle_risk_voxel.cpp:20-73)    */
 /* ------------------------------------------------------------------------------------------ */
-/* Allocates the batched SOGM  sogm[n_agents][T][H][W][L]  (fp32, time-major slabs) on `device`. */
+/* Allocates the batched SOGM  sogm[n_agents][T][H][W][L]  (fp32 or fp16 per spec->storage, time-major
+ * slabs) on `device`. */
 int  sogm_create(const SogmSpec *spec, int n_agents, int device, sogm_ctx **out);
 void sogm_destroy(sogm_ctx *ctx);
 /* Bytes of HBM held by the grid. */
 int64_t sogm_grid_bytes(const sogm_ctx *ctx);
-/* Device pointer of the grid (layout above). */
+/* Device pointer of the grid (layout above; __half elements when storage is SOGM_STORE_F16). */
 float  *sogm_grid_ptr(sogm_ctx *ctx);
 
 /* Body particles of one drone: ParticleATC::initEgoParticles (particles.cpp:62-87).

@@ -13,6 +13,7 @@ SOGM_MAX_PIECES = 16
 SOGM_MAP_FAKE = 0
 SOGM_MAP_RISKBASE = 1
 SOGM_MAP_RISKVOXEL = 2
+SOGM_STORE_F32, SOGM_STORE_F16 = 0, 1
 SOGM_DSP_MAX_T = 16
 
 SOGM_OK = 0
@@ -33,7 +34,8 @@ class SogmSpec(C.Structure):
                 ("risk_threshold", C.c_float), ("clearance", C.c_float),
                 ("ground_height", C.c_float), ("ceiling_height", C.c_float),
                 ("risk_threshold_region", C.c_float), ("risk_thres_reg_decay", C.c_float),
-                ("risk_thres_vox_decay", C.c_float), ("map_kind", C.c_int32)]
+                ("risk_thres_vox_decay", C.c_float), ("map_kind", C.c_int32),
+                ("storage", C.c_int32)]
 
 
 class SogmDspParams(C.Structure):

@@ -18,7 +18,7 @@ GRID_CONFIGS = {
 AGENTS = {"parity": 4, "cfg0": 1, "cfg1": 16, "cfg2": 128, "cfg4": 128}
 
 
-def make_spec(grid="parity", map_kind=SOGM_MAP_FAKE, clearance=0.45, time_resolution=0.2):
+def make_spec(grid="parity", map_kind=SOGM_MAP_FAKE, clearance=0.45, time_resolution=0.2, storage=None):
     L, W, H, T = GRID_CONFIGS[grid] if isinstance(grid, str) else grid
     s = SogmSpec()
     s.L, s.W, s.H, s.T = L, W, H, T
@@ -32,6 +32,8 @@ def make_spec(grid="parity", map_kind=SOGM_MAP_FAKE, clearance=0.45, time_resolu
     s.risk_thres_reg_decay = 0.2      # risk_base.cpp:22
     s.risk_thres_vox_decay = 0.2      # risk_base.cpp:23
     s.map_kind = map_kind
+    # BASELINE configs[4] (300^3 x 30, 128 agents) only fits 288 GB of HBM with fp16 occupancy cells
+    s.storage = (1 if grid == "cfg4" else 0) if storage is None else storage
     return s
 
 

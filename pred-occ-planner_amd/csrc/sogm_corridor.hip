@@ -788,7 +788,7 @@ __global__ __launch_bounds__(64) void k_corridor_segment(
     const int nx = hx - lx + 1, ny = hy - ly + 1, nz = hz - lz + 1;
     if (nx > 0 && ny > 0 && nz > 0 && js <= je) {
       const int    cells = nx * ny * nz;
-      const float *grid0 = m.slab(agent, 0);
+      const void *grid0 = m.slab(agent, 0);
       int          base  = 0;
       for (int c0 = 0; c0 < cells; c0 += 64) {
         const int c    = c0 + lane;
@@ -804,7 +804,7 @@ __global__ __launch_bounds__(64) void k_corridor_segment(
             const float thr = g.map_kind == SOGM_MAP_FAKE
                                   ? g.risk_threshold
                                   : g.risk_threshold - g.decay_voxel * (float)j;
-            if (grid0[(size_t)j * g.V + vi] > thr) {
+            if (cell_ld(grid0, (size_t)j * g.V + vi, g.half) > thr) {
               ++cnt;
               mask |= 1u << (j - js);
             }

@@ -3,6 +3,7 @@
 // expression is evaluated exactly as written (voxel indices must be bit-exact).
 #pragma once
 
+#include <hip/hip_fp16.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -26,6 +27,7 @@ struct GridGeom {
   float thr_region, decay_region, decay_voxel;
   int   inf_step;     // (int)(clearance / res) in fp32 (risk_base.cpp:31)
   int   map_kind;
+  int   half;         // 1: occupancy stored as __half (SOGM_STORE_F16), arithmetic stays fp32
 
   // map.h:153-157 — strict inequalities
   __host__ __device__ inline bool in_range(float x, float y, float z) const {
@@ -75,6 +77,7 @@ inline GridGeom make_geom(const SogmSpec &s) {
   g.decay_voxel    = s.risk_thres_vox_decay;
   g.inf_step       = (int)(s.clearance / s.resolution);
   g.map_kind       = s.map_kind;
+  g.half           = s.storage == SOGM_STORE_F16 ? 1 : 0;
   // RiskVoxel::getClearOcccupancy (risk_voxel.cpp:399-423) compares the K-cell sum with the fixed
   // map/risk_threshold_astar: the RiskBase rule with risk_threshold_region = that value and no decay.
   // It inherits MapBase::getObstaclePoints (map.cpp:480-518): fixed risk_threshold as well.
@@ -82,16 +85,45 @@ inline GridGeom make_geom(const SogmSpec &s) {
   return g;
 }
 
+// Occupancy cells are fp32 or fp16 in HBM (GridGeom::half); every access goes through these.
+__device__ inline float cell_ld(const void *slab, size_t i, int half) {
+  return half ? __half2float(reinterpret_cast<const __half *>(slab)[i]) : reinterpret_cast<const float *>(slab)[i];
+}
+__device__ inline void cell_st(void *slab, size_t i, float v, int half) {
+  if (half)
+    reinterpret_cast<__half *>(slab)[i] = __float2half(v);
+  else
+    reinterpret_cast<float *>(slab)[i] = v;
+}
+// += inc: hardware fp32 atomic, or a CAS on the 32-bit word holding the fp16 cell
+__device__ inline void cell_add(void *slab, size_t i, float inc, int half) {
+  if (!half) {
+    __hip_atomic_fetch_add(reinterpret_cast<float *>(slab) + i, inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
+  unsigned *w  = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(slab) + ((i * 2) & ~(size_t)3));
+  const int hi = (int)(i & 1);
+  unsigned  old = *w, assumed;
+  do {
+    assumed = old;
+    const unsigned short hb = (unsigned short)((assumed >> (16 * hi)) & 0xffffu);
+    const float          f  = __half2float(__ushort_as_half(hb)) + inc;
+    const unsigned       nb = (unsigned)__half_as_ushort(__float2half(f));
+    const unsigned       nw = hi ? ((assumed & 0x0000ffffu) | (nb << 16)) : ((assumed & 0xffff0000u) | nb);
+    old = atomicCAS(w, assumed, nw);
+  } while (old != assumed);
+}
+
 // Read-only view of the batched map handed to every kernel that queries it.
 struct MapView {
   GridGeom      g;
-  const float  *grid;    // [A][T][V]
+  const char   *grid;    // [A][T][V] cells of 4 (fp32) or 2 (fp16) bytes
   const float  *poses;   // [A][3]
   const double *stamps;  // [A]
   int           n_agents;
 
-  __device__ inline const float *slab(int agent, int t) const {
-    return grid + ((size_t)agent * g.T + t) * (size_t)g.V;
+  __device__ inline const void *slab(int agent, int t) const {
+    return grid + ((size_t)agent * g.T + t) * (size_t)g.V * (g.half ? 2 : 4);
   }
 };
 
@@ -113,7 +145,7 @@ __device__ inline int query_clear_idx(const MapView &m, int agent, double px, do
   const int    iy = (int)((fy + g.ry) / g.res);
   const int    iz = (int)((fz + g.rz) / g.res);
   if (!g.in_range(ix, iy, iz)) return -1;
-  const float *sl  = m.slab(agent, t);
+  const void  *sl  = m.slab(agent, t);
   const int    s   = g.inf_step;
   const int    zs  = g.map_kind == SOGM_MAP_FAKE ? 0 : s;  // fake map: z loop degenerates (:41)
   const float  thr = g.map_kind == SOGM_MAP_FAKE ? g.risk_threshold
@@ -129,7 +161,7 @@ __device__ inline int query_clear_idx(const MapView &m, int agent, double px, do
       v[k] = -1.0F;  // marks "outside the grid" (occupancies are >= 0)
       if (k < w * w) {
         const int qx = ix + (k / w - s), qy = iy + (k % w - s);
-        if (g.in_range(qx, qy, iz)) v[k] = sl[(size_t)iz * g.L * g.W + (size_t)qy * g.L + qx];
+        if (g.in_range(qx, qy, iz)) v[k] = cell_ld(sl, (size_t)iz * g.L * g.W + (size_t)qy * g.L + qx, g.half);
       }
     }
 #pragma unroll
@@ -148,7 +180,7 @@ __device__ inline int query_clear_idx(const MapView &m, int agent, double px, do
       for (int z = -zs; z <= zs; ++z) {
         const int qz = iz + z;
         if (!g.in_range(qx, qy, qz)) continue;
-        sum += sl[(size_t)qz * g.L * g.W + (size_t)qy * g.L + qx];
+        sum += cell_ld(sl, (size_t)qz * g.L * g.W + (size_t)qy * g.L + qx, g.half);
         if (sum > thr) return 1;
       }
     }
@@ -214,7 +246,8 @@ struct sogm_ctx {
   sogm::GridGeom geom;
   int            n_agents;
   int            device;
-  float         *d_grid;    // [A][T][V]
+  float         *d_grid;    // [A][T][V] cells (fp32, or __half when geom.half)
+  size_t         cell_bytes() const { return geom.half ? 2 : 4; }
   float         *d_poses;   // [A][3]
   double        *d_stamps;  // [A]
   double        *d_body;    // [n_body][3]
@@ -251,7 +284,7 @@ namespace sogm {
 inline MapView view_of(const sogm_ctx *c) {
   MapView m;
   m.g        = c->geom;
-  m.grid     = c->d_grid;
+  m.grid     = reinterpret_cast<const char *>(c->d_grid);
   m.poses    = c->d_poses;
   m.stamps   = c->d_stamps;
   m.n_agents = c->n_agents;

@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void k_clear_slabs(vfloat4 *__restrict__ p, si
 // ------------------------------------------------------------------------------------------------
 #define SOGM_MAX_CYL_LDS 1024
 
-__global__ __launch_bounds__(256) void k_stamp_cloud(GridGeom g, float *__restrict__ grid,
+__global__ __launch_bounds__(256) void k_stamp_cloud(GridGeom g, void *__restrict__ grid,
                                                      const float *__restrict__ cloud,
                                                      const int32_t *__restrict__ cloud_range,
                                                      const SogmCylinder *__restrict__ cyl,
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void k_stamp_cloud(GridGeom g, float *__restri
   const float lox = p0 - g.rx, hix = p0 + g.rx;
   const float loy = p1 - g.ry, hiy = p1 + g.ry;
   const float loz = p2 - g.rz, hiz = p2 + g.rz;
-  float      *base = grid + (size_t)agent * g.T * (size_t)g.V;
+  char        *base = reinterpret_cast<char *>(grid) + (size_t)agent * g.T * (size_t)g.V * (g.half ? 2 : 4);
 
   for (int i = begin + blockIdx.x * blockDim.x + threadIdx.x; i < end;
        i += gridDim.x * blockDim.x) {
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256) void k_stamp_cloud(GridGeom g, float *__restri
     const float x = px - p0, y = py - p1, z = pz - p2;
     if (!g.in_range(x, y, z)) continue;
     const int v = g.voxel_of(x, y, z);
-    base[v]     = 1.0F;  // slice 0 (:114)
+    cell_st(base, v, 1.0F, g.half);  // slice 0 (:114)
     // The reference then sweeps the occupied voxels of slice 0 (:121-125); every cloud point in
     // range marks exactly one such voxel and the future marks depend only on the voxel, so the
     // per-point form produces the same set of (idempotent) stores.
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) void k_stamp_cloud(GridGeom g, float *__restri
       const float fx = (cx + (vx * g.dt) * (float)k) - p0;
       const float fy = (cy + (vy * g.dt) * (float)k) - p1;
       const float fz = (cz + (0.0F * g.dt) * (float)k) - p2;
-      if (g.in_range(fx, fy, fz)) base[(size_t)k * g.V + g.voxel_of(fx, fy, fz)] = 1.0F;
+      if (g.in_range(fx, fy, fz)) cell_st(base, (size_t)k * g.V + g.voxel_of(fx, fy, fz), 1.0F, g.half);
     }
   }
 }
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256) void k_stamp_cloud(GridGeom g, float *__restri
 //     time_start < t_abs(0)  and  t_abs(s) < time_end for every s <= t
 // and t_abs is increasing, i.e.  time_start < t_abs(0) && t_abs(t) < time_end.
 __global__ __launch_bounds__(256) void k_splat_neighbours(
-    GridGeom g, float *__restrict__ grid, const SogmTrajRecord *__restrict__ rec, int n_rec,
+    GridGeom g, void *__restrict__ grid, const SogmTrajRecord *__restrict__ rec, int n_rec,
     const int32_t *__restrict__ ego_ids, const float *__restrict__ poses,
     const double *__restrict__ stamps, const double *__restrict__ body, int n_body, int n_agents) {
   const long long gid   = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(256) void k_splat_neighbours(
     }
     const float *pose = poses + agent * 3;
     const double q0 = (double)pose[0], q1 = (double)pose[1], q2 = (double)pose[2];
-    float       *slab = grid + ((size_t)agent * g.T + t) * (size_t)g.V;
+    char        *slab = reinterpret_cast<char *>(grid) + ((size_t)agent * g.T + t) * (size_t)g.V * (g.half ? 2 : 4);
     double       p[3];
     if (R.time_start < tt && time_end > tt) {
       bezier_pos(R, tt - R.time_start, p);
@@ -210,14 +210,14 @@ __global__ __launch_bounds__(256) void k_splat_neighbours(
         const float fx = (float)((p[0] + body[e * 3 + 0]) - q0);
         const float fy = (float)((p[1] + body[e * 3 + 1]) - q1);
         const float fz = (float)((p[2] + body[e * 3 + 2]) - q2);
-        if (g.in_range(fx, fy, fz)) slab[g.voxel_of(fx, fy, fz)] = 1.0F;
+        if (g.in_range(fx, fy, fz)) cell_st(slab, g.voxel_of(fx, fy, fz), 1.0F, g.half);
       }
     } else if (time_end < tt) {
       double dur = 0.0;
       for (int k = 0; k < R.n_pieces; ++k) dur += R.duration[k];
       bezier_pos(R, dur, p);
       const float fx = (float)(p[0] - q0), fy = (float)(p[1] - q1), fz = (float)(p[2] - q2);
-      if (g.in_range(fx, fy, fz)) slab[g.voxel_of(fx, fy, fz)] = 1.0F;
+      if (g.in_range(fx, fy, fz)) cell_st(slab, g.voxel_of(fx, fy, fz), 1.0F, g.half);
     }
     return;
   }
@@ -228,15 +228,15 @@ __global__ __launch_bounds__(256) void k_splat_neighbours(
   bezier_pos(R, tt - R.time_start, p);
   const float *pose = poses + agent * 3;
   const double q0 = (double)pose[0], q1 = (double)pose[1], q2 = (double)pose[2];
-  float       *slab = grid + ((size_t)agent * g.T + t) * (size_t)g.V;
+  char        *slab = reinterpret_cast<char *>(grid) + ((size_t)agent * g.T + t) * (size_t)g.V * (g.half ? 2 : 4);
   for (int e = 0; e < n_body; ++e) {
     const float fx = (float)((p[0] + body[e * 3 + 0]) - q0);
     const float fy = (float)((p[1] + body[e * 3 + 1]) - q1);
     const float fz = (float)((p[2] + body[e * 3 + 2]) - q2);
     if (!g.in_range(fx, fy, fz)) continue;
-    // += 1.0f per body particle; sums of 1.0 are exact in fp32, so the order is immaterial
-    __hip_atomic_fetch_add(slab + g.voxel_of(fx, fy, fz), 1.0F, __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
+    // += 1.0f per body particle; sums of 1.0 are exact in fp32 (and in fp16 up to 2048), so the order
+    // is immaterial
+    cell_add(slab, g.voxel_of(fx, fy, fz), 1.0F, g.half);
   }
 }
 
@@ -303,7 +303,7 @@ __global__ __launch_bounds__(256) void k_obstacle_points(
     return;
   }
   const int    cells = nx * ny * nz;
-  const float *grid0 = m.slab(agent, 0);
+  const void  *grid0 = m.slab(agent, 0);
   double      *outp  = out_pts + (size_t)b * cap * 3;
   const int    lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(256) void k_obstacle_points(
       for (int j = js; j <= je; ++j) {
         const float thr =
             g.map_kind == SOGM_MAP_FAKE ? g.risk_threshold : g.risk_threshold - g.decay_voxel * (float)j;
-        if (grid0[(size_t)j * g.V + vi] > thr) {
+        if (cell_ld(grid0, (size_t)j * g.V + vi, g.half) > thr) {
           ++cnt;
           mask |= 1u << (j - js);
         }
@@ -366,17 +366,17 @@ __global__ __launch_bounds__(256) void k_obstacle_points(
 // ------------------------------------------------------------------------------------------------
 // layout converters ([T][V] slabs <-> reference [V][T])
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_slabs_to_vt(const float *__restrict__ slabs, int V, int T,
+__global__ __launch_bounds__(256) void k_slabs_to_vt(const void *__restrict__ slabs, int V, int T, int half,
                                                      float *__restrict__ vt) {
   const int v = blockIdx.x * blockDim.x + threadIdx.x;
   if (v >= V) return;
-  for (int t = 0; t < T; ++t) vt[(size_t)v * T + t] = slabs[(size_t)t * V + v];
+  for (int t = 0; t < T; ++t) vt[(size_t)v * T + t] = cell_ld(slabs, (size_t)t * V + v, half);
 }
-__global__ __launch_bounds__(256) void k_vt_to_slabs(const float *__restrict__ vt, int V, int T,
-                                                     float *__restrict__ slabs) {
+__global__ __launch_bounds__(256) void k_vt_to_slabs(const float *__restrict__ vt, int V, int T, int half,
+                                                     void *__restrict__ slabs) {
   const int v = blockIdx.x * blockDim.x + threadIdx.x;
   if (v >= V) return;
-  for (int t = 0; t < T; ++t) slabs[(size_t)t * V + v] = vt[(size_t)v * T + t];
+  for (int t = 0; t < T; ++t) cell_st(slabs, (size_t)t * V + v, vt[(size_t)v * T + t], half);
 }
 
 // Bezier pos / vel / acc of a trajectory record at an absolute time (bernstein.cpp:25-59)
@@ -465,7 +465,8 @@ __global__ __launch_bounds__(64) void k_traj_safe(MapView m, const SogmTrajRecor
 }
 
 int launch_clear(sogm_ctx *c, hipStream_t st) {
-  const size_t n    = (size_t)c->n_agents * c->spec.T * (size_t)c->geom.V;
+  // the clear is a byte stream: n = number of 4-byte words of the grid (fp16 grids: 2 cells per word)
+  const size_t n    = (size_t)c->n_agents * c->spec.T * (size_t)c->geom.V * c->cell_bytes() / 4;
   const size_t nv4  = n / 4;
   const int    tail = (int)(n - nv4 * 4);
   size_t       want = (nv4 + 255) / 256;
@@ -504,6 +505,7 @@ int sogm_create(const SogmSpec *spec, int n_agents, int device, sogm_ctx **out) 
   if (spec->map_kind != SOGM_MAP_FAKE && spec->map_kind != SOGM_MAP_RISKBASE &&
       spec->map_kind != SOGM_MAP_RISKVOXEL)
     return SOGM_ERR_INVALID_ARG;
+  if (spec->storage != SOGM_STORE_F32 && spec->storage != SOGM_STORE_F16) return SOGM_ERR_INVALID_ARG;
   *out = nullptr;
   if (sogm_device_count() <= device || device < 0) {
     std::snprintf(sogm::g_err, sizeof(sogm::g_err), "no HIP device %d", device);
@@ -518,7 +520,7 @@ int sogm_create(const SogmSpec *spec, int n_agents, int device, sogm_ctx **out) 
   c->n_agents      = n_agents;
   c->device        = device;
   const size_t n   = (size_t)n_agents * spec->T * (size_t)c->geom.V;
-  hipError_t   e   = hipMalloc(&c->d_grid, n * sizeof(float));
+  hipError_t   e   = hipMalloc(&c->d_grid, (n * c->cell_bytes() + 15) & ~(size_t)15);
   if (e == hipSuccess) e = hipMalloc(&c->d_poses, sizeof(float) * 3 * n_agents);
   if (e == hipSuccess) e = hipMalloc(&c->d_stamps, sizeof(double) * n_agents);
   if (e == hipSuccess) e = hipMalloc(&c->d_scratch_vt, sizeof(float) * (size_t)c->geom.V * spec->T);
@@ -564,7 +566,7 @@ void sogm_destroy(sogm_ctx *c) {
 }
 
 int64_t sogm_grid_bytes(const sogm_ctx *c) {
-  return c ? (int64_t)c->n_agents * c->spec.T * (int64_t)c->geom.V * 4 : 0;
+  return c ? (int64_t)c->n_agents * c->spec.T * (int64_t)c->geom.V * (int64_t)c->cell_bytes() : 0;
 }
 float *sogm_grid_ptr(sogm_ctx *c) { return c ? c->d_grid : nullptr; }
 
@@ -626,7 +628,7 @@ int sogm_update_gt(sogm_ctx *c, const float *cloud_xyz, const int32_t *cloud_ran
   }
   // 32 workgroups of 256 lanes per agent stride over that agent's cloud range
   prof_begin(c, SOGM_PROF_STAMP, st);
-  hipLaunchKernelGGL(k_stamp_cloud, dim3(32, c->n_agents), dim3(256), 0, st, c->geom, c->d_grid,
+  hipLaunchKernelGGL(k_stamp_cloud, dim3(32, c->n_agents), dim3(256), 0, st, c->geom, (void *)c->d_grid,
                      cloud_xyz, cloud_range, cylinders, n_cyl, c->d_poses);
   prof_end(c, SOGM_PROF_STAMP, st);
   SOGM_HIP_CHECK(hipGetLastError());
@@ -644,7 +646,7 @@ int sogm_project_neighbours(sogm_ctx *c, const SogmTrajRecord *records, int n_re
   const int       nblk  = (int)((total + 255) / 256);
   prof_begin(c, SOGM_PROF_SPLAT, (hipStream_t)stream);
   hipLaunchKernelGGL(k_splat_neighbours, dim3(nblk), dim3(256), 0, (hipStream_t)stream, c->geom,
-                     c->d_grid, records, n_records, ego_ids, c->d_poses, c->d_stamps, c->d_body,
+                     (void *)c->d_grid, records, n_records, ego_ids, c->d_poses, c->d_stamps, c->d_body,
                      c->n_body, c->n_agents);
   prof_end(c, SOGM_PROF_SPLAT, (hipStream_t)stream);
   SOGM_HIP_CHECK(hipGetLastError());
@@ -666,8 +668,8 @@ int sogm_set_future_risk(sogm_ctx *c, const float *grid_vt, const float *poses,
   const int    V = c->geom.V, T = c->spec.T;
   const size_t per = (size_t)V * T;
   for (int a = 0; a < c->n_agents; ++a) {
-    hipLaunchKernelGGL(k_vt_to_slabs, dim3((V + 255) / 256), dim3(256), 0, st, grid_vt + a * per,
-                       V, T, c->d_grid + a * per);
+    hipLaunchKernelGGL(k_vt_to_slabs, dim3((V + 255) / 256), dim3(256), 0, st, grid_vt + a * per, V, T,
+                       c->geom.half, (void *)((char *)c->d_grid + a * per * c->cell_bytes()));
   }
   SOGM_HIP_CHECK(hipGetLastError());
   c->updated = 1;
@@ -680,7 +682,8 @@ int sogm_download_reference_layout(sogm_ctx *c, int agent, float *out) {
   const size_t per = (size_t)V * T;
   SOGM_HIP_CHECK(hipDeviceSynchronize());
   hipLaunchKernelGGL(k_slabs_to_vt, dim3((V + 255) / 256), dim3(256), 0, 0,
-                     c->d_grid + (size_t)agent * per, V, T, c->d_scratch_vt);
+                     (const void *)((const char *)c->d_grid + (size_t)agent * per * c->cell_bytes()), V, T,
+                     c->geom.half, c->d_scratch_vt);
   SOGM_HIP_CHECK(hipGetLastError());
   SOGM_HIP_CHECK(hipMemcpy(out, c->d_scratch_vt, per * sizeof(float), hipMemcpyDeviceToHost));
   return SOGM_OK;

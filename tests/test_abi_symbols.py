@@ -28,7 +28,7 @@ def test_every_declared_symbol_is_exported_and_bound(pop):
 def test_struct_sizes_match_header(pop):
     assert pop._abi.TRAJ_RECORD_BYTES == 4 + 4 + 8 + 16 * 8 + 16 * 15 * 8
     assert pop._abi.CYLINDER_BYTES == 8 + 11 * 8
-    assert C.sizeof(pop._abi.SogmSpec) == 14 * 4
+    assert C.sizeof(pop._abi.SogmSpec) == 15 * 4
 
 
 def test_abi_version_and_device_count(pop):
