@@ -171,10 +171,10 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32 occupancy / f64 planning",
+        "dtype": ("f16" if spec.storage == 1 else "f32") + " occupancy / f64 planning",
         "data": "synthetic",
         "config": {"workload": f"{sw.A_loc} agents/GPU x {world} GPU, {spec.L}x{spec.W}x{spec.H}x{spec.T} SOGM, "
-                               "sim_fkpcp-style moving cylinders, batched ADMM QP (BASELINE configs[2] per GPU)",
+                               f"sim_fkpcp-style moving cylinders, batched ADMM QP (BASELINE {'configs[4]' if args.grid == 'cfg4' else 'configs[2]'} per GPU)",
                    "agents_total": sw.A_tot, "grid": [spec.L, spec.W, spec.H, spec.T],
                    "cloud_points": int(sw.scene["cloud"].shape[0]), "cloud_points_scanned": sw.cloud_points, "cylinders": int(len(sw.scene["cylinders"])),
                    "replans_ok_fraction": n_ok / float(sw.A_loc * args.steps),
