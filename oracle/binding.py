@@ -321,7 +321,7 @@ def separable(A, B):
     return int(lib().orc_separable(dptr(A), len(A), dptr(B), len(B)))
 
 
-def safe_after_opt(cpts, M, records, n_records, ego_id, t_now, max_rows=152):
+def safe_after_opt(cpts, M, records, n_records, ego_id, t_now, max_rows=144):
     c = np.ascontiguousarray(cpts, np.float64)
     return int(lib().orc_safe_after_opt(dptr(c), M, records, n_records, ego_id, C.c_double(t_now), max_rows))
 

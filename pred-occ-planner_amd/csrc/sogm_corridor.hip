@@ -27,7 +27,7 @@
 namespace sogm {
 namespace {
 
-#define LP_MAX_ROWS 160  // 2 * max_faces(64) + 2 * 4 box rows, rounded up
+#define LP_MAX_ROWS 152  // 2 * max_faces(64) + 2 * 4 box rows = 136, plus head-room; keeps the segment kernel at 4 workgroups per CU (LDS <= 40 KB)
 #define LP_WORK_DOUBLES (14 * LP_MAX_ROWS)
 #define FIRI_MAX_H 128  // planes selected before truncation to max_faces
 
@@ -1285,3 +1285,13 @@ int launch_corridor(const MapView &m, const SogmPlannerParams &pp, const Corrido
 }
 
 }  // namespace sogm
+
+// debug aid (not part of include/sogm_abi.h): resident workgroups per CU of the segment kernel
+extern "C" int sogm_debug_corridor_occupancy(int pc_capacity) {
+  int n = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)sogm::k_corridor_segment, 64,
+                                                   sogm::corridor_segment_lds(pc_capacity)) != hipSuccess)
+    return -1;
+  return n;
+}
+
