@@ -155,6 +155,13 @@ def load_library(path=LIB_PATH):
         raise SogmError(
             f"HIP extension not built: {path} is missing. Run `python -c 'import __graft_entry__ as g; "
             "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    # The hosts above this binding keep device buffers in torch tensors.  torch ships its own
+    # libamdhip64; load it first so that the extension binds to the SAME HIP runtime (two runtimes in one
+    # process do not see each other's devices or allocations).
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(path)
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
