@@ -205,9 +205,24 @@ struct MvieData {
 
 // 64-lane butterfly sum: every lane ends with the same total; the association order
 // ((l, l^32), (.., ^16), ...) is what oracle/corridor_oracle.cpp::tree_sum64 replays.
+// Levels 32 and 16 cross the 16-lane rows (ds_bpermute); after them every lane of a class l mod 16 holds
+// the same value, so levels 8 and 4 can take their partner with a DPP row rotate ((l + 8) mod 16 is in
+// class (l mod 16) ^ 8, likewise for 4) and levels 2, 1 with DPP quad permutes — same pairs, same
+// (commutative) additions, no LDS crossbar round trip on four of the six levels.
+template <int CTRL>
+__device__ inline double dpp_f64(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo     = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xF, 0xF, true);
+  hi     = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
 __device__ inline double bfly_sum(double v) {
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+  v += __shfl_xor(v, 32, 64);
+  v += __shfl_xor(v, 16, 64);
+  v += dpp_f64<0x128>(v);  // row_ror:8
+  v += dpp_f64<0x124>(v);  // row_ror:4
+  v += dpp_f64<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dpp_f64<0xB1>(v);   // quad_perm [1,0,3,2]
   return v;
 }
 
