@@ -299,7 +299,10 @@ __global__ __launch_bounds__(256) void k_gm_select(GmDev d) {
 __global__ __launch_bounds__(256) void k_gm_walk(GmDev d, int round) {
   const int a = blockIdx.y;
   GmAgent  &s = d.ag[a];
-  if (!s.do_rays || !s.dedup || s.converged) return;
+  if (!s.do_rays || !s.dedup) return;
+  // converged = an earlier round r >= 1 changed no stop position (changed[] of rounds that never ran stays 0,
+  // so "the previous round changed nothing" identifies every round after the fixed point as well)
+  if (round >= 2 && s.changed[round - 1] == 0) return;
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= d.n_samples) return;
   const size_t si = (size_t)a * d.n_samples + i;
@@ -324,14 +327,11 @@ __global__ __launch_bounds__(256) void k_gm_walk(GmDev d, int round) {
   if (steps != d.stop[(round + 1) & 1][si]) atomicAdd(&s.changed[round], 1);
   d.stop[round & 1][si] = steps;
 }
-__global__ void k_gm_round_end(GmDev d, int round) {
-  const int a = blockIdx.x * blockDim.x + threadIdx.x;
-  if (a >= d.A) return;
-  GmAgent &s = d.ag[a];
-  if (!s.do_rays || !s.dedup || s.converged) return;
-  s.final_round = round;
-  if (round > 0 && s.changed[round] == 0) s.converged = 1;
-  if (round == GM_ROUNDS - 1 && !s.converged) s.err_unconverged += 1;
+// first round r >= 1 that changed nothing = the fixed point (its owners equal the previous round's)
+__device__ inline int gm_final_round(const GmAgent &s) {
+  for (int r = 1; r < GM_ROUNDS; ++r)
+    if (s.changed[r] == 0) return r;
+  return GM_ROUNDS - 1;
 }
 
 // final walk: count the arrivals (setCacheOccupancy(tmp, 0), :383) with the converged owners
@@ -347,7 +347,7 @@ __global__ __launch_bounds__(256) void k_gm_count(GmDev d) {
   const double en[3] = {s.cam[0] / d.res, s.cam[1] / d.res, s.cam[2] / d.res};
   GmRay        rc;
   rc.set(st, en);
-  const int                 fr  = s.final_round;
+  const int                 fr  = s.dedup ? gm_final_round(s) : 0;
   const unsigned long long *own = d.own[fr & 1] + (size_t)a * d.N;
   int c[3];
   while (rc.step(c)) {
@@ -368,6 +368,10 @@ __global__ void k_gm_bounds(GmDev d, int32_t *__restrict__ out_updated) {
   if (s.n_valid == 0) {  // proj_points_cnt == 0: raycastProcess returns before counting the frame (:315-320)
     s.raycast_num -= 1;
     return;
+  }
+  if (s.dedup) {
+    s.final_round = gm_final_round(s);
+    if (s.changed[s.final_round] != 0) s.err_unconverged += 1;
   }
   double mn[3], mx[3];
   for (int k = 0; k < 3; ++k) {
@@ -642,7 +646,6 @@ int sogm_gridmap_update(sogm_gridmap *g, const uint16_t *depth, const double *ca
   hipLaunchKernelGGL(k_gm_select, gs, dim3(256), 0, st, d);
   for (int r = 0; r < GM_ROUNDS; ++r) {
     hipLaunchKernelGGL(k_gm_walk, gs, dim3(256), 0, st, d, r);
-    hipLaunchKernelGGL(k_gm_round_end, ga, dim3(64), 0, st, d, r);
   }
   hipLaunchKernelGGL(k_gm_count, gs, dim3(256), 0, st, d);
   hipLaunchKernelGGL(k_gm_bounds, ga, dim3(64), 0, st, d, out_updated);
