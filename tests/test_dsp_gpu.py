@@ -119,3 +119,55 @@ def test_dsp_fast_sensor_particles_leave_map(pop, orc):
                 u["pos"] = (u["pos"] + np.asarray([0.05 * k, 0, 0.12 * k], np.float32)).astype(np.float32)
     st = _run(pop, orc, "parity", [0xA1], 10, mutate=mutate)
     assert st[2] > 0
+
+
+def test_dsp_full_size_properties_cfg1(pop):
+    """BASELINE configs[1] (16 agents, 100^3 x 15, 640x480 depth clouds): no oracle at this size — the
+    size-independent invariants of DSPMap: every live particle sits in the voxel its position maps to, vz == 0,
+    flags after resampling are 1.0 / 0.6, the voxel weight equals the sum of its particles' weights, the published
+    grid equals the accumulated future status, publishing clears the accumulators, no capacity error."""
+    import importlib
+    import torch
+    sogm = importlib.import_module("pred-occ-planner_amd.sogm")
+    dsp = importlib.import_module("pred-occ-planner_amd.dsp")
+    A = 16
+    spec = pop.config.make_spec("cfg1", map_kind=pop._abi.SOGM_MAP_RISKVOXEL)
+    m = sogm.SogmMap(spec, A)
+    g = dsp.DspMap(m, dsp.make_dsp_params(spec.T), dsp.make_tables(5))
+    cap = 5000
+    clouds = [pop.scene.make_depth_cloud(40 + a) for a in range(A)]
+    n_pix = len(clouds[0])
+    raw = sogm._dev(np.concatenate(clouds, axis=0), np.float32)
+    rng = sogm._dev(np.stack([np.arange(A) * n_pix, (np.arange(A) + 1) * n_pix], axis=1), np.int32)
+    labels = torch.zeros((A * cap, 4), dtype=torch.float32, device="cuda")
+    base = torch.arange(A, dtype=torch.int32, device="cuda") * cap
+    quat = sogm._dev(np.tile(np.float32([1, 0, 0, 0]), (A, 1)), np.float32)
+    for k in range(6):
+        pos = sogm._dev(np.tile(np.float32([0.04 * k, 0.0, 0.0]), (A, 1)), np.float32)
+        stamps = sogm._dev(np.full(A, 10.0 + k / 30.0), np.float64)
+        pts, cnt = m.filterPointCloud(raw, rng, 0.15, cap)
+        ok = g.update(pts.view(-1, 3), labels, torch.stack([base, base + cnt], dim=1).contiguous(), pos, quat, stamps)
+        assert bool(ok.all())
+    assert int(cnt.min()) > 500
+    half = np.float32(spec.resolution) * np.float32([spec.L, spec.W, spec.H]) * np.float32(0.5)
+    for a in (0, A - 1):
+        st, ob, c = g.download_state(a)
+        assert c[10] == 0 and c[11] == 0 and c[12] == 0, c
+        live = st[:, :, 0] > 0.1
+        assert live.sum() > 5000
+        assert set(np.unique(st[:, :, 0][live])) <= {np.float32(1.0), np.float32(0.6)}
+        v, p = np.nonzero(live)
+        idx = ((st[v, p, 4:7] + half) / np.float32(spec.resolution)).astype(np.int32)
+        assert np.array_equal(idx[:, 2] * spec.W * spec.L + idx[:, 1] * spec.L + idx[:, 0], v)
+        assert np.all(st[:, :, 3] == 0)
+        np.testing.assert_allclose(ob[:, 0], (st[:, :, 7] * live).sum(axis=1), rtol=1e-5, atol=1e-7)
+        fut = ob[:, 4:].copy()
+        if a == 0:
+            g.publish()
+            got = m.download(0)
+            diff = np.nonzero(got != fut)
+            assert np.all(got[diff] == 0) and np.all(diff[1] < 3)      # only the inflate-kernel zeroing differs
+            _, ob2, _ = g.download_state(0)
+            assert not ob2[:, 4:].any()
+    g.close()
+    m.close()
