@@ -366,7 +366,7 @@ int osqpDense(const double *Pin, const double *qin, const double *Ain, const dou
     }
     for (int i = 0; i < m; ++i) {
       const double zr = alpha * zt[i] + (1.0 - alpha) * zp[i];
-      double       v  = zr + y[i] / rho[i];
+      double       v  = zr + (1.0 / rho[i]) * y[i];  // OSQP update_z: rho_inv_vec[i] * y[i] (auxil.c)
       v               = v < l[i] ? l[i] : (v > u[i] ? u[i] : v);
       z[i]            = v;
       dy[i]           = rho[i] * (zr - z[i]);

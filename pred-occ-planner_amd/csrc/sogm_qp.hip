@@ -72,6 +72,7 @@ struct Rows {
   // general rows [0, G)
   double *gval;  // [G][6]
   double *gl, *gu, *grho, *gE, *gz, *gy, *gdy;
+  double *grinv;  // [G] 1 / rho (OSQP rho_inv_vec)
   int    *gcol;  // [G][6]
   int    *cidx;  // CSC entries over general rows: row * 8 + slot, row-sorted inside a column
   // safety rows [0, S):  s = off_i + 5 * face + k ; columns i*15 + k*3 + {0,1,2}
@@ -82,7 +83,7 @@ struct Rows {
 };
 
 __host__ __device__ inline size_t rows_bytes(int G, int S) {
-  return (size_t)G * (QP_ELL * 8 + 7 * 8 + QP_ELL * 4 + QP_ELL * 4) + (size_t)S * (3 * 8 + 6 * 8 + 4) + 64;
+  return (size_t)G * (QP_ELL * 8 + 8 * 8 + QP_ELL * 4 + QP_ELL * 4) + (size_t)S * (3 * 8 + 6 * 8 + 4) + 64;
 }
 __device__ inline void carve_rows(Rows &R, char *base, int G, int S) {
   double *d = (double *)base;
@@ -94,6 +95,7 @@ __device__ inline void carve_rows(Rows &R, char *base, int G, int S) {
   R.gz = d;    d += G;
   R.gy = d;    d += G;
   R.gdy = d;   d += G;
+  R.grinv = d; d += G;
   R.sval = d;  d += (size_t)S * 3;
   R.su = d;    d += S;
   R.sE = d;    d += S;
@@ -444,6 +446,7 @@ __global__ __launch_bounds__(256) void k_qp(SogmPlannerParams pp, SogmQpSettings
 
   // ---- helpers -----------------------------------------------------------------------------------
   double rho_cur = qs.rho;  // safety rows are one-sided inequalities: their rho is rho_cur itself
+  double rinv_cur = 1.0 / rho_cur;
   // Register-resident inverse factor (M <= 8).  With X = G^-1 (block lower triangular), lane rho = (bi, rc)
   // keeps ROW rho of X in slots j <= bi (row part inside block column j), COLUMN rho of X in slots
   // i' > bi (column part inside block row i') and the diagonal block's column part in slot 8, so the
@@ -463,7 +466,8 @@ __global__ __launch_bounds__(256) void k_qp(SogmPlannerParams pp, SogmQpSettings
         v = RHO_EQ_OVER_RHO_INEQ * rho_cur;
       else
         v = rho_cur;
-      R.grho[r] = v;
+      R.grho[r]  = v;
+      R.grinv[r] = 1.0 / v;
     }
     for (int s = tid; s < S; s += 256) R.sw[s] = rho_cur * R.sz[s] - R.sy[s];
     __syncthreads();
@@ -817,7 +821,7 @@ __global__ __launch_bounds__(256) void k_qp(SogmPlannerParams pp, SogmQpSettings
         }
         const double rho = R.grho[r], yr = R.gy[r];
         const double zr  = alpha * s + (1.0 - alpha) * R.gz[r];
-        double       v   = zr + yr / rho;
+        double       v   = zr + R.grinv[r] * yr;  // OSQP update_z: rho_inv_vec[i] * y[i]
         const double lo = R.gl[r], hi = R.gu[r];
         v               = v < lo ? lo : (v > hi ? hi : v);
         R.gz[r]         = v;
@@ -835,7 +839,7 @@ __global__ __launch_bounds__(256) void k_qp(SogmPlannerParams pp, SogmQpSettings
         ax += vv[2] * s_xt[c0 + 2];
         const double yr = R.sy[s];
         const double zr = alpha * ax + (1.0 - alpha) * R.sz[s];
-        double       v  = zr + yr / rho_cur;
+        double       v  = zr + rinv_cur * yr;
         const double hi = R.su[s];
         v               = v > hi ? hi : v;  // l = -OSQP_INFTY
         R.sz[s]         = v;
@@ -857,7 +861,8 @@ __global__ __launch_bounds__(256) void k_qp(SogmPlannerParams pp, SogmQpSettings
         double rho_new = rho_cur * sogm_det::sqrt_rn(pr_n / (du_n + 1e-10));
         rho_new        = rho_new < RHO_MIN ? RHO_MIN : (rho_new > 1e6 ? 1e6 : rho_new);
         if (rho_new > rho_cur * 5.0 || rho_new < rho_cur / 5.0) {
-          rho_cur = rho_new;
+          rho_cur  = rho_new;
+          rinv_cur = 1.0 / rho_cur;
           set_rho();
           if (!factor()) {
             status = -7;
