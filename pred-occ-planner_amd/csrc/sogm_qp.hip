@@ -160,8 +160,9 @@ __global__ __launch_bounds__(256) void k_qp(SogmPlannerParams pp, SogmQpSettings
   double    *s_Ginv     = s_P + (size_t)M * 225;     // [M][225] inverse of the diagonal block of G
   double    *s_Goff     = s_Ginv + (size_t)M * 225;  // [M][225] G(block i, block i-1)
   __shared__ double s_ginv[QP_NMAX];
-  __shared__ double s_x[QP_NMAX], s_xt[QP_NMAX], s_D[QP_NMAX], s_Dt[QP_NMAX];
-  __shared__ double s_cn[QP_NMAX];
+  __shared__ __attribute__((aligned(16))) double s_xt[QP_NMAX];
+  __shared__ double s_x[QP_NMAX], s_D[QP_NMAX], s_Dt[QP_NMAX];
+  __shared__ __attribute__((aligned(16))) double s_cn[QP_NMAX];
   __shared__ double s_red[4];
   __shared__ double s_sc[8];
   __shared__ int    s_off[SOGM_MAX_PIECES + 1];  // safety-row offset of each piece
@@ -455,6 +456,9 @@ __global__ __launch_bounds__(256) void k_qp(SogmPlannerParams pp, SogmQpSettings
   // it: lane h = tid & 1 keeps entries k = 8 h .. 8 h + 7 of every 15-entry part (72 doubles = 144
   // VGPRs) and the two partial dot products meet through one DPP exchange.
   double    xr[9][8] = {};
+  // Row rho of K^-1 = X^T X, columns 60 hh .. 60 hh + 59 (zero beyond n), built from xr after every
+  // factorisation: the per-iteration solve is then ONE register mat-vec and one barrier.
+  double    kinv[60] = {};
   const int rho_l = tid >> 1, hh = tid & 1, bi = rho_l / 15, rc = rho_l % 15, k0 = hh * 8;
   auto   set_rho = [&]() {
     for (int r = tid; r < G; r += 256) {
@@ -630,68 +634,59 @@ __global__ __launch_bounds__(256) void k_qp(SogmPlannerParams pp, SogmQpSettings
           }
         }
       }
+      // K^-1 = X^T X, one block row of X at a time through LDS (s_Goff is free now: 15 x n doubles).
+      // Lane (rho, hh) accumulates  kinv[kk] += X[r][rho] * X[r][60 hh + kk]  over the rows r of X.
+      {
+        double *stage = s_Goff;
+#pragma unroll
+        for (int kk = 0; kk < 60; ++kk) kinv[kk] = 0.0;
+#pragma unroll
+        for (int ib = 0; ib < 8; ++ib) {
+          if (ib < M) {  // uniform
+            __syncthreads();
+            if (tid < 2 * n && bi == ib) {  // the 30 lanes holding the rows of block ib publish them
+#pragma unroll
+              for (int jb = 0; jb < 8; ++jb) {
+                if (jb < M) {
+#pragma unroll
+                  for (int kk = 0; kk < 8; ++kk) {
+                    const int k = k0 + kk;
+                    if (k < 15) stage[rc * n + jb * 15 + k] = jb <= ib ? xr[jb][kk] : 0.0;
+                  }
+                }
+              }
+            }
+            __syncthreads();
+            if (tid < 2 * n && bi <= ib) {  // X[block row ib][rho] is zero for later blocks
+              const int kend = (ib + 1) * 15 - 60 * hh;  // columns of this half that can be non-zero
+              for (int r = 0; r < 15; ++r) {
+                const double  xj  = stage[r * n + rho_l];
+                const double *row = stage + r * n + 60 * hh;
+#pragma unroll
+                for (int kk = 0; kk < 60; ++kk)
+                  if (kk < kend) kinv[kk] = __builtin_fma(xj, row[kk], kinv[kk]);
+              }
+            }
+          }
+        }
+      }
       __syncthreads();
     }
     return s_flag != 0;
   };
   auto solveK = [&]() __attribute__((always_inline)) {
     if (use_blocks) {
-      // (fused multiply-adds here: this solve is not on the bit-exact path — the oracle factors K with a
-      // plain banded Cholesky — and every VALU instruction of a 64-lane wave costs 4 cycles)
-      // y = X rhs: row rho of X against the rhs, no chain.  All LDS operands of four blocks are fetched
-      // before any arithmetic (one latency exposure per batch instead of one per block); a block's
-      // partial sum is computed unconditionally and kept or dropped with a select.  Entry 7 of the upper
-      // half is a zero pad whose LDS index is clamped inside the vector.
-      const bool on = tid < 2 * n;
-      int        kx[8];
-#pragma unroll
-      for (int kk = 0; kk < 8; ++kk) kx[kk] = k0 + kk < 15 ? k0 + kk : 14;
+      // x~ = K^-1 rhs: one register mat-vec per lane pair (fused multiply-adds: this solve is not on the
+      // bit-exact path — the oracle factors K with a plain banded Cholesky — and every VALU instruction of a
+      // 64-lane wave costs 4 cycles).  s_xt is zero beyond n, kinv too.  The result goes to s_cn.
       {
-        double acc = 0.0;
+        const bool    on  = tid < 2 * n;
+        const double *rhs = s_xt + 60 * hh;
+        double        acc = 0.0;
 #pragma unroll
-        for (int bt = 0; bt < 2; ++bt) {
-          double rv[32];
-#pragma unroll
-          for (int q = 0; q < 32; ++q) {
-            const int jb = bt * 4 + (q >> 3);
-            rv[q]        = s_xt[(jb < M ? jb : 0) * 15 + kx[q & 7]];
-          }
-#pragma unroll
-          for (int b4 = 0; b4 < 4; ++b4) {
-            const int jb   = bt * 4 + b4;
-            double    part = 0.0;
-#pragma unroll
-            for (int kk = 0; kk < 8; ++kk) part = __builtin_fma(xr[jb][kk], rv[b4 * 8 + kk], part);
-            acc += (on && jb <= bi) ? part : 0.0;
-          }
-        }
+        for (int kk = 0; kk < 60; ++kk) acc = __builtin_fma(kinv[kk], rhs[kk], acc);
         acc += dpp_quad(acc, 0xB1);  // partner lane tid ^ 1
         if (on && hh == 0) s_cn[rho_l] = acc;
-      }
-      __syncthreads();
-      // x = X^T y: column rho of X against y (slot 0 is never a column part: the diagonal one is slot 8)
-      {
-        double acc = 0.0;
-#pragma unroll
-        for (int bt = 0; bt < 2; ++bt) {
-          double rv[32];
-#pragma unroll
-          for (int q = 0; q < 32; ++q) {
-            const int ip  = bt * 4 + (q >> 3);
-            const int blk = ip == 0 ? bi : (ip < M ? ip : 0);  // batch slot 0 carries the diagonal block
-            rv[q]         = s_cn[(on ? blk : 0) * 15 + kx[q & 7]];
-          }
-#pragma unroll
-          for (int b4 = 0; b4 < 4; ++b4) {
-            const int ip   = bt * 4 + b4;
-            double    part = 0.0;
-#pragma unroll
-            for (int kk = 0; kk < 8; ++kk) part = __builtin_fma(xr[ip == 0 ? 8 : ip][kk], rv[b4 * 8 + kk], part);
-            acc += (on && (ip == 0 || (ip > bi && ip < M))) ? part : 0.0;
-          }
-        }
-        acc += dpp_quad(acc, 0xB1);
-        if (on && hh == 0) s_xt[rho_l] = acc;
       }
     } else if (wave == 0) {
       for (int j = 0; j < n; ++j) {  // G y = b
@@ -790,7 +785,10 @@ __global__ __launch_bounds__(256) void k_qp(SogmPlannerParams pp, SogmQpSettings
   if (!chol_ok) status = -7;
 
   // ---- 4. ADMM iterations
-  const double alpha = qs.alpha;
+  const double  alpha = qs.alpha;
+  const double *xtv   = use_blocks ? s_cn : s_xt;  // where the solve leaves x~
+  for (int j = n + tid; j < 128; j += 256) s_xt[j] = 0.0;  // the register mat-vec reads 120 entries
+  __syncthreads();
   if (chol_ok) {
     for (iter = 1; iter <= qs.max_iter; ++iter) {
       // (a) rhs_j = sigma x_j - q_j + sum_rows A[r][j] (rho_r z_r - y_r)
@@ -817,7 +815,7 @@ __global__ __launch_bounds__(256) void k_qp(SogmPlannerParams pp, SogmQpSettings
         double s = 0;
         for (int k = 0; k < QP_ELL; ++k) {
           const int c = R.gcol[(size_t)r * QP_ELL + k];
-          if (c >= 0) s += R.gval[(size_t)r * QP_ELL + k] * s_xt[c];
+          if (c >= 0) s += R.gval[(size_t)r * QP_ELL + k] * xtv[c];
         }
         const double rho = R.grho[r], yr = R.gy[r];
         const double zr  = alpha * s + (1.0 - alpha) * R.gz[r];
@@ -834,9 +832,9 @@ __global__ __launch_bounds__(256) void k_qp(SogmPlannerParams pp, SogmQpSettings
         const int     c0 = R.sc0[s];
         const double *vv = R.sval + (size_t)s * 3;
         double        ax = 0;
-        ax += vv[0] * s_xt[c0];
-        ax += vv[1] * s_xt[c0 + 1];
-        ax += vv[2] * s_xt[c0 + 2];
+        ax += vv[0] * xtv[c0];
+        ax += vv[1] * xtv[c0 + 1];
+        ax += vv[2] * xtv[c0 + 2];
         const double yr = R.sy[s];
         const double zr = alpha * ax + (1.0 - alpha) * R.sz[s];
         double       v  = zr + rinv_cur * yr;
@@ -849,7 +847,7 @@ __global__ __launch_bounds__(256) void k_qp(SogmPlannerParams pp, SogmQpSettings
         R.sy[s]         = yn;
         R.sw[s]         = rho_cur * v - yn;
       }
-      for (int j = tid; j < n; j += 256) s_x[j] = alpha * s_xt[j] + (1.0 - alpha) * s_x[j];
+      for (int j = tid; j < n; j += 256) s_x[j] = alpha * xtv[j] + (1.0 - alpha) * s_x[j];
       __syncthreads();
       const bool do_adapt = qs.adaptive_rho_interval > 0 && iter % qs.adaptive_rho_interval == 0;
       const bool do_check = qs.check_termination > 0 && iter % qs.check_termination == 0;
