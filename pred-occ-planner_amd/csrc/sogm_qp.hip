@@ -785,6 +785,15 @@ __global__ __launch_bounds__(256) void k_qp(SogmPlannerParams pp, SogmQpSettings
   if (!chol_ok) status = -7;
 
   // ---- 4. ADMM iterations
+  int cj_q0 = 0, cj_q1 = 0, cj_sbase = 0, cj_nface = 0, cj_pd = 0;
+  if (tid < n) {
+    COL_DECODE(tid)
+    cj_q0    = s_cptr[tid];
+    cj_q1    = s_cptr[tid + 1];
+    cj_sbase = sbase;
+    cj_nface = nface;
+    cj_pd    = pd;
+  }
   const double  alpha = qs.alpha;
   const double *xtv   = use_blocks ? s_cn : s_xt;  // where the solve leaves x~
   for (int j = n + tid; j < 128; j += 256) s_xt[j] = 0.0;  // the register mat-vec reads 120 entries
@@ -793,17 +802,16 @@ __global__ __launch_bounds__(256) void k_qp(SogmPlannerParams pp, SogmQpSettings
     for (iter = 1; iter <= qs.max_iter; ++iter) {
       // (a) rhs_j = sigma x_j - q_j + sum_rows A[r][j] (rho_r z_r - y_r)
       if (!(ablate & 1))
-      for (int j = tid; j < n; j += 256) {
-        double s = qs.sigma * s_x[j];  // q == 0
-        for (int q = s_cptr[j]; q < s_cptr[j + 1]; ++q) {
+      if (tid < n) {  // n <= 240 < 256: one column per lane, its constants hoisted out of the loop (cj_*)
+        const int j = tid;
+        double    s = qs.sigma * s_x[j];  // q == 0
+        for (int q = cj_q0; q < cj_q1; ++q) {
           const int en = R.cidx[q], r = en >> 3;
           s += R.gval[(size_t)r * QP_ELL + (en & 7)] * (R.grho[r] * R.gz[r] - R.gy[r]);
         }
-        COL_DECODE(j)
-        for (int f = 0; f < nface; ++f) {
-          const int sr = sbase + 5 * f;
-          s += R.sval[(size_t)sr * 3 + pd] * R.sw[sr];
-        }
+        const double *sv = R.sval + (size_t)cj_sbase * 3 + cj_pd;
+        const double *sw = R.sw + cj_sbase;
+        for (int f = 0; f < cj_nface; ++f) s += sv[(size_t)15 * f] * sw[5 * f];
         s_xt[j] = s;
       }
       __syncthreads();
