@@ -1242,6 +1242,32 @@ __global__ __launch_bounds__(64) void k_safe_after_opt(const double *__restrict_
       }
     for (int k = 0; k < 3; ++k) apart = apart || hi[k] < lo[3 + k] || hi[3 + k] < lo[k];
     if (apart) return;  // wave-uniform
+    // more candidate normals (face / body diagonals, the line between the box centres), same list and
+    // order as oracle/deconflict_oracle.cpp: disjoint projections = separable, no LP needed
+    double dirs[11][3] = {{1, 1, 0}, {1, -1, 0}, {1, 0, 1}, {1, 0, -1}, {0, 1, 1}, {0, 1, -1},
+                          {1, 1, 1}, {1, 1, -1}, {1, -1, 1}, {1, -1, -1}, {0, 0, 0}};
+    for (int k = 0; k < 3; ++k) dirs[10][k] = 0.5 * (lo[3 + k] + hi[3 + k]) - 0.5 * (lo[k] + hi[k]);
+    for (int q = 0; q < 11; ++q) {
+      const double n0 = dirs[q][0], n1 = dirs[q][1], n2 = dirs[q][2];
+      double loA = INFINITY, hiA = -INFINITY, loB = INFINITY, hiB = -INFINITY;
+      for (int i = threadIdx.x; i < nA; i += 64) {
+        const double v = (n0 * ca[i * 3] + n1 * ca[i * 3 + 1]) + n2 * ca[i * 3 + 2];
+        loA = fmin(loA, v);
+        hiA = fmax(hiA, v);
+      }
+      for (int i = threadIdx.x; i < nB; i += 64) {
+        const double v = (n0 * cb[i * 3] + n1 * cb[i * 3 + 1]) + n2 * cb[i * 3 + 2];
+        loB = fmin(loB, v);
+        hiB = fmax(hiB, v);
+      }
+      for (int d = 32; d >= 1; d >>= 1) {
+        loA = fmin(loA, __shfl_xor(loA, d, 64));
+        hiA = fmax(hiA, __shfl_xor(hiA, d, 64));
+        loB = fmin(loB, __shfl_xor(loB, d, 64));
+        hiB = fmax(hiB, __shfl_xor(hiB, d, 64));
+      }
+      if (hiA < loB || hiB < loA) return;  // wave-uniform
+    }
   }
   for (int q = threadIdx.x; q < nA + nB; q += 64) {
     if (q < nA) {
