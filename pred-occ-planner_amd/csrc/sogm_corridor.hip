@@ -180,6 +180,183 @@ __device__ __noinline__ double linprog(const double *c, int m, const double *A, 
 }
 
 // ---------------------------------------------------------------------------------------------
+// The same Seidel LP executed by the whole wave (all 64 lanes call it with identical arguments; a, b, work
+// live in LDS).  Arithmetic and decisions are those of Seidel<D>::solve above: "the next violated
+// constraint" is found 64 constraints at a time with a ballot (x does not change between violations, so the
+// first set bit IS the sequential scan's hit), the reduced rows of the (D-1)-dimensional sub-problem are
+// built one per lane, and the 1-D base case is a min / max / any reduction.  Same results, bit for bit.
+// ---------------------------------------------------------------------------------------------
+__device__ inline void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+template <int D>
+struct SeidelW {
+  __device__ static bool solve(const double *a, const double *b, int m, const double *c, double *x,
+                               double *work) {
+    const int lane = threadIdx.x & 63;
+    for (int j = 0; j < D; ++j) x[j] = c[j] > 0 ? -LP_BIG : (c[j] < 0 ? LP_BIG : 0.0);
+    double *sa = work;
+    double *sb = work + LP_MAX_ROWS * (D - 1);
+    int     i  = 0;
+    while (i < m) {
+      int found = -1;
+      for (int base = i; base < m; base += 64) {
+        const int r    = base + lane;
+        bool      viol = false;
+        if (r < m) {
+          const double *ar = a + r * D;
+          double        v  = 0;
+          for (int j = 0; j < D; ++j) v += ar[j] * x[j];
+          viol = !(v <= b[r] + LP_TOL);
+        }
+        const unsigned long long mk = __ballot(viol);
+        if (mk) {
+          found = base + __ffsll((long long)mk) - 1;
+          break;
+        }
+      }
+      if (found < 0) break;
+      i                = found;
+      const double *ai = a + i * D;
+      int           k  = 0;
+      double        mx = dabs(ai[0]);
+      for (int j = 1; j < D; ++j)
+        if (dabs(ai[j]) > mx) {
+          mx = dabs(ai[j]);
+          k  = j;
+        }
+      if (mx < LP_TINY) return false;
+      const double inv = 1.0 / ai[k];
+      for (int r = lane; r < i; r += 64) {
+        const double *ar = a + r * D;
+        const double  f  = ar[k] * inv;
+        int           q  = 0;
+        for (int j = 0; j < D; ++j)
+          if (j != k) sa[r * (D - 1) + q++] = ar[j] - f * ai[j];
+        sb[r] = b[r] - f * b[i];
+      }
+      wave_lds_sync();
+      double cc[D - 1];
+      {
+        const double f = c[k] * inv;
+        int          q = 0;
+        for (int j = 0; j < D; ++j)
+          if (j != k) cc[q++] = c[j] - f * ai[j];
+      }
+      double xs[D - 1];
+      if (!SeidelW<D - 1>::solve(sa, sb, i, cc, xs, work + LP_MAX_ROWS * D)) return false;
+      double acc = b[i];
+      int    q   = 0;
+      for (int j = 0; j < D; ++j)
+        if (j != k) {
+          x[j] = xs[q++];
+          acc -= ai[j] * x[j];
+        }
+      x[k] = acc * inv;
+      wave_lds_sync();  // the sub-problem arrays are rebuilt by the next violation
+      ++i;
+    }
+    return true;
+  }
+};
+template <>
+struct SeidelW<1> {
+  __device__ static bool solve(const double *a, const double *b, int m, const double *c, double *x,
+                               double *) {
+    const int lane = threadIdx.x & 63;
+    double    lo = -LP_BIG, hi = LP_BIG;
+    bool      bad = false;
+    for (int i = lane; i < m; i += 64) {
+      if (a[i] > LP_TINY) {
+        const double v = b[i] / a[i];
+        if (v < hi) hi = v;
+      } else if (a[i] < -LP_TINY) {
+        const double v = b[i] / a[i];
+        if (v > lo) lo = v;
+      } else if (b[i] < -LP_TOL) {
+        bad = true;
+      }
+    }
+    for (int d = 32; d >= 1; d >>= 1) {
+      const double oh = __shfl_xor(hi, d, 64), ol = __shfl_xor(lo, d, 64);
+      hi = oh < hi ? oh : hi;
+      lo = ol > lo ? ol : lo;
+    }
+    if (__ballot(bad)) return false;
+    if (lo > hi + LP_TOL) return false;
+    if (lo > hi) lo = hi = 0.5 * (lo + hi);
+    if (c[0] > 0)
+      x[0] = lo;
+    else if (c[0] < 0)
+      x[0] = hi;
+    else
+      x[0] = lo > 0 ? lo : (hi < 0 ? hi : 0.0);
+    return true;
+  }
+};
+// linprog<D> for a whole wave (same row permutation, normalisation and return convention)
+template <int D>
+__device__ __noinline__ double linprog_wave(const double *c, int m, const double *A, const double *rhsv,
+                                            double *x, double *work, int *perm) {
+  const int lane = threadIdx.x & 63;
+  for (int j = 0; j < D; ++j) x[j] = 0.0;
+  if (m <= 0) {
+    double mx = 0;
+    for (int j = 0; j < D; ++j) mx = dabs(c[j]) > mx ? dabs(c[j]) : mx;
+    return mx > 0.0 ? -INFINITY : 0.0;
+  }
+  const int M  = m + 2 * D;
+  double   *a  = work;
+  double   *bb = work + LP_MAX_ROWS * D;
+  if (lane == 0) {
+    for (int i = 0; i < 2 * D; ++i)
+      for (int j = 0; j < D; ++j) a[i * D + j] = 0.0;
+    for (int j = 0; j < D; ++j) {
+      a[(2 * j) * D + j]     = 1.0;
+      bb[2 * j]              = LP_BOX;
+      a[(2 * j + 1) * D + j] = -1.0;
+      bb[2 * j + 1]          = LP_BOX;
+    }
+    for (int i = 0; i < m; ++i) perm[i] = i;
+    unsigned long long s = 0x9E3779B97F4A7C15ULL;
+    for (int i = m - 1; i > 0; --i) {
+      s           = s * 6364136223846793005ULL + 1442695040888963407ULL;
+      const int j = (int)((s >> 33) % (unsigned long long)(i + 1));
+      const int t = perm[i];
+      perm[i]     = perm[j];
+      perm[j]     = t;
+    }
+  }
+  wave_lds_sync();
+  for (int i = lane; i < m; i += 64) {
+    const double *src = A + perm[i] * D;
+    const double  rhs = rhsv[perm[i]];
+    double        nn  = 0;
+    for (int j = 0; j < D; ++j) nn += src[j] * src[j];
+    nn          = sogm_det::sqrt_rn(nn);
+    double *dst = a + (2 * D + i) * D;
+    if (nn > 0) {
+      for (int j = 0; j < D; ++j) dst[j] = src[j] / nn;
+      bb[2 * D + i] = rhs / nn;
+    } else {
+      for (int j = 0; j < D; ++j) dst[j] = 0;
+      bb[2 * D + i] = rhs;
+    }
+  }
+  wave_lds_sync();
+  double xs[D];
+  if (!SeidelW<D>::solve(a, bb, M, c, xs, work + LP_MAX_ROWS * (D + 1))) return INFINITY;
+  for (int j = 0; j < D; ++j) x[j] = xs[j];
+  for (int j = 0; j < D; ++j)
+    if (dabs(xs[j]) > 0.99 * LP_BOX) return -INFINITY;
+  double v = 0;
+  for (int j = 0; j < D; ++j) v += c[j] * xs[j];
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------------
 // MVIE (firi.hpp:44-236) — lane 0 only
 // ---------------------------------------------------------------------------------------------
 __device__ inline bool smoothedL1(double mu, double x, double &f, double &df) {
@@ -1285,11 +1462,11 @@ __global__ __launch_bounds__(64) void k_safe_after_opt(const double *__restrict_
     b[q] = -1.0;
   }
   __syncthreads();
-  if (threadIdx.x == 0) {
+  {
     const double c[4] = {0, 0, 0, 0};
     double       x[4];
-    const double v = linprog<4>(c, nA + nB, A, b, x, s_lp, s_perm);
-    if (v == INFINITY || v == -INFINITY) out_safe[a] = 0;  // plain store: every writer writes 0
+    const double v = linprog_wave<4>(c, nA + nB, A, b, x, s_lp, s_perm);  // the whole wave solves the LP
+    if (threadIdx.x == 0 && (v == INFINITY || v == -INFINITY)) out_safe[a] = 0;  // every writer writes 0
   }
 }
 

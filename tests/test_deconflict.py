@@ -124,3 +124,57 @@ def test_replan_with_swarm_applies_deconfliction(pop, orc):
     assert np.array_equal(ok2.cpu().numpy(), ok0)
     P.close()
     m.close()
+
+
+@pytest.mark.gpu
+def test_safe_after_opt_random_lp_cases(pop, orc):
+    """Random overlapping / nearly touching control-point clouds: the bounding-box and candidate-normal
+    pre-tests rarely decide, so the wave-parallel Seidel LP runs; flags must equal the oracle's."""
+    import torch
+    sogm = importlib.import_module("pred-occ-planner_amd.sogm")
+    planner = importlib.import_module("pred-occ-planner_amd.planner")
+    A = 48
+    spec = pop.config.make_spec("parity")
+    rng = np.random.default_rng(77)
+    SogmTrajRecord = pop._abi.SogmTrajRecord
+    recs = (SogmTrajRecord * A)()
+    cpts = np.zeros((A, 16 * 15))
+    npoly = np.zeros(A, np.int32)
+    centre = rng.uniform(-1, 1, (A, 3))
+    for a in range(A):
+        M = int(rng.integers(2, 9))
+        npoly[a] = M
+        # candidate: an elongated random cloud through the origin region
+        R = np.linalg.qr(rng.normal(size=(3, 3)))[0]
+        pts = (rng.normal(size=(5 * M, 3)) * np.array([1.5, 0.15, 0.15])) @ R.T + centre[a] * 0.3
+        cpts[a, :15 * M] = pts.reshape(-1)
+        r = recs[a]
+        r.drone_id, r.n_pieces, r.time_start = a, int(rng.integers(2, 9)), 99.0
+        Rb = np.linalg.qr(rng.normal(size=(3, 3)))[0]
+        off = rng.normal(size=3) * rng.choice([0.05, 0.3, 0.8])
+        pb = (rng.normal(size=(5 * r.n_pieces, 3)) * np.array([1.5, 0.15, 0.15])) @ Rb.T + off
+        for k in range(r.n_pieces):
+            r.duration[k] = 0.4
+        for k in range(15 * r.n_pieces):
+            r.cpts[k] = float(pb.reshape(-1)[k])
+    t_now = np.full(A, 99.5)
+    m = sogm.SogmMap(spec, A)
+    P = planner.SogmPlanner(m, pop.config.make_astar_params(), pop.config.make_planner_params(True),
+                            pop.config.make_qp_settings())
+    ego = np.arange(A, dtype=np.int32)
+    got = P.isSafeAfterOpt(sogm._dev(cpts, np.float64), sogm._dev(npoly, np.int32), sogm._dev(recs), A,
+                           sogm._dev(ego, np.int32), sogm._dev(t_now, np.float64)).cpu().numpy()
+    want = np.array([orc.safe_after_opt(cpts[a], int(npoly[a]), recs, A, a, t_now[a]) for a in range(A)])
+    assert np.array_equal(got, want), (got, want)
+    # pairwise too (one record at a time) so that a single wrong LP cannot hide behind another "unsafe"
+    n_sep = 0
+    for b in range(0, A, 3):
+        one = (SogmTrajRecord * 1)(recs[b])
+        g1 = P.isSafeAfterOpt(sogm._dev(cpts, np.float64), sogm._dev(npoly, np.int32), sogm._dev(one), 1,
+                              sogm._dev(ego, np.int32), sogm._dev(t_now, np.float64)).cpu().numpy()
+        w1 = np.array([orc.safe_after_opt(cpts[a], int(npoly[a]), one, 1, a, t_now[a]) for a in range(A)])
+        assert np.array_equal(g1, w1), (b, g1, w1)
+        n_sep += int(w1.sum())
+    assert 0 < n_sep < A * len(range(0, A, 3))
+    P.close()
+    m.close()

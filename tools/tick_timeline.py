@@ -1,0 +1,14 @@
+"""Timeline of one tick from a rocprofv3 kernel trace (rocpd .db): start offset / duration of every SOGM kernel."""
+import glob, sqlite3, sys
+db = glob.glob(sys.argv[1] + "/**/*.db", recursive=True)[0]
+cur = sqlite3.connect(db).cursor()
+rows = cur.execute("select name, start, end from kernels order by start").fetchall()
+# a tick starts at each k_stamp_cloud
+stamps = [i for i, r in enumerate(rows) if "k_stamp_cloud" in r[0]]
+a, b = stamps[-3], stamps[-2]
+t0 = rows[a][1]
+print(f"tick length {(rows[b][1] - t0) / 1e6:.2f} ms")
+for name, s, e in rows[a:b]:
+    n = name.split("(")[0].split("::")[-1][:28]
+    if (e - s) > 150e3 or "k_" in n:
+        print(f"{n:28s} start {(s - t0) / 1e6:7.2f}  dur {(e - s) / 1e6:7.2f}  end {(e - t0) / 1e6:7.2f}")
