@@ -298,7 +298,7 @@ struct SeidelW<1> {
 };
 // linprog<D> for a whole wave (same row permutation, normalisation and return convention)
 template <int D>
-__device__ __noinline__ double linprog_wave(const double *c, int m, const double *A, const double *rhsv,
+__device__ __forceinline__ double linprog_wave(const double *c, int m, const double *A, const double *rhsv,
                                             double *x, double *work, int *perm) {
   const int lane = threadIdx.x & 63;
   for (int j = 0; j < D; ++j) x[j] = 0.0;
@@ -850,6 +850,56 @@ __device__ bool goalReachable(const double *poly, int m, const double *start, do
   return false;
 }
 
+// whole-wave versions of the two predicates (k_corridor_finalize): same rows, same LPs, solved by linprog_wave
+__device__ bool corridorValidW(const double *polyA, int mA, const double *polyB, int mB,
+                               const SolverScratch &sc) {
+  const int    lane = threadIdx.x & 63;
+  const double c[3] = {0, 0, 0};
+  double       x[3];
+  double      *A = sc.rows, *b = sc.rows + LP_MAX_ROWS * 4;
+  for (int i = lane; i < mA + mB; i += 64) {
+    const double *h = i < mA ? polyA + i * 4 : polyB + (i - mA) * 4;
+    A[i * 3 + 0]    = h[0];
+    A[i * 3 + 1]    = h[1];
+    A[i * 3 + 2]    = h[2];
+    b[i]            = -h[3];
+  }
+  wave_lds_sync();
+  const double v = linprog_wave<3>(c, mA + mB, A, b, x, sc.lp_work, sc.perm);
+  wave_lds_sync();
+  return !(v == INFINITY || v == -INFINITY);
+}
+__device__ bool goalReachableW(const double *poly, int m, const double *start, double *goal,
+                               const SolverScratch &sc) {
+  const int lane = threadIdx.x & 63;
+  if (m <= 0) return true;
+  double mx = -INFINITY;
+  for (int i = 0; i < m; ++i) {
+    const double *h = poly + i * 4;
+    const double  v = dot3(h, goal) + h[3] * 1.0;
+    mx              = v > mx ? v : mx;
+  }
+  if (mx <= 0) return true;
+  double *A = sc.rows, *b = sc.rows + LP_MAX_ROWS * 4;
+  for (int i = lane; i < m; i += 64) {
+    const double *h = poly + i * 4;
+    A[i * 3 + 0]    = h[0];
+    A[i * 3 + 1]    = h[1];
+    A[i * 3 + 2]    = h[2];
+    b[i]            = -h[3];
+  }
+  wave_lds_sync();
+  double c[3] = {-goal[0] + start[0], -goal[1] + start[1], -goal[2] + start[2]};
+  double gmax[3], gmin[3];
+  linprog_wave<3>(c, m, A, b, gmax, sc.lp_work, sc.perm);
+  wave_lds_sync();
+  for (int j = 0; j < 3; ++j) c[j] = goal[j] - start[j];
+  linprog_wave<3>(c, m, A, b, gmin, sc.lp_work, sc.perm);
+  wave_lds_sync();
+  for (int j = 0; j < 3; ++j) goal[j] = 0.5 * (gmax[j] + gmin[j]);
+  return false;
+}
+
 // wave arg-min of (value, index): smaller value wins, ties -> smaller index
 __device__ inline void wave_argmin(double &v, int &idx) {
   for (int d = 32; d >= 1; d >>= 1) {
@@ -1281,7 +1331,9 @@ __global__ __launch_bounds__(64) void k_corridor_finalize(
   double       *s_rows = s_lp + LP_WORK_DOUBLES;
   int          *s_perm = (int *)(s_rows + LP_MAX_ROWS * 5);
   SolverScratch sc{s_lp, s_perm, s_rows, nullptr};
-  if (threadIdx.x != 0) return;
+  // The sequential bookkeeping below is executed by all 64 lanes with identical data (uniform control flow);
+  // the LPs inside are solved by the whole wave, outputs are written by lane 0 / copied lane-parallel.
+  const bool    w0    = threadIdx.x == 0;
   const int     MF    = pp.max_faces;
   const double *polys = ws.polys + (size_t)agent * SOGM_MAX_PIECES * MF * 4;
   const int    *nfs   = ws.seg_nfaces + agent * SOGM_MAX_PIECES;
@@ -1290,9 +1342,11 @@ __global__ __launch_bounds__(64) void k_corridor_finalize(
   const double *sp    = start_pva + agent * 9;
   const int     rl    = route_len[agent];
   int           npoly = 0;
-  for (int i = 0; i < SOGM_MAX_PIECES; ++i) out_nfaces[agent * SOGM_MAX_PIECES + i] = 0;
-  for (int i = 0; i < 6; ++i) out_goal[agent * 6 + i] = 0;
-  out_npoly[agent] = 0;
+  if (w0) {
+    for (int i = 0; i < SOGM_MAX_PIECES; ++i) out_nfaces[agent * SOGM_MAX_PIECES + i] = 0;
+    for (int i = 0; i < 6; ++i) out_goal[agent * 6 + i] = 0;
+    out_npoly[agent] = 0;
+  }
   if (!pp.fake_planner && rl < 2) return;
   if (rl < 1) return;
   // corridors are kept up to the first invalid one (the loop `break`s, baseline.cpp:355-358)
@@ -1302,8 +1356,8 @@ __global__ __launch_bounds__(64) void k_corridor_finalize(
   }
   if (npoly == 0) return;
   for (int i = 0; i + 1 < npoly; ++i) {
-    if (!corridorValid(polys + (size_t)i * MF * 4, nfs[i], polys + (size_t)(i + 1) * MF * 4,
-                       nfs[i + 1], sc)) {
+    if (!corridorValidW(polys + (size_t)i * MF * 4, nfs[i], polys + (size_t)(i + 1) * MF * 4,
+                        nfs[i + 1], sc)) {
       if (i < 2) return;
       npoly = pp.fake_planner ? i + 1 : i;
       break;
@@ -1318,10 +1372,10 @@ __global__ __launch_bounds__(64) void k_corridor_finalize(
   }
   bool do_scan = true;
   if (!pp.fake_planner)
-    do_scan = !goalReachable(polys + (size_t)(npoly - 1) * MF * 4, nfs[npoly - 1], sp, gpos, sc);
+    do_scan = !goalReachableW(polys + (size_t)(npoly - 1) * MF * 4, nfs[npoly - 1], sp, gpos, sc);
   if (do_scan) {
     for (int it = npoly - 1; it != 0; --it) {
-      if (goalReachable(polys + (size_t)it * MF * 4, nfs[it], sp, gpos, sc)) {
+      if (goalReachableW(polys + (size_t)it * MF * 4, nfs[it], sp, gpos, sc)) {
         npoly         = it + 1;
         const int idx = npoly - 1;
         for (int k = 0; k < 3; ++k) {
@@ -1333,16 +1387,18 @@ __global__ __launch_bounds__(64) void k_corridor_finalize(
     }
   }
   for (int i = 0; i < npoly; ++i) {
-    out_nfaces[agent * SOGM_MAX_PIECES + i] = nfs[i];
+    if (w0) out_nfaces[agent * SOGM_MAX_PIECES + i] = nfs[i];
     const double *src = polys + (size_t)i * MF * 4;
     double       *dst = out_polys + ((size_t)agent * SOGM_MAX_PIECES + i) * MF * 4;
-    for (int k = 0; k < nfs[i] * 4; ++k) dst[k] = src[k];
+    for (int k = threadIdx.x; k < nfs[i] * 4; k += 64) dst[k] = src[k];
   }
-  for (int k = 0; k < 3; ++k) {
-    out_goal[agent * 6 + k]     = gpos[k];
-    out_goal[agent * 6 + 3 + k] = gvel[k];
+  if (w0) {
+    for (int k = 0; k < 3; ++k) {
+      out_goal[agent * 6 + k]     = gpos[k];
+      out_goal[agent * 6 + 3 + k] = gvel[k];
+    }
+    out_npoly[agent] = npoly;
   }
-  out_npoly[agent] = npoly;
 }
 
 size_t corridor_segment_lds(int pc_capacity) {
