@@ -681,17 +681,20 @@ __device__ __forceinline__ bool maxVolInsEllipsoid(const double *hPoly, int M, d
   double   *Alp  = sc.rows;                    // M x 4
   double   *blp  = sc.rows + LP_MAX_ROWS * 4;  // M
   double   *sh   = sc.lm + 2 * 18 * 9;         // 16 doubles of hand-off space after the history
+  // deepest interior point: rows one per lane, LP solved by the whole wave
+  for (int i = lane; i < M; i += 64) {
+    const double *h  = hPoly + i * 4;
+    const double  hn = sogm_det::sqrt_rn((h[0] * h[0] + h[1] * h[1]) + h[2] * h[2]);
+    for (int j = 0; j < 3; ++j) Alp[i * 4 + j] = h[j] / hn;
+    Alp[i * 4 + 3] = 1.0;
+    blp[i]         = -h[3] / hn;
+  }
+  wave_lds_sync();
+  const double clp[4] = {0, 0, 0, -1.0};
+  double       xlp[4];
+  const double maxdepth = -linprog_wave<4>(clp, M, Alp, blp, xlp, sc.lp_work, sc.perm);
+  wave_lds_sync();
   if (lane == 0) {
-    for (int i = 0; i < M; ++i) {
-      const double *h  = hPoly + i * 4;
-      const double  hn = sogm_det::sqrt_rn((h[0] * h[0] + h[1] * h[1]) + h[2] * h[2]);
-      for (int j = 0; j < 3; ++j) Alp[i * 4 + j] = h[j] / hn;
-      Alp[i * 4 + 3] = 1.0;
-      blp[i]         = -h[3] / hn;
-    }
-    const double clp[4] = {0, 0, 0, -1.0};
-    double       xlp[4];
-    const double maxdepth = -linprog<4>(clp, M, Alp, blp, xlp, sc.lp_work, sc.perm);
     const bool   ok = !(!(maxdepth > 0.0) || maxdepth == INFINITY || maxdepth == -INFINITY);
     sh[12]          = ok ? 1.0 : 0.0;
     if (ok) {
@@ -1295,9 +1298,9 @@ __global__ __launch_bounds__(64) void k_corridor_segment(
     nf       = pp.max_faces;
     overflow = 1;
   }
-  if (lane == 0) {
+  {
     const double path[3] = {s_w[3] - s_w[0], s_w[4] - s_w[1], s_w[5] - s_w[2]};
-    for (int f = 0; f < nf; ++f) {
+    for (int f = lane; f < nf; f += 64) {  // one face per lane
       double      *h   = s_poly + f * 4;
       const double nrm = sogm_det::sqrt_rn(dot3(h, h));
       if (pp.fake_planner) {
@@ -1307,9 +1310,14 @@ __global__ __launch_bounds__(64) void k_corridor_segment(
       }
       h[3] += nrm * pp.shrink_size;
     }
-    const bool valid = corridorValid(s_poly, nf, nullptr, 0, sc);
-    double    *out   = ws.polys + (size_t)slot * pp.max_faces * 4;
-    for (int i = 0; i < nf * 4; ++i) out[i] = s_poly[i];
+  }
+  wave_lds_sync();
+  const bool valid = corridorValidW(s_poly, nf, nullptr, 0, sc);  // whole wave
+  {
+    double *out = ws.polys + (size_t)slot * pp.max_faces * 4;
+    for (int i = lane; i < nf * 4; i += 64) out[i] = s_poly[i];
+  }
+  if (lane == 0) {
     ws.seg_nfaces[slot] = nf;
     ws.seg_state[slot]  = overflow ? -3 : (valid ? 1 : 0);
     ws.seg_npts[slot]   = N;
