@@ -122,7 +122,14 @@ __global__ __launch_bounds__(256) void k_stamp_cloud(GridGeom g, void *__restric
     const float x = px - p0, y = py - p1, z = pz - p2;
     if (!g.in_range(x, y, z)) continue;
     const int v = g.voxel_of(x, y, z);
-    cell_st(base, v, 1.0F, g.half);  // slice 0 (:114)
+    // slice 0 (:114).  The cloud lattice (0.10 m) is finer than the voxels (0.15 m): several points land in
+    // one voxel, and everything below depends on the voxel only — the first point to mark a voxel of the
+    // freshly cleared slice does the work, the others stop here (fp32 cells; fp16 cells skip the shortcut).
+    if (!g.half) {
+      if (atomicExch(reinterpret_cast<float *>(base) + v, 1.0F) == 1.0F) continue;
+    } else {
+      cell_st(base, v, 1.0F, g.half);
+    }
     // The reference then sweeps the occupied voxels of slice 0 (:121-125); every cloud point in
     // range marks exactly one such voxel and the future marks depend only on the voxel, so the
     // per-point form produces the same set of (idempotent) stores.
