@@ -40,7 +40,7 @@ struct GmAgent {
   int    in_map, do_rays, has_first_depth, raycast_num, dedup;
   int    n_touched, n_active, n_valid;
   int    converged, final_round, changed[GM_ROUNDS];
-  int    err_unconverged, err_touched;
+  int    err_unconverged, err_touched, err_paths;
   int    local_updated;
 };
 
@@ -60,6 +60,12 @@ struct GmDev {
   int     *end_vox;   // [A][n_samples]  (-1: sample dropped)
   int     *stop[2];   // [A][n_samples] steps walked in the previous / current round
   uint8_t *active;    // [A][n_samples]
+  // de-duplicated (active) rays: compact list + their voxel paths, written once per frame
+  int      act_cap, path_max;
+  int     *act_ray;   // [A][act_cap] sample index of each active ray
+  int     *path;      // [A][path_max][act_cap] voxel address of step k (-1 outside the arrays), slot-minor
+  int     *plen;      // [A][act_cap] steps of the full path
+  int     *astop[2];  // [A][act_cap] arrivals of the previous / current round
 };
 
 __device__ inline unsigned long long d2key(double d) {
@@ -291,11 +297,52 @@ __global__ __launch_bounds__(256) void k_gm_select(GmDev d) {
   d.active[si]  = act ? 1 : 0;
   d.stop[0][si] = -1;
   d.stop[1][si] = -1;
-  if (act) atomicAdd(&s.n_active, 1);
+  if (act) {
+    const int slot = atomicAdd(&s.n_active, 1);
+    if (s.dedup) {  // the fixed-point rounds work on the compact list (order irrelevant: ray ids carry the order)
+      if (slot < d.act_cap) {
+        d.act_ray[(size_t)a * d.act_cap + slot]  = i;
+        d.astop[0][(size_t)a * d.act_cap + slot] = -1;
+        d.astop[1][(size_t)a * d.act_cap + slot] = -1;
+      } else {
+        atomicAdd(&s.err_paths, 1);
+      }
+    }
+  }
 }
 
-// one fixed-point round: walk each active ray until the first voxel owned (previous round) by an earlier
-// ray; publish this round's arrivals
+// voxel path of every active ray, once per frame: the DDA does not depend on the owners
+__global__ __launch_bounds__(256) void k_gm_paths(GmDev d) {
+  const int a = blockIdx.y;
+  GmAgent  &s = d.ag[a];
+  if (!s.do_rays || !s.dedup) return;
+  const int slot = blockIdx.x * 256 + threadIdx.x;
+  const int na   = s.n_active < d.act_cap ? s.n_active : d.act_cap;
+  if (slot >= na) return;
+  const int    i  = d.act_ray[(size_t)a * d.act_cap + slot];
+  const size_t si = (size_t)a * d.n_samples + i;
+  const double st[3] = {d.pt[si * 3] / d.res, d.pt[si * 3 + 1] / d.res, d.pt[si * 3 + 2] / d.res};
+  const double en[3] = {s.cam[0] / d.res, s.cam[1] / d.res, s.cam[2] / d.res};
+  GmRay        rc;
+  rc.set(st, en);
+  int *path = d.path + (size_t)a * d.path_max * d.act_cap + slot;
+  int  c[3], k = 0;
+  while (rc.step(c)) {
+    if (k < d.path_max) path[(size_t)k * d.act_cap] = gm_cell_addr(d, c);
+    ++k;
+  }
+  if (k > d.path_max) {
+    atomicAdd(&s.err_paths, 1);
+    k = d.path_max;
+  }
+  d.plen[(size_t)a * d.act_cap + slot] = k;
+}
+
+// One fixed-point round over the compact list.  A ray's path is fixed, so a round is: fetch the previous
+// round's owners of 16 path voxels at a time (independent loads, staged through LDS: "ray segments"), find
+// the first voxel owned by an earlier ray, then publish this round's arrivals with fire-and-forget atomics.
+// Two memory round trips per segment instead of one per voxel.
+#define GM_SEG 16
 __global__ __launch_bounds__(256) void k_gm_walk(GmDev d, int round) {
   const int a = blockIdx.y;
   GmAgent  &s = d.ag[a];
@@ -303,29 +350,48 @@ __global__ __launch_bounds__(256) void k_gm_walk(GmDev d, int round) {
   // converged = an earlier round r >= 1 changed no stop position (changed[] of rounds that never ran stays 0,
   // so "the previous round changed nothing" identifies every round after the fixed point as well)
   if (round >= 2 && s.changed[round - 1] == 0) return;
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= d.n_samples) return;
-  const size_t si = (size_t)a * d.n_samples + i;
-  if (!d.active[si]) return;
-  const double st[3] = {d.pt[si * 3] / d.res, d.pt[si * 3 + 1] / d.res, d.pt[si * 3 + 2] / d.res};
-  const double en[3] = {s.cam[0] / d.res, s.cam[1] / d.res, s.cam[2] / d.res};
-  GmRay        rc;
-  rc.set(st, en);
+  const int slot = blockIdx.x * 256 + threadIdx.x;
+  const int na   = s.n_active < d.act_cap ? s.n_active : d.act_cap;
+  if (blockIdx.x * 256 >= na) return;
+  __shared__ int                s_addr[GM_SEG][256];
+  __shared__ unsigned long long s_own[GM_SEG][256];
+  const bool on = slot < na;
+  const int  i    = on ? d.act_ray[(size_t)a * d.act_cap + slot] : 0;
+  const int  len  = on ? d.plen[(size_t)a * d.act_cap + slot] : 0;
+  const int *path = d.path + (size_t)a * d.path_max * d.act_cap + slot;
   const unsigned long long *prev = d.own[(round + 1) & 1] + (size_t)a * d.N;
   unsigned long long       *cur  = d.own[round & 1] + (size_t)a * d.N;
-  int c[3], steps = 0;
-  while (rc.step(c)) {
-    ++steps;
-    const int ad = gm_cell_addr(d, c);
-    if (ad < 0) continue;
-    atomicMax(&cur[ad], gm_key(s.raycast_num, round + 1, i));
-    if (round > 0) {
-      const int o = gm_key_ray(prev[ad], s.raycast_num, round);
-      if (o >= 0 && o < i) break;
+  const unsigned long long  key  = gm_key(s.raycast_num, round + 1, i);
+  int arrivals = len;  // steps the ray arrives at (the stopping voxel included)
+  for (int base = 0; base < len; base += GM_SEG) {
+#pragma unroll
+    for (int q = 0; q < GM_SEG; ++q) s_addr[q][threadIdx.x] = base + q < len ? path[(size_t)(base + q) * d.act_cap] : -1;
+#pragma unroll
+    for (int q = 0; q < GM_SEG; ++q) {
+      const int ad          = s_addr[q][threadIdx.x];
+      s_own[q][threadIdx.x] = (round > 0 && ad >= 0) ? prev[ad] : 0ull;
+    }
+    int stop = -1;
+#pragma unroll
+    for (int q = 0; q < GM_SEG; ++q) {
+      if (stop < 0 && base + q < len && s_addr[q][threadIdx.x] >= 0) {
+        const int o = gm_key_ray(s_own[q][threadIdx.x], s.raycast_num, round);
+        if (round > 0 && o >= 0 && o < i) stop = q;
+      }
+    }
+    const int last = stop >= 0 ? stop : GM_SEG - 1;
+#pragma unroll
+    for (int q = 0; q < GM_SEG; ++q)
+      if (q <= last && base + q < len && s_addr[q][threadIdx.x] >= 0) atomicMax(&cur[s_addr[q][threadIdx.x]], key);
+    if (stop >= 0) {
+      arrivals = base + stop + 1;
+      break;
     }
   }
-  if (steps != d.stop[(round + 1) & 1][si]) atomicAdd(&s.changed[round], 1);
-  d.stop[round & 1][si] = steps;
+  if (on) {
+    if (arrivals != d.astop[(round + 1) & 1][(size_t)a * d.act_cap + slot]) atomicAdd(&s.changed[round], 1);
+    d.astop[round & 1][(size_t)a * d.act_cap + slot] = arrivals;
+  }
 }
 // first round r >= 1 that changed nothing = the fixed point (its owners equal the previous round's)
 __device__ inline int gm_final_round(const GmAgent &s) {
@@ -601,6 +667,18 @@ int sogm_gridmap_create(const SogmGridMapParams *P, int n_agents, int device, so
   bad |= alloc((void **)&d.stop[0], A * NS * sizeof(int));
   bad |= alloc((void **)&d.stop[1], A * NS * sizeof(int));
   bad |= alloc((void **)&d.active, A * NS);
+  d.act_cap  = (int)(NS / 4 > 4096 ? NS / 4 : 4096);  // rays left after the ray-end de-duplication
+  d.path_max = 192;                                   // DDA steps of the longest ray (max_ray_length / resolution * 3)
+  {
+    const double steps = 3.0 * p.max_ray_length / p.resolution + 8.0;
+    if (steps > d.path_max) d.path_max = (int)steps;
+  }
+  const size_t AC = d.act_cap;
+  bad |= alloc((void **)&d.act_ray, A * AC * sizeof(int));
+  bad |= alloc((void **)&d.path, A * AC * (size_t)d.path_max * sizeof(int));
+  bad |= alloc((void **)&d.plen, A * AC * sizeof(int));
+  bad |= alloc((void **)&d.astop[0], A * AC * sizeof(int));
+  bad |= alloc((void **)&d.astop[1], A * AC * sizeof(int));
   if (bad) {
     set_error("sogm_gridmap_create: hipMalloc", hipGetLastError());
     sogm_gridmap_destroy(g);
@@ -644,8 +722,10 @@ int sogm_gridmap_update(sogm_gridmap *g, const uint16_t *depth, const double *ca
   hipLaunchKernelGGL(k_gm_begin, ga, dim3(64), 0, st, d, cam_pos, cam_rot, out_updated);
   hipLaunchKernelGGL(k_gm_project, gs, dim3(256), 0, st, d, depth);
   hipLaunchKernelGGL(k_gm_select, gs, dim3(256), 0, st, d);
+  const dim3 gact((d.act_cap + 255) / 256, A);
+  hipLaunchKernelGGL(k_gm_paths, gact, dim3(256), 0, st, d);
   for (int r = 0; r < GM_ROUNDS; ++r) {
-    hipLaunchKernelGGL(k_gm_walk, gs, dim3(256), 0, st, d, r);
+    hipLaunchKernelGGL(k_gm_walk, gact, dim3(256), 0, st, d, r);
   }
   hipLaunchKernelGGL(k_gm_count, gs, dim3(256), 0, st, d);
   hipLaunchKernelGGL(k_gm_bounds, ga, dim3(64), 0, st, d, out_updated);
@@ -687,7 +767,7 @@ int sogm_gridmap_download(sogm_gridmap *g, int agent, double *occ, int8_t *infla
       counters[0] = s.n_valid;
       counters[1] = s.n_active;
       counters[2] = s.final_round + 1;
-      counters[3] = s.err_unconverged + s.err_touched;
+      counters[3] = s.err_unconverged + s.err_touched + s.err_paths;
     }
   }
   return SOGM_OK;
