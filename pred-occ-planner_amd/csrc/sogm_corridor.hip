@@ -403,6 +403,9 @@ __device__ inline double bfly_sum(double v) {
   return v;
 }
 
+#ifdef SOGM_PROFILE_MVIE
+__device__ unsigned long long g_mvie_prof[2];  // profiling build only: ticks (100 MHz) and calls of costMVIE
+#endif
 // one face's contribution to cost and gradient (firi.hpp:105-122)
 __device__ inline void mvie_face(const double a[3], const double L[3][3], const double *p,
                                  double smoothEps, double acc[10]) {
@@ -491,7 +494,16 @@ __device__ __forceinline__ int lineSearchLO(const MvieData &D, double *x, double
   const double finit = f, dgtest = f_dec * dginit, dstest = s_curv * dginit;
   while (true) {
     for (int i = 0; i < 9; ++i) x[i] = xp[i] + stp * s[i];
+#ifdef SOGM_PROFILE_MVIE
+    const long long tc0 = wall_clock64();
+#endif
     f = costMVIE(D, x, g);
+#ifdef SOGM_PROFILE_MVIE
+    if ((threadIdx.x & 63) == 0) {
+      atomicAdd(&g_mvie_prof[0], (unsigned long long)(wall_clock64() - tc0));
+      atomicAdd(&g_mvie_prof[1], 1ull);
+    }
+#endif
     ++count;
     if (f != f || f == INFINITY || f == -INFINITY) return -3;
     if (f > finit + stp * dgtest) {
@@ -1577,3 +1589,11 @@ extern "C" int sogm_debug_corridor_occupancy(int pc_capacity) {
   return n;
 }
 
+#ifdef SOGM_PROFILE_MVIE
+extern "C" int sogm_debug_mvie_prof(unsigned long long *out2) {
+  if (hipMemcpyFromSymbol(out2, HIP_SYMBOL(sogm::g_mvie_prof), 16) != hipSuccess) return -1;
+  unsigned long long z[2] = {0, 0};
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(sogm::g_mvie_prof), z, 16);
+  return 0;
+}
+#endif

@@ -35,3 +35,10 @@ for name, col in (("points", 5), ("firi0 done", 6), ("mvie total", 7), ("  lbfgs
     print(f"{name:14s} us: max {us(d[:, col].max()):9.1f}  mean {us(d[:, col].mean()):9.1f}  p90 {us(np.percentile(d[:, col], 90)):9.1f}")
 i = np.argmax(d[:, 10])
 print("slowest segment:", d[i])
+
+if hasattr(lib, "sogm_debug_mvie_prof"):
+    pr = np.zeros(2, np.uint64)
+    lib.sogm_debug_mvie_prof.argtypes = [C.c_void_p]
+    lib.sogm_debug_mvie_prof(pr.ctypes.data)
+    if pr[1]:
+        print(f"costMVIE (line search): {int(pr[1])} calls, mean {pr[0] / pr[1] / 100.0:.2f} us")
