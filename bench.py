@@ -161,7 +161,8 @@ def main():
         pass
     achieved = grid_bytes / (avg[0] * 1e-3) / 1e9
     out = {
-        "metric": "replans/sec (SOGM update + A* + corridors + QP), aggregate over all agents",
+        "metric": "replans/sec (SOGM update + QP: full replan = SOGM update + A* + corridors + QP + deconfliction), "
+                  f"{sw.A_loc}-agent batch per GPU, {spec.L}x{spec.W}x{spec.H}x{spec.T} voxel grid; aggregate over all agents",
         "value": sw.A_tot * args.steps / dt,
         "unit": "replans/s",
         "n_gpus": world,
@@ -179,6 +180,7 @@ def main():
                    "cloud_points": int(sw.scene["cloud"].shape[0]), "cloud_points_scanned": sw.cloud_points, "cylinders": int(len(sw.scene["cylinders"])),
                    "replans_ok_fraction": n_ok / float(sw.A_loc * args.steps),
                    "parallelism": f"agents sharded x{world}, 1 all-gather/tick"},
+        "replans_per_s_per_agent": sw.A_tot * args.steps / dt / sw.A_tot,
         "stage_ms": {"clear": avg[0], "stamp": avg[1], "splat": avg[2], "astar": avg[3], "corridor": avg[4],
                      "qp": avg[5]},
         "roofline": {"bound": "hbm", "kernel": "k_clear_slabs (SOGM voxel update)", "achieved": achieved,
