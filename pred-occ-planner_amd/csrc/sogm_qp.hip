@@ -33,6 +33,8 @@
 #include "../../include/sogm_detmath.h"
 #include "sogm_planner.hpp"
 
+#include <type_traits>
+
 namespace sogm {
 namespace {
 
@@ -67,26 +69,34 @@ __device__ inline double block_max(double v, double *s_red) {
   return dmax(dmax(s_red[0], s_red[1]), dmax(s_red[2], s_red[3]));
 }
 
-// Row storage (LDS or HBM scratch)
+// Row storage (LDS or HBM scratch).  The "hot" arrays are the only row data the register-resident ADMM
+// iteration touches; they always live in LDS on that path, the "cold" rest may sit in HBM scratch.
 struct Rows {
   // general rows [0, G)
   double *gval;  // [G][6]
   double *gl, *gu, *grho, *gE, *gz, *gy, *gdy;
   double *grinv;  // [G] 1 / rho (OSQP rho_inv_vec)
+  double *gw;     // [G] rho z - y                                                    (hot)
   int    *gcol;  // [G][6]
   int    *cidx;  // CSC entries over general rows: row * 8 + slot, row-sorted inside a column
   // safety rows [0, S):  s = off_i + 5 * face + k ; columns i*15 + k*3 + {0,1,2}
-  double *sval;  // [S][3]
+  double *sval;  // [S][3]                                                             (hot)
   double *su, *sE, *sz, *sy, *sdy;
-  double *sw;   // [S] rho z - y (refreshed by the row update, consumed by the next A^T product)
+  double *sw;   // [S] rho z - y (refreshed by the row update, consumed by the next A^T product)   (hot)
   int    *sc0;  // [S] first column of the row's control point
 };
 
-__host__ __device__ inline size_t rows_bytes(int G, int S) {
-  return (size_t)G * (QP_ELL * 8 + 8 * 8 + QP_ELL * 4 + QP_ELL * 4) + (size_t)S * (3 * 8 + 6 * 8 + 4) + 64;
+__host__ __device__ inline size_t rows_hot_bytes(int G, int S) { return ((size_t)S * 4 + G) * 8; }
+__host__ __device__ inline size_t rows_cold_bytes(int G, int S) {
+  return (size_t)G * (QP_ELL * 8 + 8 * 8 + QP_ELL * 4 + QP_ELL * 4) + (size_t)S * (5 * 8 + 4) + 64;
 }
-__device__ inline void carve_rows(Rows &R, char *base, int G, int S) {
-  double *d = (double *)base;
+__host__ __device__ inline size_t rows_bytes(int G, int S) { return rows_hot_bytes(G, S) + rows_cold_bytes(G, S); }
+__device__ inline void carve_rows(Rows &R, char *hot, char *cold, int G, int S) {
+  double *h = (double *)hot;
+  R.sval = h;  h += (size_t)S * 3;
+  R.sw = h;    h += S;
+  R.gw = h;
+  double *d = (double *)cold;
   R.gval = d;  d += (size_t)G * QP_ELL;
   R.gl = d;    d += G;
   R.gu = d;    d += G;
@@ -96,13 +106,11 @@ __device__ inline void carve_rows(Rows &R, char *base, int G, int S) {
   R.gy = d;    d += G;
   R.gdy = d;   d += G;
   R.grinv = d; d += G;
-  R.sval = d;  d += (size_t)S * 3;
   R.su = d;    d += S;
   R.sE = d;    d += S;
   R.sz = d;    d += S;
   R.sy = d;    d += S;
   R.sdy = d;   d += S;
-  R.sw = d;    d += S;
   int *q = (int *)d;
   R.gcol = q;  q += (size_t)G * QP_ELL;
   R.sc0 = q;   q += S;
@@ -118,6 +126,13 @@ __device__ inline double dpp_quad_t(double v) {
   return __hiloint2double(hi, lo);
 }
 #define dpp_quad(v, ctrl) dpp_quad_t<ctrl>(v)
+
+// Opaque copy of a lane index: addresses derived from it inside a loop are recomputed there (one VALU add)
+// instead of being hoisted into dozens of long-lived address registers that spill to scratch.
+__device__ inline int launder(int v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
 
 __device__ inline double &KB(double *Kb, int i, int j) { return Kb[i * (QP_BW + 1) + (i - j)]; }
 
@@ -187,10 +202,15 @@ __global__ __launch_bounds__(256) void k_qp(SogmPlannerParams pp, SogmQpSettings
   const size_t head =
       ((size_t)n * (QP_BW + 1) + (size_t)M * 225 * (use_blocks ? 3 : 1)) * sizeof(double);
   const bool rows_in_lds = head + rows_bytes(G, S) <= (size_t)ws.dyn_lds_bytes;
+  // Register-resident iteration: one general row and up to four safety rows per lane, K^-1 rows in
+  // registers; needs only the hot row arrays in LDS.
+  const bool fast = use_blocks && G <= 256 && S <= 1024 &&
+                    head + rows_hot_bytes(G, S) <= (size_t)ws.dyn_lds_bytes;
   // The solver body is instantiated twice (forced inline): once with every row pointer derived from
   // the LDS array — so the compiler emits ds_read/ds_write instead of flat accesses — and once for
   // the HBM-scratch fallback.
-  auto body = [&](const Rows &R) __attribute__((always_inline)) {
+  auto body = [&](const Rows &R, auto fast_tag) __attribute__((always_inline)) {
+  constexpr bool FAST = decltype(fast_tag)::value;  // compile-time: the two iterations never share a loop
   const double *sp   = start_pva + agent * 9;
   const double *gp   = goal_pv + agent * 6;
   const double  tau  = pp.corridor_tau;  // time_alloc: every piece = corridor_tau (baseline.cpp:411)
@@ -448,19 +468,17 @@ __global__ __launch_bounds__(256) void k_qp(SogmPlannerParams pp, SogmQpSettings
   // ---- helpers -----------------------------------------------------------------------------------
   double rho_cur = qs.rho;  // safety rows are one-sided inequalities: their rho is rho_cur itself
   double rinv_cur = 1.0 / rho_cur;
-  // Register-resident inverse factor (M <= 8).  With X = G^-1 (block lower triangular), lane rho = (bi, rc)
-  // keeps ROW rho of X in slots j <= bi (row part inside block column j), COLUMN rho of X in slots
-  // i' > bi (column part inside block row i') and the diagonal block's column part in slot 8, so the
-  // per-iteration solve x = X^T (X rhs) is two register mat-vecs with no dependency chain at all.
-  // A row/column pair is 135 doubles — more than one lane's VGPR file — so two adjacent lanes share
-  // it: lane h = tid & 1 keeps entries k = 8 h .. 8 h + 7 of every 15-entry part (72 doubles = 144
-  // VGPRs) and the two partial dot products meet through one DPP exchange.
-  double    xr[9][8] = {};
-  // Row rho of K^-1 = X^T X, columns 60 hh .. 60 hh + 59 (zero beyond n), built from xr after every
-  // factorisation: the per-iteration solve is then ONE register mat-vec and one barrier.
+  // Row rho of K^-1 = X^T X (X = G^-1, block lower triangular), columns 60 hh .. 60 hh + 59 (zero beyond n),
+  // rebuilt after every factorisation: the per-iteration solve is ONE register mat-vec and one barrier.
+  // A row is 120 doubles — more than one lane's VGPR file — so two adjacent lanes share it and the two
+  // partial dot products meet through one DPP exchange.
   double    kinv[60] = {};
-  const int rho_l = tid >> 1, hh = tid & 1, bi = rho_l / 15, rc = rho_l % 15, k0 = hh * 8;
+  const int rho_l = tid >> 1, hh = tid & 1;
   auto   set_rho = [&]() {
+    // lane ids re-derived from an opaque copy: nothing in here is hoisted out of the ADMM loop
+    const int tid = launder((int)threadIdx.x), lane = tid & 63, wave = tid >> 6;
+    (void)lane;
+    (void)wave;
     for (int r = tid; r < G; r += 256) {
       const double lo = R.gl[r], hi = R.gu[r];
       double       v;
@@ -479,6 +497,14 @@ __global__ __launch_bounds__(256) void k_qp(SogmPlannerParams pp, SogmQpSettings
   // K band = P + sigma I + A^T diag(rho) A (rows in global row order: general, then safety),
   // then banded Cholesky in place
   auto factor = [&]() __attribute__((always_inline)) -> bool {
+    // lane ids re-derived from an opaque copy: nothing in here is hoisted out of the ADMM loop
+    const int tid = launder((int)threadIdx.x), lane = tid & 63, wave = tid >> 6;
+    (void)lane;
+    (void)wave;
+    const int rho_l = tid >> 1, hh = tid & 1, bi = rho_l / 15, rc = rho_l % 15, k0 = hh * 8;
+    (void)bi;
+    (void)rc;
+    (void)k0;
     for (int e = tid; e < n * (QP_BW + 1); e += 256) {
       const int i = e / (QP_BW + 1), dlt = e % (QP_BW + 1), j = i - dlt;
       double    s = 0.0;
@@ -577,34 +603,15 @@ __global__ __launch_bounds__(256) void k_qp(SogmPlannerParams pp, SogmQpSettings
         if (e < M * 225) s_Kb[e] = wv[q];
       }
       __syncthreads();
+      // Row rho of X lives in registers only while K^-1 is built: lane h = tid & 1 keeps entries
+      // k = 8 h .. 8 h + 7 of every 15-entry block part.
+      double xr[8][8];
+#pragma unroll
+      for (int jb = 0; jb < 8; ++jb)
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) xr[jb][kk] = 0.0;
       if (tid < 2 * n) {
         const double *s_W = s_Kb;
-        // column rho of X, block row by block row:  v <- -W_i' v
-        double v[15];
-#pragma unroll
-        for (int k = 0; k < 15; ++k) v[k] = s_Ginv[bi * 225 + k * 15 + rc];
-#pragma unroll
-        for (int kk = 0; kk < 8; ++kk) xr[8][kk] = hh ? (kk < 7 ? v[8 + kk] : 0.0) : v[kk];
-#pragma unroll
-        for (int ip = 1; ip < 8; ++ip) {
-          if (ip < M) {
-            const double *Wb = s_W + ip * 225;
-            double        nv[15];
-#pragma unroll
-            for (int r = 0; r < 15; ++r) {
-              double acc = 0.0;
-#pragma unroll
-              for (int k = 0; k < 15; ++k) acc += Wb[r * 15 + k] * v[k];
-              nv[r] = -acc;
-            }
-            if (ip > bi) {
-#pragma unroll
-              for (int r = 0; r < 15; ++r) v[r] = nv[r];
-#pragma unroll
-              for (int kk = 0; kk < 8; ++kk) xr[ip][kk] = hh ? (kk < 7 ? nv[8 + kk] : 0.0) : nv[kk];
-            }
-          }
-        }
         // row rho of X, block column by block column (right to left):  t <- -t W_j
         double t[15];
 #pragma unroll
@@ -682,9 +689,19 @@ __global__ __launch_bounds__(256) void k_qp(SogmPlannerParams pp, SogmQpSettings
       {
         const bool    on  = tid < 2 * n;
         const double *rhs = s_xt + 60 * hh;
-        double        acc = 0.0;
+        double        acc = 0.0, acc1 = 0.0;  // two chains: a dependent fp64 FMA stalls a lone wave
 #pragma unroll
-        for (int kk = 0; kk < 60; ++kk) acc = __builtin_fma(kinv[kk], rhs[kk], acc);
+        for (int c0 = 0; c0 < 60; c0 += 20) {
+          double v[20];  // 10 ds_read_b128 in flight per batch
+#pragma unroll
+          for (int kk = 0; kk < 20; ++kk) v[kk] = rhs[c0 + kk];
+#pragma unroll
+          for (int kk = 0; kk < 20; kk += 2) {
+            acc  = __builtin_fma(kinv[c0 + kk], v[kk], acc);
+            acc1 = __builtin_fma(kinv[c0 + kk + 1], v[kk + 1], acc1);
+          }
+        }
+        acc += acc1;
         acc += dpp_quad(acc, 0xB1);  // partner lane tid ^ 1
         if (on && hh == 0) s_cn[rho_l] = acc;
       }
@@ -722,6 +739,10 @@ __global__ __launch_bounds__(256) void k_qp(SogmPlannerParams pp, SogmQpSettings
   };
   // residual norms (unscaled), results in s_sc: 0 pr, 1 nAx, 2 nz, 3 dr, 4 nPx, 5 nAty, 6 nq(=0)
   auto residuals = [&]() {
+    // lane ids re-derived from an opaque copy: nothing in here is hoisted out of the ADMM loop
+    const int tid = launder((int)threadIdx.x), lane = tid & 63, wave = tid >> 6;
+    (void)lane;
+    (void)wave;
     double pr = 0, nAx = 0, nz = 0;
     for (int r = tid; r < G; r += 256) {
       double s = 0;
@@ -779,10 +800,120 @@ __global__ __launch_bounds__(256) void k_qp(SogmPlannerParams pp, SogmQpSettings
     __syncthreads();
   };
 
+  // ---- register-resident row / column state of the fast iteration ------------------------------------
+  // Row roles: general row r = tid, safety rows s = tid + 256 u (u < 4).  Column role: lane pair
+  // (j = tid >> 1, hh = tid & 1) shares column j — its K^-1 row, its x_j and the A^T w product, whose
+  // entries (<= 7 general rows, nface safety rows) alternate between the two lanes.
+  double *const h_sv = (double *)(qp_smem + head);  // == R.sval / R.sw / R.gw when fast, typed as LDS
+  double *const h_sw = h_sv + (size_t)S * 3;
+  double *const h_gw = h_sw + S;
+  double gv[QP_ELL], g_rho = 1.0, g_rinv = 1.0, g_lo = 0.0, g_hi = 0.0, g_z = 0.0, g_y = 0.0;
+  int    gc[QP_ELL];
+  double sv[4][3], s_hi[4], s_zr[4], s_yr[4];
+  int    s_c[4];
+  double cv[4], xj = 0.0;
+  int    cr[4];
+#pragma unroll
+  for (int k = 0; k < QP_ELL; ++k) {
+    gv[k] = 0.0;
+    gc[k] = 0;
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    sv[u][0] = sv[u][1] = sv[u][2] = 0.0;
+    s_hi[u] = s_zr[u] = s_yr[u] = 0.0;
+    s_c[u]  = 0;
+    cv[u]   = 0.0;
+    cr[u]   = 0;
+  }
+  const bool grow = tid < G, ccol = tid < 2 * n;
+  int        fj_sv = 0, fj_sw = 0, fj_n = 0;  // this lane's faces of column j: f = hh + 2 i, i < fj_n
+  // Both loaders assign every variable unconditionally (clamped index + select, no branch): the state is then
+  // dead across a refactorisation, which needs the whole register file.
+  auto fast_load = [&]() __attribute__((always_inline)) {
+    const int t  = launder(tid);
+    const int tg = grow ? t : 0;
+#pragma unroll
+    for (int k = 0; k < QP_ELL; ++k) {
+      const int    c = R.gcol[(size_t)tg * QP_ELL + k];
+      const double v = R.gval[(size_t)tg * QP_ELL + k];
+      gc[k]          = (c < 0 || !grow) ? 0 : c;
+      gv[k]          = (c < 0 || !grow) ? 0.0 : v;
+    }
+    g_lo = R.gl[tg];
+    g_hi = R.gu[tg];
+    g_z  = R.gz[tg];
+    g_y  = R.gy[tg];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int  sr = t + 256 * u;
+      const bool ok = sr < S;
+      const int  sc = ok ? sr : 0;
+      const double a0 = R.sval[(size_t)sc * 3 + 0], a1 = R.sval[(size_t)sc * 3 + 1], a2 = R.sval[(size_t)sc * 3 + 2];
+      const double hi = R.su[sc], z = R.sz[sc], y = R.sy[sc];
+      const int    c0 = R.sc0[sc];
+      sv[u][0] = ok ? a0 : 0.0;
+      sv[u][1] = ok ? a1 : 0.0;
+      sv[u][2] = ok ? a2 : 0.0;
+      s_hi[u]  = ok ? hi : 0.0;
+      s_zr[u]  = ok ? z : 0.0;
+      s_yr[u]  = ok ? y : 0.0;
+      s_c[u]   = ok ? c0 : 0;
+    }
+    {
+      const int j = ccol ? t >> 1 : 0;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int    q  = s_cptr[j] + hh + 2 * e;
+        const bool   ok = ccol && q < s_cptr[j + 1];
+        const int    en = R.cidx[ok ? q : s_cptr[j]];
+        const double v  = R.gval[(size_t)(en >> 3) * QP_ELL + (en & 7)];
+        cr[e]           = ok ? en >> 3 : 0;
+        cv[e]           = ok ? v : 0.0;
+      }
+      COL_DECODE(j)
+      fj_sv = (sbase + 5 * hh) * 3 + pd;
+      fj_sw = sbase + 5 * hh;
+      fj_n  = ccol ? (nface - hh + 1) >> 1 : 0;
+      xj    = s_x[j];
+    }
+  };
+  // after set_rho(): the general row's rho and its w = rho z - y (set_rho refreshed the safety rows' w)
+  auto fast_rho = [&]() __attribute__((always_inline)) {
+    const int t  = launder(tid);
+    const int tg = grow ? t : 0;
+    g_rho        = R.grho[tg];
+    g_rinv       = R.grinv[tg];
+    if (grow) h_gw[t] = g_rho * g_z - g_y;
+  };
+  // registers -> row storage, for the residual / termination code that reads it
+  auto fast_spill = [&]() __attribute__((always_inline)) {
+    const int t = launder(tid);
+    if (grow) {
+      R.gz[t] = g_z;
+      R.gy[t] = g_y;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int sr = t + 256 * u;
+      if (sr < S) {
+        R.sz[sr] = s_zr[u];
+        R.sy[sr] = s_yr[u];
+      }
+    }
+    if (ccol && hh == 0) s_x[t >> 1] = xj;
+    __syncthreads();
+  };
+
   set_rho();
   bool chol_ok = factor();
   int  status = -2, iter = 0;
   if (!chol_ok) status = -7;
+  if constexpr (FAST) {
+    fast_load();
+    fast_rho();
+    __syncthreads();
+  }
 
   // ---- 4. ADMM iterations
   int cj_q0 = 0, cj_q1 = 0, cj_sbase = 0, cj_nface = 0, cj_pd = 0;
@@ -801,6 +932,35 @@ __global__ __launch_bounds__(256) void k_qp(SogmPlannerParams pp, SogmQpSettings
   if (chol_ok) {
     for (iter = 1; iter <= qs.max_iter; ++iter) {
       // (a) rhs_j = sigma x_j - q_j + sum_rows A[r][j] (rho_r z_r - y_r)
+      const bool do_adapt = qs.adaptive_rho_interval > 0 && iter % qs.adaptive_rho_interval == 0;
+      const bool do_check = qs.check_termination > 0 && iter % qs.check_termination == 0;
+      if constexpr (FAST) {
+        if (!(ablate & 1) && ccol) {
+          double w[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) w[e] = h_gw[cr[e]];
+          double        p   = 0.0;
+          const double *fvp = h_sv + fj_sv, *fwp = h_sw + fj_sw;
+          const double *fv0 = fvp, *zero = s_xt + 127;  // s_xt is zero beyond n
+#pragma unroll 1
+          for (int i0 = 0; i0 < fj_n; i0 += 4, fvp += 120, fwp += 40) {  // 8 independent LDS reads per round trip
+            double a[4], b[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const bool ok = i0 + u < fj_n;
+              a[u]          = *(ok ? fvp + 30 * u : fv0);
+              b[u]          = *(ok ? fwp + 10 * u : zero);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) p += a[u] * b[u];
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) p += cv[e] * w[e];
+          p += dpp_quad(p, 0xB1);  // partner lane tid ^ 1
+          if (hh == 0) s_xt[launder(tid) >> 1] = qs.sigma * xj + p;  // q == 0
+        }
+      } else
       if (!(ablate & 1))
       if (tid < n) {  // n <= 240 < 256: one column per lane, its constants hoisted out of the loop (cj_*)
         const int j = tid;
@@ -818,6 +978,59 @@ __global__ __launch_bounds__(256) void k_qp(SogmPlannerParams pp, SogmQpSettings
       // (b) x~ = K^-1 rhs
       if (!(ablate & 2)) solveK();
       // (c) rows: z~ = A x~ ; z = proj(alpha z~ + (1-alpha) z + y/rho) ; y += rho (.. - z)
+      if constexpr (FAST) {
+        if (!(ablate & 12)) {
+          double xg[QP_ELL], xs[4][3];  // every read of x~ issued up front: one LDS round trip
+#pragma unroll
+          for (int k = 0; k < QP_ELL; ++k) xg[k] = xtv[gc[k]];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            xs[u][0] = xtv[s_c[u]];
+            xs[u][1] = xtv[s_c[u] + 1];
+            xs[u][2] = xtv[s_c[u] + 2];
+          }
+          const int    t   = launder(tid);
+          const double xtj = xtv[t >> 1];
+          __builtin_amdgcn_sched_barrier(0);
+          {
+            double s = 0;
+#pragma unroll
+            for (int k = 0; k < QP_ELL; ++k) s += gv[k] * xg[k];
+            const double zr = alpha * s + (1.0 - alpha) * g_z;
+            double       v  = zr + g_rinv * g_y;  // OSQP update_z: rho_inv_vec[i] * y[i]
+            v               = v < g_lo ? g_lo : (v > g_hi ? g_hi : v);
+            g_z             = v;
+            const double d  = g_rho * (zr - v);
+            g_y             = g_y + d;
+            if (grow) {
+              h_gw[t] = g_rho * v - g_y;
+              if (do_check) R.gdy[t] = d;
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            double ax = 0;
+            ax += sv[u][0] * xs[u][0];
+            ax += sv[u][1] * xs[u][1];
+            ax += sv[u][2] * xs[u][2];
+            const double zr = alpha * ax + (1.0 - alpha) * s_zr[u];
+            double       v  = zr + rinv_cur * s_yr[u];
+            v               = v > s_hi[u] ? s_hi[u] : v;  // l = -OSQP_INFTY
+            s_zr[u]         = v;
+            const double d  = rho_cur * (zr - v);
+            const double yn = s_yr[u] + d;
+            s_yr[u]         = yn;
+            const int sr    = t + 256 * u;
+            if (sr < S) {
+              h_sw[sr] = rho_cur * v - yn;
+              if (do_check) R.sdy[sr] = d;
+            }
+          }
+          xj = alpha * xtj + (1.0 - alpha) * xj;
+        }
+        __syncthreads();
+        if (do_adapt || do_check) fast_spill();
+      } else {
       if (!(ablate & 4))
       for (int r = tid; r < G; r += 256) {
         double s = 0;
@@ -857,8 +1070,7 @@ __global__ __launch_bounds__(256) void k_qp(SogmPlannerParams pp, SogmQpSettings
       }
       for (int j = tid; j < n; j += 256) s_x[j] = alpha * xtv[j] + (1.0 - alpha) * s_x[j];
       __syncthreads();
-      const bool do_adapt = qs.adaptive_rho_interval > 0 && iter % qs.adaptive_rho_interval == 0;
-      const bool do_check = qs.check_termination > 0 && iter % qs.check_termination == 0;
+      }
       if (do_adapt) {
         residuals();
         const double pr_n = s_sc[0] / (dmax(s_sc[1], s_sc[2]) + 1e-10);
@@ -873,6 +1085,11 @@ __global__ __launch_bounds__(256) void k_qp(SogmPlannerParams pp, SogmQpSettings
           if (!factor()) {
             status = -7;
             break;
+          }
+          if constexpr (FAST) {
+            fast_load();
+            fast_rho();
+            __syncthreads();
           }
         }
       }
@@ -945,6 +1162,7 @@ __global__ __launch_bounds__(256) void k_qp(SogmPlannerParams pp, SogmQpSettings
     }
     if (iter > qs.max_iter) {
       iter = qs.max_iter;
+      if constexpr (FAST) fast_spill();
       residuals();
       const double eps_prim = qs.eps_abs * 10 + qs.eps_rel * 10 * dmax(s_sc[1], s_sc[2]);
       const double eps_dual =
@@ -960,14 +1178,23 @@ __global__ __launch_bounds__(256) void k_qp(SogmPlannerParams pp, SogmQpSettings
     out_iters[agent]  = iter;
   }
   };  // body
+  using std::false_type;
+  using std::true_type;
   if (rows_in_lds) {
     Rows R;
-    carve_rows(R, qp_smem + head, G, S);
-    body(R);
+    carve_rows(R, qp_smem + head, qp_smem + head + rows_hot_bytes(G, S), G, S);
+    if (fast)
+      body(R, true_type{});
+    else
+      body(R, false_type{});
   } else {
-    Rows R;
-    carve_rows(R, ws.scratch + (size_t)agent * ws.scratch_stride, G, S);
-    body(R);
+    char *scr = ws.scratch + (size_t)agent * ws.scratch_stride;
+    Rows  R;
+    carve_rows(R, fast ? qp_smem + head : scr, scr + rows_hot_bytes(G, S), G, S);
+    if (fast)
+      body(R, true_type{});
+    else
+      body(R, false_type{});
   }
 }
 

@@ -20,11 +20,20 @@ sw.map.addOtherAgents(sw.all, A, sw.dev["ego_ids"])
 s = P.search(pva, sw.goals, t_start)
 c = P.generateCorridors(pva, t_start, s["route"], s["route_len"])
 qs = pop.config.make_qp_settings()
-qs.max_iter = 1000
+NIT = int(os.environ.get('SOGM_QP_ITERS', '1000'))
+qs.max_iter = NIT
 qs.check_termination = 0
 qs.adaptive_rho_interval = 0
 P2 = planner.SogmPlanner(sw.map, pop.config.make_astar_params(), pop.config.make_planner_params(True), qs)
 for _ in range(2):
     q = P2.optimize(pva, c["goal"], c["polys"], c["nfaces"], c["npoly"])
     ms = sw.map.profile_read()
-print("ablate", os.environ.get("SOGM_QP_ABLATE", "0"), "qp ms for 1000 fixed iterations:", round(ms[5], 3), "-> us/iter", round(ms[5], 3))
+print("ablate", os.environ.get("SOGM_QP_ABLATE", "0"), "qp ms for", NIT, "fixed iterations:", round(ms[5], 3))
+if os.environ.get("SOGM_QP_STATS"):
+    npoly = c["npoly"].cpu().numpy()
+    nf = c["nfaces"].cpu().numpy().reshape(A, -1)
+    S = np.array([5 * nf[a, :npoly[a]].sum() for a in range(A)])
+    it = q["iters"].cpu().numpy() if "iters" in q else None
+    print("M hist", np.bincount(npoly, minlength=17).tolist())
+    print("S: max", S.max(), "mean", S.mean(), "n>1024", int((S > 1024).sum()), "n>576", int((S > 576).sum()))
+    print("S sorted tail", np.sort(S)[-10:].tolist())
