@@ -194,13 +194,18 @@ int sogm_set_profiling(sogm_ctx *ctx, int enable);
 int sogm_profile_read(sogm_ctx *ctx, double *out_ms_host);
 
 /*
- * Tick pipelining: with overlap enabled, sogm_replan() launches the NEXT update's grid clear on an
- * internal side stream as soon as its corridor stage has finished reading the SOGM (the QP stage
- * does not touch the grid), so the HBM-bound clear runs under the latency-bound QP.  The next
- * sogm_update_gt() then waits for that clear instead of issuing its own.  While a pre-clear is
- * pending the map counts as "not updated": queries return SOGM_ERR_STATE until the next update.
+ * Tick pipelining (mode): 0 = off (every update clears its grid in stream order).
+ * 1 = in-place pre-clear: sogm_replan() launches the NEXT update's grid clear on an internal side stream as
+ *     soon as its corridor stage has finished reading the SOGM (the QP stage does not touch the grid), so the
+ *     HBM-bound clear runs under the latency-bound QP.  While that pre-clear is pending the map counts as "not
+ *     updated": queries return SOGM_ERR_STATE until the next update.
+ * 2 = double-buffered: a second grid is allocated (SOGM_ERR_CAPACITY if HBM has no room; the mode is then
+ *     unchanged) and sogm_replan() clears it under the WHOLE replan; the next update swaps it in.  The current
+ *     map stays valid for queries.  sogm_grid_ptr() changes at every update in this mode.
+ * The next sogm_update_gt() / sogm_set_future_risk() / sogm_dsp_publish() waits for the pending clear instead
+ * of issuing its own.  Changing the mode while a pre-clear is in flight synchronises the device and drops it.
  */
-int sogm_set_overlap_clear(sogm_ctx *ctx, int enable);
+int sogm_set_overlap_clear(sogm_ctx *ctx, int mode);
 
 /* ------------------------------------------------------------------------------------------ */
 /* SOGM update                                                                                 */

@@ -75,13 +75,17 @@ __device__ inline int cubic(double a, double b, double c, double d, double *out)
   }
 }
 
-__device__ inline int quartic(double a, double b, double c, double d, double e, double *out) {
+// Roots land in FIXED slots (out[0..1] the D pair, out[2..3] the E pair) with a validity mask instead of a
+// running count: a dynamically indexed local array would live in scratch memory.  Reading the valid slots in
+// slot order reproduces the reference's root order.
+__device__ inline unsigned quartic(double a, double b, double c, double d, double e, double out[4]) {
   const double a3 = b / a, a2 = c / a, a1 = d / a, a0 = e / a;
   double       ys[3];
   cubic(1, -a2, a1 * a3 - 4 * a0, 4 * a2 * a0 - a1 * a1 - a3 * a3 * a0, ys);
   const double y1 = ys[0];
   const double r  = a3 * a3 / 4 - a2 + y1;
-  if (r < 0) return 0;
+  out[0] = out[1] = out[2] = out[3] = 0.0;
+  if (r < 0) return 0u;
   const double R = sogm_det::sqrt_rn(r);
   double       D, E;
   if (R != 0) {
@@ -93,16 +97,18 @@ __device__ inline int quartic(double a, double b, double c, double d, double e, 
     D = sogm_det::sqrt_rn(0.75 * a3 * a3 - 2 * a2 + 2 * sogm_det::sqrt_rn(y1 * y1 - 4 * a0));
     E = sogm_det::sqrt_rn(0.75 * a3 * a3 - 2 * a2 - 2 * sogm_det::sqrt_rn(y1 * y1 - 4 * a0));
   }
-  int n = 0;
+  unsigned mask = 0;
   if (!(D != D)) {
-    out[n++] = -a3 / 4 + R / 2 + D / 2;
-    out[n++] = -a3 / 4 + R / 2 - D / 2;
+    out[0] = -a3 / 4 + R / 2 + D / 2;
+    out[1] = -a3 / 4 + R / 2 - D / 2;
+    mask |= 3u;
   }
   if (!(E != E)) {
-    out[n++] = -a3 / 4 - R / 2 + E / 2;
-    out[n++] = -a3 / 4 - R / 2 - E / 2;
+    out[2] = -a3 / 4 - R / 2 + E / 2;
+    out[3] = -a3 / 4 - R / 2 - E / 2;
+    mask |= 12u;
   }
-  return n;
+  return mask;
 }
 
 // estimateHeuristic (:428-468)
@@ -122,7 +128,7 @@ __device__ inline double estimate_heuristic(const SogmAstarParams &ap, const dou
   const double c4 = 0;
   const double c5 = ap.w_time;
   double       ts[5];
-  int          n     = quartic(c5, c4, c3, c2, c1, ts);
+  unsigned     mask  = quartic(c5, c4, c3, c2, c1, ts);
   const double v_max = ap.max_vel * 0.5;
   double       linf  = 0;
 #pragma unroll
@@ -131,11 +137,13 @@ __device__ inline double estimate_heuristic(const SogmAstarParams &ap, const dou
     linf           = d > linf ? d : linf;
   }
   const double t_bar = linf / v_max;
-  ts[n++]            = t_bar;
+  ts[4]              = t_bar;  // the reference appends t_bar after the roots
+  mask |= 16u;
   double cost = 100000000, t_d = t_bar;
-  for (int i = 0; i < n; ++i) {
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
     const double t = ts[i];
-    if (t < t_bar) continue;
+    if (!((mask >> i) & 1u) || t < t_bar) continue;
     const double c = -c1 / (3 * t * t * t) - c2 / (2 * t * t) - c3 / t + ap.w_time * t;
     if (c < cost) {
       cost = c;

@@ -193,10 +193,16 @@ __device__ inline void wave_lds_sync() {
 }
 template <int D>
 struct SeidelW {
+  // c and x are caller-side REGISTER arrays: every access below uses a compile-time index (select chains pick
+  // the eliminated coordinate k), so nothing is demoted to scratch memory.
   __device__ static bool solve(const double *a, const double *b, int m, const double *c, double *x,
                                double *work) {
     const int lane = threadIdx.x & 63;
-    for (int j = 0; j < D; ++j) x[j] = c[j] > 0 ? -LP_BIG : (c[j] < 0 ? LP_BIG : 0.0);
+    double    cv[D];  // the objective by value: no conditional load from the caller's array survives
+#pragma unroll
+    for (int j = 0; j < D; ++j) cv[j] = c[j];
+#pragma unroll
+    for (int j = 0; j < D; ++j) x[j] = cv[j] > 0 ? -LP_BIG : (cv[j] < 0 ? LP_BIG : 0.0);
     double *sa = work;
     double *sb = work + LP_MAX_ROWS * (D - 1);
     int     i  = 0;
@@ -208,6 +214,7 @@ struct SeidelW {
         if (r < m) {
           const double *ar = a + r * D;
           double        v  = 0;
+#pragma unroll
           for (int j = 0; j < D; ++j) v += ar[j] * x[j];
           viol = !(v <= b[r] + LP_TOL);
         }
@@ -220,41 +227,59 @@ struct SeidelW {
       if (found < 0) break;
       i                = found;
       const double *ai = a + i * D;
-      int           k  = 0;
-      double        mx = dabs(ai[0]);
+      double        av[D];
+#pragma unroll
+      for (int j = 0; j < D; ++j) av[j] = ai[j];
+      int    k  = 0;
+      double mx = dabs(av[0]), ak = av[0], ck = cv[0];
+#pragma unroll
       for (int j = 1; j < D; ++j)
-        if (dabs(ai[j]) > mx) {
-          mx = dabs(ai[j]);
+        if (dabs(av[j]) > mx) {
+          mx = dabs(av[j]);
           k  = j;
+          ak = av[j];
+          ck = cv[j];
         }
       if (mx < LP_TINY) return false;
-      const double inv = 1.0 / ai[k];
+      const double inv = 1.0 / ak;
       for (int r = lane; r < i; r += 64) {
         const double *ar = a + r * D;
         const double  f  = ar[k] * inv;
-        int           q  = 0;
-        for (int j = 0; j < D; ++j)
-          if (j != k) sa[r * (D - 1) + q++] = ar[j] - f * ai[j];
+#pragma unroll
+        for (int q = 0; q < D - 1; ++q) {
+          const int j          = q < k ? q : q + 1;
+          sa[r * (D - 1) + q] = ar[j] - f * ai[j];
+        }
         sb[r] = b[r] - f * b[i];
       }
       wave_lds_sync();
       double cc[D - 1];
       {
-        const double f = c[k] * inv;
-        int          q = 0;
-        for (int j = 0; j < D; ++j)
-          if (j != k) cc[q++] = c[j] - f * ai[j];
+        const double f = ck * inv;
+#pragma unroll
+        for (int q = 0; q < D - 1; ++q) {
+          const double cj = q < k ? cv[q] : cv[q + 1];
+          const double aj = q < k ? av[q] : av[q + 1];
+          cc[q]           = cj - f * aj;
+        }
       }
       double xs[D - 1];
       if (!SeidelW<D - 1>::solve(sa, sb, i, cc, xs, work + LP_MAX_ROWS * D)) return false;
       double acc = b[i];
-      int    q   = 0;
-      for (int j = 0; j < D; ++j)
-        if (j != k) {
-          x[j] = xs[q++];
-          acc -= ai[j] * x[j];
-        }
-      x[k] = acc * inv;
+      double xv[D];
+#pragma unroll
+      for (int j = 0; j < D; ++j) {
+        // value of coordinate j of the lifted point when j != k: xs[j] below k, xs[j - 1] above
+        const double lo = j < D - 1 ? xs[j < D - 1 ? j : 0] : 0.0;
+        const double hi = j > 0 ? xs[j > 0 ? j - 1 : 0] : 0.0;
+        const double v  = j < k ? lo : hi;
+        const double na = acc - av[j] * v;
+        acc             = j != k ? na : acc;
+        xv[j]           = v;
+      }
+      const double xk = acc * inv;
+#pragma unroll
+      for (int j = 0; j < D; ++j) x[j] = j == k ? xk : xv[j];
       wave_lds_sync();  // the sub-problem arrays are rebuilt by the next violation
       ++i;
     }
@@ -927,6 +952,146 @@ __device__ inline void wave_argmin(double &v, int &idx) {
   }
 }
 
+// Local box of segment `seg` (baseline.cpp:300-324): box[0..2] = llc, box[3..5] = lhc, w[0..5] = the two waypoints
+__device__ inline void segment_box(const SogmPlannerParams &pp, const double *sp, const double *rt, int seg,
+                                   double *box, double *w) {
+  double w0[3], w1[3];
+  for (int k = 0; k < 3; ++k) {
+    w0[k] = rt[seg * 6 + k];
+    w1[k] = rt[(seg + 1) * 6 + k];
+  }
+  if (w0[2] < 0) w0[2] = 0.1;  // baseline.cpp:314
+  if (w1[2] < 0) w1[2] = 0.1;
+  double lower[3]  = {-4 + sp[0], -4 + sp[1], -1 + sp[2]};
+  double higher[3] = {4 + sp[0], 4 + sp[1], 1 + sp[2]};
+  if (lower[2] < 0) lower[2] = 0;
+  if (higher[2] > 4) higher[2] = 4;
+  for (int k = 0; k < 3; ++k) {
+    const double mxw = w0[k] > w1[k] ? w0[k] : w1[k];
+    const double mnw = w0[k] < w1[k] ? w0[k] : w1[k];
+    const double hi  = mxw + pp.init_range;
+    const double lo  = mnw - pp.init_range;
+    box[3 + k]       = hi < higher[k] ? hi : higher[k];  // lhc
+    box[k]           = lo > lower[k] ? lo : lower[k];    // llc
+    w[k]             = w0[k];
+    w[3 + k]         = w1[k];
+  }
+}
+
+}  // namespace
+
+// =================================================================================================
+// Kernel P: obstacle points of one (segment, agent) — map.cpp:480-518 / risk_base.cpp:295-337.
+// The only corridor stage that reads the SOGM: once it has run the grid may be cleared for the next update.
+// One wave; a lane takes four consecutive cells of the box scan per step so that 4 x (slabs) loads are in
+// flight per lane, and an order-preserving wave scan keeps the reference's point order (x fastest, then y, z;
+// a cell's time slices in ascending order).
+// =================================================================================================
+__global__ __launch_bounds__(64) void k_corridor_points(MapView m, SogmPlannerParams pp, CorridorWorkspace ws,
+                                                        const double *__restrict__ start_pva,
+                                                        const double *__restrict__ t_start,
+                                                        const double *__restrict__ route,
+                                                        const int32_t *__restrict__ route_len, int route_cap,
+                                                        int agent0) {
+  const int seg   = blockIdx.x;
+  const int agent = blockIdx.y + agent0;
+  const int lane  = threadIdx.x;
+  const int rl    = route_len[agent];
+  const int slot  = agent * SOGM_MAX_PIECES + seg;
+  if (seg >= rl - 1 || seg >= SOGM_MAX_PIECES) return;
+  __shared__ double s_box[6], s_w[6];
+  const GridGeom &g    = m.g;
+  const float    *pose = m.poses + agent * 3;
+  const int       cap  = pp.pc_capacity;
+  double         *pc   = ws.pc + (size_t)slot * cap * 3;
+  if (lane == 0) segment_box(pp, start_pva + agent * 9, route + (size_t)agent * route_cap * 6, seg, s_box, s_w);
+  __syncthreads();
+  int N = 0;
+  {
+    const double stamp = m.stamps[agent];
+    const double tr    = (double)g.dt;
+    const double t1    = t_start[agent] + seg * pp.corridor_tau;
+    const double t2    = t_start[agent] + (seg + 1) * pp.corridor_tau;
+    int          js    = (int)floor((t1 - stamp) / tr);
+    int          je    = (int)ceil((t2 - stamp) / tr);
+    js                 = js < 0 ? 0 : js;
+    js                 = js > g.T ? g.T : js;
+    je                 = je > g.T ? g.T : je;
+    je                 = je < 0 ? 0 : je;
+    if (je > g.T - 1) je = g.T - 1;
+    int lx = (int)((s_box[0] - pose[0] + g.rx) / g.res);
+    int ly = (int)((s_box[1] - pose[1] + g.ry) / g.res);
+    int lz = (int)((s_box[2] - pose[2] + g.rz) / g.res);
+    int hx = (int)((s_box[3] - pose[0] + g.rx) / g.res);
+    int hy = (int)((s_box[4] - pose[1] + g.ry) / g.res);
+    int hz = (int)((s_box[5] - pose[2] + g.rz) / g.res);
+    hx     = min(hx, g.L - 1);
+    hy     = min(hy, g.W - 1);
+    hz     = min(hz, g.H - 1);
+    lx     = max(lx, 0);
+    ly     = max(ly, 0);
+    lz     = max(lz, 0);
+    const int nx = hx - lx + 1, ny = hy - ly + 1, nz = hz - lz + 1;
+    if (nx > 0 && ny > 0 && nz > 0 && js <= je) {
+      const int   cells = nx * ny * nz;
+      const void *grid0 = m.slab(agent, 0);
+      int         base  = 0;
+      for (int c0 = 0; c0 < cells; c0 += 256) {
+        int      cnt[4], vi[4];
+        unsigned mask[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int c = c0 + 4 * lane + q;
+          cnt[q]      = 0;
+          mask[q]     = 0;
+          vi[q]       = 0;
+          if (c < cells) {
+            const int x = lx + c % nx;
+            const int y = ly + (c / nx) % ny;
+            const int z = lz + c / (nx * ny);
+            vi[q]       = x + y * g.L + z * g.L * g.W;
+            for (int j = js; j <= je; ++j) {
+              const float thr = g.map_kind == SOGM_MAP_FAKE ? g.risk_threshold
+                                                             : g.risk_threshold - g.decay_voxel * (float)j;
+              if (cell_ld(grid0, (size_t)j * g.V + vi[q], g.half) > thr) {
+                ++cnt[q];
+                mask[q] |= 1u << (j - js);
+              }
+            }
+          }
+        }
+        const int mine = cnt[0] + cnt[1] + cnt[2] + cnt[3];
+        int       incl = mine;
+        for (int d = 1; d < 64; d <<= 1) {
+          const int up = __shfl_up(incl, d, 64);
+          if (lane >= d) incl += up;
+        }
+        const int total = __shfl(incl, 63, 64);
+        int       off   = base + incl - mine;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (cnt[q]) {
+            float fx, fy, fz;
+            g.corner_of(vi[q], pose, fx, fy, fz);
+            for (int j = 0; j < 32 && (mask[q] >> j); ++j)
+              if ((mask[q] >> j) & 1u) {
+                if (off < cap) {
+                  pc[off * 3 + 0] = (double)fx;
+                  pc[off * 3 + 1] = (double)fy;
+                  pc[off * 3 + 2] = (double)fz;
+                }
+                ++off;
+              }
+          }
+        base += total;
+      }
+      N = base;
+    }
+  }
+  if (lane == 0) ws.seg_npts[slot] = N;
+}
+
+namespace {
 }  // namespace
 
 // =================================================================================================
@@ -970,8 +1135,6 @@ __global__ __launch_bounds__(64) void k_corridor_segment(
   double *s_box  = s_small + 76;  // 6  llc, lhc
   double *s_w    = s_small + 82;  // 6  w0, w1
 
-  const GridGeom &g     = m.g;
-  const float    *pose  = m.poses + agent * 3;
   const double   *rt    = route + (size_t)agent * route_cap * 6;
   const double   *sp    = start_pva + agent * 9;
   const int       cap   = pp.pc_capacity;
@@ -984,27 +1147,7 @@ __global__ __launch_bounds__(64) void k_corridor_segment(
   const long long tk0 = wall_clock64();
   if (lane == 0) {
     for (int k = 0; k < 16; ++k) dbg[k] = 0;
-    double w0[3], w1[3];
-    for (int k = 0; k < 3; ++k) {
-      w0[k] = rt[seg * 6 + k];
-      w1[k] = rt[(seg + 1) * 6 + k];
-    }
-    if (w0[2] < 0) w0[2] = 0.1;  // baseline.cpp:314
-    if (w1[2] < 0) w1[2] = 0.1;
-    double lower[3]  = {-4 + sp[0], -4 + sp[1], -1 + sp[2]};
-    double higher[3] = {4 + sp[0], 4 + sp[1], 1 + sp[2]};
-    if (lower[2] < 0) lower[2] = 0;
-    if (higher[2] > 4) higher[2] = 4;
-    for (int k = 0; k < 3; ++k) {
-      const double mxw = w0[k] > w1[k] ? w0[k] : w1[k];
-      const double mnw = w0[k] < w1[k] ? w0[k] : w1[k];
-      const double hi  = mxw + pp.init_range;
-      const double lo  = mnw - pp.init_range;
-      s_box[3 + k]     = hi < higher[k] ? hi : higher[k];  // lhc
-      s_box[k]         = lo > lower[k] ? lo : lower[k];    // llc
-      s_w[k]           = w0[k];
-      s_w[3 + k]       = w1[k];
-    }
+    segment_box(pp, sp, rt, seg, s_box, s_w);
     // getInitCorridor (baseline.cpp:127-141) with the local box
     for (int i = 0; i < 24; ++i) s_bd[i] = 0;
     for (int k = 0; k < 3; ++k) {
@@ -1016,82 +1159,8 @@ __global__ __launch_bounds__(64) void k_corridor_segment(
   }
   __syncthreads();
 
-  // ---------------- obstacle points (map.cpp:480-518 / risk_base.cpp:295-337) ----------------
-  int N = 0;
-  {
-    const double stamp = m.stamps[agent];
-    const double tr    = (double)g.dt;
-    const double t1    = t_start[agent] + seg * pp.corridor_tau;
-    const double t2    = t_start[agent] + (seg + 1) * pp.corridor_tau;
-    int          js    = (int)floor((t1 - stamp) / tr);
-    int          je    = (int)ceil((t2 - stamp) / tr);
-    js                 = js < 0 ? 0 : js;
-    js                 = js > g.T ? g.T : js;
-    je                 = je > g.T ? g.T : je;
-    je                 = je < 0 ? 0 : je;
-    if (je > g.T - 1) je = g.T - 1;
-    int lx = (int)((s_box[0] - pose[0] + g.rx) / g.res);
-    int ly = (int)((s_box[1] - pose[1] + g.ry) / g.res);
-    int lz = (int)((s_box[2] - pose[2] + g.rz) / g.res);
-    int hx = (int)((s_box[3] - pose[0] + g.rx) / g.res);
-    int hy = (int)((s_box[4] - pose[1] + g.ry) / g.res);
-    int hz = (int)((s_box[5] - pose[2] + g.rz) / g.res);
-    hx     = min(hx, g.L - 1);
-    hy     = min(hy, g.W - 1);
-    hz     = min(hz, g.H - 1);
-    lx     = max(lx, 0);
-    ly     = max(ly, 0);
-    lz     = max(lz, 0);
-    const int nx = hx - lx + 1, ny = hy - ly + 1, nz = hz - lz + 1;
-    if (nx > 0 && ny > 0 && nz > 0 && js <= je) {
-      const int    cells = nx * ny * nz;
-      const void *grid0 = m.slab(agent, 0);
-      int          base  = 0;
-      for (int c0 = 0; c0 < cells; c0 += 64) {
-        const int c    = c0 + lane;
-        int       cnt  = 0;
-        unsigned  mask = 0;
-        int       vi   = 0;
-        if (c < cells) {
-          const int x = lx + c % nx;
-          const int y = ly + (c / nx) % ny;
-          const int z = lz + c / (nx * ny);
-          vi          = x + y * g.L + z * g.L * g.W;
-          for (int j = js; j <= je; ++j) {
-            const float thr = g.map_kind == SOGM_MAP_FAKE
-                                  ? g.risk_threshold
-                                  : g.risk_threshold - g.decay_voxel * (float)j;
-            if (cell_ld(grid0, (size_t)j * g.V + vi, g.half) > thr) {
-              ++cnt;
-              mask |= 1u << (j - js);
-            }
-          }
-        }
-        int incl = cnt;
-        for (int d = 1; d < 64; d <<= 1) {
-          const int up = __shfl_up(incl, d, 64);
-          if (lane >= d) incl += up;
-        }
-        const int total = __shfl(incl, 63, 64);
-        int       off   = base + incl - cnt;
-        if (cnt) {
-          float fx, fy, fz;
-          g.corner_of(vi, pose, fx, fy, fz);
-          for (int j = 0; j < 32 && (mask >> j); ++j)
-            if ((mask >> j) & 1u) {
-              if (off < cap) {
-                pc[off * 3 + 0] = (double)fx;
-                pc[off * 3 + 1] = (double)fy;
-                pc[off * 3 + 2] = (double)fz;
-              }
-              ++off;
-            }
-        }
-        base += total;
-      }
-      N = base;
-    }
-  }
+  // obstacle points: written by k_corridor_points (the only stage of the corridor generation that reads the SOGM)
+  int N = ws.seg_npts[slot];
   int overflow = 0;
   if (N > cap) {
     N        = cap;
@@ -1500,7 +1569,8 @@ __global__ __launch_bounds__(64) void k_safe_after_opt(const double *__restrict_
     double dirs[11][3] = {{1, 1, 0}, {1, -1, 0}, {1, 0, 1}, {1, 0, -1}, {0, 1, 1}, {0, 1, -1},
                           {1, 1, 1}, {1, 1, -1}, {1, -1, 1}, {1, -1, -1}, {0, 0, 0}};
     for (int k = 0; k < 3; ++k) dirs[10][k] = 0.5 * (lo[3 + k] + hi[3 + k]) - 0.5 * (lo[k] + hi[k]);
-    for (int q = 0; q < 11; ++q) {
+#pragma unroll
+    for (int q = 0; q < 11; ++q) {  // unrolled: the normals are immediates, not a scratch-memory table
       const double n0 = dirs[q][0], n1 = dirs[q][1], n2 = dirs[q][2];
       double loA = INFINITY, hiA = -INFINITY, loB = INFINITY, hiB = -INFINITY;
       for (int i = threadIdx.x; i < nA; i += 64) {
@@ -1567,7 +1637,12 @@ int launch_corridor(const MapView &m, const SogmPlannerParams &pp, const Corrido
                     int n_agents, const double *start_pva, const double *t_start,
                     const double *route, const int32_t *route_len, int route_cap,
                     double *out_polys, int32_t *out_nfaces, int32_t *out_npoly, double *out_goal,
-                    hipStream_t st, int agent0) {
+                    hipStream_t st, int agent0, hipEvent_t ev_map_read) {
+  hipLaunchKernelGGL(k_corridor_points, dim3(SOGM_MAX_PIECES, n_agents), dim3(64), 0, st, m, pp, ws, start_pva,
+                     t_start, route, route_len, route_cap, agent0);
+  if (hipGetLastError() != hipSuccess) return -1;
+  // nothing after this point reads the SOGM
+  if (ev_map_read && hipEventRecord(ev_map_read, st) != hipSuccess) return -1;
   const size_t ldsA = corridor_segment_lds(pp.pc_capacity);
   hipLaunchKernelGGL(k_corridor_segment, dim3(SOGM_MAX_PIECES, n_agents), dim3(64), ldsA, st, m,
                      pp, ws, start_pva, t_start, route, route_len, route_cap, agent0);

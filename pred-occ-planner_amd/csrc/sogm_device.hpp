@@ -254,7 +254,8 @@ struct sogm_ctx {
   int            n_body;
   int            updated;
   float         *d_scratch_vt;  // [V][T] staging for download / upload
-  int            overlap;     // tick pipelining enabled
+  int            overlap;     // tick pipelining: 0 off, 1 pre-clear in place, 2 pre-clear of the alternate grid
+  float         *d_grid_alt;  // second grid of mode 2 (the next update swaps it in)
   int            precleared;  // a side-stream clear for the next update is in flight
   hipStream_t    side;
   hipEvent_t     ev_grid_free, ev_cleared;
@@ -291,7 +292,9 @@ inline MapView view_of(const sogm_ctx *c) {
   return m;
 }
 void set_error(const char *what, hipError_t e);
-int  launch_clear(sogm_ctx *c, hipStream_t st);
+int  launch_clear(sogm_ctx *c, hipStream_t st, float *grid = nullptr, bool polite = false);
+// next update's grid becomes current (mode 2) and the stream waits for its pre-clear
+int  adopt_preclear(sogm_ctx *c, hipStream_t st);
 }  // namespace sogm
 
 #define SOGM_HIP_CHECK(expr)                    \

@@ -1258,8 +1258,8 @@ int sogm_dsp_publish(sogm_dsp *h, int32_t *out_n_occupied, void *stream) {
   hipStream_t st = (hipStream_t)stream;
   SOGM_HIP_CHECK(hipSetDevice(c->device));
   if (c->precleared) {  // a pending side-stream clear must not race the copy
-    SOGM_HIP_CHECK(hipStreamWaitEvent(st, c->ev_cleared, 0));
-    c->precleared = 0;
+    int rc = sogm::adopt_preclear(c, st);
+    if (rc) return rc;
   }
   hipLaunchKernelGGL(k_dsp_publish, dim3((unsigned)((d.V + 255) / 256), (unsigned)d.A), dim3(256), 0, st, d,
                      (void *)c->d_grid, c->geom.half, c->geom.risk_threshold, c->d_poses, c->d_stamps);

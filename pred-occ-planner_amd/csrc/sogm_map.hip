@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -33,18 +34,31 @@ void set_error(const char *what, hipError_t e) {
 // fully coalesced; 4 independent stores in flight per lane per trip.  The grid is sized to
 // ~8 workgroups per CU and strides over the buffer.
 typedef float vfloat4 __attribute__((ext_vector_type(4)));
+template <bool NT>
+__device__ inline void clear_store(vfloat4 *p) {
+  const vfloat4 z = {0.f, 0.f, 0.f, 0.f};
+  if (NT)
+    __builtin_nontemporal_store(z, p);
+  else
+    *p = z;
+}
+template <bool NT>
 __global__ __launch_bounds__(256) void k_clear_slabs(vfloat4 *__restrict__ p, size_t n_vec4,
-                                                     float *__restrict__ tail, int n_tail) {
-  const size_t  stride = (size_t)gridDim.x * blockDim.x;
-  size_t        i      = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const vfloat4 z      = {0.f, 0.f, 0.f, 0.f};
+                                                     float *__restrict__ tail, int n_tail, int throttle) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  size_t       i      = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   for (; i + 3 * stride < n_vec4; i += 4 * stride) {
-    __builtin_nontemporal_store(z, p + i);
-    __builtin_nontemporal_store(z, p + i + stride);
-    __builtin_nontemporal_store(z, p + i + 2 * stride);
-    __builtin_nontemporal_store(z, p + i + 3 * stride);
+    clear_store<NT>(p + i);
+    clear_store<NT>(p + i + stride);
+    clear_store<NT>(p + i + 2 * stride);
+    clear_store<NT>(p + i + 3 * stride);
+    // tuning aid: bound the stores a wave keeps in flight (vmcnt <= 4 / 8 / 12)
+    if (throttle == 4) __builtin_amdgcn_s_waitcnt(0x0F74);
+    else if (throttle == 8) __builtin_amdgcn_s_waitcnt(0x0F78);
+    else if (throttle == 12) __builtin_amdgcn_s_waitcnt(0x0F7C);
+    else if (throttle == 1) __builtin_amdgcn_s_waitcnt(0x0F70);
   }
-  for (; i < n_vec4; i += stride) __builtin_nontemporal_store(z, p + i);
+  for (; i < n_vec4; i += stride) clear_store<NT>(p + i);
   if (blockIdx.x == 0 && (int)threadIdx.x < n_tail) tail[threadIdx.x] = 0.f;
 }
 
@@ -471,16 +485,49 @@ __global__ __launch_bounds__(64) void k_traj_safe(MapView m, const SogmTrajRecor
   out[a] = safe;
 }
 
-int launch_clear(sogm_ctx *c, hipStream_t st) {
+int adopt_preclear(sogm_ctx *c, hipStream_t st) {
+  if (!c->precleared) return SOGM_OK;
+  if (c->overlap == 2 && c->d_grid_alt) {
+    float *t      = c->d_grid;
+    c->d_grid     = c->d_grid_alt;
+    c->d_grid_alt = t;
+  }
+  SOGM_HIP_CHECK(hipStreamWaitEvent(st, c->ev_cleared, 0));
+  c->precleared = 0;
+  return SOGM_OK;
+}
+
+// polite = the clear shares the machine with latency-bound kernels that read global memory (double-buffered
+// mode): a full-width clear (2048 persistent workgroups, unbounded stores in flight) starves every other
+// kernel's loads for its whole duration; 64 workgroups with <= 4 stores in flight per wave still stream at
+// ~5.7 TB/s and leave the memory pipeline responsive.  SOGM_CLEAR_WGS / SOGM_CLEAR_THROTTLE / SOGM_CLEAR_NT
+// override the choice (tuning aids).
+int launch_clear(sogm_ctx *c, hipStream_t st, float *grid, bool polite) {
+  if (!grid) grid = c->d_grid;
   // the clear is a byte stream: n = number of 4-byte words of the grid (fp16 grids: 2 cells per word)
   const size_t n    = (size_t)c->n_agents * c->spec.T * (size_t)c->geom.V * c->cell_bytes() / 4;
   const size_t nv4  = n / 4;
   const int    tail = (int)(n - nv4 * 4);
   size_t       want = (nv4 + 255) / 256;
-  const int    nblk = (int)(want < 1 ? 1 : (want > 2048 ? 2048 : want));
+  static int   env_wgs = -1, env_throttle = -1, nt = -1;
+  if (env_wgs < 0) {
+    const char *e = getenv("SOGM_CLEAR_WGS");
+    env_wgs       = e && atoi(e) > 0 ? atoi(e) : 0;
+    e             = getenv("SOGM_CLEAR_THROTTLE");
+    env_throttle  = e ? atoi(e) : 0;
+    e             = getenv("SOGM_CLEAR_NT");
+    nt            = e ? atoi(e) != 0 : 1;
+  }
+  const size_t max_wgs  = env_wgs ? (size_t)env_wgs : (polite ? 64 : 2048);
+  const int    throttle = env_wgs ? env_throttle : (polite ? 4 : 0);
+  const int    nblk     = (int)(want < 1 ? 1 : (want > max_wgs ? max_wgs : want));
   prof_begin(c, SOGM_PROF_CLEAR, st);
-  hipLaunchKernelGGL(k_clear_slabs, dim3(nblk), dim3(256), 0, st, (vfloat4 *)c->d_grid, nv4,
-                     c->d_grid + nv4 * 4, tail);
+  if (nt)
+    hipLaunchKernelGGL(k_clear_slabs<true>, dim3(nblk), dim3(256), 0, st, (vfloat4 *)grid, nv4, grid + nv4 * 4, tail,
+                       throttle);
+  else
+    hipLaunchKernelGGL(k_clear_slabs<false>, dim3(nblk), dim3(256), 0, st, (vfloat4 *)grid, nv4, grid + nv4 * 4, tail,
+                       throttle);
   prof_end(c, SOGM_PROF_CLEAR, st);
   SOGM_HIP_CHECK(hipGetLastError());
   return SOGM_OK;
@@ -552,6 +599,7 @@ int sogm_create(const SogmSpec *spec, int n_agents, int device, sogm_ctx **out) 
 void sogm_destroy(sogm_ctx *c) {
   if (!c) return;
   if (c->d_grid) (void)hipFree(c->d_grid);
+  if (c->d_grid_alt) (void)hipFree(c->d_grid_alt);
   if (c->d_poses) (void)hipFree(c->d_poses);
   if (c->d_stamps) (void)hipFree(c->d_stamps);
   if (c->d_body) (void)hipFree(c->d_body);
@@ -577,9 +625,27 @@ int64_t sogm_grid_bytes(const sogm_ctx *c) {
 }
 float *sogm_grid_ptr(sogm_ctx *c) { return c ? c->d_grid : nullptr; }
 
-int sogm_set_overlap_clear(sogm_ctx *c, int enable) {
-  if (!c) return SOGM_ERR_INVALID_ARG;
-  c->overlap = enable ? 1 : 0;
+int sogm_set_overlap_clear(sogm_ctx *c, int mode) {
+  if (!c || mode < 0 || mode > 2) return SOGM_ERR_INVALID_ARG;
+  if (c->precleared) {  // a pre-clear is in flight: let it finish and forget it (the next update clears itself)
+    (void)hipDeviceSynchronize();
+    c->precleared = 0;
+  }
+  if (mode == 2 && !c->d_grid_alt) {
+    const size_t bytes = ((size_t)sogm_grid_bytes(c) + 15) & ~(size_t)15;
+    if (hipMalloc(&c->d_grid_alt, bytes) != hipSuccess) {
+      (void)hipGetLastError();
+      c->d_grid_alt = nullptr;
+      sogm::set_error("sogm_set_overlap_clear: no room for a second grid", hipErrorOutOfMemory);
+      return SOGM_ERR_CAPACITY;
+    }
+  }
+  if (mode != 2 && c->d_grid_alt) {
+    (void)hipDeviceSynchronize();
+    (void)hipFree(c->d_grid_alt);
+    c->d_grid_alt = nullptr;
+  }
+  c->overlap = mode;
   return SOGM_OK;
 }
 
@@ -626,9 +692,9 @@ int sogm_update_gt(sogm_ctx *c, const float *cloud_xyz, const int32_t *cloud_ran
   SOGM_HIP_CHECK(hipMemcpyAsync(c->d_stamps, stamps, sizeof(double) * c->n_agents,
                                 hipMemcpyDeviceToDevice, st));
   if (c->precleared) {
-    // the grid was already cleared on the side stream during the previous tick's QP stage
-    SOGM_HIP_CHECK(hipStreamWaitEvent(st, c->ev_cleared, 0));
-    c->precleared = 0;
+    // the grid was already cleared on the side stream during the previous tick
+    int rc = sogm::adopt_preclear(c, st);
+    if (rc) return rc;
   } else {
     int rc = clear_grid(c, st);
     if (rc) return rc;
@@ -669,8 +735,8 @@ int sogm_set_future_risk(sogm_ctx *c, const float *grid_vt, const float *poses,
   SOGM_HIP_CHECK(hipMemcpyAsync(c->d_stamps, stamps, sizeof(double) * c->n_agents,
                                 hipMemcpyDeviceToDevice, st));
   if (c->precleared) {
-    SOGM_HIP_CHECK(hipStreamWaitEvent(st, c->ev_cleared, 0));
-    c->precleared = 0;
+    int rc = sogm::adopt_preclear(c, st);
+    if (rc) return rc;
   }
   const int    V = c->geom.V, T = c->spec.T;
   const size_t per = (size_t)V * T;

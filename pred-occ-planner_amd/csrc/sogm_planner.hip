@@ -292,6 +292,15 @@ int sogm_replan(sogm_planner *p, const double *start_pva, const double *goal,
   const MapView mv = view_of(c);
   // fan out: every group stream starts when the caller's stream has produced the inputs
   SOGM_HIP_CHECK(hipEventRecord(p->ev_in, main));
+  if (c->overlap == 2 && c->d_grid_alt) {
+    // double-buffered SOGM: the NEXT update's grid is cleared on the side stream under this whole replan (its
+    // last readers, the previous tick's corridor kernels, are ordered before ev_in)
+    SOGM_HIP_CHECK(hipStreamWaitEvent(c->side, p->ev_in, 0));
+    int rc = sogm::launch_clear(c, c->side, c->d_grid_alt, true);
+    if (rc) return rc;
+    SOGM_HIP_CHECK(hipEventRecord(c->ev_cleared, c->side));
+    c->precleared = 1;
+  }
   for (int g = 0; g < G; ++g) {
     const int a0 = (int)((long long)A * g / G), a1 = (int)((long long)A * (g + 1) / G), n = a1 - a0;
     if (n <= 0) continue;
@@ -306,9 +315,10 @@ int sogm_replan(sogm_planner *p, const double *start_pva, const double *goal,
     }
     SOGM_HIP_CHECK(hipEventRecord(p->ev_corr[g], st));
   }
-  if (c->overlap) {
-    // every group's corridor stage was the last reader of the SOGM in this tick: clear it for the
-    // next update on the side stream, under the QP stage
+  if (c->overlap == 1) {
+    // every group's corridor stage has finished with the SOGM and with global memory: clear the grid for the
+    // next update on the side stream, under the QP stage (a full-width clear starves every concurrent load, so
+    // it must not start while the FIRI kernels still read their point sets; k_qp only touches LDS)
     for (int g = 0; g < G; ++g) SOGM_HIP_CHECK(hipStreamWaitEvent(c->side, p->ev_corr[g], 0));
     int rc = sogm::launch_clear(c, c->side);
     if (rc) return rc;

@@ -36,7 +36,7 @@ int launch_corridor(const MapView &m, const SogmPlannerParams &pp, const Corrido
                     int n_agents, const double *start_pva, const double *t_start,
                     const double *route, const int32_t *route_len, int route_cap,
                     double *out_polys, int32_t *out_nfaces, int32_t *out_npoly, double *out_goal,
-                    hipStream_t st, int agent0 = 0);
+                    hipStream_t st, int agent0 = 0, hipEvent_t ev_map_read = nullptr);
 
 // Per-agent QP row storage in HBM, used only when a problem's rows do not fit in LDS.
 struct QpWorkspace {

@@ -929,11 +929,19 @@ __global__ __launch_bounds__(256) void k_qp(SogmPlannerParams pp, SogmQpSettings
   const double *xtv   = use_blocks ? s_cn : s_xt;  // where the solve leaves x~
   for (int j = n + tid; j < 128; j += 256) s_xt[j] = 0.0;  // the register mat-vec reads 120 entries
   __syncthreads();
+  int adapt_left = qs.adaptive_rho_interval, check_left = qs.check_termination;
   if (chol_ok) {
     for (iter = 1; iter <= qs.max_iter; ++iter) {
       // (a) rhs_j = sigma x_j - q_j + sum_rows A[r][j] (rho_r z_r - y_r)
-      const bool do_adapt = qs.adaptive_rho_interval > 0 && iter % qs.adaptive_rho_interval == 0;
-      const bool do_check = qs.check_termination > 0 && iter % qs.check_termination == 0;
+      bool do_adapt = false, do_check = false;  // iter % interval == 0, kept as countdowns
+      if (qs.adaptive_rho_interval > 0 && --adapt_left == 0) {
+        do_adapt   = true;
+        adapt_left = qs.adaptive_rho_interval;
+      }
+      if (qs.check_termination > 0 && --check_left == 0) {
+        do_check   = true;
+        check_left = qs.check_termination;
+      }
       if constexpr (FAST) {
         if (!(ablate & 1) && ccol) {
           double w[4];
@@ -985,9 +993,12 @@ __global__ __launch_bounds__(256) void k_qp(SogmPlannerParams pp, SogmQpSettings
           for (int k = 0; k < QP_ELL; ++k) xg[k] = xtv[gc[k]];
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
-            xs[u][0] = xtv[s_c[u]];
-            xs[u][1] = xtv[s_c[u] + 1];
-            xs[u][2] = xtv[s_c[u] + 2];
+            xs[u][0] = xs[u][1] = xs[u][2] = 0.0;
+            if (256 * u < S) {  // workgroup-uniform: slots beyond the last safety row cost nothing
+              xs[u][0] = xtv[s_c[u]];
+              xs[u][1] = xtv[s_c[u] + 1];
+              xs[u][2] = xtv[s_c[u] + 2];
+            }
           }
           const int    t   = launder(tid);
           const double xtj = xtv[t >> 1];
@@ -1009,6 +1020,7 @@ __global__ __launch_bounds__(256) void k_qp(SogmPlannerParams pp, SogmQpSettings
           }
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
+            if (256 * u >= S) continue;
             double ax = 0;
             ax += sv[u][0] * xs[u][0];
             ax += sv[u][1] * xs[u][1];

@@ -67,9 +67,25 @@ class SogmMap:
     def grid_bytes(self):
         return int(lib().sogm_grid_bytes(self._ctx))
 
-    def set_overlap_clear(self, on=True):
-        """Tick pipelining: replan() pre-clears the grid for the next update under its QP stage."""
-        check(lib().sogm_set_overlap_clear(self._ctx, 1 if on else 0), "sogm_set_overlap_clear")
+    def set_overlap_clear(self, on=True, double_buffer=None):
+        """Tick pipelining.  Mode 2 (double_buffer, the default when HBM has room for a second grid): replan()
+        clears the NEXT update's grid with a narrow streaming kernel under the whole replan.  Mode 1: the grid is
+        cleared in place at full width under the QP stage, after the corridor stage has finished with global
+        memory.  Returns the mode in effect."""
+        if not on:
+            check(lib().sogm_set_overlap_clear(self._ctx, 0), "sogm_set_overlap_clear")
+            return 0
+        if double_buffer is None:
+            free, _ = torch.cuda.mem_get_info()
+            double_buffer = free > self.grid_bytes() + (16 << 30)
+        if double_buffer:
+            rc = lib().sogm_set_overlap_clear(self._ctx, 2)
+            if rc == 0:
+                return 2
+            if rc != _abi.SOGM_ERR_CAPACITY:
+                check(rc, "sogm_set_overlap_clear")
+        check(lib().sogm_set_overlap_clear(self._ctx, 1), "sogm_set_overlap_clear")
+        return 1
 
     def isTrajSafe(self, records, t_now, check_duration):
         """BaselinePlanner::isTrajSafe for every agent's executed trajectory (device uint8 [A, 2064])."""

@@ -20,6 +20,26 @@ poses = pva[:, :3].to(torch.float32).contiguous()
 sw.map.updateMap(sw.dev["cloud"], sw.dev["cloud_range"], sw.dev["cylinders"], sw.dev["n_cyl"], poses, stamps)
 sw.map.addOtherAgents(sw.all, A, sw.dev["ego_ids"])
 s = P.search(pva, sw.goals, t_start)
+if os.environ.get("SOGM_CONTEND") == "2":
+    # contention source: the real SOGM clear (+ stamp) of a second map on a side stream
+    sogm_mod = importlib.import_module("pred-occ-planner_amd.sogm")
+    m2 = sogm_mod.SogmMap(sw.spec, A)
+    side = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    with torch.cuda.stream(side):
+        ev0.record(side)
+        for _ in range(2):
+            m2.updateMap(sw.dev["cloud"], sw.dev["cloud_range"], sw.dev["cylinders"], sw.dev["n_cyl"], poses, stamps)
+        ev1.record(side)
+elif os.environ.get("SOGM_CONTEND"):
+    # contention source: a streaming zero-fill of a 16 GiB tensor on a side stream while the corridors run
+    big = torch.empty(int(os.environ.get("SOGM_CONTEND_GB", "16")) << 28, dtype=torch.float32, device="cuda")
+    side = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        for _ in range(12):
+            big.zero_()
 c = P.generateCorridors(pva, t_start, s["route"], s["route_len"])
 ms = sw.map.profile_read()
 lib = pop.lib()
@@ -29,6 +49,11 @@ lib.sogm_debug_corridor_stats(P._p, out.ctypes.data)
 d = out[out[:, 10] > 0]
 us = lambda t: t / 100.0  # 100 MHz
 print("corridor kernel ms", round(ms[4], 2), "segments", len(d))
+if os.environ.get("SOGM_CONTEND") == "2":
+    torch.cuda.synchronize()
+    print("SUMMARY wgs", os.environ.get("SOGM_CLEAR_WGS"), "throttle", os.environ.get("SOGM_CLEAR_THROTTLE"),
+          "| 2 x (clear+stamp) ms", round(ev0.elapsed_time(ev1), 2), "| corridor ms", round(ms[4], 2),
+          "| points us max/mean", round(d[:, 5].max() / 100.0, 1), round(d[:, 5].mean() / 100.0, 1))
 print("N pts: max/mean", d[:, 0].max(), d[:, 0].mean(), " nH0 max/mean", d[:, 1].max(), d[:, 1].mean(), " nH1 max", d[:, 2].max())
 print("lbfgs iters max/mean", d[:, 3].max(), d[:, 3].mean(), " evals max/mean", d[:, 4].max(), d[:, 4].mean())
 for name, col in (("points", 5), ("firi0 done", 6), ("mvie total", 7), ("  lbfgs", 9), ("firi1 done", 8), ("segment total", 10)):
