@@ -372,31 +372,11 @@ int osqpDense(const double *Pin, const double *qin, const double *Ain, const dou
       dy[i]           = rho[i] * (zr - z[i]);
       y[i] += dy[i];
     }
-    // adaptive rho (OSQP adapt_rho / compute_rho_estimate), on unscaled normalised residuals
-    if (qs->adaptive_rho_interval > 0 && iter % qs->adaptive_rho_interval == 0) {
-      bool p_ok, d_ok;
-      residuals(qs->eps_abs, qs->eps_rel, p_ok, d_ok);
-      const double pr_n = last_pr / (std::max(last_nAx, last_nz) + 1e-10);
-      const double du_n = last_dr / (std::max(std::max(last_nPx, last_nAty), last_nq) + 1e-10);
-      double       rho_new = rho_cur * std::sqrt(pr_n / (du_n + 1e-10));
-      rho_new              = std::min(std::max(rho_new, RHO_MIN), 1e6);
-      if (rho_new > rho_cur * 5.0 || rho_new < rho_cur / 5.0) {
-        rho_cur = rho_new;
-        for (int i = 0; i < m; ++i) {
-          if (l[i] < -OSQP_INFTY * MIN_SCALING && u[i] > OSQP_INFTY * MIN_SCALING)
-            rho[i] = RHO_MIN;
-          else if (u[i] - l[i] < RHO_TOL)
-            rho[i] = RHO_EQ_OVER_RHO_INEQ * rho_cur;
-          else
-            rho[i] = rho_cur;
-        }
-        factor();
-        if (!chol_ok) return -7;
-      }
-    }
-    if (qs->check_termination > 0 && iter % qs->check_termination == 0) {
-      bool p_ok, d_ok;
-      residuals(qs->eps_abs, qs->eps_rel, p_ok, d_ok);
+    const bool do_check = qs->check_termination > 0 && iter % qs->check_termination == 0;
+    const bool do_adapt = qs->adaptive_rho_interval > 0 && iter % qs->adaptive_rho_interval == 0;
+    bool       p_ok = false, d_ok = false;
+    if (do_check || do_adapt) residuals(qs->eps_abs, qs->eps_rel, p_ok, d_ok);
+    if (do_check) {
       if (p_ok && d_ok) {
         status = 1;
         break;
@@ -426,6 +406,27 @@ int osqpDense(const double *Pin, const double *qin, const double *Ain, const dou
             break;
           }
         }
+      }
+    }
+    // adaptive rho (OSQP adapt_rho / compute_rho_estimate), on unscaled normalised residuals; after the
+    // termination test, on the same residuals (osqp.c: update_info runs once per iteration)
+    if (do_adapt) {
+      const double pr_n = last_pr / (std::max(last_nAx, last_nz) + 1e-10);
+      const double du_n = last_dr / (std::max(std::max(last_nPx, last_nAty), last_nq) + 1e-10);
+      double       rho_new = rho_cur * std::sqrt(pr_n / (du_n + 1e-10));
+      rho_new              = std::min(std::max(rho_new, RHO_MIN), 1e6);
+      if (rho_new > rho_cur * 5.0 || rho_new < rho_cur / 5.0) {
+        rho_cur = rho_new;
+        for (int i = 0; i < m; ++i) {
+          if (l[i] < -OSQP_INFTY * MIN_SCALING && u[i] > OSQP_INFTY * MIN_SCALING)
+            rho[i] = RHO_MIN;
+          else if (u[i] - l[i] < RHO_TOL)
+            rho[i] = RHO_EQ_OVER_RHO_INEQ * rho_cur;
+          else
+            rho[i] = rho_cur;
+        }
+        factor();
+        if (!chol_ok) return -7;
       }
     }
   }

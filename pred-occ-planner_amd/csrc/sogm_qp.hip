@@ -152,7 +152,14 @@ __global__ __launch_bounds__(256) void k_qp(SogmPlannerParams pp, SogmQpSettings
                                             const int32_t *__restrict__ npoly,
                                             double *__restrict__ out_cpts,
                                             int32_t *__restrict__ out_status,
-                                            int32_t *__restrict__ out_iters, int ablate, int agent0) {
+                                            int32_t *__restrict__ out_iters, int ablate_arg, int agent0) {
+  // phase ablation is a profiling aid: compiled in only with -DSOGM_QP_ABLATE_BUILD (tools/qp_ablate.py)
+#ifdef SOGM_QP_ABLATE_BUILD
+  const int ablate = ablate_arg;
+#else
+  constexpr int ablate = 0;
+  (void)ablate_arg;
+#endif
   const int agent = blockIdx.x + agent0;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int M = npoly[agent];
@@ -925,7 +932,7 @@ __global__ __launch_bounds__(256) void k_qp(SogmPlannerParams pp, SogmQpSettings
     cj_nface = nface;
     cj_pd    = pd;
   }
-  const double  alpha = qs.alpha;
+  const double  alpha = qs.alpha, oma = 1.0 - qs.alpha;
   const double *xtv   = use_blocks ? s_cn : s_xt;  // where the solve leaves x~
   for (int j = n + tid; j < 128; j += 256) s_xt[j] = 0.0;  // the register mat-vec reads 120 entries
   __syncthreads();
@@ -961,12 +968,12 @@ __global__ __launch_bounds__(256) void k_qp(SogmPlannerParams pp, SogmQpSettings
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) p += a[u] * b[u];
+            for (int u = 0; u < 4; ++u) p = __builtin_fma(a[u], b[u], p);
           }
 #pragma unroll
-          for (int e = 0; e < 4; ++e) p += cv[e] * w[e];
+          for (int e = 0; e < 4; ++e) p = __builtin_fma(cv[e], w[e], p);
           p += dpp_quad(p, 0xB1);  // partner lane tid ^ 1
-          if (hh == 0) s_xt[launder(tid) >> 1] = qs.sigma * xj + p;  // q == 0
+          if (hh == 0) s_xt[launder(tid) >> 1] = __builtin_fma(qs.sigma, xj, p);  // q == 0
         }
       } else
       if (!(ablate & 1))
@@ -1004,29 +1011,29 @@ __global__ __launch_bounds__(256) void k_qp(SogmPlannerParams pp, SogmQpSettings
           const double xtj = xtv[t >> 1];
           __builtin_amdgcn_sched_barrier(0);
           {
-            double s = 0;
+            // fused multiply-adds: like the K^-1 product, the row update is not on a bit-exact path
+            double s = gv[0] * xg[0];
 #pragma unroll
-            for (int k = 0; k < QP_ELL; ++k) s += gv[k] * xg[k];
-            const double zr = alpha * s + (1.0 - alpha) * g_z;
-            double       v  = zr + g_rinv * g_y;  // OSQP update_z: rho_inv_vec[i] * y[i]
+            for (int k = 1; k < QP_ELL; ++k) s = __builtin_fma(gv[k], xg[k], s);
+            const double zr = __builtin_fma(alpha, s, oma * g_z);
+            double       v  = __builtin_fma(g_rinv, g_y, zr);  // OSQP update_z: rho_inv_vec[i] * y[i]
             v               = v < g_lo ? g_lo : (v > g_hi ? g_hi : v);
             g_z             = v;
             const double d  = g_rho * (zr - v);
             g_y             = g_y + d;
             if (grow) {
-              h_gw[t] = g_rho * v - g_y;
+              h_gw[t] = __builtin_fma(g_rho, v, -g_y);
               if (do_check) R.gdy[t] = d;
             }
           }
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
             if (256 * u >= S) continue;
-            double ax = 0;
-            ax += sv[u][0] * xs[u][0];
-            ax += sv[u][1] * xs[u][1];
-            ax += sv[u][2] * xs[u][2];
-            const double zr = alpha * ax + (1.0 - alpha) * s_zr[u];
-            double       v  = zr + rinv_cur * s_yr[u];
+            double ax = sv[u][0] * xs[u][0];
+            ax              = __builtin_fma(sv[u][1], xs[u][1], ax);
+            ax              = __builtin_fma(sv[u][2], xs[u][2], ax);
+            const double zr = __builtin_fma(alpha, ax, oma * s_zr[u]);
+            double       v  = __builtin_fma(rinv_cur, s_yr[u], zr);
             v               = v > s_hi[u] ? s_hi[u] : v;  // l = -OSQP_INFTY
             s_zr[u]         = v;
             const double d  = rho_cur * (zr - v);
@@ -1034,11 +1041,11 @@ __global__ __launch_bounds__(256) void k_qp(SogmPlannerParams pp, SogmQpSettings
             s_yr[u]         = yn;
             const int sr    = t + 256 * u;
             if (sr < S) {
-              h_sw[sr] = rho_cur * v - yn;
+              h_sw[sr] = __builtin_fma(rho_cur, v, -yn);
               if (do_check) R.sdy[sr] = d;
             }
           }
-          xj = alpha * xtj + (1.0 - alpha) * xj;
+          xj = __builtin_fma(alpha, xtj, oma * xj);
         }
         __syncthreads();
         if (do_adapt || do_check) fast_spill();
@@ -1083,30 +1090,8 @@ __global__ __launch_bounds__(256) void k_qp(SogmPlannerParams pp, SogmQpSettings
       for (int j = tid; j < n; j += 256) s_x[j] = alpha * xtv[j] + (1.0 - alpha) * s_x[j];
       __syncthreads();
       }
-      if (do_adapt) {
-        residuals();
-        const double pr_n = s_sc[0] / (dmax(s_sc[1], s_sc[2]) + 1e-10);
-        const double du_n =
-            s_sc[3] / (dmax(dmax(cinv * s_sc[4], cinv * s_sc[5]), cinv * s_sc[6]) + 1e-10);
-        double rho_new = rho_cur * sogm_det::sqrt_rn(pr_n / (du_n + 1e-10));
-        rho_new        = rho_new < RHO_MIN ? RHO_MIN : (rho_new > 1e6 ? 1e6 : rho_new);
-        if (rho_new > rho_cur * 5.0 || rho_new < rho_cur / 5.0) {
-          rho_cur  = rho_new;
-          rinv_cur = 1.0 / rho_cur;
-          set_rho();
-          if (!factor()) {
-            status = -7;
-            break;
-          }
-          if constexpr (FAST) {
-            fast_load();
-            fast_rho();
-            __syncthreads();
-          }
-        }
-      }
+      if (do_check || do_adapt) residuals();
       if (do_check) {
-        residuals();
         const double eps_prim = qs.eps_abs + qs.eps_rel * dmax(s_sc[1], s_sc[2]);
         const double eps_dual =
             qs.eps_abs + qs.eps_rel * cinv * dmax(dmax(s_sc[4], s_sc[5]), s_sc[6]);
@@ -1168,6 +1153,28 @@ __global__ __launch_bounds__(256) void k_qp(SogmPlannerParams pp, SogmQpSettings
               status = -3;
               break;
             }
+          }
+        }
+      }
+      // adaptive rho after the termination test, on the same residuals (osqp.c: update_info runs once)
+      if (do_adapt) {
+        const double pr_n = s_sc[0] / (dmax(s_sc[1], s_sc[2]) + 1e-10);
+        const double du_n =
+            s_sc[3] / (dmax(dmax(cinv * s_sc[4], cinv * s_sc[5]), cinv * s_sc[6]) + 1e-10);
+        double rho_new = rho_cur * sogm_det::sqrt_rn(pr_n / (du_n + 1e-10));
+        rho_new        = rho_new < RHO_MIN ? RHO_MIN : (rho_new > 1e6 ? 1e6 : rho_new);
+        if (rho_new > rho_cur * 5.0 || rho_new < rho_cur / 5.0) {
+          rho_cur  = rho_new;
+          rinv_cur = 1.0 / rho_cur;
+          set_rho();
+          if (!factor()) {
+            status = -7;
+            break;
+          }
+          if constexpr (FAST) {
+            fast_load();
+            fast_rho();
+            __syncthreads();
           }
         }
       }
