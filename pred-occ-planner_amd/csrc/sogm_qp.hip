@@ -186,6 +186,7 @@ __global__ __launch_bounds__(256) void k_qp(SogmPlannerParams pp, SogmQpSettings
   __shared__ double s_x[QP_NMAX], s_D[QP_NMAX], s_Dt[QP_NMAX];
   __shared__ __attribute__((aligned(16))) double s_cn[QP_NMAX];
   __shared__ double s_red[4];
+  __shared__ double s_red6[24];
   __shared__ double s_sc[8];
   __shared__ int    s_off[SOGM_MAX_PIECES + 1];  // safety-row offset of each piece
   __shared__ int    s_nf[SOGM_MAX_PIECES];
@@ -538,6 +539,20 @@ __global__ __launch_bounds__(256) void k_qp(SogmPlannerParams pp, SogmQpSettings
     if (tid == 0) s_flag = 1;
     __syncthreads();
     if (wave == 0) {
+      // trailing update of column j touches the (a, b) pairs 1 <= b <= a <= QP_BW: a lane's three pairs are the
+      // same for every column, so the triangular index decode runs once, not n times
+      int pa[3], pb[3];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const int e = lane + 64 * q;
+        int       a = 1, rem = e;
+        while (rem >= a) {
+          rem -= a;
+          ++a;
+        }
+        pa[q] = e < (QP_BW * (QP_BW + 1)) / 2 ? a : 0;
+        pb[q] = rem + 1;
+      }
       for (int j = 0; j < n; ++j) {
         const double djj = KB(s_Kb, j, j);
         if (!(djj > 0)) {
@@ -552,14 +567,10 @@ __global__ __launch_bounds__(256) void k_qp(SogmPlannerParams pp, SogmQpSettings
         if (lane >= 1 && lane <= QP_BW && j + lane < n) KB(s_Kb, j + lane, j) = KB(s_Kb, j + lane, j) * inv;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         __builtin_amdgcn_wave_barrier();
-        for (int e = lane; e < (QP_BW * (QP_BW + 1)) / 2; e += 64) {
-          int a = 1, rem = e;
-          while (rem >= a) {
-            rem -= a;
-            ++a;
-          }
-          const int b = rem + 1;
-          if (j + a < n) KB(s_Kb, j + a, j + b) -= KB(s_Kb, j + a, j) * KB(s_Kb, j + b, j);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          const int a = pa[q], b = pb[q];
+          if (a > 0 && j + a < n) KB(s_Kb, j + a, j + b) -= KB(s_Kb, j + a, j) * KB(s_Kb, j + b, j);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         __builtin_amdgcn_wave_barrier();
@@ -763,9 +774,7 @@ __global__ __launch_bounds__(256) void k_qp(SogmPlannerParams pp, SogmQpSettings
       nz             = dmax(nz, dabs(R.gz[r] / e));
     }
     for (int s = tid; s < S; s += 256) {
-      int i = 0;
-      while (i + 1 < M && s >= s_off[i + 1]) ++i;
-      const int     c0 = i * 15 + ((s - s_off[i]) % 5) * 3;
+      const int     c0 = R.sc0[s];
       const double *v  = R.sval + (size_t)s * 3;
       double        ax = 0;
       ax += v[0] * s_x[c0];
@@ -788,22 +797,29 @@ __global__ __launch_bounds__(256) void k_qp(SogmPlannerParams pp, SogmQpSettings
       nPx             = dmax(nPx, dabs(s / dj));
       nAty            = dmax(nAty, dabs(a / dj));
     }
-    pr   = block_max(pr, s_red);
-    nAx  = block_max(nAx, s_red);
-    nz   = block_max(nz, s_red);
-    dr   = block_max(dr, s_red);
-    nPx  = block_max(nPx, s_red);
-    nAty = block_max(nAty, s_red);
+    // the six maxima share one wave-reduce / LDS / barrier round
+    pr   = wave_max(pr);
+    nAx  = wave_max(nAx);
+    nz   = wave_max(nz);
+    dr   = wave_max(dr);
+    nPx  = wave_max(nPx);
+    nAty = wave_max(nAty);
     __syncthreads();
-    if (tid == 0) {
-      s_sc[0] = pr;
-      s_sc[1] = nAx;
-      s_sc[2] = nz;
-      s_sc[3] = dr * cinv;
-      s_sc[4] = nPx;
-      s_sc[5] = nAty;
-      s_sc[6] = 0.0;
+    if (lane == 0) {
+      double *o = s_red6 + wave * 6;
+      o[0]      = pr;
+      o[1]      = nAx;
+      o[2]      = nz;
+      o[3]      = dr;
+      o[4]      = nPx;
+      o[5]      = nAty;
     }
+    __syncthreads();
+    if (tid < 6) {
+      const double m = dmax(dmax(s_red6[tid], s_red6[6 + tid]), dmax(s_red6[12 + tid], s_red6[18 + tid]));
+      s_sc[tid]      = tid == 3 ? m * cinv : m;
+    }
+    if (tid == 6) s_sc[6] = 0.0;
     __syncthreads();
   };
 

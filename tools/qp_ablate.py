@@ -22,8 +22,10 @@ c = P.generateCorridors(pva, t_start, s["route"], s["route_len"])
 qs = pop.config.make_qp_settings()
 NIT = int(os.environ.get('SOGM_QP_ITERS', '1000'))
 qs.max_iter = NIT
-qs.check_termination = 0
-qs.adaptive_rho_interval = 0
+qs.check_termination = int(os.environ.get('SOGM_QP_CHECK', '0'))
+qs.adaptive_rho_interval = int(os.environ.get('SOGM_QP_ADAPT', '0'))
+if qs.check_termination:
+    qs.eps_abs = qs.eps_rel = 1e-13  # never converges: fixed iteration count with the checks running
 P2 = planner.SogmPlanner(sw.map, pop.config.make_astar_params(), pop.config.make_planner_params(True), qs)
 for _ in range(2):
     q = P2.optimize(pva, c["goal"], c["polys"], c["nfaces"], c["npoly"])
