@@ -121,7 +121,7 @@ int sogm_planner_create(sogm_ctx *map, const SogmAstarParams *astar, const SogmP
     if (e == hipSuccess) e = hipMalloc((void **)&p->cw.seg_dbg, sizeof(long long) * 16 * slots);
     // QP row storage fallback (rows normally live in LDS)
     p->qw.scratch_stride = qp_scratch_bytes_per_agent(pp->max_faces);
-    p->qw.dyn_lds_bytes  = 144 * 1024;  // 160 KiB/CU minus k_qp's ~14 KiB of static LDS
+    p->qw.dyn_lds_bytes  = qp_dynamic_lds_bytes();  // 160 KiB/CU minus k_qp's static LDS
     if (e == hipSuccess) e = hipMalloc((void **)&p->qw.scratch, p->qw.scratch_stride * (size_t)A);
     min_jerk_block(p->qc.QM);
     if (e == hipSuccess) e = hipMalloc((void **)&p->d_polys, sizeof(double) * slots * pp->max_faces * 4);

@@ -45,6 +45,7 @@ struct QpWorkspace {
   int    dyn_lds_bytes;   // dynamic LDS per workgroup of k_qp
 };
 size_t qp_scratch_bytes_per_agent(int max_faces);
+int    qp_dynamic_lds_bytes();
 struct QpConst {
   double QM[225];  // per-piece min-jerk cost block (bezier_optimizer.cpp:96-111)
 };

@@ -41,6 +41,7 @@ namespace {
 #define QP_BW 17  // half bandwidth of K
 #define QP_NMAX (15 * SOGM_MAX_PIECES)
 #define QP_ELL 6
+#define QP_NT 512  // lanes per workgroup (8 waves: two per SIMD)
 
 __device__ const double OSQP_INFTY  = 1e30;
 __device__ const double MIN_SCALING = 1e-04, MAX_SCALING = 1e+04;
@@ -66,7 +67,8 @@ __device__ inline double block_max(double v, double *s_red) {
   __syncthreads();
   if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
   __syncthreads();
-  return dmax(dmax(s_red[0], s_red[1]), dmax(s_red[2], s_red[3]));
+  return dmax(dmax(dmax(s_red[0], s_red[1]), dmax(s_red[2], s_red[3])),
+              dmax(dmax(s_red[4], s_red[5]), dmax(s_red[6], s_red[7])));
 }
 
 // Row storage (LDS or HBM scratch).  The "hot" arrays are the only row data the register-resident ADMM
@@ -144,7 +146,7 @@ size_t qp_scratch_bytes_per_agent(int max_faces) {
   return (rows_bytes(G, S) + 255) & ~(size_t)255;
 }
 
-__global__ __launch_bounds__(256) void k_qp(SogmPlannerParams pp, SogmQpSettings qs, QpWorkspace ws,
+__global__ __launch_bounds__(QP_NT) void k_qp(SogmPlannerParams pp, SogmQpSettings qs, QpWorkspace ws,
                                             QpConst qc, const double *__restrict__ start_pva,
                                             const double *__restrict__ goal_pv,
                                             const double *__restrict__ polys,
@@ -185,8 +187,9 @@ __global__ __launch_bounds__(256) void k_qp(SogmPlannerParams pp, SogmQpSettings
   __shared__ __attribute__((aligned(16))) double s_xt[QP_NMAX];
   __shared__ double s_x[QP_NMAX], s_D[QP_NMAX], s_Dt[QP_NMAX];
   __shared__ __attribute__((aligned(16))) double s_cn[QP_NMAX];
-  __shared__ double s_red[4];
-  __shared__ double s_red6[24];
+  __shared__ double s_red[8];
+  __shared__ double s_T[2][225];  // factor(): running 15 x 15 block of the X row chains
+  __shared__ double s_red6[48];
   __shared__ double s_sc[8];
   __shared__ int    s_off[SOGM_MAX_PIECES + 1];  // safety-row offset of each piece
   __shared__ int    s_nf[SOGM_MAX_PIECES];
@@ -207,13 +210,14 @@ __global__ __launch_bounds__(256) void k_qp(SogmPlannerParams pp, SogmQpSettings
   __syncthreads();
   const int R1 = 3 * (M + 1), R3 = 9 * (M + 1), R4 = R3 + 12 * M, G = R4 + 9 * M;
   const int S = s_off[M];
-  const size_t head =
-      ((size_t)n * (QP_BW + 1) + (size_t)M * 225 * (use_blocks ? 3 : 1)) * sizeof(double);
-  const bool rows_in_lds = head + rows_bytes(G, S) <= (size_t)ws.dyn_lds_bytes;
-  // Register-resident iteration: one general row and up to four safety rows per lane, K^-1 rows in
-  // registers; needs only the hot row arrays in LDS.
-  const bool fast = use_blocks && G <= 256 && S <= 1024 &&
-                    head + rows_hot_bytes(G, S) <= (size_t)ws.dyn_lds_bytes;
+  // Register-resident iteration (FAST): K^-1 rows, one general row or up to four safety rows per lane in
+  // registers; needs the block form of the factor (M <= 8) and only the hot row arrays in LDS.
+  const size_t head1 = ((size_t)n * (QP_BW + 1) + (size_t)M * 225) * sizeof(double);
+  const size_t head3 = ((size_t)n * (QP_BW + 1) + (size_t)M * 225 * 3) * sizeof(double);
+  const bool   fast  = use_blocks && G <= 256 && S <= 1024 &&
+                    head3 + rows_hot_bytes(G, S) <= (size_t)ws.dyn_lds_bytes;
+  const size_t head        = fast ? head3 : head1;
+  const bool   rows_in_lds = head + rows_bytes(G, S) <= (size_t)ws.dyn_lds_bytes;
   // The solver body is instantiated twice (forced inline): once with every row pointer derived from
   // the LDS array — so the compiler emits ds_read/ds_write instead of flat accesses — and once for
   // the HBM-scratch fallback.
@@ -225,7 +229,7 @@ __global__ __launch_bounds__(256) void k_qp(SogmPlannerParams pp, SogmQpSettings
   const double  vmax = pp.opt_max_vel, amax = pp.opt_max_acc;
 
   // ---- 1. assembly (bezier_optimizer.cpp:113-260): general rows in ELL, one lane per row
-  for (int r = tid; r < G; r += 256) {
+  for (int r = tid; r < G; r += QP_NT) {
     int    col[QP_ELL];
     double val[QP_ELL];
     for (int k = 0; k < QP_ELL; ++k) {
@@ -327,7 +331,7 @@ __global__ __launch_bounds__(256) void k_qp(SogmPlannerParams pp, SogmQpSettings
     R.gy[r] = 0.0;
   }
   // safety rows: one lane per row (explicit zero coefficients simply stay zero)
-  for (int s = tid; s < S; s += 256) {
+  for (int s = tid; s < S; s += QP_NT) {
     int i = 0;
     while (i + 1 < M && s >= s_off[i + 1]) ++i;
     const int     q = s - s_off[i], face = q / 5;
@@ -342,16 +346,16 @@ __global__ __launch_bounds__(256) void k_qp(SogmPlannerParams pp, SogmQpSettings
     R.sw[s] = 0.0;
     R.sc0[s] = i * 15 + (q % 5) * 3;
   }
-  for (int i = tid; i < M * 225; i += 256) s_P[i] = qc.QM[i % 225];
-  for (int j = tid; j < n; j += 256) {
+  for (int i = tid; i < M * 225; i += QP_NT) s_P[i] = qc.QM[i % 225];
+  for (int j = tid; j < n; j += QP_NT) {
     s_D[j] = 1.0;
     s_x[j] = 0.0;
   }
-  for (int j = tid; j <= n; j += 256) s_cnt[j] = 0;
+  for (int j = tid; j <= n; j += QP_NT) s_cnt[j] = 0;
   __syncthreads();
 
   // ---- 2. CSC index of the general rows (row-sorted inside each column)
-  for (int r = tid; r < G; r += 256)
+  for (int r = tid; r < G; r += QP_NT)
     for (int k = 0; k < QP_ELL; ++k) {
       const int c = R.gcol[(size_t)r * QP_ELL + k];
       if (c >= 0) atomicAdd(&s_cnt[c], 1);
@@ -367,7 +371,7 @@ __global__ __launch_bounds__(256) void k_qp(SogmPlannerParams pp, SogmQpSettings
     s_cptr[n] = acc;
   }
   __syncthreads();
-  for (int r = tid; r < G; r += 256)
+  for (int r = tid; r < G; r += QP_NT)
     for (int k = 0; k < QP_ELL; ++k) {
       const int c = R.gcol[(size_t)r * QP_ELL + k];
       if (c >= 0) {
@@ -376,7 +380,7 @@ __global__ __launch_bounds__(256) void k_qp(SogmPlannerParams pp, SogmQpSettings
       }
     }
   __syncthreads();
-  for (int j = tid; j < n; j += 256) {
+  for (int j = tid; j < n; j += QP_NT) {
     const int b = s_cptr[j], e = s_cptr[j + 1];
     for (int a = b + 1; a < e; ++a) {
       const int v = R.cidx[a];
@@ -399,7 +403,7 @@ __global__ __launch_bounds__(256) void k_qp(SogmPlannerParams pp, SogmQpSettings
   // ---- 3. Ruiz equilibration with cost scaling (OSQP scale_data)
   double c_scale = 1.0;
   for (int it = 0; it < qs.scaling_iters; ++it) {
-    for (int j = tid; j < n; j += 256) {
+    for (int j = tid; j < n; j += QP_NT) {
       double        mx = 0;
       const double *Pb = s_P + (j / 15) * 225;
       const int     jj = j % 15;
@@ -413,7 +417,7 @@ __global__ __launch_bounds__(256) void k_qp(SogmPlannerParams pp, SogmQpSettings
       s_Dt[j] = 1.0 / sogm_det::sqrt_rn(limit_scaling(mx));
     }
     __syncthreads();
-    for (int r = tid; r < G; r += 256) {
+    for (int r = tid; r < G; r += QP_NT) {
       double mx = 0;
       for (int k = 0; k < QP_ELL; ++k)
         if (R.gcol[(size_t)r * QP_ELL + k] >= 0) mx = dmax(mx, dabs(R.gval[(size_t)r * QP_ELL + k]));
@@ -424,7 +428,7 @@ __global__ __launch_bounds__(256) void k_qp(SogmPlannerParams pp, SogmQpSettings
       }
       R.gE[r] *= et;
     }
-    for (int s = tid; s < S; s += 256) {
+    for (int s = tid; s < S; s += QP_NT) {
       int i = 0;
       while (i + 1 < M && s >= s_off[i + 1]) ++i;
       const int    k  = (s - s_off[i]) % 5;
@@ -437,13 +441,13 @@ __global__ __launch_bounds__(256) void k_qp(SogmPlannerParams pp, SogmQpSettings
       v[2] *= et * s_Dt[c0 + 2];
       R.sE[s] *= et;
     }
-    for (int i = tid; i < M * 225; i += 256) {
+    for (int i = tid; i < M * 225; i += QP_NT) {
       const int b = i / 225, rr = (i % 225) / 15, cc = i % 15;
       s_P[i] *= s_Dt[b * 15 + rr] * s_Dt[b * 15 + cc];
     }
-    for (int j = tid; j < n; j += 256) s_D[j] *= s_Dt[j];
+    for (int j = tid; j < n; j += QP_NT) s_D[j] *= s_Dt[j];
     __syncthreads();
-    for (int j = tid; j < n; j += 256) {
+    for (int j = tid; j < n; j += QP_NT) {
       double        mx = 0;
       const double *Pb = s_P + (j / 15) * 225;
       const int     jj = j % 15;
@@ -461,33 +465,32 @@ __global__ __launch_bounds__(256) void k_qp(SogmPlannerParams pp, SogmQpSettings
     }
     __syncthreads();
     const double ct = s_sc[0];
-    for (int i = tid; i < M * 225; i += 256) s_P[i] *= ct;
+    for (int i = tid; i < M * 225; i += QP_NT) s_P[i] *= ct;
     c_scale *= ct;
     __syncthreads();
   }
-  for (int r = tid; r < G; r += 256) {
+  for (int r = tid; r < G; r += QP_NT) {
     R.gl[r] *= R.gE[r];
     R.gu[r] *= R.gE[r];
   }
-  for (int s = tid; s < S; s += 256) R.su[s] *= R.sE[s];
+  for (int s = tid; s < S; s += QP_NT) R.su[s] *= R.sE[s];
   const double cinv = 1.0 / c_scale;
   __syncthreads();
 
   // ---- helpers -----------------------------------------------------------------------------------
   double rho_cur = qs.rho;  // safety rows are one-sided inequalities: their rho is rho_cur itself
   double rinv_cur = 1.0 / rho_cur;
-  // Row rho of K^-1 = X^T X (X = G^-1, block lower triangular), columns 60 hh .. 60 hh + 59 (zero beyond n),
+  // Row rho of K^-1 = X^T X (X = G^-1, block lower triangular), columns 30 q .. 30 q + 29 (zero beyond n),
   // rebuilt after every factorisation: the per-iteration solve is ONE register mat-vec and one barrier.
-  // A row is 120 doubles — more than one lane's VGPR file — so two adjacent lanes share it and the two
-  // partial dot products meet through one DPP exchange.
-  double    kinv[60] = {};
-  const int rho_l = tid >> 1, hh = tid & 1;
+  // Four adjacent lanes share a row (30 doubles = 60 VGPRs each); the partial dot products meet through two
+  // DPP exchanges.
+  double    kinv[30] = {};
   auto   set_rho = [&]() {
     // lane ids re-derived from an opaque copy: nothing in here is hoisted out of the ADMM loop
     const int tid = launder((int)threadIdx.x), lane = tid & 63, wave = tid >> 6;
     (void)lane;
     (void)wave;
-    for (int r = tid; r < G; r += 256) {
+    for (int r = tid; r < G; r += QP_NT) {
       const double lo = R.gl[r], hi = R.gu[r];
       double       v;
       if (lo < -OSQP_INFTY * MIN_SCALING && hi > OSQP_INFTY * MIN_SCALING)
@@ -499,7 +502,7 @@ __global__ __launch_bounds__(256) void k_qp(SogmPlannerParams pp, SogmQpSettings
       R.grho[r]  = v;
       R.grinv[r] = 1.0 / v;
     }
-    for (int s = tid; s < S; s += 256) R.sw[s] = rho_cur * R.sz[s] - R.sy[s];
+    for (int s = tid; s < S; s += QP_NT) R.sw[s] = rho_cur * R.sz[s] - R.sy[s];
     __syncthreads();
   };
   // K band = P + sigma I + A^T diag(rho) A (rows in global row order: general, then safety),
@@ -509,11 +512,7 @@ __global__ __launch_bounds__(256) void k_qp(SogmPlannerParams pp, SogmQpSettings
     const int tid = launder((int)threadIdx.x), lane = tid & 63, wave = tid >> 6;
     (void)lane;
     (void)wave;
-    const int rho_l = tid >> 1, hh = tid & 1, bi = rho_l / 15, rc = rho_l % 15, k0 = hh * 8;
-    (void)bi;
-    (void)rc;
-    (void)k0;
-    for (int e = tid; e < n * (QP_BW + 1); e += 256) {
+    for (int e = tid; e < n * (QP_BW + 1); e += QP_NT) {
       const int i = e / (QP_BW + 1), dlt = e % (QP_BW + 1), j = i - dlt;
       double    s = 0.0;
       if (j >= 0) {
@@ -577,8 +576,8 @@ __global__ __launch_bounds__(256) void k_qp(SogmPlannerParams pp, SogmQpSettings
       }
     }
     __syncthreads();
-    if (use_blocks && s_flag) {
-      for (int e = tid; e < M * 225; e += 256) {
+    if (FAST && s_flag) {
+      for (int e = tid; e < M * 225; e += QP_NT) {
         const int b = e / 225, r = (e % 225) / 15, c = e % 15;
         const int row = b * 15 + r, col = (b - 1) * 15 + c;
         s_Goff[e] = (b > 0 && row - col <= QP_BW) ? KB(s_Kb, row, col) : 0.0;
@@ -586,7 +585,7 @@ __global__ __launch_bounds__(256) void k_qp(SogmPlannerParams pp, SogmQpSettings
       }
       __syncthreads();
       // column c of inv(Gd_b): forward substitution, one lane per (block, column)
-      for (int e = tid; e < M * 15; e += 256) {
+      for (int e = tid; e < M * 15; e += QP_NT) {
         const int b = e / 15, c = e % 15, o = b * 15;
         double    v[15];
         for (int r = 0; r < 15; ++r) v[r] = 0.0;
@@ -600,10 +599,10 @@ __global__ __launch_bounds__(256) void k_qp(SogmPlannerParams pp, SogmQpSettings
       }
       __syncthreads();
       // W_b = Ginv_b G(b, b-1) (into the now idle band storage): X(i, j) = (-W_i) ... (-W_{j+1}) Ginv_j
-      double wv[8];
+      double wv[4];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int e = tid + q * 256;
+      for (int q = 0; q < 4; ++q) {
+        const int e = tid + q * QP_NT;
         wv[q]       = 0.0;
         if (e < M * 225) {
           const int b = e / 225, r = (e % 225) / 15, c = e % 15;
@@ -616,81 +615,55 @@ __global__ __launch_bounds__(256) void k_qp(SogmPlannerParams pp, SogmQpSettings
       }
       __syncthreads();
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int e = tid + q * 256;
+      for (int q = 0; q < 4; ++q) {
+        const int e = tid + q * QP_NT;
         if (e < M * 225) s_Kb[e] = wv[q];
       }
       __syncthreads();
-      // Row rho of X lives in registers only while K^-1 is built: lane h = tid & 1 keeps entries
-      // k = 8 h .. 8 h + 7 of every 15-entry block part.
-      double xr[8][8];
-#pragma unroll
-      for (int jb = 0; jb < 8; ++jb)
-#pragma unroll
-        for (int kk = 0; kk < 8; ++kk) xr[jb][kk] = 0.0;
-      if (tid < 2 * n) {
-        const double *s_W = s_Kb;
-        // row rho of X, block column by block column (right to left):  t <- -t W_j
-        double t[15];
-#pragma unroll
-        for (int k = 0; k < 15; ++k) t[k] = (k == rc) ? 1.0 : 0.0;
-#pragma unroll
-        for (int jb = 7; jb >= 0; --jb) {
-          if (jb < M) {
-            const double *Gj = s_Ginv + jb * 225, *Wj = s_W + jb * 225;
-            double        part[15], nt[15];
-#pragma unroll
-            for (int c = 0; c < 15; ++c) {
-              double a0 = 0.0, a1 = 0.0;
-#pragma unroll
-              for (int k = 0; k < 15; ++k) {
-                a0 += t[k] * Gj[k * 15 + c];
-                a1 += t[k] * Wj[k * 15 + c];
-              }
-              part[c] = a0;
-              nt[c]   = -a1;
-            }
-            if (jb <= bi) {
-#pragma unroll
-              for (int c = 0; c < 15; ++c) t[c] = nt[c];
-#pragma unroll
-              for (int kk = 0; kk < 8; ++kk) xr[jb][kk] = hh ? (kk < 7 ? part[8 + kk] : 0.0) : part[kk];
-            }
-          }
-        }
-      }
-      // K^-1 = X^T X, one block row of X at a time through LDS (s_Goff is free now: 15 x n doubles).
-      // Lane (rho, hh) accumulates  kinv[kk] += X[r][rho] * X[r][60 hh + kk]  over the rows r of X.
+      // K^-1 = X^T X, one block row of X at a time.  Block row ib of X = G^-1 is built in LDS by the whole
+      // workgroup: T starts as the identity; for jb = ib .. 0  X(ib, jb) = T Ginv_jb  and  T <- -T W_jb  (the
+      // same dot products, in the same k order, as a per-row chain would run — but 450 of them side by side:
+      // lanes 0..224 produce X(ib, jb), lanes 256..480 the next T).  `stage` (s_Goff is free now: 15 x n
+      // doubles) then holds rows 15 ib .. 15 ib + 14 of X and every lane (rho, q) accumulates
+      //   kinv[kk] += X[r][rho] * X[r][30 q + kk]      over those rows.
       {
-        double *stage = s_Goff;
+        const double *s_W   = s_Kb;
+        double       *stage = s_Goff;
+        const int     rho4 = tid >> 2, q4 = tid & 3, bi4 = rho4 / 15;
 #pragma unroll
-        for (int kk = 0; kk < 60; ++kk) kinv[kk] = 0.0;
+        for (int kk = 0; kk < 30; ++kk) kinv[kk] = 0.0;
+        for (int ib = 0; ib < M; ++ib) {  // uniform
+          __syncthreads();                // previous round's readers of stage / s_T are done
+          if (tid < 225) s_T[0][tid] = (tid / 15 == tid % 15) ? 1.0 : 0.0;
+          for (int e = tid; e < 15 * n; e += QP_NT)
+            if (e % n >= (ib + 1) * 15) stage[e] = 0.0;  // X(ib, jb) = 0 for jb > ib
+          __syncthreads();
+          int cur = 0;
+          for (int jb = ib; jb >= 0; --jb) {
+            const int role = tid >> 8, e = tid & 255;
+            if (e < 225) {
+              const int     r = e / 15, c = e % 15;
+              const double *T = s_T[cur] + r * 15;
+              const double *B = (role == 0 ? s_Ginv : s_W) + jb * 225 + c;
+              double        a = 0.0;
 #pragma unroll
-        for (int ib = 0; ib < 8; ++ib) {
-          if (ib < M) {  // uniform
-            __syncthreads();
-            if (tid < 2 * n && bi == ib) {  // the 30 lanes holding the rows of block ib publish them
-#pragma unroll
-              for (int jb = 0; jb < 8; ++jb) {
-                if (jb < M) {
-#pragma unroll
-                  for (int kk = 0; kk < 8; ++kk) {
-                    const int k = k0 + kk;
-                    if (k < 15) stage[rc * n + jb * 15 + k] = jb <= ib ? xr[jb][kk] : 0.0;
-                  }
-                }
-              }
+              for (int k = 0; k < 15; ++k) a += T[k] * B[k * 15];
+              if (role == 0)
+                stage[r * n + jb * 15 + c] = a;
+              else
+                s_T[cur ^ 1][e] = -a;
             }
+            cur ^= 1;
             __syncthreads();
-            if (tid < 2 * n && bi <= ib) {  // X[block row ib][rho] is zero for later blocks
-              const int kend = (ib + 1) * 15 - 60 * hh;  // columns of this half that can be non-zero
-              for (int r = 0; r < 15; ++r) {
-                const double  xj  = stage[r * n + rho_l];
-                const double *row = stage + r * n + 60 * hh;
+          }
+          if (tid < 4 * n && bi4 <= ib) {  // X[block row ib][rho] is zero for later blocks
+            const int kend = (ib + 1) * 15 - 30 * q4;  // columns of this quarter that can be non-zero
+            for (int r = 0; r < 15; ++r) {
+              const double  xj  = stage[r * n + rho4];
+              const double *row = stage + r * n + 30 * q4;
 #pragma unroll
-                for (int kk = 0; kk < 60; ++kk)
-                  if (kk < kend) kinv[kk] = __builtin_fma(xj, row[kk], kinv[kk]);
-              }
+              for (int kk = 0; kk < 30; ++kk)
+                if (kk < kend) kinv[kk] = __builtin_fma(xj, row[kk], kinv[kk]);
             }
           }
         }
@@ -700,29 +673,27 @@ __global__ __launch_bounds__(256) void k_qp(SogmPlannerParams pp, SogmQpSettings
     return s_flag != 0;
   };
   auto solveK = [&]() __attribute__((always_inline)) {
-    if (use_blocks) {
-      // x~ = K^-1 rhs: one register mat-vec per lane pair (fused multiply-adds: this solve is not on the
-      // bit-exact path — the oracle factors K with a plain banded Cholesky — and every VALU instruction of a
-      // 64-lane wave costs 4 cycles).  s_xt is zero beyond n, kinv too.  The result goes to s_cn.
-      {
-        const bool    on  = tid < 2 * n;
-        const double *rhs = s_xt + 60 * hh;
-        double        acc = 0.0, acc1 = 0.0;  // two chains: a dependent fp64 FMA stalls a lone wave
+    if constexpr (FAST) {
+      // x~ = K^-1 rhs: one register mat-vec per lane quad (fused multiply-adds: this solve is not on the
+      // bit-exact path — the oracle factors K with a plain banded Cholesky).  s_xt is zero beyond n, kinv too.
+      // The result goes to s_cn.
+      const double *rhs = s_xt + 30 * (tid & 3);
+      double        acc = 0.0, acc1 = 0.0;  // two chains: a dependent fp64 FMA costs 8 cycles, an independent one 4
 #pragma unroll
-        for (int c0 = 0; c0 < 60; c0 += 20) {
-          double v[20];  // 10 ds_read_b128 in flight per batch
+      for (int c0 = 0; c0 < 30; c0 += 16) {
+        double v[16];  // 8 (then 7) ds_read_b128 in flight
 #pragma unroll
-          for (int kk = 0; kk < 20; ++kk) v[kk] = rhs[c0 + kk];
+        for (int kk = 0; kk < 16; ++kk) v[kk] = c0 + kk < 30 ? rhs[c0 + kk] : 0.0;
 #pragma unroll
-          for (int kk = 0; kk < 20; kk += 2) {
-            acc  = __builtin_fma(kinv[c0 + kk], v[kk], acc);
-            acc1 = __builtin_fma(kinv[c0 + kk + 1], v[kk + 1], acc1);
-          }
+        for (int kk = 0; kk < 16; kk += 2) {
+          if (c0 + kk < 30) acc = __builtin_fma(kinv[c0 + kk], v[kk], acc);
+          if (c0 + kk + 1 < 30) acc1 = __builtin_fma(kinv[c0 + kk + 1], v[kk + 1], acc1);
         }
-        acc += acc1;
-        acc += dpp_quad(acc, 0xB1);  // partner lane tid ^ 1
-        if (on && hh == 0) s_cn[rho_l] = acc;
       }
+      acc += acc1;
+      acc += dpp_quad(acc, 0xB1);  // lane ^ 1
+      acc += dpp_quad(acc, 0x4E);  // lane ^ 2
+      if (tid < 4 * n && (tid & 3) == 0) s_cn[tid >> 2] = acc;
     } else if (wave == 0) {
       for (int j = 0; j < n; ++j) {  // G y = b
         const double xj = s_xt[j] * s_ginv[j];
@@ -762,7 +733,7 @@ __global__ __launch_bounds__(256) void k_qp(SogmPlannerParams pp, SogmQpSettings
     (void)lane;
     (void)wave;
     double pr = 0, nAx = 0, nz = 0;
-    for (int r = tid; r < G; r += 256) {
+    for (int r = tid; r < G; r += QP_NT) {
       double s = 0;
       for (int k = 0; k < QP_ELL; ++k) {
         const int c = R.gcol[(size_t)r * QP_ELL + k];
@@ -773,7 +744,7 @@ __global__ __launch_bounds__(256) void k_qp(SogmPlannerParams pp, SogmQpSettings
       nAx            = dmax(nAx, dabs(s / e));
       nz             = dmax(nz, dabs(R.gz[r] / e));
     }
-    for (int s = tid; s < S; s += 256) {
+    for (int s = tid; s < S; s += QP_NT) {
       const int     c0 = R.sc0[s];
       const double *v  = R.sval + (size_t)s * 3;
       double        ax = 0;
@@ -786,7 +757,7 @@ __global__ __launch_bounds__(256) void k_qp(SogmPlannerParams pp, SogmQpSettings
       nz             = dmax(nz, dabs(R.sz[s] / e));
     }
     double dr = 0, nPx = 0, nAty = 0;
-    for (int j = tid; j < n; j += 256) {
+    for (int j = tid; j < n; j += QP_NT) {
       double        s  = 0;
       const double *Pb = s_P + (j / 15) * 225 + (j % 15) * 15;
       const int     b0 = (j / 15) * 15;
@@ -816,7 +787,8 @@ __global__ __launch_bounds__(256) void k_qp(SogmPlannerParams pp, SogmQpSettings
     }
     __syncthreads();
     if (tid < 6) {
-      const double m = dmax(dmax(s_red6[tid], s_red6[6 + tid]), dmax(s_red6[12 + tid], s_red6[18 + tid]));
+      double m = s_red6[tid];
+      for (int w = 1; w < QP_NT / 64; ++w) m = dmax(m, s_red6[6 * w + tid]);
       s_sc[tid]      = tid == 3 ? m * cinv : m;
     }
     if (tid == 6) s_sc[6] = 0.0;
@@ -824,80 +796,95 @@ __global__ __launch_bounds__(256) void k_qp(SogmPlannerParams pp, SogmQpSettings
   };
 
   // ---- register-resident row / column state of the fast iteration ------------------------------------
-  // Row roles: general row r = tid, safety rows s = tid + 256 u (u < 4).  Column role: lane pair
-  // (j = tid >> 1, hh = tid & 1) shares column j — its K^-1 row, its x_j and the A^T w product, whose
-  // entries (<= 7 general rows, nface safety rows) alternate between the two lanes.
+  // Row roles: lanes 0..255 (waves 0-3) own general row r = tid; lanes 256..511 (waves 4-7) own safety rows
+  // s = (tid - 256) + 256 u (u < 4) — two waves per SIMD, one of each kind.  Column role: the lane quad
+  // (j = tid >> 2, q = tid & 3) shares column j — its K^-1 row, its x_j and the A^T w product, whose entries
+  // (<= 7 general rows, nface safety rows) are dealt round-robin to the four lanes.
   double *const h_sv = (double *)(qp_smem + head);  // == R.sval / R.sw / R.gw when fast, typed as LDS
   double *const h_sw = h_sv + (size_t)S * 3;
   double *const h_gw = h_sw + S;
-  double gv[QP_ELL], g_rho = 1.0, g_rinv = 1.0, g_lo = 0.0, g_hi = 0.0, g_z = 0.0, g_y = 0.0;
-  int    gc[QP_ELL];
-  double sv[4][3], s_hi[4], s_zr[4], s_yr[4];
-  int    s_c[4];
-  double cv[4], xj = 0.0;
-  int    cr[4];
+  // A lane is EITHER a general-row lane or a safety-row lane (wave-uniform), so the two kinds of row state
+  // share one set of registers: rs[0..5] = gv | rs[6] rho, [7] 1/rho, [8] l, [9] u, [10] z, [11] y (general)
+  //                             rs[6u + 0..2] = normal, [6u + 3] = u, [6u + 4] = z, [6u + 5] = y  (safety slot u)
+  double rs[24];
+  int    ri[QP_ELL];  // gc[k] | s_c[u]
+#define gv(k) rs[k]
+#define gc(k) ri[k]
+#define g_rho rs[6]
+#define g_rinv rs[7]
+#define g_lo rs[8]
+#define g_hi rs[9]
+#define g_z rs[10]
+#define g_y rs[11]
+#define sv(u, d) rs[6 * (u) + (d)]
+#define s_hi(u) rs[6 * (u) + 3]
+#define s_zr(u) rs[6 * (u) + 4]
+#define s_yr(u) rs[6 * (u) + 5]
+#define s_c(u) ri[u]
+  double cv[2], xj = 0.0;
+  int    cr[2];
 #pragma unroll
-  for (int k = 0; k < QP_ELL; ++k) {
-    gv[k] = 0.0;
-    gc[k] = 0;
-  }
+  for (int k = 0; k < 24; ++k) rs[k] = 0.0;
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    sv[u][0] = sv[u][1] = sv[u][2] = 0.0;
-    s_hi[u] = s_zr[u] = s_yr[u] = 0.0;
-    s_c[u]  = 0;
-    cv[u]   = 0.0;
-    cr[u]   = 0;
-  }
-  const bool grow = tid < G, ccol = tid < 2 * n;
-  int        fj_sv = 0, fj_sw = 0, fj_n = 0;  // this lane's faces of column j: f = hh + 2 i, i < fj_n
+  for (int k = 0; k < QP_ELL; ++k) ri[k] = 0;
+  cv[0] = cv[1] = 0.0;
+  cr[0] = cr[1] = 0;
+  const bool grole = tid < 256;            // wave-uniform: general-row waves / safety-row waves
+  const bool grow = tid < G, ccol = tid < 4 * n;
+  int        fj_sv = 0, fj_sw = 0, fj_n = 0;  // this lane's faces of column j: f = q + 4 i, i < fj_n
   // Both loaders assign every variable unconditionally (clamped index + select, no branch): the state is then
   // dead across a refactorisation, which needs the whole register file.
   auto fast_load = [&]() __attribute__((always_inline)) {
     const int t  = launder(tid);
     const int tg = grow ? t : 0;
+    if (grole) {  // wave-uniform
 #pragma unroll
-    for (int k = 0; k < QP_ELL; ++k) {
-      const int    c = R.gcol[(size_t)tg * QP_ELL + k];
-      const double v = R.gval[(size_t)tg * QP_ELL + k];
-      gc[k]          = (c < 0 || !grow) ? 0 : c;
-      gv[k]          = (c < 0 || !grow) ? 0.0 : v;
-    }
-    g_lo = R.gl[tg];
-    g_hi = R.gu[tg];
-    g_z  = R.gz[tg];
-    g_y  = R.gy[tg];
+      for (int k = 0; k < QP_ELL; ++k) {
+        const int    c = R.gcol[(size_t)tg * QP_ELL + k];
+        const double v = R.gval[(size_t)tg * QP_ELL + k];
+        gc(k)          = (c < 0 || !grow) ? 0 : c;
+        gv(k)          = (c < 0 || !grow) ? 0.0 : v;
+      }
+      g_lo = R.gl[tg];
+      g_hi = R.gu[tg];
+      g_z  = R.gz[tg];
+      g_y  = R.gy[tg];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int  sr = t + 256 * u;
-      const bool ok = sr < S;
-      const int  sc = ok ? sr : 0;
-      const double a0 = R.sval[(size_t)sc * 3 + 0], a1 = R.sval[(size_t)sc * 3 + 1], a2 = R.sval[(size_t)sc * 3 + 2];
-      const double hi = R.su[sc], z = R.sz[sc], y = R.sy[sc];
-      const int    c0 = R.sc0[sc];
-      sv[u][0] = ok ? a0 : 0.0;
-      sv[u][1] = ok ? a1 : 0.0;
-      sv[u][2] = ok ? a2 : 0.0;
-      s_hi[u]  = ok ? hi : 0.0;
-      s_zr[u]  = ok ? z : 0.0;
-      s_yr[u]  = ok ? y : 0.0;
-      s_c[u]   = ok ? c0 : 0;
+      for (int k = 12; k < 24; ++k) rs[k] = 0.0;
+    } else {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int  sr = (t - 256) + 256 * u;
+        const bool ok = sr < S;
+        const int  sc = ok ? sr : 0;
+        const double a0 = R.sval[(size_t)sc * 3 + 0], a1 = R.sval[(size_t)sc * 3 + 1], a2 = R.sval[(size_t)sc * 3 + 2];
+        const double hi = R.su[sc], z = R.sz[sc], y = R.sy[sc];
+        const int    c0 = R.sc0[sc];
+        sv(u, 0) = ok ? a0 : 0.0;
+        sv(u, 1) = ok ? a1 : 0.0;
+        sv(u, 2) = ok ? a2 : 0.0;
+        s_hi(u)  = ok ? hi : 0.0;
+        s_zr(u)  = ok ? z : 0.0;
+        s_yr(u)  = ok ? y : 0.0;
+        s_c(u)   = ok ? c0 : 0;
+      }
+      ri[4] = ri[5] = 0;
     }
     {
-      const int j = ccol ? t >> 1 : 0;
+      const int j = ccol ? t >> 2 : 0, q = t & 3;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int    q  = s_cptr[j] + hh + 2 * e;
-        const bool   ok = ccol && q < s_cptr[j + 1];
-        const int    en = R.cidx[ok ? q : s_cptr[j]];
+      for (int e = 0; e < 2; ++e) {
+        const int    qq = s_cptr[j] + q + 4 * e;
+        const bool   ok = ccol && qq < s_cptr[j + 1];
+        const int    en = R.cidx[ok ? qq : s_cptr[j]];
         const double v  = R.gval[(size_t)(en >> 3) * QP_ELL + (en & 7)];
         cr[e]           = ok ? en >> 3 : 0;
         cv[e]           = ok ? v : 0.0;
       }
       COL_DECODE(j)
-      fj_sv = (sbase + 5 * hh) * 3 + pd;
-      fj_sw = sbase + 5 * hh;
-      fj_n  = ccol ? (nface - hh + 1) >> 1 : 0;
+      fj_sv = (sbase + 5 * q) * 3 + pd;
+      fj_sw = sbase + 5 * q;
+      fj_n  = ccol ? (nface - q + 3) >> 2 : 0;
       xj    = s_x[j];
     }
   };
@@ -905,26 +892,31 @@ __global__ __launch_bounds__(256) void k_qp(SogmPlannerParams pp, SogmQpSettings
   auto fast_rho = [&]() __attribute__((always_inline)) {
     const int t  = launder(tid);
     const int tg = grow ? t : 0;
-    g_rho        = R.grho[tg];
-    g_rinv       = R.grinv[tg];
-    if (grow) h_gw[t] = g_rho * g_z - g_y;
+    if (grole) {
+      g_rho  = R.grho[tg];
+      g_rinv = R.grinv[tg];
+      if (grow) h_gw[t] = g_rho * g_z - g_y;
+    }
   };
   // registers -> row storage, for the residual / termination code that reads it
   auto fast_spill = [&]() __attribute__((always_inline)) {
     const int t = launder(tid);
-    if (grow) {
-      R.gz[t] = g_z;
-      R.gy[t] = g_y;
-    }
+    if (grole) {
+      if (grow) {
+        R.gz[t] = g_z;
+        R.gy[t] = g_y;
+      }
+    } else {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int sr = t + 256 * u;
-      if (sr < S) {
-        R.sz[sr] = s_zr[u];
-        R.sy[sr] = s_yr[u];
+      for (int u = 0; u < 4; ++u) {
+        const int sr = (t - 256) + 256 * u;
+        if (sr < S) {
+          R.sz[sr] = s_zr(u);
+          R.sy[sr] = s_yr(u);
+        }
       }
     }
-    if (ccol && hh == 0) s_x[t >> 1] = xj;
+    if (ccol && (t & 3) == 0) s_x[t >> 2] = xj;
     __syncthreads();
   };
 
@@ -949,8 +941,8 @@ __global__ __launch_bounds__(256) void k_qp(SogmPlannerParams pp, SogmQpSettings
     cj_pd    = pd;
   }
   const double  alpha = qs.alpha, oma = 1.0 - qs.alpha;
-  const double *xtv   = use_blocks ? s_cn : s_xt;  // where the solve leaves x~
-  for (int j = n + tid; j < 128; j += 256) s_xt[j] = 0.0;  // the register mat-vec reads 120 entries
+  const double *xtv   = FAST ? s_cn : s_xt;  // where the solve leaves x~
+  for (int j = n + tid; j < 128; j += QP_NT) s_xt[j] = 0.0;  // the register mat-vec reads 120 entries
   __syncthreads();
   int adapt_left = qs.adaptive_rho_interval, check_left = qs.check_termination;
   if (chol_ok) {
@@ -967,29 +959,30 @@ __global__ __launch_bounds__(256) void k_qp(SogmPlannerParams pp, SogmQpSettings
       }
       if constexpr (FAST) {
         if (!(ablate & 1) && ccol) {
-          double w[4];
+          double w[2];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) w[e] = h_gw[cr[e]];
+          for (int e = 0; e < 2; ++e) w[e] = h_gw[cr[e]];
           double        p   = 0.0;
           const double *fvp = h_sv + fj_sv, *fwp = h_sw + fj_sw;
           const double *fv0 = fvp, *zero = s_xt + 127;  // s_xt is zero beyond n
 #pragma unroll 1
-          for (int i0 = 0; i0 < fj_n; i0 += 4, fvp += 120, fwp += 40) {  // 8 independent LDS reads per round trip
+          for (int i0 = 0; i0 < fj_n; i0 += 4, fvp += 240, fwp += 80) {  // 8 independent LDS reads per round trip
             double a[4], b[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
               const bool ok = i0 + u < fj_n;
-              a[u]          = *(ok ? fvp + 30 * u : fv0);
-              b[u]          = *(ok ? fwp + 10 * u : zero);
+              a[u]          = *(ok ? fvp + 60 * u : fv0);
+              b[u]          = *(ok ? fwp + 20 * u : zero);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int u = 0; u < 4; ++u) p = __builtin_fma(a[u], b[u], p);
           }
 #pragma unroll
-          for (int e = 0; e < 4; ++e) p = __builtin_fma(cv[e], w[e], p);
-          p += dpp_quad(p, 0xB1);  // partner lane tid ^ 1
-          if (hh == 0) s_xt[launder(tid) >> 1] = __builtin_fma(qs.sigma, xj, p);  // q == 0
+          for (int e = 0; e < 2; ++e) p = __builtin_fma(cv[e], w[e], p);
+          p += dpp_quad(p, 0xB1);  // lane ^ 1
+          p += dpp_quad(p, 0x4E);  // lane ^ 2
+          if ((tid & 3) == 0) s_xt[launder(tid) >> 2] = __builtin_fma(qs.sigma, xj, p);  // q == 0
         }
       } else
       if (!(ablate & 1))
@@ -1011,26 +1004,17 @@ __global__ __launch_bounds__(256) void k_qp(SogmPlannerParams pp, SogmQpSettings
       // (c) rows: z~ = A x~ ; z = proj(alpha z~ + (1-alpha) z + y/rho) ; y += rho (.. - z)
       if constexpr (FAST) {
         if (!(ablate & 12)) {
-          double xg[QP_ELL], xs[4][3];  // every read of x~ issued up front: one LDS round trip
-#pragma unroll
-          for (int k = 0; k < QP_ELL; ++k) xg[k] = xtv[gc[k]];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            xs[u][0] = xs[u][1] = xs[u][2] = 0.0;
-            if (256 * u < S) {  // workgroup-uniform: slots beyond the last safety row cost nothing
-              xs[u][0] = xtv[s_c[u]];
-              xs[u][1] = xtv[s_c[u] + 1];
-              xs[u][2] = xtv[s_c[u] + 2];
-            }
-          }
           const int    t   = launder(tid);
-          const double xtj = xtv[t >> 1];
-          __builtin_amdgcn_sched_barrier(0);
-          {
-            // fused multiply-adds: like the K^-1 product, the row update is not on a bit-exact path
-            double s = gv[0] * xg[0];
+          const double xtj = xtv[ccol ? t >> 2 : 0];
+          if (grole) {  // waves 0-3: one general row per lane
+            double xg[QP_ELL];  // every read of x~ issued up front: one LDS round trip
 #pragma unroll
-            for (int k = 1; k < QP_ELL; ++k) s = __builtin_fma(gv[k], xg[k], s);
+            for (int k = 0; k < QP_ELL; ++k) xg[k] = xtv[gc(k)];
+            __builtin_amdgcn_sched_barrier(0);
+            // fused multiply-adds: like the K^-1 product, the row update is not on a bit-exact path
+            double s = gv(0) * xg[0];
+#pragma unroll
+            for (int k = 1; k < QP_ELL; ++k) s = __builtin_fma(gv(k), xg[k], s);
             const double zr = __builtin_fma(alpha, s, oma * g_z);
             double       v  = __builtin_fma(g_rinv, g_y, zr);  // OSQP update_z: rho_inv_vec[i] * y[i]
             v               = v < g_lo ? g_lo : (v > g_hi ? g_hi : v);
@@ -1041,24 +1025,36 @@ __global__ __launch_bounds__(256) void k_qp(SogmPlannerParams pp, SogmQpSettings
               h_gw[t] = __builtin_fma(g_rho, v, -g_y);
               if (do_check) R.gdy[t] = d;
             }
-          }
+          } else {  // waves 4-7: up to four safety rows per lane
+            double xs[4][3];
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            if (256 * u >= S) continue;
-            double ax = sv[u][0] * xs[u][0];
-            ax              = __builtin_fma(sv[u][1], xs[u][1], ax);
-            ax              = __builtin_fma(sv[u][2], xs[u][2], ax);
-            const double zr = __builtin_fma(alpha, ax, oma * s_zr[u]);
-            double       v  = __builtin_fma(rinv_cur, s_yr[u], zr);
-            v               = v > s_hi[u] ? s_hi[u] : v;  // l = -OSQP_INFTY
-            s_zr[u]         = v;
-            const double d  = rho_cur * (zr - v);
-            const double yn = s_yr[u] + d;
-            s_yr[u]         = yn;
-            const int sr    = t + 256 * u;
-            if (sr < S) {
-              h_sw[sr] = __builtin_fma(rho_cur, v, -yn);
-              if (do_check) R.sdy[sr] = d;
+            for (int u = 0; u < 4; ++u) {
+              xs[u][0] = xs[u][1] = xs[u][2] = 0.0;
+              if (256 * u < S) {  // workgroup-uniform: slots beyond the last safety row cost nothing
+                xs[u][0] = xtv[s_c(u)];
+                xs[u][1] = xtv[s_c(u) + 1];
+                xs[u][2] = xtv[s_c(u) + 2];
+              }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              if (256 * u >= S) continue;
+              double ax = sv(u, 0) * xs[u][0];
+              ax              = __builtin_fma(sv(u, 1), xs[u][1], ax);
+              ax              = __builtin_fma(sv(u, 2), xs[u][2], ax);
+              const double zr = __builtin_fma(alpha, ax, oma * s_zr(u));
+              double       v  = __builtin_fma(rinv_cur, s_yr(u), zr);
+              v               = v > s_hi(u) ? s_hi(u) : v;  // l = -OSQP_INFTY
+              s_zr(u)         = v;
+              const double d  = rho_cur * (zr - v);
+              const double yn = s_yr(u) + d;
+              s_yr(u)         = yn;
+              const int sr    = (t - 256) + 256 * u;
+              if (sr < S) {
+                h_sw[sr] = __builtin_fma(rho_cur, v, -yn);
+                if (do_check) R.sdy[sr] = d;
+              }
             }
           }
           xj = __builtin_fma(alpha, xtj, oma * xj);
@@ -1067,7 +1063,7 @@ __global__ __launch_bounds__(256) void k_qp(SogmPlannerParams pp, SogmQpSettings
         if (do_adapt || do_check) fast_spill();
       } else {
       if (!(ablate & 4))
-      for (int r = tid; r < G; r += 256) {
+      for (int r = tid; r < G; r += QP_NT) {
         double s = 0;
         for (int k = 0; k < QP_ELL; ++k) {
           const int c = R.gcol[(size_t)r * QP_ELL + k];
@@ -1084,7 +1080,7 @@ __global__ __launch_bounds__(256) void k_qp(SogmPlannerParams pp, SogmQpSettings
         R.gy[r]         = yr + d;
       }
       if (!(ablate & 8))
-      for (int s = tid; s < S; s += 256) {
+      for (int s = tid; s < S; s += QP_NT) {
         const int     c0 = R.sc0[s];
         const double *vv = R.sval + (size_t)s * 3;
         double        ax = 0;
@@ -1103,7 +1099,7 @@ __global__ __launch_bounds__(256) void k_qp(SogmPlannerParams pp, SogmQpSettings
         R.sy[s]         = yn;
         R.sw[s]         = rho_cur * v - yn;
       }
-      for (int j = tid; j < n; j += 256) s_x[j] = alpha * xtv[j] + (1.0 - alpha) * s_x[j];
+      for (int j = tid; j < n; j += QP_NT) s_x[j] = alpha * xtv[j] + (1.0 - alpha) * s_x[j];
       __syncthreads();
       }
       if (do_check || do_adapt) residuals();
@@ -1119,14 +1115,14 @@ __global__ __launch_bounds__(256) void k_qp(SogmPlannerParams pp, SogmQpSettings
         // primal infeasibility certificate (eps_prim_inf = 1e-4), as in the oracle
         const double eps_inf = 1e-4;
         double       ndy     = 0;
-        for (int r = tid; r < G; r += 256) ndy = dmax(ndy, dabs(R.gE[r] * R.gdy[r]));
-        for (int s = tid; s < S; s += 256) ndy = dmax(ndy, dabs(R.sE[s] * R.sdy[s]));
+        for (int r = tid; r < G; r += QP_NT) ndy = dmax(ndy, dabs(R.gE[r] * R.gdy[r]));
+        for (int s = tid; s < S; s += QP_NT) ndy = dmax(ndy, dabs(R.sE[s] * R.sdy[s]));
         ndy = block_max(ndy, s_red);
         __syncthreads();
         if (!p_ok && ndy > eps_inf) {
           double lhs = 0;
           int    bad = 0;
-          for (int r = tid; r < G; r += 256) {
+          for (int r = tid; r < G; r += QP_NT) {
             const double d = R.gdy[r] / ndy;
             if (R.gu[r] < OSQP_INFTY * MIN_SCALING)
               lhs += R.gu[r] * (d > 0 ? d : 0);
@@ -1137,7 +1133,7 @@ __global__ __launch_bounds__(256) void k_qp(SogmPlannerParams pp, SogmQpSettings
             else if (d < -eps_inf)
               bad = 1;
           }
-          for (int s = tid; s < S; s += 256) {
+          for (int s = tid; s < S; s += QP_NT) {
             const double d = R.sdy[s] / ndy;
             lhs += R.su[s] * (d > 0 ? d : 0);
             if (d < -eps_inf) bad = 1;  // l = -inf pushed
@@ -1146,11 +1142,11 @@ __global__ __launch_bounds__(256) void k_qp(SogmPlannerParams pp, SogmQpSettings
           __syncthreads();
           if (lane == 0) s_red[wave] = lhs;
           const int anybad = __syncthreads_or(bad);
-          lhs              = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+          lhs              = ((s_red[0] + s_red[1]) + (s_red[2] + s_red[3])) + ((s_red[4] + s_red[5]) + (s_red[6] + s_red[7]));
           __syncthreads();
           if (!anybad && lhs < -eps_inf) {
             double na = 0;
-            for (int j = tid; j < n; j += 256) {
+            for (int j = tid; j < n; j += QP_NT) {
               double a = 0;
               for (int q = s_cptr[j]; q < s_cptr[j + 1]; ++q) {
                 const int en = R.cidx[q], r = en >> 3;
@@ -1207,11 +1203,24 @@ __global__ __launch_bounds__(256) void k_qp(SogmPlannerParams pp, SogmQpSettings
   }
   __syncthreads();
   double *out = out_cpts + (size_t)agent * SOGM_MAX_PIECES * 15;
-  for (int j = tid; j < SOGM_MAX_PIECES * 15; j += 256) out[j] = j < n ? s_D[j] * s_x[j] : 0.0;
+  for (int j = tid; j < SOGM_MAX_PIECES * 15; j += QP_NT) out[j] = j < n ? s_D[j] * s_x[j] : 0.0;
   if (tid == 0) {
     out_status[agent] = status;
     out_iters[agent]  = iter;
   }
+#undef gv
+#undef gc
+#undef g_rho
+#undef g_rinv
+#undef g_lo
+#undef g_hi
+#undef g_z
+#undef g_y
+#undef sv
+#undef s_hi
+#undef s_zr
+#undef s_yr
+#undef s_c
   };  // body
   using std::false_type;
   using std::true_type;
@@ -1233,6 +1242,14 @@ __global__ __launch_bounds__(256) void k_qp(SogmPlannerParams pp, SogmQpSettings
   }
 }
 
+// Dynamic LDS k_qp may ask for: the CU's 160 KiB minus the kernel's static LDS (queried, not assumed).
+int qp_dynamic_lds_bytes() {
+  hipFuncAttributes a;
+  if (hipFuncGetAttributes(&a, (const void *)k_qp) != hipSuccess) return 128 * 1024;
+  const long dyn = 160L * 1024 - (long)a.sharedSizeBytes;
+  return (int)(dyn & ~255L);
+}
+
 int launch_qp(const SogmPlannerParams &pp, const SogmQpSettings &qs, const QpWorkspace &ws,
               const QpConst &qc, int n_agents, const double *start_pva, const double *goal_pv,
               const double *polys, const int32_t *nfaces, const int32_t *npoly, double *out_cpts,
@@ -1249,7 +1266,7 @@ int launch_qp(const SogmPlannerParams &pp, const SogmQpSettings &qs, const QpWor
     const char *e = getenv("SOGM_QP_ABLATE");
     ablate        = e ? atoi(e) : 0;
   }
-  hipLaunchKernelGGL(k_qp, dim3(n_agents), dim3(256), ws.dyn_lds_bytes, st, pp, qs, ws, qc, start_pva,
+  hipLaunchKernelGGL(k_qp, dim3(n_agents), dim3(QP_NT), ws.dyn_lds_bytes, st, pp, qs, ws, qc, start_pva,
                      goal_pv, polys, nfaces, npoly, out_cpts, out_status, out_iters, ablate, agent0);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
