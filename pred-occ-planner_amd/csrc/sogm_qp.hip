@@ -940,7 +940,10 @@ __global__ __launch_bounds__(QP_NT) void k_qp(SogmPlannerParams pp, SogmQpSettin
     cj_nface = nface;
     cj_pd    = pd;
   }
-  const double  alpha = qs.alpha, oma = 1.0 - qs.alpha;
+  // loop constants as per-lane values: read from the kernel-argument SGPR tuple they would be re-loaded eight
+  // dwords at a time (the tuple spills as a unit) at every use
+  double alpha = qs.alpha, oma = 1.0 - qs.alpha, sigma_v = qs.sigma;
+  asm volatile("" : "+v"(alpha), "+v"(oma), "+v"(sigma_v));
   const double *xtv   = FAST ? s_cn : s_xt;  // where the solve leaves x~
   for (int j = n + tid; j < 128; j += QP_NT) s_xt[j] = 0.0;  // the register mat-vec reads 120 entries
   __syncthreads();
@@ -982,7 +985,7 @@ __global__ __launch_bounds__(QP_NT) void k_qp(SogmPlannerParams pp, SogmQpSettin
           for (int e = 0; e < 2; ++e) p = __builtin_fma(cv[e], w[e], p);
           p += dpp_quad(p, 0xB1);  // lane ^ 1
           p += dpp_quad(p, 0x4E);  // lane ^ 2
-          if ((tid & 3) == 0) s_xt[launder(tid) >> 2] = __builtin_fma(qs.sigma, xj, p);  // q == 0
+          if ((tid & 3) == 0) s_xt[launder(tid) >> 2] = __builtin_fma(sigma_v, xj, p);  // q == 0
         }
       } else
       if (!(ablate & 1))
@@ -1113,6 +1116,7 @@ __global__ __launch_bounds__(QP_NT) void k_qp(SogmPlannerParams pp, SogmQpSettin
           break;
         }
         // primal infeasibility certificate (eps_prim_inf = 1e-4), as in the oracle
+        if (ablate & 16) continue;  // profiling aid (ablation build only)
         const double eps_inf = 1e-4;
         double       ndy     = 0;
         for (int r = tid; r < G; r += QP_NT) ndy = dmax(ndy, dabs(R.gE[r] * R.gdy[r]));
