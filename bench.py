@@ -141,8 +141,11 @@ def main():
     t_start = stamps + driver.REPLAN_START_TIME
     pva, valid = planner.traj_eval(sw.own, t_start)
     pva = torch.where(valid.bool().unsqueeze(1), pva, sw.hover).contiguous()
-    sw.map.updateMap(sw.dev["cloud"], sw.dev["cloud_range"], sw.dev["cylinders"], sw.dev["n_cyl"],
-                     pva[:, :3].to(torch.float32).contiguous(), stamps)
+    poses_ = pva[:, :3].to(torch.float32).contiguous()
+    standalone_clear_ms = []
+    for _ in range(3):  # the full-width clear with the machine to itself (first launch may still see the page-table
+        sw.map.updateMap(sw.dev["cloud"], sw.dev["cloud_range"], sw.dev["cylinders"], sw.dev["n_cyl"], poses_, stamps)
+        standalone_clear_ms.append(float(sw.map.profile_read()[0]))  # work of releasing the second grid)
     sw.map.addOtherAgents(sw.all, sw.A_tot, sw.dev["ego_ids"])
     s_ = sw.planner.search(pva, sw.goals, t_start)
     c_ = sw.planner.generateCorridors(pva, t_start, s_["route"], s_["route_len"])
@@ -192,9 +195,9 @@ def main():
                      # avg_launch_ms is the launch as it runs inside the tick (double-buffered mode: a narrow
                      # clear sharing the machine with the planner kernels); the same kernel at full width with
                      # the machine to itself, from the stage pass after the timed region:
-                     "standalone": {"avg_launch_ms": float(ms_stage[0]),
-                                    "achieved": grid_bytes / (float(ms_stage[0]) * 1e-3) / 1e9,
-                                    "frac": grid_bytes / (float(ms_stage[0]) * 1e-3) / 1e9 / 8000.0}},
+                     "standalone": {"launch_ms": standalone_clear_ms,
+                                    "achieved": grid_bytes / (min(standalone_clear_ms) * 1e-3) / 1e9,
+                                    "frac": grid_bytes / (min(standalone_clear_ms) * 1e-3) / 1e9 / 8000.0}},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(pop, spec, sw.scene, args.cpu_agents)
