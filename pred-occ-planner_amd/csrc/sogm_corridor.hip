@@ -428,6 +428,37 @@ __device__ inline double bfly_sum(double v) {
   return v;
 }
 
+// The ten partial sums of costMVIE reduced together, stage by stage (ten independent chains per stage: no DPP
+// hazard stalls, no serial bpermute round trips).  Lanes >= M hold exact zeros, so for M <= 16 the two cross-row
+// stages only add zeros to lanes 0..15 and are skipped; lane 0's value (the same in every lane of the full
+// butterfly, additions being commutative) is broadcast instead.  Same association order, same bits.
+__device__ inline double first_lane_f64(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo     = __builtin_amdgcn_readfirstlane(lo);
+  hi     = __builtin_amdgcn_readfirstlane(hi);
+  return __hiloint2double(hi, lo);
+}
+__device__ inline void bfly_sum10(double acc[10], int M) {
+  if (M > 16) {  // wave-uniform
+#pragma unroll
+    for (int k = 0; k < 10; ++k) acc[k] += __shfl_xor(acc[k], 32, 64);
+#pragma unroll
+    for (int k = 0; k < 10; ++k) acc[k] += __shfl_xor(acc[k], 16, 64);
+  }
+#pragma unroll
+  for (int k = 0; k < 10; ++k) acc[k] += dpp_f64<0x128>(acc[k]);  // row_ror:8
+#pragma unroll
+  for (int k = 0; k < 10; ++k) acc[k] += dpp_f64<0x124>(acc[k]);  // row_ror:4
+#pragma unroll
+  for (int k = 0; k < 10; ++k) acc[k] += dpp_f64<0x4E>(acc[k]);  // quad_perm [2,3,0,1]
+#pragma unroll
+  for (int k = 0; k < 10; ++k) acc[k] += dpp_f64<0xB1>(acc[k]);  // quad_perm [1,0,3,2]
+  if (M <= 16) {
+#pragma unroll
+    for (int k = 0; k < 10; ++k) acc[k] = first_lane_f64(acc[k]);
+  }
+}
+
 #ifdef SOGM_PROFILE_MVIE
 __device__ unsigned long long g_mvie_prof[2];  // profiling build only: ticks (100 MHz) and calls of costMVIE
 #endif
@@ -471,7 +502,7 @@ __device__ __forceinline__ double costMVIE(const MvieData &D, const double *x, d
   for (int k = 0; k < 10; ++k) acc[k] = 0.0;
   if (D.on0) mvie_face(D.a0, L, p, D.smoothEps, acc);
   if (D.on1) mvie_face(D.a1, L, p, D.smoothEps, acc);
-  for (int k = 0; k < 10; ++k) acc[k] = bfly_sum(acc[k]);
+  bfly_sum10(acc, D.M);
   double cost = acc[0];
   for (int j = 0; j < 3; ++j) {
     gdp[j]   = acc[1 + j];
