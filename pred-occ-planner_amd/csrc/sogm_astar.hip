@@ -231,7 +231,7 @@ __device__ inline void heap_push_up(const double *f, unsigned short *h, int hole
 __device__ inline void heap_push(const double *f, unsigned short *h, int &n, int value) {
   h[n] = (unsigned short)value;
   ++n;
-  heap_push_up(f, h, n - 1, 0, value);
+  heap_push_up(f, h, n - 1, 0, value);  // new nodes rarely beat their parent: the loop exits after a level or two
 }
 __device__ inline void heap_pop(const double *f, unsigned short *h, int &n) {
   if (n > 1) {
@@ -294,6 +294,14 @@ __global__ __launch_bounds__(ASTAR_THREADS) void k_astar(
   __shared__ short              s_rank[ASTAR_MAX_INPUTS];    // #EV_NEW before child i
   __shared__ int                s_src[ASTAR_MAX_INPUTS];     // leader -> child whose data its node takes
   __shared__ short              s_events[ASTAR_MAX_INPUTS];  // children with an event, in order
+  __shared__ unsigned long long s_ckey[ASTAR_MAX_INPUTS];    // keys of the gate-passing children, compacted
+  __shared__ short              s_cidx[ASTAR_MAX_INPUTS];    // their child indices
+  __shared__ int                s_cnt_w[2];
+  __shared__ int2               s_erec[ASTAR_MAX_INPUTS];    // events in child order: {type, operand}
+  __shared__ double             s_erec_f[ASTAR_MAX_INPUTS];  // ... and the child's f
+  __shared__ int                s_upd_node[ASTAR_MAX_INPUTS];  // open nodes lowered by this expansion so far
+  __shared__ double             s_upd_g[ASTAR_MAX_INPUTS];
+  __shared__ double             s_og[ASTAR_MAX_INPUTS];      // g of the open node a child hit, before this expansion
   __shared__ int                s_n_events, s_n_new_w0, s_n_ev_w0;
   __shared__ int                s_n_inputs;
   __shared__ double             s_cur_state[6];
@@ -505,17 +513,17 @@ __global__ __launch_bounds__(ASTAR_THREADS) void k_astar(
           const bool same = id[0] == s_cur_index[0] && id[1] == s_cur_index[1] &&
                             id[2] == s_cur_index[2] && (t_id - s_cur_tidx) == 0;
           gate = gate && !same;
-          // closed / open lookup (:271): find(pro_id, pro_t_id)
+          // closed / open lookup (:271): find(pro_id, pro_t_id).  The first probe of the hash table is issued
+          // before the collision gather and consumed after it, so the two global-memory latencies overlap (the
+          // gates commute: a child is dropped if EITHER its node is closed or a sample collides).
           int                found = -1, found_st = NOT_EXPAND, ev = EV_NONE;
-          unsigned long long key   = HASH_EMPTY;
+          unsigned long long key   = HASH_EMPTY, slot0 = HASH_EMPTY;
           const bool packable = pack_ok(id[0], id[1], id[2], t_id) && pack_ok(id[0], id[1], id[2], (int)new_t);
           if (packable) {
             key   = pack_key(id[0], id[1], id[2], t_id);
-            found = hash_find(htab, hcap, key);
-            if (found >= 0) found_st = pool[found].node_state;
+            slot0 = __hip_atomic_load(htab + (hash_of(key) & (hcap - 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
-          if (found >= 0 && found_st == IN_CLOSE_SET) gate = false;
-          double cg = 0.0, cf = 0.0;
+          bool collide = false;
           if (gate) {
             // collision gate (:296-331)
             for (int k = 1; k <= ap.check_num; ++k) {
@@ -523,11 +531,27 @@ __global__ __launch_bounds__(ASTAR_THREADS) void k_astar(
               double       xt[6];
               state_transit(cs, xt, um, dt);
               if (query_clear_time(m, agent, xt[0], xt[1], xt[2], s_cur_time + dt) != 0) {
-                gate = false;
+                collide = true;
                 break;
               }
             }
           }
+          double found_g = 0.0;
+          if (packable) {
+            if (slot0 == HASH_EMPTY)
+              found = -1;
+            else if ((slot0 & ~0x3FFFull) == key)
+              found = (int)(slot0 & 0x3FFF);
+            else
+              found = hash_find(htab, hcap, key);
+            if (found >= 0) {
+              found_st = pool[found].node_state;
+              found_g  = pool[found].g;
+            }
+          }
+          if (found >= 0 && found_st == IN_CLOSE_SET) gate = false;
+          if (collide) gate = false;
+          double cg = 0.0, cf = 0.0;
           if (gate) {
             double       ttg;
             const double usq = (um[0] * um[0] + um[1] * um[1]) + um[2] * um[2];
@@ -543,6 +567,7 @@ __global__ __launch_bounds__(ASTAR_THREADS) void k_astar(
           s_cg[i]    = cg;
           s_key[i]   = key;
           s_found[i] = found;
+          s_og[i]    = found_g;
           s_gate[i]  = gate ? 1 : 0;
           s_ev[i]    = (unsigned char)ev;
           s_src[i]   = i;
@@ -558,34 +583,58 @@ __global__ __launch_bounds__(ASTAR_THREADS) void k_astar(
       // leader(i) = first gate-passing child with the same key.  A child without a hash hit creates
       // a node if it is its own leader (EV_NEW); otherwise it is pruned against its leader's node
       // and replaces that node's data iff its f beats every earlier member of the group (EV_DUP).
+      // The gate-passing children are first compacted (ascending child order): the entries before a child's own
+      // slot are exactly the earlier members it has to look at, and their keys are read eight at a time.
       int my_ev = EV_NONE;
-      if (tid < n_act) {
-        const int i = tid;
-        my_ev       = s_ev[i];
-        if (s_gate[i] && my_ev == EV_NONE) {
-          const unsigned long long key = s_key[i];
-          int                      L   = i;
-          double                   mn  = 0.0;
-          bool                     has = false;
-          for (int j = 0; j < i; ++j) {
-            if (s_gate[j] && s_key[j] == key) {
-              if (!has) {
-                L   = j;
-                mn  = s_cf[j];
-                has = true;
-              } else if (s_cf[j] < mn) {
-                mn = s_cf[j];
+      {
+        const int                lane = tid & 63, wave = tid >> 6;
+        const unsigned long long lt   = lane ? (~0ull >> (64 - lane)) : 0ull;
+        const bool               mg   = tid < n_act && s_gate[tid] != 0;
+        const unsigned long long bg   = __ballot(mg);
+        if (lane == 0) s_cnt_w[wave] = __popcll(bg);
+        __syncthreads();
+        const int crank = __popcll(bg & lt) + (wave ? s_cnt_w[0] : 0);
+        if (mg) {
+          s_ckey[crank] = s_key[tid];
+          s_cidx[crank] = (short)tid;
+        }
+        __syncthreads();
+        if (tid < n_act) {
+          const int i = tid;
+          my_ev       = s_ev[i];
+          if (mg && my_ev == EV_NONE) {
+            const unsigned long long key = s_key[i];
+            int                      L   = i;
+            double                   mn  = 0.0;
+            bool                     has = false;
+            for (int c0 = 0; c0 < crank; c0 += 8) {
+              unsigned long long kk[8];
+#pragma unroll
+              for (int u = 0; u < 8; ++u) kk[u] = s_ckey[c0 + u < crank ? c0 + u : c0];
+#pragma unroll
+              for (int u = 0; u < 8; ++u) {
+                if (c0 + u < crank && kk[u] == key) {
+                  const int    j  = s_cidx[c0 + u];
+                  const double cj = s_cf[j];
+                  if (!has) {
+                    L   = j;
+                    mn  = cj;
+                    has = true;
+                  } else if (cj < mn) {
+                    mn = cj;
+                  }
+                }
               }
             }
+            s_leader[i] = (short)L;
+            if (!has) {
+              my_ev = EV_NEW;
+            } else if (s_cf[i] < mn) {
+              my_ev = EV_DUP;
+              atomicMax(&s_src[L], i);  // the last applied replacement wins (= first to reach the min)
+            }
+            s_ev[i] = (unsigned char)my_ev;
           }
-          s_leader[i] = (short)L;
-          if (!has) {
-            my_ev = EV_NEW;
-          } else if (s_cf[i] < mn) {
-            my_ev = EV_DUP;
-            atomicMax(&s_src[L], i);  // the last applied replacement wins (= first to reach the min)
-          }
-          s_ev[i] = (unsigned char)my_ev;
         }
       }
       // ranks: number of EV_NEW / of events before child i (two waves)
@@ -603,7 +652,13 @@ __global__ __launch_bounds__(ASTAR_THREADS) void k_astar(
         const int rev  = __popcll(be & lt) + (wave ? s_n_ev_w0 : 0);
         if (tid < n_act) {
           s_rank[tid] = (short)rnew;
-          if (my_ev != EV_NONE) s_events[rev] = (short)tid;
+          if (my_ev != EV_NONE) {
+            s_events[rev] = (short)tid;
+            // event record for the master's replay: {type, operand} + f.  operand = rank of the new node
+            // (EV_NEW), leader child (EV_DUP), child (EV_OPEN / EV_ERR)
+            s_erec[rev]   = make_int2(my_ev, my_ev == EV_NEW ? rnew : (my_ev == EV_DUP ? (int)s_leader[tid] : tid));
+            s_erec_f[rev] = s_cf[tid];
+          }
         }
         if (wave == 1 && lane == 0) s_n_events = s_n_ev_w0 + __popcll(be);
       }
@@ -616,38 +671,58 @@ __global__ __launch_bounds__(ASTAR_THREADS) void k_astar(
       // ---------------- master: replay the events in child order (:366-414) ----------------
       if (tid == 0) {
         const int n_ev = s_n_events;
-        int       n_written = 0;
+        int       n_written = 0, n_upd = 0;
+        int2      rec  = s_erec[0];
+        double    rcf  = s_erec_f[0];
         for (int k = 0; k < n_ev && !done; ++k) {
-          const int i  = s_events[k];
-          const int ev = s_ev[i];
+          const int    kn  = k + 1 < n_ev ? k + 1 : k;  // next record in flight while this one is replayed
+          const int2   nrec = s_erec[kn];
+          const double ncf  = s_erec_f[kn];
+          const int    ev = rec.x, opd = rec.y;
           if (ev == EV_NEW) {
-            const int node = s_base_node + s_rank[i];
-            s_f[node]      = s_cf[i];
+            const int node = s_base_node + opd;
+            s_f[node]      = rcf;
             heap_push(s_f, s_heap, heap_n, node);
             use_node_num += 1;
-            n_written = s_rank[i] + 1;
+            n_written = opd + 1;
             if (use_node_num == ap.allocate_num) {  // "run out of memory" (:393-396)
               ret  = NO_PATH;
               done = true;
             }
           } else if (ev == EV_DUP) {
-            s_f[s_base_node + s_rank[s_leader[i]]] = s_cf[i];
+            s_f[s_base_node + s_rank[opd]] = rcf;
           } else if (ev == EV_OPEN) {
-            Node &pn = pool[s_found[i]];
-            if (s_cg[i] < pn.g) {  // re-read: an earlier child of this expansion may have updated it
+            const int i     = opd;
+            const int fnode = s_found[i];
+            Node     &pn    = pool[fnode];
+            // pn.g as this expansion's earlier children left it: the value fetched with the hash probe, or the g
+            // of the last earlier child that lowered it (kept in a short list) — no global load on the serial path
+            double g_now = s_og[i];
+            int    slot  = -1;
+            for (int u = 0; u < n_upd; ++u)
+              if (s_upd_node[u] == fnode) {
+                g_now = s_upd_g[u];
+                slot  = u;
+              }
+            if (s_cg[i] < g_now) {
               for (int q = 0; q < 6; ++q) pn.state[q] = s_cstate[i][q];
-              pn.f            = s_cf[i];
-              pn.g            = s_cg[i];
-              s_f[s_found[i]] = s_cf[i];
+              pn.f       = rcf;
+              pn.g       = s_cg[i];
+              s_f[fnode] = rcf;
               for (int q = 0; q < 3; ++q) pn.input[q] = first ? start_a[q] : s_inputs[i][q];
               pn.duration = tau;
               pn.parent   = cur;
               pn.time     = new_t;
+              if (slot < 0) slot = n_upd++;
+              s_upd_node[slot] = fnode;
+              s_upd_g[slot]    = s_cg[i];
             }
           } else {
             ret  = SEARCH_ERR;
             done = true;
           }
+          rec = nrec;
+          rcf = ncf;
         }
         s_n_written = n_written;
         s_n_active  = done ? -1 : 1;

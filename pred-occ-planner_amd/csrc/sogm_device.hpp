@@ -152,26 +152,33 @@ __device__ inline int query_clear_idx(const MapView &m, int agent, double px, do
                                                  : g.thr_region - (float)t * g.decay_region;
   float        sum = 0.0F;
   if (zs == 0 && s <= 3) {
-    // Common case (fkpcp map, K = (2s+1)^2 <= 49): issue every gather first so the loads overlap,
-    // then replay the reference's running sum and early exit in kernel order (x outer, y inner).
-    float v[49];
-    const int w = 2 * s + 1;
+    // Common case (fkpcp map, K = (2s+1)^2 <= 49): issue every gather first so the loads overlap, then replay
+    // the reference's running sum in kernel order (x outer, y inner) WITHOUT divergent control flow: a cell
+    // outside the grid is read at a clamped address and masked to +0.0f (x + 0 = x exactly), and "return 1 at
+    // the first prefix sum above the threshold" is the OR of the prefix comparisons.  (49 nested early exits
+    // cost ~30 instructions and two spilled exec masks per cell.)
+    float     v[49];
+    const int w = 2 * s + 1, ww = w * w;
 #pragma unroll
     for (int k = 0; k < 49; ++k) {
-      v[k] = -1.0F;  // marks "outside the grid" (occupancies are >= 0)
-      if (k < w * w) {
-        const int qx = ix + (k / w - s), qy = iy + (k % w - s);
-        if (g.in_range(qx, qy, iz)) v[k] = cell_ld(sl, (size_t)iz * g.L * g.W + (size_t)qy * g.L + qx, g.half);
+      v[k] = 0.0F;
+      if (k < ww) {  // uniform
+        const int      qx = ix + (k / w - s), qy = iy + (k % w - s);
+        const unsigned keep = g.in_range(qx, qy, iz) ? 0xFFFFFFFFu : 0u;  // a VGPR value, not a saved exec mask
+        const int      cx = min(max(qx, 0), g.L - 1), cy = min(max(qy, 0), g.W - 1);
+        const float    val = cell_ld(sl, (size_t)iz * g.L * g.W + (size_t)cy * g.L + cx, g.half);
+        v[k]               = __uint_as_float(__float_as_uint(val) & keep);
       }
     }
+    bool hit = false;
 #pragma unroll
     for (int k = 0; k < 49; ++k) {
-      if (k < w * w && v[k] >= 0.0F) {
+      if (k < ww) {
         sum += v[k];
-        if (sum > thr) return 1;
+        hit = hit || sum > thr;
       }
     }
-    return 0;
+    return hit ? 1 : 0;
   }
   for (int x = -s; x <= s; ++x) {
     const int qx = ix + x;
