@@ -5,7 +5,8 @@ cur = sqlite3.connect(db).cursor()
 rows = cur.execute("select name, start, end from kernels order by start").fetchall()
 # a tick starts at each k_stamp_cloud
 stamps = [i for i, r in enumerate(rows) if "k_stamp_cloud" in r[0]]
-a, b = stamps[-3], stamps[-2]
+k = len(stamps) // 2  # a tick from the middle of the timed region (the run ends with stage-pass updates)
+a, b = stamps[k], stamps[k + 1]
 t0 = rows[a][1]
 print(f"tick length {(rows[b][1] - t0) / 1e6:.2f} ms")
 for name, s, e in rows[a:b]:
