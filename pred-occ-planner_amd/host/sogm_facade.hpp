@@ -131,6 +131,14 @@ class RiskMap {
   void setCoordinator(const std::vector<Vec3> &body_particles) {
     check(sogm_set_body_particles(ctx_, body_particles[0].data(), (int)body_particles.size()), "set_body");
   }
+  // Tick pipelining (no reference counterpart): 0 off, 1 in-place pre-clear under the QP stage, 2 double-buffered
+  // (second grid; returns false and leaves the mode unchanged if HBM has no room for it)
+  bool setTickPipelining(int mode) {
+    const int rc = sogm_set_overlap_clear(ctx_, mode);
+    if (rc == SOGM_ERR_CAPACITY) return false;
+    check(rc, "sogm_set_overlap_clear");
+    return true;
+  }
   // SOGM::update — FakeParticleRiskVoxel::updateMap for the whole batch (device pointers)
   void update(const float *cloud_xyz, const int32_t *cloud_range, const SogmCylinder *cyl, int n_cyl,
               const float *poses, const double *stamps, hipStream_t st = nullptr) {
