@@ -138,11 +138,15 @@ __global__ __launch_bounds__(256) void k_stamp_cloud(GridGeom g, void *__restric
     const int v = g.voxel_of(x, y, z);
     // slice 0 (:114).  The cloud lattice (0.10 m) is finer than the voxels (0.15 m): several points land in
     // one voxel, and everything below depends on the voxel only — the first point to mark a voxel of the
-    // freshly cleared slice does the work, the others stop here (fp32 cells; fp16 cells skip the shortcut).
+    // freshly cleared slice does the work, the others stop here.
     if (!g.half) {
       if (atomicExch(reinterpret_cast<float *>(base) + v, 1.0F) == 1.0F) continue;
     } else {
-      cell_st(base, v, 1.0F, g.half);
+      // fp16 cells: slice 0 holds only 0 or 1.0 (0x3C00) while the cloud is stamped, so OR-ing the bit pattern
+      // into the 32-bit word that holds the cell marks it and tells whether it was marked before
+      unsigned      *w    = reinterpret_cast<unsigned *>(base + ((size_t)v * 2 & ~(size_t)3));
+      const unsigned bits = 0x3C00u << (16 * (v & 1));
+      if ((atomicOr(w, bits) & bits) == bits) continue;
     }
     // The reference then sweeps the occupied voxels of slice 0 (:121-125); every cloud point in
     // range marks exactly one such voxel and the future marks depend only on the voxel, so the
