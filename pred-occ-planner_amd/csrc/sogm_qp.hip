@@ -4,7 +4,7 @@
 // through IOSQP (traj_opt/include/iosqp.hpp:40-115) into OSQP (external, v0.6 API, not vendored).
 // The solver restates the published OSQP algorithm exactly as oracle/qp_oracle.cpp does.
 //
-// Mapping to CDNA4: one workgroup (256 lanes = 4 waves) per agent.  The problems are tiny
+// Mapping to CDNA4: one workgroup (512 lanes = 8 waves, two per SIMD) per agent.  The problems are tiny
 // (n = 15 M <= 240 variables, m ~ 5e2..5.6e3 rows) and strictly latency-bound — an ADMM chain of
 // a few hundred dependent iterations — so the design goal is that one iteration never leaves the
 // CU and has a short critical path:
@@ -17,14 +17,20 @@
 //   * P is block diagonal (one 15x15 min-jerk block per piece), K = P + sigma I + A^T diag(rho) A is
 //     banded (half bandwidth 17): an n x 18 band in LDS, banded Cholesky on one wave
 //     (right-looking, no reductions on the dependency chain), re-factored only when rho changes;
-//     the per-iteration triangular solves walk the factor as a block-bidiagonal system held in
-//     registers (15x15 diagonal blocks, coupling folded in once per factorisation), with lane
-//     exchanges by DPP quad permutes / shuffles instead of LDS round trips on the dependency chain;
-//   * all row data sits in LDS (up to 144 KB dynamic) when it fits — the common case — and in a
-//     per-agent HBM scratch otherwise (same code through flat pointers);
-//   * an iteration is 3 barriers: [A^T w per column] | [banded solve, wave 0] | [x, then per row
-//     z~ = A x~, projection, dual update]; residual norms (every 25 iterations) are wavefront
-//     shuffle reductions combined through LDS.
+//   * register-resident iteration (M <= 8, <= 256 general and <= 1024 safety rows — every problem of the
+//     bench workload): after each factorisation the rows of K^-1 = (G G^T)^-1 are built from the
+//     block-bidiagonal factor (LDS-staged 15x15 block products) and kept in registers, 30 entries per
+//     lane, four lanes per row; x~ = K^-1 rhs is one register mat-vec with two DPP exchanges.  Waves 0-3
+//     own one general row per lane, waves 4-7 up to four safety rows per lane: coefficients, bounds, z
+//     and y live in registers, a row update is one batch of independent x~ loads plus FMAs, and only
+//     w = rho z - y (what A^T w reads) goes back to LDS.  Column entries of A are register-resident too;
+//   * general iteration (anything larger): row data in LDS when it fits, else in a per-agent HBM scratch
+//     (same code through flat pointers), banded substitution on wave 0;
+//   * an iteration is 3 barriers: [A^T w per column] | [solve] | [per row z~ = A x~, projection, dual
+//     update, x]; residual norms (every 25 iterations) are wavefront shuffle reductions combined through
+//     LDS; the termination test runs before the rho update on one residual evaluation (osqp.c order).
+// DESIGN.md section 3.1 has the measured phase split and the compiler notes (opaque lane ids, separate
+// template instances, loop constants kept out of the kernel-argument SGPR tuple).
 // No dense contraction anywhere -> no MFMA.
 #include <hip/hip_runtime.h>
 
