@@ -46,7 +46,8 @@ in gpurun_out/).
 
 State: 512-lane register-resident ADMM iteration in `k_qp` (1.27 us per iteration, was 3.9 at the start of the
 session), double-buffered SOGM with a narrow (64-workgroup) streaming clear under the whole replan, obstacle-point
-scan split from the FIRI kernel, every planner kernel free of scratch memory, 8 agent-group streams.
+scan split from the FIRI kernel, stage-wise costMVIE reduction, reworked A* expansion (19 us, was 27), every planner
+kernel free of scratch memory, 8 agent-group streams.
 
 Unprofiled bench of the same box (`python bench.py --steps 30 --warmup 3`): **{d['value']:.0f} replans/s**,
 {d['ms_per_step']:.2f} ms per tick, replans_ok {d['config']['replans_ok_fraction']:.3f}; `k_clear_slabs` inside the tick
