@@ -152,6 +152,8 @@ def main():
     q_ = sw.planner.optimize(pva, c_["goal"], c_["polys"], c_["nfaces"], c_["npoly"])
     ms_stage = sw.map.profile_read()
     avg = np.mean(np.array(clear_ms), axis=0)
+    if overlap_mode == 1 and avg[6] > 0:
+        avg[0] += avg[6]  # single-grid mode clears in two launches (narrow head + full-width rest): one clear = both
     avg[3:6] = ms_stage[3:6]
     grid_bytes = sw.map.grid_bytes()  # V * T * 4 bytes x agents of this rank = algorithmic bytes / launch
     # HBM traffic of the roofline kernel comes from the committed PMC passes (FETCH_SIZE + WRITE_SIZE,

@@ -186,7 +186,8 @@ enum {
   SOGM_PROF_ASTAR = 3,
   SOGM_PROF_CORRIDOR = 4,
   SOGM_PROF_QP = 5,
-  SOGM_PROF_N = 6
+  SOGM_PROF_CLEAR_HEAD = 6, /* single-grid pipelining: the narrow first part of a two-part clear (slot 0 = the rest) */
+  SOGM_PROF_N = 7
 };
 int sogm_set_profiling(sogm_ctx *ctx, int enable);
 /* Synchronises the device, then writes the duration (ms) of the LAST launch of each slot
@@ -195,9 +196,10 @@ int sogm_profile_read(sogm_ctx *ctx, double *out_ms_host);
 
 /*
  * Tick pipelining (mode): 0 = off (every update clears its grid in stream order).
- * 1 = in-place pre-clear: sogm_replan() launches the NEXT update's grid clear on an internal side stream as
- *     soon as its corridor stage has finished reading the SOGM (the QP stage does not touch the grid), so the
- *     HBM-bound clear runs under the latency-bound QP.  While that pre-clear is pending the map counts as "not
+ * 1 = in-place pre-clear in two parts on an internal side stream: a narrow launch clears the head of the grid
+ *     as soon as sogm_replan()'s obstacle-point kernels have read the SOGM (it shares the machine with the FIRI
+ *     kernels), and a full-width launch clears the rest once the corridor stage is done with global memory (only
+ *     the LDS-resident QP runs beside it).  While that pre-clear is pending the map counts as "not
  *     updated": queries return SOGM_ERR_STATE until the next update.
  * 2 = double-buffered: a second grid is allocated (SOGM_ERR_CAPACITY if HBM has no room; the mode is then
  *     unchanged) and sogm_replan() clears it under the WHOLE replan; the next update swaps it in.  The current

@@ -22,7 +22,7 @@ SOGM_ERR_NO_DEVICE = -2
 SOGM_ERR_HIP = -3
 SOGM_ERR_CAPACITY = -4
 SOGM_ERR_STATE = -5
-PROF_CLEAR, PROF_STAMP, PROF_SPLAT, PROF_ASTAR, PROF_CORRIDOR, PROF_QP, PROF_N = range(7)
+PROF_CLEAR, PROF_STAMP, PROF_SPLAT, PROF_ASTAR, PROF_CORRIDOR, PROF_QP, PROF_CLEAR_HEAD, PROF_N = range(8)
 
 # ASTAR_RET (path_searching/include/path_searching/dyn_a_star.h:15)
 ASTAR_NO_PATH, ASTAR_INIT_ERR, ASTAR_SEARCH_ERR, ASTAR_REACH_HORIZON, ASTAR_REACH_END, ASTAR_NEAR_END = range(6)

@@ -299,7 +299,9 @@ inline MapView view_of(const sogm_ctx *c) {
   return m;
 }
 void set_error(const char *what, hipError_t e);
-int  launch_clear(sogm_ctx *c, hipStream_t st, float *grid = nullptr, bool polite = false);
+int  launch_clear(sogm_ctx *c, hipStream_t st, float *grid = nullptr, bool polite = false, int part = 0,
+                  size_t split = 0);
+size_t clear_vec4_total(const sogm_ctx *c);
 // next update's grid becomes current (mode 2) and the stream waits for its pre-clear
 int  adopt_preclear(sogm_ctx *c, hipStream_t st);
 }  // namespace sogm

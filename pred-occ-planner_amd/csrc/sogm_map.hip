@@ -506,13 +506,20 @@ int adopt_preclear(sogm_ctx *c, hipStream_t st) {
 // kernel's loads for its whole duration; 64 workgroups with <= 4 stores in flight per wave still stream at
 // ~5.7 TB/s and leave the memory pipeline responsive.  SOGM_CLEAR_WGS / SOGM_CLEAR_THROTTLE / SOGM_CLEAR_NT
 // override the choice (tuning aids).
-int launch_clear(sogm_ctx *c, hipStream_t st, float *grid, bool polite) {
+size_t clear_vec4_total(const sogm_ctx *c) {
+  return (size_t)c->n_agents * c->spec.T * (size_t)c->geom.V * c->cell_bytes() / 4 / 4;
+}
+// part: 0 = the whole grid, 1 = the first `split` 16-byte elements, 2 = everything from `split` on
+int launch_clear(sogm_ctx *c, hipStream_t st, float *grid, bool polite, int part, size_t split) {
   if (!grid) grid = c->d_grid;
   // the clear is a byte stream: n = number of 4-byte words of the grid (fp16 grids: 2 cells per word)
-  const size_t n    = (size_t)c->n_agents * c->spec.T * (size_t)c->geom.V * c->cell_bytes() / 4;
-  const size_t nv4  = n / 4;
-  const int    tail = (int)(n - nv4 * 4);
-  size_t       want = (nv4 + 255) / 256;
+  const size_t n     = (size_t)c->n_agents * c->spec.T * (size_t)c->geom.V * c->cell_bytes() / 4;
+  const size_t nall  = n / 4;
+  const size_t first = part == 2 ? split : 0;
+  const size_t nv4   = part == 1 ? split : nall - first;
+  const int    tail  = part == 1 ? 0 : (int)(n - nall * 4);
+  const int    slot  = part == 1 ? SOGM_PROF_CLEAR_HEAD : SOGM_PROF_CLEAR;
+  size_t       want  = (nv4 + 255) / 256;
   static int   env_wgs = -1, env_throttle = -1, nt = -1;
   if (env_wgs < 0) {
     const char *e = getenv("SOGM_CLEAR_WGS");
@@ -525,14 +532,14 @@ int launch_clear(sogm_ctx *c, hipStream_t st, float *grid, bool polite) {
   const size_t max_wgs  = env_wgs ? (size_t)env_wgs : (polite ? 64 : 2048);
   const int    throttle = env_wgs ? env_throttle : (polite ? 4 : 0);
   const int    nblk     = (int)(want < 1 ? 1 : (want > max_wgs ? max_wgs : want));
-  prof_begin(c, SOGM_PROF_CLEAR, st);
+  prof_begin(c, slot, st);
   if (nt)
-    hipLaunchKernelGGL(k_clear_slabs<true>, dim3(nblk), dim3(256), 0, st, (vfloat4 *)grid, nv4, grid + nv4 * 4, tail,
-                       throttle);
+    hipLaunchKernelGGL(k_clear_slabs<true>, dim3(nblk), dim3(256), 0, st, (vfloat4 *)grid + first, nv4,
+                       grid + nall * 4, tail, throttle);
   else
-    hipLaunchKernelGGL(k_clear_slabs<false>, dim3(nblk), dim3(256), 0, st, (vfloat4 *)grid, nv4, grid + nv4 * 4, tail,
-                       throttle);
-  prof_end(c, SOGM_PROF_CLEAR, st);
+    hipLaunchKernelGGL(k_clear_slabs<false>, dim3(nblk), dim3(256), 0, st, (vfloat4 *)grid + first, nv4,
+                       grid + nall * 4, tail, throttle);
+  prof_end(c, slot, st);
   SOGM_HIP_CHECK(hipGetLastError());
   return SOGM_OK;
 }

@@ -146,6 +146,7 @@ int sogm_planner_create(sogm_ctx *map, const SogmAstarParams *astar, const SogmP
   for (int g = 0; g < p->n_groups && e == hipSuccess; ++g) {
     e = hipStreamCreateWithFlags(&p->gstream[g], hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_corr[g], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_pts[g], hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_done[g], hipEventDisableTiming);
   }
   if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_in, hipEventDisableTiming);
@@ -174,6 +175,7 @@ void sogm_planner_destroy(sogm_planner *p) {
       (void)hipStreamDestroy(p->gstream[g]);
     }
     if (p->ev_corr[g]) (void)hipEventDestroy(p->ev_corr[g]);
+    if (p->ev_pts[g]) (void)hipEventDestroy(p->ev_pts[g]);
     if (p->ev_done[g]) (void)hipEventDestroy(p->ev_done[g]);
   }
   if (p->ev_in) (void)hipEventDestroy(p->ev_in);
@@ -309,18 +311,26 @@ int sogm_replan(sogm_planner *p, const double *start_pva, const double *goal,
     if (launch_astar(mv, p->ap, p->pp.corridor_tau, p->aw, n, start_pva, goal, t_start, p->d_ret,
                      p->d_route, p->d_route_len, p->route_cap, p->d_stats, nullptr, 0, st, a0) ||
         launch_corridor(mv, p->pp, p->cw, n, start_pva, t_start, p->d_route, p->d_route_len,
-                        p->route_cap, p->d_polys, p->d_nfaces, p->d_npoly, p->d_goal, st, a0)) {
+                        p->route_cap, p->d_polys, p->d_nfaces, p->d_npoly, p->d_goal, st, a0, p->ev_pts[g])) {
       sogm::set_error("sogm_replan launch", hipGetLastError());
       return SOGM_ERR_HIP;
     }
     SOGM_HIP_CHECK(hipEventRecord(p->ev_corr[g], st));
   }
   if (c->overlap == 1) {
-    // every group's corridor stage has finished with the SOGM and with global memory: clear the grid for the
-    // next update on the side stream, under the QP stage (a full-width clear starves every concurrent load, so
-    // it must not start while the FIRI kernels still read their point sets; k_qp only touches LDS)
+    // Single grid, cleared in place for the next update in two parts on the side stream.  Head: a narrow launch
+    // as soon as every group's obstacle-point kernel — the tick's last reader of the SOGM — is done; it shares the
+    // machine with the FIRI kernels (about what they take to run: ~28 GB).  Rest: a full-width launch once every
+    // group's corridor stage has finished with global memory (a full-width clear starves every concurrent load;
+    // k_qp only touches LDS).
+    const size_t total = sogm::clear_vec4_total(c);
+    size_t       head  = (size_t)28e9 / 16;
+    if (head > total / 2) head = total / 2;
+    for (int g = 0; g < G; ++g) SOGM_HIP_CHECK(hipStreamWaitEvent(c->side, p->ev_pts[g], 0));
+    int rc = sogm::launch_clear(c, c->side, c->d_grid, true, 1, head);
+    if (rc) return rc;
     for (int g = 0; g < G; ++g) SOGM_HIP_CHECK(hipStreamWaitEvent(c->side, p->ev_corr[g], 0));
-    int rc = sogm::launch_clear(c, c->side);
+    rc = sogm::launch_clear(c, c->side, c->d_grid, false, 2, head);
     if (rc) return rc;
     SOGM_HIP_CHECK(hipEventRecord(c->ev_cleared, c->side));
     c->precleared = 1;

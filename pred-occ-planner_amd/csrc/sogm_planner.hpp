@@ -91,4 +91,5 @@ struct sogm_planner {
   int         n_groups;
   hipStream_t gstream[SOGM_MAX_GROUPS];
   hipEvent_t  ev_in, ev_corr[SOGM_MAX_GROUPS], ev_done[SOGM_MAX_GROUPS];
+  hipEvent_t  ev_pts[SOGM_MAX_GROUPS];  // after a group's obstacle-point kernel: its last read of the SOGM
 };

@@ -70,8 +70,8 @@ class SogmMap:
     def set_overlap_clear(self, on=True, double_buffer=None):
         """Tick pipelining.  Mode 2 (double_buffer, the default when HBM has room for a second grid): replan()
         clears the NEXT update's grid with a narrow streaming kernel under the whole replan.  Mode 1: the grid is
-        cleared in place at full width under the QP stage, after the corridor stage has finished with global
-        memory.  Returns the mode in effect."""
+        cleared in place in two launches — a narrow head beside the FIRI kernels, the full-width rest under the QP
+        stage.  Returns the mode in effect."""
         if not on:
             check(lib().sogm_set_overlap_clear(self._ctx, 0), "sogm_set_overlap_clear")
             return 0
