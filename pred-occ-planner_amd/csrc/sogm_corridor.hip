@@ -1014,11 +1014,11 @@ __device__ inline void segment_box(const SogmPlannerParams &pp, const double *sp
 // =================================================================================================
 // Kernel P: obstacle points of one (segment, agent) — map.cpp:480-518 / risk_base.cpp:295-337.
 // The only corridor stage that reads the SOGM: once it has run the grid may be cleared for the next update.
-// One wave; a lane takes four consecutive cells of the box scan per step so that 4 x (slabs) loads are in
-// flight per lane, and an order-preserving wave scan keeps the reference's point order (x fastest, then y, z;
-// a cell's time slices in ascending order).
+// Four waves; a lane takes four consecutive cells of the box scan per step (4 x slices loads in flight per lane,
+// 1024 cells per workgroup step), and an order-preserving wave scan + cross-wave offsets keep the reference's
+// point order (x fastest, then y, z; a cell's time slices in ascending order).
 // =================================================================================================
-__global__ __launch_bounds__(64) void k_corridor_points(MapView m, SogmPlannerParams pp, CorridorWorkspace ws,
+__global__ __launch_bounds__(256) void k_corridor_points(MapView m, SogmPlannerParams pp, CorridorWorkspace ws,
                                                         const double *__restrict__ start_pva,
                                                         const double *__restrict__ t_start,
                                                         const double *__restrict__ route,
@@ -1026,16 +1026,17 @@ __global__ __launch_bounds__(64) void k_corridor_points(MapView m, SogmPlannerPa
                                                         int agent0) {
   const int seg   = blockIdx.x;
   const int agent = blockIdx.y + agent0;
-  const int lane  = threadIdx.x;
+  const int tid   = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int rl    = route_len[agent];
   const int slot  = agent * SOGM_MAX_PIECES + seg;
   if (seg >= rl - 1 || seg >= SOGM_MAX_PIECES) return;
   __shared__ double s_box[6], s_w[6];
+  __shared__ int    s_wtot[4];
   const GridGeom &g    = m.g;
   const float    *pose = m.poses + agent * 3;
   const int       cap  = pp.pc_capacity;
   double         *pc   = ws.pc + (size_t)slot * cap * 3;
-  if (lane == 0) segment_box(pp, start_pva + agent * 9, route + (size_t)agent * route_cap * 6, seg, s_box, s_w);
+  if (tid == 0) segment_box(pp, start_pva + agent * 9, route + (size_t)agent * route_cap * 6, seg, s_box, s_w);
   __syncthreads();
   int N = 0;
   {
@@ -1067,12 +1068,12 @@ __global__ __launch_bounds__(64) void k_corridor_points(MapView m, SogmPlannerPa
       const int   cells = nx * ny * nz;
       const void *grid0 = m.slab(agent, 0);
       int         base  = 0;
-      for (int c0 = 0; c0 < cells; c0 += 256) {
+      for (int c0 = 0; c0 < cells; c0 += 1024) {
         int      cnt[4], vi[4];
         unsigned mask[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const int c = c0 + 4 * lane + q;
+          const int c = c0 + 4 * tid + q;
           cnt[q]      = 0;
           mask[q]     = 0;
           vi[q]       = 0;
@@ -1097,8 +1098,17 @@ __global__ __launch_bounds__(64) void k_corridor_points(MapView m, SogmPlannerPa
           const int up = __shfl_up(incl, d, 64);
           if (lane >= d) incl += up;
         }
-        const int total = __shfl(incl, 63, 64);
-        int       off   = base + incl - mine;
+        if (lane == 63) s_wtot[wave] = incl;
+        __syncthreads();
+        int woff = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          const int t = s_wtot[w];
+          woff += w < wave ? t : 0;
+          total += t;
+        }
+        __syncthreads();  // s_wtot is rewritten by the next step
+        int off = base + woff + incl - mine;
 #pragma unroll
         for (int q = 0; q < 4; ++q)
           if (cnt[q]) {
@@ -1119,7 +1129,7 @@ __global__ __launch_bounds__(64) void k_corridor_points(MapView m, SogmPlannerPa
       N = base;
     }
   }
-  if (lane == 0) ws.seg_npts[slot] = N;
+  if (tid == 0) ws.seg_npts[slot] = N;
 }
 
 namespace {
@@ -1669,7 +1679,7 @@ int launch_corridor(const MapView &m, const SogmPlannerParams &pp, const Corrido
                     const double *route, const int32_t *route_len, int route_cap,
                     double *out_polys, int32_t *out_nfaces, int32_t *out_npoly, double *out_goal,
                     hipStream_t st, int agent0, hipEvent_t ev_map_read) {
-  hipLaunchKernelGGL(k_corridor_points, dim3(SOGM_MAX_PIECES, n_agents), dim3(64), 0, st, m, pp, ws, start_pva,
+  hipLaunchKernelGGL(k_corridor_points, dim3(SOGM_MAX_PIECES, n_agents), dim3(256), 0, st, m, pp, ws, start_pva,
                      t_start, route, route_len, route_cap, agent0);
   if (hipGetLastError() != hipSuccess) return -1;
   // nothing after this point reads the SOGM
