@@ -486,6 +486,21 @@ int sogm_bezier_qp_solve(sogm_planner *p, const double *start_pva, const double 
                          double *out_cpts, int32_t *out_status, int32_t *out_iters, void *stream);
 
 /*
+ * sdlp::linprog<d> (traj_utils/include/traj_utils/sdlp.hpp:709-787) for a batch of independent problems
+ *   min c^T x  s.t.  A x <= b,  d = 3 or 4
+ * — the LP behind checkCorridorValidity / checkCorridorIntersect / checkGoalReachability
+ * (plan_manager/src/baseline_fake.cpp:143-199) and the MVIE's deepest interior point
+ * (plan_manager/include/sfc_gen/firi.hpp:150-165), one wave per problem.  Same arithmetic as sdlp's projective
+ * Seidel LP; the plane insertion order is a fixed permutation of the row count (sdlp draws it from a
+ * process-global std::mt19937_64, :686-705).
+ * dev c [n*d], dev A [total_rows*d] row-major, dev b [total_rows], dev row_range [n*2] int32 {begin,end};
+ * dev out_x [n*d], dev out_min [n]: the minimum, +inf infeasible, -inf unbounded (out_x then holds a
+ * direction, :777-781); NaN when a problem has more than 152 rows (the LDS capacity of one wave's LP).
+ */
+int sogm_linprog_batched(int d, const double *c, const double *A, const double *b,
+                         const int32_t *row_range, int n, double *out_x, double *out_min, void *stream);
+
+/*
  * ParticleATC::isSafeAfterOpt (traj_coordinator/src/particles.cpp:223-283) for every agent: the new
  * trajectory's control points must be linearly separable (separator::Separator::solveModel,
  * utils/separator/src/separator_glpk.cpp:75-190 — a GLPK feasibility LP, solved here with the

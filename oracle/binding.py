@@ -33,7 +33,7 @@ def lib():
         if not os.path.exists(LIB_PATH):
             build()
         _lib = C.CDLL(LIB_PATH)
-        for name in ("orc_bezier_max_rate", "orc_linprog"):
+        for name in ("orc_bezier_max_rate", "orc_linprog", "orc_linprog_perm"):
             if hasattr(_lib, name):
                 getattr(_lib, name).restype = C.c_double
     return _lib
@@ -160,6 +160,29 @@ def linprog(c, A, b):
     x = np.zeros(d)
     v = lib().orc_linprog(d, dptr(c), dptr(A), dptr(b), A.shape[0], dptr(x))
     return float(v), x
+
+
+def linprog_perm(c, A, b, perm):
+    c = np.ascontiguousarray(c, np.float64)
+    A = np.ascontiguousarray(A, np.float64)
+    b = np.ascontiguousarray(b, np.float64)
+    perm = np.ascontiguousarray(perm, np.int32)
+    assert sorted(perm.tolist()) == list(range(A.shape[0]))
+    x = np.zeros(len(c))
+    v = lib().orc_linprog_perm(len(c), dptr(c), dptr(A), dptr(b), A.shape[0], iptr(perm), dptr(x))
+    return float(v), x
+
+
+def lp_set_mode(mode, reset=True):
+    lib().orc_lp_set_mode(int(mode))
+    if reset:
+        lib().orc_lp_rng_reset()
+
+
+def lp_permutation(n, kind="fixed"):
+    p = np.zeros(max(n, 1), np.int32)
+    (lib().orc_lp_fixed_permutation if kind == "fixed" else lib().orc_lp_rand_permutation)(n, iptr(p))
+    return p[:n]
 
 
 # ---------------------------------------------------------------- FIRI / corridors

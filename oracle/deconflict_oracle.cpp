@@ -5,7 +5,11 @@
 // (set B).  The reference decides that with separator::Separator::solveModel
 // (utils/separator/src/separator_glpk.cpp:75-190): the feasibility LP  n.a + d >= 1,  n.b + d <= -1
 // with a zero objective, solved by GLPK (external, absent here) — true iff GLP_OPT / GLP_FEAS.
-// Here the same LP goes through the Seidel LP already used for the corridor checks (lp_oracle.cpp).
+// Here the same LP goes through the sdlp restatement already used for the corridor checks (lp_oracle.cpp),
+// with the variables boxed at +-1e4 (8 extra rows after the point rows): sdlp works in projective space
+// and reports a feasible point AT INFINITY (two crossing segments: the plane through both is a weakly
+// separating direction) as "-inf", which GLPK's affine model calls infeasible.  With the box the answer is
+// finite (feasible) or +inf (infeasible).
 // Parity: UNPINNED (no reference test beyond utils/separator/src/test_separator.cpp, which prints).
 #include <cmath>
 #include <vector>
@@ -65,7 +69,7 @@ extern "C" int orc_separable(const double *A, int nA, const double *B, int nB) {
       if (hiA < loB || hiB < loA) return 1;
     }
   }
-  std::vector<double> rows((size_t)(nA + nB) * 4), rhs(nA + nB);
+  std::vector<double> rows((size_t)(nA + nB + 8) * 4, 0.0), rhs(nA + nB + 8);
   for (int i = 0; i < nA; ++i) {  // -(n.a + d) <= -1
     for (int k = 0; k < 3; ++k) rows[i * 4 + k] = -A[i * 3 + k];
     rows[i * 4 + 3] = -1.0;
@@ -76,10 +80,15 @@ extern "C" int orc_separable(const double *A, int nA, const double *B, int nB) {
     rows[(nA + i) * 4 + 3] = 1.0;
     rhs[nA + i]            = -1.0;
   }
+  for (int k = 0; k < 4; ++k) {  // x_k <= 1e4, -x_k <= 1e4
+    rows[(size_t)(nA + nB + 2 * k) * 4 + k]     = 1.0;
+    rows[(size_t)(nA + nB + 2 * k + 1) * 4 + k] = -1.0;
+    rhs[nA + nB + 2 * k] = rhs[nA + nB + 2 * k + 1] = 1.0e4;
+  }
   const double c[4] = {0, 0, 0, 0};
   double       x[4];
-  const double v = orc_linprog(4, c, rows.data(), rhs.data(), nA + nB, x);
-  return !(std::isinf(v));
+  const double v = orc_linprog(4, c, rows.data(), rhs.data(), nA + nB + 8, x);
+  return !std::isinf(v);
 }
 
 // cpts: the new trajectory's 5*M control points; t_now: "ros::Time::now()" of the check.

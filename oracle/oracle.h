@@ -79,9 +79,19 @@ int orc_astar_search(const SogmSpec *s, const SogmAstarParams *ap, const float *
                      int *out_route_len, int route_cap, int out_stats[4], int *out_trace,
                      int trace_cap, int *out_trace_len);
 
-/* ---- a12: Seidel LP  min c^T x s.t. A x <= b  (traj_utils/include/traj_utils/sdlp.hpp:709-787) */
+/* ---- a12: sdlp::linprog<d>  min c^T x s.t. A x <= b  (traj_utils/include/traj_utils/sdlp.hpp:709-787) */
 /* d in {3,4}; A row-major m x d; returns minimum, +inf infeasible, -inf unbounded */
 double orc_linprog(int d, const double *c, const double *A, const double *b, int m, double *x);
+/* the same with the insertion permutation (sdlp.hpp:747, perm[m]) as an explicit input */
+double orc_linprog_perm(int d, const double *c, const double *A, const double *b, int m,
+                        const int *perm, double *x);
+/* insertion order used by orc_linprog: 0 fixed LCG permutation (the batched HIP path), 1 sdlp's
+ * static std::mt19937_64 + this image's std::uniform_int_distribution<int>, 2 the same stream with
+ * libstdc++ <= 10's range mapping (Ubuntu 20.04, the reference's platform).  See lp_oracle.cpp. */
+void orc_lp_set_mode(int mode);
+void orc_lp_rng_reset(void);                 /* generator back to a fresh process's state */
+void orc_lp_rand_permutation(int n, int *p); /* sdlp::rand_permutation (sdlp.hpp:686-706), modes 1/2 */
+void orc_lp_fixed_permutation(int n, int *p);
 
 /* ---- a11: FIRI + MVIE (plan_manager/include/sfc_gen/firi.hpp) ---- */
 /* bd: 6x4 row-major; pc: n x 3; hpoly out: up to max_faces x 4; returns number of faces or -1 */

@@ -5,7 +5,7 @@
 //   getObstaclePoints (plan_env/src/map.cpp:480-518 / risk_base.cpp:295-337)
 //   firi::firi + maxVolInsEllipsoid + costMVIE (plan_manager/include/sfc_gen/firi.hpp:44-365)
 //   lbfgs::lbfgs_optimize + Lewis-Overton line search (plan_manager/include/sfc_gen/lbfgs.hpp)
-//   sdlp::linprog<3|4> (traj_utils/include/traj_utils/sdlp.hpp) — here Seidel's published algorithm
+//   sdlp::linprog<3|4> (traj_utils/include/traj_utils/sdlp.hpp) — the projective Seidel LP, whole-wave
 //   ShrinkCorridor / checkCorridorValidity / checkCorridorIntersect / checkGoalReachability.
 //
 // Mapping to CDNA4: one workgroup (one 64-lane wave) per (agent, path segment) — 7 segments x 128
@@ -27,358 +27,435 @@
 namespace sogm {
 namespace {
 
-#define LP_MAX_ROWS 152  // 2 * max_faces(64) + 2 * 4 box rows = 136, plus head-room; keeps the segment kernel at 4 workgroups per CU (LDS <= 40 KB)
-#define LP_WORK_DOUBLES (14 * LP_MAX_ROWS)
+#define LP_MAX_ROWS 153  // planes of one LP incl. sdlp's plane 0: 2 * max_faces(64) + 1, or 144 deconfliction rows + 8 box rows + 1; keeps the segment kernel at 4 workgroups per CU (LDS <= 40 KB)
+#define LP_WORK_DOUBLES (14 * LP_MAX_ROWS)  // planes of the four recursion levels: (5 + 4 + 3 + 2) per row
 #define FIRI_MAX_H 128  // planes selected before truncation to max_faces
-
-__device__ const double LP_BOX  = 1.0e4;
-__device__ const double LP_BIG  = 1.0e7;
-__device__ const double LP_TOL  = 1.0e-10;
-__device__ const double LP_TINY = 1.0e-12;
 
 __device__ inline double dot3(const double *a, const double *b) {
   return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2];
 }
 __device__ inline double dabs(double x) { return x < 0 ? -x : x; }
 
-// ---------------------------------------------------------------------------------------------
-// Seidel LP (same algorithm and operation order as oracle/lp_oracle.cpp)
-// ---------------------------------------------------------------------------------------------
-template <int D>
-struct Seidel {
-  __device__ static bool solve(const double *a, const double *b, int m, const double *c, double *x,
-                               double *work) {
-    for (int j = 0; j < D; ++j) x[j] = c[j] > 0 ? -LP_BIG : (c[j] < 0 ? LP_BIG : 0.0);
-    double *sa = work;
-    double *sb = work + LP_MAX_ROWS * (D - 1);
-    for (int i = 0; i < m; ++i) {
-      const double *ai = a + i * D;
-      double        v  = 0;
-      for (int j = 0; j < D; ++j) v += ai[j] * x[j];
-      if (v <= b[i] + LP_TOL) continue;
-      int    k  = 0;
-      double mx = dabs(ai[0]);
-      for (int j = 1; j < D; ++j)
-        if (dabs(ai[j]) > mx) {
-          mx = dabs(ai[j]);
-          k  = j;
-        }
-      if (mx < LP_TINY) return false;
-      const double inv = 1.0 / ai[k];
-      for (int r = 0; r < i; ++r) {
-        const double *ar = a + r * D;
-        const double  f  = ar[k] * inv;
-        int           q  = 0;
-        for (int j = 0; j < D; ++j)
-          if (j != k) sa[r * (D - 1) + q++] = ar[j] - f * ai[j];
-        sb[r] = b[r] - f * b[i];
-      }
-      double cc[D - 1];
-      {
-        const double f = c[k] * inv;
-        int          q = 0;
-        for (int j = 0; j < D; ++j)
-          if (j != k) cc[q++] = c[j] - f * ai[j];
-      }
-      double xs[D - 1];
-      if (!Seidel<D - 1>::solve(sa, sb, i, cc, xs, work + LP_MAX_ROWS * D)) return false;
-      double acc = b[i];
-      int    q   = 0;
-      for (int j = 0; j < D; ++j)
-        if (j != k) {
-          x[j] = xs[q++];
-          acc -= ai[j] * x[j];
-        }
-      x[k] = acc * inv;
-    }
-    return true;
-  }
-};
-template <>
-struct Seidel<1> {
-  __device__ static bool solve(const double *a, const double *b, int m, const double *c, double *x,
-                               double *) {
-    double lo = -LP_BIG, hi = LP_BIG;
-    for (int i = 0; i < m; ++i) {
-      if (a[i] > LP_TINY) {
-        const double v = b[i] / a[i];
-        if (v < hi) hi = v;
-      } else if (a[i] < -LP_TINY) {
-        const double v = b[i] / a[i];
-        if (v > lo) lo = v;
-      } else if (b[i] < -LP_TOL) {
-        return false;
-      }
-    }
-    if (lo > hi + LP_TOL) return false;
-    if (lo > hi) lo = hi = 0.5 * (lo + hi);
-    if (c[0] > 0)
-      x[0] = lo;
-    else if (c[0] < 0)
-      x[0] = hi;
-    else
-      x[0] = lo > 0 ? lo : (hi < 0 ? hi : 0.0);
-    return true;
-  }
-};
-
-// min c^T x s.t. A[i][0..D) x <= rhs[i]  (A row-major, stride D).
-// work: LP_WORK_DOUBLES doubles (LDS), perm: LP_MAX_ROWS ints.  Returns +inf infeasible, -inf
-// unbounded (solution on the 1e4 box), else the minimum.
-template <int D>
-__device__ __noinline__ double linprog(const double *c, int m, const double *A, const double *rhsv,
-                                       double *x, double *work, int *perm) {
-  for (int j = 0; j < D; ++j) x[j] = 0.0;
-  if (m <= 0) {
-    double mx = 0;
-    for (int j = 0; j < D; ++j) mx = dabs(c[j]) > mx ? dabs(c[j]) : mx;
-    return mx > 0.0 ? -INFINITY : 0.0;
-  }
-  const int M  = m + 2 * D;
-  double   *a  = work;                    // [LP_MAX_ROWS][D]
-  double   *bb = work + LP_MAX_ROWS * D;  // [LP_MAX_ROWS]
-  for (int i = 0; i < 2 * D; ++i)
-    for (int j = 0; j < D; ++j) a[i * D + j] = 0.0;
-  for (int j = 0; j < D; ++j) {
-    a[(2 * j) * D + j]     = 1.0;
-    bb[2 * j]              = LP_BOX;
-    a[(2 * j + 1) * D + j] = -1.0;
-    bb[2 * j + 1]          = LP_BOX;
-  }
-  for (int i = 0; i < m; ++i) perm[i] = i;
-  unsigned long long s = 0x9E3779B97F4A7C15ULL;
-  for (int i = m - 1; i > 0; --i) {
-    s           = s * 6364136223846793005ULL + 1442695040888963407ULL;
-    const int j = (int)((s >> 33) % (unsigned long long)(i + 1));
-    const int t = perm[i];
-    perm[i]     = perm[j];
-    perm[j]     = t;
-  }
-  for (int i = 0; i < m; ++i) {
-    const double *src = A + perm[i] * D;
-    const double  rhs = rhsv[perm[i]];
-    double        nn  = 0;
-    for (int j = 0; j < D; ++j) nn += src[j] * src[j];
-    nn          = sogm_det::sqrt_rn(nn);
-    double *dst = a + (2 * D + i) * D;
-    if (nn > 0) {
-      for (int j = 0; j < D; ++j) dst[j] = src[j] / nn;
-      bb[2 * D + i] = rhs / nn;
-    } else {
-      for (int j = 0; j < D; ++j) dst[j] = 0;
-      bb[2 * D + i] = rhs;
-    }
-  }
-  double xs[D];
-  if (!Seidel<D>::solve(a, bb, M, c, xs, work + LP_MAX_ROWS * (D + 1))) return INFINITY;
-  for (int j = 0; j < D; ++j) x[j] = xs[j];
-  for (int j = 0; j < D; ++j)
-    if (dabs(xs[j]) > 0.99 * LP_BOX) return -INFINITY;
-  double v = 0;
-  for (int j = 0; j < D; ++j) v += c[j] * xs[j];
-  return v;
-}
-
-// ---------------------------------------------------------------------------------------------
-// The same Seidel LP executed by the whole wave (all 64 lanes call it with identical arguments; a, b, work
-// live in LDS).  Arithmetic and decisions are those of Seidel<D>::solve above: "the next violated
-// constraint" is found 64 constraints at a time with a ballot (x does not change between violations, so the
-// first set bit IS the sequential scan's hit), the reduced rows of the (D-1)-dimensional sub-problem are
-// built one per lane, and the 1-D base case is a min / max / any reduction.  Same results, bit for bit.
-// ---------------------------------------------------------------------------------------------
 __device__ inline void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
+
+// ---------------------------------------------------------------------------------------------
+// sdlp::linprog<d> (traj_utils/include/traj_utils/sdlp.hpp:709-787) executed by a whole wave.
+//
+// Hohmeyer's projective Seidel LP: planes carry d+1 homogeneous coefficients, plane 0 is "x_d >= 0", the
+// objective is n.x / d.x; a violated plane recurses into the problem on that plane with the coordinate of its
+// largest coefficient eliminated (linfracprog<d>, :526-662), the 1-D problem is a wedge on the projective line
+// (wedge / lp_base_case, :260-446).  All 64 lanes call with identical arguments; the arithmetic and every
+// decision are those of the sequential code (same operation order as oracle/lp_oracle.cpp, bit for bit):
+//   * sdlp's doubly linked list (next/prev, shared by all recursion levels) is the array ord[position] ->
+//     plane; move_to_front (:132-150) of the plane at position q rotates ord[1..q] by one, and "continue with
+//     the successor of the returned plane" is position q + 1 in either of its branches;
+//   * opt does not change between two violated planes, so "the next violated plane in list order" is found 64
+//     positions at a time with a ballot (first set bit = the sequential scan's hit); the same holds for the
+//     wedge, whose state (cw, ccw) only changes at an "offensive" plane;
+//   * the planes in front of the violated one are projected one per lane (:604-618);
+//   * objective vectors and optima live in registers (compile-time indices, select chains for imax).
+// Deviation from the reference (documented in DESIGN.md): the insertion order is a fixed LCG Fisher-Yates
+// permutation of the row count instead of sdlp's process-global mt19937_64 (call-history dependent).
+// ---------------------------------------------------------------------------------------------
+#define SDLP_EPS 1.0e-12
+enum { SDLP_MINIMUM = 0, SDLP_INFEASIBLE = 1, SDLP_UNBOUNDED = 2, SDLP_AMBIGUOUS = 3 };
+
+// lp_no_con<d> (:97-129) incl. unit<d> (:76-94)
 template <int D>
-struct SeidelW {
-  // c and x are caller-side REGISTER arrays: every access below uses a compile-time index (select chains pick
-  // the eliminated coordinate k), so nothing is demoted to scratch memory.
-  __device__ static bool solve(const double *a, const double *b, int m, const double *c, double *x,
-                               double *work) {
+__device__ __forceinline__ int lp_no_con(const double (&nv)[D + 1], const double (&dv)[D + 1],
+                                         double (&opt)[D + 1]) {
+  double n_dot_d = 0.0, d_dot_d = 0.0;
+#pragma unroll
+  for (int i = 0; i <= D; ++i) {
+    n_dot_d += nv[i] * dv[i];
+    d_dot_d += dv[i] * dv[i];
+  }
+  if (d_dot_d < SDLP_EPS * SDLP_EPS) {
+    n_dot_d = 0.0;
+    d_dot_d = 1.0;
+  }
+#pragma unroll
+  for (int i = 0; i <= D; ++i) opt[i] = -nv[i] + dv[i] * n_dot_d / d_dot_d;
+  double mag = 0.0;
+#pragma unroll
+  for (int i = 0; i <= D; ++i) mag += opt[i] * opt[i];
+  if (mag < (D + 1) * SDLP_EPS * SDLP_EPS) {
+    opt[D] = 1.0;
+    return SDLP_AMBIGUOUS;
+  }
+  mag = 1.0 / sogm_det::sqrt_rn(mag);
+#pragma unroll
+  for (int i = 0; i <= D; ++i) opt[i] *= mag;
+  return SDLP_MINIMUM;
+}
+
+// move_to_front (:132-150) on the position array: the plane at position q goes to position 1
+__device__ __forceinline__ void lp_move_to_front(int *ord, int q) {
+  if (q > 1) {  // q == 0: plane 0; q == 1: already next[0]
     const int lane = threadIdx.x & 63;
-    double    cv[D];  // the objective by value: no conditional load from the caller's array survives
+    const int iq   = ord[q];
+    const int r0 = 1 + lane, r1 = 65 + lane, r2 = 129 + lane;  // LP_MAX_ROWS <= 193 positions
+    const int v0 = r0 < q ? ord[r0] : 0;
+    const int v1 = r1 < q ? ord[r1] : 0;
+    const int v2 = r2 < q ? ord[r2] : 0;
+    wave_lds_sync();
+    if (r0 < q) ord[r0 + 1] = v0;
+    if (r1 < q) ord[r1 + 1] = v1;
+    if (r2 < q) ord[r2 + 1] = v2;
+    if (lane == 0) ord[1] = iq;
+    wave_lds_sync();
+  }
+}
+
+__device__ __forceinline__ double dot2(const double a[2], const double b[2]) { return a[0] * b[0] + a[1] * b[1]; }
+__device__ __forceinline__ double cross2(const double a[2], const double b[2]) { return a[0] * b[1] - a[1] * b[0]; }
+// unit2 (:61-73); b may alias a
+__device__ __forceinline__ bool unit2(const double a[2], double b[2]) {
+  const double a0 = a[0], a1 = a[1];
+  const double mag = sogm_det::sqrt_rn(a0 * a0 + a1 * a1);
+  if (mag < 2.0 * SDLP_EPS) return true;
+  b[0] = a0 / mag;
+  b[1] = a1 / mag;
+  return false;
+}
+
+// lp_min_lin_rat (:152-258)
+__device__ __forceinline__ void lp_min_lin_rat(bool degen, const double cw[2], const double ccw[2],
+                                               const double nv[2], const double dv[2], double opt[2]) {
+  const double d_cw = dot2(cw, dv), d_ccw = dot2(ccw, dv);
+  const double n_cw = dot2(cw, nv), n_ccw = dot2(ccw, nv);
+  bool take_cw;
+  if (degen) {
+    take_cw = n_cw / d_cw < n_ccw / d_ccw;
+  } else if (dabs(d_cw) > 2.0 * SDLP_EPS && dabs(d_ccw) > 2.0 * SDLP_EPS) {
+    if (d_cw * d_ccw > 0.0) {
+      take_cw = n_cw / d_cw < n_ccw / d_ccw;
+    } else {
+      if (d_cw > 0.0) {
+        opt[0] = -dv[1];
+        opt[1] = dv[0];
+      } else {
+        opt[0] = dv[1];
+        opt[1] = -dv[0];
+      }
+      return;
+    }
+  } else if (dabs(d_cw) > 2.0 * SDLP_EPS) {
+    take_cw = n_ccw * d_cw > 0.0;
+  } else if (dabs(d_ccw) > 2.0 * SDLP_EPS) {
+    take_cw = !(n_cw * d_ccw > 2.0 * SDLP_EPS);
+  } else {
+    take_cw = cross2(dv, nv) > 0.0;
+  }
+  opt[0] = take_cw ? cw[0] : ccw[0];
+  opt[1] = take_cw ? cw[1] : ccw[1];
+}
+
+// first position in [p, count) whose lane predicate holds (-1 if none); pred(r) is evaluated one position per lane
+template <class F>
+__device__ __forceinline__ int lp_first(int p, int count, F pred) {
+  const int lane = threadIdx.x & 63;
+  for (int base = p; base < count; base += 64) {
+    const int                r  = base + lane;
+    const bool               ok = r < count ? pred(r) : false;
+    const unsigned long long mk = __ballot(ok);
+    if (mk) return base + __ffsll((long long)mk) - 1;
+  }
+  return -1;
+}
+
+template <int D>
+struct Lfp {
+  // halves: LDS, stride D+1, indexed by plane; the list is ord[0..count).  work: planes of the lower levels.
+  __device__ __forceinline__ static int solve(const double *halves, int count, const double (&nv_in)[D + 1],
+                              const double (&dv_in)[D + 1], double (&opt)[D + 1], double *work, int *ord) {
+    const int lane = threadIdx.x & 63;
+    // the objective by value: a select between two entries of the CALLER's array would be folded into an
+    // indexed load before inlining and demote that array to scratch memory
+    double nv[D + 1], dv[D + 1];
 #pragma unroll
-    for (int j = 0; j < D; ++j) cv[j] = c[j];
+    for (int j = 0; j <= D; ++j) {
+      nv[j] = nv_in[j];
+      dv[j] = dv_in[j];
+    }
+    double    val  = 0.0;
 #pragma unroll
-    for (int j = 0; j < D; ++j) x[j] = cv[j] > 0 ? -LP_BIG : (cv[j] < 0 ? LP_BIG : 0.0);
-    double *sa = work;
-    double *sb = work + LP_MAX_ROWS * (D - 1);
-    int     i  = 0;
-    while (i < m) {
-      int found = -1;
-      for (int base = i; base < m; base += 64) {
-        const int r    = base + lane;
-        bool      viol = false;
-        if (r < m) {
-          const double *ar = a + r * D;
-          double        v  = 0;
+    for (int j = 0; j <= D; ++j) val += dv[j] * dv[j];
+    const bool d_vec_zero = val < (D + 1) * SDLP_EPS * SDLP_EPS;
+    int        status     = lp_no_con<D>(nv, dv, opt);
+    if (count <= 0) return status;
+    double *new_halves = work;  // [LP_MAX_ROWS][D]
+    int     p          = 0;
+    while (p < count) {
+      const int q = lp_first(p, count, [&](int r) {
+        const double *pl = halves + ord[r] * (D + 1);
+        double        v  = 0.0;
 #pragma unroll
-          for (int j = 0; j < D; ++j) v += ar[j] * x[j];
-          viol = !(v <= b[r] + LP_TOL);
-        }
-        const unsigned long long mk = __ballot(viol);
-        if (mk) {
-          found = base + __ffsll((long long)mk) - 1;
-          break;
+        for (int j = 0; j <= D; ++j) v += opt[j] * pl[j];
+        return v < -(D + 1) * SDLP_EPS;
+      });
+      if (q < 0) break;
+      const int     i  = ord[q];
+      const double *pi = halves + i * (D + 1);
+      double        pv[D + 1];
+#pragma unroll
+      for (int j = 0; j <= D; ++j) pv[j] = pi[j];
+      int    imax = 0;  // findimax (:449-464); the imax-th entries of the plane and of both objective vectors
+      double rmax = dabs(pv[0]), pmax = pv[0], nmax = nv[0], dmax = dv[0];  // ride along (no indexed access)
+#pragma unroll
+      for (int j = 1; j <= D; ++j) {
+        const double ab = dabs(pv[j]);
+        if (ab > rmax) {
+          imax = j;
+          rmax = ab;
+          pmax = pv[j];
+          nmax = nv[j];
+          dmax = dv[j];
         }
       }
-      if (found < 0) break;
-      i                = found;
-      const double *ai = a + i * D;
-      double        av[D];
+      if (i != 0) {  // project the planes in front of i (:604-618), one per lane
+        const double fac = 1.0 / pmax;
+        for (int r = lane; r < q; r += 64) {
+          const int     j    = ord[r];
+          const double *old  = halves + j * (D + 1);
+          const double  crit = old[imax] * fac;
+          double       *np   = new_halves + j * D;
 #pragma unroll
-      for (int j = 0; j < D; ++j) av[j] = ai[j];
-      int    k  = 0;
-      double mx = dabs(av[0]), ak = av[0], ck = cv[0];
-#pragma unroll
-      for (int j = 1; j < D; ++j)
-        if (dabs(av[j]) > mx) {
-          mx = dabs(av[j]);
-          k  = j;
-          ak = av[j];
-          ck = cv[j];
+          for (int l = 0; l < D; ++l) {
+            const int k = l < imax ? l : l + 1;
+            np[l]       = old[k] - (l < imax ? pv[l] : pv[l + 1]) * crit;
+          }
         }
-      if (mx < LP_TINY) return false;
-      const double inv = 1.0 / ak;
-      for (int r = lane; r < i; r += 64) {
-        const double *ar = a + r * D;
-        const double  f  = ar[k] * inv;
-#pragma unroll
-        for (int q = 0; q < D - 1; ++q) {
-          const int j          = q < k ? q : q + 1;
-          sa[r * (D - 1) + q] = ar[j] - f * ai[j];
-        }
-        sb[r] = b[r] - f * b[i];
       }
       wave_lds_sync();
-      double cc[D - 1];
-      {
-        const double f = ck * inv;
+      double nn[D], nd[D];
+      if (d_vec_zero) {  // vector_down (:485-507)
+        double ve = 0.0, ee = 0.0;
 #pragma unroll
-        for (int q = 0; q < D - 1; ++q) {
-          const double cj = q < k ? cv[q] : cv[q + 1];
-          const double aj = q < k ? av[q] : av[q + 1];
-          cc[q]           = cj - f * aj;
+        for (int j = 0; j <= D; ++j) {
+          ve += nv[j] * pv[j];
+          ee += pv[j] * pv[j];
+        }
+        const double fac = ve / ee;
+#pragma unroll
+        for (int l = 0; l < D; ++l) {
+          nn[l] = (l < imax ? nv[l] : nv[l + 1]) - (l < imax ? pv[l] : pv[l + 1]) * fac;
+          nd[l] = 0.0;
+        }
+      } else {  // plane_down (:509-524) for numerator and denominator
+        const double critn = nmax / pmax;
+        const double critd = dmax / pmax;
+#pragma unroll
+        for (int l = 0; l < D; ++l) {
+          const double e = l < imax ? pv[l] : pv[l + 1];
+          nn[l]          = (l < imax ? nv[l] : nv[l + 1]) - e * critn;
+          nd[l]          = (l < imax ? dv[l] : dv[l + 1]) - e * critd;
         }
       }
-      double xs[D - 1];
-      if (!SeidelW<D - 1>::solve(sa, sb, i, cc, xs, work + LP_MAX_ROWS * D)) return false;
-      double acc = b[i];
-      double xv[D];
+      double nopt[D];
+      status = Lfp<D - 1>::solve(new_halves, q, nn, nd, nopt, work + LP_MAX_ROWS * D, ord);
+      if (status == SDLP_INFEASIBLE) return status;
+      // vector_up (:466-483) then the inline unit (:641-651)
+      double acc = 0.0;
 #pragma unroll
-      for (int j = 0; j < D; ++j) {
-        // value of coordinate j of the lifted point when j != k: xs[j] below k, xs[j - 1] above
-        const double lo = j < D - 1 ? xs[j < D - 1 ? j : 0] : 0.0;
-        const double hi = j > 0 ? xs[j > 0 ? j - 1 : 0] : 0.0;
-        const double v  = j < k ? lo : hi;
-        const double na = acc - av[j] * v;
-        acc             = j != k ? na : acc;
-        xv[j]           = v;
+      for (int j = 0; j <= D; ++j) {
+        const double lo = nopt[j < D ? j : 0];       // low_vector[j]     (used when j < imax)
+        const double hi = nopt[j > 0 ? j - 1 : 0];   // low_vector[j - 1] (used when j > imax)
+        const double v  = j < imax ? lo : hi;
+        const double na = acc - pv[j] * v;
+        acc             = j != imax ? na : acc;
+        opt[j]          = v;
       }
-      const double xk = acc * inv;
+      acc /= pmax;
 #pragma unroll
-      for (int j = 0; j < D; ++j) x[j] = j == k ? xk : xv[j];
-      wave_lds_sync();  // the sub-problem arrays are rebuilt by the next violation
-      ++i;
+      for (int j = 0; j <= D; ++j) opt[j] = j == imax ? acc : opt[j];
+      double mag = 0.0;
+#pragma unroll
+      for (int j = 0; j <= D; ++j) mag += opt[j] * opt[j];
+      mag = 1.0 / sogm_det::sqrt_rn(mag);
+#pragma unroll
+      for (int j = 0; j <= D; ++j) opt[j] *= mag;
+      lp_move_to_front(ord, q);
+      p = q + 1;
     }
-    return true;
+    return status;
   }
 };
+
+// linfracprog<1> (:664-684) = lp_base_case (:378-446) over wedge (:260-375); halves stride 2
 template <>
-struct SeidelW<1> {
-  __device__ static bool solve(const double *a, const double *b, int m, const double *c, double *x,
-                               double *) {
-    const int lane = threadIdx.x & 63;
-    double    lo = -LP_BIG, hi = LP_BIG;
-    bool      bad = false;
-    for (int i = lane; i < m; i += 64) {
-      if (a[i] > LP_TINY) {
-        const double v = b[i] / a[i];
-        if (v < hi) hi = v;
-      } else if (a[i] < -LP_TINY) {
-        const double v = b[i] / a[i];
-        if (v > lo) lo = v;
-      } else if (b[i] < -LP_TOL) {
-        bad = true;
+struct Lfp<1> {
+  __device__ __forceinline__ static int solve(const double *halves, int count, const double (&nv)[2], const double (&dv)[2],
+                              double (&opt)[2], double *, int *ord) {
+    if (count <= 0) return lp_no_con<1>(nv, dv, opt);
+    const double e2 = 2.0 * SDLP_EPS;
+    double       cw[2], ccw[2];
+    bool         degen = false;
+    {  // the first plane of the list that is not (numerically) zero spans the initial half circle
+      const int q0 = lp_first(0, count, [&](int r) {
+        const double *h = halves + 2 * ord[r];
+        return !(sogm_det::sqrt_rn(h[0] * h[0] + h[1] * h[1]) < e2);
+      });
+      if (q0 < 0) return lp_no_con<1>(nv, dv, opt);  // wedge: UNBOUNDED
+      const double *h = halves + 2 * ord[q0];
+      unit2(h, ccw);
+      cw[0]  = ccw[1];
+      cw[1]  = -ccw[0];
+      ccw[0] = -cw[0];
+      ccw[1] = -cw[1];
+    }
+    int p = 0;
+    while (p < count) {
+      const int q = lp_first(p, count, [&](int r) {
+        const double *h    = halves + 2 * ord[r];
+        const double  d_cw = dot2(cw, h), d_ccw = dot2(ccw, h);
+        if (d_ccw >= e2) return d_cw <= -e2;
+        if (d_cw >= e2) return d_ccw <= -e2;
+        if (d_ccw <= -e2 && d_cw <= -e2) return true;
+        return d_cw <= -e2 || d_ccw <= -e2 || cross2(cw, h) < 0.0;
+      });
+      if (q < 0) break;
+      const double h[2]  = {halves[2 * ord[q]], halves[2 * ord[q] + 1]};
+      const double d_cw = dot2(cw, h), d_ccw = dot2(ccw, h);
+      if (d_ccw >= e2) {
+        cw[0] = h[1];
+        cw[1] = -h[0];
+        unit2(cw, cw);
+      } else if (d_cw >= e2) {
+        ccw[0] = -h[1];
+        ccw[1] = h[0];
+        unit2(ccw, ccw);
+      } else if (d_ccw <= -e2 && d_cw <= -e2) {
+        return SDLP_INFEASIBLE;
+      } else {
+        if (d_cw <= -e2)
+          unit2(ccw, cw);
+        else if (d_ccw <= -e2)
+          unit2(cw, ccw);
+        degen = true;
+      }
+      lp_move_to_front(ord, q);
+      p = q + 1;
+      if (degen) break;
+    }
+    if (degen) {
+      while (p < count) {
+        const int q = lp_first(p, count, [&](int r) {
+          const double *h = halves + 2 * ord[r];
+          return dot2(cw, h) < -e2 || dot2(ccw, h) < -e2;
+        });
+        if (q < 0) break;
+        const double h[2] = {halves[2 * ord[q]], halves[2 * ord[q] + 1]};
+        const double d_cw = dot2(cw, h), d_ccw = dot2(ccw, h);
+        if (d_cw < -e2) {
+          if (d_ccw < -e2) return SDLP_INFEASIBLE;
+          cw[0] = ccw[0];
+          cw[1] = ccw[1];
+        } else {
+          ccw[0] = cw[0];
+          ccw[1] = cw[1];
+        }
+        p = q + 1;
       }
     }
-    for (int d = 32; d >= 1; d >>= 1) {
-      const double oh = __shfl_xor(hi, d, 64), ol = __shfl_xor(lo, d, 64);
-      hi = oh < hi ? oh : hi;
-      lo = ol > lo ? ol : lo;
+    // lp_base_case (:403-445)
+    if (dabs(cross2(nv, dv)) < 2.0 * SDLP_EPS * SDLP_EPS) {
+      if (dot2(nv, nv) < 2.0 * SDLP_EPS * SDLP_EPS || dot2(dv, dv) > 2.0 * SDLP_EPS * SDLP_EPS) {
+        opt[0] = cw[0];
+        opt[1] = cw[1];
+        return SDLP_AMBIGUOUS;
+      }
+      if (!degen && cross2(cw, nv) <= 0.0 && cross2(nv, ccw) <= 0.0) {
+        opt[0] = -nv[0];
+        opt[1] = -nv[1];
+      } else if (dot2(nv, cw) > dot2(nv, ccw)) {
+        opt[0] = ccw[0];
+        opt[1] = ccw[1];
+      } else {
+        opt[0] = cw[0];
+        opt[1] = cw[1];
+      }
+      return SDLP_MINIMUM;
     }
-    if (__ballot(bad)) return false;
-    if (lo > hi + LP_TOL) return false;
-    if (lo > hi) lo = hi = 0.5 * (lo + hi);
-    if (c[0] > 0)
-      x[0] = lo;
-    else if (c[0] < 0)
-      x[0] = hi;
-    else
-      x[0] = lo > 0 ? lo : (hi < 0 ? hi : 0.0);
-    return true;
+    lp_min_lin_rat(degen, cw, ccw, nv, dv, opt);
+    return SDLP_MINIMUM;
   }
 };
-// linprog<D> for a whole wave (same row permutation, normalisation and return convention)
+
+// linprog<D> (:709-787): min c^T x s.t. A[i][0..D) x <= rhs[i]  (A row-major, stride D, in LDS).
+// work: LP_WORK_DOUBLES doubles (LDS), ord: LP_MAX_ROWS ints (LDS); rows < LP_MAX_ROWS.
+// Returns +inf infeasible, -inf unbounded / optimum at infinity, else the minimum.  Whole wave.
 template <int D>
-__device__ __forceinline__ double linprog_wave(const double *c, int m, const double *A, const double *rhsv,
-                                            double *x, double *work, int *perm) {
+__device__ __forceinline__ double linprog_wave(const double *c, int rows, const double *A, const double *rhsv,
+                                               double *x, double *work, int *ord) {
   const int lane = threadIdx.x & 63;
   for (int j = 0; j < D; ++j) x[j] = 0.0;
-  if (m <= 0) {
+  if (rows <= 0) {
     double mx = 0;
     for (int j = 0; j < D; ++j) mx = dabs(c[j]) > mx ? dabs(c[j]) : mx;
     return mx > 0.0 ? -INFINITY : 0.0;
   }
-  const int M  = m + 2 * D;
-  double   *a  = work;
-  double   *bb = work + LP_MAX_ROWS * D;
+  const int m      = rows + 1;
+  double   *halves = work;  // [LP_MAX_ROWS][D + 1]
   if (lane == 0) {
-    for (int i = 0; i < 2 * D; ++i)
-      for (int j = 0; j < D; ++j) a[i * D + j] = 0.0;
-    for (int j = 0; j < D; ++j) {
-      a[(2 * j) * D + j]     = 1.0;
-      bb[2 * j]              = LP_BOX;
-      a[(2 * j + 1) * D + j] = -1.0;
-      bb[2 * j + 1]          = LP_BOX;
-    }
-    for (int i = 0; i < m; ++i) perm[i] = i;
-    unsigned long long s = 0x9E3779B97F4A7C15ULL;
-    for (int i = m - 1; i > 0; --i) {
+    ord[0] = 0;
+    for (int i = 0; i < rows; ++i) ord[1 + i] = i + 1;
+    unsigned long long s = 0x9E3779B97F4A7C15ULL;  // the fixed insertion order (oracle: fixed_permutation)
+    for (int i = rows - 1; i > 0; --i) {
       s           = s * 6364136223846793005ULL + 1442695040888963407ULL;
       const int j = (int)((s >> 33) % (unsigned long long)(i + 1));
-      const int t = perm[i];
-      perm[i]     = perm[j];
-      perm[j]     = t;
+      const int t = ord[1 + i];
+      ord[1 + i]  = ord[1 + j];
+      ord[1 + j]  = t;
     }
+    for (int j = 0; j < D; ++j) halves[j] = 0.0;
+    halves[D] = 1.0;
   }
-  wave_lds_sync();
-  for (int i = lane; i < m; i += 64) {
-    const double *src = A + perm[i] * D;
-    const double  rhs = rhsv[perm[i]];
-    double        nn  = 0;
-    for (int j = 0; j < D; ++j) nn += src[j] * src[j];
+  for (int i = 1 + lane; i < m; i += 64) {  // halves.col(i) = (-A_i, b_i) normalised (:737-740)
+    const double *src = A + (i - 1) * D;
+    double        h[D + 1];
+#pragma unroll
+    for (int j = 0; j < D; ++j) h[j] = -src[j];
+    h[D]      = rhsv[i - 1];
+    double nn = 0.0;
+#pragma unroll
+    for (int j = 0; j <= D; ++j) nn += h[j] * h[j];
     nn          = sogm_det::sqrt_rn(nn);
-    double *dst = a + (2 * D + i) * D;
-    if (nn > 0) {
-      for (int j = 0; j < D; ++j) dst[j] = src[j] / nn;
-      bb[2 * D + i] = rhs / nn;
-    } else {
-      for (int j = 0; j < D; ++j) dst[j] = 0;
-      bb[2 * D + i] = rhs;
-    }
+    double *dst = halves + i * (D + 1);
+#pragma unroll
+    for (int j = 0; j <= D; ++j) dst[j] = nn > 0.0 ? h[j] / nn : h[j];
   }
   wave_lds_sync();
-  double xs[D];
-  if (!SeidelW<D>::solve(a, bb, M, c, xs, work + LP_MAX_ROWS * (D + 1))) return INFINITY;
-  for (int j = 0; j < D; ++j) x[j] = xs[j];
-  for (int j = 0; j < D; ++j)
-    if (dabs(xs[j]) > 0.99 * LP_BOX) return -INFINITY;
-  double v = 0;
-  for (int j = 0; j < D; ++j) v += c[j] * xs[j];
-  return v;
+  double nv[D + 1], dv[D + 1], opt[D + 1];
+#pragma unroll
+  for (int j = 0; j < D; ++j) {
+    nv[j] = c[j];
+    dv[j] = 0.0;
+  }
+  nv[D] = 0.0;
+  dv[D] = 1.0;
+  const int status = Lfp<D>::solve(halves, m, nv, dv, opt, work + LP_MAX_ROWS * (D + 1), ord);
+  double    minimum = INFINITY;
+  if (status != SDLP_INFEASIBLE) {
+    if (opt[D] != 0.0 && status != SDLP_UNBOUNDED) {
+      minimum = 0.0;
+#pragma unroll
+      for (int j = 0; j < D; ++j) {
+        x[j] = opt[j] / opt[D];
+        minimum += c[j] * x[j];
+      }
+    }
+    if (opt[D] == 0.0 || status == SDLP_UNBOUNDED) {
+#pragma unroll
+      for (int j = 0; j < D; ++j) x[j] = opt[j];
+      minimum = -INFINITY;
+    }
+  }
+  return minimum;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -876,52 +953,8 @@ __device__ __forceinline__ bool maxVolInsEllipsoid(const double *hPoly, int M, d
   return ret >= 0;
 }
 
-// checkCorridorValidity (baseline.cpp:191-204); poly rows h0 x + h1 y + h2 z + h3 <= 0; lane 0
-__device__ bool corridorValid(const double *polyA, int mA, const double *polyB, int mB,
-                              const SolverScratch &sc) {
-  const double c[3] = {0, 0, 0};
-  double       x[3];
-  double      *A = sc.rows, *b = sc.rows + LP_MAX_ROWS * 4;
-  for (int i = 0; i < mA + mB; ++i) {
-    const double *h = i < mA ? polyA + i * 4 : polyB + (i - mA) * 4;
-    A[i * 3 + 0]    = h[0];
-    A[i * 3 + 1]    = h[1];
-    A[i * 3 + 2]    = h[2];
-    b[i]            = -h[3];
-  }
-  const double v = linprog<3>(c, mA + mB, A, b, x, sc.lp_work, sc.perm);
-  return !(v == INFINITY || v == -INFINITY);
-}
-
-// checkGoalReachability (baseline.cpp:143-182); lane 0
-__device__ bool goalReachable(const double *poly, int m, const double *start, double *goal,
-                              const SolverScratch &sc) {
-  if (m <= 0) return true;
-  double mx = -INFINITY;
-  for (int i = 0; i < m; ++i) {
-    const double *h = poly + i * 4;
-    const double  v = dot3(h, goal) + h[3] * 1.0;
-    mx              = v > mx ? v : mx;
-  }
-  if (mx <= 0) return true;
-  double *A = sc.rows, *b = sc.rows + LP_MAX_ROWS * 4;
-  for (int i = 0; i < m; ++i) {
-    const double *h = poly + i * 4;
-    A[i * 3 + 0]    = h[0];
-    A[i * 3 + 1]    = h[1];
-    A[i * 3 + 2]    = h[2];
-    b[i]            = -h[3];
-  }
-  double c[3] = {-goal[0] + start[0], -goal[1] + start[1], -goal[2] + start[2]};
-  double gmax[3], gmin[3];
-  linprog<3>(c, m, A, b, gmax, sc.lp_work, sc.perm);
-  for (int j = 0; j < 3; ++j) c[j] = goal[j] - start[j];
-  linprog<3>(c, m, A, b, gmin, sc.lp_work, sc.perm);
-  for (int j = 0; j < 3; ++j) goal[j] = 0.5 * (gmax[j] + gmin[j]);
-  return false;
-}
-
-// whole-wave versions of the two predicates (k_corridor_finalize): same rows, same LPs, solved by linprog_wave
+// checkCorridorValidity (baseline.cpp:191-204; poly rows h0 x + h1 y + h2 z + h3 <= 0) and
+// checkGoalReachability (baseline.cpp:143-182), executed by the whole wave (linprog_wave)
 __device__ bool corridorValidW(const double *polyA, int mA, const double *polyB, int mB,
                                const SolverScratch &sc) {
   const int    lane = threadIdx.x & 63;
@@ -1405,7 +1438,7 @@ __global__ __launch_bounds__(64) void k_corridor_segment(
       }
       if (loop == pp.firi_iterations - 1) break;
       {
-        const int       mm  = nH < LP_MAX_ROWS - 8 ? nH : LP_MAX_ROWS - 8;
+        const int       mm  = nH < LP_MAX_ROWS - 9 ? nH : LP_MAX_ROWS - 9;
         const long long tm0 = wall_clock64();
         maxVolInsEllipsoid(s_poly, mm, R, p, r, sc, dbg);
         if (lane == 0) dbg[7] = wall_clock64() - tm0;
@@ -1541,9 +1574,11 @@ size_t corridor_segment_lds(int pc_capacity) {
 // (other agent's record, ego agent).  Set A = the new trajectory's control points, set B = the record's
 // control points from the piece that contains t_now onwards; separable iff the feasibility LP
 // n.a + d >= 1, n.b + d <= -1 (utils/separator/src/separator_glpk.cpp:75-190, zero objective) has a
-// solution — solved with the same Seidel LP as the corridor checks.
+// solution — solved with the same sdlp LP as the corridor checks, the four variables boxed at +-1e4 (8 extra
+// rows): the projective LP reports a feasible point at infinity (two crossing segments: the plane through both)
+// as "-inf", GLPK's affine model calls that infeasible; with the box the result is finite or +inf.
 // ------------------------------------------------------------------------------------------------
-#define DECONFLICT_MAX_ROWS (LP_MAX_ROWS - 8)
+#define DECONFLICT_MAX_ROWS (LP_MAX_ROWS - 9)  // 144 point rows + 8 box rows + sdlp's plane 0
 __global__ __launch_bounds__(64) void k_safe_after_opt(const double *__restrict__ cpts,
                                                        const int32_t *__restrict__ npoly,
                                                        const SogmTrajRecord *__restrict__ rec, int n_rec,
@@ -1648,12 +1683,51 @@ __global__ __launch_bounds__(64) void k_safe_after_opt(const double *__restrict_
     }
     b[q] = -1.0;
   }
+  if (threadIdx.x < 8) {  // x_k <= 1e4, -x_k <= 1e4
+    const int q = nA + nB + threadIdx.x, k = threadIdx.x >> 1;
+    for (int j = 0; j < 4; ++j) A[q * 4 + j] = j == k ? ((threadIdx.x & 1) ? -1.0 : 1.0) : 0.0;
+    b[q] = 1.0e4;
+  }
   __syncthreads();
   {
     const double c[4] = {0, 0, 0, 0};
     double       x[4];
-    const double v = linprog_wave<4>(c, nA + nB, A, b, x, s_lp, s_perm);  // the whole wave solves the LP
+    const double v = linprog_wave<4>(c, nA + nB + 8, A, b, x, s_lp, s_perm);  // the whole wave solves the LP
     if (threadIdx.x == 0 && (v == INFINITY || v == -INFINITY)) out_safe[a] = 0;  // every writer writes 0
+  }
+}
+
+// sdlp::linprog<d> for a batch of independent LPs: one wave per problem (sogm_linprog_batched)
+template <int D>
+__global__ __launch_bounds__(64) void k_linprog(const double *__restrict__ c, const double *__restrict__ A,
+                                                const double *__restrict__ b,
+                                                const int32_t *__restrict__ row_range,
+                                                double *__restrict__ out_x, double *__restrict__ out_min) {
+  extern __shared__ __attribute__((aligned(16))) double s_dyn[];
+  double   *s_lp   = s_dyn;                   // LP_WORK_DOUBLES
+  double   *s_rows = s_lp + LP_WORK_DOUBLES;  // LP_MAX_ROWS * 5
+  int      *s_ord  = (int *)(s_rows + LP_MAX_ROWS * 5);
+  const int p = blockIdx.x, lane = threadIdx.x;
+  const int r0 = row_range[2 * p], rows = row_range[2 * p + 1] - r0;
+  if (rows >= LP_MAX_ROWS || rows < 0) {  // capacity: NaN, never a silent answer
+    if (lane == 0) {
+      out_min[p] = __builtin_nan("");
+      for (int j = 0; j < D; ++j) out_x[p * D + j] = __builtin_nan("");
+    }
+    return;
+  }
+  double *sA = s_rows, *sb = s_rows + LP_MAX_ROWS * 4;
+  for (int i = lane; i < rows; i += 64) {
+    for (int j = 0; j < D; ++j) sA[i * D + j] = A[(size_t)(r0 + i) * D + j];
+    sb[i] = b[r0 + i];
+  }
+  wave_lds_sync();
+  double cv[D], x[D];
+  for (int j = 0; j < D; ++j) cv[j] = c[p * D + j];
+  const double v = linprog_wave<D>(cv, rows, sA, sb, x, s_lp, s_ord);
+  if (lane == 0) {
+    out_min[p] = v;
+    for (int j = 0; j < D; ++j) out_x[p * D + j] = x[j];
   }
 }
 
@@ -1695,6 +1769,22 @@ int launch_corridor(const MapView &m, const SogmPlannerParams &pp, const Corrido
 }
 
 }  // namespace sogm
+
+extern "C" int sogm_linprog_batched(int d, const double *c, const double *A, const double *b,
+                                    const int32_t *row_range, int n, double *out_x, double *out_min,
+                                    void *stream) {
+  if ((d != 3 && d != 4) || n < 0 || (n > 0 && (!c || !row_range || !out_x || !out_min)))
+    return SOGM_ERR_INVALID_ARG;
+  if (n == 0) return SOGM_OK;
+  const size_t lds = sizeof(double) * (LP_WORK_DOUBLES + LP_MAX_ROWS * 5) + sizeof(int) * LP_MAX_ROWS;
+  hipStream_t  st  = (hipStream_t)stream;
+  if (d == 3)
+    hipLaunchKernelGGL(sogm::k_linprog<3>, dim3(n), dim3(64), lds, st, c, A, b, row_range, out_x, out_min);
+  else
+    hipLaunchKernelGGL(sogm::k_linprog<4>, dim3(n), dim3(64), lds, st, c, A, b, row_range, out_x, out_min);
+  SOGM_HIP_CHECK(hipGetLastError());
+  return SOGM_OK;
+}
 
 // debug aid (not part of include/sogm_abi.h): resident workgroups per CU of the segment kernel
 extern "C" int sogm_debug_corridor_occupancy(int pc_capacity) {

@@ -553,7 +553,7 @@ using namespace sogm;
 // ================================================================================================
 extern "C" {
 
-int sogm_abi_version(void) { return 1; }
+int sogm_abi_version(void) { return 2; }
 const char *sogm_last_error(void) { return sogm::g_err; }
 
 int sogm_device_count(void) {

@@ -16,6 +16,18 @@ from ._abi import SOGM_MAX_PIECES, check, lib
 from .sogm import _dev, _stream
 
 
+def linprog_batched(c, A_rows, b_rows, row_range):
+    """sdlp::linprog<d> (traj_utils/include/traj_utils/sdlp.hpp:709-787) for a batch of LPs  min c.x, A x <= b.
+    c [n, d] (d = 3 | 4), A_rows [total, d], b_rows [total], row_range [n, 2] int32 — device tensors.
+    Returns (x [n, d], minimum [n]); +inf infeasible, -inf unbounded, NaN over capacity (152 rows)."""
+    n, d = c.shape
+    x = torch.zeros((n, d), dtype=torch.float64, device=c.device)
+    v = torch.zeros((n,), dtype=torch.float64, device=c.device)
+    check(lib().sogm_linprog_batched(d, c.data_ptr(), A_rows.data_ptr(), b_rows.data_ptr(), row_range.data_ptr(),
+                                     n, x.data_ptr(), v.data_ptr(), _stream()), "sogm_linprog_batched")
+    return x, v
+
+
 class SogmPlanner:
     def __init__(self, sogm_map, astar_params, planner_params, qp_settings):
         self.map = sogm_map
