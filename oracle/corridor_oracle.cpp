@@ -61,19 +61,6 @@ struct MvieData {
   std::vector<double> A;  // M x 3 row-major
 };
 
-// 64-slot butterfly sum, the association order of the HIP side's wave reduction (slot l holds
-// face l and face l + 64): v[l] += v[l ^ d] for d = 32, 16, ..., 1.  The reference accumulates
-// sequentially over faces (firi.hpp:105-122); the tree differs from that by round-off only and lets
-// the one-face-per-lane GPU evaluation match this oracle bit for bit.
-double tree_sum64(double v[64]) {
-  double t[64];
-  for (int d = 32; d >= 1; d >>= 1) {
-    for (int l = 0; l < 64; ++l) t[l] = v[l] + v[l ^ d];
-    for (int l = 0; l < 64; ++l) v[l] = t[l];
-  }
-  return v[0];
-}
-
 // firi.hpp:74-140
 double costMVIE(const MvieData &D, const double x[9], double g[9]) {
   const double *p = x, *rtd = x + 3, *cde = x + 6;
@@ -88,11 +75,10 @@ double costMVIE(const MvieData &D, const double x[9], double g[9]) {
   L[2][0] = cde[2];
   L[2][1] = cde[1];
   L[2][2] = rtd[2] * rtd[2] + DBL_EPSILON;
-  double slot[10][64];
-  for (int k = 0; k < 10; ++k)
-    for (int l = 0; l < 64; ++l) slot[k][l] = 0.0;
-  for (int i = 0; i < D.M && i < 128; ++i) {
-    const int     l = i & 63;  // faces l and l + 64 accumulate in the same slot, in that order
+  // firi.hpp:93-122: one running sum per quantity, faces in index order
+  double cost = 0;
+  for (int j = 0; j < 3; ++j) gdp[j] = gdrtd[j] = gdcde[j] = 0.0;
+  for (int i = 0; i < D.M; ++i) {
     const double *a = &D.A[(size_t)i * 3];
     double        AL[3];
     for (int j = 0; j < 3; ++j) AL[j] = (a[0] * L[0][j] + a[1] * L[1][j]) + a[2] * L[2][j];
@@ -102,20 +88,14 @@ double costMVIE(const MvieData &D, const double x[9], double g[9]) {
     const double viola  = (normAL + Ap) - 1.0;
     double       c, dc;
     if (smoothedL1(D.smoothEps, viola, c, dc)) {
-      slot[0][l] += c;
+      cost += c;
       const double vec[3] = {dc * a[0], dc * a[1], dc * a[2]};
-      for (int j = 0; j < 3; ++j) slot[1 + j][l] += vec[j];
-      for (int j = 0; j < 3; ++j) slot[4 + j][l] += adj[j] * vec[j];
-      slot[7][l] += adj[0] * vec[1];
-      slot[8][l] += adj[1] * vec[2];
-      slot[9][l] += adj[0] * vec[2];
+      for (int j = 0; j < 3; ++j) gdp[j] += vec[j];
+      for (int j = 0; j < 3; ++j) gdrtd[j] += adj[j] * vec[j];
+      gdcde[0] += adj[0] * vec[1];
+      gdcde[1] += adj[1] * vec[2];
+      gdcde[2] += adj[0] * vec[2];
     }
-  }
-  double cost = tree_sum64(slot[0]);
-  for (int j = 0; j < 3; ++j) {
-    gdp[j]   = tree_sum64(slot[1 + j]);
-    gdrtd[j] = tree_sum64(slot[4 + j]);
-    gdcde[j] = tree_sum64(slot[7 + j]);
   }
   cost *= D.penaltyWt;
   for (int j = 0; j < 3; ++j) {

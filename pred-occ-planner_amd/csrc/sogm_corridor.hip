@@ -482,66 +482,18 @@ struct MvieData {
   bool   on0, on1;
 };
 
-// 64-lane butterfly sum: every lane ends with the same total; the association order
-// ((l, l^32), (.., ^16), ...) is what oracle/corridor_oracle.cpp::tree_sum64 replays.
-// Levels 32 and 16 cross the 16-lane rows (ds_bpermute); after them every lane of a class l mod 16 holds
-// the same value, so levels 8 and 4 can take their partner with a DPP row rotate ((l + 8) mod 16 is in
-// class (l mod 16) ^ 8, likewise for 4) and levels 2, 1 with DPP quad permutes — same pairs, same
-// (commutative) additions, no LDS crossbar round trip on four of the six levels.
-template <int CTRL>
-__device__ inline double dpp_f64(double v) {
-  int lo = __double2loint(v), hi = __double2hiint(v);
-  lo     = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xF, 0xF, true);
-  hi     = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xF, 0xF, true);
-  return __hiloint2double(hi, lo);
-}
-__device__ inline double bfly_sum(double v) {
-  v += __shfl_xor(v, 32, 64);
-  v += __shfl_xor(v, 16, 64);
-  v += dpp_f64<0x128>(v);  // row_ror:8
-  v += dpp_f64<0x124>(v);  // row_ror:4
-  v += dpp_f64<0x4E>(v);   // quad_perm [2,3,0,1]
-  v += dpp_f64<0xB1>(v);   // quad_perm [1,0,3,2]
-  return v;
-}
-
-// The ten partial sums of costMVIE reduced together, stage by stage (ten independent chains per stage: no DPP
-// hazard stalls, no serial bpermute round trips).  Lanes >= M hold exact zeros, so for M <= 16 the two cross-row
-// stages only add zeros to lanes 0..15 and are skipped; lane 0's value (the same in every lane of the full
-// butterfly, additions being commutative) is broadcast instead.  Same association order, same bits.
-__device__ inline double first_lane_f64(double v) {
-  int lo = __double2loint(v), hi = __double2hiint(v);
-  lo     = __builtin_amdgcn_readfirstlane(lo);
-  hi     = __builtin_amdgcn_readfirstlane(hi);
-  return __hiloint2double(hi, lo);
-}
-__device__ inline void bfly_sum10(double acc[10], int M) {
-  if (M > 16) {  // wave-uniform
-#pragma unroll
-    for (int k = 0; k < 10; ++k) acc[k] += __shfl_xor(acc[k], 32, 64);
-#pragma unroll
-    for (int k = 0; k < 10; ++k) acc[k] += __shfl_xor(acc[k], 16, 64);
-  }
-#pragma unroll
-  for (int k = 0; k < 10; ++k) acc[k] += dpp_f64<0x128>(acc[k]);  // row_ror:8
-#pragma unroll
-  for (int k = 0; k < 10; ++k) acc[k] += dpp_f64<0x124>(acc[k]);  // row_ror:4
-#pragma unroll
-  for (int k = 0; k < 10; ++k) acc[k] += dpp_f64<0x4E>(acc[k]);  // quad_perm [2,3,0,1]
-#pragma unroll
-  for (int k = 0; k < 10; ++k) acc[k] += dpp_f64<0xB1>(acc[k]);  // quad_perm [1,0,3,2]
-  if (M <= 16) {
-#pragma unroll
-    for (int k = 0; k < 10; ++k) acc[k] = first_lane_f64(acc[k]);
-  }
-}
-
 #ifdef SOGM_PROFILE_MVIE
 __device__ unsigned long long g_mvie_prof[2];  // profiling build only: ticks (100 MHz) and calls of costMVIE
 #endif
-// one face's contribution to cost and gradient (firi.hpp:105-122)
-__device__ inline void mvie_face(const double a[3], const double L[3][3], const double *p,
-                                 double smoothEps, double acc[10]) {
+__device__ inline double lane_f64(double v, int l) {  // value of lane l (l wave-uniform)
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo     = __builtin_amdgcn_readlane(lo, l);
+  hi     = __builtin_amdgcn_readlane(hi, l);
+  return __hiloint2double(hi, lo);
+}
+// one face's terms of cost and gradient (firi.hpp:105-122); false when smoothedL1 rejects the face
+__device__ inline bool mvie_face(const double a[3], const double L[3][3], const double *p,
+                                 double smoothEps, double t[10]) {
   double AL[3];
   for (int j = 0; j < 3; ++j) AL[j] = (a[0] * L[0][j] + a[1] * L[1][j]) + a[2] * L[2][j];
   const double normAL = sogm_det::sqrt_rn((AL[0] * AL[0] + AL[1] * AL[1]) + AL[2] * AL[2]);
@@ -549,20 +501,25 @@ __device__ inline void mvie_face(const double a[3], const double L[3][3], const 
   const double Ap     = (a[0] * p[0] + a[1] * p[1]) + a[2] * p[2];
   const double viola  = (normAL + Ap) - 1.0;
   double       c, dc;
-  if (smoothedL1(smoothEps, viola, c, dc)) {
-    acc[0] += c;
-    const double vec[3] = {dc * a[0], dc * a[1], dc * a[2]};
-    for (int j = 0; j < 3; ++j) acc[1 + j] += vec[j];
-    for (int j = 0; j < 3; ++j) acc[4 + j] += adj[j] * vec[j];
-    acc[7] += adj[0] * vec[1];
-    acc[8] += adj[1] * vec[2];
-    acc[9] += adj[0] * vec[2];
-  }
+  if (!smoothedL1(smoothEps, viola, c, dc)) return false;
+  t[0]                = c;
+  const double vec[3] = {dc * a[0], dc * a[1], dc * a[2]};
+  for (int j = 0; j < 3; ++j) t[1 + j] = vec[j];
+  for (int j = 0; j < 3; ++j) t[4 + j] = adj[j] * vec[j];
+  t[7] = adj[0] * vec[1];
+  t[8] = adj[1] * vec[2];
+  t[9] = adj[0] * vec[2];
+  return true;
 }
 
-// costMVIE (firi.hpp:74-140), evaluated by the whole wave: one face per lane (two when M > 64),
-// per-lane partial sums, butterfly reduction.  Every lane returns the same cost and gradient.
-__device__ __forceinline__ double costMVIE(const MvieData &D, const double *x, double *g) {
+// costMVIE (firi.hpp:74-140), evaluated by the whole wave: one face per lane (two when M > 64).  The ten sums
+// over faces (cost, gdp, gdrtd, gdcde) are accumulated IN THE REFERENCE'S ORDER — one running sum per quantity,
+// faces in index order, only the faces smoothedL1 accepts (:111-122): the accepted faces' terms are compacted in
+// face order into LDS (`terms`, >= 10 * M doubles: the LP work area, idle during the L-BFGS), lanes 0..9 each
+// run one of the ten chains (usually a handful of dependent adds: few faces touch the ellipsoid), the totals are
+// broadcast.  Every lane returns the same cost and gradient, bit-identical to the sequential loop.
+__device__ __forceinline__ double costMVIE(const MvieData &D, const double *x, double *g, double *terms) {
+  const int     lane = threadIdx.x & 63;
   const double *p = x, *rtd = x + 3, *cde = x + 6;
   double       *gdp = g, *gdrtd = g + 3, *gdcde = g + 6;
   double L[3][3];
@@ -575,11 +532,33 @@ __device__ __forceinline__ double costMVIE(const MvieData &D, const double *x, d
   L[2][0] = cde[2];
   L[2][1] = cde[1];
   L[2][2] = rtd[2] * rtd[2] + DBL_EPSILON;
+  double t0[10], t1[10];
+  bool   a0 = false, a1 = false;
+  if (D.on0) a0 = mvie_face(D.a0, L, p, D.smoothEps, t0);
+  if (D.on1) a1 = mvie_face(D.a1, L, p, D.smoothEps, t1);
+  const unsigned long long m0 = __ballot(a0), m1 = D.M > 64 ? __ballot(a1) : 0ull;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  const int                n0 = __popcll(m0), n = n0 + __popcll(m1);
+  if (a0) {
+    double *dst = terms + __popcll(m0 & below) * 10;
+#pragma unroll
+    for (int k = 0; k < 10; ++k) dst[k] = t0[k];
+  }
+  if (a1) {
+    double *dst = terms + (n0 + __popcll(m1 & below)) * 10;
+#pragma unroll
+    for (int k = 0; k < 10; ++k) dst[k] = t1[k];
+  }
+  wave_lds_sync();
+  double sum = 0.0;
+  if (lane < 10) {
+    const double *src = terms + lane;
+    for (int r = 0; r < n; ++r) sum += src[r * 10];
+  }
+  wave_lds_sync();  // the next evaluation overwrites `terms`
   double acc[10];
-  for (int k = 0; k < 10; ++k) acc[k] = 0.0;
-  if (D.on0) mvie_face(D.a0, L, p, D.smoothEps, acc);
-  if (D.on1) mvie_face(D.a1, L, p, D.smoothEps, acc);
-  bfly_sum10(acc, D.M);
+#pragma unroll
+  for (int k = 0; k < 10; ++k) acc[k] = lane_f64(sum, k);
   double cost = acc[0];
   for (int j = 0; j < 3; ++j) {
     gdp[j]   = acc[1 + j];
@@ -615,7 +594,7 @@ __device__ inline double ninf9(const double *v) {
 
 __device__ __forceinline__ int lineSearchLO(const MvieData &D, double *x, double &f, double *g, double &stp,
                             const double *s, const double *xp, const double *gp, double stpmin,
-                            double stpmax) {
+                            double stpmax, double *terms) {
   const double f_dec = 1.0e-4, s_curv = 0.9, machine_prec = 1.0e-16;
   const int    max_linesearch = 64;
   int          count = 0;
@@ -630,7 +609,7 @@ __device__ __forceinline__ int lineSearchLO(const MvieData &D, double *x, double
 #ifdef SOGM_PROFILE_MVIE
     const long long tc0 = wall_clock64();
 #endif
-    f = costMVIE(D, x, g);
+    f = costMVIE(D, x, g, terms);
 #ifdef SOGM_PROFILE_MVIE
     if ((threadIdx.x & 63) == 0) {
       atomicAdd(&g_mvie_prof[0], (unsigned long long)(wall_clock64() - tc0));
@@ -672,7 +651,8 @@ __device__ __forceinline__ int lineSearchLO(const MvieData &D, double *x, double
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");   \
     __builtin_amdgcn_wave_barrier();                         \
   } while (0)
-__device__ __forceinline__ int lbfgsMVIE(const MvieData &D, double *x, double *lm, int *n_iter, int *n_eval) {
+__device__ __forceinline__ int lbfgsMVIE(const MvieData &D, double *x, double *lm, double *terms, int *n_iter,
+                                         int *n_eval) {
   const int    n = 9, m = 18, past = 3;
   const double g_epsilon = 0.0, delta = 1.0e-7, min_step = 1.0e-32, max_step = 1.0e+20,
                cautious = 1.0e-6;
@@ -686,7 +666,7 @@ __device__ __forceinline__ int lbfgsMVIE(const MvieData &D, double *x, double *l
     for (int i = 0; i < 2 * m; ++i) lm_alpha[i] = 0;
   }
   LBFGS_FENCE();
-  double fx = costMVIE(D, x, g);
+  double fx = costMVIE(D, x, g, terms);
   pf0       = fx;
   for (int i = 0; i < n; ++i) d[i] = -g[i];
   int          ret;
@@ -701,7 +681,7 @@ __device__ __forceinline__ int lbfgsMVIE(const MvieData &D, double *x, double *l
         xp[i] = x[i];
         gp[i] = g[i];
       }
-      const int ls = lineSearchLO(D, x, fx, g, step, d, xp, gp, min_step, max_step);
+      const int ls = lineSearchLO(D, x, fx, g, step, d, xp, gp, min_step, max_step, terms);
       *n_iter += 1;
       *n_eval += ls > 0 ? ls : 0;
       if (ls < 0) {
@@ -893,7 +873,7 @@ __device__ __forceinline__ bool maxVolInsEllipsoid(const double *hPoly, int M, d
   __syncthreads();
   int             n_it = 0, n_ev = 0;
   const long long tl0 = wall_clock64();
-  const int       ret = lbfgsMVIE(D, x, sc.lm, &n_it, &n_ev);
+  const int       ret = lbfgsMVIE(D, x, sc.lm, sc.lp_work, &n_it, &n_ev);  // LP work area: idle by now
   if (dbg && lane == 0) {
     dbg[3] = n_it;
     dbg[4] = n_ev;
