@@ -254,29 +254,46 @@ void orc_update_gt(const SogmSpec *s, const float *cloud, int n_points, const So
           break;
         }
       } else if (cy.type == 2) {
-        // :137-149 ring obstacle: plane through the ring centre spanned by q*(0,1,0), q*(1,0,0)
-        const float qw = (float)cy.qw, qx = (float)cy.qx, qy = (float)cy.qy, qz = (float)cy.qz;
-        // rotate e_y and e_x by q (fp32 rotation matrix columns)
-        const float r00 = 1 - 2 * (qy * qy + qz * qz), r10 = 2 * (qx * qy + qw * qz),
-                    r20 = 2 * (qx * qz - qw * qy);
-        const float r01 = 2 * (qx * qy - qw * qz), r11 = 1 - 2 * (qx * qx + qz * qz),
-                    r21 = 2 * (qy * qz + qw * qx);
+        // :137-149 ring obstacle: plane through the ring centre and the points centre + q*(0,1,0),
+        // centre + q*(1,0,0).  Eigen's operation sequence in fp32:
+        //   q * v  = QuaternionBase::_transformVector: uv = q.vec x v; uv += uv; v + w*uv + q.vec x uv
+        //   Hyperplane::Through(p0, p1, p2): v0 = p2 - p0, v1 = p1 - p0, normal = v0 x v1 / |v0 x v1|,
+        //                                    offset = -p0.normal   (the SVD fallback for collinear
+        //                                    points cannot trigger: the two rotated axes are orthonormal)
+        //   projection(p) = p - signedDistance(p) * normal,  signedDistance = normal.p + offset
+        const float qw = (float)cy.qw, qv[3] = {(float)cy.qx, (float)cy.qy, (float)cy.qz};
+        auto cross = [](const float a[3], const float b[3], float o[3]) {
+          o[0] = a[1] * b[2] - a[2] * b[1];
+          o[1] = a[2] * b[0] - a[0] * b[2];
+          o[2] = a[0] * b[1] - a[1] * b[0];
+        };
+        auto rotate = [&](const float v[3], float o[3]) {
+          float uv[3], w2[3];
+          cross(qv, v, uv);
+          for (int k = 0; k < 3; ++k) uv[k] += uv[k];
+          cross(qv, uv, w2);
+          for (int k = 0; k < 3; ++k) o[k] = (v[k] + qw * uv[k]) + w2[k];
+        };
         const float c0[3] = {(float)cy.x, (float)cy.y, (float)cy.z};
-        // Hyperplane::Through(p0,p1,p2): normal = (p2-p0) x (p1-p0), normalised
-        const float v0[3] = {r00, r10, r20};  // p2 - p0 = q*(1,0,0)
-        const float v1[3] = {r01, r11, r21};  // p1 - p0 = q*(0,1,0)
-        float       n[3]  = {v0[1] * v1[2] - v0[2] * v1[1], v0[2] * v1[0] - v0[0] * v1[2],
-                             v0[0] * v1[1] - v0[1] * v1[0]};
-        const float nn    = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
-        n[0] /= nn;
-        n[1] /= nn;
-        n[2] /= nn;
-        const float off = -(n[0] * c0[0] + n[1] * c0[1] + n[2] * c0[2]);
-        const float sd  = n[0] * pt[0] + n[1] * pt[1] + n[2] * pt[2] + off;  // signedDistance
+        const float ey[3] = {0, 1, 0}, ex[3] = {1, 0, 0};
+        float       ry[3], rx[3], p1[3], p2[3], v0[3], v1[3], n[3];
+        rotate(ey, ry);
+        rotate(ex, rx);
+        for (int k = 0; k < 3; ++k) {
+          p1[k] = c0[k] + ry[k];
+          p2[k] = c0[k] + rx[k];
+          v0[k] = p2[k] - c0[k];
+          v1[k] = p1[k] - c0[k];
+        }
+        cross(v0, v1, n);
+        const float nn = std::sqrt((n[0] * n[0] + n[1] * n[1]) + n[2] * n[2]);
+        for (int k = 0; k < 3; ++k) n[k] /= nn;
+        const float off = -((c0[0] * n[0] + c0[1] * n[1]) + c0[2] * n[2]);
+        const float sd  = ((n[0] * pt[0] + n[1] * pt[1]) + n[2] * pt[2]) + off;  // signedDistance
         const float b[3]          = {pt[0] - sd * n[0], pt[1] - sd * n[1], pt[2] - sd * n[2]};
         const float dist_to_plane = std::fabs(sd);
-        const float ex = c0[0] - b[0], ey = c0[1] - b[1], ez = c0[2] - b[2];
-        const float dist = std::sqrt(ex * ex + ey * ey + ez * ez);
+        const float e0 = c0[0] - b[0], e1 = c0[1] - b[1], e2 = c0[2] - b[2];
+        const float dist = std::sqrt((e0 * e0 + e1 * e1) + e2 * e2);
         // abs(cyl.w / 2 - dist) < 2 * resolution_  (double arithmetic on the left)
         if (std::fabs(cy.w / 2 - (double)dist) < (double)(2 * g.res) &&
             dist_to_plane < 2 * g.res) {

@@ -101,8 +101,11 @@ __device__ inline void cell_add(void *slab, size_t i, float inc, int half) {
     __hip_atomic_fetch_add(reinterpret_cast<float *>(slab) + i, inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return;
   }
-  unsigned *w  = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(slab) + ((i * 2) & ~(size_t)3));
-  const int hi = (int)(i & 1);
+  // word and half selected from the cell's ABSOLUTE address: a slab of an odd number of fp16 cells starts on a
+  // 2-byte boundary (odd V), where "i & 1" would pick the neighbour's half
+  const uintptr_t cp = reinterpret_cast<uintptr_t>(slab) + i * 2;
+  unsigned *w  = reinterpret_cast<unsigned *>(cp & ~(uintptr_t)3);
+  const int hi = (int)((cp >> 1) & 1);
   unsigned  old = *w, assumed;
   do {
     assumed = old;

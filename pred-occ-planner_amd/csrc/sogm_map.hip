@@ -67,6 +67,45 @@ __global__ __launch_bounds__(256) void k_clear_slabs(vfloat4 *__restrict__ p, si
 // ------------------------------------------------------------------------------------------------
 #define SOGM_MAX_CYL_LDS 1024
 
+// Ring obstacle test (fake_particle_risk_voxel.cpp:137-149): the voxel corner pt lies within 2 voxels of the
+// ring's plane and of its circle of diameter w.  Eigen's operation sequence in fp32 (as oracle/map_oracle.cpp):
+// q * v = _transformVector (uv = q.vec x v; uv += uv; v + w uv + q.vec x uv), Hyperplane::Through(p0, p1, p2)
+// (normal = (p2 - p0) x (p1 - p0), normalised; offset = -p0.normal), projection, absDistance.
+__device__ inline void cross3f(const float a[3], const float b[3], float o[3]) {
+  o[0] = a[1] * b[2] - a[2] * b[1];
+  o[1] = a[2] * b[0] - a[0] * b[2];
+  o[2] = a[0] * b[1] - a[1] * b[0];
+}
+__device__ inline void quat_rotate_f(float qw, const float qv[3], const float v[3], float o[3]) {
+  float uv[3], w2[3];
+  cross3f(qv, v, uv);
+  for (int k = 0; k < 3; ++k) uv[k] += uv[k];
+  cross3f(qv, uv, w2);
+  for (int k = 0; k < 3; ++k) o[k] = (v[k] + qw * uv[k]) + w2[k];
+}
+__device__ __noinline__ bool ring_contains(const SogmCylinder &cy, float px, float py, float pz, float res) {
+  const float qw = (float)cy.qw, qv[3] = {(float)cy.qx, (float)cy.qy, (float)cy.qz};
+  const float c0[3] = {(float)cy.x, (float)cy.y, (float)cy.z};
+  const float ey[3] = {0, 1, 0}, ex[3] = {1, 0, 0};
+  float       ry[3], rx[3], v0[3], v1[3], n[3];
+  quat_rotate_f(qw, qv, ey, ry);
+  quat_rotate_f(qw, qv, ex, rx);
+  for (int k = 0; k < 3; ++k) {
+    const float p1 = c0[k] + ry[k], p2 = c0[k] + rx[k];
+    v0[k] = p2 - c0[k];
+    v1[k] = p1 - c0[k];
+  }
+  cross3f(v0, v1, n);
+  const float nn = sqrtf((n[0] * n[0] + n[1] * n[1]) + n[2] * n[2]);
+  for (int k = 0; k < 3; ++k) n[k] /= nn;
+  const float off = -((c0[0] * n[0] + c0[1] * n[1]) + c0[2] * n[2]);
+  const float sd  = ((n[0] * px + n[1] * py) + n[2] * pz) + off;
+  const float b0 = px - sd * n[0], b1 = py - sd * n[1], b2 = pz - sd * n[2];
+  const float e0 = c0[0] - b0, e1 = c0[1] - b1, e2 = c0[2] - b2;
+  const float dist = sqrtf((e0 * e0 + e1 * e1) + e2 * e2);
+  return fabs(cy.w / 2 - (double)dist) < (double)(2 * res) && fabsf(sd) < 2 * res;
+}
+
 __global__ __launch_bounds__(256) void k_stamp_cloud(GridGeom g, void *__restrict__ grid,
                                                      const float *__restrict__ cloud,
                                                      const int32_t *__restrict__ cloud_range,
@@ -80,6 +119,7 @@ __global__ __launch_bounds__(256) void k_stamp_cloud(GridGeom g, void *__restric
   __shared__ double s_w[SOGM_MAX_CYL_LDS];
   __shared__ float  s_xyv[SOGM_MAX_CYL_LDS][4];
   __shared__ int    s_type[SOGM_MAX_CYL_LDS];
+  __shared__ int    s_orig[SOGM_MAX_CYL_LDS];  // index into cyl[] (ring records are read from there)
   __shared__ int    s_keep, s_wave[4];
   {
     const float *pz_ = poses + blockIdx.y * 3;
@@ -92,7 +132,10 @@ __global__ __launch_bounds__(256) void k_stamp_cloud(GridGeom g, void *__restric
       double    wl   = 0.0;
       if (c < n_cyl) {
         wl = cyl[c].w + (double)g.clearance;
-        const double lim_x = (double)g.rx + (double)g.res + wl + 0.5, lim_y = (double)g.ry + (double)g.res + wl + 0.5;
+        // reach of a record around its centre: a cylinder matches within w + clearance; a ring (type 2) within
+        // w/2 + 2 res of its axis point and 2 res of its plane, i.e. at most w/2 + 4 res from the centre
+        const double reach = cyl[c].type == 2 ? 0.5 * cyl[c].w + 4.0 * (double)g.res : wl;
+        const double lim_x = (double)g.rx + (double)g.res + reach + 0.5, lim_y = (double)g.ry + (double)g.res + reach + 0.5;
         keep = fabs((double)(float)cyl[c].x - (double)q0) <= lim_x && fabs((double)(float)cyl[c].y - (double)q1) <= lim_y;
       }
       const unsigned long long m = __ballot(keep);
@@ -108,6 +151,7 @@ __global__ __launch_bounds__(256) void k_stamp_cloud(GridGeom g, void *__restric
         s_xyv[off][2] = (float)cyl[c].vx;
         s_xyv[off][3] = (float)cyl[c].vy;
         s_type[off]   = cyl[c].type;
+        s_orig[off]   = c;
       }
       __syncthreads();
       if (threadIdx.x == 0) s_keep += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
@@ -144,8 +188,9 @@ __global__ __launch_bounds__(256) void k_stamp_cloud(GridGeom g, void *__restric
     } else {
       // fp16 cells: slice 0 holds only 0 or 1.0 (0x3C00) while the cloud is stamped, so OR-ing the bit pattern
       // into the 32-bit word that holds the cell marks it and tells whether it was marked before
-      unsigned      *w    = reinterpret_cast<unsigned *>(base + ((size_t)v * 2 & ~(size_t)3));
-      const unsigned bits = 0x3C00u << (16 * (v & 1));
+      const uintptr_t cp  = reinterpret_cast<uintptr_t>(base) + (size_t)v * 2;  // absolute address: odd V safe
+      unsigned      *w    = reinterpret_cast<unsigned *>(cp & ~(uintptr_t)3);
+      const unsigned bits = 0x3C00u << (16 * (int)((cp >> 1) & 1));
       if ((atomicOr(w, bits) & bits) == bits) continue;
     }
     // The reference then sweeps the occupied voxels of slice 0 (:121-125); every cloud point in
@@ -155,11 +200,12 @@ __global__ __launch_bounds__(256) void k_stamp_cloud(GridGeom g, void *__restric
     g.corner_of(v, pose, cx, cy, cz);
     float vx = 0.f, vy = 0.f;
     for (int c = 0; c < n_loop; ++c) {
-      int    type;
+      int    type, orig = c;
       float  ox, oy, wx, wy;
       double wlim;
       if (c < n_lds) {
         type = s_type[c];
+        orig = s_orig[c];
         ox   = s_xyv[c][0];
         oy   = s_xyv[c][1];
         wx   = s_xyv[c][2];
@@ -173,7 +219,15 @@ __global__ __launch_bounds__(256) void k_stamp_cloud(GridGeom g, void *__restric
         wy   = (float)cyl[c].vy;
         wlim = cyl[c].w + (double)g.clearance;
       }
-      if (type != 3) continue;  // ring obstacles (type 2) are not produced by the synthetic scenes
+      if (type == 2) {  // ring (:137-149)
+        if (ring_contains(cyl[orig], cx, cy, cz, g.res)) {
+          vx = wx;
+          vy = wy;
+          break;
+        }
+        continue;
+      }
+      if (type != 3) continue;  // unknown type: the reference prints a warning and goes on (:150-152)
       const float dx = cx - ox, dy = cy - oy, dz = cz - cz;
       const float dist = sqrtf(dx * dx + dy * dy + dz * dz);
       if ((double)dist <= wlim) {
@@ -513,7 +567,8 @@ size_t clear_vec4_total(const sogm_ctx *c) {
 int launch_clear(sogm_ctx *c, hipStream_t st, float *grid, bool polite, int part, size_t split) {
   if (!grid) grid = c->d_grid;
   // the clear is a byte stream: n = number of 4-byte words of the grid (fp16 grids: 2 cells per word)
-  const size_t n     = (size_t)c->n_agents * c->spec.T * (size_t)c->geom.V * c->cell_bytes() / 4;
+  // (rounded up: an odd number of fp16 cells ends in half a word; allocations are padded to 16 B)
+  const size_t n     = ((size_t)c->n_agents * c->spec.T * (size_t)c->geom.V * c->cell_bytes() + 3) / 4;
   const size_t nall  = n / 4;
   const size_t first = part == 2 ? split : 0;
   const size_t nv4   = part == 1 ? split : nall - first;
@@ -638,6 +693,7 @@ float *sogm_grid_ptr(sogm_ctx *c) { return c ? c->d_grid : nullptr; }
 
 int sogm_set_overlap_clear(sogm_ctx *c, int mode) {
   if (!c || mode < 0 || mode > 2) return SOGM_ERR_INVALID_ARG;
+  SOGM_HIP_CHECK(hipSetDevice(c->device));
   if (c->precleared) {  // a pre-clear is in flight: let it finish and forget it (the next update clears itself)
     (void)hipDeviceSynchronize();
     c->precleared = 0;
@@ -669,6 +725,7 @@ int sogm_set_profiling(sogm_ctx *c, int enable) {
 
 int sogm_profile_read(sogm_ctx *c, double *out_ms) {
   if (!c || !out_ms) return SOGM_ERR_INVALID_ARG;
+  SOGM_HIP_CHECK(hipSetDevice(c->device));
   SOGM_HIP_CHECK(hipDeviceSynchronize());
   for (int k = 0; k < SOGM_PROF_N; ++k) {
     out_ms[k] = -1.0;
@@ -681,6 +738,7 @@ int sogm_profile_read(sogm_ctx *c, double *out_ms) {
 
 int sogm_set_body_particles(sogm_ctx *c, const double *xyz, int n) {
   if (!c || !xyz || n <= 0) return SOGM_ERR_INVALID_ARG;
+  SOGM_HIP_CHECK(hipSetDevice(c->device));
   if (c->d_body) (void)hipFree(c->d_body);
   c->d_body = nullptr;
   SOGM_HIP_CHECK(hipMalloc(&c->d_body, sizeof(double) * 3 * n));
@@ -697,6 +755,7 @@ int sogm_update_gt(sogm_ctx *c, const float *cloud_xyz, const int32_t *cloud_ran
   if (!c || !cloud_xyz || !cloud_range || !poses || !stamps || n_cyl < 0 ||
       (n_cyl > 0 && !cylinders))
     return SOGM_ERR_INVALID_ARG;
+  SOGM_HIP_CHECK(hipSetDevice(c->device));
   hipStream_t st = (hipStream_t)stream;
   SOGM_HIP_CHECK(hipMemcpyAsync(c->d_poses, poses, sizeof(float) * 3 * c->n_agents,
                                 hipMemcpyDeviceToDevice, st));
@@ -726,6 +785,7 @@ int sogm_project_neighbours(sogm_ctx *c, const SogmTrajRecord *records, int n_re
   if (!c->updated) return SOGM_ERR_STATE;
   if (!c->d_body || c->n_body <= 0) return SOGM_ERR_STATE;
   if (n_records == 0) return SOGM_OK;
+  SOGM_HIP_CHECK(hipSetDevice(c->device));
   const long long total = (long long)c->n_agents * n_records * c->spec.T;
   const int       nblk  = (int)((total + 255) / 256);
   prof_begin(c, SOGM_PROF_SPLAT, (hipStream_t)stream);
@@ -740,6 +800,7 @@ int sogm_project_neighbours(sogm_ctx *c, const SogmTrajRecord *records, int n_re
 int sogm_set_future_risk(sogm_ctx *c, const float *grid_vt, const float *poses,
                          const double *stamps, void *stream) {
   if (!c || !grid_vt || !poses || !stamps) return SOGM_ERR_INVALID_ARG;
+  SOGM_HIP_CHECK(hipSetDevice(c->device));
   hipStream_t st = (hipStream_t)stream;
   SOGM_HIP_CHECK(hipMemcpyAsync(c->d_poses, poses, sizeof(float) * 3 * c->n_agents,
                                 hipMemcpyDeviceToDevice, st));
@@ -762,6 +823,7 @@ int sogm_set_future_risk(sogm_ctx *c, const float *grid_vt, const float *poses,
 
 int sogm_download_reference_layout(sogm_ctx *c, int agent, float *out) {
   if (!c || !out || agent < 0 || agent >= c->n_agents) return SOGM_ERR_INVALID_ARG;
+  SOGM_HIP_CHECK(hipSetDevice(c->device));
   const int    V = c->geom.V, T = c->spec.T;
   const size_t per = (size_t)V * T;
   SOGM_HIP_CHECK(hipDeviceSynchronize());
@@ -787,6 +849,7 @@ int sogm_traj_safe(sogm_ctx *c, const SogmTrajRecord *records, const double *t_n
                    int32_t *out_safe, void *stream) {
   if (!c || !records || !t_now || !out_safe) return SOGM_ERR_INVALID_ARG;
   if (!c->updated) return SOGM_ERR_STATE;
+  SOGM_HIP_CHECK(hipSetDevice(c->device));
   hipLaunchKernelGGL(k_traj_safe, dim3((c->n_agents + 63) / 64), dim3(64), 0, (hipStream_t)stream, view_of(c),
                      records, t_now, check_duration, out_safe);
   SOGM_HIP_CHECK(hipGetLastError());
@@ -798,6 +861,7 @@ int sogm_query_clear(sogm_ctx *c, const int32_t *agent_idx, const double *pos_xy
   if (!c || !agent_idx || !pos_xyz || !t || !out || n_q < 0) return SOGM_ERR_INVALID_ARG;
   if (!c->updated) return SOGM_ERR_STATE;
   if (n_q == 0) return SOGM_OK;
+  SOGM_HIP_CHECK(hipSetDevice(c->device));
   hipLaunchKernelGGL(k_query_clear, dim3((n_q + 255) / 256), dim3(256), 0, (hipStream_t)stream,
                      view_of(c), agent_idx, pos_xyz, t, t_is_index, n_q, out);
   SOGM_HIP_CHECK(hipGetLastError());
@@ -812,6 +876,7 @@ int sogm_obstacle_points(sogm_ctx *c, const int32_t *agent_idx, const double *bo
     return SOGM_ERR_INVALID_ARG;
   if (!c->updated) return SOGM_ERR_STATE;
   if (n_b == 0) return SOGM_OK;
+  SOGM_HIP_CHECK(hipSetDevice(c->device));
   hipLaunchKernelGGL(k_obstacle_points, dim3(n_b), dim3(256), 0, (hipStream_t)stream, view_of(c),
                      agent_idx, box_lo, box_hi, t0, t1, out_pts, out_counts, cap);
   SOGM_HIP_CHECK(hipGetLastError());

@@ -190,6 +190,7 @@ int sogm_astar_search(sogm_planner *p, const double *start_pva, const double *go
       !out_stats || route_cap < 2)
     return SOGM_ERR_INVALID_ARG;
   if (!p->map->updated) return SOGM_ERR_STATE;
+  SOGM_HIP_CHECK(hipSetDevice(p->map->device));
   hipStream_t st = (hipStream_t)stream;
   prof_begin(p->map, SOGM_PROF_ASTAR, st);
   int rc = launch_astar(view_of(p->map), p->ap, p->pp.corridor_tau, p->aw, p->map->n_agents,
@@ -210,6 +211,7 @@ int sogm_corridor_generate(sogm_planner *p, const double *start_pva, const doubl
       !out_npoly || !out_goal || route_cap < 2)
     return SOGM_ERR_INVALID_ARG;
   if (!p->map->updated) return SOGM_ERR_STATE;
+  SOGM_HIP_CHECK(hipSetDevice(p->map->device));
   hipStream_t st = (hipStream_t)stream;
   prof_begin(p->map, SOGM_PROF_CORRIDOR, st);
   int rc = launch_corridor(view_of(p->map), p->pp, p->cw, p->map->n_agents, start_pva, t_start,
@@ -247,6 +249,7 @@ int sogm_bezier_qp_solve(sogm_planner *p, const double *start_pva, const double 
   if (!p || !start_pva || !goal_pv || !polys || !nfaces || !npoly || !out_cpts || !out_status ||
       !out_iters)
     return SOGM_ERR_INVALID_ARG;
+  SOGM_HIP_CHECK(hipSetDevice(p->map->device));
   hipStream_t st = (hipStream_t)stream;
   prof_begin(p->map, SOGM_PROF_QP, st);
   int rc = launch_qp(p->pp, p->qs, p->qw, p->qc, p->map->n_agents, start_pva, goal_pv, polys,
@@ -282,12 +285,9 @@ int sogm_planner_set_swarm(sogm_planner *p, const SogmTrajRecord *records, int n
   return SOGM_OK;
 }
 
-int sogm_replan(sogm_planner *p, const double *start_pva, const double *goal,
-                const double *t_start, const int32_t *drone_ids, SogmTrajRecord *out_records,
-                int32_t *out_ok, void *stream) {
-  if (!p || !start_pva || !goal || !t_start || !drone_ids || !out_records || !out_ok)
-    return SOGM_ERR_INVALID_ARG;
-  if (!p->map->updated) return SOGM_ERR_STATE;
+static int replan_impl(sogm_planner *p, const double *start_pva, const double *goal,
+                       const double *t_start, const int32_t *drone_ids, SogmTrajRecord *out_records,
+                       int32_t *out_ok, void *stream) {
   sogm_ctx   *c    = p->map;
   hipStream_t main = (hipStream_t)stream;
   const int   A = c->n_agents, G = p->n_groups;
@@ -360,5 +360,25 @@ int sogm_replan(sogm_planner *p, const double *start_pva, const double *goal,
     SOGM_HIP_CHECK(hipStreamWaitEvent(main, p->ev_done[g], 0));  // fan in
   }
   return SOGM_OK;
+}
+
+int sogm_replan(sogm_planner *p, const double *start_pva, const double *goal,
+                const double *t_start, const int32_t *drone_ids, SogmTrajRecord *out_records,
+                int32_t *out_ok, void *stream) {
+  if (!p || !start_pva || !goal || !t_start || !drone_ids || !out_records || !out_ok)
+    return SOGM_ERR_INVALID_ARG;
+  if (!p->map->updated) return SOGM_ERR_STATE;
+  sogm_ctx *c = p->map;
+  SOGM_HIP_CHECK(hipSetDevice(c->device));
+  const int rc = replan_impl(p, start_pva, goal, t_start, drone_ids, out_records, out_ok, stream);
+  if (rc != SOGM_OK) {
+    // A launch failed half-way: group / side streams may hold work the caller's stream was never joined to, and
+    // a pre-clear may or may not have been issued.  Drain everything and forget the pre-clear (the next update
+    // clears its grid itself); an in-place clear (mode 1) may already have eaten part of the map.
+    (void)hipDeviceSynchronize();
+    if (c->precleared && c->overlap == 1) c->updated = 0;
+    c->precleared = 0;
+  }
+  return rc;
 }
 }

@@ -61,6 +61,48 @@ def cylinders_to_struct(cyl):
     return arr
 
 
+def add_rings(scene, rings, first=True):
+    """Ring obstacles (`Cylinder.type == 2`, fake_particle_risk_voxel.cpp:137-149; the map_generator of the
+    reference's dynamic_forest_seq emits them next to the cylinders).  rings: rows {x, y, z, w (diameter), vx, vy,
+    qw, qx, qy, qz}.  Appends the ring's circle (0.10 m spacing, 3 x 3 tube section) to the cloud and returns
+    (SogmCylinder array, count) with the rings before (first=True) or after the scene's cylinders — the
+    reference takes the FIRST record that contains a voxel."""
+    rings = np.asarray(rings, np.float64).reshape(-1, 10)
+    cyl = scene["cylinders"]
+    n = len(cyl) + len(rings)
+    arr = (SogmCylinder * max(n, 1))()
+    base = cylinders_to_struct(cyl)
+    off = len(rings) if first else 0
+    for i in range(len(cyl)):
+        C.memmove(C.addressof(arr[off + i]), C.addressof(base[i]), C.sizeof(SogmCylinder))
+    roff = 0 if first else len(cyl)
+    pts = [scene["cloud"]]
+    for i, (x, y, z, w, vx, vy, qw, qx, qy, qz) in enumerate(rings):
+        c = arr[roff + i]
+        c.type = 2
+        c.x, c.y, c.z, c.w, c.h = x, y, z, w, 0.1
+        c.vx, c.vy = vx, vy
+        c.qw, c.qx, c.qy, c.qz = qw, qx, qy, qz
+        q = np.array([qw, qx, qy, qz])
+        R = _quat_to_matrix(q / np.linalg.norm(q))
+        r = 0.5 * w
+        n_seg = max(8, int(math.ceil(2.0 * math.pi * r / 0.1)))
+        th = np.arange(n_seg) * (2.0 * math.pi / n_seg)
+        for dr in (-0.1, 0.0, 0.1):
+            for dn in (-0.1, 0.0, 0.1):
+                local = np.stack([(r + dr) * np.cos(th), (r + dr) * np.sin(th), np.full_like(th, dn)], axis=1)
+                pts.append((local @ R.T + np.array([x, y, z])).astype(np.float32))
+    scene["cloud"] = np.ascontiguousarray(np.concatenate(pts, axis=0), np.float32)
+    return arr, n
+
+
+def _quat_to_matrix(q):
+    w, x, y, z = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                     [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                     [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+
+
 def make_scene(n_agents, half_range, seed, moving=True, n_cyl=None, circle_radius=None,
                tick_time=100.0):
     """Returns a dict of numpy arrays.

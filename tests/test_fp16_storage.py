@@ -66,3 +66,30 @@ def test_dsp_publish_fp16_within_half_precision(pop, orc):
     assert want.max() > 0.1
     np.testing.assert_allclose(got, want.astype(np.float16).astype(np.float32), rtol=2e-3, atol=1e-6)
     g.close(); m.close(); o.close()
+
+
+@pytest.mark.parametrize("storage", [0, 1])
+def test_odd_grid_build_overlay_queries(pop, orc, storage):
+    """65 x 65 x 21 voxels, T = 5: V and V*T are odd, so with fp16 cells every second slab starts on a 2-byte
+    boundary (the 32-bit atomics that hold an fp16 cell must pick word and half from the absolute address)."""
+    import torch
+    sogm = importlib.import_module("pred-occ-planner_amd.sogm")
+    A = 3
+    spec = pop.config.make_spec((65, 65, 21, 5), storage=storage)
+    half = (spec.L // 2) * 0.15
+    sc = pop.scene.make_scene(A, half, seed=0x77, moving=True, circle_radius=3.0, n_cyl=10)
+    dev = sogm.upload_scene(sc)
+    m = sogm.SogmMap(spec, A)
+    cyl = pop.scene.cylinders_to_struct(sc["cylinders"])
+    recs = pop.scene.straight_records(sc)
+    for rep in range(2):  # second round: the clear must have erased every cell, incl. the last half word
+        m.updateMap(dev["cloud"], dev["cloud_range"], dev["cylinders"], dev["n_cyl"], dev["poses"], dev["stamps"])
+        m.addOtherAgents(sogm._dev(recs), A, dev["ego_ids"])
+        for a in range(A):
+            want = orc.update_gt(spec, sc["cloud"], cyl, dev["n_cyl"], sc["poses"][a])
+            n_marks = want.sum()
+            orc.project_neighbours(spec, want, recs, A, a, m.body, sc["poses"][a], sc["stamps"][a])
+            got = m.download(a)
+            assert n_marks > 0 and want.sum() > n_marks  # the += path (32-bit CAS on fp16 cells) ran
+            assert np.array_equal(got, want), f"storage {storage} agent {a}: {(got != want).sum()} cells differ"
+    m.close()
