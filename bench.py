@@ -31,6 +31,8 @@ def parse():
     ap.add_argument("--no-deconflict", action="store_true", help="skip isSafeAfterOpt at the end of replan()")
     ap.add_argument("--cpu-agents", type=float, default=12.0, dest="cpu_agents",
                     help="cpu_baseline sample: seconds of wall time to spend on the CPU oracle")
+    ap.add_argument("--sustained", type=int, default=300,
+                    help="ticks of the sustained-flight block after the timed region (0 = skip)")
     return ap.parse_args()
 
 
@@ -46,7 +48,15 @@ def cpu_baseline(pop, spec, scene, n_agents_sample):
     recs = pop.scene.straight_records(scene)
     body = pop.scene.body_particles()
     A = scene["n_agents"]
-    cores = max(1, min(8, os.cpu_count() or 1, A))  # 640 MB grid per in-flight agent: bound the threads
+    # every host core, one agent-replan per thread (SURVEY §8 d); each in-flight agent holds its own SOGM
+    # (V*T*4 B = 640 MB at 200^3 x 20) — bounded by the host's RAM, not by a constant
+    cores = max(1, min(os.cpu_count() or 1, A))
+    try:
+        avail = os.sysconf("SC_AVPHYS_PAGES") * os.sysconf("SC_PAGE_SIZE")
+        per_agent = 2.2 * spec.L * spec.W * spec.H * spec.T * 4
+        cores = max(1, min(cores, int(0.6 * avail / per_agent)))
+    except (ValueError, OSError):
+        pass
     budget_s = float(n_agents_sample)
 
     def one(a):
@@ -69,7 +79,7 @@ def cpu_baseline(pop, spec, scene, n_agents_sample):
             nxt += cores
     dt = time.time() - t0
     n = len(oks)
-    return {"value": n / dt, "unit": "replans/s", "cores": cores, "kind": "port",
+    return {"value": n / dt, "unit": "replans/s", "cores": cores, "host_cores": os.cpu_count(), "kind": "port",
             "sample": f"{n} agent-replans of tick 0 (SOGM update + overlay + A* + corridors + QP) of the same "
                       f"{spec.L}x{spec.W}x{spec.H}x{spec.T} workload, {cores} threads, "
                       f"{sum(oks)}/{n} succeeded, {dt:.1f} s wall"}
@@ -105,35 +115,32 @@ def main():
     for _ in range(args.warmup):
         sw.step()
     barrier()
+    sw.planner.counters(reset=True)
     sw.map.set_profiling(True)
-    prof = []
-    n_ok = 0
     t0 = time.perf_counter()
     oks = []
     for _ in range(args.steps):
-        oks.append(sw.step())
+        oks.append(sw.step())  # a copy of this tick's ok flags (device tensor, no host sync)
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    n_ok = int(torch.stack(oks).sum().item())
-    # per-kernel times of the last tick (HIP events recorded on the launch stream inside the library)
-    ms = sw.map.profile_read()
-    # a separate short loop for per-launch averages: the roofline kernel inside the normal tick
-    # (HIP events on its launch stream), and the planner stages through the single-stage entry
-    # points (inside sogm_replan they run concurrently on per-group streams and cannot be timed
-    # one by one)
+    n_ok = int(torch.stack(oks).sum().item())  # over ALL timed ticks
+    outcomes = sw.planner.counters(reset=True)
+    if dist is not None:
+        t = torch.tensor([n_ok] + [outcomes[k] for k in sorted(outcomes)], dtype=torch.int64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        n_ok = int(t[0].item())
+        outcomes = dict(zip(sorted(outcomes), [int(v) for v in t[1:].tolist()]))
+    # The roofline kernel, launch by launch, INSIDE the timed region: the library records a HIP event pair around
+    # every k_clear_slabs launch on the stream it is launched on (the side stream in the pipelined modes) and keeps
+    # one pair per launch, so nothing synchronises between ticks (sogm_profile_read_all).
     import numpy as np
     planner = importlib.import_module("pred-occ-planner_amd.planner")
-    clear_ms = []
-    for _ in range(min(args.steps, 10)):
-        sw.step()
-        ms_tick = sw.map.profile_read()
-        stamps = torch.full((sw.A_loc,), sw.t0 + (sw.tick - 1) * driver.TICK_PERIOD, dtype=torch.float64,
-                            device="cuda")
-        clear_ms.append(ms_tick)
+    per_slot = {k: np.array(sw.map.profile_read_all(k)) for k in range(pop._abi.PROF_N)}
+    sw.map.set_profiling(True)  # restart the rings for the stage pass below
     # stage pass on the state of the last tick (map must be live: rebuild it without the pre-clear)
     overlap_mode = sw.overlap_mode
     sw.map.set_overlap_clear(False)
@@ -151,26 +158,32 @@ def main():
     c_ = sw.planner.generateCorridors(pva, t_start, s_["route"], s_["route_len"])
     q_ = sw.planner.optimize(pva, c_["goal"], c_["polys"], c_["nfaces"], c_["npoly"])
     ms_stage = sw.map.profile_read()
-    avg = np.mean(np.array(clear_ms), axis=0)
+    avg = np.array([float(per_slot[k].mean()) if len(per_slot[k]) else -1.0 for k in range(pop._abi.PROF_N)])
+    n_clear = int(len(per_slot[0]))
     if overlap_mode == 1 and avg[6] > 0:
         avg[0] += avg[6]  # single-grid mode clears in two launches (narrow head + full-width rest): one clear = both
-    avg[3:6] = ms_stage[3:6]
+    avg[3:6] = ms_stage[3:6]  # planner stages: single-stage entry points after the timed region (inside sogm_replan
+    #                           they run concurrently on per-group streams and cannot be timed one by one)
     grid_bytes = sw.map.grid_bytes()  # V * T * 4 bytes x agents of this rank = algorithmic bytes / launch
-    # HBM traffic of the roofline kernel comes from the committed PMC passes (FETCH_SIZE + WRITE_SIZE,
-    # separate rocprofv3 runs): only valid for the workload they were collected on
-    traffic = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-            pmc = json.load(f)
-        if pmc["algorithmic_bytes_per_launch"] == grid_bytes:
-            traffic = pmc["bytes_per_launch"]
-    except (OSError, KeyError, ValueError):
-        pass
+    # HBM traffic of the roofline kernel: PMC counters cannot be read from inside this process; the figure comes
+    # from the committed rocprofv3 --pmc passes of THIS command (FETCH_SIZE and WRITE_SIZE in separate runs,
+    # tools/make_profile.sh) and is only reported when it was collected on the same workload (same bytes / launch)
+    traffic, traffic_source = None, None
+    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                pmc = json.load(f)
+            if pmc["algorithmic_bytes_per_launch"] == grid_bytes:
+                traffic, traffic_source = pmc["bytes_per_launch"], f"profiles/{name} (committed rocprofv3 --pmc passes, not measured in this run)"
+                break
+        except (OSError, KeyError, ValueError):
+            pass
     achieved = grid_bytes / (avg[0] * 1e-3) / 1e9
     out = {
         "metric": "replans/sec (SOGM update + QP: full replan = SOGM update + A* + corridors + QP + deconfliction), "
                   f"{sw.A_loc}-agent batch per GPU, {spec.L}x{spec.W}x{spec.H}x{spec.T} voxel grid; aggregate over all agents",
-        "value": sw.A_tot * args.steps / dt,
+        "value": sw.A_tot * args.steps / dt,   # replan cycles executed per second (BASELINE.json's metric)
+        "value_ok": n_ok / dt,                  # of which replan() returned true
         "unit": "replans/s",
         "n_gpus": world,
         "steps": args.steps,
@@ -185,7 +198,9 @@ def main():
                                f"sim_fkpcp-style moving cylinders, batched ADMM QP (BASELINE {'configs[4]' if args.grid == 'cfg4' else 'configs[2]'} per GPU)",
                    "agents_total": sw.A_tot, "grid": [spec.L, spec.W, spec.H, spec.T],
                    "cloud_points": int(sw.scene["cloud"].shape[0]), "cloud_points_scanned": sw.cloud_points, "cylinders": int(len(sw.scene["cylinders"])),
-                   "replans_ok_fraction": n_ok / float(sw.A_loc * args.steps),
+                   "replans_ok_fraction": n_ok / float(sw.A_tot * args.steps),
+                   # where the timed replans ended + capacity limits hit (sogm_planner_counters)
+                   "outcomes": outcomes,
                    "parallelism": f"agents sharded x{world}, 1 all-gather/tick",
                    "sogm_grids_per_agent": 2 if overlap_mode == 2 else 1},
         "replans_per_s_per_agent": sw.A_tot * args.steps / dt / sw.A_tot,
@@ -193,7 +208,9 @@ def main():
                      "qp": avg[5]},
         "roofline": {"bound": "hbm", "kernel": "k_clear_slabs (SOGM voxel update)", "achieved": achieved,
                      "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
+                     "traffic_source": traffic_source,
                      "bytes_per_launch": grid_bytes, "avg_launch_ms": float(avg[0]),
+                     "launches_timed": n_clear, "timed_where": "HIP events on the launch stream, every launch of the timed region",
                      # avg_launch_ms is the launch as it runs inside the tick (double-buffered mode: a narrow
                      # clear sharing the machine with the planner kernels); the same kernel at full width with
                      # the machine to itself, from the stage pass after the timed region:
@@ -201,6 +218,30 @@ def main():
                                     "achieved": grid_bytes / (min(standalone_clear_ms) * 1e-3) / 1e9,
                                     "frac": grid_bytes / (min(standalone_clear_ms) * 1e-3) / 1e9 / 8000.0}},
     }
+    if args.sustained > 0:
+        # sustained flight: the 20-step figure covers the first seconds (agents still far apart); keep flying —
+        # the swarm converges on the centre, searches get longer — and time every tick (host-synchronised)
+        sw.map.set_overlap_clear(overlap_mode != 0, double_buffer=(overlap_mode == 2))
+        sw.map.set_profiling(False)
+        sw.planner.counters(reset=True)
+        tick_ms, oks2 = [], []
+        barrier()
+        for _ in range(args.sustained):
+            t1 = time.perf_counter()
+            oks2.append(sw.step())
+            torch.cuda.synchronize()
+            tick_ms.append((time.perf_counter() - t1) * 1e3)
+        tm = np.array(tick_ms)
+        n_ok2 = int(torch.stack(oks2).sum().item())
+        out["sustained"] = {"ticks": args.sustained, "flight_seconds": args.sustained * driver.TICK_PERIOD,
+                            "first_tick": sw.tick - args.sustained,
+                            "tick_ms_mean": float(tm.mean()), "tick_ms_p50": float(np.percentile(tm, 50)),
+                            "tick_ms_p99": float(np.percentile(tm, 99)), "tick_ms_max": float(tm.max()),
+                            "value": sw.A_tot * args.sustained / (tm.sum() * 1e-3),
+                            "value_ok": n_ok2 * world / (tm.sum() * 1e-3),
+                            "replans_ok_fraction": n_ok2 / float(sw.A_loc * args.sustained),
+                            "outcomes_rank0": sw.planner.counters(reset=True),
+                            "note": "every tick host-synchronised (no overlap between ticks); rank 0's clock"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(pop, spec, sw.scene, args.cpu_agents)
     else:

@@ -116,7 +116,13 @@ typedef struct SogmAstarParams {
   int32_t allocate_num;
   int32_t check_num;
   int32_t tolerance; /* search/tolerance, default 1 */
-  int32_t _pad;
+  int32_t shot_ignores_time; /* 0 = FakeRiskHybridAstar: the shot trajectory is checked with
+                                getClearOcccupancy(coord, time) (fake_risk_hybrid_a_star.cpp:521);
+                                1 = RiskHybridAstar: getClearOcccupancy(coord), i.e. slice 0
+                                (risk_hybrid_a_star.cpp:514, risk_base.cpp:251-253) — the only difference
+                                between the two classes.  sogm_planner_create() sets it from
+                                SogmPlannerParams.fake_planner (BaselinePlanner owns a RiskHybridAstar,
+                                FakeBaselinePlanner a FakeRiskHybridAstar: baseline.h:155, baseline_fake.h). */
 } SogmAstarParams;
 
 /* Planner parameters = BaselineParameters (plan_manager/include/plan_manager/baseline.h:45-94). */
@@ -193,6 +199,11 @@ int sogm_set_profiling(sogm_ctx *ctx, int enable);
 /* Synchronises the device, then writes the duration (ms) of the LAST launch of each slot
  * (negative if that slot has not run since profiling was enabled).  host out_ms[SOGM_PROF_N]. */
 int sogm_profile_read(sogm_ctx *ctx, double *out_ms_host);
+/* Every launch of a slot since sogm_set_profiling(ctx, 1) keeps its own event pair (the last 1024 are kept), so a
+ * whole timed region can be measured launch by launch with no synchronisation inside it.  Synchronises the
+ * device, then writes the durations (ms, oldest first) of the last min(cap, 1024, launches) launches of `slot`
+ * to host out_ms[cap] and their number to *out_n. */
+int sogm_profile_read_all(sogm_ctx *ctx, int slot, double *out_ms_host, int cap, int *out_n);
 
 /*
  * Tick pipelining (mode): 0 = off (every update clears its grid in stream order).
@@ -520,6 +531,26 @@ int sogm_safe_after_opt(sogm_planner *p, const double *cpts, const int32_t *npol
  */
 int sogm_planner_set_swarm(sogm_planner *p, const SogmTrajRecord *records, int n_records,
                            const int32_t *ego_ids, const double *t_now);
+
+/*
+ * Cumulative counters of sogm_replan() since creation / the last reset: where each replan ended (the early
+ * returns of baseline_fake.cpp:292,405-419,447,455) and how often a capacity limit that the reference does not
+ * have (it grows std::vectors) turned a corridor / a deconfliction check into a failure.  Synchronous.
+ * host out[SOGM_CNT_N] int64.
+ */
+enum {
+  SOGM_CNT_REPLAN_OK           = 0, /* replan() returned true                                        */
+  SOGM_CNT_FAIL_SEARCH         = 1, /* A* NO_PATH after the retry (:284-295)                         */
+  SOGM_CNT_FAIL_CORRIDOR       = 2, /* no usable corridor (:405-419)                                 */
+  SOGM_CNT_FAIL_QP             = 3, /* OSQP status not SOLVED / SOLVED_INACCURATE (:447)             */
+  SOGM_CNT_FAIL_UNSAFE         = 4, /* isSafeAfterOpt false (:455-460)                               */
+  SOGM_CNT_CORRIDOR_CAPACITY   = 5, /* corridor chains cut at a segment that exceeded pc_capacity points,
+                                       128 selected planes or max_faces (treated as invalid)         */
+  SOGM_CNT_PIECES_CAPACITY     = 6, /* routes longer than SOGM_MAX_PIECES segments (truncated)       */
+  SOGM_CNT_DECONFLICT_CAPACITY = 7, /* pairs with more than 144 LP rows (treated as unsafe)          */
+  SOGM_CNT_N                   = 8
+};
+int sogm_planner_counters(sogm_planner *p, int64_t *out_host, int reset);
 
 /*
  * One full FakeBaselinePlanner::replan (baseline_fake.cpp:266-472; isSafeAfterOpt only when a swarm has

@@ -4,7 +4,8 @@
 //   search :115-426, estimateHeuristic :428-468, computeShotTraj :470-523, cubic/quartic :525-587,
 //   getPathWithVel :663-694, posToIndex/timeToIndex :795-803, stateTransit :812-824,
 //   retrievePath :826-836;  node/hash/heap types path_node.h:37-97, grid_node.h:10-51.
-// (risk_hybrid_a_star.cpp is the same algorithm; its shot check drops the time argument, :514.)
+// (risk_hybrid_a_star.cpp is the same algorithm; its shot check drops the time argument, :514 —
+//  selected with SogmAstarParams.shot_ignores_time.)
 //
 // Quirks kept on purpose:
 //   * hash insert uses (int)pro_node->time while find uses time_idx (:387 vs :271);
@@ -200,7 +201,9 @@ struct Search {
       double       coord[3];
       for (int dim = 0; dim < 3; ++dim)
         coord[dim] = ((d[dim] * 1.0 + c[dim] * t1) + b[dim] * t2) + a[dim] * t3;
-      if (query(coord, time) != 0) return false;
+      // :521 (fake) passes the time; risk_hybrid_a_star.cpp:514 calls getClearOcccupancy(coord) = slice 0
+      const int hit = ap->shot_ignores_time ? orc_query_clear_idx(spec, grid, pose, coord, 0) : query(coord, time);
+      if (hit != 0) return false;
     }
     is_shot_succ = true;
     return true;

@@ -392,3 +392,30 @@ def traj_safe(spec, grid, pose, map_stamp, record, t_now, T):
     ps = np.ascontiguousarray(pose, np.float32)
     return int(lib().orc_traj_safe(C.byref(spec), fptr(g), fptr(ps), C.c_double(map_stamp), C.byref(record),
                                    C.c_double(t_now), C.c_double(T)))
+
+
+# ---------------------------------------------------------------- f2: FSM
+class OrcFsmState(C.Structure):
+    _fields_ = [("status", C.c_int32), ("num_replan_failures", C.c_int32), ("is_success", C.c_int32),
+                ("_pad", C.c_int32), ("traj_start_time", C.c_double)]
+
+
+class OrcFsmConfig(C.Structure):
+    _fields_ = [("replan_duration", C.c_double), ("replan_start_time", C.c_double),
+                ("replan_max_failures", C.c_int32), ("_pad", C.c_int32)]
+
+
+class FsmOracle:
+    """FiniteStateMachine::FSMCallback for one agent (plan_manager/src/plan_manager.cpp:92-233)."""
+
+    def __init__(self, traj_start_time, replan_duration=0.1, replan_start_time=0.02, replan_max_failures=5):
+        self.s = OrcFsmState()
+        self.cfg = OrcFsmConfig(replan_duration, replan_start_time, replan_max_failures, 0)
+        lib().orc_fsm_init(C.byref(self.s), C.c_double(traj_start_time))
+
+    def tick(self, now, replan_ok, traj_safe, goal_reached):
+        """-> None | 'new' | ('hover', start_time)"""
+        hs = C.c_double(0.0)
+        pub = lib().orc_fsm_tick(C.byref(self.s), C.byref(self.cfg), C.c_double(now), int(replan_ok),
+                                 int(traj_safe), int(goal_reached), C.byref(hs))
+        return None if pub == 0 else ("new" if pub == 1 else ("hover", hs.value))

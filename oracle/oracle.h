@@ -154,6 +154,25 @@ void  orc_gridmap_force_frame(void *h, int raycast_num);
 void  orc_gridmap_state(void *h, double *occ, int8_t *inflate, int bounds[6]);
 int   orc_gridmap_inflate_occupancy(void *h, const double pos[3]);
 
+/* ---- f2: FiniteStateMachine::FSMCallback (plan_manager/src/plan_manager.cpp:92-233), see fsm_oracle.cpp ---- */
+enum { ORC_FSM_NEW_PLAN = 0, ORC_FSM_EXEC_TRAJ = 1, ORC_FSM_REPLAN = 2, ORC_FSM_GOAL_REACHED = 3 };
+typedef struct OrcFsmState {
+  int32_t status;
+  int32_t num_replan_failures;
+  int32_t is_success; /* the member is_success_ (set in NEW_PLAN only) */
+  int32_t _pad;
+  double  traj_start_time;
+} OrcFsmState;
+typedef struct OrcFsmConfig { /* plan_manager/config/sim_fake.yaml:7-10 */
+  double  replan_duration;
+  double  replan_start_time;
+  int32_t replan_max_failures;
+  int32_t _pad;
+} OrcFsmConfig;
+void orc_fsm_init(OrcFsmState *s, double traj_start_time);
+int  orc_fsm_tick(OrcFsmState *s, const OrcFsmConfig *cfg, double now, int replan_ok, int traj_safe,
+                  int goal_reached, double *hover_start_time);
+
 /* ---- f2: BaselinePlanner::isTrajSafe (plan_manager/src/baseline.cpp:45-68) ---- */
 int orc_traj_safe(const SogmSpec *s, const float *grid_vt, const float pose[3], double map_stamp,
                   const SogmTrajRecord *r, double t_now, double T);

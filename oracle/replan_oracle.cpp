@@ -19,6 +19,9 @@ extern "C" int orc_replan(const SogmSpec *s, const SogmAstarParams *ap, const So
   const double        t_after_map = t_start - stamp;
   std::vector<double> route(64 * 6);
   int                 route_len = 0, stats[4], ntr = 0;
+  SogmAstarParams apv   = *ap;  // BaselinePlanner: RiskHybridAstar; FakeBaselinePlanner: FakeRiskHybridAstar
+  apv.shot_ignores_time = pp->fake_planner ? 0 : 1;
+  ap                    = &apv;
   const int ret = orc_astar_search(s, ap, grid, pose, start_pva, goal, t_after_map,
                                    pp->corridor_tau, route.data(), &route_len, 64, stats, nullptr,
                                    0, &ntr);

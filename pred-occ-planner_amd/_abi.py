@@ -24,6 +24,9 @@ SOGM_ERR_CAPACITY = -4
 SOGM_ERR_STATE = -5
 PROF_CLEAR, PROF_STAMP, PROF_SPLAT, PROF_ASTAR, PROF_CORRIDOR, PROF_QP, PROF_CLEAR_HEAD, PROF_N = range(8)
 
+COUNTER_NAMES = ("replan_ok", "fail_search", "fail_corridor", "fail_qp", "fail_unsafe", "corridor_capacity",
+                 "pieces_capacity", "deconflict_capacity")
+
 # ASTAR_RET (path_searching/include/path_searching/dyn_a_star.h:15)
 ASTAR_NO_PATH, ASTAR_INIT_ERR, ASTAR_SEARCH_ERR, ASTAR_REACH_HORIZON, ASTAR_REACH_END, ASTAR_NEAR_END = range(6)
 
@@ -74,7 +77,7 @@ class SogmAstarParams(C.Structure):
                 ("w_time", C.c_double), ("horizon", C.c_double), ("lambda_heu", C.c_double),
                 ("resolution", C.c_double), ("time_resolution", C.c_double),
                 ("allocate_num", C.c_int32), ("check_num", C.c_int32), ("tolerance", C.c_int32),
-                ("_pad", C.c_int32)]
+                ("shot_ignores_time", C.c_int32)]
 
 
 class SogmPlannerParams(C.Structure):
@@ -111,6 +114,7 @@ PROTOTYPES = {
     "sogm_set_overlap_clear": (_i, [_vp, _i]),
     "sogm_set_profiling": (_i, [_vp, _i]),
     "sogm_profile_read": (_i, [_vp, C.POINTER(C.c_double)]),
+    "sogm_profile_read_all": (_i, [_vp, _i, C.POINTER(C.c_double), _i, C.POINTER(_i)]),
     "sogm_update_gt": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
     "sogm_project_neighbours": (_i, [_vp, _vp, _i, _vp, _vp]),
     "sogm_set_future_risk": (_i, [_vp, _vp, _vp, _vp, _vp]),
@@ -134,6 +138,7 @@ PROTOTYPES = {
     "sogm_gridmap_force_frame": (_i, [_vp, _i]),
     "sogm_traj_safe": (_i, [_vp, _vp, _vp, C.c_double, _vp, _vp]),
     "sogm_safe_after_opt": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
+    "sogm_planner_counters": (_i, [_vp, C.POINTER(C.c_int64), _i]),
     "sogm_planner_set_swarm": (_i, [_vp, _vp, _i, _vp, _vp]),
     "sogm_filter_point_cloud": (_i, [_vp, _vp, _vp, C.c_float, _i, _vp, _vp, _vp]),
     "sogm_filter_reserve": (_i, [_vp, _i]),

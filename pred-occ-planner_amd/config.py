@@ -37,8 +37,10 @@ def make_spec(grid="parity", map_kind=SOGM_MAP_FAKE, clearance=0.45, time_resolu
     return s
 
 
-def make_astar_params():
+def make_astar_params(fake=True):
+    """fake: FakeRiskHybridAstar (shot check with time) / RiskHybridAstar (time-less shot check)."""
     p = SogmAstarParams()
+    p.shot_ignores_time = 0 if fake else 1
     p.max_tau = 2.0
     p.max_vel = 2.0
     p.max_acc = 6.0

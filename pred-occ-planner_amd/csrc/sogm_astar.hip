@@ -438,7 +438,11 @@ __global__ __launch_bounds__(ASTAR_THREADS) void k_astar(
                 double       co[3];
                 for (int dim = 0; dim < 3; ++dim)
                   co[dim] = ((d[dim] * 1.0 + c[dim] * t1) + b[dim] * t2) + a[dim] * t3;
-                if (query_clear_time(m, agent, co[0], co[1], co[2], time) != 0) {
+                // FakeRiskHybridAstar passes the shot-relative time (:521); RiskHybridAstar asks for slice 0
+                // (risk_hybrid_a_star.cpp:514 -> risk_base.cpp:251-253)
+                const int hit = ap.shot_ignores_time ? query_clear_idx(m, agent, co[0], co[1], co[2], 0)
+                                                     : query_clear_time(m, agent, co[0], co[1], co[2], time);
+                if (hit != 0) {
                   ok = false;
                   break;
                 }

@@ -1494,9 +1494,16 @@ __global__ __launch_bounds__(64) void k_corridor_finalize(
   if (rl < 1) return;
   // corridors are kept up to the first invalid one (the loop `break`s, baseline.cpp:355-358)
   for (int i = 0; i < rl - 1 && i < SOGM_MAX_PIECES; ++i) {
-    if (state[i] != 1) break;
+    if (state[i] != 1) {
+      // a corridor that hit a capacity the reference does not have (pc_capacity points, 128 selected planes,
+      // max_faces) counts as invalid: make that visible
+      if (state[i] == -3 && w0 && ws.counters) atomicAdd(&ws.counters[SOGM_CNT_CORRIDOR_CAPACITY], 1ull);
+      break;
+    }
     ++npoly;
   }
+  if (npoly == SOGM_MAX_PIECES && rl - 1 > SOGM_MAX_PIECES && w0 && ws.counters)
+    atomicAdd(&ws.counters[SOGM_CNT_PIECES_CAPACITY], 1ull);  // route longer than 16 pieces: truncated
   if (npoly == 0) return;
   for (int i = 0; i + 1 < npoly; ++i) {
     if (!corridorValidW(polys + (size_t)i * MF * 4, nfs[i], polys + (size_t)(i + 1) * MF * 4,
@@ -1564,7 +1571,8 @@ __global__ __launch_bounds__(64) void k_safe_after_opt(const double *__restrict_
                                                        const SogmTrajRecord *__restrict__ rec, int n_rec,
                                                        const int32_t *__restrict__ ego_ids,
                                                        const double *__restrict__ t_now,
-                                                       int32_t *__restrict__ out_safe, int agent0) {
+                                                       int32_t *__restrict__ out_safe, int agent0,
+                                                       unsigned long long *counters) {
   extern __shared__ __attribute__((aligned(16))) double s_dyn[];
   double *s_lp   = s_dyn;                   // LP_WORK_DOUBLES
   double *s_rows = s_lp + LP_WORK_DOUBLES;  // LP_MAX_ROWS * 5
@@ -1589,7 +1597,10 @@ __global__ __launch_bounds__(64) void k_safe_after_opt(const double *__restrict_
   }
   const int nA = 5 * M, nB = (r.n_pieces - piece) * 5;
   if (nA + nB > DECONFLICT_MAX_ROWS) {  // LP capacity: treated as "not separable" (oracle does the same)
-    if (threadIdx.x == 0) out_safe[a] = 0;
+    if (threadIdx.x == 0) {
+      out_safe[a] = 0;
+      if (counters) atomicAdd(&counters[SOGM_CNT_DECONFLICT_CAPACITY], 1ull);
+    }
     return;
   }
   double       *A = s_rows, *b = s_rows + LP_MAX_ROWS * 4;
@@ -1718,12 +1729,12 @@ __global__ void k_fill_i32(int32_t *p, int n, int32_t v, int agent0) {
 
 int launch_deconflict(int n_agents, const double *cpts, const int32_t *npoly, const SogmTrajRecord *rec,
                       int n_rec, const int32_t *ego_ids, const double *t_now, int32_t *out_safe,
-                      hipStream_t st, int agent0) {
+                      hipStream_t st, int agent0, unsigned long long *counters) {
   hipLaunchKernelGGL(k_fill_i32, dim3((n_agents + 63) / 64), dim3(64), 0, st, out_safe, n_agents, 1, agent0);
   if (n_rec > 0) {
     const size_t lds = sizeof(double) * (LP_WORK_DOUBLES + LP_MAX_ROWS * 5) + sizeof(int) * LP_MAX_ROWS;
     hipLaunchKernelGGL(k_safe_after_opt, dim3(n_rec, n_agents), dim3(64), lds, st, cpts, npoly, rec, n_rec,
-                       ego_ids, t_now, out_safe, agent0);
+                       ego_ids, t_now, out_safe, agent0, counters);
   }
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }

@@ -5,6 +5,8 @@
 
 #include <hip/hip_fp16.h>
 #include <hip/hip_runtime.h>
+
+#include <new>
 #include <stdint.h>
 
 #include "../../include/sogm_abi.h"
@@ -274,19 +276,33 @@ struct sogm_ctx {
   int           *d_filter_blocks;
   int            filter_max_cells;
   int            profiling;
-  hipEvent_t     ev[SOGM_PROF_N][2];
-  int            ev_used[SOGM_PROF_N];
+  // per-slot ring of HIP event pairs: every launch of a profiled kernel since profiling was enabled keeps its own
+  // pair, so a run can be timed launch by launch WITHOUT synchronising between launches (sogm_profile_read_all)
+  hipEvent_t    *ring[SOGM_PROF_N];    // [SOGM_PROF_RING][2], created lazily
+  long long      ring_n[SOGM_PROF_N];  // launches recorded since sogm_set_profiling(1)
 };
+#define SOGM_PROF_RING 1024
 
 namespace sogm {
 // RAII-free helper: record the begin/end events of profiling slot `slot` on `st`.
+inline hipEvent_t *prof_pair(sogm_ctx *c, int slot, long long n) {
+  if (!c->ring[slot]) {
+    c->ring[slot] = new (std::nothrow) hipEvent_t[2 * SOGM_PROF_RING]();
+    if (!c->ring[slot]) return nullptr;
+  }
+  hipEvent_t *p = c->ring[slot] + 2 * (n % SOGM_PROF_RING);
+  if (!p[0] && (hipEventCreate(&p[0]) != hipSuccess || hipEventCreate(&p[1]) != hipSuccess)) return nullptr;
+  return p;
+}
 inline void prof_begin(sogm_ctx *c, int slot, hipStream_t st) {
-  if (c->profiling) (void)hipEventRecord(c->ev[slot][0], st);
+  if (!c->profiling) return;
+  if (hipEvent_t *p = prof_pair(c, slot, c->ring_n[slot])) (void)hipEventRecord(p[0], st);
 }
 inline void prof_end(sogm_ctx *c, int slot, hipStream_t st) {
-  if (c->profiling) {
-    (void)hipEventRecord(c->ev[slot][1], st);
-    c->ev_used[slot] = 1;
+  if (!c->profiling) return;
+  if (hipEvent_t *p = prof_pair(c, slot, c->ring_n[slot])) {
+    (void)hipEventRecord(p[1], st);
+    c->ring_n[slot]++;
   }
 }
 }  // namespace sogm

@@ -649,10 +649,6 @@ int sogm_create(const SogmSpec *spec, int n_agents, int device, sogm_ctx **out) 
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_grid_free, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_cleared, hipEventDisableTiming);
-  for (int k = 0; k < SOGM_PROF_N && e == hipSuccess; ++k) {
-    e = hipEventCreate(&c->ev[k][0]);
-    if (e == hipSuccess) e = hipEventCreate(&c->ev[k][1]);
-  }
   if (e != hipSuccess) {
     sogm::set_error("sogm_create", e);
     sogm_destroy(c);
@@ -680,8 +676,11 @@ void sogm_destroy(sogm_ctx *c) {
   if (c->ev_grid_free) (void)hipEventDestroy(c->ev_grid_free);
   if (c->ev_cleared) (void)hipEventDestroy(c->ev_cleared);
   for (int k = 0; k < SOGM_PROF_N; ++k) {
-    if (c->ev[k][0]) (void)hipEventDestroy(c->ev[k][0]);
-    if (c->ev[k][1]) (void)hipEventDestroy(c->ev[k][1]);
+    if (c->ring[k]) {
+      for (int i = 0; i < 2 * SOGM_PROF_RING; ++i)
+        if (c->ring[k][i]) (void)hipEventDestroy(c->ring[k][i]);
+      delete[] c->ring[k];
+    }
   }
   delete c;
 }
@@ -719,7 +718,7 @@ int sogm_set_overlap_clear(sogm_ctx *c, int mode) {
 int sogm_set_profiling(sogm_ctx *c, int enable) {
   if (!c) return SOGM_ERR_INVALID_ARG;
   c->profiling = enable ? 1 : 0;
-  for (int k = 0; k < SOGM_PROF_N; ++k) c->ev_used[k] = 0;
+  for (int k = 0; k < SOGM_PROF_N; ++k) c->ring_n[k] = 0;
   return SOGM_OK;
 }
 
@@ -729,9 +728,28 @@ int sogm_profile_read(sogm_ctx *c, double *out_ms) {
   SOGM_HIP_CHECK(hipDeviceSynchronize());
   for (int k = 0; k < SOGM_PROF_N; ++k) {
     out_ms[k] = -1.0;
-    if (!c->ev_used[k]) continue;
-    float ms = 0.f;
-    if (hipEventElapsedTime(&ms, c->ev[k][0], c->ev[k][1]) == hipSuccess) out_ms[k] = (double)ms;
+    if (c->ring_n[k] <= 0 || !c->ring[k]) continue;
+    hipEvent_t *p  = c->ring[k] + 2 * ((c->ring_n[k] - 1) % SOGM_PROF_RING);
+    float       ms = 0.f;
+    if (hipEventElapsedTime(&ms, p[0], p[1]) == hipSuccess) out_ms[k] = (double)ms;
+  }
+  return SOGM_OK;
+}
+
+int sogm_profile_read_all(sogm_ctx *c, int slot, double *out_ms, int cap, int *out_n) {
+  if (!c || !out_ms || !out_n || slot < 0 || slot >= SOGM_PROF_N || cap < 0) return SOGM_ERR_INVALID_ARG;
+  SOGM_HIP_CHECK(hipSetDevice(c->device));
+  SOGM_HIP_CHECK(hipDeviceSynchronize());
+  long long n = c->ring_n[slot];
+  if (n > SOGM_PROF_RING) n = SOGM_PROF_RING;
+  if (n > cap) n = cap;
+  *out_n = 0;
+  if (!c->ring[slot]) return SOGM_OK;
+  for (long long i = c->ring_n[slot] - n; i < c->ring_n[slot]; ++i) {  // oldest kept launch first
+    hipEvent_t *p  = c->ring[slot] + 2 * (i % SOGM_PROF_RING);
+    float       ms = 0.f;
+    if (hipEventElapsedTime(&ms, p[0], p[1]) != hipSuccess) ms = -1.f;
+    out_ms[(*out_n)++] = (double)ms;
   }
   return SOGM_OK;
 }

@@ -57,9 +57,17 @@ static void min_jerk_block(double *QM /*15x15*/) {
 __global__ void k_pack_records(int A, double corridor_tau, const int32_t *ret, const int32_t *npoly,
                                const int32_t *status, const int32_t *safe, const double *cpts,
                                const double *t_start, const int32_t *drone_ids, SogmTrajRecord *out,
-                               int32_t *ok, int agent0) {
+                               int32_t *ok, int agent0, unsigned long long *counters) {
   const int a = blockIdx.x * blockDim.x + threadIdx.x + agent0;
   if (a >= A) return;
+  if (counters) {  // where this replan ended (baseline_fake.cpp: :292 no path, :405-419 corridors, :447 QP, :455 unsafe)
+    int k = SOGM_CNT_REPLAN_OK;
+    if (ret[a] == 0) k = SOGM_CNT_FAIL_SEARCH;
+    else if (npoly[a] <= 0) k = SOGM_CNT_FAIL_CORRIDOR;
+    else if (!(status[a] == 1 || status[a] == 2)) k = SOGM_CNT_FAIL_QP;
+    else if (safe != nullptr && safe[a] == 0) k = SOGM_CNT_FAIL_UNSAFE;
+    atomicAdd(&counters[k], 1ull);
+  }
   SogmTrajRecord &r = out[a];
   // isSafeAfterOpt false -> replan() returns false (baseline_fake.cpp:455-460)
   const bool good = ret[a] != 0 && npoly[a] > 0 && (status[a] == 1 || status[a] == 2) &&
@@ -84,6 +92,9 @@ int sogm_planner_create(sogm_ctx *map, const SogmAstarParams *astar, const SogmP
   p->map = map;
   p->ap  = *astar;
   p->pp  = *pp;
+  // BaselinePlanner searches with RiskHybridAstar, FakeBaselinePlanner with FakeRiskHybridAstar: the classes
+  // differ in the shot check only (risk_hybrid_a_star.cpp:514 vs fake_risk_hybrid_a_star.cpp:521)
+  p->ap.shot_ignores_time = pp->fake_planner ? 0 : 1;
   p->qs  = *qp;
   if (astar->allocate_num < 2 || astar->allocate_num > astar_pool_max() || astar->check_num < 1 || !(astar->resolution > 0) ||
       !(astar->time_resolution > 0)) {
@@ -119,6 +130,8 @@ int sogm_planner_create(sogm_ctx *map, const SogmAstarParams *astar, const SogmP
     if (e == hipSuccess) e = hipMalloc((void **)&p->cw.seg_state, sizeof(int32_t) * slots);
     if (e == hipSuccess) e = hipMalloc((void **)&p->cw.seg_npts, sizeof(int32_t) * slots);
     if (e == hipSuccess) e = hipMalloc((void **)&p->cw.seg_dbg, sizeof(long long) * 16 * slots);
+    if (e == hipSuccess) e = hipMalloc((void **)&p->cw.counters, sizeof(unsigned long long) * SOGM_CNT_N);
+    if (e == hipSuccess) e = hipMemset(p->cw.counters, 0, sizeof(unsigned long long) * SOGM_CNT_N);
     // QP row storage fallback (rows normally live in LDS)
     p->qw.scratch_stride = qp_scratch_bytes_per_agent(pp->max_faces);
     p->qw.dyn_lds_bytes  = qp_dynamic_lds_bytes();  // 160 KiB/CU minus k_qp's static LDS
@@ -163,7 +176,7 @@ void sogm_planner_destroy(sogm_planner *p) {
   void *ptrs[] = {p->aw.pool, p->aw.hkeys, p->aw.dbg,
                   p->d_ret,   p->d_route_len, p->d_stats, p->d_route,
                   p->cw.pc,   p->cw.fpc,  p->cw.tang, p->cw.distr, p->cw.polys,
-                  p->cw.seg_nfaces, p->cw.seg_state, p->cw.seg_npts, p->cw.seg_dbg,
+                  p->cw.seg_nfaces, p->cw.seg_state, p->cw.seg_npts, p->cw.seg_dbg, p->cw.counters,
                   p->qw.scratch,
                   p->d_polys, p->d_goal, p->d_cpts, p->d_nfaces, p->d_npoly, p->d_status, p->d_iters,
                   p->d_safe};
@@ -275,6 +288,15 @@ int sogm_safe_after_opt(sogm_planner *p, const double *cpts, const int32_t *npol
   return SOGM_OK;
 }
 
+int sogm_planner_counters(sogm_planner *p, int64_t *out_host, int reset) {
+  if (!p || !out_host) return SOGM_ERR_INVALID_ARG;
+  SOGM_HIP_CHECK(hipSetDevice(p->map->device));
+  SOGM_HIP_CHECK(hipDeviceSynchronize());
+  SOGM_HIP_CHECK(hipMemcpy(out_host, p->cw.counters, sizeof(int64_t) * SOGM_CNT_N, hipMemcpyDeviceToHost));
+  if (reset) SOGM_HIP_CHECK(hipMemset(p->cw.counters, 0, sizeof(int64_t) * SOGM_CNT_N));
+  return SOGM_OK;
+}
+
 int sogm_planner_set_swarm(sogm_planner *p, const SogmTrajRecord *records, int n_records,
                            const int32_t *ego_ids, const double *t_now) {
   if (!p || n_records < 0 || (records && (!ego_ids || !t_now))) return SOGM_ERR_INVALID_ARG;
@@ -347,14 +369,14 @@ static int replan_impl(sogm_planner *p, const double *start_pva, const double *g
     }
     if (p->swarm) {
       if (sogm::launch_deconflict(n, p->d_cpts, p->d_npoly, p->swarm, p->n_swarm, p->swarm_ego, p->swarm_now,
-                                  p->d_safe, st, a0) != 0) {
+                                  p->d_safe, st, a0, p->cw.counters) != 0) {
         sogm::set_error("sogm_replan launch_deconflict", hipGetLastError());
         return SOGM_ERR_HIP;
       }
     }
     hipLaunchKernelGGL(k_pack_records, dim3((n + 63) / 64), dim3(64), 0, st, a1, p->pp.corridor_tau,
                        p->d_ret, p->d_npoly, p->d_status, p->swarm ? p->d_safe : nullptr, p->d_cpts, t_start,
-                       drone_ids, out_records, out_ok, a0);
+                       drone_ids, out_records, out_ok, a0, p->cw.counters);
     SOGM_HIP_CHECK(hipGetLastError());
     SOGM_HIP_CHECK(hipEventRecord(p->ev_done[g], st));
     SOGM_HIP_CHECK(hipStreamWaitEvent(main, p->ev_done[g], 0));  // fan in

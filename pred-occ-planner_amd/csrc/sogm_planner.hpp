@@ -26,12 +26,13 @@ struct CorridorWorkspace {
   int32_t *seg_state;   // [A*P] 1 valid, 0 invalid, -2 no segment, -3 capacity exceeded
   int32_t *seg_npts;    // [A*P]
   long long *seg_dbg;   // [A*P][16] diagnostics: counts and wall_clock64 ticks (100 MHz) per phase
+  unsigned long long *counters;  // [SOGM_CNT_N] cumulative outcome / capacity counters (sogm_planner_counters)
 };
 
 // ParticleATC::isSafeAfterOpt for agents [agent0, agent0 + n_agents): out_safe[a] = 1 / 0
 int launch_deconflict(int n_agents, const double *cpts, const int32_t *npoly, const SogmTrajRecord *rec,
                       int n_rec, const int32_t *ego_ids, const double *t_now, int32_t *out_safe,
-                      hipStream_t st, int agent0);
+                      hipStream_t st, int agent0, unsigned long long *counters = nullptr);
 int launch_corridor(const MapView &m, const SogmPlannerParams &pp, const CorridorWorkspace &ws,
                     int n_agents, const double *start_pva, const double *t_start,
                     const double *route, const int32_t *route_len, int route_cap,

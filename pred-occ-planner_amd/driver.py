@@ -213,4 +213,4 @@ class SwarmTick:
         self.own = merge_latest(self.new, self.own, self.ok)
         exchange_records(self.own, self.all, self.dist, self.world)
         self.tick += 1
-        return self.ok
+        return self.ok.clone()  # self.ok is rewritten by the next tick

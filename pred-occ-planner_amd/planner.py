@@ -49,6 +49,12 @@ class SogmPlanner:
         except Exception:
             pass
 
+    def counters(self, reset=False):
+        """Cumulative outcome / capacity counters of replan() (sogm_planner_counters) as a dict."""
+        out = (C.c_int64 * len(_abi.COUNTER_NAMES))()
+        check(lib().sogm_planner_counters(self._p, out, 1 if reset else 0), "sogm_planner_counters")
+        return dict(zip(_abi.COUNTER_NAMES, [int(v) for v in out]))
+
     # ---- FakeRiskHybridAstar::search + getPathWithVel ----
     def search(self, start_pva, goal, t_start, route_cap=64, trace_cap=0):
         A, dev = self.A, start_pva.device

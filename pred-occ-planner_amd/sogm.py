@@ -111,6 +111,13 @@ class SogmMap:
         check(lib().sogm_profile_read(self._ctx, out), "sogm_profile_read")
         return list(out)
 
+    def profile_read_all(self, slot, cap=1024):
+        """Durations (ms, oldest first) of every launch of `slot` since set_profiling(True) (last 1024 kept)."""
+        out = (C.c_double * cap)()
+        n = C.c_int(0)
+        check(lib().sogm_profile_read_all(self._ctx, slot, out, cap, C.byref(n)), "sogm_profile_read_all")
+        return [out[i] for i in range(n.value)]
+
     # ---- update ----
     def updateMap(self, cloud, cloud_range, cylinders, n_cyl, poses, stamps):
         """FakeParticleRiskVoxel::updateMap for every agent (device tensors)."""

@@ -39,3 +39,27 @@ def oracle_grids(pop, orc, spec, sc, recs):
             orc.project_neighbours(spec, g, recs, A, a, body, sc["poses"][a], sc["stamps"][a])
         out.append(g)
     return out
+
+
+def approaching_cylinder_scene(pop, gx, cy, vy):
+    """One agent at the origin (z = 1), goal `gx` metres ahead, one cylinder beside the goal at (gx, cy) moving
+    with velocity (0, vy): slice 0 and the later slices differ around the goal — the situation in which
+    FakeRiskHybridAstar's shot check (with time) and RiskHybridAstar's (slice 0) give different return codes."""
+    sc = pop.scene.make_scene(1, 4.95, seed=1, n_cyl=0)
+    sc["starts"][0] = (0, 0, 1)
+    sc["goals"][0] = (gx, 0, 1)
+    sc["poses"][0] = (0, 0, 1)
+    cyl = np.array([[gx, cy, 0.6, 0.0, vy]])
+    sc["cylinders"] = cyl
+    zs = np.arange(0, 40) * 0.1
+    x, y, w = cyl[0, :3]
+    r = w * 0.5
+    gxx, gyy = np.meshgrid(np.arange(int(np.floor((x - r) / 0.1)), int(np.ceil((x + r) / 0.1)) + 1) * 0.1,
+                           np.arange(int(np.floor((y - r) / 0.1)), int(np.ceil((y + r) / 0.1)) + 1) * 0.1,
+                           indexing="ij")
+    d = np.hypot(gxx - x, gyy - y)
+    m = (d <= r) & (d > r - 0.15)
+    sx, sy = gxx[m], gyy[m]
+    sc["cloud"] = np.ascontiguousarray(
+        np.stack([np.repeat(sx, zs.size), np.repeat(sy, zs.size), np.tile(zs, sx.size)], axis=1), np.float32)
+    return sc

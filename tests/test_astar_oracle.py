@@ -47,3 +47,26 @@ def test_free_space_reaches_time_horizon(pop, orc):
     # near the goal: the one-shot trajectory succeeds -> REACH_END
     w = orc.astar_search(spec, ap, g, pose, pva, np.array([0.1, 0, 1]), 0.05, 0.3)
     assert w["ret"] == 4
+
+
+SHOT_CASES = [(0, 0.9, 0.7, -1.5), (0, 0.9, 0.75, -2.0), (1, 1.2, 0.9, -2.0), (1, 0.9, 0.7, -3.0)]
+
+
+def test_shot_check_variants_differ(pop, orc):
+    """RiskHybridAstar checks the shot trajectory against slice 0 (risk_hybrid_a_star.cpp:514 ->
+    risk_base.cpp:251-253), FakeRiskHybridAstar against the slice of the shot-relative time
+    (fake_risk_hybrid_a_star.cpp:521): a cylinder closing in on the goal blocks the later slice only."""
+    from helpers import approaching_cylinder_scene
+    n_diff = 0
+    for kind, gx, cy, vy in SHOT_CASES:
+        spec = pop.config.make_spec("parity", map_kind=kind)
+        sc = approaching_cylinder_scene(pop, gx, cy, vy)
+        cyl = pop.scene.cylinders_to_struct(sc["cylinders"])
+        g = orc.update_gt(spec, sc["cloud"], cyl, 1, sc["poses"][0])
+        pva = np.concatenate([sc["starts"][0], np.zeros(6)])
+        w = [orc.astar_search(spec, pop.config.make_astar_params(fake), g, sc["poses"][0], pva, sc["goals"][0],
+                              0.05, 0.3) for fake in (True, False)]
+        assert w[0]["stats"] == w[1]["stats"]  # same expansions: only the shot check differs
+        n_diff += int(w[0]["ret"] != w[1]["ret"])
+        assert (w[0]["ret"], w[1]["ret"]) in ((5, 4), (4, 4), (5, 5))  # NEAR_END vs REACH_END
+    assert n_diff >= 2

@@ -1,5 +1,6 @@
-"""FiniteStateMachine bookkeeping (row f2): the tensorised state update of driver.fsm_apply against a direct
-per-agent transcription of the C++ switch (plan_manager/src/plan_manager.cpp:92-233); hover records; isTrajSafe."""
+"""FiniteStateMachine bookkeeping (row f2): the tensorised state update of driver.fsm_apply against the per-agent
+restatement of the C++ switch in oracle/fsm_oracle.cpp (plan_manager/src/plan_manager.cpp:92-233); hover
+records; isTrajSafe."""
 import importlib
 
 import numpy as np
@@ -7,41 +8,7 @@ import pytest
 import torch
 
 
-def _ref_tick(st, now, ok, safe, reached):
-    """One FSMCallback for one agent, written like the C++ switch.  st: dict(status, fail, traj_start, success).
-    Returns the publication of this tick: None / 'new' / ('hover', start_time)."""
-    d = importlib.import_module("pred-occ-planner_amd.driver")
-    pub = None
-    if st["status"] == d.FSM_NEW_PLAN:
-        if now - st["traj_start"] > 1.0:
-            st["traj_start"] = now
-            st["success"] = bool(ok)
-            pub = "new" if ok else ("hover", st["traj_start"])
-        if st["success"]:
-            st["status"] = d.FSM_EXEC_TRAJ
-    elif st["status"] == d.FSM_EXEC_TRAJ:
-        if now - st["traj_start"] > d.TICK_PERIOD:
-            st["status"] = d.FSM_REPLAN
-        if not safe:
-            st["status"] = d.FSM_REPLAN
-        if reached:
-            st["status"] = d.FSM_GOAL_REACHED
-    elif st["status"] == d.FSM_REPLAN:
-        st["traj_start"] = now + d.REPLAN_START_TIME
-        if ok:
-            st["fail"] = 0
-            pub = "new"
-            st["status"] = d.FSM_EXEC_TRAJ
-        else:
-            st["fail"] += 1
-            if st["fail"] > d.REPLAN_MAX_FAILURES:
-                st["status"] = d.FSM_NEW_PLAN
-                pub = ("hover", st["traj_start"])
-                st["traj_start"] = now - 1.0
-    return pub
-
-
-def test_fsm_apply_matches_switch(pop):
+def test_fsm_apply_matches_switch(pop, orc):
     d = importlib.import_module("pred-occ-planner_amd.driver")
     rng = np.random.default_rng(3)
     A, ticks = 64, 120
@@ -49,7 +16,7 @@ def test_fsm_apply_matches_switch(pop):
     fail = torch.zeros(A, dtype=torch.int32)
     success = torch.zeros(A, dtype=torch.bool)
     traj_start = torch.full((A,), 98.0, dtype=torch.float64)
-    ref = [dict(status=d.FSM_NEW_PLAN, fail=0, traj_start=98.0, success=False) for _ in range(A)]
+    ref = [orc.FsmOracle(98.0, d.TICK_PERIOD, d.REPLAN_START_TIME, d.REPLAN_MAX_FAILURES) for _ in range(A)]
     p_ok = rng.uniform(0.05, 0.95, A)  # some agents fail almost always -> hover records, NEW_PLAN retries
     seen = set()
     for k in range(ticks):
@@ -62,15 +29,15 @@ def test_fsm_apply_matches_switch(pop):
         status, fail, traj_start, success, pub_new, pub_hover, hover_start = d.fsm_apply(
             status, fail, traj_start, success, now, due_new, is_rep, ok & (due_new | is_rep), safe, reached)
         for a in range(A):
-            pub = _ref_tick(ref[a], now_f, bool(ok[a]), bool(safe[a]), bool(reached[a]))
-            assert int(status[a]) == ref[a]["status"], (k, a)
-            assert int(fail[a]) == ref[a]["fail"], (k, a)
-            assert float(traj_start[a]) == ref[a]["traj_start"], (k, a)
+            pub = ref[a].tick(now_f, bool(ok[a]), bool(safe[a]), bool(reached[a]))
+            assert int(status[a]) == ref[a].s.status, (k, a)
+            assert int(fail[a]) == ref[a].s.num_replan_failures, (k, a)
+            assert float(traj_start[a]) == ref[a].s.traj_start_time, (k, a)
             assert bool(pub_new[a]) == (pub == "new")
             assert bool(pub_hover[a]) == (isinstance(pub, tuple))
             if isinstance(pub, tuple):
                 assert float(hover_start[a]) == pub[1]
-            seen.add(ref[a]["status"])
+            seen.add(ref[a].s.status)
             if isinstance(pub, tuple):
                 seen.add("hover")
     assert {d.FSM_NEW_PLAN, d.FSM_EXEC_TRAJ, d.FSM_REPLAN, d.FSM_GOAL_REACHED, "hover"} <= seen
