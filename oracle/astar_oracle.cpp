@@ -426,9 +426,26 @@ struct Search {
 
 }  // namespace
 
+static std::vector<Node> g_last_pool;  // diagnostics: node pool of the last orc_astar_search
+
 extern "C" {
 
 void orc_astar_use_libm(int on) { orc_g_use_libm = on; }
+
+// diagnostics: rows {state[6], input[3], duration, time, g, f, index[3], time_idx, parent} = 18 doubles per node
+int orc_astar_debug_nodes(double *out, int n) {
+  int k = 0;
+  for (; k < n && k < (int)g_last_pool.size(); ++k) {
+    const Node &q = g_last_pool[k];
+    double     *o = out + (size_t)k * 18;
+    for (int i = 0; i < 6; ++i) o[i] = q.state[i];
+    for (int i = 0; i < 3; ++i) o[6 + i] = q.input[i];
+    o[9] = q.duration; o[10] = q.time; o[11] = q.g; o[12] = q.f;
+    for (int i = 0; i < 3; ++i) o[13 + i] = q.index[i];
+    o[16] = q.time_idx; o[17] = q.parent;
+  }
+  return k;
+}
 
 int orc_astar_search(const SogmSpec *s, const SogmAstarParams *ap, const float *grid,
                      const float pose[3], const double start_pva[9], const double goal[3],
@@ -460,6 +477,7 @@ int orc_astar_search(const SogmSpec *s, const SogmAstarParams *ap, const float *
     last = std::move(S);
     if (rst != NO_PATH) break;
   }
+  g_last_pool  = last.pool;
   out_stats[0] = last.use_node_num;
   out_stats[1] = last.iter_num;
   out_stats[2] = (int)last.node_path.size();

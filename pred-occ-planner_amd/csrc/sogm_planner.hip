@@ -246,6 +246,15 @@ int sogm_debug_astar_stats(sogm_planner *p, long long *out_host) {
   return SOGM_OK;
 }
 
+// diagnostics (tools/ only): raw 128-byte node records of one agent's last search
+int sogm_debug_astar_nodes(sogm_planner *p, int agent, void *out_host, int n) {
+  if (!p || !out_host || agent < 0 || agent >= p->map->n_agents || n < 0) return SOGM_ERR_INVALID_ARG;
+  SOGM_HIP_CHECK(hipDeviceSynchronize());
+  SOGM_HIP_CHECK(hipMemcpy(out_host, p->aw.pool + (size_t)agent * p->aw.pool_stride, (size_t)n * sogm::astar_node_bytes(),
+                           hipMemcpyDeviceToHost));
+  return SOGM_OK;
+}
+
 // diagnostics (tools/ only): copy the per-segment corridor counters to the host
 int sogm_debug_corridor_stats(sogm_planner *p, long long *out_host) {
   if (!p || !out_host) return SOGM_ERR_INVALID_ARG;

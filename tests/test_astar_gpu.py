@@ -79,7 +79,9 @@ def test_shot_check_variant_follows_planner_kind(pop, orc, fake):
                        sogm._dev(t_start, np.float64), route_cap=64, trace_cap=4096)
         out = {k: v.cpu().numpy() for k, v in out.items()}
         g = orc.update_gt(spec, sc["cloud"], pop.scene.cylinders_to_struct(sc["cylinders"]), 1, sc["poses"][0])
-        w = orc.astar_search(spec, ap, g, sc["poses"][0], pva[0], sc["goals"][0], 0.05, 0.3)
+        # the kernel sees t_start - stamp = (100 + 0.05) - 100, not the literal 0.05
+        w = orc.astar_search(spec, ap, g, sc["poses"][0], pva[0], sc["goals"][0],
+                             float(t_start[0] - sc["stamps"][0]), 0.3)
         assert out["ret"][0] == w["ret"] and list(out["stats"][0]) == w["stats"]
         assert np.array_equal(out["trace"][0, :w["trace_len"]], w["trace"])
         assert np.array_equal(out["route"][0, :len(w["route"])], w["route"])
