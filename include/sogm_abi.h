@@ -36,7 +36,8 @@ typedef enum sogm_status {
   SOGM_ERR_NO_DEVICE   = -2, /* no HIP device / HIP runtime error at create time             */
   SOGM_ERR_HIP         = -3, /* a HIP call failed; see sogm_last_error()                     */
   SOGM_ERR_CAPACITY    = -4, /* an output buffer / pool was too small                        */
-  SOGM_ERR_STATE       = -5  /* call order violated (e.g. query before any update)           */
+  SOGM_ERR_STATE       = -5, /* call order violated (e.g. query before any update)           */
+  SOGM_ERR_COMM        = -6  /* RCCL could not be loaded / a collective failed; see sogm_last_error() */
 } sogm_status;
 
 /* ------------------------------------------------------------------------------------------ */
@@ -562,6 +563,38 @@ int sogm_planner_counters(sogm_planner *p, int64_t *out_host, int reset);
 int sogm_replan(sogm_planner *p, const double *start_pva, const double *goal,
                 const double *t_start, const int32_t *drone_ids, SogmTrajRecord *out_records,
                 int32_t *out_ok, void *stream);
+
+/* ------------------------------------------------------------------------------------------ */
+/* trajectory exchange: the /broadcast_traj topic as ONE RCCL all-gather per replan tick          */
+/*   (plan_manager/src/plan_manager.cpp:364-399 publish, traj_coordinator/src/particles.cpp:131-191 receive)  */
+/* ------------------------------------------------------------------------------------------ */
+/*
+ * Agents are sharded over the GPUs of a node, one process per GPU; rank r owns a contiguous block of agents.
+ * After sogm_replan() (and the caller's latest-wins merge) every rank contributes the SogmTrajRecord of each of
+ * its n_local agents and receives the whole swarm's: all_records[r * n_local + i] = rank r's local_records[i].
+ * `nccl_comm` is an ncclComm_t (RCCL; <rccl/rccl.h>) whose ranks all call this with the same n_local.  RCCL is
+ * resolved with dlopen("librccl.so.1") the first time it is needed, so a host that already links RCCL (or runs
+ * PyTorch-ROCm) shares its instance and may pass a communicator of its own; sogm_comm_* creates one for hosts
+ * that do not have RCCL headers.
+ * The collective runs on an internal exchange stream: it starts when the work queued on `stream` so far is done
+ * and sogm_project_neighbours / sogm_replan (deconfliction) / sogm_safe_after_opt wait for it on their own stream,
+ * so the next tick's clear, stamp and trajectory sampling overlap with it.  A host that reads all_records by other
+ * means calls sogm_exchange_wait(ctx, its_stream) first.
+ * dev local_records [n_local], dev all_records [n_local * n_ranks].
+ */
+int sogm_traj_allgather(sogm_ctx *ctx, void *nccl_comm, const SogmTrajRecord *local_records, int n_local,
+                        SogmTrajRecord *all_records, void *stream);
+int sogm_exchange_wait(sogm_ctx *ctx, void *stream);
+
+/* Communicator helpers (thin wrappers of ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy).  Rank 0 makes
+ * an id and ships its 128 bytes to the other ranks by any out-of-band means (torch.distributed's store, MPI, a
+ * file); every rank then calls sogm_comm_create.  sogm_comm_handle returns the ncclComm_t to pass above. */
+#define SOGM_COMM_ID_BYTES 128
+typedef struct sogm_comm sogm_comm;
+int   sogm_comm_unique_id(char *out_id_host /* [SOGM_COMM_ID_BYTES] */);
+int   sogm_comm_create(const char *id_host, int rank, int n_ranks, int device, sogm_comm **out);
+void  sogm_comm_destroy(sogm_comm *comm);
+void *sogm_comm_handle(sogm_comm *comm);
 
 #ifdef __cplusplus
 }

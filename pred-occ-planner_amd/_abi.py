@@ -22,6 +22,8 @@ SOGM_ERR_NO_DEVICE = -2
 SOGM_ERR_HIP = -3
 SOGM_ERR_CAPACITY = -4
 SOGM_ERR_STATE = -5
+SOGM_ERR_COMM = -6
+SOGM_COMM_ID_BYTES = 128
 PROF_CLEAR, PROF_STAMP, PROF_SPLAT, PROF_ASTAR, PROF_CORRIDOR, PROF_QP, PROF_CLEAR_HEAD, PROF_N = range(8)
 
 COUNTER_NAMES = ("replan_ok", "fail_search", "fail_corridor", "fail_qp", "fail_unsafe", "corridor_capacity",
@@ -140,6 +142,12 @@ PROTOTYPES = {
     "sogm_safe_after_opt": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "sogm_planner_counters": (_i, [_vp, C.POINTER(C.c_int64), _i]),
     "sogm_planner_set_swarm": (_i, [_vp, _vp, _i, _vp, _vp]),
+    "sogm_traj_allgather": (_i, [_vp, _vp, _vp, _i, _vp, _vp]),
+    "sogm_exchange_wait": (_i, [_vp, _vp]),
+    "sogm_comm_unique_id": (_i, [C.c_char_p]),
+    "sogm_comm_create": (_i, [C.c_char_p, _i, _i, _i, C.POINTER(_vp)]),
+    "sogm_comm_destroy": (None, [_vp]),
+    "sogm_comm_handle": (_vp, [_vp]),
     "sogm_filter_point_cloud": (_i, [_vp, _vp, _vp, C.c_float, _i, _vp, _vp, _vp]),
     "sogm_filter_reserve": (_i, [_vp, _i]),
     "sogm_dsp_create": (_i, [_vp, C.POINTER(SogmDspParams), _vp, _vp, _i, _vp, _i, _i, C.POINTER(_vp)]),

@@ -275,6 +275,10 @@ struct sogm_ctx {
   void          *d_filter_box;
   int           *d_filter_blocks;
   int            filter_max_cells;
+  // trajectory exchange (sogm_traj_allgather): its own stream, ordered against producers / consumers by events
+  hipStream_t    xstream;
+  hipEvent_t     ev_xin, ev_xdone;
+  int            exchange_pending;
   int            profiling;
   // per-slot ring of HIP event pairs: every launch of a profiled kernel since profiling was enabled keeps its own
   // pair, so a run can be timed launch by launch WITHOUT synchronising between launches (sogm_profile_read_all)
@@ -318,6 +322,12 @@ inline MapView view_of(const sogm_ctx *c) {
   return m;
 }
 void set_error(const char *what, hipError_t e);
+void set_error_text(const char *text);
+// readers of the swarm's records wait (on their own stream) for an all-gather still in flight
+inline int join_exchange(sogm_ctx *c, hipStream_t st) {
+  if (c->exchange_pending && hipStreamWaitEvent(st, c->ev_xdone, 0) != hipSuccess) return SOGM_ERR_HIP;
+  return SOGM_OK;
+}
 int  launch_clear(sogm_ctx *c, hipStream_t st, float *grid = nullptr, bool polite = false, int part = 0,
                   size_t split = 0);
 size_t clear_vec4_total(const sogm_ctx *c);

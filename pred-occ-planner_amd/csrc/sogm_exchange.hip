@@ -1,0 +1,169 @@
+// sogm_exchange.hip — the per-tick trajectory exchange behind the C ABI: ONE RCCL all-gather over xGMI.
+//
+// Reference: every drone publishes its BezierTraj on /broadcast_traj after a successful replan
+// (FiniteStateMachine::publishTrajectory, plan_manager/src/plan_manager.cpp:364-399) and stores what the others
+// publish (ParticleATC::trajectoryCallback, traj_coordinator/src/particles.cpp:131-191; latest wins per drone_id).
+// Here agents are sharded over the GPUs of a node (SURVEY §8 e): every rank contributes the fixed-size records of
+// its agents and receives everybody's — ncclAllGather of n_local * sizeof(SogmTrajRecord) bytes per rank
+// (~264 KB at 128 agents per GPU), latency-bound; no other collective exists on this path.
+//
+// RCCL is resolved at run time (dlopen of librccl.so.1): a process that already carries RCCL (PyTorch-ROCm, or a
+// C++ host linked against it) shares that one instance, so an ncclComm_t created by the host can be passed in;
+// hosts without RCCL headers create the communicator through sogm_comm_* below.  The library itself has no
+// link-time dependency on RCCL and single-GPU users never load it.
+//
+// Ordering: the all-gather runs on the context's exchange stream.  It starts when the caller's stream has
+// produced the local records (an event recorded at call time: after sogm_replan's fan-in and the caller's
+// latest-wins merge) and it is consumed by whatever reads the swarm's records next — sogm_project_neighbours,
+// sogm_replan's deconfliction, sogm_safe_after_opt — which wait for its completion event on THEIR stream.  The next
+// tick's clear / stamp / trajectory sampling therefore overlap with the collective.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "sogm_device.hpp"
+
+namespace {
+
+struct RcclApi {
+  void *handle;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId *);
+  ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int);
+  ncclResult_t (*CommDestroy)(ncclComm_t);
+  ncclResult_t (*CommCount)(const ncclComm_t, int *);
+  ncclResult_t (*CommUserRank)(const ncclComm_t, int *);
+  ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t);
+  const char *(*GetErrorString)(ncclResult_t);
+};
+
+RcclApi *rccl() {
+  static RcclApi api;
+  static int     state = 0;  // 0 untried, 1 ok, -1 failed
+  if (state == 0) {
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char *n : names) {
+      api.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+      if (api.handle) break;
+    }
+    state = -1;
+    if (api.handle) {
+      api.GetUniqueId    = (decltype(api.GetUniqueId))dlsym(api.handle, "ncclGetUniqueId");
+      api.CommInitRank   = (decltype(api.CommInitRank))dlsym(api.handle, "ncclCommInitRank");
+      api.CommDestroy    = (decltype(api.CommDestroy))dlsym(api.handle, "ncclCommDestroy");
+      api.CommCount      = (decltype(api.CommCount))dlsym(api.handle, "ncclCommCount");
+      api.CommUserRank   = (decltype(api.CommUserRank))dlsym(api.handle, "ncclCommUserRank");
+      api.AllGather      = (decltype(api.AllGather))dlsym(api.handle, "ncclAllGather");
+      api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.handle, "ncclGetErrorString");
+      if (api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.CommCount && api.CommUserRank &&
+          api.AllGather && api.GetErrorString)
+        state = 1;
+    }
+  }
+  return state == 1 ? &api : nullptr;
+}
+
+int rccl_fail(const char *what, ncclResult_t r) {
+  RcclApi *a = rccl();
+  char     buf[384];
+  std::snprintf(buf, sizeof(buf), "%s: %s", what, a ? a->GetErrorString(r) : "RCCL not loaded");
+  sogm::set_error_text(buf);
+  return SOGM_ERR_COMM;
+}
+
+}  // namespace
+
+struct sogm_comm {
+  ncclComm_t comm;
+  int        rank, world, device;
+};
+
+extern "C" {
+
+int sogm_comm_unique_id(char *out_id_host) {
+  if (!out_id_host) return SOGM_ERR_INVALID_ARG;
+  RcclApi *a = rccl();
+  if (!a) {
+    sogm::set_error_text("sogm_comm_unique_id: librccl.so.1 could not be loaded");
+    return SOGM_ERR_COMM;
+  }
+  ncclUniqueId id;
+  ncclResult_t r = a->GetUniqueId(&id);
+  if (r != ncclSuccess) return rccl_fail("ncclGetUniqueId", r);
+  static_assert(sizeof(id) == SOGM_COMM_ID_BYTES, "ncclUniqueId size");
+  std::memcpy(out_id_host, &id, sizeof(id));
+  return SOGM_OK;
+}
+
+int sogm_comm_create(const char *id_host, int rank, int world, int device, sogm_comm **out) {
+  if (!id_host || !out || world < 1 || rank < 0 || rank >= world) return SOGM_ERR_INVALID_ARG;
+  *out       = nullptr;
+  RcclApi *a = rccl();
+  if (!a) {
+    sogm::set_error_text("sogm_comm_create: librccl.so.1 could not be loaded");
+    return SOGM_ERR_COMM;
+  }
+  if (hipSetDevice(device) != hipSuccess) return SOGM_ERR_NO_DEVICE;
+  sogm_comm *c = new (std::nothrow) sogm_comm();
+  if (!c) return SOGM_ERR_INVALID_ARG;
+  c->rank   = rank;
+  c->world  = world;
+  c->device = device;
+  ncclUniqueId id;
+  std::memcpy(&id, id_host, sizeof(id));
+  ncclResult_t r = a->CommInitRank(&c->comm, world, id, rank);
+  if (r != ncclSuccess) {
+    delete c;
+    return rccl_fail("ncclCommInitRank", r);
+  }
+  *out = c;
+  return SOGM_OK;
+}
+
+void sogm_comm_destroy(sogm_comm *c) {
+  if (!c) return;
+  RcclApi *a = rccl();
+  if (a && c->comm) {
+    (void)hipSetDevice(c->device);
+    (void)a->CommDestroy(c->comm);
+  }
+  delete c;
+}
+
+void *sogm_comm_handle(sogm_comm *c) { return c ? (void *)c->comm : nullptr; }
+
+int sogm_traj_allgather(sogm_ctx *ctx, void *nccl_comm, const SogmTrajRecord *local_records, int n_local,
+                        SogmTrajRecord *all_records, void *stream) {
+  if (!ctx || !nccl_comm || !local_records || !all_records || n_local <= 0) return SOGM_ERR_INVALID_ARG;
+  RcclApi *a = rccl();
+  if (!a) {
+    sogm::set_error_text("sogm_traj_allgather: librccl.so.1 could not be loaded");
+    return SOGM_ERR_COMM;
+  }
+  SOGM_HIP_CHECK(hipSetDevice(ctx->device));
+  if (!ctx->xstream) {
+    SOGM_HIP_CHECK(hipStreamCreateWithFlags(&ctx->xstream, hipStreamNonBlocking));
+    SOGM_HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_xin, hipEventDisableTiming));
+    SOGM_HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_xdone, hipEventDisableTiming));
+  }
+  // the local records are final once everything queued on the caller's stream so far has run; every earlier
+  // reader of all_records was queued on (or joined to) that stream as well
+  SOGM_HIP_CHECK(hipEventRecord(ctx->ev_xin, (hipStream_t)stream));
+  SOGM_HIP_CHECK(hipStreamWaitEvent(ctx->xstream, ctx->ev_xin, 0));
+  ncclResult_t r = a->AllGather(local_records, all_records, (size_t)n_local * sizeof(SogmTrajRecord), ncclUint8,
+                                (ncclComm_t)nccl_comm, ctx->xstream);
+  if (r != ncclSuccess) return rccl_fail("ncclAllGather", r);
+  SOGM_HIP_CHECK(hipEventRecord(ctx->ev_xdone, ctx->xstream));
+  ctx->exchange_pending = 1;
+  return SOGM_OK;
+}
+
+int sogm_exchange_wait(sogm_ctx *ctx, void *stream) {
+  if (!ctx) return SOGM_ERR_INVALID_ARG;
+  return sogm::join_exchange(ctx, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -26,6 +26,7 @@ static thread_local char g_err[512] = {0};
 void set_error(const char *what, hipError_t e) {
   std::snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
 }
+void set_error_text(const char *text) { std::snprintf(g_err, sizeof(g_err), "%s", text); }
 
 // ------------------------------------------------------------------------------------------------
 // clear
@@ -675,6 +676,12 @@ void sogm_destroy(sogm_ctx *c) {
   }
   if (c->ev_grid_free) (void)hipEventDestroy(c->ev_grid_free);
   if (c->ev_cleared) (void)hipEventDestroy(c->ev_cleared);
+  if (c->xstream) {
+    (void)hipStreamSynchronize(c->xstream);
+    (void)hipStreamDestroy(c->xstream);
+  }
+  if (c->ev_xin) (void)hipEventDestroy(c->ev_xin);
+  if (c->ev_xdone) (void)hipEventDestroy(c->ev_xdone);
   for (int k = 0; k < SOGM_PROF_N; ++k) {
     if (c->ring[k]) {
       for (int i = 0; i < 2 * SOGM_PROF_RING; ++i)
@@ -804,6 +811,7 @@ int sogm_project_neighbours(sogm_ctx *c, const SogmTrajRecord *records, int n_re
   if (!c->d_body || c->n_body <= 0) return SOGM_ERR_STATE;
   if (n_records == 0) return SOGM_OK;
   SOGM_HIP_CHECK(hipSetDevice(c->device));
+  if (int rc = sogm::join_exchange(c, (hipStream_t)stream)) return rc;  // records may come from an all-gather in flight
   const long long total = (long long)c->n_agents * n_records * c->spec.T;
   const int       nblk  = (int)((total + 255) / 256);
   prof_begin(c, SOGM_PROF_SPLAT, (hipStream_t)stream);

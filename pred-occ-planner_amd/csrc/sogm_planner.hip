@@ -289,6 +289,7 @@ int sogm_safe_after_opt(sogm_planner *p, const double *cpts, const int32_t *npol
   if (!p || !cpts || !npoly || !ego_ids || !t_now || !out_safe || n_records < 0 || (n_records > 0 && !records))
     return SOGM_ERR_INVALID_ARG;
   SOGM_HIP_CHECK(hipSetDevice(p->map->device));
+  if (int rc = sogm::join_exchange(p->map, (hipStream_t)stream)) return rc;
   if (sogm::launch_deconflict(p->map->n_agents, cpts, npoly, records, n_records, ego_ids, t_now, out_safe,
                               (hipStream_t)stream, 0) != 0) {
     sogm::set_error("sogm_safe_after_opt", hipGetLastError());
@@ -323,6 +324,9 @@ static int replan_impl(sogm_planner *p, const double *start_pva, const double *g
   hipStream_t main = (hipStream_t)stream;
   const int   A = c->n_agents, G = p->n_groups;
   const MapView mv = view_of(c);
+  // the swarm's records (deconfliction) may come from an all-gather still in flight on the exchange stream
+  if (p->swarm)
+    if (int rc = sogm::join_exchange(c, main)) return rc;
   // fan out: every group stream starts when the caller's stream has produced the inputs
   SOGM_HIP_CHECK(hipEventRecord(p->ev_in, main));
   if (c->overlap == 2 && c->d_grid_alt) {

@@ -45,6 +45,62 @@ def exchange_records(own, all_records, dist, world):
     return all_records
 
 
+class RecordExchange:
+    """The same all-gather behind the C ABI (sogm_traj_allgather: ncclAllGather on the context's exchange
+    stream, consumers wait for it inside the library) — what a C++ host linking libsogm_hip.so uses.  Taken when
+    torch.distributed runs on RCCL (backend "nccl"); the communicator is created through sogm_comm_* with the
+    128-byte id shipped through torch.distributed's key-value store.  Anything else (gloo on CPU tests, no
+    process group, RCCL unavailable) uses exchange_records() above."""
+    _serial = 0
+
+    def __init__(self, sogm_map, dist, rank, world, device):
+        import ctypes as C
+        import sys
+        self.map, self.comm, self.handle = sogm_map, C.c_void_p(), None
+        use = (dist is not None and dist.is_initialized() and dist.get_backend() == "nccl"
+               and os.environ.get("SOGM_EXCHANGE", "abi") == "abi")
+        if not use:
+            return
+        lib = _abi.lib()
+        key = f"sogm_comm_id/{RecordExchange._serial}"
+        RecordExchange._serial += 1
+        try:
+            store = dist.distributed_c10d._get_default_store()
+            if rank == 0:
+                buf = C.create_string_buffer(_abi.SOGM_COMM_ID_BYTES)
+                _abi.check(lib.sogm_comm_unique_id(buf), "sogm_comm_unique_id")
+                store.set(key, buf.raw)
+                ident = buf.raw
+            else:
+                ident = bytes(store.get(key))
+            _abi.check(lib.sogm_comm_create(ident, rank, world, device, C.byref(self.comm)), "sogm_comm_create")
+            self.handle = lib.sogm_comm_handle(self.comm)
+        except Exception as e:  # noqa: BLE001 — any failure here only changes which RCCL entry point is used
+            print(f"[sogm] RCCL communicator through the C ABI unavailable ({e}); using torch.distributed's", file=sys.stderr)
+            self.comm, self.handle = C.c_void_p(), None
+
+    @property
+    def active(self):
+        return self.handle is not None
+
+    def all_gather(self, own, all_records):
+        from .sogm import _stream
+        _abi.check(_abi.lib().sogm_traj_allgather(self.map.ctx, self.handle, own.data_ptr(), own.shape[0],
+                                                  all_records.data_ptr(), _stream()), "sogm_traj_allgather")
+
+    def wait(self):
+        """Make torch's current stream wait for an all-gather in flight (before torch ops read the records)."""
+        from .sogm import _stream
+        _abi.check(_abi.lib().sogm_exchange_wait(self.map.ctx, _stream()), "sogm_exchange_wait")
+
+    def close(self):
+        if self.comm:
+            torch.cuda.synchronize()
+            _abi.lib().sogm_comm_destroy(self.comm)
+            self.comm = None
+            self.handle = None
+
+
 def merge_latest(new, old, ok):
     """latest-wins per drone (particles.cpp:179-190); a failed replan keeps the previous trajectory
     (the FSM keeps executing it, plan_manager.cpp:176-196)."""
@@ -160,10 +216,26 @@ class SwarmTick:
         self.t0 = float(self.scene["stamps"][0])
         self.tick = 0
         self.n_ok_total = 0
+        self.exchange = RecordExchange(self.map, dist, rank, world, device)
 
     def close(self):
+        self.exchange.close()
         self.planner.close()
         self.map.close()
+
+    def _exchange(self):
+        """The tick's trajectory broadcast: one RCCL all-gather (behind the C ABI when available)."""
+        if self.exchange.active:
+            self.own = self.own.contiguous()
+            self.exchange.all_gather(self.own, self.all)
+        else:
+            exchange_records(self.own, self.all, self.dist, self.world)
+
+    def records_all(self):
+        """The swarm's latest records for torch-side readers (waits for an all-gather in flight)."""
+        if self.exchange.active:
+            self.exchange.wait()
+        return self.all
 
     def step_fsm(self):
         """One FSM tick (plan_manager.cpp:92-233) for every agent: NEW_PLAN / REPLAN agents plan, EXEC_TRAJ
@@ -189,7 +261,7 @@ class SwarmTick:
             self.status, self.fail, self.traj_start, self.success, now, due_new, is_rep, ok, safe, reached)
         hover = hover_records(self.dev["ego_ids"], hover_start, pva_now[:, :3])
         self.own = torch.where(pub_new.unsqueeze(1), self.new, torch.where(pub_hover.unsqueeze(1), hover, self.own))
-        exchange_records(self.own, self.all, self.dist, self.world)
+        self._exchange()
         self.tick += 1
         return ok.to(torch.int32)
 
@@ -211,6 +283,6 @@ class SwarmTick:
         self.planner.replan(pva.contiguous(), self.goals, t_start, self.dev["ego_ids"], self.new, self.ok)
         # latest-wins; a failed replan keeps executing the previous trajectory
         self.own = merge_latest(self.new, self.own, self.ok)
-        exchange_records(self.own, self.all, self.dist, self.world)
+        self._exchange()
         self.tick += 1
         return self.ok.clone()  # self.ok is rewritten by the next tick

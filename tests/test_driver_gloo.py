@@ -66,6 +66,86 @@ def test_world2_gloo_allgather_and_sharding():
     assert out[0] and out[1]
 
 
+def _closed_loop(rank, world, A_loc, ticks, dist_mod):
+    """3 ticks of merge_latest -> exchange -> next-tick overlay for the agents of `rank`, with the CPU oracle standing
+    in for the GPU kernels (tests may use it): per agent SOGM build + neighbour overlay from the EXCHANGED records,
+    oracle replan, latest-wins merge, one all-gather.  Returns (overlay checksums per tick, final records)."""
+    pop = importlib.import_module("pred-occ-planner_amd")
+    drv = importlib.import_module("pred-occ-planner_amd.driver")
+    orc = importlib.import_module("oracle.binding")
+    abi = pop._abi
+    spec = pop.config.make_spec("parity")
+    ap, pp, qs = pop.config.make_astar_params(), pop.config.make_planner_params(True), pop.config.make_qp_settings()
+    A_tot = A_loc * world
+    sc = pop.scene.make_scene(A_tot, 4.95, seed=23, circle_radius=2.5, n_cyl=30)
+    cyl = pop.scene.cylinders_to_struct(sc["cylinders"])
+    body = pop.scene.body_particles()
+    lo, hi = drv.shard_bounds(rank, world, A_loc)
+    own = torch.zeros((A_loc, abi.TRAJ_RECORD_BYTES), dtype=torch.uint8)
+    allr = torch.zeros((A_tot, abi.TRAJ_RECORD_BYTES), dtype=torch.uint8)
+    pos = sc["starts"][lo:hi].copy()
+    sums, n_ok = [], 0
+    for tick in range(ticks):
+        stamp = 100.0 + tick * drv.TICK_PERIOD
+        t_start = stamp + drv.REPLAN_START_TIME
+        recs = (abi.SogmTrajRecord * A_tot).from_buffer_copy(allr.numpy().tobytes())
+        new = torch.zeros_like(own)
+        ok = torch.zeros(A_loc, dtype=torch.int32)
+        for i in range(A_loc):
+            a = lo + i
+            mine = (abi.SogmTrajRecord * 1).from_buffer_copy(own[i].numpy().tobytes())[0]
+            pva = np.concatenate([pos[i], np.zeros(6)])
+            if mine.n_pieces > 0:  # replan start state from the executed trajectory (plan_manager.cpp:169-175)
+                d = np.array(mine.duration[:mine.n_pieces])
+                c = np.array(mine.cpts[:15 * mine.n_pieces]).reshape(-1, 3)
+                tt = min(max(t_start - mine.time_start, 0.0), d.sum())
+                pva = np.concatenate([orc.bezier_eval(d, c, tt, k) for k in range(3)])
+                pos[i] = pva[:3]
+            pose = pos[i].astype(np.float32)
+            g = orc.update_gt(spec, sc["cloud"], cyl, len(sc["cylinders"]), pose)
+            orc.project_neighbours(spec, g, recs, A_tot, a, body, pose, stamp)  # overlay of the exchanged records
+            sums.append((tick, a, float(g.sum()), int(np.flatnonzero(g.ravel()).sum() % 1000003)))
+            okk, rec, _ = orc.replan(spec, ap, pp, qs, g, pose, stamp, pva, sc["goals"][a], t_start, a)
+            ok[i] = int(okk)
+            new[i] = torch.from_numpy(np.frombuffer(bytes(rec), dtype=np.uint8).copy())
+        n_ok += int(ok.sum())
+        own = drv.merge_latest(new, own, ok)
+        drv.exchange_records(own, allr, dist_mod, world)
+    return sums, allr.numpy().copy(), n_ok
+
+
+def _worker_loop(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sums, allr, n_ok = _closed_loop(rank, world, 2, 3, dist)
+    out[rank] = (sums, allr.tobytes(), n_ok)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world2_closed_loop_matches_single_process():
+    """The N>1 data flow end to end (SURVEY §8 e): two ranks x 2 agents over gloo for 3 ticks against ONE process
+    running all 4 agents — every rank-local neighbour overlay (built from the all-gathered records, one tick stale
+    like the ROS broadcast) and the final record table must be identical."""
+    sys.path.insert(0, ROOT)
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker_loop, args=(world, _free_port(), out), nprocs=world, join=True)
+    ref_sums, ref_all, ref_ok = _closed_loop(0, 1, 4, 3, None)
+    got_sums = sorted(out[0][0] + out[1][0])
+    assert got_sums == sorted(ref_sums)
+    assert out[0][1] == out[1][1] == ref_all.tobytes()   # both ranks hold the same, complete table
+    assert out[0][2] + out[1][2] == ref_ok and ref_ok >= 6
+    # the overlay did see the neighbours: from tick 1 on the grids hold more than the obstacle marks of tick 0
+    by_agent = {}
+    for tick, a, s_, _h in ref_sums:
+        by_agent.setdefault(a, []).append(s_)
+    assert any(v[1] != v[0] for v in by_agent.values())
+
+
 def test_shard_bounds_partition_agents():
     pop = importlib.import_module("pred-occ-planner_amd")
     drv = importlib.import_module("pred-occ-planner_amd.driver")
