@@ -103,7 +103,8 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
     A_loc = args.agents if args.agents is not None else pop.config.AGENTS[args.grid]
     sw = driver.SwarmTick(args.grid, A_loc, rank, world, local, dist=dist, deconflict=not args.no_deconflict,
-                          double_buffer={"0": False, "1": True}.get(os.environ.get("SOGM_DOUBLE_BUFFER")))
+                          double_buffer={"0": False, "1": True}.get(os.environ.get("SOGM_DOUBLE_BUFFER")),
+                          grids=int(os.environ["SOGM_GRIDS"]) if os.environ.get("SOGM_GRIDS") else None)
     spec = sw.spec
 
     def barrier():
@@ -202,7 +203,7 @@ def main():
                    # where the timed replans ended + capacity limits hit (sogm_planner_counters)
                    "outcomes": outcomes,
                    "parallelism": f"agents sharded x{world}, 1 all-gather/tick",
-                   "sogm_grids_per_agent": 2 if overlap_mode == 2 else 1},
+                   "sogm_grids_per_agent": overlap_mode if overlap_mode >= 2 else 1},
         "replans_per_s_per_agent": sw.A_tot * args.steps / dt / sw.A_tot,
         "stage_ms": {"clear": avg[0], "stamp": avg[1], "splat": avg[2], "astar": avg[3], "corridor": avg[4],
                      "qp": avg[5]},
@@ -221,7 +222,7 @@ def main():
     if args.sustained > 0:
         # sustained flight: the 20-step figure covers the first seconds (agents still far apart); keep flying —
         # the swarm converges on the centre, searches get longer — and time every tick (host-synchronised)
-        sw.map.set_overlap_clear(overlap_mode != 0, double_buffer=(overlap_mode == 2))
+        sw.map.set_overlap_clear(overlap_mode != 0, grids=(overlap_mode if overlap_mode >= 2 else 1))
         sw.map.set_profiling(False)
         sw.planner.counters(reset=True)
         tick_ms, oks2 = [], []

@@ -552,6 +552,11 @@ enum {
   SOGM_CNT_N                   = 8
 };
 int sogm_planner_counters(sogm_planner *p, int64_t *out_host, int reset);
+/* sogm_replan() chains its kernels per agent through device-side ready lists ("dataflow replan");
+ * a wait that exceeds 3 s marks the tick as failed instead of hanging the GPU.  Synchronises the device and
+ * returns 0 if the last sogm_replan() completed normally, a positive code if one of its waits timed out (the
+ * affected agents then report ok = 0 / stale records), negative = sogm_status. */
+int sogm_planner_flow_error(sogm_planner *p);
 
 /*
  * One full FakeBaselinePlanner::replan (baseline_fake.cpp:266-472; isSafeAfterOpt only when a swarm has

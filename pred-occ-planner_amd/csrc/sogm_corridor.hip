@@ -1031,14 +1031,13 @@ __device__ inline void segment_box(const SogmPlannerParams &pp, const double *sp
 // 1024 cells per workgroup step), and an order-preserving wave scan + cross-wave offsets keep the reference's
 // point order (x fastest, then y, z; a cell's time slices in ascending order).
 // =================================================================================================
-__global__ __launch_bounds__(256) void k_corridor_points(MapView m, SogmPlannerParams pp, CorridorWorkspace ws,
-                                                        const double *__restrict__ start_pva,
-                                                        const double *__restrict__ t_start,
-                                                        const double *__restrict__ route,
-                                                        const int32_t *__restrict__ route_len, int route_cap,
-                                                        int agent0) {
-  const int seg   = blockIdx.x;
-  const int agent = blockIdx.y + agent0;
+// NW = waves of the calling workgroup (4: k_corridor_points; 1: the dataflow kernel, where the segment's own wave
+// extracts its points).  Same cells, same order, same output for either.
+template <int NW>
+__device__ __forceinline__ void corridor_points_body(const MapView &m, const SogmPlannerParams &pp,
+                                                     const CorridorWorkspace &ws, const double *start_pva,
+                                                     const double *t_start, const double *route,
+                                                     const int32_t *route_len, int route_cap, int agent, int seg) {
   const int tid   = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int rl    = route_len[agent];
   const int slot  = agent * SOGM_MAX_PIECES + seg;
@@ -1081,7 +1080,7 @@ __global__ __launch_bounds__(256) void k_corridor_points(MapView m, SogmPlannerP
       const int   cells = nx * ny * nz;
       const void *grid0 = m.slab(agent, 0);
       int         base  = 0;
-      for (int c0 = 0; c0 < cells; c0 += 1024) {
+      for (int c0 = 0; c0 < cells; c0 += 256 * NW) {
         int      cnt[4], vi[4];
         unsigned mask[4];
 #pragma unroll
@@ -1115,7 +1114,7 @@ __global__ __launch_bounds__(256) void k_corridor_points(MapView m, SogmPlannerP
         __syncthreads();
         int woff = 0, total = 0;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
+        for (int w = 0; w < NW; ++w) {
           const int t = s_wtot[w];
           woff += w < wave ? t : 0;
           total += t;
@@ -1145,18 +1144,27 @@ __global__ __launch_bounds__(256) void k_corridor_points(MapView m, SogmPlannerP
   if (tid == 0) ws.seg_npts[slot] = N;
 }
 
+__global__ __launch_bounds__(256) void k_corridor_points(MapView m, SogmPlannerParams pp, CorridorWorkspace ws,
+                                                        const double *__restrict__ start_pva,
+                                                        const double *__restrict__ t_start,
+                                                        const double *__restrict__ route,
+                                                        const int32_t *__restrict__ route_len, int route_cap,
+                                                        int agent0) {
+  corridor_points_body<4>(m, pp, ws, start_pva, t_start, route, route_len, route_cap, blockIdx.y + agent0,
+                          blockIdx.x);
+}
+
 namespace {
 }  // namespace
 
 // =================================================================================================
 // Kernel A: one workgroup per (segment, agent)
 // =================================================================================================
-__global__ __launch_bounds__(64) void k_corridor_segment(
-    MapView m, SogmPlannerParams pp, CorridorWorkspace ws, const double *__restrict__ start_pva,
-    const double *__restrict__ t_start, const double *__restrict__ route,
-    const int32_t *__restrict__ route_len, int route_cap, int agent0) {
-  const int seg   = blockIdx.x;
-  const int agent = blockIdx.y + agent0;
+__device__ __forceinline__ void corridor_segment_body(const MapView &m, const SogmPlannerParams &pp,
+                                                      const CorridorWorkspace &ws, const double *start_pva,
+                                                      const double *t_start, const double *route,
+                                                      const int32_t *route_len, int route_cap, int agent, int seg,
+                                                      char *smem) {
   const int lane  = threadIdx.x;
   const int rl    = route_len[agent];
   const int slot  = agent * SOGM_MAX_PIECES + seg;
@@ -1164,7 +1172,6 @@ __global__ __launch_bounds__(64) void k_corridor_segment(
     if (lane == 0) ws.seg_state[slot] = -2;  // no such segment
     return;
   }
-  extern __shared__ __attribute__((aligned(16))) char smem[];
   double        *s_lp    = (double *)smem;                    // LP_WORK_DOUBLES
   double        *s_rows  = s_lp + LP_WORK_DOUBLES;            // LP_MAX_ROWS * 5
   double        *s_lm    = s_rows + LP_MAX_ROWS * 5;          // 324 history + 16 hand-off + 36 alpha/ys
@@ -1460,20 +1467,23 @@ __global__ __launch_bounds__(64) void k_corridor_segment(
   }
 }
 
+__global__ __launch_bounds__(64) void k_corridor_segment(
+    MapView m, SogmPlannerParams pp, CorridorWorkspace ws, const double *__restrict__ start_pva,
+    const double *__restrict__ t_start, const double *__restrict__ route,
+    const int32_t *__restrict__ route_len, int route_cap, int agent0) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  corridor_segment_body(m, pp, ws, start_pva, t_start, route, route_len, route_cap, blockIdx.y + agent0, blockIdx.x,
+                        smem);
+}
+
 // =================================================================================================
 // Kernel B: per agent bookkeeping (baseline_fake.cpp:364-414 / baseline.cpp:362-403)
 // =================================================================================================
-__global__ __launch_bounds__(64) void k_corridor_finalize(
-    SogmPlannerParams pp, CorridorWorkspace ws, const double *__restrict__ start_pva,
-    const double *__restrict__ route, const int32_t *__restrict__ route_len, int route_cap,
-    double *__restrict__ out_polys, int32_t *__restrict__ out_nfaces,
-    int32_t *__restrict__ out_npoly, double *__restrict__ out_goal, int agent0) {
-  const int agent = blockIdx.x + agent0;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  double       *s_lp   = (double *)smem;
-  double       *s_rows = s_lp + LP_WORK_DOUBLES;
-  int          *s_perm = (int *)(s_rows + LP_MAX_ROWS * 5);
-  SolverScratch sc{s_lp, s_perm, s_rows, nullptr};
+__device__ __forceinline__ void corridor_finalize_body(const SogmPlannerParams &pp, const CorridorWorkspace &ws,
+                                                       const double *start_pva, const double *route,
+                                                       const int32_t *route_len, int route_cap, double *out_polys,
+                                                       int32_t *out_nfaces, int32_t *out_npoly, double *out_goal,
+                                                       int agent, const SolverScratch &sc) {
   // The sequential bookkeeping below is executed by all 64 lanes with identical data (uniform control flow);
   // the LPs inside are solved by the whole wave, outputs are written by lane 0 / copied lane-parallel.
   const bool    w0    = threadIdx.x == 0;
@@ -1551,6 +1561,95 @@ __global__ __launch_bounds__(64) void k_corridor_finalize(
   }
 }
 
+__global__ __launch_bounds__(64) void k_corridor_finalize(
+    SogmPlannerParams pp, CorridorWorkspace ws, const double *__restrict__ start_pva,
+    const double *__restrict__ route, const int32_t *__restrict__ route_len, int route_cap,
+    double *__restrict__ out_polys, int32_t *__restrict__ out_nfaces,
+    int32_t *__restrict__ out_npoly, double *__restrict__ out_goal, int agent0) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double       *s_lp   = (double *)smem;
+  double       *s_rows = s_lp + LP_WORK_DOUBLES;
+  int          *s_perm = (int *)(s_rows + LP_MAX_ROWS * 5);
+  SolverScratch sc{s_lp, s_perm, s_rows, nullptr};
+  corridor_finalize_body(pp, ws, start_pva, route, route_len, route_cap, out_polys, out_nfaces, out_npoly, out_goal,
+                         blockIdx.x + agent0, sc);
+}
+
+// =================================================================================================
+// Dataflow kernel C (sogm_replan, pipelining modes 0 / 2 / 3): ONE persistent launch for the whole corridor stage.
+// A workgroup (one wave) takes tickets; ticket k is segment k % 16 of the (k / 16)-th agent whose A* search has
+// finished (k_astar publishes agents in completion order), so an agent's corridors start the moment ITS search is
+// done — not when the slowest search of a group is.  The wave extracts the segment's obstacle points itself, runs
+// FIRI / MVIE / shrink / validity, and the wave that completes an agent's last segment does the per-agent
+// bookkeeping (adjacent intersections, goal projection) and publishes the agent to the QP kernel's ready list.
+// Waiting is a bounded spin (s_sleep polling of one word); a timeout raises FlowCtl::err and every kernel of the
+// tick drains.
+// =================================================================================================
+// Called by ALL lanes of a wave (uniform control flow; every value that steers a branch goes through
+// readfirstlane so that the compiler sees a scalar condition): returns the published value, or -1 on failure.
+__device__ inline int flow_wait_slot(int *slot, int *err) {
+  const long long t0 = wall_clock64();
+  for (;;) {
+    const int v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(slot, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT));
+    if (v >= 0) return v;
+    __builtin_amdgcn_s_sleep(32);
+    if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0)
+      return -1;
+    if (wall_clock64() - t0 > FLOW_TIMEOUT_TICKS) {
+      if ((threadIdx.x & 63) == 0) atomicExch(err, 2);
+      return -1;
+    }
+  }
+}
+__device__ inline int flow_ticket(int *counter) {  // one ticket per wave, uniform
+  int k = 0;
+  if ((threadIdx.x & 63) == 0) k = atomicAdd(counter, 1);
+  return __builtin_amdgcn_readfirstlane(k);
+}
+
+__global__ __launch_bounds__(64) void k_corridor_flow(MapView m, SogmPlannerParams pp, CorridorWorkspace ws,
+                                                      FlowCtl fc, const double *start_pva, const double *t_start,
+                                                      const double *route, const int32_t *route_len,
+                                                      int route_cap, double *out_polys, int32_t *out_nfaces,
+                                                      int32_t *out_npoly, double *out_goal, int n_agents) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane  = threadIdx.x;
+  const int total = n_agents * SOGM_MAX_PIECES;
+  for (;;) {
+    const int k = flow_ticket(&fc.hdr[FLOW_C_TICKET]);
+    if (k >= total) break;
+    const int agent = flow_wait_slot(fc.a_ready + k / SOGM_MAX_PIECES, &fc.hdr[FLOW_ERR]);
+    if (agent < 0) break;  // timed out / another kernel failed: drain
+    __threadfence();        // the search's outputs (route, route_len) were published before the ready slot
+    const int seg = k % SOGM_MAX_PIECES;
+    if (seg < route_len[agent] - 1) {
+      corridor_points_body<1>(m, pp, ws, start_pva, t_start, route, route_len, route_cap, agent, seg);
+      __threadfence_block();
+      __syncthreads();
+    }
+    corridor_segment_body(m, pp, ws, start_pva, t_start, route, route_len, route_cap, agent, seg, smem);
+    __syncthreads();
+    __threadfence();  // this segment's polytope is visible before its completion is counted
+    const int last = flow_ticket(&fc.seg_done[agent]) == SOGM_MAX_PIECES - 1;
+    if (last) {
+      __threadfence();  // the other segments' polytopes (their completions were counted before ours)
+      double       *s_lp   = (double *)smem;
+      double       *s_rows = s_lp + LP_WORK_DOUBLES;
+      int          *s_perm = (int *)(s_rows + LP_MAX_ROWS * 5);  // the head of s_lm: free between segments
+      SolverScratch sc{s_lp, s_perm, s_rows, nullptr};
+      corridor_finalize_body(pp, ws, start_pva, route, route_len, route_cap, out_polys, out_nfaces, out_npoly,
+                             out_goal, agent, sc);
+      __syncthreads();
+      __threadfence();
+      if (lane == 0) {
+        const int r = atomicAdd(&fc.hdr[FLOW_Q_READY_N], 1);
+        __hip_atomic_store(fc.q_ready + r, agent, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    __syncthreads();
+  }
+}
+
 size_t corridor_segment_lds(int pc_capacity) {
   return sizeof(double) * (LP_WORK_DOUBLES + LP_MAX_ROWS * 5 + 2 * 18 * 9 + 16 + 36 + 2 * FIRI_MAX_H * 4 + 96) +
          sizeof(int) * (LP_MAX_ROWS + 16) + (size_t)pc_capacity;
@@ -1566,26 +1665,16 @@ size_t corridor_segment_lds(int pc_capacity) {
 // as "-inf", GLPK's affine model calls that infeasible; with the box the result is finite or +inf.
 // ------------------------------------------------------------------------------------------------
 #define DECONFLICT_MAX_ROWS (LP_MAX_ROWS - 9)  // 144 point rows + 8 box rows + sdlp's plane 0
-__global__ __launch_bounds__(64) void k_safe_after_opt(const double *__restrict__ cpts,
-                                                       const int32_t *__restrict__ npoly,
-                                                       const SogmTrajRecord *__restrict__ rec, int n_rec,
-                                                       const int32_t *__restrict__ ego_ids,
-                                                       const double *__restrict__ t_now,
-                                                       int32_t *__restrict__ out_safe, int agent0,
+// One (new trajectory of agent a, record r) pair, executed by one wave: true = NOT separable (unsafe).
+// ca: the agent's 5 M control points; s_lp / s_rows / s_perm: the wave's LP scratch in LDS.
+__device__ __forceinline__ bool deconflict_pair_unsafe(const double *ca, int M, const SogmTrajRecord &r, int ego_id,
+                                                       double now, double *s_lp, double *s_rows, int *s_perm,
                                                        unsigned long long *counters) {
-  extern __shared__ __attribute__((aligned(16))) double s_dyn[];
-  double *s_lp   = s_dyn;                   // LP_WORK_DOUBLES
-  double *s_rows = s_lp + LP_WORK_DOUBLES;  // LP_MAX_ROWS * 5
-  int    *s_perm = (int *)(s_rows + LP_MAX_ROWS * 5);
-  const int a = blockIdx.y + agent0, i = blockIdx.x;
-  const int M = npoly[a];
-  if (M <= 0) return;  // nothing optimised for this agent
-  const SogmTrajRecord &r = rec[i];
-  if (r.n_pieces <= 0 || r.drone_id == ego_ids[a]) return;
+  if (M <= 0) return false;  // nothing optimised for this agent
+  if (r.n_pieces <= 0 || r.drone_id == ego_id) return false;
   double time_end = r.time_start;
   for (int k = 0; k < r.n_pieces; ++k) time_end += r.duration[k];
-  const double now = t_now[a];
-  if (!(r.time_start < now && now < time_end)) return;
+  if (!(r.time_start < now && now < time_end)) return false;
   double t     = now - r.time_start;  // Bezier::locatePiece (bernstein.hpp:164-172)
   int    piece = r.n_pieces - 1;
   for (int k = 0; k < r.n_pieces; ++k) {
@@ -1597,14 +1686,11 @@ __global__ __launch_bounds__(64) void k_safe_after_opt(const double *__restrict_
   }
   const int nA = 5 * M, nB = (r.n_pieces - piece) * 5;
   if (nA + nB > DECONFLICT_MAX_ROWS) {  // LP capacity: treated as "not separable" (oracle does the same)
-    if (threadIdx.x == 0) {
-      out_safe[a] = 0;
-      if (counters) atomicAdd(&counters[SOGM_CNT_DECONFLICT_CAPACITY], 1ull);
-    }
-    return;
+    if ((threadIdx.x & 63) == 0 && counters) atomicAdd(&counters[SOGM_CNT_DECONFLICT_CAPACITY], 1ull);
+    return true;
   }
   double       *A = s_rows, *b = s_rows + LP_MAX_ROWS * 4;
-  const double *ca = cpts + (size_t)a * SOGM_MAX_PIECES * 15, *cb = r.cpts + piece * 15;
+  const double *cb = r.cpts + piece * 15;
   // Disjoint bounding boxes are separated by an axis-aligned plane (the LP is feasible): most pairs of
   // a swarm end here without touching the LP.  64-lane min/max over the two point sets.
   {
@@ -1630,7 +1716,7 @@ __global__ __launch_bounds__(64) void k_safe_after_opt(const double *__restrict_
         hi[k] = fmax(hi[k], __shfl_xor(hi[k], d, 64));
       }
     for (int k = 0; k < 3; ++k) apart = apart || hi[k] < lo[3 + k] || hi[3 + k] < lo[k];
-    if (apart) return;  // wave-uniform
+    if (apart) return false;  // wave-uniform
     // more candidate normals (face / body diagonals, the line between the box centres), same list and
     // order as oracle/deconflict_oracle.cpp: disjoint projections = separable, no LP needed
     double dirs[11][3] = {{1, 1, 0}, {1, -1, 0}, {1, 0, 1}, {1, 0, -1}, {0, 1, 1}, {0, 1, -1},
@@ -1656,7 +1742,7 @@ __global__ __launch_bounds__(64) void k_safe_after_opt(const double *__restrict_
         loB = fmin(loB, __shfl_xor(loB, d, 64));
         hiB = fmax(hiB, __shfl_xor(hiB, d, 64));
       }
-      if (hiA < loB || hiB < loA) return;  // wave-uniform
+      if (hiA < loB || hiB < loA) return false;  // wave-uniform
     }
   }
   for (int q = threadIdx.x; q < nA + nB; q += 64) {
@@ -1679,14 +1765,120 @@ __global__ __launch_bounds__(64) void k_safe_after_opt(const double *__restrict_
     for (int j = 0; j < 4; ++j) A[q * 4 + j] = j == k ? ((threadIdx.x & 1) ? -1.0 : 1.0) : 0.0;
     b[q] = 1.0e4;
   }
-  __syncthreads();
-  {
-    const double c[4] = {0, 0, 0, 0};
-    double       x[4];
-    const double v = linprog_wave<4>(c, nA + nB + 8, A, b, x, s_lp, s_perm);  // the whole wave solves the LP
-    if (threadIdx.x == 0 && (v == INFINITY || v == -INFINITY)) out_safe[a] = 0;  // every writer writes 0
+  wave_lds_sync();
+  const double c[4] = {0, 0, 0, 0};
+  double       x[4];
+  const double v = linprog_wave<4>(c, nA + nB + 8, A, b, x, s_lp, s_perm);  // the whole wave solves the LP
+  wave_lds_sync();
+  return v == INFINITY || v == -INFINITY;
+}
+
+__global__ __launch_bounds__(64) void k_safe_after_opt(const double *__restrict__ cpts,
+                                                       const int32_t *__restrict__ npoly,
+                                                       const SogmTrajRecord *__restrict__ rec, int n_rec,
+                                                       const int32_t *__restrict__ ego_ids,
+                                                       const double *__restrict__ t_now,
+                                                       int32_t *__restrict__ out_safe, int agent0,
+                                                       unsigned long long *counters) {
+  extern __shared__ __attribute__((aligned(16))) double s_dyn[];
+  double *s_lp   = s_dyn;                   // LP_WORK_DOUBLES
+  double *s_rows = s_lp + LP_WORK_DOUBLES;  // LP_MAX_ROWS * 5
+  int    *s_perm = (int *)(s_rows + LP_MAX_ROWS * 5);
+  const int a = blockIdx.y + agent0, i = blockIdx.x;
+  if (deconflict_pair_unsafe(cpts + (size_t)a * SOGM_MAX_PIECES * 15, npoly[a], rec[i], ego_ids[a], t_now[a], s_lp,
+                             s_rows, s_perm, counters) &&
+      threadIdx.x == 0)
+    out_safe[a] = 0;  // every writer writes 0
+}
+
+// Dataflow kernel F (sogm_replan): ONE persistent launch; a wave takes the agent whose QP finished ticket-th, runs
+// ParticleATC::isSafeAfterOpt against every record of the swarm (when a swarm is set) and packs the agent's
+// SogmTrajRecord / ok flag (what k_safe_after_opt + k_pack_records do in the grouped path).
+__global__ __launch_bounds__(64) void k_finish_flow(FlowCtl fc, double corridor_tau, const int32_t *ret,
+                                                    const int32_t *npoly, const int32_t *status, const double *cpts,
+                                                    const SogmTrajRecord *swarm, int n_swarm,
+                                                    const int32_t *swarm_ego, const double *swarm_now,
+                                                    const double *t_start, const int32_t *drone_ids,
+                                                    SogmTrajRecord *out, int32_t *out_ok, int32_t *out_safe,
+                                                    unsigned long long *counters, int n_agents) {
+  extern __shared__ __attribute__((aligned(16))) double s_dyn[];
+  double   *s_lp   = s_dyn;
+  double   *s_rows = s_lp + LP_WORK_DOUBLES;
+  int      *s_perm = (int *)(s_rows + LP_MAX_ROWS * 5);
+  const int lane   = threadIdx.x;
+  for (;;) {
+    const int k = flow_ticket(&fc.hdr[FLOW_F_TICKET]);
+    if (k >= n_agents) break;
+    const int a = flow_wait_slot(fc.f_ready + k, &fc.hdr[FLOW_ERR]);
+    if (a < 0) break;
+#ifdef SOGM_FLOW_DEBUG
+    if (lane == 0) out_safe[a] = 100;
+#endif
+    __threadfence();
+    const int M    = npoly[a];
+    int       safe = 1;
+    const bool solved = ret[a] != 0 && M > 0 && (status[a] == 1 || status[a] == 2);
+    if (swarm && solved) {  // unsolved agents fail anyway: the check cannot change their outcome
+      const double *ca  = cpts + (size_t)a * SOGM_MAX_PIECES * 15;
+      const int     ego = swarm_ego[a];
+      const double  now = swarm_now[a];
+      for (int i = 0; i < n_swarm && safe; ++i)
+        if (deconflict_pair_unsafe(ca, M, swarm[i], ego, now, s_lp, s_rows, s_perm, counters)) safe = 0;
+    }
+#ifdef SOGM_FLOW_DEBUG
+    if (lane == 0) out_safe[a] = 101;
+#else
+    if (lane == 0 && out_safe) out_safe[a] = safe;
+#endif
+    // BezierTraj record (plan_manager.cpp:364-399); n_pieces = 0 marks "replan() returned false"
+    const bool      good = solved && safe != 0;
+    SogmTrajRecord &r    = out[a];
+    for (int i = lane; i < SOGM_MAX_PIECES; i += 64) r.duration[i] = (good && i < M) ? corridor_tau : 0.0;
+#ifdef SOGM_FLOW_DEBUG
+    if (lane == 0) out_safe[a] = 1010;
+#endif
+    for (int i = lane; i < SOGM_MAX_PIECES * 15; i += 64)
+      r.cpts[i] = (good && i < M * 15) ? cpts[(size_t)a * SOGM_MAX_PIECES * 15 + i] : 0.0;
+#ifdef SOGM_FLOW_DEBUG
+    if (lane == 0) out_safe[a] = 102;
+#endif
+    if (lane == 0) {
+      r.drone_id   = drone_ids[a];
+      r.time_start = t_start[a];
+      r.n_pieces   = good ? M : 0;
+      out_ok[a]    = good ? 1 : 0;
+      if (counters) {
+        int k = SOGM_CNT_REPLAN_OK;
+        if (ret[a] == 0) k = SOGM_CNT_FAIL_SEARCH;
+        else if (M <= 0) k = SOGM_CNT_FAIL_CORRIDOR;
+        else if (!(status[a] == 1 || status[a] == 2)) k = SOGM_CNT_FAIL_QP;
+        else if (!safe) k = SOGM_CNT_FAIL_UNSAFE;
+#ifdef SOGM_FLOW_DEBUG
+        out_safe[a] = 103;
+#endif
+        atomicAdd(&counters[k], 1ull);
+#ifdef SOGM_FLOW_DEBUG
+        out_safe[a] = 104;
+#endif
+      }
+    }
   }
 }
+
+// residency gate of the dataflow replan: returns when every A* workgroup has started (see k_astar)
+__global__ void k_flow_gate(FlowCtl fc, int expected) {
+  if (threadIdx.x != 0) return;
+  const long long t0 = wall_clock64();
+  while (__hip_atomic_load(&fc.hdr[FLOW_A_RESIDENT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < expected) {
+    __builtin_amdgcn_s_sleep(8);
+    if (wall_clock64() - t0 > FLOW_TIMEOUT_TICKS) {
+      atomicExch(&fc.hdr[FLOW_ERR], 1);
+      break;
+    }
+  }
+}
+
+
 
 // sdlp::linprog<d> for a batch of independent LPs: one wave per problem (sogm_linprog_batched)
 template <int D>
@@ -1736,6 +1928,34 @@ int launch_deconflict(int n_agents, const double *cpts, const int32_t *npoly, co
     hipLaunchKernelGGL(k_safe_after_opt, dim3(n_rec, n_agents), dim3(64), lds, st, cpts, npoly, rec, n_rec,
                        ego_ids, t_now, out_safe, agent0, counters);
   }
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int launch_flow_gate(const FlowCtl &fc, int expected, hipStream_t st) {
+  hipLaunchKernelGGL(k_flow_gate, dim3(1), dim3(64), 0, st, fc, expected);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int launch_corridor_flow(const MapView &m, const SogmPlannerParams &pp, const CorridorWorkspace &ws,
+                         const FlowCtl &fc, int n_agents, int n_workgroups, const double *start_pva,
+                         const double *t_start, const double *route, const int32_t *route_len, int route_cap,
+                         double *out_polys, int32_t *out_nfaces, int32_t *out_npoly, double *out_goal,
+                         hipStream_t st) {
+  hipLaunchKernelGGL(k_corridor_flow, dim3(n_workgroups), dim3(64), corridor_segment_lds(pp.pc_capacity), st, m, pp,
+                     ws, fc, start_pva, t_start, route, route_len, route_cap, out_polys, out_nfaces, out_npoly,
+                     out_goal, n_agents);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int launch_finish_flow(const FlowCtl &fc, int n_agents, int n_workgroups, double corridor_tau, const int32_t *ret,
+                       const int32_t *npoly, const int32_t *status, const double *cpts, const SogmTrajRecord *swarm,
+                       int n_swarm, const int32_t *swarm_ego, const double *swarm_now, const double *t_start,
+                       const int32_t *drone_ids, SogmTrajRecord *out, int32_t *out_ok, int32_t *out_safe,
+                       unsigned long long *counters, hipStream_t st) {
+  const size_t lds = sizeof(double) * (LP_WORK_DOUBLES + LP_MAX_ROWS * 5) + sizeof(int) * LP_MAX_ROWS;
+  hipLaunchKernelGGL(k_finish_flow, dim3(n_workgroups), dim3(64), lds, st, fc, corridor_tau, ret, npoly, status,
+                     cpts, swarm, n_swarm, swarm_ego, swarm_now, t_start, drone_ids, out, out_ok, out_safe, counters,
+                     n_agents);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

@@ -266,9 +266,16 @@ struct sogm_ctx {
   int            n_body;
   int            updated;
   float         *d_scratch_vt;  // [V][T] staging for download / upload
-  int            overlap;     // tick pipelining: 0 off, 1 pre-clear in place, 2 pre-clear of the alternate grid
-  float         *d_grid_alt;  // second grid of mode 2 (the next update swaps it in)
-  int            precleared;  // a side-stream clear for the next update is in flight
+  int            overlap;     // tick pipelining: 0 off, 1 pre-clear in place, 2 / 3 pre-clear of spare grids
+  // modes 2 and 3: d_grid rotates through a pool of 2 / 3 grids.  `ready` = spares whose clear has been queued on
+  // the side stream (FIFO; the next update adopts the front one after waiting for its event), `dirty` = spares
+  // that still hold an old map (the next sogm_replan queues their clear).  Mode 1 uses ev_cleared only.
+  float         *pool[3];
+  hipEvent_t     pool_ev[3];
+  int            n_pool, cur_idx;
+  int            ready[2], n_ready;
+  int            dirty[2], n_dirty;
+  int            precleared;  // the next update finds a (being-)cleared grid: mode 1 in place, modes 2 / 3 n_ready > 0
   hipStream_t    side;
   hipEvent_t     ev_grid_free, ev_cleared;
   float         *d_filter_cells;   // filterPointCloud leaf accumulators [A][max_cells][4] (lazy)
@@ -331,8 +338,9 @@ inline int join_exchange(sogm_ctx *c, hipStream_t st) {
 int  launch_clear(sogm_ctx *c, hipStream_t st, float *grid = nullptr, bool polite = false, int part = 0,
                   size_t split = 0);
 size_t clear_vec4_total(const sogm_ctx *c);
-// next update's grid becomes current (mode 2) and the stream waits for its pre-clear
+// next update's grid becomes current (modes 2 / 3) and the stream waits for its pre-clear
 int  adopt_preclear(sogm_ctx *c, hipStream_t st);
+int  queue_spare_clears(sogm_ctx *c, hipEvent_t after);
 }  // namespace sogm
 
 #define SOGM_HIP_CHECK(expr)                    \

@@ -546,13 +546,37 @@ __global__ __launch_bounds__(64) void k_traj_safe(MapView m, const SogmTrajRecor
 
 int adopt_preclear(sogm_ctx *c, hipStream_t st) {
   if (!c->precleared) return SOGM_OK;
-  if (c->overlap == 2 && c->d_grid_alt) {
-    float *t      = c->d_grid;
-    c->d_grid     = c->d_grid_alt;
-    c->d_grid_alt = t;
+  if (c->overlap >= 2) {
+    // rotate: the front of the ready queue becomes the current grid, the old current grid is dirty
+    const int nxt = c->ready[0];
+    for (int i = 1; i < c->n_ready; ++i) c->ready[i - 1] = c->ready[i];
+    c->n_ready--;
+    c->dirty[c->n_dirty++] = c->cur_idx;
+    c->cur_idx             = nxt;
+    c->d_grid              = c->pool[nxt];
+    SOGM_HIP_CHECK(hipStreamWaitEvent(st, c->pool_ev[nxt], 0));
+    c->precleared = c->n_ready > 0;
+    return SOGM_OK;
   }
   SOGM_HIP_CHECK(hipStreamWaitEvent(st, c->ev_cleared, 0));
   c->precleared = 0;
+  return SOGM_OK;
+}
+
+// modes 2 / 3: queue the clear of every dirty spare grid on the side stream once `after` has fired (every reader
+// of those grids is ordered before it); sogm_replan calls this right after its fan-out event
+int queue_spare_clears(sogm_ctx *c, hipEvent_t after) {
+  if (c->overlap < 2 || c->n_dirty == 0) return SOGM_OK;
+  SOGM_HIP_CHECK(hipStreamWaitEvent(c->side, after, 0));
+  for (int i = 0; i < c->n_dirty; ++i) {
+    const int g  = c->dirty[i];
+    int       rc = launch_clear(c, c->side, c->pool[g], true);
+    if (rc) return rc;
+    SOGM_HIP_CHECK(hipEventRecord(c->pool_ev[g], c->side));
+    c->ready[c->n_ready++] = g;
+  }
+  c->n_dirty    = 0;
+  c->precleared = 1;
   return SOGM_OK;
 }
 
@@ -661,8 +685,11 @@ int sogm_create(const SogmSpec *spec, int n_agents, int device, sogm_ctx **out) 
 
 void sogm_destroy(sogm_ctx *c) {
   if (!c) return;
-  if (c->d_grid) (void)hipFree(c->d_grid);
-  if (c->d_grid_alt) (void)hipFree(c->d_grid_alt);
+  if (c->n_pool == 0 && c->d_grid) (void)hipFree(c->d_grid);
+  for (int i = 0; i < c->n_pool; ++i)
+    if (c->pool[i]) (void)hipFree(c->pool[i]);
+  for (int i = 0; i < 3; ++i)
+    if (c->pool_ev[i]) (void)hipEventDestroy(c->pool_ev[i]);
   if (c->d_poses) (void)hipFree(c->d_poses);
   if (c->d_stamps) (void)hipFree(c->d_stamps);
   if (c->d_body) (void)hipFree(c->d_body);
@@ -698,26 +725,58 @@ int64_t sogm_grid_bytes(const sogm_ctx *c) {
 float *sogm_grid_ptr(sogm_ctx *c) { return c ? c->d_grid : nullptr; }
 
 int sogm_set_overlap_clear(sogm_ctx *c, int mode) {
-  if (!c || mode < 0 || mode > 2) return SOGM_ERR_INVALID_ARG;
+  if (!c || mode < 0 || mode > 3) return SOGM_ERR_INVALID_ARG;
   SOGM_HIP_CHECK(hipSetDevice(c->device));
-  if (c->precleared) {  // a pre-clear is in flight: let it finish and forget it (the next update clears itself)
+  if (c->precleared || c->n_ready || c->n_dirty) {
+    // pre-clears may be in flight: let them finish and forget them (the next update clears its grid itself)
     (void)hipDeviceSynchronize();
     c->precleared = 0;
   }
-  if (mode == 2 && !c->d_grid_alt) {
-    const size_t bytes = ((size_t)sogm_grid_bytes(c) + 15) & ~(size_t)15;
-    if (hipMalloc(&c->d_grid_alt, bytes) != hipSuccess) {
+  const int want = mode >= 2 ? mode : 1;  // grids in the pool
+  // the current grid stays where it is (slot cur_idx); spares are added / released around it
+  if (c->n_pool == 0) {
+    c->pool[0] = c->d_grid;
+    c->n_pool  = 1;
+    c->cur_idx = 0;
+  }
+  if (c->cur_idx != 0) {  // keep the current grid in slot 0 so that spares are slots 1..n_pool-1
+    float *t           = c->pool[0];
+    c->pool[0]         = c->pool[c->cur_idx];
+    c->pool[c->cur_idx] = t;
+    c->cur_idx         = 0;
+  }
+  while (c->n_pool > want) {
+    (void)hipFree(c->pool[--c->n_pool]);
+    c->pool[c->n_pool] = nullptr;
+  }
+  const size_t bytes = ((size_t)sogm_grid_bytes(c) + 15) & ~(size_t)15;
+  const int    had   = c->n_pool;
+  while (c->n_pool < want) {
+    float *g = nullptr;
+    if (hipMalloc(&g, bytes) != hipSuccess) {
       (void)hipGetLastError();
-      c->d_grid_alt = nullptr;
-      sogm::set_error("sogm_set_overlap_clear: no room for a second grid", hipErrorOutOfMemory);
+      while (c->n_pool > had) {  // all or nothing: the mode is unchanged
+        (void)hipFree(c->pool[--c->n_pool]);
+        c->pool[c->n_pool] = nullptr;
+      }
+      sogm::set_error("sogm_set_overlap_clear: no room for the spare grid(s)", hipErrorOutOfMemory);
+      c->n_ready = 0;
+      c->n_dirty = 0;
+      for (int i = 1; i < c->n_pool; ++i) c->dirty[c->n_dirty++] = i;
       return SOGM_ERR_CAPACITY;
     }
+    if (!c->pool_ev[c->n_pool] &&
+        hipEventCreateWithFlags(&c->pool_ev[c->n_pool], hipEventDisableTiming) != hipSuccess) {
+      (void)hipFree(g);
+      return SOGM_ERR_HIP;
+    }
+    c->pool[c->n_pool++] = g;
   }
-  if (mode != 2 && c->d_grid_alt) {
-    (void)hipDeviceSynchronize();
-    (void)hipFree(c->d_grid_alt);
-    c->d_grid_alt = nullptr;
-  }
+  for (int i = 0; i < c->n_pool; ++i)  // every slot takes the spare role in turn
+    if (!c->pool_ev[i]) SOGM_HIP_CHECK(hipEventCreateWithFlags(&c->pool_ev[i], hipEventDisableTiming));
+  c->n_ready = 0;
+  c->n_dirty = 0;
+  for (int i = 1; i < c->n_pool; ++i) c->dirty[c->n_dirty++] = i;  // spares hold garbage until a replan clears them
   c->overlap = mode;
   return SOGM_OK;
 }

@@ -163,6 +163,22 @@ int sogm_planner_create(sogm_ctx *map, const SogmAstarParams *astar, const SogmP
     if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_done[g], hipEventDisableTiming);
   }
   if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_in, hipEventDisableTiming);
+  // dataflow replan: control block + four streams (needs >= 5 hardware queues to overlap with the clear)
+  {
+    const char *ef = getenv("SOGM_FLOW");
+    p->flow        = ef ? atoi(ef) != 0 : 1;
+    if (e == hipSuccess) e = hipMalloc((void **)&p->d_flow, sizeof(int) * (FLOW_HDR + 4 * (size_t)A));
+    p->fc.hdr      = p->d_flow;
+    p->fc.seg_done = p->d_flow + FLOW_HDR;
+    p->fc.a_ready  = p->fc.seg_done + A;
+    p->fc.q_ready  = p->fc.a_ready + A;
+    p->fc.f_ready  = p->fc.q_ready + A;
+    for (int k = 0; k < 4 && e == hipSuccess; ++k) {
+      e = hipStreamCreateWithFlags(&p->fstream[k], hipStreamNonBlocking);
+      if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_fdone[k], hipEventDisableTiming);
+    }
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_gate, hipEventDisableTiming);
+  }
   if (e != hipSuccess) {
     sogm::set_error("sogm_planner_create", e);
     sogm_planner_destroy(p);
@@ -179,7 +195,7 @@ void sogm_planner_destroy(sogm_planner *p) {
                   p->cw.seg_nfaces, p->cw.seg_state, p->cw.seg_npts, p->cw.seg_dbg, p->cw.counters,
                   p->qw.scratch,
                   p->d_polys, p->d_goal, p->d_cpts, p->d_nfaces, p->d_npoly, p->d_status, p->d_iters,
-                  p->d_safe};
+                  p->d_safe,  p->d_flow};
   for (void *q : ptrs)
     if (q) (void)hipFree(q);
   for (int g = 0; g < SOGM_MAX_GROUPS; ++g) {
@@ -192,6 +208,14 @@ void sogm_planner_destroy(sogm_planner *p) {
     if (p->ev_done[g]) (void)hipEventDestroy(p->ev_done[g]);
   }
   if (p->ev_in) (void)hipEventDestroy(p->ev_in);
+  for (int k = 0; k < 4; ++k) {
+    if (p->fstream[k]) {
+      (void)hipStreamSynchronize(p->fstream[k]);
+      (void)hipStreamDestroy(p->fstream[k]);
+    }
+    if (p->ev_fdone[k]) (void)hipEventDestroy(p->ev_fdone[k]);
+  }
+  if (p->ev_gate) (void)hipEventDestroy(p->ev_gate);
   delete p;
 }
 
@@ -298,6 +322,28 @@ int sogm_safe_after_opt(sogm_planner *p, const double *cpts, const int32_t *npol
   return SOGM_OK;
 }
 
+// diagnostics (tools/ only): the dataflow control block, copied on a private stream while the tick's kernels run
+int sogm_debug_flow_peek(sogm_planner *p, int *out_host, int n) {
+  if (!p || !out_host || n < 0) return SOGM_ERR_INVALID_ARG;
+  static hipStream_t peek = nullptr;
+  if (!peek) SOGM_HIP_CHECK(hipStreamCreateWithFlags(&peek, hipStreamNonBlocking));
+  const int nf = FLOW_HDR + 4 * p->map->n_agents;
+  SOGM_HIP_CHECK(hipMemcpyAsync(out_host, p->d_flow, sizeof(int) * (size_t)(n < nf ? n : nf), hipMemcpyDeviceToHost, peek));
+  if (n > nf)  // followed by d_safe (progress markers in debug builds)
+    SOGM_HIP_CHECK(hipMemcpyAsync(out_host + nf, p->d_safe, sizeof(int) * (size_t)(n - nf), hipMemcpyDeviceToHost, peek));
+  SOGM_HIP_CHECK(hipStreamSynchronize(peek));
+  return SOGM_OK;
+}
+
+int sogm_planner_flow_error(sogm_planner *p) {
+  if (!p) return SOGM_ERR_INVALID_ARG;
+  int hdr[FLOW_HDR];
+  SOGM_HIP_CHECK(hipSetDevice(p->map->device));
+  SOGM_HIP_CHECK(hipDeviceSynchronize());
+  SOGM_HIP_CHECK(hipMemcpy(hdr, p->d_flow, sizeof(hdr), hipMemcpyDeviceToHost));
+  return hdr[FLOW_ERR];
+}
+
 int sogm_planner_counters(sogm_planner *p, int64_t *out_host, int reset) {
   if (!p || !out_host) return SOGM_ERR_INVALID_ARG;
   SOGM_HIP_CHECK(hipSetDevice(p->map->device));
@@ -317,6 +363,76 @@ int sogm_planner_set_swarm(sogm_planner *p, const SogmTrajRecord *records, int n
   return SOGM_OK;
 }
 
+// The dataflow replan: five launches for the whole tick.  k_astar (one workgroup per agent) publishes agents as their
+// searches finish; k_corridor_flow, k_qp_flow and k_finish_flow are persistent and chain per agent through ready
+// lists in HBM, so a slow search / corridor / QP only delays its own agent's chain.  k_flow_gate makes the waiting
+// kernels dispatch only after every search is resident (they could otherwise fill the CUs and starve it).
+static int replan_flow(sogm_planner *p, const double *start_pva, const double *goal, const double *t_start,
+                       const int32_t *drone_ids, SogmTrajRecord *out_records, int32_t *out_ok, void *stream) {
+  sogm_ctx     *c    = p->map;
+  hipStream_t   main = (hipStream_t)stream;
+  const int     A    = c->n_agents;
+  const MapView mv   = view_of(c);
+  if (p->swarm)
+    if (int rc = sogm::join_exchange(c, main)) return rc;
+  // reset the control block in stream order: counters and seg_done to 0, ready lists to -1
+  SOGM_HIP_CHECK(hipMemsetAsync(p->d_flow, 0, sizeof(int) * (FLOW_HDR + (size_t)A), main));
+  SOGM_HIP_CHECK(hipMemsetAsync(p->fc.a_ready, 0xFF, sizeof(int) * 3 * (size_t)A, main));
+  SOGM_HIP_CHECK(hipEventRecord(p->ev_in, main));
+  if (c->overlap >= 2) {
+    int rc = sogm::queue_spare_clears(c, p->ev_in);
+    if (rc) return rc;
+  }
+  hipStream_t sA = p->fstream[0], sC = p->fstream[1], sQ = p->fstream[2], sF = p->fstream[3];
+  for (int k = 0; k < 4; ++k) SOGM_HIP_CHECK(hipStreamWaitEvent(p->fstream[k], p->ev_in, 0));
+  prof_begin(c, SOGM_PROF_ASTAR, sA);
+  if (launch_astar(mv, p->ap, p->pp.corridor_tau, p->aw, A, start_pva, goal, t_start, p->d_ret, p->d_route,
+                   p->d_route_len, p->route_cap, p->d_stats, nullptr, 0, sA, 0, &p->fc)) {
+    sogm::set_error("sogm_replan: k_astar", hipGetLastError());
+    return SOGM_ERR_HIP;
+  }
+  prof_end(c, SOGM_PROF_ASTAR, sA);
+  if (sogm::launch_flow_gate(p->fc, A, sC)) return SOGM_ERR_HIP;
+  SOGM_HIP_CHECK(hipEventRecord(p->ev_gate, sC));
+  SOGM_HIP_CHECK(hipStreamWaitEvent(sQ, p->ev_gate, 0));
+  SOGM_HIP_CHECK(hipStreamWaitEvent(sF, p->ev_gate, 0));
+  // persistent workgroups: one wave each for the corridor items (4 per CU fit), a quarter of the CUs' worth of QP
+  // workgroups (each takes a whole CU's LDS while it runs), a handful of finishing waves
+  int n_cu = 256;
+  (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->device);
+  int wg_c = 4 * n_cu;
+  if (wg_c > A * SOGM_MAX_PIECES) wg_c = A * SOGM_MAX_PIECES;
+  int wg_q = (3 * n_cu) / 8;
+  if (wg_q > A) wg_q = A;
+  if (wg_q < 1) wg_q = 1;
+  int wg_f = A < 64 ? A : 64;
+  prof_begin(c, SOGM_PROF_CORRIDOR, sC);
+  if (sogm::launch_corridor_flow(mv, p->pp, p->cw, p->fc, A, wg_c, start_pva, t_start, p->d_route, p->d_route_len,
+                                 p->route_cap, p->d_polys, p->d_nfaces, p->d_npoly, p->d_goal, sC)) {
+    sogm::set_error("sogm_replan: k_corridor_flow", hipGetLastError());
+    return SOGM_ERR_HIP;
+  }
+  prof_end(c, SOGM_PROF_CORRIDOR, sC);
+  prof_begin(c, SOGM_PROF_QP, sQ);
+  if (sogm::launch_qp_flow(p->pp, p->qs, p->qw, p->qc, p->fc, A, wg_q, start_pva, p->d_goal, p->d_polys, p->d_nfaces,
+                           p->d_npoly, p->d_cpts, p->d_status, p->d_iters, sQ)) {
+    sogm::set_error("sogm_replan: k_qp_flow", hipGetLastError());
+    return SOGM_ERR_HIP;
+  }
+  prof_end(c, SOGM_PROF_QP, sQ);
+  if (sogm::launch_finish_flow(p->fc, A, wg_f, p->pp.corridor_tau, p->d_ret, p->d_npoly, p->d_status, p->d_cpts,
+                               p->swarm, p->n_swarm, p->swarm_ego, p->swarm_now, t_start, drone_ids, out_records,
+                               out_ok, p->d_safe, p->cw.counters, sF)) {
+    sogm::set_error("sogm_replan: k_finish_flow", hipGetLastError());
+    return SOGM_ERR_HIP;
+  }
+  for (int k = 0; k < 4; ++k) {
+    SOGM_HIP_CHECK(hipEventRecord(p->ev_fdone[k], p->fstream[k]));
+    SOGM_HIP_CHECK(hipStreamWaitEvent(main, p->ev_fdone[k], 0));  // fan in
+  }
+  return SOGM_OK;
+}
+
 static int replan_impl(sogm_planner *p, const double *start_pva, const double *goal,
                        const double *t_start, const int32_t *drone_ids, SogmTrajRecord *out_records,
                        int32_t *out_ok, void *stream) {
@@ -329,14 +445,13 @@ static int replan_impl(sogm_planner *p, const double *start_pva, const double *g
     if (int rc = sogm::join_exchange(c, main)) return rc;
   // fan out: every group stream starts when the caller's stream has produced the inputs
   SOGM_HIP_CHECK(hipEventRecord(p->ev_in, main));
-  if (c->overlap == 2 && c->d_grid_alt) {
-    // double-buffered SOGM: the NEXT update's grid is cleared on the side stream under this whole replan (its
-    // last readers, the previous tick's corridor kernels, are ordered before ev_in)
-    SOGM_HIP_CHECK(hipStreamWaitEvent(c->side, p->ev_in, 0));
-    int rc = sogm::launch_clear(c, c->side, c->d_grid_alt, true);
+  if (c->overlap >= 2) {
+    // double / triple-buffered SOGM: the spare grid this tick's update swapped out is cleared on the side stream
+    // under this whole replan (its last readers, the previous tick's corridor kernels, are ordered before ev_in).
+    // Mode 2: it is the NEXT update's grid (deadline: the next stamp).  Mode 3: the next update takes the grid
+    // cleared during the PREVIOUS replan, so every clear has a whole tick of slack.
+    int rc = sogm::queue_spare_clears(c, p->ev_in);
     if (rc) return rc;
-    SOGM_HIP_CHECK(hipEventRecord(c->ev_cleared, c->side));
-    c->precleared = 1;
   }
   for (int g = 0; g < G; ++g) {
     const int a0 = (int)((long long)A * g / G), a1 = (int)((long long)A * (g + 1) / G), n = a1 - a0;
@@ -405,14 +520,17 @@ int sogm_replan(sogm_planner *p, const double *start_pva, const double *goal,
   if (!p->map->updated) return SOGM_ERR_STATE;
   sogm_ctx *c = p->map;
   SOGM_HIP_CHECK(hipSetDevice(c->device));
-  const int rc = replan_impl(p, start_pva, goal, t_start, drone_ids, out_records, out_ok, stream);
+  // the in-place pre-clear (mode 1) needs the grouped path's "last reader of the SOGM" events
+  const bool use_flow = p->flow && c->overlap != 1;
+  const int  rc = use_flow ? replan_flow(p, start_pva, goal, t_start, drone_ids, out_records, out_ok, stream)
+                           : replan_impl(p, start_pva, goal, t_start, drone_ids, out_records, out_ok, stream);
   if (rc != SOGM_OK) {
     // A launch failed half-way: group / side streams may hold work the caller's stream was never joined to, and
     // a pre-clear may or may not have been issued.  Drain everything and forget the pre-clear (the next update
     // clears its grid itself); an in-place clear (mode 1) may already have eaten part of the map.
     (void)hipDeviceSynchronize();
     if (c->precleared && c->overlap == 1) c->updated = 0;
-    c->precleared = 0;
+    if (c->overlap < 2) c->precleared = 0;  // modes 2 / 3: clears already queued stay valid (events recorded)
   }
   return rc;
 }

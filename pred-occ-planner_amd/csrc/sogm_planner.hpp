@@ -29,6 +29,21 @@ struct CorridorWorkspace {
   unsigned long long *counters;  // [SOGM_CNT_N] cumulative outcome / capacity counters (sogm_planner_counters)
 };
 
+// Device-side control block of the dataflow replan (one per planner, reset at the start of every sogm_replan):
+// kernels of one tick hand agents to each other through ready lists instead of stream order.
+//   hdr[FLOW_*] counters; seg_done[A] finished segment slots per agent; a_ready[A] agents in A* completion order;
+//   q_ready[A] agents in corridor completion order (entries are -1 until published).
+enum { FLOW_A_RESIDENT = 0, FLOW_A_READY_N = 1, FLOW_C_TICKET = 2, FLOW_Q_READY_N = 3, FLOW_Q_TICKET = 4,
+       FLOW_ERR = 5, FLOW_F_READY_N = 6, FLOW_F_TICKET = 7, FLOW_HDR = 8 };
+#define FLOW_TIMEOUT_TICKS 300000000LL  // 3 s of the 100 MHz wall clock: a stuck tick fails instead of hanging
+struct FlowCtl {
+  int *hdr;       // [FLOW_HDR]
+  int *seg_done;  // [A]
+  int *a_ready;   // [A]
+  int *q_ready;   // [A]
+  int *f_ready;   // [A] agents in QP completion order
+};
+
 // ParticleATC::isSafeAfterOpt for agents [agent0, agent0 + n_agents): out_safe[a] = 1 / 0
 int launch_deconflict(int n_agents, const double *cpts, const int32_t *npoly, const SogmTrajRecord *rec,
                       int n_rec, const int32_t *ego_ids, const double *t_now, int32_t *out_safe,
@@ -38,6 +53,19 @@ int launch_corridor(const MapView &m, const SogmPlannerParams &pp, const Corrido
                     const double *route, const int32_t *route_len, int route_cap,
                     double *out_polys, int32_t *out_nfaces, int32_t *out_npoly, double *out_goal,
                     hipStream_t st, int agent0 = 0, hipEvent_t ev_map_read = nullptr);
+
+// dataflow replan launchers (persistent kernels; see k_corridor_flow / k_qp_flow / k_finish_flow)
+int launch_flow_gate(const FlowCtl &fc, int expected, hipStream_t st);
+int launch_corridor_flow(const MapView &m, const SogmPlannerParams &pp, const CorridorWorkspace &ws,
+                         const FlowCtl &fc, int n_agents, int n_workgroups, const double *start_pva,
+                         const double *t_start, const double *route, const int32_t *route_len, int route_cap,
+                         double *out_polys, int32_t *out_nfaces, int32_t *out_npoly, double *out_goal,
+                         hipStream_t st);
+int launch_finish_flow(const FlowCtl &fc, int n_agents, int n_workgroups, double corridor_tau, const int32_t *ret,
+                       const int32_t *npoly, const int32_t *status, const double *cpts, const SogmTrajRecord *swarm,
+                       int n_swarm, const int32_t *swarm_ego, const double *swarm_now, const double *t_start,
+                       const int32_t *drone_ids, SogmTrajRecord *out, int32_t *out_ok, int32_t *out_safe,
+                       unsigned long long *counters, hipStream_t st);
 
 // Per-agent QP row storage in HBM, used only when a problem's rows do not fit in LDS.
 struct QpWorkspace {
@@ -55,12 +83,17 @@ int launch_qp(const SogmPlannerParams &pp, const SogmQpSettings &qs, const QpWor
               const double *polys, const int32_t *nfaces, const int32_t *npoly, double *out_cpts,
               int32_t *out_status, int32_t *out_iters, hipStream_t st, int agent0 = 0);
 
+int launch_qp_flow(const SogmPlannerParams &pp, const SogmQpSettings &qs, const QpWorkspace &ws,
+                   const QpConst &qc, const FlowCtl &fc, int n_agents, int n_workgroups, const double *start_pva,
+                   const double *goal_pv, const double *polys, const int32_t *nfaces, const int32_t *npoly,
+                   double *out_cpts, int32_t *out_status, int32_t *out_iters, hipStream_t st);
+
 size_t astar_node_bytes();
 int    launch_astar(const MapView &m, const SogmAstarParams &ap, double corridor_tau,
                     const AstarWorkspace &wsp, int n_agents, const double *start_pva,
                     const double *goal, const double *t_start, int32_t *out_ret,
                     double *out_route, int32_t *out_route_len, int route_cap, int32_t *out_stats,
-                    int32_t *out_trace, int trace_cap, hipStream_t st, int agent0 = 0);
+                    int32_t *out_trace, int trace_cap, hipStream_t st, int agent0 = 0, const FlowCtl *fc = nullptr);
 
 }  // namespace sogm
 
@@ -93,4 +126,10 @@ struct sogm_planner {
   hipStream_t gstream[SOGM_MAX_GROUPS];
   hipEvent_t  ev_in, ev_corr[SOGM_MAX_GROUPS], ev_done[SOGM_MAX_GROUPS];
   hipEvent_t  ev_pts[SOGM_MAX_GROUPS];  // after a group's obstacle-point kernel: its last read of the SOGM
+  // dataflow replan (persistent kernels chained per agent through device-side ready lists)
+  int            flow;        // 1 = use it (pipelining modes other than the in-place pre-clear)
+  int           *d_flow;      // FLOW_HDR + 4 A ints: header, seg_done, a_ready, q_ready, f_ready
+  sogm::FlowCtl  fc;
+  hipStream_t    fstream[4];  // A*, corridors, QP, finish
+  hipEvent_t     ev_gate, ev_fdone[4];
 };

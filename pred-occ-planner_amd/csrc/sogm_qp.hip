@@ -152,15 +152,13 @@ size_t qp_scratch_bytes_per_agent(int max_faces) {
   return (rows_bytes(G, S) + 255) & ~(size_t)255;
 }
 
-__global__ __launch_bounds__(QP_NT) void k_qp(SogmPlannerParams pp, SogmQpSettings qs, QpWorkspace ws,
-                                            QpConst qc, const double *__restrict__ start_pva,
-                                            const double *__restrict__ goal_pv,
-                                            const double *__restrict__ polys,
-                                            const int32_t *__restrict__ nfaces,
-                                            const int32_t *__restrict__ npoly,
-                                            double *__restrict__ out_cpts,
-                                            int32_t *__restrict__ out_status,
-                                            int32_t *__restrict__ out_iters, int ablate_arg, int agent0) {
+// One agent's QP, executed by the whole workgroup (QP_NT lanes); called by k_qp (one workgroup per agent) and by
+// the dataflow kernel k_qp_flow (a workgroup solves agents one after the other as their corridors become final).
+__device__ __forceinline__ void qp_solve_agent(const SogmPlannerParams &pp, const SogmQpSettings &qs,
+                                               const QpWorkspace &ws, const QpConst &qc, const double *start_pva,
+                                               const double *goal_pv, const double *polys, const int32_t *nfaces,
+                                               const int32_t *npoly, double *out_cpts, int32_t *out_status,
+                                               int32_t *out_iters, int ablate_arg, int agent) {
   // phase ablation is a profiling aid: compiled in only with -DSOGM_QP_ABLATE_BUILD (tools/qp_ablate.py)
 #ifdef SOGM_QP_ABLATE_BUILD
   const int ablate = ablate_arg;
@@ -168,7 +166,6 @@ __global__ __launch_bounds__(QP_NT) void k_qp(SogmPlannerParams pp, SogmQpSettin
   constexpr int ablate = 0;
   (void)ablate_arg;
 #endif
-  const int agent = blockIdx.x + agent0;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int M = npoly[agent];
   if (M <= 0 || M > SOGM_MAX_PIECES) {
@@ -1252,11 +1249,69 @@ __global__ __launch_bounds__(QP_NT) void k_qp(SogmPlannerParams pp, SogmQpSettin
   }
 }
 
+__global__ __launch_bounds__(QP_NT) void k_qp(SogmPlannerParams pp, SogmQpSettings qs, QpWorkspace ws,
+                                            QpConst qc, const double *__restrict__ start_pva,
+                                            const double *__restrict__ goal_pv,
+                                            const double *__restrict__ polys,
+                                            const int32_t *__restrict__ nfaces,
+                                            const int32_t *__restrict__ npoly,
+                                            double *__restrict__ out_cpts,
+                                            int32_t *__restrict__ out_status,
+                                            int32_t *__restrict__ out_iters, int ablate_arg, int agent0) {
+  qp_solve_agent(pp, qs, ws, qc, start_pva, goal_pv, polys, nfaces, npoly, out_cpts, out_status, out_iters,
+                 ablate_arg, blockIdx.x + agent0);
+}
+
+// Dataflow kernel Q (sogm_replan): ONE persistent launch; a workgroup takes tickets and solves the agent whose
+// corridors became final ticket-th (k_corridor_flow publishes agents in completion order), so a 4000-iteration QP
+// only delays its own agent.  The solved agent is handed to the finishing kernel (deconfliction + record packing).
+__global__ __launch_bounds__(QP_NT) void k_qp_flow(SogmPlannerParams pp, SogmQpSettings qs, QpWorkspace ws,
+                                                 QpConst qc, FlowCtl fc, const double *start_pva,
+                                                 const double *goal_pv, const double *polys,
+                                                 const int32_t *nfaces, const int32_t *npoly, double *out_cpts,
+                                                 int32_t *out_status, int32_t *out_iters, int ablate_arg,
+                                                 int n_agents) {
+  __shared__ int s_agent;
+  for (;;) {
+    if (threadIdx.x == 0) {
+      int       a = -1;
+      const int k = atomicAdd(&fc.hdr[FLOW_Q_TICKET], 1);
+      if (k < n_agents) {
+        const long long t0 = wall_clock64();
+        while ((a = __hip_atomic_load(fc.q_ready + k, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) < 0) {
+          __builtin_amdgcn_s_sleep(64);
+          if (__hip_atomic_load(&fc.hdr[FLOW_ERR], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+          if (wall_clock64() - t0 > FLOW_TIMEOUT_TICKS) {
+            atomicExch(&fc.hdr[FLOW_ERR], 3);
+            break;
+          }
+        }
+      }
+      s_agent = a;
+    }
+    __syncthreads();
+    const int agent = __builtin_amdgcn_readfirstlane(s_agent);  // uniform: a scalar branch
+    if (agent < 0) break;  // no tickets left, or the tick failed
+    __threadfence();       // corridor outputs were published before the ready slot
+    qp_solve_agent(pp, qs, ws, qc, start_pva, goal_pv, polys, nfaces, npoly, out_cpts, out_status, out_iters,
+                   ablate_arg, agent);
+    __syncthreads();
+    __threadfence();
+    if (threadIdx.x == 0) {
+      const int r = atomicAdd(&fc.hdr[FLOW_F_READY_N], 1);
+      __hip_atomic_store(fc.f_ready + r, agent, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+  }
+}
+
 // Dynamic LDS k_qp may ask for: the CU's 160 KiB minus the kernel's static LDS (queried, not assumed).
 int qp_dynamic_lds_bytes() {
-  hipFuncAttributes a;
+  hipFuncAttributes a, b;
   if (hipFuncGetAttributes(&a, (const void *)k_qp) != hipSuccess) return 128 * 1024;
-  const long dyn = 160L * 1024 - (long)a.sharedSizeBytes;
+  if (hipFuncGetAttributes(&b, (const void *)k_qp_flow) != hipSuccess) return 128 * 1024;
+  const long stat = (long)(a.sharedSizeBytes > b.sharedSizeBytes ? a.sharedSizeBytes : b.sharedSizeBytes);
+  const long dyn  = 160L * 1024 - stat;
   return (int)(dyn & ~255L);
 }
 
@@ -1278,6 +1333,21 @@ int launch_qp(const SogmPlannerParams &pp, const SogmQpSettings &qs, const QpWor
   }
   hipLaunchKernelGGL(k_qp, dim3(n_agents), dim3(QP_NT), ws.dyn_lds_bytes, st, pp, qs, ws, qc, start_pva,
                      goal_pv, polys, nfaces, npoly, out_cpts, out_status, out_iters, ablate, agent0);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int launch_qp_flow(const SogmPlannerParams &pp, const SogmQpSettings &qs, const QpWorkspace &ws,
+                   const QpConst &qc, const FlowCtl &fc, int n_agents, int n_workgroups, const double *start_pva,
+                   const double *goal_pv, const double *polys, const int32_t *nfaces, const int32_t *npoly,
+                   double *out_cpts, int32_t *out_status, int32_t *out_iters, hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void *)k_qp_flow, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              ws.dyn_lds_bytes);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k_qp_flow, dim3(n_workgroups), dim3(QP_NT), ws.dyn_lds_bytes, st, pp, qs, ws, qc, fc,
+                     start_pva, goal_pv, polys, nfaces, npoly, out_cpts, out_status, out_iters, 0, n_agents);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

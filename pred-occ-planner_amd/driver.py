@@ -173,7 +173,7 @@ def fsm_apply(status, fail, traj_start, success, now, due_new, is_rep, ok, safe,
 class SwarmTick:
     def __init__(self, grid="cfg2", agents_per_rank=None, rank=0, world=1, device=0, seed=0x5069,
                  spec=None, scene=None, dist=None, overlap_clear=True, deconflict=True, fsm=False,
-                 double_buffer=None):
+                 double_buffer=None, grids=None):
         self.rank, self.world, self.dist = rank, world, dist
         self.spec = spec if spec is not None else config.make_spec(grid)
         self.A_loc = agents_per_rank if agents_per_rank is not None else config.AGENTS.get(grid, 4)
@@ -192,7 +192,7 @@ class SwarmTick:
         self.dev = upload_scene(loc, cloud=crop, cloud_range=crange)
         self.cloud_points = int(crop.shape[0])
         self.map = SogmMap(self.spec, self.A_loc, device)
-        self.overlap_mode = self.map.set_overlap_clear(overlap_clear, double_buffer=double_buffer)
+        self.overlap_mode = self.map.set_overlap_clear(overlap_clear, double_buffer=double_buffer, grids=grids)
         self.planner = SogmPlanner(self.map, config.make_astar_params(), config.make_planner_params(True),
                                    config.make_qp_settings())
         d = "cuda"

@@ -49,6 +49,10 @@ class SogmPlanner:
         except Exception:
             pass
 
+    def flow_error(self):
+        """0 if the last replan()'s dataflow kernels completed normally (synchronises the device)."""
+        return int(lib().sogm_planner_flow_error(self._p))
+
     def counters(self, reset=False):
         """Cumulative outcome / capacity counters of replan() (sogm_planner_counters) as a dict."""
         out = (C.c_int64 * len(_abi.COUNTER_NAMES))()

@@ -67,25 +67,32 @@ class SogmMap:
     def grid_bytes(self):
         return int(lib().sogm_grid_bytes(self._ctx))
 
-    def set_overlap_clear(self, on=True, double_buffer=None):
-        """Tick pipelining.  Mode 2 (double_buffer, the default when HBM has room for a second grid): replan()
-        clears the NEXT update's grid with a narrow streaming kernel under the whole replan.  Mode 1: the grid is
-        cleared in place in two launches — a narrow head beside the FIRI kernels, the full-width rest under the QP
-        stage.  Returns the mode in effect."""
+    def set_overlap_clear(self, on=True, double_buffer=None, grids=None):
+        """Tick pipelining.  Modes 3 / 2 (a pool of three / two grids, the default when HBM has room): replan()
+        clears the spare grid swapped out by this tick's update with a narrow streaming kernel under the whole
+        replan; with three grids the next update takes the grid cleared one tick earlier, so the clear is never on
+        the tick's critical path.  Mode 1: the grid is cleared in place in two launches — a narrow head beside the
+        FIRI kernels, the full-width rest under the QP stage.  `grids` (1 | 2 | 3) forces a mode; `double_buffer`
+        False forces mode 1.  Returns the mode in effect."""
         if not on:
             check(lib().sogm_set_overlap_clear(self._ctx, 0), "sogm_set_overlap_clear")
             return 0
-        if double_buffer is None:
-            free, _ = torch.cuda.mem_get_info()
-            double_buffer = free > self.grid_bytes() + (16 << 30)
-        if double_buffer:
-            rc = lib().sogm_set_overlap_clear(self._ctx, 2)
+        if grids is None:
+            if double_buffer is False:
+                grids = 1
+            else:
+                free, _ = torch.cuda.mem_get_info()
+                spare = (free - (16 << 30)) // max(self.grid_bytes(), 1)
+                grids = 3 if spare >= 2 else (2 if spare >= 1 else 1)
+                if double_buffer is True:
+                    grids = max(grids, 2)
+        for mode in ([3, 2, 1] if grids >= 3 else [2, 1] if grids == 2 else [1]):
+            rc = lib().sogm_set_overlap_clear(self._ctx, mode)
             if rc == 0:
-                return 2
+                return mode
             if rc != _abi.SOGM_ERR_CAPACITY:
                 check(rc, "sogm_set_overlap_clear")
-        check(lib().sogm_set_overlap_clear(self._ctx, 1), "sogm_set_overlap_clear")
-        return 1
+        return 0
 
     def isTrajSafe(self, records, t_now, check_duration):
         """BaselinePlanner::isTrajSafe for every agent's executed trajectory (device uint8 [A, 2064])."""

@@ -1,6 +1,7 @@
 """Tick pipelining must not change results: the trajectories of a short closed-loop run are identical whether
-the SOGM is cleared in stream order, pre-cleared in place under the QP stage (mode 1) or double-buffered with
-the narrow clear running beside the whole replan (mode 2)."""
+the SOGM is cleared in stream order, pre-cleared in place under the QP stage (mode 1), double-buffered with
+the narrow clear running beside the whole replan (mode 2) or triple-buffered (mode 3: every clear has a whole tick
+of slack).  Also: switching modes in the middle of a run, and updates without a replan in between."""
 import importlib
 
 import numpy as np
@@ -9,12 +10,18 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def _run(overlap, double_buffer, ticks=5):
+def _run(overlap, double_buffer, ticks=7, grids=None, switch=None):
     import torch
     driver = importlib.import_module("pred-occ-planner_amd.driver")
-    sw = driver.SwarmTick("parity", 8, overlap_clear=overlap, double_buffer=double_buffer)
+    sw = driver.SwarmTick("parity", 8, overlap_clear=overlap, double_buffer=double_buffer, grids=grids)
     oks = []
-    for _ in range(ticks):
+    for k in range(ticks):
+        if switch and k in switch:  # change the pipelining mode in mid-flight
+            sw.overlap_mode = sw.map.set_overlap_clear(True, grids=switch[k])
+        if switch and k == 4:       # two map updates in a row (no replan in between): the second one re-clears
+            st = torch.full((8,), sw.t0 + sw.tick * 0.1, dtype=torch.float64, device="cuda")
+            sw.map.updateMap(sw.dev["cloud"], sw.dev["cloud_range"], sw.dev["cylinders"], sw.dev["n_cyl"],
+                             sw.dev["poses"], st)
         oks.append(int(sw.step().sum().item()))
     torch.cuda.synchronize()
     own = sw.own.cpu().numpy().copy()
@@ -29,10 +36,12 @@ def _run(overlap, double_buffer, ticks=5):
 def test_pipelining_modes_agree():
     m0, ok0, own0, all0, g0 = _run(False, False)
     m1, ok1, own1, all1, _ = _run(True, False)
-    m2, ok2, own2, all2, g2 = _run(True, True)
-    assert (m0, m1, m2) == (0, 1, 2)
-    assert ok0 == ok1 == ok2 and sum(ok0) > 0
-    assert np.array_equal(own0, own1) and np.array_equal(own0, own2)
-    assert np.array_equal(all0, all1) and np.array_equal(all0, all2)
-    assert np.array_equal(g0, g2)
+    m2, ok2, own2, all2, g2 = _run(True, None, grids=2)
+    m3, ok3, own3, all3, g3 = _run(True, None, grids=3)
+    ms, oks, owns, alls, gs = _run(True, None, grids=3, switch={2: 2, 3: 1, 5: 3})
+    assert (m0, m1, m2, m3, ms) == (0, 1, 2, 3, 3)
+    assert ok0 == ok1 == ok2 == ok3 == oks and sum(ok0) > 0
+    for own, allr in ((own1, all1), (own2, all2), (own3, all3), (owns, alls)):
+        assert np.array_equal(own0, own) and np.array_equal(all0, allr)
+    assert np.array_equal(g0, g2) and np.array_equal(g0, g3) and np.array_equal(g0, gs)
     print("pipelining modes agree over", len(ok0), "ticks; replans ok per tick", ok0)
