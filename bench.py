@@ -161,8 +161,8 @@ def main():
     ms_stage = sw.map.profile_read()
     avg = np.array([float(per_slot[k].mean()) if len(per_slot[k]) else -1.0 for k in range(pop._abi.PROF_N)])
     n_clear = int(len(per_slot[0]))
-    if overlap_mode == 1 and avg[6] > 0:
-        avg[0] += avg[6]  # single-grid mode clears in two launches (narrow head + full-width rest): one clear = both
+    if avg[6] > 0:
+        avg[0] += avg[6]  # the clear of one grid = two launches (narrow head + full-width rest): one clear = both
     avg[3:6] = ms_stage[3:6]  # planner stages: single-stage entry points after the timed region (inside sogm_replan
     #                           they run concurrently on per-group streams and cannot be timed one by one)
     grid_bytes = sw.map.grid_bytes()  # V * T * 4 bytes x agents of this rank = algorithmic bytes / launch

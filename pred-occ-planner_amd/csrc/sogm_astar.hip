@@ -282,7 +282,11 @@ __global__ __launch_bounds__(ASTAR_THREADS) void k_astar(
   const int tid   = threadIdx.x;
   // dataflow replan: tell the gate kernel that this workgroup holds its CU resources (the corridor kernel's
   // waiting workgroups must not be dispatched before every search is resident, or they could starve it)
-  if (fc.hdr && tid == 0) atomicAdd(&fc.hdr[FLOW_A_RESIDENT], 1);
+  if (fc.hdr && tid == 0) {
+    atomicAdd(&fc.hdr[FLOW_A_RESIDENT], 1);
+    fc.ts[agent * 8 + 0] = wall_clock64();
+    fc.ts[agent * 8 + 2] = 0;
+  }
 
   __shared__ double             s_f[ASTAR_POOL_MAX];     // f-score mirror of every allocated node
   __shared__ unsigned short     s_heap[ASTAR_POOL_MAX];  // open list
@@ -835,6 +839,7 @@ __global__ __launch_bounds__(ASTAR_THREADS) void k_astar(
       for (int k = 0; k < 6; ++k) wsp.dbg[(size_t)agent * 8 + k] = tk[k];
     if (out_trace && n_trace < trace_cap) out_trace[(size_t)agent * trace_cap + n_trace] = -1;
     if (fc.hdr) {  // publish the agent, in completion order, to the corridor kernel
+      fc.ts[agent * 8 + 1] = wall_clock64();
       __threadfence();
       const int r = atomicAdd(&fc.hdr[FLOW_A_READY_N], 1);
       __hip_atomic_store(fc.a_ready + r, agent, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
@@ -850,7 +855,7 @@ int launch_astar(const MapView &m, const SogmAstarParams &ap, double corridor_ta
                  const double *goal, const double *t_start, int32_t *out_ret, double *out_route,
                  int32_t *out_route_len, int route_cap, int32_t *out_stats, int32_t *out_trace,
                  int trace_cap, hipStream_t st, int agent0, const FlowCtl *fc) {
-  const FlowCtl none{nullptr, nullptr, nullptr, nullptr, nullptr};
+  const FlowCtl none{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   hipLaunchKernelGGL(k_astar, dim3(n_agents), dim3(ASTAR_THREADS), 0, st, m, ap, corridor_tau, wsp,
                      start_pva, goal, t_start, out_ret, out_route, out_route_len, route_cap,
                      out_stats, out_trace, trace_cap, agent0, fc ? *fc : none);

@@ -1590,9 +1590,14 @@ __global__ __launch_bounds__(64) void k_corridor_finalize(
 __device__ inline int flow_wait_slot(int *slot, int *err) {
   const long long t0 = wall_clock64();
   for (;;) {
-    const int v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(slot, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT));
-    if (v >= 0) return v;
-    __builtin_amdgcn_s_sleep(32);
+    // relaxed agent-scope poll (an sc1 load); ONE acquire fence once the value is there (an acquire per poll would
+    // invalidate the CU's L1 every microsecond)
+    const int v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    if (v >= 0) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      return v;
+    }
+    __builtin_amdgcn_s_sleep(64);
     if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0)
       return -1;
     if (wall_clock64() - t0 > FLOW_TIMEOUT_TICKS) {
@@ -1622,6 +1627,7 @@ __global__ __launch_bounds__(64) void k_corridor_flow(MapView m, SogmPlannerPara
     if (agent < 0) break;  // timed out / another kernel failed: drain
     __threadfence();        // the search's outputs (route, route_len) were published before the ready slot
     const int seg = k % SOGM_MAX_PIECES;
+    if (seg == 0 && lane == 0) fc.ts[agent * 8 + 2] = wall_clock64();
     if (seg < route_len[agent] - 1) {
       corridor_points_body<1>(m, pp, ws, start_pva, t_start, route, route_len, route_cap, agent, seg);
       __threadfence_block();
@@ -1640,6 +1646,7 @@ __global__ __launch_bounds__(64) void k_corridor_flow(MapView m, SogmPlannerPara
       corridor_finalize_body(pp, ws, start_pva, route, route_len, route_cap, out_polys, out_nfaces, out_npoly,
                              out_goal, agent, sc);
       __syncthreads();
+      if (lane == 0) fc.ts[agent * 8 + 3] = wall_clock64();
       __threadfence();
       if (lane == 0) {
         const int r = atomicAdd(&fc.hdr[FLOW_Q_READY_N], 1);
@@ -1847,6 +1854,7 @@ __global__ __launch_bounds__(64) void k_finish_flow(FlowCtl fc, double corridor_
       r.time_start = t_start[a];
       r.n_pieces   = good ? M : 0;
       out_ok[a]    = good ? 1 : 0;
+      fc.ts[a * 8 + 6] = wall_clock64();
       if (counters) {
         int k = SOGM_CNT_REPLAN_OK;
         if (ret[a] == 0) k = SOGM_CNT_FAIL_SEARCH;

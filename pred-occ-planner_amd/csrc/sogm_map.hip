@@ -568,9 +568,30 @@ int adopt_preclear(sogm_ctx *c, hipStream_t st) {
 int queue_spare_clears(sogm_ctx *c, hipEvent_t after) {
   if (c->overlap < 2 || c->n_dirty == 0) return SOGM_OK;
   SOGM_HIP_CHECK(hipStreamWaitEvent(c->side, after, 0));
+  // The clear shares the machine with the whole replan, as ONE narrow launch by default.  SOGM_CLEAR_HEAD_GB (a
+  // tuning aid) splits it into a narrow head of that many GB and a full-width rest: measured with the dataflow
+  // replan (profiles/r02_*), a wide rest shortens the clear (15.9 -> 14.3 ms) but costs the planner kernels more
+  // than it saves (tick 18.2 -> 19.3 ms), because per-agent chaining spreads the global-memory phases (searches,
+  // point scans, FIRI set-up of late agents) over the whole tick.
+  static double head_gb = -1.0;
+  if (head_gb < 0) {
+    const char *e = getenv("SOGM_CLEAR_HEAD_GB");
+    head_gb       = e ? atof(e) : 1.0e9;
+  }
+  const size_t total = clear_vec4_total(c);
+  size_t       head  = (size_t)(head_gb * 1e9 / 16.0);
+  if (head > total) head = total;
   for (int i = 0; i < c->n_dirty; ++i) {
     const int g  = c->dirty[i];
-    int       rc = launch_clear(c, c->side, c->pool[g], true);
+    int       rc = SOGM_OK;
+    if (head == 0) {
+      rc = launch_clear(c, c->side, c->pool[g], false);
+    } else if (head >= total) {
+      rc = launch_clear(c, c->side, c->pool[g], true);
+    } else {
+      rc = launch_clear(c, c->side, c->pool[g], true, 1, head);
+      if (!rc) rc = launch_clear(c, c->side, c->pool[g], false, 2, head);
+    }
     if (rc) return rc;
     SOGM_HIP_CHECK(hipEventRecord(c->pool_ev[g], c->side));
     c->ready[c->n_ready++] = g;

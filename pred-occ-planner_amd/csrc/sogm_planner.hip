@@ -173,6 +173,9 @@ int sogm_planner_create(sogm_ctx *map, const SogmAstarParams *astar, const SogmP
     p->fc.a_ready  = p->fc.seg_done + A;
     p->fc.q_ready  = p->fc.a_ready + A;
     p->fc.f_ready  = p->fc.q_ready + A;
+    if (e == hipSuccess) e = hipMalloc((void **)&p->d_flow_ts, sizeof(long long) * 8 * (size_t)A);
+    if (e == hipSuccess) e = hipMemset(p->d_flow_ts, 0, sizeof(long long) * 8 * (size_t)A);
+    p->fc.ts = p->d_flow_ts;
     for (int k = 0; k < 4 && e == hipSuccess; ++k) {
       e = hipStreamCreateWithFlags(&p->fstream[k], hipStreamNonBlocking);
       if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_fdone[k], hipEventDisableTiming);
@@ -195,7 +198,7 @@ void sogm_planner_destroy(sogm_planner *p) {
                   p->cw.seg_nfaces, p->cw.seg_state, p->cw.seg_npts, p->cw.seg_dbg, p->cw.counters,
                   p->qw.scratch,
                   p->d_polys, p->d_goal, p->d_cpts, p->d_nfaces, p->d_npoly, p->d_status, p->d_iters,
-                  p->d_safe,  p->d_flow};
+                  p->d_safe,  p->d_flow, p->d_flow_ts};
   for (void *q : ptrs)
     if (q) (void)hipFree(q);
   for (int g = 0; g < SOGM_MAX_GROUPS; ++g) {
@@ -332,6 +335,14 @@ int sogm_debug_flow_peek(sogm_planner *p, int *out_host, int n) {
   if (n > nf)  // followed by d_safe (progress markers in debug builds)
     SOGM_HIP_CHECK(hipMemcpyAsync(out_host + nf, p->d_safe, sizeof(int) * (size_t)(n - nf), hipMemcpyDeviceToHost, peek));
   SOGM_HIP_CHECK(hipStreamSynchronize(peek));
+  return SOGM_OK;
+}
+
+// diagnostics (tools/ only): per-agent stage timestamps of the last dataflow replan, [A][8] ticks of 10 ns
+int sogm_debug_flow_times(sogm_planner *p, long long *out_host) {
+  if (!p || !out_host) return SOGM_ERR_INVALID_ARG;
+  SOGM_HIP_CHECK(hipDeviceSynchronize());
+  SOGM_HIP_CHECK(hipMemcpy(out_host, p->d_flow_ts, sizeof(long long) * 8 * (size_t)p->map->n_agents, hipMemcpyDeviceToHost));
   return SOGM_OK;
 }
 

@@ -42,6 +42,8 @@ struct FlowCtl {
   int *a_ready;   // [A]
   int *q_ready;   // [A]
   int *f_ready;   // [A] agents in QP completion order
+  long long *ts;  // [A][8] wall_clock64 stamps (100 MHz): 0 A* start, 1 A* done, 2 first corridor item taken,
+                  //        3 corridors final, 4 QP start, 5 QP done, 6 finished (diagnostics, always written)
 };
 
 // ParticleATC::isSafeAfterOpt for agents [agent0, agent0 + n_agents): out_safe[a] = 1 / 0
@@ -129,6 +131,7 @@ struct sogm_planner {
   // dataflow replan (persistent kernels chained per agent through device-side ready lists)
   int            flow;        // 1 = use it (pipelining modes other than the in-place pre-clear)
   int           *d_flow;      // FLOW_HDR + 4 A ints: header, seg_done, a_ready, q_ready, f_ready
+  long long     *d_flow_ts;   // [A][8]
   sogm::FlowCtl  fc;
   hipStream_t    fstream[4];  // A*, corridors, QP, finish
   hipEvent_t     ev_gate, ev_fdone[4];

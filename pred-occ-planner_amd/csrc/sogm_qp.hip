@@ -1278,8 +1278,8 @@ __global__ __launch_bounds__(QP_NT) void k_qp_flow(SogmPlannerParams pp, SogmQpS
       const int k = atomicAdd(&fc.hdr[FLOW_Q_TICKET], 1);
       if (k < n_agents) {
         const long long t0 = wall_clock64();
-        while ((a = __hip_atomic_load(fc.q_ready + k, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) < 0) {
-          __builtin_amdgcn_s_sleep(64);
+        while ((a = __hip_atomic_load(fc.q_ready + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < 0) {
+          __builtin_amdgcn_s_sleep(127);
           if (__hip_atomic_load(&fc.hdr[FLOW_ERR], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
           if (wall_clock64() - t0 > FLOW_TIMEOUT_TICKS) {
             atomicExch(&fc.hdr[FLOW_ERR], 3);
@@ -1293,9 +1293,11 @@ __global__ __launch_bounds__(QP_NT) void k_qp_flow(SogmPlannerParams pp, SogmQpS
     const int agent = __builtin_amdgcn_readfirstlane(s_agent);  // uniform: a scalar branch
     if (agent < 0) break;  // no tickets left, or the tick failed
     __threadfence();       // corridor outputs were published before the ready slot
+    if (threadIdx.x == 0) fc.ts[agent * 8 + 4] = wall_clock64();
     qp_solve_agent(pp, qs, ws, qc, start_pva, goal_pv, polys, nfaces, npoly, out_cpts, out_status, out_iters,
                    ablate_arg, agent);
     __syncthreads();
+    if (threadIdx.x == 0) fc.ts[agent * 8 + 5] = wall_clock64();
     __threadfence();
     if (threadIdx.x == 0) {
       const int r = atomicAdd(&fc.hdr[FLOW_F_READY_N], 1);
