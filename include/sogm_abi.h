@@ -321,7 +321,7 @@ typedef struct sogm_dsp sogm_dsp;
  * host p_gauss[n_gauss] (position noise, N(0, 0.05)), v_gauss[n_gauss] (velocity noise),
  * rand_tab[n_rand] (values of rand(), 0..RAND_MAX).  The tables are read cyclically.
  * max_points: capacity of one agent's cloud (5000 in MapBase::filterPointCloud, map.cpp:126).
- * Particle store per agent: V x 16 slots x 25 B (SoA) — SOGM_ERR_HIP if it does not fit in HBM.
+ * Particle store per agent: V x 16 slots x 25 B (SoA) — SOGM_ERR_HIP if it does not fit in HBM.  max_points <= 8192.
  */
 int  sogm_dsp_create(sogm_ctx *map, const SogmDspParams *params, const float *p_gauss,
                      const float *v_gauss, int n_gauss, const int32_t *rand_tab, int n_rand,
@@ -333,9 +333,14 @@ void sogm_dsp_destroy(sogm_dsp *d);
  * mapPrediction (:663), mapUpdate (:750), mapAddNewBornParticlesByObservation (:852),
  * mapOccupancyCalculationAndResample (:993).  Stream-ordered, no host round trip.
  * dev points  [n_total*3] fp32  sensor-frame points, already voxel-filtered (MapBase::filterPointCloud)
- * dev labels  [n_total*4] fp32  {vx, vy, vz, intensity} per point = the output of
- *             velocityEstimationThread (:1487-1678; PCL clustering + Munkres — not restated);
- *             new-born particles are created in the order the points are given
+ * dev labels  [n_total*4] fp32  {vx, vy, vz, intensity} per point = an externally supplied output of
+ *             velocityEstimationThread (new-born particles are then created in the order the points are given),
+ *             or NULL: velocityEstimationThread (:1487-1678) runs on the GPU — ground split, Euclidean
+ *             clustering (tolerance 2 x 0.15 m, 5..10000 points; PCL's seed / size order), centres, gated
+ *             optimal assignment to the previous frame's clusters (Munkres' role), velocity = centre
+ *             displacement / dt, and the new-born list in the reference's order [possibly-dynamic clusters]
+ *             [ground points][static clusters].  Needs a voxel-filtered cloud (<= 128 neighbours within the
+ *             tolerance, <= 256 clusters, <= 64 possibly-dynamic ones; beyond: an error counter, never a hang)
  * dev cloud_range [n_agents*2] int32 {begin,end} points of each agent
  * dev sensor_pos [n_agents*3] fp32, dev sensor_quat [n_agents*4] fp32 (w,x,y,z), dev stamps [n_agents] fp64
  * dev out_ok  [n_agents] int32: DSPMap::update's return value (0 = rejected odometry, :186-203)
@@ -360,6 +365,9 @@ int sogm_dsp_publish(sogm_dsp *d, int32_t *out_n_occupied, void *stream);
  * pool_overflow, ...}.  Any pointer may be NULL. */
 int sogm_dsp_download_state(sogm_dsp *d, int agent, float *store_host, float *objnum_host,
                             int32_t *counters_host);
+/* input_cloud_with_velocity of the last update (the new-born list, rows {x,y,z,vx,vy,vz,intensity}, at most `cap`
+ * rows), its length, and counters4 = {clusters, possibly dynamic, matched, error code of the velocity estimation}. */
+int sogm_dsp_download_born(sogm_dsp *d, int agent, float *born_host, int cap, int32_t *n_born, int32_t *counters4);
 /* Observation tables of the last update: nobs[n_pyramids], pc[n_pyramids*obs_max*5], maxlen[n_pyramids] */
 int sogm_dsp_download_observations(sogm_dsp *d, int agent, int32_t *nobs_host, float *pc_host,
                                    float *maxlen_host);

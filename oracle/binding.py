@@ -298,11 +298,19 @@ class DspOracle:
         self.S = 2 * params.max_particle_num_voxel
 
     def update(self, points, labels, pos, quat, stamp):
-        pts = np.ascontiguousarray(points, np.float32)
-        lab = np.ascontiguousarray(labels, np.float32)
-        return lib().orc_dsp_update(self.h, len(pts), fptr(pts), fptr(lab), C.c_float(pos[0]), C.c_float(pos[1]),
+        """labels=None: velocityEstimationThread runs inside the oracle (clustering + association)."""
+        pts = np.ascontiguousarray(points, np.float32).reshape(-1, 3)
+        lab = np.ascontiguousarray(labels, np.float32) if labels is not None else None
+        return lib().orc_dsp_update(self.h, len(pts), fptr(pts), fptr(lab) if lab is not None else None,
+                                    C.c_float(pos[0]), C.c_float(pos[1]),
                                     C.c_float(pos[2]), C.c_double(stamp), C.c_float(quat[0]), C.c_float(quat[1]),
                                     C.c_float(quat[2]), C.c_float(quat[3]))
+
+    def born(self, cap=8192):
+        out = np.zeros((cap, 7), np.float32)
+        cnt = (C.c_int * 3)()
+        n = lib().orc_dsp_born(self.h, fptr(out), cap, cnt)
+        return out[:n].copy(), list(cnt)
 
     def publish(self, threshold, inf_step):
         out = np.zeros((self.V, self.spec.T), np.float32)

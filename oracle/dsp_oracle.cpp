@@ -14,6 +14,7 @@
 //     matching (velocityEstimationThread, dsp_dynamic.h:1487-1678) — are inputs;
 //   * rotateVectorByQuaternion (:1391-1411) uses Eigen's quaternion product; the scalar formula of
 //     Eigen's generic (non-SIMD) product is restated below.
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -49,6 +50,14 @@ struct Dsp {
   double             last_t;
   std::vector<float> born;  // input_cloud_with_velocity: x,y,z,nx,ny,nz,intensity per point
   std::vector<float> rotated;
+  // velocityEstimationThread's function-local static (:1511): the previous frame's possibly-dynamic clusters
+  struct ClusterFeature {  // :70-81
+    float center_x = 0.f, center_y = 0.f, center_z = 0.f;
+    int   point_num = 0, match_cluster_seq = -1;
+    float vx = -10000.f, vy = -10000.f, vz = -10000.f, v = 0.f, intensity = 0.f;
+  };
+  std::vector<ClusterFeature> clusters_last;
+  int                         dbg_clusters = 0, dbg_dynamic = 0, dbg_matched = 0;
   int                dbg_voxel_full = 0, dbg_pyr_full = 0, dbg_out = 0, dbg_vel_draws = 0;
 
   float *slot(int v, int p) { return &store[((size_t)v * S + p) * 9]; }
@@ -517,8 +526,222 @@ void *orc_dsp_create(const SogmSpec *spec, const SogmDspParams *P, const float *
 
 void orc_dsp_destroy(void *h) { delete (Dsp *)h; }
 
+// Minimum-cost assignment of rows to columns (rows <= cols), potentials form of the Hungarian method with a fixed
+// scan order.  Stands for munkres-cpp's Munkres<float>::solve (external, /usr/local/lib/libmunkres.a, absent):
+// any exact solver returns the same assignment when the optimum is unique, which it is for real-valued cluster
+// distances; ties are resolved by this scan order on both sides (oracle and kernel).  asg[r] = column of row r.
+void assign_min_cost(const std::vector<float> &cost, int rows, int cols, std::vector<int> &asg) {
+  const float      INF = 3.0e38f;
+  std::vector<float> u(rows + 1, 0.f), v(cols + 1, 0.f), minv(cols + 1);
+  std::vector<int>   p(cols + 1, 0), way(cols + 1, 0);
+  std::vector<char>  used(cols + 1);
+  for (int i = 1; i <= rows; ++i) {
+    p[0]   = i;
+    int j0 = 0;
+    for (int j = 0; j <= cols; ++j) {
+      minv[j] = INF;
+      used[j] = 0;
+    }
+    do {
+      used[j0]    = 1;
+      const int i0 = p[j0];
+      float     delta = INF;
+      int       j1 = 0;
+      for (int j = 1; j <= cols; ++j)
+        if (!used[j]) {
+          const float cur = cost[(size_t)(i0 - 1) * cols + (j - 1)] - u[i0] - v[j];
+          if (cur < minv[j]) {
+            minv[j] = cur;
+            way[j]  = j0;
+          }
+          if (minv[j] < delta) {
+            delta = minv[j];
+            j1    = j;
+          }
+        }
+      for (int j = 0; j <= cols; ++j)
+        if (used[j]) {
+          u[p[j]] += delta;
+          v[j] -= delta;
+        } else {
+          minv[j] -= delta;
+        }
+      j0 = j1;
+    } while (p[j0] != 0);
+    do {
+      const int j1 = way[j0];
+      p[j0]        = p[j1];
+      j0           = j1;
+    } while (j0);
+  }
+  asg.assign(rows, -1);
+  for (int j = 1; j <= cols; ++j)
+    if (p[j] > 0) asg[p[j] - 1] = j - 1;
+}
+
+// velocityEstimationThread (dsp_dynamic.h:1487-1678): ground split, pcl::EuclideanClusterExtraction (tolerance
+// 2 x voxel_filtered_resolution, 5 <= size <= 10000), per-cluster centre, association with the previous frame's
+// possibly-dynamic clusters (gated distance cost, optimal assignment), velocity = centre displacement / dt, and
+// input_cloud_with_velocity = [points of possibly-dynamic clusters, cluster by cluster][ground points][points of
+// static clusters].  Third-party pieces restated from their published behaviour (PCL / FLANN / munkres-cpp are
+// absent here: parity unpinned):
+//   * pcl::extractEuclideanClusters: seeds in index order, breadth-first growth by radius search, a cluster's
+//     indices sorted ascending, clusters below min size dropped (their points stay "processed");
+//   * radius search = FLANN L2_Simple squared distance in float, accepted when strictly below
+//     (float)(tolerance^2) with the tolerance held as double (KdTreeFLANN::radiusSearch);
+//   * EuclideanClusterExtraction::extract then orders the clusters with
+//     std::sort(clusters.rbegin(), clusters.rend(), comparePointClusters) (size ascending over the REVERSED range
+//     = largest first; equal sizes in whatever order libstdc++'s introsort leaves them — called here directly);
+//   * the visualisation intensity generateRandomFloat(0.1, 1) (:1531) is replaced by the constant 0.55 and draws
+//     nothing from rand(): in the reference that draw races with the filter thread's own rand() calls
+//     (std::thread at :305); only "intensity > 0.01" is ever consumed (:903-913).
+void velocityEstimation(Dsp &d) {
+  const int n = (int)d.rotated.size() / 3;
+  if (n == 0) return;  // :1488
+  d.born.clear();
+  const float vres = 0.15f;  // voxel_filtered_resolution (:105)
+  std::vector<float> stat;   // static_points xyz
+  std::vector<float> ng;     // non_ground_points xyz
+  for (int s = 0; s < n; ++s) {
+    const float x = d.rotated[s * 3] + d.cur[0], y = d.rotated[s * 3 + 1] + d.cur[1], z = d.rotated[s * 3 + 2] + d.cur[2];
+    std::vector<float> &dst = z > vres ? ng : stat;
+    dst.push_back(x);
+    dst.push_back(y);
+    dst.push_back(z);
+  }
+  std::vector<Dsp::ClusterFeature> dyn;
+  const int m = (int)ng.size() / 3;
+  if (m > 0) {
+    const double tol = (double)(2 * vres);
+    const float  r2  = (float)(tol * tol);
+    std::vector<std::vector<int>> clusters;
+    std::vector<char>             processed(m, 0);
+    for (int i = 0; i < m; ++i) {
+      if (processed[i]) continue;
+      std::vector<int> q(1, i);
+      processed[i] = 1;
+      for (size_t sq = 0; sq < q.size(); ++sq) {
+        const float *a = &ng[(size_t)q[sq] * 3];
+        for (int j = 0; j < m; ++j) {
+          if (processed[j]) continue;
+          const float *b  = &ng[(size_t)j * 3];
+          float        d2 = 0.f;
+          for (int k = 0; k < 3; ++k) {
+            const float df = a[k] - b[k];
+            d2 += df * df;
+          }
+          if (d2 < r2) {
+            processed[j] = 1;
+            q.push_back(j);
+          }
+        }
+      }
+      if (q.size() >= 5 && q.size() <= 10000) {
+        std::sort(q.begin(), q.end());
+        clusters.push_back(q);
+      }
+    }
+    std::sort(clusters.rbegin(), clusters.rend(),
+              [](const std::vector<int> &a, const std::vector<int> &b) { return a.size() < b.size(); });
+    d.dbg_clusters = (int)clusters.size();
+    std::vector<char> possibly_dynamic;
+    for (const auto &ci : clusters) {
+      Dsp::ClusterFeature c;
+      c.intensity = 0.55f;
+      for (int idx : ci) {
+        c.center_x += ng[(size_t)idx * 3];
+        c.center_y += ng[(size_t)idx * 3 + 1];
+        c.center_z += ng[(size_t)idx * 3 + 2];
+        ++c.point_num;
+      }
+      c.center_x /= (float)c.point_num;
+      c.center_y /= (float)c.point_num;
+      c.center_z /= (float)c.point_num;
+      if (ci.size() > 200 || c.center_z > 1.5) {  // DYNAMIC_CLUSTER_MAX_POINT_NUM / _MAX_CENTER_HEIGHT
+        for (int idx : ci)
+          for (int k = 0; k < 3; ++k) stat.push_back(ng[(size_t)idx * 3 + k]);
+        possibly_dynamic.push_back(0);
+      } else {
+        dyn.push_back(c);
+        possibly_dynamic.push_back(1);
+      }
+    }
+    d.dbg_dynamic = (int)dyn.size();
+    d.dbg_matched = 0;
+    const float distance_gate = 1.5f, maximum_velocity = 5.f;
+    const int   point_num_gate = 100;
+    if (!d.clusters_last.empty() && !dyn.empty() && d.dt_last > 0.00001 && d.dt_last < 10.0) {
+      const int R = (int)dyn.size(), C = (int)d.clusters_last.size();
+      std::vector<float> cost((size_t)R * C), gate((size_t)R * C);
+      for (int r = 0; r < R; ++r)
+        for (int c = 0; c < C; ++c) {
+          const Dsp::ClusterFeature &a = dyn[r], &b = d.clusters_last[c];
+          const float sq = (a.center_x - b.center_x) * (a.center_x - b.center_x) +
+                           (a.center_y - b.center_y) * (a.center_y - b.center_y) +
+                           (a.center_z - b.center_z) * (a.center_z - b.center_z);
+          const float dist = sqrtf(sq);
+          if (abs(a.point_num - b.point_num) > point_num_gate || dist >= distance_gate) {
+            gate[(size_t)r * C + c] = 0.f;
+            cost[(size_t)r * C + c] = distance_gate * 5000.f;
+          } else {
+            gate[(size_t)r * C + c] = 1.f;
+            cost[(size_t)r * C + c] = dist / distance_gate * 1000.f;
+          }
+        }
+      // optimal assignment (rows <= cols for the solver: transpose when there are more new clusters than old)
+      std::vector<int> col_of_row(R, -1);
+      if (R <= C) {
+        assign_min_cost(cost, R, C, col_of_row);
+      } else {
+        std::vector<float> ct((size_t)C * R);
+        for (int r = 0; r < R; ++r)
+          for (int c = 0; c < C; ++c) ct[(size_t)c * R + r] = cost[(size_t)r * C + c];
+        std::vector<int> row_of_col;
+        assign_min_cost(ct, C, R, row_of_col);
+        for (int c = 0; c < C; ++c)
+          if (row_of_col[c] >= 0) col_of_row[row_of_col[c]] = c;
+      }
+      for (int r = 0; r < R; ++r) {
+        const int c = col_of_row[r];
+        if (c < 0 || !(gate[(size_t)r * C + c] > 0.01f)) continue;  // :1591
+        Dsp::ClusterFeature &f = dyn[r];
+        f.match_cluster_seq = c;
+        f.vx = (f.center_x - d.clusters_last[c].center_x) / d.dt_last;
+        f.vy = (f.center_y - d.clusters_last[c].center_y) / d.dt_last;
+        f.vz = (f.center_z - d.clusters_last[c].center_z) / d.dt_last;
+        f.v  = sqrtf(f.vx * f.vx + f.vy * f.vy + f.vz * f.vz);
+        f.intensity = d.clusters_last[c].intensity;
+        if (f.v > maximum_velocity) {
+          f.v  = 0.f;
+          f.vx = f.vy = f.vz = 0.f;
+        }
+        ++d.dbg_matched;
+      }
+    }
+    // velocity allocation to points (:1625-1650)
+    int dseq = 0;
+    for (size_t ci = 0; ci < clusters.size(); ++ci) {
+      if (!possibly_dynamic[ci]) continue;
+      for (int idx : clusters[ci]) {
+        for (int k = 0; k < 3; ++k) d.born.push_back(ng[(size_t)idx * 3 + k]);
+        d.born.push_back(dyn[dseq].vx);
+        d.born.push_back(dyn[dseq].vy);
+        d.born.push_back(dyn[dseq].vz);
+        d.born.push_back(dyn[dseq].intensity);
+      }
+      ++dseq;
+    }
+  }
+  for (size_t k = 0; k + 3 <= stat.size(); k += 3) {  // :1653-1663
+    for (int j = 0; j < 3; ++j) d.born.push_back(stat[k + j]);
+    for (int j = 0; j < 4; ++j) d.born.push_back(0.f);
+  }
+  d.clusters_last = dyn;  // :1665 (also when empty)
+}
+
 // DSPMap::update (:165-364).  pts: n x 3 sensor-frame points; labels: n x 4 {vx,vy,vz,intensity}
-// standing for velocityEstimationThread's output (points are born in the given order).
+// standing for velocityEstimationThread's output (points are born in the given order), or NULL: the
+// velocity estimation runs here (velocityEstimation above).
 int orc_dsp_update(void *h, int n, const float *pts, const float *labels, float px, float py,
                    float pz, double stamp, float qw, float qx, float qy, float qz) {
   Dsp &d = *(Dsp *)h;
@@ -577,7 +800,9 @@ int orc_dsp_update(void *h, int n, const float *pts, const float *labels, float 
   d.new_born_each_object_weight = d.P.newborn_weight * (float)d.P.newborn_num;
   // velocityEstimationThread (:1487-1678) replaced by the supplied labels; like the reference it
   // leaves input_cloud_with_velocity untouched when the cloud is empty (:1488).
-  if (n > 0) {
+  if (!labels) {
+    velocityEstimation(d);
+  } else if (n > 0) {
     d.born.clear();
     for (int s = 0; s < n; ++s) {
       d.born.push_back(d.rotated[s * 3 + 0] + d.cur[0]);
@@ -635,6 +860,21 @@ void orc_dsp_state(void *h, float *store, float *objnum, int *counters) {
   }
 }
 // per-pyramid observation table of the last update: nobs[NP], pc [NP][OM][5]
+// input_cloud_with_velocity of the last update: rows {x, y, z, vx, vy, vz, intensity}; returns the row count;
+// counters3 = {clusters, possibly dynamic, matched}
+int orc_dsp_born(void *h, float *out, int cap, int *counters3) {
+  Dsp      &d = *(Dsp *)h;
+  const int n = (int)d.born.size() / 7;
+  if (out)
+    for (int i = 0; i < n * 7 && i < cap * 7; ++i) out[i] = d.born[i];
+  if (counters3) {
+    counters3[0] = d.dbg_clusters;
+    counters3[1] = d.dbg_dynamic;
+    counters3[2] = d.dbg_matched;
+  }
+  return n;
+}
+
 void orc_dsp_observations(void *h, int *nobs, float *pc, float *maxlen) {
   Dsp &d = *(Dsp *)h;
   if (nobs) memcpy(nobs, d.nobs.data(), d.nobs.size() * sizeof(int));

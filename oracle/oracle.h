@@ -134,6 +134,9 @@ int   orc_dsp_update(void *h, int n, const float *pts, const float *labels, floa
 int   orc_dsp_publish(void *h, float *out_vt, float threshold, int inf_step);
 void  orc_dsp_state(void *h, float *store, float *objnum, int *counters);
 void  orc_dsp_observations(void *h, int *nobs, float *pc, float *maxlen);
+/* orc_dsp_update with labels == NULL runs velocityEstimationThread (dsp_dynamic.h:1487-1678) itself.
+ * orc_dsp_born: input_cloud_with_velocity of the last update, rows {x,y,z,vx,vy,vz,intensity} */
+int   orc_dsp_born(void *h, float *out, int cap, int *counters3);
 
 /* ---- a7: MapBase::filterPointCloud (plan_env/src/map.cpp:107-132) with pcl::VoxelGrid restated ---- */
 /* returns the number of output points (<= cap); out_xyz cap*3 */

@@ -156,6 +156,7 @@ PROTOTYPES = {
     "sogm_update_dsp": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sogm_dsp_publish": (_i, [_vp, _vp, _vp]),
     "sogm_dsp_download_state": (_i, [_vp, _i, _vp, _vp, _vp]),
+    "sogm_dsp_download_born": (_i, [_vp, _i, _vp, _i, _vp, _vp]),
     "sogm_dsp_download_observations": (_i, [_vp, _i, _vp, _vp, _vp]),
 }
 

@@ -41,6 +41,10 @@ enum : uint8_t { F_EMPTY = 0, F_VALID = 1, F_RESAMP = 2, F_MOVED = 3, F_NEW = 4,
 #define DSP_SLOTS 16   // storage slots per voxel (>= SAFE_PARTICLE_NUM_VOXEL)
 #define DSP_ROUNDS 6   // place/pyramid fixed-point rounds issued per update
 
+#define VEL_MAX_CLUSTERS 256  // accepted clusters per frame (more: error counter)
+#define VEL_MAX_DYN 64        // possibly-dynamic clusters per frame taking part in the association
+#define VEL_ADJ_CAP 128       // neighbours within the cluster tolerance kept per point
+
 struct DspAgent {  // per-agent scalars (device)
   float  last_p[3];
   int    first;
@@ -59,6 +63,10 @@ struct DspAgent {  // per-agent scalars (device)
   int    dbg_voxel_full, dbg_pyr_full, dbg_out;
   int    err_unconverged, err_pool, err_points;
   int    n_occupied;
+  // velocity estimation (velocityEstimationThread): previous frame's possibly-dynamic clusters and counters
+  int    vel_n_last;
+  int    vel_clusters, vel_dynamic, vel_matched, vel_err;
+  float  vel_last[VEL_MAX_DYN][5];  // centre x, y, z, intensity, point_num (as float)
 };
 
 struct DspDev {
@@ -76,6 +84,8 @@ struct DspDev {
   int      *obs_list;  // [A][max_pts] pi*OM + seq of every stored observation
   float    *bp_h, *bp_v;  // [A][(nph+1)*3], [A][(npv+1)*3]
   float    *born;  // [A][max_pts][7]
+  unsigned short *vel_adj;  // [A][max_pts][VEL_ADJ_CAP] neighbour lists of the clustering (velocity estimation)
+  int            *vel_deg;  // [A][max_pts]
   // candidates of the prediction step (movers + in-FOV stays)
   int     *c_key, *c_dest, *c_pyr, *c_assign, *c_vnext, *c_pnext;  // [A][cand_cap]
   uint8_t *c_kill;                                                 // [A][cand_cap]
@@ -289,7 +299,8 @@ __global__ __launch_bounds__(256) void k_dsp_observe(DspDev d, const float *__re
       born[(size_t)k * 7 + 0] = r[0] + c0;
       born[(size_t)k * 7 + 1] = r[1] + c1;
       born[(size_t)k * 7 + 2] = r[2] + c2;
-      for (int j = 0; j < 4; ++j) born[(size_t)k * 7 + 3 + j] = labels[(size_t)(begin + k) * 4 + j];
+      for (int j = 0; j < 4; ++j)  // labels == NULL: k_dsp_velocity fills (and reorders) the list afterwards
+        born[(size_t)k * 7 + 3 + j] = labels ? labels[(size_t)(begin + k) * 4 + j] : 0.f;
       pi = pyramid_of(s_bh, s_bv, d.nph, d.npv, r[0], r[1], r[2]);
     }
     s_pi[threadIdx.x] = pi;
@@ -325,6 +336,504 @@ __global__ __launch_bounds__(256) void k_dsp_observe(DspDev d, const float *__re
     s.n_obs        = s_nobs;
     s.enb          = d.w_nb * (float)s_valid * (float)d.nb;  // :299-300
     if (n > 0) s.n_born = n;  // velocityEstimationThread returns early on an empty cloud (:1488)
+  }
+}
+
+
+// ---- velocityEstimationThread (:1487-1678) --------------------------------------------------------------
+// One workgroup per agent (see oracle/dsp_oracle.cpp::velocityEstimation for the restated third-party pieces):
+//   ground split -> Euclidean clustering of the non-ground points (connected components under "squared distance
+//   < tolerance^2": neighbour lists by brute force over the LDS-resident cloud, min-label propagation with pointer
+//   jumping; a component's label = its smallest index = PCL's seed) -> clusters ordered like
+//   std::sort(rbegin, rend, size <) (libstdc++'s introsort restated, ties included) -> centres summed in ascending
+//   index order -> gated association with the previous frame's clusters (optimal assignment, same scan order as
+//   the oracle) -> input_cloud_with_velocity rewritten in the reference's order:
+//   [possibly-dynamic clusters][ground points][static clusters].  Points of rejected (small) clusters vanish.
+namespace vel {
+struct Item {
+  int size, id;
+};
+__device__ inline bool less_(const Item &a, const Item &b) { return a.size < b.size; }
+__device__ inline void swap_(Item &a, Item &b) {
+  const Item t = a;
+  a            = b;
+  b            = t;
+}
+// libstdc++ <bits/stl_heap.h> __adjust_heap / __push_heap with comp = less_
+__device__ inline void adjust_heap(Item *f, int hole, int len, Item value) {
+  const int top = hole;
+  int       child = hole;
+  while (child < (len - 1) / 2) {
+    child = 2 * (child + 1);
+    if (less_(f[child], f[child - 1])) child--;
+    f[hole] = f[child];
+    hole    = child;
+  }
+  if ((len & 1) == 0 && child == (len - 2) / 2) {
+    child   = 2 * (child + 1);
+    f[hole] = f[child - 1];
+    hole    = child - 1;
+  }
+  int parent = (hole - 1) / 2;
+  while (hole > top && less_(f[parent], value)) {
+    f[hole] = f[parent];
+    hole    = parent;
+    parent  = (hole - 1) / 2;
+  }
+  f[hole] = value;
+}
+__device__ inline void heap_sort(Item *f, int n) {  // __partial_sort(first, last, last): make_heap + sort_heap
+  if (n >= 2)
+    for (int parent = (n - 2) / 2;; --parent) {
+      adjust_heap(f, parent, n, f[parent]);
+      if (parent == 0) break;
+    }
+  for (int last = n; last > 1; --last) {
+    const Item v = f[last - 1];
+    f[last - 1]  = f[0];
+    adjust_heap(f, 0, last - 1, v);
+  }
+}
+__device__ inline void unguarded_linear_insert(Item *f, int last) {
+  const Item val = f[last];
+  int        next = last - 1;
+  while (less_(val, f[next])) {
+    f[last] = f[next];
+    last    = next;
+    --next;
+  }
+  f[last] = val;
+}
+__device__ inline void insertion_sort(Item *f, int first, int last) {
+  if (first == last) return;
+  for (int i = first + 1; i != last; ++i) {
+    if (less_(f[i], f[first])) {
+      const Item val = f[i];
+      for (int k = i; k > first; --k) f[k] = f[k - 1];
+      f[first] = val;
+    } else {
+      unguarded_linear_insert(f, i);
+    }
+  }
+}
+// std::sort(first, last, less_) of libstdc++ (<bits/stl_algo.h>: __introsort_loop + __final_insertion_sort)
+__device__ inline void std_sort(Item *f, int n) {
+  if (n <= 0) return;
+  int depth = 0;
+  for (int t = n; t > 1; t >>= 1) ++depth;  // __lg(n)
+  depth *= 2;
+  // explicit stack for the recursion on the right part
+  int st_first[40], st_last[40], st_depth[40], sp = 0;
+  int first = 0, last = n, dl = depth;
+  for (;;) {
+    while (last - first > 16) {
+      if (dl == 0) {
+        heap_sort(f + first, last - first);
+        break;
+      }
+      --dl;
+      // __unguarded_partition_pivot
+      const int mid = first + (last - first) / 2;
+      {  // __move_median_to_first(first, first + 1, mid, last - 1)
+        const int a = first + 1, b = mid, c = last - 1;
+        if (less_(f[a], f[b])) {
+          if (less_(f[b], f[c])) swap_(f[first], f[b]);
+          else if (less_(f[a], f[c])) swap_(f[first], f[c]);
+          else swap_(f[first], f[a]);
+        } else if (less_(f[a], f[c])) swap_(f[first], f[a]);
+        else if (less_(f[b], f[c])) swap_(f[first], f[c]);
+        else swap_(f[first], f[b]);
+      }
+      int lo = first + 1, hi = last;
+      for (;;) {  // __unguarded_partition(first + 1, last, first)
+        while (less_(f[lo], f[first])) ++lo;
+        --hi;
+        while (less_(f[first], f[hi])) --hi;
+        if (!(lo < hi)) break;
+        swap_(f[lo], f[hi]);
+        ++lo;
+      }
+      // recurse on [lo, last), continue with [first, lo)
+      st_first[sp] = lo;
+      st_last[sp]  = last;
+      st_depth[sp] = dl;
+      ++sp;
+      last = lo;
+    }
+    if (sp == 0) break;
+    --sp;
+    first = st_first[sp];
+    last  = st_last[sp];
+    dl    = st_depth[sp];
+  }
+  if (n > 16) {  // __final_insertion_sort
+    insertion_sort(f, 0, 16);
+    for (int i = 16; i < n; ++i) unguarded_linear_insert(f, i);
+  } else {
+    insertion_sort(f, 0, n);
+  }
+}
+}  // namespace vel
+
+__global__ __launch_bounds__(1024) void k_dsp_velocity(DspDev d, const int32_t *__restrict__ range, float vres) {
+  extern __shared__ __attribute__((aligned(16))) float s_vel[];
+  const int a   = blockIdx.x;
+  DspAgent &s   = d.ag[a];
+  const int tid = threadIdx.x;
+  if (!s.ok) return;
+  int n = range[a * 2 + 1] - range[a * 2];
+  if (n > d.max_pts) n = d.max_pts;
+  if (n <= 0) return;  // :1488 — input_cloud_with_velocity and the previous clusters stay as they are
+  const int MP = d.max_pts;
+  float *sx = s_vel, *sy = sx + MP, *sz = sy + MP;  // non-ground points, compacted in input order
+  int   *lab = (int *)(sz + MP);                    // component label (-> cluster slot later)
+  int   *aux = lab + MP;                            // sizes per root, then rank of a point inside its cluster
+  __shared__ int           s_scan[1024], s_base_ng, s_base_g, s_changed, s_nc, s_err;
+  __shared__ vel::Item     s_item[VEL_MAX_CLUSTERS];
+  __shared__ int           s_slot_of_root_n;  // unused marker (keeps the layout explicit)
+  __shared__ int           s_root[VEL_MAX_CLUSTERS], s_size[VEL_MAX_CLUSTERS], s_off[VEL_MAX_CLUSTERS],
+      s_dynseq[VEL_MAX_CLUSTERS];
+  __shared__ float         s_cx[VEL_MAX_CLUSTERS], s_cy[VEL_MAX_CLUSTERS], s_cz[VEL_MAX_CLUSTERS];
+  __shared__ float         s_v[VEL_MAX_DYN][4];  // vx vy vz intensity of the possibly-dynamic clusters
+  __shared__ int           s_ndyn, s_total_dyn, s_n_ground, s_n_static;
+  float *born = d.born + (size_t)a * MP * 7;
+  if (tid == 0) {
+    s_base_ng = 0;
+    s_base_g  = 0;
+    s_err     = 0;
+  }
+  __syncthreads();
+  // ---- ground split (:1497-1507), order-preserving compaction of both lists; a thread keeps its points' data
+  float px[8][3];
+  int   cidx[8];  // >= 0: index in the non-ground list; < 0: -(ground rank) - 1
+  const int trips = (n + 1023) / 1024;
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    if (t >= trips) break;
+    const int k = t * 1024 + tid;
+    float x = 0.f, y = 0.f, z = 0.f;
+    bool  in = k < n, ng = false;
+    if (in) {
+      x  = born[(size_t)k * 7];
+      y  = born[(size_t)k * 7 + 1];
+      z  = born[(size_t)k * 7 + 2];
+      ng = z > vres;
+    }
+    // two exclusive scans over the workgroup (non-ground and ground flags)
+    const unsigned long long bn = __ballot(in && ng), bg = __ballot(in && !ng);
+    const int lane = tid & 63, wave = tid >> 6;
+    const unsigned long long lt = lane ? (~0ull >> (64 - lane)) : 0ull;
+    if (lane == 0) {
+      s_scan[wave]      = __popcll(bn);
+      s_scan[16 + wave] = __popcll(bg);
+    }
+    __syncthreads();
+    int on = 0, og = 0, tn = 0, tg = 0;
+    for (int w = 0; w < 16; ++w) {
+      on += w < wave ? s_scan[w] : 0;
+      og += w < wave ? s_scan[16 + w] : 0;
+      tn += s_scan[w];
+      tg += s_scan[16 + w];
+    }
+    const int rn = s_base_ng + on + __popcll(bn & lt), rg = s_base_g + og + __popcll(bg & lt);
+    px[t][0] = x;
+    px[t][1] = y;
+    px[t][2] = z;
+    cidx[t]  = !in ? 0x7fffffff : (ng ? rn : -rg - 1);
+    if (in && ng) {
+      sx[rn] = x;
+      sy[rn] = y;
+      sz[rn] = z;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      s_base_ng += tn;
+      s_base_g += tg;
+    }
+    __syncthreads();
+  }
+  // (max_points <= 8192 is checked by sogm_dsp_create: the register staging above holds 8 points per thread)
+  const int m = s_base_ng, n_ground = s_base_g;
+  // ---- neighbour lists: FLANN L2_Simple squared distance, strictly below (float)(tolerance^2)
+  const double tol = (double)(2 * vres);
+  const float  r2  = (float)(tol * tol);
+  unsigned short *adj = d.vel_adj + (size_t)a * MP * VEL_ADJ_CAP;
+  int            *deg = d.vel_deg + (size_t)a * MP;
+  for (int i = tid; i < m; i += 1024) {
+    const float ax = sx[i], ay = sy[i], az = sz[i];
+    int         c  = 0;
+    for (int j = 0; j < m; ++j) {
+      float df = ax - sx[j], d2 = 0.f;
+      d2 += df * df;
+      df = ay - sy[j];
+      d2 += df * df;
+      df = az - sz[j];
+      d2 += df * df;
+      if (d2 < r2 && j != i) {
+        if (c < VEL_ADJ_CAP) adj[(size_t)i * VEL_ADJ_CAP + c] = (unsigned short)j;
+        ++c;
+      }
+    }
+    if (c > VEL_ADJ_CAP) {
+      s_err = 2;  // denser than a voxel-filtered cloud: neighbours were dropped
+      c     = VEL_ADJ_CAP;
+    }
+    deg[i] = c;
+    lab[i] = i;
+  }
+  __syncthreads();
+  // ---- connected components: min-label propagation + pointer jumping to the fixed point
+  for (int round = 0; round < 4096; ++round) {
+    if (tid == 0) s_changed = 0;
+    __syncthreads();
+    for (int i = tid; i < m; i += 1024) {
+      int mn = lab[i];
+      const int dg = deg[i];
+      for (int q = 0; q < dg; ++q) {
+        const int l = lab[adj[(size_t)i * VEL_ADJ_CAP + q]];
+        mn          = l < mn ? l : mn;
+      }
+      if (mn < lab[i]) {
+        atomicMin(&lab[lab[i]], mn);  // hook the old root as well
+        atomicMin(&lab[i], mn);
+        s_changed = 1;
+      }
+    }
+    __syncthreads();
+    for (int i = tid; i < m; i += 1024) {
+      int l = lab[i];
+      while (lab[l] < l) l = lab[l];
+      lab[i] = l;
+    }
+    __syncthreads();
+    if (!s_changed) break;
+    __syncthreads();
+  }
+  // ---- sizes, accepted clusters (5 <= size <= 10000) in seed (= root index) order
+  for (int i = tid; i < m; i += 1024) aux[i] = 0;
+  __syncthreads();
+  for (int i = tid; i < m; i += 1024) atomicAdd(&aux[lab[i]], 1);
+  __syncthreads();
+  if (tid == 0) {
+    int nc = 0;
+    for (int i = 0; i < m; ++i)
+      if (lab[i] == i && aux[i] >= 5 && aux[i] <= 10000) {
+        if (nc < VEL_MAX_CLUSTERS) {
+          s_root[nc] = i;
+          s_size[nc] = aux[i];
+        }
+        ++nc;
+      }
+    if (nc > VEL_MAX_CLUSTERS) {
+      s_err = 3;
+      nc    = VEL_MAX_CLUSTERS;
+    }
+    // EuclideanClusterExtraction::extract: std::sort(clusters.rbegin(), clusters.rend(), size <)
+    for (int k = 0; k < nc; ++k) {  // the reversed sequence
+      s_item[k].size = s_size[nc - 1 - k];
+      s_item[k].id   = nc - 1 - k;
+    }
+    vel::std_sort(s_item, nc);
+    s_nc = nc;
+  }
+  __syncthreads();
+  const int nc = s_nc;
+  // cluster slot c (extraction order) = s_item[nc - 1 - c]; point -> slot through its root
+  for (int i = tid; i < m; i += 1024) aux[i] = -1;
+  __syncthreads();
+  for (int c = tid; c < nc; c += 1024) aux[s_root[s_item[nc - 1 - c].id]] = c;  // slot of a root
+  __syncthreads();
+  for (int i = tid; i < m; i += 1024) {
+    const int sl = aux[lab[i]];     // lab[i] is the point's root; aux[root] the cluster's slot (or -1)
+    lab[i]       = sl >= 0 ? sl : 0xFFFF;  // 0xFFFF = in no accepted cluster
+  }
+  __syncthreads();
+  // ---- centres (sums in ascending index order, :1533-1542) and rank of every point inside its cluster
+  for (int c = tid; c < nc; c += 1024) {
+    float cx = 0.f, cy = 0.f, cz = 0.f;
+    int   cnt = 0;
+    for (int i = 0; i < m; ++i)
+      if (lab[i] == c) {
+        cx += sx[i];
+        cy += sy[i];
+        cz += sz[i];
+        aux[i] = cnt;
+        ++cnt;
+      }
+    s_cx[c]   = cx / (float)cnt;
+    s_cy[c]   = cy / (float)cnt;
+    s_cz[c]   = cz / (float)cnt;
+    s_size[c] = cnt;  // now in extraction order
+  }
+  __syncthreads();
+  // ---- possibly-dynamic split, association with the previous frame, output offsets (one lane)
+  if (tid == 0) {
+    int nd = 0, off = 0;
+    for (int c = 0; c < nc; ++c) {
+      const bool stat = s_size[c] > 200 || s_cz[c] > 1.5;  // DYNAMIC_CLUSTER_MAX_POINT_NUM / _MAX_CENTER_HEIGHT
+      if (!stat && nd >= VEL_MAX_DYN) s_err = 4;
+      s_dynseq[c] = (!stat && nd < VEL_MAX_DYN) ? nd : -1;
+      if (s_dynseq[c] >= 0) {
+        s_off[c] = off;
+        off += s_size[c];
+        s_v[nd][0] = -10000.f;
+        s_v[nd][1] = -10000.f;
+        s_v[nd][2] = -10000.f;
+        s_v[nd][3] = 0.55f;
+        ++nd;
+      }
+    }
+    s_ndyn      = nd;
+    s_total_dyn = off;
+    off += n_ground;
+    for (int c = 0; c < nc; ++c)
+      if (s_dynseq[c] < 0) {
+        s_off[c] = off;
+        off += s_size[c];
+      }
+    s_n_static = off - s_total_dyn - n_ground;
+    // association (:1562-1622)
+    const int   R = nd, C = s.vel_n_last;
+    const float dt = s.odom[3];  // delt_t_from_last_observation (:213)
+    int         matched = 0;
+    if (R * C > MP) s_err = 5;
+    if (R > 0 && C > 0 && R * C <= MP && dt > 0.00001 && dt < 10.0) {
+      // cost / gate matrices live in the (now free) coordinate arrays of the dynamic LDS
+      float *cost = sx, *gate = sy;  // R * C <= 64 * 64 floats each (max_pts >= 4096 is checked at create)
+      int    rows[VEL_MAX_DYN];
+      {
+        int k = 0;
+        for (int c = 0; c < nc; ++c)
+          if (s_dynseq[c] >= 0) rows[k++] = c;
+      }
+      const float distance_gate = 1.5f, maximum_velocity = 5.f;
+      const int   point_num_gate = 100;
+      for (int r = 0; r < R; ++r)
+        for (int c = 0; c < C; ++c) {
+          const int   k  = rows[r];
+          const float ex = s_cx[k] - s.vel_last[c][0], ey = s_cy[k] - s.vel_last[c][1], ez = s_cz[k] - s.vel_last[c][2];
+          const float dist = sqrtf(ex * ex + ey * ey + ez * ez);
+          const int   dn   = s_size[k] - (int)s.vel_last[c][4];
+          if ((dn < 0 ? -dn : dn) > point_num_gate || dist >= distance_gate) {
+            gate[r * C + c] = 0.f;
+            cost[r * C + c] = distance_gate * 5000.f;
+          } else {
+            gate[r * C + c] = 1.f;
+            cost[r * C + c] = dist / distance_gate * 1000.f;
+          }
+        }
+      // minimum-cost assignment, potentials form, rows <= cols (transposed view otherwise): oracle's scan order
+      const bool  tr = R > C;
+      const int   NR = tr ? C : R, NCc = tr ? R : C;
+      const float INF = 3.0e38f;
+      float u[VEL_MAX_DYN + 1], v[VEL_MAX_DYN + 1], minv[VEL_MAX_DYN + 1];
+      int   pj[VEL_MAX_DYN + 1], way[VEL_MAX_DYN + 1];
+      bool  used[VEL_MAX_DYN + 1];
+      for (int j = 0; j <= NCc; ++j) {
+        v[j]  = 0.f;
+        pj[j] = 0;
+        way[j] = 0;
+      }
+      for (int i = 0; i <= NR; ++i) u[i] = 0.f;
+      auto at = [&](int i, int j) { return tr ? cost[j * C + i] : cost[i * C + j]; };  // (row i, col j) of the NR x NCc view
+      for (int i = 1; i <= NR; ++i) {
+        pj[0]  = i;
+        int j0 = 0;
+        for (int j = 0; j <= NCc; ++j) {
+          minv[j] = INF;
+          used[j] = false;
+        }
+        do {
+          used[j0]     = true;
+          const int i0 = pj[j0];
+          float     delta = INF;
+          int       j1 = 0;
+          for (int j = 1; j <= NCc; ++j)
+            if (!used[j]) {
+              const float cur = at(i0 - 1, j - 1) - u[i0] - v[j];
+              if (cur < minv[j]) {
+                minv[j] = cur;
+                way[j]  = j0;
+              }
+              if (minv[j] < delta) {
+                delta = minv[j];
+                j1    = j;
+              }
+            }
+          for (int j = 0; j <= NCc; ++j)
+            if (used[j]) {
+              u[pj[j]] += delta;
+              v[j] -= delta;
+            } else {
+              minv[j] -= delta;
+            }
+          j0 = j1;
+        } while (pj[j0] != 0);
+        do {
+          const int j1 = way[j0];
+          pj[j0]       = pj[j1];
+          j0           = j1;
+        } while (j0);
+      }
+      for (int j = 1; j <= NCc; ++j) {
+        if (pj[j] <= 0) continue;
+        const int r = tr ? j - 1 : pj[j] - 1, c = tr ? pj[j] - 1 : j - 1;  // new cluster r <-> old cluster c
+        if (!(gate[r * C + c] > 0.01f)) continue;
+        const int k = rows[r];
+        float vx = (s_cx[k] - s.vel_last[c][0]) / dt, vy = (s_cy[k] - s.vel_last[c][1]) / dt,
+              vz = (s_cz[k] - s.vel_last[c][2]) / dt;
+        const float vv = sqrtf(vx * vx + vy * vy + vz * vz);
+        if (vv > maximum_velocity) vx = vy = vz = 0.f;
+        s_v[r][0] = vx;
+        s_v[r][1] = vy;
+        s_v[r][2] = vz;
+        s_v[r][3] = s.vel_last[c][3];
+        ++matched;
+      }
+    }
+    // clusters_feature_vector_dynamic_last = clusters_feature_vector_dynamic (:1665)
+    {
+      int k = 0;
+      for (int c = 0; c < nc; ++c)
+        if (s_dynseq[c] >= 0) {
+          s.vel_last[k][0] = s_cx[c];
+          s.vel_last[k][1] = s_cy[c];
+          s.vel_last[k][2] = s_cz[c];
+          s.vel_last[k][3] = s_v[k][3];
+          s.vel_last[k][4] = (float)s_size[c];
+          ++k;
+        }
+      s.vel_n_last = k;
+    }
+    s.vel_clusters = nc;
+    s.vel_dynamic  = nd;
+    s.vel_matched  = matched;
+    if (s_err) s.vel_err = s_err;
+    s.n_born = s_total_dyn + n_ground + s_n_static;
+  }
+  __syncthreads();
+  // ---- input_cloud_with_velocity in the reference's order (every thread writes the points it read)
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    if (t >= trips) break;
+    const int ci = cidx[t];
+    if (ci == 0x7fffffff) continue;
+    int   pos;
+    float lv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (ci < 0) {
+      pos = s_total_dyn + (-ci - 1);
+    } else {
+      const int c = lab[ci];
+      if (c == 0xFFFF) continue;  // no accepted cluster: the point is dropped
+      pos = s_off[c] + aux[ci];
+      if (s_dynseq[c] >= 0)
+        for (int j = 0; j < 4; ++j) lv[j] = s_v[s_dynseq[c]][j];
+    }
+    float *o = born + (size_t)pos * 7;
+    o[0]     = px[t][0];
+    o[1]     = px[t][1];
+    o[2]     = px[t][2];
+    for (int j = 0; j < 4; ++j) o[3 + j] = lv[j];
   }
 }
 
@@ -1064,7 +1573,7 @@ void sogm_dsp_destroy(sogm_dsp *h) {
 int sogm_dsp_create(sogm_ctx *map, const SogmDspParams *P, const float *p_gauss, const float *v_gauss,
                     int n_gauss, const int32_t *rand_tab, int n_rand, int max_points, sogm_dsp **out) {
   if (!map || !P || !out || !p_gauss || !v_gauss || !rand_tab || n_gauss <= 0 || n_rand <= 0 ||
-      max_points <= 0)
+      max_points <= 0 || max_points > 8192)
     return SOGM_ERR_INVALID_ARG;
   const SogmSpec &sp = map->spec;
   const int       S  = P->max_particle_num_voxel * 2;
@@ -1155,6 +1664,8 @@ int sogm_dsp_create(sogm_ctx *map, const SogmDspParams *P, const float *p_gauss,
   bad |= dmalloc(h, &d.bp_h, A * (d.nph + 1) * 3);
   bad |= dmalloc(h, &d.bp_v, A * (d.npv + 1) * 3);
   bad |= dmalloc(h, &d.born, A * MP * 7);
+  bad |= dmalloc(h, &d.vel_adj, A * MP * VEL_ADJ_CAP);
+  bad |= dmalloc(h, &d.vel_deg, A * MP);
   bad |= dmalloc(h, &d.c_key, A * CC);
   bad |= dmalloc(h, &d.c_dest, A * CC);
   bad |= dmalloc(h, &d.c_pyr, A * CC);
@@ -1221,8 +1732,7 @@ int sogm_dsp_create(sogm_ctx *map, const SogmDspParams *P, const float *p_gauss,
 int sogm_update_dsp(sogm_dsp *h, const float *points, const float *labels, const int32_t *cloud_range,
                     const float *sensor_pos, const float *sensor_quat, const double *stamps,
                     int32_t *out_ok, void *stream) {
-  if (!h || !points || !labels || !cloud_range || !sensor_pos || !sensor_quat || !stamps)
-    return SOGM_ERR_INVALID_ARG;
+  if (!h || !points || !cloud_range || !sensor_pos || !sensor_quat || !stamps) return SOGM_ERR_INVALID_ARG;
   DspDev     &d  = h->d;
   hipStream_t st = (hipStream_t)stream;
   SOGM_HIP_CHECK(hipSetDevice(h->map->device));
@@ -1234,6 +1744,15 @@ int sogm_update_dsp(sogm_dsp *h, const float *points, const float *labels, const
   SOGM_HIP_CHECK(hipMemsetAsync(d.phead, 0xFF, A * d.NP * sizeof(int), st));
   hipLaunchKernelGGL(k_dsp_observe, dim3((unsigned)A), dim3(256), 2 * d.NP * sizeof(int), st, d, points, labels,
                      cloud_range);
+  if (!labels) {  // velocityEstimationThread (:305): labels and point order of the new-born list are computed here
+    static bool attr = false;
+    const size_t lds = (size_t)d.max_pts * 20;
+    if (!attr) {
+      (void)hipFuncSetAttribute((const void *)k_dsp_velocity, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      attr = true;
+    }
+    hipLaunchKernelGGL(k_dsp_velocity, dim3((unsigned)A), dim3(1024), lds, st, d, cloud_range, 0.15f);
+  }
   hipLaunchKernelGGL(k_dsp_predict, g_vox256, dim3(256), 0, st, d);
   for (int r = 0; r < DSP_ROUNDS; ++r) {
     hipLaunchKernelGGL(k_dsp_place, g_vox64, dim3(64), 0, st, d, r);
@@ -1351,6 +1870,29 @@ int sogm_dsp_download_observations(sogm_dsp *h, int agent, int32_t *nobs, float 
       std::memcpy(&f, &b[i], 4);
       maxlen[i] = b[i] < 0 ? -1.f : f;
     }
+  }
+  return SOGM_OK;
+}
+
+// Parity I/O (synchronous): input_cloud_with_velocity of the last update — rows {x, y, z, vx, vy, vz, intensity} in
+// the order new-born particles are created — and counters {clusters, possibly dynamic, matched, error code}.
+int sogm_dsp_download_born(sogm_dsp *h, int agent, float *born_host, int cap, int32_t *n_born, int32_t *counters4) {
+  if (!h || agent < 0 || agent >= h->d.A || cap < 0) return SOGM_ERR_INVALID_ARG;
+  DspDev &d = h->d;
+  SOGM_HIP_CHECK(hipSetDevice(h->map->device));
+  SOGM_HIP_CHECK(hipDeviceSynchronize());
+  DspAgent ag;
+  SOGM_HIP_CHECK(hipMemcpy(&ag, d.ag + agent, sizeof(ag), hipMemcpyDeviceToHost));
+  if (n_born) *n_born = ag.n_born;
+  if (counters4) {
+    counters4[0] = ag.vel_clusters;
+    counters4[1] = ag.vel_dynamic;
+    counters4[2] = ag.vel_matched;
+    counters4[3] = ag.vel_err;
+  }
+  if (born_host) {
+    const size_t n = (size_t)(ag.n_born < cap ? ag.n_born : cap);
+    SOGM_HIP_CHECK(hipMemcpy(born_host, d.born + (size_t)agent * d.max_pts * 7, n * 7 * sizeof(float), hipMemcpyDeviceToHost));
   }
   return SOGM_OK;
 }

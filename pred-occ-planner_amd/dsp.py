@@ -47,6 +47,7 @@ class DspMap:
         check(lib().sogm_dsp_create(sogm_map.ctx, C.byref(params), pg.ctypes.data_as(fp),
                                     vg.ctypes.data_as(fp), len(pg), rnd.ctypes.data_as(C.c_void_p),
                                     len(rnd), max_points, C.byref(self._h)), "sogm_dsp_create")
+        self.max_points = max_points
         self.S = 2 * params.max_particle_num_voxel
         self.NP = (params.half_fov_h * 2 // params.angle_resolution) * (params.half_fov_v * 2 // params.angle_resolution)
 
@@ -63,12 +64,24 @@ class DspMap:
             pass
 
     def update(self, points, labels, cloud_range, sensor_pos, sensor_quat, stamps, out_ok=None):
-        """DSPMap::update for every agent; all arguments are device tensors (see sogm_abi.h)."""
+        """DSPMap::update for every agent; all arguments are device tensors (see sogm_abi.h).  labels=None runs
+        velocityEstimationThread (clustering + association) on the GPU."""
         ok = out_ok if out_ok is not None else torch.zeros(self.map.n_agents, dtype=torch.int32, device=points.device)
-        check(lib().sogm_update_dsp(self._h, points.data_ptr(), labels.data_ptr(), cloud_range.data_ptr(),
+        check(lib().sogm_update_dsp(self._h, points.data_ptr(), labels.data_ptr() if labels is not None else None,
+                                    cloud_range.data_ptr(),
                                     sensor_pos.data_ptr(), sensor_quat.data_ptr(), stamps.data_ptr(),
                                     ok.data_ptr(), _stream()), "sogm_update_dsp")
         return ok
+
+    def download_born(self, agent):
+        """input_cloud_with_velocity of the last update: (rows [n, 7], counters {clusters, dynamic, matched, err})."""
+        cap = self.max_points
+        born = np.zeros((cap, 7), np.float32)
+        n = C.c_int32(0)
+        cnt = (C.c_int32 * 4)()
+        check(lib().sogm_dsp_download_born(self._h, agent, born.ctypes.data_as(C.c_void_p), cap, C.byref(n), cnt),
+              "sogm_dsp_download_born")
+        return born[:n.value].copy(), list(cnt)
 
     def publish(self):
         """RiskVoxel::publishMap's map half: future status -> SOGM grid (+ inflate-kernel zeroing)."""

@@ -172,7 +172,6 @@ def test_cfg1_perception_riskvoxel_chain_parity(pop, orc):
     n_pix = len(clouds[0])
     raw = sogm._dev(np.concatenate(clouds, axis=0), np.float32)
     rng = sogm._dev(np.stack([np.arange(A) * n_pix, (np.arange(A) + 1) * n_pix], axis=1), np.int32)
-    labels = torch.zeros((A * cap, 4), dtype=torch.float32, device="cuda")
     base = torch.arange(A, dtype=torch.int32, device="cuda") * cap
     quat = sogm._dev(np.tile(np.float32([1, 0, 0, 0]), (A, 1)), np.float32)
     starts = np.array([[0.0, 0.6 * a - 4.5, 1.0] for a in range(A)])
@@ -181,11 +180,14 @@ def test_cfg1_perception_riskvoxel_chain_parity(pop, orc):
         pos = sogm._dev(starts.astype(np.float32))
         stamps = sogm._dev(np.full(A, 50.0 + k / 30.0), np.float64)
         pts, cnt = m.filterPointCloud(raw, rng, 0.15, cap)
-        g.update(pts.view(-1, 3), labels, torch.stack([base, base + cnt], dim=1).contiguous(), pos, quat, stamps)
+        # labels = None: velocityEstimationThread (clustering + association) runs on the GPU / in the oracle
+        g.update(pts.view(-1, 3), None, torch.stack([base, base + cnt], dim=1).contiguous(), pos, quat, stamps)
         n0 = int(cnt[0].item())
         p0 = pts[0, :n0].cpu().numpy()
-        o0.update(p0, np.zeros((n0, 4), np.float32), starts[0].astype(np.float32), np.float32([1, 0, 0, 0]),
-                  50.0 + k / 30.0)
+        o0.update(p0, None, starts[0].astype(np.float32), np.float32([1, 0, 0, 0]), 50.0 + k / 30.0)
+        gb, gc = g.download_born(0)
+        wb, wc = o0.born()
+        assert gc[3] == 0 and gc[:3] == wc and np.array_equal(gb, wb), (k, gc, wc)
     st_g = g.download_state(0)
     st_o = o0.state()
     gs, ws = st_g[0], st_o[0]  # [V][slots][9]: flag, payload; slot 8 (update time) is not stored on the GPU
