@@ -22,7 +22,7 @@ clouds = [pop.scene.make_depth_cloud(100 + a) for a in range(A)]
 n_pix = len(clouds[0])
 raw = sogm._dev(np.concatenate(clouds, axis=0), np.float32)
 rng = sogm._dev(np.stack([np.arange(A) * n_pix, (np.arange(A) + 1) * n_pix], axis=1), np.int32)
-labels = torch.zeros((A * cap, 4), dtype=torch.float32, device="cuda")
+labels = None  # velocityEstimationThread (clustering + association) runs on the GPU, in the update
 base = torch.arange(A, dtype=torch.int32, device="cuda") * cap
 quat = sogm._dev(np.tile(np.float32([1, 0, 0, 0]), (A, 1)), np.float32)
 recs = torch.zeros((A, pop._abi.TRAJ_RECORD_BYTES), dtype=torch.uint8, device="cuda")
@@ -61,7 +61,10 @@ out = {"workload": f"{A} agents, {spec.L}x{spec.W}x{spec.H}x{spec.T} particle SO
        "stage_ms": dict(zip(["filter", "dsp_update", "publish", "overlay"], ms.mean(axis=0).round(3).tolist())),
        "filtered_points": cnt.cpu().numpy().tolist()[:4], "live_particles_agent0": int((st[:, :, 0] > 0.1).sum()),
        "occupied_voxels_agent0": int((ob[:, 0] > spec.risk_threshold).sum()), "counters_agent0": c.tolist(),
-       "algorithmic_bytes_per_agent_update": b_dsp,
-       "algorithmic_GBps_dsp_update": b_dsp * A / (ms[:, 1].mean() * 1e-3) / 1e9}
+       # SURVEY 8d's per-update figure describes the reference's dense AoS sweep (every slot of every voxel read and
+       # written); the SoA / flag layout here touches 16 B per voxel plus the occupied lines, so dividing it by the
+       # update time is NOT an achieved-bandwidth figure (it exceeds the HBM peak).  Measured HBM bytes per kernel:
+       # profiles/r02_perception_rocprof.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command).
+       "reference_sweep_bytes_per_agent_update": b_dsp}
 print(json.dumps(out))
 g.close(); m.close()

@@ -1,11 +1,14 @@
-"""Assemble profiles/r01_end_rocprof.md + profiles/r01_pmc_traffic.json from gpurun_out/profile/ (tools/make_profile.sh)."""
-import json, re, sys
+"""Assemble profiles/r02_end_rocprof.md, profiles/r02_perception_rocprof.md and profiles/r02_pmc_traffic.json from
+gpurun_out/profile/ (tools/make_profile.sh)."""
+import json, re
 P = 'gpurun_out/profile/'
 last = lambda f: open(P + f).read().strip().splitlines()[-1]
-summ = open(P + 'summary.md').read()
-tl = open(P + 'timeline.txt').read()
-plain, trace, mode1, cfg4, dsp, gm = (last(f) for f in ('bench_plain.json', 'bench_trace.json', 'bench_mode1.json', 'bench_cfg4.json', 'bench_dsp.json', 'bench_gridmap.json'))
-d, m1, c4 = json.loads(plain), json.loads(mode1), json.loads(cfg4)
+read = lambda f: open(P + f).read()
+summ, tl, flow = read('summary.md'), read('timeline.txt'), read('flow.txt')
+plain, trace, flow0, grids2, mode1, cfg4, dsp, gm = (last(f) for f in (
+    'bench_plain.json', 'bench_trace.json', 'bench_flow0.json', 'bench_grids2.json', 'bench_mode1.json',
+    'bench_cfg4.json', 'bench_dsp.json', 'bench_gridmap.json'))
+d, f0, g2, m1, c4 = (json.loads(x) for x in (plain, flow0, grids2, mode1, cfg4))
 
 
 def pm(counter):
@@ -16,55 +19,58 @@ def pm(counter):
 nf, fk = pm('FETCH_SIZE')
 nw, wk = pm('WRITE_SIZE')
 traffic = int((fk + wk) * 1024)
-json.dump({"kernel": "k_clear_slabs", "source": "profiles/r01_end_rocprof.md (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes, 128 agents 200x200x200x20; mean over the narrow in-tick launches and the full-width stage-pass launch)",
-           "fetch_kb": fk, "write_kb": wk, "bytes_per_launch": traffic, "algorithmic_bytes_per_launch": 81920000000}, open('profiles/r01_pmc_traffic.json', 'w'))
+alg = d['roofline']['bytes_per_launch']
+json.dump({"kernel": "k_clear_slabs",
+           "source": "profiles/r02_end_rocprof.md (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes of "
+                     "`python bench.py --steps 2 --warmup 1 --no-cpu-baseline --sustained 0`, 128 agents 200x200x200x20; "
+                     "mean over the in-tick launches and the full-width stage-pass launches)",
+           "fetch_kb": fk, "write_kb": wk, "bytes_per_launch": traffic, "algorithmic_bytes_per_launch": alg},
+          open('profiles/r02_pmc_traffic.json', 'w'))
+r, s = d['roofline'], d['sustained']
+cb = d['cpu_baseline']
+md = f"""# Round 2 — rocprofv3 profile of `python bench.py` (MI355X, 128 agents, 200^3 x 20), numbers of record
 
+Collected by `tools/make_profile.sh` on the GPU box (`cd /tmp && export TMPDIR=/tmp`), assembled by
+`tools/make_profile_md.py`:
+- `rocprofv3 --kernel-trace --stats -d … -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline --sustained 0`
+- separate PMC passes (no trace domains): `rocprofv3 --pmc FETCH_SIZE -- python bench.py --steps 2 --warmup 1
+  --no-cpu-baseline --sustained 0` and the same with `--pmc WRITE_SIZE`.
+The rocpd databases stay in gpurun_out/ (scratch); this file holds what is cited.
 
-def stats_block(text):
-    out = []
-    for line in text.splitlines():
-        m = re.match(r"- (.*?): ([\d, ]+)$", line)
-        if m:
-            v = sorted(float(x) for x in m.group(2).split(','))
-            n = len(v)
-            out.append(f"- {m.group(1)}: n={n} min {v[0]:.0f} median {v[n//2]:.0f} mean {sum(v)/n:.0f} max {v[-1]:.0f}")
-        else:
-            out.append(line)
-    return "\n".join(out)
+State: dataflow replan (`k_astar` publishes agents in completion order; persistent `k_corridor_flow` /
+`k_qp_flow` / `k_finish_flow` chain per agent through device-side ready lists), triple-buffered SOGM with one narrow
+streaming clear per tick on a side stream, sdlp's projective Seidel LP executed whole-wave, `costMVIE` summed in the
+reference's order, ring obstacles, the velocity-estimation front end.
 
+Default run (`python bench.py`: 3 warm-up + 20 timed ticks, then 300 host-synchronised ticks of the same flight,
+then the CPU baseline): **{d['value']:.0f} replans/s** ({d['ms_per_step']:.2f} ms per tick), of which
+{d['value_ok']:.0f} successful (`replans_ok_fraction` {d['config']['replans_ok_fraction']:.3f}; outcomes
+{json.dumps(d['config']['outcomes'])}); **sustained** {s['value']:.0f} replans/s over {s['ticks']} ticks (tick mean
+{s['tick_ms_mean']:.2f} / p50 {s['tick_ms_p50']:.2f} / p99 {s['tick_ms_p99']:.2f} ms, ok {s['replans_ok_fraction']:.3f}).
+`k_clear_slabs` inside the tick (HIP events on its launch stream, every launch of the timed region, n =
+{r['launches_timed']}): {r['avg_launch_ms']:.2f} ms per launch = {r['achieved']:.0f} GB/s = **{r['frac']:.3f}** of the 8 TB/s HBM
+peak; the same kernel full width with the machine to itself {min(r['standalone']['launch_ms']):.2f} ms =
+{r['standalone']['frac']:.3f}.  CPU baseline (oracle "port", one agent-replan per thread): {cb['value']:.1f} replans/s on
+{cb['cores']} of {cb.get('host_cores')} host cores ({cb['sample']}).
 
-summ = stats_block(summ)
-r = d['roofline']
-md = f"""# Round 1 (end of round, numbers of record) — rocprofv3 profile of `python bench.py` (MI355X, 128 agents, 200^3 x 20)
-
-Collected by `tools/make_profile.sh` on the GPU box (`cd /tmp && export TMPDIR=/tmp`), assembled by `tools/make_profile_md.py`:
-- `rocprofv3 --kernel-trace --stats -d … -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline`
-- separate PMC passes (no trace domains): `rocprofv3 --pmc FETCH_SIZE -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline`
-  and the same with `--pmc WRITE_SIZE`.
-Summarised by `tools/rocprof_summary.py` / `tools/tick_timeline.py` from the rocpd databases (the .db files stay
-in gpurun_out/).
-
-State: 512-lane register-resident ADMM iteration in `k_qp` (1.27 us per iteration, was 3.9 at the start of the
-session), double-buffered SOGM with a narrow (64-workgroup) streaming clear under the whole replan, obstacle-point
-scan split from the FIRI kernel, stage-wise costMVIE reduction, reworked A* expansion (19 us, was 27), every planner
-kernel free of scratch memory, 8 agent-group streams.
-
-Unprofiled bench of the same box (`python bench.py --steps 30 --warmup 3`): **{d['value']:.0f} replans/s**,
-{d['ms_per_step']:.2f} ms per tick, replans_ok {d['config']['replans_ok_fraction']:.3f}; `k_clear_slabs` inside the tick
-{r['avg_launch_ms']:.2f} ms per launch = {r['achieved']:.0f} GB/s = {r['frac']:.3f} of the 8 TB/s HBM peak (narrow launch sharing
-the machine with the planner kernels), {r['standalone']['frac']:.3f} for the full-width launch of the stage pass (0.72-0.85 across
-boxes and runs); cpu_baseline {d['cpu_baseline']['value']:.1f} replans/s on 8 host threads.
-Single-grid mode (`SOGM_DOUBLE_BUFFER=0`, full-width clear in place under the QP stage): {m1['value']:.0f} replans/s,
-clear at {m1['roofline']['frac']:.3f}.  300^3 x 30 with fp16 cells (207 GB, single grid): {c4['value']:.0f} replans/s, clear at {c4['roofline']['frac']:.3f}.
+Variants on the same box:
+| variant | replans/s | ms/tick | clear ms (frac) | sustained replans/s (mean tick) |
+|---|---|---|---|---|
+| default: dataflow replan, 3 grids | {d['value']:.0f} | {d['ms_per_step']:.2f} | {r['avg_launch_ms']:.2f} ({r['frac']:.3f}) | {s['value']:.0f} ({s['tick_ms_mean']:.2f} ms) |
+| grouped streams (`SOGM_FLOW=0`, round-1 structure), 3 grids | {f0['value']:.0f} | {f0['ms_per_step']:.2f} | {f0['roofline']['avg_launch_ms']:.2f} ({f0['roofline']['frac']:.3f}) | {f0['sustained']['value']:.0f} ({f0['sustained']['tick_ms_mean']:.2f} ms, 100 ticks) |
+| dataflow, 2 grids (`SOGM_GRIDS=2`) | {g2['value']:.0f} | {g2['ms_per_step']:.2f} | {g2['roofline']['avg_launch_ms']:.2f} ({g2['roofline']['frac']:.3f}) | — |
+| single grid, in-place two-part clear (`SOGM_DOUBLE_BUFFER=0`, grouped path) | {m1['value']:.0f} | {m1['ms_per_step']:.2f} | {m1['roofline']['avg_launch_ms']:.2f} ({m1['roofline']['frac']:.3f}) | — |
+| BASELINE configs[4]: 300^3 x 30, fp16 cells, 207 GB, single grid | {c4['value']:.0f} | {c4['ms_per_step']:.2f} | {c4['roofline']['avg_launch_ms']:.2f} ({c4['roofline']['frac']:.3f}) | — |
 
 Reading guide:
-- `k_clear_slabs` is the roofline kernel (SOGM voxel update, 81.92 GB algorithmic bytes per launch =
-  128 agents x 640 MB); PMC: FETCH_SIZE {fk:.0f} KB + WRITE_SIZE {wk:.0f} KB = {traffic/1e9:.2f} GB per launch (KB = 1024 B),
-  i.e. {traffic/81.92e9:.4f} x the algorithmic bytes.
-- Planner kernels are launched once per agent group (8 groups of 16 agents) per tick; their per-dispatch
-  durations overlap in time (separate HIP streams), so the "total" column is not wall time — the tick timeline
-  below shows what is on the critical path (stamp -> A* -> obstacle points -> FIRI -> the slowest QP -> deconfliction).
-- the clear runs on a side stream from the start of the replan to ~75 % of the tick and is off the critical path.
+- `k_clear_slabs` is the roofline kernel (SOGM voxel update, {alg/1e9:.2f} GB algorithmic bytes per launch = 128 agents x
+  640 MB); PMC: FETCH_SIZE {fk:.0f} KB + WRITE_SIZE {wk:.0f} KB = {traffic/1e9:.2f} GB per launch (KB = 1024 B), i.e.
+  **{traffic/alg:.4f} x** the algorithmic bytes — no wasted traffic.
+- In the dataflow replan the planner is five launches per tick; `k_corridor_flow`, `k_qp_flow`, `k_finish_flow` are
+  persistent (their durations span most of the tick by construction) — the per-agent stage times below are what to
+  read, not the kernel durations.
+- The clear runs on a side stream beside the whole replan; with three grids a tick only waits for the clear queued one
+  tick earlier.
 
 {summ}
 
@@ -74,9 +80,15 @@ Reading guide:
 {tl.strip()}
 ```
 
+## per-agent chain of the dataflow replan (tools/diag_flow.py: in-kernel 100 MHz stamps, 12 ticks)
+
+```
+{flow.strip()}
+```
+
 ## bench.py JSON lines
 
-- unprofiled, same box (`python bench.py --steps 30 --warmup 3`):
+- default run:
 
 ```
 {plain}
@@ -88,24 +100,49 @@ Reading guide:
 {trace}
 ```
 
-- single-grid mode (`SOGM_DOUBLE_BUFFER=0 python bench.py --steps 30 --warmup 3 --no-cpu-baseline`):
+- grouped path (`SOGM_FLOW=0`):
+
+```
+{flow0}
+```
+
+- single-grid mode:
 
 ```
 {mode1}
 ```
 
-- BASELINE configs[4] (`python bench.py --grid cfg4 --steps 10 --warmup 2 --no-cpu-baseline`):
+- BASELINE configs[4]:
 
 ```
 {cfg4}
 ```
+"""
+open('profiles/r02_end_rocprof.md', 'w').write(md)
+md2 = f"""# Round 2 — perception kernels (particle SOGM, cloud filter, depth front end): rocprofv3 per-kernel tables
 
-## Perception side (tools/bench_dsp.py, tools/bench_gridmap.py; same box)
+`tools/make_profile.sh`: `rocprofv3 --kernel-trace --stats -- python tools/bench_dsp.py` (BASELINE configs[1]: 16
+agents, 100^3 x 15, 307 200 depth points per agent and frame, velocity estimation on the GPU) and
+`… tools/bench_gridmap.py` (400 x 400 x 30 voxels, 640 x 480 depth images), plus `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE`
+passes of the same commands (separate runs, no trace domains).  "mean value (KB)" is the counter per dispatch in KB of
+1024 B: FETCH_SIZE + WRITE_SIZE = HBM bytes a dispatch moved.  These kernels are latency- / atomics-bound scans of
+sparse structures; none of them is rated against the HBM roofline (the rated kernel is `k_clear_slabs`).
+
+## particle SOGM + filterPointCloud (tools/bench_dsp.py)
 
 ```
 {dsp}
+```
+
+{read('summary_dsp.md')}
+
+## GridMap depth front end (tools/bench_gridmap.py)
+
+```
 {gm}
 ```
+
+{read('summary_gridmap.md')}
 """
-open('profiles/r01_end_rocprof.md', 'w').write(md)
-print("wrote profiles/r01_end_rocprof.md", len(md), "bytes; traffic", traffic)
+open('profiles/r02_perception_rocprof.md', 'w').write(md2)
+print("wrote profiles/r02_end_rocprof.md", len(md), "bytes,", "profiles/r02_perception_rocprof.md", len(md2), "bytes; traffic", traffic, "x", traffic / alg)

@@ -27,7 +27,11 @@ def main():
         if "sogm::" in n or "k_pack" in n:
             by.setdefault(short(n), []).append(d)
     for k, v in by.items():
-        print(f"- {k}: " + ", ".join(f"{x:.0f}" for x in v))
+        if len(v) > 64:  # keep the file readable: distribution instead of every dispatch
+            w = sorted(v)
+            print(f"- {k}: n={len(w)} min {w[0]:.0f} median {w[len(w)//2]:.0f} mean {sum(w)/len(w):.0f} p90 {w[int(len(w)*0.9)]:.0f} max {w[-1]:.0f}")
+        else:
+            print(f"- {k}: " + ", ".join(f"{x:.0f}" for x in v))
     for pmc in sys.argv[2:]:
         c2 = sqlite3.connect(pmc).cursor()
         print(f"\n## PMC pass {pmc.split('/')[-1]} (separate run, --pmc only)\n")
