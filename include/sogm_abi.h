@@ -261,6 +261,14 @@ int sogm_set_future_risk(sogm_ctx *ctx, const float *grid_vt, const float *poses
 int sogm_download_reference_layout(sogm_ctx *ctx, int agent, float *out_vt_host);
 
 /*
+ * RiskBase::getMapTime().toSec() and getMapCenter() of one agent (plan_env/include/plan_env/risk_base.h:70,76;
+ * map.h:109-111): the stamp and pose the last update / sogm_set_future_risk adopted.  Host outputs (either may be
+ * NULL); waits for `stream`.  SOGM_ERR_STATE before the first update.
+ */
+int sogm_map_state(sogm_ctx *ctx, int agent, double *out_map_time_host, float *out_center_host /* [3] */,
+                   void *stream);
+
+/*
  * Bezier::getPos / getVel / getAcc (traj_utils/include/traj_utils/bernstein.hpp:174-187,
  * traj_utils/src/bernstein.cpp:25-59) for a batch of shared trajectories:
  * out_pva[i] = {pos, vel, acc} of records[i] at absolute time t[i] (clamped to the trajectory's
@@ -519,6 +527,37 @@ int sogm_bezier_qp_solve(sogm_planner *p, const double *start_pva, const double 
  */
 int sogm_linprog_batched(int d, const double *c, const double *A, const double *b,
                          const int32_t *row_range, int n, double *out_x, double *out_min, void *stream);
+
+/*
+ * firi::firi(bd, pc, a, b, hPoly, r, iterations, epsilon) (plan_manager/include/sfc_gen/firi.hpp:238-365) as a
+ * standalone call for n independent problems — the same wave-per-problem code the replan runs per path segment,
+ * without its box construction, ShrinkCorridor and validity LP.  No context: the current device, scratch is
+ * allocated stream-ordered.
+ * dev bd [n][n_bd][4] row-major (n_bd <= 32; rows h.x + h3 <= 0), dev pc_xyz packed fp64 points with
+ * dev pc_range [n][2] = {first, last+1} into it (at most max_points <= 16384 points per problem),
+ * dev a, b [n][3] (the seed segment), dev r [n][3] in/out (ellipsoid radii: the reference's callers pass ones),
+ * iterations >= 1 (2 at baseline.cpp:352), epsilon 1e-6 in the reference.
+ * dev out_hpoly [n][max_faces][4] (max_faces <= 128), out_nfaces [n], out_status [n]: 1 = firi returned true,
+ * 0 = it returned false (a or b outside bd; nothing else written), -3 = over capacity (more than max_points
+ * points, or more than max_faces / 128 selected planes: the polytope is truncated).
+ */
+int sogm_firi_batched(const double *bd, int n_bd, const double *pc_xyz, const int32_t *pc_range, const double *a,
+                      const double *b, double *r, int iterations, double epsilon, int n, int max_points,
+                      int max_faces, double *out_hpoly, int32_t *out_nfaces, int32_t *out_status, void *stream);
+
+/*
+ * Per-object use of the per-stage entries (host/sogm_reference_api.hpp): after select_agents(first, count),
+ * sogm_astar_search / sogm_corridor_generate / sogm_bezier_qp_solve / sogm_safe_after_opt process agents
+ * [first, first + count) only; every array keeps its full [n_agents] layout and is indexed by the absolute agent.
+ * (0, n_agents) restores the default.  sogm_replan always processes every agent.
+ * set_search_mode: 0 (default) = the replan's call pattern — search(…, init_search = true, …) and, if that returns
+ * NO_PATH, reset() + search(…, false, …) (baseline_fake.cpp:284-291); 1 / 2 = exactly one
+ * RiskHybridAstar::search with init_search = true / false (risk_hybrid_a_star.h:103-110).  Adding 4 makes
+ * sogm_astar_search read t_start[] as that function's time_start argument (seconds after the map stamp) instead of
+ * an absolute time.
+ */
+int sogm_planner_select_agents(sogm_planner *p, int first, int count);
+int sogm_planner_set_search_mode(sogm_planner *p, int mode);
 
 /*
  * ParticleATC::isSafeAfterOpt (traj_coordinator/src/particles.cpp:223-283) for every agent: the new

@@ -447,6 +447,10 @@ int orc_astar_debug_nodes(double *out, int n) {
   return k;
 }
 
+// 0: the replan's call pattern (baseline_fake.cpp:284-291); 1 / 2: one search(…, init = true / false, …)
+static int g_search_mode = 0;
+void orc_astar_set_mode(int mode) { g_search_mode = mode; }
+
 int orc_astar_search(const SogmSpec *s, const SogmAstarParams *ap, const float *grid,
                      const float pose[3], const double start_pva[9], const double goal[3],
                      double t_after_map, double corridor_tau, double *out_route,
@@ -457,7 +461,8 @@ int orc_astar_search(const SogmSpec *s, const SogmAstarParams *ap, const float *
   int              searches = 0;
   int              rst      = NO_PATH;
   Search           last;
-  for (int attempt = 0; attempt < 2; ++attempt) {  // baseline_fake.cpp:284-291
+  const int attempt_lo = g_search_mode == 2 ? 1 : 0, attempt_hi = g_search_mode == 1 ? 1 : 2;
+  for (int attempt = attempt_lo; attempt < attempt_hi; ++attempt) {  // baseline_fake.cpp:284-291
     Search S;
     S.spec = s;
     S.ap   = ap;

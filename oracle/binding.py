@@ -134,7 +134,8 @@ def astar_use_libm(on):
 
 
 def astar_search(spec, ap, grid, pose, start_pva, goal, t_after_map, corridor_tau=0.3, route_cap=64,
-                 trace_cap=20000):
+                 trace_cap=20000, mode=0):
+    lib().orc_astar_set_mode(mode)
     pose = np.ascontiguousarray(pose, np.float32)
     s = np.ascontiguousarray(start_pva, np.float64).reshape(9)
     g = np.ascontiguousarray(goal, np.float64)
@@ -186,13 +187,13 @@ def lp_permutation(n, kind="fixed"):
 
 
 # ---------------------------------------------------------------- FIRI / corridors
-def firi(bd, pc, a, b, iterations=2, max_faces=64):
+def firi(bd, pc, a, b, iterations=2, max_faces=64, r=None):
     bd = np.ascontiguousarray(bd, np.float64)
     pc = np.ascontiguousarray(pc, np.float64).reshape(-1, 3)
     a = np.ascontiguousarray(a, np.float64)
     b = np.ascontiguousarray(b, np.float64)
     hp = np.zeros((max_faces, 4))
-    r = np.ones(3)
+    r = np.ones(3) if r is None else np.ascontiguousarray(r, np.float64).copy()
     n = lib().orc_firi(dptr(bd), bd.shape[0], dptr(pc), pc.shape[0], dptr(a), dptr(b), iterations,
                        dptr(hp), max_faces, dptr(r))
     return (hp[:max(n, 0)].copy() if n <= max_faces else hp.copy()), n, r

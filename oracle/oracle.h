@@ -6,11 +6,13 @@
  *
  * Parity status: the reference cannot be compiled here (Eigen, ROS, PCL, OSQP absent, no network),
  * so the restatement is pinned against the reference's own known-answer tests
- * (traj_utils/test/test_bernstein.cpp, traj_opt/test/test_bezier_opt.cpp — see tests/golden/) and is
+ * (traj_utils/test/test_bernstein.cpp, traj_opt/test/test_bezier_opt.cpp, utils/separator/src/test_separator.cpp —
+ * see tests/golden/) and is
  * otherwise "parity unpinned": each function cites the reference file:line it follows.
  *
- * Plain C++17, no third-party code, compiled with -O2 -ffp-contract=off so that fp32/fp64
- * arithmetic is evaluated exactly as written (no FMA contraction).
+ * Plain C++17, no third-party code, compiled with -O3 -ffp-contract=off -fno-fast-math so that fp32/fp64
+ * arithmetic is evaluated exactly as written (no FMA contraction, no re-association).  No function here is
+ * shaped after the HIP kernels: summation orders, LP arithmetic and cluster orders are the reference's.
  */
 #ifndef ORACLE_H
 #define ORACLE_H
@@ -78,6 +80,10 @@ int orc_astar_search(const SogmSpec *s, const SogmAstarParams *ap, const float *
                      double t_after_map, double corridor_tau, double *out_route,
                      int *out_route_len, int route_cap, int out_stats[4], int *out_trace,
                      int trace_cap, int *out_trace_len);
+
+/* 0 (default): search(…, init = true, …), then reset() + search(…, false, …) if NO_PATH (baseline_fake.cpp:284-291);
+ * 1 / 2: exactly one RiskHybridAstar::search with init = true / false */
+void orc_astar_set_mode(int mode);
 
 /* ---- a12: sdlp::linprog<d>  min c^T x s.t. A x <= b  (traj_utils/include/traj_utils/sdlp.hpp:709-787) */
 /* d in {3,4}; A row-major m x d; returns minimum, +inf infeasible, -inf unbounded */

@@ -121,7 +121,11 @@ PROTOTYPES = {
     "sogm_project_neighbours": (_i, [_vp, _vp, _i, _vp, _vp]),
     "sogm_set_future_risk": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "sogm_download_reference_layout": (_i, [_vp, _i, _vp]),
+    "sogm_map_state": (_i, [_vp, _i, C.POINTER(C.c_double), C.POINTER(C.c_float), _vp]),
     "sogm_traj_eval": (_i, [_vp, _i, _vp, _vp, _vp, _vp]),
+    "sogm_firi_batched": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, C.c_double, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "sogm_planner_select_agents": (_i, [_vp, _i, _i]),
+    "sogm_planner_set_search_mode": (_i, [_vp, _i]),
     "sogm_query_clear": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     "sogm_obstacle_points": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp]),
     "sogm_planner_create": (_i, [_vp, C.POINTER(SogmAstarParams), C.POINTER(SogmPlannerParams),

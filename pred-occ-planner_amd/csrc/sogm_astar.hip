@@ -277,7 +277,8 @@ __global__ __launch_bounds__(ASTAR_THREADS) void k_astar(
     const double *__restrict__ start_pva, const double *__restrict__ goal,
     const double *__restrict__ t_start, int32_t *__restrict__ out_ret,
     double *__restrict__ out_route, int32_t *__restrict__ out_route_len, int route_cap,
-    int32_t *__restrict__ out_stats, int32_t *__restrict__ out_trace, int trace_cap, int agent0, FlowCtl fc) {
+    int32_t *__restrict__ out_stats, int32_t *__restrict__ out_trace, int trace_cap, int agent0, FlowCtl fc,
+    int search_mode) {
   const int agent = blockIdx.x + agent0;
   const int tid   = threadIdx.x;
   // dataflow replan: tell the gate kernel that this workgroup holds its CU resources (the corridor kernel's
@@ -333,7 +334,8 @@ __global__ __launch_bounds__(ASTAR_THREADS) void k_astar(
   const double  inv_res   = 1.0 / ap.resolution;
   const double  inv_tres  = 1.0 / ap.time_resolution;
   // baseline_fake.cpp:282: t_after_map = traj_start_time_ - map_->getMapTime()
-  const double time_start  = t_start[agent] - m.stamps[agent];
+  // search_mode bit 2: t_start already is RiskHybridAstar::search's time_start argument (seconds after the map stamp)
+  const double time_start  = (search_mode & 4) ? t_start[agent] : t_start[agent] - m.stamps[agent];
   const double time_origin = time_start;
   const double tau         = ap.time_resolution;
 
@@ -364,7 +366,10 @@ __global__ __launch_bounds__(ASTAR_THREADS) void k_astar(
   long long tk[6] = {0, 0, 0, 0, 0, 0};  // wall_clock64 ticks (100 MHz): pop, eval, dup, merge, write, n_exp
   long long tmark = 0;
 
-  for (int attempt = 0; attempt < 2; ++attempt) {  // baseline_fake.cpp:284-291
+  // search_mode 0: the replan's call pattern (init_search = true, then false if NO_PATH, baseline_fake.cpp:284-291);
+  // 1 / 2: exactly one search(…, init = true / false, …) for the per-object shim
+  const int attempt_lo = (search_mode & 3) == 2 ? 1 : 0, attempt_hi = (search_mode & 3) == 1 ? 1 : 2;
+  for (int attempt = attempt_lo; attempt < attempt_hi; ++attempt) {
     // reset(): clear the hash table (all lanes)
     for (int i = tid; i < hcap; i += ASTAR_THREADS) htab[i] = HASH_EMPTY;
     __syncthreads();
@@ -854,11 +859,11 @@ int launch_astar(const MapView &m, const SogmAstarParams &ap, double corridor_ta
                  const AstarWorkspace &wsp, int n_agents, const double *start_pva,
                  const double *goal, const double *t_start, int32_t *out_ret, double *out_route,
                  int32_t *out_route_len, int route_cap, int32_t *out_stats, int32_t *out_trace,
-                 int trace_cap, hipStream_t st, int agent0, const FlowCtl *fc) {
+                 int trace_cap, hipStream_t st, int agent0, const FlowCtl *fc, int search_mode) {
   const FlowCtl none{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   hipLaunchKernelGGL(k_astar, dim3(n_agents), dim3(ASTAR_THREADS), 0, st, m, ap, corridor_tau, wsp,
                      start_pva, goal, t_start, out_ret, out_route, out_route_len, route_cap,
-                     out_stats, out_trace, trace_cap, agent0, fc ? *fc : none);
+                     out_stats, out_trace, trace_cap, agent0, fc ? *fc : none, search_mode);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

@@ -8,15 +8,17 @@
 //   sdlp::linprog<3|4> (traj_utils/include/traj_utils/sdlp.hpp) — the projective Seidel LP, whole-wave
 //   ShrinkCorridor / checkCorridorValidity / checkCorridorIntersect / checkGoalReachability.
 //
-// Mapping to CDNA4: one workgroup (one 64-lane wave) per (agent, path segment) — 7 segments x 128
-// agents = 896 independent problems fill the 256 CUs.  Inside a workgroup the point-cloud work is
-// lane-parallel (obstacle-point extraction with an order-preserving wave scan, ellipsoid-frame
-// transform, tangent planes, the greedy plane selection with a wave arg-min that breaks ties by
-// index exactly like the reference's sequential scan); the tiny dense solves (4-D LP, 9-variable
-// L-BFGS, 3x3 Jacobi) run on lane 0 with their working set in LDS.  A second small kernel per
-// agent does the sequential bookkeeping (first invalid corridor, adjacent intersections, goal
-// projection).  All fp64, operation order identical to the CPU oracle (-ffp-contract=off,
-// include/sogm_detmath.h for log) so polytopes match bit for bit.  No dense contraction -> no MFMA.
+// Mapping to CDNA4: one 64-lane wave per (agent, path segment) — 7 segments x 128 agents = 896 independent
+// problems fill the 256 CUs (4 waves per CU, 39.8 KB LDS each).  Inside a wave the point-cloud work is lane-parallel
+// (obstacle-point extraction with an order-preserving wave scan, ellipsoid-frame transform, tangent planes, the
+// greedy plane selection with a wave arg-min that breaks ties by index exactly like the reference's sequential scan);
+// the LPs are solved by the whole wave (sdlp's projective algorithm, see linprog_wave), the MVIE cost is evaluated one
+// face per lane and summed in the reference's order, the 9-variable L-BFGS and the 3x3 Jacobi run replicated /
+// on lane 0 with their working set in LDS.  The per-agent bookkeeping (first invalid corridor, adjacent
+// intersections, goal projection) is done by the wave that finishes an agent's last segment (dataflow replan) or by
+// a second small kernel (grouped path).  All fp64, operation order identical to the CPU oracle — which follows the
+// reference's (-ffp-contract=off, include/sogm_detmath.h for log) — so polytopes match bit for bit.
+// No dense contraction -> no MFMA.
 #include <hip/hip_runtime.h>
 
 #include <cfloat>
@@ -1160,68 +1162,104 @@ namespace {
 // =================================================================================================
 // Kernel A: one workgroup per (segment, agent)
 // =================================================================================================
+// MB = capacity of the boundary block (6 in the replan path: getInitCorridor's box), DIRECT = the standalone
+// firi::firi entry (sogm_firi_batched): bd / points / a / b / r come from the caller instead of the route and the
+// map, and the polytope is returned as firi leaves it (no ShrinkCorridor, no validity LP).
+struct FiriDirect {
+  const double  *bd;        // [n][n_bd][4]
+  int            n_bd;
+  const double  *pc;        // packed xyz
+  const int32_t *pc_range;  // [n][2]
+  const double  *a, *b;     // [n][3]
+  double        *r;         // [n][3] in / out
+  int            iterations;
+  double        *hpoly;     // [n][max_faces][4]
+  int32_t       *nfaces;    // [n]
+  int32_t       *status;    // [n] 1 ok, 0 a or b outside bd (firi returns false), -3 over capacity
+  int            max_faces;
+  int            first;     // problem index of slot 0 in this launch
+  double         epsilon;
+};
+
+template <int MB>
+__host__ __device__ constexpr int firi_small_doubles() { return 34 + 9 * MB; }
+
+template <int MB, bool DIRECT>
 __device__ __forceinline__ void corridor_segment_body(const MapView &m, const SogmPlannerParams &pp,
                                                       const CorridorWorkspace &ws, const double *start_pva,
                                                       const double *t_start, const double *route,
                                                       const int32_t *route_len, int route_cap, int agent, int seg,
-                                                      char *smem) {
+                                                      char *smem, const FiriDirect &fd) {
   const int lane  = threadIdx.x;
-  const int rl    = route_len[agent];
-  const int slot  = agent * SOGM_MAX_PIECES + seg;
-  if (seg >= rl - 1 || seg >= SOGM_MAX_PIECES) {
-    if (lane == 0) ws.seg_state[slot] = -2;  // no such segment
-    return;
+  const int slot  = DIRECT ? agent : agent * SOGM_MAX_PIECES + seg;
+  if constexpr (!DIRECT) {
+    const int rl = route_len[agent];
+    if (seg >= rl - 1 || seg >= SOGM_MAX_PIECES) {
+      if (lane == 0) ws.seg_state[slot] = -2;  // no such segment
+      return;
+    }
   }
+  constexpr int  SMALL   = MB == 6 ? 96 : firi_small_doubles<MB>();
   double        *s_lp    = (double *)smem;                    // LP_WORK_DOUBLES
   double        *s_rows  = s_lp + LP_WORK_DOUBLES;            // LP_MAX_ROWS * 5
   double        *s_lm    = s_rows + LP_MAX_ROWS * 5;          // 324 history + 16 hand-off + 36 alpha/ys
   double        *s_fH    = s_lm + 2 * 18 * 9 + 16 + 36;       // FIRI_MAX_H * 4
   double        *s_poly  = s_fH + FIRI_MAX_H * 4;             // FIRI_MAX_H * 4
-  double        *s_small = s_poly + FIRI_MAX_H * 4;           // 96 doubles of shared small state
-  int           *s_perm  = (int *)(s_small + 96);             // LP_MAX_ROWS
+  double        *s_small = s_poly + FIRI_MAX_H * 4;           // SMALL doubles of shared small state
+  int           *s_perm  = (int *)(s_small + SMALL);          // LP_MAX_ROWS
   int           *s_int   = s_perm + LP_MAX_ROWS;              // 16 ints
   unsigned char *s_flag  = (unsigned char *)(s_int + 16);     // pc_capacity bytes
   SolverScratch  sc{s_lp, s_perm, s_rows, s_lm};
 
   // shared small state layout
-  double *s_fwd  = s_small;       // 9  forward
-  double *s_fa   = s_small + 9;   // 3  fwd_a
-  double *s_fb   = s_small + 12;  // 3  fwd_b
-  double *s_p    = s_small + 15;  // 3
-  double *s_fh   = s_small + 18;  // 4  current plane
-  double *s_bd   = s_small + 22;  // 24 bd
-  double *s_fB   = s_small + 46;  // 18 forwardB
-  double *s_fD   = s_small + 64;  // 6  forwardD
-  double *s_dD   = s_small + 70;  // 6  distDs
-  double *s_box  = s_small + 76;  // 6  llc, lhc
-  double *s_w    = s_small + 82;  // 6  w0, w1
+  double *s_fwd  = s_small;                 // 9  forward
+  double *s_fa   = s_small + 9;             // 3  fwd_a
+  double *s_fb   = s_small + 12;            // 3  fwd_b
+  double *s_p    = s_small + 15;            // 3
+  double *s_fh   = s_small + 18;            // 4  current plane
+  double *s_bd   = s_small + 22;            // 4 MB  bd
+  double *s_fB   = s_bd + 4 * MB;           // 3 MB  forwardB
+  double *s_fD   = s_fB + 3 * MB;           // MB    forwardD
+  double *s_dD   = s_fD + MB;               // MB    distDs
+  double *s_box  = s_dD + MB;               // 6  llc, lhc
+  double *s_w    = s_box + 6;               // 6  w0, w1 (a, b)
 
-  const double   *rt    = route + (size_t)agent * route_cap * 6;
-  const double   *sp    = start_pva + agent * 9;
+  const double   *rt    = DIRECT ? nullptr : route + (size_t)agent * route_cap * 6;
+  const double   *sp    = DIRECT ? nullptr : start_pva + agent * 9;
   const int       cap   = pp.pc_capacity;
-  double         *pc    = ws.pc + (size_t)slot * cap * 3;
+  const int       prob  = DIRECT ? fd.first + slot : 0;
+  const double   *pc    = DIRECT ? fd.pc + (size_t)fd.pc_range[prob * 2] * 3 : ws.pc + (size_t)slot * cap * 3;
   double         *fpc   = ws.fpc + (size_t)slot * cap * 3;
   double         *tang  = ws.tang + (size_t)slot * cap * 4;
   double         *distR = ws.distr + (size_t)slot * cap;
 
   long long *dbg = ws.seg_dbg + (size_t)slot * 16;
   const long long tk0 = wall_clock64();
+  const int M = DIRECT ? fd.n_bd : 6;
   if (lane == 0) {
     for (int k = 0; k < 16; ++k) dbg[k] = 0;
-    segment_box(pp, sp, rt, seg, s_box, s_w);
-    // getInitCorridor (baseline.cpp:127-141) with the local box
-    for (int i = 0; i < 24; ++i) s_bd[i] = 0;
-    for (int k = 0; k < 3; ++k) {
-      s_bd[k * 4 + k]       = 1.0;
-      s_bd[(k + 3) * 4 + k] = -1.0;
-      s_bd[k * 4 + 3]       = -s_box[3 + k];
-      s_bd[(k + 3) * 4 + 3] = s_box[k];
+    if constexpr (DIRECT) {
+      for (int i = 0; i < 4 * M; ++i) s_bd[i] = fd.bd[(size_t)prob * M * 4 + i];
+      for (int k = 0; k < 3; ++k) {
+        s_w[k]     = fd.a[prob * 3 + k];
+        s_w[3 + k] = fd.b[prob * 3 + k];
+      }
+    } else {
+      segment_box(pp, sp, rt, seg, s_box, s_w);
+      // getInitCorridor (baseline.cpp:127-141) with the local box
+      for (int i = 0; i < 24; ++i) s_bd[i] = 0;
+      for (int k = 0; k < 3; ++k) {
+        s_bd[k * 4 + k]       = 1.0;
+        s_bd[(k + 3) * 4 + k] = -1.0;
+        s_bd[k * 4 + 3]       = -s_box[3 + k];
+        s_bd[(k + 3) * 4 + 3] = s_box[k];
+      }
     }
   }
   __syncthreads();
 
   // obstacle points: written by k_corridor_points (the only stage of the corridor generation that reads the SOGM)
-  int N = ws.seg_npts[slot];
+  int N = DIRECT ? fd.pc_range[prob * 2 + 1] - fd.pc_range[prob * 2] : ws.seg_npts[slot];
   int overflow = 0;
   if (N > cap) {
     N        = cap;
@@ -1234,9 +1272,9 @@ __device__ __forceinline__ void corridor_segment_body(const MapView &m, const So
     dbg[5] = wall_clock64() - tk0;
   }
   // ---------------- firi::firi (firi.hpp:238-365) ----------------
-  const double epsilon = 1.0e-6;
-  const int    M       = 6;
+  const double epsilon = DIRECT ? fd.epsilon : 1.0e-6;
   int          nH      = 0;
+  const int    n_iter  = DIRECT ? fd.iterations : pp.firi_iterations;
   bool         seed_ok = true;
   if (lane == 0) {
     int ok = 1;
@@ -1254,7 +1292,9 @@ __device__ __forceinline__ void corridor_segment_body(const MapView &m, const So
     double R[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
     double p[3]    = {0.5 * (s_w[0] + s_w[3]), 0.5 * (s_w[1] + s_w[4]), 0.5 * (s_w[2] + s_w[5])};
     double r[3]    = {1, 1, 1};
-    for (int loop = 0; loop < pp.firi_iterations; ++loop) {
+    if constexpr (DIRECT)
+      for (int k = 0; k < 3; ++k) r[k] = fd.r[prob * 3 + k];
+    for (int loop = 0; loop < n_iter; ++loop) {
       if (lane == 0) {
         double forward[3][3], backward[3][3];
         for (int k = 0; k < 3; ++k)
@@ -1347,7 +1387,7 @@ __device__ __forceinline__ void corridor_segment_body(const MapView &m, const So
       int    pcMinId = lidx == 0x7fffffff ? 0 : lidx;
       double minSqrD = INFINITY;
       int    bdMinId = 0;
-      unsigned bdFlags = 0x3f;
+      unsigned bdFlags = M >= 32 ? 0xffffffffu : (1u << M) - 1u;
       for (int j = 0; j < M; ++j)
         if (s_dD[j] < minSqrD) {
           minSqrD = s_dD[j];
@@ -1423,7 +1463,7 @@ __device__ __forceinline__ void corridor_segment_body(const MapView &m, const So
         dbg[1 + (loop > 0)] = nH;
         dbg[6 + 2 * (loop > 0)] = wall_clock64() - tk0;
       }
-      if (loop == pp.firi_iterations - 1) break;
+      if (loop == n_iter - 1) break;
       {
         const int       mm  = nH < LP_MAX_ROWS - 9 ? nH : LP_MAX_ROWS - 9;
         const long long tm0 = wall_clock64();
@@ -1432,8 +1472,25 @@ __device__ __forceinline__ void corridor_segment_body(const MapView &m, const So
       }
       __syncthreads();
     }
+    if constexpr (DIRECT)
+      if (lane == 0)
+        for (int k = 0; k < 3; ++k) fd.r[prob * 3 + k] = r[k];
   }
 
+  if constexpr (DIRECT) {
+    int nf = seed_ok ? nH : 0;
+    if (nf > fd.max_faces) {
+      nf       = fd.max_faces;
+      overflow = 1;
+    }
+    double *out = fd.hpoly + (size_t)prob * fd.max_faces * 4;
+    for (int i = lane; i < nf * 4; i += 64) out[i] = s_poly[i];
+    if (lane == 0) {
+      fd.nfaces[prob] = nf;
+      fd.status[prob] = overflow ? -3 : (seed_ok ? 1 : 0);
+    }
+    return;
+  }
   // ---------------- ShrinkCorridor + checkCorridorValidity ----------------
   int nf = seed_ok ? nH : 0;
   if (nf > pp.max_faces) {
@@ -1472,8 +1529,16 @@ __global__ __launch_bounds__(64) void k_corridor_segment(
     const double *__restrict__ t_start, const double *__restrict__ route,
     const int32_t *__restrict__ route_len, int route_cap, int agent0) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  corridor_segment_body(m, pp, ws, start_pva, t_start, route, route_len, route_cap, blockIdx.y + agent0, blockIdx.x,
-                        smem);
+  corridor_segment_body<6, false>(m, pp, ws, start_pva, t_start, route, route_len, route_cap, blockIdx.y + agent0,
+                                  blockIdx.x, smem, FiriDirect{});
+}
+
+#define FIRI_DIRECT_BD_MAX 32
+__global__ __launch_bounds__(64) void k_firi_direct(MapView m, SogmPlannerParams pp, CorridorWorkspace ws,
+                                                    FiriDirect fd) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  corridor_segment_body<FIRI_DIRECT_BD_MAX, true>(m, pp, ws, nullptr, nullptr, nullptr, nullptr, 0, blockIdx.x, 0, smem,
+                                                  fd);
 }
 
 // =================================================================================================
@@ -1633,7 +1698,8 @@ __global__ __launch_bounds__(64) void k_corridor_flow(MapView m, SogmPlannerPara
       __threadfence_block();
       __syncthreads();
     }
-    corridor_segment_body(m, pp, ws, start_pva, t_start, route, route_len, route_cap, agent, seg, smem);
+    corridor_segment_body<6, false>(m, pp, ws, start_pva, t_start, route, route_len, route_cap, agent, seg, smem,
+                                    FiriDirect{});
     __syncthreads();
     __threadfence();  // this segment's polytope is visible before its completion is counted
     const int last = flow_ticket(&fc.seg_done[agent]) == SOGM_MAX_PIECES - 1;
@@ -1659,6 +1725,11 @@ __global__ __launch_bounds__(64) void k_corridor_flow(MapView m, SogmPlannerPara
 
 size_t corridor_segment_lds(int pc_capacity) {
   return sizeof(double) * (LP_WORK_DOUBLES + LP_MAX_ROWS * 5 + 2 * 18 * 9 + 16 + 36 + 2 * FIRI_MAX_H * 4 + 96) +
+         sizeof(int) * (LP_MAX_ROWS + 16) + (size_t)pc_capacity;
+}
+size_t firi_direct_lds(int pc_capacity) {
+  return sizeof(double) * (LP_WORK_DOUBLES + LP_MAX_ROWS * 5 + 2 * 18 * 9 + 16 + 36 + 2 * FIRI_MAX_H * 4 +
+                           firi_small_doubles<FIRI_DIRECT_BD_MAX>()) +
          sizeof(int) * (LP_MAX_ROWS + 16) + (size_t)pc_capacity;
 }
 
@@ -2002,6 +2073,37 @@ extern "C" int sogm_linprog_batched(int d, const double *c, const double *A, con
   else
     hipLaunchKernelGGL(sogm::k_linprog<4>, dim3(n), dim3(64), lds, st, c, A, b, row_range, out_x, out_min);
   SOGM_HIP_CHECK(hipGetLastError());
+  return SOGM_OK;
+}
+
+extern "C" int sogm_firi_batched(const double *bd, int n_bd, const double *pc_xyz, const int32_t *pc_range,
+                                 const double *a, const double *b, double *r, int iterations, double epsilon, int n,
+                                 int max_points, int max_faces, double *out_hpoly, int32_t *out_nfaces,
+                                 int32_t *out_status, void *stream) {
+  if (n < 0 || n_bd < 1 || n_bd > FIRI_DIRECT_BD_MAX || iterations < 1 || max_points < 1 || max_points > 16384 ||
+      max_faces < 1 || max_faces > FIRI_MAX_H ||
+      (n > 0 && (!bd || !pc_range || !a || !b || !r || !out_hpoly || !out_nfaces || !out_status)))
+    return SOGM_ERR_INVALID_ARG;
+  if (n == 0) return SOGM_OK;
+  hipStream_t st = (hipStream_t)stream;
+  // per-problem scratch (ellipsoid-frame points, tangent planes, distances, debug words): stream-ordered
+  const size_t per = sizeof(double) * 8 * (size_t)max_points + sizeof(long long) * 16;
+  char        *scratch = nullptr;
+  SOGM_HIP_CHECK(hipMallocAsync((void **)&scratch, per * (size_t)n, st));
+  sogm::CorridorWorkspace ws{};
+  ws.fpc     = (double *)scratch;
+  ws.tang    = ws.fpc + (size_t)n * max_points * 3;
+  ws.distr   = ws.tang + (size_t)n * max_points * 4;
+  ws.seg_dbg = (long long *)(ws.distr + (size_t)n * max_points);
+  SogmPlannerParams pp{};
+  pp.pc_capacity = max_points;
+  sogm::FiriDirect fd{bd, n_bd, pc_xyz, pc_range, a, b, r, iterations, out_hpoly, out_nfaces, out_status,
+                      max_faces, 0, epsilon};
+  hipLaunchKernelGGL(sogm::k_firi_direct, dim3(n), dim3(64), sogm::firi_direct_lds(max_points), st, sogm::MapView{},
+                     pp, ws, fd);
+  const hipError_t e = hipGetLastError();
+  (void)hipFreeAsync(scratch, st);
+  SOGM_HIP_CHECK(e);
   return SOGM_OK;
 }
 

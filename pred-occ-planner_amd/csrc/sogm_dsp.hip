@@ -490,12 +490,11 @@ __global__ __launch_bounds__(1024) void k_dsp_velocity(DspDev d, const int32_t *
   int   *aux = lab + MP;                            // sizes per root, then rank of a point inside its cluster
   __shared__ int           s_scan[1024], s_base_ng, s_base_g, s_changed, s_nc, s_err;
   __shared__ vel::Item     s_item[VEL_MAX_CLUSTERS];
-  __shared__ int           s_slot_of_root_n;  // unused marker (keeps the layout explicit)
   __shared__ int           s_root[VEL_MAX_CLUSTERS], s_size[VEL_MAX_CLUSTERS], s_off[VEL_MAX_CLUSTERS],
       s_dynseq[VEL_MAX_CLUSTERS];
   __shared__ float         s_cx[VEL_MAX_CLUSTERS], s_cy[VEL_MAX_CLUSTERS], s_cz[VEL_MAX_CLUSTERS];
   __shared__ float         s_v[VEL_MAX_DYN][4];  // vx vy vz intensity of the possibly-dynamic clusters
-  __shared__ int           s_ndyn, s_total_dyn, s_n_ground, s_n_static;
+  __shared__ int           s_total_dyn, s_n_static;
   float *born = d.born + (size_t)a * MP * 7;
   if (tid == 0) {
     s_base_ng = 0;
@@ -683,7 +682,6 @@ __global__ __launch_bounds__(1024) void k_dsp_velocity(DspDev d, const int32_t *
         ++nd;
       }
     }
-    s_ndyn      = nd;
     s_total_dyn = off;
     off += n_ground;
     for (int c = 0; c < nc; ++c)

@@ -941,6 +941,19 @@ int sogm_download_reference_layout(sogm_ctx *c, int agent, float *out) {
   return SOGM_OK;
 }
 
+int sogm_map_state(sogm_ctx *c, int agent, double *out_time, float *out_center, void *stream) {
+  if (!c || agent < 0 || agent >= c->n_agents || (!out_time && !out_center)) return SOGM_ERR_INVALID_ARG;
+  if (!c->updated) return SOGM_ERR_STATE;
+  SOGM_HIP_CHECK(hipSetDevice(c->device));
+  hipStream_t st = (hipStream_t)stream;
+  if (out_time)
+    SOGM_HIP_CHECK(hipMemcpyAsync(out_time, c->d_stamps + agent, sizeof(double), hipMemcpyDeviceToHost, st));
+  if (out_center)
+    SOGM_HIP_CHECK(hipMemcpyAsync(out_center, c->d_poses + 3 * agent, 3 * sizeof(float), hipMemcpyDeviceToHost, st));
+  SOGM_HIP_CHECK(hipStreamSynchronize(st));
+  return SOGM_OK;
+}
+
 int sogm_traj_eval(const SogmTrajRecord *records, int n, const double *t, double *out_pva,
                    int32_t *out_valid, void *stream) {
   if (!records || !t || !out_pva || !out_valid || n < 0) return SOGM_ERR_INVALID_ARG;

@@ -156,6 +156,9 @@ int sogm_planner_create(sogm_ctx *map, const SogmAstarParams *astar, const SogmP
     if (ng > SOGM_MAX_GROUPS) ng = SOGM_MAX_GROUPS;
     p->n_groups = A < ng ? A : ng;
   }
+  p->sel_first   = 0;
+  p->sel_count   = A;
+  p->search_mode = 0;
   for (int g = 0; g < p->n_groups && e == hipSuccess; ++g) {
     e = hipStreamCreateWithFlags(&p->gstream[g], hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_corr[g], hipEventDisableTiming);
@@ -233,9 +236,9 @@ int sogm_astar_search(sogm_planner *p, const double *start_pva, const double *go
   SOGM_HIP_CHECK(hipSetDevice(p->map->device));
   hipStream_t st = (hipStream_t)stream;
   prof_begin(p->map, SOGM_PROF_ASTAR, st);
-  int rc = launch_astar(view_of(p->map), p->ap, p->pp.corridor_tau, p->aw, p->map->n_agents,
+  int rc = launch_astar(view_of(p->map), p->ap, p->pp.corridor_tau, p->aw, p->sel_count,
                         start_pva, goal, t_start, out_ret, out_route, out_route_len, route_cap,
-                        out_stats, out_trace, out_trace ? trace_cap : 0, st);
+                        out_stats, out_trace, out_trace ? trace_cap : 0, st, p->sel_first, nullptr, p->search_mode);
   prof_end(p->map, SOGM_PROF_ASTAR, st);
   if (rc) {
     sogm::set_error("k_astar", hipGetLastError());
@@ -254,9 +257,9 @@ int sogm_corridor_generate(sogm_planner *p, const double *start_pva, const doubl
   SOGM_HIP_CHECK(hipSetDevice(p->map->device));
   hipStream_t st = (hipStream_t)stream;
   prof_begin(p->map, SOGM_PROF_CORRIDOR, st);
-  int rc = launch_corridor(view_of(p->map), p->pp, p->cw, p->map->n_agents, start_pva, t_start,
+  int rc = launch_corridor(view_of(p->map), p->pp, p->cw, p->sel_count, start_pva, t_start,
                            route, route_len, route_cap, out_polys, out_nfaces, out_npoly, out_goal,
-                           st);
+                           st, p->sel_first);
   prof_end(p->map, SOGM_PROF_CORRIDOR, st);
   if (rc) {
     sogm::set_error("k_corridor", hipGetLastError());
@@ -301,8 +304,8 @@ int sogm_bezier_qp_solve(sogm_planner *p, const double *start_pva, const double 
   SOGM_HIP_CHECK(hipSetDevice(p->map->device));
   hipStream_t st = (hipStream_t)stream;
   prof_begin(p->map, SOGM_PROF_QP, st);
-  int rc = launch_qp(p->pp, p->qs, p->qw, p->qc, p->map->n_agents, start_pva, goal_pv, polys,
-                     nfaces, npoly, out_cpts, out_status, out_iters, st);
+  int rc = launch_qp(p->pp, p->qs, p->qw, p->qc, p->sel_count, start_pva, goal_pv, polys,
+                     nfaces, npoly, out_cpts, out_status, out_iters, st, p->sel_first);
   prof_end(p->map, SOGM_PROF_QP, st);
   if (rc) {
     sogm::set_error("k_qp", hipGetLastError());
@@ -317,11 +320,23 @@ int sogm_safe_after_opt(sogm_planner *p, const double *cpts, const int32_t *npol
     return SOGM_ERR_INVALID_ARG;
   SOGM_HIP_CHECK(hipSetDevice(p->map->device));
   if (int rc = sogm::join_exchange(p->map, (hipStream_t)stream)) return rc;
-  if (sogm::launch_deconflict(p->map->n_agents, cpts, npoly, records, n_records, ego_ids, t_now, out_safe,
-                              (hipStream_t)stream, 0) != 0) {
+  if (sogm::launch_deconflict(p->sel_count, cpts, npoly, records, n_records, ego_ids, t_now, out_safe,
+                              (hipStream_t)stream, p->sel_first) != 0) {
     sogm::set_error("sogm_safe_after_opt", hipGetLastError());
     return SOGM_ERR_HIP;
   }
+  return SOGM_OK;
+}
+
+int sogm_planner_select_agents(sogm_planner *p, int first, int count) {
+  if (!p || first < 0 || count < 1 || first + count > p->map->n_agents) return SOGM_ERR_INVALID_ARG;
+  p->sel_first = first;
+  p->sel_count = count;
+  return SOGM_OK;
+}
+int sogm_planner_set_search_mode(sogm_planner *p, int mode) {
+  if (!p || mode < 0 || mode > 7 || (mode & 3) == 3) return SOGM_ERR_INVALID_ARG;
+  p->search_mode = mode;
   return SOGM_OK;
 }
 

@@ -95,7 +95,8 @@ int    launch_astar(const MapView &m, const SogmAstarParams &ap, double corridor
                     const AstarWorkspace &wsp, int n_agents, const double *start_pva,
                     const double *goal, const double *t_start, int32_t *out_ret,
                     double *out_route, int32_t *out_route_len, int route_cap, int32_t *out_stats,
-                    int32_t *out_trace, int trace_cap, hipStream_t st, int agent0 = 0, const FlowCtl *fc = nullptr);
+                    int32_t *out_trace, int trace_cap, hipStream_t st, int agent0 = 0, const FlowCtl *fc = nullptr,
+                 int search_mode = 0);
 
 }  // namespace sogm
 
@@ -135,4 +136,7 @@ struct sogm_planner {
   sogm::FlowCtl  fc;
   hipStream_t    fstream[4];  // A*, corridors, QP, finish
   hipEvent_t     ev_gate, ev_fdone[4];
+  // per-object use of the per-stage entries (sogm_planner_select_agents / _set_search_mode)
+  int sel_first, sel_count;  // agents the per-stage entries process; (0, A) by default
+  int search_mode;           // 0 the replan's two-call pattern, 1 / 2 one search with init_search true / false
 };

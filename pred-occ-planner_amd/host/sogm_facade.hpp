@@ -17,6 +17,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <array>
+#include <limits>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -131,8 +132,8 @@ class RiskMap {
   void setCoordinator(const std::vector<Vec3> &body_particles) {
     check(sogm_set_body_particles(ctx_, body_particles[0].data(), (int)body_particles.size()), "set_body");
   }
-  // Tick pipelining (no reference counterpart): 0 off, 1 in-place pre-clear under the QP stage, 2 double-buffered
-  // (second grid; returns false and leaves the mode unchanged if HBM has no room for it)
+  // Tick pipelining (no reference counterpart): 0 off, 1 in-place pre-clear under the QP stage, 2 / 3 a pool of
+  // two / three grids (returns false and leaves the mode unchanged if HBM has no room for them)
   bool setTickPipelining(int mode) {
     const int rc = sogm_set_overlap_clear(ctx_, mode);
     if (rc == SOGM_ERR_CAPACITY) return false;
@@ -144,8 +145,12 @@ class RiskMap {
               const float *poses, const double *stamps, hipStream_t st = nullptr) {
     check(sogm_update_gt(ctx_, cloud_xyz, cloud_range, cyl, n_cyl, poses, stamps, st), "sogm_update_gt");
   }
-  // RiskBase::futureRiskCallback for agent 0 of a 1-agent context: adopt one map/future_risk message
-  void futureRiskCallback(const std::vector<float> &msg_data, int stride, hipStream_t st = nullptr) {
+  // RiskBase::futureRiskCallback for agent 0 of a 1-agent context: adopt one map/future_risk message.
+  // `map_time` is the map stamp to adopt (the ROS header / receive time as a double).  The reference reads the
+  // message's trailing float32 field into a dead local (risk_base.cpp:72) and leaves last_update_time_ alone; a
+  // float32 epoch time is quantised to ~128 s, so it is only used when no map_time is given (NaN).
+  void futureRiskCallback(const std::vector<float> &msg_data, int stride, hipStream_t st = nullptr,
+                          double map_time = std::numeric_limits<double>::quiet_NaN()) {
     const SogmSpec sp = spec_;
     const int      V  = sp.L * sp.W * sp.H;
     std::vector<float> grid;
@@ -153,6 +158,7 @@ class RiskMap {
     double stamp = 0.0;
     if (n_ != 1 || !splitFutureRiskMsg(msg_data, V, sp.T, stride, grid, pose, stamp))
       throw std::runtime_error("futureRiskCallback: malformed message");
+    if (map_time == map_time) stamp = map_time;
     g_.put(grid.data(), grid.size());
     f_.put(pose, 3);
     t_.put(&stamp, 1);
@@ -221,6 +227,7 @@ class DspMap {
           "sogm_filter_point_cloud");
   }
   // int DSPMap::update(n, 3, pts, px, py, pz, stamp, qw, qx, qy, qz) for the whole batch (device pointers)
+  // labels == nullptr: velocityEstimationThread (clustering + association, :1487-1678) runs on the GPU
   void update(const float *points, const float *labels, const int32_t *cloud_range, const float *sensor_pos,
               const float *sensor_quat, const double *stamps, int32_t *out_ok, hipStream_t st = nullptr) {
     check(sogm_update_dsp(h_, points, labels, cloud_range, sensor_pos, sensor_quat, stamps, out_ok, st),

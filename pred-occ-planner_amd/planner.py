@@ -28,6 +28,23 @@ def linprog_batched(c, A_rows, b_rows, row_range):
     return x, v
 
 
+def firi_batched(bd, pc, pc_range, a, b, r=None, iterations=2, epsilon=1.0e-6, max_points=4096, max_faces=64):
+    """firi::firi (plan_manager/include/sfc_gen/firi.hpp:238-365) for n independent problems.
+    bd [n, n_bd, 4], pc [total, 3], pc_range [n, 2] int32, a / b [n, 3] — device float64 tensors; r [n, 3] in/out
+    (ones if None).  Returns (hpoly [n, max_faces, 4], nfaces [n], status [n], r [n, 3])."""
+    n, n_bd = int(bd.shape[0]), int(bd.shape[1])
+    dev = bd.device
+    if r is None:
+        r = torch.ones((n, 3), dtype=torch.float64, device=dev)
+    hp = torch.zeros((n, max_faces, 4), dtype=torch.float64, device=dev)
+    nf = torch.zeros((n,), dtype=torch.int32, device=dev)
+    st = torch.zeros((n,), dtype=torch.int32, device=dev)
+    check(lib().sogm_firi_batched(bd.data_ptr(), n_bd, pc.data_ptr(), pc_range.data_ptr(), a.data_ptr(), b.data_ptr(),
+                                  r.data_ptr(), iterations, epsilon, n, max_points, max_faces, hp.data_ptr(),
+                                  nf.data_ptr(), st.data_ptr(), _stream()), "sogm_firi_batched")
+    return hp, nf, st, r
+
+
 class SogmPlanner:
     def __init__(self, sogm_map, astar_params, planner_params, qp_settings):
         self.map = sogm_map
@@ -48,6 +65,16 @@ class SogmPlanner:
             self.close()
         except Exception:
             pass
+
+    def select_agents(self, first=0, count=None):
+        """Per-stage entries (search / generateCorridors / optimize / isSafeAfterOpt) then process agents
+        [first, first + count) only; replan() always processes all."""
+        check(lib().sogm_planner_select_agents(self._p, first, self.A if count is None else count),
+              "sogm_planner_select_agents")
+
+    def set_search_mode(self, mode):
+        """0 the replan's two-call pattern, 1 / 2 one RiskHybridAstar::search with init_search true / false."""
+        check(lib().sogm_planner_set_search_mode(self._p, mode), "sogm_planner_set_search_mode")
 
     def flow_error(self):
         """0 if the last replan()'s dataflow kernels completed normally (synchronises the device)."""

@@ -118,6 +118,13 @@ class SogmMap:
         check(lib().sogm_profile_read(self._ctx, out), "sogm_profile_read")
         return list(out)
 
+    def map_state(self, agent):
+        """(getMapTime().toSec(), getMapCenter()) of one agent (risk_base.h:70,76)."""
+        t = C.c_double(0.0)
+        c = (C.c_float * 3)()
+        check(lib().sogm_map_state(self.ctx, agent, C.byref(t), c, _stream()), "sogm_map_state")
+        return t.value, np.array(list(c), np.float32)
+
     def profile_read_all(self, slot, cap=1024):
         """Durations (ms, oldest first) of every launch of `slot` since set_profiling(True) (last 1024 kept)."""
         out = (C.c_double * cap)()
