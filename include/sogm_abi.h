@@ -251,6 +251,16 @@ int sogm_project_neighbours(sogm_ctx *ctx, const SogmTrajRecord *records, int n_
                             const int32_t *ego_ids, void *stream);
 
 /*
+ * FakeParticleRiskVoxel::updateMap as ONE call: sogm_update_gt followed by the neighbour overlay the reference runs
+ * at the end of the same function (plan_env/src/fake_particle_risk_voxel.cpp:175-226; RiskBase / RiskVoxel:
+ * risk_base.cpp:71, risk_voxel.cpp:179).  Arguments as sogm_update_gt + sogm_project_neighbours; the resulting maps
+ * are identical to the two separate calls.  Needs sogm_set_body_particles().
+ */
+int sogm_update_gt_swarm(sogm_ctx *ctx, const float *cloud_xyz, const int32_t *cloud_range,
+                         const SogmCylinder *cylinders, int n_cyl, const float *poses, const double *stamps,
+                         const SogmTrajRecord *records, int n_records, const int32_t *ego_ids, void *stream);
+
+/*
  * RiskBase::futureRiskCallback (risk_base.cpp:60-80): adopt an externally produced SOGM.
  * dev  grid_vt  [n_agents][V][T] fp32 in the REFERENCE layout (voxel-major); transposed into slabs.
  */
@@ -432,6 +442,24 @@ int sogm_gridmap_download(sogm_gridmap *g, int agent, double *occupancy_host, in
 /* Test hook: sets raycast_num_ (the de-duplication flags are chars and stop matching after frame 127). */
 int sogm_gridmap_force_frame(sogm_gridmap *g, int raycast_num);
 
+/*
+ * Tick glue of a batched planner service, each ONE launch (the FSM bookkeeping around replan()):
+ * sogm_tick_inputs — the replan start state of every agent: its executing trajectory own_records[a] sampled at
+ * stamp + replan_start_offset (FiniteStateMachine, plan_manager/src/plan_manager.cpp:169-175); an agent without a
+ * trajectory (n_pieces == 0) starts from hover_inout[a] (odom, :127-133).  hover_inout [n][9] is refreshed to
+ * {start position, 0, 0}.  Outputs (dev): out_now [n] = stamp (map stamp and "now" of the deconfliction),
+ * out_t_start [n] = stamp + offset, out_pva [n][9], out_poses [n][3] fp32 (the map centres).
+ * sogm_merge_latest — latest-wins per drone (traj_coordinator/src/particles.cpp:179-190): own_inout[a] =
+ * new_records[a] where ok[a] != 0, else unchanged (a failed replan keeps executing the previous trajectory,
+ * plan_manager.cpp:176-196); all_or_null, if given, receives a copy of the merged table (the swarm table of a
+ * single-process run; multi-GPU runs use sogm_traj_allgather instead).
+ */
+int sogm_tick_inputs(const SogmTrajRecord *own_records, int n, double stamp, double replan_start_offset,
+                     double *hover_inout, double *out_now, double *out_t_start, double *out_pva, float *out_poses,
+                     void *stream);
+int sogm_merge_latest(const SogmTrajRecord *new_records, const int32_t *ok, SogmTrajRecord *own_inout,
+                      SogmTrajRecord *all_or_null, int n, void *stream);
+
 /* ------------------------------------------------------------------------------------------ */
 /* queries                                                                                     */
 /* ------------------------------------------------------------------------------------------ */
@@ -557,6 +585,7 @@ int sogm_firi_batched(const double *bd, int n_bd, const double *pc_xyz, const in
  * an absolute time.
  */
 int sogm_planner_select_agents(sogm_planner *p, int first, int count);
+
 int sogm_planner_set_search_mode(sogm_planner *p, int mode);
 
 /*

@@ -119,8 +119,11 @@ PROTOTYPES = {
     "sogm_profile_read_all": (_i, [_vp, _i, C.POINTER(C.c_double), _i, C.POINTER(_i)]),
     "sogm_update_gt": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
     "sogm_project_neighbours": (_i, [_vp, _vp, _i, _vp, _vp]),
+    "sogm_update_gt_swarm": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp]),
     "sogm_set_future_risk": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "sogm_download_reference_layout": (_i, [_vp, _i, _vp]),
+    "sogm_tick_inputs": (_i, [_vp, _i, C.c_double, C.c_double, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "sogm_merge_latest": (_i, [_vp, _vp, _vp, _vp, _i, _vp]),
     "sogm_map_state": (_i, [_vp, _i, C.POINTER(C.c_double), C.POINTER(C.c_float), _vp]),
     "sogm_traj_eval": (_i, [_vp, _i, _vp, _vp, _vp, _vp]),
     "sogm_firi_batched": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, C.c_double, _i, _i, _i, _vp, _vp, _vp, _vp]),

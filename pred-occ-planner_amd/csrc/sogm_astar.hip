@@ -285,9 +285,10 @@ __global__ __launch_bounds__(ASTAR_THREADS) void k_astar(
   // waiting workgroups must not be dispatched before every search is resident, or they could starve it)
   if (fc.hdr && tid == 0) {
     atomicAdd(&fc.hdr[FLOW_A_RESIDENT], 1);
-    fc.ts[agent * 8 + 0] = wall_clock64();
+    fc.ts[agent * 8 + 7] = wall_clock64();
     fc.ts[agent * 8 + 2] = 0;
   }
+  if (fc.hdr && tid == 0) fc.ts[agent * 8 + 0] = wall_clock64();
 
   __shared__ double             s_f[ASTAR_POOL_MAX];     // f-score mirror of every allocated node
   __shared__ unsigned short     s_heap[ASTAR_POOL_MAX];  // open list

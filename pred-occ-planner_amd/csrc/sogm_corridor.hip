@@ -1662,7 +1662,7 @@ __device__ inline int flow_wait_slot(int *slot, int *err) {
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       return v;
     }
-    __builtin_amdgcn_s_sleep(64);
+    flow_pause();
     if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0)
       return -1;
     if (wall_clock64() - t0 > FLOW_TIMEOUT_TICKS) {

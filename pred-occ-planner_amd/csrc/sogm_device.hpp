@@ -6,6 +6,8 @@
 #include <hip/hip_fp16.h>
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include <new>
 #include <stdint.h>
 
@@ -282,6 +284,8 @@ struct sogm_ctx {
   void          *d_filter_box;
   int           *d_filter_blocks;
   int            filter_max_cells;
+  void          *d_cand;           // [A][1024] candidate cylinders of the stamp (k_cull_cylinders)
+  int           *d_ncand;          // [A]
   // trajectory exchange (sogm_traj_allgather): its own stream, ordered against producers / consumers by events
   hipStream_t    xstream;
   hipEvent_t     ev_xin, ev_xdone;
@@ -295,6 +299,32 @@ struct sogm_ctx {
 #define SOGM_PROF_RING 1024
 
 namespace sogm {
+// CU partition between the map clear and the planner kernels (tuning aid, off by default): SOGM_CLEAR_CUS = n gives the
+// clear's side stream a CU mask of n CUs per XCD (mask bit i belongs to XCD i % 8: the first 8 n bits) and the
+// planner's internal streams the complement, so that the streaming stores and the latency-bound planner waves do
+// not share SIMDs.  role: 0 = clear stream, 1 = planner stream.  Measured: the clear reaches 0.76-0.80 of
+// peak inside the tick with 8-12 CUs per XCD, but the planner chain loses more on the remaining CUs than the tick
+// gains; masking the clear alone is worse still (planner waves on the clear's CUs starve it).
+inline hipError_t create_stream_partitioned(hipStream_t *st, int role) {
+  static int n_clear = -1;
+  if (n_clear < 0) {
+    const char *e = getenv("SOGM_CLEAR_CUS");
+    n_clear       = e ? atoi(e) : 0;
+    if (n_clear < 0 || n_clear > 28) n_clear = 0;
+  }
+  if (n_clear == 0) return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
+  uint32_t mask[8];
+  for (int w = 0; w < 8; ++w) {
+    mask[w] = 0;
+    for (int b = 0; b < 32; ++b) {
+      const int  bit      = w * 32 + b;
+      const bool is_clear = bit < 8 * n_clear;
+      if (is_clear == (role == 0)) mask[w] |= 1u << b;
+    }
+  }
+  return hipExtStreamCreateWithCUMask(st, 8, mask);
+}
+
 // RAII-free helper: record the begin/end events of profiling slot `slot` on `st`.
 inline hipEvent_t *prof_pair(sogm_ctx *c, int slot, long long n) {
   if (!c->ring[slot]) {

@@ -107,64 +107,59 @@ __device__ __noinline__ bool ring_contains(const SogmCylinder &cy, float px, flo
   return fabs(cy.w / 2 - (double)dist) < (double)(2 * res) && fabsf(sd) < 2 * res;
 }
 
-__global__ __launch_bounds__(256) void k_stamp_cloud(GridGeom g, void *__restrict__ grid,
-                                                     const float *__restrict__ cloud,
-                                                     const int32_t *__restrict__ cloud_range,
-                                                     const SogmCylinder *__restrict__ cyl,
-                                                     int n_cyl, const float *__restrict__ poses) {
-  // Cylinders that can touch this agent's window, in their original order (the reference takes the FIRST
-  // cylinder containing the voxel, :127-154), staged once per workgroup as {x, y, w + clearance (fp64),
-  // vx, vy}.  A voxel corner lies inside the window, so a cylinder further than range + res + (w +
-  // clearance) from the map centre along x or y can never match; culling keeps the per-point loop
-  // independent of the size of the global obstacle field (tens of cylinders instead of thousands).
-  __shared__ double s_w[SOGM_MAX_CYL_LDS];
-  __shared__ float  s_xyv[SOGM_MAX_CYL_LDS][4];
-  __shared__ int    s_type[SOGM_MAX_CYL_LDS];
-  __shared__ int    s_orig[SOGM_MAX_CYL_LDS];  // index into cyl[] (ring records are read from there)
-  __shared__ int    s_keep, s_wave[4];
-  {
-    const float *pz_ = poses + blockIdx.y * 3;
-    const float  q0 = pz_[0], q1 = pz_[1];
-    if (threadIdx.x == 0) s_keep = 0;
-    __syncthreads();
-    for (int c0 = 0; c0 < n_cyl; c0 += 256) {
-      const int c    = c0 + threadIdx.x;
-      bool      keep = false;
-      double    wl   = 0.0;
-      if (c < n_cyl) {
-        wl = cyl[c].w + (double)g.clearance;
-        // reach of a record around its centre: a cylinder matches within w + clearance; a ring (type 2) within
-        // w/2 + 2 res of its axis point and 2 res of its plane, i.e. at most w/2 + 4 res from the centre
-        const double reach = cyl[c].type == 2 ? 0.5 * cyl[c].w + 4.0 * (double)g.res : wl;
-        const double lim_x = (double)g.rx + (double)g.res + reach + 0.5, lim_y = (double)g.ry + (double)g.res + reach + 0.5;
-        keep = fabs((double)(float)cyl[c].x - (double)q0) <= lim_x && fabs((double)(float)cyl[c].y - (double)q1) <= lim_y;
-      }
-      const unsigned long long m = __ballot(keep);
-      if ((threadIdx.x & 63) == 0) s_wave[threadIdx.x >> 6] = __popcll(m);
-      __syncthreads();
-      int off = s_keep;
-      for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) off += s_wave[w];
-      off += __popcll(m & ((1ull << (threadIdx.x & 63)) - 1ull));
-      if (keep && off < SOGM_MAX_CYL_LDS) {
-        s_w[off]      = wl;
-        s_xyv[off][0] = (float)cyl[c].x;
-        s_xyv[off][1] = (float)cyl[c].y;
-        s_xyv[off][2] = (float)cyl[c].vx;
-        s_xyv[off][3] = (float)cyl[c].vy;
-        s_type[off]   = cyl[c].type;
-        s_orig[off]   = c;
-      }
-      __syncthreads();
-      if (threadIdx.x == 0) s_keep += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
-      __syncthreads();
+// Candidate cylinders of an agent: those that can touch its window, in their original order (the reference takes
+// the FIRST record containing the voxel, :127-154).  A voxel corner lies inside the window, so a record further than
+// range + res + reach from the map centre along x or y can never match; culling keeps the per-point loop independent
+// of the size of the global obstacle field (tens of candidates instead of thousands).  One wave per agent, no LDS.
+struct CylCand {
+  float  x, y, vx, vy;
+  double wlim;  // w + clearance (fp64, as the reference compares)
+  int    type, orig;
+};
+__global__ __launch_bounds__(64) void k_cull_cylinders(GridGeom g, const SogmCylinder *__restrict__ cyl, int n_cyl,
+                                                       const float *__restrict__ poses, CylCand *__restrict__ cand,
+                                                       int *__restrict__ n_cand) {
+  const int    agent = blockIdx.x, lane = threadIdx.x;
+  const float  q0 = poses[agent * 3], q1 = poses[agent * 3 + 1];
+  CylCand     *out = cand + (size_t)agent * SOGM_MAX_CYL_LDS;
+  int          kept = 0;
+  for (int c0 = 0; c0 < n_cyl; c0 += 64) {
+    const int c    = c0 + lane;
+    bool      keep = false;
+    double    wl   = 0.0;
+    if (c < n_cyl) {
+      wl = cyl[c].w + (double)g.clearance;
+      // reach of a record around its centre: a cylinder matches within w + clearance; a ring (type 2) within
+      // w/2 + 2 res of its axis point and 2 res of its plane, i.e. at most w/2 + 4 res from the centre
+      const double reach = cyl[c].type == 2 ? 0.5 * cyl[c].w + 4.0 * (double)g.res : wl;
+      const double lim_x = (double)g.rx + (double)g.res + reach + 0.5, lim_y = (double)g.ry + (double)g.res + reach + 0.5;
+      keep = fabs((double)(float)cyl[c].x - (double)q0) <= lim_x && fabs((double)(float)cyl[c].y - (double)q1) <= lim_y;
     }
+    const unsigned long long m   = __ballot(keep);
+    const int                off = kept + __popcll(m & ((1ull << lane) - 1ull));
+    if (keep && off < SOGM_MAX_CYL_LDS)
+      out[off] = CylCand{(float)cyl[c].x, (float)cyl[c].y, (float)cyl[c].vx, (float)cyl[c].vy, wl, cyl[c].type, c};
+    kept += __popcll(m);
   }
-  // more candidates than LDS slots (never with the shipped scenes): fall back to the full list
-  const bool culled = s_keep <= SOGM_MAX_CYL_LDS;
-  const int  n_lds  = culled ? s_keep : 0;
-  const int  n_loop = culled ? s_keep : n_cyl;
+  if (lane == 0) n_cand[agent] = kept;  // > SOGM_MAX_CYL_LDS: the stamp falls back to the full list
+}
 
-  const int    agent = blockIdx.y;
+// One wave per workgroup and no LDS (the candidates come from k_cull_cylinders through L1 / the scalar cache): the
+// scattered marks are throughput-bound on HBM, and small workgroups fill the machine evenly whatever else holds LDS.
+__global__ __launch_bounds__(64) void k_stamp_cloud(GridGeom g, void *__restrict__ grid,
+                                                    const float *__restrict__ cloud,
+                                                    const int32_t *__restrict__ cloud_range,
+                                                    const SogmCylinder *__restrict__ cyl,
+                                                    int n_cyl, const float *__restrict__ poses,
+                                                    const CylCand *__restrict__ cand_all,
+                                                    const int *__restrict__ n_cand, int agent0) {
+  const int      agent  = blockIdx.y + agent0;
+  const int      kept   = n_cand[agent];
+  const bool     culled = kept <= SOGM_MAX_CYL_LDS;
+  const int      n_lds  = culled ? kept : 0;
+  const int      n_loop = culled ? kept : n_cyl;
+  const CylCand *cand   = cand_all + (size_t)agent * SOGM_MAX_CYL_LDS;
+
   const int    begin = cloud_range[agent * 2], end = cloud_range[agent * 2 + 1];
   const float *pose  = poses + agent * 3;
   const float  p0 = pose[0], p1 = pose[1], p2 = pose[2];
@@ -205,13 +200,14 @@ __global__ __launch_bounds__(256) void k_stamp_cloud(GridGeom g, void *__restric
       float  ox, oy, wx, wy;
       double wlim;
       if (c < n_lds) {
-        type = s_type[c];
-        orig = s_orig[c];
-        ox   = s_xyv[c][0];
-        oy   = s_xyv[c][1];
-        wx   = s_xyv[c][2];
-        wy   = s_xyv[c][3];
-        wlim = s_w[c];
+        const CylCand cc = cand[c];
+        type = cc.type;
+        orig = cc.orig;
+        ox   = cc.x;
+        oy   = cc.y;
+        wx   = cc.vx;
+        wy   = cc.vy;
+        wlim = cc.wlim;
       } else {
         type = cyl[c].type;
         ox   = (float)cyl[c].x;
@@ -253,18 +249,10 @@ __global__ __launch_bounds__(256) void k_stamp_cloud(GridGeom g, void *__restric
 // (risk_base.cpp:154-159) collapses to: record contributes at slice t  iff
 //     time_start < t_abs(0)  and  t_abs(s) < time_end for every s <= t
 // and t_abs is increasing, i.e.  time_start < t_abs(0) && t_abs(t) < time_end.
-__global__ __launch_bounds__(256) void k_splat_neighbours(
-    GridGeom g, void *__restrict__ grid, const SogmTrajRecord *__restrict__ rec, int n_rec,
-    const int32_t *__restrict__ ego_ids, const float *__restrict__ poses,
-    const double *__restrict__ stamps, const double *__restrict__ body, int n_body, int n_agents) {
-  const long long gid   = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long long total = (long long)n_agents * n_rec * g.T;
-  if (gid >= total) return;
-  const int t     = (int)(gid % g.T);
-  const int r     = (int)((gid / g.T) % n_rec);
-  const int agent = (int)(gid / ((long long)g.T * n_rec));
-
-  const SogmTrajRecord &R = rec[r];
+// one (agent, record, slice) item of the overlay
+__device__ inline void splat_item(const GridGeom &g, void *__restrict__ grid, const SogmTrajRecord &R, int agent,
+                                  int t, const int32_t *__restrict__ ego_ids, const float *__restrict__ poses,
+                                  const double *__restrict__ stamps, const double *__restrict__ body, int n_body) {
   if (R.n_pieces <= 0 || R.drone_id == ego_ids[agent]) return;
   double time_end = R.time_start;
   for (int k = 0; k < R.n_pieces; ++k) time_end += R.duration[k];
@@ -318,6 +306,18 @@ __global__ __launch_bounds__(256) void k_splat_neighbours(
     // is immaterial
     cell_add(slab, g.voxel_of(fx, fy, fz), 1.0F, g.half);
   }
+}
+__global__ __launch_bounds__(256) void k_splat_neighbours(
+    GridGeom g, void *__restrict__ grid, const SogmTrajRecord *__restrict__ rec, int n_rec,
+    const int32_t *__restrict__ ego_ids, const float *__restrict__ poses,
+    const double *__restrict__ stamps, const double *__restrict__ body, int n_body, int n_agents, int agent0) {
+  const long long gid   = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long total = (long long)n_agents * n_rec * g.T;
+  if (gid >= total) return;
+  const int t     = (int)(gid % g.T);
+  const int r     = (int)((gid / g.T) % n_rec);
+  const int agent = agent0 + (int)(gid / ((long long)g.T * n_rec));
+  splat_item(g, grid, rec[r], agent, t, ego_ids, poses, stamps, body, n_body);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -460,20 +460,15 @@ __global__ __launch_bounds__(256) void k_vt_to_slabs(const float *__restrict__ v
 }
 
 // Bezier pos / vel / acc of a trajectory record at an absolute time (bernstein.cpp:25-59)
-__global__ __launch_bounds__(64) void k_traj_eval(const SogmTrajRecord *__restrict__ rec, int n,
-                                                  const double *__restrict__ t,
-                                                  double *__restrict__ out, int32_t *__restrict__ ok) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const SogmTrajRecord &r = rec[i];
+// returns false (and zeros) for an empty record
+__device__ inline bool traj_eval_record(const SogmTrajRecord &r, double t_abs, double out[9]) {
   if (r.n_pieces <= 0) {
-    ok[i] = 0;
-    for (int k = 0; k < 9; ++k) out[i * 9 + k] = 0.0;
-    return;
+    for (int k = 0; k < 9; ++k) out[k] = 0.0;
+    return false;
   }
   double total = 0;
   for (int k = 0; k < r.n_pieces; ++k) total += r.duration[k];
-  double tt = t[i] - r.time_start;
+  double tt = t_abs - r.time_start;
   tt        = tt < 0 ? 0 : (tt > total ? total : tt);
   // locatePiece (bernstein.hpp:164-172)
   int    piece = r.n_pieces - 1;
@@ -503,11 +498,61 @@ __global__ __launch_bounds__(64) void k_traj_eval(const SogmTrajRecord *__restri
       v += b * S1[j];
       a += b * S2[j];
     }
-    out[i * 9 + d]     = p;
-    out[i * 9 + 3 + d] = v / dur;
-    out[i * 9 + 6 + d] = a / (dur * dur);
+    out[d]     = p;
+    out[3 + d] = v / dur;
+    out[6 + d] = a / (dur * dur);
   }
-  ok[i] = 1;
+  return true;
+}
+__global__ __launch_bounds__(64) void k_traj_eval(const SogmTrajRecord *__restrict__ rec, int n,
+                                                  const double *__restrict__ t,
+                                                  double *__restrict__ out, int32_t *__restrict__ ok) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double o[9];
+  ok[i] = traj_eval_record(rec[i], t[i], o) ? 1 : 0;
+  for (int k = 0; k < 9; ++k) out[i * 9 + k] = o[k];
+}
+
+// Start of a replan tick for n agents in one launch (the tick driver's glue): the replan start state of every agent
+// from the trajectory it is executing — FiniteStateMachine samples traj_ at the planned start time
+// (plan_manager/src/plan_manager.cpp:169-175), an agent without a trajectory starts from where it hovers
+// (odom, :127-133) — plus the stamps the map update and the replan take.
+__global__ __launch_bounds__(64) void k_tick_inputs(const SogmTrajRecord *__restrict__ own, int n, double stamp,
+                                                    double start_offset, double *__restrict__ hover,
+                                                    double *__restrict__ now, double *__restrict__ t_start,
+                                                    double *__restrict__ pva, float *__restrict__ poses) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double ts = stamp + start_offset;
+  double       o[9];
+  if (!traj_eval_record(own[i], ts, o))
+    for (int k = 0; k < 9; ++k) o[k] = hover[i * 9 + k];
+  for (int k = 0; k < 9; ++k) pva[i * 9 + k] = o[k];
+  for (int k = 0; k < 3; ++k) {
+    hover[i * 9 + k]     = o[k];
+    hover[i * 9 + 3 + k] = 0.0;
+    hover[i * 9 + 6 + k] = 0.0;
+    poses[i * 3 + k]     = (float)o[k];
+  }
+  now[i]     = stamp;
+  t_start[i] = ts;
+}
+// End of a tick: latest-wins per drone (particles.cpp:179-190) — a successful replan replaces the agent's record,
+// a failed one keeps the trajectory being executed (plan_manager.cpp:176-196); `all` (optional) is the swarm table of
+// a single-process run, refreshed in the same pass.  One lane per 16 bytes of a record.
+__global__ __launch_bounds__(256) void k_merge_latest(const SogmTrajRecord *__restrict__ fresh,
+                                                      const int32_t *__restrict__ ok, SogmTrajRecord *__restrict__ own,
+                                                      SogmTrajRecord *__restrict__ all, int n) {
+  constexpr int W = (int)(sizeof(SogmTrajRecord) / 16);
+  static_assert(sizeof(SogmTrajRecord) % 16 == 0, "record size");
+  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (long long)n * W) return;
+  const int a = (int)(gid / W), w = (int)(gid % W);
+  const uint4 *src = reinterpret_cast<const uint4 *>(ok[a] ? fresh + a : own + a);
+  const uint4  v   = src[w];
+  if (ok[a]) reinterpret_cast<uint4 *>(own + a)[w] = v;
+  if (all) reinterpret_cast<uint4 *>(all + a)[w] = v;
 }
 
 // BaselinePlanner::isTrajSafe (plan_manager/src/baseline.cpp:45-68): sample the executed trajectory every
@@ -692,7 +737,7 @@ int sogm_create(const SogmSpec *spec, int n_agents, int device, sogm_ctx **out) 
   if (e == hipSuccess) e = hipMalloc(&c->d_scratch_vt, sizeof(float) * (size_t)c->geom.V * spec->T);
   if (e == hipSuccess) e = hipMemset(c->d_poses, 0, sizeof(float) * 3 * n_agents);
   if (e == hipSuccess) e = hipMemset(c->d_stamps, 0, sizeof(double) * n_agents);
-  if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking);
+  if (e == hipSuccess) e = sogm::create_stream_partitioned(&c->side, 0);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_grid_free, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_cleared, hipEventDisableTiming);
   if (e != hipSuccess) {
@@ -715,6 +760,8 @@ void sogm_destroy(sogm_ctx *c) {
   if (c->d_stamps) (void)hipFree(c->d_stamps);
   if (c->d_body) (void)hipFree(c->d_body);
   if (c->d_scratch_vt) (void)hipFree(c->d_scratch_vt);
+  if (c->d_cand) (void)hipFree(c->d_cand);
+  if (c->d_ncand) (void)hipFree(c->d_ncand);
   if (c->d_filter_cells) (void)hipFree(c->d_filter_cells);
   if (c->d_filter_box) (void)hipFree(c->d_filter_box);
   if (c->d_filter_blocks) (void)hipFree(c->d_filter_blocks);
@@ -854,18 +901,17 @@ int sogm_set_body_particles(sogm_ctx *c, const double *xyz, int n) {
 
 static int clear_grid(sogm_ctx *c, hipStream_t st) { return sogm::launch_clear(c, st); }
 
-int sogm_update_gt(sogm_ctx *c, const float *cloud_xyz, const int32_t *cloud_range,
-                   const SogmCylinder *cylinders, int n_cyl, const float *poses,
-                   const double *stamps, void *stream) {
-  if (!c || !cloud_xyz || !cloud_range || !poses || !stamps || n_cyl < 0 ||
-      (n_cyl > 0 && !cylinders))
-    return SOGM_ERR_INVALID_ARG;
+// updateMap for every agent; with `records` (sogm_update_gt_swarm) the neighbour overlay follows in the same call
+static int update_gt_impl(sogm_ctx *c, const float *cloud_xyz, const int32_t *cloud_range,
+                          const SogmCylinder *cylinders, int n_cyl, const float *poses, const double *stamps,
+                          const SogmTrajRecord *records, int n_records, const int32_t *ego_ids, bool fused,
+                          hipStream_t st) {
   SOGM_HIP_CHECK(hipSetDevice(c->device));
-  hipStream_t st = (hipStream_t)stream;
-  SOGM_HIP_CHECK(hipMemcpyAsync(c->d_poses, poses, sizeof(float) * 3 * c->n_agents,
-                                hipMemcpyDeviceToDevice, st));
-  SOGM_HIP_CHECK(hipMemcpyAsync(c->d_stamps, stamps, sizeof(double) * c->n_agents,
-                                hipMemcpyDeviceToDevice, st));
+  const int A = c->n_agents;
+  if (fused)
+    if (int rc = sogm::join_exchange(c, st)) return rc;  // records may come from an all-gather in flight
+  SOGM_HIP_CHECK(hipMemcpyAsync(c->d_poses, poses, sizeof(float) * 3 * A, hipMemcpyDeviceToDevice, st));
+  SOGM_HIP_CHECK(hipMemcpyAsync(c->d_stamps, stamps, sizeof(double) * A, hipMemcpyDeviceToDevice, st));
   if (c->precleared) {
     // the grid was already cleared on the side stream during the previous tick
     int rc = sogm::adopt_preclear(c, st);
@@ -874,14 +920,55 @@ int sogm_update_gt(sogm_ctx *c, const float *cloud_xyz, const int32_t *cloud_ran
     int rc = clear_grid(c, st);
     if (rc) return rc;
   }
-  // 32 workgroups of 256 lanes per agent stride over that agent's cloud range
+  // candidate cylinders per agent, then one-wave workgroups stride over each agent's cloud range
+  if (!c->d_cand) {
+    SOGM_HIP_CHECK(hipMalloc(&c->d_cand, sizeof(CylCand) * SOGM_MAX_CYL_LDS * (size_t)A));
+    SOGM_HIP_CHECK(hipMalloc(&c->d_ncand, sizeof(int) * (size_t)A));
+  }
+  static int stamp_wgs = -1;
+  if (stamp_wgs < 0) {
+    const char *e = getenv("SOGM_STAMP_WGS");  // one-wave workgroups per agent (tuning aid)
+    stamp_wgs     = e && atoi(e) > 0 ? atoi(e) : 256;
+  }
   prof_begin(c, SOGM_PROF_STAMP, st);
-  hipLaunchKernelGGL(k_stamp_cloud, dim3(32, c->n_agents), dim3(256), 0, st, c->geom, (void *)c->d_grid,
-                     cloud_xyz, cloud_range, cylinders, n_cyl, c->d_poses);
+  hipLaunchKernelGGL(k_cull_cylinders, dim3(A), dim3(64), 0, st, c->geom, cylinders, n_cyl, c->d_poses,
+                     (CylCand *)c->d_cand, c->d_ncand);
+  hipLaunchKernelGGL(k_stamp_cloud, dim3(stamp_wgs, A), dim3(64), 0, st, c->geom, (void *)c->d_grid, cloud_xyz,
+                     cloud_range, cylinders, n_cyl, c->d_poses, (const CylCand *)c->d_cand, (const int *)c->d_ncand, 0);
   prof_end(c, SOGM_PROF_STAMP, st);
   SOGM_HIP_CHECK(hipGetLastError());
+  if (fused && n_records > 0) {
+    const long long total = (long long)A * n_records * c->spec.T;
+    prof_begin(c, SOGM_PROF_SPLAT, st);
+    hipLaunchKernelGGL(k_splat_neighbours, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, c->geom,
+                       (void *)c->d_grid, records, n_records, ego_ids, c->d_poses, c->d_stamps, c->d_body, c->n_body,
+                       A, 0);
+    prof_end(c, SOGM_PROF_SPLAT, st);
+    SOGM_HIP_CHECK(hipGetLastError());
+  }
   c->updated = 1;
   return SOGM_OK;
+}
+
+int sogm_update_gt(sogm_ctx *c, const float *cloud_xyz, const int32_t *cloud_range,
+                   const SogmCylinder *cylinders, int n_cyl, const float *poses,
+                   const double *stamps, void *stream) {
+  if (!c || !cloud_xyz || !cloud_range || !poses || !stamps || n_cyl < 0 ||
+      (n_cyl > 0 && !cylinders))
+    return SOGM_ERR_INVALID_ARG;
+  return update_gt_impl(c, cloud_xyz, cloud_range, cylinders, n_cyl, poses, stamps, nullptr, 0, nullptr, false,
+                        (hipStream_t)stream);
+}
+
+int sogm_update_gt_swarm(sogm_ctx *c, const float *cloud_xyz, const int32_t *cloud_range,
+                         const SogmCylinder *cylinders, int n_cyl, const float *poses, const double *stamps,
+                         const SogmTrajRecord *records, int n_records, const int32_t *ego_ids, void *stream) {
+  if (!c || !cloud_xyz || !cloud_range || !poses || !stamps || n_cyl < 0 || (n_cyl > 0 && !cylinders) ||
+      n_records < 0 || (n_records > 0 && !records) || !ego_ids)
+    return SOGM_ERR_INVALID_ARG;
+  if (!c->d_body || c->n_body <= 0) return SOGM_ERR_STATE;
+  return update_gt_impl(c, cloud_xyz, cloud_range, cylinders, n_cyl, poses, stamps, records, n_records, ego_ids,
+                        true, (hipStream_t)stream);
 }
 
 int sogm_project_neighbours(sogm_ctx *c, const SogmTrajRecord *records, int n_records,
@@ -897,7 +984,7 @@ int sogm_project_neighbours(sogm_ctx *c, const SogmTrajRecord *records, int n_re
   prof_begin(c, SOGM_PROF_SPLAT, (hipStream_t)stream);
   hipLaunchKernelGGL(k_splat_neighbours, dim3(nblk), dim3(256), 0, (hipStream_t)stream, c->geom,
                      (void *)c->d_grid, records, n_records, ego_ids, c->d_poses, c->d_stamps, c->d_body,
-                     c->n_body, c->n_agents);
+                     c->n_body, c->n_agents, 0);
   prof_end(c, SOGM_PROF_SPLAT, (hipStream_t)stream);
   SOGM_HIP_CHECK(hipGetLastError());
   return SOGM_OK;
@@ -960,6 +1047,29 @@ int sogm_traj_eval(const SogmTrajRecord *records, int n, const double *t, double
   if (n == 0) return SOGM_OK;
   hipLaunchKernelGGL(k_traj_eval, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, records, n,
                      t, out_pva, out_valid);
+  SOGM_HIP_CHECK(hipGetLastError());
+  return SOGM_OK;
+}
+
+int sogm_tick_inputs(const SogmTrajRecord *own_records, int n, double stamp, double replan_start_offset,
+                     double *hover_inout, double *out_now, double *out_t_start, double *out_pva, float *out_poses,
+                     void *stream) {
+  if (!own_records || !hover_inout || !out_now || !out_t_start || !out_pva || !out_poses || n < 0)
+    return SOGM_ERR_INVALID_ARG;
+  if (n == 0) return SOGM_OK;
+  hipLaunchKernelGGL(k_tick_inputs, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, own_records, n, stamp,
+                     replan_start_offset, hover_inout, out_now, out_t_start, out_pva, out_poses);
+  SOGM_HIP_CHECK(hipGetLastError());
+  return SOGM_OK;
+}
+
+int sogm_merge_latest(const SogmTrajRecord *new_records, const int32_t *ok, SogmTrajRecord *own_inout,
+                      SogmTrajRecord *all_or_null, int n, void *stream) {
+  if (!new_records || !ok || !own_inout || n < 0) return SOGM_ERR_INVALID_ARG;
+  if (n == 0) return SOGM_OK;
+  const long long lanes = (long long)n * (long long)(sizeof(SogmTrajRecord) / 16);
+  hipLaunchKernelGGL(k_merge_latest, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     new_records, ok, own_inout, all_or_null, n);
   SOGM_HIP_CHECK(hipGetLastError());
   return SOGM_OK;
 }

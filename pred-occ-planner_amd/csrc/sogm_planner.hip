@@ -160,7 +160,7 @@ int sogm_planner_create(sogm_ctx *map, const SogmAstarParams *astar, const SogmP
   p->sel_count   = A;
   p->search_mode = 0;
   for (int g = 0; g < p->n_groups && e == hipSuccess; ++g) {
-    e = hipStreamCreateWithFlags(&p->gstream[g], hipStreamNonBlocking);
+    e = sogm::create_stream_partitioned(&p->gstream[g], 1);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_corr[g], hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_pts[g], hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_done[g], hipEventDisableTiming);
@@ -179,8 +179,9 @@ int sogm_planner_create(sogm_ctx *map, const SogmAstarParams *astar, const SogmP
     if (e == hipSuccess) e = hipMalloc((void **)&p->d_flow_ts, sizeof(long long) * 8 * (size_t)A);
     if (e == hipSuccess) e = hipMemset(p->d_flow_ts, 0, sizeof(long long) * 8 * (size_t)A);
     p->fc.ts = p->d_flow_ts;
+
     for (int k = 0; k < 4 && e == hipSuccess; ++k) {
-      e = hipStreamCreateWithFlags(&p->fstream[k], hipStreamNonBlocking);
+      e = sogm::create_stream_partitioned(&p->fstream[k], 1);
       if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_fdone[k], hipEventDisableTiming);
     }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_gate, hipEventDisableTiming);
@@ -401,6 +402,7 @@ static int replan_flow(sogm_planner *p, const double *start_pva, const double *g
   const MapView mv   = view_of(c);
   if (p->swarm)
     if (int rc = sogm::join_exchange(c, main)) return rc;
+  hipStream_t sA = p->fstream[0], sC = p->fstream[1], sQ = p->fstream[2], sF = p->fstream[3];
   // reset the control block in stream order: counters and seg_done to 0, ready lists to -1
   SOGM_HIP_CHECK(hipMemsetAsync(p->d_flow, 0, sizeof(int) * (FLOW_HDR + (size_t)A), main));
   SOGM_HIP_CHECK(hipMemsetAsync(p->fc.a_ready, 0xFF, sizeof(int) * 3 * (size_t)A, main));
@@ -409,7 +411,6 @@ static int replan_flow(sogm_planner *p, const double *start_pva, const double *g
     int rc = sogm::queue_spare_clears(c, p->ev_in);
     if (rc) return rc;
   }
-  hipStream_t sA = p->fstream[0], sC = p->fstream[1], sQ = p->fstream[2], sF = p->fstream[3];
   for (int k = 0; k < 4; ++k) SOGM_HIP_CHECK(hipStreamWaitEvent(p->fstream[k], p->ev_in, 0));
   prof_begin(c, SOGM_PROF_ASTAR, sA);
   if (launch_astar(mv, p->ap, p->pp.corridor_tau, p->aw, A, start_pva, goal, t_start, p->d_ret, p->d_route,

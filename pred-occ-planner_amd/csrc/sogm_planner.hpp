@@ -36,6 +36,18 @@ struct CorridorWorkspace {
 enum { FLOW_A_RESIDENT = 0, FLOW_A_READY_N = 1, FLOW_C_TICKET = 2, FLOW_Q_READY_N = 3, FLOW_Q_TICKET = 4,
        FLOW_ERR = 5, FLOW_F_READY_N = 6, FLOW_F_TICKET = 7, FLOW_HDR = 8 };
 #define FLOW_TIMEOUT_TICKS 300000000LL  // 3 s of the 100 MHz wall clock: a stuck tick fails instead of hanging
+// One polling interval of the waiting loops of the dataflow replan.  A poll is a device-scope load that goes to the
+// memory side (the L2s are per XCD) while the SOGM clear streams beside it; the stages waited for take hundreds of
+// microseconds, so the waiting waves look every ~14 us (SOGM_POLL_PAUSES x s_sleep 127 = 4 x 3.4 us).
+#ifndef SOGM_POLL_PAUSES
+#define SOGM_POLL_PAUSES 4
+#endif
+#ifdef __HIPCC__
+__device__ inline void flow_pause() {
+#pragma unroll
+  for (int i = 0; i < SOGM_POLL_PAUSES; ++i) __builtin_amdgcn_s_sleep(127);
+}
+#endif
 struct FlowCtl {
   int *hdr;       // [FLOW_HDR]
   int *seg_done;  // [A]
@@ -43,7 +55,8 @@ struct FlowCtl {
   int *q_ready;   // [A]
   int *f_ready;   // [A] agents in QP completion order
   long long *ts;  // [A][8] wall_clock64 stamps (100 MHz): 0 A* start, 1 A* done, 2 first corridor item taken,
-                  //        3 corridors final, 4 QP start, 5 QP done, 6 finished (diagnostics, always written)
+                  //        3 corridors final, 4 QP start, 5 QP done, 6 finished, 7 A* workgroup resident
+                  //        (diagnostics, always written)
 };
 
 // ParticleATC::isSafeAfterOpt for agents [agent0, agent0 + n_agents): out_safe[a] = 1 / 0

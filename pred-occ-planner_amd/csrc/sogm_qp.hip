@@ -1279,7 +1279,7 @@ __global__ __launch_bounds__(QP_NT) void k_qp_flow(SogmPlannerParams pp, SogmQpS
       if (k < n_agents) {
         const long long t0 = wall_clock64();
         while ((a = __hip_atomic_load(fc.q_ready + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < 0) {
-          __builtin_amdgcn_s_sleep(127);
+          flow_pause();
           if (__hip_atomic_load(&fc.hdr[FLOW_ERR], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
           if (wall_clock64() - t0 > FLOW_TIMEOUT_TICKS) {
             atomicExch(&fc.hdr[FLOW_ERR], 3);

@@ -23,7 +23,7 @@ import torch
 
 from . import _abi, config, scene as scene_mod
 from .planner import SogmPlanner, traj_eval
-from .sogm import SogmMap, _dev, upload_scene
+from .sogm import SogmMap, _dev, _stream, upload_scene
 
 TICK_PERIOD = 0.1        # fsm/replan_duration (sim_fake.yaml:7)
 REPLAN_START_TIME = 0.02  # fsm/replan_start_time (sim_fake.yaml:8)
@@ -198,6 +198,9 @@ class SwarmTick:
         d = "cuda"
         self.goals = _dev(loc["goals"], np.float64)
         self.hover = _dev(np.concatenate([loc["starts"], np.zeros((self.A_loc, 6))], axis=1), np.float64)
+        self.pva = torch.zeros((self.A_loc, 9), dtype=torch.float64, device=d)      # replan start states of the tick
+        self.poses = torch.zeros((self.A_loc, 3), dtype=torch.float32, device=d)    # map centres of the tick
+        self.t_start = torch.zeros((self.A_loc,), dtype=torch.float64, device=d)
         self.own = torch.zeros((self.A_loc, _abi.TRAJ_RECORD_BYTES), dtype=torch.uint8, device=d)
         self.new = torch.zeros_like(self.own)
         self.ok = torch.zeros((self.A_loc,), dtype=torch.int32, device=d)
@@ -207,6 +210,7 @@ class SwarmTick:
         self.now = torch.zeros((self.A_loc,), dtype=torch.float64, device=d)
         if deconflict:
             self.planner.setSwarm(self.all, self.A_tot, self.dev["ego_ids"], self.now)
+        self.fused_update = os.environ.get("SOGM_FUSED_UPDATE", "1") != "0"
         # optional closed-loop mode: every agent runs the reference's FiniteStateMachine (step_fsm)
         self.fsm = fsm
         self.status = torch.full((self.A_loc,), FSM_NEW_PLAN, dtype=torch.int32, device=d)
@@ -270,19 +274,27 @@ class SwarmTick:
         if self.fsm:
             return self.step_fsm()
         stamp = self.t0 + self.tick * TICK_PERIOD
-        stamps = torch.full((self.A_loc,), stamp, dtype=torch.float64, device="cuda")
-        self.now.copy_(stamps)
-        t_start = stamps + REPLAN_START_TIME
-        pva, valid = traj_eval(self.own, t_start)
-        pva = torch.where(valid.bool().unsqueeze(1), pva, self.hover)
-        self.hover = torch.cat([pva[:, :3], torch.zeros_like(pva[:, 3:])], dim=1)
-        poses = pva[:, :3].to(torch.float32).contiguous()
-        self.map.updateMap(self.dev["cloud"], self.dev["cloud_range"], self.dev["cylinders"], self.dev["n_cyl"],
-                           poses, stamps)
-        self.map.addOtherAgents(self.all, self.A_tot, self.dev["ego_ids"])
-        self.planner.replan(pva.contiguous(), self.goals, t_start, self.dev["ego_ids"], self.new, self.ok)
-        # latest-wins; a failed replan keeps executing the previous trajectory
-        self.own = merge_latest(self.new, self.own, self.ok)
-        self._exchange()
+        # start states from the executed trajectories, stamps and map centres: one launch (sogm_tick_inputs)
+        _abi.check(_abi.lib().sogm_tick_inputs(self.own.data_ptr(), self.A_loc, stamp, REPLAN_START_TIME,
+                                               self.hover.data_ptr(), self.now.data_ptr(), self.t_start.data_ptr(),
+                                               self.pva.data_ptr(), self.poses.data_ptr(), _stream()),
+                   "sogm_tick_inputs")
+        # updateMap incl. its closing neighbour overlay in one call
+        if self.fused_update:
+            self.map.updateMapSwarm(self.dev["cloud"], self.dev["cloud_range"], self.dev["cylinders"],
+                                    self.dev["n_cyl"], self.poses, self.now, self.all, self.A_tot, self.dev["ego_ids"])
+        else:  # the two separate calls (SOGM_FUSED_UPDATE=0: A/B aid)
+            self.map.updateMap(self.dev["cloud"], self.dev["cloud_range"], self.dev["cylinders"], self.dev["n_cyl"],
+                               self.poses, self.now)
+            self.map.addOtherAgents(self.all, self.A_tot, self.dev["ego_ids"])
+        self.planner.replan(self.pva, self.goals, self.t_start, self.dev["ego_ids"], self.new, self.ok)
+        # latest-wins; a failed replan keeps executing the previous trajectory (sogm_merge_latest); a single
+        # process refreshes the swarm table in the same launch, several ranks all-gather it
+        local = not self.exchange.active and not (self.dist is not None and (self.world > 1 or self.dist.is_initialized()))
+        _abi.check(_abi.lib().sogm_merge_latest(self.new.data_ptr(), self.ok.data_ptr(), self.own.data_ptr(),
+                                                self.all.data_ptr() if local else None, self.A_loc, _stream()),
+                   "sogm_merge_latest")
+        if not local:
+            self._exchange()
         self.tick += 1
         return self.ok.clone()  # self.ok is rewritten by the next tick

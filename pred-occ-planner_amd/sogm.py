@@ -141,6 +141,15 @@ class SogmMap:
                                    poses.data_ptr(), stamps.data_ptr(), _stream()),
               "sogm_update_gt")
 
+    def updateMapSwarm(self, cloud, cloud_range, cylinders, n_cyl, poses, stamps, records, n_records, ego_ids):
+        """FakeParticleRiskVoxel::updateMap incl. its closing neighbour overlay, one call (sogm_update_gt_swarm);
+        the maps equal those of updateMap + addOtherAgents."""
+        self._poses, self._stamps = poses, stamps
+        check(lib().sogm_update_gt_swarm(self._ctx, cloud.data_ptr(), cloud_range.data_ptr(),
+                                         cylinders.data_ptr() if n_cyl else None, n_cyl, poses.data_ptr(),
+                                         stamps.data_ptr(), records.data_ptr() if n_records else None, n_records,
+                                         ego_ids.data_ptr(), _stream()), "sogm_update_gt_swarm")
+
     def addOtherAgents(self, records, n_records, ego_ids):
         """RiskBase::addOtherAgents / fake_particle_risk_voxel.cpp:178-218."""
         check(lib().sogm_project_neighbours(self._ctx, records.data_ptr(), n_records,
