@@ -58,12 +58,18 @@ print("N pts: max/mean", d[:, 0].max(), d[:, 0].mean(), " nH0 max/mean", d[:, 1]
 print("lbfgs iters max/mean", d[:, 3].max(), d[:, 3].mean(), " evals max/mean", d[:, 4].max(), d[:, 4].mean())
 for name, col in (("points", 5), ("firi0 done", 6), ("mvie total", 7), ("  lbfgs", 9), ("firi1 done", 8), ("segment total", 10)):
     print(f"{name:14s} us: max {us(d[:, col].max()):9.1f}  mean {us(d[:, col].mean()):9.1f}  p90 {us(np.percentile(d[:, col], 90)):9.1f}")
+if d[:, 11].max() > 0:
+    f = d[:, 11] / np.maximum(d[:, 9], 1) * 100.0
+    print(f"shader clock during the L-BFGS (clock64 / wall_clock64): mean {f.mean():.0f} MHz, min {f.min():.0f}, max {f.max():.0f}")
 i = np.argmax(d[:, 10])
 print("slowest segment:", d[i])
 
 if hasattr(lib, "sogm_debug_mvie_prof"):
-    pr = np.zeros(2, np.uint64)
+    pr = np.zeros(6, np.uint64)
     lib.sogm_debug_mvie_prof.argtypes = [C.c_void_p]
     lib.sogm_debug_mvie_prof(pr.ctypes.data)
     if pr[1]:
         print(f"costMVIE (line search): {int(pr[1])} calls, mean {pr[0] / pr[1] / 100.0:.2f} us")
+        it = max(int(pr[4]), 1)
+        print(f"L-BFGS per iteration: line search {pr[2] / it / 100.0:.2f} us, direction update (two-loop) "
+              f"{pr[3] / it / 100.0:.2f} us, mean history {pr[5] / it:.1f}, iterations {it}")

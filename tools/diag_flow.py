@@ -9,10 +9,13 @@ A = 128
 sw = driver.SwarmTick("cfg2", A, grids=int(os.environ.get("SOGM_GRIDS", "3")),
                       overlap_clear=os.environ.get("SOGM_OVERLAP", "1") != "0")
 ticks = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+every = int(sys.argv[2]) if len(sys.argv) > 2 else 1  # print every n-th tick (long flights)
 lib = pop.lib()
 names = ["A* start", "A* done", "corr first", "corr final", "QP start", "QP done", "finished"]
 for k in range(ticks):
     sw.step()
+    if k % every:
+        continue
     ts = np.zeros((A, 8), np.int64)
     lib.sogm_debug_flow_times(sw.planner._p, ts.ctypes.data_as(C.c_void_p))
     t0 = ts[:, 7].min() if ts[:, 7].min() > 0 else ts[:, 0].min()  # first A* workgroup resident
