@@ -279,16 +279,25 @@ __global__ __launch_bounds__(ASTAR_THREADS) void k_astar(
     double *__restrict__ out_route, int32_t *__restrict__ out_route_len, int route_cap,
     int32_t *__restrict__ out_stats, int32_t *__restrict__ out_trace, int trace_cap, int agent0, FlowCtl fc,
     int search_mode) {
-  const int agent = blockIdx.x + agent0;
-  const int tid   = threadIdx.x;
+  // search_mode bit 3 (dataflow replan): the launch has 2 x n workgroups; workgroup b >= n runs the SECOND attempt of
+  // agent b - n speculatively beside the first (the two searches are independent; the second one's result only
+  // counts if the first returns NO_PATH, baseline_fake.cpp:284-291) — a NO_PATH pair, the longest search a tick can
+  // hold, then takes the time of one search instead of two.
+  const bool spec   = (search_mode & 8) != 0;
+  const int  n_half = spec ? (int)gridDim.x / 2 : (int)gridDim.x;
+  const int  second = spec && (int)blockIdx.x >= n_half ? 1 : 0;
+  const int  agent  = ((int)blockIdx.x - second * n_half) + agent0;
+  const int  tid    = threadIdx.x;
   // dataflow replan: tell the gate kernel that this workgroup holds its CU resources (the corridor kernel's
   // waiting workgroups must not be dispatched before every search is resident, or they could starve it)
   if (fc.hdr && tid == 0) {
     atomicAdd(&fc.hdr[FLOW_A_RESIDENT], 1);
-    fc.ts[agent * 8 + 7] = wall_clock64();
-    fc.ts[agent * 8 + 2] = 0;
+    if (!second) {
+      fc.ts[agent * 8 + 7] = wall_clock64();
+      fc.ts[agent * 8 + 2] = 0;
+      fc.ts[agent * 8 + 0] = wall_clock64();
+    }
   }
-  if (fc.hdr && tid == 0) fc.ts[agent * 8 + 0] = wall_clock64();
 
   __shared__ double             s_f[ASTAR_POOL_MAX];     // f-score mirror of every allocated node
   __shared__ unsigned short     s_heap[ASTAR_POOL_MAX];  // open list
@@ -321,8 +330,10 @@ __global__ __launch_bounds__(ASTAR_THREADS) void k_astar(
   __shared__ int                s_was_first, s_cur_node, s_base_node, s_n_written;
   __shared__ int                s_ret;
 
-  Node               *pool = (Node *)(wsp.pool + (size_t)agent * wsp.pool_stride);
-  unsigned long long *htab = (unsigned long long *)wsp.hkeys + (size_t)agent * wsp.hash_cap;
+  // the second attempt's pool / hash table follow the first attempts' ([n_agents_total .. 2 n_agents_total))
+  const size_t        slot = (size_t)agent + (second ? (size_t)m.n_agents : 0);
+  Node               *pool = (Node *)(wsp.pool + slot * wsp.pool_stride);
+  unsigned long long *htab = (unsigned long long *)wsp.hkeys + slot * wsp.hash_cap;
   const int           hcap = wsp.hash_cap;
 
   const double *pva = start_pva + agent * 9;
@@ -369,7 +380,9 @@ __global__ __launch_bounds__(ASTAR_THREADS) void k_astar(
 
   // search_mode 0: the replan's call pattern (init_search = true, then false if NO_PATH, baseline_fake.cpp:284-291);
   // 1 / 2: exactly one search(…, init = true / false, …) for the per-object shim
-  const int attempt_lo = (search_mode & 3) == 2 ? 1 : 0, attempt_hi = (search_mode & 3) == 1 ? 1 : 2;
+  const int attempt_lo = spec ? second : ((search_mode & 3) == 2 ? 1 : 0);
+  const int attempt_hi = spec ? second + 1 : ((search_mode & 3) == 1 ? 1 : 2);
+  bool      dropped    = false;  // second attempt: the first one found a path
   for (int attempt = attempt_lo; attempt < attempt_hi; ++attempt) {
     // reset(): clear the hash table (all lanes)
     for (int i = tid; i < hcap; i += ASTAR_THREADS) htab[i] = HASH_EMPTY;
@@ -414,7 +427,11 @@ __global__ __launch_bounds__(ASTAR_THREADS) void k_astar(
       tmark = wall_clock64();
       if (tid == 0) {
         s_n_active = 0;
-        if (heap_n == 0) {
+        // speculative second attempt: every 8th expansion, look whether the first attempt has found a path
+        if (second && (iter_num & 7) == 0 &&
+            __hip_atomic_load(&wsp.verdict[agent], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1) {
+          s_ret = -1;  // dropped
+        } else if (heap_n == 0) {
           ret = NO_PATH;  // open set empty (:419-422)
         } else {
           cur          = s_heap[0];
@@ -495,6 +512,7 @@ __global__ __launch_bounds__(ASTAR_THREADS) void k_astar(
       __syncthreads();
       const int n_act = s_n_active;
       if (n_act == 0) {
+        if (second && s_ret == -1) dropped = true;  // uniform: s_ret is only set to -1 by the check above
         done = true;
         break;
       }
@@ -780,11 +798,41 @@ __global__ __launch_bounds__(ASTAR_THREADS) void k_astar(
       }
     }
     // broadcast the verdict of this attempt
+    if (dropped) break;
     if (tid == 0) s_ret = ret;
     __syncthreads();
     const int r = s_ret;
     __syncthreads();
     if (r != NO_PATH) break;
+  }
+  if (spec) {
+    // first attempt: announce the verdict; a NO_PATH first attempt leaves the agent's outputs to the second one.
+    // second attempt: wait for that verdict (bounded) and go on only if the first attempt failed.
+    if (!second) {
+      if (tid == 0) {
+        s_ret = ret;
+        __hip_atomic_store(&wsp.verdict[agent], ret != NO_PATH ? 1 : 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      __syncthreads();
+      if (s_ret == NO_PATH) return;
+    } else {
+      if (dropped) return;
+      if (tid == 0) {
+        const long long t0 = wall_clock64();
+        int             v;
+        while ((v = __hip_atomic_load(&wsp.verdict[agent], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0) {
+          flow_pause();
+          if (wall_clock64() - t0 > FLOW_TIMEOUT_TICKS) {
+            if (fc.hdr) atomicExch(&fc.hdr[FLOW_ERR], 4);
+            break;
+          }
+        }
+        s_ret = v;
+      }
+      __syncthreads();
+      if (s_ret != 2) return;
+      if (tid == 0) searches = 2;  // as the sequential pattern counts them
+    }
   }
 
   // ---------------- master: getPathWithVel(corridor_tau) (:663-694) ----------------
@@ -862,7 +910,9 @@ int launch_astar(const MapView &m, const SogmAstarParams &ap, double corridor_ta
                  int32_t *out_route_len, int route_cap, int32_t *out_stats, int32_t *out_trace,
                  int trace_cap, hipStream_t st, int agent0, const FlowCtl *fc, int search_mode) {
   const FlowCtl none{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  hipLaunchKernelGGL(k_astar, dim3(n_agents), dim3(ASTAR_THREADS), 0, st, m, ap, corridor_tau, wsp,
+  const bool spec = (search_mode & 8) != 0 && wsp.verdict && fc && !out_trace;
+  if (!spec) search_mode &= ~8;
+  hipLaunchKernelGGL(k_astar, dim3(spec ? 2 * n_agents : n_agents), dim3(ASTAR_THREADS), 0, st, m, ap, corridor_tau, wsp,
                      start_pva, goal, t_start, out_ret, out_route, out_route_len, route_cap,
                      out_stats, out_trace, trace_cap, agent0, fc ? *fc : none, search_mode);
   return hipGetLastError() == hipSuccess ? 0 : -1;

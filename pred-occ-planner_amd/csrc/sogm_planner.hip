@@ -107,8 +107,10 @@ int sogm_planner_create(sogm_ctx *map, const SogmAstarParams *astar, const SogmP
   p->aw.hash_cap    = hc;
   p->aw.pool_stride = astar_node_bytes() * (size_t)astar->allocate_num;
   p->route_cap      = 64;
-  hipError_t e      = hipMalloc((void **)&p->aw.pool, p->aw.pool_stride * A);
-  if (e == hipSuccess) e = hipMalloc(&p->aw.hkeys, 8 * (size_t)hc * A);
+  // two pools / hash tables per agent: the replan's second search attempt runs speculatively beside the first
+  hipError_t e      = hipMalloc((void **)&p->aw.pool, p->aw.pool_stride * A * 2);
+  if (e == hipSuccess) e = hipMalloc(&p->aw.hkeys, 8 * (size_t)hc * A * 2);
+  if (e == hipSuccess) e = hipMalloc((void **)&p->aw.verdict, sizeof(int) * A);
   if (e == hipSuccess) e = hipMalloc((void **)&p->aw.dbg, sizeof(long long) * 8 * A);
   if (e == hipSuccess) e = hipMalloc((void **)&p->d_ret, sizeof(int32_t) * A);
   if (e == hipSuccess) e = hipMalloc((void **)&p->d_route_len, sizeof(int32_t) * A);
@@ -159,6 +161,10 @@ int sogm_planner_create(sogm_ctx *map, const SogmAstarParams *astar, const SogmP
   p->sel_first   = 0;
   p->sel_count   = A;
   p->search_mode = 0;
+  {
+    const char *es = getenv("SOGM_SPEC_ASTAR");
+    p->spec_astar  = es ? atoi(es) != 0 : 1;
+  }
   for (int g = 0; g < p->n_groups && e == hipSuccess; ++g) {
     e = sogm::create_stream_partitioned(&p->gstream[g], 1);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_corr[g], hipEventDisableTiming);
@@ -196,7 +202,7 @@ int sogm_planner_create(sogm_ctx *map, const SogmAstarParams *astar, const SogmP
 }
 void sogm_planner_destroy(sogm_planner *p) {
   if (!p) return;
-  void *ptrs[] = {p->aw.pool, p->aw.hkeys, p->aw.dbg,
+  void *ptrs[] = {p->aw.pool, p->aw.hkeys, p->aw.dbg, p->aw.verdict,
                   p->d_ret,   p->d_route_len, p->d_stats, p->d_route,
                   p->cw.pc,   p->cw.fpc,  p->cw.tang, p->cw.distr, p->cw.polys,
                   p->cw.seg_nfaces, p->cw.seg_state, p->cw.seg_npts, p->cw.seg_dbg, p->cw.counters,
@@ -277,7 +283,8 @@ int sogm_debug_astar_stats(sogm_planner *p, long long *out_host) {
   return SOGM_OK;
 }
 
-// diagnostics (tools/ only): raw 128-byte node records of one agent's last search
+// diagnostics (tools/ only): raw 128-byte node records of one agent's last search through sogm_astar_search (the
+// replan's speculative second attempt keeps its nodes in the second half of the pool)
 int sogm_debug_astar_nodes(sogm_planner *p, int agent, void *out_host, int n) {
   if (!p || !out_host || agent < 0 || agent >= p->map->n_agents || n < 0) return SOGM_ERR_INVALID_ARG;
   SOGM_HIP_CHECK(hipDeviceSynchronize());
@@ -406,6 +413,8 @@ static int replan_flow(sogm_planner *p, const double *start_pva, const double *g
   // reset the control block in stream order: counters and seg_done to 0, ready lists to -1
   SOGM_HIP_CHECK(hipMemsetAsync(p->d_flow, 0, sizeof(int) * (FLOW_HDR + (size_t)A), main));
   SOGM_HIP_CHECK(hipMemsetAsync(p->fc.a_ready, 0xFF, sizeof(int) * 3 * (size_t)A, main));
+  const bool spec = p->spec_astar != 0;
+  if (spec) SOGM_HIP_CHECK(hipMemsetAsync(p->aw.verdict, 0, sizeof(int) * (size_t)A, main));
   SOGM_HIP_CHECK(hipEventRecord(p->ev_in, main));
   if (c->overlap >= 2) {
     int rc = sogm::queue_spare_clears(c, p->ev_in);
@@ -414,12 +423,12 @@ static int replan_flow(sogm_planner *p, const double *start_pva, const double *g
   for (int k = 0; k < 4; ++k) SOGM_HIP_CHECK(hipStreamWaitEvent(p->fstream[k], p->ev_in, 0));
   prof_begin(c, SOGM_PROF_ASTAR, sA);
   if (launch_astar(mv, p->ap, p->pp.corridor_tau, p->aw, A, start_pva, goal, t_start, p->d_ret, p->d_route,
-                   p->d_route_len, p->route_cap, p->d_stats, nullptr, 0, sA, 0, &p->fc)) {
+                   p->d_route_len, p->route_cap, p->d_stats, nullptr, 0, sA, 0, &p->fc, spec ? 8 : 0)) {
     sogm::set_error("sogm_replan: k_astar", hipGetLastError());
     return SOGM_ERR_HIP;
   }
   prof_end(c, SOGM_PROF_ASTAR, sA);
-  if (sogm::launch_flow_gate(p->fc, A, sC)) return SOGM_ERR_HIP;
+  if (sogm::launch_flow_gate(p->fc, spec ? 2 * A : A, sC)) return SOGM_ERR_HIP;
   SOGM_HIP_CHECK(hipEventRecord(p->ev_gate, sC));
   SOGM_HIP_CHECK(hipStreamWaitEvent(sQ, p->ev_gate, 0));
   SOGM_HIP_CHECK(hipStreamWaitEvent(sF, p->ev_gate, 0));

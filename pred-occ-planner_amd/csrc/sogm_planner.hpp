@@ -12,6 +12,9 @@ struct AstarWorkspace {
   void  *hkeys;        // [A][hash_cap] 64-bit slots {x, y, z, t, node id}
   int    hash_cap;     // power of two >= 2 * allocate_num
   long long *dbg;      // [A][8] per-phase wall_clock64 ticks (diagnostics)
+  // speculative second attempt (dataflow replan): a second set of pools / hash tables ([A..2A)) and the verdict of
+  // the first attempt per agent (0 pending, 1 found a path, 2 NO_PATH); null = not available
+  int *verdict;
 };
 int astar_pool_max();
 
@@ -152,4 +155,5 @@ struct sogm_planner {
   // per-object use of the per-stage entries (sogm_planner_select_agents / _set_search_mode)
   int sel_first, sel_count;  // agents the per-stage entries process; (0, A) by default
   int search_mode;           // 0 the replan's two-call pattern, 1 / 2 one search with init_search true / false
+  int spec_astar;            // dataflow replan: run the second search attempt speculatively beside the first
 };

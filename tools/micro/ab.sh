@@ -3,7 +3,7 @@
 export GPU_MAX_HW_QUEUES=16
 for cfg in "$@"; do
   echo "== $cfg"
-  env $cfg timeout 150 python bench.py --no-cpu-baseline --sustained ${SUST:-0} --steps 20 2>/dev/null | python -c "
+  env $cfg timeout 150 python bench.py --no-cpu-baseline --sustained ${SUST:-0} --steps ${STEPS:-20} 2>/dev/null | python -c "
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):
