@@ -145,6 +145,13 @@ class RiskMap {
               const float *poses, const double *stamps, hipStream_t st = nullptr) {
     check(sogm_update_gt(ctx_, cloud_xyz, cloud_range, cyl, n_cyl, poses, stamps, st), "sogm_update_gt");
   }
+  // FakeParticleRiskVoxel::updateMap including its closing neighbour overlay (fake_particle_risk_voxel.cpp:175-226)
+  void updateWithSwarm(const float *cloud_xyz, const int32_t *cloud_range, const SogmCylinder *cyl, int n_cyl,
+                       const float *poses, const double *stamps, const SogmTrajRecord *records, int n_records,
+                       const int32_t *ego_ids, hipStream_t st = nullptr) {
+    check(sogm_update_gt_swarm(ctx_, cloud_xyz, cloud_range, cyl, n_cyl, poses, stamps, records, n_records, ego_ids, st),
+          "sogm_update_gt_swarm");
+  }
   // RiskBase::futureRiskCallback for agent 0 of a 1-agent context: adopt one map/future_risk message.
   // `map_time` is the map stamp to adopt (the ROS header / receive time as a double).  The reference reads the
   // message's trailing float32 field into a dead local (risk_base.cpp:72) and leaves last_update_time_ alone; a

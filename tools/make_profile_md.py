@@ -37,10 +37,12 @@ Collected by `tools/make_profile.sh` on the GPU box (`cd /tmp && export TMPDIR=/
   --no-cpu-baseline --sustained 0` and the same with `--pmc WRITE_SIZE`.
 The rocpd databases stay in gpurun_out/ (scratch); this file holds what is cited.
 
-State: dataflow replan (`k_astar` publishes agents in completion order; persistent `k_corridor_flow` /
-`k_qp_flow` / `k_finish_flow` chain per agent through device-side ready lists), triple-buffered SOGM with one narrow
-streaming clear per tick on a side stream, sdlp's projective Seidel LP executed whole-wave, `costMVIE` summed in the
-reference's order, ring obstacles, the velocity-estimation front end.
+State: dataflow replan (`k_astar` publishes agents in completion order, the second search attempt of every agent runs
+speculatively beside the first; persistent `k_corridor_flow` / `k_qp_flow` / `k_finish_flow` chain per agent through
+device-side ready lists), triple-buffered SOGM with one narrow streaming clear per tick on a side stream, LDS-free
+one-wave cloud stamp behind a per-agent cylinder cull, tick glue in two launches (`k_tick_inputs`, `k_merge_latest`),
+sdlp's projective Seidel LP executed whole-wave, `costMVIE` summed in the reference's order with the L-BFGS history
+scalars held in lanes, ring obstacles, the velocity-estimation front end.
 
 Default run (`python bench.py`: 3 warm-up + 20 timed ticks, then 300 host-synchronised ticks of the same flight,
 then the CPU baseline): **{d['value']:.0f} replans/s** ({d['ms_per_step']:.2f} ms per tick), of which
