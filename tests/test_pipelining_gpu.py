@@ -45,3 +45,57 @@ def test_pipelining_modes_agree():
         assert np.array_equal(own0, own) and np.array_equal(all0, allr)
     assert np.array_equal(g0, g2) and np.array_equal(g0, g3) and np.array_equal(g0, gs)
     print("pipelining modes agree over", len(ok0), "ticks; replans ok per tick", ok0)
+
+
+def _enclosed_scene(pop, A):
+    """Agent 0 starts inside a palisade of pillars so tight that every motion primitive collides: each of its searches
+    ends in NO_PATH, both attempts; the others fly a normal scene around it."""
+    sc = pop.scene.make_scene(A, 4.95, seed=41, circle_radius=3.5, n_cyl=6)
+    c0 = sc["starts"][0][:2].copy()
+    ring = []
+    for k in range(14):
+        a = 2 * np.pi * k / 14
+        ring.append([c0[0] + 0.72 * np.cos(a), c0[1] + 0.72 * np.sin(a), 0.55, 0.0, 0.0])
+    cyl = np.concatenate([sc["cylinders"], np.array(ring)], axis=0)
+    sc["cylinders"] = cyl
+    # surface points of the added pillars on the 0.1 m lattice, z in [0, 4)
+    pts = [sc["cloud"]]
+    zs = np.arange(0, 40) * 0.1
+    for x, y, w, _, _ in ring:
+        th = np.linspace(0, 2 * np.pi, 24, endpoint=False)
+        xy = np.stack([x + 0.5 * w * np.cos(th), y + 0.5 * w * np.sin(th)], axis=1)
+        xy = np.round(xy / 0.1) * 0.1
+        xy = np.unique(xy, axis=0)
+        pts.append(np.concatenate([np.repeat(xy, len(zs), axis=0), np.tile(zs, len(xy))[:, None]], axis=1).astype(np.float32))
+    sc["cloud"] = np.concatenate(pts, axis=0).astype(np.float32)
+    return sc
+
+
+def _fly_spec(pop, spec, ticks=5):
+    import os
+    import torch
+    driver = importlib.import_module("pred-occ-planner_amd.driver")
+    os.environ["SOGM_SPEC_ASTAR"] = "1" if spec else "0"  # read when the planner is created
+    try:
+        sw = driver.SwarmTick("parity", 6, scene=_enclosed_scene(pop, 6))
+    finally:
+        os.environ.pop("SOGM_SPEC_ASTAR", None)
+    oks = []
+    for _ in range(ticks):
+        oks.append(sw.step().cpu().numpy().copy())
+    torch.cuda.synchronize()
+    out = (np.stack(oks), sw.own.cpu().numpy().copy(), sw.planner.counters(), sw.planner.flow_error())
+    sw.close()
+    return out
+
+
+def test_speculative_second_search_changes_nothing(pop):
+    """The replan's second A* attempt runs beside the first (own pool, verdict hand-off).  A flight with an enclosed
+    agent — NO_PATH in both attempts at every tick — and free agents must give the same ok flags, records and outcome
+    counters with the speculation on and off."""
+    ok0, rec0, cnt0, err0 = _fly_spec(pop, False)
+    ok1, rec1, cnt1, err1 = _fly_spec(pop, True)
+    assert err0 == 0 and err1 == 0
+    assert np.array_equal(ok0, ok1) and np.array_equal(rec0, rec1) and cnt0 == cnt1
+    assert cnt0["fail_search"] >= len(ok0)   # the enclosed agent failed its search at every tick
+    assert ok0[:, 1:].sum() > 0 and not ok0[:, 0].any()
