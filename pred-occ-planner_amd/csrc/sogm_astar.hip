@@ -258,7 +258,11 @@ __device__ inline void heap_pop(const double *f, unsigned short *h, int &n) {
 }
 
 #define ASTAR_MAX_INPUTS 128
-#define ASTAR_THREADS 128
+// Waves 0-1 evaluate one motion primitive per lane; wave 2's lane 0 is the MASTER that owns the open list (pop,
+// ordered replay of the children's events, termination): being on a wave of its own it can restore the heap after a
+// pop (a full-depth sift-down of dependent LDS reads, ~2 us) WHILE the other two waves evaluate the children.
+#define ASTAR_THREADS 192
+#define ASTAR_MASTER 128
 
 // per-child action decided in parallel, replayed in child order by the master
 enum { EV_NONE = 0, EV_NEW = 1, EV_DUP = 2, EV_OPEN = 3, EV_ERR = 4 };
@@ -374,7 +378,7 @@ __global__ __launch_bounds__(ASTAR_THREADS) void k_astar(
   // master-only state
   int  use_node_num = 0, iter_num = 0, heap_n = 0, n_trace = 0;
   int  ret = NO_PATH, searches = 0, terminal = -1;
-  bool is_shot_succ = false;
+  bool is_shot_succ = false, need_pop = false;
   long long tk[6] = {0, 0, 0, 0, 0, 0};  // wall_clock64 ticks (100 MHz): pop, eval, dup, merge, write, n_exp
   long long tmark = 0;
 
@@ -388,7 +392,7 @@ __global__ __launch_bounds__(ASTAR_THREADS) void k_astar(
     for (int i = tid; i < hcap; i += ASTAR_THREADS) htab[i] = HASH_EMPTY;
     __syncthreads();
     bool done = false;
-    if (tid == 0) {
+    if (tid == ASTAR_MASTER) {
       use_node_num = 0;
       iter_num     = 0;
       heap_n       = 0;
@@ -425,7 +429,7 @@ __global__ __launch_bounds__(ASTAR_THREADS) void k_astar(
     while (!done) {
       // ---------------- master: pop / terminate ----------------
       tmark = wall_clock64();
-      if (tid == 0) {
+      if (tid == ASTAR_MASTER) {
         s_n_active = 0;
         // speculative second attempt: every 8th expansion, look whether the first attempt has found a path
         if (second && (iter_num & 7) == 0 &&
@@ -491,7 +495,7 @@ __global__ __launch_bounds__(ASTAR_THREADS) void k_astar(
             stop = true;
           }
           if (!stop) {
-            heap_pop(s_f, s_heap, heap_n);
+            need_pop      = true;  // the heap is restored after the barrier, under the children's evaluation
             cn.node_state = IN_CLOSE_SET;
             iter_num += 1;
             if (out_trace && n_trace < trace_cap) out_trace[(size_t)agent * trace_cap + n_trace] = cur;
@@ -515,6 +519,10 @@ __global__ __launch_bounds__(ASTAR_THREADS) void k_astar(
         if (second && s_ret == -1) dropped = true;  // uniform: s_ret is only set to -1 by the check above
         done = true;
         break;
+      }
+      if (tid == ASTAR_MASTER && need_pop) {  // std::pop_heap's sift-down, beside the evaluation below
+        heap_pop(s_f, s_heap, heap_n);
+        need_pop = false;
       }
       {
         const long long t2 = wall_clock64();
@@ -626,9 +634,9 @@ __global__ __launch_bounds__(ASTAR_THREADS) void k_astar(
         const unsigned long long lt   = lane ? (~0ull >> (64 - lane)) : 0ull;
         const bool               mg   = tid < n_act && s_gate[tid] != 0;
         const unsigned long long bg   = __ballot(mg);
-        if (lane == 0) s_cnt_w[wave] = __popcll(bg);
+        if (lane == 0 && wave < 2) s_cnt_w[wave] = __popcll(bg);
         __syncthreads();
-        const int crank = __popcll(bg & lt) + (wave ? s_cnt_w[0] : 0);
+        const int crank = __popcll(bg & lt) + (wave == 1 ? s_cnt_w[0] : 0);
         if (mg) {
           s_ckey[crank] = s_key[tid];
           s_cidx[crank] = (short)tid;
@@ -683,8 +691,8 @@ __global__ __launch_bounds__(ASTAR_THREADS) void k_astar(
           s_n_ev_w0  = __popcll(be);
         }
         __syncthreads();
-        const int rnew = __popcll(bn & lt) + (wave ? s_n_new_w0 : 0);
-        const int rev  = __popcll(be & lt) + (wave ? s_n_ev_w0 : 0);
+        const int rnew = __popcll(bn & lt) + (wave == 1 ? s_n_new_w0 : 0);
+        const int rev  = __popcll(be & lt) + (wave == 1 ? s_n_ev_w0 : 0);
         if (tid < n_act) {
           s_rank[tid] = (short)rnew;
           if (my_ev != EV_NONE) {
@@ -704,7 +712,7 @@ __global__ __launch_bounds__(ASTAR_THREADS) void k_astar(
         tmark = t2;
       }
       // ---------------- master: replay the events in child order (:366-414) ----------------
-      if (tid == 0) {
+      if (tid == ASTAR_MASTER) {
         const int n_ev = s_n_events;
         int       n_written = 0, n_upd = 0;
         int2      rec  = s_erec[0];
@@ -799,7 +807,7 @@ __global__ __launch_bounds__(ASTAR_THREADS) void k_astar(
     }
     // broadcast the verdict of this attempt
     if (dropped) break;
-    if (tid == 0) s_ret = ret;
+    if (tid == ASTAR_MASTER) s_ret = ret;
     __syncthreads();
     const int r = s_ret;
     __syncthreads();
@@ -809,7 +817,7 @@ __global__ __launch_bounds__(ASTAR_THREADS) void k_astar(
     // first attempt: announce the verdict; a NO_PATH first attempt leaves the agent's outputs to the second one.
     // second attempt: wait for that verdict (bounded) and go on only if the first attempt failed.
     if (!second) {
-      if (tid == 0) {
+      if (tid == ASTAR_MASTER) {
         s_ret = ret;
         __hip_atomic_store(&wsp.verdict[agent], ret != NO_PATH ? 1 : 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
@@ -817,7 +825,7 @@ __global__ __launch_bounds__(ASTAR_THREADS) void k_astar(
       if (s_ret == NO_PATH) return;
     } else {
       if (dropped) return;
-      if (tid == 0) {
+      if (tid == ASTAR_MASTER) {
         const long long t0 = wall_clock64();
         int             v;
         while ((v = __hip_atomic_load(&wsp.verdict[agent], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0) {
@@ -831,12 +839,12 @@ __global__ __launch_bounds__(ASTAR_THREADS) void k_astar(
       }
       __syncthreads();
       if (s_ret != 2) return;
-      if (tid == 0) searches = 2;  // as the sequential pattern counts them
+      if (tid == ASTAR_MASTER) searches = 2;  // as the sequential pattern counts them
     }
   }
 
   // ---------------- master: getPathWithVel(corridor_tau) (:663-694) ----------------
-  if (tid == 0) {
+  if (tid == ASTAR_MASTER) {
     int n = 0;
     if (ret != NO_PATH && ret != SEARCH_ERR && terminal >= 0) {
       double *route = out_route + (size_t)agent * route_cap * 6;
