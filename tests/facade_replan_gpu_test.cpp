@@ -1,4 +1,6 @@
-// FakeBaselinePlanner::replan (plan_manager/src/baseline_fake.cpp:266-472) written statement by statement against the
+// FakeBaselinePlanner::replan (plan_manager/src/baseline_fake.cpp:266-472) and BaselinePlanner::replan
+// (plan_manager/src/baseline.cpp:252-450; the statements that differ are selected by `fake_`, each with its
+// line reference) written statement by statement against the
 // per-object shims of pred-occ-planner_amd/host/sogm_reference_api.hpp — map_->getMapTime(), a_star_->reset() /
 // search() / getPathWithVel(), getInitCorridor, map_->getObstaclePoints(), firi::firi, ShrinkCorridor,
 // checkCorridorValidity / Intersect, checkGoalReachability, traj_optimizer_->setup() / optimize() / getOptBezier(),
@@ -89,6 +91,7 @@ struct BaselineParameters {  // baseline.h:45-94 (the fields replan reads)
 
 // ---- the planner object: members as in baseline_fake.h ------------------------------------------------------------
 struct FakeBaselinePlanner {
+  bool                                       fake_ = true;  // false: BaselinePlanner (baseline.cpp)
   BaselineParameters                         cfg_;
   std::shared_ptr<sogm_ref::RiskMapView>     map_;
   std::shared_ptr<sogm_ref::RiskHybridAstar> a_star_;
@@ -98,7 +101,7 @@ struct FakeBaselinePlanner {
   sogm_ref::AgentBinding                     binding_;
   sogm_ref::Bezier                           traj_;
   double                                     traj_start_time_ = 0, prev_traj_start_time_ = 0;
-  int                                        n_corridors_ = 0, astar_ret_ = 0;
+  int                                        n_corridors_ = 0, astar_ret_ = 0, stage_ = 0, n_polys_ = 0, n_pc_ = 0;
 
   Matrix64d getInitCorridor(const Vector3d &lhc, const Vector3d &rlc) {
     return sogm_ref::CorridorTools::getInitCorridor<Matrix64d>(lhc, rlc);
@@ -131,6 +134,7 @@ struct FakeBaselinePlanner {
 
     /* if no path found, set empty trajectory */
     if (rst == sogm_ref::NO_PATH) {
+      stage_ = 1;
       return false;
     }
 
@@ -140,6 +144,10 @@ struct FakeBaselinePlanner {
     std::vector<MatrixX4d> hPolys;
 
     wpts.resize(route_vel.size()); /* copy route_vel to route */
+    if (!fake_ && route_vel.size() < 2) { /* baseline.cpp:301-304 */
+      stage_ = 2;
+      return false;
+    }
 
     for (int i = 0; i < (int)wpts.size(); i++) {
       wpts[i] = route_vel[i].head3(); /* copy position to route */
@@ -172,6 +180,7 @@ struct FakeBaselinePlanner {
       double t1_glb = traj_start_time_ + i * cfg_.corridor_tau;
       double t2_glb = traj_start_time_ + (i + 1) * cfg_.corridor_tau;
       map_->getObstaclePoints(pc, t1_glb, t2_glb, llc, lhc);
+      if (i == 0) n_pc_ = (int)pc.size();
 
       Map3Xd m_pc{pc.empty() ? nullptr : pc[0].data(), (int)pc.size()};
 
@@ -190,28 +199,37 @@ struct FakeBaselinePlanner {
     for (int i = 0; i < (int)hPolys.size() - 1; i++) {
       if (!checkCorridorIntersect(hPolys[i], hPolys[i + 1])) {
         if (i < 2) {
+          stage_ = 3;
           return false;
         } else {
-          hPolys.erase(hPolys.begin() + i + 1, hPolys.end());
+          if (fake_)
+            hPolys.erase(hPolys.begin() + i + 1, hPolys.end()); /* baseline_fake.cpp:372 */
+          else
+            hPolys.erase(hPolys.begin() + i, hPolys.end()); /* baseline.cpp:373 */
           break;
         }
       }
     }
 
-    if (hPolys.size() == 0) {
+    n_polys_ = (int)hPolys.size();
+    if (fake_ ? hPolys.size() == 0 : hPolys.size() <= 1) { /* baseline_fake.cpp:383 / baseline.cpp:383 */
+      stage_ = 4;
       return false;
     }
 
     /* Goal position and time allocation */
     Vector3d local_goal_pos = route_vel[hPolys.size() - 1].head3();
     Vector3d local_goal_vel = route_vel[hPolys.size() - 1].tail3();
-    for (auto it = hPolys.end() - 1; it != hPolys.begin(); it--) {
-      if (checkGoalReachability(*it, start_pos, local_goal_pos)) {
-        hPolys.erase(it + 1, hPolys.end());
-        int idx        = hPolys.size() - 1;
-        local_goal_pos = route_vel[idx].head3();
-        local_goal_vel = route_vel[idx].tail3();
-        break;
+    /* baseline.cpp:391 tests the last corridor first; baseline_fake.cpp:393 goes straight into the loop */
+    if (fake_ || !checkGoalReachability(hPolys.back(), start_pos, local_goal_pos)) {
+      for (auto it = hPolys.end() - 1; it != hPolys.begin(); it--) {
+        if (checkGoalReachability(*it, start_pos, local_goal_pos)) {
+          hPolys.erase(it + 1, hPolys.end());
+          int idx        = hPolys.size() - 1;
+          local_goal_pos = route_vel[idx].head3();
+          local_goal_vel = route_vel[idx].tail3();
+          break;
+        }
       }
     }
     n_corridors_ = (int)hPolys.size();
@@ -230,6 +248,7 @@ struct FakeBaselinePlanner {
     final_state.setRow(2, Vector3d(0, 0, 0));
     traj_optimizer_->setup(init_state, final_state, time_alloc, hPolys, cfg_.opt_max_vel, cfg_.opt_max_acc);
     if (!traj_optimizer_->optimize()) {
+      stage_ = 5;
       return false;
     }
 
@@ -246,17 +265,15 @@ struct FakeBaselinePlanner {
   }
 };
 
-int main() {
-  if (sogm_device_count() < 1) {
-    std::puts("no device");
-    return 77;
-  }
+// one scene, one planner kind: the fused sogm_replan against the transcription, agent by agent
+static int run_kind(bool fake) {
   SogmSpec spec{};
   spec.L = 66; spec.W = 66; spec.H = 20; spec.T = 6;
   spec.resolution = 0.15f; spec.time_resolution = 0.2f; spec.risk_threshold = 0.2f; spec.clearance = 0.45f;
   spec.ground_height = -0.01f; spec.ceiling_height = 3.0f; spec.risk_threshold_region = 1.2f;
   spec.risk_thres_reg_decay = 0.2f; spec.risk_thres_vox_decay = 0.2f;
-  spec.map_kind = SOGM_MAP_FAKE; spec.storage = SOGM_STORE_F32;
+  // FakeBaselinePlanner owns a FakeParticleRiskVoxel map, BaselinePlanner a RiskVoxel (baseline.h:155; fixed thresholds)
+  spec.map_kind = fake ? SOGM_MAP_FAKE : SOGM_MAP_RISKVOXEL; spec.storage = SOGM_STORE_F32;
   const int A = 3;
   RiskMap map(spec, A);
   std::vector<Vec3> body;
@@ -266,7 +283,9 @@ int main() {
   map.setCoordinator(body);
   // two static pillars and one moving cylinder between the agents
   std::vector<float> cloud;
-  const float px[2] = {0.0f, 1.2f}, py[2] = {0.3f, -1.4f};
+  // (the BaselinePlanner scene keeps the pillars off the straight lines: RiskBase inflates with a 5^3 kernel and
+  //  BaselinePlanner shrinks every corridor face, a pillar on the path leaves no valid first corridor)
+  const float px[2] = {fake ? 0.0f : 1.5f, fake ? 1.2f : -1.5f}, py[2] = {fake ? 0.3f : 2.0f, fake ? -1.4f : -2.0f};
   for (int c = 0; c < 2; ++c)
     for (int k = 0; k < 48; ++k)
       for (int iz = 0; iz < 30; ++iz) {
@@ -279,8 +298,8 @@ int main() {
   for (int c = 0; c < 2; ++c) {
     cyl[c].type = 3; cyl[c].x = px[c]; cyl[c].y = py[c]; cyl[c].z = 1.5; cyl[c].w = 0.8; cyl[c].h = 3.0; cyl[c].qw = 1.0;
   }
-  cyl[2].type = 3; cyl[2].x = -1.0; cyl[2].y = 1.8; cyl[2].z = 1.5; cyl[2].w = 0.6; cyl[2].h = 3.0; cyl[2].qw = 1.0;
-  cyl[2].vx = 0.4; cyl[2].vy = -0.8;
+  cyl[2].type = 3; cyl[2].x = fake ? -1.0 : -2.6; cyl[2].y = fake ? 1.8 : 2.6; cyl[2].z = 1.5; cyl[2].w = 0.6; cyl[2].h = 3.0;
+  cyl[2].qw = 1.0; cyl[2].vx = fake ? 0.4 : 0.0; cyl[2].vy = fake ? -0.8 : 0.0;
   const float   poses[9]  = {-3.f, 0.1f, 1.f, 3.f, -0.1f, 1.f, 0.2f, 3.0f, 1.2f};
   const double  stamps[3] = {100.0, 100.0, 100.0};
   const int32_t range[6]  = {0, n_pts, 0, n_pts, 0, n_pts};
@@ -293,7 +312,7 @@ int main() {
   ap.lambda_heu = 5.0; ap.resolution = 0.15; ap.time_resolution = 0.3; ap.allocate_num = 10000; ap.check_num = 1;
   ap.tolerance = 1;
   SogmPlannerParams pp{}; pp.corridor_tau = 0.3; pp.init_range = 1.2; pp.shrink_size = 0.2; pp.opt_max_vel = 3.0;
-  pp.opt_max_acc = 6.0; pp.fake_planner = 1; pp.firi_iterations = 2; pp.pc_capacity = 4096; pp.max_faces = 64;
+  pp.opt_max_acc = 6.0; pp.fake_planner = fake ? 1 : 0; pp.firi_iterations = 2; pp.pc_capacity = 4096; pp.max_faces = 64;
   SogmQpSettings qs{}; qs.rho = 0.1; qs.sigma = 1e-6; qs.alpha = 1.6; qs.eps_abs = 1e-3; qs.eps_rel = 1e-3;
   qs.max_iter = 4000; qs.check_termination = 25; qs.scaling_iters = 10; qs.adaptive_rho_interval = 25;
   Planner planner(map, ap, pp, qs);
@@ -335,7 +354,8 @@ int main() {
     P.cfg_     = {pp.corridor_tau, pp.init_range, pp.opt_max_vel, pp.opt_max_acc};
     P.binding_ = sogm_ref::AgentBinding{&map, &planner, a, pp};
     P.tools_.shrink_size  = pp.shrink_size;
-    P.tools_.fake_planner = true;
+    P.tools_.fake_planner = fake;
+    P.fake_               = fake;
     P.map_               = std::make_shared<sogm_ref::RiskMapView>(P.binding_);
     P.a_star_            = std::make_shared<sogm_ref::RiskHybridAstar>(P.binding_);
     P.collision_avoider_ = std::make_shared<sogm_ref::ParticleATC>(P.binding_, ids[a], 8, [now] { return now; });
@@ -345,8 +365,9 @@ int main() {
         sa(pva[a * 9 + 6], pva[a * 9 + 7], pva[a * 9 + 8]), gp(goal[a * 3], goal[a * 3 + 1], goal[a * 3 + 2]);
     REQUIRE(std::fabs(P.map_->getMapTime().toSec() - 100.0) == 0.0);
     const bool got = P.replan(tst[a], sp, sv, sa, gp);
-    std::printf("agent %d: transcription %d (A* ret %d, %d corridors) | sogm_replan %d (%d pieces)\n", a, (int)got,
-                P.astar_ret_, P.n_corridors_, ok[a], rec[a].n_pieces);
+    std::printf("agent %d: transcription %d (A* ret %d, %d corridors; left at stage %d, %d valid polytopes, %d points in box 0) "
+                "| sogm_replan %d (%d pieces)\n", a, (int)got, P.astar_ret_, P.n_corridors_, P.stage_, P.n_polys_, P.n_pc_,
+                ok[a], rec[a].n_pieces);
     REQUIRE((int)got == ok[a]);
     if (got) {
       ++n_true;
@@ -361,7 +382,18 @@ int main() {
     }
   }
   REQUIRE(n_true >= 2);
+  std::printf("%s::replan transcription ok: %d of %d agents planned\n", fake ? "FakeBaselinePlanner" : "BaselinePlanner",
+              n_true, A);
+  return 0;
+}
 
-  std::printf("facade replan transcription ok: %d of %d agents planned\n", n_true, A);
+int main() {
+  if (sogm_device_count() < 1) {
+    std::puts("no device");
+    return 77;
+  }
+  if (int rc = run_kind(true)) return rc;
+  if (int rc = run_kind(false)) return rc;
+  std::puts("facade replan transcription ok");
   return 0;
 }

@@ -57,8 +57,8 @@ def test_reference_api_header_compiles(tmp_path):
 
 @pytest.mark.gpu
 def test_replan_transcription_on_gpu(tmp_path):
-    """FakeBaselinePlanner::replan (baseline_fake.cpp:266-472) transcribed statement by statement against the
-    per-object shims (search / getPathWithVel / getObstaclePoints / firi::firi / ShrinkCorridor / the LP checks /
+    """FakeBaselinePlanner::replan (baseline_fake.cpp:266-472) and BaselinePlanner::replan (baseline.cpp:252-450)
+    transcribed statement by statement against the per-object shims (search / getPathWithVel / getObstaclePoints / firi::firi / ShrinkCorridor / the LP checks /
     BezierOpt / isSafeAfterOpt), three agents: every verdict and every control point equals the fused sogm_replan."""
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
