@@ -219,12 +219,26 @@ __device__ inline void hash_insert(unsigned long long *tab, int cap, unsigned lo
 
 // libstdc++ std::push_heap / std::pop_heap with NodeComparator (f(a) > f(b)), restated on an LDS
 // heap of node ids with the f-scores mirrored in LDS.
+// (std::__push_heap.  The ids of up to three ancestors and then their f are read as two batches of independent LDS
+//  loads — a dependent LDS read costs ~64 cycles — before the level-by-level comparisons; the positions read ahead are
+//  only written once the hole has moved past them, so the values are the ones the plain loop would see.)
 __device__ inline void heap_push_up(const double *f, unsigned short *h, int hole, int top, int value) {
-  int parent = (hole - 1) / 2;
-  while (hole > top && f[h[parent]] > f[value]) {
-    h[hole] = h[parent];
-    hole    = parent;
-    parent  = (hole - 1) / 2;
+  const double fv = f[value];
+  while (hole > top) {
+    const int p1 = (hole - 1) / 2;
+    const int p2 = p1 > top ? (p1 - 1) / 2 : p1;
+    const int p3 = p2 > top ? (p2 - 1) / 2 : p2;
+    const int i1 = h[p1], i2 = h[p2], i3 = h[p3];
+    const double f1 = f[i1], f2 = f[i2], f3 = f[i3];
+    if (!(f1 > fv)) break;
+    h[hole] = (unsigned short)i1;
+    hole    = p1;
+    if (!(hole > top) || !(f2 > fv)) break;
+    h[hole] = (unsigned short)i2;
+    hole    = p2;
+    if (!(hole > top) || !(f3 > fv)) break;
+    h[hole] = (unsigned short)i3;
+    hole    = p3;
   }
   h[hole] = (unsigned short)value;
 }
