@@ -23,5 +23,5 @@ for k in range(ticks):
     end = us[:, 6]
     crit = int(np.argmax(end))
     d = lambda a, b: us[:, b] - us[:, a]
-    print(f"tick {k}: end {end.max()/1000:.2f} ms (agent {crit}); mean/max ms: map wait {us[:,0].mean()/1000:.2f}/{us[:,0].max()/1000:.2f}  A* {d(0,1).mean()/1000:.2f}/{d(0,1).max()/1000:.2f}  wait->corr {d(1,2).mean()/1000:.2f}/{d(1,2).max()/1000:.2f}  corr {d(2,3).mean()/1000:.2f}/{d(2,3).max()/1000:.2f}  wait->QP {d(3,4).mean()/1000:.2f}/{d(3,4).max()/1000:.2f}  QP {d(4,5).mean()/1000:.2f}/{d(4,5).max()/1000:.2f}  fin {d(5,6).mean()/1000:.2f}/{d(5,6).max()/1000:.2f}")
+    print(f"tick {k}: end {end.max()/1000:.2f} ms (agent {crit}); mean/max ms: A* {d(0,1).mean()/1000:.2f}/{d(0,1).max()/1000:.2f}  wait->corr {d(1,2).mean()/1000:.2f}/{d(1,2).max()/1000:.2f}  corr {d(2,3).mean()/1000:.2f}/{d(2,3).max()/1000:.2f}  wait->QP {d(3,4).mean()/1000:.2f}/{d(3,4).max()/1000:.2f}  QP {d(4,5).mean()/1000:.2f}/{d(4,5).max()/1000:.2f}  fin {d(5,6).mean()/1000:.2f}/{d(5,6).max()/1000:.2f}")
     print("   critical agent:", " | ".join(f"{n} {us[crit, i]/1000:.2f}" for i, n in enumerate(names)))

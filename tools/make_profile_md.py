@@ -68,7 +68,7 @@ Reading guide:
 - `k_clear_slabs` is the roofline kernel (SOGM voxel update, {alg/1e9:.2f} GB algorithmic bytes per launch = 128 agents x
   640 MB); PMC: FETCH_SIZE {fk:.0f} KB + WRITE_SIZE {wk:.0f} KB = {traffic/1e9:.2f} GB per launch (KB = 1024 B), i.e.
   **{traffic/alg:.4f} x** the algorithmic bytes — no wasted traffic.
-- In the dataflow replan the planner is five launches per tick; `k_corridor_flow`, `k_qp_flow`, `k_finish_flow` are
+- In the dataflow replan the planner is five launches per tick (`k_astar` with 2 x 128 workgroups: both search attempts); `k_corridor_flow`, `k_qp_flow`, `k_finish_flow` are
   persistent (their durations span most of the tick by construction) — the per-agent stage times below are what to
   read, not the kernel durations.
 - The clear runs on a side stream beside the whole replan; with three grids a tick only waits for the clear queued one
@@ -76,7 +76,7 @@ Reading guide:
 
 {summ}
 
-## timeline of one tick (ms from the tick's k_stamp_cloud)
+## timeline of one tick (ms from the tick's first kernel, k_tick_inputs)
 
 ```
 {tl.strip()}
