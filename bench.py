@@ -5,7 +5,12 @@ A "step" is one replan tick over the rank's batch of agents: SOGM update (clear 
 + neighbour overlay + hybrid A* + corridors + Bezier QP, plus the trajectory all-gather (N > 1).
 N = 1 workload: BASELINE.json configs[2] — 128 agents on one MI355X, 200^3 x 20 SOGM (the
 configuration the metric is quoted on).  N > 1: the same 128 agents per GPU (weak scaling), agents
-sharded over ranks, one RCCL all-gather of trajectory records per tick.
+sharded over ranks, one RCCL all-gather of trajectory records per tick; `--agents 64 --gpus 8` is
+BASELINE configs[3] (512 agents over 8 GPUs).
+
+`python bench.py --gpus N` with N > 1 and no RANK in the environment starts the N ranks itself
+(re-executes under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1`);
+under a launcher it checks that WORLD_SIZE == N.  It refuses to run with fewer visible GPUs than ranks.
 
 Prints ONE JSON line (rank 0) with the driver's contract plus `roofline` and `cpu_baseline`.
 """
@@ -34,6 +39,37 @@ def parse():
     ap.add_argument("--sustained", type=int, default=300,
                     help="ticks of the sustained-flight block after the timed region (0 = skip)")
     return ap.parse_args()
+
+
+def launch_plan(gpus, env, device_count, argv, port=None):
+    """How `bench.py --gpus N` gets its N ranks.  Returns None (run in this process) or the command line to
+    re-execute; raises SystemExit with a message when the request cannot be honoured — a bench that silently ran
+    one rank while claiming N would print a wrong n_gpus (missing #1).
+      * launched by torch.distributed.run / the driver (RANK in env): WORLD_SIZE must equal --gpus;
+      * not launched, N == 1: this process is the only rank;
+      * not launched, N > 1: re-execute under torch.distributed.run with N local ranks (127.0.0.1 rendezvous)."""
+    if gpus < 1:
+        raise SystemExit(f"bench.py: --gpus {gpus}: need at least one GPU")
+    if "RANK" in env:
+        world, local = int(env.get("WORLD_SIZE", "1")), int(env.get("LOCAL_RANK", "0"))
+        if world != gpus:
+            raise SystemExit(f"bench.py: --gpus {gpus} but launched with WORLD_SIZE={world}: one rank per GPU")
+        if device_count <= local and device_count != 1:  # (a launcher may also show each rank its own GPU only)
+            raise SystemExit(f"bench.py: local rank {local} but {device_count} GPU(s) visible")
+        return None
+    if device_count < gpus:
+        raise SystemExit(f"bench.py: --gpus {gpus} but only {device_count} GPU(s) visible: refusing to print an "
+                         f"n_gpus = {gpus} line from fewer devices")
+    if gpus == 1:
+        return None
+    if port is None:
+        import socket
+        sk = socket.socket()
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+        sk.close()
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port)] + list(argv)
 
 
 def cpu_baseline(pop, spec, scene, n_agents_sample):
@@ -88,11 +124,18 @@ def cpu_baseline(pop, spec, scene, n_agents_sample):
 def main():
     args = parse()
     import torch
+    cmd = launch_plan(args.gpus, os.environ, torch.cuda.device_count(), sys.argv)
+    if cmd is not None:
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        sys.stdout.flush()
+        os.execvpe(cmd[0], cmd, env)
     pop = importlib.import_module("pred-occ-planner_amd")
     driver = importlib.import_module("pred-occ-planner_amd.driver")
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if torch.cuda.device_count() == 1:
+        local = 0  # the launcher shows each rank its own GPU only
     dist = None
     launched = "RANK" in os.environ and "MASTER_ADDR" in os.environ  # under torch.distributed.run
     if world > 1 or launched:
@@ -129,6 +172,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     n_ok = int(torch.stack(oks).sum().item())  # over ALL timed ticks
+    flow_code, flow_failed = sw.planner.flow_failures()  # after the barrier: every timed tick has completed
+    if flow_failed:
+        raise SystemExit(f"bench.py: {flow_failed} tick(s) of the dataflow replan timed out on the device "
+                         f"(code {flow_code}): the timed region is invalid")
     outcomes = sw.planner.counters(reset=True)
     if dist is not None:
         t = torch.tensor([n_ok] + [outcomes[k] for k in sorted(outcomes)], dtype=torch.int64, device="cuda")
@@ -203,6 +250,10 @@ def main():
                    # where the timed replans ended + capacity limits hit (sogm_planner_counters)
                    "outcomes": outcomes,
                    "parallelism": f"agents sharded x{world}, 1 all-gather/tick",
+                   # which all-gather ran: "abi" = sogm_traj_allgather (RCCL behind the C ABI), "torch" =
+                   # torch.distributed's (also RCCL; the fallback — reason given), "local" = one process
+                   "exchange": ("abi" if sw.exchange.active else "torch" if sw.distributed else "local"),
+                   "exchange_fallback_reason": sw.exchange.fallback_reason,
                    "sogm_grids_per_agent": overlap_mode if overlap_mode >= 2 else 1},
         "replans_per_s_per_agent": sw.A_tot * args.steps / dt / sw.A_tot,
         "stage_ms": {"clear": avg[0], "stamp": avg[1], "splat": avg[2], "astar": avg[3], "corridor": avg[4],

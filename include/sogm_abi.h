@@ -629,10 +629,16 @@ enum {
 };
 int sogm_planner_counters(sogm_planner *p, int64_t *out_host, int reset);
 /* sogm_replan() chains its kernels per agent through device-side ready lists ("dataflow replan");
- * a wait that exceeds 3 s marks the tick as failed instead of hanging the GPU.  Synchronises the device and
- * returns 0 if the last sogm_replan() completed normally, a positive code if one of its waits timed out (the
- * affected agents then report ok = 0 / stale records), negative = sogm_status. */
+ * a wait that exceeds 3 s marks the tick as failed instead of hanging the GPU: agents whose chain did not complete
+ * report ok = 0 and an empty record (n_pieces = 0) for that tick.  Synchronises the device and returns 0 if the
+ * last sogm_replan() completed normally, a positive code if one of its waits timed out, negative = sogm_status. */
 int sogm_planner_flow_error(sogm_planner *p);
+/* The same without synchronising anything: out[0] = code of the most recent failed tick (0 = none ever),
+ * out[1] = number of sogm_replan() calls that failed so far, as of the ticks that have COMPLETED on the device
+ * (the words live in pinned host memory and are written by the last kernel of each replan).  A tick driver polls
+ * this once per tick and stops merging records when the count moves (the reference has no analogue: its replan()
+ * cannot time out). */
+int sogm_planner_flow_failures(sogm_planner *p, int32_t out[2]);
 
 /*
  * One full FakeBaselinePlanner::replan (baseline_fake.cpp:266-472; isSafeAfterOpt only when a swarm has

@@ -14,8 +14,13 @@
 // Ruiz equilibration (10 passes, with cost scaling), rho = 0.1 (x1e3 on equality rows, 1e-6 on
 // free rows), sigma = 1e-6, alpha = 1.6, termination checked every 25 iterations on UNSCALED
 // residuals, max_iter 4000, no polish.  Adaptive rho follows SogmQpSettings.adaptive_rho_interval
-// (0 = one fixed KKT factor; default 25).  The x-update solves the reduced system (P + sigma I + A^T diag(rho) A) x = rhs by
-// Cholesky, which is algebraically the quasi-definite KKT solve OSQP performs.
+// (0 = one fixed KKT factor; default 25); its estimate is computed from the SCALED residuals and
+// norms, as auxil.c::compute_rho_estimate does (it reads the work vectors update_info left behind).  The primal
+// infeasibility certificate projects delta_y onto the polar of the recession cone of [l, u] first
+// (auxil.c::is_primal_infeasible); the dual one cannot fire (q = 0) and is not restated; max_iter ends with the
+// approximate check (solved / primal infeasible inaccurate, status 2 / 3).  The x-update solves the reduced
+// system (P + sigma I + A^T diag(rho) A) x = rhs by Cholesky, which is algebraically the quasi-definite KKT
+// solve OSQP performs.
 // Solution values: parity unpinned (OSQP absent, reference stops at 1e-3).
 #include <cmath>
 #include <cstring>
@@ -314,9 +319,13 @@ int osqpDense(const double *Pin, const double *qin, const double *Ain, const dou
   Vec Ax(m), Px(n), Aty(n);
   const double alpha = qs->alpha;
   int          status = -2, iter = 0;
-  double last_pr = 0, last_dr = 0, last_nAx = 0, last_nz = 0, last_nPx = 0, last_nAty = 0, last_nq = 0;
+  // scaled residual norms of the last evaluation: what compute_rho_estimate reads (the work vectors z_prev / x_prev
+  // still hold Ax - z and Px + q + A'y in SCALED form after update_info; OSQP 1.0 names them scaled_prim_res /
+  // scaled_dual_res), with the scaled norms of z, Ax, q, A'y, Px
+  double sc_pr = 0, sc_dr = 0, sc_nAx = 0, sc_nz = 0, sc_nPx = 0, sc_nAty = 0, sc_nq = 0;
   auto residuals = [&](double eps_abs, double eps_rel, bool &prim_ok, bool &dual_ok) {
     double pr = 0, nAx = 0, nz = 0;
+    sc_pr = sc_nAx = sc_nz = 0;
     for (int i = 0; i < m; ++i) {
       double s = 0;
       for (int j = 0; j < n; ++j) s += A[(size_t)i * n + j] * x[j];
@@ -324,8 +333,12 @@ int osqpDense(const double *Pin, const double *qin, const double *Ain, const dou
       pr    = std::max(pr, std::fabs((s - z[i]) / E[i]));
       nAx   = std::max(nAx, std::fabs(s / E[i]));
       nz    = std::max(nz, std::fabs(z[i] / E[i]));
+      sc_pr  = std::max(sc_pr, std::fabs(s - z[i]));
+      sc_nAx = std::max(sc_nAx, std::fabs(s));
+      sc_nz  = std::max(sc_nz, std::fabs(z[i]));
     }
     double dr = 0, nPx = 0, nAty = 0, nq = 0;
+    sc_dr = sc_nPx = sc_nAty = sc_nq = 0;
     for (int j = 0; j < n; ++j) {
       double s = 0, a = 0;
       for (int k = 0; k < n; ++k) s += P[(size_t)j * n + k] * x[k];
@@ -336,14 +349,46 @@ int osqpDense(const double *Pin, const double *qin, const double *Ain, const dou
       nPx    = std::max(nPx, std::fabs(s / D[j]));
       nAty   = std::max(nAty, std::fabs(a / D[j]));
       nq     = std::max(nq, std::fabs(q[j] / D[j]));
+      sc_dr   = std::max(sc_dr, std::fabs(s + q[j] + a));
+      sc_nPx  = std::max(sc_nPx, std::fabs(s));
+      sc_nAty = std::max(sc_nAty, std::fabs(a));
+      sc_nq   = std::max(sc_nq, std::fabs(q[j]));
     }
     dr *= cinv;
-    last_pr = pr; last_dr = dr; last_nAx = nAx; last_nz = nz;
-    last_nPx = cinv * nPx; last_nAty = cinv * nAty; last_nq = cinv * nq;
     const double eps_prim = eps_abs + eps_rel * std::max(nAx, nz);
     const double eps_dual = eps_abs + eps_rel * cinv * std::max(std::max(nPx, nAty), nq);
     prim_ok               = pr < eps_prim;
     dual_ok               = dr < eps_dual;
+  };
+  // primal infeasibility certificate (OSQP v0.6 auxil.c is_primal_infeasible; check_termination calls it only
+  // when the primal residual test failed).  delta_y is first PROJECTED onto the polar of the recession cone of
+  // [l, u]: a component whose upper bound is infinite can only count when negative, one whose lower bound is
+  // infinite only when positive (every corridor face is such a row, l = -OSQP_INFTY), a free row not at all.
+  // The norm, u'(dy)+ + l'(dy)- and A'dy all use the projected vector; ||dy|| and A'dy are unscaled (E dy,
+  // Dinv A'dy); both tests are relative to ||dy||.  (dy is overwritten, as work->delta_y is; the next iteration
+  // recomputes it.)
+  auto primal_infeasible = [&](double eps_inf) -> bool {
+    for (int i = 0; i < m; ++i) {
+      if (u[i] > OSQP_INFTY * MIN_SCALING) {
+        if (l[i] < -OSQP_INFTY * MIN_SCALING) dy[i] = 0.0;
+        else dy[i] = std::min(dy[i], 0.0);
+      } else if (l[i] < -OSQP_INFTY * MIN_SCALING) {
+        dy[i] = std::max(dy[i], 0.0);
+      }
+    }
+    double ndy = 0;
+    for (int i = 0; i < m; ++i) ndy = std::max(ndy, std::fabs(E[i] * dy[i]));
+    if (!(ndy > eps_inf)) return false;
+    double lhs = 0;
+    for (int i = 0; i < m; ++i) lhs += u[i] * std::max(dy[i], 0.0) + l[i] * std::min(dy[i], 0.0);
+    if (!(lhs < -eps_inf * ndy)) return false;
+    double na = 0;
+    for (int j = 0; j < n; ++j) {
+      double s = 0;
+      for (int i = 0; i < m; ++i) s += A[(size_t)i * n + j] * dy[i];
+      na = std::max(na, std::fabs(s / D[j]));
+    }
+    return na < eps_inf * ndy;
   };
   for (iter = 1; iter <= qs->max_iter; ++iter) {
     xp = x;
@@ -381,38 +426,18 @@ int osqpDense(const double *Pin, const double *qin, const double *Ain, const dou
         status = 1;
         break;
       }
-      // primal infeasibility certificate (eps_prim_inf = 1e-4)
-      const double eps_inf = 1e-4;
-      double       ndy     = 0;
-      for (int i = 0; i < m; ++i) ndy = std::max(ndy, std::fabs(E[i] * dy[i]));
-      if (!p_ok && ndy > eps_inf) {
-        double lhs = 0;
-        for (int i = 0; i < m; ++i) {
-          const double d = dy[i] / ndy;
-          if (u[i] < OSQP_INFTY * MIN_SCALING) lhs += u[i] * (d > 0 ? d : 0);
-          else if (d > eps_inf) lhs = INFINITY;
-          if (l[i] > -OSQP_INFTY * MIN_SCALING) lhs += l[i] * (d < 0 ? d : 0);
-          else if (d < -eps_inf) lhs = INFINITY;
-        }
-        if (lhs < -eps_inf) {
-          double na = 0;
-          for (int j = 0; j < n; ++j) {
-            double s = 0;
-            for (int i = 0; i < m; ++i) s += A[(size_t)i * n + j] * (dy[i] / ndy);
-            na = std::max(na, std::fabs(s / D[j]));
-          }
-          if (na < eps_inf) {
-            status = -3;
-            break;
-          }
-        }
+      if (!p_ok && primal_infeasible(1e-4)) {  // eps_prim_inf default
+        status = -3;
+        break;
       }
     }
-    // adaptive rho (OSQP adapt_rho / compute_rho_estimate), on unscaled normalised residuals; after the
-    // termination test, on the same residuals (osqp.c: update_info runs once per iteration)
+    // adaptive rho (OSQP adapt_rho / compute_rho_estimate) after the termination test, on the same residual
+    // evaluation (osqp.c: update_info runs once per iteration).  The estimate uses the SCALED residuals and norms:
+    // compute_rho_estimate reads vec_norm_inf(work->z_prev) / (work->x_prev) — the scaled Ax - z and Px + q + A'y that
+    // compute_pri_res / compute_dua_res left there — and the plain norms of z, Ax, q, A'y, Px.
     if (do_adapt) {
-      const double pr_n = last_pr / (std::max(last_nAx, last_nz) + 1e-10);
-      const double du_n = last_dr / (std::max(std::max(last_nPx, last_nAty), last_nq) + 1e-10);
+      const double pr_n = sc_pr / (std::max(sc_nz, sc_nAx) + 1e-10);
+      const double du_n = sc_dr / (std::max(std::max(sc_nq, sc_nAty), sc_nPx) + 1e-10);
       double       rho_new = rho_cur * std::sqrt(pr_n / (du_n + 1e-10));
       rho_new              = std::min(std::max(rho_new, RHO_MIN), 1e6);
       if (rho_new > rho_cur * 5.0 || rho_new < rho_cur / 5.0) {
@@ -433,8 +458,11 @@ int osqpDense(const double *Pin, const double *qin, const double *Ain, const dou
   if (iter > qs->max_iter) {
     iter = qs->max_iter;
     bool p_ok, d_ok;
+    // osqp_solve's epilogue: check_termination(work, approximate = 1) — every tolerance x 10 — then MAX_ITER_REACHED
     residuals(qs->eps_abs * 10, qs->eps_rel * 10, p_ok, d_ok);
-    status = (p_ok && d_ok) ? 2 : -2;
+    if (p_ok && d_ok) status = 2;                                // OSQP_SOLVED_INACCURATE
+    else if (!p_ok && primal_infeasible(1e-4 * 10)) status = 3;  // OSQP_PRIMAL_INFEASIBLE_INACCURATE
+    else status = -2;                                            // OSQP_MAX_ITER_REACHED
   }
   for (int j = 0; j < n; ++j) xout[j] = D[j] * x[j];
   if (yout)

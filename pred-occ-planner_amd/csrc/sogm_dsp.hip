@@ -697,7 +697,7 @@ __global__ __launch_bounds__(1024) void k_dsp_velocity(DspDev d, const int32_t *
     if (R * C > MP) s_err = 5;
     if (R > 0 && C > 0 && R * C <= MP && dt > 0.00001 && dt < 10.0) {
       // cost / gate matrices live in the (now free) coordinate arrays of the dynamic LDS
-      float *cost = sx, *gate = sy;  // R * C <= 64 * 64 floats each (max_pts >= 4096 is checked at create)
+      float *cost = sx, *gate = sy;  // R * C <= max_pts floats each: guarded just above (error 5 otherwise)
       int    rows[VEL_MAX_DYN];
       {
         int k = 0;
@@ -1580,6 +1580,19 @@ int sogm_dsp_create(sogm_ctx *map, const SogmDspParams *P, const float *p_gauss,
       P->obs_max_per_pyramid < 2 || P->half_fov_h * 2 / ar > 180 || P->half_fov_v * 2 / ar > 180)
     return SOGM_ERR_INVALID_ARG;
   SOGM_HIP_CHECK(hipSetDevice(map->device));
+  {
+    // k_dsp_velocity keeps the cloud in LDS: 20 B per point of dynamic LDS on top of its static arrays; the request
+    // must fit the workgroup limit of THIS device (160 KiB on gfx950: max_points <= ~7.4 k), checked here instead of
+    // failing every later sogm_update_dsp(labels = NULL) launch
+    hipFuncAttributes fa;
+    int               lds_max = 0;
+    SOGM_HIP_CHECK(hipFuncGetAttributes(&fa, (const void *)k_dsp_velocity));
+    SOGM_HIP_CHECK(hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, map->device));
+    if ((size_t)max_points * 20 + fa.sharedSizeBytes > (size_t)lds_max) {
+      set_error("sogm_dsp_create: max_points needs more LDS than a workgroup can have (k_dsp_velocity)", hipErrorInvalidValue);
+      return SOGM_ERR_CAPACITY;
+    }
+  }
   sogm_dsp *h = new (std::nothrow) sogm_dsp;
   if (!h) return SOGM_ERR_HIP;
   h->map    = map;
@@ -1718,11 +1731,17 @@ int sogm_dsp_create(sogm_ctx *map, const SogmDspParams *P, const float *p_gauss,
     sogm_dsp_destroy(h);
     return SOGM_ERR_HIP;
   }
-  // the observe / newborn kernels keep per-pyramid counters / the 1/C_k list in dynamic LDS
-  (void)hipFuncSetAttribute((const void *)k_dsp_observe, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)(2 * NP * sizeof(int)));
-  (void)hipFuncSetAttribute((const void *)k_dsp_newborn, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)(MP * sizeof(float)));
+  // the observe / newborn kernels keep per-pyramid counters / the 1/C_k list in dynamic LDS (function attributes
+  // are process-wide: keep the largest request of any handle)
+  static size_t lds_obs = 0, lds_born = 0;
+  if (2 * NP * sizeof(int) > lds_obs) {
+    lds_obs = 2 * NP * sizeof(int);
+    (void)hipFuncSetAttribute((const void *)k_dsp_observe, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_obs);
+  }
+  if (MP * sizeof(float) > lds_born) {
+    lds_born = MP * sizeof(float);
+    (void)hipFuncSetAttribute((const void *)k_dsp_newborn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_born);
+  }
   *out = h;
   return SOGM_OK;
 }
@@ -1743,11 +1762,13 @@ int sogm_update_dsp(sogm_dsp *h, const float *points, const float *labels, const
   hipLaunchKernelGGL(k_dsp_observe, dim3((unsigned)A), dim3(256), 2 * d.NP * sizeof(int), st, d, points, labels,
                      cloud_range);
   if (!labels) {  // velocityEstimationThread (:305): labels and point order of the new-born list are computed here
-    static bool attr = false;
-    const size_t lds = (size_t)d.max_pts * 20;
-    if (!attr) {
-      (void)hipFuncSetAttribute((const void *)k_dsp_velocity, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      attr = true;
+    // the attribute is per function, not per sogm_dsp: raise it whenever a handle asks for more than any before
+    // (size checked against the device limit in sogm_dsp_create)
+    static size_t attr_lds = 0;
+    const size_t  lds      = (size_t)d.max_pts * 20;
+    if (lds > attr_lds) {
+      SOGM_HIP_CHECK(hipFuncSetAttribute((const void *)k_dsp_velocity, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      attr_lds = lds;
     }
     hipLaunchKernelGGL(k_dsp_velocity, dim3((unsigned)A), dim3(1024), lds, st, d, cloud_range, 0.15f);
   }

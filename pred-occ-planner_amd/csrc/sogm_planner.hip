@@ -1,5 +1,7 @@
-// sogm_planner.hip — planner context (search + corridors + QP).  Stage kernels are being brought
-// up one at a time; entry points not yet wired return SOGM_ERR_STATE.
+// sogm_planner.hip — planner context and host side of the planner entry points: the per-stage calls (search,
+// corridors, QP, deconfliction) and sogm_replan in its two forms — the dataflow replan (replan_flow: five launches,
+// persistent corridor / QP / finish kernels chained per agent through ready lists) and the grouped-stream chain
+// (replan_impl).  SOGM_ERR_STATE from an entry point means a call-order error (no map update before planning).
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
@@ -79,6 +81,17 @@ __global__ void k_pack_records(int A, double corridor_tau, const int32_t *ret, c
   for (int i = 0; i < SOGM_MAX_PIECES * 15; ++i)
     r.cpts[i] = (good && i < npoly[a] * 15) ? cpts[(size_t)a * SOGM_MAX_PIECES * 15 + i] : 0.0;
   ok[a] = good ? 1 : 0;
+}
+
+// End of a dataflow replan (one lane, on the caller's stream after the fan-in): a wait of this tick timed out ->
+// remember the code and count the tick in pinned host memory, so the host can see failed ticks without a device
+// synchronisation (sogm_planner_flow_failures).
+__global__ void k_flow_report(const int *__restrict__ hdr, int *__restrict__ host_words) {
+  const int e = hdr[FLOW_ERR];
+  if (e != 0) {
+    host_words[0] = e;
+    host_words[1] = host_words[1] + 1;
+  }
 }
 
 extern "C" {
@@ -191,6 +204,8 @@ int sogm_planner_create(sogm_ctx *map, const SogmAstarParams *astar, const SogmP
       if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_fdone[k], hipEventDisableTiming);
     }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_gate, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&p->h_flow_fail, sizeof(int) * 2, hipHostMallocMapped);
+    if (e == hipSuccess) p->h_flow_fail[0] = p->h_flow_fail[1] = 0;
   }
   if (e != hipSuccess) {
     sogm::set_error("sogm_planner_create", e);
@@ -229,6 +244,7 @@ void sogm_planner_destroy(sogm_planner *p) {
     if (p->ev_fdone[k]) (void)hipEventDestroy(p->ev_fdone[k]);
   }
   if (p->ev_gate) (void)hipEventDestroy(p->ev_gate);
+  if (p->h_flow_fail) (void)hipHostFree(p->h_flow_fail);
   delete p;
 }
 
@@ -378,6 +394,14 @@ int sogm_planner_flow_error(sogm_planner *p) {
   return hdr[FLOW_ERR];
 }
 
+int sogm_planner_flow_failures(sogm_planner *p, int32_t out[2]) {
+  if (!p || !out) return SOGM_ERR_INVALID_ARG;
+  volatile int *h = p->h_flow_fail;
+  out[0]          = h ? h[0] : 0;
+  out[1]          = h ? h[1] : 0;
+  return SOGM_OK;
+}
+
 int sogm_planner_counters(sogm_planner *p, int64_t *out_host, int reset) {
   if (!p || !out_host) return SOGM_ERR_INVALID_ARG;
   SOGM_HIP_CHECK(hipSetDevice(p->map->device));
@@ -415,6 +439,10 @@ static int replan_flow(sogm_planner *p, const double *start_pva, const double *g
   SOGM_HIP_CHECK(hipMemsetAsync(p->fc.a_ready, 0xFF, sizeof(int) * 3 * (size_t)A, main));
   const bool spec = p->spec_astar != 0;
   if (spec) SOGM_HIP_CHECK(hipMemsetAsync(p->aw.verdict, 0, sizeof(int) * (size_t)A, main));
+  // k_finish_flow writes ok / the record of every agent whose chain completes; an agent whose chain does NOT (a wait
+  // timed out, FLOW_ERR) must report ok = 0 and an empty record, not the previous tick's
+  SOGM_HIP_CHECK(hipMemsetAsync(out_ok, 0, sizeof(int32_t) * (size_t)A, main));
+  SOGM_HIP_CHECK(hipMemsetAsync(out_records, 0, sizeof(SogmTrajRecord) * (size_t)A, main));
   SOGM_HIP_CHECK(hipEventRecord(p->ev_in, main));
   if (c->overlap >= 2) {
     int rc = sogm::queue_spare_clears(c, p->ev_in);
@@ -466,6 +494,8 @@ static int replan_flow(sogm_planner *p, const double *start_pva, const double *g
     SOGM_HIP_CHECK(hipEventRecord(p->ev_fdone[k], p->fstream[k]));
     SOGM_HIP_CHECK(hipStreamWaitEvent(main, p->ev_fdone[k], 0));  // fan in
   }
+  hipLaunchKernelGGL(k_flow_report, dim3(1), dim3(1), 0, main, (const int *)p->d_flow, p->h_flow_fail);
+  SOGM_HIP_CHECK(hipGetLastError());
   return SOGM_OK;
 }
 

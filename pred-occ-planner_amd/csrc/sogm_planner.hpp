@@ -152,6 +152,7 @@ struct sogm_planner {
   sogm::FlowCtl  fc;
   hipStream_t    fstream[4];  // A*, corridors, QP, finish
   hipEvent_t     ev_gate, ev_fdone[4];
+  int           *h_flow_fail;  // pinned, device-visible: {last FLOW_ERR code, ticks that failed} (k_flow_report)
   // per-object use of the per-stage entries (sogm_planner_select_agents / _set_search_mode)
   int sel_first, sel_count;  // agents the per-stage entries process; (0, A) by default
   int search_mode;           // 0 the replan's two-call pattern, 1 / 2 one search with init_search true / false

@@ -192,8 +192,8 @@ __device__ __forceinline__ void qp_solve_agent(const SogmPlannerParams &pp, cons
   __shared__ __attribute__((aligned(16))) double s_cn[QP_NMAX];
   __shared__ double s_red[8];
   __shared__ double s_T[2][225];  // factor(): running 15 x 15 block of the X row chains
-  __shared__ double s_red6[48];
-  __shared__ double s_sc[8];
+  __shared__ double s_red12[96];
+  __shared__ double s_sc[16];
   __shared__ int    s_off[SOGM_MAX_PIECES + 1];  // safety-row offset of each piece
   __shared__ int    s_nf[SOGM_MAX_PIECES];
   __shared__ int    s_cnt[QP_NMAX + 1];
@@ -729,23 +729,29 @@ __device__ __forceinline__ void qp_solve_agent(const SogmPlannerParams &pp, cons
     }
     return a;
   };
-  // residual norms (unscaled), results in s_sc: 0 pr, 1 nAx, 2 nz, 3 dr, 4 nPx, 5 nAty, 6 nq(=0)
+  // residual norms, results in s_sc: 0 pr, 1 nAx, 2 nz, 3 dr, 4 nPx, 5 nAty, 6 nq(=0) UNSCALED (the termination
+  // tests); 8..13 the same six SCALED (no E / D / c: what OSQP's compute_rho_estimate reads), 14 scaled nq(=0)
   auto residuals = [&]() {
     // lane ids re-derived from an opaque copy: nothing in here is hoisted out of the ADMM loop
     const int tid = launder((int)threadIdx.x), lane = tid & 63, wave = tid >> 6;
     (void)lane;
     (void)wave;
-    double pr = 0, nAx = 0, nz = 0;
+    double m[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) m[k] = 0.0;
     for (int r = tid; r < G; r += QP_NT) {
       double s = 0;
       for (int k = 0; k < QP_ELL; ++k) {
         const int c = R.gcol[(size_t)r * QP_ELL + k];
         if (c >= 0) s += R.gval[(size_t)r * QP_ELL + k] * s_x[c];
       }
-      const double e = R.gE[r];
-      pr             = dmax(pr, dabs((s - R.gz[r]) / e));
-      nAx            = dmax(nAx, dabs(s / e));
-      nz             = dmax(nz, dabs(R.gz[r] / e));
+      const double e = R.gE[r], z = R.gz[r];
+      m[0]           = dmax(m[0], dabs((s - z) / e));
+      m[1]           = dmax(m[1], dabs(s / e));
+      m[2]           = dmax(m[2], dabs(z / e));
+      m[6]           = dmax(m[6], dabs(s - z));
+      m[7]           = dmax(m[7], dabs(s));
+      m[8]           = dmax(m[8], dabs(z));
     }
     for (int s = tid; s < S; s += QP_NT) {
       const int     c0 = R.sc0[s];
@@ -754,12 +760,14 @@ __device__ __forceinline__ void qp_solve_agent(const SogmPlannerParams &pp, cons
       ax += v[0] * s_x[c0];
       ax += v[1] * s_x[c0 + 1];
       ax += v[2] * s_x[c0 + 2];
-      const double e = R.sE[s];
-      pr             = dmax(pr, dabs((ax - R.sz[s]) / e));
-      nAx            = dmax(nAx, dabs(ax / e));
-      nz             = dmax(nz, dabs(R.sz[s] / e));
+      const double e = R.sE[s], z = R.sz[s];
+      m[0]           = dmax(m[0], dabs((ax - z) / e));
+      m[1]           = dmax(m[1], dabs(ax / e));
+      m[2]           = dmax(m[2], dabs(z / e));
+      m[6]           = dmax(m[6], dabs(ax - z));
+      m[7]           = dmax(m[7], dabs(ax));
+      m[8]           = dmax(m[8], dabs(z));
     }
-    double dr = 0, nPx = 0, nAty = 0;
     for (int j = tid; j < n; j += QP_NT) {
       double        s  = 0;
       const double *Pb = s_P + (j / 15) * 225 + (j % 15) * 15;
@@ -767,34 +775,29 @@ __device__ __forceinline__ void qp_solve_agent(const SogmPlannerParams &pp, cons
       for (int k = 0; k < 15; ++k) s += Pb[k] * s_x[b0 + k];
       const double a  = col_sum_y(j);
       const double dj = s_D[j];
-      dr              = dmax(dr, dabs((s + a) / dj));
-      nPx             = dmax(nPx, dabs(s / dj));
-      nAty            = dmax(nAty, dabs(a / dj));
+      m[3]            = dmax(m[3], dabs((s + a) / dj));
+      m[4]            = dmax(m[4], dabs(s / dj));
+      m[5]            = dmax(m[5], dabs(a / dj));
+      m[9]            = dmax(m[9], dabs(s + a));
+      m[10]           = dmax(m[10], dabs(s));
+      m[11]           = dmax(m[11], dabs(a));
     }
-    // the six maxima share one wave-reduce / LDS / barrier round
-    pr   = wave_max(pr);
-    nAx  = wave_max(nAx);
-    nz   = wave_max(nz);
-    dr   = wave_max(dr);
-    nPx  = wave_max(nPx);
-    nAty = wave_max(nAty);
+    // the twelve maxima share one wave-reduce / LDS / barrier round
+#pragma unroll
+    for (int k = 0; k < 12; ++k) m[k] = wave_max(m[k]);
     __syncthreads();
     if (lane == 0) {
-      double *o = s_red6 + wave * 6;
-      o[0]      = pr;
-      o[1]      = nAx;
-      o[2]      = nz;
-      o[3]      = dr;
-      o[4]      = nPx;
-      o[5]      = nAty;
+      double *o = s_red12 + wave * 12;
+#pragma unroll
+      for (int k = 0; k < 12; ++k) o[k] = m[k];
     }
     __syncthreads();
-    if (tid < 6) {
-      double m = s_red6[tid];
-      for (int w = 1; w < QP_NT / 64; ++w) m = dmax(m, s_red6[6 * w + tid]);
-      s_sc[tid]      = tid == 3 ? m * cinv : m;
+    if (tid < 12) {
+      double v = s_red12[tid];
+      for (int w = 1; w < QP_NT / 64; ++w) v = dmax(v, s_red12[12 * w + tid]);
+      s_sc[tid < 6 ? tid : tid + 2] = tid == 3 ? v * cinv : v;
     }
-    if (tid == 6) s_sc[6] = 0.0;
+    if (tid == 12) s_sc[6] = s_sc[14] = 0.0;
     __syncthreads();
   };
 
@@ -923,6 +926,55 @@ __device__ __forceinline__ void qp_solve_agent(const SogmPlannerParams &pp, cons
     __syncthreads();
   };
 
+  // Primal infeasibility certificate (OSQP auxil.c is_primal_infeasible; called when the primal residual test
+  // failed): delta_y is first projected onto the polar of the recession cone of [l, u] — general rows have two
+  // finite bounds (untouched), every safety row has l = -OSQP_INFTY, so only its positive part counts (the stored
+  // delta_y is overwritten like OSQP's work vector; the next iteration recomputes it) — then, relative to the
+  // unscaled ||dy||inf:  u'(dy)+ + l'(dy)- < -eps ||dy||  and  ||Dinv A'dy||inf < eps ||dy||.  Workgroup-uniform.
+  auto primal_infeasible = [&](double eps_inf) -> bool {
+    const int tid = launder((int)threadIdx.x), lane = tid & 63, wave = tid >> 6;
+    double    ndy = 0;
+    for (int r = tid; r < G; r += QP_NT) ndy = dmax(ndy, dabs(R.gE[r] * R.gdy[r]));
+    for (int s = tid; s < S; s += QP_NT) {
+      const double d = R.sdy[s] > 0.0 ? R.sdy[s] : 0.0;
+      R.sdy[s]       = d;
+      ndy            = dmax(ndy, dabs(R.sE[s] * d));
+    }
+    ndy = block_max(ndy, s_red);
+    __syncthreads();
+    if (!(ndy > eps_inf)) return false;
+    double lhs = 0;
+    for (int r = tid; r < G; r += QP_NT) {
+      const double d = R.gdy[r];
+      lhs += R.gu[r] * (d > 0 ? d : 0) + R.gl[r] * (d < 0 ? d : 0);
+    }
+    for (int s = tid; s < S; s += QP_NT) lhs += R.su[s] * R.sdy[s];  // projected: dy >= 0
+    lhs = wave_sum(lhs);
+    __syncthreads();
+    if (lane == 0) s_red[wave] = lhs;
+    __syncthreads();
+    lhs = ((s_red[0] + s_red[1]) + (s_red[2] + s_red[3])) + ((s_red[4] + s_red[5]) + (s_red[6] + s_red[7]));
+    __syncthreads();
+    if (!(lhs < -eps_inf * ndy)) return false;
+    double na = 0;
+    for (int j = tid; j < n; j += QP_NT) {
+      double a = 0;
+      for (int q = s_cptr[j]; q < s_cptr[j + 1]; ++q) {
+        const int en = R.cidx[q], r = en >> 3;
+        a += R.gval[(size_t)r * QP_ELL + (en & 7)] * R.gdy[r];
+      }
+      COL_DECODE(j)
+      for (int f = 0; f < nface; ++f) {
+        const int sr = sbase + 5 * f;
+        a += R.sval[(size_t)sr * 3 + pd] * R.sdy[sr];
+      }
+      na = dmax(na, dabs(a / s_D[j]));
+    }
+    na = block_max(na, s_red);
+    __syncthreads();
+    return na < eps_inf * ndy;
+  };
+
   set_rho();
   bool chol_ok = factor();
   int  status = -2, iter = 0;
@@ -1029,7 +1081,7 @@ __device__ __forceinline__ void qp_solve_agent(const SogmPlannerParams &pp, cons
             g_y             = g_y + d;
             if (grow) {
               h_gw[t] = __builtin_fma(g_rho, v, -g_y);
-              if (do_check) R.gdy[t] = d;
+              if (do_check || iter == qs.max_iter) R.gdy[t] = d;
             }
           } else {  // waves 4-7: up to four safety rows per lane
             double xs[4][3];
@@ -1059,7 +1111,7 @@ __device__ __forceinline__ void qp_solve_agent(const SogmPlannerParams &pp, cons
               const int sr    = (t - 256) + 256 * u;
               if (sr < S) {
                 h_sw[sr] = __builtin_fma(rho_cur, v, -yn);
-                if (do_check) R.sdy[sr] = d;
+                if (do_check || iter == qs.max_iter) R.sdy[sr] = d;
               }
             }
           }
@@ -1118,68 +1170,17 @@ __device__ __forceinline__ void qp_solve_agent(const SogmPlannerParams &pp, cons
           status = 1;
           break;
         }
-        // primal infeasibility certificate (eps_prim_inf = 1e-4), as in the oracle
         if (ablate & 16) continue;  // profiling aid (ablation build only)
-        const double eps_inf = 1e-4;
-        double       ndy     = 0;
-        for (int r = tid; r < G; r += QP_NT) ndy = dmax(ndy, dabs(R.gE[r] * R.gdy[r]));
-        for (int s = tid; s < S; s += QP_NT) ndy = dmax(ndy, dabs(R.sE[s] * R.sdy[s]));
-        ndy = block_max(ndy, s_red);
-        __syncthreads();
-        if (!p_ok && ndy > eps_inf) {
-          double lhs = 0;
-          int    bad = 0;
-          for (int r = tid; r < G; r += QP_NT) {
-            const double d = R.gdy[r] / ndy;
-            if (R.gu[r] < OSQP_INFTY * MIN_SCALING)
-              lhs += R.gu[r] * (d > 0 ? d : 0);
-            else if (d > eps_inf)
-              bad = 1;
-            if (R.gl[r] > -OSQP_INFTY * MIN_SCALING)
-              lhs += R.gl[r] * (d < 0 ? d : 0);
-            else if (d < -eps_inf)
-              bad = 1;
-          }
-          for (int s = tid; s < S; s += QP_NT) {
-            const double d = R.sdy[s] / ndy;
-            lhs += R.su[s] * (d > 0 ? d : 0);
-            if (d < -eps_inf) bad = 1;  // l = -inf pushed
-          }
-          lhs = wave_sum(lhs);
-          __syncthreads();
-          if (lane == 0) s_red[wave] = lhs;
-          const int anybad = __syncthreads_or(bad);
-          lhs              = ((s_red[0] + s_red[1]) + (s_red[2] + s_red[3])) + ((s_red[4] + s_red[5]) + (s_red[6] + s_red[7]));
-          __syncthreads();
-          if (!anybad && lhs < -eps_inf) {
-            double na = 0;
-            for (int j = tid; j < n; j += QP_NT) {
-              double a = 0;
-              for (int q = s_cptr[j]; q < s_cptr[j + 1]; ++q) {
-                const int en = R.cidx[q], r = en >> 3;
-                a += R.gval[(size_t)r * QP_ELL + (en & 7)] * (R.gdy[r] / ndy);
-              }
-              COL_DECODE(j)
-              for (int f = 0; f < nface; ++f) {
-                const int sr = sbase + 5 * f;
-                a += R.sval[(size_t)sr * 3 + pd] * (R.sdy[sr] / ndy);
-              }
-              na = dmax(na, dabs(a / s_D[j]));
-            }
-            na = block_max(na, s_red);
-            __syncthreads();
-            if (na < eps_inf) {
-              status = -3;
-              break;
-            }
-          }
+        if (!p_ok && primal_infeasible(1e-4)) {  // eps_prim_inf default
+          status = -3;
+          break;
         }
       }
-      // adaptive rho after the termination test, on the same residuals (osqp.c: update_info runs once)
+      // adaptive rho after the termination test, on the same residual evaluation (osqp.c: update_info runs once);
+      // the estimate reads the SCALED residuals and norms (auxil.c compute_rho_estimate, see the oracle)
       if (do_adapt) {
-        const double pr_n = s_sc[0] / (dmax(s_sc[1], s_sc[2]) + 1e-10);
-        const double du_n =
-            s_sc[3] / (dmax(dmax(cinv * s_sc[4], cinv * s_sc[5]), cinv * s_sc[6]) + 1e-10);
+        const double pr_n = s_sc[8] / (dmax(s_sc[10], s_sc[9]) + 1e-10);
+        const double du_n = s_sc[11] / (dmax(dmax(s_sc[14], s_sc[13]), s_sc[12]) + 1e-10);
         double rho_new = rho_cur * sogm_det::sqrt_rn(pr_n / (du_n + 1e-10));
         rho_new        = rho_new < RHO_MIN ? RHO_MIN : (rho_new > 1e6 ? 1e6 : rho_new);
         if (rho_new > rho_cur * 5.0 || rho_new < rho_cur / 5.0) {
@@ -1205,7 +1206,14 @@ __device__ __forceinline__ void qp_solve_agent(const SogmPlannerParams &pp, cons
       const double eps_prim = qs.eps_abs * 10 + qs.eps_rel * 10 * dmax(s_sc[1], s_sc[2]);
       const double eps_dual =
           qs.eps_abs * 10 + qs.eps_rel * 10 * cinv * dmax(dmax(s_sc[4], s_sc[5]), s_sc[6]);
-      status = (s_sc[0] < eps_prim && s_sc[3] < eps_dual) ? 2 : -2;
+      // osqp_solve's epilogue: check_termination(approximate = 1), every tolerance x 10, else MAX_ITER_REACHED
+      const bool p_ok = s_sc[0] < eps_prim;
+      if (p_ok && s_sc[3] < eps_dual)
+        status = 2;  // OSQP_SOLVED_INACCURATE
+      else if (!p_ok && primal_infeasible(1e-4 * 10))
+        status = 3;  // OSQP_PRIMAL_INFEASIBLE_INACCURATE
+      else
+        status = -2;
     }
   }
   __syncthreads();

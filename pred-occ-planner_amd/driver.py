@@ -49,54 +49,61 @@ class RecordExchange:
     """The same all-gather behind the C ABI (sogm_traj_allgather: ncclAllGather on the context's exchange
     stream, consumers wait for it inside the library) — what a C++ host linking libsogm_hip.so uses.  Taken when
     torch.distributed runs on RCCL (backend "nccl"); the communicator is created through sogm_comm_* with the
-    128-byte id shipped through torch.distributed's key-value store.  Anything else (gloo on CPU tests, no
-    process group, RCCL unavailable) uses exchange_records() above."""
-    _serial = 0
+    128-byte id broadcast from rank 0 (dist.broadcast_object_list, like ncclGetUniqueId + MPI_Bcast in an MPI host).
+    Anything else (gloo on CPU tests, no process group) uses exchange_records() above; if the communicator cannot be
+    created the fallback is torch.distributed's own all-gather and `self.fallback_reason` says why (bench.py prints
+    it: never silent).  `lib` / `backends` / `stream` are injection points for the CPU test, which runs this class
+    against a stub library at world size 2 (tests/test_driver_gloo.py)."""
 
-    def __init__(self, sogm_map, dist, rank, world, device):
+    def __init__(self, ctx, dist, rank, world, device, lib=None, backends=("nccl",), stream=None):
         import ctypes as C
         import sys
-        self.map, self.comm, self.handle = sogm_map, C.c_void_p(), None
-        use = (dist is not None and dist.is_initialized() and dist.get_backend() == "nccl"
-               and os.environ.get("SOGM_EXCHANGE", "abi") == "abi")
-        if not use:
+        self.ctx, self.comm, self.handle, self.fallback_reason = ctx, C.c_void_p(), None, None
+        self._stream = stream if stream is not None else _stream
+        self.lib = None
+        if not (dist is not None and dist.is_initialized() and dist.get_backend() in backends):
             return
-        lib = _abi.lib()
-        key = f"sogm_comm_id/{RecordExchange._serial}"
-        RecordExchange._serial += 1
-        try:
-            store = dist.distributed_c10d._get_default_store()
-            if rank == 0:
-                buf = C.create_string_buffer(_abi.SOGM_COMM_ID_BYTES)
-                _abi.check(lib.sogm_comm_unique_id(buf), "sogm_comm_unique_id")
-                store.set(key, buf.raw)
-                ident = buf.raw
-            else:
-                ident = bytes(store.get(key))
-            _abi.check(lib.sogm_comm_create(ident, rank, world, device, C.byref(self.comm)), "sogm_comm_create")
-            self.handle = lib.sogm_comm_handle(self.comm)
-        except Exception as e:  # noqa: BLE001 — any failure here only changes which RCCL entry point is used
-            print(f"[sogm] RCCL communicator through the C ABI unavailable ({e}); using torch.distributed's", file=sys.stderr)
-            self.comm, self.handle = C.c_void_p(), None
+        if os.environ.get("SOGM_EXCHANGE", "abi") != "abi":
+            self.fallback_reason = "SOGM_EXCHANGE != abi"
+            return
+        self.lib = lib if lib is not None else _abi.lib()
+        ident = [None]
+        if rank == 0:
+            buf = C.create_string_buffer(_abi.SOGM_COMM_ID_BYTES)
+            rc = self.lib.sogm_comm_unique_id(buf)
+            ident = [buf.raw if rc == 0 else rc]
+        dist.broadcast_object_list(ident, src=0)   # every rank takes part, whatever rank 0 got
+        rc = ident[0] if isinstance(ident[0], int) else self.lib.sogm_comm_create(
+            ident[0], rank, world, device, C.byref(self.comm))
+        # all ranks must agree on the path: one failed communicator sends everybody to the fallback
+        flags = [None] * world
+        dist.all_gather_object(flags, int(rc))
+        if any(f != 0 for f in flags):
+            if rc == 0:
+                self.lib.sogm_comm_destroy(self.comm)
+            self.comm, self.fallback_reason = C.c_void_p(), f"sogm_comm_create returned {flags} (per rank)"
+            print(f"[sogm] rank {rank}: RCCL communicator through the C ABI unavailable: {self.fallback_reason}; "
+                  "using torch.distributed's all-gather", file=sys.stderr)
+            return
+        self.handle = self.lib.sogm_comm_handle(self.comm)
 
     @property
     def active(self):
         return self.handle is not None
 
     def all_gather(self, own, all_records):
-        from .sogm import _stream
-        _abi.check(_abi.lib().sogm_traj_allgather(self.map.ctx, self.handle, own.data_ptr(), own.shape[0],
-                                                  all_records.data_ptr(), _stream()), "sogm_traj_allgather")
+        _abi.check(self.lib.sogm_traj_allgather(self.ctx, self.handle, own.data_ptr(), own.shape[0],
+                                                all_records.data_ptr(), self._stream()), "sogm_traj_allgather")
 
     def wait(self):
         """Make torch's current stream wait for an all-gather in flight (before torch ops read the records)."""
-        from .sogm import _stream
-        _abi.check(_abi.lib().sogm_exchange_wait(self.map.ctx, _stream()), "sogm_exchange_wait")
+        _abi.check(self.lib.sogm_exchange_wait(self.ctx, self._stream()), "sogm_exchange_wait")
 
     def close(self):
         if self.comm:
-            torch.cuda.synchronize()
-            _abi.lib().sogm_comm_destroy(self.comm)
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
+            self.lib.sogm_comm_destroy(self.comm)
             self.comm = None
             self.handle = None
 
@@ -170,10 +177,79 @@ def fsm_apply(status, fail, traj_start, success, now, due_new, is_rep, ok, safe,
     return st, fail, traj_start, success, pub_new, pub_hover, hover_start
 
 
+class HipCompute:
+    """The rank's kernels behind the C ABI: the four calls one tick of SwarmTick.step() makes.  The product path.
+    (tests/test_driver_gloo.py runs the same SwarmTick.step() over gloo on CPU with the oracle standing in for this
+    class — the rank-local bookkeeping around these calls is what that test covers.)"""
+    device = "cuda"
+
+    def __init__(self, spec, scene, lo, hi, device, overlap_clear=True, double_buffer=None, grids=None):
+        half = (spec.L // 2) * 0.15
+        A_loc = hi - lo
+        loc = dict(scene)
+        loc["n_agents"] = A_loc
+        for k in ("starts", "goals", "poses", "stamps", "ego_ids"):
+            loc[k] = scene[k][lo:hi]
+        torch.cuda.set_device(device)
+        # each agent scans only the cloud around it (its sensing neighbourhood): map half range +
+        # the distance it can fly during a run, so per-agent work does not grow with the swarm
+        crop, crange = scene_mod.crop_clouds(scene, lo, hi, half + 10.0)
+        self.dev = upload_scene(loc, cloud=crop, cloud_range=crange)
+        self.cloud_points = int(crop.shape[0])
+        self.A_loc = A_loc
+        self.map = SogmMap(spec, A_loc, device)
+        self.overlap_mode = self.map.set_overlap_clear(overlap_clear, double_buffer=double_buffer, grids=grids)
+        self.planner = SogmPlanner(self.map, config.make_astar_params(), config.make_planner_params(True),
+                                   config.make_qp_settings())
+        self.ego_ids = self.dev["ego_ids"]
+        self.fused_update = os.environ.get("SOGM_FUSED_UPDATE", "1") != "0"
+
+    @property
+    def ctx(self):
+        return self.map.ctx
+
+    def set_swarm(self, all_records, A_tot, now):
+        self.planner.setSwarm(all_records, A_tot, self.ego_ids, now)
+
+    def tick_inputs(self, own, stamp, hover, now, t_start, pva, poses):
+        """start states from the executed trajectories, stamps and map centres: one launch (sogm_tick_inputs)"""
+        _abi.check(_abi.lib().sogm_tick_inputs(own.data_ptr(), self.A_loc, stamp, REPLAN_START_TIME, hover.data_ptr(),
+                                               now.data_ptr(), t_start.data_ptr(), pva.data_ptr(), poses.data_ptr(),
+                                               _stream()), "sogm_tick_inputs")
+
+    def update_map(self, poses, now, all_records, A_tot):
+        """updateMap incl. its closing neighbour overlay in one call"""
+        d = self.dev
+        if self.fused_update:
+            self.map.updateMapSwarm(d["cloud"], d["cloud_range"], d["cylinders"], d["n_cyl"], poses, now,
+                                    all_records, A_tot, self.ego_ids)
+        else:  # the two separate calls (SOGM_FUSED_UPDATE=0: A/B aid)
+            self.map.updateMap(d["cloud"], d["cloud_range"], d["cylinders"], d["n_cyl"], poses, now)
+            self.map.addOtherAgents(all_records, A_tot, self.ego_ids)
+
+    def replan(self, pva, goals, t_start, new, ok):
+        # a dataflow replan whose device-side waits timed out reports ok = 0 for the agents it could not finish and
+        # counts the tick in pinned memory: a flight must not go on merging records past such a tick
+        code, n = self.planner.flow_failures()
+        if n:
+            raise RuntimeError(f"sogm_replan: {n} tick(s) failed on the device (flow error code {code})")
+        self.planner.replan(pva, goals, t_start, self.ego_ids, new, ok)
+
+    def merge_latest(self, new, ok, own, all_records):
+        """latest-wins in one launch; `all_records` (single process only) refreshes the swarm table as well"""
+        _abi.check(_abi.lib().sogm_merge_latest(new.data_ptr(), ok.data_ptr(), own.data_ptr(),
+                                                all_records.data_ptr() if all_records is not None else None,
+                                                self.A_loc, _stream()), "sogm_merge_latest")
+
+    def close(self):
+        self.planner.close()
+        self.map.close()
+
+
 class SwarmTick:
     def __init__(self, grid="cfg2", agents_per_rank=None, rank=0, world=1, device=0, seed=0x5069,
                  spec=None, scene=None, dist=None, overlap_clear=True, deconflict=True, fsm=False,
-                 double_buffer=None, grids=None):
+                 double_buffer=None, grids=None, compute=None, exchange=None):
         self.rank, self.world, self.dist = rank, world, dist
         self.spec = spec if spec is not None else config.make_spec(grid)
         self.A_loc = agents_per_rank if agents_per_rank is not None else config.AGENTS.get(grid, 4)
@@ -181,23 +257,15 @@ class SwarmTick:
         half = (self.spec.L // 2) * 0.15
         self.scene = scene if scene is not None else scene_mod.make_scene(self.A_tot, half, seed=seed)
         lo, hi = shard_bounds(rank, world, self.A_loc)
-        loc = dict(self.scene)
-        loc["n_agents"] = self.A_loc
-        for k in ("starts", "goals", "poses", "stamps", "ego_ids"):
-            loc[k] = self.scene[k][lo:hi]
-        torch.cuda.set_device(device)
-        # each agent scans only the cloud around it (its sensing neighbourhood): map half range +
-        # the distance it can fly during a run, so per-agent work does not grow with the swarm
-        crop, crange = scene_mod.crop_clouds(self.scene, lo, hi, half + 10.0)
-        self.dev = upload_scene(loc, cloud=crop, cloud_range=crange)
-        self.cloud_points = int(crop.shape[0])
-        self.map = SogmMap(self.spec, self.A_loc, device)
-        self.overlap_mode = self.map.set_overlap_clear(overlap_clear, double_buffer=double_buffer, grids=grids)
-        self.planner = SogmPlanner(self.map, config.make_astar_params(), config.make_planner_params(True),
-                                   config.make_qp_settings())
-        d = "cuda"
-        self.goals = _dev(loc["goals"], np.float64)
-        self.hover = _dev(np.concatenate([loc["starts"], np.zeros((self.A_loc, 6))], axis=1), np.float64)
+        self.compute = compute if compute is not None else HipCompute(
+            self.spec, self.scene, lo, hi, device, overlap_clear, double_buffer, grids)
+        c = self.compute
+        # the HIP objects, for the bench / tools / tests that use the staged entry points beside step()
+        self.map, self.planner, self.dev = getattr(c, "map", None), getattr(c, "planner", None), getattr(c, "dev", None)
+        self.overlap_mode, self.cloud_points = getattr(c, "overlap_mode", 0), getattr(c, "cloud_points", 0)
+        d = c.device
+        self.goals = _dev(self.scene["goals"][lo:hi], np.float64, d)
+        self.hover = _dev(np.concatenate([self.scene["starts"][lo:hi], np.zeros((self.A_loc, 6))], axis=1), np.float64, d)
         self.pva = torch.zeros((self.A_loc, 9), dtype=torch.float64, device=d)      # replan start states of the tick
         self.poses = torch.zeros((self.A_loc, 3), dtype=torch.float32, device=d)    # map centres of the tick
         self.t_start = torch.zeros((self.A_loc,), dtype=torch.float64, device=d)
@@ -209,8 +277,7 @@ class SwarmTick:
         # (baseline_fake.cpp:453-460); "now" of the check = the tick's stamp
         self.now = torch.zeros((self.A_loc,), dtype=torch.float64, device=d)
         if deconflict:
-            self.planner.setSwarm(self.all, self.A_tot, self.dev["ego_ids"], self.now)
-        self.fused_update = os.environ.get("SOGM_FUSED_UPDATE", "1") != "0"
+            c.set_swarm(self.all, self.A_tot, self.now)
         # optional closed-loop mode: every agent runs the reference's FiniteStateMachine (step_fsm)
         self.fsm = fsm
         self.status = torch.full((self.A_loc,), FSM_NEW_PLAN, dtype=torch.int32, device=d)
@@ -220,12 +287,13 @@ class SwarmTick:
         self.t0 = float(self.scene["stamps"][0])
         self.tick = 0
         self.n_ok_total = 0
-        self.exchange = RecordExchange(self.map, dist, rank, world, device)
+        # several ranks (or a process group of one): the swarm table is refreshed by the all-gather, not locally
+        self.distributed = dist is not None and (world > 1 or dist.is_initialized())
+        self.exchange = exchange if exchange is not None else RecordExchange(c.ctx, dist, rank, world, device)
 
     def close(self):
         self.exchange.close()
-        self.planner.close()
-        self.map.close()
+        self.compute.close()
 
     def _exchange(self):
         """The tick's trajectory broadcast: one RCCL all-gather (behind the C ABI when available)."""
@@ -234,6 +302,16 @@ class SwarmTick:
             self.exchange.all_gather(self.own, self.all)
         else:
             exchange_records(self.own, self.all, self.dist, self.world)
+
+    def _publish(self):
+        """End of a tick: latest-wins merge of the new records into the rank's own table (a failed replan keeps
+        executing the previous trajectory, plan_manager.cpp:176-196), then the broadcast (plan_manager.cpp:364-399
+        -> particles.cpp:131-191): a single process refreshes the swarm table in the same launch, several ranks
+        all-gather it — the records every rank overlays on its NEXT tick are one tick stale, like the ROS topic."""
+        local = not self.exchange.active and not self.distributed
+        self.compute.merge_latest(self.new, self.ok, self.own, self.all if local else None)
+        if not local:
+            self._exchange()
 
     def records_all(self):
         """The swarm's latest records for torch-side readers (waits for an all-gather in flight)."""
@@ -274,27 +352,10 @@ class SwarmTick:
         if self.fsm:
             return self.step_fsm()
         stamp = self.t0 + self.tick * TICK_PERIOD
-        # start states from the executed trajectories, stamps and map centres: one launch (sogm_tick_inputs)
-        _abi.check(_abi.lib().sogm_tick_inputs(self.own.data_ptr(), self.A_loc, stamp, REPLAN_START_TIME,
-                                               self.hover.data_ptr(), self.now.data_ptr(), self.t_start.data_ptr(),
-                                               self.pva.data_ptr(), self.poses.data_ptr(), _stream()),
-                   "sogm_tick_inputs")
-        # updateMap incl. its closing neighbour overlay in one call
-        if self.fused_update:
-            self.map.updateMapSwarm(self.dev["cloud"], self.dev["cloud_range"], self.dev["cylinders"],
-                                    self.dev["n_cyl"], self.poses, self.now, self.all, self.A_tot, self.dev["ego_ids"])
-        else:  # the two separate calls (SOGM_FUSED_UPDATE=0: A/B aid)
-            self.map.updateMap(self.dev["cloud"], self.dev["cloud_range"], self.dev["cylinders"], self.dev["n_cyl"],
-                               self.poses, self.now)
-            self.map.addOtherAgents(self.all, self.A_tot, self.dev["ego_ids"])
-        self.planner.replan(self.pva, self.goals, self.t_start, self.dev["ego_ids"], self.new, self.ok)
-        # latest-wins; a failed replan keeps executing the previous trajectory (sogm_merge_latest); a single
-        # process refreshes the swarm table in the same launch, several ranks all-gather it
-        local = not self.exchange.active and not (self.dist is not None and (self.world > 1 or self.dist.is_initialized()))
-        _abi.check(_abi.lib().sogm_merge_latest(self.new.data_ptr(), self.ok.data_ptr(), self.own.data_ptr(),
-                                                self.all.data_ptr() if local else None, self.A_loc, _stream()),
-                   "sogm_merge_latest")
-        if not local:
-            self._exchange()
+        c = self.compute
+        c.tick_inputs(self.own, stamp, self.hover, self.now, self.t_start, self.pva, self.poses)
+        c.update_map(self.poses, self.now, self.all, self.A_tot)
+        c.replan(self.pva, self.goals, self.t_start, self.new, self.ok)
+        self._publish()
         self.tick += 1
         return self.ok.clone()  # self.ok is rewritten by the next tick

@@ -80,6 +80,13 @@ class SogmPlanner:
         """0 if the last replan()'s dataflow kernels completed normally (synchronises the device)."""
         return int(lib().sogm_planner_flow_error(self._p))
 
+    def flow_failures(self):
+        """(code of the most recent failed tick, number of failed replan() calls) as of the ticks completed on the
+        device — no synchronisation (sogm_planner_flow_failures)."""
+        out = (C.c_int32 * 2)()
+        check(lib().sogm_planner_flow_failures(self._p, out), "sogm_planner_flow_failures")
+        return int(out[0]), int(out[1])
+
     def counters(self, reset=False):
         """Cumulative outcome / capacity counters of replan() (sogm_planner_counters) as a dict."""
         out = (C.c_int64 * len(_abi.COUNTER_NAMES))()

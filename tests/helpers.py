@@ -63,3 +63,92 @@ def approaching_cylinder_scene(pop, gx, cy, vy):
     sc["cloud"] = np.ascontiguousarray(
         np.stack([np.repeat(sx, zs.size), np.repeat(sy, zs.size), np.tile(zs, sx.size)], axis=1), np.float32)
     return sc
+
+
+class OracleCompute:
+    """The CPU oracle standing in for driver.HipCompute (the four kernels calls of a tick), so that the rank-local
+    bookkeeping of driver.SwarmTick.step() — tick inputs, map update from the EXCHANGED records, replan, latest-wins
+    merge, the all-gather — runs on CPU over gloo (tests/test_driver_gloo.py).  Test infrastructure only."""
+    device = "cpu"
+    ctx = None
+
+    def __init__(self, pop, orc, spec, scene, lo, hi):
+        self.pop, self.orc, self.spec, self.scene, self.lo, self.hi = pop, orc, spec, scene, lo, hi
+        self.abi = pop._abi
+        self.ap, self.pp, self.qs = (pop.config.make_astar_params(), pop.config.make_planner_params(True),
+                                     pop.config.make_qp_settings())
+        self.cyl = pop.scene.cylinders_to_struct(scene["cylinders"])
+        self.body = pop.scene.body_particles()
+        self.grids, self.swarm = [None] * (hi - lo), None
+        self.overlay_sums = []   # (tick stamp, agent, sum of the SOGM, hash of the occupied cells) per agent-update
+
+    def set_swarm(self, all_records, A_tot, now):
+        self.swarm = (all_records, A_tot)
+
+    def _records(self, t):
+        n = t.shape[0]
+        return (self.abi.SogmTrajRecord * n).from_buffer_copy(t.numpy().tobytes())
+
+    def tick_inputs(self, own, stamp, hover, now, t_start, pva, poses):
+        """k_tick_inputs (csrc/sogm_map.hip) restated: start state = the executed trajectory at stamp + 0.02, or
+        the hover state; hover <- position with zero velocity / acceleration."""
+        import importlib
+        drv = importlib.import_module("pred-occ-planner_amd.driver")
+        recs = self._records(own)
+        ts = stamp + drv.REPLAN_START_TIME
+        for i in range(own.shape[0]):
+            r = recs[i]
+            if r.n_pieces > 0:
+                d = np.array(r.duration[:r.n_pieces])
+                c = np.array(r.cpts[:15 * r.n_pieces]).reshape(-1, 3)
+                tt = min(max(ts - r.time_start, 0.0), d.sum())
+                o = np.concatenate([self.orc.bezier_eval(d, c, tt, k) for k in range(3)])
+            else:
+                o = hover[i].numpy().copy()
+            pva[i] = torch_from(o)
+            hover[i, :3] = torch_from(o[:3])
+            hover[i, 3:] = 0.0
+            poses[i] = torch_from(o[:3].astype(np.float32))
+        now.fill_(stamp)
+        t_start.fill_(ts)
+
+    def update_map(self, poses, now, all_records, A_tot):
+        recs = self._records(all_records)
+        for i in range(self.hi - self.lo):
+            pose = poses[i].numpy()
+            g = self.orc.update_gt(self.spec, self.scene["cloud"], self.cyl, len(self.scene["cylinders"]), pose)
+            self.orc.project_neighbours(self.spec, g, recs, A_tot, self.lo + i, self.body, pose, float(now[i]))
+            self.grids[i] = g
+            self.overlay_sums.append((round(float(now[i]), 6), self.lo + i, float(g.sum()),
+                                      int(np.flatnonzero(g.ravel()).sum() % 1000003)))
+
+    def replan(self, pva, goals, t_start, new, ok):
+        import torch
+        allr = self._records(self.swarm[0]) if self.swarm else None
+        for i in range(self.hi - self.lo):
+            a = self.lo + i
+            pose = pva[i, :3].numpy().astype(np.float32)
+            stamp = float(t_start[i]) - 0.02
+            okk, rec, _ = self.orc.replan(self.spec, self.ap, self.pp, self.qs, self.grids[i], pose, stamp,
+                                          pva[i].numpy(), goals[i].numpy(), float(t_start[i]), a)
+            if okk and allr is not None:  # isSafeAfterOpt, the last step of replan() (baseline_fake.cpp:453-460)
+                okk = self.orc.safe_after_opt(np.asarray(rec.cpts[:15 * rec.n_pieces]), rec.n_pieces, allr,
+                                              self.swarm[1], a, stamp)
+            ok[i] = int(bool(okk))
+            new[i] = torch.from_numpy(np.frombuffer(bytes(rec), dtype=np.uint8).copy())
+
+    def merge_latest(self, new, ok, own, all_records):
+        """k_merge_latest restated: a successful replan replaces the agent's record, a failed one keeps it; the
+        swarm table (single process only) is refreshed in the same pass."""
+        sel = ok.bool().unsqueeze(1)
+        own.copy_(new.where(sel, own))
+        if all_records is not None:
+            all_records.copy_(own)
+
+    def close(self):
+        pass
+
+
+def torch_from(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a))

@@ -66,84 +66,156 @@ def test_world2_gloo_allgather_and_sharding():
     assert out[0] and out[1]
 
 
-def _closed_loop(rank, world, A_loc, ticks, dist_mod):
-    """3 ticks of merge_latest -> exchange -> next-tick overlay for the agents of `rank`, with the CPU oracle standing
-    in for the GPU kernels (tests may use it): per agent SOGM build + neighbour overlay from the EXCHANGED records,
-    oracle replan, latest-wins merge, one all-gather.  Returns (overlay checksums per tick, final records)."""
+class _StubExchangeLib:
+    """Stands in for libsogm_hip.so's sogm_comm_* / sogm_traj_allgather entry points on CPU so that
+    driver.RecordExchange — the id hand-off from rank 0, the all-ranks-agree rule, the call sequence — runs at world
+    size 2 without a GPU.  The "collective" is gloo's all-gather on the tensors behind the raw pointers."""
+
+    def __init__(self, dist_mod, rec_bytes, fail_create_on=None):
+        self.dist, self.rec_bytes, self.fail_create_on = dist_mod, rec_bytes, fail_create_on
+        self.ids, self.calls, self.rank, self.world = [], [], None, None
+
+    def sogm_comm_unique_id(self, buf):
+        import ctypes as C
+        raw = bytes((7 * i + 3) % 251 for i in range(128))
+        C.memmove(buf, raw, 128)
+        self.calls.append("unique_id")
+        return 0
+
+    def sogm_comm_create(self, ident, rank, world, device, out):
+        self.calls.append("create")
+        self.ids.append(bytes(ident))
+        self.rank, self.world = rank, world
+        if self.fail_create_on == rank:
+            return -4
+        out._obj.value = 0xC0FFEE + rank
+        return 0
+
+    def sogm_comm_handle(self, comm):
+        return comm.value
+
+    def sogm_traj_allgather(self, ctx, handle, own_ptr, n_local, all_ptr, stream):
+        import ctypes as C
+        assert handle == 0xC0FFEE + self.rank
+        nb = n_local * self.rec_bytes
+        own = torch.from_numpy(np.frombuffer((C.c_uint8 * nb).from_address(own_ptr), dtype=np.uint8).copy())
+        allr = torch.zeros(nb * self.world, dtype=torch.uint8)
+        self.dist.all_gather_into_tensor(allr, own)
+        C.memmove(all_ptr, allr.numpy().ctypes.data, nb * self.world)
+        self.calls.append("allgather")
+        return 0
+
+    def sogm_exchange_wait(self, ctx, stream):
+        self.calls.append("wait")
+        return 0
+
+    def sogm_comm_destroy(self, comm):
+        self.calls.append("destroy")
+
+
+def _swarm_tick_loop(rank, world, A_loc, ticks, dist_mod, exchange_kind="torch"):
+    """`ticks` ticks of driver.SwarmTick.step() ITSELF for the agents of `rank` — the product's rank-local
+    bookkeeping (tick inputs, map update from the exchanged table, replan, latest-wins merge, publication) — with
+    the CPU oracle standing in for the four kernel calls (tests/helpers.OracleCompute).  exchange_kind "stub" routes
+    the broadcast through driver.RecordExchange with a stub library, "stub-fail" makes rank 1's communicator fail."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
     pop = importlib.import_module("pred-occ-planner_amd")
     drv = importlib.import_module("pred-occ-planner_amd.driver")
     orc = importlib.import_module("oracle.binding")
-    abi = pop._abi
+    helpers = importlib.import_module("helpers")
     spec = pop.config.make_spec("parity")
-    ap, pp, qs = pop.config.make_astar_params(), pop.config.make_planner_params(True), pop.config.make_qp_settings()
     A_tot = A_loc * world
     sc = pop.scene.make_scene(A_tot, 4.95, seed=23, circle_radius=2.5, n_cyl=30)
-    cyl = pop.scene.cylinders_to_struct(sc["cylinders"])
-    body = pop.scene.body_particles()
+    sc["stamps"] = np.full(A_tot, 100.0)
     lo, hi = drv.shard_bounds(rank, world, A_loc)
-    own = torch.zeros((A_loc, abi.TRAJ_RECORD_BYTES), dtype=torch.uint8)
-    allr = torch.zeros((A_tot, abi.TRAJ_RECORD_BYTES), dtype=torch.uint8)
-    pos = sc["starts"][lo:hi].copy()
-    sums, n_ok = [], 0
-    for tick in range(ticks):
-        stamp = 100.0 + tick * drv.TICK_PERIOD
-        t_start = stamp + drv.REPLAN_START_TIME
-        recs = (abi.SogmTrajRecord * A_tot).from_buffer_copy(allr.numpy().tobytes())
-        new = torch.zeros_like(own)
-        ok = torch.zeros(A_loc, dtype=torch.int32)
-        for i in range(A_loc):
-            a = lo + i
-            mine = (abi.SogmTrajRecord * 1).from_buffer_copy(own[i].numpy().tobytes())[0]
-            pva = np.concatenate([pos[i], np.zeros(6)])
-            if mine.n_pieces > 0:  # replan start state from the executed trajectory (plan_manager.cpp:169-175)
-                d = np.array(mine.duration[:mine.n_pieces])
-                c = np.array(mine.cpts[:15 * mine.n_pieces]).reshape(-1, 3)
-                tt = min(max(t_start - mine.time_start, 0.0), d.sum())
-                pva = np.concatenate([orc.bezier_eval(d, c, tt, k) for k in range(3)])
-                pos[i] = pva[:3]
-            pose = pos[i].astype(np.float32)
-            g = orc.update_gt(spec, sc["cloud"], cyl, len(sc["cylinders"]), pose)
-            orc.project_neighbours(spec, g, recs, A_tot, a, body, pose, stamp)  # overlay of the exchanged records
-            sums.append((tick, a, float(g.sum()), int(np.flatnonzero(g.ravel()).sum() % 1000003)))
-            okk, rec, _ = orc.replan(spec, ap, pp, qs, g, pose, stamp, pva, sc["goals"][a], t_start, a)
-            ok[i] = int(okk)
-            new[i] = torch.from_numpy(np.frombuffer(bytes(rec), dtype=np.uint8).copy())
-        n_ok += int(ok.sum())
-        own = drv.merge_latest(new, own, ok)
-        drv.exchange_records(own, allr, dist_mod, world)
-    return sums, allr.numpy().copy(), n_ok
+    comp = helpers.OracleCompute(pop, orc, spec, sc, lo, hi)
+    exchange, stub = None, None
+    if exchange_kind != "torch":
+        stub = _StubExchangeLib(dist_mod, pop._abi.TRAJ_RECORD_BYTES, fail_create_on=1 if exchange_kind == "stub-fail" else None)
+        exchange = drv.RecordExchange(None, dist_mod, rank, world, 0, lib=stub, backends=("gloo",), stream=lambda: None)
+    sw = drv.SwarmTick("parity", A_loc, rank, world, spec=spec, scene=sc, dist=dist_mod, compute=comp, exchange=exchange)
+    n_ok = 0
+    for _ in range(ticks):
+        n_ok += int(sw.step().sum())
+    table = sw.records_all().numpy().copy()
+    info = {"active": sw.exchange.active, "reason": sw.exchange.fallback_reason, "calls": stub.calls if stub else [],
+            "ids": stub.ids if stub else []}
+    sw.close()
+    return comp.overlay_sums, table, n_ok, info
 
 
-def _worker_loop(rank, world, port, out):
+def _worker_loop(rank, world, port, out, kind):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    sums, allr, n_ok = _closed_loop(rank, world, 2, 3, dist)
-    out[rank] = (sums, allr.tobytes(), n_ok)
+    sums, allr, n_ok, info = _swarm_tick_loop(rank, world, 2, 3, dist, kind)
+    out[rank] = (sums, allr.tobytes(), n_ok, info)
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_world2_closed_loop_matches_single_process():
-    """The N>1 data flow end to end (SURVEY §8 e): two ranks x 2 agents over gloo for 3 ticks against ONE process
-    running all 4 agents — every rank-local neighbour overlay (built from the all-gathered records, one tick stale
-    like the ROS broadcast) and the final record table must be identical."""
+def _run_world2(kind):
     sys.path.insert(0, ROOT)
-    world = 2
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_worker_loop, args=(world, _free_port(), out), nprocs=world, join=True)
-    ref_sums, ref_all, ref_ok = _closed_loop(0, 1, 4, 3, None)
+    mp.spawn(_worker_loop, args=(2, _free_port(), out, kind), nprocs=2, join=True)
+    return out
+
+
+_REF = {}
+
+
+def _reference():
+    if not _REF:
+        _REF["v"] = _swarm_tick_loop(0, 1, 4, 3, None)
+    return _REF["v"]
+
+
+def _check_against_single_process(out):
+    ref_sums, ref_all, ref_ok, _ = _reference()
     got_sums = sorted(out[0][0] + out[1][0])
     assert got_sums == sorted(ref_sums)
     assert out[0][1] == out[1][1] == ref_all.tobytes()   # both ranks hold the same, complete table
     assert out[0][2] + out[1][2] == ref_ok and ref_ok >= 6
     # the overlay did see the neighbours: from tick 1 on the grids hold more than the obstacle marks of tick 0
     by_agent = {}
-    for tick, a, s_, _h in ref_sums:
+    for _stamp, a, s_, _h in sorted(ref_sums):
         by_agent.setdefault(a, []).append(s_)
     assert any(v[1] != v[0] for v in by_agent.values())
+
+
+def test_world2_swarm_tick_matches_single_process():
+    """The N>1 data flow end to end (SURVEY §8 e) through driver.SwarmTick.step(): two ranks x 2 agents over gloo
+    for 3 ticks against ONE process running all 4 agents — every rank-local neighbour overlay (built from the
+    all-gathered records, one tick stale like the ROS broadcast), the ok counts and the final record table must be
+    identical."""
+    _check_against_single_process(_run_world2("torch"))
+
+
+def test_world2_record_exchange_through_the_abi_entry_points():
+    """The same flight with the broadcast routed through driver.RecordExchange (the sogm_comm_* / sogm_traj_allgather
+    call sequence a C++ host makes), a stub library standing in for libsogm_hip.so: rank 0's id reaches rank 1, one
+    all-gather per tick, records_all() waits for the exchange stream, the communicator is destroyed on close."""
+    out = _run_world2("stub")
+    _check_against_single_process(out)
+    for r in (0, 1):
+        info = out[r][3]
+        assert info["active"] and info["reason"] is None
+        assert info["calls"] == (["unique_id"] if r == 0 else []) + ["create"] + ["allgather"] * 3 + ["wait", "destroy"]
+    assert out[0][3]["ids"] == out[1][3]["ids"] and len(out[0][3]["ids"][0]) == 128
+
+
+def test_world2_failed_communicator_sends_every_rank_to_the_fallback():
+    """One rank failing sogm_comm_create must not leave the ranks on different collectives: all of them fall back to
+    torch.distributed's all-gather, say why, and the flight is unchanged."""
+    out = _run_world2("stub-fail")
+    _check_against_single_process(out)
+    for r in (0, 1):
+        info = out[r][3]
+        assert not info["active"] and "sogm_comm_create" in info["reason"]
+        assert "allgather" not in info["calls"]
+    assert out[0][3]["calls"].count("destroy") == 1   # the communicator rank 0 did get is released again
 
 
 def test_shard_bounds_partition_agents():

@@ -77,16 +77,21 @@ def test_tight_solve_satisfies_kkt_and_bounds_the_1e3_solution(pop, orc):
 
 
 def test_fixed_rho_vs_adaptive(pop, orc):
-    """north_star asks for a fixed KKT factor; on the reference's own fixture fixed rho = 0.1 does
-    not reach eps = 1e-3 within OSQP's 4000 iterations, adaptive rho does (QP section)."""
+    """The reference's own 3-cube fixture under OSQP's defaults: with the rho estimate computed from the SCALED
+    residuals (auxil.c compute_rho_estimate) it never leaves the factor-5 band around rho = 0.1, so adaptive rho and
+    the fixed KKT factor the north_star asks for are the same solve here — max_iter 4000 is reached with status 2
+    (SOLVED_INACCURATE: optimize() still returns true, bezier_optimizer.cpp:280-283, and the solution meets the
+    test's 1e-3 boundary tolerances, see above); with more iterations both reach eps = 1e-3."""
     t = G["three"]
-    fixed = pop.config.make_qp_settings()
-    fixed.adaptive_rho_interval = 0
-    st0, _, it0 = orc.qp_solve(t["start"], t["end"], t["t"], _polys(t["cubes"]), [6, 6, 6], MF, 3.0, 3.0, fixed)
-    st1, _, it1 = orc.qp_solve(t["start"], t["end"], t["t"], _polys(t["cubes"]), [6, 6, 6], MF, 3.0, 3.0,
-                               pop.config.make_qp_settings())
-    assert it0 == 4000 and st0 == 2
-    assert st1 == 1 and it1 < 2000
+    out = {}
+    for name, interval in (("fixed", 0), ("adaptive", 25)):
+        for max_iter in (4000, 8000):
+            qs = pop.config.make_qp_settings()
+            qs.adaptive_rho_interval, qs.max_iter = interval, max_iter
+            st, _, it = orc.qp_solve(t["start"], t["end"], t["t"], _polys(t["cubes"]), [6, 6, 6], MF, 3.0, 3.0, qs)
+            out[name, max_iter] = (st, it)
+    assert out["fixed", 4000] == out["adaptive", 4000] == (2, 4000)
+    assert out["fixed", 8000] == out["adaptive", 8000] and out["fixed", 8000][0] == 1 and 4000 < out["fixed", 8000][1] < 6000
 
 
 def test_infeasible_qp_is_reported(pop, orc):
