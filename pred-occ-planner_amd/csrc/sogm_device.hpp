@@ -280,6 +280,16 @@ struct sogm_ctx {
   int            precleared;  // the next update finds a (being-)cleared grid: mode 1 in place, modes 2 / 3 n_ready > 0
   hipStream_t    side;
   hipEvent_t     ev_grid_free, ev_cleared;
+  // width-adaptive clear (dataflow replan, modes 2 / 3): the side-stream clear starts narrow; a second, wide launch
+  // on side2 joins it once the word *clear_gate reaches clear_gate_target (the planner's "corridors final" counter:
+  // from then on the tick's remaining kernels iterate in LDS); clear_cursor is the chunk counter the two launches
+  // share.  clear_gate == nullptr: one launch of fixed width.
+  const int          *clear_gate;
+  const int          *clear_gate_err;
+  int                 clear_gate_target;
+  unsigned long long *clear_cursor;
+  hipStream_t         side2;  // the wide part's stream
+  hipEvent_t          ev_side2_go, ev_side2_done;
   float         *d_filter_cells;   // filterPointCloud leaf accumulators [A][max_cells][4] (lazy)
   void          *d_filter_box;
   int           *d_filter_blocks;

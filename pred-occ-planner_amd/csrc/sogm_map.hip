@@ -63,6 +63,56 @@ __global__ __launch_bounds__(256) void k_clear_slabs(vfloat4 *__restrict__ p, si
   if (blockIdx.x == 0 && (int)threadIdx.x < n_tail) tail[threadIdx.x] = 0.f;
 }
 
+// The same stream of stores with a width that follows the tick (side-stream clear of the dataflow replan).  The
+// grid is cut into 4 MiB chunks handed out by an atomic cursor shared by TWO launches: a narrow one (64 workgroups,
+// <= 4 stores in flight per wave: what the latency-bound planner kernels tolerate beside them) that starts with the
+// tick, and a wide, unbounded one on a second stream behind k_clear_gate, which returns once *gate >= gate_target —
+// every agent's corridors are final, what is left of the tick iterates in LDS (QP) — or the tick failed, or no
+// chunk is left.  (Gating at launch granularity matters: workgroups that merely SLEEP on a CU hold a wave slot per
+// SIMD, and a QP workgroup — 2 x 256 registers per SIMD — cannot be placed beside them.)  A workgroup asks for its
+// next chunk before it stores the current one, so the cursor's round trip hides under the stores.
+#define CLEAR_CHUNK_V4 (size_t)(4u << 20 >> 4)  // 16-byte elements per chunk
+__global__ void k_clear_gate(const unsigned long long *__restrict__ cursor, size_t nchunks,
+                             const int *__restrict__ gate, const int *__restrict__ gate_err, int gate_target) {
+  if (threadIdx.x != 0) return;
+  while (__hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gate_target &&
+         __hip_atomic_load(gate_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 &&
+         __hip_atomic_load(cursor, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nchunks) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) __builtin_amdgcn_s_sleep(127);  // ~14 us between polls
+  }
+}
+template <bool POLITE>
+__global__ __launch_bounds__(256) void k_clear_chunks(vfloat4 *__restrict__ p, size_t n_vec4,
+                                                      float *__restrict__ tail, int n_tail,
+                                                      unsigned long long *__restrict__ cursor) {
+  __shared__ unsigned long long s_next;
+  const size_t nchunks = (n_vec4 + CLEAR_CHUNK_V4 - 1) / CLEAR_CHUNK_V4;
+  if (threadIdx.x == 0) s_next = atomicAdd(cursor, 1ull);
+  __syncthreads();
+  unsigned long long cur = s_next;
+  while (cur < nchunks) {
+    __syncthreads();  // everybody holds `cur`
+    unsigned long long nxt = 0;
+    if (threadIdx.x == 0) nxt = atomicAdd(cursor, 1ull);  // in flight under the stores below
+    const size_t b = (size_t)cur * CLEAR_CHUNK_V4;
+    const size_t e = b + CLEAR_CHUNK_V4 < n_vec4 ? b + CLEAR_CHUNK_V4 : n_vec4;
+    size_t       i = b + threadIdx.x;
+    for (; i + 768 < e; i += 1024) {
+      clear_store<true>(p + i);
+      clear_store<true>(p + i + 256);
+      clear_store<true>(p + i + 512);
+      clear_store<true>(p + i + 768);
+      if (POLITE) __builtin_amdgcn_s_waitcnt(0x0F75);  // vmcnt <= 5: four stores (+ the cursor's atomic on lane 0)
+    }
+    for (; i < e; i += 256) clear_store<true>(p + i);
+    if (threadIdx.x == 0) s_next = nxt;
+    __syncthreads();
+    cur = s_next;
+  }
+  if (POLITE && blockIdx.x == 0 && (int)threadIdx.x < n_tail) tail[threadIdx.x] = 0.f;
+}
+
 // ------------------------------------------------------------------------------------------------
 // stamp: cloud -> slice 0, GT velocity -> slices 1..T-1
 // ------------------------------------------------------------------------------------------------
@@ -678,6 +728,29 @@ int launch_clear(sogm_ctx *c, hipStream_t st, float *grid, bool polite, int part
   const size_t max_wgs  = env_wgs ? (size_t)env_wgs : (polite ? 64 : 2048);
   const int    throttle = env_wgs ? env_throttle : (polite ? 4 : 0);
   const int    nblk     = (int)(want < 1 ? 1 : (want > max_wgs ? max_wgs : want));
+  static int   wide_wgs = -1;
+  if (wide_wgs < 0) {
+    const char *e = getenv("SOGM_CLEAR_WIDE_WGS");  // 0 switches the adaptive width off
+    wide_wgs      = e ? atoi(e) : 256;
+  }
+  if (polite && part == 0 && c->clear_gate && c->clear_cursor && c->side2 && wide_wgs > 0 && nt) {
+    const size_t nchunks = (nall + CLEAR_CHUNK_V4 - 1) / CLEAR_CHUNK_V4;
+    SOGM_HIP_CHECK(hipMemsetAsync(c->clear_cursor, 0, sizeof(unsigned long long), st));
+    SOGM_HIP_CHECK(hipEventRecord(c->ev_side2_go, st));
+    SOGM_HIP_CHECK(hipStreamWaitEvent(c->side2, c->ev_side2_go, 0));
+    prof_begin(c, slot, st);
+    hipLaunchKernelGGL(k_clear_chunks<true>, dim3(nblk), dim3(256), 0, st, (vfloat4 *)grid, nall, grid + nall * 4,
+                       tail, c->clear_cursor);
+    hipLaunchKernelGGL(k_clear_gate, dim3(1), dim3(64), 0, c->side2, c->clear_cursor, nchunks, c->clear_gate,
+                       c->clear_gate_err, c->clear_gate_target);
+    hipLaunchKernelGGL(k_clear_chunks<false>, dim3(wide_wgs), dim3(256), 0, c->side2, (vfloat4 *)grid, nall,
+                       grid + nall * 4, 0, c->clear_cursor);
+    SOGM_HIP_CHECK(hipEventRecord(c->ev_side2_done, c->side2));
+    SOGM_HIP_CHECK(hipStreamWaitEvent(st, c->ev_side2_done, 0));  // the clear is complete when both launches are
+    prof_end(c, slot, st);
+    SOGM_HIP_CHECK(hipGetLastError());
+    return SOGM_OK;
+  }
   prof_begin(c, slot, st);
   if (nt)
     hipLaunchKernelGGL(k_clear_slabs<true>, dim3(nblk), dim3(256), 0, st, (vfloat4 *)grid + first, nv4,
@@ -737,7 +810,11 @@ int sogm_create(const SogmSpec *spec, int n_agents, int device, sogm_ctx **out) 
   if (e == hipSuccess) e = hipMalloc(&c->d_scratch_vt, sizeof(float) * (size_t)c->geom.V * spec->T);
   if (e == hipSuccess) e = hipMemset(c->d_poses, 0, sizeof(float) * 3 * n_agents);
   if (e == hipSuccess) e = hipMemset(c->d_stamps, 0, sizeof(double) * n_agents);
+  if (e == hipSuccess) e = hipMalloc((void **)&c->clear_cursor, sizeof(unsigned long long));
   if (e == hipSuccess) e = sogm::create_stream_partitioned(&c->side, 0);
+  if (e == hipSuccess) e = sogm::create_stream_partitioned(&c->side2, 0);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_side2_go, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_side2_done, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_grid_free, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_cleared, hipEventDisableTiming);
   if (e != hipSuccess) {
@@ -758,6 +835,7 @@ void sogm_destroy(sogm_ctx *c) {
     if (c->pool_ev[i]) (void)hipEventDestroy(c->pool_ev[i]);
   if (c->d_poses) (void)hipFree(c->d_poses);
   if (c->d_stamps) (void)hipFree(c->d_stamps);
+  if (c->clear_cursor) (void)hipFree(c->clear_cursor);
   if (c->d_body) (void)hipFree(c->d_body);
   if (c->d_scratch_vt) (void)hipFree(c->d_scratch_vt);
   if (c->d_cand) (void)hipFree(c->d_cand);
@@ -769,6 +847,12 @@ void sogm_destroy(sogm_ctx *c) {
     (void)hipStreamSynchronize(c->side);
     (void)hipStreamDestroy(c->side);
   }
+  if (c->side2) {
+    (void)hipStreamSynchronize(c->side2);
+    (void)hipStreamDestroy(c->side2);
+  }
+  if (c->ev_side2_go) (void)hipEventDestroy(c->ev_side2_go);
+  if (c->ev_side2_done) (void)hipEventDestroy(c->ev_side2_done);
   if (c->ev_grid_free) (void)hipEventDestroy(c->ev_grid_free);
   if (c->ev_cleared) (void)hipEventDestroy(c->ev_cleared);
   if (c->xstream) {

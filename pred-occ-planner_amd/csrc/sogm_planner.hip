@@ -445,7 +445,12 @@ static int replan_flow(sogm_planner *p, const double *start_pva, const double *g
   SOGM_HIP_CHECK(hipMemsetAsync(out_records, 0, sizeof(SogmTrajRecord) * (size_t)A, main));
   SOGM_HIP_CHECK(hipEventRecord(p->ev_in, main));
   if (c->overlap >= 2) {
-    int rc = sogm::queue_spare_clears(c, p->ev_in);
+    // the side-stream clear goes wide once every agent's corridors are final (FLOW_Q_READY_N == A)
+    c->clear_gate        = p->fc.hdr + FLOW_Q_READY_N;
+    c->clear_gate_err    = p->fc.hdr + FLOW_ERR;
+    c->clear_gate_target = A;
+    int rc               = sogm::queue_spare_clears(c, p->ev_in);
+    c->clear_gate        = nullptr;
     if (rc) return rc;
   }
   for (int k = 0; k < 4; ++k) SOGM_HIP_CHECK(hipStreamWaitEvent(p->fstream[k], p->ev_in, 0));
@@ -460,13 +465,15 @@ static int replan_flow(sogm_planner *p, const double *start_pva, const double *g
   SOGM_HIP_CHECK(hipEventRecord(p->ev_gate, sC));
   SOGM_HIP_CHECK(hipStreamWaitEvent(sQ, p->ev_gate, 0));
   SOGM_HIP_CHECK(hipStreamWaitEvent(sF, p->ev_gate, 0));
-  // persistent workgroups: one wave each for the corridor items (4 per CU fit), a quarter of the CUs' worth of QP
-  // workgroups (each takes a whole CU's LDS while it runs), a handful of finishing waves
+  // persistent workgroups: one wave each for the corridor items (4 per CU fit), half of the CUs' worth of QP
+  // workgroups (each takes a whole CU's LDS while it runs; with fewer, agents queue for a solver — measured: 64 / 96
+  // / 128 / 160 workgroups -> 6.3 / 6.9 / 7.5 / 7.4 k replans/s), a handful of finishing waves
   int n_cu = 256;
   (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->device);
   int wg_c = 4 * n_cu;
   if (wg_c > A * SOGM_MAX_PIECES) wg_c = A * SOGM_MAX_PIECES;
-  int wg_q = (3 * n_cu) / 8;
+  int wg_q = n_cu / 2;
+  if (const char *e = getenv("SOGM_QP_WGS")) wg_q = atoi(e);  // tuning aid
   if (wg_q > A) wg_q = A;
   if (wg_q < 1) wg_q = 1;
   int wg_f = A < 64 ? A : 64;

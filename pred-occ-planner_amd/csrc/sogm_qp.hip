@@ -68,6 +68,35 @@ __device__ inline double wave_sum(double v) {
   for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
   return v;
 }
+// wave-wide max / sum of a per-lane value without the LDS crossbar: two quad permutes, row_half_mirror, row_mirror
+// (after which every lane of a 16-lane row holds the row's result), then the four rows through readlane.  All 64
+// lanes must be active.  Maxima of non-negative values (v_max_f64 ignores a NaN operand like the oracle's std::max).
+template <int CTRL>
+__device__ inline double dpp_ctrl_t(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo     = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xF, 0xF, true);
+  hi     = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+__device__ inline double read_lane(double v, int l) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l),
+                          __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+__device__ inline double wave_max_dpp(double v) {
+  v = __builtin_fmax(v, dpp_ctrl_t<0xB1>(v));
+  v = __builtin_fmax(v, dpp_ctrl_t<0x4E>(v));
+  v = __builtin_fmax(v, dpp_ctrl_t<0x141>(v));
+  v = __builtin_fmax(v, dpp_ctrl_t<0x140>(v));
+  return __builtin_fmax(__builtin_fmax(read_lane(v, 0), read_lane(v, 16)),
+                        __builtin_fmax(read_lane(v, 32), read_lane(v, 48)));
+}
+__device__ inline double wave_sum_dpp(double v) {
+  v += dpp_ctrl_t<0xB1>(v);
+  v += dpp_ctrl_t<0x4E>(v);
+  v += dpp_ctrl_t<0x141>(v);
+  v += dpp_ctrl_t<0x140>(v);
+  return (read_lane(v, 0) + read_lane(v, 16)) + (read_lane(v, 32) + read_lane(v, 48));
+}
 __device__ inline double block_max(double v, double *s_red) {
   v = wave_max(v);
   __syncthreads();
@@ -739,6 +768,7 @@ __device__ __forceinline__ void qp_solve_agent(const SogmPlannerParams &pp, cons
     double m[12];
 #pragma unroll
     for (int k = 0; k < 12; ++k) m[k] = 0.0;
+    if (!(ablate & 32))
     for (int r = tid; r < G; r += QP_NT) {
       double s = 0;
       for (int k = 0; k < QP_ELL; ++k) {
@@ -753,6 +783,7 @@ __device__ __forceinline__ void qp_solve_agent(const SogmPlannerParams &pp, cons
       m[7]           = dmax(m[7], dabs(s));
       m[8]           = dmax(m[8], dabs(z));
     }
+    if (!(ablate & 32))
     for (int s = tid; s < S; s += QP_NT) {
       const int     c0 = R.sc0[s];
       const double *v  = R.sval + (size_t)s * 3;
@@ -768,6 +799,7 @@ __device__ __forceinline__ void qp_solve_agent(const SogmPlannerParams &pp, cons
       m[7]           = dmax(m[7], dabs(ax));
       m[8]           = dmax(m[8], dabs(z));
     }
+    if (!(ablate & 64))
     for (int j = tid; j < n; j += QP_NT) {
       double        s  = 0;
       const double *Pb = s_P + (j / 15) * 225 + (j % 15) * 15;
@@ -783,6 +815,7 @@ __device__ __forceinline__ void qp_solve_agent(const SogmPlannerParams &pp, cons
       m[11]           = dmax(m[11], dabs(a));
     }
     // the twelve maxima share one wave-reduce / LDS / barrier round
+    if (!(ablate & 128))
 #pragma unroll
     for (int k = 0; k < 12; ++k) m[k] = wave_max(m[k]);
     __syncthreads();
@@ -931,30 +964,38 @@ __device__ __forceinline__ void qp_solve_agent(const SogmPlannerParams &pp, cons
   // finite bounds (untouched), every safety row has l = -OSQP_INFTY, so only its positive part counts (the stored
   // delta_y is overwritten like OSQP's work vector; the next iteration recomputes it) — then, relative to the
   // unscaled ||dy||inf:  u'(dy)+ + l'(dy)- < -eps ||dy||  and  ||Dinv A'dy||inf < eps ||dy||.  Workgroup-uniform.
-  auto primal_infeasible = [&](double eps_inf) -> bool {
+  // Stage 1 (the projection, ||dy|| -> s_sc[7], the bound product -> s_sc[15]) is part of the register-resident
+  // residual pass on the fast path; cert_stage1 is the same over the row storage.
+  auto cert_stage1 = [&]() {
     const int tid = launder((int)threadIdx.x), lane = tid & 63, wave = tid >> 6;
-    double    ndy = 0;
-    for (int r = tid; r < G; r += QP_NT) ndy = dmax(ndy, dabs(R.gE[r] * R.gdy[r]));
+    double    ndy = 0, lhs = 0;
+    for (int r = tid; r < G; r += QP_NT) {
+      const double d = R.gdy[r];
+      ndy            = dmax(ndy, dabs(R.gE[r] * d));
+      lhs += R.gu[r] * (d > 0 ? d : 0) + R.gl[r] * (d < 0 ? d : 0);
+    }
     for (int s = tid; s < S; s += QP_NT) {
       const double d = R.sdy[s] > 0.0 ? R.sdy[s] : 0.0;
       R.sdy[s]       = d;
       ndy            = dmax(ndy, dabs(R.sE[s] * d));
+      lhs += R.su[s] * d;  // projected: dy >= 0
     }
     ndy = block_max(ndy, s_red);
-    __syncthreads();
-    if (!(ndy > eps_inf)) return false;
-    double lhs = 0;
-    for (int r = tid; r < G; r += QP_NT) {
-      const double d = R.gdy[r];
-      lhs += R.gu[r] * (d > 0 ? d : 0) + R.gl[r] * (d < 0 ? d : 0);
-    }
-    for (int s = tid; s < S; s += QP_NT) lhs += R.su[s] * R.sdy[s];  // projected: dy >= 0
     lhs = wave_sum(lhs);
     __syncthreads();
     if (lane == 0) s_red[wave] = lhs;
     __syncthreads();
-    lhs = ((s_red[0] + s_red[1]) + (s_red[2] + s_red[3])) + ((s_red[4] + s_red[5]) + (s_red[6] + s_red[7]));
+    if (tid == 0) {
+      s_sc[7]  = ndy;
+      s_sc[15] = ((s_red[0] + s_red[1]) + (s_red[2] + s_red[3])) + ((s_red[4] + s_red[5]) + (s_red[6] + s_red[7]));
+    }
     __syncthreads();
+  };
+  auto primal_infeasible = [&](double eps_inf) -> bool {
+    const int tid = launder((int)threadIdx.x);
+    if constexpr (!FAST) cert_stage1();
+    const double ndy = s_sc[7], lhs = s_sc[15];
+    if (!(ndy > eps_inf)) return false;
     if (!(lhs < -eps_inf * ndy)) return false;
     double na = 0;
     for (int j = tid; j < n; j += QP_NT) {
@@ -973,6 +1014,107 @@ __device__ __forceinline__ void qp_solve_agent(const SogmPlannerParams &pp, cons
     na = block_max(na, s_red);
     __syncthreads();
     return na < eps_inf * ndy;
+  };
+
+  // The residual pass of the register-resident iteration (fast path): the row norms and the certificate's stage 1
+  // come straight from the row state in registers (one batch of x loads per lane; |v| / e is monotone in |v|, so
+  // max(|Ax|, |z|) / e replaces two of the three divisions per row), the dual norms from one lane per column in the
+  // row order of the oracle's dense sums; ten wave reductions on the DPP path, one LDS round for the eight waves.
+  // Fills s_sc like residuals() (1 / 4 / 9 / 12 hold the pair maxima, their partners 0) plus s_sc[7], s_sc[15].
+  auto fast_residuals = [&]() __attribute__((always_inline)) {
+    const int t = launder(tid), lane = t & 63, wave = t >> 6;
+    double    v[10];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) v[k] = 0.0;
+    if (grole) {  // wave-uniform
+      double xg[QP_ELL];
+#pragma unroll
+      for (int k = 0; k < QP_ELL; ++k) xg[k] = s_x[gc(k)];
+      const int    tg = grow ? t : 0;
+      const double e = R.gE[tg], d = R.gdy[tg];
+      double       ax = 0.0;
+#pragma unroll
+      for (int k = 0; k < QP_ELL; ++k) ax += gv(k) * xg[k];  // absent entries are 0 * x[0]
+      if (grow) {
+        const double r_ = dabs(ax - g_z), n_ = dmax(dabs(ax), dabs(g_z));
+        v[0] = r_ / e;
+        v[1] = n_ / e;
+        v[2] = r_;
+        v[3] = n_;
+        v[8] = dabs(e * d);
+        v[9] = g_hi * (d > 0 ? d : 0) + g_lo * (d < 0 ? d : 0);
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (256 * u >= S) continue;  // workgroup-uniform
+        const int    sr = (t - 256) + 256 * u;
+        const bool   ok = sr < S;
+        const int    sc = ok ? sr : 0;
+        const double x0 = s_x[s_c(u)], x1 = s_x[s_c(u) + 1], x2 = s_x[s_c(u) + 2];
+        const double e = R.sE[sc], dr_ = R.sdy[sc];
+        double       ax = 0.0;
+        ax += sv(u, 0) * x0;
+        ax += sv(u, 1) * x1;
+        ax += sv(u, 2) * x2;
+        if (ok) {
+          const double d  = dr_ > 0.0 ? dr_ : 0.0;  // projection onto the polar of the recession cone
+          R.sdy[sr]       = d;
+          const double r_ = dabs(ax - s_zr(u)), n_ = dmax(dabs(ax), dabs(s_zr(u)));
+          v[0] = dmax(v[0], r_ / e);
+          v[1] = dmax(v[1], n_ / e);
+          v[2] = dmax(v[2], r_);
+          v[3] = dmax(v[3], n_);
+          v[8] = dmax(v[8], dabs(e * d));
+          v[9] += s_hi(u) * d;
+        }
+      }
+    }
+    if (t < n) {
+      const int     j  = t;
+      const double *Pb = s_P + (j / 15) * 225 + (j % 15) * 15;
+      const int     b0 = (j / 15) * 15;
+      double        pk[15], xk[15];
+#pragma unroll
+      for (int k = 0; k < 15; ++k) {
+        pk[k] = Pb[k];
+        xk[k] = s_x[b0 + k];
+      }
+      double s_ = 0;
+#pragma unroll
+      for (int k = 0; k < 15; ++k) s_ += pk[k] * xk[k];
+      const double a_ = col_sum_y(j);
+      const double dj = s_D[j];
+      const double r_ = dabs(s_ + a_), n_ = dmax(dabs(s_), dabs(a_));
+      v[4] = r_ / dj;
+      v[5] = n_ / dj;
+      v[6] = r_;
+      v[7] = n_;
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) v[k] = wave_max_dpp(v[k]);
+    v[9] = wave_sum_dpp(v[9]);
+    if (lane == 0) {
+#pragma unroll
+      for (int k = 0; k < 10; ++k) s_red12[wave * 12 + k] = v[k];
+    }
+    __syncthreads();
+    if (t < 10) {
+      double r_;
+      if (t == 9) {
+        r_ = ((s_red12[9] + s_red12[21]) + (s_red12[33] + s_red12[45])) + ((s_red12[57] + s_red12[69]) + (s_red12[81] + s_red12[93]));
+      } else {
+        r_ = s_red12[t];
+        for (int w = 1; w < QP_NT / 64; ++w) r_ = dmax(r_, s_red12[12 * w + t]);
+      }
+      // slots: pr 0 | max(nAx, nz) 1 | sc_pr 8 | max(sc_nAx, sc_nz) 9 | dr 3 | max(nPx, nAty) 4 | sc_dr 11 |
+      // max(sc_nPx, sc_nAty) 12 | ||dy|| 7 | bound product 15
+      const int slot = t == 0 ? 0 : t == 1 ? 1 : t == 2 ? 8 : t == 3 ? 9 : t == 4 ? 3 : t == 5 ? 4 : t == 6 ? 11 : t == 7 ? 12 : t == 8 ? 7 : 15;
+      s_sc[slot] = t == 4 ? r_ * cinv : r_;
+    }
+    if (t >= 10 && t < 16)  // the partners of the pair maxima, and ||q|| = 0
+      s_sc[t == 10 ? 2 : t == 11 ? 5 : t == 12 ? 6 : t == 13 ? 10 : t == 14 ? 13 : 14] = 0.0;
+    __syncthreads();
   };
 
   set_rho();
@@ -1002,19 +1144,13 @@ __device__ __forceinline__ void qp_solve_agent(const SogmPlannerParams &pp, cons
   const double *xtv   = FAST ? s_cn : s_xt;  // where the solve leaves x~
   for (int j = n + tid; j < 128; j += QP_NT) s_xt[j] = 0.0;  // the register mat-vec reads 120 entries
   __syncthreads();
-  int adapt_left = qs.adaptive_rho_interval, check_left = qs.check_termination;
-  if (chol_ok) {
-    for (iter = 1; iter <= qs.max_iter; ++iter) {
+  // One ADMM iteration (three barriers).  STORE = this is the last iteration before a termination check: the
+  // rows also store delta_y (the infeasibility certificate reads it).  The iterations between two checks run in an
+  // inner loop of their own whose body is only this lambda, so that nothing of the check / refactorisation code is
+  // live in it (register allocation of the hot loop: no SGPR spill traffic).
+  auto iteration = [&](auto store_tag) __attribute__((always_inline)) {
+      constexpr bool STORE = decltype(store_tag)::value;
       // (a) rhs_j = sigma x_j - q_j + sum_rows A[r][j] (rho_r z_r - y_r)
-      bool do_adapt = false, do_check = false;  // iter % interval == 0, kept as countdowns
-      if (qs.adaptive_rho_interval > 0 && --adapt_left == 0) {
-        do_adapt   = true;
-        adapt_left = qs.adaptive_rho_interval;
-      }
-      if (qs.check_termination > 0 && --check_left == 0) {
-        do_check   = true;
-        check_left = qs.check_termination;
-      }
       if constexpr (FAST) {
         if (!(ablate & 1) && ccol) {
           double w[2];
@@ -1081,7 +1217,7 @@ __device__ __forceinline__ void qp_solve_agent(const SogmPlannerParams &pp, cons
             g_y             = g_y + d;
             if (grow) {
               h_gw[t] = __builtin_fma(g_rho, v, -g_y);
-              if (do_check || iter == qs.max_iter) R.gdy[t] = d;
+              if constexpr (STORE) R.gdy[t] = d;
             }
           } else {  // waves 4-7: up to four safety rows per lane
             double xs[4][3];
@@ -1111,14 +1247,13 @@ __device__ __forceinline__ void qp_solve_agent(const SogmPlannerParams &pp, cons
               const int sr    = (t - 256) + 256 * u;
               if (sr < S) {
                 h_sw[sr] = __builtin_fma(rho_cur, v, -yn);
-                if (do_check || iter == qs.max_iter) R.sdy[sr] = d;
+                if constexpr (STORE) R.sdy[sr] = d;
               }
             }
           }
           xj = __builtin_fma(alpha, xtj, oma * xj);
         }
         __syncthreads();
-        if (do_adapt || do_check) fast_spill();
       } else {
       if (!(ablate & 4))
       for (int r = tid; r < G; r += QP_NT) {
@@ -1160,19 +1295,47 @@ __device__ __forceinline__ void qp_solve_agent(const SogmPlannerParams &pp, cons
       for (int j = tid; j < n; j += QP_NT) s_x[j] = alpha * xtv[j] + (1.0 - alpha) * s_x[j];
       __syncthreads();
       }
-      if (do_check || do_adapt) residuals();
+  };
+  int adapt_left = qs.adaptive_rho_interval, check_left = qs.check_termination;
+  bool finished = !chol_ok;
+  if (chol_ok) {
+    const int max_iter = qs.max_iter, adapt_iv = qs.adaptive_rho_interval, check_iv = qs.check_termination;
+    while (iter < max_iter) {
+      // iterations up to the next check / rho update (iter % interval == 0), the last one storing delta_y
+      int chunk = max_iter - iter;
+      if (adapt_iv > 0 && adapt_left < chunk) chunk = adapt_left;
+      if (check_iv > 0 && check_left < chunk) chunk = check_left;
+#pragma unroll 1
+      for (int k = 1; k < chunk; ++k) iteration(std::false_type{});
+      iteration(std::true_type{});
+      iter += chunk;
+      adapt_left -= chunk;
+      check_left -= chunk;
+      const bool do_adapt = adapt_iv > 0 && adapt_left == 0, do_check = check_iv > 0 && check_left == 0;
+      if (do_adapt) adapt_left = adapt_iv;
+      if (do_check) check_left = check_iv;
+      if (!do_adapt && !do_check) continue;  // (only when max_iter ended the chunk)
+      if constexpr (FAST) {
+        fast_spill();
+        fast_residuals();
+      } else {
+        residuals();
+      }
       if (do_check) {
         const double eps_prim = qs.eps_abs + qs.eps_rel * dmax(s_sc[1], s_sc[2]);
         const double eps_dual =
             qs.eps_abs + qs.eps_rel * cinv * dmax(dmax(s_sc[4], s_sc[5]), s_sc[6]);
         const bool p_ok = s_sc[0] < eps_prim, d_ok = s_sc[3] < eps_dual;
         if (p_ok && d_ok) {
-          status = 1;
+          status   = 1;
+          finished = true;
           break;
         }
         if (ablate & 16) continue;  // profiling aid (ablation build only)
+        if ((ablate & 256) && !p_ok) continue;
         if (!p_ok && primal_infeasible(1e-4)) {  // eps_prim_inf default
-          status = -3;
+          status   = -3;
+          finished = true;
           break;
         }
       }
@@ -1188,7 +1351,8 @@ __device__ __forceinline__ void qp_solve_agent(const SogmPlannerParams &pp, cons
           rinv_cur = 1.0 / rho_cur;
           set_rho();
           if (!factor()) {
-            status = -7;
+            status   = -7;
+            finished = true;
             break;
           }
           if constexpr (FAST) {
@@ -1199,10 +1363,13 @@ __device__ __forceinline__ void qp_solve_agent(const SogmPlannerParams &pp, cons
         }
       }
     }
-    if (iter > qs.max_iter) {
-      iter = qs.max_iter;
-      if constexpr (FAST) fast_spill();
-      residuals();
+    if (!finished) {  // max_iter reached
+      if constexpr (FAST) {
+        fast_spill();
+        fast_residuals();
+      } else {
+        residuals();
+      }
       const double eps_prim = qs.eps_abs * 10 + qs.eps_rel * 10 * dmax(s_sc[1], s_sc[2]);
       const double eps_dual =
           qs.eps_abs * 10 + qs.eps_rel * 10 * cinv * dmax(dmax(s_sc[4], s_sc[5]), s_sc[6]);
