@@ -1910,6 +1910,81 @@ __device__ __forceinline__ bool deconflict_pair_unsafe(const double *ca, int M, 
   return v == INFINITY || v == -INFINITY;
 }
 
+// The cheap part of deconflict_pair_unsafe with ONE LANE PER RECORD (the dataflow replan's finishing kernel: the
+// wave-per-pair form above walks the swarm table record by record, two dependent global round trips each, and
+// those round trips are the first thing a streaming clear beside it stretches).  Same decisions bit for bit: the
+// activity tests, the bounding boxes and the 11 candidate-normal projections are minima / maxima of the same
+// products, whatever the order.  sA: the agent's nA control points (LDS), boxA lo[3] hi[3], prA[q][2] = (lo, hi) of
+// A's projection on the ten fixed normals.  Returns true when the pair still needs the full test (the LP, or the
+// capacity rule), i.e. whenever deconflict_pair_unsafe would not return false before its LP assembly.
+__device__ inline bool deconflict_prefilter(const double *sA, int nA, const double *boxA, const double (*prA)[2],
+                                            const SogmTrajRecord &r, int ego_id, double now) {
+  const int np = r.n_pieces;
+  if (np <= 0 || r.drone_id == ego_id) return false;
+  const double ts = r.time_start;
+  double       time_end = ts;
+  for (int k = 0; k < np; ++k) time_end += r.duration[k];
+  if (!(ts < now && now < time_end)) return false;
+  double t     = now - ts;
+  int    piece = np - 1;
+  for (int k = 0; k < np; ++k) {
+    t -= r.duration[k];
+    if (t < 0) {
+      piece = k;
+      break;
+    }
+  }
+  const int nB = (np - piece) * 5;
+  if (nA + nB > DECONFLICT_MAX_ROWS) return true;  // the capacity rule (and its counter) live in the full test
+  const double *cb = r.cpts + piece * 15;
+  const double  dirs[10][3] = {{1, 1, 0}, {1, -1, 0}, {1, 0, 1}, {1, 0, -1}, {0, 1, 1},
+                               {0, 1, -1}, {1, 1, 1}, {1, 1, -1}, {1, -1, 1}, {1, -1, -1}};
+  double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+  double plo[10], phi[10];
+#pragma unroll
+  for (int q = 0; q < 10; ++q) {
+    plo[q] = INFINITY;
+    phi[q] = -INFINITY;
+  }
+#pragma unroll 4
+  for (int i = 0; i < nB; ++i) {
+    const double x = cb[i * 3], y = cb[i * 3 + 1], z = cb[i * 3 + 2];
+    lo[0] = fmin(lo[0], x);
+    hi[0] = fmax(hi[0], x);
+    lo[1] = fmin(lo[1], y);
+    hi[1] = fmax(hi[1], y);
+    lo[2] = fmin(lo[2], z);
+    hi[2] = fmax(hi[2], z);
+#pragma unroll
+    for (int q = 0; q < 10; ++q) {
+      const double v = (dirs[q][0] * x + dirs[q][1] * y) + dirs[q][2] * z;
+      plo[q]         = fmin(plo[q], v);
+      phi[q]         = fmax(phi[q], v);
+    }
+  }
+  for (int k = 0; k < 3; ++k)
+    if (boxA[3 + k] < lo[k] || hi[k] < boxA[k]) return false;  // disjoint bounding boxes
+#pragma unroll
+  for (int q = 0; q < 10; ++q)
+    if (prA[q][1] < plo[q] || phi[q] < prA[q][0]) return false;
+  // the line between the box centres
+  double n[3];
+  for (int k = 0; k < 3; ++k) n[k] = 0.5 * (lo[k] + hi[k]) - 0.5 * (boxA[k] + boxA[3 + k]);
+  double loA = INFINITY, hiA = -INFINITY, loB = INFINITY, hiB = -INFINITY;
+  for (int i = 0; i < nA; ++i) {
+    const double v = (n[0] * sA[i * 3] + n[1] * sA[i * 3 + 1]) + n[2] * sA[i * 3 + 2];
+    loA            = fmin(loA, v);
+    hiA            = fmax(hiA, v);
+  }
+  for (int i = 0; i < nB; ++i) {
+    const double v = (n[0] * cb[i * 3] + n[1] * cb[i * 3 + 1]) + n[2] * cb[i * 3 + 2];
+    loB            = fmin(loB, v);
+    hiB            = fmax(hiB, v);
+  }
+  if (hiA < loB || hiB < loA) return false;
+  return true;
+}
+
 __global__ __launch_bounds__(64) void k_safe_after_opt(const double *__restrict__ cpts,
                                                        const int32_t *__restrict__ npoly,
                                                        const SogmTrajRecord *__restrict__ rec, int n_rec,
@@ -1959,8 +2034,71 @@ __global__ __launch_bounds__(64) void k_finish_flow(FlowCtl fc, double corridor_
       const double *ca  = cpts + (size_t)a * SOGM_MAX_PIECES * 15;
       const int     ego = swarm_ego[a];
       const double  now = swarm_now[a];
-      for (int i = 0; i < n_swarm && safe; ++i)
-        if (deconflict_pair_unsafe(ca, M, swarm[i], ego, now, s_lp, s_rows, s_perm, counters)) safe = 0;
+      const int     nA  = 5 * M;
+      // set A once per agent: its points in LDS (the LP scratch is idle until a pair needs the LP), its box and
+      // its projections on the ten fixed normals as wave-uniform values
+      double *sA = s_lp;
+      double  boxA[6], prA[10][2];
+      auto stage_A = [&]() {
+        for (int q = lane; q < nA * 3; q += 64) sA[q] = ca[q];
+        wave_lds_sync();
+      };
+      stage_A();
+      {
+        const double dirs[10][3] = {{1, 1, 0}, {1, -1, 0}, {1, 0, 1}, {1, 0, -1}, {0, 1, 1},
+                                    {0, 1, -1}, {1, 1, 1}, {1, 1, -1}, {1, -1, 1}, {1, -1, -1}};
+        double lo[13], hi[13];
+#pragma unroll
+        for (int k = 0; k < 13; ++k) {
+          lo[k] = INFINITY;
+          hi[k] = -INFINITY;
+        }
+        for (int q = lane; q < nA; q += 64) {
+          const double x = sA[q * 3], y = sA[q * 3 + 1], z = sA[q * 3 + 2];
+          lo[0] = fmin(lo[0], x);
+          hi[0] = fmax(hi[0], x);
+          lo[1] = fmin(lo[1], y);
+          hi[1] = fmax(hi[1], y);
+          lo[2] = fmin(lo[2], z);
+          hi[2] = fmax(hi[2], z);
+#pragma unroll
+          for (int k = 0; k < 10; ++k) {
+            const double v = (dirs[k][0] * x + dirs[k][1] * y) + dirs[k][2] * z;
+            lo[3 + k]      = fmin(lo[3 + k], v);
+            hi[3 + k]      = fmax(hi[3 + k], v);
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < 13; ++k)
+          for (int d = 32; d >= 1; d >>= 1) {
+            lo[k] = fmin(lo[k], __shfl_xor(lo[k], d, 64));
+            hi[k] = fmax(hi[k], __shfl_xor(hi[k], d, 64));
+          }
+        for (int k = 0; k < 3; ++k) {
+          boxA[k]     = lo[k];
+          boxA[3 + k] = hi[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 10; ++k) {
+          prA[k][0] = lo[3 + k];
+          prA[k][1] = hi[3 + k];
+        }
+      }
+      // one lane per record decides whether the pair needs the full test; the few that do go through it one at a
+      // time, in record order (first unsafe pair ends the check, as the sequential loop did)
+      for (int i0 = 0; i0 < n_swarm && safe; i0 += 64) {
+        const int  i    = i0 + lane;
+        const bool need = i < n_swarm && deconflict_prefilter(sA, nA, boxA, prA, swarm[i], ego, now);
+        unsigned long long m = __ballot(need);
+        bool               lp_ran = false;
+        while (m != 0 && safe) {
+          const int j = __builtin_ctzll(m);
+          m &= m - 1;
+          if (deconflict_pair_unsafe(ca, M, swarm[i0 + j], ego, now, s_lp, s_rows, s_perm, counters)) safe = 0;
+          lp_ran = true;
+        }
+        if (lp_ran && safe && i0 + 64 < n_swarm) stage_A();  // the LP used the scratch that held set A
+      }
     }
 #ifdef SOGM_FLOW_DEBUG
     if (lane == 0) out_safe[a] = 101;
