@@ -284,9 +284,15 @@ struct sogm_ctx {
   // on side2 joins it once the word *clear_gate reaches clear_gate_target (the planner's "corridors final" counter:
   // from then on the tick's remaining kernels iterate in LDS); clear_cursor is the chunk counter the two launches
   // share.  clear_gate == nullptr: one launch of fixed width.
+  // The planner registers the gate at creation (dataflow replan).  *clear_epoch_word names the replan in flight: a
+  // replan writes a fresh epoch (clear_epoch) after resetting its counters, the next update writes 0.  The gate only
+  // trusts the counter while the word equals its epoch (a later one: that replan is over, open), and the wide
+  // launch takes chunks only while it does — it retires when the next tick begins, the narrow launch goes on.
   const int          *clear_gate;
   const int          *clear_gate_err;
   int                 clear_gate_target;
+  int                *clear_epoch_word;
+  int                 clear_epoch, clear_epoch_ahead;
   unsigned long long *clear_cursor;
   hipStream_t         side2;  // the wide part's stream
   hipEvent_t          ev_side2_go, ev_side2_done;
@@ -294,6 +300,7 @@ struct sogm_ctx {
   void          *d_filter_box;
   int           *d_filter_blocks;
   int            filter_max_cells;
+  unsigned      *d_stamp_bits;     // [A][ceil(V / 32)] occupancy bits of slice 0 between k_stamp_bits and k_stamp_marks (lazy)
   void          *d_cand;           // [A][1024] candidate cylinders of the stamp (k_cull_cylinders)
   int           *d_ncand;          // [A]
   // trajectory exchange (sogm_traj_allgather): its own stream, ordered against producers / consumers by events
@@ -380,6 +387,7 @@ int  launch_clear(sogm_ctx *c, hipStream_t st, float *grid = nullptr, bool polit
 size_t clear_vec4_total(const sogm_ctx *c);
 // next update's grid becomes current (modes 2 / 3) and the stream waits for its pre-clear
 int  adopt_preclear(sogm_ctx *c, hipStream_t st);
+int  announce_clear_epoch(sogm_ctx *c, hipStream_t st);
 int  queue_spare_clears(sogm_ctx *c, hipEvent_t after);
 }  // namespace sogm
 

@@ -73,28 +73,42 @@ __global__ __launch_bounds__(256) void k_clear_slabs(vfloat4 *__restrict__ p, si
 // next chunk before it stores the current one, so the cursor's round trip hides under the stores.
 #define CLEAR_CHUNK_V4 (size_t)(4u << 20 >> 4)  // 16-byte elements per chunk
 __global__ void k_clear_gate(const unsigned long long *__restrict__ cursor, size_t nchunks,
-                             const int *__restrict__ gate, const int *__restrict__ gate_err, int gate_target) {
+                             const int *__restrict__ gate, const int *__restrict__ gate_err, int gate_target,
+                             const int *__restrict__ epoch_word, int epoch) {
   if (threadIdx.x != 0) return;
-  while (__hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gate_target &&
-         __hip_atomic_load(gate_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 &&
-         __hip_atomic_load(cursor, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nchunks) {
+  for (;;) {
+    if (__hip_atomic_load(cursor, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= nchunks) break;
+    // the replan this clear runs under writes `epoch` after resetting its counters; a later epoch = it is over
+    const int e = __hip_atomic_load(epoch_word, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+    if (e != 0 && e - epoch > 0) break;
+    if (e == epoch && (__hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= gate_target ||
+                       __hip_atomic_load(gate_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0))
+      break;
 #pragma unroll
     for (int i = 0; i < 4; ++i) __builtin_amdgcn_s_sleep(127);  // ~14 us between polls
   }
 }
+__global__ void k_set_word(int *p, int v) { *p = v; }
 template <bool POLITE>
 __global__ __launch_bounds__(256) void k_clear_chunks(vfloat4 *__restrict__ p, size_t n_vec4,
                                                       float *__restrict__ tail, int n_tail,
-                                                      unsigned long long *__restrict__ cursor) {
+                                                      unsigned long long *__restrict__ cursor,
+                                                      const int *__restrict__ epoch_word, int epoch) {
   __shared__ unsigned long long s_next;
   const size_t nchunks = (n_vec4 + CLEAR_CHUNK_V4 - 1) / CLEAR_CHUNK_V4;
-  if (threadIdx.x == 0) s_next = atomicAdd(cursor, 1ull);
+  // the wide launch only streams while the replan it was opened for is in flight (*epoch_word == epoch): once the
+  // next update starts (word reset) its workgroups take no further chunk and the narrow launch finishes alone
+  auto take = [&]() -> unsigned long long {
+    if (!POLITE && __hip_atomic_load(epoch_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) return ~0ull;
+    return atomicAdd(cursor, 1ull);
+  };
+  if (threadIdx.x == 0) s_next = take();
   __syncthreads();
   unsigned long long cur = s_next;
   while (cur < nchunks) {
     __syncthreads();  // everybody holds `cur`
     unsigned long long nxt = 0;
-    if (threadIdx.x == 0) nxt = atomicAdd(cursor, 1ull);  // in flight under the stores below
+    if (threadIdx.x == 0) nxt = take();  // in flight under the stores below
     const size_t b = (size_t)cur * CLEAR_CHUNK_V4;
     const size_t e = b + CLEAR_CHUNK_V4 < n_vec4 ? b + CLEAR_CHUNK_V4 : n_vec4;
     size_t       i = b + threadIdx.x;
@@ -194,13 +208,47 @@ __global__ __launch_bounds__(64) void k_cull_cylinders(GridGeom g, const SogmCyl
   if (lane == 0) n_cand[agent] = kept;  // > SOGM_MAX_CYL_LDS: the stamp falls back to the full list
 }
 
-// One wave per workgroup and no LDS (the candidates come from k_cull_cylinders through L1 / the scalar cache): the
-// scattered marks are throughput-bound on HBM, and small workgroups fill the machine evenly whatever else holds LDS.
-__global__ __launch_bounds__(64) void k_stamp_cloud(GridGeom g, void *__restrict__ grid,
-                                                    const float *__restrict__ cloud,
-                                                    const int32_t *__restrict__ cloud_range,
-                                                    const SogmCylinder *__restrict__ cyl,
-                                                    int n_cyl, const float *__restrict__ poses,
+// The stamp in two passes (one-wave workgroups, no LDS; the candidates come from k_cull_cylinders through L1 / the
+// scalar cache).  The cloud arrives z-fastest (an obstacle generator walks x, y, z), i.e. consecutive points are a
+// whole z-layer apart in the grid, and the T - 1 future marks of a voxel sit a slice (V cells) apart: stamped point
+// by point, every 4-byte mark dirtied a sector of its own (rocprof WRITE_SIZE 8.8 x the marked bytes, r02).  Now
+//   k_stamp_bits   per (agent, cloud point): crop, voxel index, ONE fire-and-forget atomic OR into the agent's
+//                  occupancy bitmask of slice 0 (V bits: on-chip traffic; duplicates — the 0.10 m cloud lattice is
+//                  finer than the 0.15 m voxels — cost nothing more);
+//   k_stamp_marks  per (agent, 64 mask words): lanes take the set bits of a non-zero word — 32 x-consecutive
+//                  voxels — so the slice-0 mark and the T - 1 future marks of neighbouring voxels leave the wave as
+//                  stores to neighbouring addresses of one slice (a few 64-byte lines per instruction instead of one
+//                  line per mark); the velocity lookup runs once per occupied voxel as before; consumed words are
+//                  zeroed for the next update.
+// The set of marked cells is the one the per-point form produced (marks are idempotent, the lookup depends on the
+// voxel only).
+__global__ __launch_bounds__(64) void k_stamp_bits(GridGeom g, const float *__restrict__ cloud,
+                                                   const int32_t *__restrict__ cloud_range,
+                                                   const float *__restrict__ poses, unsigned *__restrict__ bits,
+                                                   int words_per_agent, int agent0) {
+  const int    agent = blockIdx.y + agent0;
+  const int    begin = cloud_range[agent * 2], end = cloud_range[agent * 2 + 1];
+  const float *pose  = poses + agent * 3;
+  const float  p0 = pose[0], p1 = pose[1], p2 = pose[2];
+  // PassThrough limits (fake_particle_risk_voxel.cpp:88-104), fp32
+  const float lox = p0 - g.rx, hix = p0 + g.rx;
+  const float loy = p1 - g.ry, hiy = p1 + g.ry;
+  const float loz = p2 - g.rz, hiz = p2 + g.rz;
+  unsigned   *mask = bits + (size_t)agent * words_per_agent;
+  for (int i = begin + blockIdx.x * blockDim.x + threadIdx.x; i < end; i += gridDim.x * blockDim.x) {
+    const float px = cloud[i * 3], py = cloud[i * 3 + 1], pz = cloud[i * 3 + 2];
+    if (!(px >= lox && px <= hix && py >= loy && py <= hiy && pz >= loz && pz <= hiz)) continue;
+    const float x = px - p0, y = py - p1, z = pz - p2;
+    if (!g.in_range(x, y, z)) continue;
+    const int v = g.voxel_of(x, y, z);
+    __hip_atomic_fetch_or(mask + (v >> 5), 1u << (v & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+__global__ __launch_bounds__(64) void k_stamp_marks(GridGeom g, void *__restrict__ grid,
+                                                    unsigned *__restrict__ bits, int words_per_agent,
+                                                    const SogmCylinder *__restrict__ cyl, int n_cyl,
+                                                    const float *__restrict__ poses,
                                                     const CylCand *__restrict__ cand_all,
                                                     const int *__restrict__ n_cand, int agent0) {
   const int      agent  = blockIdx.y + agent0;
@@ -209,85 +257,99 @@ __global__ __launch_bounds__(64) void k_stamp_cloud(GridGeom g, void *__restrict
   const int      n_lds  = culled ? kept : 0;
   const int      n_loop = culled ? kept : n_cyl;
   const CylCand *cand   = cand_all + (size_t)agent * SOGM_MAX_CYL_LDS;
-
-  const int    begin = cloud_range[agent * 2], end = cloud_range[agent * 2 + 1];
-  const float *pose  = poses + agent * 3;
-  const float  p0 = pose[0], p1 = pose[1], p2 = pose[2];
-  // PassThrough limits (fake_particle_risk_voxel.cpp:88-104), fp32
-  const float lox = p0 - g.rx, hix = p0 + g.rx;
-  const float loy = p1 - g.ry, hiy = p1 + g.ry;
-  const float loz = p2 - g.rz, hiz = p2 + g.rz;
-  char        *base = reinterpret_cast<char *>(grid) + (size_t)agent * g.T * (size_t)g.V * (g.half ? 2 : 4);
-
-  for (int i = begin + blockIdx.x * blockDim.x + threadIdx.x; i < end;
-       i += gridDim.x * blockDim.x) {
-    const float px = cloud[i * 3], py = cloud[i * 3 + 1], pz = cloud[i * 3 + 2];
-    if (!(px >= lox && px <= hix && py >= loy && py <= hiy && pz >= loz && pz <= hiz)) continue;
-    const float x = px - p0, y = py - p1, z = pz - p2;
-    if (!g.in_range(x, y, z)) continue;
-    const int v = g.voxel_of(x, y, z);
-    // slice 0 (:114).  The cloud lattice (0.10 m) is finer than the voxels (0.15 m): several points land in
-    // one voxel, and everything below depends on the voxel only — the first point to mark a voxel of the
-    // freshly cleared slice does the work, the others stop here.
-    if (!g.half) {
-      if (atomicExch(reinterpret_cast<float *>(base) + v, 1.0F) == 1.0F) continue;
-    } else {
-      // fp16 cells: slice 0 holds only 0 or 1.0 (0x3C00) while the cloud is stamped, so OR-ing the bit pattern
-      // into the 32-bit word that holds the cell marks it and tells whether it was marked before
-      const uintptr_t cp  = reinterpret_cast<uintptr_t>(base) + (size_t)v * 2;  // absolute address: odd V safe
-      unsigned      *w    = reinterpret_cast<unsigned *>(cp & ~(uintptr_t)3);
-      const unsigned bits = 0x3C00u << (16 * (int)((cp >> 1) & 1));
-      if ((atomicOr(w, bits) & bits) == bits) continue;
+  const float   *pose   = poses + agent * 3;
+  const float    p0 = pose[0], p1 = pose[1], p2 = pose[2];
+  char          *base = reinterpret_cast<char *>(grid) + (size_t)agent * g.T * (size_t)g.V * (g.half ? 2 : 4);
+  unsigned      *mask = bits + (size_t)agent * words_per_agent;
+  const int      lane = threadIdx.x;
+  // a trip covers 256 mask words (8192 voxels): every lane loads four, the set bits of the whole trip are numbered
+  // by a wave scan of the pop counts, and lane t of chunk b takes set bit b + t — dense lanes whatever the
+  // occupancy pattern, and neighbouring lanes still hold neighbouring voxels (words_per_agent is padded to 256)
+  for (int w0 = blockIdx.x * 256; w0 < words_per_agent; w0 += gridDim.x * 256) {
+    uint4 *wp = reinterpret_cast<uint4 *>(mask + w0) + lane;
+    uint4  w4 = *wp;
+    if ((w4.x | w4.y | w4.z | w4.w) != 0u) *wp = make_uint4(0u, 0u, 0u, 0u);  // consumed: clean for the next update
+    const int c0 = __popc(w4.x), c1 = c0 + __popc(w4.y), c2 = c1 + __popc(w4.z), cnt = c2 + __popc(w4.w);
+    int       inc = cnt;  // inclusive prefix sum over the lanes
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int o = __shfl_up(inc, d, 64);
+      if (lane >= d) inc += o;
     }
-    // The reference then sweeps the occupied voxels of slice 0 (:121-125); every cloud point in
-    // range marks exactly one such voxel and the future marks depend only on the voxel, so the
-    // per-point form produces the same set of (idempotent) stores.
-    float cx, cy, cz;
-    g.corner_of(v, pose, cx, cy, cz);
-    float vx = 0.f, vy = 0.f;
-    for (int c = 0; c < n_loop; ++c) {
-      int    type, orig = c;
-      float  ox, oy, wx, wy;
-      double wlim;
-      if (c < n_lds) {
-        const CylCand cc = cand[c];
-        type = cc.type;
-        orig = cc.orig;
-        ox   = cc.x;
-        oy   = cc.y;
-        wx   = cc.vx;
-        wy   = cc.vy;
-        wlim = cc.wlim;
-      } else {
-        type = cyl[c].type;
-        ox   = (float)cyl[c].x;
-        oy   = (float)cyl[c].y;
-        wx   = (float)cyl[c].vx;
-        wy   = (float)cyl[c].vy;
-        wlim = cyl[c].w + (double)g.clearance;
+    const int excl  = inc - cnt;
+    const int total = __shfl(inc, 63, 64);
+    for (int b0 = 0; b0 < total; b0 += 64) {  // uniform
+      const int  i      = b0 + lane;
+      const bool active = i < total;
+      // owner lane: the last one whose exclusive prefix is <= i (binary search with lane reads; lanes with no set
+      // bit share their successor's prefix and lose the comparison)
+      int lo = 0, hi = 63;
+#pragma unroll
+      for (int it = 0; it < 6; ++it) {
+        const int mid = (lo + hi + 1) >> 1;
+        const int em  = __shfl(excl, mid, 64);
+        if (em <= i) lo = mid; else hi = mid - 1;
       }
-      if (type == 2) {  // ring (:137-149)
-        if (ring_contains(cyl[orig], cx, cy, cz, g.res)) {
+      const int      own = lo;
+      const int      r   = i - __shfl(excl, own, 64);  // rank of the bit among the owner's 128
+      const unsigned q0 = (unsigned)__shfl((int)w4.x, own, 64), q1 = (unsigned)__shfl((int)w4.y, own, 64);
+      const unsigned q2 = (unsigned)__shfl((int)w4.z, own, 64), q3 = (unsigned)__shfl((int)w4.w, own, 64);
+      const int      k0 = __shfl(c0, own, 64), k1 = __shfl(c1, own, 64), k2 = __shfl(c2, own, 64);
+      if (!active) continue;
+      const int sel = r < k0 ? 0 : r < k1 ? 1 : r < k2 ? 2 : 3;
+      unsigned  wv  = sel == 0 ? q0 : sel == 1 ? q1 : sel == 2 ? q2 : q3;
+      int       rr  = r - (sel == 0 ? 0 : sel == 1 ? k0 : sel == 2 ? k1 : k2);
+      while (rr-- > 0) wv &= wv - 1;  // drop the lower set bits
+      const int v = (w0 + own * 4 + sel) * 32 + __builtin_ctz(wv);
+      // slice 0 (:114), then the occupied voxel's future marks (:121-170): GT velocity of the first matching record
+      cell_st(base, (size_t)v, 1.0F, g.half);
+      float cx, cy, cz;
+      g.corner_of(v, pose, cx, cy, cz);
+      float vx = 0.f, vy = 0.f;
+      for (int c = 0; c < n_loop; ++c) {
+        int    type, orig = c;
+        float  ox, oy, wx, wy;
+        double wlim;
+        if (c < n_lds) {
+          const CylCand cc = cand[c];
+          type = cc.type;
+          orig = cc.orig;
+          ox   = cc.x;
+          oy   = cc.y;
+          wx   = cc.vx;
+          wy   = cc.vy;
+          wlim = cc.wlim;
+        } else {
+          type = cyl[c].type;
+          ox   = (float)cyl[c].x;
+          oy   = (float)cyl[c].y;
+          wx   = (float)cyl[c].vx;
+          wy   = (float)cyl[c].vy;
+          wlim = cyl[c].w + (double)g.clearance;
+        }
+        if (type == 2) {  // ring (:137-149)
+          if (ring_contains(cyl[orig], cx, cy, cz, g.res)) {
+            vx = wx;
+            vy = wy;
+            break;
+          }
+          continue;
+        }
+        if (type != 3) continue;  // unknown type: the reference prints a warning and goes on (:150-152)
+        const float dx = cx - ox, dy = cy - oy, dz = cz - cz;
+        const float dist = sqrtf(dx * dx + dy * dy + dz * dz);
+        if ((double)dist <= wlim) {
           vx = wx;
           vy = wy;
           break;
         }
-        continue;
       }
-      if (type != 3) continue;  // unknown type: the reference prints a warning and goes on (:150-152)
-      const float dx = cx - ox, dy = cy - oy, dz = cz - cz;
-      const float dist = sqrtf(dx * dx + dy * dy + dz * dz);
-      if ((double)dist <= wlim) {
-        vx = wx;
-        vy = wy;
-        break;
+      for (int k = 1; k < g.T; ++k) {
+        const float fx = (cx + (vx * g.dt) * (float)k) - p0;
+        const float fy = (cy + (vy * g.dt) * (float)k) - p1;
+        const float fz = (cz + (0.0F * g.dt) * (float)k) - p2;
+        if (g.in_range(fx, fy, fz)) cell_st(base, (size_t)k * g.V + g.voxel_of(fx, fy, fz), 1.0F, g.half);
       }
-    }
-    for (int k = 1; k < g.T; ++k) {
-      const float fx = (cx + (vx * g.dt) * (float)k) - p0;
-      const float fy = (cy + (vy * g.dt) * (float)k) - p1;
-      const float fz = (cz + (0.0F * g.dt) * (float)k) - p2;
-      if (g.in_range(fx, fy, fz)) cell_st(base, (size_t)k * g.V + g.voxel_of(fx, fy, fz), 1.0F, g.half);
     }
   }
 }
@@ -651,6 +713,28 @@ int adopt_preclear(sogm_ctx *c, hipStream_t st) {
     c->d_grid              = c->pool[nxt];
     SOGM_HIP_CHECK(hipStreamWaitEvent(st, c->pool_ev[nxt], 0));
     c->precleared = c->n_ready > 0;
+    static int early = -1;
+    if (early < 0) {
+      const char *e = getenv("SOGM_CLEAR_EARLY");
+      early         = e ? atoi(e) : 0;
+    }
+    if (c->clear_gate) {
+      // a new tick: wide clear workgroups opened for the replan that just ended retire (the stamp, the searches and
+      // the corridor stage want the memory pipeline responsive), the narrow launch goes on
+      hipLaunchKernelGGL(k_set_word, dim3(1), dim3(1), 0, st, c->clear_epoch_word, 0);
+      SOGM_HIP_CHECK(hipGetLastError());
+    }
+    if (c->clear_gate && early) {
+      // tuning aid (SOGM_CLEAR_EARLY=1): queue the clear of the swapped-out grid NOW, under the stamp — its readers,
+      // the previous replan's kernels, are complete on `st` in stream order — for the replan that will announce
+      // epoch clear_epoch + 1.  Measured: the stamp beside it takes twice as long (1.4 -> 3.1 ms) and the first
+      // ticks of a flight lose 5 %; later ticks gain 3 %.  Off by default.
+      c->clear_epoch_ahead = 1;
+      SOGM_HIP_CHECK(hipEventRecord(c->ev_grid_free, st));
+      const int rc         = queue_spare_clears(c, c->ev_grid_free);
+      c->clear_epoch_ahead = 0;
+      return rc;
+    }
     return SOGM_OK;
   }
   SOGM_HIP_CHECK(hipStreamWaitEvent(st, c->ev_cleared, 0));
@@ -725,7 +809,7 @@ int launch_clear(sogm_ctx *c, hipStream_t st, float *grid, bool polite, int part
     e             = getenv("SOGM_CLEAR_NT");
     nt            = e ? atoi(e) != 0 : 1;
   }
-  const size_t max_wgs  = env_wgs ? (size_t)env_wgs : (polite ? 64 : 2048);
+  const size_t max_wgs  = env_wgs ? (size_t)env_wgs : (polite ? (c->clear_gate && part == 0 ? 80 : 64) : 2048);
   const int    throttle = env_wgs ? env_throttle : (polite ? 4 : 0);
   const int    nblk     = (int)(want < 1 ? 1 : (want > max_wgs ? max_wgs : want));
   static int   wide_wgs = -1;
@@ -739,12 +823,13 @@ int launch_clear(sogm_ctx *c, hipStream_t st, float *grid, bool polite, int part
     SOGM_HIP_CHECK(hipEventRecord(c->ev_side2_go, st));
     SOGM_HIP_CHECK(hipStreamWaitEvent(c->side2, c->ev_side2_go, 0));
     prof_begin(c, slot, st);
+    const int epoch = c->clear_epoch + c->clear_epoch_ahead;
     hipLaunchKernelGGL(k_clear_chunks<true>, dim3(nblk), dim3(256), 0, st, (vfloat4 *)grid, nall, grid + nall * 4,
-                       tail, c->clear_cursor);
+                       tail, c->clear_cursor, c->clear_epoch_word, epoch);
     hipLaunchKernelGGL(k_clear_gate, dim3(1), dim3(64), 0, c->side2, c->clear_cursor, nchunks, c->clear_gate,
-                       c->clear_gate_err, c->clear_gate_target);
+                       c->clear_gate_err, c->clear_gate_target, c->clear_epoch_word, epoch);
     hipLaunchKernelGGL(k_clear_chunks<false>, dim3(wide_wgs), dim3(256), 0, c->side2, (vfloat4 *)grid, nall,
-                       grid + nall * 4, 0, c->clear_cursor);
+                       grid + nall * 4, 0, c->clear_cursor, c->clear_epoch_word, epoch);
     SOGM_HIP_CHECK(hipEventRecord(c->ev_side2_done, c->side2));
     SOGM_HIP_CHECK(hipStreamWaitEvent(st, c->ev_side2_done, 0));  // the clear is complete when both launches are
     prof_end(c, slot, st);
@@ -759,6 +844,13 @@ int launch_clear(sogm_ctx *c, hipStream_t st, float *grid, bool polite, int part
     hipLaunchKernelGGL(k_clear_slabs<false>, dim3(nblk), dim3(256), 0, st, (vfloat4 *)grid + first, nv4,
                        grid + nall * 4, tail, throttle);
   prof_end(c, slot, st);
+  SOGM_HIP_CHECK(hipGetLastError());
+  return SOGM_OK;
+}
+
+int announce_clear_epoch(sogm_ctx *c, hipStream_t st) {
+  if (++c->clear_epoch <= 0) c->clear_epoch = 1;  // 0 = "no replan in flight"
+  hipLaunchKernelGGL(k_set_word, dim3(1), dim3(1), 0, st, c->clear_epoch_word, c->clear_epoch);
   SOGM_HIP_CHECK(hipGetLastError());
   return SOGM_OK;
 }
@@ -839,6 +931,7 @@ void sogm_destroy(sogm_ctx *c) {
   if (c->d_body) (void)hipFree(c->d_body);
   if (c->d_scratch_vt) (void)hipFree(c->d_scratch_vt);
   if (c->d_cand) (void)hipFree(c->d_cand);
+  if (c->d_stamp_bits) (void)hipFree(c->d_stamp_bits);
   if (c->d_ncand) (void)hipFree(c->d_ncand);
   if (c->d_filter_cells) (void)hipFree(c->d_filter_cells);
   if (c->d_filter_box) (void)hipFree(c->d_filter_box);
@@ -1017,8 +1110,15 @@ static int update_gt_impl(sogm_ctx *c, const float *cloud_xyz, const int32_t *cl
   prof_begin(c, SOGM_PROF_STAMP, st);
   hipLaunchKernelGGL(k_cull_cylinders, dim3(A), dim3(64), 0, st, c->geom, cylinders, n_cyl, c->d_poses,
                      (CylCand *)c->d_cand, c->d_ncand);
-  hipLaunchKernelGGL(k_stamp_cloud, dim3(stamp_wgs, A), dim3(64), 0, st, c->geom, (void *)c->d_grid, cloud_xyz,
-                     cloud_range, cylinders, n_cyl, c->d_poses, (const CylCand *)c->d_cand, (const int *)c->d_ncand, 0);
+  const int words = (((c->geom.V + 31) / 32) + 255) & ~255;  // k_stamp_marks reads 256 words per trip
+  if (!c->d_stamp_bits) {
+    SOGM_HIP_CHECK(hipMalloc((void **)&c->d_stamp_bits, sizeof(unsigned) * (size_t)words * A));
+    SOGM_HIP_CHECK(hipMemsetAsync(c->d_stamp_bits, 0, sizeof(unsigned) * (size_t)words * A, st));
+  }
+  hipLaunchKernelGGL(k_stamp_bits, dim3(stamp_wgs, A), dim3(64), 0, st, c->geom, cloud_xyz, cloud_range, c->d_poses,
+                     c->d_stamp_bits, words, 0);
+  hipLaunchKernelGGL(k_stamp_marks, dim3(stamp_wgs, A), dim3(64), 0, st, c->geom, (void *)c->d_grid, c->d_stamp_bits,
+                     words, cylinders, n_cyl, c->d_poses, (const CylCand *)c->d_cand, (const int *)c->d_ncand, 0);
   prof_end(c, SOGM_PROF_STAMP, st);
   SOGM_HIP_CHECK(hipGetLastError());
   if (fused && n_records > 0) {

@@ -204,6 +204,8 @@ int sogm_planner_create(sogm_ctx *map, const SogmAstarParams *astar, const SogmP
       if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_fdone[k], hipEventDisableTiming);
     }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_gate, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipMalloc((void **)&p->d_epoch, sizeof(int));
+    if (e == hipSuccess) e = hipMemset(p->d_epoch, 0, sizeof(int));
     if (e == hipSuccess) e = hipHostMalloc((void **)&p->h_flow_fail, sizeof(int) * 2, hipHostMallocMapped);
     if (e == hipSuccess) p->h_flow_fail[0] = p->h_flow_fail[1] = 0;
   }
@@ -212,18 +214,28 @@ int sogm_planner_create(sogm_ctx *map, const SogmAstarParams *astar, const SogmP
     sogm_planner_destroy(p);
     return SOGM_ERR_HIP;
   }
+  if (p->flow) {  // the map's pooled clear follows this planner's "corridors final" counter (sogm_device.hpp)
+    map->clear_gate        = p->fc.hdr + FLOW_Q_READY_N;
+    map->clear_gate_err    = p->fc.hdr + FLOW_ERR;
+    map->clear_gate_target = A;
+    map->clear_epoch_word  = p->d_epoch;
+  }
   *out = p;
   return SOGM_OK;
 }
 void sogm_planner_destroy(sogm_planner *p) {
   if (!p) return;
+  if (p->map && p->d_epoch && p->map->clear_epoch_word == p->d_epoch) {
+    (void)hipDeviceSynchronize();  // a gate kernel may still be polling this planner's words
+    p->map->clear_gate = p->map->clear_gate_err = p->map->clear_epoch_word = nullptr;
+  }
   void *ptrs[] = {p->aw.pool, p->aw.hkeys, p->aw.dbg, p->aw.verdict,
                   p->d_ret,   p->d_route_len, p->d_stats, p->d_route,
                   p->cw.pc,   p->cw.fpc,  p->cw.tang, p->cw.distr, p->cw.polys,
                   p->cw.seg_nfaces, p->cw.seg_state, p->cw.seg_npts, p->cw.seg_dbg, p->cw.counters,
                   p->qw.scratch,
                   p->d_polys, p->d_goal, p->d_cpts, p->d_nfaces, p->d_npoly, p->d_status, p->d_iters,
-                  p->d_safe,  p->d_flow, p->d_flow_ts};
+                  p->d_safe,  p->d_flow, p->d_flow_ts, p->d_epoch};
   for (void *q : ptrs)
     if (q) (void)hipFree(q);
   for (int g = 0; g < SOGM_MAX_GROUPS; ++g) {
@@ -445,12 +457,13 @@ static int replan_flow(sogm_planner *p, const double *start_pva, const double *g
   SOGM_HIP_CHECK(hipMemsetAsync(out_records, 0, sizeof(SogmTrajRecord) * (size_t)A, main));
   SOGM_HIP_CHECK(hipEventRecord(p->ev_in, main));
   if (c->overlap >= 2) {
-    // the side-stream clear goes wide once every agent's corridors are final (FLOW_Q_READY_N == A)
-    c->clear_gate        = p->fc.hdr + FLOW_Q_READY_N;
-    c->clear_gate_err    = p->fc.hdr + FLOW_ERR;
-    c->clear_gate_target = A;
-    int rc               = sogm::queue_spare_clears(c, p->ev_in);
-    c->clear_gate        = nullptr;
+    // the side-stream clear of the grid this tick's update swapped out: narrow, with a wide second launch that joins
+    // once every agent's corridors are final (FLOW_Q_READY_N == A, registered as the gate at planner creation) —
+    // announce this replan's epoch now that the counters are reset
+    if (c->clear_gate) {
+      if (int rc = sogm::announce_clear_epoch(c, main)) return rc;
+    }
+    int rc = sogm::queue_spare_clears(c, p->ev_in);  // grids still dirty (first ticks, pool changes)
     if (rc) return rc;
   }
   for (int k = 0; k < 4; ++k) SOGM_HIP_CHECK(hipStreamWaitEvent(p->fstream[k], p->ev_in, 0));

@@ -152,6 +152,7 @@ struct sogm_planner {
   sogm::FlowCtl  fc;
   hipStream_t    fstream[4];  // A*, corridors, QP, finish
   hipEvent_t     ev_gate, ev_fdone[4];
+  int           *d_epoch;      // device word: the clear epoch of the replan in flight (sogm_ctx::clear_epoch_word)
   int           *h_flow_fail;  // pinned, device-visible: {last FLOW_ERR code, ticks that failed} (k_flow_report)
   // per-object use of the per-stage entries (sogm_planner_select_agents / _set_search_mode)
   int sel_first, sel_count;  // agents the per-stage entries process; (0, A) by default
