@@ -22,7 +22,9 @@
 #include <rccl/rccl.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 
 #include "sogm_device.hpp"
@@ -41,15 +43,18 @@ struct RcclApi {
 };
 
 RcclApi *rccl() {
-  static RcclApi api;
-  static int     state = 0;  // 0 untried, 1 ok, -1 failed
-  if (state == 0) {
-    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  static RcclApi        api;
+  static int            state = -1;  // 1 ok, -1 failed
+  static std::once_flag once;        // several contexts / host threads may reach the first collective together
+  std::call_once(once, [] {
+    // SOGM_RCCL_LIB names the library to load instead (tests substitute an in-process stand-in for RCCL whose
+    // collectives take a visible amount of time: tests/fake_rccl.cpp)
+    const char *names[] = {getenv("SOGM_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     for (const char *n : names) {
+      if (!n || !*n) continue;
       api.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
       if (api.handle) break;
     }
-    state = -1;
     if (api.handle) {
       api.GetUniqueId    = (decltype(api.GetUniqueId))dlsym(api.handle, "ncclGetUniqueId");
       api.CommInitRank   = (decltype(api.CommInitRank))dlsym(api.handle, "ncclCommInitRank");
@@ -62,7 +67,7 @@ RcclApi *rccl() {
           api.AllGather && api.GetErrorString)
         state = 1;
     }
-  }
+  });
   return state == 1 ? &api : nullptr;
 }
 
@@ -155,9 +160,11 @@ int sogm_traj_allgather(sogm_ctx *ctx, void *nccl_comm, const SogmTrajRecord *lo
   SOGM_HIP_CHECK(hipStreamWaitEvent(ctx->xstream, ctx->ev_xin, 0));
   ncclResult_t r = a->AllGather(local_records, all_records, (size_t)n_local * sizeof(SogmTrajRecord), ncclUint8,
                                 (ncclComm_t)nccl_comm, ctx->xstream);
-  if (r != ncclSuccess) return rccl_fail("ncclAllGather", r);
+  // (recorded even when the collective failed: consumers stay ordered behind the producers on the exchange stream
+  //  instead of behind the previous collective's event)
   SOGM_HIP_CHECK(hipEventRecord(ctx->ev_xdone, ctx->xstream));
   ctx->exchange_pending = 1;
+  if (r != ncclSuccess) return rccl_fail("ncclAllGather", r);
   return SOGM_OK;
 }
 

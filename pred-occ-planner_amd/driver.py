@@ -343,6 +343,9 @@ class SwarmTick:
             self.status, self.fail, self.traj_start, self.success, now, due_new, is_rep, ok, safe, reached)
         hover = hover_records(self.dev["ego_ids"], hover_start, pva_now[:, :3])
         self.own = torch.where(pub_new.unsqueeze(1), self.new, torch.where(pub_hover.unsqueeze(1), hover, self.own))
+        # what this FSMCallback saw and did (device tensors; tests compare them with oracle/fsm_oracle.cpp)
+        self.last_fsm = {"now": stamp, "ok": ok, "safe": safe, "reached": reached, "pub_new": pub_new,
+                         "pub_hover": pub_hover, "hover_start": hover_start, "t_start": t_start, "pos": pva_now[:, :3]}
         self._exchange()
         self.tick += 1
         return ok.to(torch.int32)

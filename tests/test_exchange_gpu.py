@@ -50,3 +50,125 @@ def test_allgather_world1_and_consumer_ordering(pop, orc):
     torch.cuda.synchronize()
     lib.sogm_comm_destroy(comm)
     m.close()
+
+
+def test_swarm_tick_under_a_one_rank_process_group_takes_the_abi_exchange(pop):
+    """driver.SwarmTick under torch.distributed (backend nccl = RCCL, world size 1): the communicator comes through
+    sogm_comm_* with the id broadcast from rank 0, every tick's records travel through sogm_traj_allgather on the
+    exchange stream, and the flight — ok flags and records of 5 ticks — is the one the process-group-less run gives."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    driver = importlib.import_module("pred-occ-planner_amd.driver")
+
+    def flight(d):
+        sw = driver.SwarmTick("parity", 6, 0, 1, 0, dist=d)
+        oks = [sw.step().cpu().numpy().copy() for _ in range(5)]
+        table = sw.records_all().cpu().numpy().copy()
+        info = (sw.exchange.active, sw.exchange.fallback_reason, sw.distributed)
+        sw.close()
+        return oks, table, info
+
+    ref_oks, ref_table, ref_info = flight(None)
+    assert ref_info == (False, None, False)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        oks, table, info = flight(dist)
+    finally:
+        dist.destroy_process_group()
+    assert info == (True, None, True)
+    assert all(np.array_equal(a, b) for a, b in zip(oks, ref_oks)) and sum(int(o.sum()) for o in oks) >= 12
+    assert np.array_equal(table, ref_table)
+
+
+_TWO_RANK_SCRIPT = r"""
+import ctypes as C, importlib, os, sys, threading
+import numpy as np, torch
+sys.path.insert(0, os.environ["SOGM_REPO"])
+pop = importlib.import_module("pred-occ-planner_amd")
+sogm = importlib.import_module("pred-occ-planner_amd.sogm")
+abi, lib = pop._abi, pop.lib()
+WORLD, A_LOC, TICKS = 2, 3, 4
+spec = pop.config.make_spec("parity")
+ident = C.create_string_buffer(abi.SOGM_COMM_ID_BYTES)
+abi.check(lib.sogm_comm_unique_id(ident), "unique_id")
+assert ident.raw.startswith(b"fake-rccl-"), ident.raw[:16]          # the stand-in, not torch's RCCL
+# per tick and rank: distinct records (drone ids = global agent index, time_start = tick)
+def make(tick, rank):
+    sc = pop.scene.make_scene(WORLD * A_LOC, 4.95, seed=100 + tick)
+    sc["stamps"] = np.full(WORLD * A_LOC, float(tick))
+    recs = pop.scene.straight_records(sc)
+    b = np.frombuffer(bytes(recs), dtype=np.uint8).reshape(WORLD * A_LOC, abi.TRAJ_RECORD_BYTES)
+    return b[rank * A_LOC:(rank + 1) * A_LOC].copy(), b.copy()
+snaps, errs = {}, []
+def run(rank):
+    try:
+        torch.cuda.set_device(0)
+        st = torch.cuda.Stream()
+        m = sogm.SogmMap(spec, A_LOC)
+        comm = C.c_void_p()
+        abi.check(lib.sogm_comm_create(ident.raw, rank, WORLD, 0, C.byref(comm)), "comm_create")
+        handle = lib.sogm_comm_handle(comm)
+        own = torch.zeros((A_LOC, abi.TRAJ_RECORD_BYTES), dtype=torch.uint8, device="cuda")
+        allr = torch.zeros((WORLD * A_LOC, abi.TRAJ_RECORD_BYTES), dtype=torch.uint8, device="cuda")
+        big = torch.zeros(64 << 20, dtype=torch.float32, device="cuda")
+        out = []
+        with torch.cuda.stream(st):
+            for tick in range(TICKS):
+                mine, _ = make(tick, rank)
+                src = torch.from_numpy(mine).cuda()
+                for _ in range(4):
+                    big.add_(1.0)                     # a slow producer: the local records land ~1 ms after the call
+                own.copy_(src)
+                abi.check(lib.sogm_traj_allgather(m.ctx, handle, own.data_ptr(), A_LOC, allr.data_ptr(),
+                                                  C.c_void_p(st.cuda_stream)), "allgather")
+                # consumer on the caller's stream, ordered inside the library only (no host / stream sync here)
+                if not os.environ.get("SOGM_TEST_SKIP_CONSUMER_WAIT"):   # (negative control: see the test below)
+                    abi.check(lib.sogm_exchange_wait(m.ctx, C.c_void_p(st.cuda_stream)), "exchange_wait")
+                out.append(allr.clone())
+        st.synchronize()
+        snaps[rank] = [o.cpu().numpy() for o in out]
+        torch.cuda.synchronize()
+        lib.sogm_comm_destroy(comm)
+        m.close()
+    except Exception as e:  # noqa: BLE001
+        errs.append((rank, repr(e)))
+ts = [threading.Thread(target=run, args=(r,)) for r in range(WORLD)]
+[t.start() for t in ts]
+[t.join(120) for t in ts]
+assert not errs, errs
+assert not any(t.is_alive() for t in ts), "a rank hung in the collective"
+for tick in range(TICKS):
+    _, want = make(tick, 0)
+    for r in range(WORLD):
+        assert np.array_equal(snaps[r][tick], want), (tick, r)
+print("two-rank exchange ok")
+"""
+
+
+def test_allgather_two_ranks_event_ordering_against_a_slow_collective(pop, tmp_path):
+    """sogm_traj_allgather with TWO ranks and a collective that is not a no-op: tests/fake_rccl.cpp (an in-process
+    stand-in for librccl, two host threads = two ranks on one GPU, loaded through SOGM_RCCL_LIB) moves the bytes on
+    the exchange streams behind a 1 ms spin.  The producer is slow too, so a collective that did not wait for the
+    caller's stream would gather the previous tick's records, and a consumer not ordered behind the completion event
+    would read the previous tick's table: 4 ticks, both ranks must see exactly the table of each tick."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = tmp_path / "libfake_rccl.so"
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-std=c++17", "-shared", "-fPIC",
+                           os.path.join(root, "tests", "fake_rccl.cpp"), "-o", str(so)])
+    env = dict(os.environ, SOGM_RCCL_LIB=str(so), SOGM_REPO=root)
+    r = subprocess.run([sys.executable, "-c", _TWO_RANK_SCRIPT], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "two-rank exchange ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+    # negative control: the same flight with the consumer NOT ordered behind the collective must read stale tables —
+    # i.e. the stand-in's collective really is slow enough for this test to see a missing wait
+    env["SOGM_TEST_SKIP_CONSUMER_WAIT"] = "1"
+    r = subprocess.run([sys.executable, "-c", _TWO_RANK_SCRIPT], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "AssertionError" in r.stderr and "two-rank exchange ok" not in r.stdout

@@ -89,8 +89,22 @@ def _tick_with_parity(pop, orc, sw, agents, check_grid_cells=True):
                 stats["worst_dx"] = max(stats["worst_dx"], d)
                 stats["qp_ok"] += 1
         stats["agents"] += 1
-    # advance the closed loop exactly like SwarmTick.step()
+    # advance the closed loop exactly like SwarmTick.step() — and hold the fused sogm_replan (dataflow kernels) to
+    # the staged entry points just checked against the oracle: same ok flag, same record, bit for bit
+    safe = P.isSafeAfterOpt(q["cpts"], c["npoly"], sw.all, sw.A_tot, sw.dev["ego_ids"], sw.now).cpu().numpy()
     P.replan(pva, sw.goals, t_start, sw.dev["ego_ids"], sw.new, sw.ok)
+    new = planner.records_from_bytes(sw.new.cpu().numpy())
+    okf = sw.ok.cpu().numpy()
+    stats["fused_checked"] = 0
+    for a in agents:
+        M = int(cn["npoly"][a])
+        want_ok = bool(sn["ret"][a] != 0 and M > 0 and qn["status"][a] in (1, 2) and safe[a] != 0)
+        assert bool(okf[a]) == want_ok, (sw.tick, a, okf[a], sn["ret"][a], M, qn["status"][a], safe[a])
+        assert new[a].n_pieces == (M if want_ok else 0) and new[a].drone_id == int(ego[a])
+        if want_ok:
+            assert np.array_equal(np.array(new[a].cpts[:15 * M]), qn["cpts"][a, :15 * M]), (sw.tick, a)
+            assert list(new[a].duration[:M]) == [pp.corridor_tau] * M and new[a].time_start == float(ts[a])
+        stats["fused_checked"] += 1
     sw.own = driver.merge_latest(sw.new, sw.own, sw.ok)
     driver.exchange_records(sw.own, sw.all, sw.dist, sw.world)
     sw.tick += 1
@@ -114,6 +128,55 @@ def test_cfg2_bench_scene_chain_parity(pop, orc):
         _sum(acc, _tick_with_parity(pop, orc, sw, agents, check_grid_cells=(sw.tick == 0)))
     print("cfg2:", acc)
     assert acc["agents"] == 24 and acc["expansions"] > 100 and acc["polys"] > 50 and acc["qp_ok"] >= 16
+    assert acc["fused_checked"] == 24
+    sw.close()
+
+
+def test_cfg2_fused_tick_all_agents_against_oracle_replans(pop, orc):
+    """The configuration the bench runs — SwarmTick.step() itself: 128 agents, pooled grids with the side-stream
+    clear, the dataflow sogm_replan (persistent corridor / QP / finish kernels, speculative second search) — checked
+    against the CPU oracle's full replan (search + corridors + QP + isSafeAfterOpt) for 16 agents spread over the
+    swarm, on the third tick of the flight (agents moving, neighbours' records in the overlay)."""
+    import torch
+    driver = importlib.import_module("pred-occ-planner_amd.driver")
+    planner = importlib.import_module("pred-occ-planner_amd.planner")
+    sw = driver.SwarmTick("cfg2", 128)
+    for _ in range(2):
+        sw.step()
+    all_before = sw.all.clone()
+    sw.step()
+    torch.cuda.synchronize()
+    assert sw.planner.flow_failures() == (0, 0)
+    spec, P = sw.spec, sw.planner
+    pv, ps = sw.pva.cpu().numpy(), sw.poses.cpu().numpy()
+    ts, now = sw.t_start.cpu().numpy(), sw.now.cpu().numpy()
+    goals = sw.goals.cpu().numpy()
+    recs = planner.records_from_bytes(all_before.cpu().numpy())
+    new = planner.records_from_bytes(sw.new.cpu().numpy())
+    okf = sw.ok.cpu().numpy()
+    cloud, crange = sw.dev["cloud"].cpu().numpy(), sw.dev["cloud_range"].cpu().numpy()
+    cyl = pop.scene.cylinders_to_struct(sw.scene["cylinders"])
+    ego = sw.dev["ego_ids"].cpu().numpy()
+    n_ok, worst = 0, 0.0
+    for a in range(3, 128, 8):  # 16 agents
+        g = orc.update_gt(spec, cloud[crange[a, 0]:crange[a, 1]], cyl, len(sw.scene["cylinders"]), ps[a])
+        orc.project_neighbours(spec, g, recs, sw.A_tot, int(ego[a]), sw.map.body, ps[a], float(now[a]))
+        ok, rec, _ = orc.replan(spec, P.ap, P.pp, P.qs, g, ps[a], float(now[a]), pv[a], goals[a], float(ts[a]), int(ego[a]))
+        del g
+        if ok:
+            ok = orc.safe_after_opt(np.asarray(rec.cpts[:15 * rec.n_pieces]), rec.n_pieces, recs, sw.A_tot, int(ego[a]),
+                                    float(now[a]))
+        assert bool(okf[a]) == bool(ok), (a, okf[a], ok)
+        if ok:
+            M = rec.n_pieces
+            assert new[a].n_pieces == M
+            d = float(np.abs(np.array(new[a].cpts[:15 * M]) - np.array(rec.cpts[:15 * M])).max())
+            assert d <= TOL, (a, d)
+            worst, n_ok = max(worst, d), n_ok + 1
+        else:
+            assert new[a].n_pieces == 0
+    print("cfg2 fused vs oracle: ok", n_ok, "of 16, worst |dx|", worst)
+    assert n_ok >= 10
     sw.close()
 
 
