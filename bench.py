@@ -177,6 +177,10 @@ def main():
         raise SystemExit(f"bench.py: {flow_failed} tick(s) of the dataflow replan timed out on the device "
                          f"(code {flow_code}): the timed region is invalid")
     outcomes = sw.planner.counters(reset=True)
+    cap_hits = outcomes["corridor_capacity"] + outcomes["pieces_capacity"] + outcomes["deconflict_capacity"]
+    if cap_hits:  # a replan cut short by a buffer limit is an outcome the reference (growing vectors) cannot have
+        raise SystemExit(f"bench.py: {cap_hits} replans of the timed region hit a capacity limit ({outcomes}): "
+                         "the timed region is invalid")
     if dist is not None:
         t = torch.tensor([n_ok] + [outcomes[k] for k in sorted(outcomes)], dtype=torch.int64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
@@ -292,8 +296,12 @@ def main():
                             "value": sw.A_tot * args.sustained / (tm.sum() * 1e-3),
                             "value_ok": n_ok2 * world / (tm.sum() * 1e-3),
                             "replans_ok_fraction": n_ok2 / float(sw.A_loc * args.sustained),
-                            "outcomes_rank0": sw.planner.counters(reset=True),
+                            "outcomes_rank0": sw.planner.counters(reset=False),
                             "note": "every tick host-synchronised (no overlap between ticks); rank 0's clock"}
+    if args.sustained > 0:
+        c2 = sw.planner.counters(reset=True)
+        if c2["corridor_capacity"] + c2["pieces_capacity"] + c2["deconflict_capacity"]:
+            raise SystemExit(f"bench.py: capacity limits hit during the sustained block ({c2})")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(pop, spec, sw.scene, args.cpu_agents)
     else:

@@ -64,7 +64,7 @@ def make_planner_params(fake=True):
     p.opt_max_acc = 6.0
     p.fake_planner = 1 if fake else 0
     p.firi_iterations = 2
-    p.pc_capacity = 4096
+    p.pc_capacity = 16384  # obstacle points per corridor box (the reference grows its vector, baseline.cpp:317)
     p.max_faces = 64
     return p
 

@@ -1265,9 +1265,11 @@ __device__ __forceinline__ void corridor_segment_body(const MapView &m, const So
   double        *s_fH    = s_lm + 2 * 18 * 9 + 16 + 36;       // FIRI_MAX_H * 4
   double        *s_poly  = s_fH + FIRI_MAX_H * 4;             // FIRI_MAX_H * 4
   double        *s_small = s_poly + FIRI_MAX_H * 4;           // SMALL doubles of shared small state
-  int           *s_perm  = (int *)(s_small + SMALL);          // LP_MAX_ROWS
+  // "point not yet covered" flags of the greedy selection: one BIT per obstacle point, 64 per word — the 64 lanes of
+  // a trip of the point loops share one word, which lane 0 rewrites from a ballot (no atomics, 2 KiB for 16 k points)
+  unsigned long long *s_fw = (unsigned long long *)(s_small + SMALL);  // (pc_capacity + 63) / 64 words
+  int           *s_perm  = (int *)(s_fw + (pp.pc_capacity + 63) / 64);   // LP_MAX_ROWS
   int           *s_int   = s_perm + LP_MAX_ROWS;              // 16 ints
-  unsigned char *s_flag  = (unsigned char *)(s_int + 16);     // pc_capacity bytes
   SolverScratch  sc{s_lp, s_perm, s_rows, s_lm};
 
   // shared small state layout
@@ -1433,7 +1435,10 @@ __device__ __forceinline__ void corridor_segment_body(const MapView &m, const So
           for (int k = 0; k < 3; ++k) fpc[i * 3 + k] = q[k];
           for (int k = 0; k < 4; ++k) tang[i * 4 + k] = t[k];
           distR[i]  = dr;
-          s_flag[i] = 1;
+          {  // every point starts uncovered: the active lanes of this trip are exactly the points i < N of its word
+            const unsigned long long act = __ballot(1);
+            if (lane == 0) s_fw[i >> 6] = act;
+          }
           if (dr < lmin) {
             lmin = dr;
             lidx = i;
@@ -1463,7 +1468,7 @@ __device__ __forceinline__ void corridor_segment_body(const MapView &m, const So
             fh[3] = s_fD[bdMinId];
           } else {
             for (int k = 0; k < 4; ++k) fh[k] = tang[pcMinId * 4 + k];
-            s_flag[pcMinId] = 0;
+            s_fw[pcMinId >> 6] &= ~(1ull << (pcMinId & 63));
           }
           for (int k = 0; k < 4; ++k) s_fh[k] = fh[k];
         }
@@ -1484,10 +1489,12 @@ __device__ __forceinline__ void corridor_segment_body(const MapView &m, const So
         int          li = 0x7fffffff;
         int          open = 0;
         for (int j = lane; j < N; j += 64) {
-          if (s_flag[j]) {
+          const unsigned long long word = s_fw[j >> 6];  // uniform over the trip's lanes
+          bool                     covered = false;
+          if ((word >> lane) & 1ull) {
             const double *q = fpc + j * 3;
             if (((fh0 * q[0] + fh1 * q[1]) + fh2 * q[2]) + fh3 > -epsilon) {
-              s_flag[j] = 0;
+              covered = true;
             } else {
               open = 1;
               if (lm > distR[j]) {
@@ -1496,6 +1503,8 @@ __device__ __forceinline__ void corridor_segment_body(const MapView &m, const So
               }
             }
           }
+          const unsigned long long clr = __ballot(covered);
+          if (clr != 0ull && lane == 0) s_fw[j >> 6] = word & ~clr;
         }
         wave_argmin(lm, li);
         if (__any(open)) completed = false;
@@ -1784,12 +1793,12 @@ __global__ __launch_bounds__(64) void k_corridor_flow(MapView m, SogmPlannerPara
 
 size_t corridor_segment_lds(int pc_capacity) {
   return sizeof(double) * (LP_WORK_DOUBLES + LP_MAX_ROWS * 5 + 2 * 18 * 9 + 16 + 36 + 2 * FIRI_MAX_H * 4 + 96) +
-         sizeof(int) * (LP_MAX_ROWS + 16) + (size_t)pc_capacity;
+         sizeof(int) * (LP_MAX_ROWS + 16) + 8 * (((size_t)pc_capacity + 63) / 64);
 }
 size_t firi_direct_lds(int pc_capacity) {
   return sizeof(double) * (LP_WORK_DOUBLES + LP_MAX_ROWS * 5 + 2 * 18 * 9 + 16 + 36 + 2 * FIRI_MAX_H * 4 +
                            firi_small_doubles<FIRI_DIRECT_BD_MAX>()) +
-         sizeof(int) * (LP_MAX_ROWS + 16) + (size_t)pc_capacity;
+         sizeof(int) * (LP_MAX_ROWS + 16) + 8 * (((size_t)pc_capacity + 63) / 64);
 }
 
 // ------------------------------------------------------------------------------------------------

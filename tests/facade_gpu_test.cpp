@@ -66,7 +66,7 @@ int main() {
   ap.lambda_heu = 5.0; ap.resolution = 0.15; ap.time_resolution = 0.3; ap.allocate_num = 10000; ap.check_num = 1;
   ap.tolerance = 1;
   SogmPlannerParams pp{}; pp.corridor_tau = 0.3; pp.init_range = 1.2; pp.shrink_size = 0.2; pp.opt_max_vel = 3.0;
-  pp.opt_max_acc = 6.0; pp.fake_planner = 1; pp.firi_iterations = 2; pp.pc_capacity = 4096; pp.max_faces = 64;
+  pp.opt_max_acc = 6.0; pp.fake_planner = 1; pp.firi_iterations = 2; pp.pc_capacity = 16384; pp.max_faces = 64;
   SogmQpSettings qs{}; qs.rho = 0.1; qs.sigma = 1e-6; qs.alpha = 1.6; qs.eps_abs = 1e-3; qs.eps_rel = 1e-3;
   qs.max_iter = 4000; qs.check_termination = 25; qs.scaling_iters = 10; qs.adaptive_rho_interval = 25;
   Planner planner(map, ap, pp, qs);
