@@ -540,6 +540,20 @@ int sogm_corridor_generate(sogm_planner *p, const double *start_pva, const doubl
 int sogm_bezier_qp_solve(sogm_planner *p, const double *start_pva, const double *goal_pv,
                          const double *polys, const int32_t *nfaces, const int32_t *npoly,
                          double *out_cpts, int32_t *out_status, int32_t *out_iters, void *stream);
+/*
+ * BezierOpt::setup in full (traj_opt/src/bezier_optimizer.cpp:27-54,113-260) + optimize: an arbitrary time
+ * allocation t_[i] per piece (continuity rows scaled by 1 / t, 1 / t^2 of either side of a knot :164-165,191-192;
+ * velocity / acceleration boxes by t, t^2 :220-246), an end state with velocity AND acceleration (:150-160,205-215)
+ * and the caller's limits — replan() itself only ever asks for t_[i] = corridor_tau and a final acceleration of
+ * zero (baseline.cpp:411,423), which is what sogm_bezier_qp_solve / sogm_replan assemble.
+ * dev end_pva    [n_agents*9]  fp64 rows pos, vel, acc of the end state
+ * dev time_alloc [n_agents*SOGM_MAX_PIECES] fp64, entries [0, npoly) used
+ * Everything else as sogm_bezier_qp_solve.  (The reference writes pow(t, 2); the kernel multiplies.)
+ */
+int sogm_bezier_qp_solve_timed(sogm_planner *p, const double *start_pva, const double *end_pva,
+                               const double *time_alloc, double max_vel, double max_acc, const double *polys,
+                               const int32_t *nfaces, const int32_t *npoly, double *out_cpts,
+                               int32_t *out_status, int32_t *out_iters, void *stream);
 
 /*
  * sdlp::linprog<d> (traj_utils/include/traj_utils/sdlp.hpp:709-787) for a batch of independent problems

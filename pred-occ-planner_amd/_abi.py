@@ -137,6 +137,7 @@ PROTOTYPES = {
     "sogm_astar_search": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp]),
     "sogm_corridor_generate": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "sogm_bezier_qp_solve": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "sogm_bezier_qp_solve_timed": (_i, [_vp, _vp, _vp, _vp, C.c_double, C.c_double, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sogm_linprog_batched": (_i, [_i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
     "sogm_replan": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sogm_gridmap_create": (_i, [C.POINTER(SogmGridMapParams), _i, _i, C.POINTER(_vp)]),

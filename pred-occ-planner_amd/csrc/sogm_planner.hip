@@ -349,6 +349,31 @@ int sogm_bezier_qp_solve(sogm_planner *p, const double *start_pva, const double 
   }
   return SOGM_OK;
 }
+int sogm_bezier_qp_solve_timed(sogm_planner *p, const double *start_pva, const double *end_pva,
+                               const double *time_alloc, double max_vel, double max_acc, const double *polys,
+                               const int32_t *nfaces, const int32_t *npoly, double *out_cpts, int32_t *out_status,
+                               int32_t *out_iters, void *stream) {
+  if (!p || !start_pva || !end_pva || !time_alloc || !polys || !nfaces || !npoly || !out_cpts || !out_status ||
+      !out_iters || !(max_vel > 0) || !(max_acc > 0))
+    return SOGM_ERR_INVALID_ARG;
+  SOGM_HIP_CHECK(hipSetDevice(p->map->device));
+  hipStream_t       st = (hipStream_t)stream;
+  SogmPlannerParams pp = p->pp;
+  pp.opt_max_vel       = max_vel;
+  pp.opt_max_acc       = max_acc;
+  sogm::QpWorkspace qw = p->qw;
+  qw.t_alloc           = time_alloc;
+  qw.goal_stride       = 9;
+  prof_begin(p->map, SOGM_PROF_QP, st);
+  int rc = launch_qp(pp, p->qs, qw, p->qc, p->sel_count, start_pva, end_pva, polys, nfaces, npoly, out_cpts,
+                     out_status, out_iters, st, p->sel_first);
+  prof_end(p->map, SOGM_PROF_QP, st);
+  if (rc) {
+    sogm::set_error("k_qp", hipGetLastError());
+    return SOGM_ERR_HIP;
+  }
+  return SOGM_OK;
+}
 int sogm_safe_after_opt(sogm_planner *p, const double *cpts, const int32_t *npoly,
                         const SogmTrajRecord *records, int n_records, const int32_t *ego_ids,
                         const double *t_now, int32_t *out_safe, void *stream) {

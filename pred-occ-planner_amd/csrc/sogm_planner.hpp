@@ -90,6 +90,11 @@ struct QpWorkspace {
   char  *scratch;         // [A][scratch_stride]
   size_t scratch_stride;  // bytes per agent (rows at M = SOGM_MAX_PIECES, max_faces faces)
   int    dyn_lds_bytes;   // dynamic LDS per workgroup of k_qp
+  // BezierOpt::setup in full (sogm_bezier_qp_solve_timed): per-piece time allocation [A][SOGM_MAX_PIECES] and an
+  // end state with acceleration (goal rows of 9 doubles instead of 6).  nullptr / 6: every piece = corridor_tau,
+  // final acceleration 0 — what replan() asks for (baseline.cpp:411,423).
+  const double *t_alloc;
+  int           goal_stride;
 };
 size_t qp_scratch_bytes_per_agent(int max_faces);
 int    qp_dynamic_lds_bytes();

@@ -256,8 +256,12 @@ __device__ __forceinline__ void qp_solve_agent(const SogmPlannerParams &pp, cons
   auto body = [&](const Rows &R, auto fast_tag) __attribute__((always_inline)) {
   constexpr bool FAST = decltype(fast_tag)::value;  // compile-time: the two iterations never share a loop
   const double *sp   = start_pva + agent * 9;
-  const double *gp   = goal_pv + agent * 6;
-  const double  tau  = pp.corridor_tau;  // time_alloc: every piece = corridor_tau (baseline.cpp:411)
+  const int     gstr = ws.goal_stride == 9 ? 9 : 6;
+  const double *gp   = goal_pv + agent * gstr;
+  // time allocation t_[i] (bezier_optimizer.cpp:135,164-165,191-192,220,231): replan() gives every piece
+  // corridor_tau (baseline.cpp:411); the general entry passes its own vector
+  const double *tal  = ws.t_alloc ? ws.t_alloc + (size_t)agent * SOGM_MAX_PIECES : nullptr;
+  auto          T    = [&](int i) -> double { return tal ? tal[i] : pp.corridor_tau; };
   const double  vmax = pp.opt_max_vel, amax = pp.opt_max_acc;
 
   // ---- 1. assembly (bezier_optimizer.cpp:113-260): general rows in ELL, one lane per row
@@ -295,22 +299,23 @@ __device__ __forceinline__ void qp_solve_agent(const SogmPlannerParams &pp, cons
           val[0] = -4;
           col[1] = 3 + d;
           val[1] = 4;
-          lo = hi = sp[3 + d] * tau;
+          lo = hi = sp[3 + d] * T(0);
         } else if (gidx == M) {
           col[0] = M * 15 - 6 + d;
           val[0] = -4;
           col[1] = M * 15 - 3 + d;
           val[1] = 4;
-          lo = hi = gp[3 + d] * tau;
+          lo = hi = gp[3 + d] * T(M - 1);
         } else {
           col[0] = gidx * 15 + d;
-          val[0] = -4.0 / tau;
+          const double t1 = T(gidx), t1_ = T(gidx - 1);
+          val[0] = -4.0 / t1;
           col[1] = gidx * 15 + 3 + d;
-          val[1] = 4.0 / tau;
+          val[1] = 4.0 / t1;
           col[2] = gidx * 15 - 3 + d;
-          val[2] = -4.0 / tau;
+          val[2] = -4.0 / t1_;
           col[3] = gidx * 15 - 6 + d;
-          val[3] = 4.0 / tau;
+          val[3] = 4.0 / t1_;
         }
       } else {
         if (gidx == 0) {
@@ -318,20 +323,21 @@ __device__ __forceinline__ void qp_solve_agent(const SogmPlannerParams &pp, cons
             col[k] = k * 3 + d;
             val[k] = p2a[k];
           }
-          lo = hi = sp[6 + d] * tau * tau;
+          lo = hi = sp[6 + d] * T(0) * T(0);
         } else if (gidx == M) {
           for (int k = 0; k < 3; ++k) {
             col[k] = M * 15 - 9 + k * 3 + d;
             val[k] = p2a[k];
           }
-          lo = hi = 0.0 * tau * tau;  // final acceleration = 0 (baseline.cpp:423)
+          // final acceleration: 0 for replan() (baseline.cpp:423), the caller's for the general entry
+          lo = hi = (gstr == 9 ? gp[6 + d] : 0.0) * T(M - 1) * T(M - 1);
         } else {
-          const double t2 = tau * tau;
+          const double t2 = T(gidx) * T(gidx), t2_ = T(gidx - 1) * T(gidx - 1);  // pow(t_[i], 2) (:191-192)
           for (int k = 0; k < 3; ++k) {
             col[k]     = gidx * 15 + k * 3 + d;
             val[k]     = p2a[k] / t2;
             col[3 + k] = gidx * 15 - 9 + k * 3 + d;
-            val[3 + k] = -p2a[k] / t2;
+            val[3 + k] = -p2a[k] / t2_;
           }
         }
       }
@@ -341,16 +347,16 @@ __device__ __forceinline__ void qp_solve_agent(const SogmPlannerParams &pp, cons
       val[0] = -4;
       col[1] = i * 15 + j * 3 + 3 + d;
       val[1] = 4;
-      hi     = vmax * 1.0 * tau;
-      lo     = -vmax * 1.0 * tau;
+      hi     = vmax * 1.0 * T(i);
+      lo     = -vmax * 1.0 * T(i);
     } else {
       const int rr = r - R4, i = rr / 9, j = (rr % 9) / 3, d = rr % 3;
       for (int k = 0; k < 3; ++k) {
         col[k] = i * 15 + j * 3 + k * 3 + d;
         val[k] = p2a[k];
       }
-      hi = amax * 1.0 * tau * tau;
-      lo = -amax * 1.0 * tau * tau;
+      hi = amax * 1.0 * T(i) * T(i);
+      lo = -amax * 1.0 * T(i) * T(i);
     }
     for (int k = 0; k < QP_ELL; ++k) {
       R.gcol[(size_t)r * QP_ELL + k] = col[k];

@@ -183,7 +183,12 @@ class RiskHybridAstar {
   template <class V3>
   ASTAR_RET search(V3 start_pt, V3 start_vel, V3 start_acc, V3 end_pt, V3 end_vel, bool init, bool dynamic = false,
                    double time_start = -1.0) {
-    if (!dynamic) throw std::invalid_argument("RiskHybridAstar::search: only the dynamic (space-time) search exists");
+    // dynamic = false is not a function of its arguments in the reference: the branch never writes PathNode::time /
+    // time_idx / time_origin_ (risk_hybrid_a_star.cpp:153-162; path_node.h:44-45 leaves them uninitialised, reset()
+    // :84-101 does not touch them) yet reads them for the horizon test (:177), the collision time (:300) and the
+    // hash key (:264-265) — it sees whatever an earlier search left in the pool.  No call site passes false
+    // (baseline.cpp:268-283, baseline_fake.cpp:279-291).  Refused rather than given an invented meaning.
+    if (!dynamic) throw std::invalid_argument("RiskHybridAstar::search: dynamic = false reads uninitialised node times in the reference; only the space-time search is defined");
     for (int d = 0; d < 3; ++d)
       if (end_vel(d) != 0.0) throw std::invalid_argument("RiskHybridAstar::search: end_vel must be zero");
     const int a = b_.agent;
@@ -392,14 +397,16 @@ class BezierOpt {
  public:
   explicit BezierOpt(const AgentBinding &b) : b_(b) {
     const size_t A = (size_t)b_.map->agents(), MF = (size_t)b_.pp.max_faces;
-    d_pva_.resize(A * 9); d_goal_.resize(A * 6); d_polys_.resize(A * SOGM_MAX_PIECES * MF * 4);
+    d_pva_.resize(A * 9); d_goal_.resize(A * 9); d_tal_.resize(A * SOGM_MAX_PIECES);
+    d_polys_.resize(A * SOGM_MAX_PIECES * MF * 4);
     d_nf_.resize(A * SOGM_MAX_PIECES); d_np_.resize(A); d_cpts_.resize(A * SOGM_MAX_PIECES * 15); d_st_.resize(A);
     d_it_.resize(A);
   }
   // void setup(const Matrix3d &start, const Matrix3d &end, time_allocation, constraints, max_vel, max_acc)
-  // start / end rows = position, velocity, acceleration.  The batched QP allocates corridor_tau to every piece,
-  // bounds with the planner's opt_max_vel / opt_max_acc and ends at rest in acceleration, as every call site does
-  // (baseline_fake.cpp:429-441, baseline.cpp:420-432); anything else is refused.
+  // start / end rows = position, velocity, acceleration; any time allocation per piece, any end state, the
+  // caller's limits (bezier_optimizer.cpp:27-54,113-260) — sogm_bezier_qp_solve_timed.  (replan()'s call sites,
+  // baseline_fake.cpp:429-441 / baseline.cpp:420-432, pass corridor_tau for every piece and a zero final
+  // acceleration: the special case the fused sogm_replan assembles.)
   template <class M3, class HP>
   void setup(const M3 &start, const M3 &end, const std::vector<double> &time_allocation,
              const std::vector<HP> &constraints, const double &max_vel = 3.0, const double &max_acc = 3.0) {
@@ -407,16 +414,18 @@ class BezierOpt {
     if (M < 1 || M > SOGM_MAX_PIECES || (int)time_allocation.size() != M)
       throw std::invalid_argument("BezierOpt::setup: piece count");
     for (double t : time_allocation)
-      if (t != b_.pp.corridor_tau) throw std::invalid_argument("BezierOpt::setup: time allocation != corridor_tau");
-    if (max_vel != b_.pp.opt_max_vel || max_acc != b_.pp.opt_max_acc)
-      throw std::invalid_argument("BezierOpt::setup: limits differ from the planner's");
-    double pva[9], goal[6];
+      if (!(t > 0.0)) throw std::invalid_argument("BezierOpt::setup: time allocation must be positive");
+    if (!(max_vel > 0.0) || !(max_acc > 0.0)) throw std::invalid_argument("BezierOpt::setup: limits must be positive");
+    vmax_ = max_vel;
+    amax_ = max_acc;
+    t_    = time_allocation;
+    double pva[9], goal[9], tal[SOGM_MAX_PIECES] = {0};
     for (int r = 0; r < 3; ++r)
-      for (int d = 0; d < 3; ++d) pva[r * 3 + d] = start(r, d);
-    for (int r = 0; r < 2; ++r)
-      for (int d = 0; d < 3; ++d) goal[r * 3 + d] = end(r, d);
-    for (int d = 0; d < 3; ++d)
-      if (end(2, d) != 0.0) throw std::invalid_argument("BezierOpt::setup: final acceleration must be zero");
+      for (int d = 0; d < 3; ++d) {
+        pva[r * 3 + d]  = start(r, d);
+        goal[r * 3 + d] = end(r, d);
+      }
+    for (int i = 0; i < M; ++i) tal[i] = time_allocation[i];
     std::vector<double>  polys((size_t)SOGM_MAX_PIECES * MF * 4, 0.0);
     std::vector<int32_t> nf(SOGM_MAX_PIECES, 0);
     for (int i = 0; i < M; ++i) {
@@ -429,7 +438,8 @@ class BezierOpt {
     const int     a  = b_.agent;
     const int32_t np = M;
     (void)hipMemcpy(d_pva_.data() + a * 9, pva, sizeof(pva), hipMemcpyHostToDevice);
-    (void)hipMemcpy(d_goal_.data() + a * 6, goal, sizeof(goal), hipMemcpyHostToDevice);
+    (void)hipMemcpy(d_goal_.data() + a * 9, goal, sizeof(goal), hipMemcpyHostToDevice);
+    (void)hipMemcpy(d_tal_.data() + (size_t)a * SOGM_MAX_PIECES, tal, sizeof(tal), hipMemcpyHostToDevice);
     (void)hipMemcpy(d_polys_.data() + (size_t)a * SOGM_MAX_PIECES * MF * 4, polys.data(), polys.size() * sizeof(double),
                     hipMemcpyHostToDevice);
     (void)hipMemcpy(d_nf_.data() + a * SOGM_MAX_PIECES, nf.data(), nf.size() * sizeof(int32_t), hipMemcpyHostToDevice);
@@ -439,15 +449,16 @@ class BezierOpt {
   bool optimize() {  // OSQP status solved (1) or solved-inaccurate (2) -> true (bezier_optimizer.cpp:318-337)
     if (M_ <= 0) throw std::logic_error("BezierOpt::optimize before setup");
     SelectAgent sel(b_);
-    check(sogm_bezier_qp_solve(b_.planner->handle(), d_pva_.data(), d_goal_.data(), d_polys_.data(), d_nf_.data(),
-                               d_np_.data(), d_cpts_.data(), d_st_.data(), d_it_.data(), nullptr),
-          "sogm_bezier_qp_solve");
+    check(sogm_bezier_qp_solve_timed(b_.planner->handle(), d_pva_.data(), d_goal_.data(), d_tal_.data(), vmax_, amax_,
+                                     d_polys_.data(), d_nf_.data(), d_np_.data(), d_cpts_.data(), d_st_.data(),
+                                     d_it_.data(), nullptr),
+          "sogm_bezier_qp_solve_timed");
     (void)hipMemcpy(&status_, d_st_.data() + b_.agent, sizeof(status_), hipMemcpyDeviceToHost);
     (void)hipMemcpy(&iters_, d_it_.data() + b_.agent, sizeof(iters_), hipMemcpyDeviceToHost);
     return status_ == 1 || status_ == 2;
   }
   void getOptBezier(Bezier &bc) const {
-    std::vector<double> c((size_t)M_ * 15), t((size_t)M_, b_.pp.corridor_tau);
+    std::vector<double> c((size_t)M_ * 15), t(t_);
     (void)hipMemcpy(c.data(), const_cast<DevBuf<double> &>(d_cpts_).data() + (size_t)b_.agent * SOGM_MAX_PIECES * 15,
                     c.size() * sizeof(double), hipMemcpyDeviceToHost);
     bc = Bezier(t, c);
@@ -469,7 +480,9 @@ class BezierOpt {
   AgentBinding    b_;
   int             M_ = 0;
   int32_t         status_ = 0, iters_ = 0;
-  DevBuf<double>  d_pva_, d_goal_, d_polys_, d_cpts_;
+  double          vmax_ = 3.0, amax_ = 3.0;
+  std::vector<double> t_;
+  DevBuf<double>  d_pva_, d_goal_, d_tal_, d_polys_, d_cpts_;
   DevBuf<int32_t> d_nf_, d_np_, d_st_, d_it_;
 };
 

@@ -141,6 +141,21 @@ class SogmPlanner:
                                          out["iters"].data_ptr(), _stream()), "sogm_bezier_qp_solve")
         return out
 
+    def optimize_timed(self, start_pva, end_pva, time_alloc, polys, nfaces, npoly, max_vel, max_acc):
+        """BezierOpt::setup(start, end, time_allocation, constraints, max_vel, max_acc) + optimize in full: any time
+        allocation per piece [A, 16], an end state with acceleration [A, 9], the caller's limits."""
+        A, dev = self.A, start_pva.device
+        out = {
+            "cpts": torch.zeros((A, SOGM_MAX_PIECES * 15), dtype=torch.float64, device=dev),
+            "status": torch.zeros((A,), dtype=torch.int32, device=dev),
+            "iters": torch.zeros((A,), dtype=torch.int32, device=dev),
+        }
+        check(lib().sogm_bezier_qp_solve_timed(self._p, start_pva.data_ptr(), end_pva.data_ptr(), time_alloc.data_ptr(),
+                                               float(max_vel), float(max_acc), polys.data_ptr(), nfaces.data_ptr(),
+                                               npoly.data_ptr(), out["cpts"].data_ptr(), out["status"].data_ptr(),
+                                               out["iters"].data_ptr(), _stream()), "sogm_bezier_qp_solve_timed")
+        return out
+
     # ---- ParticleATC::isSafeAfterOpt ----
     def isSafeAfterOpt(self, cpts, npoly, records, n_records, ego_ids, t_now):
         safe = torch.empty((self.A,), dtype=torch.int32, device=cpts.device)

@@ -147,3 +147,69 @@ def test_qp_solver_paths_match_oracle(pop, orc, M, nf):
     assert (qn["status"] == 1).any(), "the synthetic corridors are meant to be solvable"
     P.close()
     m.close()
+
+
+def test_time_allocation_end_state_and_limits_of_bezieropt_setup(pop, orc):
+    """BezierOpt::setup in full (sogm_bezier_qp_solve_timed): the reference's own 3-cube fixture with ITS time vector
+    (test_bezier_opt.cpp:57-99: t = [2, 4, 2], limits 3 / 3, an end state with velocity), plus per-agent variations —
+    other time vectors, a non-zero final acceleration, other limits — against the oracle's assembly + OSQP
+    restatement: same status and iteration count, coefficients within 1e-4; and the fixture's solution still meets the
+    reference test's own boundary tolerances (:156-185)."""
+    import json
+    import os
+    import torch
+    sogm = importlib.import_module("pred-occ-planner_amd.sogm")
+    planner = importlib.import_module("pred-occ-planner_amd.planner")
+    G = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "bezier_opt_fixture.json")))
+    t = G["three"]
+    A, MP = 6, pop._abi.SOGM_MAX_PIECES
+    spec = pop.config.make_spec("parity")
+    m = sogm.SogmMap(spec, A)
+    pp = pop.config.make_planner_params(True)
+    P = planner.SogmPlanner(m, pop.config.make_astar_params(), pp, pop.config.make_qp_settings())
+    MF = pp.max_faces
+    cubes = np.array(t["cubes"], float)                                    # [3][6][4]
+    start, end = np.array(t["start"], float), np.array(t["end"], float)   # rows pos, vel, acc
+    cases = []
+    for a in range(A):
+        tv = np.array(t["t"], float) * [1.0, 0.5, 1.5, 1.0, 0.8, 1.0][a]
+        if a == 3:
+            tv = np.array([1.5, 3.0, 2.5])
+        e = end.copy()
+        if a in (2, 4):
+            e[2] = [0.3, -0.2, 0.1]                                          # final acceleration
+        if a == 5:
+            e[1] = [0.0, 0.0, 0.0]
+        lim = (3.0, 3.0) if a != 4 else (4.0, 5.0)
+        cases.append((tv, e, lim))
+    polys = np.zeros((A, MP, MF, 4))
+    nf = np.zeros((A, MP), np.int32)
+    tal = np.zeros((A, MP))
+    for a, (tv, e, lim) in enumerate(cases):
+        polys[a, :3, :6] = cubes
+        nf[a, :3] = 6
+        tal[a, :3] = tv
+    # one launch per limit pair (the limits are arguments of the call, not per agent)
+    got = {}
+    for lim in sorted({c[2] for c in cases}):
+        q = P.optimize_timed(sogm._dev(np.tile(start.reshape(1, 9), (A, 1)), np.float64),
+                             sogm._dev(np.stack([c[1].reshape(9) for c in cases]), np.float64),
+                             sogm._dev(tal, np.float64), sogm._dev(polys, np.float64), sogm._dev(nf),
+                             sogm._dev(np.full(A, 3, np.int32)), lim[0], lim[1])
+        got[lim] = {k: v.cpu().numpy() for k, v in q.items()}
+    n_solved = 0
+    for a, (tv, e, lim) in enumerate(cases):
+        st, x, it = orc.qp_solve(start, e, tv, polys[a], nf[a], MF, lim[0], lim[1], P.qs)
+        g = got[lim]
+        assert (g["status"][a], g["iters"][a]) == (st, it), (a, g["status"][a], st, g["iters"][a], it)
+        if st in (1, 2):
+            n_solved += 1
+            assert np.abs(g["cpts"][a, :45] - x).max() <= 1e-4, a
+    assert n_solved >= 4 and got[(3.0, 3.0)]["status"][0] in (1, 2)   # (halving the times makes one case infeasible)
+    # agent 0 is the reference's fixture itself: its own boundary checks (TestWaypoints, 1e-3)
+    X, d = got[(3.0, 3.0)]["cpts"][0, :45].reshape(15, 3), np.array(t["t"], float)
+    for der in range(3):
+        assert np.abs(orc.bezier_eval(d, X, 0.0, der) - start[der]).max() < t["bc_tol"]
+        assert np.abs(orc.bezier_eval(d, X, d.sum(), der) - end[der]).max() < t["bc_tol"]
+    P.close()
+    m.close()
