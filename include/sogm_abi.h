@@ -142,7 +142,12 @@ typedef struct SogmPlannerParams {
 /* QP solver settings = OSQP v0.6 defaults as used through IOSQP (traj_opt/include/iosqp.hpp:40-115,
  * traj_opt/src/bezier_optimizer.cpp:269).  adaptive_rho_interval: 0 = fixed rho (one KKT factor
  * for the whole solve); k > 0 = OSQP's adaptive rho evaluated every k iterations (OSQP's
- * wall-clock-derived interval lands on its check_termination multiple, 25, for problems this size). */
+ * wall-clock-derived interval lands on its check_termination multiple, 25, for problems this size).
+ * residual_fp32 (BASELINE configs[4], "mixed-precision ADMM residuals"; 0 = off, the default): the termination
+ * checks evaluate the residual norms, their normalisations and the workgroup reductions in fp32 (the iteration
+ * itself, the rho estimate's inputs and the infeasibility certificate's A'dy stay fp64).  A check near its threshold
+ * may then pass one check earlier or later than OSQP's fp64 test: the contract of this mode is "same status,
+ * coefficients within 1e-4 of the fp64 solve", not "same iteration count". */
 typedef struct SogmQpSettings {
   double  rho;
   double  sigma;
@@ -153,6 +158,8 @@ typedef struct SogmQpSettings {
   int32_t check_termination;
   int32_t scaling_iters;
   int32_t adaptive_rho_interval;
+  int32_t residual_fp32;
+  int32_t reserved_;
 } SogmQpSettings;
 
 typedef struct sogm_ctx sogm_ctx;

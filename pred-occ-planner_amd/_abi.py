@@ -94,7 +94,7 @@ class SogmQpSettings(C.Structure):
     _fields_ = [("rho", C.c_double), ("sigma", C.c_double), ("alpha", C.c_double),
                 ("eps_abs", C.c_double), ("eps_rel", C.c_double), ("max_iter", C.c_int32),
                 ("check_termination", C.c_int32), ("scaling_iters", C.c_int32),
-                ("adaptive_rho_interval", C.c_int32)]
+                ("adaptive_rho_interval", C.c_int32), ("residual_fp32", C.c_int32), ("reserved_", C.c_int32)]
 
 
 TRAJ_RECORD_BYTES = C.sizeof(SogmTrajRecord)  # 2064

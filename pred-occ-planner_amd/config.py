@@ -81,6 +81,7 @@ def make_qp_settings():
     q.check_termination = 25
     q.scaling_iters = 10
     q.adaptive_rho_interval = 25
+    q.residual_fp32 = 0  # 1: BASELINE configs[4]'s "mixed-precision ADMM residuals" (see sogm_abi.h)
     return q
 
 

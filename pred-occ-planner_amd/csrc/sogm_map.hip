@@ -864,7 +864,7 @@ using namespace sogm;
 // ================================================================================================
 extern "C" {
 
-int sogm_abi_version(void) { return 2; }
+int sogm_abi_version(void) { return 3; }
 const char *sogm_last_error(void) { return sogm::g_err; }
 
 int sogm_device_count(void) {

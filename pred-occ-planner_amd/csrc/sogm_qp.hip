@@ -90,6 +90,22 @@ __device__ inline double wave_max_dpp(double v) {
   return __builtin_fmax(__builtin_fmax(read_lane(v, 0), read_lane(v, 16)),
                         __builtin_fmax(read_lane(v, 32), read_lane(v, 48)));
 }
+// the same for fp32 values (one DPP move per step instead of two)
+template <int CTRL>
+__device__ inline float dpp_ctrl_f(float v) {
+  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+__device__ inline float wave_max_dpp_f(float v) {
+  v = __builtin_fmaxf(v, dpp_ctrl_f<0xB1>(v));
+  v = __builtin_fmaxf(v, dpp_ctrl_f<0x4E>(v));
+  v = __builtin_fmaxf(v, dpp_ctrl_f<0x141>(v));
+  v = __builtin_fmaxf(v, dpp_ctrl_f<0x140>(v));
+  const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+  const float b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+  const float c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+  const float d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+  return __builtin_fmaxf(__builtin_fmaxf(a, b), __builtin_fmaxf(c, d));
+}
 __device__ inline double wave_sum_dpp(double v) {
   v += dpp_ctrl_t<0xB1>(v);
   v += dpp_ctrl_t<0x4E>(v);
@@ -1028,7 +1044,8 @@ __device__ __forceinline__ void qp_solve_agent(const SogmPlannerParams &pp, cons
   // row order of the oracle's dense sums; ten wave reductions on the DPP path, one LDS round for the eight waves.
   // Fills s_sc like residuals() (1 / 4 / 9 / 12 hold the pair maxima, their partners 0) plus s_sc[7], s_sc[15].
   auto fast_residuals = [&]() __attribute__((always_inline)) {
-    const int t = launder(tid), lane = t & 63, wave = t >> 6;
+    const int  t = launder(tid), lane = t & 63, wave = t >> 6;
+    const bool f32 = qs.residual_fp32 != 0;  // BASELINE configs[4]: residual norms / reductions in fp32
     double    v[10];
 #pragma unroll
     for (int k = 0; k < 10; ++k) v[k] = 0.0;
@@ -1043,8 +1060,8 @@ __device__ __forceinline__ void qp_solve_agent(const SogmPlannerParams &pp, cons
       for (int k = 0; k < QP_ELL; ++k) ax += gv(k) * xg[k];  // absent entries are 0 * x[0]
       if (grow) {
         const double r_ = dabs(ax - g_z), n_ = dmax(dabs(ax), dabs(g_z));
-        v[0] = r_ / e;
-        v[1] = n_ / e;
+        v[0] = f32 ? (double)((float)r_ / (float)e) : r_ / e;
+        v[1] = f32 ? (double)((float)n_ / (float)e) : n_ / e;
         v[2] = r_;
         v[3] = n_;
         v[8] = dabs(e * d);
@@ -1067,8 +1084,8 @@ __device__ __forceinline__ void qp_solve_agent(const SogmPlannerParams &pp, cons
           const double d  = dr_ > 0.0 ? dr_ : 0.0;  // projection onto the polar of the recession cone
           R.sdy[sr]       = d;
           const double r_ = dabs(ax - s_zr(u)), n_ = dmax(dabs(ax), dabs(s_zr(u)));
-          v[0] = dmax(v[0], r_ / e);
-          v[1] = dmax(v[1], n_ / e);
+          v[0] = dmax(v[0], f32 ? (double)((float)r_ / (float)e) : r_ / e);
+          v[1] = dmax(v[1], f32 ? (double)((float)n_ / (float)e) : n_ / e);
           v[2] = dmax(v[2], r_);
           v[3] = dmax(v[3], n_);
           v[8] = dmax(v[8], dabs(e * d));
@@ -1092,13 +1109,22 @@ __device__ __forceinline__ void qp_solve_agent(const SogmPlannerParams &pp, cons
       const double a_ = col_sum_y(j);
       const double dj = s_D[j];
       const double r_ = dabs(s_ + a_), n_ = dmax(dabs(s_), dabs(a_));
-      v[4] = r_ / dj;
-      v[5] = n_ / dj;
+      v[4] = f32 ? (double)((float)r_ / (float)dj) : r_ / dj;
+      v[5] = f32 ? (double)((float)n_ / (float)dj) : n_ / dj;
       v[6] = r_;
       v[7] = n_;
     }
+    if (f32) {  // the nine maxima as fp32 values (rounded up to the next float: a maximum must not shrink)
 #pragma unroll
-    for (int k = 0; k < 9; ++k) v[k] = wave_max_dpp(v[k]);
+      for (int k = 0; k < 9; ++k) {
+        float fv = (float)v[k];
+        if ((double)fv < v[k]) fv = __int_as_float(__float_as_int(fv) + 1);  // next float up (v >= 0, finite)
+        v[k] = (double)wave_max_dpp_f(fv);
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 9; ++k) v[k] = wave_max_dpp(v[k]);
+    }
     v[9] = wave_sum_dpp(v[9]);
     if (lane == 0) {
 #pragma unroll

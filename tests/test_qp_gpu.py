@@ -213,3 +213,28 @@ def test_time_allocation_end_state_and_limits_of_bezieropt_setup(pop, orc):
         assert np.abs(orc.bezier_eval(d, X, d.sum(), der) - end[der]).max() < t["bc_tol"]
     P.close()
     m.close()
+
+
+def test_fp32_residual_mode_keeps_status_and_coefficients(pop, orc):
+    """BASELINE configs[4]'s "mixed-precision ADMM residuals" (SogmQpSettings.residual_fp32 = 1): the termination
+    checks run in fp32.  Contract (sogm_abi.h): same status as the fp64 solve and coefficients within 1e-4 — a check
+    may pass one interval earlier or later, so the iteration count may differ by a multiple of check_termination."""
+    sogm, planner, spec, sc, pva, recs, dev, m, ap, pp, qs, P = _setup(pop, 12, 99)
+    qs32 = pop.config.make_qp_settings()
+    qs32.residual_fp32 = 1
+    P32 = planner.SogmPlanner(m, ap, pp, qs32)
+    t_start = sc["stamps"] + 0.05
+    d_pva, d_ts = sogm._dev(pva, np.float64), sogm._dev(t_start, np.float64)
+    s = P.search(d_pva, sogm._dev(sc["goals"], np.float64), d_ts)
+    c = P.generateCorridors(d_pva, d_ts, s["route"], s["route_len"])
+    q64 = {k: v.cpu().numpy() for k, v in P.optimize(d_pva, c["goal"], c["polys"], c["nfaces"], c["npoly"]).items()}
+    q32 = {k: v.cpu().numpy() for k, v in P32.optimize(d_pva, c["goal"], c["polys"], c["nfaces"], c["npoly"]).items()}
+    assert np.array_equal(q32["status"], q64["status"])
+    d_it = np.abs(q32["iters"] - q64["iters"])
+    assert (d_it % qs.check_termination == 0).all() and d_it.max() <= 2 * qs.check_termination, d_it
+    ok = np.isin(q64["status"], (1, 2))
+    assert ok.sum() >= 8 and np.abs(q32["cpts"][ok] - q64["cpts"][ok]).max() <= TOL
+    print("fp32 residuals: iteration differences", d_it.tolist(), "max |dx|", np.abs(q32["cpts"][ok] - q64["cpts"][ok]).max())
+    P32.close()
+    P.close()
+    m.close()
