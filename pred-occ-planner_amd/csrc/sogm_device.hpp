@@ -293,7 +293,8 @@ struct sogm_ctx {
   int                 clear_gate_target;
   int                *clear_epoch_word;
   int                 clear_epoch, clear_epoch_ahead;
-  unsigned long long *clear_cursor;
+  unsigned long long *clear_cursor;  // [2], used in turn (clear_seq)
+  unsigned            clear_seq;
   hipStream_t         side2;  // the wide part's stream
   hipEvent_t          ev_side2_go, ev_side2_done;
   float         *d_filter_cells;   // filterPointCloud leaf accumulators [A][max_cells][4] (lazy)

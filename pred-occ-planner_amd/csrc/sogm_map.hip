@@ -93,8 +93,12 @@ template <bool POLITE>
 __global__ __launch_bounds__(256) void k_clear_chunks(vfloat4 *__restrict__ p, size_t n_vec4,
                                                       float *__restrict__ tail, int n_tail,
                                                       unsigned long long *__restrict__ cursor,
+                                                      unsigned long long *__restrict__ next_cursor,
                                                       const int *__restrict__ epoch_word, int epoch) {
   __shared__ unsigned long long s_next;
+  // two cursors take turns: the narrow launch of a clear zeroes the one the NEXT clear will use (the clear that used
+  // it last is complete — both of its launches are ordered before this one on the side stream); no memset node
+  if (POLITE && blockIdx.x == 0 && threadIdx.x == 0) *next_cursor = 0ull;
   const size_t nchunks = (n_vec4 + CLEAR_CHUNK_V4 - 1) / CLEAR_CHUNK_V4;
   // the wide launch only streams while the replan it was opened for is in flight (*epoch_word == epoch): once the
   // next update starts (word reset) its workgroups take no further chunk and the narrow launch finishes alone
@@ -818,18 +822,19 @@ int launch_clear(sogm_ctx *c, hipStream_t st, float *grid, bool polite, int part
     wide_wgs      = e ? atoi(e) : 256;
   }
   if (polite && part == 0 && c->clear_gate && c->clear_cursor && c->side2 && wide_wgs > 0 && nt) {
-    const size_t nchunks = (nall + CLEAR_CHUNK_V4 - 1) / CLEAR_CHUNK_V4;
-    SOGM_HIP_CHECK(hipMemsetAsync(c->clear_cursor, 0, sizeof(unsigned long long), st));
+    const size_t        nchunks = (nall + CLEAR_CHUNK_V4 - 1) / CLEAR_CHUNK_V4;
+    unsigned long long *cur = c->clear_cursor + (c->clear_seq & 1), *nxt = c->clear_cursor + ((c->clear_seq + 1) & 1);
+    ++c->clear_seq;
     SOGM_HIP_CHECK(hipEventRecord(c->ev_side2_go, st));
     SOGM_HIP_CHECK(hipStreamWaitEvent(c->side2, c->ev_side2_go, 0));
     prof_begin(c, slot, st);
     const int epoch = c->clear_epoch + c->clear_epoch_ahead;
     hipLaunchKernelGGL(k_clear_chunks<true>, dim3(nblk), dim3(256), 0, st, (vfloat4 *)grid, nall, grid + nall * 4,
-                       tail, c->clear_cursor, c->clear_epoch_word, epoch);
-    hipLaunchKernelGGL(k_clear_gate, dim3(1), dim3(64), 0, c->side2, c->clear_cursor, nchunks, c->clear_gate,
+                       tail, cur, nxt, c->clear_epoch_word, epoch);
+    hipLaunchKernelGGL(k_clear_gate, dim3(1), dim3(64), 0, c->side2, cur, nchunks, c->clear_gate,
                        c->clear_gate_err, c->clear_gate_target, c->clear_epoch_word, epoch);
     hipLaunchKernelGGL(k_clear_chunks<false>, dim3(wide_wgs), dim3(256), 0, c->side2, (vfloat4 *)grid, nall,
-                       grid + nall * 4, 0, c->clear_cursor, c->clear_epoch_word, epoch);
+                       grid + nall * 4, 0, cur, nxt, c->clear_epoch_word, epoch);
     SOGM_HIP_CHECK(hipEventRecord(c->ev_side2_done, c->side2));
     SOGM_HIP_CHECK(hipStreamWaitEvent(st, c->ev_side2_done, 0));  // the clear is complete when both launches are
     prof_end(c, slot, st);
@@ -902,7 +907,8 @@ int sogm_create(const SogmSpec *spec, int n_agents, int device, sogm_ctx **out) 
   if (e == hipSuccess) e = hipMalloc(&c->d_scratch_vt, sizeof(float) * (size_t)c->geom.V * spec->T);
   if (e == hipSuccess) e = hipMemset(c->d_poses, 0, sizeof(float) * 3 * n_agents);
   if (e == hipSuccess) e = hipMemset(c->d_stamps, 0, sizeof(double) * n_agents);
-  if (e == hipSuccess) e = hipMalloc((void **)&c->clear_cursor, sizeof(unsigned long long));
+  if (e == hipSuccess) e = hipMalloc((void **)&c->clear_cursor, 2 * sizeof(unsigned long long));
+  if (e == hipSuccess) e = hipMemset(c->clear_cursor, 0, 2 * sizeof(unsigned long long));
   if (e == hipSuccess) e = sogm::create_stream_partitioned(&c->side, 0);
   if (e == hipSuccess) e = sogm::create_stream_partitioned(&c->side2, 0);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_side2_go, hipEventDisableTiming);

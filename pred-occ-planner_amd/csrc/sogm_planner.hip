@@ -218,6 +218,10 @@ int sogm_planner_create(sogm_ctx *map, const SogmAstarParams *astar, const SogmP
     map->clear_gate        = p->fc.hdr + FLOW_Q_READY_N;
     map->clear_gate_err    = p->fc.hdr + FLOW_ERR;
     map->clear_gate_target = A;
+    if (const char *e = getenv("SOGM_CLEAR_GATE_FRAC")) {  // tuning aid: open the wide clear at a fraction of A
+      const double f = atof(e);
+      if (f > 0.0 && f <= 1.0) map->clear_gate_target = (int)(f * A + 0.5) < 1 ? 1 : (int)(f * A + 0.5);
+    }
     map->clear_epoch_word  = p->d_epoch;
   }
   *out = p;
