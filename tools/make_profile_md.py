@@ -1,4 +1,4 @@
-"""Assemble profiles/r02_end_rocprof.md, profiles/r02_perception_rocprof.md and profiles/r02_pmc_traffic.json from
+"""Assemble profiles/r03_end_rocprof.md, profiles/r03_perception_rocprof.md and profiles/r03_pmc_traffic.json from
 gpurun_out/profile/ (tools/make_profile.sh)."""
 import json, re
 P = 'gpurun_out/profile/'
@@ -11,21 +11,31 @@ plain, trace, flow0, grids2, mode1, cfg4, dsp, gm = (last(f) for f in (
 d, f0, g2, m1, c4 = (json.loads(x) for x in (plain, flow0, grids2, mode1, cfg4))
 
 
-def pm(counter):
-    m = re.search(r"k_clear_slabs<true> \| %s \| (\d+) \| ([\d.]+) \|" % counter, summ)
+def pm(counter, kernel="k_clear_chunks<true>"):
+    m = re.search(r"%s \| %s \| (\d+) \| ([\d.]+) \|" % (re.escape(kernel), counter), summ)
     return int(m.group(1)), float(m.group(2))
 
 
+# the in-tick clear = k_clear_chunks (narrow launch; under counter collection kernels are serialised and the narrow
+# launch clears the whole grid, tools/diag_clear_pmc.py); k_clear_slabs = the full-width launch of the stage pass
 nf, fk = pm('FETCH_SIZE')
 nw, wk = pm('WRITE_SIZE')
+_, fk_s = pm('FETCH_SIZE', 'k_clear_slabs<true>')
+_, wk_s = pm('WRITE_SIZE', 'k_clear_slabs<true>')
+_, wk_bits = pm('WRITE_SIZE', 'k_stamp_bits')
+_, wk_marks = pm('WRITE_SIZE', 'k_stamp_marks')
+_, fk_bits = pm('FETCH_SIZE', 'k_stamp_bits')
+_, fk_marks = pm('FETCH_SIZE', 'k_stamp_marks')
 traffic = int((fk + wk) * 1024)
 alg = d['roofline']['bytes_per_launch']
-json.dump({"kernel": "k_clear_slabs",
-           "source": "profiles/r02_end_rocprof.md (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes of "
-                     "`python bench.py --steps 2 --warmup 1 --no-cpu-baseline --sustained 0`, 128 agents 200x200x200x20; "
-                     "mean over the in-tick launches and the full-width stage-pass launches)",
-           "fetch_kb": fk, "write_kb": wk, "bytes_per_launch": traffic, "algorithmic_bytes_per_launch": alg},
-          open('profiles/r02_pmc_traffic.json', 'w'))
+json.dump({"kernel": "k_clear_chunks (the in-tick SOGM clear) / k_clear_slabs (full-width stage pass)",
+           "source": "profiles/r03_end_rocprof.md (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes of "
+                     "`SOGM_CLEAR_EARLY=1 python tools/diag_clear_pmc.py` for k_clear_chunks and of `SOGM_FLOW=0 python "
+                     "bench.py --steps 2 --warmup 1 --no-cpu-baseline --sustained 0` for k_clear_slabs, 128 agents "
+                     "200x200x200x20)",
+           "fetch_kb": fk, "write_kb": wk, "bytes_per_launch": traffic, "algorithmic_bytes_per_launch": alg,
+           "k_clear_slabs": {"fetch_kb": fk_s, "write_kb": wk_s}},
+          open('profiles/r03_pmc_traffic.json', 'w'))
 r, s = d['roofline'], d['sustained']
 cb = d['cpu_baseline']
 md = f"""# Round 2 — rocprofv3 profile of `python bench.py` (MI355X, 128 agents, 200^3 x 20), numbers of record
