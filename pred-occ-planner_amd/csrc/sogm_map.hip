@@ -76,7 +76,12 @@ __global__ void k_clear_gate(const unsigned long long *__restrict__ cursor, size
                              const int *__restrict__ gate, const int *__restrict__ gate_err, int gate_target,
                              const int *__restrict__ epoch_word, int epoch) {
   if (threadIdx.x != 0) return;
+  // bounded like every device-side wait of the tick (0.5 s of the 100 MHz clock): opening the wide launch early is
+  // harmless, a gate that never returns is not (e.g. under a profiler that serialises kernels and runs this one
+  // before the narrow launch it watches)
+  const long long t0 = wall_clock64();
   for (;;) {
+    if (wall_clock64() - t0 > 50000000LL) break;
     if (__hip_atomic_load(cursor, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= nchunks) break;
     // the replan this clear runs under writes `epoch` after resetting its counters; a later epoch = it is over
     const int e = __hip_atomic_load(epoch_word, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
@@ -1102,6 +1107,15 @@ static int update_gt_impl(sogm_ctx *c, const float *cloud_xyz, const int32_t *cl
   } else {
     int rc = clear_grid(c, st);
     if (rc) return rc;
+    if (c->overlap >= 2 && c->n_dirty > 0 && c->clear_gate && getenv("SOGM_CLEAR_EARLY") && atoi(getenv("SOGM_CLEAR_EARLY"))) {
+      // tuning-aid mode: the pool's spare grids (dirty at the start, no readers) are cleared from here on as well,
+      // so that a run of updates alone exercises the pooled clear (tools/diag_clear_pmc.py)
+      c->clear_epoch_ahead = 1;
+      SOGM_HIP_CHECK(hipEventRecord(c->ev_grid_free, st));
+      rc                   = sogm::queue_spare_clears(c, c->ev_grid_free);
+      c->clear_epoch_ahead = 0;
+      if (rc) return rc;
+    }
   }
   // candidate cylinders per agent, then one-wave workgroups stride over each agent's cloud range
   if (!c->d_cand) {

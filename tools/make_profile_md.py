@@ -38,51 +38,70 @@ json.dump({"kernel": "k_clear_chunks (the in-tick SOGM clear) / k_clear_slabs (f
           open('profiles/r03_pmc_traffic.json', 'w'))
 r, s = d['roofline'], d['sustained']
 cb = d['cpu_baseline']
-md = f"""# Round 2 — rocprofv3 profile of `python bench.py` (MI355X, 128 agents, 200^3 x 20), numbers of record
+smi = lambda f: " / ".join(l.split(":", 1)[1].strip() if ":" in l else l.strip() for l in read(f).splitlines()
+                           if any(k in l for k in ("sclk", "mclk", "Power (W)", "Temperature (Sensor junction)")))
+cap, cfg4r, qpar = read('capacity.txt').strip(), read('cfg4_residuals.txt').strip(), read('qp_parity.txt').strip()
+qpdump = read('qp_dump.log').strip().splitlines()[-1]
+try:
+    qp_table = open('profiles/r03_qp_infeasible_table.txt').read().strip()
+except OSError:
+    qp_table = "(run `python tools/diag_qp_infeasible.py analyze gpurun_out/qp_dump.npz > profiles/r03_qp_infeasible_table.txt`)"
+md = f"""# Round 3 — rocprofv3 profile of `python bench.py` (MI355X, 128 agents, 200^3 x 20), numbers of record
 
-Collected by `tools/make_profile.sh` on the GPU box (`cd /tmp && export TMPDIR=/tmp`), assembled by
+Collected by `tools/make_profile.sh` on ONE GPU box (`cd /tmp && export TMPDIR=/tmp`), assembled by
 `tools/make_profile_md.py`:
 - `rocprofv3 --kernel-trace --stats -d … -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline --sustained 0`
-- separate PMC passes (no trace domains): `rocprofv3 --pmc FETCH_SIZE -- python bench.py --steps 2 --warmup 1
-  --no-cpu-baseline --sustained 0` and the same with `--pmc WRITE_SIZE`.
+- separate PMC passes (no trace domains): `rocprofv3 --pmc FETCH_SIZE …` and `… --pmc WRITE_SIZE …` of
+  `SOGM_CLEAR_EARLY=1 python tools/diag_clear_pmc.py` (the in-tick clear kernels `k_clear_chunks` and the stamp
+  kernels by themselves: counter collection serialises kernels, under which the dataflow replan cannot run) and of
+  `SOGM_FLOW=0 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --sustained 0` (grouped path: `k_clear_slabs`).
 The rocpd databases stay in gpurun_out/ (scratch); this file holds what is cited.
 
-State: dataflow replan (`k_astar` publishes agents in completion order, the second search attempt of every agent runs
-speculatively beside the first; persistent `k_corridor_flow` / `k_qp_flow` / `k_finish_flow` chain per agent through
-device-side ready lists), triple-buffered SOGM with one narrow streaming clear per tick on a side stream, LDS-free
-one-wave cloud stamp behind a per-agent cylinder cull, tick glue in two launches (`k_tick_inputs`, `k_merge_latest`),
-sdlp's projective Seidel LP executed whole-wave, `costMVIE` summed in the reference's order with the L-BFGS history
-scalars held in lanes, ring obstacles, the velocity-estimation front end.
+**Box state** (`rocm-smi --showclocks --showpower --showtemp`; idle readings — the shader clock parks at ~100 MHz
+between kernels, mclk is fixed): before the default run: {smi('smi_before.txt')}; after it: {smi('smi_after.txt')}.
+Boxes differ: the same full-width clear takes 12.2–13.6 ms (0.75–0.84 of peak) from box to box, so only figures of ONE
+box (one make_profile run, one `tools/micro/ab.sh` call) are compared with each other in DESIGN.md.
+
+State: dataflow replan (`k_astar` with the speculative second attempt; persistent `k_corridor_flow` / `k_qp_flow` /
+`k_finish_flow` chained per agent), three SOGM grids, **width-adaptive chunked clear** (`k_clear_chunks`: narrow launch
+from the replan's start, a wide launch behind `k_clear_gate` once every agent's corridors are final, retiring when the
+next tick begins), **two-pass stamp** (`k_stamp_bits` occupancy bitmask, `k_stamp_marks` x-ordered marks), OSQP restated
+with the recession-cone projection in the infeasibility certificate and the scaled rho estimate, ADMM iterations between
+two checks in a clean inner loop, register-resident residual pass, one lane per record in `k_finish_flow`.
 
 Default run (`python bench.py`: 3 warm-up + 20 timed ticks, then 300 host-synchronised ticks of the same flight,
 then the CPU baseline): **{d['value']:.0f} replans/s** ({d['ms_per_step']:.2f} ms per tick), of which
 {d['value_ok']:.0f} successful (`replans_ok_fraction` {d['config']['replans_ok_fraction']:.3f}; outcomes
 {json.dumps(d['config']['outcomes'])}); **sustained** {s['value']:.0f} replans/s over {s['ticks']} ticks (tick mean
-{s['tick_ms_mean']:.2f} / p50 {s['tick_ms_p50']:.2f} / p99 {s['tick_ms_p99']:.2f} ms, ok {s['replans_ok_fraction']:.3f}).
-`k_clear_slabs` inside the tick (HIP events on its launch stream, every launch of the timed region, n =
-{r['launches_timed']}): {r['avg_launch_ms']:.2f} ms per launch = {r['achieved']:.0f} GB/s = **{r['frac']:.3f}** of the 8 TB/s HBM
-peak; the same kernel full width with the machine to itself {min(r['standalone']['launch_ms']):.2f} ms =
+{s['tick_ms_mean']:.2f} / p50 {s['tick_ms_p50']:.2f} / p99 {s['tick_ms_p99']:.2f} ms, ok {s['replans_ok_fraction']:.3f}; outcomes
+{json.dumps(s['outcomes_rank0'])}).
+The SOGM clear inside the tick (HIP events on its launch stream around BOTH launches, every clear of the timed region,
+n = {r['launches_timed']}): {r['avg_launch_ms']:.2f} ms per clear = {r['achieved']:.0f} GB/s = **{r['frac']:.3f}** of the 8 TB/s HBM
+peak; `k_clear_slabs` full width with the machine to itself {min(r['standalone']['launch_ms']):.2f} ms =
 {r['standalone']['frac']:.3f}.  CPU baseline (oracle "port", one agent-replan per thread): {cb['value']:.1f} replans/s on
 {cb['cores']} of {cb.get('host_cores')} host cores ({cb['sample']}).
 
 Variants on the same box:
 | variant | replans/s | ms/tick | clear ms (frac) | sustained replans/s (mean tick) |
 |---|---|---|---|---|
-| default: dataflow replan, 3 grids | {d['value']:.0f} | {d['ms_per_step']:.2f} | {r['avg_launch_ms']:.2f} ({r['frac']:.3f}) | {s['value']:.0f} ({s['tick_ms_mean']:.2f} ms) |
-| grouped streams (`SOGM_FLOW=0`, round-1 structure), 3 grids | {f0['value']:.0f} | {f0['ms_per_step']:.2f} | {f0['roofline']['avg_launch_ms']:.2f} ({f0['roofline']['frac']:.3f}) | {f0['sustained']['value']:.0f} ({f0['sustained']['tick_ms_mean']:.2f} ms, 100 ticks) |
+| default: dataflow replan, 3 grids, adaptive clear | {d['value']:.0f} | {d['ms_per_step']:.2f} | {r['avg_launch_ms']:.2f} ({r['frac']:.3f}) | {s['value']:.0f} ({s['tick_ms_mean']:.2f} ms) |
+| grouped streams (`SOGM_FLOW=0`, round-1 structure; fixed narrow clear), 3 grids | {f0['value']:.0f} | {f0['ms_per_step']:.2f} | {f0['roofline']['avg_launch_ms']:.2f} ({f0['roofline']['frac']:.3f}) | {f0['sustained']['value']:.0f} ({f0['sustained']['tick_ms_mean']:.2f} ms, 100 ticks) |
 | dataflow, 2 grids (`SOGM_GRIDS=2`) | {g2['value']:.0f} | {g2['ms_per_step']:.2f} | {g2['roofline']['avg_launch_ms']:.2f} ({g2['roofline']['frac']:.3f}) | — |
 | single grid, in-place two-part clear (`SOGM_DOUBLE_BUFFER=0`, grouped path) | {m1['value']:.0f} | {m1['ms_per_step']:.2f} | {m1['roofline']['avg_launch_ms']:.2f} ({m1['roofline']['frac']:.3f}) | — |
 | BASELINE configs[4]: 300^3 x 30, fp16 cells, 207 GB, single grid | {c4['value']:.0f} | {c4['ms_per_step']:.2f} | {c4['roofline']['avg_launch_ms']:.2f} ({c4['roofline']['frac']:.3f}) | — |
 
 Reading guide:
-- `k_clear_slabs` is the roofline kernel (SOGM voxel update, {alg/1e9:.2f} GB algorithmic bytes per launch = 128 agents x
-  640 MB); PMC: FETCH_SIZE {fk:.0f} KB + WRITE_SIZE {wk:.0f} KB = {traffic/1e9:.2f} GB per launch (KB = 1024 B), i.e.
-  **{traffic/alg:.4f} x** the algorithmic bytes — no wasted traffic.
-- In the dataflow replan the planner is five launches per tick (`k_astar` with 2 x 128 workgroups: both search attempts); `k_corridor_flow`, `k_qp_flow`, `k_finish_flow` are
+- The roofline kernel is the SOGM clear ({alg/1e9:.2f} GB algorithmic bytes per clear = 128 agents x 640 MB).  PMC of
+  `k_clear_chunks<true>` (serialised: the narrow launch clears the whole grid): FETCH_SIZE {fk:.0f} KB + WRITE_SIZE
+  {wk:.0f} KB = {traffic/1e9:.2f} GB per clear (KB = 1024 B), i.e. **{traffic/alg:.4f} x** the algorithmic bytes;
+  `k_clear_slabs<true>`: FETCH {fk_s:.0f} KB + WRITE {wk_s:.0f} KB = x {(fk_s + wk_s) * 1024 / alg:.4f}.  No wasted traffic.
+- Stamp: `k_stamp_bits` WRITE {wk_bits/1e6:.2f} GB (device-scope atomics) / FETCH {fk_bits/1e6:.2f} GB, `k_stamp_marks`
+  WRITE {wk_marks/1e6:.2f} GB / FETCH {fk_marks/1e6:.2f} GB per tick: **{(wk_bits + wk_marks) * 1024 / 0.28e9:.1f} x** the ≈0.28 GB of
+  marked bytes (round 2, one pass in cloud order: 2.41 GB = 8.8 x).
+- In the dataflow replan the planner is five launches per tick; `k_corridor_flow`, `k_qp_flow`, `k_finish_flow` are
   persistent (their durations span most of the tick by construction) — the per-agent stage times below are what to
-  read, not the kernel durations.
-- The clear runs on a side stream beside the whole replan; with three grids a tick only waits for the clear queued one
-  tick earlier.
+  read, not the kernel durations.  `k_clear_chunks<true>` (narrow) spans the whole clear, `k_clear_gate` ends when the
+  last agent's corridors are final, `k_clear_chunks<false>` (wide) runs from then until the next tick begins.
 
 {summ}
 
@@ -96,6 +115,36 @@ Reading guide:
 
 ```
 {flow.strip()}
+```
+
+## the QPs that fail: infeasible, and how soon OSQP's certificate sees it (tools/diag_qp_infeasible.py)
+
+Every QP of 23 ticks of the bench flight, dumped on the GPU ({qpdump}); each failing one then goes through a HiGHS
+feasibility LP on {{l <= Ax <= u}} and through the CPU oracle's OSQP restatement ("dumped" = this round's kernel, i.e.
+recession-cone projection + scaled rho estimate; the same analysis at the start of the round, with round 2's
+certificate and unscaled estimate: 201 failing QPs, all infeasible, 194 certified at a median of 725 iterations, 7 at
+max_iter; projection alone: 193 / 201 certified at the same iteration):
+
+```
+{qp_table}
+```
+
+GPU vs oracle on the same corridors (tools/diag_qp_parity.py, 3 ticks x 128 agents):
+
+```
+{qpar}
+```
+
+## capacity limits over a 323-tick flight (tools/diag_capacity.py)
+
+```
+{cap}
+```
+
+## BASELINE configs[4]: fp64 vs fp32 residual checks on 300^3 x 30 (tools/diag_cfg4_residuals.py)
+
+```
+{cfg4r}
 ```
 
 ## bench.py JSON lines
@@ -130,15 +179,45 @@ Reading guide:
 {cfg4}
 ```
 """
-open('profiles/r02_end_rocprof.md', 'w').write(md)
-md2 = f"""# Round 2 — perception kernels (particle SOGM, cloud filter, depth front end): rocprofv3 per-kernel tables
+open('profiles/r03_end_rocprof.md', 'w').write(md)
+
+
+def kern(table, name):
+    """(calls, avg_ms) of a kernel in a rocprof_summary kernel-trace table"""
+    m = re.search(r"\| [^|]*%s[^|]* \| (\d+) \| [\d.]+ \| ([\d.]+) \|" % re.escape(name), table)
+    return (int(m.group(1)), float(m.group(2))) if m else (0, float('nan'))
+
+
+def pmc(table, name, counter):
+    m = re.search(r"\| [^|]*%s[^|]* \| %s \| \d+ \| ([\d.]+) \|" % (re.escape(name), counter), table)
+    return float(m.group(1)) if m else float('nan')
+
+
+sd = read('summary_dsp.md')
+_, pub_ms = kern(sd, 'k_dsp_publish')
+pub_f, pub_w = pmc(sd, 'k_dsp_publish', 'FETCH_SIZE'), pmc(sd, 'k_dsp_publish', 'WRITE_SIZE')
+V, T, A1 = 100 ** 3, 15, 16
+pub_alg = A1 * (3 * V * T * 4 + 4 * V)  # read fut, write grid, zero fut; read the occupancy plane
+_, occ_ms = kern(sd, 'k_dsp_occupancy')
+occ_f, occ_w = pmc(sd, 'k_dsp_occupancy', 'FETCH_SIZE'), pmc(sd, 'k_dsp_occupancy', 'WRITE_SIZE')
+md2 = f"""# Round 3 — perception kernels (particle SOGM, cloud filter, depth front end): rocprofv3 per-kernel tables
 
 `tools/make_profile.sh`: `rocprofv3 --kernel-trace --stats -- python tools/bench_dsp.py` (BASELINE configs[1]: 16
 agents, 100^3 x 15, 307 200 depth points per agent and frame, velocity estimation on the GPU) and
 `… tools/bench_gridmap.py` (400 x 400 x 30 voxels, 640 x 480 depth images), plus `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE`
 passes of the same commands (separate runs, no trace domains).  "mean value (KB)" is the counter per dispatch in KB of
-1024 B: FETCH_SIZE + WRITE_SIZE = HBM bytes a dispatch moved.  These kernels are latency- / atomics-bound scans of
-sparse structures; none of them is rated against the HBM roofline (the rated kernel is `k_clear_slabs`).
+1024 B: FETCH_SIZE + WRITE_SIZE = HBM bytes a dispatch moved.
+
+**Roofline ratings of the streaming kernels on this side** (the others are latency- / atomics-bound scans of sparse
+structures and are not rated):
+- `k_dsp_publish` — a pure stream: per agent it reads the future-occupancy accumulators `fut[T][V]`, writes them into
+  the SOGM slabs, zeroes them, and reads one occupancy plane: algorithmic bytes 3 V T 4 + 4 V per agent =
+  {pub_alg/1e9:.2f} GB for 16 agents x 100^3 x 15.  Kernel-trace average {pub_ms:.3f} ms -> **{pub_alg/1e9/pub_ms:.2f} TB/s =
+  {pub_alg/1e9/pub_ms/8:.2f} of the 8 TB/s peak**; PMC FETCH {pub_f/1e6:.2f} GB + WRITE {pub_w/1e6:.2f} GB =
+  x {(pub_f + pub_w) * 1024 / pub_alg:.2f} the algorithmic bytes.
+- `k_dsp_occupancy` (per-voxel resample + occupancy: one 16-byte flag load per voxel, the occupied slots' lines):
+  {occ_ms:.3f} ms, PMC FETCH {occ_f/1e6:.2f} GB + WRITE {occ_w/1e6:.2f} GB -> {(occ_f + occ_w) * 1024 / 1e9 / occ_ms:.2f} TB/s of actual
+  traffic (it touches a data-dependent subset of the store, so there is no algorithmic byte count to rate it against).
 
 ## particle SOGM + filterPointCloud (tools/bench_dsp.py)
 
@@ -146,7 +225,7 @@ sparse structures; none of them is rated against the HBM roofline (the rated ker
 {dsp}
 ```
 
-{read('summary_dsp.md')}
+{sd}
 
 ## GridMap depth front end (tools/bench_gridmap.py)
 
@@ -156,5 +235,5 @@ sparse structures; none of them is rated against the HBM roofline (the rated ker
 
 {read('summary_gridmap.md')}
 """
-open('profiles/r02_perception_rocprof.md', 'w').write(md2)
-print("wrote profiles/r02_end_rocprof.md", len(md), "bytes,", "profiles/r02_perception_rocprof.md", len(md2), "bytes; traffic", traffic, "x", traffic / alg)
+open('profiles/r03_perception_rocprof.md', 'w').write(md2)
+print("wrote profiles/r03_end_rocprof.md", len(md), "bytes,", "profiles/r03_perception_rocprof.md", len(md2), "bytes; traffic", traffic, "x", traffic / alg)
