@@ -639,16 +639,28 @@ __global__ __launch_bounds__(64) void k_traj_eval(const SogmTrajRecord *__restri
 // from the trajectory it is executing — FiniteStateMachine samples traj_ at the planned start time
 // (plan_manager/src/plan_manager.cpp:169-175), an agent without a trajectory starts from where it hovers
 // (odom, :127-133) — plus the stamps the map update and the replan take.
+// One wave per agent: the 2064-byte record is fetched with ONE coalesced batch of loads into LDS (a lane walking
+// n_pieces -> durations -> control points through global memory needs four dependent round trips, which the tail
+// of the streaming clear beside this kernel stretches to a millisecond each), lane 0 evaluates it there.
 __global__ __launch_bounds__(64) void k_tick_inputs(const SogmTrajRecord *__restrict__ own, int n, double stamp,
                                                     double start_offset, double *__restrict__ hover,
                                                     double *__restrict__ now, double *__restrict__ t_start,
                                                     double *__restrict__ pva, float *__restrict__ poses) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  __shared__ __attribute__((aligned(16))) SogmTrajRecord s_rec;
+  __shared__ double                                      s_hov[9];
+  const int i = blockIdx.x;
   if (i >= n) return;
+  constexpr int W = (int)(sizeof(SogmTrajRecord) / 16);
+  const uint4  *src = reinterpret_cast<const uint4 *>(own + i);
+  uint4        *dst = reinterpret_cast<uint4 *>(&s_rec);
+  for (int w = threadIdx.x; w < W; w += 64) dst[w] = src[w];
+  if (threadIdx.x < 9) s_hov[threadIdx.x] = hover[i * 9 + threadIdx.x];
+  __syncthreads();
+  if (threadIdx.x != 0) return;
   const double ts = stamp + start_offset;
   double       o[9];
-  if (!traj_eval_record(own[i], ts, o))
-    for (int k = 0; k < 9; ++k) o[k] = hover[i * 9 + k];
+  if (!traj_eval_record(s_rec, ts, o))
+    for (int k = 0; k < 9; ++k) o[k] = s_hov[k];
   for (int k = 0; k < 9; ++k) pva[i * 9 + k] = o[k];
   for (int k = 0; k < 3; ++k) {
     hover[i * 9 + k]     = o[k];
@@ -670,9 +682,12 @@ __global__ __launch_bounds__(256) void k_merge_latest(const SogmTrajRecord *__re
   const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (gid >= (long long)n * W) return;
   const int a = (int)(gid / W), w = (int)(gid % W);
-  const uint4 *src = reinterpret_cast<const uint4 *>(ok[a] ? fresh + a : own + a);
-  const uint4  v   = src[w];
-  if (ok[a]) reinterpret_cast<uint4 *>(own + a)[w] = v;
+  // all three loads are issued together: this kernel often runs beside the tail of the streaming clear, where a
+  // dependent global round trip costs a millisecond
+  const int   good = ok[a];
+  const uint4 vf = reinterpret_cast<const uint4 *>(fresh + a)[w], vo = reinterpret_cast<const uint4 *>(own + a)[w];
+  const uint4 v  = good ? vf : vo;
+  if (good) reinterpret_cast<uint4 *>(own + a)[w] = v;
   if (all) reinterpret_cast<uint4 *>(all + a)[w] = v;
 }
 
@@ -1261,7 +1276,7 @@ int sogm_tick_inputs(const SogmTrajRecord *own_records, int n, double stamp, dou
   if (!own_records || !hover_inout || !out_now || !out_t_start || !out_pva || !out_poses || n < 0)
     return SOGM_ERR_INVALID_ARG;
   if (n == 0) return SOGM_OK;
-  hipLaunchKernelGGL(k_tick_inputs, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, own_records, n, stamp,
+  hipLaunchKernelGGL(k_tick_inputs, dim3(n), dim3(64), 0, (hipStream_t)stream, own_records, n, stamp,
                      replan_start_offset, hover_inout, out_now, out_t_start, out_pva, out_poses);
   SOGM_HIP_CHECK(hipGetLastError());
   return SOGM_OK;
