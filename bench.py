@@ -221,7 +221,7 @@ def main():
     # from the committed rocprofv3 --pmc passes of THIS command (FETCH_SIZE and WRITE_SIZE in separate runs,
     # tools/make_profile.sh) and is only reported when it was collected on the same workload (same bytes / launch)
     traffic, traffic_source = None, None
-    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 pmc = json.load(f)
@@ -262,11 +262,14 @@ def main():
         "replans_per_s_per_agent": sw.A_tot * args.steps / dt / sw.A_tot,
         "stage_ms": {"clear": avg[0], "stamp": avg[1], "splat": avg[2], "astar": avg[3], "corridor": avg[4],
                      "qp": avg[5]},
-        "roofline": {"bound": "hbm", "kernel": "k_clear_slabs (SOGM voxel update)", "achieved": achieved,
+        "roofline": {"bound": "hbm",
+                     "kernel": "the SOGM clear (voxel update): k_clear_chunks narrow + wide launches in the pooled modes, "
+                               "k_clear_slabs otherwise", "achieved": achieved,
                      "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
                      "traffic_source": traffic_source,
                      "bytes_per_launch": grid_bytes, "avg_launch_ms": float(avg[0]),
-                     "launches_timed": n_clear, "timed_where": "HIP events on the launch stream, every launch of the timed region",
+                     "launches_timed": n_clear,
+                     "timed_where": "HIP events on the clear's stream around the clear (both of its launches), every clear of the timed region",
                      # avg_launch_ms is the launch as it runs inside the tick (double-buffered mode: a narrow
                      # clear sharing the machine with the planner kernels); the same kernel at full width with
                      # the machine to itself, from the stage pass after the timed region:

@@ -648,6 +648,19 @@ enum {
   SOGM_CNT_DECONFLICT_CAPACITY = 7, /* pairs with more than 144 LP rows (treated as unsafe)          */
   SOGM_CNT_N                   = 8
 };
+/*
+ * Publication inside the replan.  The reference's FSM publishes a successful replan's trajectory and keeps executing
+ * the previous one otherwise (plan_manager.cpp:176-199,364-399); every other drone stores what it receives
+ * (particles.cpp:131-191).  sogm_merge_latest does that in a launch of its own after sogm_replan; with a table
+ * registered here the replan's finishing kernel does it per agent as its chain completes (same stores, overlapped with
+ * the other agents' chains — beside the streaming clear a separate store-heavy launch takes 2 ms):
+ *   own_records [n_agents]  dev: overwritten with the new record where the replan succeeded (latest wins);
+ *   next_table  [n_agents]  dev or NULL: receives every agent's CURRENT record (new, or the one it keeps executing) —
+ *                           the swarm table of the NEXT tick for a single-process host (n_total == n_agents), which
+ *                           must differ from the table registered with sogm_planner_set_swarm for this replan.
+ * NULL, NULL switches it off (the default).  Pointers are read by later sogm_replan calls.
+ */
+int sogm_planner_set_publish(sogm_planner *p, SogmTrajRecord *own_records, SogmTrajRecord *next_table);
 int sogm_planner_counters(sogm_planner *p, int64_t *out_host, int reset);
 /* sogm_replan() chains its kernels per agent through device-side ready lists ("dataflow replan");
  * a wait that exceeds 3 s marks the tick as failed instead of hanging the GPU: agents whose chain did not complete

@@ -150,6 +150,7 @@ PROTOTYPES = {
     "sogm_safe_after_opt": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "sogm_planner_flow_error": (_i, [_vp]),
     "sogm_planner_flow_failures": (_i, [_vp, _vp]),
+    "sogm_planner_set_publish": (_i, [_vp, _vp, _vp]),
     "sogm_planner_counters": (_i, [_vp, C.POINTER(C.c_int64), _i]),
     "sogm_planner_set_swarm": (_i, [_vp, _vp, _i, _vp, _vp]),
     "sogm_traj_allgather": (_i, [_vp, _vp, _vp, _i, _vp, _vp]),

@@ -940,4 +940,14 @@ int launch_astar(const MapView &m, const SogmAstarParams &ap, double corridor_ta
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
+// How many k_astar workgroups the device holds at once.  The speculative second attempts (workgroups A .. 2A - 1)
+// wait for the first attempts' verdicts: that is only free of a dispatch-order assumption while all 2 A are resident.
+int astar_resident_workgroups(int device) {
+  int per_cu = 0, n_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_astar, ASTAR_THREADS, 0) != hipSuccess ||
+      hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess)
+    return 0;
+  return per_cu * n_cu;
+}
+
 }  // namespace sogm

@@ -2021,7 +2021,8 @@ __global__ __launch_bounds__(64) void k_finish_flow(FlowCtl fc, double corridor_
                                                     const int32_t *swarm_ego, const double *swarm_now,
                                                     const double *t_start, const int32_t *drone_ids,
                                                     SogmTrajRecord *out, int32_t *out_ok, int32_t *out_safe,
-                                                    unsigned long long *counters, int n_agents) {
+                                                    unsigned long long *counters, int n_agents,
+                                                    SogmTrajRecord *pub_own, SogmTrajRecord *pub_table) {
   extern __shared__ __attribute__((aligned(16))) double s_dyn[];
   double   *s_lp   = s_dyn;
   double   *s_rows = s_lp + LP_WORK_DOUBLES;
@@ -2114,23 +2115,35 @@ __global__ __launch_bounds__(64) void k_finish_flow(FlowCtl fc, double corridor_
 #else
     if (lane == 0 && out_safe) out_safe[a] = safe;
 #endif
-    // BezierTraj record (plan_manager.cpp:364-399); n_pieces = 0 marks "replan() returned false"
+    // BezierTraj record (plan_manager.cpp:364-399); n_pieces = 0 marks "replan() returned false".
+    // Publication (sogm_planner_set_publish): a successful replan's record also goes — in the same stores — into
+    // the host's own table (latest wins; a failed replan keeps executing the previous trajectory, :176-196) and the
+    // agent's current record into the next tick's swarm table, HERE, where the stores overlap with the other agents'
+    // chains, instead of in a store-heavy kernel after the replan (beside the streaming clear that kernel took 2 ms).
     const bool      good = solved && safe != 0;
-    SogmTrajRecord &r    = out[a];
-    for (int i = lane; i < SOGM_MAX_PIECES; i += 64) r.duration[i] = (good && i < M) ? corridor_tau : 0.0;
-#ifdef SOGM_FLOW_DEBUG
-    if (lane == 0) out_safe[a] = 1010;
-#endif
-    for (int i = lane; i < SOGM_MAX_PIECES * 15; i += 64)
-      r.cpts[i] = (good && i < M * 15) ? cpts[(size_t)a * SOGM_MAX_PIECES * 15 + i] : 0.0;
-#ifdef SOGM_FLOW_DEBUG
-    if (lane == 0) out_safe[a] = 102;
-#endif
+    SogmTrajRecord *dst[3] = {out + a, (good && pub_own) ? pub_own + a : nullptr,
+                              (good && pub_own && pub_table) ? pub_table + a : nullptr};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      SogmTrajRecord *r = dst[k];
+      if (!r) continue;  // wave-uniform
+      for (int i = lane; i < SOGM_MAX_PIECES; i += 64) r->duration[i] = (good && i < M) ? corridor_tau : 0.0;
+      for (int i = lane; i < SOGM_MAX_PIECES * 15; i += 64)
+        r->cpts[i] = (good && i < M * 15) ? cpts[(size_t)a * SOGM_MAX_PIECES * 15 + i] : 0.0;
+      if (lane == 0) {
+        r->drone_id   = drone_ids[a];
+        r->time_start = t_start[a];
+        r->n_pieces   = good ? M : 0;
+      }
+    }
+    if (!good && pub_own && pub_table) {  // the table still lists the trajectory the agent goes on executing
+      constexpr int W   = (int)(sizeof(SogmTrajRecord) / 16);
+      const uint4  *src = reinterpret_cast<const uint4 *>(pub_own + a);
+      uint4        *t   = reinterpret_cast<uint4 *>(pub_table + a);
+      for (int w = lane; w < W; w += 64) t[w] = src[w];
+    }
+    if (lane == 0) out_ok[a] = good ? 1 : 0;
     if (lane == 0) {
-      r.drone_id   = drone_ids[a];
-      r.time_start = t_start[a];
-      r.n_pieces   = good ? M : 0;
-      out_ok[a]    = good ? 1 : 0;
       fc.ts[a * 8 + 6] = wall_clock64();
       if (counters) {
         int k = SOGM_CNT_REPLAN_OK;
@@ -2236,11 +2249,12 @@ int launch_finish_flow(const FlowCtl &fc, int n_agents, int n_workgroups, double
                        const int32_t *npoly, const int32_t *status, const double *cpts, const SogmTrajRecord *swarm,
                        int n_swarm, const int32_t *swarm_ego, const double *swarm_now, const double *t_start,
                        const int32_t *drone_ids, SogmTrajRecord *out, int32_t *out_ok, int32_t *out_safe,
-                       unsigned long long *counters, hipStream_t st) {
+                       unsigned long long *counters, hipStream_t st, SogmTrajRecord *pub_own,
+                       SogmTrajRecord *pub_table) {
   const size_t lds = sizeof(double) * (LP_WORK_DOUBLES + LP_MAX_ROWS * 5) + sizeof(int) * LP_MAX_ROWS;
   hipLaunchKernelGGL(k_finish_flow, dim3(n_workgroups), dim3(64), lds, st, fc, corridor_tau, ret, npoly, status,
                      cpts, swarm, n_swarm, swarm_ego, swarm_now, t_start, drone_ids, out, out_ok, out_safe, counters,
-                     n_agents);
+                     n_agents, pub_own, pub_table);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void k_clear_chunks(vfloat4 *__restrict__ p, s
                                                       float *__restrict__ tail, int n_tail,
                                                       unsigned long long *__restrict__ cursor,
                                                       unsigned long long *__restrict__ next_cursor,
-                                                      const int *__restrict__ epoch_word, int epoch) {
+                                                      const int *__restrict__ epoch_word, int epoch, int bound) {
   __shared__ unsigned long long s_next;
   // two cursors take turns: the narrow launch of a clear zeroes the one the NEXT clear will use (the clear that used
   // it last is complete — both of its launches are ordered before this one on the side stream); no memset node
@@ -127,6 +127,11 @@ __global__ __launch_bounds__(256) void k_clear_chunks(vfloat4 *__restrict__ p, s
       clear_store<true>(p + i + 512);
       clear_store<true>(p + i + 768);
       if (POLITE) __builtin_amdgcn_s_waitcnt(0x0F75);  // vmcnt <= 5: four stores (+ the cursor's atomic on lane 0)
+      else if (bound == 8) __builtin_amdgcn_s_waitcnt(0x0F78);
+      else if (bound == 12) __builtin_amdgcn_s_waitcnt(0x0F7C);
+      else if (bound == 16) __builtin_amdgcn_s_waitcnt(0x4F70);
+      else if (bound == 24) __builtin_amdgcn_s_waitcnt(0x4F78);
+      else if (bound == 32) __builtin_amdgcn_s_waitcnt(0x8F70);
     }
     for (; i < e; i += 256) clear_store<true>(p + i);
     if (threadIdx.x == 0) s_next = nxt;
@@ -836,10 +841,12 @@ int launch_clear(sogm_ctx *c, hipStream_t st, float *grid, bool polite, int part
   const size_t max_wgs  = env_wgs ? (size_t)env_wgs : (polite ? (c->clear_gate && part == 0 ? 80 : 64) : 2048);
   const int    throttle = env_wgs ? env_throttle : (polite ? 4 : 0);
   const int    nblk     = (int)(want < 1 ? 1 : (want > max_wgs ? max_wgs : want));
-  static int   wide_wgs = -1;
+  static int   wide_wgs = -1, wide_bound = 0;
   if (wide_wgs < 0) {
     const char *e = getenv("SOGM_CLEAR_WIDE_WGS");  // 0 switches the adaptive width off
     wide_wgs      = e ? atoi(e) : 256;
+    e             = getenv("SOGM_CLEAR_WIDE_BOUND");  // stores in flight per wave of the wide launch (0 = unbounded)
+    wide_bound    = e ? atoi(e) : 0;
   }
   if (polite && part == 0 && c->clear_gate && c->clear_cursor && c->side2 && wide_wgs > 0 && nt) {
     const size_t        nchunks = (nall + CLEAR_CHUNK_V4 - 1) / CLEAR_CHUNK_V4;
@@ -850,11 +857,11 @@ int launch_clear(sogm_ctx *c, hipStream_t st, float *grid, bool polite, int part
     prof_begin(c, slot, st);
     const int epoch = c->clear_epoch + c->clear_epoch_ahead;
     hipLaunchKernelGGL(k_clear_chunks<true>, dim3(nblk), dim3(256), 0, st, (vfloat4 *)grid, nall, grid + nall * 4,
-                       tail, cur, nxt, c->clear_epoch_word, epoch);
+                       tail, cur, nxt, c->clear_epoch_word, epoch, 0);
     hipLaunchKernelGGL(k_clear_gate, dim3(1), dim3(64), 0, c->side2, cur, nchunks, c->clear_gate,
                        c->clear_gate_err, c->clear_gate_target, c->clear_epoch_word, epoch);
     hipLaunchKernelGGL(k_clear_chunks<false>, dim3(wide_wgs), dim3(256), 0, c->side2, (vfloat4 *)grid, nall,
-                       grid + nall * 4, 0, cur, nxt, c->clear_epoch_word, epoch);
+                       grid + nall * 4, 0, cur, nxt, c->clear_epoch_word, epoch, wide_bound);
     SOGM_HIP_CHECK(hipEventRecord(c->ev_side2_done, c->side2));
     SOGM_HIP_CHECK(hipStreamWaitEvent(st, c->ev_side2_done, 0));  // the clear is complete when both launches are
     prof_end(c, slot, st);
@@ -1038,7 +1045,16 @@ int sogm_set_overlap_clear(sogm_ctx *c, int mode) {
     }
     if (!c->pool_ev[c->n_pool] &&
         hipEventCreateWithFlags(&c->pool_ev[c->n_pool], hipEventDisableTiming) != hipSuccess) {
+      // same roll-back as a failed allocation: the grids added by this call go, the lists describe the pool again
       (void)hipFree(g);
+      while (c->n_pool > had) {
+        (void)hipFree(c->pool[--c->n_pool]);
+        c->pool[c->n_pool] = nullptr;
+      }
+      c->n_ready = 0;
+      c->n_dirty = 0;
+      for (int i = 1; i < c->n_pool; ++i) c->dirty[c->n_dirty++] = i;
+      sogm::set_error("sogm_set_overlap_clear: event", hipErrorUnknown);
       return SOGM_ERR_HIP;
     }
     c->pool[c->n_pool++] = g;

@@ -59,7 +59,8 @@ static void min_jerk_block(double *QM /*15x15*/) {
 __global__ void k_pack_records(int A, double corridor_tau, const int32_t *ret, const int32_t *npoly,
                                const int32_t *status, const int32_t *safe, const double *cpts,
                                const double *t_start, const int32_t *drone_ids, SogmTrajRecord *out,
-                               int32_t *ok, int agent0, unsigned long long *counters) {
+                               int32_t *ok, int agent0, unsigned long long *counters, SogmTrajRecord *pub_own,
+                               SogmTrajRecord *pub_table) {
   const int a = blockIdx.x * blockDim.x + threadIdx.x + agent0;
   if (a >= A) return;
   if (counters) {  // where this replan ended (baseline_fake.cpp: :292 no path, :405-419 corridors, :447 QP, :455 unsafe)
@@ -81,6 +82,10 @@ __global__ void k_pack_records(int A, double corridor_tau, const int32_t *ret, c
   for (int i = 0; i < SOGM_MAX_PIECES * 15; ++i)
     r.cpts[i] = (good && i < npoly[a] * 15) ? cpts[(size_t)a * SOGM_MAX_PIECES * 15 + i] : 0.0;
   ok[a] = good ? 1 : 0;
+  if (pub_own) {  // publication, as k_finish_flow does it (sogm_planner_set_publish)
+    if (good) pub_own[a] = r;
+    if (pub_table) pub_table[a] = pub_own[a];
+  }
 }
 
 // End of a dataflow replan (one lane, on the caller's stream after the fan-in): a wait of this tick timed out ->
@@ -181,6 +186,8 @@ int sogm_planner_create(sogm_ctx *map, const SogmAstarParams *astar, const SogmP
   {
     const char *es = getenv("SOGM_SPEC_ASTAR");
     p->spec_astar  = es ? atoi(es) != 0 : 1;
+    // the second attempts wait on the first ones: only when every workgroup of both is resident at once
+    if (p->spec_astar && 2 * A > sogm::astar_resident_workgroups(map->device)) p->spec_astar = 0;
   }
   for (int g = 0; g < p->n_groups && e == hipSuccess; ++g) {
     e = sogm::create_stream_partitioned(&p->gstream[g], 1);
@@ -456,6 +463,13 @@ int sogm_planner_counters(sogm_planner *p, int64_t *out_host, int reset) {
   return SOGM_OK;
 }
 
+int sogm_planner_set_publish(sogm_planner *p, SogmTrajRecord *own_records, SogmTrajRecord *next_table) {
+  if (!p || (next_table && !own_records)) return SOGM_ERR_INVALID_ARG;
+  p->pub_own   = own_records;
+  p->pub_table = next_table;
+  return SOGM_OK;
+}
+
 int sogm_planner_set_swarm(sogm_planner *p, const SogmTrajRecord *records, int n_records,
                            const int32_t *ego_ids, const double *t_now) {
   if (!p || n_records < 0 || (records && (!ego_ids || !t_now))) return SOGM_ERR_INVALID_ARG;
@@ -539,7 +553,7 @@ static int replan_flow(sogm_planner *p, const double *start_pva, const double *g
   prof_end(c, SOGM_PROF_QP, sQ);
   if (sogm::launch_finish_flow(p->fc, A, wg_f, p->pp.corridor_tau, p->d_ret, p->d_npoly, p->d_status, p->d_cpts,
                                p->swarm, p->n_swarm, p->swarm_ego, p->swarm_now, t_start, drone_ids, out_records,
-                               out_ok, p->d_safe, p->cw.counters, sF)) {
+                               out_ok, p->d_safe, p->cw.counters, sF, p->pub_own, p->pub_table)) {
     sogm::set_error("sogm_replan: k_finish_flow", hipGetLastError());
     return SOGM_ERR_HIP;
   }
@@ -629,7 +643,7 @@ static int replan_impl(sogm_planner *p, const double *start_pva, const double *g
     }
     hipLaunchKernelGGL(k_pack_records, dim3((n + 63) / 64), dim3(64), 0, st, a1, p->pp.corridor_tau,
                        p->d_ret, p->d_npoly, p->d_status, p->swarm ? p->d_safe : nullptr, p->d_cpts, t_start,
-                       drone_ids, out_records, out_ok, a0, p->cw.counters);
+                       drone_ids, out_records, out_ok, a0, p->cw.counters, p->pub_own, p->pub_table);
     SOGM_HIP_CHECK(hipGetLastError());
     SOGM_HIP_CHECK(hipEventRecord(p->ev_done[g], st));
     SOGM_HIP_CHECK(hipStreamWaitEvent(main, p->ev_done[g], 0));  // fan in

@@ -83,7 +83,8 @@ int launch_finish_flow(const FlowCtl &fc, int n_agents, int n_workgroups, double
                        const int32_t *npoly, const int32_t *status, const double *cpts, const SogmTrajRecord *swarm,
                        int n_swarm, const int32_t *swarm_ego, const double *swarm_now, const double *t_start,
                        const int32_t *drone_ids, SogmTrajRecord *out, int32_t *out_ok, int32_t *out_safe,
-                       unsigned long long *counters, hipStream_t st);
+                       unsigned long long *counters, hipStream_t st, SogmTrajRecord *pub_own = nullptr,
+                       SogmTrajRecord *pub_table = nullptr);
 
 // Per-agent QP row storage in HBM, used only when a problem's rows do not fit in LDS.
 struct QpWorkspace {
@@ -101,6 +102,7 @@ int    qp_dynamic_lds_bytes();
 struct QpConst {
   double QM[225];  // per-piece min-jerk cost block (bezier_optimizer.cpp:96-111)
 };
+int astar_resident_workgroups(int device);
 int launch_qp(const SogmPlannerParams &pp, const SogmQpSettings &qs, const QpWorkspace &ws,
               const QpConst &qc, int n_agents, const double *start_pva, const double *goal_pv,
               const double *polys, const int32_t *nfaces, const int32_t *npoly, double *out_cpts,
@@ -144,6 +146,8 @@ struct sogm_planner {
   int                   n_swarm;
   const int32_t        *swarm_ego;
   const double         *swarm_now;
+  // publication inside the replan (sogm_planner_set_publish): the host's own-record table and the next swarm table
+  SogmTrajRecord       *pub_own, *pub_table;
   // agent groups: sogm_replan runs each group's search -> corridors -> QP chain on its own stream,
   // so one slow agent (a long A* search, an infeasible QP) only delays its own group
   int         n_groups;

@@ -211,6 +211,11 @@ class HipCompute:
     def set_swarm(self, all_records, A_tot, now):
         self.planner.setSwarm(all_records, A_tot, self.ego_ids, now)
 
+    def set_publish(self, own, next_table):
+        """replan() merges the new records into `own` (latest wins) and writes every agent's current record into
+        `next_table` itself (sogm_planner_set_publish) — no merge launch after the replan"""
+        self.planner.setPublish(own, next_table)
+
     def tick_inputs(self, own, stamp, hover, now, t_start, pva, poses):
         """start states from the executed trajectories, stamps and map centres: one launch (sogm_tick_inputs)"""
         _abi.check(_abi.lib().sogm_tick_inputs(own.data_ptr(), self.A_loc, stamp, REPLAN_START_TIME, hover.data_ptr(),
@@ -276,8 +281,14 @@ class SwarmTick:
         # replan() ends with ParticleATC::isSafeAfterOpt against the swarm's latest trajectories
         # (baseline_fake.cpp:453-460); "now" of the check = the tick's stamp
         self.now = torch.zeros((self.A_loc,), dtype=torch.float64, device=d)
+        self.deconflict = deconflict
         if deconflict:
             c.set_swarm(self.all, self.A_tot, self.now)
+        # publication inside the replan (default; SOGM_PUBLISH=0: the separate sogm_merge_latest launch): a single
+        # process alternates between two swarm tables — the replan reads one (overlay, deconfliction) and its
+        # finishing kernel fills the other for the next tick
+        self.publish = os.environ.get("SOGM_PUBLISH", "1") != "0" and hasattr(c, "set_publish") and not fsm
+        self._tables = [self.all, torch.zeros_like(self.all)] if self.publish else None
         # optional closed-loop mode: every agent runs the reference's FiniteStateMachine (step_fsm)
         self.fsm = fsm
         self.status = torch.full((self.A_loc,), FSM_NEW_PLAN, dtype=torch.int32, device=d)
@@ -358,7 +369,19 @@ class SwarmTick:
         c = self.compute
         c.tick_inputs(self.own, stamp, self.hover, self.now, self.t_start, self.pva, self.poses)
         c.update_map(self.poses, self.now, self.all, self.A_tot)
-        c.replan(self.pva, self.goals, self.t_start, self.new, self.ok)
-        self._publish()
+        if self.publish:
+            local = not self.exchange.active and not self.distributed
+            nxt = self._tables[(self.tick + 1) & 1] if local else None
+            c.set_publish(self.own, nxt)
+            if self.deconflict:
+                c.set_swarm(self.all, self.A_tot, self.now)
+            c.replan(self.pva, self.goals, self.t_start, self.new, self.ok)
+            if local:
+                self.all = nxt   # what every agent executes after this tick: the next tick's table
+            else:
+                self._exchange()
+        else:
+            c.replan(self.pva, self.goals, self.t_start, self.new, self.ok)
+            self._publish()
         self.tick += 1
         return self.ok.clone()  # self.ok is rewritten by the next tick

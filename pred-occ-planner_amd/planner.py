@@ -174,6 +174,14 @@ class SogmPlanner:
             check(lib().sogm_planner_set_swarm(self._p, records.data_ptr(), n_records, ego_ids.data_ptr(),
                                                t_now.data_ptr()), "sogm_planner_set_swarm")
 
+    def setPublish(self, own_records, next_table=None):
+        """replan() then also merges every successful record into `own_records` and writes each agent's current
+        record into `next_table` (sogm_planner_set_publish); None switches it off.  Tensors are kept alive here."""
+        self._publish = (own_records, next_table)
+        check(lib().sogm_planner_set_publish(self._p, own_records.data_ptr() if own_records is not None else None,
+                                             next_table.data_ptr() if next_table is not None else None),
+              "sogm_planner_set_publish")
+
     # ---- BaselinePlanner::replan ----
     def replan(self, start_pva, goal, t_start, drone_ids, out_records=None, out_ok=None):
         A, dev = self.A, start_pva.device

@@ -86,12 +86,14 @@ class SogmMap:
                 grids = 3 if spare >= 2 else (2 if spare >= 1 else 1)
                 if double_buffer is True:
                     grids = max(grids, 2)
+        rc = 0
         for mode in ([3, 2, 1] if grids >= 3 else [2, 1] if grids == 2 else [1]):
             rc = lib().sogm_set_overlap_clear(self._ctx, mode)
             if rc == 0:
                 return mode
             if rc != _abi.SOGM_ERR_CAPACITY:
                 check(rc, "sogm_set_overlap_clear")
+        check(rc, "sogm_set_overlap_clear")  # even the last fallback (mode 1 needs no memory) failed: not silent
         return 0
 
     def isTrajSafe(self, records, t_now, check_duration):

@@ -79,11 +79,14 @@ class OracleCompute:
                                      pop.config.make_qp_settings())
         self.cyl = pop.scene.cylinders_to_struct(scene["cylinders"])
         self.body = pop.scene.body_particles()
-        self.grids, self.swarm = [None] * (hi - lo), None
+        self.grids, self.swarm, self.pub = [None] * (hi - lo), None, None
         self.overlay_sums = []   # (tick stamp, agent, sum of the SOGM, hash of the occupied cells) per agent-update
 
     def set_swarm(self, all_records, A_tot, now):
         self.swarm = (all_records, A_tot)
+
+    def set_publish(self, own, next_table):
+        self.pub = (own, next_table)
 
     def _records(self, t):
         n = t.shape[0]
@@ -136,6 +139,11 @@ class OracleCompute:
                                               self.swarm[1], a, stamp)
             ok[i] = int(bool(okk))
             new[i] = torch.from_numpy(np.frombuffer(bytes(rec), dtype=np.uint8).copy())
+        if self.pub is not None and self.pub[0] is not None:  # sogm_planner_set_publish restated
+            own, table = self.pub
+            own.copy_(new.where(ok.bool().unsqueeze(1), own))
+            if table is not None:
+                table.copy_(own)
 
     def merge_latest(self, new, ok, own, all_records):
         """k_merge_latest restated: a successful replan replaces the agent's record, a failed one keeps it; the

@@ -218,6 +218,16 @@ def test_world2_failed_communicator_sends_every_rank_to_the_fallback():
     assert out[0][3]["calls"].count("destroy") == 1   # the communicator rank 0 did get is released again
 
 
+def test_publication_modes_fly_the_same_flight(monkeypatch):
+    """SwarmTick.step() with the publication inside the replan (default) and with the separate latest-wins merge
+    (SOGM_PUBLISH=0): same overlays, same table, same ok count (single process, oracle backend)."""
+    sys.path.insert(0, ROOT)
+    monkeypatch.setenv("SOGM_PUBLISH", "0")
+    merged = _swarm_tick_loop(0, 1, 4, 3, None)
+    ref = _reference()   # default mode (cached)
+    assert sorted(merged[0]) == sorted(ref[0]) and merged[1].tobytes() == ref[1].tobytes() and merged[2] == ref[2]
+
+
 def test_shard_bounds_partition_agents():
     pop = importlib.import_module("pred-occ-planner_amd")
     drv = importlib.import_module("pred-occ-planner_amd.driver")
