@@ -183,9 +183,12 @@ open('profiles/r03_end_rocprof.md', 'w').write(md)
 
 
 def kern(table, name):
-    """(calls, avg_ms) of a kernel in a rocprof_summary kernel-trace table"""
-    m = re.search(r"\| [^|]*%s[^|]* \| (\d+) \| [\d.]+ \| ([\d.]+) \|" % re.escape(name), table)
-    return (int(m.group(1)), float(m.group(2))) if m else (0, float('nan'))
+    """(calls, median ms) of a kernel from the per-dispatch list of a rocprof_summary file"""
+    m = re.search(r"^- [^\n]*%s: ([\d, ]+)$" % re.escape(name), table, re.M)
+    if not m:
+        return 0, float('nan')
+    v = sorted(float(x) for x in m.group(1).split(","))
+    return len(v), v[len(v) // 2] / 1e3
 
 
 def pmc(table, name, counter):
@@ -212,7 +215,7 @@ passes of the same commands (separate runs, no trace domains).  "mean value (KB)
 structures and are not rated):
 - `k_dsp_publish` — a pure stream: per agent it reads the future-occupancy accumulators `fut[T][V]`, writes them into
   the SOGM slabs, zeroes them, and reads one occupancy plane: algorithmic bytes 3 V T 4 + 4 V per agent =
-  {pub_alg/1e9:.2f} GB for 16 agents x 100^3 x 15.  Kernel-trace average {pub_ms:.3f} ms -> **{pub_alg/1e9/pub_ms:.2f} TB/s =
+  {pub_alg/1e9:.2f} GB for 16 agents x 100^3 x 15.  Kernel-trace median {pub_ms:.3f} ms -> **{pub_alg/1e9/pub_ms:.2f} TB/s =
   {pub_alg/1e9/pub_ms/8:.2f} of the 8 TB/s peak**; PMC FETCH {pub_f/1e6:.2f} GB + WRITE {pub_w/1e6:.2f} GB =
   x {(pub_f + pub_w) * 1024 / pub_alg:.2f} the algorithmic bytes.
 - `k_dsp_occupancy` (per-voxel resample + occupancy: one 16-byte flag load per voxel, the occupied slots' lines):
