@@ -17,6 +17,8 @@ class StubDist:
         self.rank, self.a_loc = rank, a_loc
     def is_initialized(self):
         return True
+    def get_backend(self):
+        return "stub"   # not "nccl": the driver uses all_gather_into_tensor below
     def all_gather_into_tensor(self, out, own):
         out[self.rank * self.a_loc:(self.rank + 1) * self.a_loc].copy_(own)
 
@@ -35,3 +37,12 @@ oks = [sw.step() for _ in range(steps)]
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / steps
 print(f"world {world} rank {rank}: {dt*1e3:.2f} ms/tick -> {128/dt:.0f} replans/s per GPU, ok {torch.stack(oks).float().mean().item():.3f}")
+# per-agent stage times of the last tick (in-kernel stamps of the dataflow replan)
+import ctypes as C
+ts = np.zeros((128, 8), np.int64)
+pop.lib().sogm_debug_flow_times(sw.planner._p, ts.ctypes.data_as(C.c_void_p))
+t0 = ts[:, 7].min() if ts[:, 7].min() > 0 else ts[:, 0].min()
+us = (ts[:, :7] - t0) / 100.0
+d = lambda a, b: us[:, b] - us[:, a]
+print(f"last tick: end {us[:, 6].max()/1000:.2f} ms; mean/max ms: A* {d(0,1).mean()/1000:.2f}/{d(0,1).max()/1000:.2f}  corr {d(2,3).mean()/1000:.2f}/{d(2,3).max()/1000:.2f}  "
+      f"wait->QP {d(3,4).mean()/1000:.2f}/{d(3,4).max()/1000:.2f}  QP {d(4,5).mean()/1000:.2f}/{d(4,5).max()/1000:.2f}  fin {d(5,6).mean()/1000:.2f}/{d(5,6).max()/1000:.2f}")
