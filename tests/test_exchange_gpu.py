@@ -173,3 +173,85 @@ def test_allgather_two_ranks_event_ordering_against_a_slow_collective(pop, tmp_p
     env["SOGM_TEST_SKIP_CONSUMER_WAIT"] = "1"
     r = subprocess.run([sys.executable, "-c", _TWO_RANK_SCRIPT], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "AssertionError" in r.stderr and "two-rank exchange ok" not in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
+
+
+_TWO_RANK_FLIGHT = r"""
+import ctypes as C, importlib, os, sys, threading
+import numpy as np, torch
+sys.path.insert(0, os.environ["SOGM_REPO"])
+pop = importlib.import_module("pred-occ-planner_amd")
+driver = importlib.import_module("pred-occ-planner_amd.driver")
+WORLD, A_LOC, TICKS = 2, 4, 6
+tls = threading.local()
+
+class ThreadDist:
+    # what driver.RecordExchange needs of torch.distributed, between the threads of one process
+    def __init__(self, world):
+        self.world, self.bar, self.box, self.shared = world, threading.Barrier(world), [None] * world, None
+    def is_initialized(self): return True
+    def get_backend(self): return "nccl"
+    def broadcast_object_list(self, lst, src=0):
+        if tls.rank == src: self.shared = list(lst)
+        self.bar.wait(); lst[:] = self.shared; self.bar.wait()
+    def all_gather_object(self, out, obj):
+        self.box[tls.rank] = obj
+        self.bar.wait(); out[:] = list(self.box); self.bar.wait()
+
+dist = ThreadDist(WORLD)
+res, errs = {}, []
+def run(rank):
+    try:
+        tls.rank = rank
+        torch.cuda.set_device(0)
+        with torch.cuda.stream(torch.cuda.Stream()):
+            sw = driver.SwarmTick("parity", A_LOC, rank, WORLD, 0, dist=dist)
+            assert sw.exchange.active and sw.distributed and sw.publish      # RCCL (stand-in) behind the C ABI
+            oks = [int(sw.step().sum().item()) for _ in range(TICKS)]
+            table = sw.records_all().cpu().numpy().copy()
+            own = sw.own.cpu().numpy().copy()
+            torch.cuda.current_stream().synchronize()
+            res[rank] = (oks, table, own)
+            dist.bar.wait()          # nobody destroys its communicator while the other is still in a collective
+            sw.close()
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        errs.append((rank, traceback.format_exc()))
+        try: dist.bar.abort()
+        except Exception: pass
+ts = [threading.Thread(target=run, args=(r,), daemon=True) for r in range(WORLD)]
+[t.start() for t in ts]
+[t.join(240) for t in ts]
+if errs or any(t.is_alive() for t in ts):
+    print("FAILED", errs, [t.is_alive() for t in ts], flush=True)
+    os._exit(3)
+# the same flight in one process (no process group, the table refreshed by the replan's publication)
+sw = driver.SwarmTick("parity", A_LOC * WORLD)
+ref_oks = [int(sw.step().sum().item()) for _ in range(TICKS)]
+ref_table = sw.records_all().cpu().numpy().copy()
+sw.close()
+assert np.array_equal(res[0][1], res[1][1]), "ranks hold different tables"
+assert np.array_equal(res[0][1], ref_table), "two-rank table differs from the single-process flight"
+for r in range(WORLD):
+    assert np.array_equal(res[r][2], ref_table[r * A_LOC:(r + 1) * A_LOC])
+assert [a + b for a, b in zip(res[0][0], res[1][0])] == ref_oks and sum(ref_oks) >= 3 * TICKS
+print("two-rank flight ok", ref_oks)
+"""
+
+
+def test_two_rank_flight_on_one_gpu_matches_the_single_process_flight(pop, tmp_path):
+    """The N > 1 tick on real kernels: two SwarmTick ranks (two host threads, one GPU, world size 2) fly 6 ticks with
+    HipCompute, the publication inside the replan and the trajectory exchange through sogm_comm_* /
+    sogm_traj_allgather — RCCL replaced by the in-process stand-in (tests/fake_rccl.cpp), torch.distributed by a
+    thread rendezvous — and must end with the table, the own records and the per-tick ok counts of ONE process flying
+    all 8 agents: rank-local overlays and deconfliction read the all-gathered table (one tick stale, like the ROS
+    broadcast), consumers are ordered behind the collective inside the library only."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = tmp_path / "libfake_rccl.so"
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-std=c++17", "-shared", "-fPIC",
+                           os.path.join(root, "tests", "fake_rccl.cpp"), "-o", str(so)])
+    env = dict(os.environ, SOGM_RCCL_LIB=str(so), SOGM_REPO=root)
+    r = subprocess.run([sys.executable, "-c", _TWO_RANK_FLIGHT], env=env, capture_output=True, text=True, timeout=500)
+    assert r.returncode == 0 and "two-rank flight ok" in r.stdout, (r.stdout[-3000:], r.stderr[-3000:])
