@@ -47,7 +47,12 @@ SOGM_HD double scale2(double x, int k) { return x * from_bits((uint64_t)(1023 + 
 
 SOGM_HD double fabs_(double x) { return x < 0 ? -x : x; }
 
-/* cube root: exponent split + fixed Newton iterations on the mantissa */
+/* cube root: exponent split, then division-free Newton on t = m^(-1/3) and one Newton step on y = m t^2.
+ * (A Newton iteration on y itself divides by 3 y^2 every step: seven dependent fp64 divisions cost the A* child
+ * evaluation ~0.5 us per call on the GPU.)  Initial guess: a quadratic per octave of m in [1,8), relative error
+ * 1.8e-3; t <- t + t (1 - m t^3) / 3 squares the error twice (-> 8e-11); the closing step
+ * y <- y - (y^3 - m) t^2 / 3 leaves the rounding of its own five operations: <= 0.96 ulp from the exact root over
+ * 2e7 samples, exact on perfect cubes (tests/test_detmath.py). */
 SOGM_HD double cbrt(double x) {
   if (x == 0.0 || x != x) return x;
   const bool neg = x < 0;
@@ -62,17 +67,24 @@ SOGM_HD double cbrt(double x) {
     e     = (int)(u >> 52) & 0x7ff;
     shift = -18;
   }
-  int    ex = e - 1023;                                 /* a = m * 2^ex, m in [1,2) */
-  int    q  = ex >= 0 ? ex / 3 : -((-ex + 2) / 3);      /* floor(ex / 3) */
-  int    r  = ex - 3 * q;                               /* 0,1,2 */
-  double m  = from_bits((u & 0x000fffffffffffffULL) | ((uint64_t)(1023 + r) << 52)); /* [1,8) */
-  /* initial guess: linear fit on [1,8), then fixed Newton steps y <- y - (y^3 - m) / (3 y^2) */
-  double y = 0.7 + 0.16 * m;
-  for (int i = 0; i < 7; ++i) {
-    const double y2 = y * y;
-    y               = y - (y2 * y - m) / (3.0 * y2);
+  const int    ex = e - 1023;                            /* a = m * 2^ex, m in [1,2) */
+  const int    q  = ex >= 0 ? ex / 3 : -((-ex + 2) / 3); /* floor(ex / 3) */
+  const int    r  = ex - 3 * q;                          /* 0,1,2 */
+  const double m  = from_bits((u & 0x000fffffffffffffULL) | ((uint64_t)(1023 + r) << 52)); /* [2^r, 2^(r+1)) */
+  const double c2 = r == 0 ? 0.09339756192967737 : (r == 1 ? 0.018532423507304427 : 0.00367729857137654);
+  const double c1 = r == 0 ? -0.4833214344056348 : (r == 1 ? -0.19180623835357227 : -0.07611835613412744);
+  const double c0 = r == 0 ? 1.38815612815435 : (r == 1 ? 1.1017802490641597 : 0.8744835632011081);
+  const double third = 1.0 / 3.0;
+  double       t     = (c2 * m + c1) * m + c0;
+  for (int i = 0; i < 2; ++i) {
+    const double t3 = (t * t) * t;
+    t               = t + t * ((1.0 - m * t3) * third);
   }
-  y = scale2(y, q + shift);
+  const double t2 = t * t;
+  double       y  = m * t2;
+  const double y2 = y * y;
+  y               = y - (y2 * y - m) * (t2 * third);
+  y               = scale2(y, q + shift);
   return neg ? -y : y;
 }
 

@@ -601,12 +601,11 @@ __global__ __launch_bounds__(ASTAR_THREADS) void k_astar(
               found = (int)(slot0 & 0x3FFF);
             else
               found = hash_find(htab, hcap, key);
-            if (found >= 0) {
+            if (found >= 0) {  // (consumed after the heuristic below: the node read runs under its arithmetic)
               found_st = pool[found].node_state;
               found_g  = pool[found].g;
             }
           }
-          if (found >= 0 && found_st == IN_CLOSE_SET) gate = false;
           if (collide) gate = false;
           double cg = 0.0, cf = 0.0;
           if (gate) {
@@ -614,6 +613,9 @@ __global__ __launch_bounds__(ASTAR_THREADS) void k_astar(
             const double usq = (um[0] * um[0] + um[1] * um[1]) + um[2] * um[2];
             cg               = (usq + ap.w_time) * tau + s_cur_g;
             cf = cg + ap.lambda_heu * estimate_heuristic(ap, ps, end_state, ttg);
+          }
+          if (found >= 0 && found_st == IN_CLOSE_SET) gate = false;
+          if (gate) {
             if (!packable)
               ev = EV_ERR;  // index outside the packable range
             else if (found >= 0)

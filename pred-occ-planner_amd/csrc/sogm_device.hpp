@@ -134,6 +134,51 @@ struct MapView {
   }
 };
 
+// The (2S+1)^2 window of getClearOcccupancy at one height (fkpcp map: the z loop degenerates): every gather is
+// issued first so the loads overlap, then the reference's running sum is replayed in kernel order (x outer, y inner)
+// WITHOUT divergent control flow — a cell outside the grid is read at a clamped address and masked to +0.0f
+// (x + 0 = x exactly), and "return 1 at the first prefix sum above the threshold" is the OR of the prefix
+// comparisons (49 nested early exits cost ~30 instructions and two spilled exec masks per cell).  The window size is
+// a template parameter and the clamps / range tests are per row and per column, ~4 instructions per cell: with a
+// run-time window (k / w, k % w, six range compares and a 64-bit address per cell) this one query was 5.5 of the
+// 7 us of an A* child evaluation — instruction-bound, not memory-bound.  (ix, iy, iz) is inside the grid.
+template <int S>
+__device__ inline int window_sum_hits(const char *base, const GridGeom &g, int ix, int iy, int iz, float thr) {
+  constexpr int W  = 2 * S + 1;
+  const int     sh = g.half ? 1 : 2;
+  unsigned      col[W], colok[W];
+#pragma unroll
+  for (int a = 0; a < W; ++a) {
+    const int qx = ix + a - S;
+    colok[a]     = (unsigned)qx < (unsigned)g.L ? 0xFFFFFFFFu : 0u;
+    col[a]       = (unsigned)min(max(qx, 0), g.L - 1) << sh;
+  }
+  float v[W][W];  // [x][y]
+#pragma unroll
+  for (int b = 0; b < W; ++b) {
+    const int      qy    = iy + b - S;
+    const unsigned rowok = (unsigned)qy < (unsigned)g.W ? 0xFFFFFFFFu : 0u;
+    // byte offset of the row inside the slab: V * 4 < 2^32 is checked where the map is created
+    const unsigned row = ((unsigned)(iz * g.W + min(max(qy, 0), g.W - 1)) * (unsigned)g.L) << sh;
+#pragma unroll
+    for (int a = 0; a < W; ++a) {
+      const char *p   = base + (row + col[a]);
+      const float val = g.half ? __half2float(*reinterpret_cast<const __half *>(p)) : *reinterpret_cast<const float *>(p);
+      v[a][b]         = __uint_as_float(__float_as_uint(val) & (rowok & colok[a]));
+    }
+  }
+  float sum = 0.0F;
+  bool  hit = false;
+#pragma unroll
+  for (int a = 0; a < W; ++a)
+#pragma unroll
+    for (int b = 0; b < W; ++b) {
+      sum += v[a][b];
+      hit = hit || sum > thr;
+    }
+  return hit ? 1 : 0;
+}
+
 // getClearOcccupancy(pos, int t): fake_particle_risk_voxel.cpp:309-331 / risk_base.cpp:228-251.
 // Summation order = inflate-kernel build order (x, y, z nested) so the fp32 running sum and its
 // early exit are identical to the reference.
@@ -159,33 +204,14 @@ __device__ inline int query_clear_idx(const MapView &m, int agent, double px, do
                                                  : g.thr_region - (float)t * g.decay_region;
   float        sum = 0.0F;
   if (zs == 0 && s <= 3) {
-    // Common case (fkpcp map, K = (2s+1)^2 <= 49): issue every gather first so the loads overlap, then replay
-    // the reference's running sum in kernel order (x outer, y inner) WITHOUT divergent control flow: a cell
-    // outside the grid is read at a clamped address and masked to +0.0f (x + 0 = x exactly), and "return 1 at
-    // the first prefix sum above the threshold" is the OR of the prefix comparisons.  (49 nested early exits
-    // cost ~30 instructions and two spilled exec masks per cell.)
-    float     v[49];
-    const int w = 2 * s + 1, ww = w * w;
-#pragma unroll
-    for (int k = 0; k < 49; ++k) {
-      v[k] = 0.0F;
-      if (k < ww) {  // uniform
-        const int      qx = ix + (k / w - s), qy = iy + (k % w - s);
-        const unsigned keep = g.in_range(qx, qy, iz) ? 0xFFFFFFFFu : 0u;  // a VGPR value, not a saved exec mask
-        const int      cx = min(max(qx, 0), g.L - 1), cy = min(max(qy, 0), g.W - 1);
-        const float    val = cell_ld(sl, (size_t)iz * g.L * g.W + (size_t)cy * g.L + cx, g.half);
-        v[k]               = __uint_as_float(__float_as_uint(val) & keep);
-      }
+    // Common case (fkpcp map, K = (2s+1)^2 <= 49): see window_sum_hits
+    const char *base = reinterpret_cast<const char *>(sl);
+    switch (s) {
+      case 0: return window_sum_hits<0>(base, g, ix, iy, iz, thr);
+      case 1: return window_sum_hits<1>(base, g, ix, iy, iz, thr);
+      case 2: return window_sum_hits<2>(base, g, ix, iy, iz, thr);
+      default: return window_sum_hits<3>(base, g, ix, iy, iz, thr);
     }
-    bool hit = false;
-#pragma unroll
-    for (int k = 0; k < 49; ++k) {
-      if (k < ww) {
-        sum += v[k];
-        hit = hit || sum > thr;
-      }
-    }
-    return hit ? 1 : 0;
   }
   for (int x = -s; x <= s; ++x) {
     const int qx = ix + x;

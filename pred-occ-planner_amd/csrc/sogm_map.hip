@@ -914,6 +914,11 @@ int sogm_create(const SogmSpec *spec, int n_agents, int device, sogm_ctx **out) 
       spec->map_kind != SOGM_MAP_RISKVOXEL)
     return SOGM_ERR_INVALID_ARG;
   if (spec->storage != SOGM_STORE_F32 && spec->storage != SOGM_STORE_F16) return SOGM_ERR_INVALID_ARG;
+  // one time slice is addressed with 32-bit byte offsets (window_sum_hits) and V is an int
+  if ((unsigned long long)spec->L * spec->W * spec->H >= (1ull << 30)) {
+    sogm::set_error_text("sogm_create: L * W * H must stay below 2^30 cells per time slice");
+    return SOGM_ERR_INVALID_ARG;
+  }
   *out = nullptr;
   if (sogm_device_count() <= device || device < 0) {
     std::snprintf(sogm::g_err, sizeof(sogm::g_err), "no HIP device %d", device);
