@@ -222,8 +222,7 @@ __device__ inline void hash_insert(unsigned long long *tab, int cap, unsigned lo
 // (std::__push_heap.  The ids of up to three ancestors and then their f are read as two batches of independent LDS
 //  loads — a dependent LDS read costs ~64 cycles — before the level-by-level comparisons; the positions read ahead are
 //  only written once the hole has moved past them, so the values are the ones the plain loop would see.)
-__device__ inline void heap_push_up(const double *f, unsigned short *h, int hole, int top, int value) {
-  const double fv = f[value];
+__device__ inline void heap_push_up(const double *f, unsigned short *h, int hole, int top, int value, double fv) {
   while (hole > top) {
     const int p1 = (hole - 1) / 2;
     const int p2 = p1 > top ? (p1 - 1) / 2 : p1;
@@ -242,10 +241,29 @@ __device__ inline void heap_push_up(const double *f, unsigned short *h, int hole
   }
   h[hole] = (unsigned short)value;
 }
-__device__ inline void heap_push(const double *f, unsigned short *h, int &n, int value) {
+__device__ inline void heap_push(const double *f, unsigned short *h, int &n, int value, double fv) {  // fv = f[value]
   h[n] = (unsigned short)value;
   ++n;
-  heap_push_up(f, h, n - 1, 0, value);  // new nodes rarely beat their parent: the loop exits after a level or two
+  heap_push_up(f, h, n - 1, 0, value, fv);  // new nodes rarely beat their parent: the loop exits after a level or two
+}
+// std::push_heap by a whole wave (all 64 lanes call it with the same arguments; n, value, fv uniform): the path
+// from the new leaf to the root is known in advance, so lane j-1 fetches the level-j ancestor's id and f (two LDS
+// latencies for the whole path instead of two per level — the children of an expansion have f close to the open
+// list's minimum and climb most of its ~12 levels), the hole climbs while "ancestor's f > fv" holds (the first lane
+// where it does not ends it: the loop of std::__push_heap, also where in-place f updates have bent the heap
+// property), and the moved ancestors are written one level down by their lanes.
+__device__ inline void wave_heap_push(const double *f, unsigned short *h, int &n, int value, double fv, int lane) {
+  const int q0 = n + 1;  // 1-based position of the new leaf
+  ++n;
+  const int                j     = lane + 1;
+  const int                q     = j < 31 ? q0 >> j : 0;  // 1-based position of the level-j ancestor (0: above the root)
+  const bool               valid = q >= 1;
+  const int                id    = valid ? h[q - 1] : 0;
+  const double             fj    = f[id];
+  const unsigned long long mv    = __ballot(valid && fj > fv);
+  const int                k     = __builtin_ctzll(~mv);  // levels the hole climbs (lanes >= 14 are never valid)
+  if (j <= k) h[(q0 >> (j - 1)) - 1] = (unsigned short)id;
+  if (lane == 0) h[(q0 >> k) - 1] = (unsigned short)value;
 }
 __device__ inline void heap_pop(const double *f, unsigned short *h, int &n) {
   if (n > 1) {
@@ -266,7 +284,7 @@ __device__ inline void heap_pop(const double *f, unsigned short *h, int &n) {
       h[hole] = h[child - 1];
       hole    = child - 1;
     }
-    heap_push_up(f, h, hole, 0, value);
+    heap_push_up(f, h, hole, 0, value, f[value]);
   }
   --n;
 }
@@ -347,6 +365,7 @@ __global__ __launch_bounds__(ASTAR_THREADS) void k_astar(
   __shared__ int                s_first;     // 1 = "init" expansion (single input = start acc)
   __shared__ int                s_was_first, s_cur_node, s_base_node, s_n_written;
   __shared__ int                s_ret;
+  __shared__ unsigned           s_closed[ASTAR_POOL_MAX / 32];  // bit n: node n is in the closed set
 
   // the second attempt's pool / hash table follow the first attempts' ([n_agents_total .. 2 n_agents_total))
   const size_t        slot = (size_t)agent + (second ? (size_t)m.n_agents : 0);
@@ -395,6 +414,7 @@ __global__ __launch_bounds__(ASTAR_THREADS) void k_astar(
   bool is_shot_succ = false, need_pop = false;
   long long tk[6] = {0, 0, 0, 0, 0, 0};  // wall_clock64 ticks (100 MHz): pop, eval, dup, merge, write, n_exp
   long long tmark = 0;
+  const bool timed = wsp.dbg != nullptr;  // phase statistics (sogm_debug_astar_stats): s_memrealtime is not free
 
   // search_mode 0: the replan's call pattern (init_search = true, then false if NO_PATH, baseline_fake.cpp:284-291);
   // 1 / 2: exactly one search(…, init = true / false, …) for the per-object shim
@@ -404,6 +424,7 @@ __global__ __launch_bounds__(ASTAR_THREADS) void k_astar(
   for (int attempt = attempt_lo; attempt < attempt_hi; ++attempt) {
     // reset(): clear the hash table (all lanes)
     for (int i = tid; i < hcap; i += ASTAR_THREADS) htab[i] = HASH_EMPTY;
+    for (int i = tid; i < ASTAR_POOL_MAX / 32; i += ASTAR_THREADS) s_closed[i] = 0u;
     __syncthreads();
     bool done = false;
     if (tid == ASTAR_MASTER) {
@@ -426,7 +447,7 @@ __global__ __launch_bounds__(ASTAR_THREADS) void k_astar(
       n0.f          = ap.lambda_heu * estimate_heuristic(ap, n0.state, end_state, ttg);
       s_f[0]        = n0.f;
       n0.node_state = IN_OPEN_SET;
-      heap_push(s_f, s_heap, heap_n, 0);
+      heap_push(s_f, s_heap, heap_n, 0, n0.f);
       use_node_num += 1;
       n0.time     = time_start;
       n0.time_idx = (int)floor((time_start - time_origin) * inv_tres);
@@ -442,7 +463,7 @@ __global__ __launch_bounds__(ASTAR_THREADS) void k_astar(
     int cur = -1;
     while (!done) {
       // ---------------- master: pop / terminate ----------------
-      tmark = wall_clock64();
+      if (timed) tmark = wall_clock64();
       if (tid == ASTAR_MASTER) {
         s_n_active = 0;
         // speculative second attempt: every 8th expansion, look whether the first attempt has found a path
@@ -453,7 +474,14 @@ __global__ __launch_bounds__(ASTAR_THREADS) void k_astar(
           ret = NO_PATH;  // open set empty (:419-422)
         } else {
           cur          = s_heap[0];
-          Node &cn     = pool[cur];
+          const Node cn = pool[cur];  // the whole record in one batch of loads
+          // (what the lanes need of it goes to LDS at once, whether or not the search stops here: every field is
+          //  then fetched by the first batch instead of a second round trip after the termination tests)
+          for (int i = 0; i < 6; ++i) s_cur_state[i] = cn.state[i];
+          s_cur_time = cn.time;
+          s_cur_g    = cn.g;
+          for (int i = 0; i < 3; ++i) s_cur_index[i] = cn.index[i];
+          s_cur_tidx = cn.time_idx;
           double d3[3] = {cn.state[0] - start_pt[0], cn.state[1] - start_pt[1],
                           cn.state[2] - start_pt[2]};
           const bool reach_horizon = sogm_det::sqrt_rn(dot3(d3, d3)) >= ap.horizon;
@@ -509,16 +537,11 @@ __global__ __launch_bounds__(ASTAR_THREADS) void k_astar(
             stop = true;
           }
           if (!stop) {
-            need_pop      = true;  // the heap is restored after the barrier, under the children's evaluation
-            cn.node_state = IN_CLOSE_SET;
+            need_pop = true;  // the heap is restored after the barrier, under the children's evaluation
+            // closed: the lanes read this bit; the record's node_state is stored after the barrier (a global store
+            // before it would be waited for)
+            s_closed[cur >> 5] |= 1u << (cur & 31);
             iter_num += 1;
-            if (out_trace && n_trace < trace_cap) out_trace[(size_t)agent * trace_cap + n_trace] = cur;
-            ++n_trace;
-            for (int i = 0; i < 6; ++i) s_cur_state[i] = cn.state[i];
-            s_cur_time = cn.time;
-            s_cur_g    = cn.g;
-            for (int i = 0; i < 3; ++i) s_cur_index[i] = cn.index[i];
-            s_cur_tidx  = cn.time_idx;
             s_n_active  = s_first ? 1 : s_n_inputs;
             s_was_first = s_first;
             s_first     = 0;  // init_search = false after the first expansion (:243)
@@ -535,10 +558,13 @@ __global__ __launch_bounds__(ASTAR_THREADS) void k_astar(
         break;
       }
       if (tid == ASTAR_MASTER && need_pop) {  // std::pop_heap's sift-down, beside the evaluation below
+        pool[cur].node_state = IN_CLOSE_SET;
+        if (out_trace && n_trace < trace_cap) out_trace[(size_t)agent * trace_cap + n_trace] = cur;
+        ++n_trace;
         heap_pop(s_f, s_heap, heap_n);
         need_pop = false;
       }
-      {
+      if (timed) {
         const long long t2 = wall_clock64();
         tk[0] += t2 - tmark;
         tmark = t2;
@@ -601,9 +627,10 @@ __global__ __launch_bounds__(ASTAR_THREADS) void k_astar(
               found = (int)(slot0 & 0x3FFF);
             else
               found = hash_find(htab, hcap, key);
-            if (found >= 0) {  // (consumed after the heuristic below: the node read runs under its arithmetic)
-              found_st = pool[found].node_state;
-              found_g  = pool[found].g;
+            if (found >= 0) {
+              // a node reached through the table is open or closed (LDS bit); its g matters for an open one only
+              found_st = ((s_closed[found >> 5] >> (found & 31)) & 1u) ? IN_CLOSE_SET : IN_OPEN_SET;
+              if (found_st == IN_OPEN_SET) found_g = pool[found].g;
             }
           }
           if (collide) gate = false;
@@ -633,7 +660,7 @@ __global__ __launch_bounds__(ASTAR_THREADS) void k_astar(
         }
       }
       __syncthreads();
-      {
+      if (timed) {
         const long long t2 = wall_clock64();
         tk[1] += t2 - tmark;
         tmark = t2;
@@ -722,72 +749,89 @@ __global__ __launch_bounds__(ASTAR_THREADS) void k_astar(
         if (wave == 1 && lane == 0) s_n_events = s_n_ev_w0 + __popcll(be);
       }
       __syncthreads();
-      {
+      if (timed) {
         const long long t2 = wall_clock64();
         tk[2] += t2 - tmark;
         tmark = t2;
       }
-      // ---------------- master: replay the events in child order (:366-414) ----------------
-      if (tid == ASTAR_MASTER) {
+      // ---------------- master wave: replay the events in child order (:366-414) ----------------
+      // Every lane of the master's wave runs the replay with the master's open-list state (the pushes use the
+      // lanes, wave_heap_push); lane 0 alone writes what is not a push.
+      if (tid >= ASTAR_MASTER) {
+        const int lane = tid - ASTAR_MASTER;
+        int       hn   = __builtin_amdgcn_readfirstlane(heap_n);
+        int       unn  = __builtin_amdgcn_readfirstlane(use_node_num);
+        int       rt   = __builtin_amdgcn_readfirstlane(ret);
+        const int curb = __builtin_amdgcn_readfirstlane(cur);
+        bool      dn   = false;
         const int n_ev = s_n_events;
         int       n_written = 0, n_upd = 0;
         int2      rec  = s_erec[0];
         double    rcf  = s_erec_f[0];
-        for (int k = 0; k < n_ev && !done; ++k) {
+        for (int k = 0; k < n_ev && !dn; ++k) {
           const int    kn  = k + 1 < n_ev ? k + 1 : k;  // next record in flight while this one is replayed
           const int2   nrec = s_erec[kn];
           const double ncf  = s_erec_f[kn];
           const int    ev = rec.x, opd = rec.y;
           if (ev == EV_NEW) {
             const int node = s_base_node + opd;
-            s_f[node]      = rcf;
-            heap_push(s_f, s_heap, heap_n, node);
-            use_node_num += 1;
+            if (lane == 0) s_f[node] = rcf;
+            wave_heap_push(s_f, s_heap, hn, node, rcf, lane);
+            unn += 1;
             n_written = opd + 1;
-            if (use_node_num == ap.allocate_num) {  // "run out of memory" (:393-396)
-              ret  = NO_PATH;
-              done = true;
+            if (unn == ap.allocate_num) {  // "run out of memory" (:393-396)
+              rt = NO_PATH;
+              dn = true;
             }
           } else if (ev == EV_DUP) {
-            s_f[s_base_node + s_rank[opd]] = rcf;
+            if (lane == 0) s_f[s_base_node + s_rank[opd]] = rcf;
           } else if (ev == EV_OPEN) {
-            const int i     = opd;
-            const int fnode = s_found[i];
-            Node     &pn    = pool[fnode];
-            // pn.g as this expansion's earlier children left it: the value fetched with the hash probe, or the g
-            // of the last earlier child that lowered it (kept in a short list) — no global load on the serial path
-            double g_now = s_og[i];
-            int    slot  = -1;
-            for (int u = 0; u < n_upd; ++u)
-              if (s_upd_node[u] == fnode) {
-                g_now = s_upd_g[u];
-                slot  = u;
+            if (lane == 0) {
+              const int i     = opd;
+              const int fnode = s_found[i];
+              Node     &pn    = pool[fnode];
+              // pn.g as this expansion's earlier children left it: the value fetched with the hash probe, or the g
+              // of the last earlier child that lowered it (kept in a short list) — no global load on the serial path
+              double g_now = s_og[i];
+              int    slot  = -1;
+              for (int u = 0; u < n_upd; ++u)
+                if (s_upd_node[u] == fnode) {
+                  g_now = s_upd_g[u];
+                  slot  = u;
+                }
+              if (s_cg[i] < g_now) {
+                for (int q = 0; q < 6; ++q) pn.state[q] = s_cstate[i][q];
+                pn.f       = rcf;
+                pn.g       = s_cg[i];
+                s_f[fnode] = rcf;
+                for (int q = 0; q < 3; ++q) pn.input[q] = first ? start_a[q] : s_inputs[i][q];
+                pn.duration = tau;
+                pn.parent   = curb;
+                pn.time     = new_t;
+                if (slot < 0) slot = n_upd++;
+                s_upd_node[slot] = fnode;
+                s_upd_g[slot]    = s_cg[i];
               }
-            if (s_cg[i] < g_now) {
-              for (int q = 0; q < 6; ++q) pn.state[q] = s_cstate[i][q];
-              pn.f       = rcf;
-              pn.g       = s_cg[i];
-              s_f[fnode] = rcf;
-              for (int q = 0; q < 3; ++q) pn.input[q] = first ? start_a[q] : s_inputs[i][q];
-              pn.duration = tau;
-              pn.parent   = cur;
-              pn.time     = new_t;
-              if (slot < 0) slot = n_upd++;
-              s_upd_node[slot] = fnode;
-              s_upd_g[slot]    = s_cg[i];
             }
           } else {
-            ret  = SEARCH_ERR;
-            done = true;
+            rt = SEARCH_ERR;
+            dn = true;
           }
           rec = nrec;
           rcf = ncf;
         }
-        s_n_written = n_written;
-        s_n_active  = done ? -1 : 1;
+        // (the same values in every lane of the wave; the master lane's copies are the ones read later)
+        heap_n       = hn;
+        use_node_num = unn;
+        ret          = rt;
+        if (dn) done = true;
+        if (lane == 0) {
+          s_n_written = n_written;
+          s_n_active  = dn ? -1 : 1;
+        }
       }
       __syncthreads();
-      {
+      if (timed) {
         const long long t2 = wall_clock64();
         tk[3] += t2 - tmark;
         tmark = t2;
@@ -815,7 +859,7 @@ __global__ __launch_bounds__(ASTAR_THREADS) void k_astar(
       }
       if (s_n_active < 0) done = true;
       __syncthreads();
-      {
+      if (timed) {
         const long long t2 = wall_clock64();
         tk[4] += t2 - tmark;
         tk[5] += 1;

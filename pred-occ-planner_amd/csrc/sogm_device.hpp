@@ -143,7 +143,8 @@ struct MapView {
 // run-time window (k / w, k % w, six range compares and a 64-bit address per cell) this one query was 5.5 of the
 // 7 us of an A* child evaluation — instruction-bound, not memory-bound.  (ix, iy, iz) is inside the grid.
 template <int S>
-__device__ inline int window_sum_hits(const char *base, const GridGeom &g, int ix, int iy, int iz, float thr) {
+__device__ inline void window_gather(const char *base, const GridGeom &g, int ix, int iy, int iz,
+                                     float (&v)[2 * S + 1][2 * S + 1]) {  // v[x][y]
   constexpr int W  = 2 * S + 1;
   const int     sh = g.half ? 1 : 2;
   unsigned      col[W], colok[W];
@@ -153,22 +154,43 @@ __device__ inline int window_sum_hits(const char *base, const GridGeom &g, int i
     colok[a]     = (unsigned)qx < (unsigned)g.L ? 0xFFFFFFFFu : 0u;
     col[a]       = (unsigned)min(max(qx, 0), g.L - 1) << sh;
   }
-  float v[W][W];  // [x][y]
+  if (!g.half && ix - S >= 0 && ix + S < g.L) {
+    // fp32 cells, window inside the grid in x: a row's W cells are one run of dwords (4-byte aligned), fetched with
+    // one or two wide loads instead of W
+    struct __attribute__((packed, aligned(4))) Row {
+      float c[W];
+    };
+    const unsigned x0 = (unsigned)(ix - S) << 2;
 #pragma unroll
-  for (int b = 0; b < W; ++b) {
-    const int      qy    = iy + b - S;
-    const unsigned rowok = (unsigned)qy < (unsigned)g.W ? 0xFFFFFFFFu : 0u;
-    // byte offset of the row inside the slab: V * 4 < 2^32 is checked where the map is created
-    const unsigned row = ((unsigned)(iz * g.W + min(max(qy, 0), g.W - 1)) * (unsigned)g.L) << sh;
+    for (int b = 0; b < W; ++b) {
+      const int      qy    = iy + b - S;
+      const unsigned rowok = (unsigned)qy < (unsigned)g.W ? 0xFFFFFFFFu : 0u;
+      const unsigned row   = ((unsigned)(iz * g.W + min(max(qy, 0), g.W - 1)) * (unsigned)g.L) << 2;
+      const Row      r     = *reinterpret_cast<const Row *>(base + (row + x0));
 #pragma unroll
-    for (int a = 0; a < W; ++a) {
-      const char *p   = base + (row + col[a]);
-      const float val = g.half ? __half2float(*reinterpret_cast<const __half *>(p)) : *reinterpret_cast<const float *>(p);
-      v[a][b]         = __uint_as_float(__float_as_uint(val) & (rowok & colok[a]));
+      for (int a = 0; a < W; ++a) v[a][b] = __uint_as_float(__float_as_uint(r.c[a]) & rowok);
+    }
+  } else {
+#pragma unroll
+    for (int b = 0; b < W; ++b) {
+      const int      qy    = iy + b - S;
+      const unsigned rowok = (unsigned)qy < (unsigned)g.W ? 0xFFFFFFFFu : 0u;
+      // byte offset of the row inside the slab: V * 4 < 2^32 is checked where the map is created
+      const unsigned row = ((unsigned)(iz * g.W + min(max(qy, 0), g.W - 1)) * (unsigned)g.L) << sh;
+#pragma unroll
+      for (int a = 0; a < W; ++a) {
+        const char *p   = base + (row + col[a]);
+        const float val = g.half ? __half2float(*reinterpret_cast<const __half *>(p)) : *reinterpret_cast<const float *>(p);
+        v[a][b]         = __uint_as_float(__float_as_uint(val) & (rowok & colok[a]));
+      }
     }
   }
-  float sum = 0.0F;
-  bool  hit = false;
+}
+template <int S>
+__device__ inline int window_replay(const float (&v)[2 * S + 1][2 * S + 1], float thr) {
+  constexpr int W   = 2 * S + 1;
+  float         sum = 0.0F;
+  bool          hit = false;
 #pragma unroll
   for (int a = 0; a < W; ++a)
 #pragma unroll
@@ -177,6 +199,12 @@ __device__ inline int window_sum_hits(const char *base, const GridGeom &g, int i
       hit = hit || sum > thr;
     }
   return hit ? 1 : 0;
+}
+template <int S>
+__device__ inline int window_sum_hits(const char *base, const GridGeom &g, int ix, int iy, int iz, float thr) {
+  float v[2 * S + 1][2 * S + 1];
+  window_gather<S>(base, g, ix, iy, iz, v);
+  return window_replay<S>(v, thr);
 }
 
 // getClearOcccupancy(pos, int t): fake_particle_risk_voxel.cpp:309-331 / risk_base.cpp:228-251.

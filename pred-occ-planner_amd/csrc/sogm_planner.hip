@@ -275,6 +275,14 @@ void sogm_planner_destroy(sogm_planner *p) {
   delete p;
 }
 
+// The search's per-phase clock statistics (sogm_debug_astar_stats, tools/diag_astar.py) are collected while the map's
+// profiling is on: five s_memrealtime reads per expansion are not free.
+static sogm::AstarWorkspace astar_ws(const sogm_planner *p) {
+  sogm::AstarWorkspace w = p->aw;
+  if (!p->map->profiling) w.dbg = nullptr;
+  return w;
+}
+
 int sogm_astar_search(sogm_planner *p, const double *start_pva, const double *goal,
                       const double *t_start, int32_t *out_ret, double *out_route,
                       int32_t *out_route_len, int route_cap, int32_t *out_stats,
@@ -286,7 +294,7 @@ int sogm_astar_search(sogm_planner *p, const double *start_pva, const double *go
   SOGM_HIP_CHECK(hipSetDevice(p->map->device));
   hipStream_t st = (hipStream_t)stream;
   prof_begin(p->map, SOGM_PROF_ASTAR, st);
-  int rc = launch_astar(view_of(p->map), p->ap, p->pp.corridor_tau, p->aw, p->sel_count,
+  int rc = launch_astar(view_of(p->map), p->ap, p->pp.corridor_tau, astar_ws(p), p->sel_count,
                         start_pva, goal, t_start, out_ret, out_route, out_route_len, route_cap,
                         out_stats, out_trace, out_trace ? trace_cap : 0, st, p->sel_first, nullptr, p->search_mode);
   prof_end(p->map, SOGM_PROF_ASTAR, st);
@@ -515,7 +523,7 @@ static int replan_flow(sogm_planner *p, const double *start_pva, const double *g
   }
   for (int k = 0; k < 4; ++k) SOGM_HIP_CHECK(hipStreamWaitEvent(p->fstream[k], p->ev_in, 0));
   prof_begin(c, SOGM_PROF_ASTAR, sA);
-  if (launch_astar(mv, p->ap, p->pp.corridor_tau, p->aw, A, start_pva, goal, t_start, p->d_ret, p->d_route,
+  if (launch_astar(mv, p->ap, p->pp.corridor_tau, astar_ws(p), A, start_pva, goal, t_start, p->d_ret, p->d_route,
                    p->d_route_len, p->route_cap, p->d_stats, nullptr, 0, sA, 0, &p->fc, spec ? 8 : 0)) {
     sogm::set_error("sogm_replan: k_astar", hipGetLastError());
     return SOGM_ERR_HIP;
@@ -597,7 +605,7 @@ static int replan_impl(sogm_planner *p, const double *start_pva, const double *g
     if (n <= 0) continue;
     hipStream_t st = p->gstream[g];
     SOGM_HIP_CHECK(hipStreamWaitEvent(st, p->ev_in, 0));
-    if (launch_astar(mv, p->ap, p->pp.corridor_tau, p->aw, n, start_pva, goal, t_start, p->d_ret,
+    if (launch_astar(mv, p->ap, p->pp.corridor_tau, astar_ws(p), n, start_pva, goal, t_start, p->d_ret,
                      p->d_route, p->d_route_len, p->route_cap, p->d_stats, nullptr, 0, st, a0) ||
         launch_corridor(mv, p->pp, p->cw, n, start_pva, t_start, p->d_route, p->d_route_len,
                         p->route_cap, p->d_polys, p->d_nfaces, p->d_npoly, p->d_goal, st, a0, p->ev_pts[g])) {
