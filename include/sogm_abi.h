@@ -184,8 +184,23 @@ int  sogm_create(const SogmSpec *spec, int n_agents, int device, sogm_ctx **out)
 void sogm_destroy(sogm_ctx *ctx);
 /* Bytes of HBM held by the grid. */
 int64_t sogm_grid_bytes(const sogm_ctx *ctx);
-/* Device pointer of the grid (layout above; __half elements when storage is SOGM_STORE_F16). */
+/* Device pointer of the grid (layout above; __half elements when storage is SOGM_STORE_F16).  The caller may write
+ * through it: the grid's next reset is then the dense clear (see sogm_set_sparse_reset). */
 float  *sogm_grid_ptr(sogm_ctx *ctx);
+
+/* Sparse reset of the map.  The reference rebuilds the SOGM from zero at every update
+ * (fake_particle_risk_voxel.cpp:107-108, a fill over all V x T cells, then the marks).  The library produces the
+ * same cells without touching the ones that are zero already: every mark written by sogm_update_gt[_swarm] /
+ * sogm_project_neighbours is logged as the index of its 32-byte sector (one log per agent and per grid of the pool,
+ * log_capacity entries per agent: 0 keeps the current value, default 2^20 or SOGM_LOG_CAP), and the grid's next reset
+ * zeroes exactly the logged sectors.  A grid written by a dense writer (sogm_set_future_risk, sogm_dsp_publish, the
+ * caller through sogm_grid_ptr), a freshly allocated one, and an agent whose log overflowed are cleared densely.
+ * enable = 0 restores the dense clear everywhere (also: SOGM_SPARSE_RESET=0 in the environment at sogm_create).
+ * Synchronises the device; call between ticks. */
+int sogm_set_sparse_reset(sogm_ctx *ctx, int enable, int log_capacity);
+/* host out[4]: {enabled, log capacity per agent, 1 if the current grid is covered by its log, largest per-agent
+ * entry count of the current grid's log (above the capacity: that agent's next reset is dense)}.  Synchronises. */
+int sogm_sparse_reset_state(sogm_ctx *ctx, int32_t *out_host);
 
 /* Body particles of one drone: ParticleATC::initEgoParticles (particles.cpp:62-87).
  * host: xyz[n*3] offsets (fp64).  Every drone of the swarm uses the same set. */
@@ -194,7 +209,7 @@ int sogm_set_body_particles(sogm_ctx *ctx, const double *xyz_host, int n);
 /* Per-kernel timing with HIP events recorded on the caller's stream around each launch (used by
  * bench.py for the roofline figure).  Slots: */
 enum {
-  SOGM_PROF_CLEAR = 0, /* k_clear_slabs  (the voxel-update roofline kernel) */
+  SOGM_PROF_CLEAR = 0, /* the grid's reset: k_reset_sectors (sparse) or k_clear_slabs / k_clear_chunks (dense) */
   SOGM_PROF_STAMP = 1, /* k_stamp_cloud                                      */
   SOGM_PROF_SPLAT = 2, /* k_splat_neighbours                                 */
   SOGM_PROF_ASTAR = 3,

@@ -52,6 +52,11 @@ struct Grid {
     int iz = (int)((z + rz) / res);
     return iz * L * W + iy * L + ix;
   }
+  // A write through indexF is dropped when the index is >= V: reference UB (a coordinate one ulp below +range rounds
+  // up in "x + r" and in the fp32 division, the index component equals the axis size; for z the reference writes
+  // outside risk_maps_).  x / y overflows that stay inside the array wrap into the next row / layer as the
+  // reference's do.  The HIP path drops the same marks (csrc/sogm_map.hip, k_stamp_bits).
+  bool writableF(float x, float y, float z) const { return inRangeF(x, y, z) && indexF(x, y, z) < L * W * H; }
   int indexI(int x, int y, int z) const { return z * L * W + y * L + x; }
   // map.h:186-194: voxel CORNER + pose
   void position(int index, const float pose[3], float out[3]) const {
@@ -228,7 +233,7 @@ void orc_update_gt(const SogmSpec *s, const float *cloud, int n_points, const So
     if (!(pz >= loz && pz <= hiz)) continue;
     // :111-116
     const float x = px - pose[0], y = py - pose[1], z = pz - pose[2];
-    if (g.inRangeF(x, y, z)) grid[(size_t)g.indexF(x, y, z) * T + 0] = 1.0F;
+    if (g.writableF(x, y, z)) grid[(size_t)g.indexF(x, y, z) * T + 0] = 1.0F;
   }
   // :121-125 collect occupied voxels of slice 0 in index order
   std::vector<int> obs;
@@ -309,7 +314,7 @@ void orc_update_gt(const SogmSpec *s, const float *cloud, int n_points, const So
       const float fx = (pt[0] + (vel[0] * s->time_resolution) * (float)k) - pose[0];
       const float fy = (pt[1] + (vel[1] * s->time_resolution) * (float)k) - pose[1];
       const float fz = (pt[2] + (vel[2] * s->time_resolution) * (float)k) - pose[2];
-      if (g.inRangeF(fx, fy, fz)) grid[(size_t)g.indexF(fx, fy, fz) * T + k] = 1.0F;
+      if (g.writableF(fx, fy, fz)) grid[(size_t)g.indexF(fx, fy, fz) * T + k] = 1.0F;
     }
   }
 }
@@ -358,7 +363,7 @@ static void projectNeighboursRiskVoxel(const SogmSpec *s, const SogmTrajRecord *
       const float fx = (float)(pts[e * 3 + 0] - (double)pose[0]);
       const float fy = (float)(pts[e * 3 + 1] - (double)pose[1]);
       const float fz = (float)(pts[e * 3 + 2] - (double)pose[2]);
-      if (!g.inRangeF(fx, fy, fz)) continue;
+      if (!g.writableF(fx, fy, fz)) continue;
       grid[(size_t)g.indexF(fx, fy, fz) * T + t_idx] = 1.0F;
     }
   }
@@ -410,7 +415,7 @@ void orc_project_neighbours(const SogmSpec *s, const SogmTrajRecord *rec, int n_
         const float fx = (float)(pts[e * 3 + 0] - (double)pose[0]);
         const float fy = (float)(pts[e * 3 + 1] - (double)pose[1]);
         const float fz = (float)(pts[e * 3 + 2] - (double)pose[2]);
-        if (!g.inRangeF(fx, fy, fz)) continue;
+        if (!g.writableF(fx, fy, fz)) continue;
         grid[(size_t)g.indexF(fx, fy, fz) * T + t_idx] += 1.0F;
       }
     }

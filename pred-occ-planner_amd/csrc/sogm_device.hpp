@@ -356,6 +356,18 @@ struct sogm_ctx {
   int           *d_filter_blocks;
   int            filter_max_cells;
   unsigned      *d_stamp_bits;     // [A][ceil(V / 32)] occupancy bits of slice 0 between k_stamp_bits and k_stamp_marks (lazy)
+  // Sparse reset.  The reference rebuilds the map from zero at every update (fake_particle_risk_voxel.cpp:107-108:
+  // a fill over all V x T cells); here every mark written into a grid since its last reset is logged as the index
+  // of its 32-byte sector (per agent), and the reset zeroes exactly those sectors — the cells of the rebuilt map
+  // are the same, the 640 MB per agent of zero stores are not issued.  tracked[s] = every non-zero cell of slot s
+  // is covered by its log (false after dense writers — sogm_set_future_risk, sogm_dsp_publish, sogm_grid_ptr —
+  // and for a fresh allocation: the next reset of that slot is the dense clear).  A log that overflows makes the
+  // reset kernel zero that agent's whole grid.
+  int            sparse;           // feature switch (sogm_set_sparse_reset; default on, SOGM_SPARSE_RESET=0 turns it off)
+  int            log_cap;          // entries per agent
+  unsigned      *d_log[3];         // [A][log_cap] per pool slot (slot 0 = the only grid without a pool), lazy
+  unsigned      *d_log_n[3];       // [A] entries appended since the slot's last reset (beyond log_cap: overflow)
+  int            tracked[3];
   void          *d_cand;           // [A][1024] candidate cylinders of the stamp (k_cull_cylinders)
   int           *d_ncand;          // [A]
   // trajectory exchange (sogm_traj_allgather): its own stream, ordered against producers / consumers by events
@@ -444,6 +456,16 @@ size_t clear_vec4_total(const sogm_ctx *c);
 int  adopt_preclear(sogm_ctx *c, hipStream_t st);
 int  announce_clear_epoch(sogm_ctx *c, hipStream_t st);
 int  queue_spare_clears(sogm_ctx *c, hipEvent_t after);
+// sparse reset (sogm_map.hip): the mark log of a pool slot as the writers see it (null entries = not logging)
+struct MarkLog {
+  unsigned *entries;  // [A][cap]
+  unsigned *n;        // [A]
+  int       cap;
+};
+inline int cur_slot(const sogm_ctx *c) { return c->n_pool ? c->cur_idx : 0; }
+MarkLog    mark_log(sogm_ctx *c, int slot);
+// zero slot `slot`'s grid on `st`: the logged sectors when the slot is tracked, the dense clear otherwise
+int  reset_slot(sogm_ctx *c, hipStream_t st, int slot, float *grid, bool polite);
 }  // namespace sogm
 
 #define SOGM_HIP_CHECK(expr)                    \

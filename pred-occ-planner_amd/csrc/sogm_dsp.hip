@@ -1799,6 +1799,7 @@ int sogm_dsp_publish(sogm_dsp *h, int32_t *out_n_occupied, void *stream) {
     int rc = sogm::adopt_preclear(c, st);
     if (rc) return rc;
   }
+  c->tracked[sogm::cur_slot(c)] = 0;  // every cell is written: the next reset of this grid is the dense clear
   hipLaunchKernelGGL(k_dsp_publish, dim3((unsigned)((d.V + 255) / 256), (unsigned)d.A), dim3(256), 0, st, d,
                      (void *)c->d_grid, c->geom.half, c->geom.risk_threshold, c->d_poses, c->d_stamps);
   hipLaunchKernelGGL(k_dsp_publish_ego, dim3((unsigned)d.A), dim3(128), 0, st, d, (void *)c->d_grid, c->geom.half, c->geom.inf_step,

@@ -13,6 +13,9 @@
 //   k_slabs_to_vt / k_vt_to_slabs   layout converters for parity I/O and futureRiskCallback.
 #include <hip/hip_runtime.h>
 
+#include <utility>
+#include <vector>
+
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -94,6 +97,46 @@ __global__ void k_clear_gate(const unsigned long long *__restrict__ cursor, size
   }
 }
 __global__ void k_set_word(int *p, int v) { *p = v; }
+
+// Sparse reset: zero the 32-byte sectors named by an agent's mark log (duplicates and ~0 place-holders included; the
+// sector of a logged cell holds nothing but marks of the same log or zeros).  An overflowed log (n > cap) makes the
+// agent's workgroups zero its whole grid instead.  Launched (blocks, A); the counts are reset by a memset behind it.
+__global__ __launch_bounds__(256) void k_reset_sectors(char *__restrict__ grid, size_t agent_bytes,
+                                                       const unsigned *__restrict__ entries,
+                                                       const unsigned *__restrict__ counts, int cap) {
+  const int      agent = blockIdx.y;
+  const unsigned n     = counts[agent];
+  char          *base  = grid + (size_t)agent * agent_bytes;
+  const vfloat4  z     = {0.f, 0.f, 0.f, 0.f};
+  const size_t   tid   = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nthr = (size_t)gridDim.x * blockDim.x;
+  if (n > (unsigned)cap) {
+    // dense fall-back for this agent: 16-byte stores over the aligned body, bytes at the two ends
+    char  *lo = reinterpret_cast<char *>((reinterpret_cast<uintptr_t>(base) + 15) & ~(uintptr_t)15);
+    char  *hi = reinterpret_cast<char *>(reinterpret_cast<uintptr_t>(base + agent_bytes) & ~(uintptr_t)15);
+    if (hi < lo) hi = lo = base + agent_bytes;
+    const size_t nv = (size_t)(hi - lo) / 16;
+    for (size_t i = tid; i < nv; i += nthr) __builtin_nontemporal_store(z, reinterpret_cast<vfloat4 *>(lo) + i);
+    if (tid == 0) {
+      for (char *q = base; q < lo && q < base + agent_bytes; ++q) *q = 0;
+      for (char *q = hi; q < base + agent_bytes; ++q) *q = 0;
+    }
+    return;
+  }
+  const unsigned *e = entries + (size_t)agent * cap;
+  for (size_t i = tid; i < n; i += nthr) {
+    const unsigned sct = e[i];
+    if (sct == 0xFFFFFFFFu) continue;
+    const size_t off = (size_t)sct * 32;
+    char        *q   = base + off;
+    if (off + 32 <= agent_bytes && (reinterpret_cast<uintptr_t>(q) & 15) == 0) {
+      reinterpret_cast<vfloat4 *>(q)[0] = z;
+      reinterpret_cast<vfloat4 *>(q)[1] = z;
+    } else {  // odd grid sizes: the agent's base is only cell-aligned, or the last sector is short
+      const size_t end = off + 32 <= agent_bytes ? off + 32 : agent_bytes;
+      for (size_t b = off; b + 2 <= end; b += 2) *reinterpret_cast<unsigned short *>(base + b) = 0;
+    }
+  }
+}
 template <bool POLITE>
 __global__ __launch_bounds__(256) void k_clear_chunks(vfloat4 *__restrict__ p, size_t n_vec4,
                                                       float *__restrict__ tail, int n_tail,
@@ -255,6 +298,11 @@ __global__ __launch_bounds__(64) void k_stamp_bits(GridGeom g, const float *__re
     const float x = px - p0, y = py - p1, z = pz - p2;
     if (!g.in_range(x, y, z)) continue;
     const int v = g.voxel_of(x, y, z);
+    // Reference UB (map.h:169-174): a coordinate one ulp below +range rounds up to range in "x + r" and to the full
+    // count in the fp32 division, so the index component equals the axis size; for z (or y on the top layer) the
+    // voxel index is >= V and the reference writes outside risk_maps_.  Such marks are dropped, here and in the
+    // oracle (x / y overflows inside the array wrap into the next row / layer exactly as the reference's do).
+    if (v >= g.V) continue;
     __hip_atomic_fetch_or(mask + (v >> 5), 1u << (v & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
@@ -264,7 +312,7 @@ __global__ __launch_bounds__(64) void k_stamp_marks(GridGeom g, void *__restrict
                                                     const SogmCylinder *__restrict__ cyl, int n_cyl,
                                                     const float *__restrict__ poses,
                                                     const CylCand *__restrict__ cand_all,
-                                                    const int *__restrict__ n_cand, int agent0) {
+                                                    const int *__restrict__ n_cand, int agent0, MarkLog lg) {
   const int      agent  = blockIdx.y + agent0;
   const int      kept   = n_cand[agent];
   const bool     culled = kept <= SOGM_MAX_CYL_LDS;
@@ -309,6 +357,18 @@ __global__ __launch_bounds__(64) void k_stamp_marks(GridGeom g, void *__restrict
       const unsigned q0 = (unsigned)__shfl((int)w4.x, own, 64), q1 = (unsigned)__shfl((int)w4.y, own, 64);
       const unsigned q2 = (unsigned)__shfl((int)w4.z, own, 64), q3 = (unsigned)__shfl((int)w4.w, own, 64);
       const int      k0 = __shfl(c0, own, 64), k1 = __shfl(c1, own, 64), k2 = __shfl(c2, own, 64);
+      // mark log (sparse reset): the wave reserves T entries per occupied voxel with one atomic; slice k's entries of
+      // the wave are contiguous (entry = sector of the marked cell, or ~0 for a mark that falls outside the grid)
+      const unsigned long long am   = __ballot(active);
+      const int                n_ac = __popcll(am);
+      unsigned                 lbase = 0;
+      unsigned                *lent  = nullptr;
+      if (lg.entries) {
+        if (lane == 0) lbase = atomicAdd(lg.n + agent, (unsigned)(n_ac * g.T));
+        lbase = (unsigned)__shfl((int)lbase, 0, 64) + (unsigned)lane;  // lanes 0 .. n_ac - 1 are the active ones
+        lent  = lg.entries + (size_t)agent * lg.cap;
+      }
+      const int esh = g.half ? 4 : 3;  // cells per 32-byte sector, as a shift
       if (!active) continue;
       const int sel = r < k0 ? 0 : r < k1 ? 1 : r < k2 ? 2 : 3;
       unsigned  wv  = sel == 0 ? q0 : sel == 1 ? q1 : sel == 2 ? q2 : q3;
@@ -317,6 +377,7 @@ __global__ __launch_bounds__(64) void k_stamp_marks(GridGeom g, void *__restrict
       const int v = (w0 + own * 4 + sel) * 32 + __builtin_ctz(wv);
       // slice 0 (:114), then the occupied voxel's future marks (:121-170): GT velocity of the first matching record
       cell_st(base, (size_t)v, 1.0F, g.half);
+      if (lent && lbase < (unsigned)lg.cap) lent[lbase] = (unsigned)v >> esh;
       float cx, cy, cz;
       g.corner_of(v, pose, cx, cy, cz);
       float vx = 0.f, vy = 0.f;
@@ -362,7 +423,12 @@ __global__ __launch_bounds__(64) void k_stamp_marks(GridGeom g, void *__restrict
         const float fx = (cx + (vx * g.dt) * (float)k) - p0;
         const float fy = (cy + (vy * g.dt) * (float)k) - p1;
         const float fz = (cz + (0.0F * g.dt) * (float)k) - p2;
-        if (g.in_range(fx, fy, fz)) cell_st(base, (size_t)k * g.V + g.voxel_of(fx, fy, fz), 1.0F, g.half);
+        const int    fv = g.in_range(fx, fy, fz) ? g.voxel_of(fx, fy, fz) : g.V;
+        const bool   in = fv < g.V;  // (index >= V: the reference's out-of-bounds case, see k_stamp_bits)
+        const size_t ci = (size_t)k * g.V + (in ? fv : 0);
+        if (in) cell_st(base, ci, 1.0F, g.half);
+        const unsigned li = lbase + (unsigned)(k * n_ac);
+        if (lent && li < (unsigned)lg.cap) lent[li] = in ? (unsigned)(ci >> esh) : 0xFFFFFFFFu;
       }
     }
   }
@@ -378,7 +444,13 @@ __global__ __launch_bounds__(64) void k_stamp_marks(GridGeom g, void *__restrict
 // one (agent, record, slice) item of the overlay
 __device__ inline void splat_item(const GridGeom &g, void *__restrict__ grid, const SogmTrajRecord &R, int agent,
                                   int t, const int32_t *__restrict__ ego_ids, const float *__restrict__ poses,
-                                  const double *__restrict__ stamps, const double *__restrict__ body, int n_body) {
+                                  const double *__restrict__ stamps, const double *__restrict__ body, int n_body,
+                                  const MarkLog &lg) {
+  // mark log (sparse reset): a lane that writes reserves n_body entries (or one) and fills them with the sectors of
+  // its cells, ~0 for a particle outside the grid
+  const int    esh   = g.half ? 4 : 3;
+  const size_t tslab = (size_t)t * g.V;
+  unsigned    *lent  = lg.entries ? lg.entries + (size_t)agent * lg.cap : nullptr;
   if (R.n_pieces <= 0 || R.drone_id == ego_ids[agent]) return;
   double time_end = R.time_start;
   for (int k = 0; k < R.n_pieces; ++k) time_end += R.duration[k];
@@ -400,18 +472,29 @@ __device__ inline void splat_item(const GridGeom &g, void *__restrict__ grid, co
     double       p[3];
     if (R.time_start < tt && time_end > tt) {
       bezier_pos(R, tt - R.time_start, p);
+      const unsigned lb = lent ? atomicAdd(lg.n + agent, (unsigned)n_body) : 0u;
       for (int e = 0; e < n_body; ++e) {
         const float fx = (float)((p[0] + body[e * 3 + 0]) - q0);
         const float fy = (float)((p[1] + body[e * 3 + 1]) - q1);
         const float fz = (float)((p[2] + body[e * 3 + 2]) - q2);
-        if (g.in_range(fx, fy, fz)) cell_st(slab, g.voxel_of(fx, fy, fz), 1.0F, g.half);
+        const int   vx = g.in_range(fx, fy, fz) ? g.voxel_of(fx, fy, fz) : g.V;
+        const bool  in = vx < g.V;  // (index >= V: the reference's out-of-bounds case, see k_stamp_bits)
+        if (in) cell_st(slab, vx, 1.0F, g.half);
+        if (lent && lb + (unsigned)e < (unsigned)lg.cap) lent[lb + e] = in ? (unsigned)((tslab + vx) >> esh) : 0xFFFFFFFFu;
       }
     } else if (time_end < tt) {
       double dur = 0.0;
       for (int k = 0; k < R.n_pieces; ++k) dur += R.duration[k];
       bezier_pos(R, dur, p);
       const float fx = (float)(p[0] - q0), fy = (float)(p[1] - q1), fz = (float)(p[2] - q2);
-      if (g.in_range(fx, fy, fz)) cell_st(slab, g.voxel_of(fx, fy, fz), 1.0F, g.half);
+      const int vx = g.in_range(fx, fy, fz) ? g.voxel_of(fx, fy, fz) : g.V;
+      if (vx < g.V) {
+        cell_st(slab, vx, 1.0F, g.half);
+        if (lent) {
+          const unsigned lb = atomicAdd(lg.n + agent, 1u);
+          if (lb < (unsigned)lg.cap) lent[lb] = (unsigned)((tslab + vx) >> esh);
+        }
+      }
     }
     return;
   }
@@ -423,27 +506,32 @@ __device__ inline void splat_item(const GridGeom &g, void *__restrict__ grid, co
   const float *pose = poses + agent * 3;
   const double q0 = (double)pose[0], q1 = (double)pose[1], q2 = (double)pose[2];
   char        *slab = reinterpret_cast<char *>(grid) + ((size_t)agent * g.T + t) * (size_t)g.V * (g.half ? 2 : 4);
+  const unsigned lb = lent ? atomicAdd(lg.n + agent, (unsigned)n_body) : 0u;
   for (int e = 0; e < n_body; ++e) {
     const float fx = (float)((p[0] + body[e * 3 + 0]) - q0);
     const float fy = (float)((p[1] + body[e * 3 + 1]) - q1);
     const float fz = (float)((p[2] + body[e * 3 + 2]) - q2);
-    if (!g.in_range(fx, fy, fz)) continue;
+    const int   vx = g.in_range(fx, fy, fz) ? g.voxel_of(fx, fy, fz) : g.V;
+    const bool  in = vx < g.V;
+    if (lent && lb + (unsigned)e < (unsigned)lg.cap) lent[lb + e] = in ? (unsigned)((tslab + vx) >> esh) : 0xFFFFFFFFu;
+    if (!in) continue;
     // += 1.0f per body particle; sums of 1.0 are exact in fp32 (and in fp16 up to 2048), so the order
     // is immaterial
-    cell_add(slab, g.voxel_of(fx, fy, fz), 1.0F, g.half);
+    cell_add(slab, vx, 1.0F, g.half);
   }
 }
 __global__ __launch_bounds__(256) void k_splat_neighbours(
     GridGeom g, void *__restrict__ grid, const SogmTrajRecord *__restrict__ rec, int n_rec,
     const int32_t *__restrict__ ego_ids, const float *__restrict__ poses,
-    const double *__restrict__ stamps, const double *__restrict__ body, int n_body, int n_agents, int agent0) {
+    const double *__restrict__ stamps, const double *__restrict__ body, int n_body, int n_agents, int agent0,
+    MarkLog lg) {
   const long long gid   = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long total = (long long)n_agents * n_rec * g.T;
   if (gid >= total) return;
   const int t     = (int)(gid % g.T);
   const int r     = (int)((gid / g.T) % n_rec);
   const int agent = agent0 + (int)(gid / ((long long)g.T * n_rec));
-  splat_item(g, grid, rec[r], agent, t, ego_ids, poses, stamps, body, n_body);
+  splat_item(g, grid, rec[r], agent, t, ego_ids, poses, stamps, body, n_body, lg);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -730,6 +818,58 @@ __global__ __launch_bounds__(64) void k_traj_safe(MapView m, const SogmTrajRecor
   out[a] = safe;
 }
 
+static int launch_clear_impl(sogm_ctx *c, hipStream_t st, float *grid, bool polite, int part, size_t split);
+// ---- sparse reset: logs per pool slot --------------------------------------------------------------------
+static int slot_of_grid(const sogm_ctx *c, const float *grid) {
+  if (c->n_pool == 0) return 0;
+  for (int i = 0; i < c->n_pool; ++i)
+    if (c->pool[i] == grid) return i;
+  return -1;
+}
+// the log of a slot, allocated on first use; {nullptr, ...} when the feature is off or there is no room for it (the
+// slot then stays untracked and is cleared densely)
+MarkLog mark_log(sogm_ctx *c, int slot) {
+  MarkLog none{nullptr, nullptr, 0};
+  if (!c->sparse || slot < 0 || slot > 2) return none;
+  if (!c->d_log[slot]) {
+    unsigned *e = nullptr, *n = nullptr;
+    if (hipMalloc((void **)&e, sizeof(unsigned) * (size_t)c->log_cap * c->n_agents) != hipSuccess ||
+        hipMalloc((void **)&n, sizeof(unsigned) * (size_t)c->n_agents) != hipSuccess ||
+        hipMemset(n, 0, sizeof(unsigned) * (size_t)c->n_agents) != hipSuccess) {
+      (void)hipGetLastError();
+      if (e) (void)hipFree(e);
+      if (n) (void)hipFree(n);
+      c->sparse = 0;  // no room: dense clears from here on
+      for (int i = 0; i < 3; ++i) c->tracked[i] = 0;
+      return none;
+    }
+    c->d_log[slot]   = e;
+    c->d_log_n[slot] = n;
+    c->tracked[slot] = 0;  // what the grid holds now was written without a log
+  }
+  return MarkLog{c->d_log[slot], c->d_log_n[slot], c->log_cap};
+}
+static size_t agent_grid_bytes(const sogm_ctx *c) { return (size_t)c->spec.T * (size_t)c->geom.V * c->cell_bytes(); }
+
+int reset_slot(sogm_ctx *c, hipStream_t st, int slot, float *grid, bool polite) {
+  const MarkLog lg = mark_log(c, slot);
+  if (lg.entries && c->tracked[slot]) {
+    static int wgs = -1;
+    if (wgs < 0) {
+      const char *e = getenv("SOGM_RESET_WGS");  // workgroups per agent (tuning aid)
+      wgs           = e && atoi(e) > 0 ? atoi(e) : 32;
+    }
+    prof_begin(c, SOGM_PROF_CLEAR, st);
+    hipLaunchKernelGGL(k_reset_sectors, dim3(wgs, c->n_agents), dim3(256), 0, st, reinterpret_cast<char *>(grid),
+                       agent_grid_bytes(c), lg.entries, lg.n, lg.cap);
+    prof_end(c, SOGM_PROF_CLEAR, st);
+    SOGM_HIP_CHECK(hipGetLastError());
+    SOGM_HIP_CHECK(hipMemsetAsync(lg.n, 0, sizeof(unsigned) * (size_t)c->n_agents, st));
+    return SOGM_OK;
+  }
+  return launch_clear(c, st, grid, polite);  // (a complete dense clear restarts the slot's log, see launch_clear)
+}
+
 int adopt_preclear(sogm_ctx *c, hipStream_t st) {
   if (!c->precleared) return SOGM_OK;
   if (c->overlap >= 2) {
@@ -792,7 +932,9 @@ int queue_spare_clears(sogm_ctx *c, hipEvent_t after) {
   for (int i = 0; i < c->n_dirty; ++i) {
     const int g  = c->dirty[i];
     int       rc = SOGM_OK;
-    if (head == 0) {
+    if (c->sparse && c->tracked[g] && mark_log(c, g).entries) {
+      rc = reset_slot(c, c->side, g, c->pool[g], true);  // the logged sectors only: a fraction of a millisecond
+    } else if (head == 0) {
       rc = launch_clear(c, c->side, c->pool[g], false);
     } else if (head >= total) {
       rc = launch_clear(c, c->side, c->pool[g], true);
@@ -820,6 +962,18 @@ size_t clear_vec4_total(const sogm_ctx *c) {
 // part: 0 = the whole grid, 1 = the first `split` 16-byte elements, 2 = everything from `split` on
 int launch_clear(sogm_ctx *c, hipStream_t st, float *grid, bool polite, int part, size_t split) {
   if (!grid) grid = c->d_grid;
+  const int rc = launch_clear_impl(c, st, grid, polite, part, split);
+  if (rc == SOGM_OK && part != 1) {
+    // this launch completes a dense clear of the slot: behind it (stream order) the slot's mark log starts empty and
+    // covers every non-zero cell again
+    const int     slot = slot_of_grid(c, grid);
+    const MarkLog lg   = mark_log(c, slot);
+    if (lg.entries)
+      c->tracked[slot] = hipMemsetAsync(lg.n, 0, sizeof(unsigned) * (size_t)c->n_agents, st) == hipSuccess ? 1 : 0;
+  }
+  return rc;
+}
+static int launch_clear_impl(sogm_ctx *c, hipStream_t st, float *grid, bool polite, int part, size_t split) {
   // the clear is a byte stream: n = number of 4-byte words of the grid (fp16 grids: 2 cells per word)
   // (rounded up: an odd number of fp16 cells ends in half a word; allocations are padded to 16 B)
   const size_t n     = ((size_t)c->n_agents * c->spec.T * (size_t)c->geom.V * c->cell_bytes() + 3) / 4;
@@ -896,7 +1050,7 @@ using namespace sogm;
 // ================================================================================================
 extern "C" {
 
-int sogm_abi_version(void) { return 3; }
+int sogm_abi_version(void) { return 4; }
 const char *sogm_last_error(void) { return sogm::g_err; }
 
 int sogm_device_count(void) {
@@ -932,6 +1086,12 @@ int sogm_create(const SogmSpec *spec, int n_agents, int device, sogm_ctx **out) 
   c->geom          = make_geom(*spec);
   c->n_agents      = n_agents;
   c->device        = device;
+  {
+    const char *e = getenv("SOGM_SPARSE_RESET");
+    c->sparse     = e ? atoi(e) != 0 : 1;
+    e             = getenv("SOGM_LOG_CAP");
+    c->log_cap    = e && atoi(e) > 0 ? atoi(e) : (1 << 20);
+  }
   const size_t n   = (size_t)n_agents * spec->T * (size_t)c->geom.V;
   hipError_t   e   = hipMalloc(&c->d_grid, (n * c->cell_bytes() + 15) & ~(size_t)15);
   if (e == hipSuccess) e = hipMalloc(&c->d_poses, sizeof(float) * 3 * n_agents);
@@ -963,6 +1123,10 @@ void sogm_destroy(sogm_ctx *c) {
     if (c->pool[i]) (void)hipFree(c->pool[i]);
   for (int i = 0; i < 3; ++i)
     if (c->pool_ev[i]) (void)hipEventDestroy(c->pool_ev[i]);
+  for (int i = 0; i < 3; ++i) {
+    if (c->d_log[i]) (void)hipFree(c->d_log[i]);
+    if (c->d_log_n[i]) (void)hipFree(c->d_log_n[i]);
+  }
   if (c->d_poses) (void)hipFree(c->d_poses);
   if (c->d_stamps) (void)hipFree(c->d_stamps);
   if (c->clear_cursor) (void)hipFree(c->clear_cursor);
@@ -1005,7 +1169,46 @@ void sogm_destroy(sogm_ctx *c) {
 int64_t sogm_grid_bytes(const sogm_ctx *c) {
   return c ? (int64_t)c->n_agents * c->spec.T * (int64_t)c->geom.V * (int64_t)c->cell_bytes() : 0;
 }
-float *sogm_grid_ptr(sogm_ctx *c) { return c ? c->d_grid : nullptr; }
+float *sogm_grid_ptr(sogm_ctx *c) {
+  if (!c) return nullptr;
+  c->tracked[sogm::cur_slot(c)] = 0;  // the caller may write cells the mark log does not see
+  return c->d_grid;
+}
+
+int sogm_set_sparse_reset(sogm_ctx *c, int enable, int log_capacity) {
+  if (!c || log_capacity < 0) return SOGM_ERR_INVALID_ARG;
+  SOGM_HIP_CHECK(hipSetDevice(c->device));
+  SOGM_HIP_CHECK(hipDeviceSynchronize());  // resets / writers in flight use the logs
+  for (int i = 0; i < 3; ++i) {
+    if (c->d_log[i]) (void)hipFree(c->d_log[i]);
+    if (c->d_log_n[i]) (void)hipFree(c->d_log_n[i]);
+    c->d_log[i]   = nullptr;
+    c->d_log_n[i] = nullptr;
+    c->tracked[i] = 0;  // contents unknown to the (new) logs: each slot's next reset is dense
+  }
+  c->sparse = enable ? 1 : 0;
+  if (log_capacity > 0) c->log_cap = log_capacity;
+  return SOGM_OK;
+}
+
+int sogm_sparse_reset_state(sogm_ctx *c, int32_t *out) {
+  if (!c || !out) return SOGM_ERR_INVALID_ARG;
+  SOGM_HIP_CHECK(hipSetDevice(c->device));
+  SOGM_HIP_CHECK(hipDeviceSynchronize());
+  const int slot = sogm::cur_slot(c);
+  out[0] = c->sparse;
+  out[1] = c->log_cap;
+  out[2] = c->tracked[slot];
+  out[3] = 0;  // largest per-agent entry count of the current grid's log
+  if (c->sparse && c->d_log_n[slot]) {
+    std::vector<unsigned> n((size_t)c->n_agents);
+    SOGM_HIP_CHECK(hipMemcpy(n.data(), c->d_log_n[slot], sizeof(unsigned) * n.size(), hipMemcpyDeviceToHost));
+    unsigned mx = 0;
+    for (unsigned v : n) mx = v > mx ? v : mx;
+    out[3] = (int32_t)(mx > 0x7FFFFFFFu ? 0x7FFFFFFFu : mx);
+  }
+  return SOGM_OK;
+}
 
 int sogm_set_overlap_clear(sogm_ctx *c, int mode) {
   if (!c || mode < 0 || mode > 3) return SOGM_ERR_INVALID_ARG;
@@ -1026,12 +1229,16 @@ int sogm_set_overlap_clear(sogm_ctx *c, int mode) {
     float *t           = c->pool[0];
     c->pool[0]         = c->pool[c->cur_idx];
     c->pool[c->cur_idx] = t;
+    std::swap(c->d_log[0], c->d_log[c->cur_idx]);  // the mark logs follow their grids
+    std::swap(c->d_log_n[0], c->d_log_n[c->cur_idx]);
+    std::swap(c->tracked[0], c->tracked[c->cur_idx]);
     c->cur_idx         = 0;
   }
   while (c->n_pool > want) {
     (void)hipFree(c->pool[--c->n_pool]);
     c->pool[c->n_pool] = nullptr;
   }
+  for (int i = 1; i < 3; ++i) c->tracked[i] = 0;  // spares hold garbage: their first reset is the dense clear
   const size_t bytes = ((size_t)sogm_grid_bytes(c) + 15) & ~(size_t)15;
   const int    had   = c->n_pool;
   while (c->n_pool < want) {
@@ -1123,7 +1330,7 @@ int sogm_set_body_particles(sogm_ctx *c, const double *xyz, int n) {
   return SOGM_OK;
 }
 
-static int clear_grid(sogm_ctx *c, hipStream_t st) { return sogm::launch_clear(c, st); }
+static int clear_grid(sogm_ctx *c, hipStream_t st) { return sogm::reset_slot(c, st, sogm::cur_slot(c), c->d_grid, false); }
 
 // updateMap for every agent; with `records` (sogm_update_gt_swarm) the neighbour overlay follows in the same call
 static int update_gt_impl(sogm_ctx *c, const float *cloud_xyz, const int32_t *cloud_range,
@@ -1173,8 +1380,9 @@ static int update_gt_impl(sogm_ctx *c, const float *cloud_xyz, const int32_t *cl
   }
   hipLaunchKernelGGL(k_stamp_bits, dim3(stamp_wgs, A), dim3(64), 0, st, c->geom, cloud_xyz, cloud_range, c->d_poses,
                      c->d_stamp_bits, words, 0);
+  const sogm::MarkLog lg = sogm::mark_log(c, sogm::cur_slot(c));
   hipLaunchKernelGGL(k_stamp_marks, dim3(stamp_wgs, A), dim3(64), 0, st, c->geom, (void *)c->d_grid, c->d_stamp_bits,
-                     words, cylinders, n_cyl, c->d_poses, (const CylCand *)c->d_cand, (const int *)c->d_ncand, 0);
+                     words, cylinders, n_cyl, c->d_poses, (const CylCand *)c->d_cand, (const int *)c->d_ncand, 0, lg);
   prof_end(c, SOGM_PROF_STAMP, st);
   SOGM_HIP_CHECK(hipGetLastError());
   if (fused && n_records > 0) {
@@ -1182,7 +1390,7 @@ static int update_gt_impl(sogm_ctx *c, const float *cloud_xyz, const int32_t *cl
     prof_begin(c, SOGM_PROF_SPLAT, st);
     hipLaunchKernelGGL(k_splat_neighbours, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, c->geom,
                        (void *)c->d_grid, records, n_records, ego_ids, c->d_poses, c->d_stamps, c->d_body, c->n_body,
-                       A, 0);
+                       A, 0, lg);
     prof_end(c, SOGM_PROF_SPLAT, st);
     SOGM_HIP_CHECK(hipGetLastError());
   }
@@ -1224,7 +1432,7 @@ int sogm_project_neighbours(sogm_ctx *c, const SogmTrajRecord *records, int n_re
   prof_begin(c, SOGM_PROF_SPLAT, (hipStream_t)stream);
   hipLaunchKernelGGL(k_splat_neighbours, dim3(nblk), dim3(256), 0, (hipStream_t)stream, c->geom,
                      (void *)c->d_grid, records, n_records, ego_ids, c->d_poses, c->d_stamps, c->d_body,
-                     c->n_body, c->n_agents, 0);
+                     c->n_body, c->n_agents, 0, sogm::mark_log(c, sogm::cur_slot(c)));
   prof_end(c, SOGM_PROF_SPLAT, (hipStream_t)stream);
   SOGM_HIP_CHECK(hipGetLastError());
   return SOGM_OK;
@@ -1245,6 +1453,7 @@ int sogm_set_future_risk(sogm_ctx *c, const float *grid_vt, const float *poses,
   }
   const int    V = c->geom.V, T = c->spec.T;
   const size_t per = (size_t)V * T;
+  c->tracked[sogm::cur_slot(c)] = 0;  // every cell is written: the next reset of this grid is the dense clear
   for (int a = 0; a < c->n_agents; ++a) {
     hipLaunchKernelGGL(k_vt_to_slabs, dim3((V + 255) / 256), dim3(256), 0, st, grid_vt + a * per, V, T,
                        c->geom.half, (void *)((char *)c->d_grid + a * per * c->cell_bytes()));

@@ -111,6 +111,16 @@ class SogmMap:
                                             out.data_ptr(), cnt.data_ptr(), _stream()), "sogm_filter_point_cloud")
         return out, cnt
 
+    # ---- sparse reset (sogm_abi.h: sogm_set_sparse_reset) ----
+    def set_sparse_reset(self, on=True, log_capacity=0):
+        check(lib().sogm_set_sparse_reset(self._ctx, 1 if on else 0, int(log_capacity)), "sogm_set_sparse_reset")
+
+    def sparse_reset_state(self):
+        """{enabled, log_capacity, tracked (current grid covered by its log), max_entries (largest per-agent count)}."""
+        out = (C.c_int32 * 4)()
+        check(lib().sogm_sparse_reset_state(self._ctx, out), "sogm_sparse_reset_state")
+        return {"enabled": bool(out[0]), "log_capacity": out[1], "tracked": bool(out[2]), "max_entries": out[3]}
+
     # ---- profiling (HIP events around each kernel, on the caller's stream) ----
     def set_profiling(self, on=True):
         check(lib().sogm_set_profiling(self._ctx, 1 if on else 0), "sogm_set_profiling")

@@ -187,3 +187,26 @@ def test_riskvoxel_overlay_sets_cells_and_stamps_last_point(pop, orc):
         changed += int((want != base[a]).sum())
     assert changed > 0
     m.close()
+
+
+def test_mark_one_ulp_below_the_upper_range_is_dropped(pop, orc):
+    """Reference UB (map.h:169-174): with the map centre at z = 1.1 the cloud's z = 2.6 layer sits one ulp below
+    +range; "z + rz" and the fp32 division round up and the index component equals H, i.e. the voxel index is >= V —
+    the reference writes outside risk_maps_.  Both sides drop such marks (before: the HIP path wrote them into the
+    next slice / the next agent's grid, the oracle outside its array)."""
+    sogm, spec, sc, dev, m = _mk(pop, "parity", 4, 0x77)
+    sc = dict(sc)
+    sc["poses"] = (sc["poses"] + np.array([0, 0, 0.1], np.float32)).astype(np.float32)
+    g_rz = (spec.H // 2) * np.float32(spec.resolution)
+    z = (sc["cloud"][:, 2] - sc["poses"][0, 2]).astype(np.float32)
+    edge = (z < g_rz) & (((z + g_rz).astype(np.float32) / np.float32(spec.resolution)).astype(np.float32) >= spec.H)
+    assert edge.any(), "the scene no longer has a point in the rounding gap"
+    dev = sogm.upload_scene(sc)
+    m.updateMap(dev["cloud"], dev["cloud_range"], dev["cylinders"], dev["n_cyl"], dev["poses"], dev["stamps"])
+    cyl = pop.scene.cylinders_to_struct(sc["cylinders"])
+    for a in range(4):
+        want = orc.update_gt(spec, sc["cloud"], cyl, dev["n_cyl"], sc["poses"][a])
+        got = m.download(a)
+        assert np.array_equal(got, want), f"agent {a}: {(got != want).sum()} cells differ"
+        assert not got[: spec.L * spec.W].any()  # nothing spilled into the bottom layer of the next slice / agent
+    m.close()
