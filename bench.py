@@ -192,6 +192,8 @@ def main():
     import numpy as np
     planner = importlib.import_module("pred-occ-planner_amd.planner")
     per_slot = {k: np.array(sw.map.profile_read_all(k)) for k in range(pop._abi.PROF_N)}
+    # sparse reset (the default): the log of the grid the last tick built = what the next reset will read and zero
+    sparse = sw.map.sparse_reset_state()
     sw.map.set_profiling(True)  # restart the rings for the stage pass below
     # stage pass on the state of the last tick (map must be live: rebuild it without the pre-clear)
     overlap_mode = sw.overlap_mode
@@ -201,6 +203,8 @@ def main():
     pva, valid = planner.traj_eval(sw.own, t_start)
     pva = torch.where(valid.bool().unsqueeze(1), pva, sw.hover).contiguous()
     poses_ = pva[:, :3].to(torch.float32).contiguous()
+    if sparse["enabled"]:
+        sw.map.set_sparse_reset(False)  # the stand-alone figure below is the DENSE clear's (first ticks, dense writers)
     standalone_clear_ms = []
     for _ in range(3):  # the full-width clear with the machine to itself (first launch may still see the page-table
         sw.map.updateMap(sw.dev["cloud"], sw.dev["cloud_range"], sw.dev["cylinders"], sw.dev["n_cyl"], poses_, stamps)
@@ -230,7 +234,55 @@ def main():
                 break
         except (OSError, KeyError, ValueError):
             pass
-    achieved = grid_bytes / (avg[0] * 1e-3) / 1e9
+    standalone = {"kernel": "k_clear_slabs (the dense clear, full width, machine to itself; stage pass after the timed region)",
+                  "launch_ms": standalone_clear_ms,
+                  "bytes_per_launch": grid_bytes,
+                  "achieved": grid_bytes / (min(standalone_clear_ms) * 1e-3) / 1e9,
+                  "frac": grid_bytes / (min(standalone_clear_ms) * 1e-3) / 1e9 / 8000.0}
+    if sparse["enabled"] and sparse["tracked"]:
+        # The map is no longer rebuilt by filling V x T cells: the reset zeroes the 32-byte sectors named by the mark
+        # log (DESIGN 3.1 "Sparse reset").  The kernel is rated on the bytes it has to move — 4 B read and 32 B
+        # written per log entry — and SURVEY 8(d)'s dense figure is given beside it for comparison.
+        entries = int(sparse["total_entries"])
+        reset_bytes = entries * 36
+        achieved = reset_bytes / (avg[0] * 1e-3) / 1e9
+        rt = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r03_pmc_reset.json")) as f:
+                pmc = json.load(f)
+            rt = {"bytes_per_entry": pmc["bytes_per_entry"], "bytes_per_launch_scaled": pmc["bytes_per_entry"] * entries,
+                  "source": "profiles/r03_pmc_reset.json (committed rocprofv3 --pmc passes of tools/diag_reset_pmc.py, "
+                            "scaled by this run's entry count; not measured in this run)"}
+        except (OSError, KeyError, ValueError):
+            pass
+        roofline = {"bound": "hbm",
+                    "kernel": "k_reset_sectors: the sparse reset of the SOGM (zeroes the logged 32-byte sectors of the grid "
+                              "the update swapped out; side stream, under the replan)",
+                    "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+                    "traffic": rt["bytes_per_launch_scaled"] if rt else None,
+                    "traffic_source": rt["source"] if rt else None,
+                    "bytes_per_launch": reset_bytes, "log_entries_per_launch": entries,
+                    "avg_launch_ms": float(avg[0]), "launches_timed": n_clear,
+                    "timed_where": "HIP events on the side stream around every reset of the timed region",
+                    "note": "no kernel of the tick is HBM-bound any more: the tick is bound by the per-agent A* -> "
+                            "corridor -> QP chain (stage_ms); this is the largest streaming kernel left",
+                    "dense_equivalent": {"bytes": grid_bytes, "rate_GBps": grid_bytes / (avg[0] * 1e-3) / 1e9,
+                                         "note": "SURVEY 8(d)'s V*T*4 B per agent-update divided by this launch: above "
+                                                 "the HBM peak because the fill is not executed"},
+                    "standalone": standalone}
+    else:
+        achieved = grid_bytes / (avg[0] * 1e-3) / 1e9
+        roofline = {"bound": "hbm",
+                    "kernel": "the SOGM clear (voxel update): k_clear_chunks narrow + wide launches in the pooled modes, "
+                              "k_clear_slabs otherwise", "achieved": achieved,
+                    "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
+                    "traffic_source": traffic_source,
+                    "bytes_per_launch": grid_bytes, "avg_launch_ms": float(avg[0]),
+                    "launches_timed": n_clear,
+                    "timed_where": "HIP events on the clear's stream around the clear (both of its launches), every clear of the timed region",
+                    # avg_launch_ms is the launch as it runs inside the tick (a narrow clear sharing the machine
+                    # with the planner kernels); the same kernel at full width with the machine to itself:
+                    "standalone": standalone}
     out = {
         "metric": "replans/sec (SOGM update + QP: full replan = SOGM update + A* + corridors + QP + deconfliction), "
                   f"{sw.A_loc}-agent batch per GPU, {spec.L}x{spec.W}x{spec.H}x{spec.T} voxel grid; aggregate over all agents",
@@ -258,30 +310,22 @@ def main():
                    # torch.distributed's (also RCCL; the fallback — reason given), "local" = one process
                    "exchange": ("abi" if sw.exchange.active else "torch" if sw.distributed else "local"),
                    "exchange_fallback_reason": sw.exchange.fallback_reason,
-                   "sogm_grids_per_agent": overlap_mode if overlap_mode >= 2 else 1},
+                   "sogm_grids_per_agent": overlap_mode if overlap_mode >= 2 else 1,
+                   "sogm_reset": "sparse (logged 32-byte sectors)" if sparse["enabled"] else "dense clear"},
         "replans_per_s_per_agent": sw.A_tot * args.steps / dt / sw.A_tot,
         "stage_ms": {"clear": avg[0], "stamp": avg[1], "splat": avg[2], "astar": avg[3], "corridor": avg[4],
                      "qp": avg[5]},
-        "roofline": {"bound": "hbm",
-                     "kernel": "the SOGM clear (voxel update): k_clear_chunks narrow + wide launches in the pooled modes, "
-                               "k_clear_slabs otherwise", "achieved": achieved,
-                     "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
-                     "traffic_source": traffic_source,
-                     "bytes_per_launch": grid_bytes, "avg_launch_ms": float(avg[0]),
-                     "launches_timed": n_clear,
-                     "timed_where": "HIP events on the clear's stream around the clear (both of its launches), every clear of the timed region",
-                     # avg_launch_ms is the launch as it runs inside the tick (double-buffered mode: a narrow
-                     # clear sharing the machine with the planner kernels); the same kernel at full width with
-                     # the machine to itself, from the stage pass after the timed region:
-                     "standalone": {"launch_ms": standalone_clear_ms,
-                                    "achieved": grid_bytes / (min(standalone_clear_ms) * 1e-3) / 1e9,
-                                    "frac": grid_bytes / (min(standalone_clear_ms) * 1e-3) / 1e9 / 8000.0}},
+        "roofline": roofline,
     }
     if args.sustained > 0:
         # sustained flight: the 20-step figure covers the first seconds (agents still far apart); keep flying —
         # the swarm converges on the centre, searches get longer — and time every tick (host-synchronised)
         sw.map.set_overlap_clear(overlap_mode != 0, grids=(overlap_mode if overlap_mode >= 2 else 1))
         sw.map.set_profiling(False)
+        if sparse["enabled"]:
+            sw.map.set_sparse_reset(True)
+            for _ in range(3):  # untimed: every grid of the pool is cleared densely once before its log takes over
+                sw.step()
         sw.planner.counters(reset=True)
         tick_ms, oks2 = [], []
         barrier()

@@ -198,8 +198,9 @@ float  *sogm_grid_ptr(sogm_ctx *ctx);
  * enable = 0 restores the dense clear everywhere (also: SOGM_SPARSE_RESET=0 in the environment at sogm_create).
  * Synchronises the device; call between ticks. */
 int sogm_set_sparse_reset(sogm_ctx *ctx, int enable, int log_capacity);
-/* host out[4]: {enabled, log capacity per agent, 1 if the current grid is covered by its log, largest per-agent
- * entry count of the current grid's log (above the capacity: that agent's next reset is dense)}.  Synchronises. */
+/* host out[5]: {enabled, log capacity per agent, 1 if the current grid is covered by its log, largest per-agent
+ * entry count of the current grid's log (above the capacity: that agent's next reset is dense), entries of all
+ * agents together (saturating)}.  Synchronises. */
 int sogm_sparse_reset_state(sogm_ctx *ctx, int32_t *out_host);
 
 /* Body particles of one drone: ParticleATC::initEgoParticles (particles.cpp:62-87).

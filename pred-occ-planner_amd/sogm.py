@@ -116,10 +116,12 @@ class SogmMap:
         check(lib().sogm_set_sparse_reset(self._ctx, 1 if on else 0, int(log_capacity)), "sogm_set_sparse_reset")
 
     def sparse_reset_state(self):
-        """{enabled, log_capacity, tracked (current grid covered by its log), max_entries (largest per-agent count)}."""
-        out = (C.c_int32 * 4)()
+        """{enabled, log_capacity, tracked (current grid covered by its log), max_entries (largest per-agent count),
+        total_entries (all agents)} of the current grid."""
+        out = (C.c_int32 * 5)()
         check(lib().sogm_sparse_reset_state(self._ctx, out), "sogm_sparse_reset_state")
-        return {"enabled": bool(out[0]), "log_capacity": out[1], "tracked": bool(out[2]), "max_entries": out[3]}
+        return {"enabled": bool(out[0]), "log_capacity": out[1], "tracked": bool(out[2]), "max_entries": out[3],
+                "total_entries": out[4]}
 
     # ---- profiling (HIP events around each kernel, on the caller's stream) ----
     def set_profiling(self, on=True):
