@@ -192,15 +192,16 @@ float  *sogm_grid_ptr(sogm_ctx *ctx);
  * (fake_particle_risk_voxel.cpp:107-108, a fill over all V x T cells, then the marks).  The library produces the
  * same cells without touching the ones that are zero already: every mark written by sogm_update_gt[_swarm] /
  * sogm_project_neighbours is logged as the index of its 32-byte sector (one log per agent and per grid of the pool,
- * log_capacity entries per agent: 0 keeps the current value, default 2^20 or SOGM_LOG_CAP), and the grid's next reset
+ * log_capacity entries per agent: 0 keeps the current value; default V*T/80, at least 2^20, or SOGM_LOG_CAP), and the grid's next reset
  * zeroes exactly the logged sectors.  A grid written by a dense writer (sogm_set_future_risk, sogm_dsp_publish, the
  * caller through sogm_grid_ptr), a freshly allocated one, and an agent whose log overflowed are cleared densely.
  * enable = 0 restores the dense clear everywhere (also: SOGM_SPARSE_RESET=0 in the environment at sogm_create).
  * Synchronises the device; call between ticks. */
 int sogm_set_sparse_reset(sogm_ctx *ctx, int enable, int log_capacity);
-/* host out[5]: {enabled, log capacity per agent, 1 if the current grid is covered by its log, largest per-agent
+/* host out[7]: {enabled, log capacity per agent, 1 if the current grid is covered by its log, largest per-agent
  * entry count of the current grid's log (above the capacity: that agent's next reset is dense), entries of all
- * agents together (saturating)}.  Synchronises. */
+ * agents together (saturating), sparse resets launched since the previous call, mean entries read per such
+ * launch}.  Synchronises. */
 int sogm_sparse_reset_state(sogm_ctx *ctx, int32_t *out_host);
 
 /* Body particles of one drone: ParticleATC::initEgoParticles (particles.cpp:62-87).

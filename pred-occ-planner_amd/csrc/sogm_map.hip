@@ -103,9 +103,14 @@ __global__ void k_set_word(int *p, int v) { *p = v; }
 // agent's workgroups zero its whole grid instead.  Launched (blocks, A); the counts are reset by a memset behind it.
 __global__ __launch_bounds__(256) void k_reset_sectors(char *__restrict__ grid, size_t agent_bytes,
                                                        const unsigned *__restrict__ entries,
-                                                       const unsigned *__restrict__ counts, int cap) {
+                                                       const unsigned *__restrict__ counts, int cap,
+                                                       unsigned long long *__restrict__ stat) {
   const int      agent = blockIdx.y;
   const unsigned n     = counts[agent];
+  if (blockIdx.x == 0 && threadIdx.x == 0) {  // statistics for sogm_sparse_reset_state: entries read, launches
+    atomicAdd(stat, (unsigned long long)(n > (unsigned)cap ? (unsigned)cap : n));
+    if (agent == 0) atomicAdd(stat + 1, 1ull);
+  }
   char          *base  = grid + (size_t)agent * agent_bytes;
   const vfloat4  z     = {0.f, 0.f, 0.f, 0.f};
   const size_t   tid   = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nthr = (size_t)gridDim.x * blockDim.x;
@@ -864,6 +869,16 @@ MarkLog mark_log(sogm_ctx *c, int slot) {
       for (int i = 0; i < 3; ++i) c->tracked[i] = 0;
       return none;
     }
+    if (!c->d_reset_stat &&
+        (hipMalloc((void **)&c->d_reset_stat, 2 * sizeof(unsigned long long)) != hipSuccess ||
+         hipMemset(c->d_reset_stat, 0, 2 * sizeof(unsigned long long)) != hipSuccess)) {
+      (void)hipGetLastError();
+      (void)hipFree(e);
+      (void)hipFree(n);
+      c->sparse = 0;
+      for (int i = 0; i < 3; ++i) c->tracked[i] = 0;
+      return none;
+    }
     c->d_log[slot]   = e;
     c->d_log_n[slot] = n;
     c->tracked[slot] = 0;  // what the grid holds now was written without a log
@@ -882,7 +897,7 @@ int reset_slot(sogm_ctx *c, hipStream_t st, int slot, float *grid, bool polite) 
     }
     prof_begin(c, SOGM_PROF_CLEAR, st);
     hipLaunchKernelGGL(k_reset_sectors, dim3(wgs, c->n_agents), dim3(256), 0, st, reinterpret_cast<char *>(grid),
-                       agent_grid_bytes(c), lg.entries, lg.n, lg.cap);
+                       agent_grid_bytes(c), lg.entries, lg.n, lg.cap, c->d_reset_stat);
     prof_end(c, SOGM_PROF_CLEAR, st);
     SOGM_HIP_CHECK(hipGetLastError());
     SOGM_HIP_CHECK(hipMemsetAsync(lg.n, 0, sizeof(unsigned) * (size_t)c->n_agents, st));
@@ -1111,7 +1126,10 @@ int sogm_create(const SogmSpec *spec, int n_agents, int device, sogm_ctx **out) 
     const char *e = getenv("SOGM_SPARSE_RESET");
     c->sparse     = e ? atoi(e) != 0 : 1;
     e             = getenv("SOGM_LOG_CAP");
-    c->log_cap    = e && atoi(e) > 0 ? atoi(e) : (1 << 20);
+    // default capacity per agent: one entry per 80 cells, at least 2^20 (the bench scenes log ~0.7 M entries per
+    // agent and tick at 200^3 x 20, i.e. one per 230 cells)
+    const long long dflt = (long long)spec->L * spec->W * spec->H * spec->T / 80;
+    c->log_cap    = e && atoi(e) > 0 ? atoi(e) : (int)(dflt < (1 << 20) ? (1 << 20) : (dflt > (1 << 26) ? (1 << 26) : dflt));
   }
   const size_t n   = (size_t)n_agents * spec->T * (size_t)c->geom.V;
   hipError_t   e   = hipMalloc(&c->d_grid, (n * c->cell_bytes() + 15) & ~(size_t)15);
@@ -1148,6 +1166,7 @@ void sogm_destroy(sogm_ctx *c) {
     if (c->d_log[i]) (void)hipFree(c->d_log[i]);
     if (c->d_log_n[i]) (void)hipFree(c->d_log_n[i]);
   }
+  if (c->d_reset_stat) (void)hipFree(c->d_reset_stat);
   if (c->d_poses) (void)hipFree(c->d_poses);
   if (c->d_stamps) (void)hipFree(c->d_stamps);
   if (c->clear_cursor) (void)hipFree(c->clear_cursor);
@@ -1233,6 +1252,15 @@ int sogm_sparse_reset_state(sogm_ctx *c, int32_t *out) {
     }
     out[3] = (int32_t)(mx > 0x7FFFFFFFu ? 0x7FFFFFFFu : mx);
     out[4] = (int32_t)(tot > 0x7FFFFFFFull ? 0x7FFFFFFFull : tot);
+  }
+  out[5] = out[6] = 0;  // sparse resets since the previous call: launches, and entries read per launch (mean)
+  if (c->d_reset_stat) {
+    unsigned long long st[2] = {0, 0};
+    SOGM_HIP_CHECK(hipMemcpy(st, c->d_reset_stat, sizeof(st), hipMemcpyDeviceToHost));
+    SOGM_HIP_CHECK(hipMemset(c->d_reset_stat, 0, sizeof(st)));
+    out[5] = (int32_t)(st[1] > 0x7FFFFFFFull ? 0x7FFFFFFFull : st[1]);
+    const unsigned long long mean = st[1] ? st[0] / st[1] : 0;
+    out[6] = (int32_t)(mean > 0x7FFFFFFFull ? 0x7FFFFFFFull : mean);
   }
   return SOGM_OK;
 }

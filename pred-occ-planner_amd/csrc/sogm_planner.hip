@@ -624,11 +624,18 @@ static int replan_impl(sogm_planner *p, const double *start_pva, const double *g
     size_t       head  = (size_t)28e9 / 16;
     if (head > total / 2) head = total / 2;
     for (int g = 0; g < G; ++g) SOGM_HIP_CHECK(hipStreamWaitEvent(c->side, p->ev_pts[g], 0));
-    int rc = sogm::launch_clear(c, c->side, c->d_grid, true, 1, head);
-    if (rc) return rc;
-    for (int g = 0; g < G; ++g) SOGM_HIP_CHECK(hipStreamWaitEvent(c->side, p->ev_corr[g], 0));
-    rc = sogm::launch_clear(c, c->side, c->d_grid, false, 2, head);
-    if (rc) return rc;
+    const int slot = sogm::cur_slot(c);
+    if (c->sparse && c->tracked[slot] && sogm::mark_log(c, slot).entries) {
+      // sparse reset: the logged sectors only, as soon as the SOGM's last readers are done
+      int rc = sogm::reset_slot(c, c->side, slot, c->d_grid, true);
+      if (rc) return rc;
+    } else {
+      int rc = sogm::launch_clear(c, c->side, c->d_grid, true, 1, head);
+      if (rc) return rc;
+      for (int g = 0; g < G; ++g) SOGM_HIP_CHECK(hipStreamWaitEvent(c->side, p->ev_corr[g], 0));
+      rc = sogm::launch_clear(c, c->side, c->d_grid, false, 2, head);
+      if (rc) return rc;
+    }
     SOGM_HIP_CHECK(hipEventRecord(c->ev_cleared, c->side));
     c->precleared = 1;
     c->updated    = 0;

@@ -117,11 +117,12 @@ class SogmMap:
 
     def sparse_reset_state(self):
         """{enabled, log_capacity, tracked (current grid covered by its log), max_entries (largest per-agent count),
-        total_entries (all agents)} of the current grid."""
-        out = (C.c_int32 * 5)()
+        total_entries (all agents)} of the current grid; resets / entries_per_reset: the sparse resets launched since the
+        previous call."""
+        out = (C.c_int32 * 7)()
         check(lib().sogm_sparse_reset_state(self._ctx, out), "sogm_sparse_reset_state")
         return {"enabled": bool(out[0]), "log_capacity": out[1], "tracked": bool(out[2]), "max_entries": out[3],
-                "total_entries": out[4]}
+                "total_entries": out[4], "resets": out[5], "entries_per_reset": out[6]}
 
     # ---- profiling (HIP events around each kernel, on the caller's stream) ----
     def set_profiling(self, on=True):

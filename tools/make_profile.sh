@@ -3,7 +3,9 @@
 # parts so that one gpurun call stays short (every step under its own `timeout`):
 #   bash tools/make_profile.sh core    bench lines (default run incl. the sustained block and the CPU baseline),
 #                                      kernel-trace + stats of `python bench.py`, separate PMC passes (FETCH_SIZE,
-#                                      WRITE_SIZE; no trace domains), tick timeline, per-agent chain, rocm-smi state
+#                                      WRITE_SIZE; no trace domains) of the dense clear kernels and of the sparse
+#                                      reset, the dense-clear variant of the bench, tick timeline, per-agent chain,
+#                                      rocm-smi state
 #   bash tools/make_profile.sh rest    variants (grouped path, two grids, single grid, cfg4), perception side benches
 #                                      with their trace / PMC passes, the capacity / QP / residual diagnostics
 # tools/make_profile_md.py assembles profiles/r03_*.md from it.
@@ -25,10 +27,16 @@ if [ "$PART" = core ]; then
   #  (k_clear_chunks) and the stamp run by themselves in tools/diag_clear_pmc.py)
   SOGM_FLOW=0 timeout 300 rocprofv3 --pmc FETCH_SIZE -d /tmp/prof_fetch -- python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --sustained 0 > /dev/null 2> $OUT/fetch.err
   SOGM_FLOW=0 timeout 300 rocprofv3 --pmc WRITE_SIZE -d /tmp/prof_write -- python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --sustained 0 > /dev/null 2> $OUT/write.err
-  SOGM_CLEAR_EARLY=1 timeout 200 rocprofv3 --pmc FETCH_SIZE -d /tmp/prof_cfetch -- python $REPO/tools/diag_clear_pmc.py > /dev/null 2> $OUT/cfetch.err
-  SOGM_CLEAR_EARLY=1 timeout 200 rocprofv3 --pmc WRITE_SIZE -d /tmp/prof_cwrite -- python $REPO/tools/diag_clear_pmc.py > $OUT/clear_alone.txt 2> $OUT/cwrite.err
+  SOGM_SPARSE_RESET=0 SOGM_CLEAR_EARLY=1 timeout 200 rocprofv3 --pmc FETCH_SIZE -d /tmp/prof_cfetch -- python $REPO/tools/diag_clear_pmc.py > /dev/null 2> $OUT/cfetch.err
+  SOGM_SPARSE_RESET=0 SOGM_CLEAR_EARLY=1 timeout 200 rocprofv3 --pmc WRITE_SIZE -d /tmp/prof_cwrite -- python $REPO/tools/diag_clear_pmc.py > $OUT/clear_alone.txt 2> $OUT/cwrite.err
+  # the sparse reset (k_reset_sectors) and the logging stamp / overlay by themselves
+  timeout 200 rocprofv3 --pmc FETCH_SIZE -d /tmp/prof_rfetch -- python $REPO/tools/diag_reset_pmc.py > /dev/null 2> $OUT/rfetch.err
+  timeout 200 rocprofv3 --pmc WRITE_SIZE -d /tmp/prof_rwrite -- python $REPO/tools/diag_reset_pmc.py > $OUT/reset_alone.txt 2> $OUT/rwrite.err
+  timeout 200 python $REPO/tools/diag_reset_pmc.py > $OUT/reset_alone_plain.txt 2>/dev/null
+  # the dense clear in the tick (the path of rounds 1-2), for comparison on this box
+  SOGM_SPARSE_RESET=0 timeout 300 python $REPO/bench.py --steps 20 --warmup 3 --no-cpu-baseline --sustained 100 > $OUT/bench_dense.json 2>/dev/null
   cd $REPO
-  python tools/rocprof_summary.py "$(db /tmp/prof_trace)" "$(db /tmp/prof_fetch)" "$(db /tmp/prof_write)" "$(db /tmp/prof_cfetch)" "$(db /tmp/prof_cwrite)" > $OUT/summary.md 2> $OUT/summary.err
+  python tools/rocprof_summary.py "$(db /tmp/prof_trace)" "$(db /tmp/prof_fetch)" "$(db /tmp/prof_write)" "$(db /tmp/prof_cfetch)" "$(db /tmp/prof_cwrite)" "$(db /tmp/prof_rfetch)" "$(db /tmp/prof_rwrite)" > $OUT/summary.md 2> $OUT/summary.err
   python tools/tick_timeline.py /tmp/prof_trace > $OUT/timeline.txt 2>&1
   timeout 200 python tools/diag_flow.py 12 > $OUT/flow.txt 2>&1
   tail -c 400 $OUT/bench_plain.json

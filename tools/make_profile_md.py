@@ -5,15 +5,17 @@ P = 'gpurun_out/profile/'
 last = lambda f: open(P + f).read().strip().splitlines()[-1]
 read = lambda f: open(P + f).read()
 summ, tl, flow = read('summary.md'), read('timeline.txt'), read('flow.txt')
-plain, trace, flow0, grids2, mode1, cfg4, dsp, gm = (last(f) for f in (
+plain, trace, flow0, grids2, mode1, cfg4, dsp, gm, dense = (last(f) for f in (
     'bench_plain.json', 'bench_trace.json', 'bench_flow0.json', 'bench_grids2.json', 'bench_mode1.json',
-    'bench_cfg4.json', 'bench_dsp.json', 'bench_gridmap.json'))
-d, f0, g2, m1, c4 = (json.loads(x) for x in (plain, flow0, grids2, mode1, cfg4))
+    'bench_cfg4.json', 'bench_dsp.json', 'bench_gridmap.json', 'bench_dense.json'))
+d, f0, g2, m1, c4, dn = (json.loads(x) for x in (plain, flow0, grids2, mode1, cfg4, dense))
 
 
-def pm(counter, kernel="k_clear_chunks<true>"):
-    m = re.search(r"%s \| %s \| (\d+) \| ([\d.]+) \|" % (re.escape(kernel), counter), summ)
-    return int(m.group(1)), float(m.group(2))
+def pm(counter, kernel="k_clear_chunks<true>", last=False):
+    """(dispatches, mean KB) of a kernel's counter: from the first PMC pass that lists it, or the last one"""
+    m = re.findall(r"%s \| %s \| (\d+) \| ([\d.]+) \|" % (re.escape(kernel), counter), summ)
+    m = m[-1] if last else m[0]
+    return int(m[0]), float(m[1])
 
 
 # the in-tick clear = k_clear_chunks (narrow launch; under counter collection kernels are serialised and the narrow
@@ -27,7 +29,20 @@ _, wk_marks = pm('WRITE_SIZE', 'k_stamp_marks')
 _, fk_bits = pm('FETCH_SIZE', 'k_stamp_bits')
 _, fk_marks = pm('FETCH_SIZE', 'k_stamp_marks')
 traffic = int((fk + wk) * 1024)
-alg = d['roofline']['bytes_per_launch']
+alg = dn['roofline']['bytes_per_launch']
+# the sparse reset by itself (tools/diag_reset_pmc.py: 5 sparse resets, entry counts printed by the plain run)
+_, fk_r = pm('FETCH_SIZE', 'k_reset_sectors', last=True)  # the diag_reset_pmc passes come last in the summary
+_, wk_r = pm('WRITE_SIZE', 'k_reset_sectors', last=True)
+ra = read('reset_alone_plain.txt')
+ent = [int(x) for x in re.search(r"log entries after each update: \[([\d, ]+)\]", ra).group(1).split(",")]
+reset_ms = [float(x) for x in re.search(r"ms: \[([\d., ]+)\]", ra).group(1).split(",")]
+ent_reset = sum(ent[:-1]) / len(ent[:-1])  # reset k reads the log update k-1 wrote
+json.dump({"kernel": "k_reset_sectors (sparse reset of the SOGM)",
+           "source": "profiles/r03_end_rocprof.md (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes of "
+                     "`python tools/diag_reset_pmc.py`: 128 agents 200x200x200x20, single grid, update = reset + stamp + overlay)",
+           "fetch_kb": fk_r, "write_kb": wk_r, "entries_per_launch": ent_reset,
+           "bytes_per_entry": (fk_r + wk_r) * 1024 / ent_reset, "issued_bytes_per_entry": 36},
+          open('profiles/r03_pmc_reset.json', 'w'))
 json.dump({"kernel": "k_clear_chunks (the in-tick SOGM clear) / k_clear_slabs (full-width stage pass)",
            "source": "profiles/r03_end_rocprof.md (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes of "
                      "`SOGM_CLEAR_EARLY=1 python tools/diag_clear_pmc.py` for k_clear_chunks and of `SOGM_FLOW=0 python "
@@ -63,45 +78,55 @@ Boxes differ: the same full-width clear takes 12.2–13.6 ms (0.75–0.84 of pea
 box (one make_profile run, one `tools/micro/ab.sh` call) are compared with each other in DESIGN.md.
 
 State: dataflow replan (`k_astar` with the speculative second attempt; persistent `k_corridor_flow` / `k_qp_flow` /
-`k_finish_flow` chained per agent), three SOGM grids, **width-adaptive chunked clear** (`k_clear_chunks`: narrow launch
-from the replan's start, a wide launch behind `k_clear_gate` once every agent's corridors are final, retiring when the
-next tick begins), **two-pass stamp** (`k_stamp_bits` occupancy bitmask, `k_stamp_marks` x-ordered marks), OSQP restated
-with the recession-cone projection in the infeasibility certificate and the scaled rho estimate, ADMM iterations between
-two checks in a clean inner loop, register-resident residual pass, one lane per record in `k_finish_flow`.
+`k_finish_flow` chained per agent), three SOGM grids, **sparse reset of the SOGM** (`k_reset_sectors`: the stamp and the
+overlay log the 32-byte sector of every mark; the grid the update swaps out is reset on the side stream by zeroing the
+logged sectors — the dense clear, `k_clear_chunks` / `k_clear_slabs`, remains for untracked grids and `SOGM_SPARSE_RESET=0`),
+**two-pass stamp** (`k_stamp_bits` occupancy bitmask, `k_stamp_marks` x-ordered marks + log), A* with the templated SOGM
+window query, wave-parallel heap pushes and the closed set in LDS, OSQP restated with the recession-cone projection in
+the infeasibility certificate and the scaled rho estimate.
 
 Default run (`python bench.py`: 3 warm-up + 20 timed ticks, then 300 host-synchronised ticks of the same flight,
 then the CPU baseline): **{d['value']:.0f} replans/s** ({d['ms_per_step']:.2f} ms per tick), of which
 {d['value_ok']:.0f} successful (`replans_ok_fraction` {d['config']['replans_ok_fraction']:.3f}; outcomes
 {json.dumps(d['config']['outcomes'])}); **sustained** {s['value']:.0f} replans/s over {s['ticks']} ticks (tick mean
-{s['tick_ms_mean']:.2f} / p50 {s['tick_ms_p50']:.2f} / p99 {s['tick_ms_p99']:.2f} ms, ok {s['replans_ok_fraction']:.3f}; outcomes
-{json.dumps(s['outcomes_rank0'])}).
-The SOGM clear inside the tick (HIP events on its launch stream around BOTH launches, every clear of the timed region,
-n = {r['launches_timed']}): {r['avg_launch_ms']:.2f} ms per clear = {r['achieved']:.0f} GB/s = **{r['frac']:.3f}** of the 8 TB/s HBM
-peak; `k_clear_slabs` full width with the machine to itself {min(r['standalone']['launch_ms']):.2f} ms =
-{r['standalone']['frac']:.3f}.  CPU baseline (oracle "port", one agent-replan per thread): {cb['value']:.1f} replans/s on
+{s['tick_ms_mean']:.2f} / p50 {s['tick_ms_p50']:.2f} / p99 {s['tick_ms_p99']:.2f} / max {s['tick_ms_max']:.2f} ms, ok
+{s['replans_ok_fraction']:.3f}, {s['value_ok']:.0f} successful replans/s; outcomes {json.dumps(s['outcomes_rank0'])}).
+The reset inside the tick (HIP events on its stream around every reset of the timed region, n = {r['launches_timed']},
+{r['sparse_resets']} of them sparse): {r['avg_launch_ms']:.2f} ms for {r['log_entries_per_launch']/1e6:.1f} M log entries =
+{r['bytes_per_launch']/1e9:.2f} GB issued (4 B read + 32 B written per entry) = {r['achieved']:.0f} GB/s = **{r['frac']:.3f}** of
+the 8 TB/s HBM peak — off the critical path and no longer what bounds the tick: SURVEY 8(d)'s dense figure
+({alg/1e9:.2f} GB per rebuild) divided by this launch is {r['dense_equivalent']['rate_GBps']/1e3:.1f} TB/s.  The dense clear
+`k_clear_slabs` full width with the machine to itself: {min(r['standalone']['launch_ms']):.2f} ms =
+{r['standalone']['frac']:.3f} of peak; inside the tick (`SOGM_SPARSE_RESET=0`, below): {dn['roofline']['avg_launch_ms']:.2f} ms =
+{dn['roofline']['frac']:.3f}.  CPU baseline (oracle "port", one agent-replan per thread): {cb['value']:.1f} replans/s on
 {cb['cores']} of {cb.get('host_cores')} host cores ({cb['sample']}).
 
 Variants on the same box:
-| variant | replans/s | ms/tick | clear ms (frac) | sustained replans/s (mean tick) |
+| variant | replans/s | ms/tick | reset / clear ms | sustained replans/s (mean tick) |
 |---|---|---|---|---|
-| default: dataflow replan, 3 grids, adaptive clear | {d['value']:.0f} | {d['ms_per_step']:.2f} | {r['avg_launch_ms']:.2f} ({r['frac']:.3f}) | {s['value']:.0f} ({s['tick_ms_mean']:.2f} ms) |
-| grouped streams (`SOGM_FLOW=0`, round-1 structure; fixed narrow clear), 3 grids | {f0['value']:.0f} | {f0['ms_per_step']:.2f} | {f0['roofline']['avg_launch_ms']:.2f} ({f0['roofline']['frac']:.3f}) | {f0['sustained']['value']:.0f} ({f0['sustained']['tick_ms_mean']:.2f} ms, 100 ticks) |
-| dataflow, 2 grids (`SOGM_GRIDS=2`) | {g2['value']:.0f} | {g2['ms_per_step']:.2f} | {g2['roofline']['avg_launch_ms']:.2f} ({g2['roofline']['frac']:.3f}) | — |
-| single grid, in-place two-part clear (`SOGM_DOUBLE_BUFFER=0`, grouped path) | {m1['value']:.0f} | {m1['ms_per_step']:.2f} | {m1['roofline']['avg_launch_ms']:.2f} ({m1['roofline']['frac']:.3f}) | — |
-| BASELINE configs[4]: 300^3 x 30, fp16 cells, 207 GB, single grid | {c4['value']:.0f} | {c4['ms_per_step']:.2f} | {c4['roofline']['avg_launch_ms']:.2f} ({c4['roofline']['frac']:.3f}) | — |
+| default: dataflow replan, 3 grids, sparse reset | {d['value']:.0f} | {d['ms_per_step']:.2f} | {r['avg_launch_ms']:.2f} | {s['value']:.0f} ({s['tick_ms_mean']:.2f} ms) |
+| **dense clear** (`SOGM_SPARSE_RESET=0`: rounds 1-2; width-adaptive chunked clear) | {dn['value']:.0f} | {dn['ms_per_step']:.2f} | {dn['roofline']['avg_launch_ms']:.2f} (frac {dn['roofline']['frac']:.3f}) | {dn['sustained']['value']:.0f} ({dn['sustained']['tick_ms_mean']:.2f} ms, 100 ticks) |
+| grouped streams (`SOGM_FLOW=0`, round-1 structure), 3 grids | {f0['value']:.0f} | {f0['ms_per_step']:.2f} | {f0['roofline']['avg_launch_ms']:.2f} | {f0['sustained']['value']:.0f} ({f0['sustained']['tick_ms_mean']:.2f} ms, 100 ticks) |
+| dataflow, 2 grids (`SOGM_GRIDS=2`: 164 GB instead of 246) | {g2['value']:.0f} | {g2['ms_per_step']:.2f} | {g2['roofline']['avg_launch_ms']:.2f} | — |
+| single grid, reset in place after the last reader (`SOGM_DOUBLE_BUFFER=0`, grouped path) | {m1['value']:.0f} | {m1['ms_per_step']:.2f} | {m1['roofline']['avg_launch_ms']:.2f} | — |
+| BASELINE configs[4]: 300^3 x 30, fp16 cells, 207 GB, single grid | {c4['value']:.0f} | {c4['ms_per_step']:.2f} | {c4['roofline']['avg_launch_ms']:.2f} | — |
 
 Reading guide:
-- The roofline kernel is the SOGM clear ({alg/1e9:.2f} GB algorithmic bytes per clear = 128 agents x 640 MB).  PMC of
-  `k_clear_chunks<true>` (serialised: the narrow launch clears the whole grid): FETCH_SIZE {fk:.0f} KB + WRITE_SIZE
-  {wk:.0f} KB = {traffic/1e9:.2f} GB per clear (KB = 1024 B), i.e. **{traffic/alg:.4f} x** the algorithmic bytes;
+- **Sparse reset.**  `k_reset_sectors` by itself (tools/diag_reset_pmc.py, single grid, every update = reset + stamp +
+  overlay; launches {", ".join("%.2f" % x for x in reset_ms[1:])} ms, the first update's dense clear {reset_ms[0]:.2f} ms):
+  {ent_reset/1e6:.1f} M entries per launch; PMC FETCH_SIZE {fk_r/1e6:.2f} GB + WRITE_SIZE {wk_r/1e6:.2f} GB per launch (KB = 1024 B) =
+  **{(fk_r + wk_r) * 1024 / ent_reset:.1f} B of HBM traffic per entry** against the 36 B issued (duplicate sectors are absorbed
+  by the L2) — {(fk_r + wk_r) * 1024 / alg * 100:.1f} % of the {alg/1e9:.2f} GB a dense rebuild writes.
+- **Dense clear** (kept for untracked grids; `SOGM_SPARSE_RESET=0`): {alg/1e9:.2f} GB algorithmic bytes per clear = 128
+  agents x 640 MB.  PMC of `k_clear_chunks<true>` (serialised: the narrow launch clears the whole grid): FETCH_SIZE
+  {fk:.0f} KB + WRITE_SIZE {wk:.0f} KB = {traffic/1e9:.2f} GB per clear, i.e. **{traffic/alg:.4f} x** the algorithmic bytes;
   `k_clear_slabs<true>`: FETCH {fk_s:.0f} KB + WRITE {wk_s:.0f} KB = x {(fk_s + wk_s) * 1024 / alg:.4f}.  No wasted traffic.
-- Stamp: `k_stamp_bits` WRITE {wk_bits/1e6:.2f} GB (device-scope atomics) / FETCH {fk_bits/1e6:.2f} GB, `k_stamp_marks`
-  WRITE {wk_marks/1e6:.2f} GB / FETCH {fk_marks/1e6:.2f} GB per tick: **{(wk_bits + wk_marks) * 1024 / 0.28e9:.1f} x** the ≈0.28 GB of
-  marked bytes (round 2, one pass in cloud order: 2.41 GB = 8.8 x).
+- Stamp (with the log): `k_stamp_bits` WRITE {wk_bits/1e6:.2f} GB (device-scope atomics) / FETCH {fk_bits/1e6:.2f} GB,
+  `k_stamp_marks` WRITE {wk_marks/1e6:.2f} GB / FETCH {fk_marks/1e6:.2f} GB per tick: the ≈0.28 GB of marked bytes plus
+  {ent_reset*4/1e9:.2f} GB of log entries (round 2, one pass in cloud order, no log: 2.41 GB).
 - In the dataflow replan the planner is five launches per tick; `k_corridor_flow`, `k_qp_flow`, `k_finish_flow` are
   persistent (their durations span most of the tick by construction) — the per-agent stage times below are what to
-  read, not the kernel durations.  `k_clear_chunks<true>` (narrow) spans the whole clear, `k_clear_gate` ends when the
-  last agent's corridors are final, `k_clear_chunks<false>` (wide) runs from then until the next tick begins.
+  read, not the kernel durations.
 
 {summ}
 
@@ -159,6 +184,12 @@ GPU vs oracle on the same corridors (tools/diag_qp_parity.py, 3 ticks x 128 agen
 
 ```
 {trace}
+```
+
+- dense clear (`SOGM_SPARSE_RESET=0`):
+
+```
+{dense}
 ```
 
 - grouped path (`SOGM_FLOW=0`):
