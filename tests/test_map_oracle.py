@@ -106,3 +106,22 @@ def test_query_semantics_fake_vs_riskbase(pop, orc):
     g[idz, 0] = 5.0
     assert orc.query_clear(s, g, pose, pos, 0.0) == 0
     assert orc.query_clear(sr, g, pose, pos, 0.0) == 1
+
+
+def test_mark_whose_index_leaves_the_array_is_dropped(pop, orc):
+    """Reference UB (map.h:169-174): z one ulp below +range passes the strict range test, but "z + rz" and the fp32
+    division round up and the z index equals H — voxel index >= V, a write outside risk_maps_ in the reference.  The
+    oracle (like the HIP path) drops the mark instead of writing past its array."""
+    import ctypes as C
+    s = pop.config.make_spec("parity")
+    L = orc.lib()
+    rz = np.float32(s.H // 2) * np.float32(s.resolution)
+    z = np.nextafter(rz, np.float32(0), dtype=np.float32)  # largest float below +rz
+    p = np.array([0.0, 0.0, z], np.float32)
+    assert L.orc_is_in_range_f(C.byref(s), orc.fptr(p)) == 1
+    assert L.orc_voxel_index_f(C.byref(s), orc.fptr(p)) >= s.L * s.W * s.H   # the reference's index leaves the array
+    pose = np.zeros(3, np.float32)
+    cloud = np.array([[0.0, 0.0, z], [0.3, 0.3, 0.3]], np.float32)
+    cyl = pop.scene.cylinders_to_struct(np.zeros((0, 5)))
+    g = orc.update_gt(s, cloud, cyl, 0, pose)
+    assert int((g[:, 0] > 0).sum()) == 1 and int((g > 0).sum()) == s.T  # only the interior point is marked
