@@ -132,13 +132,18 @@ class RiskMap {
   void setCoordinator(const std::vector<Vec3> &body_particles) {
     check(sogm_set_body_particles(ctx_, body_particles[0].data(), (int)body_particles.size()), "set_body");
   }
-  // Tick pipelining (no reference counterpart): 0 off, 1 in-place pre-clear under the QP stage, 2 / 3 a pool of
+  // Tick pipelining (no reference counterpart): 0 off, 1 in-place reset after the replan's last map reader, 2 / 3 a pool of
   // two / three grids (returns false and leaves the mode unchanged if HBM has no room for them)
   bool setTickPipelining(int mode) {
     const int rc = sogm_set_overlap_clear(ctx_, mode);
     if (rc == SOGM_ERR_CAPACITY) return false;
     check(rc, "sogm_set_overlap_clear");
     return true;
+  }
+  // How updateMap's "fill the map with zeros" (fake_particle_risk_voxel.cpp:107-108) is carried out: by zeroing the
+  // logged sectors of the previous build's marks (default) or by the dense clear; same cells either way
+  void setSparseReset(bool on, int log_capacity_per_agent = 0) {
+    check(sogm_set_sparse_reset(ctx_, on ? 1 : 0, log_capacity_per_agent), "sogm_set_sparse_reset");
   }
   // SOGM::update — FakeParticleRiskVoxel::updateMap for the whole batch (device pointers)
   void update(const float *cloud_xyz, const int32_t *cloud_range, const SogmCylinder *cyl, int n_cyl,
