@@ -347,6 +347,7 @@ struct sogm_ctx {
   int                 clear_gate_target;
   int                *clear_epoch_word;
   int                 clear_epoch, clear_epoch_ahead;
+  int                 wide_clear_pending;  // a dense adaptive clear was queued since the last update wrote epoch 0
   unsigned long long *clear_cursor;  // [2], used in turn (clear_seq)
   unsigned            clear_seq;
   hipStream_t         side2;  // the wide part's stream
@@ -456,6 +457,7 @@ size_t clear_vec4_total(const sogm_ctx *c);
 // next update's grid becomes current (modes 2 / 3) and the stream waits for its pre-clear
 int  adopt_preclear(sogm_ctx *c, hipStream_t st);
 int  announce_clear_epoch(sogm_ctx *c, hipStream_t st);
+int  next_clear_epoch(sogm_ctx *c);  // the epoch a replan writes itself (k_flow_reset) instead of a launch of its own
 int  queue_spare_clears(sogm_ctx *c, hipEvent_t after);
 // sparse reset (sogm_map.hip): the mark log of a pool slot as the writers see it (null entries = not logging)
 struct MarkLog {

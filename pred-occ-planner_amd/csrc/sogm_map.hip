@@ -923,11 +923,13 @@ int adopt_preclear(sogm_ctx *c, hipStream_t st) {
       const char *e = getenv("SOGM_CLEAR_EARLY");
       early         = e ? atoi(e) : 0;
     }
-    if (c->clear_gate) {
+    if (c->clear_gate && c->wide_clear_pending) {
       // a new tick: wide clear workgroups opened for the replan that just ended retire (the stamp, the searches and
-      // the corridor stage want the memory pipeline responsive), the narrow launch goes on
+      // the corridor stage want the memory pipeline responsive), the narrow launch goes on.  (Only when a dense
+      // clear was queued since the last update: sparse resets have no wide launch.)
       hipLaunchKernelGGL(k_set_word, dim3(1), dim3(1), 0, st, c->clear_epoch_word, 0);
       SOGM_HIP_CHECK(hipGetLastError());
+      c->wide_clear_pending = 0;
     }
     if (c->clear_gate && early) {
       // tuning aid (SOGM_CLEAR_EARLY=1): queue the clear of the swapped-out grid NOW, under the stamp — its readers,
@@ -1046,6 +1048,7 @@ static int launch_clear_impl(sogm_ctx *c, hipStream_t st, float *grid, bool poli
     SOGM_HIP_CHECK(hipStreamWaitEvent(c->side2, c->ev_side2_go, 0));
     prof_begin(c, slot, st);
     const int epoch = c->clear_epoch + c->clear_epoch_ahead;
+    c->wide_clear_pending = 1;
     hipLaunchKernelGGL(k_clear_chunks<true>, dim3(nblk), dim3(256), 0, st, (vfloat4 *)grid, nall, grid + nall * 4,
                        tail, cur, nxt, c->clear_epoch_word, epoch, 0);
     hipLaunchKernelGGL(k_clear_gate, dim3(1), dim3(64), 0, c->side2, cur, nchunks, c->clear_gate,
@@ -1070,8 +1073,12 @@ static int launch_clear_impl(sogm_ctx *c, hipStream_t st, float *grid, bool poli
   return SOGM_OK;
 }
 
-int announce_clear_epoch(sogm_ctx *c, hipStream_t st) {
+int next_clear_epoch(sogm_ctx *c) {
   if (++c->clear_epoch <= 0) c->clear_epoch = 1;  // 0 = "no replan in flight"
+  return c->clear_epoch;
+}
+int announce_clear_epoch(sogm_ctx *c, hipStream_t st) {
+  next_clear_epoch(c);
   hipLaunchKernelGGL(k_set_word, dim3(1), dim3(1), 0, st, c->clear_epoch_word, c->clear_epoch);
   SOGM_HIP_CHECK(hipGetLastError());
   return SOGM_OK;

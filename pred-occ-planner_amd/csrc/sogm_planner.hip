@@ -492,6 +492,28 @@ int sogm_planner_set_swarm(sogm_planner *p, const SogmTrajRecord *records, int n
 // searches finish; k_corridor_flow, k_qp_flow and k_finish_flow are persistent and chain per agent through ready
 // lists in HBM, so a slow search / corridor / QP only delays its own agent's chain.  k_flow_gate makes the waiting
 // kernels dispatch only after every search is resident (they could otherwise fill the CUs and starve it).
+// The dataflow replan's control block and outputs back to their start values: counters / seg_done 0, ready lists -1,
+// verdicts 0, ok 0, records empty.
+// epoch_word (dense clear's gate, sogm_device.hpp): this replan's epoch, written by the block that reset the counters
+// and after them.
+__global__ __launch_bounds__(256) void k_flow_reset(int *hdr, int n_hdr, int *ready, int n_ready, int *verdict,
+                                                    int n_verdict, int32_t *ok, int n_ok, int *records, int n_rec,
+                                                    int *epoch_word, int epoch) {
+  const int i0 = (int)(blockIdx.x * blockDim.x + threadIdx.x), step = (int)(gridDim.x * blockDim.x);
+  if (blockIdx.x == 0) {
+    for (int i = (int)threadIdx.x; i < n_hdr; i += (int)blockDim.x) hdr[i] = 0;
+    __threadfence();
+    __syncthreads();
+    if (epoch_word && threadIdx.x == 0)
+      __hip_atomic_store(epoch_word, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  for (int i = i0; i < n_ready; i += step) ready[i] = -1;
+  if (verdict)
+    for (int i = i0; i < n_verdict; i += step) verdict[i] = 0;
+  for (int i = i0; i < n_ok; i += step) ok[i] = 0;
+  for (int i = i0; i < n_rec; i += step) records[i] = 0;
+}
+
 static int replan_flow(sogm_planner *p, const double *start_pva, const double *goal, const double *t_start,
                        const int32_t *drone_ids, SogmTrajRecord *out_records, int32_t *out_ok, void *stream) {
   sogm_ctx     *c    = p->map;
@@ -502,22 +524,21 @@ static int replan_flow(sogm_planner *p, const double *start_pva, const double *g
     if (int rc = sogm::join_exchange(c, main)) return rc;
   hipStream_t sA = p->fstream[0], sC = p->fstream[1], sQ = p->fstream[2], sF = p->fstream[3];
   // reset the control block in stream order: counters and seg_done to 0, ready lists to -1
-  SOGM_HIP_CHECK(hipMemsetAsync(p->d_flow, 0, sizeof(int) * (FLOW_HDR + (size_t)A), main));
-  SOGM_HIP_CHECK(hipMemsetAsync(p->fc.a_ready, 0xFF, sizeof(int) * 3 * (size_t)A, main));
-  const bool spec = p->spec_astar != 0;
-  if (spec) SOGM_HIP_CHECK(hipMemsetAsync(p->aw.verdict, 0, sizeof(int) * (size_t)A, main));
+  // (one launch instead of five memset nodes: each cost a dispatch gap on the tick's critical path)
   // k_finish_flow writes ok / the record of every agent whose chain completes; an agent whose chain does NOT (a wait
   // timed out, FLOW_ERR) must report ok = 0 and an empty record, not the previous tick's
-  SOGM_HIP_CHECK(hipMemsetAsync(out_ok, 0, sizeof(int32_t) * (size_t)A, main));
-  SOGM_HIP_CHECK(hipMemsetAsync(out_records, 0, sizeof(SogmTrajRecord) * (size_t)A, main));
+  const bool spec = p->spec_astar != 0;
+  hipLaunchKernelGGL(k_flow_reset, dim3(64), dim3(256), 0, main, p->d_flow, FLOW_HDR + A, p->fc.a_ready, 3 * A,
+                     spec ? p->aw.verdict : nullptr, A, out_ok, A, reinterpret_cast<int *>(out_records),
+                     (int)(sizeof(SogmTrajRecord) / sizeof(int)) * A,
+                     c->overlap >= 2 && c->clear_gate ? c->clear_epoch_word : nullptr,
+                     c->overlap >= 2 && c->clear_gate ? sogm::next_clear_epoch(c) : 0);
+  SOGM_HIP_CHECK(hipGetLastError());
   SOGM_HIP_CHECK(hipEventRecord(p->ev_in, main));
   if (c->overlap >= 2) {
     // the side-stream clear of the grid this tick's update swapped out: narrow, with a wide second launch that joins
     // once every agent's corridors are final (FLOW_Q_READY_N == A, registered as the gate at planner creation) —
     // announce this replan's epoch now that the counters are reset
-    if (c->clear_gate) {
-      if (int rc = sogm::announce_clear_epoch(c, main)) return rc;
-    }
     int rc = sogm::queue_spare_clears(c, p->ev_in);  // grids still dirty (first ticks, pool changes)
     if (rc) return rc;
   }
