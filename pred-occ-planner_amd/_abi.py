@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsogm_hip.so")
+# (SOGM_LIB_PATH: another build of the same ABI, for same-box A/B runs of two library versions — tools/micro/ab.sh)
+LIB_PATH = os.environ.get("SOGM_LIB_PATH") or os.path.join(_HERE, "libsogm_hip.so")
 
 SOGM_MAX_PIECES = 16
 SOGM_MAP_FAKE = 0

@@ -242,11 +242,16 @@ struct CylCand {
   double wlim;  // w + clearance (fp64, as the reference compares)
   int    type, orig;
 };
+// (The kernel also files the update's poses and stamps into the context's arrays — the later kernels of the update
+//  and the queries read those —, which saves two copy nodes in front of it.)
 __global__ __launch_bounds__(64) void k_cull_cylinders(GridGeom g, const SogmCylinder *__restrict__ cyl, int n_cyl,
                                                        const float *__restrict__ poses, CylCand *__restrict__ cand,
-                                                       int *__restrict__ n_cand) {
+                                                       int *__restrict__ n_cand, const double *__restrict__ stamps_in,
+                                                       float *__restrict__ poses_out, double *__restrict__ stamps_out) {
   const int    agent = blockIdx.x, lane = threadIdx.x;
   const float  q0 = poses[agent * 3], q1 = poses[agent * 3 + 1];
+  if (lane < 3) poses_out[agent * 3 + lane] = poses[agent * 3 + lane];
+  if (lane == 3) stamps_out[agent] = stamps_in[agent];
   CylCand     *out = cand + (size_t)agent * SOGM_MAX_CYL_LDS;
   int          kept = 0;
   for (int c0 = 0; c0 < n_cyl; c0 += 64) {
@@ -1403,8 +1408,7 @@ static int update_gt_impl(sogm_ctx *c, const float *cloud_xyz, const int32_t *cl
   const int A = c->n_agents;
   if (fused)
     if (int rc = sogm::join_exchange(c, st)) return rc;  // records may come from an all-gather in flight
-  SOGM_HIP_CHECK(hipMemcpyAsync(c->d_poses, poses, sizeof(float) * 3 * A, hipMemcpyDeviceToDevice, st));
-  SOGM_HIP_CHECK(hipMemcpyAsync(c->d_stamps, stamps, sizeof(double) * A, hipMemcpyDeviceToDevice, st));
+  // (poses / stamps are filed into the context by k_cull_cylinders below)
   if (c->precleared) {
     // the grid was already cleared on the side stream during the previous tick
     int rc = sogm::adopt_preclear(c, st);
@@ -1433,8 +1437,8 @@ static int update_gt_impl(sogm_ctx *c, const float *cloud_xyz, const int32_t *cl
     stamp_wgs     = e && atoi(e) > 0 ? atoi(e) : 256;
   }
   prof_begin(c, SOGM_PROF_STAMP, st);
-  hipLaunchKernelGGL(k_cull_cylinders, dim3(A), dim3(64), 0, st, c->geom, cylinders, n_cyl, c->d_poses,
-                     (CylCand *)c->d_cand, c->d_ncand);
+  hipLaunchKernelGGL(k_cull_cylinders, dim3(A), dim3(64), 0, st, c->geom, cylinders, n_cyl, poses,
+                     (CylCand *)c->d_cand, c->d_ncand, stamps, c->d_poses, c->d_stamps);
   const int words = (((c->geom.V + 31) / 32) + 255) & ~255;  // k_stamp_marks reads 256 words per trip
   if (!c->d_stamp_bits) {
     SOGM_HIP_CHECK(hipMalloc((void **)&c->d_stamp_bits, sizeof(unsigned) * (size_t)words * A));

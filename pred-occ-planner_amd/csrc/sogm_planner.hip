@@ -522,7 +522,9 @@ static int replan_flow(sogm_planner *p, const double *start_pva, const double *g
   const MapView mv   = view_of(c);
   if (p->swarm)
     if (int rc = sogm::join_exchange(c, main)) return rc;
-  hipStream_t sA = p->fstream[0], sC = p->fstream[1], sQ = p->fstream[2], sF = p->fstream[3];
+  // (the searches run on the caller's stream: they are the first kernel of the chain, and a hop to another stream
+  //  costs an event round trip on the critical path)
+  hipStream_t sA = main, sC = p->fstream[1], sQ = p->fstream[2], sF = p->fstream[3];
   // reset the control block in stream order: counters and seg_done to 0, ready lists to -1
   // (one launch instead of five memset nodes: each cost a dispatch gap on the tick's critical path)
   // k_finish_flow writes ok / the record of every agent whose chain completes; an agent whose chain does NOT (a wait
