@@ -366,6 +366,8 @@ __global__ __launch_bounds__(ASTAR_THREADS) void k_astar(
   __shared__ int                s_was_first, s_cur_node, s_base_node, s_n_written;
   __shared__ int                s_ret;
   __shared__ unsigned           s_closed[ASTAR_POOL_MAX / 32];  // bit n: node n is in the closed set
+  __shared__ short              s_new_leader[ASTAR_MAX_INPUTS];  // rank of a new node -> its leader child
+  __shared__ int                s_stop;  // set by the replay: the search ends after this expansion's nodes are written
 
   // the second attempt's pool / hash table follow the first attempts' ([n_agents_total .. 2 n_agents_total))
   const size_t        slot = (size_t)agent + (second ? (size_t)m.n_agents : 0);
@@ -412,6 +414,11 @@ __global__ __launch_bounds__(ASTAR_THREADS) void k_astar(
   int  use_node_num = 0, iter_num = 0, heap_n = 0, n_trace = 0;
   int  ret = NO_PATH, searches = 0, terminal = -1;
   bool is_shot_succ = false, need_pop = false;
+  // The nodes an expansion creates are written to HBM by the lanes WHILE the master already checks the next pop (no
+  // barrier in between).  If that pop is one of them (ids >= prev_base), the master takes its record from the
+  // children's LDS arrays, which stay as they are until the next evaluation.
+  int    prev_base = 0x7fffffff, prev_cur = -1, prev_new_ti = 0;
+  double prev_new_t = 0.0;
   long long tk[6] = {0, 0, 0, 0, 0, 0};  // wall_clock64 ticks (100 MHz): pop, eval, dup, merge, write, n_exp
   long long tmark = 0;
   const bool timed = wsp.dbg != nullptr;  // phase statistics (sogm_debug_astar_stats): s_memrealtime is not free
@@ -427,6 +434,7 @@ __global__ __launch_bounds__(ASTAR_THREADS) void k_astar(
     for (int i = tid; i < ASTAR_POOL_MAX / 32; i += ASTAR_THREADS) s_closed[i] = 0u;
     __syncthreads();
     bool done = false;
+    prev_base = 0x7fffffff;
     if (tid == ASTAR_MASTER) {
       use_node_num = 0;
       iter_num     = 0;
@@ -474,7 +482,21 @@ __global__ __launch_bounds__(ASTAR_THREADS) void k_astar(
           ret = NO_PATH;  // open set empty (:419-422)
         } else {
           cur          = s_heap[0];
-          const Node cn = pool[cur];  // the whole record in one batch of loads
+          Node cn;
+          if (cur >= prev_base) {
+            // created by the expansion that has just been replayed: its record is on its way to HBM; the same data
+            // from the children's arrays (what the write phase stores)
+            const int L = s_new_leader[cur - prev_base], i = s_src[L];
+            for (int q = 0; q < 6; ++q) cn.state[q] = s_cstate[i][q];
+            cn.g        = s_cg[i];
+            cn.f        = s_cf[i];
+            cn.time     = prev_new_t;
+            cn.time_idx = prev_new_ti;
+            pos_to_index(s_cstate[L], center, inv_res, cn.index);
+            cn.parent = prev_cur;
+          } else {
+            cn = pool[cur];  // the whole record in one batch of loads
+          }
           // (what the lanes need of it goes to LDS at once, whether or not the search stops here: every field is
           //  then fetched by the first batch instead of a second round trip after the termination tests)
           for (int i = 0; i < 6; ++i) s_cur_state[i] = cn.state[i];
@@ -573,6 +595,11 @@ __global__ __launch_bounds__(ASTAR_THREADS) void k_astar(
       const bool   first  = s_was_first != 0;
       const double new_t  = s_cur_time + tau;
       const int    new_ti = (int)floor((new_t - time_origin) * inv_tres);
+      const int    my_base = s_base_node, my_cur = s_cur_node;  // (the master rewrites them while the lanes still write)
+      prev_base   = my_base;
+      prev_cur    = my_cur;
+      prev_new_t  = new_t;
+      prev_new_ti = new_ti;
       {
         const int i = tid;
         if (i < n_act) {
@@ -738,6 +765,7 @@ __global__ __launch_bounds__(ASTAR_THREADS) void k_astar(
         const int rev  = __popcll(be & lt) + (wave == 1 ? s_n_ev_w0 : 0);
         if (tid < n_act) {
           s_rank[tid] = (short)rnew;
+          if (my_ev == EV_NEW) s_new_leader[rnew] = (short)tid;
           if (my_ev != EV_NONE) {
             s_events[rev] = (short)tid;
             // event record for the master's replay: {type, operand} + f.  operand = rank of the new node
@@ -827,20 +855,23 @@ __global__ __launch_bounds__(ASTAR_THREADS) void k_astar(
         if (dn) done = true;
         if (lane == 0) {
           s_n_written = n_written;
-          s_n_active  = dn ? -1 : 1;
+          s_stop      = dn ? 1 : 0;
         }
       }
       __syncthreads();
+      if (s_stop) done = true;  // (uniform; read here: the master is about to reuse the control words)
       if (timed) {
         const long long t2 = wall_clock64();
         tk[3] += t2 - tmark;
         tmark = t2;
       }
       // ---------------- all lanes: write the new nodes + their hash entries ----------------
+      // (no barrier behind this phase: the master goes on to the next pop check meanwhile, see prev_base above; the
+      //  lanes' stores are waited for at the barrier that ends that check, before anybody reads a node record)
       if (tid < n_act && s_ev[tid] == EV_NEW && s_rank[tid] < s_n_written) {
         const int L    = tid;
         const int i    = s_src[L];  // child whose data the node ends up with
-        const int node = s_base_node + s_rank[L];
+        const int node = my_base + s_rank[L];
         Node     &pn   = pool[node];
         int       id[3];
         pos_to_index(s_cstate[L], center, inv_res, id);
@@ -850,21 +881,20 @@ __global__ __launch_bounds__(ASTAR_THREADS) void k_astar(
         pn.g = s_cg[i];
         for (int q = 0; q < 3; ++q) pn.input[q] = first ? start_a[q] : s_inputs[i][q];
         pn.duration   = tau;
-        pn.parent     = s_cur_node;
+        pn.parent     = my_cur;
         pn.node_state = IN_OPEN_SET;
         pn.time       = new_t;
         pn.time_idx   = new_ti;
         // :387 quirk — insert(pro_id, pro_node->time, ...): double -> int truncation
         hash_insert(htab, hcap, pack_key(id[0], id[1], id[2], (int)new_t), node);
       }
-      if (s_n_active < 0) done = true;
-      __syncthreads();
       if (timed) {
         const long long t2 = wall_clock64();
         tk[4] += t2 - tmark;
         tk[5] += 1;
       }
     }
+    __syncthreads();  // the last expansion's node records are written
     // broadcast the verdict of this attempt
     if (dropped) break;
     if (tid == ASTAR_MASTER) s_ret = ret;
