@@ -792,7 +792,8 @@ __global__ __launch_bounds__(ASTAR_THREADS) void k_astar(
         int       rt   = __builtin_amdgcn_readfirstlane(ret);
         const int curb = __builtin_amdgcn_readfirstlane(cur);
         bool      dn   = false;
-        const int n_ev = s_n_events;
+        const int n_ev = __builtin_amdgcn_readfirstlane(s_n_events);  // (uniform values in SGPRs: scalar branches)
+        const int baseb = __builtin_amdgcn_readfirstlane(s_base_node);
         int       n_written = 0, n_upd = 0;
         int2      rec  = s_erec[0];
         double    rcf  = s_erec_f[0];
@@ -800,9 +801,9 @@ __global__ __launch_bounds__(ASTAR_THREADS) void k_astar(
           const int    kn  = k + 1 < n_ev ? k + 1 : k;  // next record in flight while this one is replayed
           const int2   nrec = s_erec[kn];
           const double ncf  = s_erec_f[kn];
-          const int    ev = rec.x, opd = rec.y;
+          const int    ev = __builtin_amdgcn_readfirstlane(rec.x), opd = __builtin_amdgcn_readfirstlane(rec.y);
           if (ev == EV_NEW) {
-            const int node = s_base_node + opd;
+            const int node = baseb + opd;
             if (lane == 0) s_f[node] = rcf;
             wave_heap_push(s_f, s_heap, hn, node, rcf, lane);
             unn += 1;
@@ -812,7 +813,7 @@ __global__ __launch_bounds__(ASTAR_THREADS) void k_astar(
               dn = true;
             }
           } else if (ev == EV_DUP) {
-            if (lane == 0) s_f[s_base_node + s_rank[opd]] = rcf;
+            if (lane == 0) s_f[baseb + s_rank[opd]] = rcf;
           } else if (ev == EV_OPEN) {
             if (lane == 0) {
               const int i     = opd;
