@@ -350,7 +350,6 @@ __global__ __launch_bounds__(ASTAR_THREADS) void k_astar(
   __shared__ short              s_events[ASTAR_MAX_INPUTS];  // children with an event, in order
   __shared__ unsigned long long s_ckey[ASTAR_MAX_INPUTS];    // keys of the gate-passing children, compacted
   __shared__ short              s_cidx[ASTAR_MAX_INPUTS];    // their child indices
-  __shared__ int                s_cnt_w[2];
   __shared__ int2               s_erec[ASTAR_MAX_INPUTS];    // events in child order: {type, operand}
   __shared__ double             s_erec_f[ASTAR_MAX_INPUTS];  // ... and the child's f
   __shared__ int                s_upd_node[ASTAR_MAX_INPUTS];  // open nodes lowered by this expansion so far
@@ -704,9 +703,9 @@ __global__ __launch_bounds__(ASTAR_THREADS) void k_astar(
         const unsigned long long lt   = lane ? (~0ull >> (64 - lane)) : 0ull;
         const bool               mg   = tid < n_act && s_gate[tid] != 0;
         const unsigned long long bg   = __ballot(mg);
-        if (lane == 0 && wave < 2) s_cnt_w[wave] = __popcll(bg);
-        __syncthreads();
-        const int crank = __popcll(bg & lt) + (wave == 1 ? s_cnt_w[0] : 0);
+        // (wave 1 counts wave 0's gate-passing children itself, from their flags: no barrier for a hand-over)
+        const unsigned long long bg0  = __ballot(lane < n_act && s_gate[lane] != 0);
+        const int crank = __popcll(bg & lt) + (wave == 1 ? __popcll(bg0) : 0);
         if (mg) {
           s_ckey[crank] = s_key[tid];
           s_cidx[crank] = (short)tid;
