@@ -161,7 +161,9 @@ def main():
     barrier()
     sw.planner.counters(reset=True)
     sw.map.sparse_reset_state()  # restart the reset statistics: the timed region's alone are reported
-    sw.map.set_profiling(True)
+    # only the rated kernel (slot 0, and its two-part form's slot 6) is timed inside the timed region: each timed launch
+    # costs two event records on its stream, and the stamp / overlay / planner launches are on the tick's critical path
+    sw.map.set_profiling(slots=(0, 6))
     t0 = time.perf_counter()
     oks = []
     for _ in range(args.steps):
@@ -204,6 +206,8 @@ def main():
     pva, valid = planner.traj_eval(sw.own, t_start)
     pva = torch.where(valid.bool().unsqueeze(1), pva, sw.hover).contiguous()
     poses_ = pva[:, :3].to(torch.float32).contiguous()
+    sw.map.updateMap(sw.dev["cloud"], sw.dev["cloud_range"], sw.dev["cylinders"], sw.dev["n_cyl"], poses_, stamps)
+    stamp_ms = float(sw.map.profile_read()[1])  # the stamp as the tick runs it (with the mark log)
     if sparse["enabled"]:
         sw.map.set_sparse_reset(False)  # the stand-alone figure below is the DENSE clear's (first ticks, dense writers)
     standalone_clear_ms = []
@@ -215,10 +219,12 @@ def main():
     c_ = sw.planner.generateCorridors(pva, t_start, s_["route"], s_["route_len"])
     q_ = sw.planner.optimize(pva, c_["goal"], c_["polys"], c_["nfaces"], c_["npoly"])
     ms_stage = sw.map.profile_read()
+    ms_stage[1] = stamp_ms
     avg = np.array([float(per_slot[k].mean()) if len(per_slot[k]) else -1.0 for k in range(pop._abi.PROF_N)])
     n_clear = int(len(per_slot[0]))
     if avg[6] > 0:
         avg[0] += avg[6]  # the clear of one grid = two launches (narrow head + full-width rest): one clear = both
+    avg[1:3] = ms_stage[1:3]  # stamp / overlay: the stage pass's launches (not timed inside the timed region)
     avg[3:6] = ms_stage[3:6]  # planner stages: single-stage entry points after the timed region (inside sogm_replan
     #                           they run concurrently on per-group streams and cannot be timed one by one)
     grid_bytes = sw.map.grid_bytes()  # V * T * 4 bytes x agents of this rank = algorithmic bytes / launch

@@ -212,7 +212,7 @@ int sogm_set_body_particles(sogm_ctx *ctx, const double *xyz_host, int n);
  * bench.py for the roofline figure).  Slots: */
 enum {
   SOGM_PROF_CLEAR = 0, /* the grid's reset: k_reset_sectors (sparse) or k_clear_slabs / k_clear_chunks (dense) */
-  SOGM_PROF_STAMP = 1, /* k_stamp_cloud                                      */
+  SOGM_PROF_STAMP = 1, /* k_cull_cylinders + k_stamp_bits + k_stamp_marks    */
   SOGM_PROF_SPLAT = 2, /* k_splat_neighbours                                 */
   SOGM_PROF_ASTAR = 3,
   SOGM_PROF_CORRIDOR = 4,
@@ -221,6 +221,9 @@ enum {
   SOGM_PROF_N = 7
 };
 int sogm_set_profiling(sogm_ctx *ctx, int enable);
+/* The same for a choice of slots (bit k of slot_mask = slot k; 0 = off): every timed launch costs two event records on
+ * its stream, which a tick's critical path notices — bench.py times only the rated kernel inside its timed region. */
+int sogm_set_profiling_slots(sogm_ctx *ctx, int slot_mask);
 /* Synchronises the device, then writes the duration (ms) of the LAST launch of each slot
  * (negative if that slot has not run since profiling was enabled).  host out_ms[SOGM_PROF_N]. */
 int sogm_profile_read(sogm_ctx *ctx, double *out_ms_host);

@@ -118,6 +118,7 @@ PROTOTYPES = {
     "sogm_set_body_particles": (_i, [_vp, C.POINTER(C.c_double), _i]),
     "sogm_set_overlap_clear": (_i, [_vp, _i]),
     "sogm_set_profiling": (_i, [_vp, _i]),
+    "sogm_set_profiling_slots": (_i, [_vp, _i]),
     "sogm_profile_read": (_i, [_vp, C.POINTER(C.c_double)]),
     "sogm_profile_read_all": (_i, [_vp, _i, C.POINTER(C.c_double), _i, C.POINTER(_i)]),
     "sogm_update_gt": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),

@@ -376,7 +376,7 @@ struct sogm_ctx {
   hipStream_t    xstream;
   hipEvent_t     ev_xin, ev_xdone;
   int            exchange_pending;
-  int            profiling;
+  int            profiling;   // bit k: slot k is timed (sogm_set_profiling: all, sogm_set_profiling_slots: a choice)
   // per-slot ring of HIP event pairs: every launch of a profiled kernel since profiling was enabled keeps its own
   // pair, so a run can be timed launch by launch WITHOUT synchronising between launches (sogm_profile_read_all)
   hipEvent_t    *ring[SOGM_PROF_N];    // [SOGM_PROF_RING][2], created lazily
@@ -422,11 +422,11 @@ inline hipEvent_t *prof_pair(sogm_ctx *c, int slot, long long n) {
   return p;
 }
 inline void prof_begin(sogm_ctx *c, int slot, hipStream_t st) {
-  if (!c->profiling) return;
+  if (!((c->profiling >> slot) & 1)) return;
   if (hipEvent_t *p = prof_pair(c, slot, c->ring_n[slot])) (void)hipEventRecord(p[0], st);
 }
 inline void prof_end(sogm_ctx *c, int slot, hipStream_t st) {
-  if (!c->profiling) return;
+  if (!((c->profiling >> slot) & 1)) return;
   if (hipEvent_t *p = prof_pair(c, slot, c->ring_n[slot])) {
     (void)hipEventRecord(p[1], st);
     c->ring_n[slot]++;

@@ -1348,8 +1348,12 @@ int sogm_set_overlap_clear(sogm_ctx *c, int mode) {
 }
 
 int sogm_set_profiling(sogm_ctx *c, int enable) {
-  if (!c) return SOGM_ERR_INVALID_ARG;
-  c->profiling = enable ? 1 : 0;
+  return sogm_set_profiling_slots(c, enable ? (1 << SOGM_PROF_N) - 1 : 0);
+}
+
+int sogm_set_profiling_slots(sogm_ctx *c, int slot_mask) {
+  if (!c || slot_mask < 0 || slot_mask >= (1 << SOGM_PROF_N)) return SOGM_ERR_INVALID_ARG;
+  c->profiling = slot_mask;
   for (int k = 0; k < SOGM_PROF_N; ++k) c->ring_n[k] = 0;
   return SOGM_OK;
 }

@@ -279,7 +279,7 @@ void sogm_planner_destroy(sogm_planner *p) {
 // profiling is on: five s_memrealtime reads per expansion are not free.
 static sogm::AstarWorkspace astar_ws(const sogm_planner *p) {
   sogm::AstarWorkspace w = p->aw;
-  if (!p->map->profiling) w.dbg = nullptr;
+  if (!((p->map->profiling >> SOGM_PROF_ASTAR) & 1)) w.dbg = nullptr;
   return w;
 }
 

@@ -125,7 +125,14 @@ class SogmMap:
                 "total_entries": out[4], "resets": out[5], "entries_per_reset": out[6]}
 
     # ---- profiling (HIP events around each kernel, on the caller's stream) ----
-    def set_profiling(self, on=True):
+    def set_profiling(self, on=True, slots=None):
+        """Time every profiled kernel (on=True), none, or the given slots only (iterable of SOGM_PROF_* indices)."""
+        if slots is not None:
+            mask = 0
+            for k in slots:
+                mask |= 1 << int(k)
+            check(lib().sogm_set_profiling_slots(self._ctx, mask), "sogm_set_profiling_slots")
+            return
         check(lib().sogm_set_profiling(self._ctx, 1 if on else 0), "sogm_set_profiling")
 
     def profile_read(self):
