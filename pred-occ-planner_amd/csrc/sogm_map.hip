@@ -976,6 +976,20 @@ int queue_spare_clears(sogm_ctx *c, hipEvent_t after) {
     const int g  = c->dirty[i];
     int       rc = SOGM_OK;
     if (c->sparse && c->tracked[g] && mark_log(c, g).entries) {
+      static int late = -1;
+      if (late < 0) {
+        // The reset is held back until every agent's corridors are final (the gate the dense clear's wide launch
+        // uses): beside the searches and the corridor stage's point scans its 3 GB of scattered stores cost the
+        // chain 0.8 ms (tick 13.8 -> 12.9 ms); under the QP stage, which lives in LDS, they cost nothing and the
+        // reset itself takes 1.3 instead of 2.4 ms.  SOGM_RESET_LATE=0: start it with the replan.
+        const char *e = getenv("SOGM_RESET_LATE");
+        late          = e ? atoi(e) : 1;
+      }
+      if (late && c->clear_gate) {
+        hipLaunchKernelGGL(k_clear_gate, dim3(1), dim3(64), 0, c->side, c->clear_cursor, ~(size_t)0, c->clear_gate,
+                           c->clear_gate_err, c->clear_gate_target, c->clear_epoch_word, c->clear_epoch);
+        SOGM_HIP_CHECK(hipGetLastError());
+      }
       rc = reset_slot(c, c->side, g, c->pool[g], true);  // the logged sectors only: a fraction of a millisecond
     } else if (head == 0) {
       rc = launch_clear(c, c->side, c->pool[g], false);
