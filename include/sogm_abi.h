@@ -681,6 +681,37 @@ enum {
  * NULL, NULL switches it off (the default).  Pointers are read by later sogm_replan calls.
  */
 int sogm_planner_set_publish(sogm_planner *p, SogmTrajRecord *own_records, SogmTrajRecord *next_table);
+
+/* Pre-stamp.  The tick's critical path is "map update -> chain of the slowest agent", yet an agent's next map centre
+ * depends on its own new record only, which is final when its replan finishes.  With a SogmPrestamp registered (and
+ * publication on, two or three grids per agent, the dataflow replan), sogm_replan also builds the NEXT tick's map —
+ * sogm_tick_inputs' start states, then FakeParticleRiskVoxel::updateMap's stamp (fake_particle_risk_voxel.cpp:80-170)
+ * — agent by agent as their records are published, into the pool's next grid; the next tick then calls
+ * sogm_update_prestamped (the grid swap + the neighbour overlay) instead of sogm_tick_inputs + sogm_update_gt_swarm.
+ * Same cells, same start states.  ps = NULL switches it off; the arrays stay owned by the caller and must not be the
+ * ones the replan in flight reads (start_pva, t_start: double-buffer them).  A replan that could not pre-stamp (no
+ * spare grid ready yet: first ticks) leaves sogm_update_prestamped returning SOGM_ERR_STATE: fall back to the two
+ * calls. */
+typedef struct SogmPrestamp {
+  const float        *cloud_xyz;    /* next update's inputs, as for sogm_update_gt (device) */
+  const int32_t      *cloud_range;
+  const SogmCylinder *cylinders;
+  int32_t             n_cyl;
+  int32_t             reserved_;
+  double              next_stamp;           /* sogm_tick_inputs' stamp of the next tick */
+  double              replan_start_offset;
+  double             *hover_inout;          /* sogm_tick_inputs' in/out and outputs for the next tick (device) */
+  double             *out_now;
+  double             *out_t_start;
+  double             *out_pva;
+} SogmPrestamp;
+int sogm_planner_set_prestamp(sogm_planner *p, const SogmPrestamp *ps);
+/* 1 if the last sogm_replan pre-stamped the next grid (no synchronisation: host-side state). */
+int sogm_prestamp_pending(const sogm_ctx *ctx);
+/* The update of a pre-stamped tick: adopts the grid, its map centres and stamps, then adds the neighbour overlay
+ * (records may be NULL with n_records = 0). */
+int sogm_update_prestamped(sogm_ctx *ctx, const SogmTrajRecord *records, int n_records, const int32_t *ego_ids,
+                           void *stream);
 int sogm_planner_counters(sogm_planner *p, int64_t *out_host, int reset);
 /* sogm_replan() chains its kernels per agent through device-side ready lists ("dataflow replan");
  * a wait that exceeds 3 s marks the tick as failed instead of hanging the GPU: agents whose chain did not complete

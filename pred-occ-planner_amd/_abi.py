@@ -98,6 +98,13 @@ class SogmQpSettings(C.Structure):
                 ("adaptive_rho_interval", C.c_int32), ("residual_fp32", C.c_int32), ("reserved_", C.c_int32)]
 
 
+class SogmPrestamp(C.Structure):
+    _fields_ = [("cloud_xyz", C.c_void_p), ("cloud_range", C.c_void_p), ("cylinders", C.c_void_p),
+                ("n_cyl", C.c_int32), ("reserved_", C.c_int32), ("next_stamp", C.c_double),
+                ("replan_start_offset", C.c_double), ("hover_inout", C.c_void_p), ("out_now", C.c_void_p),
+                ("out_t_start", C.c_void_p), ("out_pva", C.c_void_p)]
+
+
 TRAJ_RECORD_BYTES = C.sizeof(SogmTrajRecord)  # 2064
 CYLINDER_BYTES = C.sizeof(SogmCylinder)  # 96
 
@@ -155,6 +162,9 @@ PROTOTYPES = {
     "sogm_planner_flow_error": (_i, [_vp]),
     "sogm_planner_flow_failures": (_i, [_vp, _vp]),
     "sogm_planner_set_publish": (_i, [_vp, _vp, _vp]),
+    "sogm_planner_set_prestamp": (_i, [_vp, _vp]),
+    "sogm_prestamp_pending": (_i, [_vp]),
+    "sogm_update_prestamped": (_i, [_vp, _vp, _i, _vp, _vp]),
     "sogm_planner_counters": (_i, [_vp, C.POINTER(C.c_int64), _i]),
     "sogm_planner_set_swarm": (_i, [_vp, _vp, _i, _vp, _vp]),
     "sogm_traj_allgather": (_i, [_vp, _vp, _vp, _i, _vp, _vp]),

@@ -1720,31 +1720,6 @@ __global__ __launch_bounds__(64) void k_corridor_finalize(
 // =================================================================================================
 // Called by ALL lanes of a wave (uniform control flow; every value that steers a branch goes through
 // readfirstlane so that the compiler sees a scalar condition): returns the published value, or -1 on failure.
-__device__ inline int flow_wait_slot(int *slot, int *err) {
-  const long long t0 = wall_clock64();
-  for (;;) {
-    // relaxed agent-scope poll (an sc1 load); ONE acquire fence once the value is there (an acquire per poll would
-    // invalidate the CU's L1 every microsecond)
-    const int v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    if (v >= 0) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      return v;
-    }
-    flow_pause();
-    if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0)
-      return -1;
-    if (wall_clock64() - t0 > FLOW_TIMEOUT_TICKS) {
-      if ((threadIdx.x & 63) == 0) atomicExch(err, 2);
-      return -1;
-    }
-  }
-}
-__device__ inline int flow_ticket(int *counter) {  // one ticket per wave, uniform
-  int k = 0;
-  if ((threadIdx.x & 63) == 0) k = atomicAdd(counter, 1);
-  return __builtin_amdgcn_readfirstlane(k);
-}
-
 __global__ __launch_bounds__(64) void k_corridor_flow(MapView m, SogmPlannerParams pp, CorridorWorkspace ws,
                                                       FlowCtl fc, const double *start_pva, const double *t_start,
                                                       const double *route, const int32_t *route_len,
@@ -2143,6 +2118,13 @@ __global__ __launch_bounds__(64) void k_finish_flow(FlowCtl fc, double corridor_
       for (int w = lane; w < W; w += 64) t[w] = src[w];
     }
     if (lane == 0) out_ok[a] = good ? 1 : 0;
+    if (fc.p_ready) {  // the agent's record is final: hand it to the pre-stamp
+      __threadfence();
+      if (lane == 0) {
+        const int r = atomicAdd(&fc.hdr[FLOW_P_READY_N], 1);
+        __hip_atomic_store(fc.p_ready + r, a, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
     if (lane == 0) {
       fc.ts[a * 8 + 6] = wall_clock64();
       if (counters) {

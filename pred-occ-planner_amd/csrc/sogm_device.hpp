@@ -364,6 +364,11 @@ struct sogm_ctx {
   // is covered by its log (false after dense writers — sogm_set_future_risk, sogm_dsp_publish, sogm_grid_ptr —
   // and for a fresh allocation: the next reset of that slot is the dense clear).  A log that overflows makes the
   // reset kernel zero that agent's whole grid.
+  // pre-stamp (sogm_planner_set_prestamp): the replan builds the next tick's map into pool slot prestamp_slot (-1:
+  // none) with the next map centres / stamps in d_poses_next / d_stamps_next; sogm_update_prestamped adopts both
+  float         *d_poses_next;
+  double        *d_stamps_next;
+  int            prestamp_slot;
   int            sparse;           // feature switch (sogm_set_sparse_reset; default on, SOGM_SPARSE_RESET=0 turns it off)
   int            log_cap;          // entries per agent
   unsigned      *d_log[3];         // [A][log_cap] per pool slot (slot 0 = the only grid without a pool), lazy
@@ -469,6 +474,11 @@ inline int cur_slot(const sogm_ctx *c) { return c->n_pool ? c->cur_idx : 0; }
 MarkLog    mark_log(sogm_ctx *c, int slot);
 // zero slot `slot`'s grid on `st`: the logged sectors when the slot is tracked, the dense clear otherwise
 int  reset_slot(sogm_ctx *c, hipStream_t st, int slot, float *grid, bool polite);
+struct PrestampDev;
+// the map's part of the pre-stamp arguments (buffers allocated on first use); a gate launch on `st` that returns when
+// every agent's corridors are final (the planner registered the counter)
+int  prestamp_buffers(sogm_ctx *c, PrestampDev *d);
+int  launch_clear_gate_only(sogm_ctx *c, hipStream_t st);
 }  // namespace sogm
 
 #define SOGM_HIP_CHECK(expr)                    \

@@ -22,6 +22,7 @@
 #include <new>
 
 #include "sogm_device.hpp"
+#include "sogm_planner.hpp"  // FlowCtl: the pre-stamp consumes the dataflow replan's list of finished agents
 
 namespace sogm {
 
@@ -244,16 +245,10 @@ struct CylCand {
 };
 // (The kernel also files the update's poses and stamps into the context's arrays — the later kernels of the update
 //  and the queries read those —, which saves two copy nodes in front of it.)
-__global__ __launch_bounds__(64) void k_cull_cylinders(GridGeom g, const SogmCylinder *__restrict__ cyl, int n_cyl,
-                                                       const float *__restrict__ poses, CylCand *__restrict__ cand,
-                                                       int *__restrict__ n_cand, const double *__restrict__ stamps_in,
-                                                       float *__restrict__ poses_out, double *__restrict__ stamps_out) {
-  const int    agent = blockIdx.x, lane = threadIdx.x;
-  const float  q0 = poses[agent * 3], q1 = poses[agent * 3 + 1];
-  if (lane < 3) poses_out[agent * 3 + lane] = poses[agent * 3 + lane];
-  if (lane == 3) stamps_out[agent] = stamps_in[agent];
-  CylCand     *out = cand + (size_t)agent * SOGM_MAX_CYL_LDS;
-  int          kept = 0;
+__device__ __forceinline__ void cull_agent(const GridGeom &g, const SogmCylinder *__restrict__ cyl, int n_cyl,
+                                           float q0, float q1, CylCand *__restrict__ out, int *__restrict__ n_out,
+                                           int lane) {
+  int kept = 0;
   for (int c0 = 0; c0 < n_cyl; c0 += 64) {
     const int c    = c0 + lane;
     bool      keep = false;
@@ -272,7 +267,17 @@ __global__ __launch_bounds__(64) void k_cull_cylinders(GridGeom g, const SogmCyl
       out[off] = CylCand{(float)cyl[c].x, (float)cyl[c].y, (float)cyl[c].vx, (float)cyl[c].vy, wl, cyl[c].type, c};
     kept += __popcll(m);
   }
-  if (lane == 0) n_cand[agent] = kept;  // > SOGM_MAX_CYL_LDS: the stamp falls back to the full list
+  if (lane == 0) *n_out = kept;  // > SOGM_MAX_CYL_LDS: the stamp falls back to the full list
+}
+__global__ __launch_bounds__(64) void k_cull_cylinders(GridGeom g, const SogmCylinder *__restrict__ cyl, int n_cyl,
+                                                       const float *__restrict__ poses, CylCand *__restrict__ cand,
+                                                       int *__restrict__ n_cand, const double *__restrict__ stamps_in,
+                                                       float *__restrict__ poses_out, double *__restrict__ stamps_out) {
+  const int    agent = blockIdx.x, lane = threadIdx.x;
+  const float  q0 = poses[agent * 3], q1 = poses[agent * 3 + 1];
+  if (lane < 3) poses_out[agent * 3 + lane] = poses[agent * 3 + lane];
+  if (lane == 3) stamps_out[agent] = stamps_in[agent];
+  cull_agent(g, cyl, n_cyl, q0, q1, cand + (size_t)agent * SOGM_MAX_CYL_LDS, n_cand + agent, lane);
 }
 
 // The stamp in two passes (one-wave workgroups, no LDS; the candidates come from k_cull_cylinders through L1 / the
@@ -289,20 +294,14 @@ __global__ __launch_bounds__(64) void k_cull_cylinders(GridGeom g, const SogmCyl
 //                  zeroed for the next update.
 // The set of marked cells is the one the per-point form produced (marks are idempotent, the lookup depends on the
 // voxel only).
-__global__ __launch_bounds__(64) void k_stamp_bits(GridGeom g, const float *__restrict__ cloud,
-                                                   const int32_t *__restrict__ cloud_range,
-                                                   const float *__restrict__ poses, unsigned *__restrict__ bits,
-                                                   int words_per_agent, int agent0) {
-  const int    agent = blockIdx.y + agent0;
-  const int    begin = cloud_range[agent * 2], end = cloud_range[agent * 2 + 1];
-  const float *pose  = poses + agent * 3;
-  const float  p0 = pose[0], p1 = pose[1], p2 = pose[2];
+// points first, first + stride, ... of [begin, end) (lane included in `first`)
+__device__ __forceinline__ void stamp_bits_range(const GridGeom &g, const float *__restrict__ cloud, int first, int end,
+                                                 int stride, float p0, float p1, float p2, unsigned *__restrict__ mask) {
   // PassThrough limits (fake_particle_risk_voxel.cpp:88-104), fp32
   const float lox = p0 - g.rx, hix = p0 + g.rx;
   const float loy = p1 - g.ry, hiy = p1 + g.ry;
   const float loz = p2 - g.rz, hiz = p2 + g.rz;
-  unsigned   *mask = bits + (size_t)agent * words_per_agent;
-  for (int i = begin + blockIdx.x * blockDim.x + threadIdx.x; i < end; i += gridDim.x * blockDim.x) {
+  for (int i = first; i < end; i += stride) {
     const float px = cloud[i * 3], py = cloud[i * 3 + 1], pz = cloud[i * 3 + 2];
     if (!(px >= lox && px <= hix && py >= loy && py <= hiy && pz >= loz && pz <= hiz)) continue;
     const float x = px - p0, y = py - p1, z = pz - p2;
@@ -316,14 +315,24 @@ __global__ __launch_bounds__(64) void k_stamp_bits(GridGeom g, const float *__re
     __hip_atomic_fetch_or(mask + (v >> 5), 1u << (v & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
+__global__ __launch_bounds__(64) void k_stamp_bits(GridGeom g, const float *__restrict__ cloud,
+                                                   const int32_t *__restrict__ cloud_range,
+                                                   const float *__restrict__ poses, unsigned *__restrict__ bits,
+                                                   int words_per_agent, int agent0) {
+  const int    agent = blockIdx.y + agent0;
+  const int    begin = cloud_range[agent * 2], end = cloud_range[agent * 2 + 1];
+  const float *pose  = poses + agent * 3;
+  stamp_bits_range(g, cloud, begin + (int)(blockIdx.x * blockDim.x + threadIdx.x), end, (int)(gridDim.x * blockDim.x),
+                   pose[0], pose[1], pose[2], bits + (size_t)agent * words_per_agent);
+}
 
-__global__ __launch_bounds__(64) void k_stamp_marks(GridGeom g, void *__restrict__ grid,
-                                                    unsigned *__restrict__ bits, int words_per_agent,
-                                                    const SogmCylinder *__restrict__ cyl, int n_cyl,
-                                                    const float *__restrict__ poses,
-                                                    const CylCand *__restrict__ cand_all,
-                                                    const int *__restrict__ n_cand, int agent0, MarkLog lg) {
-  const int      agent  = blockIdx.y + agent0;
+__device__ __forceinline__ void stamp_marks_trips(const GridGeom &g, void *__restrict__ grid,
+                                                  unsigned *__restrict__ bits, int words_per_agent,
+                                                  const SogmCylinder *__restrict__ cyl, int n_cyl,
+                                                  const float *__restrict__ poses,
+                                                  const CylCand *__restrict__ cand_all,
+                                                  const int *__restrict__ n_cand, int agent, const MarkLog &lg,
+                                                  int w_first, int w_stride) {
   const int      kept   = n_cand[agent];
   const bool     culled = kept <= SOGM_MAX_CYL_LDS;
   const int      n_lds  = culled ? kept : 0;
@@ -337,7 +346,7 @@ __global__ __launch_bounds__(64) void k_stamp_marks(GridGeom g, void *__restrict
   // a trip covers 256 mask words (8192 voxels): every lane loads four, the set bits of the whole trip are numbered
   // by a wave scan of the pop counts, and lane t of chunk b takes set bit b + t — dense lanes whatever the
   // occupancy pattern, and neighbouring lanes still hold neighbouring voxels (words_per_agent is padded to 256)
-  for (int w0 = blockIdx.x * 256; w0 < words_per_agent; w0 += gridDim.x * 256) {
+  for (int w0 = w_first; w0 < words_per_agent; w0 += w_stride) {
     uint4 *wp = reinterpret_cast<uint4 *>(mask + w0) + lane;
     uint4  w4 = *wp;
     if ((w4.x | w4.y | w4.z | w4.w) != 0u) *wp = make_uint4(0u, 0u, 0u, 0u);  // consumed: clean for the next update
@@ -442,6 +451,16 @@ __global__ __launch_bounds__(64) void k_stamp_marks(GridGeom g, void *__restrict
       }
     }
   }
+}
+
+__global__ __launch_bounds__(64) void k_stamp_marks(GridGeom g, void *__restrict__ grid,
+                                                    unsigned *__restrict__ bits, int words_per_agent,
+                                                    const SogmCylinder *__restrict__ cyl, int n_cyl,
+                                                    const float *__restrict__ poses,
+                                                    const CylCand *__restrict__ cand_all,
+                                                    const int *__restrict__ n_cand, int agent0, MarkLog lg) {
+  stamp_marks_trips(g, grid, bits, words_per_agent, cyl, n_cyl, poses, cand_all, n_cand, (int)blockIdx.y + agent0, lg,
+                    (int)blockIdx.x * 256, (int)gridDim.x * 256);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -766,6 +785,26 @@ __global__ __launch_bounds__(64) void k_traj_eval(const SogmTrajRecord *__restri
 // One wave per agent: the 2064-byte record is fetched with ONE coalesced batch of loads into LDS (a lane walking
 // n_pieces -> durations -> control points through global memory needs four dependent round trips, which the tail
 // of the streaming clear beside this kernel stretches to a millisecond each), lane 0 evaluates it there.
+// One agent's tick inputs (plan_manager.cpp:169-175): the start state sampled from its executing trajectory at
+// stamp + start_offset, or where it hovers; the map centre of the tick is that position.
+__device__ inline void tick_inputs_agent(const SogmTrajRecord &rec, const double *hov, int i, double stamp,
+                                         double start_offset, double *__restrict__ hover, double *__restrict__ now,
+                                         double *__restrict__ t_start, double *__restrict__ pva,
+                                         float *__restrict__ poses) {
+  const double ts = stamp + start_offset;
+  double       o[9];
+  if (!traj_eval_record(rec, ts, o))
+    for (int k = 0; k < 9; ++k) o[k] = hov[k];
+  for (int k = 0; k < 9; ++k) pva[i * 9 + k] = o[k];
+  for (int k = 0; k < 3; ++k) {
+    hover[i * 9 + k]     = o[k];
+    hover[i * 9 + 3 + k] = 0.0;
+    hover[i * 9 + 6 + k] = 0.0;
+    poses[i * 3 + k]     = (float)o[k];
+  }
+  now[i]     = stamp;
+  t_start[i] = ts;
+}
 __global__ __launch_bounds__(64) void k_tick_inputs(const SogmTrajRecord *__restrict__ own, int n, double stamp,
                                                     double start_offset, double *__restrict__ hover,
                                                     double *__restrict__ now, double *__restrict__ t_start,
@@ -781,19 +820,89 @@ __global__ __launch_bounds__(64) void k_tick_inputs(const SogmTrajRecord *__rest
   if (threadIdx.x < 9) s_hov[threadIdx.x] = hover[i * 9 + threadIdx.x];
   __syncthreads();
   if (threadIdx.x != 0) return;
-  const double ts = stamp + start_offset;
-  double       o[9];
-  if (!traj_eval_record(s_rec, ts, o))
-    for (int k = 0; k < 9; ++k) o[k] = s_hov[k];
-  for (int k = 0; k < 9; ++k) pva[i * 9 + k] = o[k];
-  for (int k = 0; k < 3; ++k) {
-    hover[i * 9 + k]     = o[k];
-    hover[i * 9 + 3 + k] = 0.0;
-    hover[i * 9 + 6 + k] = 0.0;
-    poses[i * 3 + k]     = (float)o[k];
+  tick_inputs_agent(s_rec, s_hov, i, stamp, start_offset, hover, now, t_start, pva, poses);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Pre-stamp: the NEXT tick's map built inside this tick's replan (dataflow replan only).
+// The tick's critical path was "stamp (1.8 ms, nothing else running) -> chain of the slowest agent"; but an agent's
+// next map centre only depends on its OWN new record, which is final the moment k_finish_flow publishes it.  This
+// persistent kernel (launched behind the gate that holds stores back until every agent's corridors are final)
+// takes agents in publication order and, for each: samples the start state of the next tick (k_tick_inputs' rule),
+// culls the cylinders, sets the occupancy bits and writes the marks + log entries into the pool's next grid — split
+// into PS_BITS + PS_MARKS one-wave tickets per agent handed out in order (a ticket only ever waits for lower ones, so
+// any number of resident waves makes progress).  The next update then only adopts the grid and adds the overlay
+// (sogm_update_prestamped).  Same kernels' code, same cells.
+// ------------------------------------------------------------------------------------------------
+#define PS_BITS 16
+#define PS_MARKS 16
+__device__ inline int flow_wait_count(int *p, int target, int *err) {
+  const long long t0 = wall_clock64();
+  for (;;) {
+    const int v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    if (v >= target) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      return 0;
+    }
+    flow_pause();
+    if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0)
+      return -1;
+    if (wall_clock64() - t0 > FLOW_TIMEOUT_TICKS) {
+      if ((threadIdx.x & 63) == 0) atomicExch(err, 6);
+      return -1;
+    }
   }
-  now[i]     = stamp;
-  t_start[i] = ts;
+}
+__global__ __launch_bounds__(64) void k_prestamp_flow(GridGeom g, FlowCtl fc, PrestampDev ps) {
+  __shared__ __attribute__((aligned(16))) SogmTrajRecord s_rec;
+  __shared__ double                                      s_hov[9];
+  const int lane  = threadIdx.x;
+  const int per   = PS_BITS + PS_MARKS;
+  const int total = ps.n_agents * per;
+  for (;;) {
+    const int t = flow_ticket(&fc.hdr[FLOW_P_TICKET]);
+    if (t >= total) break;
+    const int agent = flow_wait_slot(fc.p_ready + t / per, &fc.hdr[FLOW_ERR]);
+    if (agent < 0) break;
+    __threadfence();  // the agent's own record was published before its slot
+    const int s = t % per;
+    if (s == 0) {
+      // next tick's inputs of this agent (k_tick_inputs), then its candidate cylinders around the new centre
+      constexpr int W   = (int)(sizeof(SogmTrajRecord) / 16);
+      const uint4  *src = reinterpret_cast<const uint4 *>(ps.own + agent);
+      uint4        *dst = reinterpret_cast<uint4 *>(&s_rec);
+      for (int w = lane; w < W; w += 64) dst[w] = src[w];
+      if (lane < 9) s_hov[lane] = ps.hover[agent * 9 + lane];
+      __syncthreads();
+      if (lane == 0) {
+        tick_inputs_agent(s_rec, s_hov, agent, ps.stamp, ps.start_offset, ps.hover, ps.now, ps.t_start, ps.pva, ps.poses);
+        ps.stamps[agent] = ps.stamp;
+      }
+      __threadfence();
+      __syncthreads();
+      cull_agent(g, ps.cyl, ps.n_cyl, ps.poses[agent * 3], ps.poses[agent * 3 + 1],
+                 (CylCand *)ps.cand + (size_t)agent * SOGM_MAX_CYL_LDS, ps.n_cand + agent, lane);
+      __threadfence();
+      if (lane == 0) atomicAdd(&fc.stage[agent], 1);
+    }
+    if (s < PS_BITS) {
+      if (flow_wait_count(&fc.stage[agent], 1, &fc.hdr[FLOW_ERR])) break;
+      const float p0 = ps.poses[agent * 3], p1 = ps.poses[agent * 3 + 1], p2 = ps.poses[agent * 3 + 2];
+      const int   begin = ps.cloud_range[agent * 2], end = ps.cloud_range[agent * 2 + 1];
+      stamp_bits_range(g, ps.cloud, begin + s * 64 + lane, end, PS_BITS * 64, p0, p1, p2,
+                       ps.bits + (size_t)agent * ps.words);
+      __threadfence();
+      if (lane == 0) atomicAdd(&fc.stage[agent], 1);
+    } else {
+      if (flow_wait_count(&fc.stage[agent], 1 + PS_BITS, &fc.hdr[FLOW_ERR])) break;
+      stamp_marks_trips(g, ps.grid, ps.bits, ps.words, ps.cyl, ps.n_cyl, ps.poses, (const CylCand *)ps.cand, ps.n_cand, agent, ps.lg,
+                        (s - PS_BITS) * 256, PS_MARKS * 256);
+    }
+  }
+}
+int launch_prestamp_flow(const GridGeom &g, const FlowCtl &fc, const PrestampDev &ps, int n_workgroups, hipStream_t st) {
+  hipLaunchKernelGGL(k_prestamp_flow, dim3(n_workgroups), dim3(64), 0, st, g, fc, ps);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 // End of a tick: latest-wins per drone (particles.cpp:179-190) — a successful replan replaces the agent's record,
 // a failed one keeps the trajectory being executed (plan_manager.cpp:176-196); `all` (optional) is the swarm table of
@@ -909,6 +1018,44 @@ int reset_slot(sogm_ctx *c, hipStream_t st, int slot, float *grid, bool polite) 
     return SOGM_OK;
   }
   return launch_clear(c, st, grid, polite);  // (a complete dense clear restarts the slot's log, see launch_clear)
+}
+
+int launch_clear_gate_only(sogm_ctx *c, hipStream_t st) {
+  if (!c->clear_gate) return SOGM_OK;
+  hipLaunchKernelGGL(k_clear_gate, dim3(1), dim3(64), 0, st, c->clear_cursor, ~(size_t)0, c->clear_gate,
+                     c->clear_gate_err, c->clear_gate_target, c->clear_epoch_word, c->clear_epoch);
+  SOGM_HIP_CHECK(hipGetLastError());
+  return SOGM_OK;
+}
+static int stamp_scratch(sogm_ctx *c, hipStream_t st, int *words_out) {
+  const int A = c->n_agents;
+  if (!c->d_cand) {
+    SOGM_HIP_CHECK(hipMalloc(&c->d_cand, sizeof(CylCand) * SOGM_MAX_CYL_LDS * (size_t)A));
+    SOGM_HIP_CHECK(hipMalloc(&c->d_ncand, sizeof(int) * (size_t)A));
+  }
+  const int words = (((c->geom.V + 31) / 32) + 255) & ~255;  // k_stamp_marks reads 256 words per trip
+  if (!c->d_stamp_bits) {
+    SOGM_HIP_CHECK(hipMalloc((void **)&c->d_stamp_bits, sizeof(unsigned) * (size_t)words * A));
+    SOGM_HIP_CHECK(hipMemsetAsync(c->d_stamp_bits, 0, sizeof(unsigned) * (size_t)words * A, st));
+  }
+  *words_out = words;
+  return SOGM_OK;
+}
+int prestamp_buffers(sogm_ctx *c, PrestampDev *d) {
+  SOGM_HIP_CHECK(hipSetDevice(c->device));
+  if (!c->d_poses_next) {
+    SOGM_HIP_CHECK(hipMalloc(&c->d_poses_next, sizeof(float) * 3 * (size_t)c->n_agents));
+    SOGM_HIP_CHECK(hipMalloc(&c->d_stamps_next, sizeof(double) * (size_t)c->n_agents));
+  }
+  int words = 0;
+  if (int rc = stamp_scratch(c, nullptr, &words)) return rc;
+  d->bits   = c->d_stamp_bits;
+  d->words  = words;
+  d->cand   = c->d_cand;
+  d->n_cand = c->d_ncand;
+  d->poses  = c->d_poses_next;
+  d->stamps = c->d_stamps_next;
+  return SOGM_OK;
 }
 
 int adopt_preclear(sogm_ctx *c, hipStream_t st) {
@@ -1148,6 +1295,7 @@ int sogm_create(const SogmSpec *spec, int n_agents, int device, sogm_ctx **out) 
   c->geom          = make_geom(*spec);
   c->n_agents      = n_agents;
   c->device        = device;
+  c->prestamp_slot = -1;
   {
     const char *e = getenv("SOGM_SPARSE_RESET");
     c->sparse     = e ? atoi(e) != 0 : 1;
@@ -1193,6 +1341,8 @@ void sogm_destroy(sogm_ctx *c) {
     if (c->d_log_n[i]) (void)hipFree(c->d_log_n[i]);
   }
   if (c->d_reset_stat) (void)hipFree(c->d_reset_stat);
+  if (c->d_poses_next) (void)hipFree(c->d_poses_next);
+  if (c->d_stamps_next) (void)hipFree(c->d_stamps_next);
   if (c->d_poses) (void)hipFree(c->d_poses);
   if (c->d_stamps) (void)hipFree(c->d_stamps);
   if (c->clear_cursor) (void)hipFree(c->clear_cursor);
@@ -1299,6 +1449,7 @@ int sogm_set_overlap_clear(sogm_ctx *c, int mode) {
     (void)hipDeviceSynchronize();
     c->precleared = 0;
   }
+  c->prestamp_slot = -1;  // (a pre-stamped spare is dirty like the others: reset below)
   const int want = mode >= 2 ? mode : 1;  // grids in the pool
   // the current grid stays where it is (slot cur_idx); spares are added / released around it
   if (c->n_pool == 0) {
@@ -1427,10 +1578,18 @@ static int update_gt_impl(sogm_ctx *c, const float *cloud_xyz, const int32_t *cl
   if (fused)
     if (int rc = sogm::join_exchange(c, st)) return rc;  // records may come from an all-gather in flight
   // (poses / stamps are filed into the context by k_cull_cylinders below)
+  // A grid the previous replan pre-stamped is not what this call builds (other inputs): it is the front of the ready
+  // queue, i.e. the grid adopted below — its marks are in its log, so it is reset again before the stamp.
+  const int stale = c->prestamp_slot;
+  c->prestamp_slot = -1;
   if (c->precleared) {
     // the grid was already cleared on the side stream during the previous tick
     int rc = sogm::adopt_preclear(c, st);
     if (rc) return rc;
+    if (stale >= 0 && sogm::cur_slot(c) == stale) {
+      rc = sogm::reset_slot(c, st, stale, c->d_grid, false);
+      if (rc) return rc;
+    }
   } else {
     int rc = clear_grid(c, st);
     if (rc) return rc;
@@ -1445,10 +1604,8 @@ static int update_gt_impl(sogm_ctx *c, const float *cloud_xyz, const int32_t *cl
     }
   }
   // candidate cylinders per agent, then one-wave workgroups stride over each agent's cloud range
-  if (!c->d_cand) {
-    SOGM_HIP_CHECK(hipMalloc(&c->d_cand, sizeof(CylCand) * SOGM_MAX_CYL_LDS * (size_t)A));
-    SOGM_HIP_CHECK(hipMalloc(&c->d_ncand, sizeof(int) * (size_t)A));
-  }
+  int words = 0;
+  if (int rc = sogm::stamp_scratch(c, st, &words)) return rc;
   static int stamp_wgs = -1;
   if (stamp_wgs < 0) {
     const char *e = getenv("SOGM_STAMP_WGS");  // one-wave workgroups per agent (tuning aid)
@@ -1457,11 +1614,6 @@ static int update_gt_impl(sogm_ctx *c, const float *cloud_xyz, const int32_t *cl
   prof_begin(c, SOGM_PROF_STAMP, st);
   hipLaunchKernelGGL(k_cull_cylinders, dim3(A), dim3(64), 0, st, c->geom, cylinders, n_cyl, poses,
                      (CylCand *)c->d_cand, c->d_ncand, stamps, c->d_poses, c->d_stamps);
-  const int words = (((c->geom.V + 31) / 32) + 255) & ~255;  // k_stamp_marks reads 256 words per trip
-  if (!c->d_stamp_bits) {
-    SOGM_HIP_CHECK(hipMalloc((void **)&c->d_stamp_bits, sizeof(unsigned) * (size_t)words * A));
-    SOGM_HIP_CHECK(hipMemsetAsync(c->d_stamp_bits, 0, sizeof(unsigned) * (size_t)words * A, st));
-  }
   hipLaunchKernelGGL(k_stamp_bits, dim3(stamp_wgs, A), dim3(64), 0, st, c->geom, cloud_xyz, cloud_range, c->d_poses,
                      c->d_stamp_bits, words, 0);
   const sogm::MarkLog lg = sogm::mark_log(c, sogm::cur_slot(c));
@@ -1502,6 +1654,37 @@ int sogm_update_gt_swarm(sogm_ctx *c, const float *cloud_xyz, const int32_t *clo
   return update_gt_impl(c, cloud_xyz, cloud_range, cylinders, n_cyl, poses, stamps, records, n_records, ego_ids,
                         true, (hipStream_t)stream);
 }
+
+int sogm_update_prestamped(sogm_ctx *c, const SogmTrajRecord *records, int n_records, const int32_t *ego_ids,
+                           void *stream) {
+  if (!c || n_records < 0 || (n_records > 0 && (!records || !ego_ids))) return SOGM_ERR_INVALID_ARG;
+  if (c->prestamp_slot < 0 || c->n_ready <= 0 || c->ready[0] != c->prestamp_slot || !c->precleared) {
+    sogm::set_error_text("sogm_update_prestamped: the previous sogm_replan did not pre-stamp the next grid");
+    return SOGM_ERR_STATE;
+  }
+  if (n_records > 0 && (!c->d_body || c->n_body <= 0)) return SOGM_ERR_STATE;
+  SOGM_HIP_CHECK(hipSetDevice(c->device));
+  hipStream_t st = (hipStream_t)stream;
+  if (n_records > 0)
+    if (int rc = sogm::join_exchange(c, st)) return rc;  // records may come from an all-gather in flight
+  if (int rc = sogm::adopt_preclear(c, st)) return rc;   // the pre-stamped grid becomes the current one
+  std::swap(c->d_poses, c->d_poses_next);                // its map centres and stamps with it
+  std::swap(c->d_stamps, c->d_stamps_next);
+  c->prestamp_slot = -1;
+  if (n_records > 0) {
+    const long long total = (long long)c->n_agents * n_records * c->spec.T;
+    prof_begin(c, SOGM_PROF_SPLAT, st);
+    hipLaunchKernelGGL(k_splat_neighbours, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, c->geom,
+                       (void *)c->d_grid, records, n_records, ego_ids, c->d_poses, c->d_stamps, c->d_body, c->n_body,
+                       c->n_agents, 0, sogm::mark_log(c, sogm::cur_slot(c)));
+    prof_end(c, SOGM_PROF_SPLAT, st);
+    SOGM_HIP_CHECK(hipGetLastError());
+  }
+  c->updated = 1;
+  return SOGM_OK;
+}
+
+int sogm_prestamp_pending(const sogm_ctx *c) { return c && c->prestamp_slot >= 0 ? 1 : 0; }
 
 int sogm_project_neighbours(sogm_ctx *c, const SogmTrajRecord *records, int n_records,
                             const int32_t *ego_ids, void *stream) {

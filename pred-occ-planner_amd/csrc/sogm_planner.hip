@@ -200,12 +200,17 @@ int sogm_planner_create(sogm_ctx *map, const SogmAstarParams *astar, const SogmP
   {
     const char *ef = getenv("SOGM_FLOW");
     p->flow        = ef ? atoi(ef) != 0 : 1;
-    if (e == hipSuccess) e = hipMalloc((void **)&p->d_flow, sizeof(int) * (FLOW_HDR + 4 * (size_t)A));
+    // layout: header, seg_done[A], stage[A] (zeroed per replan), then the four ready lists (-1 per replan)
+    if (e == hipSuccess) e = hipMalloc((void **)&p->d_flow, sizeof(int) * (FLOW_HDR + 6 * (size_t)A));
     p->fc.hdr      = p->d_flow;
     p->fc.seg_done = p->d_flow + FLOW_HDR;
-    p->fc.a_ready  = p->fc.seg_done + A;
+    p->fc.stage    = p->fc.seg_done + A;
+    p->fc.a_ready  = p->fc.stage + A;
     p->fc.q_ready  = p->fc.a_ready + A;
     p->fc.f_ready  = p->fc.q_ready + A;
+    p->fc.p_ready  = p->fc.f_ready + A;
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&p->pstream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_pdone, hipEventDisableTiming);
     if (e == hipSuccess) e = hipMalloc((void **)&p->d_flow_ts, sizeof(long long) * 8 * (size_t)A);
     if (e == hipSuccess) e = hipMemset(p->d_flow_ts, 0, sizeof(long long) * 8 * (size_t)A);
     p->fc.ts = p->d_flow_ts;
@@ -271,6 +276,11 @@ void sogm_planner_destroy(sogm_planner *p) {
     if (p->ev_fdone[k]) (void)hipEventDestroy(p->ev_fdone[k]);
   }
   if (p->ev_gate) (void)hipEventDestroy(p->ev_gate);
+  if (p->pstream) {
+    (void)hipStreamSynchronize(p->pstream);
+    (void)hipStreamDestroy(p->pstream);
+  }
+  if (p->ev_pdone) (void)hipEventDestroy(p->ev_pdone);
   if (p->h_flow_fail) (void)hipHostFree(p->h_flow_fail);
   delete p;
 }
@@ -429,7 +439,7 @@ int sogm_debug_flow_peek(sogm_planner *p, int *out_host, int n) {
   if (!p || !out_host || n < 0) return SOGM_ERR_INVALID_ARG;
   static hipStream_t peek = nullptr;
   if (!peek) SOGM_HIP_CHECK(hipStreamCreateWithFlags(&peek, hipStreamNonBlocking));
-  const int nf = FLOW_HDR + 4 * p->map->n_agents;
+  const int nf = FLOW_HDR + 6 * p->map->n_agents;
   SOGM_HIP_CHECK(hipMemcpyAsync(out_host, p->d_flow, sizeof(int) * (size_t)(n < nf ? n : nf), hipMemcpyDeviceToHost, peek));
   if (n > nf)  // followed by d_safe (progress markers in debug builds)
     SOGM_HIP_CHECK(hipMemcpyAsync(out_host + nf, p->d_safe, sizeof(int) * (size_t)(n - nf), hipMemcpyDeviceToHost, peek));
@@ -475,6 +485,30 @@ int sogm_planner_set_publish(sogm_planner *p, SogmTrajRecord *own_records, SogmT
   if (!p || (next_table && !own_records)) return SOGM_ERR_INVALID_ARG;
   p->pub_own   = own_records;
   p->pub_table = next_table;
+  return SOGM_OK;
+}
+
+int sogm_planner_set_prestamp(sogm_planner *p, const SogmPrestamp *ps) {
+  if (!p) return SOGM_ERR_INVALID_ARG;
+  if (!ps) {
+    p->ps_on = 0;
+    return SOGM_OK;
+  }
+  if (!ps->cloud_xyz || !ps->cloud_range || ps->n_cyl < 0 || (ps->n_cyl > 0 && !ps->cylinders) || !ps->hover_inout ||
+      !ps->out_now || !ps->out_t_start || !ps->out_pva)
+    return SOGM_ERR_INVALID_ARG;
+  std::memset(&p->ps, 0, sizeof(p->ps));
+  p->ps.cloud        = ps->cloud_xyz;
+  p->ps.cloud_range  = ps->cloud_range;
+  p->ps.cyl          = ps->cylinders;
+  p->ps.n_cyl        = ps->n_cyl;
+  p->ps.stamp        = ps->next_stamp;
+  p->ps.start_offset = ps->replan_start_offset;
+  p->ps.hover        = ps->hover_inout;
+  p->ps.now          = ps->out_now;
+  p->ps.t_start      = ps->out_t_start;
+  p->ps.pva          = ps->out_pva;
+  p->ps_on           = 1;
   return SOGM_OK;
 }
 
@@ -530,7 +564,7 @@ static int replan_flow(sogm_planner *p, const double *start_pva, const double *g
   // k_finish_flow writes ok / the record of every agent whose chain completes; an agent whose chain does NOT (a wait
   // timed out, FLOW_ERR) must report ok = 0 and an empty record, not the previous tick's
   const bool spec = p->spec_astar != 0;
-  hipLaunchKernelGGL(k_flow_reset, dim3(64), dim3(256), 0, main, p->d_flow, FLOW_HDR + A, p->fc.a_ready, 3 * A,
+  hipLaunchKernelGGL(k_flow_reset, dim3(64), dim3(256), 0, main, p->d_flow, FLOW_HDR + 2 * A, p->fc.a_ready, 4 * A,
                      spec ? p->aw.verdict : nullptr, A, out_ok, A, reinterpret_cast<int *>(out_records),
                      (int)(sizeof(SogmTrajRecord) / sizeof(int)) * A,
                      c->overlap >= 2 && c->clear_gate ? c->clear_epoch_word : nullptr,
@@ -582,11 +616,40 @@ static int replan_flow(sogm_planner *p, const double *start_pva, const double *g
     return SOGM_ERR_HIP;
   }
   prof_end(c, SOGM_PROF_QP, sQ);
-  if (sogm::launch_finish_flow(p->fc, A, wg_f, p->pp.corridor_tau, p->d_ret, p->d_npoly, p->d_status, p->d_cpts,
+  sogm::FlowCtl fcf = p->fc;
+  if (!(p->ps_on && c->overlap >= 2 && c->n_ready > 0 && p->pub_own && c->clear_gate)) fcf.p_ready = nullptr;
+  if (sogm::launch_finish_flow(fcf, A, wg_f, p->pp.corridor_tau, p->d_ret, p->d_npoly, p->d_status, p->d_cpts,
                                p->swarm, p->n_swarm, p->swarm_ego, p->swarm_now, t_start, drone_ids, out_records,
                                out_ok, p->d_safe, p->cw.counters, sF, p->pub_own, p->pub_table)) {
     sogm::set_error("sogm_replan: k_finish_flow", hipGetLastError());
     return SOGM_ERR_HIP;
+  }
+  // pre-stamp (sogm_planner_set_prestamp): the next tick's map, agent by agent as their records are published, into
+  // the pool's next grid — behind the gate that keeps store streams away from the searches and point scans, and
+  // behind that grid's reset
+  c->prestamp_slot = -1;
+  if (p->ps_on && c->overlap >= 2 && c->n_ready > 0 && p->pub_own && c->clear_gate) {
+    const int nxt = c->ready[0];
+    sogm::PrestampDev d = p->ps;
+    d.grid     = (void *)c->pool[nxt];
+    d.lg       = sogm::mark_log(c, nxt);
+    d.own      = p->pub_own;
+    d.poses    = c->d_poses_next;
+    d.stamps   = c->d_stamps_next;
+    d.n_agents = A;
+    if (int rc = sogm::prestamp_buffers(c, &d)) return rc;
+    SOGM_HIP_CHECK(hipStreamWaitEvent(p->pstream, p->ev_in, 0));
+    SOGM_HIP_CHECK(hipStreamWaitEvent(p->pstream, c->pool_ev[nxt], 0));
+    if (int rc = sogm::launch_clear_gate_only(c, p->pstream)) return rc;
+    int wg_p = 4 * n_cu;
+    if (const char *e = getenv("SOGM_PRESTAMP_WGS")) wg_p = atoi(e) > 0 ? atoi(e) : wg_p;
+    if (sogm::launch_prestamp_flow(c->geom, p->fc, d, wg_p, p->pstream)) {
+      sogm::set_error("sogm_replan: k_prestamp_flow", hipGetLastError());
+      return SOGM_ERR_HIP;
+    }
+    SOGM_HIP_CHECK(hipEventRecord(p->ev_pdone, p->pstream));
+    SOGM_HIP_CHECK(hipStreamWaitEvent(main, p->ev_pdone, 0));
+    c->prestamp_slot = nxt;
   }
   for (int k = 0; k < 4; ++k) {
     SOGM_HIP_CHECK(hipEventRecord(p->ev_fdone[k], p->fstream[k]));

@@ -36,8 +36,10 @@ struct CorridorWorkspace {
 // kernels of one tick hand agents to each other through ready lists instead of stream order.
 //   hdr[FLOW_*] counters; seg_done[A] finished segment slots per agent; a_ready[A] agents in A* completion order;
 //   q_ready[A] agents in corridor completion order (entries are -1 until published).
+//   f_ready[A] agents in QP completion order; p_ready[A] agents whose record is published (k_finish_flow done), the
+//   pre-stamp's input; stage[A] per-agent progress counter of the pre-stamp (0 at the start of a replan).
 enum { FLOW_A_RESIDENT = 0, FLOW_A_READY_N = 1, FLOW_C_TICKET = 2, FLOW_Q_READY_N = 3, FLOW_Q_TICKET = 4,
-       FLOW_ERR = 5, FLOW_F_READY_N = 6, FLOW_F_TICKET = 7, FLOW_HDR = 8 };
+       FLOW_ERR = 5, FLOW_F_READY_N = 6, FLOW_F_TICKET = 7, FLOW_P_READY_N = 8, FLOW_P_TICKET = 9, FLOW_HDR = 10 };
 #define FLOW_TIMEOUT_TICKS 300000000LL  // 3 s of the 100 MHz wall clock: a stuck tick fails instead of hanging
 // One polling interval of the waiting loops of the dataflow replan.  A poll is a device-scope load that goes to the
 // memory side (the L2s are per XCD) while the SOGM clear streams beside it; the stages waited for take hundreds of
@@ -60,7 +62,57 @@ struct FlowCtl {
   long long *ts;  // [A][8] wall_clock64 stamps (100 MHz): 0 A* start, 1 A* done, 2 first corridor item taken,
                   //        3 corridors final, 4 QP start, 5 QP done, 6 finished, 7 A* workgroup resident
                   //        (diagnostics, always written)
+  int *p_ready;   // [A] agents in publication order (null: nobody consumes it)
+  int *stage;     // [A]
 };
+#ifdef __HIPCC__
+// hand-over primitives of the persistent kernels: a ticket per wave, a bounded wait for a published slot
+__device__ inline int flow_wait_slot(int *slot, int *err) {
+  const long long t0 = wall_clock64();
+  for (;;) {
+    // relaxed agent-scope poll (an sc1 load); ONE acquire fence once the value is there (an acquire per poll would
+    // invalidate the CU's L1 every microsecond)
+    const int v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    if (v >= 0) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      return v;
+    }
+    flow_pause();
+    if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0)
+      return -1;
+    if (wall_clock64() - t0 > FLOW_TIMEOUT_TICKS) {
+      if ((threadIdx.x & 63) == 0) atomicExch(err, 2);
+      return -1;
+    }
+  }
+}
+__device__ inline int flow_ticket(int *counter) {  // one ticket per wave, uniform
+  int k = 0;
+  if ((threadIdx.x & 63) == 0) k = atomicAdd(counter, 1);
+  return __builtin_amdgcn_readfirstlane(k);
+}
+#endif
+// Arguments of the pre-stamp kernel (csrc/sogm_map.hip, k_prestamp_flow): the next tick's update inputs, the grid and
+// mark log it builds into, and where the next tick's start states go.
+struct PrestampDev {
+  void                 *grid;         // the pool's next grid (all agents)
+  unsigned             *bits;         // [A][words] occupancy bits of slice 0
+  int                   words;
+  const float          *cloud;
+  const int32_t        *cloud_range;
+  const SogmCylinder   *cyl;
+  int                   n_cyl;
+  void                 *cand;         // [A][1024] CylCand
+  int                  *n_cand;       // [A]
+  MarkLog               lg;
+  const SogmTrajRecord *own;          // the records the replan publishes into
+  double                stamp, start_offset;
+  double               *hover, *now, *t_start, *pva;  // sogm_tick_inputs' outputs for the next tick
+  float                *poses;        // the context's NEXT poses / stamps (swapped in by sogm_update_prestamped)
+  double               *stamps;
+  int                   n_agents;
+};
+int launch_prestamp_flow(const GridGeom &g, const FlowCtl &fc, const PrestampDev &ps, int n_workgroups, hipStream_t st);
 
 // ParticleATC::isSafeAfterOpt for agents [agent0, agent0 + n_agents): out_safe[a] = 1 / 0
 int launch_deconflict(int n_agents, const double *cpts, const int32_t *npoly, const SogmTrajRecord *rec,
@@ -160,6 +212,10 @@ struct sogm_planner {
   long long     *d_flow_ts;   // [A][8]
   sogm::FlowCtl  fc;
   hipStream_t    fstream[4];  // A*, corridors, QP, finish
+  hipStream_t    pstream;     // pre-stamp (sogm_planner_set_prestamp)
+  hipEvent_t     ev_pdone;
+  sogm::PrestampDev ps;       // the host's part of the pre-stamp arguments
+  int            ps_on;
   hipEvent_t     ev_gate, ev_fdone[4];
   int           *d_epoch;      // device word: the clear epoch of the replan in flight (sogm_ctx::clear_epoch_word)
   int           *h_flow_fail;  // pinned, device-visible: {last FLOW_ERR code, ticks that failed} (k_flow_report)

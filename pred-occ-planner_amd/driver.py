@@ -232,6 +232,19 @@ class HipCompute:
             self.map.updateMap(d["cloud"], d["cloud_range"], d["cylinders"], d["n_cyl"], poses, now)
             self.map.addOtherAgents(all_records, A_tot, self.ego_ids)
 
+    def set_prestamp(self, next_stamp, hover, now, t_start, pva):
+        """the replan about to run also builds the NEXT tick's map and start states (sogm_planner_set_prestamp)"""
+        d = self.dev
+        self.planner.setPrestamp(d["cloud"], d["cloud_range"], d["cylinders"], d["n_cyl"], next_stamp,
+                                 REPLAN_START_TIME, hover, now, t_start, pva)
+
+    def prestamp_pending(self):
+        return self.map.prestamp_pending()
+
+    def update_prestamped(self, all_records, A_tot):
+        """the update of a pre-stamped tick: grid swap + neighbour overlay"""
+        self.map.updatePrestamped(all_records, A_tot, self.ego_ids)
+
     def replan(self, pva, goals, t_start, new, ok):
         # a dataflow replan whose device-side waits timed out reports ok = 0 for the agents it could not finish and
         # counts the tick in pinned memory: a flight must not go on merging records past such a tick
@@ -254,7 +267,7 @@ class HipCompute:
 class SwarmTick:
     def __init__(self, grid="cfg2", agents_per_rank=None, rank=0, world=1, device=0, seed=0x5069,
                  spec=None, scene=None, dist=None, overlap_clear=True, deconflict=True, fsm=False,
-                 double_buffer=None, grids=None, compute=None, exchange=None):
+                 double_buffer=None, grids=None, compute=None, exchange=None, prestamp=None):
         self.rank, self.world, self.dist = rank, world, dist
         self.spec = spec if spec is not None else config.make_spec(grid)
         self.A_loc = agents_per_rank if agents_per_rank is not None else config.AGENTS.get(grid, 4)
@@ -289,6 +302,12 @@ class SwarmTick:
         # finishing kernel fills the other for the next tick
         self.publish = os.environ.get("SOGM_PUBLISH", "1") != "0" and hasattr(c, "set_publish") and not fsm
         self._tables = [self.all, torch.zeros_like(self.all)] if self.publish else None
+        # pre-stamp (SOGM_PRESTAMP=1): every replan also builds the next tick's map and start states, agent by agent as
+        # their records are published; the tick's inputs are double-buffered (the replan in flight reads one set)
+        want = (os.environ.get("SOGM_PRESTAMP", "0") != "0") if prestamp is None else bool(prestamp)
+        self.prestamp = want and self.publish and hasattr(c, "set_prestamp") and self.overlap_mode >= 2
+        self._alt = (torch.zeros_like(self.pva), torch.zeros_like(self.t_start), torch.zeros_like(self.now)) \
+            if self.prestamp else None
         # optional closed-loop mode: every agent runs the reference's FiniteStateMachine (step_fsm)
         self.fsm = fsm
         self.status = torch.full((self.A_loc,), FSM_NEW_PLAN, dtype=torch.int32, device=d)
@@ -367,14 +386,22 @@ class SwarmTick:
             return self.step_fsm()
         stamp = self.t0 + self.tick * TICK_PERIOD
         c = self.compute
-        c.tick_inputs(self.own, stamp, self.hover, self.now, self.t_start, self.pva, self.poses)
-        c.update_map(self.poses, self.now, self.all, self.A_tot)
+        if self.prestamp and c.prestamp_pending():
+            # the previous replan built this tick's map and start states (into the alternate buffers)
+            (self.pva, self.t_start, self.now), self._alt = self._alt, (self.pva, self.t_start, self.now)
+            c.update_prestamped(self.all, self.A_tot)
+        else:
+            c.tick_inputs(self.own, stamp, self.hover, self.now, self.t_start, self.pva, self.poses)
+            c.update_map(self.poses, self.now, self.all, self.A_tot)
         if self.publish:
             local = not self.exchange.active and not self.distributed
             nxt = self._tables[(self.tick + 1) & 1] if local else None
             c.set_publish(self.own, nxt)
             if self.deconflict:
                 c.set_swarm(self.all, self.A_tot, self.now)
+            if self.prestamp:
+                c.set_prestamp(self.t0 + (self.tick + 1) * TICK_PERIOD, self.hover, self._alt[2], self._alt[1],
+                               self._alt[0])
             c.replan(self.pva, self.goals, self.t_start, self.new, self.ok)
             if local:
                 self.all = nxt   # what every agent executes after this tick: the next tick's table

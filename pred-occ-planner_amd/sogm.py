@@ -172,6 +172,16 @@ class SogmMap:
                                          stamps.data_ptr(), records.data_ptr() if n_records else None, n_records,
                                          ego_ids.data_ptr(), _stream()), "sogm_update_gt_swarm")
 
+    def prestamp_pending(self):
+        """True if the last replan pre-stamped the next grid (sogm_planner_set_prestamp)."""
+        return bool(lib().sogm_prestamp_pending(self._ctx))
+
+    def updatePrestamped(self, records, n_records, ego_ids):
+        """The update of a pre-stamped tick: grid swap + neighbour overlay (sogm_update_prestamped)."""
+        check(lib().sogm_update_prestamped(self._ctx, records.data_ptr() if records is not None else None, n_records,
+                                           ego_ids.data_ptr() if ego_ids is not None else None, _stream()),
+              "sogm_update_prestamped")
+
     def addOtherAgents(self, records, n_records, ego_ids):
         """RiskBase::addOtherAgents / fake_particle_risk_voxel.cpp:178-218."""
         check(lib().sogm_project_neighbours(self._ctx, records.data_ptr(), n_records,

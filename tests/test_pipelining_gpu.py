@@ -126,3 +126,35 @@ def test_publication_inside_the_replan_equals_the_merge_launch(monkeypatch):
         assert np.array_equal(x[0], y[0]), k
         assert np.array_equal(x[1], y[1]), k
         assert np.array_equal(x[2], y[2]), k
+
+
+@pytest.mark.parametrize("grids", [2, 3])
+def test_prestamp_flight_equals_the_plain_flight(pop, grids):
+    """Pre-stamp (sogm_planner_set_prestamp): every replan also builds the NEXT tick's start states and map, agent by
+    agent as their records are published, into the pool's next grid; the next tick only swaps the grid in and adds
+    the overlay.  Per-tick ok flags, the start states each tick planned from, the final records and every cell of
+    the final grids equal the flight that runs sogm_tick_inputs + sogm_update_gt_swarm at the start of each tick."""
+    import importlib
+    import numpy as np
+    driver = importlib.import_module("pred-occ-planner_amd.driver")
+    out = []
+    for pre in (True, False):
+        sw = driver.SwarmTick("parity", 6, grids=grids, prestamp=pre)
+        assert sw.prestamp == pre
+        oks, pvas, used = [], [], 0
+        for _ in range(8):
+            pending = pre and sw.compute.prestamp_pending()
+            used += int(pending)
+            oks.append(sw.step().cpu().numpy().copy())
+            pvas.append(sw.pva.cpu().numpy().copy())
+        table = sw.records_all().cpu().numpy().copy()
+        own = sw.own.cpu().numpy().copy()
+        grids_now = [sw.map.download(a) for a in range(6)]
+        out.append((oks, pvas, table, own, grids_now, used))
+        sw.close()
+    (oa, pa, ta, wa, ga, ua), (ob, pb, tb, wb, gb, ub) = out
+    assert ua >= 5 and ub == 0          # the first ticks have no spare grid ready yet: they fall back
+    assert all(np.array_equal(x, y) for x, y in zip(oa, ob)) and sum(int(x.sum()) for x in oa) > 0
+    assert all(np.array_equal(x, y) for x, y in zip(pa, pb))
+    assert np.array_equal(ta, tb) and np.array_equal(wa, wb)
+    assert all(np.array_equal(x, y) for x, y in zip(ga, gb))
