@@ -704,6 +704,7 @@ typedef struct SogmPrestamp {
   double             *out_now;
   double             *out_t_start;
   double             *out_pva;
+  float              *out_poses;            /* the next map centres, [A][3] (may be NULL: the context keeps its own) */
 } SogmPrestamp;
 int sogm_planner_set_prestamp(sogm_planner *p, const SogmPrestamp *ps);
 /* 1 if the last sogm_replan pre-stamped the next grid (no synchronisation: host-side state). */

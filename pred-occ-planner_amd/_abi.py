@@ -102,7 +102,7 @@ class SogmPrestamp(C.Structure):
     _fields_ = [("cloud_xyz", C.c_void_p), ("cloud_range", C.c_void_p), ("cylinders", C.c_void_p),
                 ("n_cyl", C.c_int32), ("reserved_", C.c_int32), ("next_stamp", C.c_double),
                 ("replan_start_offset", C.c_double), ("hover_inout", C.c_void_p), ("out_now", C.c_void_p),
-                ("out_t_start", C.c_void_p), ("out_pva", C.c_void_p)]
+                ("out_t_start", C.c_void_p), ("out_pva", C.c_void_p), ("out_poses", C.c_void_p)]
 
 
 TRAJ_RECORD_BYTES = C.sizeof(SogmTrajRecord)  # 2064

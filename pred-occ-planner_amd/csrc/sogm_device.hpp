@@ -475,10 +475,8 @@ MarkLog    mark_log(sogm_ctx *c, int slot);
 // zero slot `slot`'s grid on `st`: the logged sectors when the slot is tracked, the dense clear otherwise
 int  reset_slot(sogm_ctx *c, hipStream_t st, int slot, float *grid, bool polite);
 struct PrestampDev;
-// the map's part of the pre-stamp arguments (buffers allocated on first use); a gate launch on `st` that returns when
-// every agent's corridors are final (the planner registered the counter)
+// the map's part of the pre-stamp arguments (buffers allocated on first use)
 int  prestamp_buffers(sogm_ctx *c, PrestampDev *d);
-int  launch_clear_gate_only(sogm_ctx *c, hipStream_t st);
 }  // namespace sogm
 
 #define SOGM_HIP_CHECK(expr)                    \

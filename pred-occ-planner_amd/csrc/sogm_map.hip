@@ -98,6 +98,12 @@ __global__ void k_clear_gate(const unsigned long long *__restrict__ cursor, size
   }
 }
 __global__ void k_set_word(int *p, int v) { *p = v; }
+// (the mark log's counters are zeroed by a kernel, not a memset node: measured with four hardware queues, a 24-byte
+//  hipMemsetAsync ran AFTER work another stream had ordered behind an event recorded after it)
+__global__ void k_zero_words(unsigned *p, int n) {
+  const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (i < n) p[i] = 0u;
+}
 
 // Sparse reset: zero the 32-byte sectors named by an agent's mark log (duplicates and ~0 place-holders included; the
 // sector of a logged cell holds nothing but marks of the same log or zeros).  An overflowed log (n > cap) makes the
@@ -830,12 +836,10 @@ __global__ __launch_bounds__(64) void k_tick_inputs(const SogmTrajRecord *__rest
 // persistent kernel (launched behind the gate that holds stores back until every agent's corridors are final)
 // takes agents in publication order and, for each: samples the start state of the next tick (k_tick_inputs' rule),
 // culls the cylinders, sets the occupancy bits and writes the marks + log entries into the pool's next grid — split
-// into PS_BITS + PS_MARKS one-wave tickets per agent handed out in order (a ticket only ever waits for lower ones, so
+// into ps.n_bits + ps.n_marks one-wave tickets per agent (64 + 64 by default) handed out in order (a ticket only ever waits for lower ones, so
 // any number of resident waves makes progress).  The next update then only adopts the grid and adds the overlay
 // (sogm_update_prestamped).  Same kernels' code, same cells.
 // ------------------------------------------------------------------------------------------------
-#define PS_BITS 16
-#define PS_MARKS 16
 __device__ inline int flow_wait_count(int *p, int target, int *err) {
   const long long t0 = wall_clock64();
   for (;;) {
@@ -853,11 +857,32 @@ __device__ inline int flow_wait_count(int *p, int target, int *err) {
     }
   }
 }
+// Launch gate of the pre-stamp (one lane, on its stream in front of it): every agent's corridors final — store streams
+// stay away from the searches and point scans — AND every QP workgroup and finishing wave of this replan resident:
+// the pre-stamp's waves wait for what those produce, and a QP workgroup that is not placed yet (its launch can sit
+// behind another kernel when streams share a hardware queue) needs a whole CU, which thousands of small waiting
+// waves would never leave it.  Bounded like every wait of the tick: on a timeout the tick fails, the waves drain.
+__global__ void k_prestamp_gate(int *hdr, int n_agents, int n_qp, int n_finish) {
+  if (threadIdx.x != 0) return;
+  const long long t0 = wall_clock64();
+  for (;;) {
+    if (__hip_atomic_load(&hdr[FLOW_ERR], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
+    if (__hip_atomic_load(&hdr[FLOW_Q_READY_N], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= n_agents &&
+        __hip_atomic_load(&hdr[FLOW_Q_RESIDENT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= n_qp &&
+        __hip_atomic_load(&hdr[FLOW_F_TICKET], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= n_finish)
+      return;
+    if (wall_clock64() - t0 > FLOW_TIMEOUT_TICKS) {
+      atomicExch(&hdr[FLOW_ERR], 7);
+      return;
+    }
+    flow_pause();
+  }
+}
 __global__ __launch_bounds__(64) void k_prestamp_flow(GridGeom g, FlowCtl fc, PrestampDev ps) {
   __shared__ __attribute__((aligned(16))) SogmTrajRecord s_rec;
   __shared__ double                                      s_hov[9];
   const int lane  = threadIdx.x;
-  const int per   = PS_BITS + PS_MARKS;
+  const int per   = ps.n_bits + ps.n_marks;
   const int total = ps.n_agents * per;
   for (;;) {
     const int t = flow_ticket(&fc.hdr[FLOW_P_TICKET]);
@@ -877,6 +902,8 @@ __global__ __launch_bounds__(64) void k_prestamp_flow(GridGeom g, FlowCtl fc, Pr
       if (lane == 0) {
         tick_inputs_agent(s_rec, s_hov, agent, ps.stamp, ps.start_offset, ps.hover, ps.now, ps.t_start, ps.pva, ps.poses);
         ps.stamps[agent] = ps.stamp;
+        if (ps.poses_host)
+          for (int k = 0; k < 3; ++k) ps.poses_host[agent * 3 + k] = ps.poses[agent * 3 + k];
       }
       __threadfence();
       __syncthreads();
@@ -885,22 +912,24 @@ __global__ __launch_bounds__(64) void k_prestamp_flow(GridGeom g, FlowCtl fc, Pr
       __threadfence();
       if (lane == 0) atomicAdd(&fc.stage[agent], 1);
     }
-    if (s < PS_BITS) {
+    if (s < ps.n_bits) {
       if (flow_wait_count(&fc.stage[agent], 1, &fc.hdr[FLOW_ERR])) break;
       const float p0 = ps.poses[agent * 3], p1 = ps.poses[agent * 3 + 1], p2 = ps.poses[agent * 3 + 2];
       const int   begin = ps.cloud_range[agent * 2], end = ps.cloud_range[agent * 2 + 1];
-      stamp_bits_range(g, ps.cloud, begin + s * 64 + lane, end, PS_BITS * 64, p0, p1, p2,
+      stamp_bits_range(g, ps.cloud, begin + s * 64 + lane, end, ps.n_bits * 64, p0, p1, p2,
                        ps.bits + (size_t)agent * ps.words);
       __threadfence();
       if (lane == 0) atomicAdd(&fc.stage[agent], 1);
     } else {
-      if (flow_wait_count(&fc.stage[agent], 1 + PS_BITS, &fc.hdr[FLOW_ERR])) break;
+      if (flow_wait_count(&fc.stage[agent], 1 + ps.n_bits, &fc.hdr[FLOW_ERR])) break;
       stamp_marks_trips(g, ps.grid, ps.bits, ps.words, ps.cyl, ps.n_cyl, ps.poses, (const CylCand *)ps.cand, ps.n_cand, agent, ps.lg,
-                        (s - PS_BITS) * 256, PS_MARKS * 256);
+                        (s - ps.n_bits) * 256, ps.n_marks * 256);
     }
   }
 }
-int launch_prestamp_flow(const GridGeom &g, const FlowCtl &fc, const PrestampDev &ps, int n_workgroups, hipStream_t st) {
+int launch_prestamp_flow(const GridGeom &g, const FlowCtl &fc, const PrestampDev &ps, int n_workgroups, int n_qp,
+                         int n_finish, hipStream_t st) {
+  hipLaunchKernelGGL(k_prestamp_gate, dim3(1), dim3(64), 0, st, fc.hdr, ps.n_agents, n_qp, n_finish);
   hipLaunchKernelGGL(k_prestamp_flow, dim3(n_workgroups), dim3(64), 0, st, g, fc, ps);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
@@ -1014,19 +1043,13 @@ int reset_slot(sogm_ctx *c, hipStream_t st, int slot, float *grid, bool polite) 
                        agent_grid_bytes(c), lg.entries, lg.n, lg.cap, c->d_reset_stat);
     prof_end(c, SOGM_PROF_CLEAR, st);
     SOGM_HIP_CHECK(hipGetLastError());
-    SOGM_HIP_CHECK(hipMemsetAsync(lg.n, 0, sizeof(unsigned) * (size_t)c->n_agents, st));
+    hipLaunchKernelGGL(k_zero_words, dim3((c->n_agents + 255) / 256), dim3(256), 0, st, lg.n, c->n_agents);
+    SOGM_HIP_CHECK(hipGetLastError());
     return SOGM_OK;
   }
   return launch_clear(c, st, grid, polite);  // (a complete dense clear restarts the slot's log, see launch_clear)
 }
 
-int launch_clear_gate_only(sogm_ctx *c, hipStream_t st) {
-  if (!c->clear_gate) return SOGM_OK;
-  hipLaunchKernelGGL(k_clear_gate, dim3(1), dim3(64), 0, st, c->clear_cursor, ~(size_t)0, c->clear_gate,
-                     c->clear_gate_err, c->clear_gate_target, c->clear_epoch_word, c->clear_epoch);
-  SOGM_HIP_CHECK(hipGetLastError());
-  return SOGM_OK;
-}
 static int stamp_scratch(sogm_ctx *c, hipStream_t st, int *words_out) {
   const int A = c->n_agents;
   if (!c->d_cand) {
@@ -1173,7 +1196,10 @@ int launch_clear(sogm_ctx *c, hipStream_t st, float *grid, bool polite, int part
     const int     slot = slot_of_grid(c, grid);
     const MarkLog lg   = mark_log(c, slot);
     if (lg.entries)
-      c->tracked[slot] = hipMemsetAsync(lg.n, 0, sizeof(unsigned) * (size_t)c->n_agents, st) == hipSuccess ? 1 : 0;
+    {
+      hipLaunchKernelGGL(k_zero_words, dim3((c->n_agents + 255) / 256), dim3(256), 0, st, lg.n, c->n_agents);
+      c->tracked[slot] = hipGetLastError() == hipSuccess ? 1 : 0;
+    }
   }
   return rc;
 }

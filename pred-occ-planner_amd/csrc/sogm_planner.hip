@@ -4,6 +4,7 @@
 // (replan_impl).  SOGM_ERR_STATE from an entry point means a call-order error (no map update before planning).
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -209,7 +210,6 @@ int sogm_planner_create(sogm_ctx *map, const SogmAstarParams *astar, const SogmP
     p->fc.q_ready  = p->fc.a_ready + A;
     p->fc.f_ready  = p->fc.q_ready + A;
     p->fc.p_ready  = p->fc.f_ready + A;
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&p->pstream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_pdone, hipEventDisableTiming);
     if (e == hipSuccess) e = hipMalloc((void **)&p->d_flow_ts, sizeof(long long) * 8 * (size_t)A);
     if (e == hipSuccess) e = hipMemset(p->d_flow_ts, 0, sizeof(long long) * 8 * (size_t)A);
@@ -276,10 +276,6 @@ void sogm_planner_destroy(sogm_planner *p) {
     if (p->ev_fdone[k]) (void)hipEventDestroy(p->ev_fdone[k]);
   }
   if (p->ev_gate) (void)hipEventDestroy(p->ev_gate);
-  if (p->pstream) {
-    (void)hipStreamSynchronize(p->pstream);
-    (void)hipStreamDestroy(p->pstream);
-  }
   if (p->ev_pdone) (void)hipEventDestroy(p->ev_pdone);
   if (p->h_flow_fail) (void)hipHostFree(p->h_flow_fail);
   delete p;
@@ -508,6 +504,7 @@ int sogm_planner_set_prestamp(sogm_planner *p, const SogmPrestamp *ps) {
   p->ps.now          = ps->out_now;
   p->ps.t_start      = ps->out_t_start;
   p->ps.pva          = ps->out_pva;
+  p->ps.poses_host   = ps->out_poses;
   p->ps_on           = 1;
   return SOGM_OK;
 }
@@ -571,13 +568,6 @@ static int replan_flow(sogm_planner *p, const double *start_pva, const double *g
                      c->overlap >= 2 && c->clear_gate ? sogm::next_clear_epoch(c) : 0);
   SOGM_HIP_CHECK(hipGetLastError());
   SOGM_HIP_CHECK(hipEventRecord(p->ev_in, main));
-  if (c->overlap >= 2) {
-    // the side-stream clear of the grid this tick's update swapped out: narrow, with a wide second launch that joins
-    // once every agent's corridors are final (FLOW_Q_READY_N == A, registered as the gate at planner creation) —
-    // announce this replan's epoch now that the counters are reset
-    int rc = sogm::queue_spare_clears(c, p->ev_in);  // grids still dirty (first ticks, pool changes)
-    if (rc) return rc;
-  }
   for (int k = 0; k < 4; ++k) SOGM_HIP_CHECK(hipStreamWaitEvent(p->fstream[k], p->ev_in, 0));
   prof_begin(c, SOGM_PROF_ASTAR, sA);
   if (launch_astar(mv, p->ap, p->pp.corridor_tau, astar_ws(p), A, start_pva, goal, t_start, p->d_ret, p->d_route,
@@ -616,6 +606,15 @@ static int replan_flow(sogm_planner *p, const double *start_pva, const double *g
     return SOGM_ERR_HIP;
   }
   prof_end(c, SOGM_PROF_QP, sQ);
+  // (queued AFTER the searches / corridor / QP launches: its gate waits for the corridor stage, and when streams share a
+  //  hardware queue a launch behind a waiting gate waits with it — a QP kernel started 5 ms late costs the tick 5 ms)
+  if (c->overlap >= 2) {
+    // the side-stream clear of the grid this tick's update swapped out: narrow, with a wide second launch that joins
+    // once every agent's corridors are final (FLOW_Q_READY_N == A, registered as the gate at planner creation) —
+    // announce this replan's epoch now that the counters are reset
+    int rc = sogm::queue_spare_clears(c, p->ev_in);  // grids still dirty (first ticks, pool changes)
+    if (rc) return rc;
+  }
   sogm::FlowCtl fcf = p->fc;
   if (!(p->ps_on && c->overlap >= 2 && c->n_ready > 0 && p->pub_own && c->clear_gate)) fcf.p_ready = nullptr;
   if (sogm::launch_finish_flow(fcf, A, wg_f, p->pp.corridor_tau, p->d_ret, p->d_npoly, p->d_status, p->d_cpts,
@@ -637,17 +636,32 @@ static int replan_flow(sogm_planner *p, const double *start_pva, const double *g
     d.poses    = c->d_poses_next;
     d.stamps   = c->d_stamps_next;
     d.n_agents = A;
+    static int nb = -1, nm = -1;
+    if (nb < 0) {
+      // tickets per agent (tuning aids): too few and the last agents' stamps trail the replan, too many and the
+      // hand-overs cost more than the work (bits + marks 16+16 / 32+64 / 64+64 / 128+256 tickets: 13.1 / 12.1 / 12.2 /
+      // 14.1 ms per tick, 13.0 without the pre-stamp)
+      const char *e = getenv("SOGM_PRESTAMP_BITS");
+      nb            = e && atoi(e) > 0 ? atoi(e) : 32;
+      e             = getenv("SOGM_PRESTAMP_MARKS");
+      nm            = e && atoi(e) > 0 ? atoi(e) : 64;
+    }
+    d.n_bits  = nb;
+    d.n_marks = nm;
     if (int rc = sogm::prestamp_buffers(c, &d)) return rc;
-    SOGM_HIP_CHECK(hipStreamWaitEvent(p->pstream, p->ev_in, 0));
-    SOGM_HIP_CHECK(hipStreamWaitEvent(p->pstream, c->pool_ev[nxt], 0));
-    if (int rc = sogm::launch_clear_gate_only(c, p->pstream)) return rc;
-    int wg_p = 4 * n_cu;
+    // On the map's side stream, i.e. in stream order behind every reset queued so far — the target grid's among them
+    // (this replan's, or an earlier one's).  (A stream of its own waiting for the grid's reset event was not enough:
+    // with four hardware queues and the first, dense clears of a flight, the pre-stamp was seen running beside the
+    // kernel that restarts the grid's log, which lost the entries of all but the last agent.)
+    hipStream_t pst = c->side;
+    SOGM_HIP_CHECK(hipStreamWaitEvent(pst, p->ev_in, 0));
+    int wg_p = 8 * n_cu;  // one-wave workgroups (512 / 1024 / 2048+: 14.0 / 12.3 / 12.1 ms per tick)
     if (const char *e = getenv("SOGM_PRESTAMP_WGS")) wg_p = atoi(e) > 0 ? atoi(e) : wg_p;
-    if (sogm::launch_prestamp_flow(c->geom, p->fc, d, wg_p, p->pstream)) {
+    if (sogm::launch_prestamp_flow(c->geom, p->fc, d, wg_p, wg_q, wg_f < A ? wg_f : A, pst)) {
       sogm::set_error("sogm_replan: k_prestamp_flow", hipGetLastError());
       return SOGM_ERR_HIP;
     }
-    SOGM_HIP_CHECK(hipEventRecord(p->ev_pdone, p->pstream));
+    SOGM_HIP_CHECK(hipEventRecord(p->ev_pdone, pst));
     SOGM_HIP_CHECK(hipStreamWaitEvent(main, p->ev_pdone, 0));
     c->prestamp_slot = nxt;
   }

@@ -39,7 +39,8 @@ struct CorridorWorkspace {
 //   f_ready[A] agents in QP completion order; p_ready[A] agents whose record is published (k_finish_flow done), the
 //   pre-stamp's input; stage[A] per-agent progress counter of the pre-stamp (0 at the start of a replan).
 enum { FLOW_A_RESIDENT = 0, FLOW_A_READY_N = 1, FLOW_C_TICKET = 2, FLOW_Q_READY_N = 3, FLOW_Q_TICKET = 4,
-       FLOW_ERR = 5, FLOW_F_READY_N = 6, FLOW_F_TICKET = 7, FLOW_P_READY_N = 8, FLOW_P_TICKET = 9, FLOW_HDR = 10 };
+       FLOW_ERR = 5, FLOW_F_READY_N = 6, FLOW_F_TICKET = 7, FLOW_P_READY_N = 8, FLOW_P_TICKET = 9,
+       FLOW_Q_RESIDENT = 10 /* QP workgroups that have started */, FLOW_HDR = 11 };
 #define FLOW_TIMEOUT_TICKS 300000000LL  // 3 s of the 100 MHz wall clock: a stuck tick fails instead of hanging
 // One polling interval of the waiting loops of the dataflow replan.  A poll is a device-scope load that goes to the
 // memory side (the L2s are per XCD) while the SOGM clear streams beside it; the stages waited for take hundreds of
@@ -109,10 +110,15 @@ struct PrestampDev {
   double                stamp, start_offset;
   double               *hover, *now, *t_start, *pva;  // sogm_tick_inputs' outputs for the next tick
   float                *poses;        // the context's NEXT poses / stamps (swapped in by sogm_update_prestamped)
+  float                *poses_host;   // the caller's copy of the next map centres (optional)
   double               *stamps;
   int                   n_agents;
+  int                   n_bits, n_marks;  // one-wave tickets per agent for the two passes of the stamp
 };
-int launch_prestamp_flow(const GridGeom &g, const FlowCtl &fc, const PrestampDev &ps, int n_workgroups, hipStream_t st);
+// n_qp / n_finish: the QP workgroups and finishing waves of this replan — the pre-stamp's waves are not dispatched before
+// all of them are resident (they wait for what those produce, and a QP workgroup needs a whole CU)
+int launch_prestamp_flow(const GridGeom &g, const FlowCtl &fc, const PrestampDev &ps, int n_workgroups, int n_qp,
+                         int n_finish, hipStream_t st);
 
 // ParticleATC::isSafeAfterOpt for agents [agent0, agent0 + n_agents): out_safe[a] = 1 / 0
 int launch_deconflict(int n_agents, const double *cpts, const int32_t *npoly, const SogmTrajRecord *rec,
@@ -212,7 +218,6 @@ struct sogm_planner {
   long long     *d_flow_ts;   // [A][8]
   sogm::FlowCtl  fc;
   hipStream_t    fstream[4];  // A*, corridors, QP, finish
-  hipStream_t    pstream;     // pre-stamp (sogm_planner_set_prestamp)
   hipEvent_t     ev_pdone;
   sogm::PrestampDev ps;       // the host's part of the pre-stamp arguments
   int            ps_on;

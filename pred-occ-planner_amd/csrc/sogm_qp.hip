@@ -1479,6 +1479,7 @@ __global__ __launch_bounds__(QP_NT) void k_qp_flow(SogmPlannerParams pp, SogmQpS
                                                  int32_t *out_status, int32_t *out_iters, int ablate_arg,
                                                  int n_agents) {
   __shared__ int s_agent;
+  if (threadIdx.x == 0) atomicAdd(&fc.hdr[FLOW_Q_RESIDENT], 1);  // this workgroup holds its CU (pre-stamp gate)
   for (;;) {
     if (threadIdx.x == 0) {
       int       a = -1;

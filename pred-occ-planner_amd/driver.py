@@ -232,11 +232,11 @@ class HipCompute:
             self.map.updateMap(d["cloud"], d["cloud_range"], d["cylinders"], d["n_cyl"], poses, now)
             self.map.addOtherAgents(all_records, A_tot, self.ego_ids)
 
-    def set_prestamp(self, next_stamp, hover, now, t_start, pva):
+    def set_prestamp(self, next_stamp, hover, now, t_start, pva, poses):
         """the replan about to run also builds the NEXT tick's map and start states (sogm_planner_set_prestamp)"""
         d = self.dev
         self.planner.setPrestamp(d["cloud"], d["cloud_range"], d["cylinders"], d["n_cyl"], next_stamp,
-                                 REPLAN_START_TIME, hover, now, t_start, pva)
+                                 REPLAN_START_TIME, hover, now, t_start, pva, poses)
 
     def prestamp_pending(self):
         return self.map.prestamp_pending()
@@ -302,12 +302,13 @@ class SwarmTick:
         # finishing kernel fills the other for the next tick
         self.publish = os.environ.get("SOGM_PUBLISH", "1") != "0" and hasattr(c, "set_publish") and not fsm
         self._tables = [self.all, torch.zeros_like(self.all)] if self.publish else None
-        # pre-stamp (SOGM_PRESTAMP=1): every replan also builds the next tick's map and start states, agent by agent as
-        # their records are published; the tick's inputs are double-buffered (the replan in flight reads one set)
-        want = (os.environ.get("SOGM_PRESTAMP", "0") != "0") if prestamp is None else bool(prestamp)
+        # pre-stamp (default; SOGM_PRESTAMP=0 or prestamp=False: off): every replan also builds the next tick's map and
+        # start states, agent by agent as their records are published; the tick's inputs are double-buffered (the replan
+        # in flight reads one set)
+        want = (os.environ.get("SOGM_PRESTAMP", "1") != "0") if prestamp is None else bool(prestamp)
         self.prestamp = want and self.publish and hasattr(c, "set_prestamp") and self.overlap_mode >= 2
-        self._alt = (torch.zeros_like(self.pva), torch.zeros_like(self.t_start), torch.zeros_like(self.now)) \
-            if self.prestamp else None
+        self._alt = (torch.zeros_like(self.pva), torch.zeros_like(self.t_start), torch.zeros_like(self.now),
+                     torch.zeros_like(self.poses)) if self.prestamp else None
         # optional closed-loop mode: every agent runs the reference's FiniteStateMachine (step_fsm)
         self.fsm = fsm
         self.status = torch.full((self.A_loc,), FSM_NEW_PLAN, dtype=torch.int32, device=d)
@@ -388,7 +389,8 @@ class SwarmTick:
         c = self.compute
         if self.prestamp and c.prestamp_pending():
             # the previous replan built this tick's map and start states (into the alternate buffers)
-            (self.pva, self.t_start, self.now), self._alt = self._alt, (self.pva, self.t_start, self.now)
+            (self.pva, self.t_start, self.now, self.poses), self._alt = self._alt, (self.pva, self.t_start, self.now,
+                                                                                    self.poses)
             c.update_prestamped(self.all, self.A_tot)
         else:
             c.tick_inputs(self.own, stamp, self.hover, self.now, self.t_start, self.pva, self.poses)
@@ -401,7 +403,7 @@ class SwarmTick:
                 c.set_swarm(self.all, self.A_tot, self.now)
             if self.prestamp:
                 c.set_prestamp(self.t0 + (self.tick + 1) * TICK_PERIOD, self.hover, self._alt[2], self._alt[1],
-                               self._alt[0])
+                               self._alt[0], self._alt[3])
             c.replan(self.pva, self.goals, self.t_start, self.new, self.ok)
             if local:
                 self.all = nxt   # what every agent executes after this tick: the next tick's table

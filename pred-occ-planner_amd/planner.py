@@ -182,7 +182,8 @@ class SogmPlanner:
                                              next_table.data_ptr() if next_table is not None else None),
               "sogm_planner_set_publish")
 
-    def setPrestamp(self, cloud, cloud_range, cylinders, n_cyl, next_stamp, start_offset, hover, now, t_start, pva):
+    def setPrestamp(self, cloud, cloud_range, cylinders, n_cyl, next_stamp, start_offset, hover, now, t_start, pva,
+                    poses=None):
         """The next replan() also builds the next tick's map and start states (sogm_planner_set_prestamp); the device
         tensors are kept alive here.  cloud=None switches it off."""
         if cloud is None:
@@ -191,8 +192,8 @@ class SogmPlanner:
             return
         ps = _abi.SogmPrestamp(cloud.data_ptr(), cloud_range.data_ptr(), cylinders.data_ptr(), int(n_cyl), 0,
                                float(next_stamp), float(start_offset), hover.data_ptr(), now.data_ptr(),
-                               t_start.data_ptr(), pva.data_ptr())
-        self._prestamp = (cloud, cloud_range, cylinders, hover, now, t_start, pva)
+                               t_start.data_ptr(), pva.data_ptr(), poses.data_ptr() if poses is not None else None)
+        self._prestamp = (cloud, cloud_range, cylinders, hover, now, t_start, pva, poses)
         check(lib().sogm_planner_set_prestamp(self._p, C.byref(ps)), "sogm_planner_set_prestamp")
 
     # ---- BaselinePlanner::replan ----

@@ -83,7 +83,7 @@ def test_swarm_tick_under_a_one_rank_process_group_takes_the_abi_exchange(pop):
         dist.destroy_process_group()
     assert info == (True, None, True)
     assert all(np.array_equal(a, b) for a, b in zip(oks, ref_oks)) and sum(int(o.sum()) for o in oks) >= 12
-    assert np.array_equal(table, ref_table)
+    assert np.array_equal(table, ref_table), np.argwhere((table != ref_table).any(axis=1)).ravel().tolist()
 
 
 _TWO_RANK_SCRIPT = r"""

@@ -146,7 +146,11 @@ def test_cfg2_fused_tick_all_agents_against_oracle_replans(pop, orc):
     all_before = sw.all.clone()
     sw.step()
     torch.cuda.synchronize()
-    assert sw.planner.flow_failures() == (0, 0)
+    if sw.planner.flow_failures() != (0, 0):  # say where the dataflow stopped
+        import ctypes as C
+        buf = np.zeros(11 + 6 * 128, np.int32)
+        pop.lib().sogm_debug_flow_peek(sw.planner._p, buf.ctypes.data_as(C.c_void_p), buf.size)
+        raise AssertionError((sw.planner.flow_failures(), sw.overlap_mode, sw.prestamp, buf[:11].tolist()))
     spec, P = sw.spec, sw.planner
     pv, ps = sw.pva.cpu().numpy(), sw.poses.cpu().numpy()
     ts, now = sw.t_start.cpu().numpy(), sw.now.cpu().numpy()

@@ -5,6 +5,8 @@ cur = sqlite3.connect(db).cursor()
 rows = cur.execute("select name, start, end from kernels order by start").fetchall()
 # a tick starts at each k_stamp_cloud
 mark = "k_tick_inputs" if any("k_tick_inputs" in r[0] for r in rows) else "k_stamp_cloud"
+if any("k_prestamp_flow" in r[0] for r in rows):  # pre-stamped ticks have no k_tick_inputs: a tick = replan to replan
+    mark = "k_flow_reset"
 stamps = [i for i, r in enumerate(rows) if mark in r[0]]
 k = len(stamps) // 2  # a tick from the middle of the timed region (the run ends with stage-pass updates)
 a, b = stamps[k], stamps[k + 1]
