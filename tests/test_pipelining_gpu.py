@@ -158,3 +158,32 @@ def test_prestamp_flight_equals_the_plain_flight(pop, grids):
     assert all(np.array_equal(x, y) for x, y in zip(pa, pb))
     assert np.array_equal(ta, tb) and np.array_equal(wa, wb)
     assert all(np.array_equal(x, y) for x, y in zip(ga, gb))
+
+
+def test_prestamped_grid_is_discarded_by_a_plain_update(pop, orc):
+    """A host that stops using the pre-stamp mid-flight: the replan has stamped the next tick's map into the pool's
+    next grid; a plain sogm_update_gt with OTHER inputs then adopts that grid, resets it through its log and builds its
+    own map — cell for cell the oracle's build from zero; sogm_update_prestamped without a pre-stamp is refused."""
+    import importlib
+    import numpy as np
+    import pytest as _pytest
+    driver = importlib.import_module("pred-occ-planner_amd.driver")
+    sogm = importlib.import_module("pred-occ-planner_amd.sogm")
+    sw = driver.SwarmTick("parity", 4, grids=3, prestamp=True)
+    for _ in range(3):
+        sw.step()
+    assert sw.compute.prestamp_pending()
+    sc = dict(sw.scene)
+    poses = (sw.scene["poses"][:4] + np.array([0.4, -0.3, 0.05], np.float32)).astype(np.float32)
+    d = sw.dev
+    sw.map.updateMap(d["cloud"], d["cloud_range"], d["cylinders"], d["n_cyl"], sogm._dev(poses, np.float32),
+                     sogm._dev(sw.scene["stamps"][:4] + 5.0, np.float64))
+    assert not sw.compute.prestamp_pending()
+    cyl = pop.scene.cylinders_to_struct(sc["cylinders"])
+    cloud, crange = d["cloud"].cpu().numpy(), d["cloud_range"].cpu().numpy()
+    for a in range(4):
+        want = orc.update_gt(sw.spec, cloud[crange[a, 0]:crange[a, 1]], cyl, d["n_cyl"], poses[a])
+        assert np.array_equal(sw.map.download(a), want), a
+    with _pytest.raises(Exception):
+        sw.map.updatePrestamped(sw.all, sw.A_tot, d["ego_ids"])
+    sw.close()
