@@ -157,6 +157,11 @@ class RiskMap {
     check(sogm_update_gt_swarm(ctx_, cloud_xyz, cloud_range, cyl, n_cyl, poses, stamps, records, n_records, ego_ids, st),
           "sogm_update_gt_swarm");
   }
+  // The update of a tick whose map the previous replan pre-stamped (Planner::setPrestamp): grid swap + overlay
+  bool prestampPending() const { return sogm_prestamp_pending(ctx_) != 0; }
+  void updatePrestamped(const SogmTrajRecord *records, int n_records, const int32_t *ego_ids, hipStream_t st = nullptr) {
+    check(sogm_update_prestamped(ctx_, records, n_records, ego_ids, st), "sogm_update_prestamped");
+  }
   // RiskBase::futureRiskCallback for agent 0 of a 1-agent context: adopt one map/future_risk message.
   // `map_time` is the map stamp to adopt (the ROS header / receive time as a double).  The reference reads the
   // message's trailing float32 field into a dead local (risk_base.cpp:72) and leaves last_update_time_ alone; a
@@ -303,6 +308,15 @@ class Planner {
                 const int32_t *npoly, double *cpts, int32_t *status, int32_t *iters, hipStream_t st = nullptr) {
     check(sogm_bezier_qp_solve(p_, start_pva, goal_pv, polys, nfaces, npoly, cpts, status, iters, st),
           "sogm_bezier_qp_solve");
+  }
+  // Publication and pre-stamp of the tick loop (no reference counterparts: plan_manager.cpp:176-196 / :364-399 keep
+  // the latest trajectory per drone on the host; here the replan's finishing kernel does, and — with a pre-stamp
+  // registered — the replan also builds the next tick's start states and map, see sogm_abi.h)
+  void setPublish(SogmTrajRecord *own_records, SogmTrajRecord *next_table = nullptr) {
+    check(sogm_planner_set_publish(p_, own_records, next_table), "sogm_planner_set_publish");
+  }
+  void setPrestamp(const SogmPrestamp *next_tick) {
+    check(sogm_planner_set_prestamp(p_, next_tick), "sogm_planner_set_prestamp");
   }
   // bool BaselinePlanner::replan(t, start_pos, start_vel, start_acc, goal_pos) — batched
   void replan(const double *start_pva, const double *goal, const double *t_start, const int32_t *drone_ids,
