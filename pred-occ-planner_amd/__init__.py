@@ -7,7 +7,14 @@ The directory name contains '-', so import it with::
 
 Importing requires the in-tree HIP extension (libsogm_hip.so); there is no CPU fallback.
 """
-from . import _abi, config, scene  # noqa: F401
-from ._abi import SogmError, lib, load_library  # noqa: F401
+import os as _os
+
+# sogm_replan runs its kernels on up to nine HIP streams; streams beyond the number of hardware queues share a queue
+# and serialise (ROCm's default is four).  Must be in the environment before HIP initialises, i.e. before the first
+# torch.cuda / hip call of the process: a host that initialises HIP earlier sets it itself (INTEGRATION.md).
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
+from . import _abi, config, scene  # noqa: E402,F401
+from ._abi import SogmError, lib, load_library  # noqa: E402,F401
 
 __all__ = ["_abi", "config", "scene", "lib", "load_library", "SogmError"]

@@ -187,3 +187,39 @@ def test_prestamped_grid_is_discarded_by_a_plain_update(pop, orc):
     with _pytest.raises(Exception):
         sw.map.updatePrestamped(sw.all, sw.A_tot, d["ego_ids"])
     sw.close()
+
+
+_FOUR_QUEUES = r"""
+import importlib, os, sys
+import numpy as np, torch
+sys.path.insert(0, os.environ["SOGM_REPO"])
+driver = importlib.import_module("pred-occ-planner_amd.driver")
+out = []
+for pre in (False, True):
+    sw = driver.SwarmTick("parity", 6, grids=3, prestamp=pre)
+    oks = [sw.step().cpu().numpy().copy() for _ in range(8)]
+    table = sw.records_all().cpu().numpy().copy()
+    grids = [sw.map.download(a) for a in range(6)]
+    assert sw.planner.flow_failures() == (0, 0)
+    out.append((oks, table, grids, sw.map.sparse_reset_state()["total_entries"]))
+    sw.close()
+(oa, ta, ga, la), (ob, tb, gb, lb) = out
+assert all(np.array_equal(x, y) for x, y in zip(oa, ob)) and np.array_equal(ta, tb)
+assert all(np.array_equal(x, y) for x, y in zip(ga, gb)) and la == lb, (la, lb)
+print("four queues ok", la)
+"""
+
+
+def test_prestamp_and_sparse_reset_with_four_hardware_queues(pop):
+    """ROCm's default of four hardware queues (a host that forgets GPU_MAX_HW_QUEUES): streams share queues and
+    serialise, launches trail gates of other streams.  The flight must only get slower — same ok flags, records, cells
+    and mark-log fill with and without the pre-stamp, no failed tick.  (Found this way: a pre-stamp ordered by the reset's
+    event on a stream of its own ran beside the kernel that restarts the grid's log; QP workgroups launched behind a
+    gate of another stream were starved by the waiting pre-stamp waves.)"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="4", SOGM_REPO=root)
+    r = subprocess.run([sys.executable, "-c", _FOUR_QUEUES], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "four queues ok" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
