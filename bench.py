@@ -321,7 +321,10 @@ def main():
                    "exchange": ("abi" if sw.exchange.active else "torch" if sw.distributed else "local"),
                    "exchange_fallback_reason": sw.exchange.fallback_reason,
                    "sogm_grids_per_agent": overlap_mode if overlap_mode >= 2 else 1,
-                   "sogm_reset": "sparse (logged 32-byte sectors)" if sparse["enabled"] else "dense clear"},
+                   "sogm_reset": "sparse (logged 32-byte sectors)" if sparse["enabled"] else "dense clear",
+                   # where the tick's map update runs: inside the previous replan, agent by agent as their records are
+                   # published (sogm_planner_set_prestamp), or at the start of the tick
+                   "map_update": "pre-stamped by the previous replan" if sw.prestamp else "at the start of the tick"},
         "replans_per_s_per_agent": sw.A_tot * args.steps / dt / sw.A_tot,
         "stage_ms": {"clear": avg[0], "stamp": avg[1], "splat": avg[2], "astar": avg[3], "corridor": avg[4],
                      "qp": avg[5]},
