@@ -324,7 +324,8 @@ def main():
                    "sogm_reset": "sparse (logged 32-byte sectors)" if sparse["enabled"] else "dense clear",
                    # where the tick's map update runs: inside the previous replan, agent by agent as their records are
                    # published (sogm_planner_set_prestamp), or at the start of the tick
-                   "map_update": "pre-stamped by the previous replan" if sw.prestamp else "at the start of the tick"},
+                   "map_update": ("pre-stamped by the previous replan" if sw.prestamp and sparse["enabled"]
+                                  else "at the start of the tick")},
         "replans_per_s_per_agent": sw.A_tot * args.steps / dt / sw.A_tot,
         "stage_ms": {"clear": avg[0], "stamp": avg[1], "splat": avg[2], "astar": avg[3], "corridor": avg[4],
                      "qp": avg[5]},

@@ -616,7 +616,10 @@ static int replan_flow(sogm_planner *p, const double *start_pva, const double *g
     if (rc) return rc;
   }
   sogm::FlowCtl fcf = p->fc;
-  if (!(p->ps_on && c->overlap >= 2 && c->n_ready > 0 && p->pub_own && c->clear_gate)) fcf.p_ready = nullptr;
+  // (not with the dense clear: the pre-stamp runs behind the target grid's reset on the side stream, and a dense clear
+  //  fills that stream for the whole tick)
+  const bool prestamp = p->ps_on && c->sparse && c->overlap >= 2 && c->n_ready > 0 && p->pub_own && c->clear_gate;
+  if (!prestamp) fcf.p_ready = nullptr;
   if (sogm::launch_finish_flow(fcf, A, wg_f, p->pp.corridor_tau, p->d_ret, p->d_npoly, p->d_status, p->d_cpts,
                                p->swarm, p->n_swarm, p->swarm_ego, p->swarm_now, t_start, drone_ids, out_records,
                                out_ok, p->d_safe, p->cw.counters, sF, p->pub_own, p->pub_table)) {
@@ -627,7 +630,7 @@ static int replan_flow(sogm_planner *p, const double *start_pva, const double *g
   // the pool's next grid — behind the gate that keeps store streams away from the searches and point scans, and
   // behind that grid's reset
   c->prestamp_slot = -1;
-  if (p->ps_on && c->overlap >= 2 && c->n_ready > 0 && p->pub_own && c->clear_gate) {
+  if (prestamp) {
     const int nxt = c->ready[0];
     sogm::PrestampDev d = p->ps;
     d.grid     = (void *)c->pool[nxt];
