@@ -25,7 +25,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 # before anything initialises HIP (torch.cuda.device_count() below does): the replan's streams want a hardware queue
 # each — ROCm's default is four; the package sets the same default when it is imported first
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
 
 
 def parse():

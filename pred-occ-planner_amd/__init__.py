@@ -10,9 +10,9 @@ Importing requires the in-tree HIP extension (libsogm_hip.so); there is no CPU f
 import os as _os
 
 # sogm_replan runs its kernels on up to nine HIP streams; streams beyond the number of hardware queues share a queue
-# and serialise (ROCm's default is four).  Must be in the environment before HIP initialises, i.e. before the first
+# and serialise (ROCm's default is four; RCCL's channels take queues as well: 16 was too few beside it).  Must be in the environment before HIP initialises, i.e. before the first
 # torch.cuda / hip call of the process: a host that initialises HIP earlier sets it itself.
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
 
 from . import _abi, config, scene  # noqa: E402,F401
 from ._abi import SogmError, lib, load_library  # noqa: E402,F401

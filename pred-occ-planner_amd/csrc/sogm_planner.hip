@@ -172,7 +172,7 @@ int sogm_planner_create(sogm_ctx *map, const SogmAstarParams *astar, const SogmP
     if (e == hipSuccess) e = hipMalloc((void **)&p->d_safe, sizeof(int32_t) * A);
   }
   // Streams beyond the number of hardware queues (ROCm default GPU_MAX_HW_QUEUES = 4) share a queue
-  // and serialise, so the default is 2 groups; the Python driver raises both (GPU_MAX_HW_QUEUES = 16,
+  // and serialise, so the default is 2 groups; the Python driver raises both (GPU_MAX_HW_QUEUES = 32,
   // SOGM_GROUPS = 8) before HIP initialises.
   {
     const char *eg = getenv("SOGM_GROUPS");

@@ -15,7 +15,7 @@ import os
 
 # sogm_replan runs agent groups on separate HIP streams; streams beyond the number of hardware
 # queues share a queue and serialise, so ask the runtime for more queues before HIP initialises.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
 os.environ.setdefault("SOGM_GROUPS", "8")
 
 import numpy as np

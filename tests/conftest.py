@@ -6,7 +6,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # as the package does on import — but some GPU tests touch torch.cuda before they import it
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
