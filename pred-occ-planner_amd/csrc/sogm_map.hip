@@ -882,15 +882,22 @@ __global__ __launch_bounds__(64) void k_prestamp_flow(GridGeom g, FlowCtl fc, Pr
   __shared__ __attribute__((aligned(16))) SogmTrajRecord s_rec;
   __shared__ double                                      s_hov[9];
   const int lane  = threadIdx.x;
-  const int per   = ps.n_bits + ps.n_marks;
-  const int total = ps.n_agents * per;
+  // the last agents to be published get finer tickets: nobody is left to share the waves with, and their stamps are
+  // what trails the replan
+  const int n_early = ps.n_agents > ps.n_late ? ps.n_agents - ps.n_late : 0;
+  const int per_e = ps.n_bits + ps.n_marks, per_l = ps.n_bits_late + ps.n_marks_late;
+  const int total = n_early * per_e + (ps.n_agents - n_early) * per_l;
   for (;;) {
     const int t = flow_ticket(&fc.hdr[FLOW_P_TICKET]);
     if (t >= total) break;
-    const int agent = flow_wait_slot(fc.p_ready + t / per, &fc.hdr[FLOW_ERR]);
+    const bool late = t >= n_early * per_e;
+    const int  tl   = late ? t - n_early * per_e : t;
+    const int  per  = late ? per_l : per_e;
+    const int  n_bits = late ? ps.n_bits_late : ps.n_bits, n_marks = late ? ps.n_marks_late : ps.n_marks;
+    const int agent = flow_wait_slot(fc.p_ready + (late ? n_early : 0) + tl / per, &fc.hdr[FLOW_ERR]);
     if (agent < 0) break;
     __threadfence();  // the agent's own record was published before its slot
-    const int s = t % per;
+    const int s = tl % per;
     if (s == 0) {
       // next tick's inputs of this agent (k_tick_inputs), then its candidate cylinders around the new centre
       constexpr int W   = (int)(sizeof(SogmTrajRecord) / 16);
@@ -912,18 +919,18 @@ __global__ __launch_bounds__(64) void k_prestamp_flow(GridGeom g, FlowCtl fc, Pr
       __threadfence();
       if (lane == 0) atomicAdd(&fc.stage[agent], 1);
     }
-    if (s < ps.n_bits) {
+    if (s < n_bits) {
       if (flow_wait_count(&fc.stage[agent], 1, &fc.hdr[FLOW_ERR])) break;
       const float p0 = ps.poses[agent * 3], p1 = ps.poses[agent * 3 + 1], p2 = ps.poses[agent * 3 + 2];
       const int   begin = ps.cloud_range[agent * 2], end = ps.cloud_range[agent * 2 + 1];
-      stamp_bits_range(g, ps.cloud, begin + s * 64 + lane, end, ps.n_bits * 64, p0, p1, p2,
+      stamp_bits_range(g, ps.cloud, begin + s * 64 + lane, end, n_bits * 64, p0, p1, p2,
                        ps.bits + (size_t)agent * ps.words);
       __threadfence();
       if (lane == 0) atomicAdd(&fc.stage[agent], 1);
     } else {
-      if (flow_wait_count(&fc.stage[agent], 1 + ps.n_bits, &fc.hdr[FLOW_ERR])) break;
+      if (flow_wait_count(&fc.stage[agent], 1 + n_bits, &fc.hdr[FLOW_ERR])) break;
       stamp_marks_trips(g, ps.grid, ps.bits, ps.words, ps.cyl, ps.n_cyl, ps.poses, (const CylCand *)ps.cand, ps.n_cand, agent, ps.lg,
-                        (s - ps.n_bits) * 256, ps.n_marks * 256);
+                        (s - n_bits) * 256, n_marks * 256);
     }
   }
 }
