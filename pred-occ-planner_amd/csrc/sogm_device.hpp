@@ -381,6 +381,12 @@ struct sogm_ctx {
   hipStream_t    xstream;
   hipEvent_t     ev_xin, ev_xdone;
   int            exchange_pending;
+  // set by a publishing sogm_replan: the event after which `records_final_ptr` (the host's own records) and every
+  // reader of the swarm table inside that replan are done — the finishing kernel's end.  sogm_traj_allgather of exactly
+  // those records starts from it instead of from the caller's stream position, i.e. under the pre-stamp's tail.
+  hipEvent_t            ev_records_final;
+  const SogmTrajRecord *records_final_ptr;
+  int                   records_final_valid;
   int            profiling;   // bit k: slot k is timed (sogm_set_profiling: all, sogm_set_profiling_slots: a choice)
   // per-slot ring of HIP event pairs: every launch of a profiled kernel since profiling was enabled keeps its own
   // pair, so a run can be timed launch by launch WITHOUT synchronising between launches (sogm_profile_read_all)

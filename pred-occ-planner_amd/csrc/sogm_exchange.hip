@@ -156,8 +156,16 @@ int sogm_traj_allgather(sogm_ctx *ctx, void *nccl_comm, const SogmTrajRecord *lo
   }
   // the local records are final once everything queued on the caller's stream so far has run; every earlier
   // reader of all_records was queued on (or joined to) that stream as well
-  SOGM_HIP_CHECK(hipEventRecord(ctx->ev_xin, (hipStream_t)stream));
-  SOGM_HIP_CHECK(hipStreamWaitEvent(ctx->xstream, ctx->ev_xin, 0));
+  if (ctx->records_final_valid && ctx->records_final_ptr == local_records) {
+    // the records a publishing sogm_replan has just written: final — and the swarm table free of that replan's readers
+    // — when its finishing kernel ends, which is before the caller's stream gets there (the pre-stamp's tail, the
+    // report): the collective runs under those
+    SOGM_HIP_CHECK(hipStreamWaitEvent(ctx->xstream, ctx->ev_records_final, 0));
+  } else {
+    SOGM_HIP_CHECK(hipEventRecord(ctx->ev_xin, (hipStream_t)stream));
+    SOGM_HIP_CHECK(hipStreamWaitEvent(ctx->xstream, ctx->ev_xin, 0));
+  }
+  ctx->records_final_valid = 0;
   ncclResult_t r = a->AllGather(local_records, all_records, (size_t)n_local * sizeof(SogmTrajRecord), ncclUint8,
                                 (ncclComm_t)nccl_comm, ctx->xstream);
   // (recorded even when the collective failed: consumers stay ordered behind the producers on the exchange stream

@@ -1615,6 +1615,7 @@ static int update_gt_impl(sogm_ctx *c, const float *cloud_xyz, const int32_t *cl
   // queue, i.e. the grid adopted below — its marks are in its log, so it is reset again before the stamp.
   const int stale = c->prestamp_slot;
   c->prestamp_slot = -1;
+  c->records_final_valid = 0;
   if (c->precleared) {
     // the grid was already cleared on the side stream during the previous tick
     int rc = sogm::adopt_preclear(c, st);
@@ -1701,6 +1702,7 @@ int sogm_update_prestamped(sogm_ctx *c, const SogmTrajRecord *records, int n_rec
   if (n_records > 0)
     if (int rc = sogm::join_exchange(c, st)) return rc;  // records may come from an all-gather in flight
   if (int rc = sogm::adopt_preclear(c, st)) return rc;   // the pre-stamped grid becomes the current one
+  c->records_final_valid = 0;
   std::swap(c->d_poses, c->d_poses_next);                // its map centres and stamps with it
   std::swap(c->d_stamps, c->d_stamps_next);
   c->prestamp_slot = -1;

@@ -684,6 +684,13 @@ static int replan_flow(sogm_planner *p, const double *start_pva, const double *g
     SOGM_HIP_CHECK(hipEventRecord(p->ev_fdone[k], p->fstream[k]));
     SOGM_HIP_CHECK(hipStreamWaitEvent(main, p->ev_fdone[k], 0));  // fan in
   }
+  // the exchange of the records this replan publishes may start when the finishing kernel is done (sogm_traj_allgather)
+  c->records_final_valid = 0;
+  if (p->pub_own) {
+    c->ev_records_final    = p->ev_fdone[3];
+    c->records_final_ptr   = p->pub_own;
+    c->records_final_valid = 1;
+  }
   static int retire = -1;
   if (retire < 0) {
     const char *e = getenv("SOGM_CLEAR_RETIRE_AT_END");
