@@ -676,13 +676,28 @@ static int replan_flow(sogm_planner *p, const double *start_pva, const double *g
       sogm::set_error("sogm_replan: k_prestamp_flow", hipGetLastError());
       return SOGM_ERR_HIP;
     }
-    SOGM_HIP_CHECK(hipEventRecord(p->ev_pdone, pst));
-    SOGM_HIP_CHECK(hipStreamWaitEvent(main, p->ev_pdone, 0));
     c->prestamp_slot = nxt;
   }
   for (int k = 0; k < 4; ++k) {
     SOGM_HIP_CHECK(hipEventRecord(p->ev_fdone[k], p->fstream[k]));
     SOGM_HIP_CHECK(hipStreamWaitEvent(main, p->ev_fdone[k], 0));  // fan in
+  }
+  bool reported = false;
+  if (c->prestamp_slot >= 0) {
+    // the tick's report behind the pre-stamp on ITS stream (the last kernel of the tick to end), so that the caller's
+    // stream goes from the fan-in straight to the next tick's first kernel instead of through one more launch
+    static int retire_p = -1;
+    if (retire_p < 0) {
+      const char *e = getenv("SOGM_CLEAR_RETIRE_AT_END");
+      retire_p      = e ? atoi(e) : 0;
+    }
+    for (int k = 1; k < 4; ++k) SOGM_HIP_CHECK(hipStreamWaitEvent(c->side, p->ev_fdone[k], 0));
+    hipLaunchKernelGGL(k_flow_report, dim3(1), dim3(1), 0, c->side, (const int *)p->d_flow, p->h_flow_fail,
+                       retire_p ? p->d_epoch : (int *)nullptr);
+    SOGM_HIP_CHECK(hipGetLastError());
+    SOGM_HIP_CHECK(hipEventRecord(p->ev_pdone, c->side));
+    SOGM_HIP_CHECK(hipStreamWaitEvent(main, p->ev_pdone, 0));
+    reported = true;
   }
   // the exchange of the records this replan publishes may start when the finishing kernel is done (sogm_traj_allgather)
   c->records_final_valid = 0;
@@ -696,9 +711,11 @@ static int replan_flow(sogm_planner *p, const double *start_pva, const double *g
     const char *e = getenv("SOGM_CLEAR_RETIRE_AT_END");
     retire        = e ? atoi(e) : 0;  // measured: tick -2 %, but the clear 14.5 -> 15.5 ms; off
   }
-  hipLaunchKernelGGL(k_flow_report, dim3(1), dim3(1), 0, main, (const int *)p->d_flow, p->h_flow_fail,
-                     retire ? p->d_epoch : (int *)nullptr);
-  SOGM_HIP_CHECK(hipGetLastError());
+  if (!reported) {
+    hipLaunchKernelGGL(k_flow_report, dim3(1), dim3(1), 0, main, (const int *)p->d_flow, p->h_flow_fail,
+                       retire ? p->d_epoch : (int *)nullptr);
+    SOGM_HIP_CHECK(hipGetLastError());
+  }
   return SOGM_OK;
 }
 
