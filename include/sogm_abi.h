@@ -684,7 +684,8 @@ int sogm_planner_set_publish(sogm_planner *p, SogmTrajRecord *own_records, SogmT
 
 /* Pre-stamp.  The tick's critical path is "map update -> chain of the slowest agent", yet an agent's next map centre
  * depends on its own new record only, which is final when its replan finishes.  With a SogmPrestamp registered (and
- * publication on, two or three grids per agent, the dataflow replan), sogm_replan also builds the NEXT tick's map —
+ * publication on, two or three grids per agent, the sparse reset, the dataflow replan), sogm_replan also builds the NEXT
+ * tick's map —
  * sogm_tick_inputs' start states, then FakeParticleRiskVoxel::updateMap's stamp (fake_particle_risk_voxel.cpp:80-170)
  * — agent by agent as their records are published, into the pool's next grid; the next tick then calls
  * sogm_update_prestamped (the grid swap + the neighbour overlay) instead of sogm_tick_inputs + sogm_update_gt_swarm.
