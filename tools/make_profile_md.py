@@ -31,8 +31,8 @@ _, fk_marks = pm('FETCH_SIZE', 'k_stamp_marks')
 traffic = int((fk + wk) * 1024)
 alg = dn['roofline']['bytes_per_launch']
 # the sparse reset by itself (tools/diag_reset_pmc.py: 5 sparse resets, entry counts printed by the plain run)
-_, fk_r = pm('FETCH_SIZE', 'k_reset_sectors', last=True)  # the diag_reset_pmc passes come last in the summary
-_, wk_r = pm('WRITE_SIZE', 'k_reset_sectors', last=True)
+_, fk_r = pm('FETCH_SIZE', 'k_reset_sectors<4, 8>', last=True)  # the diag_reset_pmc passes come last in the summary
+_, wk_r = pm('WRITE_SIZE', 'k_reset_sectors<4, 8>', last=True)
 ra = read('reset_alone_plain.txt')
 ent = [int(x) for x in re.search(r"log entries after each update: \[([\d, ]+)\]", ra).group(1).split(",")]
 reset_ms = [float(x) for x in re.search(r"ms: \[([\d., ]+)\]", ra).group(1).split(",")]
@@ -93,7 +93,7 @@ then the CPU baseline): **{d['value']:.0f} replans/s** ({d['ms_per_step']:.2f} m
 {s['replans_ok_fraction']:.3f}, {s['value_ok']:.0f} successful replans/s; outcomes {json.dumps(s['outcomes_rank0'])}).
 The reset inside the tick (HIP events on its stream around every reset of the timed region, n = {r['launches_timed']},
 {r['sparse_resets']} of them sparse): {r['avg_launch_ms']:.2f} ms for {r['log_entries_per_launch']/1e6:.1f} M log entries =
-{r['bytes_per_launch']/1e9:.2f} GB issued (4 B read + 32 B written per entry) = {r['achieved']:.0f} GB/s = **{r['frac']:.3f}** of
+{r['bytes_per_launch']/1e9:.2f} GB algorithmic (4 B entry read + its 32-byte sector zeroed) = {r['achieved']:.0f} GB/s = **{r['frac']:.3f}** of
 the 8 TB/s HBM peak — off the critical path and no longer what bounds the tick: SURVEY 8(d)'s dense figure
 ({alg/1e9:.2f} GB per rebuild) divided by this launch is {r['dense_equivalent']['rate_GBps']/1e3:.1f} TB/s.  The dense clear
 `k_clear_slabs` full width with the machine to itself: {min(r['standalone']['launch_ms']):.2f} ms =
@@ -115,8 +115,10 @@ Reading guide:
 - **Sparse reset.**  `k_reset_sectors` by itself (tools/diag_reset_pmc.py, single grid, every update = reset + stamp +
   overlay; launches {", ".join("%.2f" % x for x in reset_ms[1:])} ms, the first update's dense clear {reset_ms[0]:.2f} ms):
   {ent_reset/1e6:.1f} M entries per launch; PMC FETCH_SIZE {fk_r/1e6:.2f} GB + WRITE_SIZE {wk_r/1e6:.2f} GB per launch (KB = 1024 B) =
-  **{(fk_r + wk_r) * 1024 / ent_reset:.1f} B of HBM traffic per entry** against the 36 B issued (duplicate sectors are absorbed
-  by the L2) — {(fk_r + wk_r) * 1024 / alg * 100:.1f} % of the {alg/1e9:.2f} GB a dense rebuild writes.
+  **{(fk_r + wk_r) * 1024 / ent_reset:.1f} B of HBM traffic per entry** against the 36 algorithmic bytes (four lanes zero the
+  aligned 64-byte line of an entry's sector, eight entries per trip, repeats of the previous entry skipped, the other
+  duplicates absorbed by the L2; with one lane and two 16-byte stores per entry the launch took 1.10 ms and moved
+  15.7 B per entry, with four lanes and one entry per trip 0.87 ms) — {(fk_r + wk_r) * 1024 / alg * 100:.1f} % of the {alg/1e9:.2f} GB a dense rebuild writes.
 - **Dense clear** (kept for untracked grids; `SOGM_SPARSE_RESET=0`): {alg/1e9:.2f} GB algorithmic bytes per clear = 128
   agents x 640 MB.  PMC of `k_clear_chunks<true>` (serialised: the narrow launch clears the whole grid): FETCH_SIZE
   {fk:.0f} KB + WRITE_SIZE {wk:.0f} KB = {traffic/1e9:.2f} GB per clear, i.e. **{traffic/alg:.4f} x** the algorithmic bytes;
