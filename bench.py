@@ -252,7 +252,7 @@ def main():
     if sparse["enabled"] and sparse["resets"] > 0:
         # The map is no longer rebuilt by filling V x T cells: the reset zeroes the 32-byte sectors named by the mark
         # log (DESIGN 3.1 "Sparse reset").  The kernel is rated on the bytes it has to move — 4 B read and the
-        # 32-byte sector written per log entry (it zeroes the sector's 64-byte line; the PMC traffic says what moved) — and SURVEY 8(d)'s dense figure is given beside it for comparison.
+        # 32-byte sector written per log entry (the PMC traffic says what moved) — and SURVEY 8(d)'s dense figure is given beside it for comparison.
         entries = int(sparse["entries_per_reset"])  # mean over the resets of the timed region
         reset_bytes = entries * 36
         achieved = reset_bytes / (avg[0] * 1e-3) / 1e9

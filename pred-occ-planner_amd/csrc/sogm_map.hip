@@ -109,11 +109,11 @@ __global__ void k_zero_words(unsigned *p, int n) {
 // sector of a logged cell holds nothing but marks of the same log or zeros).  An overflowed log (n > cap) makes the
 // agent's workgroups zero its whole grid instead.  Launched (blocks, A); the counts are reset by a kernel behind it.
 // LANES adjacent lanes zero one entry with one 16-byte store each, so an entry is ONE write request of 16*LANES bytes
-// at the L2 instead of two of 16; LANES = 4 (the default) zeroes the aligned 64-byte pair of sectors (everything
+// at the L2 instead of two of 16; LANES = 4 zeroes the aligned 64-byte pair of sectors (everything
 // non-zero in a tracked grid is in the log, so the neighbour sector holds marks of the same log or zeros as well).  An
 // entry equal to the one before it in the wave is skipped: neighbouring marks of a stamp row log the same sector.
 // Measured alone on 80.6 M entries (cfg2, 128 agents): one lane per entry with two stores 1.10 ms; 2 lanes 0.91;
-// 4 lanes 0.87; 4 lanes x 8 entries per trip 0.745; 8 lanes (128-byte lines) 1.08-1.2.
+// 4 lanes 0.87; 4 lanes x 8 entries per trip 0.745; 8 lanes (128-byte lines) 1.08-1.2.  reset_slot picks per use.
 template <int LANES, int UNROLL>
 __global__ __launch_bounds__(256) void k_reset_sectors(char *__restrict__ grid, size_t agent_bytes,
                                                        const unsigned *__restrict__ entries,
@@ -1065,13 +1065,14 @@ int reset_slot(sogm_ctx *c, hipStream_t st, int slot, float *grid, bool polite) 
       const char *e = getenv("SOGM_RESET_WGS");  // workgroups per agent (tuning aid)
       wgs           = e && atoi(e) > 0 ? atoi(e) : 32;
     }
-    static int lanes = -1;
-    if (lanes < 0) {
-      const char *e = getenv("SOGM_RESET_LANES");  // 2 or 4 lanes (16-byte stores) per log entry
-      lanes         = e && atoi(e) == 2 ? 2 : 4;
-    }
+    // under the replan (polite: beside the QP stage, few CUs free) two lanes and 32-byte lines are faster - 1.05 ms
+    // against 1.17 for the 64-byte lines, half the write traffic; with the machine to itself (reset in the update's
+    // own stream) four lanes x eight entries per trip - 0.75 ms against 0.91.  Both switches are tuning aids.
+    static const int lanes_env  = getenv("SOGM_RESET_LANES") ? atoi(getenv("SOGM_RESET_LANES")) : 0;
+    static const int unroll_env = getenv("SOGM_RESET_UNROLL") ? atoi(getenv("SOGM_RESET_UNROLL")) : 0;
+    const int lanes  = lanes_env == 2 || lanes_env == 4 ? lanes_env : polite ? 2 : 4;
+    const int unroll = unroll_env == 1 || unroll_env == 8 ? unroll_env : polite ? 1 : 8;
     prof_begin(c, SOGM_PROF_CLEAR, st);
-    static int unroll = getenv("SOGM_RESET_UNROLL") ? atoi(getenv("SOGM_RESET_UNROLL")) : 8;  // entries per trip: 1 or 8
     auto *kern = lanes == 4 ? (unroll == 1 ? k_reset_sectors<4, 1> : k_reset_sectors<4, 8>)
                             : (unroll == 1 ? k_reset_sectors<2, 1> : k_reset_sectors<2, 8>);
     hipLaunchKernelGGL(kern, dim3(wgs, c->n_agents), dim3(256), 0, st, reinterpret_cast<char *>(grid),

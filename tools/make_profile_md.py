@@ -31,11 +31,12 @@ _, fk_marks = pm('FETCH_SIZE', 'k_stamp_marks')
 traffic = int((fk + wk) * 1024)
 alg = dn['roofline']['bytes_per_launch']
 # the sparse reset by itself (tools/diag_reset_pmc.py: 5 sparse resets, entry counts printed by the plain run)
-_, fk_r = pm('FETCH_SIZE', 'k_reset_sectors<4, 8>', last=True)  # the diag_reset_pmc passes come last in the summary
-_, wk_r = pm('WRITE_SIZE', 'k_reset_sectors<4, 8>', last=True)
+_, fk_r = pm('FETCH_SIZE', 'k_reset_sectors<2, 1>', last=True)  # the diag_reset_pmc passes come last in the summary
+_, wk_r = pm('WRITE_SIZE', 'k_reset_sectors<2, 1>', last=True)
 ra = read('reset_alone_plain.txt')
 ent = [int(x) for x in re.search(r"log entries after each update: \[([\d, ]+)\]", ra).group(1).split(",")]
 reset_ms = [float(x) for x in re.search(r"ms: \[([\d., ]+)\]", ra).group(1).split(",")]
+wide_ms = [float(x) for x in re.search(r"ms: \[([\d., ]+)\]", read('reset_alone_wide.txt')).group(1).split(",")]
 ent_reset = sum(ent[:-1]) / len(ent[:-1])  # reset k reads the log update k-1 wrote
 json.dump({"kernel": "k_reset_sectors (sparse reset of the SOGM)",
            "source": "profiles/r03_end_rocprof.md (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes of "
@@ -115,10 +116,11 @@ Reading guide:
 - **Sparse reset.**  `k_reset_sectors` by itself (tools/diag_reset_pmc.py, single grid, every update = reset + stamp +
   overlay; launches {", ".join("%.2f" % x for x in reset_ms[1:])} ms, the first update's dense clear {reset_ms[0]:.2f} ms):
   {ent_reset/1e6:.1f} M entries per launch; PMC FETCH_SIZE {fk_r/1e6:.2f} GB + WRITE_SIZE {wk_r/1e6:.2f} GB per launch (KB = 1024 B) =
-  **{(fk_r + wk_r) * 1024 / ent_reset:.1f} B of HBM traffic per entry** against the 36 algorithmic bytes (four lanes zero the
-  aligned 64-byte line of an entry's sector, eight entries per trip, repeats of the previous entry skipped, the other
-  duplicates absorbed by the L2; with one lane and two 16-byte stores per entry the launch took 1.10 ms and moved
-  15.7 B per entry, with four lanes and one entry per trip 0.87 ms) — {(fk_r + wk_r) * 1024 / alg * 100:.1f} % of the {alg/1e9:.2f} GB a dense rebuild writes.
+  **{(fk_r + wk_r) * 1024 / ent_reset:.1f} B of HBM traffic per entry** against the 36 algorithmic bytes (two lanes zero an
+  entry's 32-byte sector with one store each, repeats of the previous entry skipped, the other duplicates absorbed by
+  the L2: the variant the tick runs under the replan).  In the update's own stream (single-grid mode, these launches'
+  case) four lanes zero the sector's 64-byte line, eight entries per trip: {", ".join("%.2f" % x for x in wide_ms[1:])} ms, 26 B of
+  traffic per entry — faster alone, slower beside the QP stage (1.17 against 1.05 ms) — {(fk_r + wk_r) * 1024 / alg * 100:.1f} % of the {alg/1e9:.2f} GB a dense rebuild writes.
 - **Dense clear** (kept for untracked grids; `SOGM_SPARSE_RESET=0`): {alg/1e9:.2f} GB algorithmic bytes per clear = 128
   agents x 640 MB.  PMC of `k_clear_chunks<true>` (serialised: the narrow launch clears the whole grid): FETCH_SIZE
   {fk:.0f} KB + WRITE_SIZE {wk:.0f} KB = {traffic/1e9:.2f} GB per clear, i.e. **{traffic/alg:.4f} x** the algorithmic bytes;
