@@ -692,7 +692,13 @@ int sogm_planner_set_publish(sogm_planner *p, SogmTrajRecord *own_records, SogmT
  * Same cells, same start states.  ps = NULL switches it off; the arrays stay owned by the caller and must not be the
  * ones the replan in flight reads (start_pva, t_start: double-buffer them).  A replan that could not pre-stamp (no
  * spare grid ready yet: first ticks) leaves sogm_update_prestamped returning SOGM_ERR_STATE: fall back to the two
- * calls. */
+ * calls.
+ * Stream order: a pre-stamping sogm_replan leaves `stream` behind its own outputs (out_records, out_ok), NOT behind the
+ * pre-stamp, which goes on for a few hundred microseconds on a stream of the context.  The SogmPrestamp outputs and the
+ * pre-stamped grid are complete in stream order behind the next sogm_update_prestamped / sogm_update_* / sogm_replan
+ * call on a stream (each joins it), or after a device synchronisation — sogm_update_prestamped launches its overlay
+ * under that tail, an agent's additions waiting for that agent's stamp.  SOGM_SPLAT_OVERLAP=0 restores the join
+ * inside sogm_replan. */
 typedef struct SogmPrestamp {
   const float        *cloud_xyz;    /* next update's inputs, as for sogm_update_gt (device) */
   const int32_t      *cloud_range;

@@ -387,6 +387,13 @@ struct sogm_ctx {
   hipEvent_t            ev_records_final;
   const SogmTrajRecord *records_final_ptr;
   int                   records_final_valid;
+  // set by a pre-stamping sogm_replan: the caller's stream is NOT joined to the pre-stamp's end inside that call — the
+  // next update's overlay starts behind the replan's fan-in and waits per agent for ps_stage[agent] == FLOW_PS_DONE,
+  // under the pre-stamp's tail — but by the first later call that needs it (join_prestamp)
+  hipEvent_t            ev_pdone;
+  int                   pdone_pending;
+  const int            *ps_stage;  // the planner's per-agent pre-stamp progress words, ps_err its error word
+  const int            *ps_err;
   int            profiling;   // bit k: slot k is timed (sogm_set_profiling: all, sogm_set_profiling_slots: a choice)
   // per-slot ring of HIP event pairs: every launch of a profiled kernel since profiling was enabled keeps its own
   // pair, so a run can be timed launch by launch WITHOUT synchronising between launches (sogm_profile_read_all)
@@ -458,6 +465,15 @@ inline MapView view_of(const sogm_ctx *c) {
 void set_error(const char *what, hipError_t e);
 void set_error_text(const char *text);
 // readers of the swarm's records wait (on their own stream) for an all-gather still in flight
+// the caller's stream waits for the end of the last replan's pre-stamp (and its report), if it has not yet
+inline int join_prestamp(sogm_ctx *c, hipStream_t st) {
+  if (c->pdone_pending) {
+    if (hipStreamWaitEvent(st, c->ev_pdone, 0) != hipSuccess) return SOGM_ERR_HIP;
+    c->pdone_pending = 0;
+  }
+  c->ps_stage = nullptr;
+  return SOGM_OK;
+}
 inline int join_exchange(sogm_ctx *c, hipStream_t st) {
   if (c->exchange_pending && hipStreamWaitEvent(st, c->ev_xdone, 0) != hipSuccess) return SOGM_ERR_HIP;
   return SOGM_OK;
@@ -466,7 +482,8 @@ int  launch_clear(sogm_ctx *c, hipStream_t st, float *grid = nullptr, bool polit
                   size_t split = 0);
 size_t clear_vec4_total(const sogm_ctx *c);
 // next update's grid becomes current (modes 2 / 3) and the stream waits for its pre-clear
-int  adopt_preclear(sogm_ctx *c, hipStream_t st);
+int  adopt_preclear(sogm_ctx *c, hipStream_t st, bool join = true);
+int  retire_wide_clear(sogm_ctx *c, hipStream_t st);
 int  announce_clear_epoch(sogm_ctx *c, hipStream_t st);
 int  next_clear_epoch(sogm_ctx *c);  // the epoch a replan writes itself (k_flow_reset) instead of a launch of its own
 int  queue_spare_clears(sogm_ctx *c, hipEvent_t after);

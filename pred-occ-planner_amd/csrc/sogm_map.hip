@@ -600,14 +600,35 @@ __global__ __launch_bounds__(256) void k_splat_neighbours(
     GridGeom g, void *__restrict__ grid, const SogmTrajRecord *__restrict__ rec, int n_rec,
     const int32_t *__restrict__ ego_ids, const float *__restrict__ poses,
     const double *__restrict__ stamps, const double *__restrict__ body, int n_body, int n_agents, int agent0,
-    MarkLog lg) {
-  const long long gid   = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long long total = (long long)n_agents * n_rec * g.T;
-  if (gid >= total) return;
-  const int t     = (int)(gid % g.T);
-  const int r     = (int)((gid / g.T) % n_rec);
-  const int agent = agent0 + (int)(gid / ((long long)g.T * n_rec));
-  splat_item(g, grid, rec[r], agent, t, ego_ids, poses, stamps, body, n_body, lg);
+    MarkLog lg, const int *wait_stage, const int *wait_err) {
+  const long long total  = (long long)n_agents * n_rec * g.T;
+  const long long stride = (long long)gridDim.x * blockDim.x;  // (one item per lane unless the launch is narrower)
+  for (long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x; gid < total; gid += stride) {
+    const int t     = (int)(gid % g.T);
+    const int r     = (int)((gid / g.T) % n_rec);
+    const int agent = agent0 + (int)(gid / ((long long)g.T * n_rec));
+    if (wait_stage) {
+      // launched under the tail of the pre-stamp that builds this grid (sogm_update_prestamped): an agent's overlay
+      // starts when ITS stamp is complete — stores of 1.0 first, the overlay's additions after them, as in the serial
+      // order.  The launch is narrow (the waiting lanes must leave room for the pre-stamp's own waves: a full-size
+      // grid of pollers starved a pre-stamp that was not resident yet until the timeouts fired).  Bounded: a
+      // pre-stamp that failed has set the error word (the tick is reported as failed); nothing is written then.
+      const long long t0 = wall_clock64();
+      bool            ok = false;
+      for (;;) {
+        if (__hip_atomic_load(wait_stage + agent, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= FLOW_PS_DONE) {
+          ok = true;
+          break;
+        }
+        if (__hip_atomic_load(wait_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+        if (wall_clock64() - t0 > FLOW_TIMEOUT_TICKS) break;
+        flow_pause();
+      }
+      if (!ok) return;
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    splat_item(g, grid, rec[r], agent, t, ego_ids, poses, stamps, body, n_body, lg);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -951,6 +972,10 @@ __global__ __launch_bounds__(64) void k_prestamp_flow(GridGeom g, FlowCtl fc, Pr
       if (flow_wait_count(&fc.stage[agent], 1 + n_bits, &fc.hdr[FLOW_ERR])) break;
       stamp_marks_trips(g, ps.grid, ps.bits, ps.words, ps.cyl, ps.n_cyl, ps.poses, (const CylCand *)ps.cand, ps.n_cand, agent, ps.lg,
                         (s - n_bits) * 256, n_marks * 256);
+      // the agent's last marks ticket to finish declares its grid complete (the next update's overlay waits for it)
+      __threadfence();
+      if (lane == 0 && atomicAdd(&fc.stage[agent], 1) + 1 == 1 + n_bits + n_marks)
+        __hip_atomic_store(&fc.stage[agent], FLOW_PS_DONE, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }
@@ -1117,7 +1142,22 @@ int prestamp_buffers(sogm_ctx *c, PrestampDev *d) {
   return SOGM_OK;
 }
 
-int adopt_preclear(sogm_ctx *c, hipStream_t st) {
+// a new tick: wide clear workgroups opened for the replan that just ended retire (the stamp, the searches and the
+// corridor stage want the memory pipeline responsive), the narrow launch goes on.  (Only when a dense clear was
+// queued since the last update: sparse resets have no wide launch.)  Behind the side stream's work of that replan: its
+// gate kernels compare the word with their epoch.
+int retire_wide_clear(sogm_ctx *c, hipStream_t st) {
+  if (c->overlap >= 2 && c->clear_gate && c->wide_clear_pending) {
+    hipLaunchKernelGGL(k_set_word, dim3(1), dim3(1), 0, st, c->clear_epoch_word, 0);
+    SOGM_HIP_CHECK(hipGetLastError());
+    c->wide_clear_pending = 0;
+  }
+  return SOGM_OK;
+}
+
+int adopt_preclear(sogm_ctx *c, hipStream_t st, bool join) {
+  if (join)  // (sogm_update_prestamped joins behind its overlay instead, and retires the wide clear there)
+    if (int rc = join_prestamp(c, st)) return rc;
   if (!c->precleared) return SOGM_OK;
   if (c->overlap >= 2) {
     // rotate: the front of the ready queue becomes the current grid, the old current grid is dirty
@@ -1134,14 +1174,8 @@ int adopt_preclear(sogm_ctx *c, hipStream_t st) {
       const char *e = getenv("SOGM_CLEAR_EARLY");
       early         = e ? atoi(e) : 0;
     }
-    if (c->clear_gate && c->wide_clear_pending) {
-      // a new tick: wide clear workgroups opened for the replan that just ended retire (the stamp, the searches and
-      // the corridor stage want the memory pipeline responsive), the narrow launch goes on.  (Only when a dense
-      // clear was queued since the last update: sparse resets have no wide launch.)
-      hipLaunchKernelGGL(k_set_word, dim3(1), dim3(1), 0, st, c->clear_epoch_word, 0);
-      SOGM_HIP_CHECK(hipGetLastError());
-      c->wide_clear_pending = 0;
-    }
+    if (join)
+      if (int rc = retire_wide_clear(c, st)) return rc;
     if (c->clear_gate && early) {
       // tuning aid (SOGM_CLEAR_EARLY=1): queue the clear of the swapped-out grid NOW, under the stamp — its readers,
       // the previous replan's kernels, are complete on `st` in stream order — for the replan that will announce
@@ -1637,6 +1671,7 @@ static int update_gt_impl(sogm_ctx *c, const float *cloud_xyz, const int32_t *cl
                           hipStream_t st) {
   SOGM_HIP_CHECK(hipSetDevice(c->device));
   const int A = c->n_agents;
+  if (int rc = sogm::join_prestamp(c, st)) return rc;  // a pre-stamp of the last replan may still be running
   if (fused)
     if (int rc = sogm::join_exchange(c, st)) return rc;  // records may come from an all-gather in flight
   // (poses / stamps are filed into the context by k_cull_cylinders below)
@@ -1689,7 +1724,7 @@ static int update_gt_impl(sogm_ctx *c, const float *cloud_xyz, const int32_t *cl
     prof_begin(c, SOGM_PROF_SPLAT, st);
     hipLaunchKernelGGL(k_splat_neighbours, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, c->geom,
                        (void *)c->d_grid, records, n_records, ego_ids, c->d_poses, c->d_stamps, c->d_body, c->n_body,
-                       A, 0, lg);
+                       A, 0, lg, nullptr, nullptr);
     prof_end(c, SOGM_PROF_SPLAT, st);
     SOGM_HIP_CHECK(hipGetLastError());
   }
@@ -1730,20 +1765,37 @@ int sogm_update_prestamped(sogm_ctx *c, const SogmTrajRecord *records, int n_rec
   hipStream_t st = (hipStream_t)stream;
   if (n_records > 0)
     if (int rc = sogm::join_exchange(c, st)) return rc;  // records may come from an all-gather in flight
-  if (int rc = sogm::adopt_preclear(c, st)) return rc;   // the pre-stamped grid becomes the current one
+  if (int rc = sogm::adopt_preclear(c, st, false)) return rc;  // the pre-stamped grid becomes the current one
   c->records_final_valid = 0;
   std::swap(c->d_poses, c->d_poses_next);                // its map centres and stamps with it
   std::swap(c->d_stamps, c->d_stamps_next);
   c->prestamp_slot = -1;
   if (n_records > 0) {
+    // The replan that pre-stamped this grid left the caller's stream behind its fan-in, not behind the pre-stamp's
+    // end: the overlay is launched now, narrow, and waits per agent for the stamp's completion word — it runs under the
+    // pre-stamp's tail (the last agents' stamps, the report) instead of after it.
+    // (a pre-stamp that has ended already — a host that synchronises every tick — needs no waiting: full width)
+    if (c->pdone_pending && hipEventQuery(c->ev_pdone) == hipSuccess)
+      if (int rc = sogm::join_prestamp(c, st)) return rc;
+    (void)hipGetLastError();  // (hipErrorNotReady is not an error here)
+    const int      *stage = c->pdone_pending ? c->ps_stage : nullptr;
     const long long total = (long long)c->n_agents * n_records * c->spec.T;
+    long long       nblk  = (total + 255) / 256;
+    static int      cap   = -1;
+    if (cap < 0) {
+      const char *e = getenv("SOGM_SPLAT_WGS");  // workgroups of the waiting launch (tuning aid)
+      cap           = e && atoi(e) > 0 ? atoi(e) : 256;  // (128 / 256 / 512 / 2048: 11.22 / 11.25 / 11.31 / 11.26 ms per tick)
+    }
+    if (stage && nblk > cap) nblk = cap;
     prof_begin(c, SOGM_PROF_SPLAT, st);
-    hipLaunchKernelGGL(k_splat_neighbours, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, c->geom,
-                       (void *)c->d_grid, records, n_records, ego_ids, c->d_poses, c->d_stamps, c->d_body, c->n_body,
-                       c->n_agents, 0, sogm::mark_log(c, sogm::cur_slot(c)));
+    hipLaunchKernelGGL(k_splat_neighbours, dim3((unsigned)nblk), dim3(256), 0, st, c->geom, (void *)c->d_grid, records,
+                       n_records, ego_ids, c->d_poses, c->d_stamps, c->d_body, c->n_body, c->n_agents, 0,
+                       sogm::mark_log(c, sogm::cur_slot(c)), stage, c->ps_err);
     prof_end(c, SOGM_PROF_SPLAT, st);
     SOGM_HIP_CHECK(hipGetLastError());
   }
+  if (int rc = sogm::join_prestamp(c, st)) return rc;  // whatever follows is behind the pre-stamp's end
+  if (int rc = sogm::retire_wide_clear(c, st)) return rc;
   c->updated = 1;
   return SOGM_OK;
 }
@@ -1763,7 +1815,7 @@ int sogm_project_neighbours(sogm_ctx *c, const SogmTrajRecord *records, int n_re
   prof_begin(c, SOGM_PROF_SPLAT, (hipStream_t)stream);
   hipLaunchKernelGGL(k_splat_neighbours, dim3(nblk), dim3(256), 0, (hipStream_t)stream, c->geom,
                      (void *)c->d_grid, records, n_records, ego_ids, c->d_poses, c->d_stamps, c->d_body,
-                     c->n_body, c->n_agents, 0, sogm::mark_log(c, sogm::cur_slot(c)));
+                     c->n_body, c->n_agents, 0, sogm::mark_log(c, sogm::cur_slot(c)), nullptr, nullptr);
   prof_end(c, SOGM_PROF_SPLAT, (hipStream_t)stream);
   SOGM_HIP_CHECK(hipGetLastError());
   return SOGM_OK;

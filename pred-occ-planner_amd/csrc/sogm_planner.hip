@@ -696,7 +696,21 @@ static int replan_flow(sogm_planner *p, const double *start_pva, const double *g
                        retire_p ? p->d_epoch : (int *)nullptr);
     SOGM_HIP_CHECK(hipGetLastError());
     SOGM_HIP_CHECK(hipEventRecord(p->ev_pdone, c->side));
-    SOGM_HIP_CHECK(hipStreamWaitEvent(main, p->ev_pdone, 0));
+    static int defer = -1;
+    if (defer < 0) {
+      const char *e = getenv("SOGM_SPLAT_OVERLAP");  // 0: the caller's stream waits for the pre-stamp's end here
+      defer         = e ? atoi(e) != 0 : 1;
+    }
+    if (defer) {
+      // the caller's stream goes on behind the fan-in: the next update's overlay waits per agent (sogm_update_prestamped),
+      // everything else joins the pre-stamp's end when it is called (sogm::join_prestamp)
+      c->ev_pdone      = p->ev_pdone;
+      c->pdone_pending = 1;
+      c->ps_stage      = p->fc.stage;
+      c->ps_err        = &p->fc.hdr[FLOW_ERR];
+    } else {
+      SOGM_HIP_CHECK(hipStreamWaitEvent(main, p->ev_pdone, 0));
+    }
     reported = true;
   }
   // the exchange of the records this replan publishes may start when the finishing kernel is done (sogm_traj_allgather)
@@ -815,6 +829,7 @@ int sogm_replan(sogm_planner *p, const double *start_pva, const double *goal,
   SOGM_HIP_CHECK(hipSetDevice(c->device));
   // the in-place pre-clear (mode 1) needs the grouped path's "last reader of the SOGM" events
   const bool use_flow = p->flow && c->overlap != 1;
+  if (int jr = sogm::join_prestamp(c, (hipStream_t)stream)) return jr;  // a pre-stamp nobody has waited for yet
   const int  rc = use_flow ? replan_flow(p, start_pva, goal, t_start, drone_ids, out_records, out_ok, stream)
                            : replan_impl(p, start_pva, goal, t_start, drone_ids, out_records, out_ok, stream);
   if (rc != SOGM_OK) {

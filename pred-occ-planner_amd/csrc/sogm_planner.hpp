@@ -41,6 +41,7 @@ struct CorridorWorkspace {
 enum { FLOW_A_RESIDENT = 0, FLOW_A_READY_N = 1, FLOW_C_TICKET = 2, FLOW_Q_READY_N = 3, FLOW_Q_TICKET = 4,
        FLOW_ERR = 5, FLOW_F_READY_N = 6, FLOW_F_TICKET = 7, FLOW_P_READY_N = 8, FLOW_P_TICKET = 9,
        FLOW_Q_RESIDENT = 10 /* QP workgroups that have started */, FLOW_HDR = 11 };
+#define FLOW_PS_DONE (1 << 20)  // stage[agent] once the agent's pre-stamp is complete (its last marks ticket sets it)
 #define FLOW_TIMEOUT_TICKS 300000000LL  // 3 s of the 100 MHz wall clock: a stuck tick fails instead of hanging
 // One polling interval of the waiting loops of the dataflow replan.  A poll is a device-scope load that goes to the
 // memory side (the L2s are per XCD) while the SOGM clear streams beside it; the stages waited for take hundreds of

@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B aid: compact bench lines under the environments given as arguments ("K=V K=V" per argument)
-export GPU_MAX_HW_QUEUES=16
+export GPU_MAX_HW_QUEUES=32
 for cfg in "$@"; do
   echo "== $cfg"
   env $cfg timeout 150 python bench.py --no-cpu-baseline --sustained ${SUST:-0} --steps ${STEPS:-20} 2>/dev/null | python -c "
