@@ -223,3 +223,39 @@ def test_prestamp_and_sparse_reset_with_four_hardware_queues(pop):
     env = dict(os.environ, GPU_MAX_HW_QUEUES="4", SOGM_REPO=root)
     r = subprocess.run([sys.executable, "-c", _FOUR_QUEUES], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "four queues ok" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+
+
+def test_overlay_under_the_prestamp_tail_at_full_size(pop):
+    """sogm_update_prestamped launches the neighbour overlay while the previous replan's pre-stamp may still be running;
+    an agent's additions wait for that agent's completion word.  At 128 agents / 200^3 x 20 and WITHOUT a host
+    synchronisation between the ticks the first pre-stamp sits behind the flight's first dense clears, so the overlay
+    really waits: a full-size grid of waiting lanes filled the machine, the pre-stamp never started, the overlay's
+    timeout fired and the tick had no overlay.  The pipelined flight must equal the flight that synchronises every tick
+    (there the pre-stamp has ended before the update: full-width overlay, no waiting), and must not stall."""
+    import time
+    import torch
+    driver = importlib.import_module("pred-occ-planner_amd.driver")
+    out = []
+    for sync in (True, False):
+        sw = driver.SwarmTick("cfg2", 128)
+        torch.cuda.synchronize()
+        t0, oks, used = time.perf_counter(), [], 0
+        for k in range(4):
+            used += int(bool(sw.prestamp and sw.compute.prestamp_pending()))
+            oks.append(sw.step())
+            if sync:
+                torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        assert sw.compute.planner.flow_failures() == (0, 0)
+        grids = [sw.map.download(a) for a in (0, 77, 127)]
+        out.append(([o.cpu().numpy() for o in oks], sw.own.cpu().numpy().copy(), grids, used, dt))
+        sw.close()
+    (ok_a, own_a, g_a, used_a, _), (ok_b, own_b, g_b, used_b, dt_b) = out
+    assert used_a >= 3 and used_b >= 3      # the pre-stamped path is what ran
+    assert dt_b < 1.0, f"pipelined first ticks took {dt_b:.2f} s: a device-side wait ran into its timeout"
+    for x, y in zip(ok_a, ok_b):
+        np.testing.assert_array_equal(x, y)
+    np.testing.assert_array_equal(own_a, own_b)
+    for x, y in zip(g_a, g_b):
+        np.testing.assert_array_equal(x, y)
