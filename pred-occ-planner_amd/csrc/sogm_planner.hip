@@ -245,6 +245,11 @@ int sogm_planner_create(sogm_ctx *map, const SogmAstarParams *astar, const SogmP
 }
 void sogm_planner_destroy(sogm_planner *p) {
   if (!p) return;
+  if (p->map && p->map->pdone_pending && p->map->ev_pdone == p->ev_pdone) {
+    (void)hipDeviceSynchronize();  // a pre-stamp nobody joined: its event and progress words go away with this planner
+    p->map->pdone_pending = 0;
+    p->map->ps_stage = p->map->ps_err = nullptr;
+  }
   if (p->map && p->d_epoch && p->map->clear_epoch_word == p->d_epoch) {
     (void)hipDeviceSynchronize();  // a gate kernel may still be polling this planner's words
     p->map->clear_gate = p->map->clear_gate_err = p->map->clear_epoch_word = nullptr;
