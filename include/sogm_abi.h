@@ -716,6 +716,10 @@ typedef struct SogmPrestamp {
 int sogm_planner_set_prestamp(sogm_planner *p, const SogmPrestamp *ps);
 /* 1 if the last sogm_replan pre-stamped the next grid (no synchronisation: host-side state). */
 int sogm_prestamp_pending(const sogm_ctx *ctx);
+/* `stream` waits for the end of the last replan's pre-stamp, if nothing has joined it yet (see "Stream order" above):
+ * for a host that touches the SogmPrestamp arrays itself — e.g. sogm_tick_inputs on the same hover_inout — before its
+ * next sogm_update_* / sogm_replan call.  No-op otherwise. */
+int sogm_prestamp_join(sogm_ctx *ctx, void *stream);
 /* The update of a pre-stamped tick: adopts the grid, its map centres and stamps, then adds the neighbour overlay
  * (records may be NULL with n_records = 0). */
 int sogm_update_prestamped(sogm_ctx *ctx, const SogmTrajRecord *records, int n_records, const int32_t *ego_ids,

@@ -164,6 +164,7 @@ PROTOTYPES = {
     "sogm_planner_set_publish": (_i, [_vp, _vp, _vp]),
     "sogm_planner_set_prestamp": (_i, [_vp, _vp]),
     "sogm_prestamp_pending": (_i, [_vp]),
+    "sogm_prestamp_join": (_i, [_vp, _vp]),
     "sogm_update_prestamped": (_i, [_vp, _vp, _i, _vp, _vp]),
     "sogm_planner_counters": (_i, [_vp, C.POINTER(C.c_int64), _i]),
     "sogm_planner_set_swarm": (_i, [_vp, _vp, _i, _vp, _vp]),

@@ -1801,6 +1801,11 @@ int sogm_update_prestamped(sogm_ctx *c, const SogmTrajRecord *records, int n_rec
 }
 
 int sogm_prestamp_pending(const sogm_ctx *c) { return c && c->prestamp_slot >= 0 ? 1 : 0; }
+int sogm_prestamp_join(sogm_ctx *c, void *stream) {
+  if (!c) return SOGM_ERR_INVALID_ARG;
+  SOGM_HIP_CHECK(hipSetDevice(c->device));
+  return sogm::join_prestamp(c, (hipStream_t)stream);
+}
 
 int sogm_project_neighbours(sogm_ctx *c, const SogmTrajRecord *records, int n_records,
                             const int32_t *ego_ids, void *stream) {

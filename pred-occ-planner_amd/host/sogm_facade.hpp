@@ -159,6 +159,7 @@ class RiskMap {
   }
   // The update of a tick whose map the previous replan pre-stamped (Planner::setPrestamp): grid swap + overlay
   bool prestampPending() const { return sogm_prestamp_pending(ctx_) != 0; }
+  void prestampJoin(void *stream = nullptr) { check(sogm_prestamp_join(ctx_, stream), "sogm_prestamp_join"); }
   void updatePrestamped(const SogmTrajRecord *records, int n_records, const int32_t *ego_ids, hipStream_t st = nullptr) {
     check(sogm_update_prestamped(ctx_, records, n_records, ego_ids, st), "sogm_update_prestamped");
   }

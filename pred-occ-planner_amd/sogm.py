@@ -176,6 +176,10 @@ class SogmMap:
         """True if the last replan pre-stamped the next grid (sogm_planner_set_prestamp)."""
         return bool(lib().sogm_prestamp_pending(self._ctx))
 
+    def prestamp_join(self):
+        """the current stream waits for the end of the last replan's pre-stamp, if nothing has joined it yet"""
+        check(lib().sogm_prestamp_join(self._ctx, _stream()), "sogm_prestamp_join")
+
     def updatePrestamped(self, records, n_records, ego_ids):
         """The update of a pre-stamped tick: grid swap + neighbour overlay (sogm_update_prestamped)."""
         check(lib().sogm_update_prestamped(self._ctx, records.data_ptr() if records is not None else None, n_records,

@@ -186,6 +186,17 @@ def test_prestamped_grid_is_discarded_by_a_plain_update(pop, orc):
         assert np.array_equal(sw.map.download(a), want), a
     with _pytest.raises(Exception):
         sw.map.updatePrestamped(sw.all, sw.A_tot, d["ego_ids"])
+    # a replan that pre-stamps leaves the stream behind its own outputs; the explicit join is for hosts that touch the
+    # pre-stamp's arrays themselves (nothing pending after the plain update above: a no-op; pending after a replan)
+    sw.map.prestamp_join()
+    for _ in range(3):
+        sw.step()
+    assert sw.compute.prestamp_pending()
+    sw.map.prestamp_join()
+    import torch
+    torch.cuda.current_stream().synchronize()   # stream-only synchronisation: the pre-stamp's outputs are complete
+    nxt_now = sw._alt[2].cpu().numpy()
+    assert np.allclose(nxt_now, sw.t0 + sw.tick * 0.1)
     sw.close()
 
 
