@@ -393,7 +393,7 @@ struct sogm_ctx {
   hipEvent_t            ev_pdone;
   int                   pdone_pending;
   const int            *ps_stage;  // the planner's per-agent pre-stamp progress words, ps_err its error word
-  const int            *ps_err;
+  int                  *ps_err;
   int            profiling;   // bit k: slot k is timed (sogm_set_profiling: all, sogm_set_profiling_slots: a choice)
   // per-slot ring of HIP event pairs: every launch of a profiled kernel since profiling was enabled keeps its own
   // pair, so a run can be timed launch by launch WITHOUT synchronising between launches (sogm_profile_read_all)

@@ -600,7 +600,7 @@ __global__ __launch_bounds__(256) void k_splat_neighbours(
     GridGeom g, void *__restrict__ grid, const SogmTrajRecord *__restrict__ rec, int n_rec,
     const int32_t *__restrict__ ego_ids, const float *__restrict__ poses,
     const double *__restrict__ stamps, const double *__restrict__ body, int n_body, int n_agents, int agent0,
-    MarkLog lg, const int *wait_stage, const int *wait_err) {
+    MarkLog lg, const int *wait_stage, int *wait_err) {
   const long long total  = (long long)n_agents * n_rec * g.T;
   const long long stride = (long long)gridDim.x * blockDim.x;  // (one item per lane unless the launch is narrower)
   for (long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x; gid < total; gid += stride) {
@@ -612,7 +612,8 @@ __global__ __launch_bounds__(256) void k_splat_neighbours(
       // starts when ITS stamp is complete — stores of 1.0 first, the overlay's additions after them, as in the serial
       // order.  The launch is narrow (the waiting lanes must leave room for the pre-stamp's own waves: a full-size
       // grid of pollers starved a pre-stamp that was not resident yet until the timeouts fired).  Bounded: a
-      // pre-stamp that failed has set the error word (the tick is reported as failed); nothing is written then.
+      // pre-stamp that failed has set the error word (the tick is reported as failed); nothing is written then, and an
+      // overlay whose own wait runs out sets it (code 8).
       const long long t0 = wall_clock64();
       bool            ok = false;
       for (;;) {
@@ -621,7 +622,10 @@ __global__ __launch_bounds__(256) void k_splat_neighbours(
           break;
         }
         if (__hip_atomic_load(wait_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
-        if (wall_clock64() - t0 > FLOW_TIMEOUT_TICKS) break;
+        if (wall_clock64() - t0 > FLOW_TIMEOUT_TICKS) {
+          atomicExch(wait_err, 8);  // the tick is reported as failed (the report runs behind the pre-stamp), not
+          break;                    // silently left without its overlay
+        }
         flow_pause();
       }
       if (!ok) return;
