@@ -198,11 +198,17 @@ float  *sogm_grid_ptr(sogm_ctx *ctx);
  * enable = 0 restores the dense clear everywhere (also: SOGM_SPARSE_RESET=0 in the environment at sogm_create).
  * Synchronises the device; call between ticks. */
 int sogm_set_sparse_reset(sogm_ctx *ctx, int enable, int log_capacity);
-/* host out[7]: {enabled, log capacity per agent, 1 if the current grid is covered by its log, largest per-agent
+/* host out[8]: {enabled, log capacity per agent, 1 if the current grid is covered by its log, largest per-agent
  * entry count of the current grid's log (above the capacity: that agent's next reset is dense), entries of all
  * agents together (saturating), sparse resets launched since the previous call, mean entries read per such
- * launch}.  Synchronises. */
+ * launch, mean KiB zeroed per such launch (the stores the reset kernel issued, counted on the device)}.
+ * Synchronises. */
 int sogm_sparse_reset_state(sogm_ctx *ctx, int32_t *out_host);
+/* How the CURRENT grid (the one queries and planning read) came to be; host out[4]: {pool slot, resets of that slot
+ * through its mark log since the pool was built, dense clears of that slot (fake_particle_risk_voxel.cpp:107-108's
+ * fill), 1 if the grid was built by the previous sogm_replan's pre-stamp and adopted by sogm_update_prestamped}.
+ * Host-side launch counts; does not synchronise.  (Parity tests use it to assert which path built the map.) */
+int sogm_grid_history(sogm_ctx *ctx, int32_t *out_host);
 
 /* Body particles of one drone: ParticleATC::initEgoParticles (particles.cpp:62-87).
  * host: xyz[n*3] offsets (fp64).  Every drone of the swarm uses the same set. */

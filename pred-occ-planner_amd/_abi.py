@@ -122,6 +122,7 @@ PROTOTYPES = {
     "sogm_grid_ptr": (_vp, [_vp]),
     "sogm_set_sparse_reset": (_i, [_vp, _i, _i]),
     "sogm_sparse_reset_state": (_i, [_vp, _vp]),
+    "sogm_grid_history": (_i, [_vp, _vp]),
     "sogm_set_body_particles": (_i, [_vp, C.POINTER(C.c_double), _i]),
     "sogm_set_overlap_clear": (_i, [_vp, _i]),
     "sogm_set_profiling": (_i, [_vp, _i]),

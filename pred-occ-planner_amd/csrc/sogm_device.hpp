@@ -374,7 +374,12 @@ struct sogm_ctx {
   unsigned      *d_log[3];         // [A][log_cap] per pool slot (slot 0 = the only grid without a pool), lazy
   unsigned      *d_log_n[3];       // [A] entries appended since the slot's last reset (beyond log_cap: overflow)
   int            tracked[3];
-  unsigned long long *d_reset_stat;  // {entries read, launches} of k_reset_sectors since the last state query
+  unsigned long long *d_reset_stat;  // {entries read, launches, lines zeroed} of k_reset_sectors since the last state query
+  // history of each pool slot since the pool was (re)built: resets through its log, dense clears (host-side launch
+  // counts), and whether the CURRENT grid was built by a replan's pre-stamp (sogm_grid_history: lets a parity test
+  // assert that the grid it compares went through k_reset_sectors and k_prestamp_flow)
+  int            hist_sparse[3], hist_dense[3];
+  int            cur_prestamped;
   void          *d_cand;           // [A][1024] candidate cylinders of the stamp (k_cull_cylinders)
   int           *d_ncand;          // [A]
   // trajectory exchange (sogm_traj_allgather): its own stream, ordered against producers / consumers by events

@@ -142,6 +142,7 @@ __global__ __launch_bounds__(256) void k_reset_sectors(char *__restrict__ grid, 
     return;
   }
   const unsigned *e       = entries + (size_t)agent * cap;
+  unsigned        n_lines = 0;  // lines this lane group zeroed (counted on the group's first lane)
   const int       part    = (int)(threadIdx.x % LANES);
   const bool      first   = (threadIdx.x & 63) < LANES;  // the wave's first entry has no predecessor to compare with
   const bool      aligned = (reinterpret_cast<uintptr_t>(base) & (16 * LANES - 1)) == 0;
@@ -156,6 +157,7 @@ __global__ __launch_bounds__(256) void k_reset_sectors(char *__restrict__ grid, 
       const unsigned id   = LANES == 4 ? sct[u] >> 1 : sct[u];  // the 16*LANES-byte line this entry zeroes
       const unsigned prev = __shfl_up(id, LANES);               // (lanes below an active lane are active: smaller i0)
       if (sct[u] == 0xFFFFFFFFu || (!first && prev == id)) continue;
+      if (part == 0) ++n_lines;
       const size_t off = (size_t)id * (16 * LANES) + 16 * part;
       if (aligned) {
         if (off + 16 <= agent_bytes) *reinterpret_cast<vfloat4 *>(base + off) = z;
@@ -168,6 +170,9 @@ __global__ __launch_bounds__(256) void k_reset_sectors(char *__restrict__ grid, 
       }
     }
   }
+  // statistics: the 16 * LANES-byte lines zeroed (what the launch wrote), one atomic per wave
+  for (int d = 32; d >= 1; d >>= 1) n_lines += (unsigned)__shfl_xor((int)n_lines, d, 64);
+  if ((threadIdx.x & 63) == 0 && n_lines) atomicAdd(stat + 2, (unsigned long long)n_lines * (unsigned)(16 * LANES));
 }
 template <bool POLITE>
 __global__ __launch_bounds__(256) void k_clear_chunks(vfloat4 *__restrict__ p, size_t n_vec4,
@@ -402,31 +407,23 @@ __device__ __forceinline__ void stamp_marks_trips(const GridGeom &g, void *__res
       const unsigned q0 = (unsigned)__shfl((int)w4.x, own, 64), q1 = (unsigned)__shfl((int)w4.y, own, 64);
       const unsigned q2 = (unsigned)__shfl((int)w4.z, own, 64), q3 = (unsigned)__shfl((int)w4.w, own, 64);
       const int      k0 = __shfl(c0, own, 64), k1 = __shfl(c1, own, 64), k2 = __shfl(c2, own, 64);
-      // mark log (sparse reset): the wave reserves T entries per occupied voxel with one atomic; slice k's entries of
-      // the wave are contiguous (entry = sector of the marked cell, or ~0 for a mark that falls outside the grid)
-      const unsigned long long am   = __ballot(active);
-      const int                n_ac = __popcll(am);
-      unsigned                 lbase = 0;
-      unsigned                *lent  = nullptr;
-      if (lg.entries) {
-        if (lane == 0) lbase = atomicAdd(lg.n + agent, (unsigned)(n_ac * g.T));
-        lbase = (unsigned)__shfl((int)lbase, 0, 64) + (unsigned)lane;  // lanes 0 .. n_ac - 1 are the active ones
-        lent  = lg.entries + (size_t)agent * lg.cap;
-      }
+      // Every lane of the wave goes through the slice loops (the mark log's offsets come from ballots): lanes without a
+      // voxel carry v = 0 and write nothing.
       const int esh = g.half ? 4 : 3;  // cells per 32-byte sector, as a shift
-      if (!active) continue;
-      const int sel = r < k0 ? 0 : r < k1 ? 1 : r < k2 ? 2 : 3;
-      unsigned  wv  = sel == 0 ? q0 : sel == 1 ? q1 : sel == 2 ? q2 : q3;
-      int       rr  = r - (sel == 0 ? 0 : sel == 1 ? k0 : sel == 2 ? k1 : k2);
-      while (rr-- > 0) wv &= wv - 1;  // drop the lower set bits
-      const int v = (w0 + own * 4 + sel) * 32 + __builtin_ctz(wv);
+      int       v   = 0;
+      if (active) {
+        const int sel = r < k0 ? 0 : r < k1 ? 1 : r < k2 ? 2 : 3;
+        unsigned  wv  = sel == 0 ? q0 : sel == 1 ? q1 : sel == 2 ? q2 : q3;
+        int       rr  = r - (sel == 0 ? 0 : sel == 1 ? k0 : sel == 2 ? k1 : k2);
+        while (rr-- > 0) wv &= wv - 1;  // drop the lower set bits
+        v = (w0 + own * 4 + sel) * 32 + __builtin_ctz(wv);
+      }
       // slice 0 (:114), then the occupied voxel's future marks (:121-170): GT velocity of the first matching record
-      cell_st(base, (size_t)v, 1.0F, g.half);
-      if (lent && lbase < (unsigned)lg.cap) lent[lbase] = (unsigned)v >> esh;
+      if (active) cell_st(base, (size_t)v, 1.0F, g.half);
       float cx, cy, cz;
       g.corner_of(v, pose, cx, cy, cz);
       float vx = 0.f, vy = 0.f;
-      for (int c = 0; c < n_loop; ++c) {
+      for (int c = 0; active && c < n_loop; ++c) {
         int    type, orig = c;
         float  ox, oy, wx, wy;
         double wlim;
@@ -464,16 +461,54 @@ __device__ __forceinline__ void stamp_marks_trips(const GridGeom &g, void *__res
           break;
         }
       }
-      for (int k = 1; k < g.T; ++k) {
+      // the cell of slice k this voxel marks (g.V: none — outside the grid, or the reference's out-of-bounds index)
+      auto future_cell = [&](int k) -> int {
         const float fx = (cx + (vx * g.dt) * (float)k) - p0;
         const float fy = (cy + (vy * g.dt) * (float)k) - p1;
         const float fz = (cz + (0.0F * g.dt) * (float)k) - p2;
-        const int    fv = g.in_range(fx, fy, fz) ? g.voxel_of(fx, fy, fz) : g.V;
-        const bool   in = fv < g.V;  // (index >= V: the reference's out-of-bounds case, see k_stamp_bits)
+        const int   fv = g.in_range(fx, fy, fz) ? g.voxel_of(fx, fy, fz) : g.V;
+        return fv < g.V ? fv : g.V;  // (index >= V: the reference's out-of-bounds case, see k_stamp_bits)
+      };
+      // Mark log (sparse reset).  The lanes of a trip hold x-ordered voxels, so the marks of neighbouring lanes fall
+      // into the same 32-byte sector most of the time (8 fp32 cells), in slice 0 and — same velocity — in every later
+      // slice: a lane logs its sector only when it differs from its lower neighbour's, and marks outside the grid log
+      // nothing (60 % fewer entries than one per mark; the reset reads what is written here).  Pass 1 stores the
+      // marks and counts the entries slice by slice (lane k keeps the number of entries of the slices before k);
+      // ONE atomic reserves the wave's entries; pass 2 recomputes the sectors and writes them, slice after slice.
+      const unsigned long long lt = lane ? (~0ull >> (64 - lane)) : 0ull;
+      unsigned                 pref = 0, run = 0;
+      auto keep_of = [&](unsigned sector, bool in) -> unsigned long long {
+        const unsigned below = (unsigned)__shfl_up((int)sector, 1, 64);
+        return __ballot(active && in && (lane == 0 || below != sector));
+      };
+      {
+        const unsigned long long m = keep_of((unsigned)v >> esh, true);
+        run                        = (unsigned)__popcll(m);
+      }
+      for (int k = 1; k < g.T; ++k) {
+        const int    fv = future_cell(k);
+        const bool   in = fv < g.V;
         const size_t ci = (size_t)k * g.V + (in ? fv : 0);
-        if (in) cell_st(base, ci, 1.0F, g.half);
-        const unsigned li = lbase + (unsigned)(k * n_ac);
-        if (lent && li < (unsigned)lg.cap) lent[li] = in ? (unsigned)(ci >> esh) : 0xFFFFFFFFu;
+        if (active && in) cell_st(base, ci, 1.0F, g.half);
+        if (lg.entries) {
+          const unsigned long long m = keep_of(in ? (unsigned)(ci >> esh) : 0xFFFFFFFFu, in);
+          if (lane == k) pref = run;
+          run += (unsigned)__popcll(m);
+        }
+      }
+      if (lg.entries) {
+        unsigned lbase = 0;
+        if (lane == 0) lbase = atomicAdd(lg.n + agent, run);
+        lbase          = (unsigned)__shfl((int)lbase, 0, 64);
+        unsigned *lent = lg.entries + (size_t)agent * lg.cap;
+        for (int k = 0; k < g.T; ++k) {
+          const int                fv  = k == 0 ? v : future_cell(k);
+          const bool               in  = fv < g.V;
+          const unsigned           sec = in ? (unsigned)(((size_t)k * g.V + fv) >> esh) : 0xFFFFFFFFu;
+          const unsigned long long m   = keep_of(sec, in);
+          const unsigned           li  = lbase + (unsigned)__shfl((int)pref, k, 64) + (unsigned)__popcll(m & lt);
+          if (((m >> lane) & 1ull) && li < (unsigned)lg.cap) lent[li] = sec;
+        }
       }
     }
   }
@@ -1069,8 +1104,8 @@ MarkLog mark_log(sogm_ctx *c, int slot) {
       return none;
     }
     if (!c->d_reset_stat &&
-        (hipMalloc((void **)&c->d_reset_stat, 2 * sizeof(unsigned long long)) != hipSuccess ||
-         hipMemset(c->d_reset_stat, 0, 2 * sizeof(unsigned long long)) != hipSuccess)) {
+        (hipMalloc((void **)&c->d_reset_stat, 4 * sizeof(unsigned long long)) != hipSuccess ||
+         hipMemset(c->d_reset_stat, 0, 4 * sizeof(unsigned long long)) != hipSuccess)) {
       (void)hipGetLastError();
       (void)hipFree(e);
       (void)hipFree(n);
@@ -1110,6 +1145,7 @@ int reset_slot(sogm_ctx *c, hipStream_t st, int slot, float *grid, bool polite) 
     SOGM_HIP_CHECK(hipGetLastError());
     hipLaunchKernelGGL(k_zero_words, dim3((c->n_agents + 255) / 256), dim3(256), 0, st, lg.n, c->n_agents);
     SOGM_HIP_CHECK(hipGetLastError());
+    c->hist_sparse[slot]++;
     return SOGM_OK;
   }
   return launch_clear(c, st, grid, polite);  // (a complete dense clear restarts the slot's log, see launch_clear)
@@ -1269,6 +1305,7 @@ int launch_clear(sogm_ctx *c, hipStream_t st, float *grid, bool polite, int part
     // covers every non-zero cell again
     const int     slot = slot_of_grid(c, grid);
     const MarkLog lg   = mark_log(c, slot);
+    if (slot >= 0 && slot < 3) c->hist_dense[slot]++;
     if (lg.entries)
     {
       hipLaunchKernelGGL(k_zero_words, dim3((c->n_agents + 255) / 256), dim3(256), 0, st, lg.n, c->n_agents);
@@ -1529,15 +1566,27 @@ int sogm_sparse_reset_state(sogm_ctx *c, int32_t *out) {
     out[3] = (int32_t)(mx > 0x7FFFFFFFu ? 0x7FFFFFFFu : mx);
     out[4] = (int32_t)(tot > 0x7FFFFFFFull ? 0x7FFFFFFFull : tot);
   }
-  out[5] = out[6] = 0;  // sparse resets since the previous call: launches, and entries read per launch (mean)
+  out[5] = out[6] = out[7] = 0;  // sparse resets since the previous call: launches, entries read and KiB zeroed per launch (means)
   if (c->d_reset_stat) {
-    unsigned long long st[2] = {0, 0};
+    unsigned long long st[4] = {0, 0, 0, 0};
     SOGM_HIP_CHECK(hipMemcpy(st, c->d_reset_stat, sizeof(st), hipMemcpyDeviceToHost));
     SOGM_HIP_CHECK(hipMemset(c->d_reset_stat, 0, sizeof(st)));
     out[5] = (int32_t)(st[1] > 0x7FFFFFFFull ? 0x7FFFFFFFull : st[1]);
     const unsigned long long mean = st[1] ? st[0] / st[1] : 0;
     out[6] = (int32_t)(mean > 0x7FFFFFFFull ? 0x7FFFFFFFull : mean);
+    const unsigned long long kib = st[1] ? st[2] / st[1] / 1024 : 0;
+    out[7] = (int32_t)(kib > 0x7FFFFFFFull ? 0x7FFFFFFFull : kib);
   }
+  return SOGM_OK;
+}
+
+int sogm_grid_history(sogm_ctx *c, int32_t *out) {
+  if (!c || !out) return SOGM_ERR_INVALID_ARG;
+  const int slot = sogm::cur_slot(c);
+  out[0] = slot;
+  out[1] = c->hist_sparse[slot];
+  out[2] = c->hist_dense[slot];
+  out[3] = c->cur_prestamped;
   return SOGM_OK;
 }
 
@@ -1564,6 +1613,8 @@ int sogm_set_overlap_clear(sogm_ctx *c, int mode) {
     std::swap(c->d_log[0], c->d_log[c->cur_idx]);  // the mark logs follow their grids
     std::swap(c->d_log_n[0], c->d_log_n[c->cur_idx]);
     std::swap(c->tracked[0], c->tracked[c->cur_idx]);
+    std::swap(c->hist_sparse[0], c->hist_sparse[c->cur_idx]);
+    std::swap(c->hist_dense[0], c->hist_dense[c->cur_idx]);
     c->cur_idx         = 0;
   }
   while (c->n_pool > want) {
@@ -1571,6 +1622,7 @@ int sogm_set_overlap_clear(sogm_ctx *c, int mode) {
     c->pool[c->n_pool] = nullptr;
   }
   for (int i = 1; i < 3; ++i) c->tracked[i] = 0;  // spares hold garbage: their first reset is the dense clear
+  for (int i = 1; i < 3; ++i) c->hist_sparse[i] = c->hist_dense[i] = 0;
   const size_t bytes = ((size_t)sogm_grid_bytes(c) + 15) & ~(size_t)15;
   const int    had   = c->n_pool;
   while (c->n_pool < want) {
@@ -1683,6 +1735,7 @@ static int update_gt_impl(sogm_ctx *c, const float *cloud_xyz, const int32_t *cl
   // queue, i.e. the grid adopted below — its marks are in its log, so it is reset again before the stamp.
   const int stale = c->prestamp_slot;
   c->prestamp_slot = -1;
+  c->cur_prestamped = 0;
   c->records_final_valid = 0;
   if (c->precleared) {
     // the grid was already cleared on the side stream during the previous tick
@@ -1774,6 +1827,7 @@ int sogm_update_prestamped(sogm_ctx *c, const SogmTrajRecord *records, int n_rec
   std::swap(c->d_poses, c->d_poses_next);                // its map centres and stamps with it
   std::swap(c->d_stamps, c->d_stamps_next);
   c->prestamp_slot = -1;
+  c->cur_prestamped = 1;
   if (n_records > 0) {
     // The replan that pre-stamped this grid left the caller's stream behind its fan-in, not behind the pre-stamp's
     // end: the overlay is launched now, narrow, and waits per agent for the stamp's completion word — it runs under the
@@ -1846,6 +1900,7 @@ int sogm_set_future_risk(sogm_ctx *c, const float *grid_vt, const float *poses,
   const int    V = c->geom.V, T = c->spec.T;
   const size_t per = (size_t)V * T;
   c->tracked[sogm::cur_slot(c)] = 0;  // every cell is written: the next reset of this grid is the dense clear
+  c->cur_prestamped = 0;
   for (int a = 0; a < c->n_agents; ++a) {
     hipLaunchKernelGGL(k_vt_to_slabs, dim3((V + 255) / 256), dim3(256), 0, st, grid_vt + a * per, V, T,
                        c->geom.half, (void *)((char *)c->d_grid + a * per * c->cell_bytes()));

@@ -119,10 +119,17 @@ class SogmMap:
         """{enabled, log_capacity, tracked (current grid covered by its log), max_entries (largest per-agent count),
         total_entries (all agents)} of the current grid; resets / entries_per_reset: the sparse resets launched since the
         previous call."""
-        out = (C.c_int32 * 7)()
+        out = (C.c_int32 * 8)()
         check(lib().sogm_sparse_reset_state(self._ctx, out), "sogm_sparse_reset_state")
         return {"enabled": bool(out[0]), "log_capacity": out[1], "tracked": bool(out[2]), "max_entries": out[3],
-                "total_entries": out[4], "resets": out[5], "entries_per_reset": out[6]}
+                "total_entries": out[4], "resets": out[5], "entries_per_reset": out[6],
+                "zeroed_bytes_per_reset": int(out[7]) * 1024}
+
+    def grid_history(self):
+        """How the current grid came to be: {slot, sparse_resets, dense_clears, prestamped} (sogm_grid_history)."""
+        out = (C.c_int32 * 4)()
+        check(lib().sogm_grid_history(self._ctx, out), "sogm_grid_history")
+        return {"slot": out[0], "sparse_resets": out[1], "dense_clears": out[2], "prestamped": bool(out[3])}
 
     # ---- profiling (HIP events around each kernel, on the caller's stream) ----
     def set_profiling(self, on=True, slots=None):

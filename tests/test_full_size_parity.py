@@ -111,15 +111,139 @@ def _tick_with_parity(pop, orc, sw, agents, check_grid_cells=True):
     return stats
 
 
+def _step_with_parity(pop, orc, sw, agents, cell_agents, expect):
+    """One tick of the BENCH's own path — SwarmTick.step(): grid taken from the pool (reset through its mark log by
+    k_reset_sectors, stamped inside the previous replan by k_prestamp_flow, adopted by sogm_update_prestamped), the
+    dataflow sogm_replan — and then, on the map that tick planned on (still current after the step):
+      * `expect` asserted against sogm_grid_history (which path built the grid),
+      * every cell of `cell_agents`' grids against the oracle's build from zero
+        (fake_particle_risk_voxel.cpp:107-108 fill + marks + overlay),
+      * for every agent of `agents`: A* return / node counts / pop order / route, polytopes (bit-exact), QP status /
+        iterations / coefficients (1e-4) of the staged entry points run on that map against the oracle run on ITS map,
+      * the tick's own published record (sogm_replan's output) against those stage results, bit for bit."""
+    import torch
+    planner = importlib.import_module("pred-occ-planner_amd.planner")
+    spec, P = sw.spec, sw.planner
+    ap, pp, qs = P.ap, P.pp, P.qs
+    all_before = sw.all.clone()  # the table this tick's overlay and deconfliction read
+    tick = sw.tick
+    sw.step()
+    torch.cuda.synchronize()
+    assert sw.planner.flow_failures() == (0, 0), (tick, sw.planner.flow_failures())
+    hist = sw.map.grid_history()
+    for k, v in expect.items():
+        if k.startswith("min_"):
+            assert hist[k[4:]] >= v, (tick, hist, expect)
+        else:
+            assert hist[k] == v, (tick, hist, expect)
+    pva, t_start, poses = sw.pva, sw.t_start, sw.poses  # this tick's inputs (written by the previous replan's pre-stamp)
+    pv, ps, ts, now = pva.cpu().numpy(), poses.cpu().numpy(), t_start.cpu().numpy(), sw.now.cpu().numpy()
+    # the map centres the pre-stamp filed with the grid are the ones the host sees
+    for a in cell_agents:
+        mt, mc = sw.map.map_state(a)
+        assert mt == float(now[a]) and np.array_equal(mc, ps[a]), (tick, a, mt, now[a], mc, ps[a])
+    s = P.search(pva, sw.goals, t_start, route_cap=64, trace_cap=12000)
+    c = P.generateCorridors(pva, t_start, s["route"], s["route_len"])
+    q = P.optimize(pva, c["goal"], c["polys"], c["nfaces"], c["npoly"])
+    safe = P.isSafeAfterOpt(q["cpts"], c["npoly"], all_before, sw.A_tot, sw.dev["ego_ids"], sw.now).cpu().numpy()
+    sn = {k: v.cpu().numpy() for k, v in s.items()}
+    cn = {k: v.cpu().numpy() for k, v in c.items()}
+    qn = {k: v.cpu().numpy() for k, v in q.items()}
+    goals = sw.goals.cpu().numpy()
+    recs = planner.records_from_bytes(all_before.cpu().numpy())
+    new = planner.records_from_bytes(sw.new.cpu().numpy())
+    okf = sw.ok.cpu().numpy()
+    cloud, crange = sw.dev["cloud"].cpu().numpy(), sw.dev["cloud_range"].cpu().numpy()
+    cyl = pop.scene.cylinders_to_struct(sw.scene["cylinders"])
+    n_cyl = len(sw.scene["cylinders"])
+    ego = sw.dev["ego_ids"].cpu().numpy()
+    stats = {"agents": 0, "cells": 0, "expansions": 0, "polys": 0, "qp_ok": 0, "worst_dx": 0.0, "fused_ok": 0}
+    for a in agents:
+        stamp = float(now[a])
+        g = orc.update_gt(spec, cloud[crange[a, 0]:crange[a, 1]], cyl, n_cyl, ps[a])
+        orc.project_neighbours(spec, g, recs, sw.A_tot, int(ego[a]), sw.map.body, ps[a], stamp)
+        if a in cell_agents:
+            got = sw.map.download(a)
+            assert np.array_equal(got, g), f"tick {tick} agent {a}: SOGM differs in {(got != g).sum()} cells"
+            assert int((g != 0).sum()) > 1000  # (a populated map, not two empty ones)
+            stats["cells"] += g.size
+            del got
+        w = orc.astar_search(spec, ap, g, ps[a], pv[a], goals[a], float(ts[a] - stamp), pp.corridor_tau, trace_cap=12000)
+        assert sn["ret"][a] == w["ret"], (tick, a, sn["ret"][a], w["ret"])
+        assert list(sn["stats"][a]) == w["stats"], (tick, a, sn["stats"][a], w["stats"])
+        k = min(w["trace_len"], 12000)
+        assert np.array_equal(sn["trace"][a, :k], w["trace"][:k]), f"tick {tick} agent {a}: A* pop order differs"
+        n = len(w["route"])
+        assert sn["route_len"][a] == n and np.array_equal(sn["route"][a, :n], w["route"])
+        stats["expansions"] += w["stats"][1]
+        cc = orc.corridor_generate(spec, pp, g, ps[a], stamp, pv[a], float(ts[a]), w["route"])
+        del g
+        M = cc["npoly"]
+        assert cn["npoly"][a] == M, (tick, a, cn["npoly"][a], M)
+        assert np.array_equal(cn["nfaces"][a][:max(M, 0)], cc["nfaces"][:max(M, 0)])
+        for i in range(max(M, 0)):
+            nf = cc["nfaces"][i]
+            assert np.array_equal(cn["polys"][a, i, :nf], cc["polys"][i, :nf]), (tick, a, i)
+            stats["polys"] += 1
+        st = 0
+        if M > 0:
+            assert np.array_equal(cn["goal"][a], cc["goal"])
+            goal = np.concatenate([cc["goal"], np.zeros(3)])
+            st, x, it = orc.qp_solve(pv[a], goal, [pp.corridor_tau] * M, cc["polys"], cc["nfaces"], pp.max_faces,
+                                     pp.opt_max_vel, pp.opt_max_acc, qs)
+            assert qn["status"][a] == st and qn["iters"][a] == it, (tick, a, qn["status"][a], st, qn["iters"][a], it)
+            if st in (1, 2):
+                d = float(np.abs(qn["cpts"][a, :15 * M] - x).max())
+                assert d <= TOL, (tick, a, d)
+                stats["worst_dx"] = max(stats["worst_dx"], d)
+                stats["qp_ok"] += 1
+        # the tick's own output (dataflow sogm_replan on the same map): the stage results, bit for bit
+        want_ok = bool(sn["ret"][a] != 0 and M > 0 and st in (1, 2) and safe[a] != 0)
+        assert bool(okf[a]) == want_ok, (tick, a, okf[a], sn["ret"][a], M, st, safe[a])
+        assert new[a].n_pieces == (M if want_ok else 0) and new[a].drone_id == int(ego[a])
+        if want_ok:
+            assert np.array_equal(np.array(new[a].cpts[:15 * M]), qn["cpts"][a, :15 * M]), (tick, a)
+            assert new[a].time_start == float(ts[a])
+            stats["fused_ok"] += 1
+        stats["agents"] += 1
+    return stats
+
+
 def _sum(acc, s):
     for k, v in s.items():
         acc[k] = max(acc.get(k, 0.0), v) if k == "worst_dx" else acc.get(k, 0) + v
     return acc
 
 
+def test_cfg2_bench_path_on_reset_prestamped_grids(pop, orc):
+    """BASELINE configs[2], the path bench.py times, at the bench's size: 128 agents, 200^3 x 20, the default pool of
+    three grids, sparse reset, pre-stamp, publication inside the replan.  The pool's slots are first adopted after a
+    reset through their logs at ticks 3, 4 and 5 (tick 0 builds slot 0 after a dense clear; ticks 1 and 2 adopt spares
+    cleared densely on first use): those three ticks are checked — every cell of two agents' 640 MB grids against the
+    oracle's build from zero (a different pair per tick, so all three slots and six agents are covered), and the A* trace
+    / polytopes / QP / published record of eight agents."""
+    driver = importlib.import_module("pred-occ-planner_amd.driver")
+    sw = driver.SwarmTick("cfg2", 128)
+    assert sw.overlap_mode == 3 and sw.prestamp and sw.publish and sw.map.sparse_reset_state()["enabled"]
+    agents = [0, 17, 33, 50, 64, 81, 99, 127]
+    for _ in range(3):
+        sw.step()
+    acc, slots = {}, set()
+    for k, cells in enumerate(([0, 81], [33, 127], [17, 64])):
+        st = _step_with_parity(pop, orc, sw, agents, cells, {"min_sparse_resets": 1, "dense_clears": 1, "prestamped": True})
+        slots.add(sw.map.grid_history()["slot"])
+        _sum(acc, st)
+    print("cfg2 bench path, ticks 3-5:", acc)
+    assert slots == {0, 1, 2}
+    assert acc["agents"] == 24 and acc["cells"] == 6 * 160_000_000 and acc["expansions"] > 100 and acc["polys"] > 50
+    assert acc["qp_ok"] >= 16 and acc["fused_ok"] >= 14
+    sw.close()
+
+
 def test_cfg2_bench_scene_chain_parity(pop, orc):
-    """BASELINE configs[2]: the bench's own 128-agent scene at 200^3 x 20 (double-buffered SOGM: 164 GB), 3 ticks;
-    8 agents spread over the swarm are checked stage by stage."""
+    """BASELINE configs[2]: the bench's own 128-agent scene at 200^3 x 20 through the STAGED entry points (sogm_update_gt
+    + sogm_project_neighbours: densely cleared grids, no pool), 3 ticks; 8 agents spread over the swarm are checked
+    stage by stage.  (The bench's own path — pooled, sparse-reset, pre-stamped grids — is the test above.)"""
     driver = importlib.import_module("pred-occ-planner_amd.driver")
     sw = driver.SwarmTick("cfg2", 128)
     agents = [0, 17, 33, 50, 64, 81, 99, 127]
@@ -136,16 +260,19 @@ def test_cfg2_fused_tick_all_agents_against_oracle_replans(pop, orc):
     """The configuration the bench runs — SwarmTick.step() itself: 128 agents, pooled grids with the side-stream
     clear, the dataflow sogm_replan (persistent corridor / QP / finish kernels, speculative second search) — checked
     against the CPU oracle's full replan (search + corridors + QP + isSafeAfterOpt) for 16 agents spread over the
-    swarm, on the third tick of the flight (agents moving, neighbours' records in the overlay)."""
+    swarm, on the FIFTH tick of the flight (tick index 4: agents moving, neighbours' records in the overlay, and the map a
+    pool slot that has been reset through its mark log and stamped by the previous replan's pre-stamp)."""
     import torch
     driver = importlib.import_module("pred-occ-planner_amd.driver")
     planner = importlib.import_module("pred-occ-planner_amd.planner")
     sw = driver.SwarmTick("cfg2", 128)
-    for _ in range(2):
+    for _ in range(4):
         sw.step()
     all_before = sw.all.clone()
     sw.step()
     torch.cuda.synchronize()
+    hist = sw.map.grid_history()
+    assert hist["sparse_resets"] >= 1 and hist["prestamped"], hist
     if sw.planner.flow_failures() != (0, 0):  # say where the dataflow stopped
         import ctypes as C
         buf = np.zeros(11 + 6 * 128, np.int32)
@@ -203,8 +330,11 @@ def test_cfg0_static_pillars_chain_parity(pop, orc, seed, min_ok):
 
 
 def test_cfg4_fp16_chain_parity(pop, orc):
-    """BASELINE configs[4]: 300^3 x 30 with fp16 occupancy cells, 2 agents, 2 ticks (the oracle's fp32 grid is
-    3.2 GB per agent; marks and neighbour counts are exact in fp16, so cells compare bit for bit)."""
+    """BASELINE configs[4]: 300^3 x 30 with fp16 occupancy cells, 2 agents (the oracle's fp32 grid is 3.2 GB per
+    agent; marks and neighbour counts are exact in fp16, so cells compare bit for bit).  Two ticks through the staged
+    entry points, then the flight's own path — SwarmTick.step() — for five ticks: ticks 3 and 4 plan on pool slots
+    reset through their logs (16-cell fp16 sectors) and stamped by the previous replan; both are checked cell by cell
+    and stage by stage."""
     driver = importlib.import_module("pred-occ-planner_amd.driver")
     spec = pop.config.make_spec("cfg4")
     assert spec.storage == pop._abi.SOGM_STORE_F16
@@ -214,6 +344,16 @@ def test_cfg4_fp16_chain_parity(pop, orc):
         _sum(acc, _tick_with_parity(pop, orc, sw, [0, 1], check_grid_cells=(sw.tick == 0)))
     print("cfg4:", acc)
     assert acc["agents"] == 4 and acc["polys"] > 8 and acc["qp_ok"] >= 2
+    sw.close()
+    sw = driver.SwarmTick("cfg4", 2, spec=spec)
+    assert sw.overlap_mode == 3 and sw.prestamp and sw.map.sparse_reset_state()["enabled"]
+    for _ in range(3):
+        sw.step()
+    acc = {}
+    for cells in ([0], [1]):
+        _sum(acc, _step_with_parity(pop, orc, sw, [0, 1], cells, {"min_sparse_resets": 1, "prestamped": True}))
+    print("cfg4 flight path, ticks 3-4:", acc)
+    assert acc["agents"] == 4 and acc["cells"] == 2 * 27_000_000 * 30 and acc["polys"] > 8 and acc["qp_ok"] >= 2
     sw.close()
 
 
