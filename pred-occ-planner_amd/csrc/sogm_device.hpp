@@ -415,20 +415,32 @@ namespace sogm {
 // peak inside the tick with 8-12 CUs per XCD, but the planner chain loses more on the remaining CUs than the tick
 // gains; masking the clear alone is worse still (planner waves on the clear's CUs starve it).
 inline hipError_t create_stream_partitioned(hipStream_t *st, int role) {
-  static int n_clear = -1;
+  static int n_clear = -1, n_qp = -1;
   if (n_clear < 0) {
     const char *e = getenv("SOGM_CLEAR_CUS");
     n_clear       = e ? atoi(e) : 0;
     if (n_clear < 0 || n_clear > 28) n_clear = 0;
+    // SOGM_QP_CUS = n (experiment): the QP stage's stream (role 2) owns the first n CUs of every XCD, every other
+    // internal stream the rest — the ADMM iteration runs 1.03 us alone and 1.4 us with corridor / search / stamp waves
+    // on its CU
+    e    = getenv("SOGM_QP_CUS");
+    n_qp = e ? atoi(e) : 0;
+    if (n_qp < 0 || n_qp > 28) n_qp = 0;
   }
-  if (n_clear == 0) return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
+  if (n_clear == 0 && n_qp == 0) return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
   uint32_t mask[8];
   for (int w = 0; w < 8; ++w) {
     mask[w] = 0;
     for (int b = 0; b < 32; ++b) {
-      const int  bit      = w * 32 + b;
-      const bool is_clear = bit < 8 * n_clear;
-      if (is_clear == (role == 0)) mask[w] |= 1u << b;
+      const int bit = w * 32 + b;
+      bool      on;
+      if (n_qp > 0) {
+        on = (bit < 8 * n_qp) == (role == 2);
+      } else {
+        const bool is_clear = bit < 8 * n_clear;
+        on                  = is_clear == (role == 0);
+      }
+      if (on) mask[w] |= 1u << b;
     }
   }
   return hipExtStreamCreateWithCUMask(st, 8, mask);

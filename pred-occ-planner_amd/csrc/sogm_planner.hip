@@ -161,6 +161,9 @@ int sogm_planner_create(sogm_ctx *map, const SogmAstarParams *astar, const SogmP
     p->qw.scratch_stride = qp_scratch_bytes_per_agent(pp->max_faces);
     p->qw.dyn_lds_bytes  = qp_dynamic_lds_bytes();  // 160 KiB/CU minus k_qp's static LDS
     if (e == hipSuccess) e = hipMalloc((void **)&p->qw.scratch, p->qw.scratch_stride * (size_t)A);
+    if (e == hipSuccess) e = hipMalloc((void **)&p->qw.k1_scratch, qp_k1_scratch_bytes_per_agent() * (size_t)A);
+    if (e == hipSuccess) e = hipMalloc((void **)&p->qw.dbg, sizeof(long long) * 16 * (size_t)A);
+    if (e == hipSuccess) e = hipMemset(p->qw.dbg, 0, sizeof(long long) * 16 * (size_t)A);
     min_jerk_block(p->qc.QM);
     if (e == hipSuccess) e = hipMalloc((void **)&p->d_polys, sizeof(double) * slots * pp->max_faces * 4);
     if (e == hipSuccess) e = hipMalloc((void **)&p->d_goal, sizeof(double) * 6 * A);
@@ -216,7 +219,7 @@ int sogm_planner_create(sogm_ctx *map, const SogmAstarParams *astar, const SogmP
     p->fc.ts = p->d_flow_ts;
 
     for (int k = 0; k < 4 && e == hipSuccess; ++k) {
-      e = sogm::create_stream_partitioned(&p->fstream[k], 1);
+      e = sogm::create_stream_partitioned(&p->fstream[k], k == 2 ? 2 : 1);
       if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_fdone[k], hipEventDisableTiming);
     }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_gate, hipEventDisableTiming);
@@ -258,7 +261,7 @@ void sogm_planner_destroy(sogm_planner *p) {
                   p->d_ret,   p->d_route_len, p->d_stats, p->d_route,
                   p->cw.pc,   p->cw.fpc,  p->cw.tang, p->cw.distr, p->cw.polys,
                   p->cw.seg_nfaces, p->cw.seg_state, p->cw.seg_npts, p->cw.seg_dbg, p->cw.counters,
-                  p->qw.scratch,
+                  p->qw.scratch, p->qw.dbg, p->qw.k1_scratch,
                   p->d_polys, p->d_goal, p->d_cpts, p->d_nfaces, p->d_npoly, p->d_status, p->d_iters,
                   p->d_safe,  p->d_flow, p->d_flow_ts, p->d_epoch};
   for (void *q : ptrs)
@@ -352,6 +355,14 @@ int sogm_debug_astar_nodes(sogm_planner *p, int agent, void *out_host, int n) {
   SOGM_HIP_CHECK(hipDeviceSynchronize());
   SOGM_HIP_CHECK(hipMemcpy(out_host, p->aw.pool + (size_t)agent * p->aw.pool_stride, (size_t)n * sogm::astar_node_bytes(),
                            hipMemcpyDeviceToHost));
+  return SOGM_OK;
+}
+
+// diagnostics (tools/ only): per-agent clock split of the last QP solve (QpWorkspace::dbg), [A][16]
+int sogm_debug_qp_stats(sogm_planner *p, long long *out_host) {
+  if (!p || !out_host) return SOGM_ERR_INVALID_ARG;
+  SOGM_HIP_CHECK(hipDeviceSynchronize());
+  SOGM_HIP_CHECK(hipMemcpy(out_host, p->qw.dbg, sizeof(long long) * 16 * (size_t)p->map->n_agents, hipMemcpyDeviceToHost));
   return SOGM_OK;
 }
 
@@ -593,6 +604,8 @@ static int replan_flow(sogm_planner *p, const double *start_pva, const double *g
   int wg_c = 4 * n_cu;
   if (wg_c > A * SOGM_MAX_PIECES) wg_c = A * SOGM_MAX_PIECES;
   int wg_q = n_cu / 2;
+  if (const char *e = getenv("SOGM_QP_CUS"))
+    if (atoi(e) > 0 && atoi(e) <= 28) wg_q = 8 * atoi(e);  // one workgroup per CU of the QP partition
   if (const char *e = getenv("SOGM_QP_WGS")) wg_q = atoi(e);  // tuning aid
   if (wg_q > A) wg_q = A;
   if (wg_q < 1) wg_q = 1;

@@ -151,13 +151,19 @@ struct QpWorkspace {
   char  *scratch;         // [A][scratch_stride]
   size_t scratch_stride;  // bytes per agent (rows at M = SOGM_MAX_PIECES, max_faces faces)
   int    dyn_lds_bytes;   // dynamic LDS per workgroup of k_qp
+  double *k1_scratch;     // [A][120 * 18] band of A^T diag(rho / rho_cur) A when it does not fit in LDS beside the rows
   // BezierOpt::setup in full (sogm_bezier_qp_solve_timed): per-piece time allocation [A][SOGM_MAX_PIECES] and an
   // end state with acceleration (goal rows of 9 doubles instead of 6).  nullptr / 6: every piece = corridor_tau,
   // final acceleration 0 — what replan() asks for (baseline.cpp:411,423).
   const double *t_alloc;
   int           goal_stride;
+  // diagnostics (tools/): [A][16] wall_clock64 ticks (100 MHz) of the agent's last solve — 0 total, 1 set-up (assembly,
+  // scaling, first factorisation), 2 later refactorisations, 3 their count, 4 checks (residual passes + certificates),
+  // 5 their count, 6 iterations run, 8-10 the three phases of factor() summed over all factorisations; always written (a handful of clock reads per 25 iterations)
+  long long    *dbg;
 };
 size_t qp_scratch_bytes_per_agent(int max_faces);
+size_t qp_k1_scratch_bytes_per_agent();
 int    qp_dynamic_lds_bytes();
 struct QpConst {
   double QM[225];  // per-piece min-jerk cost block (bezier_optimizer.cpp:96-111)

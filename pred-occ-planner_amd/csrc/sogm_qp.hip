@@ -48,6 +48,7 @@ namespace {
 #define QP_NMAX (15 * SOGM_MAX_PIECES)
 #define QP_ELL 6
 #define QP_NT 512  // lanes per workgroup (8 waves: two per SIMD)
+#define QP_K1_DOUBLES (120 * (QP_BW + 1))  // K1 band of a register-resident problem (M <= 8)
 
 __device__ const double OSQP_INFTY  = 1e30;
 __device__ const double MIN_SCALING = 1e-04, MAX_SCALING = 1e+04;
@@ -191,6 +192,7 @@ __device__ inline double &KB(double *Kb, int i, int j) { return Kb[i * (QP_BW + 
 
 }  // namespace
 
+size_t qp_k1_scratch_bytes_per_agent() { return (size_t)QP_K1_DOUBLES * sizeof(double); }
 size_t qp_scratch_bytes_per_agent(int max_faces) {
   const int G = 9 * (SOGM_MAX_PIECES + 1) + 21 * SOGM_MAX_PIECES;
   const int S = 5 * max_faces * SOGM_MAX_PIECES;
@@ -212,6 +214,9 @@ __device__ __forceinline__ void qp_solve_agent(const SogmPlannerParams &pp, cons
   (void)ablate_arg;
 #endif
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long long dbg_t0 = wall_clock64(), dbg_clk0 = clock64();
+  long long       dbg_refac = 0, dbg_check = 0, dbg_f1 = 0, dbg_f2 = 0, dbg_f3 = 0;
+  int             dbg_nrefac = 0, dbg_ncheck = 0;
   const int M = npoly[agent];
   if (M <= 0 || M > SOGM_MAX_PIECES) {
     if (tid == 0) {
@@ -224,13 +229,13 @@ __device__ __forceinline__ void qp_solve_agent(const SogmPlannerParams &pp, cons
   const int n  = 15 * M;
 
   extern __shared__ __attribute__((aligned(16))) char qp_smem[];
-  double *s_Kb = (double *)qp_smem;               // [n][18]  K band / Cholesky factor
-  double *s_P  = s_Kb + (size_t)n * (QP_BW + 1);  // [M][225] scaled cost blocks
-  // Block form of the factor for the per-iteration solve (M <= 8): K is block tridiagonal in 15x15
-  // piece blocks (the profile of the continuity rows), so G = chol(K) is block bidiagonal.
+  // Dynamic LDS, general path: s_Kb [n][18] K band / Cholesky factor | s_P [M][225] scaled cost blocks | rows.
+  // Register-resident path (M <= 8): K is block tridiagonal in 15 x 15 piece blocks (the profile of the continuity
+  // rows) and its inverse is built block by block (factor()):
+  //   s_P [M][225] | s_Dv [M][225] diagonal blocks of K, then inv(D_i) | s_V [M][225] K(i, i-1), then V_i |
+  //   s_Z [M][225] one block row of K^-1 | hot rows | cold rows | K1 [n][18] the band of A^T diag(rho / rho_cur) A
+  //   (the cold rows and K1 sit in LDS when everything fits, in the agent's HBM scratch otherwise)
   const bool use_blocks = M <= 8;
-  double    *s_Ginv     = s_P + (size_t)M * 225;     // [M][225] inverse of the diagonal block of G
-  double    *s_Goff     = s_Ginv + (size_t)M * 225;  // [M][225] G(block i, block i-1)
   __shared__ double s_ginv[QP_NMAX];
   __shared__ __attribute__((aligned(16))) double s_xt[QP_NMAX];
   __shared__ double s_x[QP_NMAX], s_D[QP_NMAX], s_Dt[QP_NMAX];
@@ -261,11 +266,20 @@ __device__ __forceinline__ void qp_solve_agent(const SogmPlannerParams &pp, cons
   // Register-resident iteration (FAST): K^-1 rows, one general row or up to four safety rows per lane in
   // registers; needs the block form of the factor (M <= 8) and only the hot row arrays in LDS.
   const size_t head1 = ((size_t)n * (QP_BW + 1) + (size_t)M * 225) * sizeof(double);
-  const size_t head3 = ((size_t)n * (QP_BW + 1) + (size_t)M * 225 * 3) * sizeof(double);
+  const size_t head4 = (size_t)M * 225 * 4 * sizeof(double);
+  const size_t k1_bytes = (size_t)n * (QP_BW + 1) * sizeof(double);
   const bool   fast  = use_blocks && G <= 256 && S <= 1024 &&
-                    head3 + rows_hot_bytes(G, S) <= (size_t)ws.dyn_lds_bytes;
-  const size_t head        = fast ? head3 : head1;
-  const bool   rows_in_lds = head + rows_bytes(G, S) <= (size_t)ws.dyn_lds_bytes;
+                    head4 + rows_hot_bytes(G, S) <= (size_t)ws.dyn_lds_bytes;
+  const size_t head        = fast ? head4 : head1;
+  const size_t rows_al     = (rows_bytes(G, S) + 15) & ~(size_t)15;
+  const bool   rows_in_lds = head + rows_al + (fast ? k1_bytes : 0) <= (size_t)ws.dyn_lds_bytes;
+  double *s_Kb = (double *)qp_smem;
+  double *s_P  = fast ? (double *)qp_smem : s_Kb + (size_t)n * (QP_BW + 1);
+  double *s_Dv = s_P + (size_t)M * 225, *s_V = s_Dv + (size_t)M * 225, *s_Z = s_V + (size_t)M * 225;  // fast only
+  // (read through a generic pointer: once per entry and factorisation)
+  const double *k1r = rows_in_lds ? (const double *)(qp_smem + head + rows_al)
+                                  : (const double *)(ws.k1_scratch + (size_t)agent * QP_K1_DOUBLES);
+  double       *k1w = const_cast<double *>(k1r);
   // The solver body is instantiated twice (forced inline): once with every row pointer derived from
   // the LDS array — so the compiler emits ds_read/ds_write instead of flat accesses — and once for
   // the HBM-scratch fallback.
@@ -559,6 +573,37 @@ __device__ __forceinline__ void qp_solve_agent(const SogmPlannerParams &pp, cons
     for (int s = tid; s < S; s += QP_NT) R.sw[s] = rho_cur * R.sz[s] - R.sy[s];
     __syncthreads();
   };
+  // Register-resident path: every row's rho is rho_cur times a constant (1000 for an equality row, 1 otherwise: the
+  // general rows of this QP all have two finite bounds, the safety rows one), so K = P + sigma I + rho_cur K1 with
+  // K1 = A^T diag(rho / rho_cur) A fixed after the scaling: its band is built once and a refactorisation starts from
+  // three LDS reads per entry instead of the walk over the column's rows.
+  auto build_K1 = [&]() {
+    const int tid = launder((int)threadIdx.x);
+    for (int e = tid; e < n * (QP_BW + 1); e += QP_NT) {
+      const int i = e / (QP_BW + 1), dlt = e % (QP_BW + 1), j = i - dlt;
+      double    s = 0.0;
+      if (j >= 0) {
+        for (int a = s_cptr[i]; a < s_cptr[i + 1]; ++a) {
+          const int    en = R.cidx[a], r = en >> 3;
+          const double vi = R.gval[(size_t)r * QP_ELL + (en & 7)];
+          const double mr = R.gu[r] - R.gl[r] < RHO_TOL ? RHO_EQ_OVER_RHO_INEQ : 1.0;
+          for (int k = 0; k < QP_ELL; ++k)
+            if (R.gcol[(size_t)r * QP_ELL + k] == j) s += vi * mr * R.gval[(size_t)r * QP_ELL + k];
+        }
+        if (i / 3 == j / 3) {  // same control point: safety rows couple its 3 coordinates
+          COL_DECODE(i)
+          const int jd = j % 3;
+          for (int f = 0; f < nface; ++f) {
+            const double *v = R.sval + (size_t)(sbase + 5 * f) * 3;
+            s += v[pd] * v[jd];
+          }
+        }
+      }
+      k1w[e] = s;
+    }
+    __threadfence_block();
+    __syncthreads();
+  };
   // K band = P + sigma I + A^T diag(rho) A (rows in global row order: general, then safety),
   // then banded Cholesky in place
   auto factor = [&]() __attribute__((always_inline)) -> bool {
@@ -566,6 +611,170 @@ __device__ __forceinline__ void qp_solve_agent(const SogmPlannerParams &pp, cons
     const int tid = launder((int)threadIdx.x), lane = tid & 63, wave = tid >> 6;
     (void)lane;
     (void)wave;
+    if constexpr (FAST) {
+      const long long dbg_fa = wall_clock64();
+      // ---- K^-1 of the block tridiagonal K, block by block (no scalar Cholesky chain, no X^T X product) ------------
+      // 1. the blocks of K: diagonal D_b = K(b, b) into s_Dv, sub-diagonal O_b = K(b, b-1) into s_V.  An entry is
+      //    evaluated with its larger index first, so (i, j) and (j, i) are the same sum: the blocks are symmetric
+      //    bit for bit.
+      for (int e = tid; e < 2 * M * 225; e += QP_NT) {
+        const int which = e >= M * 225 ? 1 : 0, ee = e - which * M * 225;
+        const int b = ee / 225, r = (ee % 225) / 15, c = ee % 15;
+        int       i = b * 15 + r, j = (b - which) * 15 + c;
+        double    s = 0.0;
+        if (j >= 0) {
+          if (i < j) {
+            const int t_ = i;
+            i            = j;
+            j            = t_;
+          }
+          if (i / 15 == j / 15) s = s_P[(i / 15) * 225 + (i % 15) * 15 + (j % 15)];
+          if (i == j) s += qs.sigma;
+          if (i - j <= QP_BW) s = __builtin_fma(rho_cur, k1r[i * (QP_BW + 1) + (i - j)], s);
+        }
+        (which ? s_V : s_Dv)[ee] = s;
+      }
+      if (tid == 0) s_flag = 1;
+      __syncthreads();
+      const long long dbg_fb = wall_clock64();
+      dbg_f1 += dbg_fb - dbg_fa;
+      // 2. forward sweep: S_0 = D_0, S_i = D_i - O_i inv(S_{i-1}) O_i^T; s_Dv block i <- inv(S_i), s_V block i <-
+      //    V_i = O_i inv(S_{i-1}).  The inverse of a 15 x 15 SPD block is fifteen symmetric sweeps (Gauss-Jordan
+      //    without pivoting: a_pp <- -1/d, a_rp <- a_rp/d, a_rc <- a_rc - a_rp a_pc/d; all pivots swept: -inv(A)), one
+      //    lane per entry, the entry in a register, the block ping-ponged between two LDS copies: one barrier per sweep.
+      const int  er = (tid % 225) / 15, ec = tid % 15;  // this lane's entry of a 15 x 15 block (lanes < 225)
+      const bool el = tid < 225;
+      const int  hi_ = er > ec ? er : ec, lo_ = er > ec ? ec : er;
+      for (int i = 0; i < M; ++i) {  // uniform
+        double a = 0.0;
+        if (i > 0) {
+          // T = O_i inv(S_{i-1})
+          if (el) {
+            const double *Or = s_V + i * 225 + er * 15, *Dc = s_Dv + (i - 1) * 225 + ec;
+            double        t  = 0.0;
+#pragma unroll
+            for (int k = 0; k < 15; ++k) t = __builtin_fma(Or[k], Dc[k * 15], t);
+            s_T[0][tid] = t;
+          }
+          __syncthreads();
+          // S_i = D_i - T O_i^T, evaluated for (max, min) on both sides of the diagonal: symmetric bit for bit
+          if (el) {
+            const double *Tr = s_T[0] + hi_ * 15, *Oc = s_V + i * 225 + lo_ * 15;
+            double        t  = s_Dv[i * 225 + hi_ * 15 + lo_];
+#pragma unroll
+            for (int k = 0; k < 15; ++k) t = __builtin_fma(-Tr[k], Oc[k], t);
+            a = t;
+          }
+          __syncthreads();  // every reader of O_i is done: V_i takes its place
+          if (el) s_V[i * 225 + tid] = s_T[0][tid];
+        } else if (el) {
+          a = s_Dv[hi_ * 15 + lo_];
+        }
+        if (el) s_T[1][tid] = a;
+        __syncthreads();
+        int cur = 1;
+#pragma unroll 1
+        for (int p = 0; p < 15; ++p) {
+          const double *A_ = s_T[cur];
+          const double  d  = A_[p * 16];  // every lane reads the pivot: the failure test is workgroup-uniform
+          if (!(d > 0.0)) {
+            if (tid == 0) s_flag = 0;
+            break;
+          }
+          if (el) {
+            const double inv = 1.0 / d;
+            if (er != p && ec != p)
+              a = __builtin_fma(-(A_[er * 15 + p] * A_[p * 15 + ec]), inv, a);
+            else if (er == p && ec == p)
+              a = -inv;
+            else
+              a = a * inv;
+            s_T[cur ^ 1][tid] = a;
+          }
+          cur ^= 1;
+          __syncthreads();
+        }
+        if (el) s_Dv[i * 225 + tid] = -a;  // inv(S_i)
+        __syncthreads();
+        if (!s_flag) break;  // uniform
+      }
+      const long long dbg_fc = wall_clock64();
+      dbg_f2 += dbg_fc - dbg_fb;
+      if (s_flag) {
+        // 3. backward: block row i of Z = K^-1 from block row i + 1,
+        //      Z(i, j) = -V_{i+1}^T Z(i+1, j)  (j > i),   Z(i, i) = inv(S_i) - V_{i+1}^T Z(i, i+1)^T,
+        //    two rows in LDS (s_Z), and every lane (row rho4, columns 30 q4 .. 30 q4 + 29) picks its entries of K^-1
+        //    out of the row just finished: directly when the row is in block row i, transposed when its columns are.
+        // (the K^-1 layout of solveK: wave w, lane l -> row 16 w + (l & 15), column quarter l >> 4)
+        const int rho4 = (tid >> 6) * 16 + (tid & 15), q4 = (tid >> 4) & 3, bi4 = rho4 / 15, rr4 = rho4 % 15;
+#pragma unroll
+        for (int kk = 0; kk < 30; ++kk) kinv[kk] = 0.0;
+        for (int i = M - 1; i >= 0; --i) {  // uniform
+          double *Zi = s_Z;  // ONE block row, rewritten in place: block (i, j) only needs block (i + 1, j)
+          if (i == M - 1) {
+            if (el) Zi[i * 225 + tid] = s_Dv[i * 225 + tid];
+          } else {
+            const double *Vn = s_V + (i + 1) * 225;
+            const int     ne = (M - 1 - i) * 225;
+            double        tq[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {  // (M <= 8: at most 7 * 225 entries)
+              const int e = tid + q * QP_NT;
+              tq[q]       = 0.0;
+              if (e < ne) {
+                const int     j = i + 1 + e / 225, r = (e % 225) / 15, c = e % 15;
+                const double *Zc = Zi + j * 225 + c;
+                double        t  = 0.0;
+#pragma unroll
+                for (int k = 0; k < 15; ++k) t = __builtin_fma(Vn[k * 15 + r], Zc[k * 15], t);
+                tq[q] = -t;
+              }
+            }
+            __syncthreads();  // every read of row i + 1 is done (the lanes' K^-1 entries of it as well)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const int e = tid + q * QP_NT;
+              if (e < ne) Zi[(i + 1) * 225 + e] = tq[q];
+            }
+            __syncthreads();
+            if (el) {  // the diagonal block, (max, min) on both sides
+              const double *Zr = Zi + (i + 1) * 225 + lo_ * 15;
+              double        t  = s_Dv[i * 225 + hi_ * 15 + lo_];
+#pragma unroll
+              for (int k = 0; k < 15; ++k) t = __builtin_fma(-Vn[k * 15 + hi_], Zr[k], t);
+              Zi[i * 225 + tid] = t;
+            }
+          }
+          __syncthreads();
+          if (rho4 < n) {
+            const int c0 = 2 * q4, c1 = 2 * q4 + 1;
+            if (bi4 == i) {
+              if (c0 >= i && c0 < M) {
+#pragma unroll
+                for (int kk = 0; kk < 15; ++kk) kinv[kk] = Zi[c0 * 225 + rr4 * 15 + kk];
+              }
+              if (c1 >= i && c1 < M) {
+#pragma unroll
+                for (int kk = 0; kk < 15; ++kk) kinv[15 + kk] = Zi[c1 * 225 + rr4 * 15 + kk];
+              }
+            } else if (bi4 > i) {
+              if (c0 == i) {
+#pragma unroll
+                for (int kk = 0; kk < 15; ++kk) kinv[kk] = Zi[bi4 * 225 + kk * 15 + rr4];
+              }
+              if (c1 == i) {
+#pragma unroll
+                for (int kk = 0; kk < 15; ++kk) kinv[15 + kk] = Zi[bi4 * 225 + kk * 15 + rr4];
+              }
+            }
+          }
+          // (the next stage only reads this row until its first barrier)
+        }
+        __syncthreads();
+      }
+      dbg_f3 += wall_clock64() - dbg_fc;
+      return s_flag != 0;
+    } else {
     for (int e = tid; e < n * (QP_BW + 1); e += QP_NT) {
       const int i = e / (QP_BW + 1), dlt = e % (QP_BW + 1), j = i - dlt;
       double    s = 0.0;
@@ -630,124 +839,52 @@ __device__ __forceinline__ void qp_solve_agent(const SogmPlannerParams &pp, cons
       }
     }
     __syncthreads();
-    if (FAST && s_flag) {
-      for (int e = tid; e < M * 225; e += QP_NT) {
-        const int b = e / 225, r = (e % 225) / 15, c = e % 15;
-        const int row = b * 15 + r, col = (b - 1) * 15 + c;
-        s_Goff[e] = (b > 0 && row - col <= QP_BW) ? KB(s_Kb, row, col) : 0.0;
-        s_Ginv[e] = 0.0;
-      }
-      __syncthreads();
-      // column c of inv(Gd_b): forward substitution, one lane per (block, column)
-      for (int e = tid; e < M * 15; e += QP_NT) {
-        const int b = e / 15, c = e % 15, o = b * 15;
-        double    v[15];
-        for (int r = 0; r < 15; ++r) v[r] = 0.0;
-        v[c] = s_ginv[o + c];
-        for (int r = c + 1; r < 15; ++r) {
-          double acc = 0.0;
-          for (int k = c; k < r; ++k) acc += KB(s_Kb, o + r, o + k) * v[k];
-          v[r] = -acc * s_ginv[o + r];
-        }
-        for (int r = c; r < 15; ++r) s_Ginv[b * 225 + r * 15 + c] = v[r];
-      }
-      __syncthreads();
-      // W_b = Ginv_b G(b, b-1) (into the now idle band storage): X(i, j) = (-W_i) ... (-W_{j+1}) Ginv_j
-      double wv[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int e = tid + q * QP_NT;
-        wv[q]       = 0.0;
-        if (e < M * 225) {
-          const int b = e / 225, r = (e % 225) / 15, c = e % 15;
-          if (b > 0) {
-            double acc = 0.0;
-            for (int k = 0; k <= r; ++k) acc += s_Ginv[b * 225 + r * 15 + k] * s_Goff[b * 225 + k * 15 + c];
-            wv[q] = acc;
-          }
-        }
-      }
-      __syncthreads();
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int e = tid + q * QP_NT;
-        if (e < M * 225) s_Kb[e] = wv[q];
-      }
-      __syncthreads();
-      // K^-1 = X^T X, one block row of X at a time.  Block row ib of X = G^-1 is built in LDS by the whole
-      // workgroup: T starts as the identity; for jb = ib .. 0  X(ib, jb) = T Ginv_jb  and  T <- -T W_jb  (the
-      // same dot products, in the same k order, as a per-row chain would run — but 450 of them side by side:
-      // lanes 0..224 produce X(ib, jb), lanes 256..480 the next T).  `stage` (s_Goff is free now: 15 x n
-      // doubles) then holds rows 15 ib .. 15 ib + 14 of X and every lane (rho, q) accumulates
-      //   kinv[kk] += X[r][rho] * X[r][30 q + kk]      over those rows.
-      {
-        const double *s_W   = s_Kb;
-        double       *stage = s_Goff;
-        const int     rho4 = tid >> 2, q4 = tid & 3, bi4 = rho4 / 15;
-#pragma unroll
-        for (int kk = 0; kk < 30; ++kk) kinv[kk] = 0.0;
-        for (int ib = 0; ib < M; ++ib) {  // uniform
-          __syncthreads();                // previous round's readers of stage / s_T are done
-          if (tid < 225) s_T[0][tid] = (tid / 15 == tid % 15) ? 1.0 : 0.0;
-          for (int e = tid; e < 15 * n; e += QP_NT)
-            if (e % n >= (ib + 1) * 15) stage[e] = 0.0;  // X(ib, jb) = 0 for jb > ib
-          __syncthreads();
-          int cur = 0;
-          for (int jb = ib; jb >= 0; --jb) {
-            const int role = tid >> 8, e = tid & 255;
-            if (e < 225) {
-              const int     r = e / 15, c = e % 15;
-              const double *T = s_T[cur] + r * 15;
-              const double *B = (role == 0 ? s_Ginv : s_W) + jb * 225 + c;
-              double        a = 0.0;
-#pragma unroll
-              for (int k = 0; k < 15; ++k) a += T[k] * B[k * 15];
-              if (role == 0)
-                stage[r * n + jb * 15 + c] = a;
-              else
-                s_T[cur ^ 1][e] = -a;
-            }
-            cur ^= 1;
-            __syncthreads();
-          }
-          if (tid < 4 * n && bi4 <= ib) {  // X[block row ib][rho] is zero for later blocks
-            const int kend = (ib + 1) * 15 - 30 * q4;  // columns of this quarter that can be non-zero
-            for (int r = 0; r < 15; ++r) {
-              const double  xj  = stage[r * n + rho4];
-              const double *row = stage + r * n + 30 * q4;
-#pragma unroll
-              for (int kk = 0; kk < 30; ++kk)
-                if (kk < kend) kinv[kk] = __builtin_fma(xj, row[kk], kinv[kk]);
-            }
-          }
-        }
-      }
-      __syncthreads();
-    }
     return s_flag != 0;
+    }
   };
   auto solveK = [&]() __attribute__((always_inline)) {
     if constexpr (FAST) {
-      // x~ = K^-1 rhs: one register mat-vec per lane quad (fused multiply-adds: this solve is not on the
-      // bit-exact path — the oracle factors K with a plain banded Cholesky).  s_xt is zero beyond n, kinv too.
-      // The result goes to s_cn.
-      const double *rhs = s_xt + 30 * (tid & 3);
-      double        acc = 0.0, acc1 = 0.0;  // two chains: a dependent fp64 FMA costs 8 cycles, an independent one 4
-#pragma unroll
-      for (int c0 = 0; c0 < 30; c0 += 16) {
-        double v[16];  // 8 (then 7) ds_read_b128 in flight
-#pragma unroll
-        for (int kk = 0; kk < 16; ++kk) v[kk] = c0 + kk < 30 ? rhs[c0 + kk] : 0.0;
-#pragma unroll
-        for (int kk = 0; kk < 16; kk += 2) {
-          if (c0 + kk < 30) acc = __builtin_fma(kinv[c0 + kk], v[kk], acc);
-          if (c0 + kk + 1 < 30) acc1 = __builtin_fma(kinv[c0 + kk + 1], v[kk + 1], acc1);
-        }
-      }
+      // x~ = K^-1 rhs as a register mat-vec WITHOUT reading the right-hand side 64 times per wave: lane (q, i) of wave
+      // w — q = lane >> 4 is the 16-lane DPP row, i = lane & 15 — owns K^-1[16 w + i][30 q .. 30 q + 29] and loads
+      // just rhs[30 q + i] and rhs[30 q + 16 + i]; entry kk of the quarter reaches the sixteen lanes of the row through
+      // the DPP broadcast of v_fmac_f64 (row_newbcast:kk reads lane kk of each row for src0): 30 fused multiply-adds, two
+      // LDS reads per lane instead of thirty (the product was bound by those reads: 123 KB per iteration).  The four
+      // quarter sums of a row meet through two cross-row exchanges.  (Fused multiply-adds: this solve is not on the
+      // bit-exact path — the oracle factors K with a plain banded Cholesky.)  s_xt is zero beyond n, kinv too.  The
+      // result goes to s_cn.
+      const int    tl = launder(tid), li = tl & 15, lq = (tl >> 4) & 3;
+      const double r0 = s_xt[30 * lq + li], r1 = s_xt[30 * lq + 16 + li];
+      double       acc = 0.0, acc1 = 0.0;  // two chains: a dependent fp64 FMA costs 8 cycles, an independent one 4
+#define QP_BC(A, R, KV, L) "v_fmac_f64_dpp " A ", " R ", " KV " row_newbcast:" #L " row_mask:0xf bank_mask:0xf\n\t"
+      asm("s_nop 1\n\t"  // (a VGPR written by the VALU needs two wait states before a DPP read)
+          QP_BC("%0", "%2", "%3", 0) QP_BC("%1", "%2", "%4", 1) QP_BC("%0", "%2", "%5", 2) QP_BC("%1", "%2", "%6", 3)
+          QP_BC("%0", "%2", "%7", 4) QP_BC("%1", "%2", "%8", 5) QP_BC("%0", "%2", "%9", 6) QP_BC("%1", "%2", "%10", 7)
+          : "+v"(acc), "+v"(acc1)
+          : "v"(r0), "v"(kinv[0]), "v"(kinv[1]), "v"(kinv[2]), "v"(kinv[3]), "v"(kinv[4]), "v"(kinv[5]), "v"(kinv[6]),
+            "v"(kinv[7]));
+      asm("s_nop 1\n\t"
+          QP_BC("%0", "%2", "%3", 8) QP_BC("%1", "%2", "%4", 9) QP_BC("%0", "%2", "%5", 10) QP_BC("%1", "%2", "%6", 11)
+          QP_BC("%0", "%2", "%7", 12) QP_BC("%1", "%2", "%8", 13) QP_BC("%0", "%2", "%9", 14) QP_BC("%1", "%2", "%10", 15)
+          : "+v"(acc), "+v"(acc1)
+          : "v"(r0), "v"(kinv[8]), "v"(kinv[9]), "v"(kinv[10]), "v"(kinv[11]), "v"(kinv[12]), "v"(kinv[13]), "v"(kinv[14]),
+            "v"(kinv[15]));
+      asm("s_nop 1\n\t"
+          QP_BC("%0", "%2", "%3", 0) QP_BC("%1", "%2", "%4", 1) QP_BC("%0", "%2", "%5", 2) QP_BC("%1", "%2", "%6", 3)
+          QP_BC("%0", "%2", "%7", 4) QP_BC("%1", "%2", "%8", 5) QP_BC("%0", "%2", "%9", 6) QP_BC("%1", "%2", "%10", 7)
+          : "+v"(acc), "+v"(acc1)
+          : "v"(r1), "v"(kinv[16]), "v"(kinv[17]), "v"(kinv[18]), "v"(kinv[19]), "v"(kinv[20]), "v"(kinv[21]),
+            "v"(kinv[22]), "v"(kinv[23]));
+      asm("s_nop 1\n\t"
+          QP_BC("%0", "%2", "%3", 8) QP_BC("%1", "%2", "%4", 9) QP_BC("%0", "%2", "%5", 10) QP_BC("%1", "%2", "%6", 11)
+          QP_BC("%0", "%2", "%7", 12) QP_BC("%1", "%2", "%8", 13)
+          : "+v"(acc), "+v"(acc1)
+          : "v"(r1), "v"(kinv[24]), "v"(kinv[25]), "v"(kinv[26]), "v"(kinv[27]), "v"(kinv[28]), "v"(kinv[29]));
+#undef QP_BC
       acc += acc1;
-      acc += dpp_quad(acc, 0xB1);  // lane ^ 1
-      acc += dpp_quad(acc, 0x4E);  // lane ^ 2
-      if (tid < 4 * n && (tid & 3) == 0) s_cn[tid >> 2] = acc;
+      acc += __shfl_xor(acc, 16, 64);  // the other quarter of this half
+      acc += __shfl_xor(acc, 32, 64);  // the other half
+      const int row = (tl >> 6) * 16 + li;
+      if (lq == 0 && row < n) s_cn[row] = acc;
     } else if (wave == 0) {
       for (int j = 0; j < n; ++j) {  // G y = b
         const double xj = s_xt[j] * s_ginv[j];
@@ -1150,7 +1287,9 @@ __device__ __forceinline__ void qp_solve_agent(const SogmPlannerParams &pp, cons
   };
 
   set_rho();
+  if constexpr (FAST) build_K1();
   bool chol_ok = factor();
+  const long long dbg_setup = wall_clock64() - dbg_t0;
   int  status = -2, iter = 0;
   if (!chol_ok) status = -7;
   if constexpr (FAST) {
@@ -1347,6 +1486,8 @@ __device__ __forceinline__ void qp_solve_agent(const SogmPlannerParams &pp, cons
       if (do_adapt) adapt_left = adapt_iv;
       if (do_check) check_left = check_iv;
       if (!do_adapt && !do_check) continue;  // (only when max_iter ended the chunk)
+      const long long dbg_c0 = wall_clock64();
+      ++dbg_ncheck;
       if constexpr (FAST) {
         fast_spill();
         fast_residuals();
@@ -1361,6 +1502,7 @@ __device__ __forceinline__ void qp_solve_agent(const SogmPlannerParams &pp, cons
         if (p_ok && d_ok) {
           status   = 1;
           finished = true;
+          dbg_check += wall_clock64() - dbg_c0;
           break;
         }
         if (ablate & 16) continue;  // profiling aid (ablation build only)
@@ -1368,9 +1510,11 @@ __device__ __forceinline__ void qp_solve_agent(const SogmPlannerParams &pp, cons
         if (!p_ok && primal_infeasible(1e-4)) {  // eps_prim_inf default
           status   = -3;
           finished = true;
+          dbg_check += wall_clock64() - dbg_c0;
           break;
         }
       }
+      dbg_check += wall_clock64() - dbg_c0;
       // adaptive rho after the termination test, on the same residual evaluation (osqp.c: update_info runs once);
       // the estimate reads the SCALED residuals and norms (auxil.c compute_rho_estimate, see the oracle)
       if (do_adapt) {
@@ -1379,6 +1523,8 @@ __device__ __forceinline__ void qp_solve_agent(const SogmPlannerParams &pp, cons
         double rho_new = rho_cur * sogm_det::sqrt_rn(pr_n / (du_n + 1e-10));
         rho_new        = rho_new < RHO_MIN ? RHO_MIN : (rho_new > 1e6 ? 1e6 : rho_new);
         if (rho_new > rho_cur * 5.0 || rho_new < rho_cur / 5.0) {
+          const long long dbg_r0 = wall_clock64();
+          ++dbg_nrefac;
           rho_cur  = rho_new;
           rinv_cur = 1.0 / rho_cur;
           set_rho();
@@ -1392,6 +1538,7 @@ __device__ __forceinline__ void qp_solve_agent(const SogmPlannerParams &pp, cons
             fast_rho();
             __syncthreads();
           }
+          dbg_refac += wall_clock64() - dbg_r0;
         }
       }
     }
@@ -1421,6 +1568,21 @@ __device__ __forceinline__ void qp_solve_agent(const SogmPlannerParams &pp, cons
   if (tid == 0) {
     out_status[agent] = status;
     out_iters[agent]  = iter;
+    if (ws.dbg) {
+      long long *o = ws.dbg + (size_t)agent * 16;
+      o[8]  = dbg_f1;  // factor(): block assembly | forward sweep | backward rows + K^-1 registers (all factorisations)
+      o[9]  = dbg_f2;
+      o[10] = dbg_f3;
+      o[11] = clock64() - dbg_clk0;  // shader clocks of the whole solve (o[0]: the same span in 10 ns ticks)
+      o[0] = wall_clock64() - dbg_t0;
+      o[1] = dbg_setup;
+      o[2] = dbg_refac;
+      o[3] = dbg_nrefac;
+      o[4] = dbg_check;
+      o[5] = dbg_ncheck;
+      o[6] = iter;
+      o[7] = (FAST ? 1 : 0) | (rows_in_lds ? 2 : 0);  // bit 0: register-resident iteration, bit 1: every row array in LDS
+    }
   }
 #undef gv
 #undef gc
