@@ -39,6 +39,8 @@ def parse():
     ap.add_argument("--no-deconflict", action="store_true", help="skip isSafeAfterOpt at the end of replan()")
     ap.add_argument("--cpu-agents", type=float, default=12.0, dest="cpu_agents",
                     help="cpu_baseline sample: seconds of wall time to spend on the CPU oracle")
+    ap.add_argument("--dense-ticks", type=int, default=8, dest="dense_ticks",
+                    help="ticks of the block that runs the DENSE clear inside the tick (kernels[dense clear].in_tick; 0 = skip)")
     ap.add_argument("--sustained", type=int, default=300,
                     help="ticks of the sustained-flight block after the timed region (0 = skip)")
     return ap.parse_args()
@@ -118,10 +120,65 @@ def cpu_baseline(pop, spec, scene, n_agents_sample):
             nxt += cores
     dt = time.time() - t0
     n = len(oks)
+    # single-thread latency per stage (the reference prints the same split, baseline.cpp:286,380,435):
+    # a few agents of tick 0, one after the other, nothing else running on the host
+    lat = {"sogm_update": [], "astar": [], "corridor": [], "qp": []}
+    for a in range(min(A, 5)):
+        t1 = time.perf_counter()
+        g = orc.update_gt(spec, scene["cloud"], cyl, len(scene["cylinders"]), scene["poses"][a])
+        orc.project_neighbours(spec, g, recs, A, a, body, scene["poses"][a], scene["stamps"][a])
+        t2 = time.perf_counter()
+        pva = np.concatenate([scene["starts"][a], np.zeros(6)])
+        w = orc.astar_search(spec, ap, g, scene["poses"][a], pva, scene["goals"][a], 0.02, pp.corridor_tau)
+        t3 = time.perf_counter()
+        lat["sogm_update"].append(t2 - t1)
+        lat["astar"].append(t3 - t2)
+        if w["ret"] == 0:
+            continue
+        cc = orc.corridor_generate(spec, pp, g, scene["poses"][a], float(scene["stamps"][a]), pva,
+                                   float(scene["stamps"][a]) + 0.02, w["route"])
+        t4 = time.perf_counter()
+        lat["corridor"].append(t4 - t3)
+        M = cc["npoly"]
+        if M <= 0:
+            continue
+        goal = np.concatenate([cc["goal"], np.zeros(3)])
+        orc.qp_solve(pva, goal, [pp.corridor_tau] * M, cc["polys"], cc["nfaces"], pp.max_faces, pp.opt_max_vel,
+                     pp.opt_max_acc, qs)
+        lat["qp"].append(time.perf_counter() - t4)
+        del g
+    stages = {k: (float(np.median(v)) * 1e3 if v else None) for k, v in lat.items()}
+    stages["what"] = (f"median single-thread latency in ms over {len(lat['sogm_update'])} agents of tick 0, stage by stage "
+                      "(SOGM update = fill + marks + overlay of a 640 MB grid; the GPU's per-agent stage times are chain_ms)")
     return {"value": n / dt, "unit": "replans/s", "cores": cores, "host_cores": os.cpu_count(), "kind": "port",
+            "stages_ms": stages,
             "sample": f"{n} agent-replans of tick 0 (SOGM update + overlay + A* + corridors + QP) of the same "
                       f"{spec.L}x{spec.W}x{spec.H}x{spec.T} workload, {cores} threads, "
                       f"{sum(oks)}/{n} succeeded, {dt:.1f} s wall"}
+
+
+def flow_chain(pop, sw):
+    """Per-agent stage times of the LAST dataflow replan (device timestamps, sogm_debug_flow_times): how the tick runs
+    the stages — chained per agent — and which agent's chain ended it.  Synchronises."""
+    import ctypes as C
+    import numpy as np
+    A = sw.A_loc
+    ts = np.zeros((A, 8), np.int64)
+    pop.lib().sogm_debug_flow_times(sw.planner._p, ts.ctypes.data_as(C.c_void_p))
+    if not ts[:, 6].any():
+        return None  # (the grouped-stream replan keeps no per-agent stamps)
+    t0 = ts[:, 7].min() if ts[:, 7].min() > 0 else ts[:, 0].min()
+    ms = (ts[:, :7] - t0) / 1e5  # 100 MHz ticks -> ms
+    d = lambda a, b: ms[:, b] - ms[:, a]
+    crit = int(np.argmax(ms[:, 6]))
+    return {"astar_mean": float(d(0, 1).mean()), "astar_max": float(d(0, 1).max()),
+            "corridor_mean": float(d(2, 3).mean()), "corridor_max": float(d(2, 3).max()),
+            "qp_mean": float(d(4, 5).mean()), "qp_max": float(d(4, 5).max()),
+            "finish_mean": float(d(5, 6).mean()), "chain_mean": float(ms[:, 6].mean()), "chain_end": float(ms[:, 6].max()),
+            "critical_agent": crit,
+            "critical_chain": {"astar": float(d(0, 1)[crit]), "corridor": float(ms[crit, 3] - ms[crit, 1]),
+                               "qp": float(ms[crit, 5] - ms[crit, 3]), "finish": float(d(5, 6)[crit])},
+            "what": "device timestamps of the dataflow replan's persistent kernels, first search resident = 0"}
 
 
 def main():
@@ -166,19 +223,25 @@ def main():
     sw.map.sparse_reset_state()  # restart the reset statistics: the timed region's alone are reported
     # only the rated kernel (slot 0, and its two-part form's slot 6) is timed inside the timed region: each timed launch
     # costs two event records on its stream, and the stamp / overlay / planner launches are on the tick's critical path
-    sw.map.set_profiling(slots=(0, 6))
+    sw.map.set_profiling(slots=(0, 6, pop._abi.PROF_EXCHANGE))
+    sw.map.map_traffic(reset=True)
     t0 = time.perf_counter()
     oks = []
     for _ in range(args.steps):
         oks.append(sw.step())  # a copy of this tick's ok flags (device tensor, no host sync)
     barrier()
     dt = time.perf_counter() - t0
+    dt_local = dt
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     n_ok = int(torch.stack(oks).sum().item())  # over ALL timed ticks
     flow_code, flow_failed = sw.planner.flow_failures()  # after the barrier: every timed tick has completed
+    if dist is not None:  # on every rank: one failed rank fails the line
+        t = torch.tensor([flow_failed], dtype=torch.int64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        flow_failed = int(t.item())
     if flow_failed:
         raise SystemExit(f"bench.py: {flow_failed} tick(s) of the dataflow replan timed out on the device "
                          f"(code {flow_code}): the timed region is invalid")
@@ -192,14 +255,15 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         n_ok = int(t[0].item())
         outcomes = dict(zip(sorted(outcomes), [int(v) for v in t[1:].tolist()]))
-    # The roofline kernel, launch by launch, INSIDE the timed region: the library records a HIP event pair around
-    # every k_clear_slabs launch on the stream it is launched on (the side stream in the pipelined modes) and keeps
-    # one pair per launch, so nothing synchronises between ticks (sogm_profile_read_all).
+    # The rated kernel, launch by launch, INSIDE the timed region: the library records a HIP event pair around every
+    # reset (and every all-gather) on the stream it is launched on and keeps one pair per launch, so nothing
+    # synchronises between ticks (sogm_profile_read_all).
     import numpy as np
     planner = importlib.import_module("pred-occ-planner_amd.planner")
     per_slot = {k: np.array(sw.map.profile_read_all(k)) for k in range(pop._abi.PROF_N)}
-    # sparse reset (the default): the log of the grid the last tick built = what the next reset will read and zero
-    sparse = sw.map.sparse_reset_state()
+    moved = sw.map.map_traffic(reset=True)      # device-side counts of the timed region: what the resets and stamps moved
+    sparse = sw.map.sparse_reset_state()        # (after it: this call restarts the reset's own counters)
+    chain = flow_chain(pop, sw)                 # the last timed tick's per-agent stage times (dataflow replan)
     sw.map.set_profiling(True)  # restart the rings for the stage pass below
     # stage pass on the state of the last tick (map must be live: rebuild it without the pre-clear)
     overlap_mode = sw.overlap_mode
@@ -210,7 +274,8 @@ def main():
     pva = torch.where(valid.bool().unsqueeze(1), pva, sw.hover).contiguous()
     poses_ = pva[:, :3].to(torch.float32).contiguous()
     sw.map.updateMap(sw.dev["cloud"], sw.dev["cloud_range"], sw.dev["cylinders"], sw.dev["n_cyl"], poses_, stamps)
-    stamp_ms = float(sw.map.profile_read()[1])  # the stamp as the tick runs it (with the mark log)
+    stamp_ms = float(sw.map.profile_read()[1])  # the stamp as the tick runs it (with the mark log), machine to itself
+    stamp_moved = sw.map.map_traffic(reset=True)
     if sparse["enabled"]:
         sw.map.set_sparse_reset(False)  # the stand-alone figure below is the DENSE clear's (first ticks, dense writers)
     standalone_clear_ms = []
@@ -229,70 +294,97 @@ def main():
         avg[0] += avg[6]  # the clear of one grid = two launches (narrow head + full-width rest): one clear = both
     avg[1:3] = ms_stage[1:3]  # stamp / overlay: the stage pass's launches (not timed inside the timed region)
     avg[3:6] = ms_stage[3:6]  # planner stages: single-stage entry points after the timed region (inside sogm_replan
-    #                           they run concurrently on per-group streams and cannot be timed one by one)
-    grid_bytes = sw.map.grid_bytes()  # V * T * 4 bytes x agents of this rank = algorithmic bytes / launch
-    # HBM traffic of the roofline kernel: PMC counters cannot be read from inside this process; the figure comes
-    # from the committed rocprofv3 --pmc passes of THIS command (FETCH_SIZE and WRITE_SIZE in separate runs,
-    # tools/make_profile.sh) and is only reported when it was collected on the same workload (same bytes / launch)
-    traffic, traffic_source = None, None
-    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    #                           they run per agent in persistent kernels and cannot be timed one by one: chain_ms)
+    grid_bytes = sw.map.grid_bytes()  # V * T * 4 bytes x agents of this rank = SURVEY 8(d)'s bytes per SOGM build
+    PEAK = 8000.0  # GB/s, MI355X HBM3E (MI355X_MICROARCH guide)
+
+    def rate(nbytes, ms):
+        gbps = nbytes / (ms * 1e-3) / 1e9 if ms and ms > 0 else None
+        return gbps, (gbps / PEAK if gbps is not None else None)
+
+    def committed(name):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
-                pmc = json.load(f)
-            if pmc["algorithmic_bytes_per_launch"] == grid_bytes:
-                traffic, traffic_source = pmc["bytes_per_launch"], f"profiles/{name} (committed rocprofv3 --pmc passes, not measured in this run)"
-                break
-        except (OSError, KeyError, ValueError):
-            pass
-    standalone = {"kernel": "k_clear_slabs (the dense clear, full width, machine to itself; stage pass after the timed region)",
-                  "launch_ms": standalone_clear_ms,
-                  "bytes_per_launch": grid_bytes,
-                  "achieved": grid_bytes / (min(standalone_clear_ms) * 1e-3) / 1e9,
-                  "frac": grid_bytes / (min(standalone_clear_ms) * 1e-3) / 1e9 / 8000.0}
-    if sparse["enabled"] and sparse["resets"] > 0:
-        # The map is no longer rebuilt by filling V x T cells: the reset zeroes the 32-byte sectors named by the mark
-        # log (DESIGN 3.1 "Sparse reset").  The kernel is rated on the bytes it has to move — 4 B read and the
-        # 32-byte sector written per log entry (the PMC traffic says what moved) — and SURVEY 8(d)'s dense figure is given beside it for comparison.
-        entries = int(sparse["entries_per_reset"])  # mean over the resets of the timed region
-        reset_bytes = entries * 36
-        achieved = reset_bytes / (avg[0] * 1e-3) / 1e9
-        rt = None
-        try:
-            with open(os.path.join(ROOT, "profiles", "r03_pmc_reset.json")) as f:
-                pmc = json.load(f)
-            rt = {"bytes_per_entry": pmc["bytes_per_entry"], "bytes_per_launch_scaled": pmc["bytes_per_entry"] * entries,
-                  "source": "profiles/r03_pmc_reset.json (committed rocprofv3 --pmc passes of tools/diag_reset_pmc.py, "
-                            "scaled by this run's entry count; not measured in this run)"}
-        except (OSError, KeyError, ValueError):
-            pass
-        roofline = {"bound": "hbm",
-                    "kernel": "k_reset_sectors: the sparse reset of the SOGM (zeroes the logged 32-byte sectors of the grid "
-                              "the update swapped out; side stream, under the replan)",
-                    "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                    "traffic": rt["bytes_per_launch_scaled"] if rt else None,
-                    "traffic_source": rt["source"] if rt else None,
+                return json.load(f)
+        except (OSError, ValueError):
+            return None
+
+    # ---- the dense clear: the kernel that does SURVEY 8(d)'s work (first use of a grid, dense writers, SOGM_SPARSE_RESET=0)
+    sa_gbps, sa_frac = rate(grid_bytes, min(standalone_clear_ms))
+    pmc_dense = committed("r04_pmc_traffic.json") or committed("r03_pmc_traffic.json")
+    k_dense = {"kernel": "k_clear_slabs / k_clear_chunks (dense clear: V*T*4 B per agent-update, SURVEY 8(d))",
+               "bytes_per_launch": grid_bytes,
+               "standalone": {"where": "full width, machine to itself, stage pass after the timed region",
+                              "launch_ms": standalone_clear_ms, "achieved": sa_gbps, "frac": sa_frac},
+               "in_tick": None,  # filled below (a block of ticks with the sparse reset off)
+               "traffic": pmc_dense["bytes_per_launch"] if pmc_dense and pmc_dense.get("algorithmic_bytes_per_launch") == grid_bytes else None,
+               "traffic_source": "committed rocprofv3 --pmc passes (profiles/), not measured in this run"}
+    # ---- the stamp (k_cull_cylinders + k_stamp_bits + k_stamp_marks, stage pass: machine to itself)
+    marks, s_entries = int(stamp_moved["stamp_marks"]), int(stamp_moved["stamp_entries"])
+    stamp_alg = 4 * marks + 4 * s_entries
+    st_gbps, st_frac = rate(stamp_alg, stamp_ms)
+    pmc_stamp = committed("r04_pmc_stamp.json")
+    k_stamp = {"kernel": "k_cull_cylinders + k_stamp_bits + k_stamp_marks (the stamp; stage pass after the timed region, "
+                         "machine to itself — inside the tick it runs as k_prestamp_flow under the replan)",
+               "launch_ms": stamp_ms, "marks": marks, "log_entries": s_entries,
+               "algorithmic_bytes": stamp_alg, "achieved": st_gbps, "frac": st_frac,
+               "note": "algorithmic bytes = 4 B per marked cell + 4 B per log entry; a mark costs HBM a 32-byte sector "
+                       "unless its x-neighbours share it: traffic / algorithmic is the write amplification",
+               "traffic": (pmc_stamp or {}).get("bytes_per_launch"),
+               "write_amplification": ((pmc_stamp["bytes_per_launch"] / pmc_stamp["algorithmic_bytes_per_launch"])
+                                       if pmc_stamp and pmc_stamp.get("algorithmic_bytes_per_launch") else None),
+               "traffic_source": "profiles/r04_pmc_stamp.json (committed rocprofv3 --pmc passes, not measured in this run)"
+                                 if pmc_stamp else None}
+    if sparse["enabled"] and moved["resets"] > 0:
+        # The map is no longer rebuilt by filling V x T cells: the reset zeroes the lines named by the mark log (DESIGN
+        # 3.1 "Sparse reset").  Rated on what it MOVED in this run, counted on the device: 4 B read per log entry + the
+        # bytes of the stores it issued (repeated and out-of-grid entries store nothing).
+        n_res = int(moved["resets"])
+        entries = moved["reset_entries"] / n_res
+        zeroed = moved["reset_bytes_zeroed"] / n_res
+        reset_bytes = 4.0 * entries + zeroed
+        achieved, frac = rate(reset_bytes, avg[0])
+        pmc = committed("r04_pmc_reset.json")
+        traffic = pmc["bytes_per_entry"] * entries if pmc and "bytes_per_entry" in pmc else None
+        k_reset = {"kernel": "k_reset_sectors (sparse reset of the grid the update swapped out; side stream, under the replan's QP stage)",
+                   "avg_launch_ms": float(avg[0]), "launches_timed": n_clear, "log_entries_per_launch": entries,
+                   "bytes_zeroed_per_launch": zeroed, "bytes_per_launch": reset_bytes, "achieved": achieved, "frac": frac,
+                   "traffic": traffic,
+                   "traffic_frac": (traffic / (avg[0] * 1e-3) / 1e9 / PEAK) if traffic else None,
+                   "traffic_source": "profiles/r04_pmc_reset.json: rocprofv3 --pmc FETCH_SIZE (doubled, gfx950 streaming-read "
+                                     "correction) + WRITE_SIZE per log entry, scaled by this run's entry count" if traffic else None}
+        roofline = {"bound": "hbm", "kernel": k_reset["kernel"],
+                    "achieved": achieved, "peak": PEAK, "unit": "GB/s", "frac": frac,
+                    "traffic": traffic, "traffic_source": k_reset["traffic_source"],
                     "bytes_per_launch": reset_bytes, "log_entries_per_launch": entries,
-                    "avg_launch_ms": float(avg[0]), "launches_timed": n_clear, "sparse_resets": int(sparse["resets"]),
+                    "bytes_zeroed_per_launch": zeroed,
+                    "avg_launch_ms": float(avg[0]), "launches_timed": n_clear, "sparse_resets": n_res,
+                    "bytes_counted": "on the device in this run (sogm_map_traffic): 4 B x log entries read + 16 B x stores issued",
                     "timed_where": "HIP events on the reset's stream around every reset of the timed region",
-                    "note": "no kernel of the tick is HBM-bound any more: the tick is bound by the per-agent A* -> "
-                            "corridor -> QP chain (stage_ms); this is the largest streaming kernel left",
-                    "dense_equivalent": {"bytes": grid_bytes, "rate_GBps": grid_bytes / (avg[0] * 1e-3) / 1e9,
-                                         "note": "SURVEY 8(d)'s V*T*4 B per agent-update divided by this launch: above "
-                                                 "the HBM peak because the fill is not executed"},
-                    "standalone": standalone}
+                    "note": "no kernel of the tick is HBM-bound: the tick is bound by the per-agent A* -> corridor -> QP "
+                            "chain (chain_ms); the reset is the largest streaming kernel left, latency-bound scattered "
+                            "32-byte stores; SURVEY 8(d)'s V*T*4 B fill is not executed (dense_equivalent), the kernel "
+                            "that does execute it is kernels[dense clear]",
+                    "dense_equivalent": {"bytes": grid_bytes, "rate_GBps": grid_bytes / (avg[0] * 1e-3) / 1e9},
+                    "standalone": dict(k_dense["standalone"], kernel=k_dense["kernel"], bytes_per_launch=grid_bytes),
+                    "kernels": [k_reset, k_stamp, k_dense]}
     else:
-        achieved = grid_bytes / (avg[0] * 1e-3) / 1e9
+        achieved, frac = rate(grid_bytes, avg[0])
+        k_dense["in_tick"] = {"avg_launch_ms": float(avg[0]), "launches_timed": n_clear, "achieved": achieved, "frac": frac}
         roofline = {"bound": "hbm",
                     "kernel": "the SOGM clear (voxel update): k_clear_chunks narrow + wide launches in the pooled modes, "
                               "k_clear_slabs otherwise", "achieved": achieved,
-                    "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
-                    "traffic_source": traffic_source,
+                    "peak": PEAK, "unit": "GB/s", "frac": frac, "traffic": k_dense["traffic"],
+                    "traffic_source": k_dense["traffic_source"],
                     "bytes_per_launch": grid_bytes, "avg_launch_ms": float(avg[0]),
                     "launches_timed": n_clear,
                     "timed_where": "HIP events on the clear's stream around the clear (both of its launches), every clear of the timed region",
-                    # avg_launch_ms is the launch as it runs inside the tick (a narrow clear sharing the machine
-                    # with the planner kernels); the same kernel at full width with the machine to itself:
-                    "standalone": standalone}
+                    "standalone": dict(k_dense["standalone"], kernel=k_dense["kernel"], bytes_per_launch=grid_bytes),
+                    "kernels": [k_stamp, k_dense]}
+    exchange_kind = "abi" if sw.exchange.active else "torch" if sw.distributed else "local"
+    if world > 1 and exchange_kind != "abi":
+        raise SystemExit(f"bench.py: {world} ranks but the trajectory exchange is '{exchange_kind}' "
+                         f"({sw.exchange.fallback_reason}): the N > 1 line must measure the all-gather behind the C ABI")
     out = {
         "metric": "replans/sec (SOGM update + QP: full replan = SOGM update + A* + corridors + QP + deconfliction), "
                   f"{sw.A_loc}-agent batch per GPU, {spec.L}x{spec.W}x{spec.H}x{spec.T} voxel grid; aggregate over all agents",
@@ -316,9 +408,9 @@ def main():
                    # where the timed replans ended + capacity limits hit (sogm_planner_counters)
                    "outcomes": outcomes,
                    "parallelism": f"agents sharded x{world}, 1 all-gather/tick",
-                   # which all-gather ran: "abi" = sogm_traj_allgather (RCCL behind the C ABI), "torch" =
-                   # torch.distributed's (also RCCL; the fallback — reason given), "local" = one process
-                   "exchange": ("abi" if sw.exchange.active else "torch" if sw.distributed else "local"),
+                   "tick_overlap": "lock-step (every agent's tick k ends before any agent's tick k + 1 starts)",
+                   # which all-gather ran: "abi" = sogm_traj_allgather (RCCL behind the C ABI), "local" = one process
+                   "exchange": exchange_kind,
                    "exchange_fallback_reason": sw.exchange.fallback_reason,
                    "sogm_grids_per_agent": overlap_mode if overlap_mode >= 2 else 1,
                    "sogm_reset": "sparse (logged 32-byte sectors)" if sparse["enabled"] else "dense clear",
@@ -328,13 +420,52 @@ def main():
                                   else "at the start of the tick")},
         "replans_per_s_per_agent": sw.A_tot * args.steps / dt / sw.A_tot,
         "stage_ms": {"clear": avg[0], "stamp": avg[1], "splat": avg[2], "astar": avg[3], "corridor": avg[4],
-                     "qp": avg[5]},
+                     "qp": avg[5],
+                     "what": "clear: the reset inside the timed region; the rest: ONE grouped launch per stage over all "
+                             "agents after the timed region (sogm_astar_search / sogm_corridor_generate / "
+                             "sogm_bezier_qp_solve), i.e. each stage's slowest agent — NOT how the tick runs them "
+                             "(per agent, chained: chain_ms)"},
+        "chain_ms": chain,
         "roofline": roofline,
     }
+    if world > 1:  # the first N > 1 run verifies itself: what RCCL says, every rank's clock, the collective's own duration
+        info = sw.exchange.info()
+        mine = torch.tensor([dt_local / args.steps * 1e3, float(info["ranks"]),
+                             float(per_slot[pop._abi.PROF_EXCHANGE].mean()) if len(per_slot[pop._abi.PROF_EXCHANGE]) else -1.0],
+                            dtype=torch.float64, device="cuda")
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        out["multi_gpu"] = {"rccl_ranks": info["ranks"], "rccl_ranks_per_rank": [int(t[1].item()) for t in allr],
+                            "rank_ms_per_step": [float(t[0].item()) for t in allr],
+                            "allgather_ms_per_rank": [float(t[2].item()) for t in allr],
+                            "allgather_launches_timed": int(len(per_slot[pop._abi.PROF_EXCHANGE])),
+                            "allgather_bytes_per_rank": sw.A_loc * pop._abi.TRAJ_RECORD_BYTES,
+                            "exchange": exchange_kind}
+        if any(int(t[1].item()) != world for t in allr):
+            raise SystemExit(f"bench.py: ncclCommCount != {world} on some rank: {out['multi_gpu']}")
+    # ---- the dense clear INSIDE the tick (sparse reset off): the fill of SURVEY 8(d) as the tick used to run it
+    sw.map.set_overlap_clear(overlap_mode != 0, grids=(overlap_mode if overlap_mode >= 2 else 1))
+    if sparse["enabled"] and args.dense_ticks > 0:
+        sw.map.set_profiling(False)
+        for _ in range(3):  # every grid of the pool once through the dense path
+            sw.step()
+        barrier()
+        sw.map.set_profiling(slots=(0, 6))
+        t1 = time.perf_counter()
+        for _ in range(args.dense_ticks):
+            sw.step()
+        barrier()
+        dense_tick_ms = (time.perf_counter() - t1) / args.dense_ticks * 1e3
+        d0, d6 = np.array(sw.map.profile_read_all(0)), np.array(sw.map.profile_read_all(6))
+        ms = float(d0.mean()) + (float(d6.mean()) if len(d6) else 0.0) if len(d0) else None
+        g_, f_ = rate(grid_bytes, ms)
+        k_dense["in_tick"] = {"avg_launch_ms": ms, "launches_timed": int(len(d0)), "achieved": g_, "frac": f_,
+                              "tick_ms": dense_tick_ms,
+                              "where": f"{args.dense_ticks} ticks with the sparse reset off (sogm_set_sparse_reset 0), after the timed region"}
+        sw.map.set_profiling(False)
     if args.sustained > 0:
         # sustained flight: the 20-step figure covers the first seconds (agents still far apart); keep flying —
         # the swarm converges on the centre, searches get longer — and time every tick (host-synchronised)
-        sw.map.set_overlap_clear(overlap_mode != 0, grids=(overlap_mode if overlap_mode >= 2 else 1))
         sw.map.set_profiling(False)
         if sparse["enabled"]:
             sw.map.set_sparse_reset(True)
@@ -342,12 +473,15 @@ def main():
                 sw.step()
         sw.planner.counters(reset=True)
         tick_ms, oks2 = [], []
+        slowest = None
         barrier()
         for _ in range(args.sustained):
             t1 = time.perf_counter()
             oks2.append(sw.step())
             torch.cuda.synchronize()
             tick_ms.append((time.perf_counter() - t1) * 1e3)
+            if slowest is None or tick_ms[-1] > slowest["tick_ms"]:  # (between two timed ticks: not in either)
+                slowest = dict(flow_chain(pop, sw), tick=sw.tick - 1, tick_ms=tick_ms[-1])
         tm = np.array(tick_ms)
         n_ok2 = int(torch.stack(oks2).sum().item())
         out["sustained"] = {"ticks": args.sustained, "flight_seconds": args.sustained * driver.TICK_PERIOD,
@@ -358,8 +492,13 @@ def main():
                             "value_ok": n_ok2 * world / (tm.sum() * 1e-3),
                             "replans_ok_fraction": n_ok2 / float(sw.A_loc * args.sustained),
                             "outcomes_rank0": sw.planner.counters(reset=False),
+                            # the slowest tick accounted for: its critical agent's chain (device timestamps) — the part of
+                            # tick_ms the chain does not cover is host / launch time of that tick
+                            "slowest_tick": slowest,
                             "note": "every tick host-synchronised (no overlap between ticks); rank 0's clock"}
-    if args.sustained > 0:
+        flow_code, flow_failed = sw.planner.flow_failures()
+        if flow_failed:
+            raise SystemExit(f"bench.py: {flow_failed} tick(s) of the sustained block timed out on the device (code {flow_code})")
         c2 = sw.planner.counters(reset=True)
         if c2["corridor_capacity"] + c2["pieces_capacity"] + c2["deconflict_capacity"]:
             raise SystemExit(f"bench.py: capacity limits hit during the sustained block ({c2})")

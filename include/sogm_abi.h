@@ -204,6 +204,11 @@ int sogm_set_sparse_reset(sogm_ctx *ctx, int enable, int log_capacity);
  * launch, mean KiB zeroed per such launch (the stores the reset kernel issued, counted on the device)}.
  * Synchronises. */
 int sogm_sparse_reset_state(sogm_ctx *ctx, int32_t *out_host);
+/* What the map kernels moved since the last reset of these counters (device-side counts, for the roofline figures of
+ * bench.py); host out[6]: {resets through the mark logs, log entries those resets read, bytes they zeroed, stamps
+ * launched (sogm_update_gt* and pre-stamps), marks (cells set to 1) the stamps wrote, log entries the stamps
+ * appended}.  Counted while the sparse reset is on.  reset != 0 zeroes the counters.  Synchronises. */
+int sogm_map_traffic(sogm_ctx *ctx, int64_t *out_host, int reset);
 /* How the CURRENT grid (the one queries and planning read) came to be; host out[4]: {pool slot, resets of that slot
  * through its mark log since the pool was built, dense clears of that slot (fake_particle_risk_voxel.cpp:107-108's
  * fill), 1 if the grid was built by the previous sogm_replan's pre-stamp and adopted by sogm_update_prestamped}.
@@ -224,7 +229,8 @@ enum {
   SOGM_PROF_CORRIDOR = 4,
   SOGM_PROF_QP = 5,
   SOGM_PROF_CLEAR_HEAD = 6, /* single-grid pipelining: the narrow first part of a two-part clear (slot 0 = the rest) */
-  SOGM_PROF_N = 7
+  SOGM_PROF_EXCHANGE = 7, /* sogm_traj_allgather: the ncclAllGather on the exchange stream */
+  SOGM_PROF_N = 8
 };
 int sogm_set_profiling(sogm_ctx *ctx, int enable);
 /* The same for a choice of slots (bit k of slot_mask = slot k; 0 = off): every timed launch costs two event records on
@@ -785,6 +791,9 @@ int   sogm_comm_unique_id(char *out_id_host /* [SOGM_COMM_ID_BYTES] */);
 int   sogm_comm_create(const char *id_host, int rank, int n_ranks, int device, sogm_comm **out);
 void  sogm_comm_destroy(sogm_comm *comm);
 void *sogm_comm_handle(sogm_comm *comm);
+/* what RCCL itself says about the communicator: host out[2] = {ncclCommCount, ncclCommUserRank} (a multi-GPU bench line
+ * reports them: a run that silently fell back to fewer ranks cannot print the requested N) */
+int   sogm_comm_info(sogm_comm *comm, int32_t *out_host);
 
 #ifdef __cplusplus
 }

@@ -25,7 +25,7 @@ SOGM_ERR_CAPACITY = -4
 SOGM_ERR_STATE = -5
 SOGM_ERR_COMM = -6
 SOGM_COMM_ID_BYTES = 128
-PROF_CLEAR, PROF_STAMP, PROF_SPLAT, PROF_ASTAR, PROF_CORRIDOR, PROF_QP, PROF_CLEAR_HEAD, PROF_N = range(8)
+PROF_CLEAR, PROF_STAMP, PROF_SPLAT, PROF_ASTAR, PROF_CORRIDOR, PROF_QP, PROF_CLEAR_HEAD, PROF_EXCHANGE, PROF_N = range(9)
 
 COUNTER_NAMES = ("replan_ok", "fail_search", "fail_corridor", "fail_qp", "fail_unsafe", "corridor_capacity",
                  "pieces_capacity", "deconflict_capacity")
@@ -123,6 +123,7 @@ PROTOTYPES = {
     "sogm_set_sparse_reset": (_i, [_vp, _i, _i]),
     "sogm_sparse_reset_state": (_i, [_vp, _vp]),
     "sogm_grid_history": (_i, [_vp, _vp]),
+    "sogm_map_traffic": (_i, [_vp, _vp, _i]),
     "sogm_set_body_particles": (_i, [_vp, C.POINTER(C.c_double), _i]),
     "sogm_set_overlap_clear": (_i, [_vp, _i]),
     "sogm_set_profiling": (_i, [_vp, _i]),
@@ -175,6 +176,7 @@ PROTOTYPES = {
     "sogm_comm_create": (_i, [C.c_char_p, _i, _i, _i, C.POINTER(_vp)]),
     "sogm_comm_destroy": (None, [_vp]),
     "sogm_comm_handle": (_vp, [_vp]),
+    "sogm_comm_info": (_i, [_vp, _vp]),
     "sogm_filter_point_cloud": (_i, [_vp, _vp, _vp, C.c_float, _i, _vp, _vp, _vp]),
     "sogm_filter_reserve": (_i, [_vp, _i]),
     "sogm_dsp_create": (_i, [_vp, C.POINTER(SogmDspParams), _vp, _vp, _i, _vp, _i, _i, C.POINTER(_vp)]),

@@ -374,7 +374,9 @@ struct sogm_ctx {
   unsigned      *d_log[3];         // [A][log_cap] per pool slot (slot 0 = the only grid without a pool), lazy
   unsigned      *d_log_n[3];       // [A] entries appended since the slot's last reset (beyond log_cap: overflow)
   int            tracked[3];
-  unsigned long long *d_reset_stat;  // {entries read, launches, lines zeroed} of k_reset_sectors since the last state query
+  unsigned long long *d_reset_stat;  // [8]: {entries read, launches, bytes zeroed, -} of k_reset_sectors since the last
+                                     // state query; {marks written, entries logged, -, -} of the stamp (sogm_map_traffic)
+  long long      n_stamps;           // stamps launched since the last sogm_map_traffic reset (host count)
   // history of each pool slot since the pool was (re)built: resets through its log, dense clears (host-side launch
   // counts), and whether the CURRENT grid was built by a replan's pre-stamp (sogm_grid_history: lets a parity test
   // assert that the grid it compares went through k_reset_sectors and k_prestamp_flow)
@@ -509,6 +511,7 @@ struct MarkLog {
   unsigned *entries;  // [A][cap]
   unsigned *n;        // [A]
   int       cap;
+  unsigned long long *stat;  // {marks written by the stamp, entries it logged} (sogm_map_traffic), or null
 };
 inline int cur_slot(const sogm_ctx *c) { return c->n_pool ? c->cur_idx : 0; }
 MarkLog    mark_log(sogm_ctx *c, int slot);

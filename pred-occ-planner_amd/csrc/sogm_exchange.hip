@@ -140,6 +140,19 @@ void sogm_comm_destroy(sogm_comm *c) {
 
 void *sogm_comm_handle(sogm_comm *c) { return c ? (void *)c->comm : nullptr; }
 
+int sogm_comm_info(sogm_comm *c, int32_t *out) {
+  if (!c || !out) return SOGM_ERR_INVALID_ARG;
+  RcclApi *a = rccl();
+  if (!a) return SOGM_ERR_COMM;
+  int          n = -1, r = -1;
+  ncclResult_t e = a->CommCount(c->comm, &n);
+  if (e == ncclSuccess) e = a->CommUserRank(c->comm, &r);
+  if (e != ncclSuccess) return rccl_fail("ncclCommCount / ncclCommUserRank", e);
+  out[0] = n;
+  out[1] = r;
+  return SOGM_OK;
+}
+
 int sogm_traj_allgather(sogm_ctx *ctx, void *nccl_comm, const SogmTrajRecord *local_records, int n_local,
                         SogmTrajRecord *all_records, void *stream) {
   if (!ctx || !nccl_comm || !local_records || !all_records || n_local <= 0) return SOGM_ERR_INVALID_ARG;
@@ -166,8 +179,10 @@ int sogm_traj_allgather(sogm_ctx *ctx, void *nccl_comm, const SogmTrajRecord *lo
     SOGM_HIP_CHECK(hipStreamWaitEvent(ctx->xstream, ctx->ev_xin, 0));
   }
   ctx->records_final_valid = 0;
+  sogm::prof_begin(ctx, SOGM_PROF_EXCHANGE, ctx->xstream);
   ncclResult_t r = a->AllGather(local_records, all_records, (size_t)n_local * sizeof(SogmTrajRecord), ncclUint8,
                                 (ncclComm_t)nccl_comm, ctx->xstream);
+  sogm::prof_end(ctx, SOGM_PROF_EXCHANGE, ctx->xstream);
   // (recorded even when the collective failed: consumers stay ordered behind the producers on the exchange stream
   //  instead of behind the previous collective's event)
   SOGM_HIP_CHECK(hipEventRecord(ctx->ev_xdone, ctx->xstream));

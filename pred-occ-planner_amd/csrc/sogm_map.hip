@@ -374,6 +374,7 @@ __device__ __forceinline__ void stamp_marks_trips(const GridGeom &g, void *__res
   char          *base = reinterpret_cast<char *>(grid) + (size_t)agent * g.T * (size_t)g.V * (g.half ? 2 : 4);
   unsigned      *mask = bits + (size_t)agent * words_per_agent;
   const int      lane = threadIdx.x;
+  unsigned n_marks = 0, n_logged = 0;  // this lane's marks, the wave's log entries (statistics: two atomics per call)
   // a trip covers 256 mask words (8192 voxels): every lane loads four, the set bits of the whole trip are numbered
   // by a wave scan of the pop counts, and lane t of chunk b takes set bit b + t — dense lanes whatever the
   // occupancy pattern, and neighbouring lanes still hold neighbouring voxels (words_per_agent is padded to 256)
@@ -419,7 +420,10 @@ __device__ __forceinline__ void stamp_marks_trips(const GridGeom &g, void *__res
         v = (w0 + own * 4 + sel) * 32 + __builtin_ctz(wv);
       }
       // slice 0 (:114), then the occupied voxel's future marks (:121-170): GT velocity of the first matching record
-      if (active) cell_st(base, (size_t)v, 1.0F, g.half);
+      if (active) {
+        cell_st(base, (size_t)v, 1.0F, g.half);
+        ++n_marks;
+      }
       float cx, cy, cz;
       g.corner_of(v, pose, cx, cy, cz);
       float vx = 0.f, vy = 0.f;
@@ -489,7 +493,10 @@ __device__ __forceinline__ void stamp_marks_trips(const GridGeom &g, void *__res
         const int    fv = future_cell(k);
         const bool   in = fv < g.V;
         const size_t ci = (size_t)k * g.V + (in ? fv : 0);
-        if (active && in) cell_st(base, ci, 1.0F, g.half);
+        if (active && in) {
+          cell_st(base, ci, 1.0F, g.half);
+          ++n_marks;
+        }
         if (lg.entries) {
           const unsigned long long m = keep_of(in ? (unsigned)(ci >> esh) : 0xFFFFFFFFu, in);
           if (lane == k) pref = run;
@@ -500,6 +507,7 @@ __device__ __forceinline__ void stamp_marks_trips(const GridGeom &g, void *__res
         unsigned lbase = 0;
         if (lane == 0) lbase = atomicAdd(lg.n + agent, run);
         lbase          = (unsigned)__shfl((int)lbase, 0, 64);
+        n_logged += run;
         unsigned *lent = lg.entries + (size_t)agent * lg.cap;
         for (int k = 0; k < g.T; ++k) {
           const int                fv  = k == 0 ? v : future_cell(k);
@@ -510,6 +518,13 @@ __device__ __forceinline__ void stamp_marks_trips(const GridGeom &g, void *__res
           if (((m >> lane) & 1ull) && li < (unsigned)lg.cap) lent[li] = sec;
         }
       }
+    }
+  }
+  if (lg.stat) {
+    for (int d = 32; d >= 1; d >>= 1) n_marks += (unsigned)__shfl_xor((int)n_marks, d, 64);
+    if (lane == 0 && n_marks) {
+      atomicAdd(lg.stat, (unsigned long long)n_marks);
+      atomicAdd(lg.stat + 1, (unsigned long long)n_logged);
     }
   }
 }
@@ -1089,7 +1104,7 @@ static int slot_of_grid(const sogm_ctx *c, const float *grid) {
 // the log of a slot, allocated on first use; {nullptr, ...} when the feature is off or there is no room for it (the
 // slot then stays untracked and is cleared densely)
 MarkLog mark_log(sogm_ctx *c, int slot) {
-  MarkLog none{nullptr, nullptr, 0};
+  MarkLog none{nullptr, nullptr, 0, nullptr};
   if (!c->sparse || slot < 0 || slot > 2) return none;
   if (!c->d_log[slot]) {
     unsigned *e = nullptr, *n = nullptr;
@@ -1104,8 +1119,8 @@ MarkLog mark_log(sogm_ctx *c, int slot) {
       return none;
     }
     if (!c->d_reset_stat &&
-        (hipMalloc((void **)&c->d_reset_stat, 4 * sizeof(unsigned long long)) != hipSuccess ||
-         hipMemset(c->d_reset_stat, 0, 4 * sizeof(unsigned long long)) != hipSuccess)) {
+        (hipMalloc((void **)&c->d_reset_stat, 8 * sizeof(unsigned long long)) != hipSuccess ||
+         hipMemset(c->d_reset_stat, 0, 8 * sizeof(unsigned long long)) != hipSuccess)) {
       (void)hipGetLastError();
       (void)hipFree(e);
       (void)hipFree(n);
@@ -1117,7 +1132,7 @@ MarkLog mark_log(sogm_ctx *c, int slot) {
     c->d_log_n[slot] = n;
     c->tracked[slot] = 0;  // what the grid holds now was written without a log
   }
-  return MarkLog{c->d_log[slot], c->d_log_n[slot], c->log_cap};
+  return MarkLog{c->d_log[slot], c->d_log_n[slot], c->log_cap, c->d_reset_stat ? c->d_reset_stat + 4 : nullptr};
 }
 static size_t agent_grid_bytes(const sogm_ctx *c) { return (size_t)c->spec.T * (size_t)c->geom.V * c->cell_bytes(); }
 
@@ -1570,12 +1585,31 @@ int sogm_sparse_reset_state(sogm_ctx *c, int32_t *out) {
   if (c->d_reset_stat) {
     unsigned long long st[4] = {0, 0, 0, 0};
     SOGM_HIP_CHECK(hipMemcpy(st, c->d_reset_stat, sizeof(st), hipMemcpyDeviceToHost));
-    SOGM_HIP_CHECK(hipMemset(c->d_reset_stat, 0, sizeof(st)));
+    SOGM_HIP_CHECK(hipMemset(c->d_reset_stat, 0, sizeof(st)));  // (the reset's counters only: the stamp's stay)
     out[5] = (int32_t)(st[1] > 0x7FFFFFFFull ? 0x7FFFFFFFull : st[1]);
     const unsigned long long mean = st[1] ? st[0] / st[1] : 0;
     out[6] = (int32_t)(mean > 0x7FFFFFFFull ? 0x7FFFFFFFull : mean);
     const unsigned long long kib = st[1] ? st[2] / st[1] / 1024 : 0;
     out[7] = (int32_t)(kib > 0x7FFFFFFFull ? 0x7FFFFFFFull : kib);
+  }
+  return SOGM_OK;
+}
+
+int sogm_map_traffic(sogm_ctx *c, int64_t *out, int reset) {
+  if (!c || !out) return SOGM_ERR_INVALID_ARG;
+  SOGM_HIP_CHECK(hipSetDevice(c->device));
+  SOGM_HIP_CHECK(hipDeviceSynchronize());
+  unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (c->d_reset_stat) SOGM_HIP_CHECK(hipMemcpy(st, c->d_reset_stat, sizeof(st), hipMemcpyDeviceToHost));
+  out[0] = (int64_t)st[1];  // resets through the mark logs
+  out[1] = (int64_t)st[0];  // log entries they read
+  out[2] = (int64_t)st[2];  // bytes they zeroed
+  out[3] = (int64_t)c->n_stamps;
+  out[4] = (int64_t)st[4];  // marks (cells set to 1) the stamps wrote
+  out[5] = (int64_t)st[5];  // log entries the stamps appended
+  if (reset) {
+    if (c->d_reset_stat) SOGM_HIP_CHECK(hipMemset(c->d_reset_stat, 0, sizeof(st)));
+    c->n_stamps = 0;
   }
   return SOGM_OK;
 }
@@ -1766,6 +1800,7 @@ static int update_gt_impl(sogm_ctx *c, const float *cloud_xyz, const int32_t *cl
     const char *e = getenv("SOGM_STAMP_WGS");  // one-wave workgroups per agent (tuning aid)
     stamp_wgs     = e && atoi(e) > 0 ? atoi(e) : 256;
   }
+  c->n_stamps++;
   prof_begin(c, SOGM_PROF_STAMP, st);
   hipLaunchKernelGGL(k_cull_cylinders, dim3(A), dim3(64), 0, st, c->geom, cylinders, n_cyl, poses,
                      (CylCand *)c->d_cand, c->d_ncand, stamps, c->d_poses, c->d_stamps);

@@ -695,6 +695,7 @@ static int replan_flow(sogm_planner *p, const double *start_pva, const double *g
       return SOGM_ERR_HIP;
     }
     c->prestamp_slot = nxt;
+    c->n_stamps++;
   }
   for (int k = 0; k < 4; ++k) {
     SOGM_HIP_CHECK(hipEventRecord(p->ev_fdone[k], p->fstream[k]));

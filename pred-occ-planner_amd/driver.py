@@ -91,6 +91,13 @@ class RecordExchange:
     def active(self):
         return self.handle is not None
 
+    def info(self):
+        """{ranks, rank} as RCCL itself reports them for the communicator (ncclCommCount / ncclCommUserRank)."""
+        import ctypes as C
+        out = (C.c_int32 * 2)()
+        _abi.check(self.lib.sogm_comm_info(self.comm, out), "sogm_comm_info")
+        return {"ranks": int(out[0]), "rank": int(out[1])}
+
     def all_gather(self, own, all_records):
         _abi.check(self.lib.sogm_traj_allgather(self.ctx, self.handle, own.data_ptr(), own.shape[0],
                                                 all_records.data_ptr(), self._stream()), "sogm_traj_allgather")

@@ -125,6 +125,13 @@ class SogmMap:
                 "total_entries": out[4], "resets": out[5], "entries_per_reset": out[6],
                 "zeroed_bytes_per_reset": int(out[7]) * 1024}
 
+    def map_traffic(self, reset=False):
+        """Device-side counts of what the resets and stamps moved since the counters' last reset (sogm_map_traffic)."""
+        out = (C.c_int64 * 6)()
+        check(lib().sogm_map_traffic(self._ctx, out, 1 if reset else 0), "sogm_map_traffic")
+        return {"resets": out[0], "reset_entries": out[1], "reset_bytes_zeroed": out[2], "stamps": out[3],
+                "stamp_marks": out[4], "stamp_entries": out[5]}
+
     def grid_history(self):
         """How the current grid came to be: {slot, sparse_resets, dense_clears, prestamped} (sogm_grid_history)."""
         out = (C.c_int32 * 4)()
