@@ -204,6 +204,23 @@ int sogm_set_sparse_reset(sogm_ctx *ctx, int enable, int log_capacity);
  * launch, mean KiB zeroed per such launch (the stores the reset kernel issued, counted on the device)}.
  * Synchronises. */
 int sogm_sparse_reset_state(sogm_ctx *ctx, int32_t *out_host);
+/* Tuning knobs.  Every internal width and switch of the library has a default chosen on MI355X; a host that wants
+ * another value sets it per context — nothing is read from the environment (the library's only environment switches are
+ * SOGM_SPARSE_RESET, SOGM_FLOW and SOGM_RCCL_LIB).  Keys (defaults in parentheses):
+ *   read by sogm_planner_create (set them before):  "groups" (2) agent groups of the grouped-stream replan,
+ *     "spec_astar" (1) speculative second search, "clear_gate_frac" (1.0);
+ *   read at every call:  "qp_wgs" (0 = half the CUs) persistent QP workgroups, "stamp_wgs" (256), "splat_wgs" (256),
+ *     "splat_overlap" (1), "reset_wgs" (32), "reset_lanes" (0 = auto: 2 under the replan, 4 alone), "reset_unroll"
+ *     (0 = auto: 1 / 8), "reset_late" (1), "prestamp_bits" (32), "prestamp_marks" (64), "prestamp_wgs" (0 = 8 per CU),
+ *     "prestamp_late_agents" (8), "prestamp_late_bits" (128), "prestamp_late_marks" (256), and the dense clear's
+ *     "clear_wgs" (0 = auto), "clear_throttle" (0), "clear_nt" (1), "clear_wide_wgs" (256; 0 = fixed width),
+ *     "clear_wide_bound" (0), "clear_head_gb" (1e9), "clear_early" (0), "clear_retire_at_end" (0); "qp_ablate" (0;
+ *     profiling builds only).
+ * Not thread-safe against calls on the same context (like every other call).  Unknown key: SOGM_ERR_INVALID_ARG.
+ * sogm_tuning_key(i) enumerates the keys (NULL past the last). */
+int         sogm_set_tuning(sogm_ctx *ctx, const char *key, double value);
+int         sogm_get_tuning(const sogm_ctx *ctx, const char *key, double *out_value_host);
+const char *sogm_tuning_key(int index);
 /* What the map kernels moved since the last reset of these counters (device-side counts, for the roofline figures of
  * bench.py); host out[6]: {resets through the mark logs, log entries those resets read, bytes they zeroed, stamps
  * launched (sogm_update_gt* and pre-stamps), marks (cells set to 1) the stamps wrote, log entries the stamps

@@ -308,6 +308,41 @@ __device__ inline void bezier_pos(const SogmTrajRecord &r, double t, double out[
 
 }  // namespace sogm
 
+// ---- tuning knobs (sogm_set_tuning / sogm_get_tuning): one table per context, defaults below, no environment ----
+#define SOGM_TUNING_TABLE(X)                                                                                             \
+  X(GROUPS, "groups", 2)                   /* [planner create] agent groups of the grouped-stream replan            */  \
+  X(SPEC_ASTAR, "spec_astar", 1)           /* [planner create] speculative second search beside the first          */  \
+  X(CLEAR_GATE_FRAC, "clear_gate_frac", 1) /* [planner create] fraction of agents with final corridors that opens the wide clear */ \
+  X(QP_WGS, "qp_wgs", 0)                   /* persistent QP workgroups of the dataflow replan; 0 = half the CUs    */  \
+  X(QP_ABLATE, "qp_ablate", 0)             /* phase ablation mask (only in -DSOGM_QP_ABLATE_BUILD libraries)       */  \
+  X(CLEAR_WGS, "clear_wgs", 0)             /* dense clear: workgroups; 0 = 64 / 80 polite, 2048 alone              */  \
+  X(CLEAR_THROTTLE, "clear_throttle", 0)   /* dense clear: stores in flight per wave when clear_wgs is set         */  \
+  X(CLEAR_NT, "clear_nt", 1)               /* dense clear: non-temporal stores                                      */  \
+  X(CLEAR_WIDE_WGS, "clear_wide_wgs", 256) /* dense clear: workgroups of the gated wide launch; 0 = fixed width    */  \
+  X(CLEAR_WIDE_BOUND, "clear_wide_bound", 0) /* dense clear: stores in flight per wave of the wide launch; 0 = unbounded */ \
+  X(CLEAR_HEAD_GB, "clear_head_gb", 1.0e9) /* dense clear: GB of the narrow head before a full-width rest          */  \
+  X(CLEAR_EARLY, "clear_early", 0)         /* dense clear: queue the swapped-out grid's clear under the stamp      */  \
+  X(CLEAR_RETIRE_AT_END, "clear_retire_at_end", 0) /* dense clear: the wide launch retires when the replan ends    */  \
+  X(RESET_WGS, "reset_wgs", 32)            /* sparse reset: workgroups per agent                                    */  \
+  X(RESET_LANES, "reset_lanes", 0)         /* sparse reset: 2 / 4 lanes per entry; 0 = 2 under the replan, 4 alone  */  \
+  X(RESET_UNROLL, "reset_unroll", 0)       /* sparse reset: 1 / 8 entries per trip; 0 = 1 under the replan, 8 alone */  \
+  X(RESET_LATE, "reset_late", 1)           /* sparse reset: held back until every agent's corridors are final       */  \
+  X(STAMP_WGS, "stamp_wgs", 256)           /* stamp: one-wave workgroups per agent                                  */  \
+  X(SPLAT_WGS, "splat_wgs", 256)           /* overlay launched under a pre-stamp's tail: workgroups                 */  \
+  X(SPLAT_OVERLAP, "splat_overlap", 1)     /* 0: sogm_replan joins the pre-stamp's end itself                       */  \
+  X(PRESTAMP_BITS, "prestamp_bits", 32)    /* pre-stamp: one-wave tickets per agent, occupancy bits pass            */  \
+  X(PRESTAMP_MARKS, "prestamp_marks", 64)  /* pre-stamp: one-wave tickets per agent, marks pass                     */  \
+  X(PRESTAMP_WGS, "prestamp_wgs", 0)       /* pre-stamp: one-wave workgroups; 0 = 8 per CU                          */  \
+  X(PRESTAMP_LATE_AGENTS, "prestamp_late_agents", 8)  /* the last agents to be published get finer tickets ...     */  \
+  X(PRESTAMP_LATE_BITS, "prestamp_late_bits", 128)    /* ... this many for the bits pass                           */  \
+  X(PRESTAMP_LATE_MARKS, "prestamp_late_marks", 256)  /* ... and for the marks pass                                */
+enum {
+#define X(id, name, dflt) SOGM_TUNE_##id,
+  SOGM_TUNING_TABLE(X)
+#undef X
+  SOGM_TUNE_N
+};
+
 // ---- context (opaque in the C ABI) ----
 struct sogm_ctx {
   SogmSpec       spec;
@@ -401,6 +436,8 @@ struct sogm_ctx {
   int                   pdone_pending;
   const int            *ps_stage;  // the planner's per-agent pre-stamp progress words, ps_err its error word
   int                  *ps_err;
+  double         tune[SOGM_TUNE_N];  // sogm_set_tuning; defaults from SOGM_TUNING_TABLE at sogm_create
+  int            tune_i(int k) const { return (int)tune[k]; }
   int            profiling;   // bit k: slot k is timed (sogm_set_profiling: all, sogm_set_profiling_slots: a choice)
   // per-slot ring of HIP event pairs: every launch of a profiled kernel since profiling was enabled keeps its own
   // pair, so a run can be timed launch by launch WITHOUT synchronising between launches (sogm_profile_read_all)
@@ -410,42 +447,10 @@ struct sogm_ctx {
 #define SOGM_PROF_RING 1024
 
 namespace sogm {
-// CU partition between the map clear and the planner kernels (tuning aid, off by default): SOGM_CLEAR_CUS = n gives the
-// clear's side stream a CU mask of n CUs per XCD (mask bit i belongs to XCD i % 8: the first 8 n bits) and the
-// planner's internal streams the complement, so that the streaming stores and the latency-bound planner waves do
-// not share SIMDs.  role: 0 = clear stream, 1 = planner stream.  Measured: the clear reaches 0.76-0.80 of
-// peak inside the tick with 8-12 CUs per XCD, but the planner chain loses more on the remaining CUs than the tick
-// gains; masking the clear alone is worse still (planner waves on the clear's CUs starve it).
-inline hipError_t create_stream_partitioned(hipStream_t *st, int role) {
-  static int n_clear = -1, n_qp = -1;
-  if (n_clear < 0) {
-    const char *e = getenv("SOGM_CLEAR_CUS");
-    n_clear       = e ? atoi(e) : 0;
-    if (n_clear < 0 || n_clear > 28) n_clear = 0;
-    // SOGM_QP_CUS = n (experiment): the QP stage's stream (role 2) owns the first n CUs of every XCD, every other
-    // internal stream the rest — the ADMM iteration runs 1.03 us alone and 1.4 us with corridor / search / stamp waves
-    // on its CU
-    e    = getenv("SOGM_QP_CUS");
-    n_qp = e ? atoi(e) : 0;
-    if (n_qp < 0 || n_qp > 28) n_qp = 0;
-  }
-  if (n_clear == 0 && n_qp == 0) return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
-  uint32_t mask[8];
-  for (int w = 0; w < 8; ++w) {
-    mask[w] = 0;
-    for (int b = 0; b < 32; ++b) {
-      const int bit = w * 32 + b;
-      bool      on;
-      if (n_qp > 0) {
-        on = (bit < 8 * n_qp) == (role == 2);
-      } else {
-        const bool is_clear = bit < 8 * n_clear;
-        on                  = is_clear == (role == 0);
-      }
-      if (on) mask[w] |= 1u << b;
-    }
-  }
-  return hipExtStreamCreateWithCUMask(st, 8, mask);
+// Internal streams.  (CU-masked variants — the clear or the QP stage on CUs of their own — were measured in rounds 3
+// and 4 and lost: the latency-bound planner waves need the whole machine, profiles/EXPERIMENTS.md.)
+inline hipError_t create_stream_partitioned(hipStream_t *st, int /*role*/) {
+  return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
 }
 
 // RAII-free helper: record the begin/end events of profiling slot `slot` on `st`.

@@ -1139,16 +1139,11 @@ static size_t agent_grid_bytes(const sogm_ctx *c) { return (size_t)c->spec.T * (
 int reset_slot(sogm_ctx *c, hipStream_t st, int slot, float *grid, bool polite) {
   const MarkLog lg = mark_log(c, slot);
   if (lg.entries && c->tracked[slot]) {
-    static int wgs = -1;
-    if (wgs < 0) {
-      const char *e = getenv("SOGM_RESET_WGS");  // workgroups per agent (tuning aid)
-      wgs           = e && atoi(e) > 0 ? atoi(e) : 32;
-    }
+    const int wgs = c->tune_i(SOGM_TUNE_RESET_WGS) > 0 ? c->tune_i(SOGM_TUNE_RESET_WGS) : 32;  // workgroups per agent
     // under the replan (polite: beside the QP stage, few CUs free) two lanes and 32-byte lines are faster - 1.05 ms
     // against 1.17 for the 64-byte lines, half the write traffic; with the machine to itself (reset in the update's
     // own stream) four lanes x eight entries per trip - 0.75 ms against 0.91.  Both switches are tuning aids.
-    static const int lanes_env  = getenv("SOGM_RESET_LANES") ? atoi(getenv("SOGM_RESET_LANES")) : 0;
-    static const int unroll_env = getenv("SOGM_RESET_UNROLL") ? atoi(getenv("SOGM_RESET_UNROLL")) : 0;
+    const int lanes_env = c->tune_i(SOGM_TUNE_RESET_LANES), unroll_env = c->tune_i(SOGM_TUNE_RESET_UNROLL);
     const int lanes  = lanes_env == 2 || lanes_env == 4 ? lanes_env : polite ? 2 : 4;
     const int unroll = unroll_env == 1 || unroll_env == 8 ? unroll_env : polite ? 1 : 8;
     prof_begin(c, SOGM_PROF_CLEAR, st);
@@ -1224,15 +1219,11 @@ int adopt_preclear(sogm_ctx *c, hipStream_t st, bool join) {
     c->d_grid              = c->pool[nxt];
     SOGM_HIP_CHECK(hipStreamWaitEvent(st, c->pool_ev[nxt], 0));
     c->precleared = c->n_ready > 0;
-    static int early = -1;
-    if (early < 0) {
-      const char *e = getenv("SOGM_CLEAR_EARLY");
-      early         = e ? atoi(e) : 0;
-    }
+    const int early = c->tune_i(SOGM_TUNE_CLEAR_EARLY);
     if (join)
       if (int rc = retire_wide_clear(c, st)) return rc;
     if (c->clear_gate && early) {
-      // tuning aid (SOGM_CLEAR_EARLY=1): queue the clear of the swapped-out grid NOW, under the stamp — its readers,
+      // tuning aid (clear_early = 1): queue the clear of the swapped-out grid NOW, under the stamp — its readers,
       // the previous replan's kernels, are complete on `st` in stream order — for the replan that will announce
       // epoch clear_epoch + 1.  Measured: the stamp beside it takes twice as long (1.4 -> 3.1 ms) and the first
       // ticks of a flight lose 5 %; later ticks gain 3 %.  Off by default.
@@ -1254,16 +1245,12 @@ int adopt_preclear(sogm_ctx *c, hipStream_t st, bool join) {
 int queue_spare_clears(sogm_ctx *c, hipEvent_t after) {
   if (c->overlap < 2 || c->n_dirty == 0) return SOGM_OK;
   SOGM_HIP_CHECK(hipStreamWaitEvent(c->side, after, 0));
-  // The clear shares the machine with the whole replan, as ONE narrow launch by default.  SOGM_CLEAR_HEAD_GB (a
+  // The clear shares the machine with the whole replan, as ONE narrow launch by default.  clear_head_gb (a
   // tuning aid) splits it into a narrow head of that many GB and a full-width rest: measured with the dataflow
   // replan (profiles/r02_*), a wide rest shortens the clear (15.9 -> 14.3 ms) but costs the planner kernels more
   // than it saves (tick 18.2 -> 19.3 ms), because per-agent chaining spreads the global-memory phases (searches,
   // point scans, FIRI set-up of late agents) over the whole tick.
-  static double head_gb = -1.0;
-  if (head_gb < 0) {
-    const char *e = getenv("SOGM_CLEAR_HEAD_GB");
-    head_gb       = e ? atof(e) : 1.0e9;
-  }
+  const double head_gb = c->tune[SOGM_TUNE_CLEAR_HEAD_GB] >= 0 ? c->tune[SOGM_TUNE_CLEAR_HEAD_GB] : 1.0e9;
   const size_t total = clear_vec4_total(c);
   size_t       head  = (size_t)(head_gb * 1e9 / 16.0);
   if (head > total) head = total;
@@ -1271,15 +1258,11 @@ int queue_spare_clears(sogm_ctx *c, hipEvent_t after) {
     const int g  = c->dirty[i];
     int       rc = SOGM_OK;
     if (c->sparse && c->tracked[g] && mark_log(c, g).entries) {
-      static int late = -1;
-      if (late < 0) {
-        // The reset is held back until every agent's corridors are final (the gate the dense clear's wide launch
-        // uses): beside the searches and the corridor stage's point scans its 3 GB of scattered stores cost the
-        // chain 0.8 ms (tick 13.8 -> 12.9 ms); under the QP stage, which lives in LDS, they cost nothing and the
-        // reset itself takes 1.3 instead of 2.4 ms.  SOGM_RESET_LATE=0: start it with the replan.
-        const char *e = getenv("SOGM_RESET_LATE");
-        late          = e ? atoi(e) : 1;
-      }
+      // The reset is held back until every agent's corridors are final (the gate the dense clear's wide launch
+      // uses): beside the searches and the corridor stage's point scans its 3 GB of scattered stores cost the
+      // chain 0.8 ms (tick 13.8 -> 12.9 ms); under the QP stage, which lives in LDS, they cost nothing and the
+      // reset itself takes 1.3 instead of 2.4 ms.  reset_late = 0: start it with the replan.
+      const int late = c->tune_i(SOGM_TUNE_RESET_LATE);
       if (late && c->clear_gate) {
         hipLaunchKernelGGL(k_clear_gate, dim3(1), dim3(64), 0, c->side, c->clear_cursor, ~(size_t)0, c->clear_gate,
                            c->clear_gate_err, c->clear_gate_target, c->clear_epoch_word, c->clear_epoch);
@@ -1307,7 +1290,7 @@ int queue_spare_clears(sogm_ctx *c, hipEvent_t after) {
 // mode): a full-width clear (2048 persistent workgroups, unbounded stores in flight) starves every other
 // kernel's loads for its whole duration; 64 workgroups with <= 4 stores in flight per wave still stream at
 // ~5.7 TB/s and leave the memory pipeline responsive.  SOGM_CLEAR_WGS / SOGM_CLEAR_THROTTLE / SOGM_CLEAR_NT
-// override the choice (tuning aids).
+// override the choice (tuning aids: clear_wgs / clear_throttle / clear_nt).
 size_t clear_vec4_total(const sogm_ctx *c) {
   return (size_t)c->n_agents * c->spec.T * (size_t)c->geom.V * c->cell_bytes() / 4 / 4;
 }
@@ -1339,25 +1322,13 @@ static int launch_clear_impl(sogm_ctx *c, hipStream_t st, float *grid, bool poli
   const int    tail  = part == 1 ? 0 : (int)(n - nall * 4);
   const int    slot  = part == 1 ? SOGM_PROF_CLEAR_HEAD : SOGM_PROF_CLEAR;
   size_t       want  = (nv4 + 255) / 256;
-  static int   env_wgs = -1, env_throttle = -1, nt = -1;
-  if (env_wgs < 0) {
-    const char *e = getenv("SOGM_CLEAR_WGS");
-    env_wgs       = e && atoi(e) > 0 ? atoi(e) : 0;
-    e             = getenv("SOGM_CLEAR_THROTTLE");
-    env_throttle  = e ? atoi(e) : 0;
-    e             = getenv("SOGM_CLEAR_NT");
-    nt            = e ? atoi(e) != 0 : 1;
-  }
+  const int env_wgs = c->tune_i(SOGM_TUNE_CLEAR_WGS) > 0 ? c->tune_i(SOGM_TUNE_CLEAR_WGS) : 0;
+  const int env_throttle = c->tune_i(SOGM_TUNE_CLEAR_THROTTLE), nt = c->tune_i(SOGM_TUNE_CLEAR_NT) != 0;
   const size_t max_wgs  = env_wgs ? (size_t)env_wgs : (polite ? (c->clear_gate && part == 0 ? 80 : 64) : 2048);
   const int    throttle = env_wgs ? env_throttle : (polite ? 4 : 0);
   const int    nblk     = (int)(want < 1 ? 1 : (want > max_wgs ? max_wgs : want));
-  static int   wide_wgs = -1, wide_bound = 0;
-  if (wide_wgs < 0) {
-    const char *e = getenv("SOGM_CLEAR_WIDE_WGS");  // 0 switches the adaptive width off
-    wide_wgs      = e ? atoi(e) : 256;
-    e             = getenv("SOGM_CLEAR_WIDE_BOUND");  // stores in flight per wave of the wide launch (0 = unbounded)
-    wide_bound    = e ? atoi(e) : 0;
-  }
+  // clear_wide_wgs = 0 switches the adaptive width off; clear_wide_bound: stores in flight per wave of the wide launch
+  const int wide_wgs = c->tune_i(SOGM_TUNE_CLEAR_WIDE_WGS), wide_bound = c->tune_i(SOGM_TUNE_CLEAR_WIDE_BOUND);
   if (polite && part == 0 && c->clear_gate && c->clear_cursor && c->side2 && wide_wgs > 0 && nt) {
     const size_t        nchunks = (nall + CLEAR_CHUNK_V4 - 1) / CLEAR_CHUNK_V4;
     unsigned long long *cur = c->clear_cursor + (c->clear_seq & 1), *nxt = c->clear_cursor + ((c->clear_seq + 1) & 1);
@@ -1449,13 +1420,15 @@ int sogm_create(const SogmSpec *spec, int n_agents, int device, sogm_ctx **out) 
   c->device        = device;
   c->prestamp_slot = -1;
   {
-    const char *e = getenv("SOGM_SPARSE_RESET");
+#define X(id, name, dflt) c->tune[SOGM_TUNE_##id] = (double)(dflt);
+    SOGM_TUNING_TABLE(X)
+#undef X
+    const char *e = getenv("SOGM_SPARSE_RESET");  // (one of the library's three environment switches)
     c->sparse     = e ? atoi(e) != 0 : 1;
-    e             = getenv("SOGM_LOG_CAP");
-    // default capacity per agent: one entry per 80 cells, at least 2^20 (the bench scenes log ~0.7 M entries per
-    // agent and tick at 200^3 x 20, i.e. one per 230 cells)
+    // default capacity per agent: one entry per 80 cells, at least 2^20 (the bench scenes log ~0.3 M entries per
+    // agent and tick at 200^3 x 20); sogm_set_sparse_reset changes it
     const long long dflt = (long long)spec->L * spec->W * spec->H * spec->T / 80;
-    c->log_cap    = e && atoi(e) > 0 ? atoi(e) : (int)(dflt < (1 << 20) ? (1 << 20) : (dflt > (1 << 26) ? (1 << 26) : dflt));
+    c->log_cap    = (int)(dflt < (1 << 20) ? (1 << 20) : (dflt > (1 << 26) ? (1 << 26) : dflt));
   }
   const size_t n   = (size_t)n_agents * spec->T * (size_t)c->geom.V;
   hipError_t   e   = hipMalloc(&c->d_grid, (n * c->cell_bytes() + 15) & ~(size_t)15);
@@ -1594,6 +1567,38 @@ int sogm_sparse_reset_state(sogm_ctx *c, int32_t *out) {
   }
   return SOGM_OK;
 }
+
+static const char *const k_tune_names[SOGM_TUNE_N] = {
+#define X(id, name, dflt) name,
+    SOGM_TUNING_TABLE(X)
+#undef X
+};
+static int tune_index(const char *key) {
+  if (!key) return -1;
+  for (int i = 0; i < SOGM_TUNE_N; ++i)
+    if (std::strcmp(key, k_tune_names[i]) == 0) return i;
+  return -1;
+}
+int sogm_set_tuning(sogm_ctx *c, const char *key, double value) {
+  const int i = tune_index(key);
+  if (!c || i < 0 || !(value == value)) {
+    if (c && i < 0) {
+      char buf[160];
+      std::snprintf(buf, sizeof(buf), "sogm_set_tuning: unknown key '%s'", key ? key : "(null)");
+      sogm::set_error_text(buf);
+    }
+    return SOGM_ERR_INVALID_ARG;
+  }
+  c->tune[i] = value;
+  return SOGM_OK;
+}
+int sogm_get_tuning(const sogm_ctx *c, const char *key, double *out) {
+  const int i = tune_index(key);
+  if (!c || !out || i < 0) return SOGM_ERR_INVALID_ARG;
+  *out = c->tune[i];
+  return SOGM_OK;
+}
+const char *sogm_tuning_key(int index) { return index >= 0 && index < SOGM_TUNE_N ? k_tune_names[index] : nullptr; }
 
 int sogm_map_traffic(sogm_ctx *c, int64_t *out, int reset) {
   if (!c || !out) return SOGM_ERR_INVALID_ARG;
@@ -1782,7 +1787,7 @@ static int update_gt_impl(sogm_ctx *c, const float *cloud_xyz, const int32_t *cl
   } else {
     int rc = clear_grid(c, st);
     if (rc) return rc;
-    if (c->overlap >= 2 && c->n_dirty > 0 && c->clear_gate && getenv("SOGM_CLEAR_EARLY") && atoi(getenv("SOGM_CLEAR_EARLY"))) {
+    if (c->overlap >= 2 && c->n_dirty > 0 && c->clear_gate && c->tune_i(SOGM_TUNE_CLEAR_EARLY)) {
       // tuning-aid mode: the pool's spare grids (dirty at the start, no readers) are cleared from here on as well,
       // so that a run of updates alone exercises the pooled clear (tools/diag_clear_pmc.py)
       c->clear_epoch_ahead = 1;
@@ -1795,11 +1800,7 @@ static int update_gt_impl(sogm_ctx *c, const float *cloud_xyz, const int32_t *cl
   // candidate cylinders per agent, then one-wave workgroups stride over each agent's cloud range
   int words = 0;
   if (int rc = sogm::stamp_scratch(c, st, &words)) return rc;
-  static int stamp_wgs = -1;
-  if (stamp_wgs < 0) {
-    const char *e = getenv("SOGM_STAMP_WGS");  // one-wave workgroups per agent (tuning aid)
-    stamp_wgs     = e && atoi(e) > 0 ? atoi(e) : 256;
-  }
+  const int stamp_wgs = c->tune_i(SOGM_TUNE_STAMP_WGS) > 0 ? c->tune_i(SOGM_TUNE_STAMP_WGS) : 256;  // one-wave workgroups per agent
   c->n_stamps++;
   prof_begin(c, SOGM_PROF_STAMP, st);
   hipLaunchKernelGGL(k_cull_cylinders, dim3(A), dim3(64), 0, st, c->geom, cylinders, n_cyl, poses,
@@ -1874,11 +1875,8 @@ int sogm_update_prestamped(sogm_ctx *c, const SogmTrajRecord *records, int n_rec
     const int      *stage = c->pdone_pending ? c->ps_stage : nullptr;
     const long long total = (long long)c->n_agents * n_records * c->spec.T;
     long long       nblk  = (total + 255) / 256;
-    static int      cap   = -1;
-    if (cap < 0) {
-      const char *e = getenv("SOGM_SPLAT_WGS");  // workgroups of the waiting launch (tuning aid)
-      cap           = e && atoi(e) > 0 ? atoi(e) : 256;  // (128 / 256 / 512 / 2048: 11.22 / 11.25 / 11.31 / 11.26 ms per tick)
-    }
+    // workgroups of the waiting launch (128 / 256 / 512 / 2048: 11.22 / 11.25 / 11.31 / 11.26 ms per tick)
+    const int cap = c->tune_i(SOGM_TUNE_SPLAT_WGS) > 0 ? c->tune_i(SOGM_TUNE_SPLAT_WGS) : 256;
     if (stage && nblk > cap) nblk = cap;
     prof_begin(c, SOGM_PROF_SPLAT, st);
     hipLaunchKernelGGL(k_splat_neighbours, dim3((unsigned)nblk), dim3(256), 0, st, c->geom, (void *)c->d_grid, records,

@@ -175,11 +175,10 @@ int sogm_planner_create(sogm_ctx *map, const SogmAstarParams *astar, const SogmP
     if (e == hipSuccess) e = hipMalloc((void **)&p->d_safe, sizeof(int32_t) * A);
   }
   // Streams beyond the number of hardware queues (ROCm default GPU_MAX_HW_QUEUES = 4) share a queue
-  // and serialise, so the default is 2 groups; the Python driver raises both (GPU_MAX_HW_QUEUES = 32,
-  // SOGM_GROUPS = 8) before HIP initialises.
+  // and serialise, so the default is 2 groups; the Python driver raises both (GPU_MAX_HW_QUEUES = 32 before HIP
+  // initialises, sogm_set_tuning "groups" = 8 before it creates the planner).
   {
-    const char *eg = getenv("SOGM_GROUPS");
-    int         ng = eg ? atoi(eg) : 2;
+    int ng = map->tune_i(SOGM_TUNE_GROUPS);
     if (ng < 1) ng = 1;
     if (ng > SOGM_MAX_GROUPS) ng = SOGM_MAX_GROUPS;
     p->n_groups = A < ng ? A : ng;
@@ -188,8 +187,7 @@ int sogm_planner_create(sogm_ctx *map, const SogmAstarParams *astar, const SogmP
   p->sel_count   = A;
   p->search_mode = 0;
   {
-    const char *es = getenv("SOGM_SPEC_ASTAR");
-    p->spec_astar  = es ? atoi(es) != 0 : 1;
+    p->spec_astar = map->tune_i(SOGM_TUNE_SPEC_ASTAR) != 0;
     // the second attempts wait on the first ones: only when every workgroup of both is resident at once
     if (p->spec_astar && 2 * A > sogm::astar_resident_workgroups(map->device)) p->spec_astar = 0;
   }
@@ -202,7 +200,7 @@ int sogm_planner_create(sogm_ctx *map, const SogmAstarParams *astar, const SogmP
   if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_in, hipEventDisableTiming);
   // dataflow replan: control block + four streams (needs >= 5 hardware queues to overlap with the clear)
   {
-    const char *ef = getenv("SOGM_FLOW");
+    const char *ef = getenv("SOGM_FLOW");  // (one of the library's three environment switches)
     p->flow        = ef ? atoi(ef) != 0 : 1;
     // layout: header, seg_done[A], stage[A] (zeroed per replan), then the four ready lists (-1 per replan)
     if (e == hipSuccess) e = hipMalloc((void **)&p->d_flow, sizeof(int) * (FLOW_HDR + 6 * (size_t)A));
@@ -237,9 +235,9 @@ int sogm_planner_create(sogm_ctx *map, const SogmAstarParams *astar, const SogmP
     map->clear_gate        = p->fc.hdr + FLOW_Q_READY_N;
     map->clear_gate_err    = p->fc.hdr + FLOW_ERR;
     map->clear_gate_target = A;
-    if (const char *e = getenv("SOGM_CLEAR_GATE_FRAC")) {  // tuning aid: open the wide clear at a fraction of A
-      const double f = atof(e);
-      if (f > 0.0 && f <= 1.0) map->clear_gate_target = (int)(f * A + 0.5) < 1 ? 1 : (int)(f * A + 0.5);
+    {  // tuning aid: open the wide clear at a fraction of A
+      const double f = map->tune[SOGM_TUNE_CLEAR_GATE_FRAC];
+      if (f > 0.0 && f < 1.0) map->clear_gate_target = (int)(f * A + 0.5) < 1 ? 1 : (int)(f * A + 0.5);
     }
     map->clear_epoch_word  = p->d_epoch;
   }
@@ -385,7 +383,9 @@ int sogm_bezier_qp_solve(sogm_planner *p, const double *start_pva, const double 
   SOGM_HIP_CHECK(hipSetDevice(p->map->device));
   hipStream_t st = (hipStream_t)stream;
   prof_begin(p->map, SOGM_PROF_QP, st);
-  int rc = launch_qp(p->pp, p->qs, p->qw, p->qc, p->sel_count, start_pva, goal_pv, polys,
+  sogm::QpWorkspace qw0 = p->qw;
+  qw0.ablate            = p->map->tune_i(SOGM_TUNE_QP_ABLATE);
+  int rc = launch_qp(p->pp, p->qs, qw0, p->qc, p->sel_count, start_pva, goal_pv, polys,
                      nfaces, npoly, out_cpts, out_status, out_iters, st, p->sel_first);
   prof_end(p->map, SOGM_PROF_QP, st);
   if (rc) {
@@ -604,9 +604,7 @@ static int replan_flow(sogm_planner *p, const double *start_pva, const double *g
   int wg_c = 4 * n_cu;
   if (wg_c > A * SOGM_MAX_PIECES) wg_c = A * SOGM_MAX_PIECES;
   int wg_q = n_cu / 2;
-  if (const char *e = getenv("SOGM_QP_CUS"))
-    if (atoi(e) > 0 && atoi(e) <= 28) wg_q = 8 * atoi(e);  // one workgroup per CU of the QP partition
-  if (const char *e = getenv("SOGM_QP_WGS")) wg_q = atoi(e);  // tuning aid
+  if (c->tune_i(SOGM_TUNE_QP_WGS) > 0) wg_q = c->tune_i(SOGM_TUNE_QP_WGS);  // tuning aid
   if (wg_q > A) wg_q = A;
   if (wg_q < 1) wg_q = 1;
   int wg_f = A < 64 ? A : 64;
@@ -657,30 +655,17 @@ static int replan_flow(sogm_planner *p, const double *start_pva, const double *g
     d.poses    = c->d_poses_next;
     d.stamps   = c->d_stamps_next;
     d.n_agents = A;
-    static int nb = -1, nm = -1;
-    if (nb < 0) {
-      // tickets per agent (tuning aids): too few and the last agents' stamps trail the replan, too many and the
-      // hand-overs cost more than the work (bits + marks 16+16 / 32+64 / 64+64 / 128+256 tickets: 13.1 / 12.1 / 12.2 /
-      // 14.1 ms per tick, 13.0 without the pre-stamp)
-      const char *e = getenv("SOGM_PRESTAMP_BITS");
-      nb            = e && atoi(e) > 0 ? atoi(e) : 32;
-      e             = getenv("SOGM_PRESTAMP_MARKS");
-      nm            = e && atoi(e) > 0 ? atoi(e) : 64;
-    }
-    d.n_bits  = nb;
-    d.n_marks = nm;
-    static int nl = -1, nbl = -1, nml = -1;
-    if (nl < 0) {
-      const char *e = getenv("SOGM_PRESTAMP_LATE");  // "agents,bits,marks" for the last agents to be published
-      int         a = 8, b = 128, m = 256;   // (none / 8 / 16 late agents: 12.06 / 11.85 / 11.98 ms per tick)
-      if (e) (void)std::sscanf(e, "%d,%d,%d", &a, &b, &m);
-      nl = a < 0 ? 0 : a;
-      nbl = b > 0 ? b : nb;
-      nml = m > 0 ? m : nm;
-    }
-    d.n_late       = nl;
-    d.n_bits_late  = nbl;
-    d.n_marks_late = nml;
+    // tickets per agent (tuning aids): too few and the last agents' stamps trail the replan, too many and the
+    // hand-overs cost more than the work (bits + marks 16+16 / 32+64 / 64+64 / 128+256 tickets: 13.1 / 12.1 / 12.2 /
+    // 14.1 ms per tick, 13.0 without the pre-stamp); finer tickets for the last agents to be published (none / 8 / 16
+    // late agents: 12.06 / 11.85 / 11.98 ms per tick)
+    const int nb = c->tune_i(SOGM_TUNE_PRESTAMP_BITS) > 0 ? c->tune_i(SOGM_TUNE_PRESTAMP_BITS) : 32;
+    const int nm = c->tune_i(SOGM_TUNE_PRESTAMP_MARKS) > 0 ? c->tune_i(SOGM_TUNE_PRESTAMP_MARKS) : 64;
+    d.n_bits       = nb;
+    d.n_marks      = nm;
+    d.n_late       = c->tune_i(SOGM_TUNE_PRESTAMP_LATE_AGENTS) < 0 ? 0 : c->tune_i(SOGM_TUNE_PRESTAMP_LATE_AGENTS);
+    d.n_bits_late  = c->tune_i(SOGM_TUNE_PRESTAMP_LATE_BITS) > 0 ? c->tune_i(SOGM_TUNE_PRESTAMP_LATE_BITS) : nb;
+    d.n_marks_late = c->tune_i(SOGM_TUNE_PRESTAMP_LATE_MARKS) > 0 ? c->tune_i(SOGM_TUNE_PRESTAMP_LATE_MARKS) : nm;
     if (int rc = sogm::prestamp_buffers(c, &d)) return rc;
     // On the map's side stream, i.e. in stream order behind every reset queued so far — the target grid's among them
     // (this replan's, or an earlier one's).  (A stream of its own waiting for the grid's reset event was not enough:
@@ -689,7 +674,7 @@ static int replan_flow(sogm_planner *p, const double *start_pva, const double *g
     hipStream_t pst = c->side;
     SOGM_HIP_CHECK(hipStreamWaitEvent(pst, p->ev_in, 0));
     int wg_p = 8 * n_cu;  // one-wave workgroups (512 / 1024 / 2048+: 14.0 / 12.3 / 12.1 ms per tick)
-    if (const char *e = getenv("SOGM_PRESTAMP_WGS")) wg_p = atoi(e) > 0 ? atoi(e) : wg_p;
+    if (c->tune_i(SOGM_TUNE_PRESTAMP_WGS) > 0) wg_p = c->tune_i(SOGM_TUNE_PRESTAMP_WGS);
     if (sogm::launch_prestamp_flow(c->geom, p->fc, d, wg_p, wg_q, wg_f < A ? wg_f : A, pst)) {
       sogm::set_error("sogm_replan: k_prestamp_flow", hipGetLastError());
       return SOGM_ERR_HIP;
@@ -705,21 +690,13 @@ static int replan_flow(sogm_planner *p, const double *start_pva, const double *g
   if (c->prestamp_slot >= 0) {
     // the tick's report behind the pre-stamp on ITS stream (the last kernel of the tick to end), so that the caller's
     // stream goes from the fan-in straight to the next tick's first kernel instead of through one more launch
-    static int retire_p = -1;
-    if (retire_p < 0) {
-      const char *e = getenv("SOGM_CLEAR_RETIRE_AT_END");
-      retire_p      = e ? atoi(e) : 0;
-    }
+    const int retire_p = c->tune_i(SOGM_TUNE_CLEAR_RETIRE_AT_END);
     for (int k = 1; k < 4; ++k) SOGM_HIP_CHECK(hipStreamWaitEvent(c->side, p->ev_fdone[k], 0));
     hipLaunchKernelGGL(k_flow_report, dim3(1), dim3(1), 0, c->side, (const int *)p->d_flow, p->h_flow_fail,
                        retire_p ? p->d_epoch : (int *)nullptr);
     SOGM_HIP_CHECK(hipGetLastError());
     SOGM_HIP_CHECK(hipEventRecord(p->ev_pdone, c->side));
-    static int defer = -1;
-    if (defer < 0) {
-      const char *e = getenv("SOGM_SPLAT_OVERLAP");  // 0: the caller's stream waits for the pre-stamp's end here
-      defer         = e ? atoi(e) != 0 : 1;
-    }
+    const int defer = c->tune_i(SOGM_TUNE_SPLAT_OVERLAP) != 0;  // 0: the caller's stream waits for the pre-stamp's end here
     if (defer) {
       // the caller's stream goes on behind the fan-in: the next update's overlay waits per agent (sogm_update_prestamped),
       // everything else joins the pre-stamp's end when it is called (sogm::join_prestamp)
@@ -739,11 +716,7 @@ static int replan_flow(sogm_planner *p, const double *start_pva, const double *g
     c->records_final_ptr   = p->pub_own;
     c->records_final_valid = 1;
   }
-  static int retire = -1;
-  if (retire < 0) {
-    const char *e = getenv("SOGM_CLEAR_RETIRE_AT_END");
-    retire        = e ? atoi(e) : 0;  // measured: tick -2 %, but the clear 14.5 -> 15.5 ms; off
-  }
+  const int retire = c->tune_i(SOGM_TUNE_CLEAR_RETIRE_AT_END);  // measured: tick -2 %, but the clear 14.5 -> 15.5 ms; off
   if (!reported) {
     hipLaunchKernelGGL(k_flow_report, dim3(1), dim3(1), 0, main, (const int *)p->d_flow, p->h_flow_fail,
                        retire ? p->d_epoch : (int *)nullptr);

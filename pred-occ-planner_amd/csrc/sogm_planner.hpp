@@ -161,6 +161,7 @@ struct QpWorkspace {
   // scaling, first factorisation), 2 later refactorisations, 3 their count, 4 checks (residual passes + certificates),
   // 5 their count, 6 iterations run, 8-10 the three phases of factor() summed over all factorisations; always written (a handful of clock reads per 25 iterations)
   long long    *dbg;
+  int           ablate;  // phase ablation mask of the staged k_qp launch (profiling builds only; tuning key qp_ablate)
 };
 size_t qp_scratch_bytes_per_agent(int max_faces);
 size_t qp_k1_scratch_bytes_per_agent();

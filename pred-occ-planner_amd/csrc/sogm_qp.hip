@@ -1697,12 +1697,8 @@ int launch_qp(const SogmPlannerParams &pp, const SogmQpSettings &qs, const QpWor
                               ws.dyn_lds_bytes);
     attr_set = true;
   }
-  // SOGM_QP_ABLATE (profiling aid only): bit0 skip A^T w, bit1 skip the solve, bit2/3 skip row updates
-  static int ablate = -1;
-  if (ablate < 0) {
-    const char *e = getenv("SOGM_QP_ABLATE");
-    ablate        = e ? atoi(e) : 0;
-  }
+  // ws.ablate (profiling aid only, tuning key qp_ablate): bit0 skip A^T w, bit1 skip the solve, bit2/3 skip row updates
+  const int ablate = ws.ablate;
   hipLaunchKernelGGL(k_qp, dim3(n_agents), dim3(QP_NT), ws.dyn_lds_bytes, st, pp, qs, ws, qc, start_pva,
                      goal_pv, polys, nfaces, npoly, out_cpts, out_status, out_iters, ablate, agent0);
   return hipGetLastError() == hipSuccess ? 0 : -1;

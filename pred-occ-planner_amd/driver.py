@@ -16,7 +16,6 @@ import os
 # sogm_replan runs agent groups on separate HIP streams; streams beyond the number of hardware
 # queues share a queue and serialise, so ask the runtime for more queues before HIP initialises.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
-os.environ.setdefault("SOGM_GROUPS", "8")
 
 import numpy as np
 import torch
@@ -190,7 +189,7 @@ class HipCompute:
     class — the rank-local bookkeeping around these calls is what that test covers.)"""
     device = "cuda"
 
-    def __init__(self, spec, scene, lo, hi, device, overlap_clear=True, double_buffer=None, grids=None):
+    def __init__(self, spec, scene, lo, hi, device, overlap_clear=True, double_buffer=None, grids=None, tuning=None):
         half = (spec.L // 2) * 0.15
         A_loc = hi - lo
         loc = dict(scene)
@@ -206,6 +205,10 @@ class HipCompute:
         self.A_loc = A_loc
         self.map = SogmMap(spec, A_loc, device)
         self.overlap_mode = self.map.set_overlap_clear(overlap_clear, double_buffer=double_buffer, grids=grids)
+        if "groups=" not in os.environ.get("SOGM_TUNING", ""):
+            self.map.set_tuning("groups", 8)  # the grouped-stream replan (SOGM_FLOW=0): eight agent groups (32 hardware queues)
+        for k, v in (tuning or {}).items():
+            self.map.set_tuning(k, v)
         self.planner = SogmPlanner(self.map, config.make_astar_params(), config.make_planner_params(True),
                                    config.make_qp_settings())
         self.ego_ids = self.dev["ego_ids"]
@@ -274,7 +277,7 @@ class HipCompute:
 class SwarmTick:
     def __init__(self, grid="cfg2", agents_per_rank=None, rank=0, world=1, device=0, seed=0x5069,
                  spec=None, scene=None, dist=None, overlap_clear=True, deconflict=True, fsm=False,
-                 double_buffer=None, grids=None, compute=None, exchange=None, prestamp=None):
+                 double_buffer=None, grids=None, compute=None, exchange=None, prestamp=None, tuning=None):
         self.rank, self.world, self.dist = rank, world, dist
         self.spec = spec if spec is not None else config.make_spec(grid)
         self.A_loc = agents_per_rank if agents_per_rank is not None else config.AGENTS.get(grid, 4)
@@ -283,7 +286,7 @@ class SwarmTick:
         self.scene = scene if scene is not None else scene_mod.make_scene(self.A_tot, half, seed=seed)
         lo, hi = shard_bounds(rank, world, self.A_loc)
         self.compute = compute if compute is not None else HipCompute(
-            self.spec, self.scene, lo, hi, device, overlap_clear, double_buffer, grids)
+            self.spec, self.scene, lo, hi, device, overlap_clear, double_buffer, grids, tuning)
         c = self.compute
         # the HIP objects, for the bench / tools / tests that use the staged entry points beside step()
         self.map, self.planner, self.dev = getattr(c, "map", None), getattr(c, "planner", None), getattr(c, "dev", None)

@@ -6,6 +6,7 @@ plan_env/include/plan_env/fake_particle_risk_voxel.h:49-107, risk_base.h:33-110.
 only as plumbing: device buffers and the current HIP stream.  All compute runs in libsogm_hip.so.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -46,6 +47,20 @@ class SogmMap:
             "sogm_set_body_particles")
         self.V = spec.L * spec.W * spec.H
         self._keep = []  # tensors referenced by in-flight calls
+        # SOGM_TUNING="key=value,key=value": tools and A/B scripts set the library's tuning knobs this way — applied
+        # HERE, by the binding, through sogm_set_tuning (the library itself reads no tuning from the environment)
+        for kv in filter(None, os.environ.get("SOGM_TUNING", "").split(",")):
+            k, _, v = kv.partition("=")
+            self.set_tuning(k.strip(), float(v))
+
+    # ---- tuning knobs (sogm_abi.h: sogm_set_tuning) ----
+    def set_tuning(self, key, value):
+        check(lib().sogm_set_tuning(self._ctx, key.encode(), float(value)), f"sogm_set_tuning({key})")
+
+    def get_tuning(self, key):
+        out = C.c_double(0.0)
+        check(lib().sogm_get_tuning(self._ctx, key.encode(), C.byref(out)), f"sogm_get_tuning({key})")
+        return out.value
 
     # ---- lifetime ----
     def close(self):

@@ -75,11 +75,8 @@ def _fly_spec(pop, spec, ticks=5):
     import os
     import torch
     driver = importlib.import_module("pred-occ-planner_amd.driver")
-    os.environ["SOGM_SPEC_ASTAR"] = "1" if spec else "0"  # read when the planner is created
-    try:
-        sw = driver.SwarmTick("parity", 6, scene=_enclosed_scene(pop, 6))
-    finally:
-        os.environ.pop("SOGM_SPEC_ASTAR", None)
+    # (read when the planner is created: sogm_set_tuning before sogm_planner_create)
+    sw = driver.SwarmTick("parity", 6, scene=_enclosed_scene(pop, 6), tuning={"spec_astar": 1 if spec else 0})
     oks = []
     for _ in range(ticks):
         oks.append(sw.step().cpu().numpy().copy())

@@ -1,0 +1,62 @@
+"""GPU: the bench tick under reduced residency.  The dataflow replan is built from persistent kernels that wait for each
+other on the device; its forward progress assumes that the searches, the QP workgroups and the finishing waves of a tick
+are resident together.  Here the full-size tick (128 agents, 200^3 x 20: BASELINE configs[2]) flies in child processes
+  * with ROCm's default of four hardware queues (streams share queues, launches trail gates of other streams),
+  * with half of the device's compute units masked away (ROC_GLOBAL_CU_MASK),
+and must only get slower: no failed tick, and records, ok flags and outcome counters identical, bit for bit, to the
+flight with the whole device and 32 queues."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+_FLIGHT = r"""
+import hashlib, importlib, json, os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.environ["SOGM_REPO"])
+driver = importlib.import_module("pred-occ-planner_amd.driver")
+sw = driver.SwarmTick("cfg2", 128)
+for _ in range(2):
+    sw.step()
+torch.cuda.synchronize()
+t0, oks = time.perf_counter(), []
+for _ in range(6):
+    oks.append(sw.step())
+torch.cuda.synchronize()
+ms = (time.perf_counter() - t0) / 6 * 1e3
+h = hashlib.sha256()
+h.update(sw.own.cpu().numpy().tobytes())
+h.update(torch.stack(oks).cpu().numpy().tobytes())
+print("FLIGHT " + json.dumps({"digest": h.hexdigest(), "ms_per_tick": ms, "flow_failures": list(sw.planner.flow_failures()),
+                              "counters": sw.planner.counters(), "cus": torch.cuda.get_device_properties(0).multi_processor_count}))
+sw.close()
+"""
+
+
+def _fly(**env):
+    e = dict(os.environ, SOGM_REPO=ROOT, **env)
+    r = subprocess.run([sys.executable, "-c", _FLIGHT], env=e, capture_output=True, text=True, timeout=900)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("FLIGHT ")]
+    assert r.returncode == 0 and lines, (env, r.stdout[-1500:], r.stderr[-3000:])
+    return json.loads(lines[-1][7:])
+
+
+def test_full_size_tick_with_four_queues_and_with_half_the_compute_units():
+    base = _fly(GPU_MAX_HW_QUEUES="32")
+    assert base["flow_failures"] == [0, 0]
+    four = _fly(GPU_MAX_HW_QUEUES="4")
+    half = _fly(GPU_MAX_HW_QUEUES="32", ROC_GLOBAL_CU_MASK="0x" + "f" * (base["cus"] // 8))  # the lower half of the mask bits
+    print("residency: ms per tick — whole device %.2f, four hardware queues %.2f (x%.2f), half the CUs %.2f (x%.2f)" % (
+        base["ms_per_tick"], four["ms_per_tick"], four["ms_per_tick"] / base["ms_per_tick"],
+        half["ms_per_tick"], half["ms_per_tick"] / base["ms_per_tick"]))
+    for name, f in (("four queues", four), ("half the CUs", half)):
+        assert f["flow_failures"] == [0, 0], (name, f)
+        assert f["counters"] == base["counters"], (name, f["counters"], base["counters"])
+        assert f["digest"] == base["digest"], f"{name}: records / ok flags differ from the unconstrained flight"
+    # the mask must have bitten: a masked run that is not slower did not restrict anything
+    assert half["ms_per_tick"] > 1.15 * base["ms_per_tick"], (half["ms_per_tick"], base["ms_per_tick"])

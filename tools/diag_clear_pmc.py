@@ -1,13 +1,13 @@
 """The chunked, width-adaptive SOGM clear (k_clear_chunks) by itself, for counter collection: rocprofv3 --pmc
 serialises kernels, under which the dataflow replan cannot run (its persistent kernels wait for each other), so the
 traffic of the in-tick clear kernels is measured here — the pooled update queues the clear of the swapped-out grid
-(SOGM_CLEAR_EARLY=1 makes the update itself queue it) and nothing else runs.  Serialised, the narrow launch clears the
+(tuning key clear_early = 1 makes the update itself queue it) and nothing else runs.  Serialised, the narrow launch clears the
 whole grid (the wide launch finds the cursor exhausted): bytes per launch = the grid.
 
-    SOGM_CLEAR_EARLY=1 rocprofv3 --pmc WRITE_SIZE -d /tmp/cw -- python tools/diag_clear_pmc.py
+    SOGM_TUNING=clear_early=1 rocprofv3 --pmc WRITE_SIZE -d /tmp/cw -- python tools/diag_clear_pmc.py
 """
 import importlib, os, sys
-os.environ.setdefault("SOGM_CLEAR_EARLY", "1")
+os.environ.setdefault("SOGM_TUNING", "clear_early=1")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 driver = importlib.import_module("pred-occ-planner_amd.driver")

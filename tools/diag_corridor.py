@@ -51,7 +51,7 @@ us = lambda t: t / 100.0  # 100 MHz
 print("corridor kernel ms", round(ms[4], 2), "segments", len(d))
 if os.environ.get("SOGM_CONTEND") == "2":
     torch.cuda.synchronize()
-    print("SUMMARY wgs", os.environ.get("SOGM_CLEAR_WGS"), "throttle", os.environ.get("SOGM_CLEAR_THROTTLE"),
+    print("SUMMARY tuning", os.environ.get("SOGM_TUNING"),
           "| 2 x (clear+stamp) ms", round(ev0.elapsed_time(ev1), 2), "| corridor ms", round(ms[4], 2),
           "| points us max/mean", round(d[:, 5].max() / 100.0, 1), round(d[:, 5].mean() / 100.0, 1))
 print("N pts: max/mean", d[:, 0].max(), d[:, 0].mean(), " nH0 max/mean", d[:, 1].max(), d[:, 1].mean(), " nH1 max", d[:, 2].max())

@@ -27,15 +27,15 @@ if [ "$PART" = core ]; then
   #  (k_clear_chunks) and the stamp run by themselves in tools/diag_clear_pmc.py)
   SOGM_FLOW=0 timeout 300 rocprofv3 --pmc FETCH_SIZE -d /tmp/prof_fetch -- python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --sustained 0 > /dev/null 2> $OUT/fetch.err
   SOGM_FLOW=0 timeout 300 rocprofv3 --pmc WRITE_SIZE -d /tmp/prof_write -- python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --sustained 0 > /dev/null 2> $OUT/write.err
-  SOGM_SPARSE_RESET=0 SOGM_CLEAR_EARLY=1 timeout 200 rocprofv3 --pmc FETCH_SIZE -d /tmp/prof_cfetch -- python $REPO/tools/diag_clear_pmc.py > /dev/null 2> $OUT/cfetch.err
-  SOGM_SPARSE_RESET=0 SOGM_CLEAR_EARLY=1 timeout 200 rocprofv3 --pmc WRITE_SIZE -d /tmp/prof_cwrite -- python $REPO/tools/diag_clear_pmc.py > $OUT/clear_alone.txt 2> $OUT/cwrite.err
+  SOGM_SPARSE_RESET=0 SOGM_TUNING=clear_early=1 timeout 200 rocprofv3 --pmc FETCH_SIZE -d /tmp/prof_cfetch -- python $REPO/tools/diag_clear_pmc.py > /dev/null 2> $OUT/cfetch.err
+  SOGM_SPARSE_RESET=0 SOGM_TUNING=clear_early=1 timeout 200 rocprofv3 --pmc WRITE_SIZE -d /tmp/prof_cwrite -- python $REPO/tools/diag_clear_pmc.py > $OUT/clear_alone.txt 2> $OUT/cwrite.err
   # the sparse reset (k_reset_sectors) and the logging stamp / overlay by themselves; counters for the variant the tick
   # runs under the replan (2 lanes, 1 entry per trip), launch times for it and for the in-stream variant (4 lanes x 8)
-  export SOGM_RESET_LANES=2 SOGM_RESET_UNROLL=1
+  export SOGM_TUNING=reset_lanes=2,reset_unroll=1
   timeout 200 rocprofv3 --pmc FETCH_SIZE -d /tmp/prof_rfetch -- python $REPO/tools/diag_reset_pmc.py > /dev/null 2> $OUT/rfetch.err
   timeout 200 rocprofv3 --pmc WRITE_SIZE -d /tmp/prof_rwrite -- python $REPO/tools/diag_reset_pmc.py > $OUT/reset_alone.txt 2> $OUT/rwrite.err
   timeout 200 python $REPO/tools/diag_reset_pmc.py > $OUT/reset_alone_plain.txt 2>/dev/null
-  unset SOGM_RESET_LANES SOGM_RESET_UNROLL
+  unset SOGM_TUNING
   timeout 200 python $REPO/tools/diag_reset_pmc.py > $OUT/reset_alone_wide.txt 2>/dev/null
   # the dense clear in the tick (the path of rounds 1-2), for comparison on this box
   SOGM_SPARSE_RESET=0 timeout 300 python $REPO/bench.py --steps 20 --warmup 3 --no-cpu-baseline --sustained 100 > $OUT/bench_dense.json 2>/dev/null

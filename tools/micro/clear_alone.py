@@ -1,4 +1,4 @@
-"""Micro: duration of k_clear_slabs alone on an idle GPU for the width given by SOGM_CLEAR_WGS / SOGM_CLEAR_THROTTLE
+"""Micro: duration of k_clear_slabs alone on an idle GPU for the width given by SOGM_TUNING="clear_wgs=..,clear_throttle=.."
 (128 agents x 200^3 x 20 = 81.92 GB), via the in-stream clear of an un-pipelined update."""
 import importlib, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -16,5 +16,5 @@ for _ in range(4):
     m.updateMap(dev["cloud"], dev["cloud_range"], dev["cylinders"], dev["n_cyl"], dev["poses"], dev["stamps"])
     torch.cuda.synchronize()
     ts.append(m.profile_read()[0])
-print("wgs", os.environ.get("SOGM_CLEAR_WGS", "full"), "throttle", os.environ.get("SOGM_CLEAR_THROTTLE", "-"),
+print("tuning", os.environ.get("SOGM_TUNING", "defaults"),
       "clear ms", [round(t, 2) for t in ts], "TB/s", round(81.92 / min(ts[1:]), 2))

@@ -1,4 +1,5 @@
-"""Profiling aid: fixed-iteration QP timing with phases ablated (SOGM_QP_ABLATE bitmask)."""
+"""Profiling aid: fixed-iteration QP timing with phases ablated (SOGM_QP_ABLATE bitmask -> tuning key qp_ablate; needs
+a library built with EXTRA=-DSOGM_QP_ABLATE_BUILD, e.g. SOGM_LIB_PATH=build/ablate/libsogm_hip.so)."""
 import importlib, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -26,6 +27,7 @@ qs.check_termination = int(os.environ.get('SOGM_QP_CHECK', '0'))
 qs.adaptive_rho_interval = int(os.environ.get('SOGM_QP_ADAPT', '0'))
 if qs.check_termination:
     qs.eps_abs = qs.eps_rel = 1e-13  # never converges: fixed iteration count with the checks running
+sw.map.set_tuning("qp_ablate", int(os.environ.get("SOGM_QP_ABLATE", "0")))
 P2 = planner.SogmPlanner(sw.map, pop.config.make_astar_params(), pop.config.make_planner_params(True), qs)
 for _ in range(2):
     q = P2.optimize(pva, c["goal"], c["polys"], c["nfaces"], c["npoly"])
