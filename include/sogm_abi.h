@@ -554,7 +554,10 @@ int sogm_obstacle_points(sogm_ctx *ctx, const int32_t *agent_idx, const double *
 /* ------------------------------------------------------------------------------------------ */
 typedef struct sogm_planner sogm_planner;
 
-/* FakeBaselinePlanner::init / BaselinePlanner::init (baseline_fake.cpp:18-51, baseline.cpp:15-43). */
+/* FakeBaselinePlanner::init / BaselinePlanner::init (baseline_fake.cpp:18-51, baseline.cpp:15-43).
+ * Lifetime: a planner refers to its map context until it is destroyed — destroy planners BEFORE their sogm_ctx
+ * (sogm_planner_destroy unregisters the gate / progress words the map's kernels poll and waits for them on the map's
+ * device; a C++ host declares the map member before the planner member, as host/sogm_reference_api.hpp does). */
 int  sogm_planner_create(sogm_ctx *map, const SogmAstarParams *astar, const SogmPlannerParams *pp,
                          const SogmQpSettings *qp, sogm_planner **out);
 void sogm_planner_destroy(sogm_planner *p);
@@ -706,7 +709,10 @@ enum {
  *   own_records [n_agents]  dev: overwritten with the new record where the replan succeeded (latest wins);
  *   next_table  [n_agents]  dev or NULL: receives every agent's CURRENT record (new, or the one it keeps executing) —
  *                           the swarm table of the NEXT tick for a single-process host (n_total == n_agents), which
- *                           must differ from the table registered with sogm_planner_set_swarm for this replan.
+ *                           must differ from the table registered with sogm_planner_set_swarm for this replan
+ *                           (sogm_replan returns SOGM_ERR_INVALID_ARG when the two are the same table, or when
+ *                           own_records overlaps its out_records: the finishing kernel would write what other agents'
+ *                           deconfliction reads in the same launch).
  * NULL, NULL switches it off (the default).  Pointers are read by later sogm_replan calls.
  */
 int sogm_planner_set_publish(sogm_planner *p, SogmTrajRecord *own_records, SogmTrajRecord *next_table);
@@ -726,8 +732,11 @@ int sogm_planner_set_publish(sogm_planner *p, SogmTrajRecord *own_records, SogmT
  * pre-stamp, which goes on for a few hundred microseconds on a stream of the context.  The SogmPrestamp outputs and the
  * pre-stamped grid are complete in stream order behind the next sogm_update_prestamped / sogm_update_* / sogm_replan
  * call on a stream (each joins it), or after a device synchronisation — sogm_update_prestamped launches its overlay
- * under that tail, an agent's additions waiting for that agent's stamp.  SOGM_SPLAT_OVERLAP=0 restores the join
- * inside sogm_replan. */
+ * under that tail, an agent's additions waiting for that agent's stamp.  Tuning key "splat_overlap" = 0 restores the
+ * join inside sogm_replan.
+ * Failed ticks: if the pre-stamping replan failed on the device (sogm_planner_flow_failures), its grid is incomplete;
+ * sogm_update_prestamped then returns SOGM_ERR_STATE once the failure has reached the host — rebuild the map with
+ * sogm_tick_inputs + sogm_update_gt_swarm, which discards the grid and clears the stamp's bitmask. */
 typedef struct SogmPrestamp {
   const float        *cloud_xyz;    /* next update's inputs, as for sogm_update_gt (device) */
   const int32_t      *cloud_range;

@@ -436,6 +436,11 @@ struct sogm_ctx {
   int                   pdone_pending;
   const int            *ps_stage;  // the planner's per-agent pre-stamp progress words, ps_err its error word
   int                  *ps_err;
+  // the pre-stamping planner's pinned failure words {code, failed ticks} and the count when the pre-stamp was queued:
+  // a pre-stamped grid whose replan failed since is refused by sogm_update_prestamped (the host falls back to
+  // sogm_update_gt*, which discards the grid and clears the stamp's bitmask)
+  volatile int         *ps_fail_host;
+  int                   ps_fail_seen;
   double         tune[SOGM_TUNE_N];  // sogm_set_tuning; defaults from SOGM_TUNING_TABLE at sogm_create
   int            tune_i(int k) const { return (int)tune[k]; }
   int            profiling;   // bit k: slot k is timed (sogm_set_profiling: all, sogm_set_profiling_slots: a choice)

@@ -1784,6 +1784,12 @@ static int update_gt_impl(sogm_ctx *c, const float *cloud_xyz, const int32_t *cl
       rc = sogm::reset_slot(c, st, stale, c->d_grid, false);
       if (rc) return rc;
     }
+    if (stale >= 0 && c->d_stamp_bits) {
+      // a pre-stamp that was cut short (a failed tick) may have left occupancy bits behind — only consumed words are
+      // zeroed — and they are relative to ITS map centres: start this stamp from a clean mask
+      const int words = (((c->geom.V + 31) / 32) + 255) & ~255;
+      SOGM_HIP_CHECK(hipMemsetAsync(c->d_stamp_bits, 0, sizeof(unsigned) * (size_t)words * A, st));
+    }
   } else {
     int rc = clear_grid(c, st);
     if (rc) return rc;
@@ -1854,6 +1860,11 @@ int sogm_update_prestamped(sogm_ctx *c, const SogmTrajRecord *records, int n_rec
     return SOGM_ERR_STATE;
   }
   if (n_records > 0 && (!c->d_body || c->n_body <= 0)) return SOGM_ERR_STATE;
+  if (c->ps_fail_host && c->ps_fail_host[1] != c->ps_fail_seen) {
+    sogm::set_error_text("sogm_update_prestamped: the replan that pre-stamped this grid failed on the device "
+                         "(sogm_planner_flow_failures); build the map with sogm_update_gt[_swarm] instead");
+    return SOGM_ERR_STATE;
+  }
   SOGM_HIP_CHECK(hipSetDevice(c->device));
   hipStream_t st = (hipStream_t)stream;
   if (n_records > 0)

@@ -246,6 +246,9 @@ int sogm_planner_create(sogm_ctx *map, const SogmAstarParams *astar, const SogmP
 }
 void sogm_planner_destroy(sogm_planner *p) {
   if (!p) return;
+  // (the planner's map must still exist: sogm_abi.h "destroy planners before their sogm_ctx")
+  if (p->map) (void)hipSetDevice(p->map->device);
+  if (p->map && p->map->ps_fail_host == p->h_flow_fail) p->map->ps_fail_host = nullptr;
   if (p->map && p->map->pdone_pending && p->map->ev_pdone == p->ev_pdone) {
     (void)hipDeviceSynchronize();  // a pre-stamp nobody joined: its event and progress words go away with this planner
     p->map->pdone_pending = 0;
@@ -632,8 +635,11 @@ static int replan_flow(sogm_planner *p, const double *start_pva, const double *g
     if (rc) return rc;
   }
   sogm::FlowCtl fcf = p->fc;
-  // (not with the dense clear: the pre-stamp runs behind the target grid's reset on the side stream, and a dense clear
-  //  fills that stream for the whole tick)
+  // (only with the sparse reset: the pre-stamp runs behind the target grid's reset on the side stream, and with
+  //  SOGM_SPARSE_RESET=0 a dense clear fills that stream for the whole tick.  On the first ticks of a flight — and
+  //  after a dense writer — queue_spare_clears above has queued dense clears even in sparse mode: the pre-stamp, the
+  //  report and ev_pdone then sit behind them, the next sogm_update_prestamped overlay waits per agent for as long
+  //  (tests/test_pipelining_gpu.py::test_overlay_under_the_prestamp_tail_at_full_size flies exactly that).)
   const bool prestamp = p->ps_on && c->sparse && c->overlap >= 2 && c->n_ready > 0 && p->pub_own && c->clear_gate;
   if (!prestamp) fcf.p_ready = nullptr;
   if (sogm::launch_finish_flow(fcf, A, wg_f, p->pp.corridor_tau, p->d_ret, p->d_npoly, p->d_status, p->d_cpts,
@@ -681,6 +687,8 @@ static int replan_flow(sogm_planner *p, const double *start_pva, const double *g
     }
     c->prestamp_slot = nxt;
     c->n_stamps++;
+    c->ps_fail_host = p->h_flow_fail;  // sogm_update_prestamped refuses the grid if this replan turns out to have failed
+    c->ps_fail_seen = p->h_flow_fail ? p->h_flow_fail[1] : 0;
   }
   for (int k = 0; k < 4; ++k) {
     SOGM_HIP_CHECK(hipEventRecord(p->ev_fdone[k], p->fstream[k]));
@@ -818,6 +826,20 @@ int sogm_replan(sogm_planner *p, const double *start_pva, const double *goal,
     return SOGM_ERR_INVALID_ARG;
   if (!p->map->updated) return SOGM_ERR_STATE;
   sogm_ctx *c = p->map;
+  // publication (sogm_planner_set_publish): the finishing kernel writes every agent's record into next_table while
+  // other agents' deconfliction still reads the swarm table, and into own_records while out_records is written
+  if (p->pub_table && p->swarm && (const void *)p->pub_table == (const void *)p->swarm) {
+    sogm::set_error_text("sogm_replan: sogm_planner_set_publish's next_table is the table given to sogm_planner_set_swarm");
+    return SOGM_ERR_INVALID_ARG;
+  }
+  if (p->pub_own) {
+    const char *a0 = (const char *)p->pub_own, *a1 = a0 + sizeof(SogmTrajRecord) * (size_t)c->n_agents;
+    const char *b0 = (const char *)out_records, *b1 = b0 + sizeof(SogmTrajRecord) * (size_t)c->n_agents;
+    if (a0 < b1 && b0 < a1) {
+      sogm::set_error_text("sogm_replan: out_records overlaps sogm_planner_set_publish's own_records");
+      return SOGM_ERR_INVALID_ARG;
+    }
+  }
   SOGM_HIP_CHECK(hipSetDevice(c->device));
   // the in-place pre-clear (mode 1) needs the grouped path's "last reader of the SOGM" events
   const bool use_flow = p->flow && c->overlap != 1;

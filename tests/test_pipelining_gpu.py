@@ -267,3 +267,29 @@ def test_overlay_under_the_prestamp_tail_at_full_size(pop):
     np.testing.assert_array_equal(own_a, own_b)
     for x, y in zip(g_a, g_b):
         np.testing.assert_array_equal(x, y)
+
+
+def test_publication_into_the_table_the_replan_reads_is_refused(pop):
+    """sogm_planner_set_publish: next_table must not be the swarm table of the same replan (the finishing kernel would
+    write what other agents' deconfliction reads in the same launch), own_records must not overlap out_records:
+    sogm_replan refuses both instead of racing."""
+    import torch
+    driver = importlib.import_module("pred-occ-planner_amd.driver")
+    sw = driver.SwarmTick("parity", 4, prestamp=False)
+    sw.step()
+    c = sw.compute
+    c.tick_inputs(sw.own, sw.t0 + sw.tick * 0.1, sw.hover, sw.now, sw.t_start, sw.pva, sw.poses)
+    c.update_map(sw.poses, sw.now, sw.all, sw.A_tot)
+    P = sw.planner
+    P.setSwarm(sw.all, sw.A_tot, sw.dev["ego_ids"], sw.now)
+    P.setPublish(sw.own, sw.all)  # next_table == the swarm table
+    with pytest.raises(pop._abi.SogmError, match="next_table"):
+        P.replan(sw.pva, sw.goals, sw.t_start, sw.dev["ego_ids"], sw.new, sw.ok)
+    P.setPublish(sw.own, torch.zeros_like(sw.all))
+    with pytest.raises(pop._abi.SogmError, match="overlaps"):
+        P.replan(sw.pva, sw.goals, sw.t_start, sw.dev["ego_ids"], sw.own, sw.ok)  # out_records == own_records
+    P.setPublish(sw.own, torch.zeros_like(sw.all))
+    P.replan(sw.pva, sw.goals, sw.t_start, sw.dev["ego_ids"], sw.new, sw.ok)     # the valid form still runs
+    torch.cuda.synchronize()
+    assert P.flow_failures() == (0, 0)
+    sw.close()
