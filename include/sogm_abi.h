@@ -204,6 +204,19 @@ int sogm_set_sparse_reset(sogm_ctx *ctx, int enable, int log_capacity);
  * launch, mean KiB zeroed per such launch (the stores the reset kernel issued, counted on the device)}.
  * Synchronises. */
 int sogm_sparse_reset_state(sogm_ctx *ctx, int32_t *out_host);
+/* Resample branch of ParticleATC::getParticlesWithRisk (particles.cpp:365-409; swarm/replan_risk_rate and
+ * swarm/num_resample, particles.cpp:33-34 — 0.00 in every shipped configuration, which is also the default here).  With
+ * a rate > 0 a neighbour's body particle at slice time t is replaced, once replan_risk_rate * (t - time_start) >= 1e-3,
+ * by num_resample Gaussian samples weighted exp(-|n|^2 / 2 sigma^2), the weights normalised to num_resample per
+ * particle, and the map receives the weights instead of 1.0.  The reference draws the noise from
+ * std::default_random_engine(time(NULL)), re-seeded at every call: every call of one wall-clock second replays one
+ * sequence.  The host injects that sequence as a table of standard normals (device, float, kept alive by the caller,
+ * >= 3 * body particles * num_resample entries): sample i of particle e uses entries 3 (e n + i) + {0, 1, 2} times
+ * sigma.  Applies to sogm_project_neighbours / sogm_update_gt_swarm / sogm_update_prestamped on FAKE and RISKBASE maps
+ * with fp32 cells (RiskVoxel's overlay does not resample, risk_voxel.cpp:258-339).  Call after
+ * sogm_set_body_particles.  rate 0 or num_resample 0 switches it off. */
+int sogm_set_resample(sogm_ctx *ctx, float replan_risk_rate, int num_resample, const float *normal_table_dev,
+                      int n_table);
 /* Tuning knobs.  Every internal width and switch of the library has a default chosen on MI355X; a host that wants
  * another value sets it per context — nothing is read from the environment (the library's only environment switches are
  * SOGM_SPARSE_RESET, SOGM_FLOW and SOGM_RCCL_LIB).  Keys (defaults in parentheses):
@@ -655,7 +668,9 @@ int sogm_firi_batched(const double *bd, int n_bd, const double *pc_xyz, const in
  * NO_PATH, reset() + search(…, false, …) (baseline_fake.cpp:284-291); 1 / 2 = exactly one
  * RiskHybridAstar::search with init_search = true / false (risk_hybrid_a_star.h:103-110).  Adding 4 makes
  * sogm_astar_search read t_start[] as that function's time_start argument (seconds after the map stamp) instead of
- * an absolute time.
+ * an absolute time.  Adding 16 selects search(…, dynamic = false, …): the reference's branch reads node times it never
+ * writes (risk_hybrid_a_star.cpp:153-158,177,271,324); they are DEFINED as zero here (oracle/astar_oracle.cpp does the
+ * same): a spatial search over the SOGM's first tau seconds, t_start ignored.
  */
 int sogm_planner_select_agents(sogm_planner *p, int first, int count);
 

@@ -227,5 +227,38 @@ SOGM_HD double log(double x) {
   return ef * LN2_H + (lm + ef * LN2_L);
 }
 
+/* exp(x) for a float x <= 0, returned as a float: the Gaussian weight of ParticleATC::getParticlesWithRisk's resample
+ * branch (particles.cpp:399).  exp(x) = 2^k exp(r), k = nearest integer to x / ln 2, r = x - k ln 2 in two parts,
+ * exp(r) by its Taylor series to r^13 (|r| <= 0.35: remainder < 1e-17) — fp64 operations only, so the oracle and the
+ * device agree bit for bit; against libm's expf the float result differs by at most one ulp. */
+SOGM_HD float expf_neg(float xf) {
+  if (!(xf <= 0.0f)) return 1.0f;  /* (also NaN) */
+  if (xf < -104.0f) return 0.0f;
+  const double x     = (double)xf;
+  const double LOG2E = 1.44269504088896338700e+00;
+  const double LN2_H = 6.93147180369123816490e-01;
+  const double LN2_L = 1.90821492927058770002e-10;
+  const double kd    = (double)(long long)(x * LOG2E - 0.5);  /* x <= 0: truncation after -0.5 rounds to nearest */
+  const double r     = (x - kd * LN2_H) - kd * LN2_L;
+  double       p     = 1.0 / 6227020800.0;
+  p                  = p * r + 1.0 / 479001600.0;
+  p                  = p * r + 1.0 / 39916800.0;
+  p                  = p * r + 1.0 / 3628800.0;
+  p                  = p * r + 1.0 / 362880.0;
+  p                  = p * r + 1.0 / 40320.0;
+  p                  = p * r + 1.0 / 5040.0;
+  p                  = p * r + 1.0 / 720.0;
+  p                  = p * r + 1.0 / 120.0;
+  p                  = p * r + 1.0 / 24.0;
+  p                  = p * r + 1.0 / 6.0;
+  p                  = p * r + 0.5;
+  p                  = p * r + 1.0;
+  p                  = p * r + 1.0;
+  const int k        = (int)kd;  /* >= -151 */
+  /* 2^k in two exact factors (k may be below the normal exponent range of one factor for a float-denormal result) */
+  const int k1 = k / 2, k2 = k - k1;
+  return (float)((p * from_bits((uint64_t)(1023 + k1) << 52)) * from_bits((uint64_t)(1023 + k2) << 52));
+}
+
 }  // namespace sogm_det
 #endif

@@ -218,9 +218,15 @@ struct Search {
     std::reverse(node_path.begin(), node_path.end());
   }
 
+  // dynamic = false (risk_hybrid_a_star.cpp:153-158,271,287,350-358): the reference never writes PathNode::time /
+  // time_idx in that branch and reads them all the same (collision sample times :324, exceed_time :177) —
+  // uninitialised members of `new PathNode`, or the values a previous search left in the reused pool.  DEFINED here
+  // (and in the HIP kernel, search_mode bit 4) as zero: every node's time and time index are 0, which makes the
+  // 4-D table / prune / same-voxel tests coincide with the branch's 3-D ones and samples the SOGM at [0, tau].
+  bool dynamic = true;
   int search(const double start_pt[3], const double start_v[3], const double start_a[3],
              const double end_pt[3], const double end_v[3], bool init, double time_start) {
-    const bool dynamic = true;
+    if (!dynamic) time_start = 0.0;
     std::priority_queue<int, std::vector<int>, Cmp> open_set(Cmp{&pool});
     for (int i = 0; i < 3; ++i) map_center[i] = (double)pose[i];  // :126
     Node &n0 = pool[0];
@@ -301,7 +307,7 @@ struct Search {
         const double tau   = tau_fixed;
         double       pro_state[6];
         stateTransit(cur_state, pro_state, um, tau);
-        const double pro_t = pool[cur].time + tau;
+        const double pro_t = dynamic ? pool[cur].time + tau : 0.0;
         int          pro_id[3];
         posToIndex(pro_state, pro_id);
         const int pro_t_id = timeToIndex(pro_t);
@@ -344,7 +350,7 @@ struct Search {
               for (int q = 0; q < 6; ++q) en.state[q] = pro_state[q];
               for (int q = 0; q < 3; ++q) en.input[q] = um[q];
               en.duration = tau;
-              en.time     = pool[cur].time + tau;
+              en.time     = dynamic ? pool[cur].time + tau : 0.0;
             }
             break;
           }
@@ -361,7 +367,7 @@ struct Search {
             pn.duration   = tau;
             pn.parent     = cur;
             pn.node_state = IN_OPEN_SET;
-            pn.time       = pool[cur].time + tau;
+            pn.time       = dynamic ? pool[cur].time + tau : 0.0;
             pn.time_idx   = timeToIndex(pn.time);
             open_set.push(pro_node);
             // :387  insert(pro_id, pro_node->time, pro_node): double -> int truncation
@@ -378,7 +384,7 @@ struct Search {
               for (int q = 0; q < 3; ++q) pn.input[q] = um[q];
               pn.duration = tau;
               pn.parent   = cur;
-              pn.time     = pool[cur].time + tau;
+              pn.time     = dynamic ? pool[cur].time + tau : 0.0;
             }
           } else {
             return SEARCH_ERR;
@@ -447,7 +453,8 @@ int orc_astar_debug_nodes(double *out, int n) {
   return k;
 }
 
-// 0: the replan's call pattern (baseline_fake.cpp:284-291); 1 / 2: one search(…, init = true / false, …)
+// 0: the replan's call pattern (baseline_fake.cpp:284-291); 1 / 2: one search(…, init = true / false, …);
+// + 16: search(…, dynamic = false, …) with node times defined as zero (see Search::dynamic)
 static int g_search_mode = 0;
 void orc_astar_set_mode(int mode) { g_search_mode = mode; }
 
@@ -461,7 +468,7 @@ int orc_astar_search(const SogmSpec *s, const SogmAstarParams *ap, const float *
   int              searches = 0;
   int              rst      = NO_PATH;
   Search           last;
-  const int attempt_lo = g_search_mode == 2 ? 1 : 0, attempt_hi = g_search_mode == 1 ? 1 : 2;
+  const int attempt_lo = (g_search_mode & 3) == 2 ? 1 : 0, attempt_hi = (g_search_mode & 3) == 1 ? 1 : 2;
   for (int attempt = attempt_lo; attempt < attempt_hi; ++attempt) {  // baseline_fake.cpp:284-291
     Search S;
     S.spec = s;
@@ -477,6 +484,7 @@ int orc_astar_search(const SogmSpec *s, const SogmAstarParams *ap, const float *
     S.inv_time_resolution = 1.0 / ap->time_resolution;
     S.tie_breaker         = 1.0 + 1.0 / 10000;
     S.trace               = &trace;
+    S.dynamic             = (g_search_mode & 16) == 0;
     rst = S.search(start_pva, start_pva + 3, start_pva + 6, goal, zero, attempt == 0, t_after_map);
     ++searches;
     last = std::move(S);

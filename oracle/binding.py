@@ -110,6 +110,16 @@ def project_neighbours(spec, grid, records, n_rec, ego_id, body, pose, stamp):
     return grid
 
 
+_resample_keep = None
+
+
+def set_resample(rate, n, table):
+    """ParticleATC's resample branch for project_neighbours (off: rate 0); `table` float32 standard normals."""
+    global _resample_keep
+    _resample_keep = np.ascontiguousarray(table, np.float32) if table is not None else None
+    lib().orc_set_resample(C.c_float(rate), int(n), fptr(_resample_keep) if _resample_keep is not None else None)
+
+
 def query_clear(spec, grid, pose, pos, t, t_is_index=False):
     pose = np.ascontiguousarray(pose, np.float32)
     pos = np.ascontiguousarray(pos, np.float64)

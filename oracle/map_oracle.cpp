@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "oracle.h"
+#include "../include/sogm_detmath.h"
 
 namespace {
 
@@ -369,6 +370,17 @@ static void projectNeighboursRiskVoxel(const SogmSpec *s, const SogmTrajRecord *
   }
 }
 
+// ParticleATC's resample branch (particles.cpp:365-409), off by default; see include/sogm_abi.h sogm_set_resample for
+// the injected table that stands in for std::default_random_engine(time(NULL))
+static float        g_rs_rate = 0.0f;
+static int          g_rs_n    = 0;
+static const float *g_rs_z    = nullptr;
+void orc_set_resample(float rate, int n, const float *table) {
+  g_rs_rate = rate;
+  g_rs_n    = n;
+  g_rs_z    = table;
+}
+
 void orc_project_neighbours(const SogmSpec *s, const SogmTrajRecord *rec, int n_rec, int ego_id,
                             const double *body, int n_body, const float pose[3], double stamp,
                             float *grid) {
@@ -409,6 +421,35 @@ void orc_project_neighbours(const SogmSpec *s, const SogmTrajRecord *rec, int n_
       const bool ok = got && !pts.empty();
       valid[i]      = ok ? 1 : 0;
       if (!ok) continue;
+      // :365  float pos_stddev = replan_risk_rate_ * static_cast<float>(t0 - ptr->time_start)
+      const float sd = g_rs_rate * (float)(t - r.time_start);
+      if (g_rs_n > 0 && g_rs_z && !(sd < 1e-3F)) {  // :382-409 resample particles
+        const int n = g_rs_n;
+        for (size_t e = 0; e < pts.size() / 3; ++e) {
+          const float       *z = g_rs_z + 3 * e * n;
+          std::vector<float> risk_buf, noise;
+          for (int i = 0; i < n; ++i) {
+            const float nx = z[3 * i] * sd, ny = z[3 * i + 1] * sd, nz = z[3 * i + 2] * sd;  // N(0, sd) = z * sd + 0
+            noise.push_back(nx);
+            noise.push_back(ny);
+            noise.push_back(nz);
+            // :399  std::exp(-0.5f * (nx * nx + ny * ny + nz * nz) / (pos_stddev * pos_stddev))
+            risk_buf.push_back(sogm_det::expf_neg((-0.5F * ((nx * nx + ny * ny) + nz * nz)) / (sd * sd)));
+          }
+          float sum = 0.0F;  // :405 std::accumulate(..., 0.0f)
+          for (float v : risk_buf) sum += v;
+          for (int i = 0; i < n; ++i) {
+            const float rk = (risk_buf[i] * (float)n) / sum;  // :406 r * num_resample_ / sum
+            const float fx = (float)((pts[e * 3 + 0] + (double)noise[3 * i + 0]) - (double)pose[0]);
+            const float fy = (float)((pts[e * 3 + 1] + (double)noise[3 * i + 1]) - (double)pose[1]);
+            const float fz = (float)((pts[e * 3 + 2] + (double)noise[3 * i + 2]) - (double)pose[2]);
+            if (!g.writableF(fx, fy, fz)) continue;
+            // (the reference indexes one risks vector with all agents' particles, UB: each particle adds its own weight)
+            grid[(size_t)g.indexF(fx, fy, fz) * T + t_idx] += rk;
+          }
+        }
+        continue;
+      }
       // replan_risk_rate == 0  ->  risk 1.0 per particle (:375-381)
       for (size_t e = 0; e < pts.size() / 3; ++e) {
         // risk_base.cpp:162-164: pt - pose_.cast<double>(), then cast<float> (:203)

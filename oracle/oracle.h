@@ -84,6 +84,7 @@ int orc_astar_search(const SogmSpec *s, const SogmAstarParams *ap, const float *
 /* 0 (default): search(…, init = true, …), then reset() + search(…, false, …) if NO_PATH (baseline_fake.cpp:284-291);
  * 1 / 2: exactly one RiskHybridAstar::search with init = true / false */
 void orc_astar_set_mode(int mode);
+void orc_set_resample(float rate, int n, const float *table);  /* particles.cpp:365-409, off by default */
 
 /* ---- a12: sdlp::linprog<d>  min c^T x s.t. A x <= b  (traj_utils/include/traj_utils/sdlp.hpp:709-787) */
 /* d in {3,4}; A row-major m x d; returns minimum, +inf infeasible, -inf unbounded */

@@ -124,6 +124,7 @@ PROTOTYPES = {
     "sogm_sparse_reset_state": (_i, [_vp, _vp]),
     "sogm_grid_history": (_i, [_vp, _vp]),
     "sogm_map_traffic": (_i, [_vp, _vp, _i]),
+    "sogm_set_resample": (_i, [_vp, C.c_float, _i, _vp, _i]),
     "sogm_set_tuning": (_i, [_vp, C.c_char_p, C.c_double]),
     "sogm_get_tuning": (_i, [_vp, C.c_char_p, C.POINTER(C.c_double)]),
     "sogm_tuning_key": (C.c_char_p, [_i]),

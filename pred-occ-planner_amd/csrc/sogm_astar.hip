@@ -385,7 +385,12 @@ __global__ __launch_bounds__(ASTAR_THREADS) void k_astar(
   const double  inv_tres  = 1.0 / ap.time_resolution;
   // baseline_fake.cpp:282: t_after_map = traj_start_time_ - map_->getMapTime()
   // search_mode bit 2: t_start already is RiskHybridAstar::search's time_start argument (seconds after the map stamp)
-  const double time_start  = (search_mode & 4) ? t_start[agent] : t_start[agent] - m.stamps[agent];
+  // search_mode bit 4: RiskHybridAstar::search(..., dynamic = false, ...) — the reference's branch never writes the
+  // nodes' time / time_idx and reads them all the same (risk_hybrid_a_star.cpp:153-158,177,271,324): defined here, as
+  // in oracle/astar_oracle.cpp, with every node's time and time index ZERO, under which the 4-D table, the prune and
+  // the same-voxel test coincide with the branch's 3-D ones and the SOGM is sampled over [0, tau]
+  const bool   static_time = (search_mode & 16) != 0;
+  const double time_start  = static_time ? 0.0 : (search_mode & 4) ? t_start[agent] : t_start[agent] - m.stamps[agent];
   const double time_origin = time_start;
   const double tau         = ap.time_resolution;
 
@@ -592,8 +597,8 @@ __global__ __launch_bounds__(ASTAR_THREADS) void k_astar(
       }
       // ---------------- all lanes: evaluate primitive `tid` + probe the hash ----------------
       const bool   first  = s_was_first != 0;
-      const double new_t  = s_cur_time + tau;
-      const int    new_ti = (int)floor((new_t - time_origin) * inv_tres);
+      const double new_t  = static_time ? 0.0 : s_cur_time + tau;
+      const int    new_ti = static_time ? 0 : (int)floor((new_t - time_origin) * inv_tres);
       const int    my_base = s_base_node, my_cur = s_cur_node;  // (the master rewrites them while the lanes still write)
       prev_base   = my_base;
       prev_cur    = my_cur;

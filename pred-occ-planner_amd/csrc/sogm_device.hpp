@@ -12,6 +12,7 @@
 #include <stdint.h>
 
 #include "../../include/sogm_abi.h"
+#include "../../include/sogm_detmath.h"
 
 namespace sogm {
 
@@ -32,6 +33,11 @@ struct GridGeom {
   int   inf_step;     // (int)(clearance / res) in fp32 (risk_base.cpp:31)
   int   map_kind;
   int   half;         // 1: occupancy stored as __half (SOGM_STORE_F16), arithmetic stays fp32
+  // resample branch of ParticleATC::getParticlesWithRisk (sogm_set_resample; rate 0 = off, the shipped configurations)
+  float        rs_rate;  // swarm/replan_risk_rate
+  int          rs_n;     // swarm/num_resample
+  const float *rs_z;     // injected standard-normal table, device
+  int          rs_nz;
 
   // map.h:153-157 — strict inequalities
   __host__ __device__ inline bool in_range(float x, float y, float z) const {
@@ -82,6 +88,10 @@ inline GridGeom make_geom(const SogmSpec &s) {
   g.inf_step       = (int)(s.clearance / s.resolution);
   g.map_kind       = s.map_kind;
   g.half           = s.storage == SOGM_STORE_F16 ? 1 : 0;
+  g.rs_rate        = 0.0f;
+  g.rs_n           = 0;
+  g.rs_z           = nullptr;
+  g.rs_nz          = 0;
   // RiskVoxel::getClearOcccupancy (risk_voxel.cpp:399-423) compares the K-cell sum with the fixed
   // map/risk_threshold_astar: the RiskBase rule with risk_threshold_region = that value and no decay.
   // It inherits MapBase::getObstaclePoints (map.cpp:480-518): fixed risk_threshold as well.

@@ -632,6 +632,42 @@ __device__ inline void splat_item(const GridGeom &g, void *__restrict__ grid, co
   const float *pose = poses + agent * 3;
   const double q0 = (double)pose[0], q1 = (double)pose[1], q2 = (double)pose[2];
   char        *slab = reinterpret_cast<char *>(grid) + ((size_t)agent * g.T + t) * (size_t)g.V * (g.half ? 2 : 4);
+  // getParticlesWithRisk (particles.cpp:365-409): pos_stddev = replan_risk_rate * (t - time_start) in float; below 1e-3
+  // (every shipped configuration: the rate is 0) each body particle counts 1.0; otherwise each is replaced by
+  // num_resample Gaussian samples whose weights are normalised to num_resample per particle.
+  const float sd = g.rs_rate * (float)(tt - R.time_start);
+  if (g.rs_n > 0 && g.rs_z != nullptr && !(sd < 1e-3F)) {
+    // The reference draws from std::default_random_engine(time(NULL)) — re-seeded at every call, so every call within
+    // one second sees the same sequence: the injected table plays that sequence, entry 3 (e n + i) + d for sample i of
+    // particle e, axis d (sogm_set_resample).  Weights: float arithmetic in the reference's order; exp through
+    // sogm_det::expf_neg on both sides.  (RiskBase::addOtherAgents indexes ONE risks vector, cleared by every
+    // getParticlesWithRisk call, with the particles of ALL agents — an out-of-bounds read once two agents contribute;
+    // here and in the oracle a particle adds its own weight, the evident intent.)
+    const int      n  = g.rs_n;
+    const unsigned lb = lent ? log_reserve(lg, agent, (unsigned)(n_body * n)) : 0u;
+    for (int e = 0; e < n_body; ++e) {
+      const double w0 = p[0] + body[e * 3 + 0], w1 = p[1] + body[e * 3 + 1], w2 = p[2] + body[e * 3 + 2];
+      const float *z  = g.rs_z + 3 * e * n;
+      float        sum = 0.0F;  // std::accumulate(risk_buf.begin(), risk_buf.end(), 0.0f)
+      for (int i = 0; i < n; ++i) {
+        const float nx = z[3 * i] * sd, ny = z[3 * i + 1] * sd, nz = z[3 * i + 2] * sd;
+        sum += sogm_det::expf_neg((-0.5F * ((nx * nx + ny * ny) + nz * nz)) / (sd * sd));
+      }
+      for (int i = 0; i < n; ++i) {
+        const float nx = z[3 * i] * sd, ny = z[3 * i + 1] * sd, nz = z[3 * i + 2] * sd;
+        const float rk = (sogm_det::expf_neg((-0.5F * ((nx * nx + ny * ny) + nz * nz)) / (sd * sd)) * (float)n) / sum;
+        const float fx = (float)((w0 + (double)nx) - q0);
+        const float fy = (float)((w1 + (double)ny) - q1);
+        const float fz = (float)((w2 + (double)nz) - q2);
+        const int   vx = g.in_range(fx, fy, fz) ? g.voxel_of(fx, fy, fz) : g.V;
+        const bool  in = vx < g.V;
+        const unsigned li = lb + (unsigned)(e * n + i);
+        if (lent && li < (unsigned)lg.cap) lent[li] = in ? (unsigned)((tslab + vx) >> esh) : 0xFFFFFFFFu;
+        if (in) cell_add(slab, vx, rk, g.half);  // (fractional weights: the sum depends on the order in the last bits)
+      }
+    }
+    return;
+  }
   const unsigned lb = lent ? log_reserve(lg, agent, (unsigned)n_body) : 0u;
   for (int e = 0; e < n_body; ++e) {
     const float fx = (float)((p[0] + body[e * 3 + 0]) - q0);
@@ -1599,6 +1635,27 @@ int sogm_get_tuning(const sogm_ctx *c, const char *key, double *out) {
   return SOGM_OK;
 }
 const char *sogm_tuning_key(int index) { return index >= 0 && index < SOGM_TUNE_N ? k_tune_names[index] : nullptr; }
+
+int sogm_set_resample(sogm_ctx *c, float replan_risk_rate, int num_resample, const float *normal_table_dev, int n_table) {
+  if (!c || !(replan_risk_rate >= 0.0f) || num_resample < 0 || n_table < 0) return SOGM_ERR_INVALID_ARG;
+  const bool on = replan_risk_rate > 0.0f && num_resample > 0;
+  if (on) {
+    if (!normal_table_dev || c->n_body <= 0 || n_table < 3 * c->n_body * num_resample) {
+      sogm::set_error_text("sogm_set_resample: the table must hold 3 * body particles * num_resample standard normals "
+                           "(call sogm_set_body_particles first)");
+      return SOGM_ERR_INVALID_ARG;
+    }
+    if (c->geom.half) {
+      sogm::set_error_text("sogm_set_resample: fractional weights need SOGM_STORE_F32 cells");
+      return SOGM_ERR_INVALID_ARG;
+    }
+  }
+  c->geom.rs_rate = on ? replan_risk_rate : 0.0f;
+  c->geom.rs_n    = on ? num_resample : 0;
+  c->geom.rs_z    = on ? normal_table_dev : nullptr;
+  c->geom.rs_nz   = on ? n_table : 0;
+  return SOGM_OK;
+}
 
 int sogm_map_traffic(sogm_ctx *c, int64_t *out, int reset) {
   if (!c || !out) return SOGM_ERR_INVALID_ARG;

@@ -444,7 +444,7 @@ int sogm_planner_select_agents(sogm_planner *p, int first, int count) {
   return SOGM_OK;
 }
 int sogm_planner_set_search_mode(sogm_planner *p, int mode) {
-  if (!p || mode < 0 || mode > 7 || (mode & 3) == 3) return SOGM_ERR_INVALID_ARG;
+  if (!p || mode < 0 || (mode & ~(3 | 4 | 16)) != 0 || (mode & 3) == 3) return SOGM_ERR_INVALID_ARG;
   p->search_mode = mode;
   return SOGM_OK;
 }

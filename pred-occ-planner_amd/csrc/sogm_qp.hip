@@ -215,7 +215,7 @@ __device__ __forceinline__ void qp_solve_agent(const SogmPlannerParams &pp, cons
 #endif
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const long long dbg_t0 = wall_clock64(), dbg_clk0 = clock64();
-  long long       dbg_refac = 0, dbg_check = 0, dbg_f1 = 0, dbg_f2 = 0, dbg_f3 = 0;
+  long long       dbg_refac = 0, dbg_check = 0, dbg_f1 = 0, dbg_f2 = 0, dbg_f3 = 0, dbg_k1 = 0, dbg_k2 = 0;
   int             dbg_nrefac = 0, dbg_ncheck = 0;
   const int M = npoly[agent];
   if (M <= 0 || M > SOGM_MAX_PIECES) {
@@ -1157,18 +1157,30 @@ __device__ __forceinline__ void qp_solve_agent(const SogmPlannerParams &pp, cons
     if (!(ndy > eps_inf)) return false;
     if (!(lhs < -eps_inf * ndy)) return false;
     double na = 0;
-    for (int j = tid; j < n; j += QP_NT) {
-      double a = 0;
-      for (int q = s_cptr[j]; q < s_cptr[j + 1]; ++q) {
-        const int en = R.cidx[q], r = en >> 3;
-        a += R.gval[(size_t)r * QP_ELL + (en & 7)] * R.gdy[r];
+    if constexpr (FAST) {
+      if (ccol) {  // A^T dy on the column quads, as the dual norms above
+        const int     j = tid >> 2;
+        double        a = __builtin_fma(cv[1], R.gdy[cr[1]], cv[0] * R.gdy[cr[0]]);
+        const double *fv = R.sval + fj_sv, *fy = R.sdy + fj_sw;
+        for (int i = 0; i < fj_n; ++i) a = __builtin_fma(fv[60 * i], fy[20 * i], a);
+        a += dpp_quad(a, 0xB1);
+        a += dpp_quad(a, 0x4E);
+        na = dabs(a / s_D[j]);
       }
-      COL_DECODE(j)
-      for (int f = 0; f < nface; ++f) {
-        const int sr = sbase + 5 * f;
-        a += R.sval[(size_t)sr * 3 + pd] * R.sdy[sr];
+    } else {
+      for (int j = tid; j < n; j += QP_NT) {
+        double a = 0;
+        for (int q = s_cptr[j]; q < s_cptr[j + 1]; ++q) {
+          const int en = R.cidx[q], r = en >> 3;
+          a += R.gval[(size_t)r * QP_ELL + (en & 7)] * R.gdy[r];
+        }
+        COL_DECODE(j)
+        for (int f = 0; f < nface; ++f) {
+          const int sr = sbase + 5 * f;
+          a += R.sval[(size_t)sr * 3 + pd] * R.sdy[sr];
+        }
+        na = dmax(na, dabs(a / s_D[j]));
       }
-      na = dmax(na, dabs(a / s_D[j]));
     }
     na = block_max(na, s_red);
     __syncthreads();
@@ -1230,26 +1242,41 @@ __device__ __forceinline__ void qp_solve_agent(const SogmPlannerParams &pp, cons
         }
       }
     }
-    if (t < n) {
-      const int     j  = t;
+    if (ccol) {
+      // dual norms on the column quads of the iteration (lane q of column j holds every fourth entry of the column —
+      // its general-row entries in cv / cr, its faces behind fj_sv / fj_sw — and every fourth term of row j of P): one
+      // batch of loads, two DPP exchanges, instead of one lane walking the column (the oracle's row order is not
+      // kept: the sums differ from its dense ones in the last bits, the norms are compared with 1e-3 tolerances)
+      const int     j = t >> 2, q = t & 3, b0 = (j / 15) * 15;
       const double *Pb = s_P + (j / 15) * 225 + (j % 15) * 15;
-      const int     b0 = (j / 15) * 15;
-      double        pk[15], xk[15];
+      double        pk[4], xk[4], yg[2];
 #pragma unroll
-      for (int k = 0; k < 15; ++k) {
-        pk[k] = Pb[k];
-        xk[k] = s_x[b0 + k];
+      for (int u = 0; u < 4; ++u) {
+        const int k = q + 4 * u, kk = k < 15 ? k : 0;
+        pk[u]       = Pb[kk];
+        xk[u]       = s_x[b0 + kk];
       }
-      double s_ = 0;
 #pragma unroll
-      for (int k = 0; k < 15; ++k) s_ += pk[k] * xk[k];
-      const double a_ = col_sum_y(j);
-      const double dj = s_D[j];
-      const double r_ = dabs(s_ + a_), n_ = dmax(dabs(s_), dabs(a_));
-      v[4] = f32 ? (double)((float)r_ / (float)dj) : r_ / dj;
-      v[5] = f32 ? (double)((float)n_ / (float)dj) : n_ / dj;
-      v[6] = r_;
-      v[7] = n_;
+      for (int e = 0; e < 2; ++e) yg[e] = R.gy[cr[e]];
+      double        s_ = 0.0, a_ = 0.0;
+      const double *fv = R.sval + fj_sv, *fy = R.sy + fj_sw;
+      for (int i = 0; i < fj_n; ++i) a_ = __builtin_fma(fv[60 * i], fy[20 * i], a_);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) s_ = __builtin_fma(q + 4 * u < 15 ? pk[u] : 0.0, xk[u], s_);
+#pragma unroll
+      for (int e = 0; e < 2; ++e) a_ = __builtin_fma(cv[e], yg[e], a_);
+      s_ += dpp_quad(s_, 0xB1);
+      a_ += dpp_quad(a_, 0xB1);
+      s_ += dpp_quad(s_, 0x4E);
+      a_ += dpp_quad(a_, 0x4E);
+      if (q == 0) {
+        const double dj = s_D[j];
+        const double r_ = dabs(s_ + a_), n_ = dmax(dabs(s_), dabs(a_));
+        v[4] = f32 ? (double)((float)r_ / (float)dj) : r_ / dj;
+        v[5] = f32 ? (double)((float)n_ / (float)dj) : n_ / dj;
+        v[6] = r_;
+        v[7] = n_;
+      }
     }
     if (f32) {  // the nine maxima as fp32 values (rounded up to the next float: a maximum must not shrink)
 #pragma unroll
@@ -1490,7 +1517,10 @@ __device__ __forceinline__ void qp_solve_agent(const SogmPlannerParams &pp, cons
       ++dbg_ncheck;
       if constexpr (FAST) {
         fast_spill();
+        const long long dbg_c1 = wall_clock64();
+        dbg_k1 += dbg_c1 - dbg_c0;
         fast_residuals();
+        dbg_k2 += wall_clock64() - dbg_c1;
       } else {
         residuals();
       }
@@ -1573,7 +1603,9 @@ __device__ __forceinline__ void qp_solve_agent(const SogmPlannerParams &pp, cons
       o[8]  = dbg_f1;  // factor(): block assembly | forward sweep | backward rows + K^-1 registers (all factorisations)
       o[9]  = dbg_f2;
       o[10] = dbg_f3;
-      o[11] = clock64() - dbg_clk0;  // shader clocks of the whole solve (o[0]: the same span in 10 ns ticks)
+      o[11] = clock64() - dbg_clk0;
+      o[12] = dbg_k1;  // checks: the spill of the row state | the residual pass (the rest of o[4]: tests, certificate)
+      o[13] = dbg_k2;  // shader clocks of the whole solve (o[0]: the same span in 10 ns ticks)
       o[0] = wall_clock64() - dbg_t0;
       o[1] = dbg_setup;
       o[2] = dbg_refac;

@@ -183,12 +183,13 @@ class RiskHybridAstar {
   template <class V3>
   ASTAR_RET search(V3 start_pt, V3 start_vel, V3 start_acc, V3 end_pt, V3 end_vel, bool init, bool dynamic = false,
                    double time_start = -1.0) {
-    // dynamic = false is not a function of its arguments in the reference: the branch never writes PathNode::time /
-    // time_idx / time_origin_ (risk_hybrid_a_star.cpp:153-162; path_node.h:44-45 leaves them uninitialised, reset()
-    // :84-101 does not touch them) yet reads them for the horizon test (:177), the collision time (:300) and the
-    // hash key (:264-265) — it sees whatever an earlier search left in the pool.  No call site passes false
-    // (baseline.cpp:268-283, baseline_fake.cpp:279-291).  Refused rather than given an invented meaning.
-    if (!dynamic) throw std::invalid_argument("RiskHybridAstar::search: dynamic = false reads uninitialised node times in the reference; only the space-time search is defined");
+    // dynamic = false: the reference's branch never writes PathNode::time / time_idx / time_origin_
+    // (risk_hybrid_a_star.cpp:153-162; path_node.h:44-45 leaves them uninitialised, reset() :84-101 does not touch
+    // them) yet reads them for the horizon test (:177), the collision time (:300) and the hash key (:264-265) — it sees
+    // whatever an earlier search left in the pool; no call site passes false (baseline.cpp:268-283,
+    // baseline_fake.cpp:279-291).  DEFINED here as the oracle defines it (oracle/astar_oracle.cpp, Search::dynamic):
+    // every node's time and time index are zero — the spatial search over the SOGM's first tau seconds that a freshly
+    // allocated pool gives the reference; time_start is ignored, as the branch ignores it.
     for (int d = 0; d < 3; ++d)
       if (end_vel(d) != 0.0) throw std::invalid_argument("RiskHybridAstar::search: end_vel must be zero");
     const int a = b_.agent;
@@ -203,7 +204,8 @@ class RiskHybridAstar {
     (void)hipMemcpy(d_goal_.data() + a * 3, goal, sizeof(goal), hipMemcpyHostToDevice);
     (void)hipMemcpy(d_t_.data() + a, &time_start, sizeof(double), hipMemcpyHostToDevice);
     SelectAgent sel(b_);
-    check(sogm_planner_set_search_mode(b_.planner->handle(), 4 | (init ? 1 : 2)), "sogm_planner_set_search_mode");
+    check(sogm_planner_set_search_mode(b_.planner->handle(), 4 | (init ? 1 : 2) | (dynamic ? 0 : 16)),
+          "sogm_planner_set_search_mode");
     const int rc = sogm_astar_search(b_.planner->handle(), d_pva_.data(), d_goal_.data(), d_t_.data(), d_ret_.data(),
                                      d_route_.data(), d_len_.data(), cap_, d_stats_.data(), nullptr, 0, nullptr);
     (void)sogm_planner_set_search_mode(b_.planner->handle(), 0);

@@ -140,6 +140,14 @@ class SogmMap:
                 "total_entries": out[4], "resets": out[5], "entries_per_reset": out[6],
                 "zeroed_bytes_per_reset": int(out[7]) * 1024}
 
+    def set_resample(self, replan_risk_rate, num_resample, normal_table):
+        """ParticleATC's resample branch (sogm_set_resample): `normal_table` = device float32 tensor of standard
+        normals, >= 3 * body particles * num_resample entries, kept alive here."""
+        self._resample_table = normal_table
+        check(lib().sogm_set_resample(self._ctx, float(replan_risk_rate), int(num_resample),
+                                      normal_table.data_ptr() if normal_table is not None else None,
+                                      int(normal_table.numel()) if normal_table is not None else 0), "sogm_set_resample")
+
     def map_traffic(self, reset=False):
         """Device-side counts of what the resets and stamps moved since the counters' last reset (sogm_map_traffic)."""
         out = (C.c_int64 * 6)()

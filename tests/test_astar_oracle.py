@@ -70,3 +70,21 @@ def test_shot_check_variants_differ(pop, orc):
         n_diff += int(w[0]["ret"] != w[1]["ret"])
         assert (w[0]["ret"], w[1]["ret"]) in ((5, 4), (4, 4), (5, 5))  # NEAR_END vs REACH_END
     assert n_diff >= 2
+
+
+def test_dynamic_false_is_the_spatial_search_with_zero_node_times(orc):
+    """oracle: search(dynamic = false) as defined in astar_oracle.cpp (node times zero): it ignores time_start and still
+    finds a route through a static scene."""
+    import importlib
+    pop = importlib.import_module("pred-occ-planner_amd")
+    spec = pop.config.make_spec("parity")
+    sc = pop.scene.make_scene(2, 4.95, seed=0x5067, moving=False)
+    cyl = pop.scene.cylinders_to_struct(sc["cylinders"])
+    ap = pop.config.make_astar_params()
+    g = orc.update_gt(spec, sc["cloud"], cyl, len(sc["cylinders"]), sc["poses"][0])
+    pva = np.concatenate([sc["starts"][0], np.zeros(6)])
+    a = orc.astar_search(spec, ap, g, sc["poses"][0], pva, sc["goals"][0], 0.05, 0.3, mode=16 | 2)
+    b = orc.astar_search(spec, ap, g, sc["poses"][0], pva, sc["goals"][0], 0.85, 0.3, mode=16 | 2)
+    orc.astar_search(spec, ap, g, sc["poses"][0], pva, sc["goals"][0], 0.05, 0.3, mode=0)  # restore the default mode
+    assert a["ret"] != 0 and a["stats"] == b["stats"] and np.array_equal(a["trace"], b["trace"])
+    assert np.array_equal(a["route"], b["route"]) and len(a["route"]) >= 2

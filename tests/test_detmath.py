@@ -1,4 +1,4 @@
-"""CPU: include/sogm_detmath.h (deterministic cbrt/cos/acos/log shared by oracle and HIP path)
+"""CPU: include/sogm_detmath.h (deterministic cbrt/cos/acos/log/expf shared by oracle and HIP path)
 stays within a few ulp of libm."""
 import os
 import subprocess
@@ -20,7 +20,14 @@ int main() {
     double a = U(g); ma = std::max(ma, ulp(sogm_det::acos(a), std::acos(a)));
     double p = std::pow(10.0, U(g) * 20); ml = std::max(ml, ulp(sogm_det::log(p), std::log(p)));
   }
-  std::printf("%%.3f %%.3f %%.3f %%.3f\n", mc, mo, ma, ml);
+  double me = 0;  // expf_neg against libm's expf, in float ulps
+  for (int i = 0; i < 400000; i++) {
+    float x = -(float)(std::fabs(U(g)) * std::pow(10.0, U(g) * 2.0));
+    float a = sogm_det::expf_neg(x), b = std::exp(x);
+    if (a != b) { float u = std::nextafterf(std::fabs(b), INFINITY) - std::fabs(b); me = std::max(me, (double)(std::fabs(a - b) / u)); }
+  }
+  if (sogm_det::expf_neg(0.0f) != 1.0f || sogm_det::expf_neg(-200.0f) != 0.0f) return 3;
+  std::printf("%%.3f %%.3f %%.3f %%.3f %%.3f\n", mc, mo, ma, ml, me);
   for (int k = -300; k <= 300; ++k) if (sogm_det::cbrt((double)k * k * k) != (double)k) return 2;  // perfect cubes
   return (sogm_det::cbrt(27.0) == 3.0 && sogm_det::cbrt(-8.0) == -2.0 && sogm_det::acos(1.0) == 0.0 && sogm_det::log(1.0) == 0.0) ? 0 : 1;
 }
@@ -33,5 +40,5 @@ def test_detmath_accuracy(tmp_path):
     exe = tmp_path / "t"
     subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-o", str(exe), str(src)])
     out = subprocess.check_output([str(exe)]).decode().split()
-    cbrt_ulp, cos_eps, acos_ulp, log_ulp = map(float, out)
-    assert cbrt_ulp <= 1 and cos_eps <= 2 and acos_ulp <= 4 and log_ulp <= 4
+    cbrt_ulp, cos_eps, acos_ulp, log_ulp, expf_ulp = map(float, out)
+    assert cbrt_ulp <= 1 and cos_eps <= 2 and acos_ulp <= 4 and log_ulp <= 4 and expf_ulp <= 1

@@ -1,0 +1,90 @@
+"""ParticleATC::getParticlesWithRisk's resample branch (traj_coordinator/src/particles.cpp:365-409): with
+swarm/replan_risk_rate > 0 a neighbour's body particles are replaced by num_resample Gaussian samples with normalised
+weights once rate * (t - time_start) >= 1e-3.  The reference's noise comes from std::default_random_engine(time(NULL));
+the build injects the sequence as a table of standard normals (include/sogm_abi.h: sogm_set_resample).  The oracle
+restates the branch; the HIP overlay must reproduce it (fractional fp32 additions: 1e-4, the north_star's tolerance for
+occupancy values — the order of atomic additions moves the last bits)."""
+import importlib
+
+import numpy as np
+import pytest
+
+
+def _scene(pop, A=6):
+    from helpers import hard_cases
+    spec = pop.config.make_spec("parity")
+    sc, _ = hard_cases(pop, A, 17, field=3.0)  # agents inside each other's windows
+    recs = pop.scene.straight_records(sc, speed=1.0)
+    for r in recs:  # started 0.4 s before the map stamp: sigma = rate * (t - time_start) grows from 0.2 m
+        r.time_start -= 0.4
+    return spec, sc, recs
+
+
+def _table(n_body, n, seed=7):
+    return np.random.default_rng(seed).standard_normal(3 * n_body * n).astype(np.float32)
+
+
+def test_oracle_resample_conserves_the_weight_per_particle(pop, orc):
+    spec, sc, recs = _scene(pop)
+    body = pop.scene.body_particles()
+    z = _table(len(body), 10)
+    cyl = pop.scene.cylinders_to_struct(sc["cylinders"])
+    plain = orc.update_gt(spec, sc["cloud"], cyl, len(sc["cylinders"]), sc["poses"][0])
+    base = plain.copy()
+    orc.project_neighbours(spec, plain, recs, len(recs), 0, body, sc["poses"][0], sc["stamps"][0])
+    res = base.copy()
+    orc.set_resample(0.5, 10, z)
+    try:
+        orc.project_neighbours(spec, res, recs, len(recs), 0, body, sc["poses"][0], sc["stamps"][0])
+    finally:
+        orc.set_resample(0.0, 0, None)
+    added_plain, added_res = float((plain - base).sum()), float((res - base).sum())
+    assert added_plain > 100 and not np.array_equal(plain, res)
+    # weights are normalised to num_resample per particle: the total added stays n x the particle count as long as
+    # the samples stay inside the grid (a few fall outside: slightly less)
+    assert 0.9 * 10 * added_plain <= added_res <= 10 * added_plain * (1 + 1e-5)
+    # below the threshold (rate * dt < 1e-3) the branch is the plain one, bit for bit
+    tiny = base.copy()
+    orc.set_resample(1e-5, 10, z)
+    try:
+        orc.project_neighbours(spec, tiny, recs, len(recs), 0, body, sc["poses"][0], sc["stamps"][0])
+    finally:
+        orc.set_resample(0.0, 0, None)
+    assert np.array_equal(tiny, plain)
+
+
+@pytest.mark.gpu
+def test_hip_overlay_with_resampling_matches_the_oracle(pop, orc):
+    import torch
+    sogm = importlib.import_module("pred-occ-planner_amd.sogm")
+    spec, sc, recs = _scene(pop)
+    A = len(recs)
+    dev = sogm.upload_scene(sc)
+    m = sogm.SogmMap(spec, A)
+    z = _table(len(m.body), 10)
+    with pytest.raises(pop._abi.SogmError):
+        m.set_resample(0.5, 10, torch.from_numpy(z[:100]).cuda())  # table too short
+    m.set_resample(0.5, 10, torch.from_numpy(z).cuda())
+    cyl = pop.scene.cylinders_to_struct(sc["cylinders"])
+    orc.set_resample(0.5, 10, z)
+    try:
+        for k in range(3):  # update after update: the resampled cells are in the mark log and reset like the others
+            m.updateMapSwarm(dev["cloud"], dev["cloud_range"], dev["cylinders"], dev["n_cyl"], dev["poses"], dev["stamps"],
+                             sogm._dev(recs), A, dev["ego_ids"])
+            for a in range(A):
+                want = orc.update_gt(spec, sc["cloud"], cyl, len(sc["cylinders"]), sc["poses"][a])
+                stamped = want.copy()
+                orc.project_neighbours(spec, want, recs, A, a, m.body, sc["poses"][a], sc["stamps"][a])
+                got = m.download(a)
+                assert (want != stamped).sum() > 500  # the resampled overlay is there
+                assert np.array_equal(got != 0, want != 0), (k, a)
+                np.testing.assert_allclose(got, want, rtol=0, atol=1e-4)
+    finally:
+        orc.set_resample(0.0, 0, None)
+    m.set_resample(0.0, 0, None)  # off again: the plain overlay, bit for bit
+    m.updateMapSwarm(dev["cloud"], dev["cloud_range"], dev["cylinders"], dev["n_cyl"], dev["poses"], dev["stamps"],
+                     sogm._dev(recs), A, dev["ego_ids"])
+    want = orc.update_gt(spec, sc["cloud"], cyl, len(sc["cylinders"]), sc["poses"][1])
+    orc.project_neighbours(spec, want, recs, A, 1, m.body, sc["poses"][1], sc["stamps"][1])
+    assert np.array_equal(m.download(1), want)
+    m.close()

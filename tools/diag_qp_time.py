@@ -16,6 +16,7 @@ lib = pop.lib()
 lib.sogm_debug_qp_stats.argtypes = [C.c_void_p, C.c_void_p]
 tot = np.zeros(8)
 fac = np.zeros(4)
+chk = np.zeros(3)
 for k in range(ticks):
     sw.step()
     torch.cuda.synchronize()
@@ -27,6 +28,7 @@ for k in range(ticks):
     ok = it > 0
     tot[:4] += us[ok].sum(0); tot[4] += plain[ok].sum(); tot[5] += it[ok].sum(); tot[6] += st[ok, 3].sum(); tot[7] += st[ok, 5].sum()
     fac[:3] += st[ok, 8:11].sum(0) / 100.0; fac[3] += (st[ok, 3] + 1).sum()
+    chk[:2] += st[ok, 12:14].sum(0) / 100.0; chk[2] += st[ok, 5].sum()
     if k % every:
         continue
     order = np.argsort(-us[:, 0])[:8]
@@ -38,3 +40,4 @@ print(f"all solves of {ticks} ticks: set-up {tot[1]/tot[0]:.1%}, refactorisation
       f"checks {tot[3]/tot[0]:.1%} ({tot[3]/max(tot[7],1):.2f} us each), iterations {tot[4]/tot[0]:.1%} ({tot[4]/max(tot[5],1):.3f} us each)")
 print(f"shader clock during the solves of the last tick: {np.median(st[ok, 11] / (st[ok, 0] * 10.0)):.2f} GHz (median over agents)")
 print(f"factor() phases, us per factorisation: block assembly {fac[0]/fac[3]:.1f}, forward sweeps {fac[1]/fac[3]:.1f}, backward rows + registers {fac[2]/fac[3]:.1f}")
+print(f"checks, us each: spill of the row state {chk[0]/chk[2]:.2f}, residual pass {chk[1]/chk[2]:.2f}, tests / certificate {tot[3]/tot[7] - (chk[0]+chk[1])/chk[2]:.2f}")

@@ -11,7 +11,8 @@ import torch
 driver = importlib.import_module("pred-occ-planner_amd.driver")
 sw = driver.SwarmTick("cfg2", 128, overlap_clear=False)
 sw.map.set_profiling(True)
-entries = []
+entries, moved = [], []
+sw.map.map_traffic(reset=True)
 for k in range(6):  # update 0 clears densely (the grid is untracked), updates 1.. reset the logged sectors
     sw.compute.tick_inputs(sw.own, sw.t0, sw.hover, sw.now, sw.t_start, sw.pva, sw.poses)
     sw.map.updateMapSwarm(sw.dev["cloud"], sw.dev["cloud_range"], sw.dev["cylinders"], sw.dev["n_cyl"], sw.poses, sw.now,
@@ -19,7 +20,9 @@ for k in range(6):  # update 0 clears densely (the grid is untracked), updates 1
     torch.cuda.synchronize()
     st = sw.map.sparse_reset_state()
     entries.append(st["total_entries"])
+    moved.append(sw.map.map_traffic(reset=True))
 ms = sw.map.profile_read_all(0)
 print("reset launches (first = dense clear) ms:", [round(x, 3) for x in ms])
 print("log entries after each update:", entries, "max per agent", st["max_entries"], "capacity", st["log_capacity"])
+print("device-side counts per update (sogm_map_traffic):", moved)
 sw.close()
