@@ -481,7 +481,7 @@ def main():
             torch.cuda.synchronize()
             tick_ms.append((time.perf_counter() - t1) * 1e3)
             if slowest is None or tick_ms[-1] > slowest["tick_ms"]:  # (between two timed ticks: not in either)
-                slowest = dict(flow_chain(pop, sw), tick=sw.tick - 1, tick_ms=tick_ms[-1])
+                slowest = dict(flow_chain(pop, sw) or {}, tick=sw.tick - 1, tick_ms=tick_ms[-1])
         tm = np.array(tick_ms)
         n_ok2 = int(torch.stack(oks2).sum().item())
         out["sustained"] = {"ticks": args.sustained, "flight_seconds": args.sustained * driver.TICK_PERIOD,

@@ -343,6 +343,8 @@ __device__ inline void bezier_pos(const SogmTrajRecord &r, double t, double out[
   X(PRESTAMP_BITS, "prestamp_bits", 32)    /* pre-stamp: one-wave tickets per agent, occupancy bits pass            */  \
   X(PRESTAMP_MARKS, "prestamp_marks", 64)  /* pre-stamp: one-wave tickets per agent, marks pass                     */  \
   X(PRESTAMP_WGS, "prestamp_wgs", 0)       /* pre-stamp: one-wave workgroups; 0 = 8 per CU                          */  \
+  X(PRESTAMP_GATE_FRAC, "prestamp_gate_frac", 1) /* pre-stamp: fraction of the agents whose corridors must be final before it starts */ \
+  X(PRESTAMP_STREAM, "prestamp_stream", 1) /* pre-stamp on a stream of its own behind its target grid's reset EVENT; 0 = on the resets' stream */ \
   X(PRESTAMP_LATE_AGENTS, "prestamp_late_agents", 8)  /* the last agents to be published get finer tickets ...     */  \
   X(PRESTAMP_LATE_BITS, "prestamp_late_bits", 128)    /* ... this many for the bits pass                           */  \
   X(PRESTAMP_LATE_MARKS, "prestamp_late_marks", 256)  /* ... and for the marks pass                                */
@@ -378,6 +380,9 @@ struct sogm_ctx {
   int            dirty[2], n_dirty;
   int            precleared;  // the next update finds a (being-)cleared grid: mode 1 in place, modes 2 / 3 n_ready > 0
   hipStream_t    side;
+  hipStream_t    pstream;     // the pre-stamp's stream (tuning key prestamp_stream; the resets stay on `side`)
+  hipEvent_t     ev_gate_open;  // recorded on `side` behind the reset's gate kernel of the replan being queued ("every
+  int            gate_open_valid;  // agent's corridors are final"): the pre-stamp's stream waits for it instead of spinning
   hipEvent_t     ev_grid_free, ev_cleared;
   // width-adaptive clear (dataflow replan, modes 2 / 3): the side-stream clear starts narrow; a second, wide launch
   // on side2 joins it once the word *clear_gate reaches clear_gate_target (the planner's "corridors final" counter:

@@ -1726,6 +1726,7 @@ int sogm_dsp_create(sogm_ctx *map, const SogmDspParams *P, const float *p_gauss,
   if (e == hipSuccess) e = hipMemset(d.pc, 0, A * NP * d.OM * 5 * sizeof(float));
   if (e == hipSuccess) e = hipMemset(d.maxlen, 0xFF, A * NP * sizeof(int));
   for (int k = 0; k < 6 && e == hipSuccess; ++k) e = hipMemset(d.f[k], 0, A * VS * sizeof(float));
+  if (e == hipSuccess) e = hipStreamSynchronize(nullptr);  // null-stream memsets: complete before the first update on another stream
   if (e != hipSuccess) {
     set_error("sogm_dsp_create: init", e);
     sogm_dsp_destroy(h);

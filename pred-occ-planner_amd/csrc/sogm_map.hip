@@ -427,42 +427,55 @@ __device__ __forceinline__ void stamp_marks_trips(const GridGeom &g, void *__res
       float cx, cy, cz;
       g.corner_of(v, pose, cx, cy, cz);
       float vx = 0.f, vy = 0.f;
-      for (int c = 0; active && c < n_loop; ++c) {
-        int    type, orig = c;
-        float  ox, oy, wx, wy;
-        double wlim;
-        if (c < n_lds) {
-          const CylCand cc = cand[c];
-          type = cc.type;
-          orig = cc.orig;
-          ox   = cc.x;
-          oy   = cc.y;
-          wx   = cc.vx;
-          wy   = cc.vy;
-          wlim = cc.wlim;
-        } else {
-          type = cyl[c].type;
-          ox   = (float)cyl[c].x;
-          oy   = (float)cyl[c].y;
-          wx   = (float)cyl[c].vx;
-          wy   = (float)cyl[c].vy;
-          wlim = cyl[c].w + (double)g.clearance;
-        }
-        if (type == 2) {  // ring (:137-149)
-          if (ring_contains(cyl[orig], cx, cy, cz, g.res)) {
-            vx = wx;
-            vy = wy;
-            break;
+      // GT velocity of the FIRST record containing the voxel (:127-154).  The walk is wave-uniform — every lane visits
+      // the candidates in order until all lanes have their match — and takes the candidates four at a time: their loads
+      // do not depend on the tests, so four are in flight instead of one (the walk stopped at each lane's own match
+      // before: one dependent L1 round trip per candidate, ~30 us per chunk of 64 voxels with the bench scene's ~280
+      // candidates, which is what an agent's pre-stamp — and the tick's tail behind the last QP — waited for).
+      bool found = !active;
+      for (int c0 = 0; c0 < n_loop; c0 += 4) {  // uniform
+        if (__builtin_amdgcn_readfirstlane((int)(__ballot(!found) == 0ull))) break;
+        int    type[4], orig[4];
+        float  ox[4], oy[4], wx[4], wy[4];
+        double wlim[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int c = c0 + u < n_loop ? c0 + u : n_loop - 1;  // (clamped: the test below skips it)
+          if (c < n_lds) {
+            const CylCand cc = cand[c];
+            type[u] = cc.type;
+            orig[u] = cc.orig;
+            ox[u]   = cc.x;
+            oy[u]   = cc.y;
+            wx[u]   = cc.vx;
+            wy[u]   = cc.vy;
+            wlim[u] = cc.wlim;
+          } else {
+            type[u] = cyl[c].type;
+            orig[u] = c;
+            ox[u]   = (float)cyl[c].x;
+            oy[u]   = (float)cyl[c].y;
+            wx[u]   = (float)cyl[c].vx;
+            wy[u]   = (float)cyl[c].vy;
+            wlim[u] = cyl[c].w + (double)g.clearance;
           }
-          continue;
         }
-        if (type != 3) continue;  // unknown type: the reference prints a warning and goes on (:150-152)
-        const float dx = cx - ox, dy = cy - oy, dz = cz - cz;
-        const float dist = sqrtf(dx * dx + dy * dy + dz * dz);
-        if ((double)dist <= wlim) {
-          vx = wx;
-          vy = wy;
-          break;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (found || c0 + u >= n_loop) continue;
+          bool hit = false;
+          if (type[u] == 2) {  // ring (:137-149)
+            hit = ring_contains(cyl[orig[u]], cx, cy, cz, g.res);
+          } else if (type[u] == 3) {  // (unknown type: the reference prints a warning and goes on, :150-152)
+            const float dx = cx - ox[u], dy = cy - oy[u], dz = cz - cz;
+            const float dist = sqrtf(dx * dx + dy * dy + dz * dz);
+            hit = (double)dist <= wlim[u];
+          }
+          if (hit) {
+            vx    = wx[u];
+            vy    = wy[u];
+            found = true;
+          }
         }
       }
       // the cell of slice k this voxel marks (g.V: none — outside the grid, or the reference's out-of-bounds index)
@@ -1028,8 +1041,10 @@ __global__ __launch_bounds__(64) void k_prestamp_flow(GridGeom g, FlowCtl fc, Pr
     const int agent = flow_wait_slot(fc.p_ready + (late ? n_early : 0) + tl / per, &fc.hdr[FLOW_ERR]);
     if (agent < 0) break;
     __threadfence();  // the agent's own record was published before its slot
-    const int s = tl % per;
+    const int  s   = tl % per;
+    long long *pts = fc.ts + 8 * (size_t)ps.n_agents + 4 * (size_t)agent;  // diagnostics (sogm_debug_prestamp_times)
     if (s == 0) {
+      if (lane == 0) pts[0] = wall_clock64();
       // next tick's inputs of this agent (k_tick_inputs), then its candidate cylinders around the new centre
       constexpr int W   = (int)(sizeof(SogmTrajRecord) / 16);
       const uint4  *src = reinterpret_cast<const uint4 *>(ps.own + agent);
@@ -1048,7 +1063,10 @@ __global__ __launch_bounds__(64) void k_prestamp_flow(GridGeom g, FlowCtl fc, Pr
       cull_agent(g, ps.cyl, ps.n_cyl, ps.poses[agent * 3], ps.poses[agent * 3 + 1],
                  (CylCand *)ps.cand + (size_t)agent * SOGM_MAX_CYL_LDS, ps.n_cand + agent, lane);
       __threadfence();
-      if (lane == 0) atomicAdd(&fc.stage[agent], 1);
+      if (lane == 0) {
+        pts[1] = wall_clock64();
+        atomicAdd(&fc.stage[agent], 1);
+      }
     }
     if (s < n_bits) {
       if (flow_wait_count(&fc.stage[agent], 1, &fc.hdr[FLOW_ERR])) break;
@@ -1057,21 +1075,23 @@ __global__ __launch_bounds__(64) void k_prestamp_flow(GridGeom g, FlowCtl fc, Pr
       stamp_bits_range(g, ps.cloud, begin + s * 64 + lane, end, n_bits * 64, p0, p1, p2,
                        ps.bits + (size_t)agent * ps.words);
       __threadfence();
-      if (lane == 0) atomicAdd(&fc.stage[agent], 1);
+      if (lane == 0 && atomicAdd(&fc.stage[agent], 1) + 1 == 1 + n_bits) pts[2] = wall_clock64();
     } else {
       if (flow_wait_count(&fc.stage[agent], 1 + n_bits, &fc.hdr[FLOW_ERR])) break;
       stamp_marks_trips(g, ps.grid, ps.bits, ps.words, ps.cyl, ps.n_cyl, ps.poses, (const CylCand *)ps.cand, ps.n_cand, agent, ps.lg,
                         (s - n_bits) * 256, n_marks * 256);
       // the agent's last marks ticket to finish declares its grid complete (the next update's overlay waits for it)
       __threadfence();
-      if (lane == 0 && atomicAdd(&fc.stage[agent], 1) + 1 == 1 + n_bits + n_marks)
+      if (lane == 0 && atomicAdd(&fc.stage[agent], 1) + 1 == 1 + n_bits + n_marks) {
+        pts[3] = wall_clock64();
         __hip_atomic_store(&fc.stage[agent], FLOW_PS_DONE, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      }
     }
   }
 }
 int launch_prestamp_flow(const GridGeom &g, const FlowCtl &fc, const PrestampDev &ps, int n_workgroups, int n_qp,
                          int n_finish, hipStream_t st) {
-  hipLaunchKernelGGL(k_prestamp_gate, dim3(1), dim3(64), 0, st, fc.hdr, ps.n_agents, n_qp, n_finish);
+  hipLaunchKernelGGL(k_prestamp_gate, dim3(1), dim3(64), 0, st, fc.hdr, ps.gate_agents, n_qp, n_finish);
   hipLaunchKernelGGL(k_prestamp_flow, dim3(n_workgroups), dim3(64), 0, st, g, fc, ps);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
@@ -1144,9 +1164,15 @@ MarkLog mark_log(sogm_ctx *c, int slot) {
   if (!c->sparse || slot < 0 || slot > 2) return none;
   if (!c->d_log[slot]) {
     unsigned *e = nullptr, *n = nullptr;
+    // (The counters' first zeroing is COMPLETE when this returns: the memset is a null-stream operation, which the
+    //  library's non-blocking streams do not wait for — with a second context busy on the device it was seen to run
+    //  after the first stamp had appended its entries, i.e. it threw them away, and the slot's first reset through
+    //  its log left that stamp's marks in the grid.  Only the null stream is synchronised: persistent kernels of a
+    //  replan in flight on other streams are not waited for.)
     if (hipMalloc((void **)&e, sizeof(unsigned) * (size_t)c->log_cap * c->n_agents) != hipSuccess ||
         hipMalloc((void **)&n, sizeof(unsigned) * (size_t)c->n_agents) != hipSuccess ||
-        hipMemset(n, 0, sizeof(unsigned) * (size_t)c->n_agents) != hipSuccess) {
+        hipMemset(n, 0, sizeof(unsigned) * (size_t)c->n_agents) != hipSuccess ||
+        hipStreamSynchronize(nullptr) != hipSuccess) {
       (void)hipGetLastError();
       if (e) (void)hipFree(e);
       if (n) (void)hipFree(n);
@@ -1156,7 +1182,8 @@ MarkLog mark_log(sogm_ctx *c, int slot) {
     }
     if (!c->d_reset_stat &&
         (hipMalloc((void **)&c->d_reset_stat, 8 * sizeof(unsigned long long)) != hipSuccess ||
-         hipMemset(c->d_reset_stat, 0, 8 * sizeof(unsigned long long)) != hipSuccess)) {
+         hipMemset(c->d_reset_stat, 0, 8 * sizeof(unsigned long long)) != hipSuccess ||
+         hipStreamSynchronize(nullptr) != hipSuccess)) {
       (void)hipGetLastError();
       (void)hipFree(e);
       (void)hipFree(n);
@@ -1303,6 +1330,10 @@ int queue_spare_clears(sogm_ctx *c, hipEvent_t after) {
         hipLaunchKernelGGL(k_clear_gate, dim3(1), dim3(64), 0, c->side, c->clear_cursor, ~(size_t)0, c->clear_gate,
                            c->clear_gate_err, c->clear_gate_target, c->clear_epoch_word, c->clear_epoch);
         SOGM_HIP_CHECK(hipGetLastError());
+        // "every agent's corridors are final" as an EVENT for the pre-stamp's stream (sogm_replan): no second gate kernel
+        // spinning at the head of a stream (with shared or oversubscribed hardware queues every spinner is a hazard)
+        SOGM_HIP_CHECK(hipEventRecord(c->ev_gate_open, c->side));
+        c->gate_open_valid = 1;
       }
       rc = reset_slot(c, c->side, g, c->pool[g], true);  // the logged sectors only: a fraction of a millisecond
     } else if (head == 0) {
@@ -1477,10 +1508,14 @@ int sogm_create(const SogmSpec *spec, int n_agents, int device, sogm_ctx **out) 
   if (e == hipSuccess) e = hipMemset(c->clear_cursor, 0, 2 * sizeof(unsigned long long));
   if (e == hipSuccess) e = sogm::create_stream_partitioned(&c->side, 0);
   if (e == hipSuccess) e = sogm::create_stream_partitioned(&c->side2, 0);
+  if (e == hipSuccess) e = sogm::create_stream_partitioned(&c->pstream, 0);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_side2_go, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_side2_done, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_grid_free, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_cleared, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_gate_open, hipEventDisableTiming);
+  // the memsets above are null-stream operations, which the non-blocking streams every later call uses do not wait for
+  if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
   if (e != hipSuccess) {
     sogm::set_error("sogm_create", e);
     sogm_destroy(c);
@@ -1523,10 +1558,15 @@ void sogm_destroy(sogm_ctx *c) {
     (void)hipStreamSynchronize(c->side2);
     (void)hipStreamDestroy(c->side2);
   }
+  if (c->pstream) {
+    (void)hipStreamSynchronize(c->pstream);
+    (void)hipStreamDestroy(c->pstream);
+  }
   if (c->ev_side2_go) (void)hipEventDestroy(c->ev_side2_go);
   if (c->ev_side2_done) (void)hipEventDestroy(c->ev_side2_done);
   if (c->ev_grid_free) (void)hipEventDestroy(c->ev_grid_free);
   if (c->ev_cleared) (void)hipEventDestroy(c->ev_cleared);
+  if (c->ev_gate_open) (void)hipEventDestroy(c->ev_gate_open);
   if (c->xstream) {
     (void)hipStreamSynchronize(c->xstream);
     (void)hipStreamDestroy(c->xstream);
@@ -1673,6 +1713,16 @@ int sogm_map_traffic(sogm_ctx *c, int64_t *out, int reset) {
     if (c->d_reset_stat) SOGM_HIP_CHECK(hipMemset(c->d_reset_stat, 0, sizeof(st)));
     c->n_stamps = 0;
   }
+  return SOGM_OK;
+}
+
+// diagnostics (tools/ only): one agent's CURRENT grid ([T][V] cells, device layout) copied to a device buffer in stream
+// order — no device synchronisation, no effect on the mark logs (unlike sogm_grid_ptr)
+int sogm_debug_copy_grid(sogm_ctx *c, int agent, void *dst_dev, void *stream) {
+  if (!c || !dst_dev || agent < 0 || agent >= c->n_agents) return SOGM_ERR_INVALID_ARG;
+  const size_t bytes = (size_t)c->spec.T * (size_t)c->geom.V * c->cell_bytes();
+  SOGM_HIP_CHECK(hipMemcpyAsync(dst_dev, (const char *)c->d_grid + (size_t)agent * bytes, bytes, hipMemcpyDeviceToDevice,
+                                (hipStream_t)stream));
   return SOGM_OK;
 }
 

@@ -191,9 +191,10 @@ int sogm_planner_create(sogm_ctx *map, const SogmAstarParams *astar, const SogmP
     // the second attempts wait on the first ones: only when every workgroup of both is resident at once
     if (p->spec_astar && 2 * A > sogm::astar_resident_workgroups(map->device)) p->spec_astar = 0;
   }
+  // (the group streams themselves are created by the grouped path's first replan: the dataflow path never uses them,
+  // and every stream is a hardware queue the process holds — INTEGRATION.md section 2 on sharing a GPU)
   for (int g = 0; g < p->n_groups && e == hipSuccess; ++g) {
-    e = sogm::create_stream_partitioned(&p->gstream[g], 1);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_corr[g], hipEventDisableTiming);
+    e = hipEventCreateWithFlags(&p->ev_corr[g], hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_pts[g], hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_done[g], hipEventDisableTiming);
   }
@@ -212,8 +213,9 @@ int sogm_planner_create(sogm_ctx *map, const SogmAstarParams *astar, const SogmP
     p->fc.f_ready  = p->fc.q_ready + A;
     p->fc.p_ready  = p->fc.f_ready + A;
     if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_pdone, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipMalloc((void **)&p->d_flow_ts, sizeof(long long) * 8 * (size_t)A);
-    if (e == hipSuccess) e = hipMemset(p->d_flow_ts, 0, sizeof(long long) * 8 * (size_t)A);
+    // [A][8] chain stamps, then [A][4] pre-stamp stamps (record seen, cull done, bits done, marks done)
+    if (e == hipSuccess) e = hipMalloc((void **)&p->d_flow_ts, sizeof(long long) * 12 * (size_t)A);
+    if (e == hipSuccess) e = hipMemset(p->d_flow_ts, 0, sizeof(long long) * 12 * (size_t)A);
     p->fc.ts = p->d_flow_ts;
 
     for (int k = 0; k < 4 && e == hipSuccess; ++k) {
@@ -226,6 +228,8 @@ int sogm_planner_create(sogm_ctx *map, const SogmAstarParams *astar, const SogmP
     if (e == hipSuccess) e = hipHostMalloc((void **)&p->h_flow_fail, sizeof(int) * 2, hipHostMallocMapped);
     if (e == hipSuccess) p->h_flow_fail[0] = p->h_flow_fail[1] = 0;
   }
+  // (the memsets above are null-stream operations: complete before any kernel on the planner's non-blocking streams)
+  if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
   if (e != hipSuccess) {
     sogm::set_error("sogm_planner_create", e);
     sogm_planner_destroy(p);
@@ -470,6 +474,35 @@ int sogm_debug_flow_times(sogm_planner *p, long long *out_host) {
   return SOGM_OK;
 }
 
+// diagnostics (tools/ only): the internal stage outputs of the last sogm_replan, copied to the host.  which: 0 polytopes
+// [A][16][max_faces][4] f64, 1 faces per polytope [A][16] i32, 2 polytopes per agent [A] i32, 3 local goal [A][6] f64,
+// 4 route [A][route_cap][6] f64, 5 route length [A] i32, 6 control points [A][16 * 15] f64, 7 QP iterations [A] i32,
+// 8 QP status [A] i32, 9 search return codes [A] i32, 10 search stats [A][4] i32
+int sogm_debug_planner_buffer(sogm_planner *p, int which, void *out_host, size_t bytes) {
+  if (!p || !out_host) return SOGM_ERR_INVALID_ARG;
+  const size_t A = (size_t)p->map->n_agents, slots = A * SOGM_MAX_PIECES;
+  const void  *src[11] = {p->d_polys, p->d_nfaces, p->d_npoly, p->d_goal, p->d_route, p->d_route_len, p->d_cpts, p->d_iters,
+                          p->d_status, p->d_ret, p->d_stats};
+  const size_t len[11] = {sizeof(double) * slots * p->pp.max_faces * 4, sizeof(int32_t) * slots, sizeof(int32_t) * A,
+                          sizeof(double) * 6 * A, sizeof(double) * 6 * p->route_cap * A, sizeof(int32_t) * A,
+                          sizeof(double) * slots * 15, sizeof(int32_t) * A, sizeof(int32_t) * A, sizeof(int32_t) * A,
+                          sizeof(int32_t) * 4 * A};
+  if (which < 0 || which > 10 || bytes > len[which]) return SOGM_ERR_INVALID_ARG;
+  SOGM_HIP_CHECK(hipDeviceSynchronize());
+  SOGM_HIP_CHECK(hipMemcpy(out_host, src[which], bytes, hipMemcpyDeviceToHost));
+  return SOGM_OK;
+}
+
+// diagnostics (tools/ only): per-agent stamps of the last pre-stamp, [A][4] ticks of 10 ns: the agent's record seen by its
+// first ticket, cylinders culled, last bits ticket done, last marks ticket done
+int sogm_debug_prestamp_times(sogm_planner *p, long long *out_host) {
+  if (!p || !out_host) return SOGM_ERR_INVALID_ARG;
+  SOGM_HIP_CHECK(hipDeviceSynchronize());
+  SOGM_HIP_CHECK(hipMemcpy(out_host, p->d_flow_ts + 8 * (size_t)p->map->n_agents, sizeof(long long) * 4 * (size_t)p->map->n_agents,
+                           hipMemcpyDeviceToHost));
+  return SOGM_OK;
+}
+
 int sogm_planner_flow_error(sogm_planner *p) {
   if (!p) return SOGM_ERR_INVALID_ARG;
   int hdr[FLOW_HDR];
@@ -627,6 +660,7 @@ static int replan_flow(sogm_planner *p, const double *start_pva, const double *g
   prof_end(c, SOGM_PROF_QP, sQ);
   // (queued AFTER the searches / corridor / QP launches: its gate waits for the corridor stage, and when streams share a
   //  hardware queue a launch behind a waiting gate waits with it — a QP kernel started 5 ms late costs the tick 5 ms)
+  c->gate_open_valid = 0;
   if (c->overlap >= 2) {
     // the side-stream clear of the grid this tick's update swapped out: narrow, with a wide second launch that joins
     // once every agent's corridors are final (FLOW_Q_READY_N == A, registered as the gate at planner creation) —
@@ -661,6 +695,10 @@ static int replan_flow(sogm_planner *p, const double *start_pva, const double *g
     d.poses    = c->d_poses_next;
     d.stamps   = c->d_stamps_next;
     d.n_agents = A;
+    {
+      const double f = c->tune[SOGM_TUNE_PRESTAMP_GATE_FRAC];
+      d.gate_agents  = f >= 1.0 ? A : f <= 0.0 ? 0 : (int)(f * A + 0.5);
+    }
     // tickets per agent (tuning aids): too few and the last agents' stamps trail the replan, too many and the
     // hand-overs cost more than the work (bits + marks 16+16 / 32+64 / 64+64 / 128+256 tickets: 13.1 / 12.1 / 12.2 /
     // 14.1 ms per tick, 13.0 without the pre-stamp); finer tickets for the last agents to be published (none / 8 / 16
@@ -673,12 +711,25 @@ static int replan_flow(sogm_planner *p, const double *start_pva, const double *g
     d.n_bits_late  = c->tune_i(SOGM_TUNE_PRESTAMP_LATE_BITS) > 0 ? c->tune_i(SOGM_TUNE_PRESTAMP_LATE_BITS) : nb;
     d.n_marks_late = c->tune_i(SOGM_TUNE_PRESTAMP_LATE_MARKS) > 0 ? c->tune_i(SOGM_TUNE_PRESTAMP_LATE_MARKS) : nm;
     if (int rc = sogm::prestamp_buffers(c, &d)) return rc;
-    // On the map's side stream, i.e. in stream order behind every reset queued so far — the target grid's among them
-    // (this replan's, or an earlier one's).  (A stream of its own waiting for the grid's reset event was not enough:
-    // with four hardware queues and the first, dense clears of a flight, the pre-stamp was seen running beside the
-    // kernel that restarts the grid's log, which lost the entries of all but the last agent.)
-    hipStream_t pst = c->side;
+    // The pre-stamp's target grid was reset by an EARLIER replan when the pool holds three grids (the front of the ready
+    // queue), yet on the resets' stream the launch would also sit behind THIS replan's reset — which is held back until
+    // every agent's corridors are final and then takes a millisecond: traces showed the pre-stamp starting at 5.6 ms
+    // of the tick, working off a backlog of ~100 published agents on the CUs the QP workgroups leave free, and ending
+    // 1-2.5 ms after the last QP in half of the ticks — the tick's end.  It runs on a stream of its own, ordered
+    // behind its target's reset (and log restart) by that grid's event and behind "every agent's corridors are final"
+    // by the event recorded after the reset's gate kernel: reset and pre-stamp then run side by side.  No second
+    // spinning gate: with prestamp_gate_frac < 1 (the pre-stamp starts when that fraction of the corridors is final,
+    // ~4 % faster) k_prestamp_gate spins at the head of this stream for milliseconds, which stalled ticks for the 3 s
+    // of the wait limit when hardware queues were shared (two ranks in one process, four queues) or oversubscribed
+    // (a second process holding a context) — measured, hence not the default.  (prestamp_stream = 0: round 3's
+    // placement on the resets' stream.)
+    const bool  own_stream = c->tune_i(SOGM_TUNE_PRESTAMP_STREAM) != 0 && c->pstream != nullptr;
+    hipStream_t pst        = own_stream ? c->pstream : c->side;
     SOGM_HIP_CHECK(hipStreamWaitEvent(pst, p->ev_in, 0));
+    if (own_stream) {
+      SOGM_HIP_CHECK(hipStreamWaitEvent(pst, c->pool_ev[nxt], 0));
+      if (c->gate_open_valid && d.gate_agents >= A) SOGM_HIP_CHECK(hipStreamWaitEvent(pst, c->ev_gate_open, 0));
+    }
     int wg_p = 8 * n_cu;  // one-wave workgroups (512 / 1024 / 2048+: 14.0 / 12.3 / 12.1 ms per tick)
     if (c->tune_i(SOGM_TUNE_PRESTAMP_WGS) > 0) wg_p = c->tune_i(SOGM_TUNE_PRESTAMP_WGS);
     if (sogm::launch_prestamp_flow(c->geom, p->fc, d, wg_p, wg_q, wg_f < A ? wg_f : A, pst)) {
@@ -699,11 +750,12 @@ static int replan_flow(sogm_planner *p, const double *start_pva, const double *g
     // the tick's report behind the pre-stamp on ITS stream (the last kernel of the tick to end), so that the caller's
     // stream goes from the fan-in straight to the next tick's first kernel instead of through one more launch
     const int retire_p = c->tune_i(SOGM_TUNE_CLEAR_RETIRE_AT_END);
-    for (int k = 1; k < 4; ++k) SOGM_HIP_CHECK(hipStreamWaitEvent(c->side, p->ev_fdone[k], 0));
-    hipLaunchKernelGGL(k_flow_report, dim3(1), dim3(1), 0, c->side, (const int *)p->d_flow, p->h_flow_fail,
+    hipStream_t rst = c->tune_i(SOGM_TUNE_PRESTAMP_STREAM) != 0 && c->pstream ? c->pstream : c->side;  // = pst above
+    for (int k = 1; k < 4; ++k) SOGM_HIP_CHECK(hipStreamWaitEvent(rst, p->ev_fdone[k], 0));
+    hipLaunchKernelGGL(k_flow_report, dim3(1), dim3(1), 0, rst, (const int *)p->d_flow, p->h_flow_fail,
                        retire_p ? p->d_epoch : (int *)nullptr);
     SOGM_HIP_CHECK(hipGetLastError());
-    SOGM_HIP_CHECK(hipEventRecord(p->ev_pdone, c->side));
+    SOGM_HIP_CHECK(hipEventRecord(p->ev_pdone, rst));
     const int defer = c->tune_i(SOGM_TUNE_SPLAT_OVERLAP) != 0;  // 0: the caller's stream waits for the pre-stamp's end here
     if (defer) {
       // the caller's stream goes on behind the fan-in: the next update's overlay waits per agent (sogm_update_prestamped),
@@ -740,6 +792,8 @@ static int replan_impl(sogm_planner *p, const double *start_pva, const double *g
   hipStream_t main = (hipStream_t)stream;
   const int   A = c->n_agents, G = p->n_groups;
   const MapView mv = view_of(c);
+  for (int g = 0; g < G; ++g)
+    if (!p->gstream[g]) SOGM_HIP_CHECK(sogm::create_stream_partitioned(&p->gstream[g], 1));
   // the swarm's records (deconfliction) may come from an all-gather still in flight on the exchange stream
   if (p->swarm)
     if (int rc = sogm::join_exchange(c, main)) return rc;

@@ -116,6 +116,7 @@ struct PrestampDev {
   int                   n_agents;
   int                   n_bits, n_marks;  // one-wave tickets per agent for the two passes of the stamp
   int                   n_late, n_bits_late, n_marks_late;  // ... and for the last n_late agents to be published
+  int                   gate_agents;  // agents whose corridors must be final before the pre-stamp starts (tuning key prestamp_gate_frac)
 };
 // n_qp / n_finish: the QP workgroups and finishing waves of this replan — the pre-stamp's waves are not dispatched before
 // all of them are resident (they wait for what those produce, and a QP workgroup needs a whole CU)

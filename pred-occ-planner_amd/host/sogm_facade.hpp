@@ -142,6 +142,13 @@ class RiskMap {
   }
   // How updateMap's "fill the map with zeros" (fake_particle_risk_voxel.cpp:107-108) is carried out: by zeroing the
   // logged sectors of the previous build's marks (default) or by the dense clear; same cells either way
+  // swarm/replan_risk_rate, swarm/num_resample (particles.cpp:33-34) and the injected standard-normal table that
+  // stands in for getParticlesWithRisk's time(NULL)-seeded generator (sogm_set_resample); rate 0 = off (the default)
+  void setResample(float replan_risk_rate, int num_resample, const float *normal_table_dev, int n_table) {
+    check(sogm_set_resample(ctx_, replan_risk_rate, num_resample, normal_table_dev, n_table), "sogm_set_resample");
+  }
+  // a tuning knob of this context (sogm_abi.h "Tuning knobs")
+  void setTuning(const char *key, double value) { check(sogm_set_tuning(ctx_, key, value), "sogm_set_tuning"); }
   void setSparseReset(bool on, int log_capacity_per_agent = 0) {
     check(sogm_set_sparse_reset(ctx_, on ? 1 : 0, log_capacity_per_agent), "sogm_set_sparse_reset");
   }

@@ -13,6 +13,20 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "own_device: flies full-size ticks in child processes and is collected FIRST, before "
+                            "this process holds hardware queues of its own (INTEGRATION.md section 2: the queues of every "
+                            "process on the GPU share 32 hardware slots)")
+
+
+def pytest_collection_modifyitems(config, items):
+    """Tests marked own_device run before every other test: a pytest process that has run GPU tests keeps the hardware
+    queues of the streams it used (ROCm pools them), and a child process flying the persistent-kernel tick beside a
+    parent that already holds most of the device's 32 queue slots is time-sliced by the firmware — measured with
+    tools/soak_with_parent.py: parent 24 queues + child 8: clean, + child 16: ticks of seconds, flow code 2."""
+    first = [it for it in items if it.get_closest_marker("own_device")]
+    if first:
+        rest = [it for it in items if not it.get_closest_marker("own_device")]
+        items[:] = first + rest
 
 
 @pytest.fixture(scope="session")

@@ -25,3 +25,10 @@ for k in range(ticks):
     d = lambda a, b: us[:, b] - us[:, a]
     print(f"tick {k}: end {end.max()/1000:.2f} ms (agent {crit}); mean/max ms: A* {d(0,1).mean()/1000:.2f}/{d(0,1).max()/1000:.2f}  wait->corr {d(1,2).mean()/1000:.2f}/{d(1,2).max()/1000:.2f}  corr {d(2,3).mean()/1000:.2f}/{d(2,3).max()/1000:.2f}  wait->QP {d(3,4).mean()/1000:.2f}/{d(3,4).max()/1000:.2f}  QP {d(4,5).mean()/1000:.2f}/{d(4,5).max()/1000:.2f}  fin {d(5,6).mean()/1000:.2f}/{d(5,6).max()/1000:.2f}")
     print("   critical agent:", " | ".join(f"{n} {us[crit, i]/1000:.2f}" for i, n in enumerate(names)))
+    if hasattr(lib, "sogm_debug_prestamp_times"):
+        pt = np.zeros((A, 4), np.int64)
+        lib.sogm_debug_prestamp_times(sw.planner._p, pt.ctypes.data_as(C.c_void_p))
+        pu = (pt - t0) / 100.0
+        last = np.argsort(-pu[:, 3])[:4]  # the agents whose pre-stamp ended last
+        for a in last:
+            print(f"   pre-stamp of agent {a}: finished {us[a, 6]/1000:.2f} | record seen {pu[a, 0]/1000:.2f} | culled {pu[a, 1]/1000:.2f} | bits {pu[a, 2]/1000:.2f} | marks {pu[a, 3]/1000:.2f}")

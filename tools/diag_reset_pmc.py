@@ -18,11 +18,13 @@ for k in range(6):  # update 0 clears densely (the grid is untracked), updates 1
     sw.map.updateMapSwarm(sw.dev["cloud"], sw.dev["cloud_range"], sw.dev["cylinders"], sw.dev["n_cyl"], sw.poses, sw.now,
                           sw.all, sw.A_tot, sw.dev["ego_ids"])
     torch.cuda.synchronize()
+    moved.append(sw.map.map_traffic(reset=True))  # (before the state query: that one restarts the reset's counters)
     st = sw.map.sparse_reset_state()
     entries.append(st["total_entries"])
-    moved.append(sw.map.map_traffic(reset=True))
 ms = sw.map.profile_read_all(0)
 print("reset launches (first = dense clear) ms:", [round(x, 3) for x in ms])
 print("log entries after each update:", entries, "max per agent", st["max_entries"], "capacity", st["log_capacity"])
-print("device-side counts per update (sogm_map_traffic):", moved)
+import json
+print("device-side counts per update (sogm_map_traffic): " + json.dumps(moved))
+print("stamp (cull + bits + marks) launches ms:", [round(x, 3) for x in sw.map.profile_read_all(1)])
 sw.close()

@@ -1,140 +1,188 @@
-"""Assemble profiles/r03_end_rocprof.md, profiles/r03_perception_rocprof.md and profiles/r03_pmc_traffic.json from
-gpurun_out/profile/ (tools/make_profile.sh)."""
-import json, re
+"""Assemble profiles/r04_end_rocprof.md and the PMC figures bench.py cites (profiles/r04_pmc_reset.json,
+r04_pmc_stamp.json, r04_pmc_traffic.json) from gpurun_out/profile/ (tools/make_profile.sh core + rest)."""
+import json, os, re
 P = 'gpurun_out/profile/'
-last = lambda f: open(P + f).read().strip().splitlines()[-1]
-read = lambda f: open(P + f).read()
-summ, tl, flow = read('summary.md'), read('timeline.txt'), read('flow.txt')
-plain, trace, flow0, grids2, mode1, cfg4, dsp, gm, dense = (last(f) for f in (
-    'bench_plain.json', 'bench_trace.json', 'bench_flow0.json', 'bench_grids2.json', 'bench_mode1.json',
-    'bench_cfg4.json', 'bench_dsp.json', 'bench_gridmap.json', 'bench_dense.json'))
-d, f0, g2, m1, c4, dn = (json.loads(x) for x in (plain, flow0, grids2, mode1, cfg4, dense))
+R = 'r04'
 
 
-def pm(counter, kernel="k_clear_chunks<true>", last=False):
-    """(dispatches, mean KB) of a kernel's counter: from the first PMC pass that lists it, or the last one"""
+def read(f, default=""):
+    try:
+        return open(P + f).read()
+    except OSError:
+        return default
+
+
+def last_json(f):
+    for line in reversed(read(f).strip().splitlines()):
+        if line.startswith('{'):
+            return line, json.loads(line)
+    return "", None
+
+
+summ, tl, flow, qpt = read('summary.md'), read('timeline.txt'), read('flow.txt'), read('qp_time.txt')
+
+
+def pm(counter, kernel, last=False):
+    """(dispatches, mean KB of 1024 B) of a kernel's counter: from the first PMC pass that lists it, or the last one"""
     m = re.findall(r"%s \| %s \| (\d+) \| ([\d.]+) \|" % (re.escape(kernel), counter), summ)
+    if not m:
+        return 0, float('nan')
     m = m[-1] if last else m[0]
     return int(m[0]), float(m[1])
 
 
-# the in-tick clear = k_clear_chunks (narrow launch; under counter collection kernels are serialised and the narrow
-# launch clears the whole grid, tools/diag_clear_pmc.py); k_clear_slabs = the full-width launch of the stage pass
-nf, fk = pm('FETCH_SIZE')
-nw, wk = pm('WRITE_SIZE')
-_, fk_s = pm('FETCH_SIZE', 'k_clear_slabs<true>')
-_, wk_s = pm('WRITE_SIZE', 'k_clear_slabs<true>')
-_, wk_bits = pm('WRITE_SIZE', 'k_stamp_bits')
-_, wk_marks = pm('WRITE_SIZE', 'k_stamp_marks')
-_, fk_bits = pm('FETCH_SIZE', 'k_stamp_bits')
-_, fk_marks = pm('FETCH_SIZE', 'k_stamp_marks')
-traffic = int((fk + wk) * 1024)
-alg = dn['roofline']['bytes_per_launch']
-# the sparse reset by itself (tools/diag_reset_pmc.py: 5 sparse resets, entry counts printed by the plain run)
-_, fk_r = pm('FETCH_SIZE', 'k_reset_sectors<2, 1>', last=True)  # the diag_reset_pmc passes come last in the summary
-_, wk_r = pm('WRITE_SIZE', 'k_reset_sectors<2, 1>', last=True)
+KB = 1024.0
+# ---- sparse reset + stamp + overlay by themselves (tools/diag_reset_pmc.py under --pmc) -----------------------------
+_, fk_r = pm('FETCH_SIZE', 'k_reset_sectors<2, 1>')
+_, wk_r = pm('WRITE_SIZE', 'k_reset_sectors<2, 1>')
+_, fk_m = pm('FETCH_SIZE', 'k_stamp_marks')
+_, wk_m = pm('WRITE_SIZE', 'k_stamp_marks')
+_, fk_b = pm('FETCH_SIZE', 'k_stamp_bits')
+_, wk_b = pm('WRITE_SIZE', 'k_stamp_bits')
 ra = read('reset_alone_plain.txt')
 ent = [int(x) for x in re.search(r"log entries after each update: \[([\d, ]+)\]", ra).group(1).split(",")]
-reset_ms = [float(x) for x in re.search(r"ms: \[([\d., ]+)\]", ra).group(1).split(",")]
-wide_ms = [float(x) for x in re.search(r"ms: \[([\d., ]+)\]", read('reset_alone_wide.txt')).group(1).split(",")]
-ent_reset = sum(ent[:-1]) / len(ent[:-1])  # reset k reads the log update k-1 wrote
-json.dump({"kernel": "k_reset_sectors (sparse reset of the SOGM)",
-           "source": "profiles/r03_end_rocprof.md (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes of "
-                     "`python tools/diag_reset_pmc.py`: 128 agents 200x200x200x20, single grid, update = reset + stamp + overlay)",
-           "fetch_kb": fk_r, "write_kb": wk_r, "entries_per_launch": ent_reset,
-           "bytes_per_entry": (fk_r + wk_r) * 1024 / ent_reset, "issued_bytes_per_entry": 36},
-          open('profiles/r03_pmc_reset.json', 'w'))
-json.dump({"kernel": "k_clear_chunks (the in-tick SOGM clear) / k_clear_slabs (full-width stage pass)",
-           "source": "profiles/r03_end_rocprof.md (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes of "
-                     "`SOGM_CLEAR_EARLY=1 python tools/diag_clear_pmc.py` for k_clear_chunks and of `SOGM_FLOW=0 python "
-                     "bench.py --steps 2 --warmup 1 --no-cpu-baseline --sustained 0` for k_clear_slabs, 128 agents "
-                     "200x200x200x20)",
-           "fetch_kb": fk, "write_kb": wk, "bytes_per_launch": traffic, "algorithmic_bytes_per_launch": alg,
-           "k_clear_slabs": {"fetch_kb": fk_s, "write_kb": wk_s}},
-          open('profiles/r03_pmc_traffic.json', 'w'))
-r, s = d['roofline'], d['sustained']
-cb = d['cpu_baseline']
+reset_ms = [float(x) for x in re.search(r"reset launches[^:]*: \[([\d., ]+)\]", ra).group(1).split(",")]
+stamp_ms = [float(x) for x in re.search(r"stamp \(cull \+ bits \+ marks\) launches ms: \[([\d., ]+)\]", ra).group(1).split(",")]
+moved = json.loads(re.search(r"sogm_map_traffic\): (\[.*\])", ra).group(1))
+wide = read('reset_alone_wide.txt')
+wide_ms = [float(x) for x in re.search(r"reset launches[^:]*: \[([\d., ]+)\]", wide).group(1).split(",")] if wide else []
+ent_reset = sum(ent[:-1]) / len(ent[:-1])        # reset k reads the log update k-1 wrote
+marks = moved[-1]["stamp_marks"]
+s_entries = moved[-1]["stamp_entries"]
+zeroed = moved[-1]["reset_bytes_zeroed"]
+# gfx950: FETCH_SIZE reports half of a coalesced streaming read (MI355X_MICROARCH guide, HBM / rocprofv3 section): x 2
+reset_fetch, reset_write = 2 * fk_r * KB, wk_r * KB
+reset_traffic = reset_fetch + reset_write
+reset_counted = 4 * ent_reset + zeroed
+json.dump({"kernel": "k_reset_sectors (sparse reset of the SOGM, 2 lanes x 1 entry per trip: the variant the tick runs)",
+           "source": f"profiles/{R}_end_rocprof.md: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes of "
+                     "`python tools/diag_reset_pmc.py` (128 agents 200x200x200x20, single grid, update = reset + stamp + overlay)",
+           "fetch_kb": fk_r, "write_kb": wk_r, "fetch_bytes_corrected": reset_fetch, "write_bytes": reset_write,
+           "entries_per_launch": ent_reset, "bytes_per_entry": reset_traffic / ent_reset,
+           "device_counted_bytes_per_launch": reset_counted, "counted_over_traffic": reset_counted / reset_traffic},
+          open(f'profiles/{R}_pmc_reset.json', 'w'))
+stamp_alg = 4 * (marks + s_entries)
+stamp_traffic = (2 * fk_m + wk_m) * KB
+json.dump({"kernel": "k_stamp_marks (x-ordered marks + mark log)",
+           "source": f"profiles/{R}_end_rocprof.md (same passes as the reset)",
+           "fetch_kb": fk_m, "write_kb": wk_m, "bytes_per_launch": stamp_traffic, "marks": marks, "log_entries": s_entries,
+           "algorithmic_bytes_per_launch": stamp_alg, "sectors_logged": s_entries,
+           "sector_granular_minimum": 32 * s_entries + 4 * s_entries,
+           "k_stamp_bits": {"fetch_kb": fk_b, "write_kb": wk_b}},
+          open(f'profiles/{R}_pmc_stamp.json', 'w'))
+# ---- dense clear kernels (tools/diag_clear_pmc.py) ------------------------------------------------------------------
+_, fk_c = pm('FETCH_SIZE', 'k_clear_chunks<true>', last=True)
+_, wk_c = pm('WRITE_SIZE', 'k_clear_chunks<true>', last=True)
+plain_line, d = last_json('bench_plain.json')
+alg = d['roofline']['dense_equivalent']['bytes'] if 'dense_equivalent' in d['roofline'] else d['roofline']['bytes_per_launch']
+dense_traffic = int((fk_c + wk_c) * KB)
+json.dump({"kernel": "k_clear_chunks (the in-tick dense SOGM clear)",
+           "source": f"profiles/{R}_end_rocprof.md: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                     "`SOGM_SPARSE_RESET=0 SOGM_TUNING=clear_early=1 python tools/diag_clear_pmc.py`",
+           "fetch_kb": fk_c, "write_kb": wk_c, "bytes_per_launch": dense_traffic, "algorithmic_bytes_per_launch": alg},
+          open(f'profiles/{R}_pmc_traffic.json', 'w'))
+
+r, s, cb = d['roofline'], d.get('sustained') or {}, d.get('cpu_baseline') or {}
+kern = {k['kernel'].split(' ')[0]: k for k in r.get('kernels', [])}
+kd = next((k for k in r.get('kernels', []) if k['kernel'].startswith('k_clear_slabs')), {})
 smi = lambda f: " / ".join(l.split(":", 1)[1].strip() if ":" in l else l.strip() for l in read(f).splitlines()
                            if any(k in l for k in ("sclk", "mclk", "Power (W)", "Temperature (Sensor junction)")))
-cap, cfg4r, qpar = read('capacity.txt').strip(), read('cfg4_residuals.txt').strip(), read('qp_parity.txt').strip()
-qpdump = read('qp_dump.log').strip().splitlines()[-1]
-try:
-    qp_table = open('profiles/r03_qp_infeasible_table.txt').read().strip()
-except OSError:
-    qp_table = "(run `python tools/diag_qp_infeasible.py analyze gpurun_out/qp_dump.npz > profiles/r03_qp_infeasible_table.txt`)"
-md = f"""# Round 3 — rocprofv3 profile of `python bench.py` (MI355X, 128 agents, 200^3 x 20), numbers of record
+var = {}
+for name in ('dense', 'flow0', 'grids2', 'mode1', 'cfg4', 'trace'):
+    var[name] = last_json(f'bench_{name}.json')
 
-Collected by `tools/make_profile.sh` on ONE GPU box (`cd /tmp && export TMPDIR=/tmp`), assembled by
+
+def vrow(label, key):
+    line, v = var[key]
+    if not v:
+        return f"| {label} | (not collected) | | | |"
+    rr, ss = v['roofline'], v.get('sustained') or {}
+    sus = f"{ss['value']:.0f} ({ss['tick_ms_mean']:.2f} ms)" if ss else "—"
+    return f"| {label} | {v['value']:.0f} | {v['ms_per_step']:.2f} | {rr['avg_launch_ms']:.2f} (frac {rr['frac']:.3f}) | {sus} |"
+
+
+ch = d.get('chain_ms') or {}
+st = cb.get('stages_ms') or {}
+slow = s.get('slowest_tick') or {}
+md = f"""# Round 4 — rocprofv3 profile of `python bench.py` (MI355X, 128 agents, 200^3 x 20), numbers of record
+
+Collected by `tools/make_profile.sh core` and `... rest` on ONE GPU box (`cd /tmp && export TMPDIR=/tmp`), assembled by
 `tools/make_profile_md.py`:
-- `rocprofv3 --kernel-trace --stats -d … -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline --sustained 0`
+- `rocprofv3 --kernel-trace --stats -d … -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline --sustained 0 --dense-ticks 0`
 - separate PMC passes (no trace domains): `rocprofv3 --pmc FETCH_SIZE …` and `… --pmc WRITE_SIZE …` of
-  `SOGM_CLEAR_EARLY=1 python tools/diag_clear_pmc.py` (the in-tick clear kernels `k_clear_chunks` and the stamp
-  kernels by themselves: counter collection serialises kernels, under which the dataflow replan cannot run) and of
-  `SOGM_FLOW=0 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --sustained 0` (grouped path: `k_clear_slabs`).
+  `SOGM_TUNING=reset_lanes=2,reset_unroll=1 python tools/diag_reset_pmc.py` (the sparse reset, the logging stamp and the
+  overlay by themselves: counter collection serialises kernels, under which the dataflow replan cannot run) and of
+  `SOGM_SPARSE_RESET=0 SOGM_TUNING=clear_early=1 python tools/diag_clear_pmc.py` (the in-tick dense clear kernels).
 The rocpd databases stay in gpurun_out/ (scratch); this file holds what is cited.
 
-**Box state** (`rocm-smi --showclocks --showpower --showtemp`; idle readings — the shader clock parks at ~100 MHz
-between kernels, mclk is fixed): before the default run: {smi('smi_before.txt')}; after it: {smi('smi_after.txt')}.
-Boxes differ: the same full-width clear takes 12.2–13.6 ms (0.75–0.84 of peak) from box to box, so only figures of ONE
-box (one make_profile run, one `tools/micro/ab.sh` call) are compared with each other in DESIGN.md.
+**Box state** (`rocm-smi --showclocks --showpower --showtemp`; idle readings): before the default run:
+{smi('smi_before.txt')}; after it: {smi('smi_after.txt')}.  Boxes differ by several per cent (the same full-width clear:
+12.2–13.8 ms), so only figures of ONE box are compared with each other in DESIGN.md; code versions are compared on one
+box with `tools/micro/ab.sh` (`SOGM_LIB_PATH`).
 
-State: dataflow replan (`k_astar` with the speculative second attempt; persistent `k_corridor_flow` / `k_qp_flow` /
-`k_finish_flow` chained per agent), three SOGM grids, **sparse reset of the SOGM** (`k_reset_sectors`: the stamp and the
-overlay log the 32-byte sector of every mark; the grid the update swaps out is reset on the side stream by zeroing the
-logged sectors — the dense clear, `k_clear_chunks` / `k_clear_slabs`, remains for untracked grids and `SOGM_SPARSE_RESET=0`),
-**two-pass stamp** (`k_stamp_bits` occupancy bitmask, `k_stamp_marks` x-ordered marks + log), A* with the templated SOGM
-window query, wave-parallel heap pushes and the closed set in LDS, OSQP restated with the recession-cone projection in
-the infeasibility certificate and the scaled rho estimate.
+## Default run (`python bench.py`: 3 warm-up + 20 timed ticks, the dense-clear block, 300 host-synchronised ticks, CPU baseline)
 
-Default run (`python bench.py`: 3 warm-up + 20 timed ticks, then 300 host-synchronised ticks of the same flight,
-then the CPU baseline): **{d['value']:.0f} replans/s** ({d['ms_per_step']:.2f} ms per tick), of which
-{d['value_ok']:.0f} successful (`replans_ok_fraction` {d['config']['replans_ok_fraction']:.3f}; outcomes
-{json.dumps(d['config']['outcomes'])}); **sustained** {s['value']:.0f} replans/s over {s['ticks']} ticks (tick mean
-{s['tick_ms_mean']:.2f} / p50 {s['tick_ms_p50']:.2f} / p99 {s['tick_ms_p99']:.2f} / max {s['tick_ms_max']:.2f} ms, ok
-{s['replans_ok_fraction']:.3f}, {s['value_ok']:.0f} successful replans/s; outcomes {json.dumps(s['outcomes_rank0'])}).
-The reset inside the tick (HIP events on its stream around every reset of the timed region, n = {r['launches_timed']},
-{r['sparse_resets']} of them sparse): {r['avg_launch_ms']:.2f} ms for {r['log_entries_per_launch']/1e6:.1f} M log entries =
-{r['bytes_per_launch']/1e9:.2f} GB algorithmic (4 B entry read + its 32-byte sector zeroed) = {r['achieved']:.0f} GB/s = **{r['frac']:.3f}** of
-the 8 TB/s HBM peak — off the critical path and no longer what bounds the tick: SURVEY 8(d)'s dense figure
-({alg/1e9:.2f} GB per rebuild) divided by this launch is {r['dense_equivalent']['rate_GBps']/1e3:.1f} TB/s.  The dense clear
-`k_clear_slabs` full width with the machine to itself: {min(r['standalone']['launch_ms']):.2f} ms =
-{r['standalone']['frac']:.3f} of peak; inside the tick (`SOGM_SPARSE_RESET=0`, below): {dn['roofline']['avg_launch_ms']:.2f} ms =
-{dn['roofline']['frac']:.3f}.  CPU baseline (oracle "port", one agent-replan per thread): {cb['value']:.1f} replans/s on
-{cb['cores']} of {cb.get('host_cores')} host cores ({cb['sample']}).
+**{d['value']:.0f} replans/s** ({d['ms_per_step']:.2f} ms per tick), {d['value_ok']:.0f} successful
+(`replans_ok_fraction` {d['config']['replans_ok_fraction']:.3f}; outcomes {json.dumps(d['config']['outcomes'])}).
+Sustained: {s.get('value', 0):.0f} replans/s over {s.get('ticks')} ticks (tick mean {s.get('tick_ms_mean', 0):.2f} / p50
+{s.get('tick_ms_p50', 0):.2f} / p99 {s.get('tick_ms_p99', 0):.2f} / max {s.get('tick_ms_max', 0):.2f} ms, ok
+{s.get('replans_ok_fraction', 0):.3f}); the slowest tick ({slow.get('tick_ms', 0):.2f} ms, tick {slow.get('tick')}): chain end
+{slow.get('chain_end', 0):.2f} ms, critical agent {slow.get('critical_agent')} = {json.dumps(slow.get('critical_chain'))} — an
+exhaustive A\\* search (both attempts NO_PATH) is what the long ticks are.
 
-Variants on the same box:
-| variant | replans/s | ms/tick | reset / clear ms | sustained replans/s (mean tick) |
-|---|---|---|---|---|
-| default: dataflow replan, 3 grids, sparse reset | {d['value']:.0f} | {d['ms_per_step']:.2f} | {r['avg_launch_ms']:.2f} | {s['value']:.0f} ({s['tick_ms_mean']:.2f} ms) |
-| **dense clear** (`SOGM_SPARSE_RESET=0`: rounds 1-2; width-adaptive chunked clear) | {dn['value']:.0f} | {dn['ms_per_step']:.2f} | {dn['roofline']['avg_launch_ms']:.2f} (frac {dn['roofline']['frac']:.3f}) | {dn['sustained']['value']:.0f} ({dn['sustained']['tick_ms_mean']:.2f} ms, 100 ticks) |
-| grouped streams (`SOGM_FLOW=0`, round-1 structure), 3 grids | {f0['value']:.0f} | {f0['ms_per_step']:.2f} | {f0['roofline']['avg_launch_ms']:.2f} | {f0['sustained']['value']:.0f} ({f0['sustained']['tick_ms_mean']:.2f} ms, 100 ticks) |
-| dataflow, 2 grids (`SOGM_GRIDS=2`: 164 GB instead of 246) | {g2['value']:.0f} | {g2['ms_per_step']:.2f} | {g2['roofline']['avg_launch_ms']:.2f} | — |
-| single grid, reset in place after the last reader (`SOGM_DOUBLE_BUFFER=0`, grouped path) | {m1['value']:.0f} | {m1['ms_per_step']:.2f} | {m1['roofline']['avg_launch_ms']:.2f} | — |
-| BASELINE configs[4]: 300^3 x 30, fp16 cells, 207 GB, single grid | {c4['value']:.0f} | {c4['ms_per_step']:.2f} | {c4['roofline']['avg_launch_ms']:.2f} | — |
+Per-agent chain of the last timed tick (device timestamps, ms): A\\* {ch.get('astar_mean', 0):.2f} mean / {ch.get('astar_max', 0):.2f} max,
+corridors {ch.get('corridor_mean', 0):.2f} / {ch.get('corridor_max', 0):.2f}, QP {ch.get('qp_mean', 0):.2f} / {ch.get('qp_max', 0):.2f}; mean chain
+{ch.get('chain_mean', 0):.2f}, chain end {ch.get('chain_end', 0):.2f} (critical agent {ch.get('critical_agent')}: {json.dumps(ch.get('critical_chain'))}).
+CPU baseline (oracle "port"): {cb.get('value', 0):.1f} replans/s on {cb.get('cores')} of {cb.get('host_cores')} host cores;
+single-thread stage latencies of tick 0: SOGM update {st.get('sogm_update') or 0:.1f} ms, A\\* {st.get('astar') or 0:.2f} ms, corridors
+{st.get('corridor') or 0:.2f} ms, QP {st.get('qp') or 0:.1f} ms.
+
+## Roofline: what moved
+
+| kernel | time | bytes counted on the device / algorithmic | rate | of 8 TB/s | PMC traffic (FETCH x 2 + WRITE) | traffic / counted |
+|---|---|---|---|---|---|---|
+| `k_reset_sectors` inside the tick (n = {r.get('launches_timed')}) | {r['avg_launch_ms']:.3f} ms | {r['bytes_per_launch']/1e9:.3f} GB = 4 B x {r.get('log_entries_per_launch', 0)/1e6:.1f} M entries + {r.get('bytes_zeroed_per_launch', 0)/1e9:.3f} GB zeroed | {r['achieved']:.0f} GB/s | **{r['frac']:.3f}** | {(r.get('traffic') or 0)/1e9:.3f} GB (scaled per entry from the pass below) | {((r.get('traffic') or 0)/r['bytes_per_launch']):.3f} |
+| `k_reset_sectors` alone (PMC pass; launches {", ".join("%.3f" % x for x in reset_ms[1:])} ms) | {sum(reset_ms[1:])/len(reset_ms[1:]):.3f} ms | {reset_counted/1e9:.3f} GB = 4 B x {ent_reset/1e6:.1f} M + {zeroed/1e9:.3f} GB | {reset_counted/(sum(reset_ms[1:])/len(reset_ms[1:]))/1e6:.0f} GB/s | {reset_counted/(sum(reset_ms[1:])/len(reset_ms[1:]))/1e6/8000:.3f} | {reset_traffic/1e9:.3f} GB = {reset_fetch/1e9:.3f} + {reset_write/1e9:.3f} | {reset_traffic/reset_counted:.3f} |
+| the stamp alone (cull + bits + marks; launches {", ".join("%.2f" % x for x in stamp_ms[1:])} ms) | {sum(stamp_ms[1:])/len(stamp_ms[1:]):.2f} ms | {stamp_alg/1e9:.3f} GB = 4 B x ({marks/1e6:.1f} M marks + {s_entries/1e6:.1f} M log entries) | {stamp_alg/(sum(stamp_ms[1:])/len(stamp_ms[1:]))/1e6:.0f} GB/s | {stamp_alg/(sum(stamp_ms[1:])/len(stamp_ms[1:]))/1e6/8000:.3f} | `k_stamp_marks` {stamp_traffic/1e9:.3f} GB (FETCH {2*fk_m*KB/1e9:.3f} + WRITE {wk_m*KB/1e9:.3f}); `k_stamp_bits` WRITE {wk_b*KB/1e9:.2f} GB of device-scope atomics | {stamp_traffic/stamp_alg:.2f} |
+| dense clear alone (full width) | {min(kd.get('standalone', {}).get('launch_ms', [0])):.2f} ms | {alg/1e9:.2f} GB | {kd.get('standalone', {}).get('achieved', 0):.0f} GB/s | **{kd.get('standalone', {}).get('frac', 0):.3f}** | {dense_traffic/1e9:.2f} GB (`k_clear_chunks`) | {dense_traffic/alg:.4f} |
+| dense clear inside the tick (`sogm_set_sparse_reset 0`, {(kd.get('in_tick') or {}).get('launches_timed')} ticks) | {(kd.get('in_tick') or {}).get('avg_launch_ms', 0):.2f} ms | {alg/1e9:.2f} GB | {(kd.get('in_tick') or {}).get('achieved', 0):.0f} GB/s | **{(kd.get('in_tick') or {}).get('frac', 0):.3f}** (tick {(kd.get('in_tick') or {}).get('tick_ms', 0):.2f} ms) | — | — |
 
 Reading guide:
-- **Sparse reset.**  `k_reset_sectors` by itself (tools/diag_reset_pmc.py, single grid, every update = reset + stamp +
-  overlay; launches {", ".join("%.2f" % x for x in reset_ms[1:])} ms, the first update's dense clear {reset_ms[0]:.2f} ms):
-  {ent_reset/1e6:.1f} M entries per launch; PMC FETCH_SIZE {fk_r/1e6:.2f} GB + WRITE_SIZE {wk_r/1e6:.2f} GB per launch (KB = 1024 B) =
-  **{(fk_r + wk_r) * 1024 / ent_reset:.1f} B of HBM traffic per entry** against the 36 algorithmic bytes (two lanes zero an
-  entry's 32-byte sector with one store each, repeats of the previous entry skipped, the other duplicates absorbed by
-  the L2: the variant the tick runs under the replan).  In the update's own stream (single-grid mode, these launches'
-  case) four lanes zero the sector's 64-byte line, eight entries per trip: {", ".join("%.2f" % x for x in wide_ms[1:])} ms, 26 B of
-  traffic per entry — faster alone, slower beside the QP stage (1.17 against 1.05 ms) — {(fk_r + wk_r) * 1024 / alg * 100:.1f} % of the {alg/1e9:.2f} GB a dense rebuild writes.
-- **Dense clear** (kept for untracked grids; `SOGM_SPARSE_RESET=0`): {alg/1e9:.2f} GB algorithmic bytes per clear = 128
-  agents x 640 MB.  PMC of `k_clear_chunks<true>` (serialised: the narrow launch clears the whole grid): FETCH_SIZE
-  {fk:.0f} KB + WRITE_SIZE {wk:.0f} KB = {traffic/1e9:.2f} GB per clear, i.e. **{traffic/alg:.4f} x** the algorithmic bytes;
-  `k_clear_slabs<true>`: FETCH {fk_s:.0f} KB + WRITE {wk_s:.0f} KB = x {(fk_s + wk_s) * 1024 / alg:.4f}.  No wasted traffic.
-- Stamp (with the log): `k_stamp_bits` WRITE {wk_bits/1e6:.2f} GB (device-scope atomics) / FETCH {fk_bits/1e6:.2f} GB,
-  `k_stamp_marks` WRITE {wk_marks/1e6:.2f} GB / FETCH {fk_marks/1e6:.2f} GB per tick: the ≈0.28 GB of marked bytes plus
-  {ent_reset*4/1e9:.2f} GB of log entries (round 2, one pass in cloud order, no log: 2.41 GB).
-- In the dataflow replan the planner is five launches per tick; `k_corridor_flow`, `k_qp_flow`, `k_finish_flow` are
-  persistent (their durations span most of the tick by construction) — the per-agent stage times below are what to
-  read, not the kernel durations.
+- **The reset** is rated on what it moved: `sogm_map_traffic` counts, on the device and in the run, the log entries read
+  and the bytes of the stores issued; the PMC pass (reset alone, same variant) agrees within
+  {abs(reset_traffic/reset_counted - 1)*100:.1f} % (FETCH_SIZE doubled: gfx950 reports half of a coalesced streaming read).
+  It is a scatter of 32-byte stores behind a 4-byte index stream: latency-bound at ≈{reset_counted/(sum(reset_ms[1:])/len(reset_ms[1:]))/1e6/8000:.2f} of
+  the HBM peak, off the critical path (side stream, under the QP stage).  SURVEY 8(d)'s {alg/1e9:.2f} GB fill is not
+  executed; the kernel that does execute it is the dense clear (last two rows).
+- **Mark log**: this round the stamp logs a sector once per run of x-neighbouring marks instead of once per mark:
+  {s_entries/1e6:.1f} M entries per tick (round 3: 87.6 M), one per distinct sector.
+- **Stamp write amplification**: against "4 B per mark + 4 B per log entry" `k_stamp_marks` writes
+  x {stamp_traffic/stamp_alg:.2f}; but the {marks/1e6:.1f} M marks fall into {s_entries/1e6:.1f} M distinct 32-byte sectors
+  ({marks/s_entries:.2f} marks per sector: cylinder surfaces cross an x-row in two or three cells), and HBM writes whole
+  sectors: the sector-granular minimum is 32 B x sectors + 4 B x entries = {(36*s_entries)/1e9:.3f} GB, the counters show
+  {stamp_traffic/1e9:.3f} GB = x {stamp_traffic/(36*s_entries):.3f} of it.  Nothing is written twice; fewer bytes need a grid
+  layout in which a pillar's marks share sectors (z-fastest or blocked), which the A\\* window query pays for
+  (DESIGN 3.1).
+- In the dataflow replan the planner is five launches per tick; `k_corridor_flow`, `k_qp_flow`, `k_finish_flow`,
+  `k_prestamp_flow` are persistent (their durations span most of the tick by construction) — the per-agent chain is what
+  to read, not the kernel durations.
+
+## Variants on the same box
+
+| variant | replans/s | ms/tick | reset / clear ms | sustained replans/s (mean tick) |
+|---|---|---|---|---|
+| default: dataflow replan, 3 grids, sparse reset, pre-stamp | {d['value']:.0f} | {d['ms_per_step']:.2f} | {r['avg_launch_ms']:.2f} (frac {r['frac']:.3f}) | {s.get('value', 0):.0f} ({s.get('tick_ms_mean', 0):.2f} ms) |
+{vrow("dense clear (`SOGM_SPARSE_RESET=0`)", 'dense')}
+{vrow("grouped streams (`SOGM_FLOW=0`), 3 grids", 'flow0')}
+{vrow("dataflow, 2 grids (`SOGM_GRIDS=2`)", 'grids2')}
+{vrow("single grid, reset in place (`SOGM_DOUBLE_BUFFER=0`)", 'mode1')}
+{vrow("BASELINE configs[4]: 300^3 x 30, fp16 cells", 'cfg4')}
+
+Reduced residency (tests/test_residency_gpu.py, full-size tick, identical records): {read('residency.txt').strip() or '(not collected)'}
 
 {summ}
 
-## timeline of one tick (ms from the tick's first kernel, k_tick_inputs)
+## timeline of one tick (ms from the tick's first kernel)
 
 ```
 {tl.strip()}
@@ -146,34 +194,16 @@ Reading guide:
 {flow.strip()}
 ```
 
-## the QPs that fail: infeasible, and how soon OSQP's certificate sees it (tools/diag_qp_infeasible.py)
-
-Every QP of 23 ticks of the bench flight, dumped on the GPU ({qpdump}); each failing one then goes through a HiGHS
-feasibility LP on {{l <= Ax <= u}} and through the CPU oracle's OSQP restatement ("dumped" = this round's kernel, i.e.
-recession-cone projection + scaled rho estimate; the same analysis at the start of the round, with round 2's
-certificate and unscaled estimate: 201 failing QPs, all infeasible, 194 certified at a median of 725 iterations, 7 at
-max_iter; projection alone: 193 / 201 certified at the same iteration):
+## where the QP stage spends its time (tools/diag_qp_time.py: per-solve clock split inside `k_qp_flow`, 12 ticks)
 
 ```
-{qp_table}
-```
-
-GPU vs oracle on the same corridors (tools/diag_qp_parity.py, 3 ticks x 128 agents):
-
-```
-{qpar}
+{qpt.strip()}
 ```
 
 ## capacity limits over a 323-tick flight (tools/diag_capacity.py)
 
 ```
-{cap}
-```
-
-## BASELINE configs[4]: fp64 vs fp32 residual checks on 300^3 x 30 (tools/diag_cfg4_residuals.py)
-
-```
-{cfg4r}
+{read('capacity.txt').strip()}
 ```
 
 ## bench.py JSON lines
@@ -181,97 +211,33 @@ GPU vs oracle on the same corridors (tools/diag_qp_parity.py, 3 ticks x 128 agen
 - default run:
 
 ```
-{plain}
+{plain_line}
 ```
 
 - under `--kernel-trace --stats`:
 
 ```
-{trace}
+{var['trace'][0]}
 ```
 
 - dense clear (`SOGM_SPARSE_RESET=0`):
 
 ```
-{dense}
+{var['dense'][0]}
 ```
 
 - grouped path (`SOGM_FLOW=0`):
 
 ```
-{flow0}
-```
-
-- single-grid mode:
-
-```
-{mode1}
+{var['flow0'][0]}
 ```
 
 - BASELINE configs[4]:
 
 ```
-{cfg4}
+{var['cfg4'][0]}
 ```
 """
-open('profiles/r03_end_rocprof.md', 'w').write(md)
-
-
-def kern(table, name):
-    """(calls, median ms) of a kernel from the per-dispatch list of a rocprof_summary file"""
-    m = re.search(r"^- [^\n]*%s: ([\d, ]+)$" % re.escape(name), table, re.M)
-    if not m:
-        return 0, float('nan')
-    v = sorted(float(x) for x in m.group(1).split(","))
-    return len(v), v[len(v) // 2] / 1e3
-
-
-def pmc(table, name, counter):
-    m = re.search(r"\| [^|]*%s[^|]* \| %s \| \d+ \| ([\d.]+) \|" % (re.escape(name), counter), table)
-    return float(m.group(1)) if m else float('nan')
-
-
-sd = read('summary_dsp.md')
-_, pub_ms = kern(sd, 'k_dsp_publish')
-pub_f, pub_w = pmc(sd, 'k_dsp_publish', 'FETCH_SIZE'), pmc(sd, 'k_dsp_publish', 'WRITE_SIZE')
-V, T, A1 = 100 ** 3, 15, 16
-pub_alg = A1 * (3 * V * T * 4 + 4 * V)  # read fut, write grid, zero fut; read the occupancy plane
-_, occ_ms = kern(sd, 'k_dsp_occupancy')
-occ_f, occ_w = pmc(sd, 'k_dsp_occupancy', 'FETCH_SIZE'), pmc(sd, 'k_dsp_occupancy', 'WRITE_SIZE')
-md2 = f"""# Round 3 — perception kernels (particle SOGM, cloud filter, depth front end): rocprofv3 per-kernel tables
-
-`tools/make_profile.sh`: `rocprofv3 --kernel-trace --stats -- python tools/bench_dsp.py` (BASELINE configs[1]: 16
-agents, 100^3 x 15, 307 200 depth points per agent and frame, velocity estimation on the GPU) and
-`… tools/bench_gridmap.py` (400 x 400 x 30 voxels, 640 x 480 depth images), plus `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE`
-passes of the same commands (separate runs, no trace domains).  "mean value (KB)" is the counter per dispatch in KB of
-1024 B: FETCH_SIZE + WRITE_SIZE = HBM bytes a dispatch moved.
-
-**Roofline ratings of the streaming kernels on this side** (the others are latency- / atomics-bound scans of sparse
-structures and are not rated):
-- `k_dsp_publish` — a pure stream: per agent it reads the future-occupancy accumulators `fut[T][V]`, writes them into
-  the SOGM slabs, zeroes them, and reads one occupancy plane: algorithmic bytes 3 V T 4 + 4 V per agent =
-  {pub_alg/1e9:.2f} GB for 16 agents x 100^3 x 15.  Kernel-trace median {pub_ms:.3f} ms -> **{pub_alg/1e9/pub_ms:.2f} TB/s =
-  {pub_alg/1e9/pub_ms/8:.2f} of the 8 TB/s peak**; PMC FETCH {pub_f/1e6:.2f} GB + WRITE {pub_w/1e6:.2f} GB =
-  x {(pub_f + pub_w) * 1024 / pub_alg:.2f} the algorithmic bytes.
-- `k_dsp_occupancy` (per-voxel resample + occupancy: one 16-byte flag load per voxel, the occupied slots' lines):
-  {occ_ms:.3f} ms, PMC FETCH {occ_f/1e6:.2f} GB + WRITE {occ_w/1e6:.2f} GB -> {(occ_f + occ_w) * 1024 / 1e9 / occ_ms:.2f} TB/s of actual
-  traffic (it touches a data-dependent subset of the store, so there is no algorithmic byte count to rate it against).
-
-## particle SOGM + filterPointCloud (tools/bench_dsp.py)
-
-```
-{dsp}
-```
-
-{sd}
-
-## GridMap depth front end (tools/bench_gridmap.py)
-
-```
-{gm}
-```
-
-{read('summary_gridmap.md')}
-"""
-open('profiles/r03_perception_rocprof.md', 'w').write(md2)
-print("wrote profiles/r03_end_rocprof.md", len(md), "bytes,", "profiles/r03_perception_rocprof.md", len(md2), "bytes; traffic", traffic, "x", traffic / alg)
+open(f'profiles/{R}_end_rocprof.md', 'w').write(md)
+print(f"wrote profiles/{R}_end_rocprof.md", len(md), "bytes; reset counted/traffic", reset_counted / reset_traffic,
+      "stamp amplification", stamp_traffic / stamp_alg)
