@@ -5,7 +5,9 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-# as the package does on import — but some GPU tests touch torch.cuda before they import it
+# as the package does on import — but some GPU tests touch torch.cuda before they import it (INTEGRATION.md section 2:
+# every stream of a running planner wants a hardware queue of its own; with 12 the two-rank-in-one-process flight,
+# 2 x 9 streams, shares queues across the two contexts and stalls)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

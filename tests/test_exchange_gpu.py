@@ -238,6 +238,7 @@ print("two-rank flight ok", ref_oks)
 """
 
 
+@pytest.mark.own_device  # (a child process with two planners, ~20 streams: flown before this process holds queues of its own)
 def test_two_rank_flight_on_one_gpu_matches_the_single_process_flight(pop, tmp_path):
     """The N > 1 tick on real kernels: two SwarmTick ranks (two host threads, one GPU, world size 2) fly 6 ticks with
     HipCompute, the publication inside the replan and the trajectory exchange through sogm_comm_* /

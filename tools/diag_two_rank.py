@@ -67,7 +67,14 @@ for rep in range(int(sys.argv[1]) if len(sys.argv) > 1 else 4):
                 sw.close()
         except Exception:
             import traceback
-            errs.append((rank, traceback.format_exc()))
+            extra = ""
+            try:  # what the device saw (sogm_planner_flow_failures + the control block's header)
+                hdr = np.zeros(11, np.int32)
+                lib.sogm_debug_flow_peek(sw.planner._p, hdr.ctypes.data_as(C.c_void_p), hdr.size)
+                extra = f" flow_failures {sw.planner.flow_failures()} flow header {hdr.tolist()}"
+            except Exception as e2:
+                extra = f" (no flow state: {e2!r})"
+            errs.append((rank, traceback.format_exc()[-600:] + extra))
             try: dist.bar.abort()
             except Exception: pass
     ts = [threading.Thread(target=run, args=(r,), daemon=True) for r in range(WORLD)]
