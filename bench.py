@@ -171,7 +171,18 @@ def flow_chain(pop, sw):
     ms = (ts[:, :7] - t0) / 1e5  # 100 MHz ticks -> ms
     d = lambda a, b: ms[:, b] - ms[:, a]
     crit = int(np.argmax(ms[:, 6]))
-    return {"astar_mean": float(d(0, 1).mean()), "astar_max": float(d(0, 1).max()),
+    # the slowest QP of that replan, from the solve's own clocks (QpWorkspace::dbg: 100 MHz wall clock + shader clock)
+    st = np.zeros((A, 16), np.int64)
+    pop.lib().sogm_debug_qp_stats(sw.planner._p, st.ctypes.data_as(C.c_void_p))
+    q = int(np.argmax(d(4, 5)))
+    its = max(int(st[q, 6]), 1)
+    slow_qp = {"agent": q, "ms": float(st[q, 0]) / 1e5, "iterations": int(st[q, 6]), "refactorisations": int(st[q, 3]),
+               "checks": int(st[q, 5]), "setup_ms": float(st[q, 1]) / 1e5, "refactor_ms": float(st[q, 2]) / 1e5,
+               "checks_ms": float(st[q, 4]) / 1e5,
+               "us_per_iteration": float(st[q, 0] - st[q, 1] - st[q, 2] - st[q, 4]) / 100.0 / its,
+               "register_resident": bool(st[q, 7] & 1), "rows_in_lds": bool(st[q, 7] & 2),
+               "shader_clock_ghz": float(st[q, 11]) / max(float(st[q, 0]) * 10.0, 1.0)}
+    return {"slowest_qp": slow_qp,"astar_mean": float(d(0, 1).mean()), "astar_max": float(d(0, 1).max()),
             "corridor_mean": float(d(2, 3).mean()), "corridor_max": float(d(2, 3).max()),
             "qp_mean": float(d(4, 5).mean()), "qp_max": float(d(4, 5).max()),
             "finish_mean": float(d(5, 6).mean()), "chain_mean": float(ms[:, 6].mean()), "chain_end": float(ms[:, 6].max()),

@@ -274,6 +274,10 @@ struct CylCand {
   double wlim;  // w + clearance (fp64, as the reference compares)
   int    type, orig;
 };
+static_assert(sizeof(CylCand) == 32, "CylCand is copied in 16-byte pieces");
+// candidates a pre-stamp wave keeps in LDS (16 KiB; the bench scene keeps ~280 of its 555 cylinders per agent, the rest
+// of a longer list is read from global memory as before)
+constexpr int PRESTAMP_CAND_LDS = 512;
 // (The kernel also files the update's poses and stamps into the context's arrays — the later kernels of the update
 //  and the queries read those —, which saves two copy nodes in front of it.)
 __device__ __forceinline__ void cull_agent(const GridGeom &g, const SogmCylinder *__restrict__ cyl, int n_cyl,
@@ -357,13 +361,25 @@ __global__ __launch_bounds__(64) void k_stamp_bits(GridGeom g, const float *__re
                    pose[0], pose[1], pose[2], bits + (size_t)agent * words_per_agent);
 }
 
+// Profiling build only (make EXTRA=-DSOGM_PROFILE_PRESTAMP, tools/diag_prestamp.py): 100 MHz ticks the pre-stamp's waves
+// spend [0] waiting for a published agent, [1] waiting for the agent's cull / bits pass, [2] in the cull, [3] in the bits
+// pass, [4] in the marks pass, of which [5] the candidate walk and [6] the slice loops; [7] tickets, [8] chunks of 64 voxels
+#ifdef SOGM_PROFILE_PRESTAMP
+__device__ unsigned long long g_ps_prof[12];
+#define PS_CLK() wall_clock64()
+#define PS_ADD(i, v) do { if (threadIdx.x == 0) atomicAdd(&g_ps_prof[i], (unsigned long long)(v)); } while (0)
+#else
+#define PS_CLK() 0ll
+#define PS_ADD(i, v) do { } while (0)
+#endif
 __device__ __forceinline__ void stamp_marks_trips(const GridGeom &g, void *__restrict__ grid,
                                                   unsigned *__restrict__ bits, int words_per_agent,
                                                   const SogmCylinder *__restrict__ cyl, int n_cyl,
                                                   const float *__restrict__ poses,
                                                   const CylCand *__restrict__ cand_all,
                                                   const int *__restrict__ n_cand, int agent, const MarkLog &lg,
-                                                  int w_first, int w_stride) {
+                                                  int w_first, int w_stride, CylCand *cand_lds = nullptr,
+                                                  int cand_lds_cap = 0) {
   const int      kept   = n_cand[agent];
   const bool     culled = kept <= SOGM_MAX_CYL_LDS;
   const int      n_lds  = culled ? kept : 0;
@@ -375,6 +391,12 @@ __device__ __forceinline__ void stamp_marks_trips(const GridGeom &g, void *__res
   unsigned      *mask = bits + (size_t)agent * words_per_agent;
   const int      lane = threadIdx.x;
   unsigned n_marks = 0, n_logged = 0;  // this lane's marks, the wave's log entries (statistics: two atomics per call)
+  // One-wave workgroups of the dataflow pre-stamp stage the head of the agent's candidate list in LDS at their first
+  // occupied trip (16-byte pieces, coalesced): the walk below reads every candidate for every chunk of 64 voxels, and
+  // from global memory each batch of four cost a ~0.7 us L2 round trip in the tick — 51 us per chunk, three quarters of
+  // the pre-stamp's wave time (tools/diag_prestamp.py) and what the tick's end waited for in half of the ticks.
+  int n_staged = 0;
+  bool staged  = cand_lds == nullptr;
   // a trip covers 256 mask words (8192 voxels): every lane loads four, the set bits of the whole trip are numbered
   // by a wave scan of the pop counts, and lane t of chunk b takes set bit b + t — dense lanes whatever the
   // occupancy pattern, and neighbouring lanes still hold neighbouring voxels (words_per_agent is padded to 256)
@@ -391,6 +413,15 @@ __device__ __forceinline__ void stamp_marks_trips(const GridGeom &g, void *__res
     }
     const int excl  = inc - cnt;
     const int total = __shfl(inc, 63, 64);
+    if (total > 0 && !staged) {  // uniform
+      n_staged            = n_lds < cand_lds_cap ? n_lds : cand_lds_cap;
+      const uint4 *src    = reinterpret_cast<const uint4 *>(cand);
+      uint4       *dst    = reinterpret_cast<uint4 *>(cand_lds);
+      const int    pieces = n_staged * (int)(sizeof(CylCand) / 16);
+      for (int q = lane; q < pieces; q += 64) dst[q] = src[q];
+      __syncthreads();  // (one wave: the LDS writes above are visible to the reads of the walk)
+      staged = true;
+    }
     for (int b0 = 0; b0 < total; b0 += 64) {  // uniform
       const int  i      = b0 + lane;
       const bool active = i < total;
@@ -433,51 +464,111 @@ __device__ __forceinline__ void stamp_marks_trips(const GridGeom &g, void *__res
       // before: one dependent L1 round trip per candidate, ~30 us per chunk of 64 voxels with the bench scene's ~280
       // candidates, which is what an agent's pre-stamp — and the tick's tail behind the last QP — waited for).
       bool found = !active;
-      for (int c0 = 0; c0 < n_loop; c0 += 4) {  // uniform
-        if (__builtin_amdgcn_readfirstlane((int)(__ballot(!found) == 0ull))) break;
-        int    type[4], orig[4];
-        float  ox[4], oy[4], wx[4], wy[4];
-        double wlim[4];
+      [[maybe_unused]] const long long ps_w0 = PS_CLK();
+      if (cand_lds != nullptr && n_staged == n_loop) {
+        // Every candidate is in LDS: the ordered walk only has to VISIT the candidates that can contain a voxel of this
+        // chunk.  The chunk's 64 voxels are neighbouring set bits (one obstacle's cross-section, usually): their xy
+        // bounding box is tested against 64 candidates at a time, one per lane (a cylinder whose axis is farther from
+        // the box than its radius + 1 cm cannot pass the test below for any voxel in it; rings are always visited), and
+        // the walk takes the surviving candidates in list order — the first match per voxel is the one the full walk
+        // finds.  ~280 visits per chunk become a handful (25 -> 2 us per chunk with the bench scene).
+        float xlo = active ? cx : INFINITY, xhi = active ? cx : -INFINITY;
+        float ylo = active ? cy : INFINITY, yhi = active ? cy : -INFINITY;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int c = c0 + u < n_loop ? c0 + u : n_loop - 1;  // (clamped: the test below skips it)
-          if (c < n_lds) {
-            const CylCand cc = cand[c];
-            type[u] = cc.type;
-            orig[u] = cc.orig;
-            ox[u]   = cc.x;
-            oy[u]   = cc.y;
-            wx[u]   = cc.vx;
-            wy[u]   = cc.vy;
-            wlim[u] = cc.wlim;
-          } else {
-            type[u] = cyl[c].type;
-            orig[u] = c;
-            ox[u]   = (float)cyl[c].x;
-            oy[u]   = (float)cyl[c].y;
-            wx[u]   = (float)cyl[c].vx;
-            wy[u]   = (float)cyl[c].vy;
-            wlim[u] = cyl[c].w + (double)g.clearance;
+        for (int d = 32; d >= 1; d >>= 1) {
+          xlo = fminf(xlo, __shfl_xor(xlo, d, 64));
+          xhi = fmaxf(xhi, __shfl_xor(xhi, d, 64));
+          ylo = fminf(ylo, __shfl_xor(ylo, d, 64));
+          yhi = fmaxf(yhi, __shfl_xor(yhi, d, 64));
+        }
+        bool done = false;
+        for (int c0 = 0; c0 < n_loop && !done; c0 += 64) {  // uniform
+          bool maybe = false;
+          if (c0 + lane < n_loop) {
+            const CylCand cc = cand_lds[c0 + lane];
+            if (cc.type == 3) {
+              const float ex = fmaxf(fmaxf(xlo - cc.x, cc.x - xhi), 0.0F), ey = fmaxf(fmaxf(ylo - cc.y, cc.y - yhi), 0.0F);
+              maybe          = (double)sqrtf(ex * ex + ey * ey) <= cc.wlim + 0.01;
+            } else {
+              maybe = cc.type == 2;
+            }
+          }
+          unsigned long long m = __ballot(maybe);
+          while (m) {  // uniform
+            const int c = c0 + __builtin_ctzll(m);
+            m &= m - 1;
+            const CylCand cc = cand_lds[c];
+            if (!found) {
+              bool hit = false;
+              if (cc.type == 2) {  // ring (:137-149)
+                hit = ring_contains(cyl[cc.orig], cx, cy, cz, g.res);
+              } else if (cc.type == 3) {
+                const float dx = cx - cc.x, dy = cy - cc.y, dz = cz - cz;
+                const float dist = sqrtf(dx * dx + dy * dy + dz * dz);
+                hit = (double)dist <= cc.wlim;
+              }
+              if (hit) {
+                vx    = cc.vx;
+                vy    = cc.vy;
+                found = true;
+              }
+            }
+            if (__builtin_amdgcn_readfirstlane((int)(__ballot(!found) == 0ull))) {
+              done = true;
+              break;
+            }
           }
         }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          if (found || c0 + u >= n_loop) continue;
-          bool hit = false;
-          if (type[u] == 2) {  // ring (:137-149)
-            hit = ring_contains(cyl[orig[u]], cx, cy, cz, g.res);
-          } else if (type[u] == 3) {  // (unknown type: the reference prints a warning and goes on, :150-152)
-            const float dx = cx - ox[u], dy = cy - oy[u], dz = cz - cz;
-            const float dist = sqrtf(dx * dx + dy * dy + dz * dz);
-            hit = (double)dist <= wlim[u];
+      } else {
+        for (int c0 = 0; c0 < n_loop; c0 += 4) {  // uniform
+          if (__builtin_amdgcn_readfirstlane((int)(__ballot(!found) == 0ull))) break;
+          int    type[4], orig[4];
+          float  ox[4], oy[4], wx[4], wy[4];
+          double wlim[4];
+  #pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int c = c0 + u < n_loop ? c0 + u : n_loop - 1;  // (clamped: the test below skips it)
+            if (c < n_lds) {
+              const CylCand cc = c < n_staged ? cand_lds[c] : cand[c];
+              type[u] = cc.type;
+              orig[u] = cc.orig;
+              ox[u]   = cc.x;
+              oy[u]   = cc.y;
+              wx[u]   = cc.vx;
+              wy[u]   = cc.vy;
+              wlim[u] = cc.wlim;
+            } else {
+              type[u] = cyl[c].type;
+              orig[u] = c;
+              ox[u]   = (float)cyl[c].x;
+              oy[u]   = (float)cyl[c].y;
+              wx[u]   = (float)cyl[c].vx;
+              wy[u]   = (float)cyl[c].vy;
+              wlim[u] = cyl[c].w + (double)g.clearance;
+            }
           }
-          if (hit) {
-            vx    = wx[u];
-            vy    = wy[u];
-            found = true;
+  #pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            if (found || c0 + u >= n_loop) continue;
+            bool hit = false;
+            if (type[u] == 2) {  // ring (:137-149)
+              hit = ring_contains(cyl[orig[u]], cx, cy, cz, g.res);
+            } else if (type[u] == 3) {  // (unknown type: the reference prints a warning and goes on, :150-152)
+              const float dx = cx - ox[u], dy = cy - oy[u], dz = cz - cz;
+              const float dist = sqrtf(dx * dx + dy * dy + dz * dz);
+              hit = (double)dist <= wlim[u];
+            }
+            if (hit) {
+              vx    = wx[u];
+              vy    = wy[u];
+              found = true;
+            }
           }
         }
       }
+      [[maybe_unused]] const long long ps_w1 = PS_CLK();
+      PS_ADD(5, ps_w1 - ps_w0);
+      PS_ADD(8, 1);
       // the cell of slice k this voxel marks (g.V: none — outside the grid, or the reference's out-of-bounds index)
       auto future_cell = [&](int k) -> int {
         const float fx = (cx + (vx * g.dt) * (float)k) - p0;
@@ -531,6 +622,7 @@ __device__ __forceinline__ void stamp_marks_trips(const GridGeom &g, void *__res
           if (((m >> lane) & 1ull) && li < (unsigned)lg.cap) lent[li] = sec;
         }
       }
+      PS_ADD(6, PS_CLK() - ps_w1);
     }
   }
   if (lg.stat) {
@@ -1025,6 +1117,7 @@ __global__ void k_prestamp_gate(int *hdr, int n_agents, int n_qp, int n_finish) 
 __global__ __launch_bounds__(64) void k_prestamp_flow(GridGeom g, FlowCtl fc, PrestampDev ps) {
   __shared__ __attribute__((aligned(16))) SogmTrajRecord s_rec;
   __shared__ double                                      s_hov[9];
+  __shared__ __attribute__((aligned(16))) CylCand        s_cand[PRESTAMP_CAND_LDS];
   const int lane  = threadIdx.x;
   // the last agents to be published get finer tickets: nobody is left to share the waves with, and their stamps are
   // what trails the replan
@@ -1034,16 +1127,20 @@ __global__ __launch_bounds__(64) void k_prestamp_flow(GridGeom g, FlowCtl fc, Pr
   for (;;) {
     const int t = flow_ticket(&fc.hdr[FLOW_P_TICKET]);
     if (t >= total) break;
+    [[maybe_unused]] const long long ps_t0 = PS_CLK();
+    PS_ADD(7, 1);
     const bool late = t >= n_early * per_e;
     const int  tl   = late ? t - n_early * per_e : t;
     const int  per  = late ? per_l : per_e;
     const int  n_bits = late ? ps.n_bits_late : ps.n_bits, n_marks = late ? ps.n_marks_late : ps.n_marks;
     const int agent = flow_wait_slot(fc.p_ready + (late ? n_early : 0) + tl / per, &fc.hdr[FLOW_ERR]);
     if (agent < 0) break;
+    PS_ADD(0, PS_CLK() - ps_t0);
     __threadfence();  // the agent's own record was published before its slot
     const int  s   = tl % per;
     long long *pts = fc.ts + 8 * (size_t)ps.n_agents + 4 * (size_t)agent;  // diagnostics (sogm_debug_prestamp_times)
     if (s == 0) {
+      [[maybe_unused]] const long long ps_c0 = PS_CLK();
       if (lane == 0) pts[0] = wall_clock64();
       // next tick's inputs of this agent (k_tick_inputs), then its candidate cylinders around the new centre
       constexpr int W   = (int)(sizeof(SogmTrajRecord) / 16);
@@ -1067,21 +1164,30 @@ __global__ __launch_bounds__(64) void k_prestamp_flow(GridGeom g, FlowCtl fc, Pr
         pts[1] = wall_clock64();
         atomicAdd(&fc.stage[agent], 1);
       }
+      PS_ADD(2, PS_CLK() - ps_c0);
     }
+    [[maybe_unused]] const long long ps_t1 = PS_CLK();
     if (s < n_bits) {
       if (flow_wait_count(&fc.stage[agent], 1, &fc.hdr[FLOW_ERR])) break;
+      [[maybe_unused]] const long long ps_t2 = PS_CLK();
+      PS_ADD(1, ps_t2 - ps_t1);
       const float p0 = ps.poses[agent * 3], p1 = ps.poses[agent * 3 + 1], p2 = ps.poses[agent * 3 + 2];
       const int   begin = ps.cloud_range[agent * 2], end = ps.cloud_range[agent * 2 + 1];
       stamp_bits_range(g, ps.cloud, begin + s * 64 + lane, end, n_bits * 64, p0, p1, p2,
                        ps.bits + (size_t)agent * ps.words);
       __threadfence();
+      PS_ADD(3, PS_CLK() - ps_t2);
       if (lane == 0 && atomicAdd(&fc.stage[agent], 1) + 1 == 1 + n_bits) pts[2] = wall_clock64();
     } else {
       if (flow_wait_count(&fc.stage[agent], 1 + n_bits, &fc.hdr[FLOW_ERR])) break;
+      [[maybe_unused]] const long long ps_t2 = PS_CLK();
+      PS_ADD(1, ps_t2 - ps_t1);
       stamp_marks_trips(g, ps.grid, ps.bits, ps.words, ps.cyl, ps.n_cyl, ps.poses, (const CylCand *)ps.cand, ps.n_cand, agent, ps.lg,
-                        (s - n_bits) * 256, n_marks * 256);
+                        (s - n_bits) * 256, n_marks * 256, s_cand, PRESTAMP_CAND_LDS);
+      __syncthreads();  // (the next ticket's staging overwrites s_cand)
       // the agent's last marks ticket to finish declares its grid complete (the next update's overlay waits for it)
       __threadfence();
+      PS_ADD(4, PS_CLK() - ps_t2);
       if (lane == 0 && atomicAdd(&fc.stage[agent], 1) + 1 == 1 + n_bits + n_marks) {
         pts[3] = wall_clock64();
         __hip_atomic_store(&fc.stage[agent], FLOW_PS_DONE, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
@@ -1089,6 +1195,19 @@ __global__ __launch_bounds__(64) void k_prestamp_flow(GridGeom g, FlowCtl fc, Pr
     }
   }
 }
+#ifdef SOGM_PROFILE_PRESTAMP
+}  // namespace sogm
+extern "C" int sogm_debug_prestamp_prof(unsigned long long *out12_host, int reset) {
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  if (out12_host && hipMemcpyFromSymbol(out12_host, HIP_SYMBOL(sogm::g_ps_prof), sizeof(unsigned long long) * 12) != hipSuccess) return -1;
+  if (reset) {
+    unsigned long long z[12] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(sogm::g_ps_prof), z, sizeof(z)) != hipSuccess) return -1;
+  }
+  return 0;
+}
+namespace sogm {
+#endif
 int launch_prestamp_flow(const GridGeom &g, const FlowCtl &fc, const PrestampDev &ps, int n_workgroups, int n_qp,
                          int n_finish, hipStream_t st) {
   hipLaunchKernelGGL(k_prestamp_gate, dim3(1), dim3(64), 0, st, fc.hdr, ps.gate_agents, n_qp, n_finish);

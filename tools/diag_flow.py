@@ -29,6 +29,11 @@ for k in range(ticks):
         pt = np.zeros((A, 4), np.int64)
         lib.sogm_debug_prestamp_times(sw.planner._p, pt.ctypes.data_as(C.c_void_p))
         pu = (pt - t0) / 100.0
+        fin = us[:, 6]
+        q = lambda v: f"{v.mean()/1000:.2f}/{np.percentile(v, 90)/1000:.2f}/{v.max()/1000:.2f}"
+        print(f"   pre-stamp, mean/p90/max ms over agents: finished -> record seen {q(pu[:, 0] - fin)} | -> culled {q(pu[:, 1] - pu[:, 0])} | "
+              f"-> bits {q(pu[:, 2] - pu[:, 1])} | -> marks {q(pu[:, 3] - pu[:, 2])} | whole {q(pu[:, 3] - fin)};  first record seen at "
+              f"{pu[:, 0].min()/1000:.2f} ms, agents finished before that: {int((fin < pu[:, 0].min()).sum())}, last marks {pu[:, 3].max()/1000:.2f}")
         last = np.argsort(-pu[:, 3])[:4]  # the agents whose pre-stamp ended last
         for a in last:
             print(f"   pre-stamp of agent {a}: finished {us[a, 6]/1000:.2f} | record seen {pu[a, 0]/1000:.2f} | culled {pu[a, 1]/1000:.2f} | bits {pu[a, 2]/1000:.2f} | marks {pu[a, 3]/1000:.2f}")
