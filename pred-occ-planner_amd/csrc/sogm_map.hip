@@ -336,19 +336,34 @@ __device__ __forceinline__ void stamp_bits_range(const GridGeom &g, const float 
   const float lox = p0 - g.rx, hix = p0 + g.rx;
   const float loy = p1 - g.ry, hiy = p1 + g.ry;
   const float loz = p2 - g.rz, hiz = p2 + g.rz;
-  for (int i = first; i < end; i += stride) {
-    const float px = cloud[i * 3], py = cloud[i * 3 + 1], pz = cloud[i * 3 + 2];
-    if (!(px >= lox && px <= hix && py >= loy && py <= hiy && pz >= loz && pz <= hiz)) continue;
+  auto point = [&](float px, float py, float pz) __attribute__((always_inline)) {
+    if (!(px >= lox && px <= hix && py >= loy && py <= hiy && pz >= loz && pz <= hiz)) return;
     const float x = px - p0, y = py - p1, z = pz - p2;
-    if (!g.in_range(x, y, z)) continue;
+    if (!g.in_range(x, y, z)) return;
     const int v = g.voxel_of(x, y, z);
     // Reference UB (map.h:169-174): a coordinate one ulp below +range rounds up to range in "x + r" and to the full
     // count in the fp32 division, so the index component equals the axis size; for z (or y on the top layer) the
     // voxel index is >= V and the reference writes outside risk_maps_.  Such marks are dropped, here and in the
     // oracle (x / y overflows inside the array wrap into the next row / layer exactly as the reference's do).
-    if (v >= g.V) continue;
+    if (v >= g.V) return;
     __hip_atomic_fetch_or(mask + (v >> 5), 1u << (v & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  // four points per trip: their twelve loads are in flight together (one point per trip was a dependent HBM / L2 round
+  // trip each, ~2.3 us per point and lane inside the tick; the marks are idempotent ORs, their order is free)
+  int i = first;
+  for (; (long long)i + 3ll * stride < end; i += 4 * stride) {
+    float px[4], py[4], pz[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const size_t q = (size_t)(i + u * stride) * 3;
+      px[u] = cloud[q];
+      py[u] = cloud[q + 1];
+      pz[u] = cloud[q + 2];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) point(px[u], py[u], pz[u]);
   }
+  for (; i < end; i += stride) point(cloud[(size_t)i * 3], cloud[(size_t)i * 3 + 1], cloud[(size_t)i * 3 + 2]);
 }
 __global__ __launch_bounds__(64) void k_stamp_bits(GridGeom g, const float *__restrict__ cloud,
                                                    const int32_t *__restrict__ cloud_range,
@@ -465,13 +480,14 @@ __device__ __forceinline__ void stamp_marks_trips(const GridGeom &g, void *__res
       // candidates, which is what an agent's pre-stamp — and the tick's tail behind the last QP — waited for).
       bool found = !active;
       [[maybe_unused]] const long long ps_w0 = PS_CLK();
-      if (cand_lds != nullptr && n_staged == n_loop) {
-        // Every candidate is in LDS: the ordered walk only has to VISIT the candidates that can contain a voxel of this
-        // chunk.  The chunk's 64 voxels are neighbouring set bits (one obstacle's cross-section, usually): their xy
-        // bounding box is tested against 64 candidates at a time, one per lane (a cylinder whose axis is farther from
-        // the box than its radius + 1 cm cannot pass the test below for any voxel in it; rings are always visited), and
-        // the walk takes the surviving candidates in list order — the first match per voxel is the one the full walk
-        // finds.  ~280 visits per chunk become a handful (25 -> 2 us per chunk with the bench scene).
+      // The ordered walk only has to VISIT the candidates that can contain a voxel of this chunk.  The chunk's 64 voxels
+      // are neighbouring set bits (one obstacle's cross-section, usually): their xy bounding box is tested against 64
+      // candidates at a time, one per lane (a cylinder whose axis is farther from the box than its radius + 1 cm cannot
+      // pass the test below for any voxel in it; rings are always visited), and the walk takes the surviving candidates
+      // in list order — the first match per voxel is the one the full walk finds.  ~280 visits per chunk become a
+      // handful (pre-stamp wave, list in LDS: 25 -> 5 us per chunk with the bench scene).  `cl`: the culled list, in
+      // LDS (pre-stamp waves) or in global memory (k_stamp_marks: one coalesced load per 64 candidates).
+      auto walk_filtered = [&](const auto *cl) __attribute__((always_inline)) {
         float xlo = active ? cx : INFINITY, xhi = active ? cx : -INFINITY;
         float ylo = active ? cy : INFINITY, yhi = active ? cy : -INFINITY;
 #pragma unroll
@@ -485,7 +501,7 @@ __device__ __forceinline__ void stamp_marks_trips(const GridGeom &g, void *__res
         for (int c0 = 0; c0 < n_loop && !done; c0 += 64) {  // uniform
           bool maybe = false;
           if (c0 + lane < n_loop) {
-            const CylCand cc = cand_lds[c0 + lane];
+            const CylCand cc = cl[c0 + lane];
             if (cc.type == 3) {
               const float ex = fmaxf(fmaxf(xlo - cc.x, cc.x - xhi), 0.0F), ey = fmaxf(fmaxf(ylo - cc.y, cc.y - yhi), 0.0F);
               maybe          = (double)sqrtf(ex * ex + ey * ey) <= cc.wlim + 0.01;
@@ -497,7 +513,7 @@ __device__ __forceinline__ void stamp_marks_trips(const GridGeom &g, void *__res
           while (m) {  // uniform
             const int c = c0 + __builtin_ctzll(m);
             m &= m - 1;
-            const CylCand cc = cand_lds[c];
+            const CylCand cc = cl[c];
             if (!found) {
               bool hit = false;
               if (cc.type == 2) {  // ring (:137-149)
@@ -519,6 +535,11 @@ __device__ __forceinline__ void stamp_marks_trips(const GridGeom &g, void *__res
             }
           }
         }
+      };
+      if (cand_lds != nullptr && n_staged == n_loop) {
+        walk_filtered(cand_lds);
+      } else if (culled) {
+        walk_filtered(cand);
       } else {
         for (int c0 = 0; c0 < n_loop; c0 += 4) {  // uniform
           if (__builtin_amdgcn_readfirstlane((int)(__ballot(!found) == 0ull))) break;
