@@ -535,6 +535,11 @@ __device__ __forceinline__ double costMVIE(const MvieData &D, const double *x, d
   L[2][0] = cde[2];
   L[2][1] = cde[1];
   L[2][2] = rtd[2] * rtd[2] + DBL_EPSILON;
+  // log and reciprocal of the three diagonal entries (the barrier term, used at the end): one entry per lane (lanes
+  // 0..2; the others repeat entry 0) instead of three chains one after the other on the single wave of a SIMD, and
+  // issued here, where the face terms' own dependent chains leave issue slots free; same functions, same inputs
+  const double Ld = lane == 1 ? L[1][1] : (lane == 2 ? L[2][2] : L[0][0]);
+  const double lg = sogm_det::log(Ld), rc = 1.0 / Ld;
   double t0[10], t1[10];
   bool   a0 = false, a1 = false;
   if (D.on0) a0 = mvie_face(D.a0, L, p, D.smoothEps, t0);
@@ -574,10 +579,10 @@ __device__ __forceinline__ double costMVIE(const MvieData &D, const double *x, d
     gdrtd[j] *= D.penaltyWt;
     gdcde[j] *= D.penaltyWt;
   }
-  cost -= sogm_det::log(L[0][0]) + sogm_det::log(L[1][1]) + sogm_det::log(L[2][2]);
-  gdrtd[0] -= 1.0 / L[0][0];
-  gdrtd[1] -= 1.0 / L[1][1];
-  gdrtd[2] -= 1.0 / L[2][2];
+  cost -= lane_f64(lg, 0) + lane_f64(lg, 1) + lane_f64(lg, 2);
+  gdrtd[0] -= lane_f64(rc, 0);
+  gdrtd[1] -= lane_f64(rc, 1);
+  gdrtd[2] -= lane_f64(rc, 2);
   gdrtd[0] *= 2.0 * rtd[0];
   gdrtd[1] *= 2.0 * rtd[1];
   gdrtd[2] *= 2.0 * rtd[2];
@@ -760,35 +765,47 @@ __device__ __forceinline__ int lbfgsMVIE(const MvieData &D, double *x, double *l
         bound = m < bound ? m : bound;
         end   = end + 1 == m ? 0 : end + 1;
         int j = end;
+        // The two-loop recursion with d spread over the lanes: lane (row r, i) — i = lane & 15 < 9, every 16-lane DPP row
+        // alike — holds d[i] and reads ITS element of s_j and y_j (two LDS reads per entry instead of eighteen); the nine
+        // products of a dot product are one instruction, the update two, and the sum is taken in dotn9's order,
+        // ((0 + p0) + p1) + ... + p8, by nine dependent v_fmac_f64_dpp with row_newbcast:k (acc += lane k's product x 1.0:
+        // the product by one is exact, so each is the plain addition, rounded once) — every lane ends with the same sum.
+        // 85 -> ~40 instructions per entry for a wave that is alone on its SIMD and issues in order; same operations on
+        // the same values as the replicated form (polytopes stay bit-identical to the oracle's).
+        const int ql  = (lane & 15) < n ? (lane & 15) : 0;
+        double    dl  = d[0];
+#pragma unroll
+        for (int q = 1; q < n; ++q) dl = ql == q ? d[q] : dl;
+        double one = 1.0;
+        asm volatile("" : "+v"(one));
+#define LBFGS_BC(K) "v_fmac_f64_dpp %0, %1, %2 row_newbcast:" #K " row_mask:0xf bank_mask:0xf\n\t"
+        auto ordered_sum = [&](double p) __attribute__((always_inline)) -> double {
+          double acc = 0.0;
+          asm volatile("s_nop 1\n\t"  // (a VGPR written by the VALU needs two wait states before a DPP read)
+                       LBFGS_BC(0) LBFGS_BC(1) LBFGS_BC(2) LBFGS_BC(3) LBFGS_BC(4) LBFGS_BC(5) LBFGS_BC(6) LBFGS_BC(7)
+                       LBFGS_BC(8)
+                       : "+v"(acc)
+                       : "v"(p), "v"(one));
+          return acc;
+        };
+#undef LBFGS_BC
         for (int i = 0; i < bound; ++i) {
           j = j == 0 ? m - 1 : j - 1;
-          double        hs[9], hy[9];
-          const double *ps = lm_s + j * n, *py = lm_y + j * n;
-#pragma unroll
-          for (int q = 0; q < n; ++q) {
-            hs[q] = ps[q];
-            hy[q] = py[q];
-          }
-          const double alpha = dotn9(hs, d) / lane_f64(ys_keep, j);
+          const double hsq = lm_s[j * n + ql], hyq = lm_y[j * n + ql];
+          const double alpha = ordered_sum(hsq * dl) / lane_f64(ys_keep, j);
           if (lane == j) al_keep = alpha;  // lm_alpha[j]
-#pragma unroll
-          for (int q = 0; q < n; ++q) d[q] += (-alpha) * hy[q];
+          dl += (-alpha) * hyq;
         }
-        for (int q = 0; q < n; ++q) d[q] *= ys / yy;
+        dl *= ys / yy;
         for (int i = 0; i < bound; ++i) {
-          double        hs[9], hy[9];
-          const double *ps = lm_s + j * n, *py = lm_y + j * n;
-#pragma unroll
-          for (int q = 0; q < n; ++q) {
-            hs[q] = ps[q];
-            hy[q] = py[q];
-          }
-          const double beta = dotn9(hy, d) / lane_f64(ys_keep, j);
+          const double hsq = lm_s[j * n + ql], hyq = lm_y[j * n + ql];
+          const double beta = ordered_sum(hyq * dl) / lane_f64(ys_keep, j);
           const double al   = lane_f64(al_keep, j);
-#pragma unroll
-          for (int q = 0; q < n; ++q) d[q] += (al - beta) * hs[q];
+          dl += (al - beta) * hsq;
           j = j + 1 == m ? 0 : j + 1;
         }
+#pragma unroll
+        for (int q = 0; q < n; ++q) d[q] = lane_f64(dl, q);
       }
       step = 1.0;
 #ifdef SOGM_PROFILE_MVIE
