@@ -486,7 +486,7 @@ struct MvieData {
 
 #ifdef SOGM_PROFILE_MVIE
 __device__ unsigned long long g_mvie_prof[2];  // profiling build only: ticks (100 MHz) and calls of costMVIE
-__device__ unsigned long long g_lbfgs_prof[4];  // line-search ticks, two-loop ticks, iterations, history entries
+__device__ unsigned long long g_lbfgs_prof[5];  // line-search ticks, direction-update ticks, iterations, history entries, ticks of the two loops alone
 #endif
 __device__ inline double lane_f64(double v, int l) {  // value of lane l (l wave-uniform)
   int lo = __double2loint(v), hi = __double2hiint(v);
@@ -682,7 +682,7 @@ __device__ __forceinline__ int lbfgsMVIE(const MvieData &D, double *x, double *l
   double      *lm_s = lm, *lm_y = lm + m * n;
   double       ys_keep = 0.0, al_keep = 0.0;
 #ifdef SOGM_PROFILE_MVIE
-  long long prof[6] = {0, 0, 0, 0, 0, 0};
+  long long prof[7] = {0, 0, 0, 0, 0, 0, 0};
 #endif
   if (writer)
     for (int i = 0; i < 2 * m * n; ++i) lm[i] = 0;
@@ -761,6 +761,9 @@ __device__ __forceinline__ int lbfgsMVIE(const MvieData &D, double *x, double *l
       // every lane holds the same values: make the bookkeeping provably wave-uniform (scalar branches, and
       // readlane needs a scalar lane index)
       if (__builtin_amdgcn_readfirstlane((int)(ys > cau))) {
+#ifdef SOGM_PROFILE_MVIE
+        const long long tw0 = wall_clock64();
+#endif
         ++bound;
         bound = m < bound ? m : bound;
         end   = end + 1 == m ? 0 : end + 1;
@@ -806,6 +809,9 @@ __device__ __forceinline__ int lbfgsMVIE(const MvieData &D, double *x, double *l
         }
 #pragma unroll
         for (int q = 0; q < n; ++q) d[q] = lane_f64(dl, q);
+#ifdef SOGM_PROFILE_MVIE
+        prof[6] += wall_clock64() - tw0;
+#endif
       }
       step = 1.0;
 #ifdef SOGM_PROFILE_MVIE
@@ -822,6 +828,7 @@ __device__ __forceinline__ int lbfgsMVIE(const MvieData &D, double *x, double *l
     atomicAdd(&g_lbfgs_prof[1], (unsigned long long)prof[3]);
     atomicAdd(&g_lbfgs_prof[2], (unsigned long long)prof[4]);
     atomicAdd(&g_lbfgs_prof[3], (unsigned long long)prof[5]);
+    atomicAdd(&g_lbfgs_prof[4], (unsigned long long)prof[6]);
   }
 #endif
   return ret;
@@ -2338,10 +2345,10 @@ extern "C" int sogm_debug_corridor_occupancy(int pc_capacity) {
 #ifdef SOGM_PROFILE_MVIE
 extern "C" int sogm_debug_mvie_prof(unsigned long long *out2) {
   if (hipMemcpyFromSymbol(out2, HIP_SYMBOL(sogm::g_mvie_prof), 16) != hipSuccess) return -1;
-  if (hipMemcpyFromSymbol(out2 + 2, HIP_SYMBOL(sogm::g_lbfgs_prof), 32) != hipSuccess) return -1;
-  unsigned long long z[4] = {0, 0, 0, 0};
+  if (hipMemcpyFromSymbol(out2 + 2, HIP_SYMBOL(sogm::g_lbfgs_prof), 40) != hipSuccess) return -1;
+  unsigned long long z[5] = {0, 0, 0, 0, 0};
   (void)hipMemcpyToSymbol(HIP_SYMBOL(sogm::g_mvie_prof), z, 16);
-  (void)hipMemcpyToSymbol(HIP_SYMBOL(sogm::g_lbfgs_prof), z, 32);
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(sogm::g_lbfgs_prof), z, 40);
   return 0;
 }
 #endif

@@ -65,11 +65,11 @@ i = np.argmax(d[:, 10])
 print("slowest segment:", d[i])
 
 if hasattr(lib, "sogm_debug_mvie_prof"):
-    pr = np.zeros(6, np.uint64)
+    pr = np.zeros(7, np.uint64)
     lib.sogm_debug_mvie_prof.argtypes = [C.c_void_p]
     lib.sogm_debug_mvie_prof(pr.ctypes.data)
     if pr[1]:
         print(f"costMVIE (line search): {int(pr[1])} calls, mean {pr[0] / pr[1] / 100.0:.2f} us")
         it = max(int(pr[4]), 1)
         print(f"L-BFGS per iteration: line search {pr[2] / it / 100.0:.2f} us, direction update (two-loop) "
-              f"{pr[3] / it / 100.0:.2f} us, mean history {pr[5] / it:.1f}, iterations {it}")
+              f"{pr[3] / it / 100.0:.2f} us (its two loops alone {pr[6] / it / 100.0:.2f}), mean history {pr[5] / it:.1f}, iterations {it}")
