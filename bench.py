@@ -287,7 +287,19 @@ def main():
     sw.map.updateMap(sw.dev["cloud"], sw.dev["cloud_range"], sw.dev["cylinders"], sw.dev["n_cyl"], poses_, stamps)
     stamp_ms = float(sw.map.profile_read()[1])  # the stamp as the tick runs it (with the mark log), machine to itself
     stamp_moved = sw.map.map_traffic(reset=True)
+    reset_alone = None
     if sparse["enabled"]:
+        # the sparse reset with the machine to itself: a second update of the (now log-covered) single grid resets it in
+        # the update's own stream — the kernel's wide variant (4 lanes = 64-byte lines, 8 entries per trip)
+        sw.map.updateMap(sw.dev["cloud"], sw.dev["cloud_range"], sw.dev["cylinders"], sw.dev["n_cyl"], poses_, stamps)
+        r_ms = float(sw.map.profile_read()[0])
+        mv = sw.map.map_traffic(reset=True)
+        if mv["resets"] == 1 and r_ms > 0:
+            b_ = 4.0 * mv["reset_entries"] + mv["reset_bytes_zeroed"]
+            reset_alone = {"where": "machine to itself, in the update's own stream (4 lanes = 64-byte lines, 8 entries per trip), "
+                                    "stage pass after the timed region",
+                           "launch_ms": r_ms, "log_entries": int(mv["reset_entries"]), "bytes_zeroed": int(mv["reset_bytes_zeroed"]),
+                           "bytes_per_launch": b_, "achieved": b_ / (r_ms * 1e-3) / 1e9, "frac": b_ / (r_ms * 1e-3) / 1e9 / 8000.0}
         sw.map.set_sparse_reset(False)  # the stand-alone figure below is the DENSE clear's (first ticks, dense writers)
     standalone_clear_ms = []
     for _ in range(3):  # the full-width clear with the machine to itself (first launch may still see the page-table
@@ -360,7 +372,7 @@ def main():
         k_reset = {"kernel": "k_reset_sectors (sparse reset of the grid the update swapped out; side stream, under the replan's QP stage)",
                    "avg_launch_ms": float(avg[0]), "launches_timed": n_clear, "log_entries_per_launch": entries,
                    "bytes_zeroed_per_launch": zeroed, "bytes_per_launch": reset_bytes, "achieved": achieved, "frac": frac,
-                   "traffic": traffic,
+                   "traffic": traffic, "standalone": reset_alone,
                    "traffic_frac": (traffic / (avg[0] * 1e-3) / 1e9 / PEAK) if traffic else None,
                    "traffic_source": "profiles/r04_pmc_reset.json: rocprofv3 --pmc FETCH_SIZE (doubled, gfx950 streaming-read "
                                      "correction) + WRITE_SIZE per log entry, scaled by this run's entry count" if traffic else None}
