@@ -881,8 +881,21 @@ __device__ __forceinline__ void qp_solve_agent(const SogmPlannerParams &pp, cons
           : "v"(r1), "v"(kinv[24]), "v"(kinv[25]), "v"(kinv[26]), "v"(kinv[27]), "v"(kinv[28]), "v"(kinv[29]));
 #undef QP_BC
       acc += acc1;
-      acc += __shfl_xor(acc, 16, 64);  // the other quarter of this half
-      acc += __shfl_xor(acc, 32, 64);  // the other half
+      // the four quarter sums of a row meet: (q0 + q1) + (q2 + q3) in every lane, by gfx950's row / half swaps (a copy of
+      // the value is swapped against itself: odd rows <-> even rows, then upper <-> lower half; one add each) instead
+      // of two __shfl_xor butterflies through the LDS crossbar (ds_bpermute: ~20 instructions and two LDS round trips on
+      // the iteration's critical path).  Same additions in the same order (tools/micro/permlane_rows.hip).
+      {
+        typedef unsigned u2v __attribute__((ext_vector_type(2)));
+        unsigned lo = (unsigned)__double2loint(acc), hi = (unsigned)__double2hiint(acc);
+        u2v      a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+        u2v      b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+        acc        = __hiloint2double((int)b.x, (int)a.x) + __hiloint2double((int)b.y, (int)a.y);
+        lo = (unsigned)__double2loint(acc), hi = (unsigned)__double2hiint(acc);
+        a   = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+        b   = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+        acc = __hiloint2double((int)b.x, (int)a.x) + __hiloint2double((int)b.y, (int)a.y);
+      }
       const int row = (tl >> 6) * 16 + li;
       if (lq == 0 && row < n) s_cn[row] = acc;
     } else if (wave == 0) {
