@@ -1359,8 +1359,10 @@ __device__ __forceinline__ void qp_solve_agent(const SogmPlannerParams &pp, cons
   // rows also store delta_y (the infeasibility certificate reads it).  The iterations between two checks run in an
   // inner loop of their own whose body is only this lambda, so that nothing of the check / refactorisation code is
   // live in it (register allocation of the hot loop: no SGPR spill traffic).
-  auto iteration = [&](auto store_tag) __attribute__((always_inline)) {
+  auto iteration = [&](auto store_tag, auto ns_tag) __attribute__((always_inline)) {
       constexpr bool STORE = decltype(store_tag)::value;
+      constexpr int  NS    = decltype(ns_tag)::value;  // safety-row slots in use: ceil(S / 256), a compile-time count
+      (void)NS;
       // (a) rhs_j = sigma x_j - q_j + sum_rows A[r][j] (rho_r z_r - y_r)
       if constexpr (FAST) {
         if (!(ablate & 1) && ccol) {
@@ -1431,20 +1433,19 @@ __device__ __forceinline__ void qp_solve_agent(const SogmPlannerParams &pp, cons
               if constexpr (STORE) R.gdy[t] = d;
             }
           } else {  // waves 4-7: up to four safety rows per lane
-            double xs[4][3];
+            // (NS, the number of slots that hold rows, is a template argument of the loop between two checks: with the
+            //  run-time test "256 u < S" per slot the compiler kept a zero fill, a materialised flag and two branches
+            //  per slot in the hot loop)
+            double xs[NS][3];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-              xs[u][0] = xs[u][1] = xs[u][2] = 0.0;
-              if (256 * u < S) {  // workgroup-uniform: slots beyond the last safety row cost nothing
-                xs[u][0] = xtv[s_c(u)];
-                xs[u][1] = xtv[s_c(u) + 1];
-                xs[u][2] = xtv[s_c(u) + 2];
-              }
+            for (int u = 0; u < NS; ++u) {
+              xs[u][0] = xtv[s_c(u)];
+              xs[u][1] = xtv[s_c(u) + 1];
+              xs[u][2] = xtv[s_c(u) + 2];
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-              if (256 * u >= S) continue;
+            for (int u = 0; u < NS; ++u) {
               double ax = sv(u, 0) * xs[u][0];
               ax              = __builtin_fma(sv(u, 1), xs[u][1], ax);
               ax              = __builtin_fma(sv(u, 2), xs[u][2], ax);
@@ -1516,9 +1517,22 @@ __device__ __forceinline__ void qp_solve_agent(const SogmPlannerParams &pp, cons
       int chunk = max_iter - iter;
       if (adapt_iv > 0 && adapt_left < chunk) chunk = adapt_left;
       if (check_iv > 0 && check_left < chunk) chunk = check_left;
+      auto run_chunk = [&](auto ns_tag) __attribute__((always_inline)) {
 #pragma unroll 1
-      for (int k = 1; k < chunk; ++k) iteration(std::false_type{});
-      iteration(std::true_type{});
+        for (int k = 1; k < chunk; ++k) iteration(std::false_type{}, ns_tag);
+        iteration(std::true_type{}, ns_tag);
+      };
+      if constexpr (FAST) {
+        switch (__builtin_amdgcn_readfirstlane((S + 255) >> 8)) {  // (FAST: S <= 1024)
+          case 0:
+          case 1: run_chunk(std::integral_constant<int, 1>{}); break;
+          case 2: run_chunk(std::integral_constant<int, 2>{}); break;
+          case 3: run_chunk(std::integral_constant<int, 3>{}); break;
+          default: run_chunk(std::integral_constant<int, 4>{}); break;
+        }
+      } else {
+        run_chunk(std::integral_constant<int, 4>{});
+      }
       iter += chunk;
       adapt_left -= chunk;
       check_left -= chunk;
