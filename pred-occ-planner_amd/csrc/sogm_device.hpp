@@ -343,7 +343,7 @@ __device__ inline void bezier_pos(const SogmTrajRecord &r, double t, double out[
   X(PRESTAMP_BITS, "prestamp_bits", 32)    /* pre-stamp: one-wave tickets per agent, occupancy bits pass            */  \
   X(PRESTAMP_MARKS, "prestamp_marks", 64)  /* pre-stamp: one-wave tickets per agent, marks pass                     */  \
   X(PRESTAMP_WGS, "prestamp_wgs", 0)       /* pre-stamp: one-wave workgroups; 0 = 8 per CU                          */  \
-  X(PRESTAMP_GATE_FRAC, "prestamp_gate_frac", 1) /* pre-stamp: fraction of the agents whose corridors must be final before it starts */ \
+  X(PRESTAMP_GATE_FRAC, "prestamp_gate_frac", 0.9) /* pre-stamp: fraction of the agents whose corridors must be final before it starts */ \
   X(PRESTAMP_STREAM, "prestamp_stream", 1) /* pre-stamp on a stream of its own behind its target grid's reset EVENT; 0 = on the resets' stream */ \
   X(PRESTAMP_LATE_AGENTS, "prestamp_late_agents", 8)  /* the last agents to be published get finer tickets ...     */  \
   X(PRESTAMP_LATE_BITS, "prestamp_late_bits", 128)    /* ... this many for the bits pass                           */  \
@@ -381,6 +381,8 @@ struct sogm_ctx {
   int            precleared;  // the next update finds a (being-)cleared grid: mode 1 in place, modes 2 / 3 n_ready > 0
   hipStream_t    side;
   hipStream_t    pstream;     // the pre-stamp's stream (tuning key prestamp_stream; the resets stay on `side`)
+  hipEvent_t     ev_gate_frac;  // (the same for prestamp_gate_frac < 1: recorded behind a gate kernel with that share of the agents as its target)
+  int            gate_frac_valid, gate_frac_agents;  // gate_frac_agents: set per replan before queue_spare_clears (0: no such gate)
   hipEvent_t     ev_gate_open;  // recorded on `side` behind the reset's gate kernel of the replan being queued ("every
   int            gate_open_valid;  // agent's corridors are final"): the pre-stamp's stream waits for it instead of spinning
   hipEvent_t     ev_grid_free, ev_cleared;

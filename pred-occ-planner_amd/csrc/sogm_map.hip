@@ -1467,6 +1467,16 @@ int queue_spare_clears(sogm_ctx *c, hipEvent_t after) {
       // reset itself takes 1.3 instead of 2.4 ms.  reset_late = 0: start it with the replan.
       const int late = c->tune_i(SOGM_TUNE_RESET_LATE);
       if (late && c->clear_gate) {
+        if (c->gate_frac_agents > 0 && c->gate_frac_agents < c->clear_gate_target && !c->gate_frac_valid) {
+          // the pre-stamp may start when this share of the agents' corridors is final (tuning key prestamp_gate_frac):
+          // the same gate kernel with a lower target, on THIS stream (which spins for the full gate anyway), and an
+          // event for the pre-stamp's stream — no spinning kernel at the head of a second stream
+          hipLaunchKernelGGL(k_clear_gate, dim3(1), dim3(64), 0, c->side, c->clear_cursor, ~(size_t)0, c->clear_gate,
+                             c->clear_gate_err, c->gate_frac_agents, c->clear_epoch_word, c->clear_epoch);
+          SOGM_HIP_CHECK(hipGetLastError());
+          SOGM_HIP_CHECK(hipEventRecord(c->ev_gate_frac, c->side));
+          c->gate_frac_valid = 1;
+        }
         hipLaunchKernelGGL(k_clear_gate, dim3(1), dim3(64), 0, c->side, c->clear_cursor, ~(size_t)0, c->clear_gate,
                            c->clear_gate_err, c->clear_gate_target, c->clear_epoch_word, c->clear_epoch);
         SOGM_HIP_CHECK(hipGetLastError());
@@ -1654,6 +1664,7 @@ int sogm_create(const SogmSpec *spec, int n_agents, int device, sogm_ctx **out) 
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_grid_free, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_cleared, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_gate_open, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_gate_frac, hipEventDisableTiming);
   // the memsets above are null-stream operations, which the non-blocking streams every later call uses do not wait for
   if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
   if (e != hipSuccess) {
@@ -1707,6 +1718,7 @@ void sogm_destroy(sogm_ctx *c) {
   if (c->ev_grid_free) (void)hipEventDestroy(c->ev_grid_free);
   if (c->ev_cleared) (void)hipEventDestroy(c->ev_cleared);
   if (c->ev_gate_open) (void)hipEventDestroy(c->ev_gate_open);
+  if (c->ev_gate_frac) (void)hipEventDestroy(c->ev_gate_frac);
   if (c->xstream) {
     (void)hipStreamSynchronize(c->xstream);
     (void)hipStreamDestroy(c->xstream);

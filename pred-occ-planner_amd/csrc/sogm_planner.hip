@@ -661,6 +661,11 @@ static int replan_flow(sogm_planner *p, const double *start_pva, const double *g
   // (queued AFTER the searches / corridor / QP launches: its gate waits for the corridor stage, and when streams share a
   //  hardware queue a launch behind a waiting gate waits with it — a QP kernel started 5 ms late costs the tick 5 ms)
   c->gate_open_valid = 0;
+  c->gate_frac_valid = 0;
+  {
+    const double f      = c->tune[SOGM_TUNE_PRESTAMP_GATE_FRAC];
+    c->gate_frac_agents = f > 0.0 && f < 1.0 ? ((int)(f * A + 0.5) < 1 ? 1 : (int)(f * A + 0.5)) : 0;
+  }
   if (c->overlap >= 2) {
     // the side-stream clear of the grid this tick's update swapped out: narrow, with a wide second launch that joins
     // once every agent's corridors are final (FLOW_Q_READY_N == A, registered as the gate at planner creation) —
@@ -717,18 +722,23 @@ static int replan_flow(sogm_planner *p, const double *start_pva, const double *g
     // of the tick, working off a backlog of ~100 published agents on the CUs the QP workgroups leave free, and ending
     // 1-2.5 ms after the last QP in half of the ticks — the tick's end.  It runs on a stream of its own, ordered
     // behind its target's reset (and log restart) by that grid's event and behind "every agent's corridors are final"
-    // by the event recorded after the reset's gate kernel: reset and pre-stamp then run side by side.  No second
-    // spinning gate: with prestamp_gate_frac < 1 (the pre-stamp starts when that fraction of the corridors is final,
-    // ~4 % faster) k_prestamp_gate spins at the head of this stream for milliseconds, which stalled ticks for the 3 s
-    // of the wait limit when hardware queues were shared (two ranks in one process, four queues) or oversubscribed
-    // (a second process holding a context) — measured, hence not the default.  (prestamp_stream = 0: round 3's
-    // placement on the resets' stream.)
+    // by an event recorded after a gate kernel on the resets' stream: reset and pre-stamp then run side by side.  The
+    // pre-stamp's gate is "prestamp_gate_frac of the agents' corridors are final" (default 0.9): waiting for ALL of them
+    // makes 127 agents' stamps wait for one late search — seen as ticks ending 1.5-2.9 ms after their slowest chain — while
+    // the few agents still searching or scanning points pay little for the stores beside them (same box: burst 9.07 ->
+    // 8.81 ms, 300 sustained ticks 10.3 -> 11.3 k replans/s; 0.5 starts too early and loses late in a flight).  The gate
+    // with the lower target is a kernel on the resets' stream — which spins for the full gate anyway — followed by an
+    // event; a first version put a spinning gate at the head of THIS stream, one more spinner for shared or
+    // oversubscribed hardware queues to stall on.  (prestamp_stream = 0: round 3's placement on the resets' stream.)
     const bool  own_stream = c->tune_i(SOGM_TUNE_PRESTAMP_STREAM) != 0 && c->pstream != nullptr;
     hipStream_t pst        = own_stream ? c->pstream : c->side;
     SOGM_HIP_CHECK(hipStreamWaitEvent(pst, p->ev_in, 0));
     if (own_stream) {
       SOGM_HIP_CHECK(hipStreamWaitEvent(pst, c->pool_ev[nxt], 0));
-      if (c->gate_open_valid && d.gate_agents >= A) SOGM_HIP_CHECK(hipStreamWaitEvent(pst, c->ev_gate_open, 0));
+      if (c->gate_frac_valid && d.gate_agents < A)
+        SOGM_HIP_CHECK(hipStreamWaitEvent(pst, c->ev_gate_frac, 0));
+      else if (c->gate_open_valid && d.gate_agents >= A)
+        SOGM_HIP_CHECK(hipStreamWaitEvent(pst, c->ev_gate_open, 0));
     }
     int wg_p = 8 * n_cu;  // one-wave workgroups (512 / 1024 / 2048+: 14.0 / 12.3 / 12.1 ms per tick)
     if (c->tune_i(SOGM_TUNE_PRESTAMP_WGS) > 0) wg_p = c->tune_i(SOGM_TUNE_PRESTAMP_WGS);
