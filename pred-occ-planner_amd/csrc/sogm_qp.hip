@@ -1424,7 +1424,7 @@ __device__ __forceinline__ void qp_solve_agent(const SogmPlannerParams &pp, cons
             for (int k = 1; k < QP_ELL; ++k) s = __builtin_fma(gv(k), xg[k], s);
             const double zr = __builtin_fma(alpha, s, oma * g_z);
             double       v  = __builtin_fma(g_rinv, g_y, zr);  // OSQP update_z: rho_inv_vec[i] * y[i]
-            v               = v < g_lo ? g_lo : (v > g_hi ? g_hi : v);
+            v               = __builtin_fmin(__builtin_fmax(v, g_lo), g_hi);  // (l <= u: the clamp, two instructions)
             g_z             = v;
             const double d  = g_rho * (zr - v);
             g_y             = g_y + d;
@@ -1451,13 +1451,13 @@ __device__ __forceinline__ void qp_solve_agent(const SogmPlannerParams &pp, cons
               ax              = __builtin_fma(sv(u, 2), xs[u][2], ax);
               const double zr = __builtin_fma(alpha, ax, oma * s_zr(u));
               double       v  = __builtin_fma(rinv_cur, s_yr(u), zr);
-              v               = v > s_hi(u) ? s_hi(u) : v;  // l = -OSQP_INFTY
+              v               = __builtin_fmin(v, s_hi(u));  // l = -OSQP_INFTY
               s_zr(u)         = v;
               const double d  = rho_cur * (zr - v);
               const double yn = s_yr(u) + d;
               s_yr(u)         = yn;
               const int sr    = (t - 256) + 256 * u;
-              if (sr < S) {
+              if (u + 1 < NS || sr < S) {  // (only the last slot in use can hold rows beyond S)
                 h_sw[sr] = __builtin_fma(rho_cur, v, -yn);
                 if constexpr (STORE) R.sdy[sr] = d;
               }
