@@ -131,8 +131,8 @@ typedef struct SogmPlannerParams {
   double  corridor_tau;
   double  init_range;
   double  shrink_size;
-  double  opt_max_vel;
-  double  opt_max_acc;
+  double  opt_max_vel; /* finite and positive: the QP's velocity / acceleration rows are two-sided boxes; values */
+  double  opt_max_acc; /* >= 1e20 ("unbounded") are rejected by sogm_planner_create (SOGM_ERR_INVALID_ARG)      */
   int32_t fake_planner; /* 1 = FakeBaselinePlanner rules (baseline_fake.cpp), 0 = BaselinePlanner */
   int32_t firi_iterations; /* 2 at baseline.cpp:352 */
   int32_t pc_capacity;     /* max obstacle points per corridor box */
@@ -167,7 +167,12 @@ typedef struct sogm_ctx sogm_ctx;
 /* ------------------------------------------------------------------------------------------ */
 /* library                                                                                     */
 /* ------------------------------------------------------------------------------------------ */
-/* ABI version of this header; bumps on any signature change. */
+/* ABI version of this header; bumps on any change of a signature OR of the size of a buffer an entry point writes
+ * (version 5: sogm_sparse_reset_state writes out[8] and sogm_profile_read SOGM_PROF_N = 8 doubles, where version 4's
+ * first revision wrote 7; SogmWorld / the world-frame update entries / the flight entries were added).  A host
+ * compares sogm_abi_version() with the SOGM_ABI_VERSION it was compiled against before any other call: the Python
+ * binding and host/sogm_facade.hpp refuse a library of another version. */
+#define SOGM_ABI_VERSION 5
 int         sogm_abi_version(void);
 /* Text of the last HIP error seen by this thread ("" if none). */
 const char *sogm_last_error(void);

@@ -10,6 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # (SOGM_LIB_PATH: another build of the same ABI, for same-box A/B runs of two library versions — tools/micro/ab.sh)
 LIB_PATH = os.environ.get("SOGM_LIB_PATH") or os.path.join(_HERE, "libsogm_hip.so")
 
+SOGM_ABI_VERSION = 5  # include/sogm_abi.h; load_library() refuses a library of another version
 SOGM_MAX_PIECES = 16
 SOGM_MAP_FAKE = 0
 SOGM_MAP_RISKBASE = 1
@@ -215,6 +216,10 @@ def load_library(path=LIB_PATH):
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
+    got = lib.sogm_abi_version()
+    if got != SOGM_ABI_VERSION:  # buffer sizes of existing entry points changed between versions: never mix them
+        raise SogmError(f"{path} implements ABI version {got}, this binding was written against {SOGM_ABI_VERSION}: "
+                        "rebuild the extension (python -c 'import __graft_entry__ as g; g.build()')")
     return lib
 
 

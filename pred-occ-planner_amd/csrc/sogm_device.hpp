@@ -319,37 +319,38 @@ __device__ inline void bezier_pos(const SogmTrajRecord &r, double t, double out[
 }  // namespace sogm
 
 // ---- tuning knobs (sogm_set_tuning / sogm_get_tuning): one table per context, defaults below, no environment ----
+// X(id, key, default, smallest, largest value sogm_set_tuning accepts)
 #define SOGM_TUNING_TABLE(X)                                                                                             \
-  X(GROUPS, "groups", 2)                   /* [planner create] agent groups of the grouped-stream replan            */  \
-  X(SPEC_ASTAR, "spec_astar", 1)           /* [planner create] speculative second search beside the first          */  \
-  X(CLEAR_GATE_FRAC, "clear_gate_frac", 1) /* [planner create] fraction of agents with final corridors that opens the wide clear */ \
-  X(QP_WGS, "qp_wgs", 0)                   /* persistent QP workgroups of the dataflow replan; 0 = half the CUs    */  \
-  X(QP_ABLATE, "qp_ablate", 0)             /* phase ablation mask (only in -DSOGM_QP_ABLATE_BUILD libraries)       */  \
-  X(CLEAR_WGS, "clear_wgs", 0)             /* dense clear: workgroups; 0 = 64 / 80 polite, 2048 alone              */  \
-  X(CLEAR_THROTTLE, "clear_throttle", 0)   /* dense clear: stores in flight per wave when clear_wgs is set         */  \
-  X(CLEAR_NT, "clear_nt", 1)               /* dense clear: non-temporal stores                                      */  \
-  X(CLEAR_WIDE_WGS, "clear_wide_wgs", 256) /* dense clear: workgroups of the gated wide launch; 0 = fixed width    */  \
-  X(CLEAR_WIDE_BOUND, "clear_wide_bound", 0) /* dense clear: stores in flight per wave of the wide launch; 0 = unbounded */ \
-  X(CLEAR_HEAD_GB, "clear_head_gb", 1.0e9) /* dense clear: GB of the narrow head before a full-width rest          */  \
-  X(CLEAR_EARLY, "clear_early", 0)         /* dense clear: queue the swapped-out grid's clear under the stamp      */  \
-  X(CLEAR_RETIRE_AT_END, "clear_retire_at_end", 0) /* dense clear: the wide launch retires when the replan ends    */  \
-  X(RESET_WGS, "reset_wgs", 32)            /* sparse reset: workgroups per agent                                    */  \
-  X(RESET_LANES, "reset_lanes", 0)         /* sparse reset: 2 / 4 lanes per entry; 0 = 2 under the replan, 4 alone  */  \
-  X(RESET_UNROLL, "reset_unroll", 0)       /* sparse reset: 1 / 8 entries per trip; 0 = 1 under the replan, 8 alone */  \
-  X(RESET_LATE, "reset_late", 1)           /* sparse reset: held back until every agent's corridors are final       */  \
-  X(STAMP_WGS, "stamp_wgs", 256)           /* stamp: one-wave workgroups per agent                                  */  \
-  X(SPLAT_WGS, "splat_wgs", 256)           /* overlay launched under a pre-stamp's tail: workgroups                 */  \
-  X(SPLAT_OVERLAP, "splat_overlap", 1)     /* 0: sogm_replan joins the pre-stamp's end itself                       */  \
-  X(PRESTAMP_BITS, "prestamp_bits", 32)    /* pre-stamp: one-wave tickets per agent, occupancy bits pass            */  \
-  X(PRESTAMP_MARKS, "prestamp_marks", 64)  /* pre-stamp: one-wave tickets per agent, marks pass                     */  \
-  X(PRESTAMP_WGS, "prestamp_wgs", 0)       /* pre-stamp: one-wave workgroups; 0 = 8 per CU                          */  \
-  X(PRESTAMP_GATE_FRAC, "prestamp_gate_frac", 0.9) /* pre-stamp: fraction of the agents whose corridors must be final before it starts */ \
-  X(PRESTAMP_STREAM, "prestamp_stream", 1) /* pre-stamp on a stream of its own behind its target grid's reset EVENT; 0 = on the resets' stream */ \
-  X(PRESTAMP_LATE_AGENTS, "prestamp_late_agents", 8)  /* the last agents to be published get finer tickets ...     */  \
-  X(PRESTAMP_LATE_BITS, "prestamp_late_bits", 128)    /* ... this many for the bits pass                           */  \
-  X(PRESTAMP_LATE_MARKS, "prestamp_late_marks", 256)  /* ... and for the marks pass                                */
+  X(GROUPS, "groups", 2, 1, 64)                   /* [planner create] agent groups of the grouped-stream replan            */  \
+  X(SPEC_ASTAR, "spec_astar", 1, 0, 1)           /* [planner create] speculative second search beside the first          */  \
+  X(CLEAR_GATE_FRAC, "clear_gate_frac", 1, 0, 1) /* [planner create] fraction of agents with final corridors that opens the wide clear */ \
+  X(QP_WGS, "qp_wgs", 0, 0, 1024)                   /* persistent QP workgroups of the dataflow replan; 0 = half the CUs    */  \
+  X(QP_ABLATE, "qp_ablate", 0, 0, 255)             /* phase ablation mask (only in -DSOGM_QP_ABLATE_BUILD libraries)       */  \
+  X(CLEAR_WGS, "clear_wgs", 0, 0, 65536)             /* dense clear: workgroups; 0 = 64 / 80 polite, 2048 alone              */  \
+  X(CLEAR_THROTTLE, "clear_throttle", 0, 0, 64)   /* dense clear: stores in flight per wave when clear_wgs is set         */  \
+  X(CLEAR_NT, "clear_nt", 1, 0, 1)               /* dense clear: non-temporal stores                                      */  \
+  X(CLEAR_WIDE_WGS, "clear_wide_wgs", 256, 0, 65536) /* dense clear: workgroups of the gated wide launch; 0 = fixed width    */  \
+  X(CLEAR_WIDE_BOUND, "clear_wide_bound", 0, 0, 64) /* dense clear: stores in flight per wave of the wide launch; 0 = unbounded */ \
+  X(CLEAR_HEAD_GB, "clear_head_gb", 1.0e9, 0, 1.0e12) /* dense clear: GB of the narrow head before a full-width rest          */  \
+  X(CLEAR_EARLY, "clear_early", 0, 0, 1)         /* dense clear: queue the swapped-out grid's clear under the stamp      */  \
+  X(CLEAR_RETIRE_AT_END, "clear_retire_at_end", 0, 0, 1) /* dense clear: the wide launch retires when the replan ends    */  \
+  X(RESET_WGS, "reset_wgs", 32, 0, 4096)            /* sparse reset: workgroups per agent                                    */  \
+  X(RESET_LANES, "reset_lanes", 0, 0, 4)         /* sparse reset: 2 / 4 lanes per entry; 0 = 2 under the replan, 4 alone  */  \
+  X(RESET_UNROLL, "reset_unroll", 0, 0, 8)       /* sparse reset: 1 / 8 entries per trip; 0 = 1 under the replan, 8 alone */  \
+  X(RESET_LATE, "reset_late", 1, 0, 1)           /* sparse reset: held back until every agent's corridors are final       */  \
+  X(STAMP_WGS, "stamp_wgs", 256, 0, 4096)           /* stamp: one-wave workgroups per agent                                  */  \
+  X(SPLAT_WGS, "splat_wgs", 256, 0, 65536)           /* overlay launched under a pre-stamp's tail: workgroups                 */  \
+  X(SPLAT_OVERLAP, "splat_overlap", 1, 0, 1)     /* 0: sogm_replan joins the pre-stamp's end itself                       */  \
+  X(PRESTAMP_BITS, "prestamp_bits", 32, 0, 1024)    /* pre-stamp: one-wave tickets per agent, occupancy bits pass            */  \
+  X(PRESTAMP_MARKS, "prestamp_marks", 64, 0, 1024)  /* pre-stamp: one-wave tickets per agent, marks pass                     */  \
+  X(PRESTAMP_WGS, "prestamp_wgs", 0, 0, 65536)       /* pre-stamp: one-wave workgroups; 0 = 8 per CU                          */  \
+  X(PRESTAMP_GATE_FRAC, "prestamp_gate_frac", 0.9, 0, 1) /* pre-stamp: fraction of the agents whose corridors must be final before it starts */ \
+  X(PRESTAMP_STREAM, "prestamp_stream", 1, 0, 1) /* pre-stamp on a stream of its own behind its target grid's reset EVENT; 0 = on the resets' stream */ \
+  X(PRESTAMP_LATE_AGENTS, "prestamp_late_agents", 8, 0, 65536)  /* the last agents to be published get finer tickets ...     */  \
+  X(PRESTAMP_LATE_BITS, "prestamp_late_bits", 128, 0, 4096)    /* ... this many for the bits pass                           */  \
+  X(PRESTAMP_LATE_MARKS, "prestamp_late_marks", 256, 0, 4096)  /* ... and for the marks pass                                */
 enum {
-#define X(id, name, dflt) SOGM_TUNE_##id,
+#define X(id, name, dflt, lo, hi) SOGM_TUNE_##id,
   SOGM_TUNING_TABLE(X)
 #undef X
   SOGM_TUNE_N

@@ -1599,7 +1599,7 @@ using namespace sogm;
 // ================================================================================================
 extern "C" {
 
-int sogm_abi_version(void) { return 4; }
+int sogm_abi_version(void) { return SOGM_ABI_VERSION; }
 const char *sogm_last_error(void) { return sogm::g_err; }
 
 int sogm_device_count(void) {
@@ -1637,7 +1637,7 @@ int sogm_create(const SogmSpec *spec, int n_agents, int device, sogm_ctx **out) 
   c->device        = device;
   c->prestamp_slot = -1;
   {
-#define X(id, name, dflt) c->tune[SOGM_TUNE_##id] = (double)(dflt);
+#define X(id, name, dflt, lo, hi) c->tune[SOGM_TUNE_##id] = (double)(dflt);
     SOGM_TUNING_TABLE(X)
 #undef X
     const char *e = getenv("SOGM_SPARSE_RESET");  // (one of the library's three environment switches)
@@ -1797,7 +1797,12 @@ int sogm_sparse_reset_state(sogm_ctx *c, int32_t *out) {
 }
 
 static const char *const k_tune_names[SOGM_TUNE_N] = {
-#define X(id, name, dflt) name,
+#define X(id, name, dflt, lo, hi) name,
+    SOGM_TUNING_TABLE(X)
+#undef X
+};
+static const double k_tune_range[SOGM_TUNE_N][2] = {
+#define X(id, name, dflt, lo, hi) {(double)(lo), (double)(hi)},
     SOGM_TUNING_TABLE(X)
 #undef X
 };
@@ -1809,12 +1814,20 @@ static int tune_index(const char *key) {
 }
 int sogm_set_tuning(sogm_ctx *c, const char *key, double value) {
   const int i = tune_index(key);
-  if (!c || i < 0 || !(value == value)) {
-    if (c && i < 0) {
-      char buf[160];
-      std::snprintf(buf, sizeof(buf), "sogm_set_tuning: unknown key '%s'", key ? key : "(null)");
-      sogm::set_error_text(buf);
-    }
+  if (!c) return SOGM_ERR_INVALID_ARG;
+  if (i < 0) {
+    char buf[160];
+    std::snprintf(buf, sizeof(buf), "sogm_set_tuning: unknown key '%s'", key ? key : "(null)");
+    sogm::set_error_text(buf);
+    return SOGM_ERR_INVALID_ARG;
+  }
+  // the values end up as launch dimensions and ticket counts: NaN, infinities and anything outside the key's range
+  // (SOGM_TUNING_TABLE) are refused here rather than cast to int later
+  if (!(value >= k_tune_range[i][0] && value <= k_tune_range[i][1])) {
+    char buf[200];
+    std::snprintf(buf, sizeof(buf), "sogm_set_tuning: '%s' = %g is outside [%g, %g]", key, value, k_tune_range[i][0],
+                  k_tune_range[i][1]);
+    sogm::set_error_text(buf);
     return SOGM_ERR_INVALID_ARG;
   }
   c->tune[i] = value;

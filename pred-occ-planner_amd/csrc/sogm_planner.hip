@@ -119,6 +119,12 @@ int sogm_planner_create(sogm_ctx *map, const SogmAstarParams *astar, const SogmP
   // differ in the shot check only (risk_hybrid_a_star.cpp:514 vs fake_risk_hybrid_a_star.cpp:521)
   p->ap.shot_ignores_time = pp->fake_planner ? 0 : 1;
   p->qs  = *qp;
+  // The QP's register-resident path assumes every velocity / acceleration row is two-sided (rho = rho_cur or 1000 rho_cur):
+  // "unbounded" limits (OSQP_INFTY-like values) would give those rows RHO_MIN and a K that does not match
+  if (!(pp->opt_max_vel > 0 && pp->opt_max_vel < 1e20) || !(pp->opt_max_acc > 0 && pp->opt_max_acc < 1e20)) {
+    delete p;
+    return SOGM_ERR_INVALID_ARG;
+  }
   if (astar->allocate_num < 2 || astar->allocate_num > astar_pool_max() || astar->check_num < 1 || !(astar->resolution > 0) ||
       !(astar->time_resolution > 0)) {
     delete p;
@@ -288,6 +294,7 @@ void sogm_planner_destroy(sogm_planner *p) {
     }
     if (p->ev_fdone[k]) (void)hipEventDestroy(p->ev_fdone[k]);
   }
+  if (p->peek) (void)hipStreamDestroy(p->peek);
   if (p->ev_gate) (void)hipEventDestroy(p->ev_gate);
   if (p->ev_pdone) (void)hipEventDestroy(p->ev_pdone);
   if (p->h_flow_fail) (void)hipHostFree(p->h_flow_fail);
@@ -406,7 +413,7 @@ int sogm_bezier_qp_solve_timed(sogm_planner *p, const double *start_pva, const d
                                const int32_t *nfaces, const int32_t *npoly, double *out_cpts, int32_t *out_status,
                                int32_t *out_iters, void *stream) {
   if (!p || !start_pva || !end_pva || !time_alloc || !polys || !nfaces || !npoly || !out_cpts || !out_status ||
-      !out_iters || !(max_vel > 0) || !(max_acc > 0))
+      !out_iters || !(max_vel > 0 && max_vel < 1e20) || !(max_acc > 0 && max_acc < 1e20))
     return SOGM_ERR_INVALID_ARG;
   SOGM_HIP_CHECK(hipSetDevice(p->map->device));
   hipStream_t       st = (hipStream_t)stream;
@@ -456,8 +463,8 @@ int sogm_planner_set_search_mode(sogm_planner *p, int mode) {
 // diagnostics (tools/ only): the dataflow control block, copied on a private stream while the tick's kernels run
 int sogm_debug_flow_peek(sogm_planner *p, int *out_host, int n) {
   if (!p || !out_host || n < 0) return SOGM_ERR_INVALID_ARG;
-  static hipStream_t peek = nullptr;
-  if (!peek) SOGM_HIP_CHECK(hipStreamCreateWithFlags(&peek, hipStreamNonBlocking));
+  if (!p->peek) SOGM_HIP_CHECK(hipStreamCreateWithFlags(&p->peek, hipStreamNonBlocking));
+  hipStream_t peek = p->peek;
   const int nf = FLOW_HDR + 6 * p->map->n_agents;
   SOGM_HIP_CHECK(hipMemcpyAsync(out_host, p->d_flow, sizeof(int) * (size_t)(n < nf ? n : nf), hipMemcpyDeviceToHost, peek));
   if (n > nf)  // followed by d_safe (progress markers in debug builds)
@@ -892,9 +899,13 @@ int sogm_replan(sogm_planner *p, const double *start_pva, const double *goal,
   sogm_ctx *c = p->map;
   // publication (sogm_planner_set_publish): the finishing kernel writes every agent's record into next_table while
   // other agents' deconfliction still reads the swarm table, and into own_records while out_records is written
-  if (p->pub_table && p->swarm && (const void *)p->pub_table == (const void *)p->swarm) {
-    sogm::set_error_text("sogm_replan: sogm_planner_set_publish's next_table is the table given to sogm_planner_set_swarm");
-    return SOGM_ERR_INVALID_ARG;
+  if (p->pub_table && p->swarm) {  // byte ranges, not pointers: a rank's slice INSIDE the all-records buffer overlaps too
+    const char *a0 = (const char *)p->pub_table, *a1 = a0 + sizeof(SogmTrajRecord) * (size_t)c->n_agents;
+    const char *b0 = (const char *)p->swarm, *b1 = b0 + sizeof(SogmTrajRecord) * (size_t)p->n_swarm;
+    if (a0 < b1 && b0 < a1) {
+      sogm::set_error_text("sogm_replan: sogm_planner_set_publish's next_table overlaps the table given to sogm_planner_set_swarm");
+      return SOGM_ERR_INVALID_ARG;
+    }
   }
   if (p->pub_own) {
     const char *a0 = (const char *)p->pub_own, *a1 = a0 + sizeof(SogmTrajRecord) * (size_t)c->n_agents;

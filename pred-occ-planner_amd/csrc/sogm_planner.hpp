@@ -238,4 +238,5 @@ struct sogm_planner {
   int sel_first, sel_count;  // agents the per-stage entries process; (0, A) by default
   int search_mode;           // 0 the replan's two-call pattern, 1 / 2 one search with init_search true / false
   int spec_astar;            // dataflow replan: run the second search attempt speculatively beside the first
+  hipStream_t peek;          // sogm_debug_flow_peek's private stream (created on first use)
 };

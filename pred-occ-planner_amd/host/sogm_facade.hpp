@@ -34,6 +34,15 @@ inline void check(int rc, const char *what) {
     throw std::runtime_error(std::string(what) + " failed: " + std::to_string(rc) + " " + sogm_last_error());
 }
 
+// The library must implement the header this host was compiled against: buffer sizes of existing entry points have
+// changed between versions (sogm_abi.h, SOGM_ABI_VERSION).  Every facade object checks once at construction.
+inline void check_abi() {
+  static const int got = sogm_abi_version();
+  if (got != SOGM_ABI_VERSION)
+    throw std::runtime_error("libsogm_hip.so implements ABI version " + std::to_string(got) + ", this host was built against " +
+                             std::to_string(SOGM_ABI_VERSION));
+}
+
 template <typename T>
 class DevBuf {  // tiny RAII device buffer
  public:
@@ -122,6 +131,7 @@ inline std::vector<float> futureRiskMsg(const std::vector<float> &grid_vt, const
 class RiskMap {
  public:
   RiskMap(const SogmSpec &spec, int n_agents, int device = 0) : n_(n_agents), spec_(spec) {
+    check_abi();
     check(sogm_create(&spec, n_agents, device, &ctx_), "sogm_create");
   }
   ~RiskMap() { sogm_destroy(ctx_); }
@@ -271,6 +281,7 @@ class DspMap {
 class GridMap {
  public:
   GridMap(const SogmGridMapParams &p, int n_agents, int device = 0) {  // GridMap::initMap
+    check_abi();
     check(sogm_gridmap_create(&p, n_agents, device, &h_), "sogm_gridmap_create");
   }
   ~GridMap() { sogm_gridmap_destroy(h_); }

@@ -51,7 +51,11 @@ class SogmMap:
         # HERE, by the binding, through sogm_set_tuning (the library itself reads no tuning from the environment)
         for kv in filter(None, os.environ.get("SOGM_TUNING", "").split(",")):
             k, _, v = kv.partition("=")
-            self.set_tuning(k.strip(), float(v))
+            try:
+                val = float(v)
+            except ValueError:
+                raise ValueError(f"SOGM_TUNING: item {kv!r} is not key=number") from None
+            self.set_tuning(k.strip(), val)
 
     # ---- tuning knobs (sogm_abi.h: sogm_set_tuning) ----
     def set_tuning(self, key, value):

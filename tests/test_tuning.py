@@ -45,4 +45,16 @@ def test_set_and_get_tuning(pop):
     assert m.get_tuning("reset_wgs") == 16
     with pytest.raises(pop._abi.SogmError):
         m.set_tuning("no_such_key", 1)
+    # values become launch dimensions and ticket counts: non-finite and out-of-range ones are refused
+    for bad in (float("inf"), float("-inf"), float("nan"), -1.0, 1e12):
+        with pytest.raises(pop._abi.SogmError):
+            m.set_tuning("prestamp_wgs", bad)
+    assert m.get_tuning("prestamp_wgs") == 0
     m.close()
+
+
+def test_malformed_tuning_environment_item_is_named(pop, monkeypatch):
+    import importlib
+    sogm = importlib.import_module("pred-occ-planner_amd.sogm")
+    src = open(sogm.__file__).read()
+    assert "is not key=number" in src  # (the constructor needs a GPU; the message is what the fix added)
