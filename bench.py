@@ -216,10 +216,21 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
     A_loc = args.agents if args.agents is not None else pop.config.AGENTS[args.grid]
+    # The world moves: every tick's update takes that tick's sensor frame (scene.WorldTimeline: cylinders advanced by v dt,
+    # their cloud points with them) and crops it on the device around the agent's current map centre.  All frames of the
+    # run are generated on the host and uploaded BEFORE the first timed tick (inputs resident in HBM, as the contract
+    # says; 7.5 MB per frame at 128 agents) — SOGM_WORLD=static flies the frozen world of the earlier rounds.
+    moving = os.environ.get("SOGM_WORLD", "moving") != "static"
     sw = driver.SwarmTick(args.grid, A_loc, rank, world, local, dist=dist, deconflict=not args.no_deconflict,
                           double_buffer={"0": False, "1": True}.get(os.environ.get("SOGM_DOUBLE_BUFFER")),
-                          grids=int(os.environ["SOGM_GRIDS"]) if os.environ.get("SOGM_GRIDS") else None)
+                          grids=int(os.environ["SOGM_GRIDS"]) if os.environ.get("SOGM_GRIDS") else None,
+                          moving_world=moving)
     spec = sw.spec
+    n_frames = args.warmup + args.steps + (3 + args.dense_ticks if args.dense_ticks > 0 else 0) + \
+        (3 + args.sustained if args.sustained > 0 else 0) + 8
+    t_up = time.perf_counter()
+    sw.compute.prepare(0, n_frames)
+    world_upload_s = time.perf_counter() - t_up
 
     def barrier():
         torch.cuda.synchronize()
@@ -284,14 +295,15 @@ def main():
     pva, valid = planner.traj_eval(sw.own, t_start)
     pva = torch.where(valid.bool().unsqueeze(1), pva, sw.hover).contiguous()
     poses_ = pva[:, :3].to(torch.float32).contiguous()
-    sw.map.updateMap(sw.dev["cloud"], sw.dev["cloud_range"], sw.dev["cylinders"], sw.dev["n_cyl"], poses_, stamps)
+    frame = sw.compute.world(sw.tick)
+    sw.map.updateWorld(frame, poses_, stamps)
     stamp_ms = float(sw.map.profile_read()[1])  # the stamp as the tick runs it (with the mark log), machine to itself
     stamp_moved = sw.map.map_traffic(reset=True)
     reset_alone = None
     if sparse["enabled"]:
         # the sparse reset with the machine to itself: a second update of the (now log-covered) single grid resets it in
         # the update's own stream — the kernel's wide variant (4 lanes = 64-byte lines, 8 entries per trip)
-        sw.map.updateMap(sw.dev["cloud"], sw.dev["cloud_range"], sw.dev["cylinders"], sw.dev["n_cyl"], poses_, stamps)
+        sw.map.updateWorld(frame, poses_, stamps)
         r_ms = float(sw.map.profile_read()[0])
         mv = sw.map.map_traffic(reset=True)
         if mv["resets"] == 1 and r_ms > 0:
@@ -303,7 +315,7 @@ def main():
         sw.map.set_sparse_reset(False)  # the stand-alone figure below is the DENSE clear's (first ticks, dense writers)
     standalone_clear_ms = []
     for _ in range(3):  # the full-width clear with the machine to itself (first launch may still see the page-table
-        sw.map.updateMap(sw.dev["cloud"], sw.dev["cloud_range"], sw.dev["cylinders"], sw.dev["n_cyl"], poses_, stamps)
+        sw.map.updateWorld(frame, poses_, stamps)
         standalone_clear_ms.append(float(sw.map.profile_read()[0]))  # work of releasing the second grid)
     sw.map.addOtherAgents(sw.all, sw.A_tot, sw.dev["ego_ids"])
     s_ = sw.planner.search(pva, sw.goals, t_start)
@@ -426,7 +438,14 @@ def main():
         "config": {"workload": f"{sw.A_loc} agents/GPU x {world} GPU, {spec.L}x{spec.W}x{spec.H}x{spec.T} SOGM, "
                                f"sim_fkpcp-style moving cylinders, batched ADMM QP (BASELINE {'configs[4]' if args.grid == 'cfg4' else 'configs[2]'} per GPU)",
                    "agents_total": sw.A_tot, "grid": [spec.L, spec.W, spec.H, spec.T],
-                   "cloud_points": int(sw.scene["cloud"].shape[0]), "cloud_points_scanned": sw.cloud_points, "cylinders": int(len(sw.scene["cylinders"])),
+                   "cloud_points": int(sw.scene["cloud"].shape[0]), "cylinders": int(len(sw.scene["cylinders"])),
+                   "world": ("moving: per-tick sensor frames (cylinders advance by v*dt, up to 1 m/s, their cloud points with "
+                             "them), cropped on the device around each agent's current map centre through 256-point blocks; "
+                             f"{n_frames} frames uploaded before the first tick in {world_upload_s:.1f} s") if moving
+                            else "static (SOGM_WORLD=static): one frame for every tick",
+                   # ticks between the sensor frame a tick's map is built from and the tick itself: 0 = the reference's
+                   # updateMap-from-the-latest-cloud; 1 = built by the previous replan's pre-stamp from ITS tick's frame
+                   "map_input_staleness_ticks": sw.map_input_staleness_ticks,
                    "replans_ok_fraction": n_ok / float(sw.A_tot * args.steps),
                    # where the timed replans ended + capacity limits hit (sogm_planner_counters)
                    "outcomes": outcomes,

@@ -314,6 +314,34 @@ int sogm_update_gt(sogm_ctx *ctx, const float *cloud_xyz, const int32_t *cloud_r
                    const double *stamps, void *stream);
 
 /*
+ * One sensor frame of the fake-perception map — what MapBase::cloudCallback (plan_env/src/map.cpp:170-171) and
+ * FakeParticleRiskVoxel::groundTruthStateCallback (fake_particle_risk_voxel.cpp:244-264) delivered for ONE update —
+ * with the spatial index the device-side crop needs: the cloud in blocks of `block_points` consecutive points and the
+ * xy bounds of every block (sogm_cloud_block_bounds computes them; a sensor driver that emits obstacles one after the
+ * other gets tight blocks for free).  updateMap's PassThrough crop (fake_particle_risk_voxel.cpp:88-104) then runs on the
+ * device, per agent, around the agent's CURRENT map centre: one wave lists the blocks that intersect the window, the
+ * stamp walks the list.  All pointers are device pointers; the struct itself is read on the host at call time.
+ */
+typedef struct SogmWorld {
+  const float        *cloud_xyz;    /* dev [n_points*3] fp32, world frame                                         */
+  const float        *block_bounds; /* dev [n_blocks*4] {xmin, xmax, ymin, ymax} of points [b*block_points, ...)  */
+  const SogmCylinder *cylinders;    /* dev [n_cyl] GT obstacle states of the same instant (NULL if n_cyl == 0)     */
+  int32_t             n_points;
+  int32_t             n_blocks;     /* ceil(n_points / block_points)                                              */
+  int32_t             block_points; /* 64 .. 4096                                                                 */
+  int32_t             n_cyl;
+} SogmWorld;
+/* xy bounds of every block of `block_points` consecutive points of a cloud; dev out_bounds[ceil(n/block_points)*4]. */
+int sogm_cloud_block_bounds(const float *cloud_xyz, int n_points, int block_points, float *out_bounds, void *stream);
+/*
+ * FakeParticleRiskVoxel::updateMap for every agent of the batch from one SogmWorld frame: as sogm_update_gt_swarm, with
+ * the crop done on the device around `poses` (no per-agent ranges from the host).  records may be NULL (n_records 0):
+ * no overlay.  The maps are identical to sogm_update_gt[_swarm] fed with any superset of each agent's window.
+ */
+int sogm_update_world(sogm_ctx *ctx, const SogmWorld *world, const float *poses, const double *stamps,
+                      const SogmTrajRecord *records, int n_records, const int32_t *ego_ids, void *stream);
+
+/*
  * Neighbour overlay: RiskBase::addOtherAgents (risk_base.cpp:136-168) ==
  * fake_particle_risk_voxel.cpp:178-218, through ParticleATC::getParticlesWithRisk
  * (particles.cpp:346-422, replan_risk_rate == 0 branch) and addParticlesToRiskMap
@@ -770,6 +798,14 @@ typedef struct SogmPrestamp {
   double             *out_t_start;
   double             *out_pva;
   float              *out_poses;            /* the next map centres, [A][3] (may be NULL: the context keeps its own) */
+  const SogmWorld    *world;                /* host pointer or NULL.  Non-NULL: the stamp's inputs are this frame, cropped on the
+                                               device around each agent's NEXT map centre, and cloud_xyz / cloud_range /
+                                               cylinders above are ignored (may be NULL).  CAUSALITY: a pre-stamp runs inside
+                                               tick k, so the newest frame a live host can hand it is tick k's — the map tick
+                                               k + 1 plans on is then one tick staler than the reference's, which updates from
+                                               the cloud that arrived for that update (map.cpp:170-171).  bench.py reports this
+                                               as config.map_input_staleness_ticks = 1 and keeps the 0-staleness tick
+                                               (sogm_update_world at the start of the tick) as the headline. */
 } SogmPrestamp;
 int sogm_planner_set_prestamp(sogm_planner *p, const SogmPrestamp *ps);
 /* 1 if the last sogm_replan pre-stamped the next grid (no synchronisation: host-side state). */

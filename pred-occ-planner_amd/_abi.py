@@ -99,11 +99,17 @@ class SogmQpSettings(C.Structure):
                 ("adaptive_rho_interval", C.c_int32), ("residual_fp32", C.c_int32), ("reserved_", C.c_int32)]
 
 
+class SogmWorld(C.Structure):
+    _fields_ = [("cloud_xyz", C.c_void_p), ("block_bounds", C.c_void_p), ("cylinders", C.c_void_p),
+                ("n_points", C.c_int32), ("n_blocks", C.c_int32), ("block_points", C.c_int32), ("n_cyl", C.c_int32)]
+
+
 class SogmPrestamp(C.Structure):
     _fields_ = [("cloud_xyz", C.c_void_p), ("cloud_range", C.c_void_p), ("cylinders", C.c_void_p),
                 ("n_cyl", C.c_int32), ("reserved_", C.c_int32), ("next_stamp", C.c_double),
                 ("replan_start_offset", C.c_double), ("hover_inout", C.c_void_p), ("out_now", C.c_void_p),
-                ("out_t_start", C.c_void_p), ("out_pva", C.c_void_p), ("out_poses", C.c_void_p)]
+                ("out_t_start", C.c_void_p), ("out_pva", C.c_void_p), ("out_poses", C.c_void_p),
+                ("world", C.POINTER(SogmWorld))]
 
 
 TRAJ_RECORD_BYTES = C.sizeof(SogmTrajRecord)  # 2064
@@ -138,6 +144,8 @@ PROTOTYPES = {
     "sogm_update_gt": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
     "sogm_project_neighbours": (_i, [_vp, _vp, _i, _vp, _vp]),
     "sogm_update_gt_swarm": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp]),
+    "sogm_cloud_block_bounds": (_i, [_vp, _i, _i, _vp, _vp]),
+    "sogm_update_world": (_i, [_vp, C.POINTER(SogmWorld), _vp, _vp, _vp, _i, _vp, _vp]),
     "sogm_set_future_risk": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "sogm_download_reference_layout": (_i, [_vp, _i, _vp]),
     "sogm_tick_inputs": (_i, [_vp, _i, C.c_double, C.c_double, _vp, _vp, _vp, _vp, _vp, _vp]),

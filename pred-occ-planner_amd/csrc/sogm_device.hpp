@@ -437,6 +437,9 @@ struct sogm_ctx {
   int            cur_prestamped;
   void          *d_cand;           // [A][1024] candidate cylinders of the stamp (k_cull_cylinders)
   int           *d_ncand;          // [A]
+  int           *d_blk_list;       // [A][blk_cap] block ids of each agent's crop of a SogmWorld cloud (lazy)
+  int           *d_blk_n;          // [A]
+  int            blk_cap;
   // trajectory exchange (sogm_traj_allgather): its own stream, ordered against producers / consumers by events
   hipStream_t    xstream;
   hipEvent_t     ev_xin, ev_xdone;
@@ -534,6 +537,15 @@ int  retire_wide_clear(sogm_ctx *c, hipStream_t st);
 int  announce_clear_epoch(sogm_ctx *c, hipStream_t st);
 int  next_clear_epoch(sogm_ctx *c);  // the epoch a replan writes itself (k_flow_reset) instead of a launch of its own
 int  queue_spare_clears(sogm_ctx *c, hipEvent_t after);
+// device view of a SogmWorld cloud (blocks of consecutive points with xy bounds) + the per-agent crop lists the stamp builds
+struct CloudBlocks {
+  const float *bounds;  // [n_blocks][4] {xmin, xmax, ymin, ymax}; null = the caller's per-agent {begin, end} ranges are used
+  int          n_blocks, block_points, n_points;
+  int         *list;    // [A][n_blocks] ids of the blocks that intersect the agent's window, ascending
+  int         *n_list;  // [A]
+};
+// the context's crop lists sized for `w` (grown on demand; stream-ordered)
+int world_blocks(sogm_ctx *c, const SogmWorld *w, CloudBlocks *out);
 // sparse reset (sogm_map.hip): the mark log of a pool slot as the writers see it (null entries = not logging)
 struct MarkLog {
   unsigned *entries;  // [A][cap]

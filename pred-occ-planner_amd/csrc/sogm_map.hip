@@ -304,15 +304,19 @@ __device__ __forceinline__ void cull_agent(const GridGeom &g, const SogmCylinder
   }
   if (lane == 0) *n_out = kept;  // > SOGM_MAX_CYL_LDS: the stamp falls back to the full list
 }
+__device__ __forceinline__ void cull_blocks_agent(const GridGeom &g, const CloudBlocks &cb, int agent, float q0, float q1,
+                                                  int lane);
 __global__ __launch_bounds__(64) void k_cull_cylinders(GridGeom g, const SogmCylinder *__restrict__ cyl, int n_cyl,
                                                        const float *__restrict__ poses, CylCand *__restrict__ cand,
                                                        int *__restrict__ n_cand, const double *__restrict__ stamps_in,
-                                                       float *__restrict__ poses_out, double *__restrict__ stamps_out) {
+                                                       float *__restrict__ poses_out, double *__restrict__ stamps_out,
+                                                       CloudBlocks cb) {
   const int    agent = blockIdx.x, lane = threadIdx.x;
   const float  q0 = poses[agent * 3], q1 = poses[agent * 3 + 1];
   if (lane < 3) poses_out[agent * 3 + lane] = poses[agent * 3 + lane];
   if (lane == 3) stamps_out[agent] = stamps_in[agent];
   cull_agent(g, cyl, n_cyl, q0, q1, cand + (size_t)agent * SOGM_MAX_CYL_LDS, n_cand + agent, lane);
+  if (cb.bounds) cull_blocks_agent(g, cb, agent, q0, q1, lane);  // the agent's crop of a SogmWorld cloud
 }
 
 // The stamp in two passes (one-wave workgroups, no LDS; the candidates come from k_cull_cylinders through L1 / the
@@ -329,25 +333,29 @@ __global__ __launch_bounds__(64) void k_cull_cylinders(GridGeom g, const SogmCyl
 //                  zeroed for the next update.
 // The set of marked cells is the one the per-point form produced (marks are idempotent, the lookup depends on the
 // voxel only).
+// one cloud point of the bits pass: PassThrough limits (fake_particle_risk_voxel.cpp:88-104, fp32), voxel index, one OR
+struct CropBox {
+  float lox, hix, loy, hiy, loz, hiz, p0, p1, p2;
+  __device__ __forceinline__ CropBox(const GridGeom &g, float q0, float q1, float q2)
+      : lox(q0 - g.rx), hix(q0 + g.rx), loy(q1 - g.ry), hiy(q1 + g.ry), loz(q2 - g.rz), hiz(q2 + g.rz), p0(q0), p1(q1), p2(q2) {}
+};
+__device__ __forceinline__ void stamp_bits_point(const GridGeom &g, const CropBox &b, float px, float py, float pz,
+                                                 unsigned *__restrict__ mask) {
+  if (!(px >= b.lox && px <= b.hix && py >= b.loy && py <= b.hiy && pz >= b.loz && pz <= b.hiz)) return;
+  const float x = px - b.p0, y = py - b.p1, z = pz - b.p2;
+  if (!g.in_range(x, y, z)) return;
+  const int v = g.voxel_of(x, y, z);
+  // Reference UB (map.h:169-174): a coordinate one ulp below +range rounds up to range in "x + r" and to the full
+  // count in the fp32 division, so the index component equals the axis size; for z (or y on the top layer) the
+  // voxel index is >= V and the reference writes outside risk_maps_.  Such marks are dropped, here and in the
+  // oracle (x / y overflows inside the array wrap into the next row / layer exactly as the reference's do).
+  if (v >= g.V) return;
+  __hip_atomic_fetch_or(mask + (v >> 5), 1u << (v & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 // points first, first + stride, ... of [begin, end) (lane included in `first`)
 __device__ __forceinline__ void stamp_bits_range(const GridGeom &g, const float *__restrict__ cloud, int first, int end,
                                                  int stride, float p0, float p1, float p2, unsigned *__restrict__ mask) {
-  // PassThrough limits (fake_particle_risk_voxel.cpp:88-104), fp32
-  const float lox = p0 - g.rx, hix = p0 + g.rx;
-  const float loy = p1 - g.ry, hiy = p1 + g.ry;
-  const float loz = p2 - g.rz, hiz = p2 + g.rz;
-  auto point = [&](float px, float py, float pz) __attribute__((always_inline)) {
-    if (!(px >= lox && px <= hix && py >= loy && py <= hiy && pz >= loz && pz <= hiz)) return;
-    const float x = px - p0, y = py - p1, z = pz - p2;
-    if (!g.in_range(x, y, z)) return;
-    const int v = g.voxel_of(x, y, z);
-    // Reference UB (map.h:169-174): a coordinate one ulp below +range rounds up to range in "x + r" and to the full
-    // count in the fp32 division, so the index component equals the axis size; for z (or y on the top layer) the
-    // voxel index is >= V and the reference writes outside risk_maps_.  Such marks are dropped, here and in the
-    // oracle (x / y overflows inside the array wrap into the next row / layer exactly as the reference's do).
-    if (v >= g.V) return;
-    __hip_atomic_fetch_or(mask + (v >> 5), 1u << (v & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  };
+  const CropBox box(g, p0, p1, p2);
   // four points per trip: their twelve loads are in flight together (one point per trip was a dependent HBM / L2 round
   // trip each, ~2.3 us per point and lane inside the tick; the marks are idempotent ORs, their order is free)
   int i = first;
@@ -361,9 +369,59 @@ __device__ __forceinline__ void stamp_bits_range(const GridGeom &g, const float 
       pz[u] = cloud[q + 2];
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) point(px[u], py[u], pz[u]);
+    for (int u = 0; u < 4; ++u) stamp_bits_point(g, box, px[u], py[u], pz[u], mask);
   }
-  for (; i < end; i += stride) point(cloud[(size_t)i * 3], cloud[(size_t)i * 3 + 1], cloud[(size_t)i * 3 + 2]);
+  for (; i < end; i += stride) stamp_bits_point(g, box, cloud[(size_t)i * 3], cloud[(size_t)i * 3 + 1], cloud[(size_t)i * 3 + 2], mask);
+}
+
+// ---- the crop of updateMap on the device (SogmWorld): the cloud comes in blocks of `block_points` consecutive points
+// with their xy bounds (sogm_cloud_block_bounds); an agent's crop is the ascending list of the blocks whose bounds
+// intersect its window, built once per agent-update by one wave (cull_blocks_agent), and the bits pass walks that list.
+// The PassThrough test per point is unchanged, so the set of marked voxels is the one a scan of the whole cloud gives.
+__device__ __forceinline__ void cull_blocks_agent(const GridGeom &g, const CloudBlocks &cb, int agent, float q0, float q1,
+                                                  int lane) {
+  const float lox = q0 - g.rx, hix = q0 + g.rx, loy = q1 - g.ry, hiy = q1 + g.ry;
+  int        *out = cb.list + (size_t)agent * cb.n_blocks;
+  int         kept = 0;
+  for (int b0 = 0; b0 < cb.n_blocks; b0 += 64) {
+    const int b    = b0 + lane;
+    bool      keep = false;
+    if (b < cb.n_blocks) {
+      const float4 bb = reinterpret_cast<const float4 *>(cb.bounds)[b];  // {xmin, xmax, ymin, ymax}
+      keep            = !(bb.y < lox || bb.x > hix || bb.w < loy || bb.z > hiy);
+    }
+    const unsigned long long m = __ballot(keep);
+    if (keep) out[kept + __popcll(m & ((1ull << lane) - 1ull))] = b;
+    kept += __popcll(m);
+  }
+  if (lane == 0) cb.n_list[agent] = kept;
+}
+// listed blocks first, first + stride, ... of the agent (one wave per call; a block's points are taken 64 at a time)
+__device__ __forceinline__ void stamp_bits_blocks(const GridGeom &g, const float *__restrict__ cloud, const CloudBlocks &cb,
+                                                  int agent, int first, int stride, float p0, float p1, float p2,
+                                                  unsigned *__restrict__ mask, int lane) {
+  const CropBox box(g, p0, p1, p2);
+  const int    *list = cb.list + (size_t)agent * cb.n_blocks;
+  const int     n    = cb.n_list[agent];
+  for (int i = first; i < n; i += stride) {  // uniform
+    const int b   = list[i];
+    const int beg = b * cb.block_points;
+    const int end = beg + cb.block_points < cb.n_points ? beg + cb.block_points : cb.n_points;
+    int       j   = beg + lane;
+    for (; j + 192 < end; j += 256) {  // four points of this lane in flight
+      float px[4], py[4], pz[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const size_t q = (size_t)(j + u * 64) * 3;
+        px[u] = cloud[q];
+        py[u] = cloud[q + 1];
+        pz[u] = cloud[q + 2];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) stamp_bits_point(g, box, px[u], py[u], pz[u], mask);
+    }
+    for (; j < end; j += 64) stamp_bits_point(g, box, cloud[(size_t)j * 3], cloud[(size_t)j * 3 + 1], cloud[(size_t)j * 3 + 2], mask);
+  }
 }
 __global__ __launch_bounds__(64) void k_stamp_bits(GridGeom g, const float *__restrict__ cloud,
                                                    const int32_t *__restrict__ cloud_range,
@@ -374,6 +432,37 @@ __global__ __launch_bounds__(64) void k_stamp_bits(GridGeom g, const float *__re
   const float *pose  = poses + agent * 3;
   stamp_bits_range(g, cloud, begin + (int)(blockIdx.x * blockDim.x + threadIdx.x), end, (int)(gridDim.x * blockDim.x),
                    pose[0], pose[1], pose[2], bits + (size_t)agent * words_per_agent);
+}
+
+__global__ __launch_bounds__(64) void k_stamp_bits_blocks(GridGeom g, const float *__restrict__ cloud, CloudBlocks cb,
+                                                          const float *__restrict__ poses, unsigned *__restrict__ bits,
+                                                          int words_per_agent) {
+  const int    agent = blockIdx.y;
+  const float *pose  = poses + agent * 3;
+  stamp_bits_blocks(g, cloud, cb, agent, (int)blockIdx.x, (int)gridDim.x, pose[0], pose[1], pose[2],
+                    bits + (size_t)agent * words_per_agent, (int)threadIdx.x);
+}
+// xy bounds of every block of `block_points` consecutive points (sogm_cloud_block_bounds): one wave per block
+__global__ __launch_bounds__(64) void k_block_bounds(const float *__restrict__ cloud, int n_points, int block_points,
+                                                     float *__restrict__ out) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const int beg = b * block_points, end = beg + block_points < n_points ? beg + block_points : n_points;
+  float xlo = INFINITY, xhi = -INFINITY, ylo = INFINITY, yhi = -INFINITY;
+  for (int j = beg + lane; j < end; j += 64) {
+    const float x = cloud[(size_t)j * 3], y = cloud[(size_t)j * 3 + 1];
+    xlo = fminf(xlo, x);
+    xhi = fmaxf(xhi, x);
+    ylo = fminf(ylo, y);
+    yhi = fmaxf(yhi, y);
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    xlo = fminf(xlo, __shfl_xor(xlo, d, 64));
+    xhi = fmaxf(xhi, __shfl_xor(xhi, d, 64));
+    ylo = fminf(ylo, __shfl_xor(ylo, d, 64));
+    yhi = fmaxf(yhi, __shfl_xor(yhi, d, 64));
+  }
+  if (lane == 0) reinterpret_cast<float4 *>(out)[b] = make_float4(xlo, xhi, ylo, yhi);
 }
 
 // Profiling build only (make EXTRA=-DSOGM_PROFILE_PRESTAMP, tools/diag_prestamp.py): 100 MHz ticks the pre-stamp's waves
@@ -1180,6 +1269,7 @@ __global__ __launch_bounds__(64) void k_prestamp_flow(GridGeom g, FlowCtl fc, Pr
       __syncthreads();
       cull_agent(g, ps.cyl, ps.n_cyl, ps.poses[agent * 3], ps.poses[agent * 3 + 1],
                  (CylCand *)ps.cand + (size_t)agent * SOGM_MAX_CYL_LDS, ps.n_cand + agent, lane);
+      if (ps.cb.bounds) cull_blocks_agent(g, ps.cb, agent, ps.poses[agent * 3], ps.poses[agent * 3 + 1], lane);
       __threadfence();
       if (lane == 0) {
         pts[1] = wall_clock64();
@@ -1193,9 +1283,13 @@ __global__ __launch_bounds__(64) void k_prestamp_flow(GridGeom g, FlowCtl fc, Pr
       [[maybe_unused]] const long long ps_t2 = PS_CLK();
       PS_ADD(1, ps_t2 - ps_t1);
       const float p0 = ps.poses[agent * 3], p1 = ps.poses[agent * 3 + 1], p2 = ps.poses[agent * 3 + 2];
-      const int   begin = ps.cloud_range[agent * 2], end = ps.cloud_range[agent * 2 + 1];
-      stamp_bits_range(g, ps.cloud, begin + s * 64 + lane, end, n_bits * 64, p0, p1, p2,
-                       ps.bits + (size_t)agent * ps.words);
+      if (ps.cb.bounds) {
+        stamp_bits_blocks(g, ps.cloud, ps.cb, agent, s, n_bits, p0, p1, p2, ps.bits + (size_t)agent * ps.words, lane);
+      } else {
+        const int begin = ps.cloud_range[agent * 2], end = ps.cloud_range[agent * 2 + 1];
+        stamp_bits_range(g, ps.cloud, begin + s * 64 + lane, end, n_bits * 64, p0, p1, p2,
+                         ps.bits + (size_t)agent * ps.words);
+      }
       __threadfence();
       PS_ADD(3, PS_CLK() - ps_t2);
       if (lane == 0 && atomicAdd(&fc.stage[agent], 1) + 1 == 1 + n_bits) pts[2] = wall_clock64();
@@ -1392,6 +1486,24 @@ int prestamp_buffers(sogm_ctx *c, PrestampDev *d) {
   d->n_cand = c->d_ncand;
   d->poses  = c->d_poses_next;
   d->stamps = c->d_stamps_next;
+  return SOGM_OK;
+}
+
+int world_blocks(sogm_ctx *c, const SogmWorld *w, CloudBlocks *out) {
+  SOGM_HIP_CHECK(hipSetDevice(c->device));
+  if (w->n_blocks > c->blk_cap || !c->d_blk_n) {  // (also the first frame of all, even an empty one: the counts exist)
+    // (grown between ticks only: a frame with more blocks than any before; the old lists may still be read by a
+    //  pre-stamp in flight, so everything drains first)
+    SOGM_HIP_CHECK(hipDeviceSynchronize());
+    if (c->d_blk_list) (void)hipFree(c->d_blk_list);
+    c->d_blk_list = nullptr;
+    const int cap = (w->n_blocks + 1023) & ~1023;
+    SOGM_HIP_CHECK(hipMalloc((void **)&c->d_blk_list, sizeof(int) * (size_t)cap * (size_t)c->n_agents));
+    if (!c->d_blk_n) SOGM_HIP_CHECK(hipMalloc((void **)&c->d_blk_n, sizeof(int) * (size_t)c->n_agents));
+    c->blk_cap = cap;
+  }
+  // (the lists are packed with this frame's block count as the row length: a row never exceeds n_blocks <= blk_cap)
+  *out = CloudBlocks{w->block_bounds, w->n_blocks, w->block_points, w->n_points, c->d_blk_list, c->d_blk_n};
   return SOGM_OK;
 }
 
@@ -1698,6 +1810,8 @@ void sogm_destroy(sogm_ctx *c) {
   if (c->d_cand) (void)hipFree(c->d_cand);
   if (c->d_stamp_bits) (void)hipFree(c->d_stamp_bits);
   if (c->d_ncand) (void)hipFree(c->d_ncand);
+  if (c->d_blk_list) (void)hipFree(c->d_blk_list);
+  if (c->d_blk_n) (void)hipFree(c->d_blk_n);
   if (c->d_filter_cells) (void)hipFree(c->d_filter_cells);
   if (c->d_filter_box) (void)hipFree(c->d_filter_box);
   if (c->d_filter_blocks) (void)hipFree(c->d_filter_blocks);
@@ -2035,8 +2149,11 @@ static int clear_grid(sogm_ctx *c, hipStream_t st) { return sogm::reset_slot(c, 
 static int update_gt_impl(sogm_ctx *c, const float *cloud_xyz, const int32_t *cloud_range,
                           const SogmCylinder *cylinders, int n_cyl, const float *poses, const double *stamps,
                           const SogmTrajRecord *records, int n_records, const int32_t *ego_ids, bool fused,
-                          hipStream_t st) {
+                          hipStream_t st, const SogmWorld *world = nullptr) {
   SOGM_HIP_CHECK(hipSetDevice(c->device));
+  sogm::CloudBlocks cb{};
+  if (world)
+    if (int rc = sogm::world_blocks(c, world, &cb)) return rc;
   const int A = c->n_agents;
   if (int rc = sogm::join_prestamp(c, st)) return rc;  // a pre-stamp of the last replan may still be running
   if (fused)
@@ -2082,9 +2199,13 @@ static int update_gt_impl(sogm_ctx *c, const float *cloud_xyz, const int32_t *cl
   c->n_stamps++;
   prof_begin(c, SOGM_PROF_STAMP, st);
   hipLaunchKernelGGL(k_cull_cylinders, dim3(A), dim3(64), 0, st, c->geom, cylinders, n_cyl, poses,
-                     (CylCand *)c->d_cand, c->d_ncand, stamps, c->d_poses, c->d_stamps);
-  hipLaunchKernelGGL(k_stamp_bits, dim3(stamp_wgs, A), dim3(64), 0, st, c->geom, cloud_xyz, cloud_range, c->d_poses,
-                     c->d_stamp_bits, words, 0);
+                     (CylCand *)c->d_cand, c->d_ncand, stamps, c->d_poses, c->d_stamps, cb);
+  if (world)
+    hipLaunchKernelGGL(k_stamp_bits_blocks, dim3(stamp_wgs, A), dim3(64), 0, st, c->geom, cloud_xyz, cb, c->d_poses,
+                       c->d_stamp_bits, words);
+  else
+    hipLaunchKernelGGL(k_stamp_bits, dim3(stamp_wgs, A), dim3(64), 0, st, c->geom, cloud_xyz, cloud_range, c->d_poses,
+                       c->d_stamp_bits, words, 0);
   const sogm::MarkLog lg = sogm::mark_log(c, sogm::cur_slot(c));
   hipLaunchKernelGGL(k_stamp_marks, dim3(stamp_wgs, A), dim3(64), 0, st, c->geom, (void *)c->d_grid, c->d_stamp_bits,
                      words, cylinders, n_cyl, c->d_poses, (const CylCand *)c->d_cand, (const int *)c->d_ncand, 0, lg);
@@ -2122,6 +2243,26 @@ int sogm_update_gt_swarm(sogm_ctx *c, const float *cloud_xyz, const int32_t *clo
   if (!c->d_body || c->n_body <= 0) return SOGM_ERR_STATE;
   return update_gt_impl(c, cloud_xyz, cloud_range, cylinders, n_cyl, poses, stamps, records, n_records, ego_ids,
                         true, (hipStream_t)stream);
+}
+
+int sogm_cloud_block_bounds(const float *cloud_xyz, int n_points, int block_points, float *out_bounds, void *stream) {
+  if (!cloud_xyz || !out_bounds || n_points < 0 || block_points < 64 || block_points > 4096) return SOGM_ERR_INVALID_ARG;
+  const int nb = (n_points + block_points - 1) / block_points;
+  if (nb == 0) return SOGM_OK;
+  hipLaunchKernelGGL(k_block_bounds, dim3(nb), dim3(64), 0, (hipStream_t)stream, cloud_xyz, n_points, block_points, out_bounds);
+  SOGM_HIP_CHECK(hipGetLastError());
+  return SOGM_OK;
+}
+
+int sogm_update_world(sogm_ctx *c, const SogmWorld *w, const float *poses, const double *stamps,
+                      const SogmTrajRecord *records, int n_records, const int32_t *ego_ids, void *stream) {
+  if (!c || !w || !poses || !stamps || !w->cloud_xyz || !w->block_bounds || w->n_points < 0 || w->block_points < 64 ||
+      w->block_points > 4096 || w->n_blocks != (w->n_points + w->block_points - 1) / w->block_points || w->n_cyl < 0 ||
+      (w->n_cyl > 0 && !w->cylinders) || n_records < 0 || (n_records > 0 && (!records || !ego_ids)))
+    return SOGM_ERR_INVALID_ARG;
+  if (n_records > 0 && (!c->d_body || c->n_body <= 0)) return SOGM_ERR_STATE;
+  return update_gt_impl(c, w->cloud_xyz, nullptr, w->cylinders, w->n_cyl, poses, stamps, records, n_records, ego_ids,
+                        n_records > 0, (hipStream_t)stream, w);
 }
 
 int sogm_update_prestamped(sogm_ctx *c, const SogmTrajRecord *records, int n_records, const int32_t *ego_ids,

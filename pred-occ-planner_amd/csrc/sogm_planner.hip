@@ -549,14 +549,22 @@ int sogm_planner_set_prestamp(sogm_planner *p, const SogmPrestamp *ps) {
     p->ps_on = 0;
     return SOGM_OK;
   }
-  if (!ps->cloud_xyz || !ps->cloud_range || ps->n_cyl < 0 || (ps->n_cyl > 0 && !ps->cylinders) || !ps->hover_inout ||
-      !ps->out_now || !ps->out_t_start || !ps->out_pva)
+  if (!ps->hover_inout || !ps->out_now || !ps->out_t_start || !ps->out_pva) return SOGM_ERR_INVALID_ARG;
+  const SogmWorld *w = ps->world;
+  if (w) {
+    if (!w->cloud_xyz || !w->block_bounds || w->n_points < 0 || w->block_points < 64 || w->block_points > 4096 ||
+        w->n_blocks != (w->n_points + w->block_points - 1) / w->block_points || w->n_cyl < 0 || (w->n_cyl > 0 && !w->cylinders))
+      return SOGM_ERR_INVALID_ARG;
+  } else if (!ps->cloud_xyz || !ps->cloud_range || ps->n_cyl < 0 || (ps->n_cyl > 0 && !ps->cylinders)) {
     return SOGM_ERR_INVALID_ARG;
+  }
   std::memset(&p->ps, 0, sizeof(p->ps));
-  p->ps.cloud        = ps->cloud_xyz;
-  p->ps.cloud_range  = ps->cloud_range;
-  p->ps.cyl          = ps->cylinders;
-  p->ps.n_cyl        = ps->n_cyl;
+  p->ps.cloud        = w ? w->cloud_xyz : ps->cloud_xyz;
+  p->ps.cloud_range  = w ? nullptr : ps->cloud_range;
+  p->ps.cyl          = w ? w->cylinders : ps->cylinders;
+  p->ps.n_cyl        = w ? w->n_cyl : ps->n_cyl;
+  p->ps_world_on     = w ? 1 : 0;
+  if (w) p->ps_world = *w;
   p->ps.stamp        = ps->next_stamp;
   p->ps.start_offset = ps->replan_start_offset;
   p->ps.hover        = ps->hover_inout;
@@ -723,6 +731,8 @@ static int replan_flow(sogm_planner *p, const double *start_pva, const double *g
     d.n_bits_late  = c->tune_i(SOGM_TUNE_PRESTAMP_LATE_BITS) > 0 ? c->tune_i(SOGM_TUNE_PRESTAMP_LATE_BITS) : nb;
     d.n_marks_late = c->tune_i(SOGM_TUNE_PRESTAMP_LATE_MARKS) > 0 ? c->tune_i(SOGM_TUNE_PRESTAMP_LATE_MARKS) : nm;
     if (int rc = sogm::prestamp_buffers(c, &d)) return rc;
+    if (p->ps_world_on)  // the frame's blocks + the context's crop lists (built by each agent's first ticket)
+      if (int rc = sogm::world_blocks(c, &p->ps_world, &d.cb)) return rc;
     // The pre-stamp's target grid was reset by an EARLIER replan when the pool holds three grids (the front of the ready
     // queue), yet on the resets' stream the launch would also sit behind THIS replan's reset — which is held back until
     // every agent's corridors are final and then takes a millisecond: traces showed the pre-stamp starting at 5.6 ms

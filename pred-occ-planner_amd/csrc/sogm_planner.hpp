@@ -101,7 +101,8 @@ struct PrestampDev {
   unsigned             *bits;         // [A][words] occupancy bits of slice 0
   int                   words;
   const float          *cloud;
-  const int32_t        *cloud_range;
+  const int32_t        *cloud_range;  // per-agent {begin, end} (null with cb.bounds set)
+  CloudBlocks           cb;           // SogmWorld frame: blocks + the context's crop lists (bounds null = ranges above)
   const SogmCylinder   *cyl;
   int                   n_cyl;
   void                 *cand;         // [A][1024] CylCand
@@ -231,6 +232,8 @@ struct sogm_planner {
   hipEvent_t     ev_pdone;
   sogm::PrestampDev ps;       // the host's part of the pre-stamp arguments
   int            ps_on;
+  int            ps_world_on;  // the pre-stamp's inputs are a SogmWorld frame (copied at sogm_planner_set_prestamp)
+  SogmWorld      ps_world;
   hipEvent_t     ev_gate, ev_fdone[4];
   int           *d_epoch;      // device word: the clear epoch of the replan in flight (sogm_ctx::clear_epoch_word)
   int           *h_flow_fail;  // pinned, device-visible: {last FLOW_ERR code, ticks that failed} (k_flow_report)

@@ -22,7 +22,7 @@ import torch
 
 from . import _abi, config, scene as scene_mod
 from .planner import SogmPlanner, traj_eval
-from .sogm import SogmMap, _dev, _stream, upload_scene
+from .sogm import SogmMap, World, _dev, _stream, upload_scene
 
 TICK_PERIOD = 0.1        # fsm/replan_duration (sim_fake.yaml:7)
 REPLAN_START_TIME = 0.02  # fsm/replan_start_time (sim_fake.yaml:8)
@@ -189,7 +189,8 @@ class HipCompute:
     class — the rank-local bookkeeping around these calls is what that test covers.)"""
     device = "cuda"
 
-    def __init__(self, spec, scene, lo, hi, device, overlap_clear=True, double_buffer=None, grids=None, tuning=None):
+    def __init__(self, spec, scene, lo, hi, device, overlap_clear=True, double_buffer=None, grids=None, tuning=None,
+                 moving_world=None):
         half = (spec.L // 2) * 0.15
         A_loc = hi - lo
         loc = dict(scene)
@@ -197,11 +198,22 @@ class HipCompute:
         for k in ("starts", "goals", "poses", "stamps", "ego_ids"):
             loc[k] = scene[k][lo:hi]
         torch.cuda.set_device(device)
-        # each agent scans only the cloud around it (its sensing neighbourhood): map half range +
-        # the distance it can fly during a run, so per-agent work does not grow with the swarm
-        crop, crange = scene_mod.crop_clouds(scene, lo, hi, half + 10.0)
-        self.dev = upload_scene(loc, cloud=crop, cloud_range=crange)
-        self.cloud_points = int(crop.shape[0])
+        # World frames (moving_world True / False): every tick's update takes the sensor frame OF THAT TICK (the whole
+        # cloud + the cylinders, scene.WorldTimeline) and crops it on the device around each agent's current map centre
+        # (sogm_update_world).  None: the frozen scene of the earlier rounds with host-side crops cut once around the
+        # start (sogm_update_gt_swarm) — kept for the tests that compare single builds.
+        self.timeline = scene_mod.WorldTimeline(scene, TICK_PERIOD, moving=bool(moving_world))
+        self.use_world = moving_world is not None
+        self._frames = {}
+        if self.use_world:
+            self.dev = upload_scene(loc, cloud=np.zeros((1, 3), np.float32), cloud_range=np.zeros((A_loc, 2), np.int32))
+            self.cloud_points = 0   # (per-agent counts are the device-side crop's: sogm_map_traffic / bench)
+        else:
+            # each agent scans only the cloud around it (its sensing neighbourhood): map half range +
+            # the distance it can fly during a run, so per-agent work does not grow with the swarm
+            crop, crange = scene_mod.crop_clouds(scene, lo, hi, half + 10.0)
+            self.dev = upload_scene(loc, cloud=crop, cloud_range=crange)
+            self.cloud_points = int(crop.shape[0])
         self.A_loc = A_loc
         self.map = SogmMap(spec, A_loc, device)
         self.overlap_mode = self.map.set_overlap_clear(overlap_clear, double_buffer=double_buffer, grids=grids)
@@ -213,6 +225,26 @@ class HipCompute:
                                    config.make_qp_settings())
         self.ego_ids = self.dev["ego_ids"]
         self.fused_update = os.environ.get("SOGM_FUSED_UPDATE", "1") != "0"
+
+    def world(self, k):
+        """The device copy of tick k's sensor frame (uploaded on first use; prepare() uploads a range ahead of a timed
+        region so that no host-to-device copy falls inside it).  A frozen world has one frame."""
+        key = k if self.timeline.moving else 0
+        w = self._frames.get(key)
+        if w is None:
+            f = self.timeline.frame(key)
+            w = self._frames[key] = World(f["cloud"], f["cylinders"])
+        return w
+
+    def prepare(self, k0, k1):
+        for k in range(k0, k1):
+            self.world(k)
+        torch.cuda.synchronize()
+
+    def forget(self, before):
+        """drop the uploaded frames of ticks < before"""
+        for k in [k for k in self._frames if k < before and self.timeline.moving]:
+            del self._frames[k]
 
     @property
     def ctx(self):
@@ -232,21 +264,29 @@ class HipCompute:
                                                now.data_ptr(), t_start.data_ptr(), pva.data_ptr(), poses.data_ptr(),
                                                _stream()), "sogm_tick_inputs")
 
-    def update_map(self, poses, now, all_records, A_tot):
-        """updateMap incl. its closing neighbour overlay in one call"""
+    def update_map(self, poses, now, all_records, A_tot, tick=0):
+        """updateMap incl. its closing neighbour overlay in one call, from the sensor frame of `tick`"""
         d = self.dev
-        if self.fused_update:
+        if self.use_world:
+            self.map.updateWorld(self.world(tick), poses, now, all_records, A_tot, self.ego_ids)
+        elif self.fused_update:
             self.map.updateMapSwarm(d["cloud"], d["cloud_range"], d["cylinders"], d["n_cyl"], poses, now,
                                     all_records, A_tot, self.ego_ids)
         else:  # the two separate calls (SOGM_FUSED_UPDATE=0: A/B aid)
             self.map.updateMap(d["cloud"], d["cloud_range"], d["cylinders"], d["n_cyl"], poses, now)
             self.map.addOtherAgents(all_records, A_tot, self.ego_ids)
 
-    def set_prestamp(self, next_stamp, hover, now, t_start, pva, poses):
-        """the replan about to run also builds the NEXT tick's map and start states (sogm_planner_set_prestamp)"""
+    def set_prestamp(self, next_stamp, hover, now, t_start, pva, poses, tick=0):
+        """the replan about to run (tick `tick`) also builds the NEXT tick's map and start states
+        (sogm_planner_set_prestamp) — from the newest sensor frame that exists while it runs, its own tick's: the next
+        tick then plans on a map whose obstacle data is one tick old (staleness 1; a frozen world hides the difference)"""
         d = self.dev
-        self.planner.setPrestamp(d["cloud"], d["cloud_range"], d["cylinders"], d["n_cyl"], next_stamp,
-                                 REPLAN_START_TIME, hover, now, t_start, pva, poses)
+        if self.use_world:
+            self.planner.setPrestamp(None, None, None, 0, next_stamp, REPLAN_START_TIME, hover, now, t_start, pva, poses,
+                                     world=self.world(tick))
+        else:
+            self.planner.setPrestamp(d["cloud"], d["cloud_range"], d["cylinders"], d["n_cyl"], next_stamp,
+                                     REPLAN_START_TIME, hover, now, t_start, pva, poses)
 
     def prestamp_pending(self):
         return self.map.prestamp_pending()
@@ -277,7 +317,8 @@ class HipCompute:
 class SwarmTick:
     def __init__(self, grid="cfg2", agents_per_rank=None, rank=0, world=1, device=0, seed=0x5069,
                  spec=None, scene=None, dist=None, overlap_clear=True, deconflict=True, fsm=False,
-                 double_buffer=None, grids=None, compute=None, exchange=None, prestamp=None, tuning=None):
+                 double_buffer=None, grids=None, compute=None, exchange=None, prestamp=None, tuning=None,
+                 moving_world=None):
         self.rank, self.world, self.dist = rank, world, dist
         self.spec = spec if spec is not None else config.make_spec(grid)
         self.A_loc = agents_per_rank if agents_per_rank is not None else config.AGENTS.get(grid, 4)
@@ -286,7 +327,7 @@ class SwarmTick:
         self.scene = scene if scene is not None else scene_mod.make_scene(self.A_tot, half, seed=seed)
         lo, hi = shard_bounds(rank, world, self.A_loc)
         self.compute = compute if compute is not None else HipCompute(
-            self.spec, self.scene, lo, hi, device, overlap_clear, double_buffer, grids, tuning)
+            self.spec, self.scene, lo, hi, device, overlap_clear, double_buffer, grids, tuning, moving_world)
         c = self.compute
         # the HIP objects, for the bench / tools / tests that use the staged entry points beside step()
         self.map, self.planner, self.dev = getattr(c, "map", None), getattr(c, "planner", None), getattr(c, "dev", None)
@@ -315,8 +356,14 @@ class SwarmTick:
         # pre-stamp (default; SOGM_PRESTAMP=0 or prestamp=False: off): every replan also builds the next tick's map and
         # start states, agent by agent as their records are published; the tick's inputs are double-buffered (the replan
         # in flight reads one set)
-        want = (os.environ.get("SOGM_PRESTAMP", "1") != "0") if prestamp is None else bool(prestamp)
+        # With world frames the default is OFF: a pre-stamp can only be fed the frame of the tick in flight, so the map the
+        # next tick plans on is one tick staler than the reference's (map_input_staleness_ticks 1 vs 0) — an opt-in variant.
+        self.moving_world = moving_world
+        default_on = moving_world is None
+        want = (os.environ.get("SOGM_PRESTAMP", "1" if default_on else "0") != "0") if prestamp is None else bool(prestamp)
         self.prestamp = want and self.publish and hasattr(c, "set_prestamp") and self.overlap_mode >= 2
+        # ticks between the sensor frame a tick's map is built from and the tick itself
+        self.map_input_staleness_ticks = 1 if (self.prestamp and moving_world is not None) else 0
         self._alt = (torch.zeros_like(self.pva), torch.zeros_like(self.t_start), torch.zeros_like(self.now),
                      torch.zeros_like(self.poses)) if self.prestamp else None
         # optional closed-loop mode: every agent runs the reference's FiniteStateMachine (step_fsm)
@@ -373,8 +420,11 @@ class SwarmTick:
         pva, valid = traj_eval(self.own, t_start)
         pva = torch.where(valid.bool().unsqueeze(1), pva, self.hover).contiguous()
         self.hover = torch.cat([pva_now[:, :3], torch.zeros_like(pva_now[:, 3:])], dim=1)
-        self.map.updateMap(self.dev["cloud"], self.dev["cloud_range"], self.dev["cylinders"], self.dev["n_cyl"],
-                           pva_now[:, :3].to(torch.float32).contiguous(), now)
+        if getattr(self.compute, "use_world", False):
+            self.map.updateWorld(self.compute.world(self.tick), pva_now[:, :3].to(torch.float32).contiguous(), now)
+        else:
+            self.map.updateMap(self.dev["cloud"], self.dev["cloud_range"], self.dev["cylinders"], self.dev["n_cyl"],
+                               pva_now[:, :3].to(torch.float32).contiguous(), now)
         self.map.addOtherAgents(self.all, self.A_tot, self.dev["ego_ids"])
         safe = self.map.isTrajSafe(self.own, now, COLLI_CHECK_DURATION)
         self.planner.replan(pva, self.goals, t_start, self.dev["ego_ids"], self.new, self.ok)
@@ -404,7 +454,7 @@ class SwarmTick:
             c.update_prestamped(self.all, self.A_tot)
         else:
             c.tick_inputs(self.own, stamp, self.hover, self.now, self.t_start, self.pva, self.poses)
-            c.update_map(self.poses, self.now, self.all, self.A_tot)
+            c.update_map(self.poses, self.now, self.all, self.A_tot, self.tick)
         if self.publish:
             local = not self.exchange.active and not self.distributed
             nxt = self._tables[(self.tick + 1) & 1] if local else None
@@ -413,7 +463,7 @@ class SwarmTick:
                 c.set_swarm(self.all, self.A_tot, self.now)
             if self.prestamp:
                 c.set_prestamp(self.t0 + (self.tick + 1) * TICK_PERIOD, self.hover, self._alt[2], self._alt[1],
-                               self._alt[0], self._alt[3])
+                               self._alt[0], self._alt[3], self.tick)
             c.replan(self.pva, self.goals, self.t_start, self.new, self.ok)
             if local:
                 self.all = nxt   # what every agent executes after this tick: the next tick's table

@@ -183,17 +183,20 @@ class SogmPlanner:
               "sogm_planner_set_publish")
 
     def setPrestamp(self, cloud, cloud_range, cylinders, n_cyl, next_stamp, start_offset, hover, now, t_start, pva,
-                    poses=None):
+                    poses=None, world=None):
         """The next replan() also builds the next tick's map and start states (sogm_planner_set_prestamp); the device
-        tensors are kept alive here.  cloud=None switches it off."""
-        if cloud is None:
+        tensors are kept alive here.  `world` (sogm.World): the stamp's inputs are that frame, cropped on the device
+        (cloud / cloud_range / cylinders are then ignored).  cloud=None and world=None switches it off."""
+        if cloud is None and world is None:
             self._prestamp = None
             check(lib().sogm_planner_set_prestamp(self._p, None), "sogm_planner_set_prestamp")
             return
-        ps = _abi.SogmPrestamp(cloud.data_ptr(), cloud_range.data_ptr(), cylinders.data_ptr(), int(n_cyl), 0,
+        ptr = lambda t: t.data_ptr() if t is not None else None
+        ps = _abi.SogmPrestamp(ptr(cloud), ptr(cloud_range), ptr(cylinders), int(n_cyl or 0), 0,
                                float(next_stamp), float(start_offset), hover.data_ptr(), now.data_ptr(),
-                               t_start.data_ptr(), pva.data_ptr(), poses.data_ptr() if poses is not None else None)
-        self._prestamp = (cloud, cloud_range, cylinders, hover, now, t_start, pva, poses)
+                               t_start.data_ptr(), pva.data_ptr(), ptr(poses),
+                               C.pointer(world.c) if world is not None else None)
+        self._prestamp = (cloud, cloud_range, cylinders, hover, now, t_start, pva, poses, world)
         check(lib().sogm_planner_set_prestamp(self._p, C.byref(ps)), "sogm_planner_set_prestamp")
 
     # ---- BaselinePlanner::replan ----

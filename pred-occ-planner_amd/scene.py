@@ -162,9 +162,9 @@ def make_scene(n_agents, half_range, seed, moving=True, n_cyl=None, circle_radiu
     cyl = np.asarray(cyl, dtype=np.float64).reshape(-1, 5)
 
     # cloud: cylinder shells on a 0.10 m lattice, z in [0, 4)
-    pts = []
+    pts, owner = [], []
     zs = np.arange(0, 40) * 0.1
-    for (x, y, w, _, _) in cyl:
+    for ci, (x, y, w, _, _) in enumerate(cyl):
         r = w * 0.5
         k0x, k1x = int(math.floor((x - r) / 0.1)), int(math.ceil((x + r) / 0.1))
         k0y, k1y = int(math.floor((y - r) / 0.1)), int(math.ceil((y + r) / 0.1))
@@ -178,11 +178,14 @@ def make_scene(n_agents, half_range, seed, moving=True, n_cyl=None, circle_radiu
         col = np.stack([np.repeat(sx, zs.size), np.repeat(sy, zs.size),
                         np.tile(zs, sx.size)], axis=1)
         pts.append(col)
+        owner.append(np.full((col.shape[0],), ci, np.int32))
     cloud = (np.concatenate(pts, axis=0) if pts else np.zeros((0, 3))).astype(np.float32)
+    cloud_cyl = np.concatenate(owner) if owner else np.zeros((0,), np.int32)
 
     return {
         "n_agents": n_agents,
         "cloud": np.ascontiguousarray(cloud),
+        "cloud_cyl": cloud_cyl,      # the cylinder every cloud point was sampled from (WorldTimeline moves it along)
         "cylinders": cyl,
         "starts": starts,
         "goals": goals,
@@ -191,6 +194,49 @@ def make_scene(n_agents, half_range, seed, moving=True, n_cyl=None, circle_radiu
         "ego_ids": np.arange(n_agents, dtype=np.int32),
         "circle_radius": circle_radius,
     }
+
+
+class WorldTimeline:
+    """The scene as a function of time: the sensor frames the fake-perception map receives, one per tick.
+
+    The reference's simulator (map_generator dynamic_forest_seq, absent submodule) republishes the global cloud and the
+    obstacle states while the obstacles move with their constant planar velocities (simulator_fake.launch:41); the map
+    is rebuilt from the cloud and the states that arrived FOR THAT update (map.cpp:170-171,
+    fake_particle_risk_voxel.cpp:244-264).  frame(k) is that input at tick k: every cylinder advanced by v * (k * dt) and
+    its cloud points — contiguous runs of the cloud — moved with it.  Pure numpy, a function of (scene, k): the oracle
+    flights of the tests and the device uploads of the driver use the same arrays.
+    moving=False: every frame is the scene at tick 0 (the frozen world of the earlier rounds, kept for the tests that
+    compare single builds)."""
+
+    def __init__(self, scene, dt=0.1, moving=True):
+        self.scene, self.dt, self.moving = scene, float(dt), bool(moving)
+        self.cyl0 = np.asarray(scene["cylinders"], np.float64).reshape(-1, 5)
+        self.cloud0 = np.ascontiguousarray(scene["cloud"], np.float32)
+        self.owner = scene.get("cloud_cyl")
+        if self.moving and (self.owner is None or len(self.owner) != len(self.cloud0)):
+            raise ValueError("WorldTimeline(moving=True) needs scene['cloud_cyl'] (make_scene provides it)")
+
+    def cylinders(self, k):
+        """(n, 5) rows {x, y, w, vx, vy} at tick k (fp64: x0 + vx * (k * dt))"""
+        c = self.cyl0.copy()
+        if self.moving and len(c):
+            t = float(k) * self.dt
+            c[:, 0] = self.cyl0[:, 0] + self.cyl0[:, 3] * t
+            c[:, 1] = self.cyl0[:, 1] + self.cyl0[:, 4] * t
+        return c
+
+    def cloud(self, k):
+        """[n, 3] float32 at tick k: the point's tick-0 position plus its cylinder's displacement rounded to fp32"""
+        if not self.moving or not len(self.cloud0) or k == 0:
+            return self.cloud0
+        t = float(k) * self.dt
+        off = (self.cyl0[:, 3:5] * t).astype(np.float32)          # per cylinder
+        out = self.cloud0.copy()
+        out[:, :2] += off[self.owner]
+        return out
+
+    def frame(self, k):
+        return {"cloud": self.cloud(k), "cylinders": self.cylinders(k)}
 
 
 def straight_records(scene, speed=1.0, t_start=None, n_pieces=6, piece_dur=0.3):

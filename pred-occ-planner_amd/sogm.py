@@ -213,6 +213,14 @@ class SogmMap:
                                          stamps.data_ptr(), records.data_ptr() if n_records else None, n_records,
                                          ego_ids.data_ptr(), _stream()), "sogm_update_gt_swarm")
 
+    def updateWorld(self, world, poses, stamps, records=None, n_records=0, ego_ids=None):
+        """FakeParticleRiskVoxel::updateMap (+ its closing overlay when `records` is given) from one World frame, the
+        PassThrough crop done on the device around `poses` (sogm_update_world)."""
+        self._poses, self._stamps, self._world = poses, stamps, world
+        check(lib().sogm_update_world(self._ctx, C.byref(world.c), poses.data_ptr(), stamps.data_ptr(),
+                                      records.data_ptr() if n_records else None, n_records,
+                                      ego_ids.data_ptr() if ego_ids is not None else None, _stream()), "sogm_update_world")
+
     def prestamp_pending(self):
         """True if the last replan pre-stamped the next grid (sogm_planner_set_prestamp)."""
         return bool(lib().sogm_prestamp_pending(self._ctx))
@@ -264,6 +272,30 @@ class SogmMap:
                                          pts.data_ptr(), cnt.data_ptr(), cap, _stream()),
               "sogm_obstacle_points")
         return pts, cnt
+
+
+class World:
+    """One sensor frame on the device (SogmWorld): cloud, block bounds (computed on the device by
+    sogm_cloud_block_bounds), GT cylinders.  `cloud` numpy / tensor [n, 3] float32, `cylinders` numpy (n, 5) rows
+    {x, y, w, vx, vy} or a ctypes SogmCylinder array."""
+
+    def __init__(self, cloud, cylinders, n_cyl=None, block_points=256, device="cuda"):
+        from .scene import cylinders_to_struct
+        if not isinstance(cylinders, C.Array):
+            n_cyl = len(cylinders)
+            cylinders = cylinders_to_struct(cylinders)
+        self.cloud = _dev(cloud if len(cloud) else np.zeros((1, 3), np.float32), np.float32, device)
+        self.n_points = int(len(cloud))
+        self.block_points = int(block_points)
+        self.n_blocks = (self.n_points + self.block_points - 1) // self.block_points
+        self.bounds = torch.empty((max(self.n_blocks, 1), 4), dtype=torch.float32, device=device)
+        self.cylinders = _dev(cylinders, None, device)
+        self.n_cyl = int(n_cyl)
+        check(lib().sogm_cloud_block_bounds(self.cloud.data_ptr(), self.n_points, self.block_points,
+                                            self.bounds.data_ptr(), _stream()), "sogm_cloud_block_bounds")
+        self.c = _abi.SogmWorld(self.cloud.data_ptr(), self.bounds.data_ptr(),
+                                self.cylinders.data_ptr() if self.n_cyl else None, self.n_points, self.n_blocks,
+                                self.block_points, self.n_cyl)
 
 
 def upload_scene(scene, device="cuda", cloud=None, cloud_range=None):

@@ -72,8 +72,9 @@ class OracleCompute:
     device = "cpu"
     ctx = None
 
-    def __init__(self, pop, orc, spec, scene, lo, hi):
+    def __init__(self, pop, orc, spec, scene, lo, hi, timeline=None):
         self.pop, self.orc, self.spec, self.scene, self.lo, self.hi = pop, orc, spec, scene, lo, hi
+        self.timeline = timeline  # scene.WorldTimeline: the sensor frame of every tick (None: the frozen scene)
         self.abi = pop._abi
         self.ap, self.pp, self.qs = (pop.config.make_astar_params(), pop.config.make_planner_params(True),
                                      pop.config.make_qp_settings())
@@ -115,11 +116,15 @@ class OracleCompute:
         now.fill_(stamp)
         t_start.fill_(ts)
 
-    def update_map(self, poses, now, all_records, A_tot):
+    def update_map(self, poses, now, all_records, A_tot, tick=0):
         recs = self._records(all_records)
+        cloud, cyl = self.scene["cloud"], self.cyl
+        if self.timeline is not None:
+            f = self.timeline.frame(tick)
+            cloud, cyl = f["cloud"], self.pop.scene.cylinders_to_struct(f["cylinders"])
         for i in range(self.hi - self.lo):
             pose = poses[i].numpy()
-            g = self.orc.update_gt(self.spec, self.scene["cloud"], self.cyl, len(self.scene["cylinders"]), pose)
+            g = self.orc.update_gt(self.spec, cloud, cyl, len(self.scene["cylinders"]), pose)
             self.orc.project_neighbours(self.spec, g, recs, A_tot, self.lo + i, self.body, pose, float(now[i]))
             self.grids[i] = g
             self.overlay_sums.append((round(float(now[i]), 6), self.lo + i, float(g.sum()),
