@@ -233,7 +233,12 @@ int sogm_set_resample(sogm_ctx *ctx, float replan_risk_rate, int num_resample, c
  *     "prestamp_late_agents" (8), "prestamp_late_bits" (128), "prestamp_late_marks" (256), and the dense clear's
  *     "clear_wgs" (0 = auto), "clear_throttle" (0), "clear_nt" (1), "clear_wide_wgs" (256; 0 = fixed width),
  *     "clear_wide_bound" (0), "clear_head_gb" (1e9), "clear_early" (0), "clear_retire_at_end" (0); "qp_ablate" (0;
- *     profiling builds only).
+ *     profiling builds only);
+ *   sogm_flight_run (read at its first call: the masked streams are created once):  "flight_qp_units" (4),
+ *     "flight_search_units" (2), "flight_map_units" (4) — compute units in units of 16 for the QP / search / map kernels,
+ *     the corridor + finish kernel takes the rest —, "flight_masks" (1; 0 = unmasked streams), "flight_spec" (1: both
+ *     search attempts side by side), and per (agent, tick) one-wave tickets "flight_reset" (8), "flight_bits" (16),
+ *     "flight_marks" (32), "flight_splat" (4).
  * Not thread-safe against calls on the same context (like every other call).  Unknown key: SOGM_ERR_INVALID_ARG.
  * sogm_tuning_key(i) enumerates the keys (NULL past the last). */
 int         sogm_set_tuning(sogm_ctx *ctx, const char *key, double value);
@@ -818,6 +823,45 @@ int sogm_prestamp_join(sogm_ctx *ctx, void *stream);
  * (records may be NULL with n_records = 0). */
 int sogm_update_prestamped(sogm_ctx *ctx, const SogmTrajRecord *records, int n_records, const int32_t *ego_ids,
                            void *stream);
+/*
+ * Flight: n_ticks replan ticks of every agent of the batch in ONE call, every agent on its own clock — the reference's
+ * drones each run their own FSM and read whatever trajectories arrived last (plan_manager/src/plan_manager.cpp:92-233,
+ * traj_coordinator/src/particles.cpp:179-190); a lock-step sogm_replan per tick makes 127 agents wait for the slowest
+ * chain of every tick.  RESULTS are fixed by a staleness rule, so a flight is reproducible whatever the schedule:
+ *   agent a's tick k  =  FakeParticleRiskVoxel::updateMap from worlds[k] around a's start state of tick k (sampled from
+ *   its own record of tick k - 1 at t0 + k * period + replan_start_offset), overlay and isSafeAfterOpt against table
+ *   ver(k - 2) — every agent's executed record as of ITS tick k - 2 —, then FakeBaselinePlanner::replan; a may start tick
+ *   k as soon as its own tick k - 1 is finished and EVERY agent has finished tick k - 2.
+ * (sogm_replan's lock-step tick reads ver(k - 1): the flight's neighbour records are one tick staler, like a record that
+ * missed one broadcast period.)  tables is a ring of four versions, ver(j) at tables[(j & 3) * n_total]: on entry ver(first_tick - 1)
+ * and ver(first_tick - 2) must hold the swarm's records of those ticks (a fresh flight: the initial table — empty or hover
+ * records — in both); on return ver(first_tick + n_ticks - 1) and ver(first_tick + n_ticks - 2) are complete, i.e. a
+ * following call with first_tick advanced by n_ticks continues the flight.  Needs the sparse reset (the agent's single grid is
+ * reset through its mark log at the start of each of its ticks), body particles, 32-byte aligned agent grids; single
+ * process (n_total == n_agents: every row of the tables is written by this call's agents).  Four persistent kernels on
+ * four streams with disjoint compute-unit masks (tuning keys flight_*_units, 16 CUs per unit); asynchronous: `stream`
+ * waits for the flight's end.  SOGM_ERR_STATE if the planner was created without the dataflow path.
+ */
+typedef struct SogmFlight {
+  int32_t          n_ticks;              /* 1 .. 64 */
+  int32_t          first_tick;           /* absolute index of this call's first tick (>= 0) */
+  double           t0, period;           /* stamp of tick k = t0 + k * period */
+  double           replan_start_offset;  /* fsm/replan_start_time */
+  const SogmWorld *worlds;               /* host array [n_ticks]: the sensor frame of tick first_tick + i */
+  const double    *goals;                /* dev [A][3] */
+  const int32_t   *drone_ids;            /* dev [A]  (ego ids of the batch = rows agent0 .. agent0 + A - 1 of the tables) */
+  double          *hover_inout;          /* dev [A][9] where an agent without a trajectory hovers (sogm_tick_inputs) */
+  SogmTrajRecord  *own_inout;            /* dev [A] the records the agents execute (latest wins) */
+  SogmTrajRecord  *tables;               /* dev [4][n_total] */
+  int32_t          n_total, agent0;
+  SogmTrajRecord  *log_records;          /* dev [n_ticks][A] every tick's sogm_replan-style output record ... */
+  int32_t         *log_ok;               /* dev [n_ticks][A] ... and ok flag */
+} SogmFlight;
+int sogm_flight_run(sogm_planner *p, const SogmFlight *flight, void *stream);
+/* After a flight (synchronises): host out_ms[A][8] = per-agent sums over the last flight in ms {wait at the tick k - 2 gate,
+ * map (reset + stamp + overlay), search (queue + A*), corridors (queue + FIRI), QP (queue + solve), finish, whole chain,
+ * ticks completed}; host out_hdr[16] = the flight's control header (FL_* counters; [10] = error code, 0 = none). */
+int sogm_flight_stats(sogm_planner *p, double *out_ms_host, int32_t *out_hdr_host);
 int sogm_planner_counters(sogm_planner *p, int64_t *out_host, int reset);
 /* sogm_replan() chains its kernels per agent through device-side ready lists ("dataflow replan");
  * a wait that exceeds 3 s marks the tick as failed instead of hanging the GPU: agents whose chain did not complete

@@ -112,6 +112,16 @@ class SogmPrestamp(C.Structure):
                 ("world", C.POINTER(SogmWorld))]
 
 
+class SogmFlight(C.Structure):
+    _fields_ = [("n_ticks", C.c_int32), ("first_tick", C.c_int32), ("t0", C.c_double), ("period", C.c_double),
+                ("replan_start_offset", C.c_double), ("worlds", C.POINTER(SogmWorld)), ("goals", C.c_void_p),
+                ("drone_ids", C.c_void_p), ("hover_inout", C.c_void_p), ("own_inout", C.c_void_p),
+                ("tables", C.c_void_p), ("n_total", C.c_int32), ("agent0", C.c_int32), ("log_records", C.c_void_p),
+                ("log_ok", C.c_void_p)]
+
+
+FLIGHT_MAX_TICKS = 64
+FLIGHT_STAT_NAMES = ("gate_wait", "map", "search", "corridor", "qp", "finish", "chain", "ticks")
 TRAJ_RECORD_BYTES = C.sizeof(SogmTrajRecord)  # 2064
 CYLINDER_BYTES = C.sizeof(SogmCylinder)  # 96
 
@@ -182,6 +192,8 @@ PROTOTYPES = {
     "sogm_prestamp_join": (_i, [_vp, _vp]),
     "sogm_update_prestamped": (_i, [_vp, _vp, _i, _vp, _vp]),
     "sogm_planner_counters": (_i, [_vp, C.POINTER(C.c_int64), _i]),
+    "sogm_flight_run": (_i, [_vp, C.POINTER(SogmFlight), _vp]),
+    "sogm_flight_stats": (_i, [_vp, _vp, _vp]),
     "sogm_planner_set_swarm": (_i, [_vp, _vp, _i, _vp, _vp]),
     "sogm_traj_allgather": (_i, [_vp, _vp, _vp, _i, _vp, _vp]),
     "sogm_exchange_wait": (_i, [_vp, _vp]),

@@ -307,33 +307,22 @@ __device__ inline void pos_to_index(const double *p, const double *center, doubl
 
 }  // namespace
 
-// One workgroup (two 64-lane waves) per agent: lane i evaluates motion primitive i.
-__global__ __launch_bounds__(ASTAR_THREADS) void k_astar(
-    MapView m, SogmAstarParams ap, double corridor_tau, AstarWorkspace wsp,
+// One search by one workgroup (three 64-lane waves): waves 0-1 evaluate one motion primitive per lane, wave 2 owns the open list.
+// `second` / `spec`: this workgroup runs the agent's SECOND attempt speculatively beside the first (the two searches are
+// independent; the second one's result only counts if the first returns NO_PATH, baseline_fake.cpp:284-291) — a NO_PATH
+// pair, the longest search a tick can hold, then takes the time of one search instead of two.  The two workgroups meet
+// through wsp.verdict[agent]: vbase + 1 = the first attempt found a path, vbase + 2 = it did not, anything else =
+// pending (vbase: 0 for the per-tick launches, whose verdicts are zeroed per replan; 4 x (tick + 1) in a flight, where
+// the word is never reset).  Returns true (uniformly) when THIS workgroup wrote the agent's search outputs — the caller
+// publishes the agent — and false when it leaves them to the other attempt.
+__device__ __forceinline__ bool astar_search_wg(
+    const MapView &m, const SogmAstarParams &ap, double corridor_tau, const AstarWorkspace &wsp,
     const double *__restrict__ start_pva, const double *__restrict__ goal,
     const double *__restrict__ t_start, int32_t *__restrict__ out_ret,
     double *__restrict__ out_route, int32_t *__restrict__ out_route_len, int route_cap,
-    int32_t *__restrict__ out_stats, int32_t *__restrict__ out_trace, int trace_cap, int agent0, FlowCtl fc,
-    int search_mode) {
-  // search_mode bit 3 (dataflow replan): the launch has 2 x n workgroups; workgroup b >= n runs the SECOND attempt of
-  // agent b - n speculatively beside the first (the two searches are independent; the second one's result only
-  // counts if the first returns NO_PATH, baseline_fake.cpp:284-291) — a NO_PATH pair, the longest search a tick can
-  // hold, then takes the time of one search instead of two.
-  const bool spec   = (search_mode & 8) != 0;
-  const int  n_half = spec ? (int)gridDim.x / 2 : (int)gridDim.x;
-  const int  second = spec && (int)blockIdx.x >= n_half ? 1 : 0;
-  const int  agent  = ((int)blockIdx.x - second * n_half) + agent0;
+    int32_t *__restrict__ out_stats, int32_t *__restrict__ out_trace, int trace_cap, int agent, int second, bool spec,
+    int vbase, int *flow_err, int search_mode) {
   const int  tid    = threadIdx.x;
-  // dataflow replan: tell the gate kernel that this workgroup holds its CU resources (the corridor kernel's
-  // waiting workgroups must not be dispatched before every search is resident, or they could starve it)
-  if (fc.hdr && tid == 0) {
-    atomicAdd(&fc.hdr[FLOW_A_RESIDENT], 1);
-    if (!second) {
-      fc.ts[agent * 8 + 7] = wall_clock64();
-      fc.ts[agent * 8 + 2] = 0;
-      fc.ts[agent * 8 + 0] = wall_clock64();
-    }
-  }
 
   __shared__ double             s_f[ASTAR_POOL_MAX];     // f-score mirror of every allocated node
   __shared__ unsigned short     s_heap[ASTAR_POOL_MAX];  // open list
@@ -480,7 +469,7 @@ __global__ __launch_bounds__(ASTAR_THREADS) void k_astar(
         s_n_active = 0;
         // speculative second attempt: every 8th expansion, look whether the first attempt has found a path
         if (second && (iter_num & 7) == 0 &&
-            __hip_atomic_load(&wsp.verdict[agent], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1) {
+            __hip_atomic_load(&wsp.verdict[agent], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == vbase + 1) {
           s_ret = -1;  // dropped
         } else if (heap_n == 0) {
           ret = NO_PATH;  // open set empty (:419-422)
@@ -914,26 +903,29 @@ __global__ __launch_bounds__(ASTAR_THREADS) void k_astar(
     if (!second) {
       if (tid == ASTAR_MASTER) {
         s_ret = ret;
-        __hip_atomic_store(&wsp.verdict[agent], ret != NO_PATH ? 1 : 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&wsp.verdict[agent], vbase + (ret != NO_PATH ? 1 : 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       __syncthreads();
-      if (s_ret == NO_PATH) return;
+      if (s_ret == NO_PATH) return false;
     } else {
-      if (dropped) return;
+      if (dropped) return false;
       if (tid == ASTAR_MASTER) {
         const long long t0 = wall_clock64();
         int             v;
-        while ((v = __hip_atomic_load(&wsp.verdict[agent], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0) {
+        for (;;) {
+          v = __hip_atomic_load(&wsp.verdict[agent], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - vbase;
+          if (v == 1 || v == 2) break;
           flow_pause();
           if (wall_clock64() - t0 > FLOW_TIMEOUT_TICKS) {
-            if (fc.hdr) atomicExch(&fc.hdr[FLOW_ERR], 4);
+            if (flow_err) atomicExch(flow_err, 4);
+            v = 0;
             break;
           }
         }
         s_ret = v;
       }
       __syncthreads();
-      if (s_ret != 2) return;
+      if (s_ret != 2) return false;
       if (tid == ASTAR_MASTER) searches = 2;  // as the sequential pattern counts them
     }
   }
@@ -995,13 +987,87 @@ __global__ __launch_bounds__(ASTAR_THREADS) void k_astar(
     if (wsp.dbg)
       for (int k = 0; k < 6; ++k) wsp.dbg[(size_t)agent * 8 + k] = tk[k];
     if (out_trace && n_trace < trace_cap) out_trace[(size_t)agent * trace_cap + n_trace] = -1;
-    if (fc.hdr) {  // publish the agent, in completion order, to the corridor kernel
-      fc.ts[agent * 8 + 1] = wall_clock64();
-      __threadfence();
-      const int r = atomicAdd(&fc.hdr[FLOW_A_READY_N], 1);
-      __hip_atomic_store(fc.a_ready + r, agent, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  return true;
+}
+
+// One workgroup per (agent, attempt): lane i evaluates motion primitive i.
+__global__ __launch_bounds__(ASTAR_THREADS) void k_astar(
+    MapView m, SogmAstarParams ap, double corridor_tau, AstarWorkspace wsp,
+    const double *__restrict__ start_pva, const double *__restrict__ goal,
+    const double *__restrict__ t_start, int32_t *__restrict__ out_ret,
+    double *__restrict__ out_route, int32_t *__restrict__ out_route_len, int route_cap,
+    int32_t *__restrict__ out_stats, int32_t *__restrict__ out_trace, int trace_cap, int agent0, FlowCtl fc,
+    int search_mode) {
+  // search_mode bit 3 (dataflow replan): the launch has 2 x n workgroups; workgroup b >= n runs the SECOND attempt of
+  // agent b - n speculatively beside the first
+  const bool spec   = (search_mode & 8) != 0;
+  const int  n_half = spec ? (int)gridDim.x / 2 : (int)gridDim.x;
+  const int  second = spec && (int)blockIdx.x >= n_half ? 1 : 0;
+  const int  agent  = ((int)blockIdx.x - second * n_half) + agent0;
+  const int  tid    = threadIdx.x;
+  // dataflow replan: tell the gate kernel that this workgroup holds its CU resources (the corridor kernel's
+  // waiting workgroups must not be dispatched before every search is resident, or they could starve it)
+  if (fc.hdr && tid == 0) {
+    atomicAdd(&fc.hdr[FLOW_A_RESIDENT], 1);
+    if (!second) {
+      fc.ts[agent * 8 + 7] = wall_clock64();
+      fc.ts[agent * 8 + 2] = 0;
+      fc.ts[agent * 8 + 0] = wall_clock64();
     }
   }
+  const bool mine = astar_search_wg(m, ap, corridor_tau, wsp, start_pva, goal, t_start, out_ret, out_route, out_route_len,
+                                    route_cap, out_stats, out_trace, trace_cap, agent, second, spec, 0,
+                                    fc.hdr ? &fc.hdr[FLOW_ERR] : nullptr, search_mode);
+  if (mine && fc.hdr && tid == ASTAR_MASTER) {  // publish the agent, in completion order, to the corridor kernel
+    fc.ts[agent * 8 + 1] = wall_clock64();
+    __threadfence();
+    const int r = atomicAdd(&fc.hdr[FLOW_A_READY_N], 1);
+    __hip_atomic_store(fc.a_ready + r, agent, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// Flight kernel S (sogm_flight_run): persistent search workgroups.  A ticket is one (agent, attempt) of the agent whose
+// map became ready ticket / 2-th (both attempts of an agent are handed out back to back, the first one first, so the
+// workgroup running the second can always wait for the first's verdict).  The attempt whose result counts publishes the
+// agent to the corridor queue.
+__global__ __launch_bounds__(ASTAR_THREADS) void k_flight_search(
+    MapView m, SogmAstarParams ap, double corridor_tau, AstarWorkspace wsp, FlightCtl fl,
+    const double *__restrict__ start_pva, const double *__restrict__ goal, const double *__restrict__ t_start,
+    int32_t *__restrict__ out_ret, double *__restrict__ out_route, int32_t *__restrict__ out_route_len, int route_cap,
+    int32_t *__restrict__ out_stats, int spec) {
+  __shared__ int s_item;
+  const int tid   = threadIdx.x;
+  const int per   = spec ? 2 : 1;
+  const int total = fl.n_agents * fl.n_ticks * per;
+  for (;;) {
+    __syncthreads();  // (s_item of the previous trip has been read by everybody)
+    if (tid == 0) s_item = atomicAdd(&fl.hdr[FL_S_TICKET], 1);
+    __syncthreads();
+    const int t = s_item;
+    if (t >= total) break;
+    const int agent = fl_wait_item(fl.s_ring, fl.ring_mask, t / per, &fl.hdr[FL_ERR]);
+    if (agent < 0) break;
+    const int second = spec ? (t & 1) : 0;
+    const int k      = fl.tick_of[agent];
+    if (tid == 0 && !second) fl.ts[agent * 12 + 0] = wall_clock64();
+    const bool mine = astar_search_wg(m, ap, corridor_tau, wsp, start_pva, goal, t_start, out_ret, out_route, out_route_len,
+                                      route_cap, out_stats, nullptr, 0, agent, second, spec != 0, 4 * (k + 1),
+                                      &fl.hdr[FL_ERR], 0);
+    if (mine && tid == ASTAR_MASTER) {
+      fl.ts[agent * 12 + 1] = wall_clock64();
+      fl_publish(fl.a_ring, fl.ring_mask, &fl.hdr[FL_A_READY], agent);
+    }
+  }
+}
+
+int launch_flight_search(const MapView &m, const SogmAstarParams &ap, double corridor_tau, const AstarWorkspace &wsp,
+                         const FlightCtl &fl, int n_workgroups, const double *start_pva, const double *goal,
+                         const double *t_start, int32_t *out_ret, double *out_route, int32_t *out_route_len, int route_cap,
+                         int32_t *out_stats, int spec, hipStream_t st) {
+  hipLaunchKernelGGL(k_flight_search, dim3(n_workgroups), dim3(ASTAR_THREADS), 0, st, m, ap, corridor_tau, wsp, fl, start_pva,
+                     goal, t_start, out_ret, out_route, out_route_len, route_cap, out_stats, spec);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
 size_t astar_node_bytes() { return sizeof(Node); }

@@ -2011,17 +2011,133 @@ __global__ __launch_bounds__(64) void k_safe_after_opt(const double *__restrict_
     out_safe[a] = 0;  // every writer writes 0
 }
 
+// What the finishing role does for one agent (one wave): ParticleATC::isSafeAfterOpt against every record of the swarm
+// (when a swarm is set), then the agent's SogmTrajRecord / ok flag and the publication — shared by k_finish_flow
+// (sogm_replan) and k_flight_light (sogm_flight_run).  Returns bit 0 = safe, bit 1 = replan() returned true.
+__device__ __forceinline__ int finish_agent(const FinishArgs &f, int a, double *s_lp, double *s_rows, int *s_perm, int lane) {
+  const int M    = f.npoly[a];
+  int       safe = 1;
+  const bool solved = f.ret[a] != 0 && M > 0 && (f.status[a] == 1 || f.status[a] == 2);
+  if (f.swarm && solved) {  // unsolved agents fail anyway: the check cannot change their outcome
+    const double *ca  = f.cpts + (size_t)a * SOGM_MAX_PIECES * 15;
+    const int     ego = f.swarm_ego[a];
+    const double  now = f.swarm_now[a];
+    const int     nA  = 5 * M;
+    // set A once per agent: its points in LDS (the LP scratch is idle until a pair needs the LP), its box and
+    // its projections on the ten fixed normals as wave-uniform values
+    double *sA = s_lp;
+    double  boxA[6], prA[10][2];
+    auto stage_A = [&]() {
+      for (int q = lane; q < nA * 3; q += 64) sA[q] = ca[q];
+      wave_lds_sync();
+    };
+    stage_A();
+    {
+      const double dirs[10][3] = {{1, 1, 0}, {1, -1, 0}, {1, 0, 1}, {1, 0, -1}, {0, 1, 1},
+                                  {0, 1, -1}, {1, 1, 1}, {1, 1, -1}, {1, -1, 1}, {1, -1, -1}};
+      double lo[13], hi[13];
+#pragma unroll
+      for (int k = 0; k < 13; ++k) {
+        lo[k] = INFINITY;
+        hi[k] = -INFINITY;
+      }
+      for (int q = lane; q < nA; q += 64) {
+        const double x = sA[q * 3], y = sA[q * 3 + 1], z = sA[q * 3 + 2];
+        lo[0] = fmin(lo[0], x);
+        hi[0] = fmax(hi[0], x);
+        lo[1] = fmin(lo[1], y);
+        hi[1] = fmax(hi[1], y);
+        lo[2] = fmin(lo[2], z);
+        hi[2] = fmax(hi[2], z);
+#pragma unroll
+        for (int k = 0; k < 10; ++k) {
+          const double v = (dirs[k][0] * x + dirs[k][1] * y) + dirs[k][2] * z;
+          lo[3 + k]      = fmin(lo[3 + k], v);
+          hi[3 + k]      = fmax(hi[3 + k], v);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 13; ++k)
+        for (int d = 32; d >= 1; d >>= 1) {
+          lo[k] = fmin(lo[k], __shfl_xor(lo[k], d, 64));
+          hi[k] = fmax(hi[k], __shfl_xor(hi[k], d, 64));
+        }
+      for (int k = 0; k < 3; ++k) {
+        boxA[k]     = lo[k];
+        boxA[3 + k] = hi[k];
+      }
+#pragma unroll
+      for (int k = 0; k < 10; ++k) {
+        prA[k][0] = lo[3 + k];
+        prA[k][1] = hi[3 + k];
+      }
+    }
+    // one lane per record decides whether the pair needs the full test; the few that do go through it one at a
+    // time, in record order (first unsafe pair ends the check, as the sequential loop did)
+    for (int i0 = 0; i0 < f.n_swarm && safe; i0 += 64) {
+      const int  i    = i0 + lane;
+      const bool need = i < f.n_swarm && deconflict_prefilter(sA, nA, boxA, prA, f.swarm[i], ego, now);
+      unsigned long long m = __ballot(need);
+      bool               lp_ran = false;
+      while (m != 0 && safe) {
+        const int j = __builtin_ctzll(m);
+        m &= m - 1;
+        if (deconflict_pair_unsafe(ca, M, f.swarm[i0 + j], ego, now, s_lp, s_rows, s_perm, f.counters)) safe = 0;
+        lp_ran = true;
+      }
+      if (lp_ran && safe && i0 + 64 < f.n_swarm) stage_A();  // the LP used the scratch that held set A
+    }
+  }
+#ifdef SOGM_FLOW_DEBUG
+  if (lane == 0) f.out_safe[a] = 101;
+#else
+  if (lane == 0 && f.out_safe) f.out_safe[a] = safe;
+#endif
+  // BezierTraj record (plan_manager.cpp:364-399); n_pieces = 0 marks "replan() returned false".
+  // Publication (sogm_planner_set_publish): a successful replan's record also goes — in the same stores — into
+  // the host's own table (latest wins; a failed replan keeps executing the previous trajectory, :176-196) and the
+  // agent's current record into the next tick's swarm table, HERE, where the stores overlap with the other agents'
+  // chains, instead of in a store-heavy kernel after the replan (beside the streaming clear that kernel took 2 ms).
+  const bool      good = solved && safe != 0;
+  SogmTrajRecord *dst[3] = {f.out + a, (good && f.pub_own) ? f.pub_own + a : nullptr,
+                            (good && f.pub_own && f.pub_table) ? f.pub_table + a : nullptr};
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    SogmTrajRecord *r = dst[k];
+    if (!r) continue;  // wave-uniform
+    for (int i = lane; i < SOGM_MAX_PIECES; i += 64) r->duration[i] = (good && i < M) ? f.corridor_tau : 0.0;
+    for (int i = lane; i < SOGM_MAX_PIECES * 15; i += 64)
+      r->cpts[i] = (good && i < M * 15) ? f.cpts[(size_t)a * SOGM_MAX_PIECES * 15 + i] : 0.0;
+    if (lane == 0) {
+      r->drone_id   = f.drone_ids[a];
+      r->time_start = f.t_start[a];
+      r->n_pieces   = good ? M : 0;
+    }
+  }
+  if (!good && f.pub_own && f.pub_table) {  // the table still lists the trajectory the agent goes on executing
+    constexpr int W   = (int)(sizeof(SogmTrajRecord) / 16);
+    const uint4  *src = reinterpret_cast<const uint4 *>(f.pub_own + a);
+    uint4        *t   = reinterpret_cast<uint4 *>(f.pub_table + a);
+    for (int w = lane; w < W; w += 64) t[w] = src[w];
+  }
+  if (lane == 0) f.out_ok[a] = good ? 1 : 0;
+  return (safe ? 1 : 0) | (good ? 2 : 0);
+}
+
+// where this replan ended (baseline_fake.cpp: :292 no path, :405-419 corridors, :447 QP, :455 unsafe); one lane
+__device__ __forceinline__ void finish_count(const FinishArgs &f, int a, bool safe) {
+  if (!f.counters) return;
+  const int M = f.npoly[a];
+  int       k = SOGM_CNT_REPLAN_OK;
+  if (f.ret[a] == 0) k = SOGM_CNT_FAIL_SEARCH;
+  else if (M <= 0) k = SOGM_CNT_FAIL_CORRIDOR;
+  else if (!(f.status[a] == 1 || f.status[a] == 2)) k = SOGM_CNT_FAIL_QP;
+  else if (!safe) k = SOGM_CNT_FAIL_UNSAFE;
+  atomicAdd(&f.counters[k], 1ull);
+}
 // Dataflow kernel F (sogm_replan): ONE persistent launch; a wave takes the agent whose QP finished ticket-th, runs
-// ParticleATC::isSafeAfterOpt against every record of the swarm (when a swarm is set) and packs the agent's
-// SogmTrajRecord / ok flag (what k_safe_after_opt + k_pack_records do in the grouped path).
-__global__ __launch_bounds__(64) void k_finish_flow(FlowCtl fc, double corridor_tau, const int32_t *ret,
-                                                    const int32_t *npoly, const int32_t *status, const double *cpts,
-                                                    const SogmTrajRecord *swarm, int n_swarm,
-                                                    const int32_t *swarm_ego, const double *swarm_now,
-                                                    const double *t_start, const int32_t *drone_ids,
-                                                    SogmTrajRecord *out, int32_t *out_ok, int32_t *out_safe,
-                                                    unsigned long long *counters, int n_agents,
-                                                    SogmTrajRecord *pub_own, SogmTrajRecord *pub_table) {
+// finish_agent (what k_safe_after_opt + k_pack_records do in the grouped path) and hands the agent to the pre-stamp.
+__global__ __launch_bounds__(64) void k_finish_flow(FlowCtl fc, FinishArgs f, int n_agents) {
   extern __shared__ __attribute__((aligned(16))) double s_dyn[];
   double   *s_lp   = s_dyn;
   double   *s_rows = s_lp + LP_WORK_DOUBLES;
@@ -2032,116 +2148,9 @@ __global__ __launch_bounds__(64) void k_finish_flow(FlowCtl fc, double corridor_
     if (k >= n_agents) break;
     const int a = flow_wait_slot(fc.f_ready + k, &fc.hdr[FLOW_ERR]);
     if (a < 0) break;
-#ifdef SOGM_FLOW_DEBUG
-    if (lane == 0) out_safe[a] = 100;
-#endif
     __threadfence();
-    const int M    = npoly[a];
-    int       safe = 1;
-    const bool solved = ret[a] != 0 && M > 0 && (status[a] == 1 || status[a] == 2);
-    if (swarm && solved) {  // unsolved agents fail anyway: the check cannot change their outcome
-      const double *ca  = cpts + (size_t)a * SOGM_MAX_PIECES * 15;
-      const int     ego = swarm_ego[a];
-      const double  now = swarm_now[a];
-      const int     nA  = 5 * M;
-      // set A once per agent: its points in LDS (the LP scratch is idle until a pair needs the LP), its box and
-      // its projections on the ten fixed normals as wave-uniform values
-      double *sA = s_lp;
-      double  boxA[6], prA[10][2];
-      auto stage_A = [&]() {
-        for (int q = lane; q < nA * 3; q += 64) sA[q] = ca[q];
-        wave_lds_sync();
-      };
-      stage_A();
-      {
-        const double dirs[10][3] = {{1, 1, 0}, {1, -1, 0}, {1, 0, 1}, {1, 0, -1}, {0, 1, 1},
-                                    {0, 1, -1}, {1, 1, 1}, {1, 1, -1}, {1, -1, 1}, {1, -1, -1}};
-        double lo[13], hi[13];
-#pragma unroll
-        for (int k = 0; k < 13; ++k) {
-          lo[k] = INFINITY;
-          hi[k] = -INFINITY;
-        }
-        for (int q = lane; q < nA; q += 64) {
-          const double x = sA[q * 3], y = sA[q * 3 + 1], z = sA[q * 3 + 2];
-          lo[0] = fmin(lo[0], x);
-          hi[0] = fmax(hi[0], x);
-          lo[1] = fmin(lo[1], y);
-          hi[1] = fmax(hi[1], y);
-          lo[2] = fmin(lo[2], z);
-          hi[2] = fmax(hi[2], z);
-#pragma unroll
-          for (int k = 0; k < 10; ++k) {
-            const double v = (dirs[k][0] * x + dirs[k][1] * y) + dirs[k][2] * z;
-            lo[3 + k]      = fmin(lo[3 + k], v);
-            hi[3 + k]      = fmax(hi[3 + k], v);
-          }
-        }
-#pragma unroll
-        for (int k = 0; k < 13; ++k)
-          for (int d = 32; d >= 1; d >>= 1) {
-            lo[k] = fmin(lo[k], __shfl_xor(lo[k], d, 64));
-            hi[k] = fmax(hi[k], __shfl_xor(hi[k], d, 64));
-          }
-        for (int k = 0; k < 3; ++k) {
-          boxA[k]     = lo[k];
-          boxA[3 + k] = hi[k];
-        }
-#pragma unroll
-        for (int k = 0; k < 10; ++k) {
-          prA[k][0] = lo[3 + k];
-          prA[k][1] = hi[3 + k];
-        }
-      }
-      // one lane per record decides whether the pair needs the full test; the few that do go through it one at a
-      // time, in record order (first unsafe pair ends the check, as the sequential loop did)
-      for (int i0 = 0; i0 < n_swarm && safe; i0 += 64) {
-        const int  i    = i0 + lane;
-        const bool need = i < n_swarm && deconflict_prefilter(sA, nA, boxA, prA, swarm[i], ego, now);
-        unsigned long long m = __ballot(need);
-        bool               lp_ran = false;
-        while (m != 0 && safe) {
-          const int j = __builtin_ctzll(m);
-          m &= m - 1;
-          if (deconflict_pair_unsafe(ca, M, swarm[i0 + j], ego, now, s_lp, s_rows, s_perm, counters)) safe = 0;
-          lp_ran = true;
-        }
-        if (lp_ran && safe && i0 + 64 < n_swarm) stage_A();  // the LP used the scratch that held set A
-      }
-    }
-#ifdef SOGM_FLOW_DEBUG
-    if (lane == 0) out_safe[a] = 101;
-#else
-    if (lane == 0 && out_safe) out_safe[a] = safe;
-#endif
-    // BezierTraj record (plan_manager.cpp:364-399); n_pieces = 0 marks "replan() returned false".
-    // Publication (sogm_planner_set_publish): a successful replan's record also goes — in the same stores — into
-    // the host's own table (latest wins; a failed replan keeps executing the previous trajectory, :176-196) and the
-    // agent's current record into the next tick's swarm table, HERE, where the stores overlap with the other agents'
-    // chains, instead of in a store-heavy kernel after the replan (beside the streaming clear that kernel took 2 ms).
-    const bool      good = solved && safe != 0;
-    SogmTrajRecord *dst[3] = {out + a, (good && pub_own) ? pub_own + a : nullptr,
-                              (good && pub_own && pub_table) ? pub_table + a : nullptr};
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      SogmTrajRecord *r = dst[k];
-      if (!r) continue;  // wave-uniform
-      for (int i = lane; i < SOGM_MAX_PIECES; i += 64) r->duration[i] = (good && i < M) ? corridor_tau : 0.0;
-      for (int i = lane; i < SOGM_MAX_PIECES * 15; i += 64)
-        r->cpts[i] = (good && i < M * 15) ? cpts[(size_t)a * SOGM_MAX_PIECES * 15 + i] : 0.0;
-      if (lane == 0) {
-        r->drone_id   = drone_ids[a];
-        r->time_start = t_start[a];
-        r->n_pieces   = good ? M : 0;
-      }
-    }
-    if (!good && pub_own && pub_table) {  // the table still lists the trajectory the agent goes on executing
-      constexpr int W   = (int)(sizeof(SogmTrajRecord) / 16);
-      const uint4  *src = reinterpret_cast<const uint4 *>(pub_own + a);
-      uint4        *t   = reinterpret_cast<uint4 *>(pub_table + a);
-      for (int w = lane; w < W; w += 64) t[w] = src[w];
-    }
-    if (lane == 0) out_ok[a] = good ? 1 : 0;
+    const int  code = finish_agent(f, a, s_lp, s_rows, s_perm, lane);
+    const bool safe = (code & 1) != 0;
     if (fc.p_ready) {  // the agent's record is final: hand it to the pre-stamp
       __threadfence();
       if (lane == 0) {
@@ -2151,20 +2160,108 @@ __global__ __launch_bounds__(64) void k_finish_flow(FlowCtl fc, double corridor_
     }
     if (lane == 0) {
       fc.ts[a * 8 + 6] = wall_clock64();
-      if (counters) {
-        int k = SOGM_CNT_REPLAN_OK;
-        if (ret[a] == 0) k = SOGM_CNT_FAIL_SEARCH;
-        else if (M <= 0) k = SOGM_CNT_FAIL_CORRIDOR;
-        else if (!(status[a] == 1 || status[a] == 2)) k = SOGM_CNT_FAIL_QP;
-        else if (!safe) k = SOGM_CNT_FAIL_UNSAFE;
-#ifdef SOGM_FLOW_DEBUG
-        out_safe[a] = 103;
-#endif
-        atomicAdd(&counters[k], 1ull);
-#ifdef SOGM_FLOW_DEBUG
-        out_safe[a] = 104;
-#endif
+      finish_count(f, a, safe);
+    }
+  }
+}
+
+// Flight kernel L (sogm_flight_run): role-less one-wave workgroups over the flight's two light queues.  A wave claims —
+// without blocking: only tickets of published items are handed out — a finish item first (short, and it releases the
+// agent's next tick), else a corridor segment ticket; with neither it naps.  Corridor tickets: 16 per (agent, tick) as in
+// k_corridor_flow, the wave that completes an agent's last segment slot finalises its corridors and queues the QP.  Finish
+// items: finish_agent against table ver(k - 2), the record into ver(k) and the flight log, then the tick's accounting and
+// the agent's next map item.  The launch ends when every finish item has been claimed.
+__global__ __launch_bounds__(64) void k_flight_light(MapView m, SogmPlannerParams pp, CorridorWorkspace ws, FlightCtl fl,
+                                                     FlightLightDev d) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane  = threadIdx.x;
+  const int total = fl.n_agents * fl.n_ticks;
+  int       naps  = 0;
+  for (;;) {
+    if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&fl.hdr[FL_ERR], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0) break;
+    // ---- finish ----
+    int t = fl_try_claim(&fl.hdr[FL_F_TICKET], &fl.hdr[FL_F_READY], 1);
+    if (t >= 0) {
+      const int a = fl_wait_item(fl.f_ring, fl.ring_mask, t, &fl.hdr[FL_ERR]);
+      if (a < 0) break;
+      __threadfence();
+      const int k  = fl.tick_of[a];
+      const int kl = k - fl.first_tick;
+      FinishArgs f = d.fin;
+      f.swarm      = d.tables ? d.tables + (size_t)((k - 2) & 3) * d.n_total : nullptr;
+      f.pub_table  = d.tables ? d.tables + (size_t)(k & 3) * d.n_total + d.agent0 : nullptr;
+      f.out        = d.log_records + (size_t)kl * fl.n_agents;
+      f.out_ok     = d.log_ok + (size_t)kl * fl.n_agents;
+      double *s_lp = (double *)smem, *s_rows = s_lp + LP_WORK_DOUBLES;
+      int    *s_perm = (int *)(s_rows + LP_MAX_ROWS * 5);
+      const int code = finish_agent(f, a, s_lp, s_rows, s_perm, lane);
+      __syncthreads();
+      __threadfence();  // the record (own, ver(k), log) is out before the tick counts as finished
+      if (lane == 0) {
+        const long long now = wall_clock64();
+        long long      *ts  = fl.ts + (size_t)a * 12, *acc = fl.acc + (size_t)a * 8;
+        ts[6]               = now;
+        acc[0] += ts[9] - ts[8];    // gate wait
+        acc[1] += ts[11] - ts[9];   // map: reset + stamp + overlay
+        acc[2] += ts[1] - ts[11];   // search queue + A*
+        acc[3] += ts[3] - ts[1];    // corridor queue + corridors
+        acc[4] += ts[5] - ts[3];    // QP queue + QP
+        acc[5] += now - ts[5];      // finish queue + finish
+        acc[6] += now - ts[8];      // the whole chain
+        acc[7] += 1;
+        finish_count(f, a, (code & 1) != 0);
+        __hip_atomic_fetch_add(&fl.tick_done[kl], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        atomicAdd(&fl.hdr[FL_FINISHED], 1);
+        if (kl + 1 < fl.n_ticks) {  // the agent's next tick: its map item
+          fl.tick_of[a] = k + 1;
+          fl_publish(fl.m_ring, fl.ring_mask, &fl.hdr[FL_M_READY], a);
+        }
       }
+      naps = 0;
+      continue;
+    }
+    // ---- corridor segment ----
+    t = fl_try_claim(&fl.hdr[FL_C_TICKET], &fl.hdr[FL_A_READY], SOGM_MAX_PIECES);
+    if (t >= 0) {
+      const int agent = fl_wait_item(fl.a_ring, fl.ring_mask, t / SOGM_MAX_PIECES, &fl.hdr[FL_ERR]);
+      if (agent < 0) break;
+      __threadfence();
+      const int seg = t % SOGM_MAX_PIECES;
+      if (seg == 0 && lane == 0) fl.ts[agent * 12 + 2] = wall_clock64();
+      if (seg < d.route_len[agent] - 1) {
+        corridor_points_body<1>(m, pp, ws, d.start_pva, d.t_start, d.route, d.route_len, d.route_cap, agent, seg);
+        __threadfence_block();
+        __syncthreads();
+      }
+      corridor_segment_body<6, false>(m, pp, ws, d.start_pva, d.t_start, d.route, d.route_len, d.route_cap, agent, seg, smem,
+                                      FiriDirect{});
+      __syncthreads();
+      __threadfence();
+      const int last = (flow_ticket(&fl.seg_done[agent]) & (SOGM_MAX_PIECES - 1)) == SOGM_MAX_PIECES - 1;
+      if (last) {
+        __threadfence();
+        double       *s_lp   = (double *)smem;
+        double       *s_rows = s_lp + LP_WORK_DOUBLES;
+        int          *s_perm = (int *)(s_rows + LP_MAX_ROWS * 5);
+        SolverScratch sc{s_lp, s_perm, s_rows, nullptr};
+        corridor_finalize_body(pp, ws, d.start_pva, d.route, d.route_len, d.route_cap, d.out_polys, d.out_nfaces, d.out_npoly,
+                               d.out_goal, agent, sc);
+        __syncthreads();
+        if (lane == 0) {
+          fl.ts[agent * 12 + 3] = wall_clock64();
+          fl_publish(fl.q_ring, fl.ring_mask, &fl.hdr[FL_Q_READY], agent);
+        }
+      }
+      __syncthreads();
+      naps = 0;
+      continue;
+    }
+    // ---- nothing to claim: done, or nap ----
+    if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&fl.hdr[FL_F_TICKET], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >= total) break;
+    flow_pause();
+    if (++naps > 400000) {  // ~3 s of naps with nothing to claim: the flight is stuck
+      if (lane == 0) atomicExch(&fl.hdr[FL_ERR], 13);
+      break;
     }
   }
 }
@@ -2258,9 +2355,15 @@ int launch_finish_flow(const FlowCtl &fc, int n_agents, int n_workgroups, double
                        unsigned long long *counters, hipStream_t st, SogmTrajRecord *pub_own,
                        SogmTrajRecord *pub_table) {
   const size_t lds = sizeof(double) * (LP_WORK_DOUBLES + LP_MAX_ROWS * 5) + sizeof(int) * LP_MAX_ROWS;
-  hipLaunchKernelGGL(k_finish_flow, dim3(n_workgroups), dim3(64), lds, st, fc, corridor_tau, ret, npoly, status,
-                     cpts, swarm, n_swarm, swarm_ego, swarm_now, t_start, drone_ids, out, out_ok, out_safe, counters,
-                     n_agents, pub_own, pub_table);
+  const FinishArgs f{corridor_tau, ret, npoly, status, cpts, swarm, n_swarm, swarm_ego, swarm_now, t_start, drone_ids,
+                     out, out_ok, out_safe, counters, pub_own, pub_table};
+  hipLaunchKernelGGL(k_finish_flow, dim3(n_workgroups), dim3(64), lds, st, fc, f, n_agents);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int launch_flight_light(const MapView &m, const SogmPlannerParams &pp, const CorridorWorkspace &ws, const FlightCtl &fl,
+                        const FlightLightDev &d, int n_workgroups, hipStream_t st) {
+  hipLaunchKernelGGL(k_flight_light, dim3(n_workgroups), dim3(64), corridor_segment_lds(pp.pc_capacity), st, m, pp, ws, fl, d);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

@@ -348,7 +348,16 @@ __device__ inline void bezier_pos(const SogmTrajRecord &r, double t, double out[
   X(PRESTAMP_STREAM, "prestamp_stream", 1, 0, 1) /* pre-stamp on a stream of its own behind its target grid's reset EVENT; 0 = on the resets' stream */ \
   X(PRESTAMP_LATE_AGENTS, "prestamp_late_agents", 8, 0, 65536)  /* the last agents to be published get finer tickets ...     */  \
   X(PRESTAMP_LATE_BITS, "prestamp_late_bits", 128, 0, 4096)    /* ... this many for the bits pass                           */  \
-  X(PRESTAMP_LATE_MARKS, "prestamp_late_marks", 256, 0, 4096)  /* ... and for the marks pass                                */
+  X(PRESTAMP_LATE_MARKS, "prestamp_late_marks", 256, 0, 4096)  /* ... and for the marks pass                                */  \
+  X(FLIGHT_QP_UNITS, "flight_qp_units", 4, 1, 13)          /* flight: 16-CU units of the QP kernel                            */  \
+  X(FLIGHT_SEARCH_UNITS, "flight_search_units", 2, 1, 13)  /* flight: ... of the search kernel                                */  \
+  X(FLIGHT_MAP_UNITS, "flight_map_units", 4, 1, 13)        /* flight: ... of the map kernel (corridor + finish: the rest)     */  \
+  X(FLIGHT_MASKS, "flight_masks", 1, 0, 1)                 /* flight: streams with compute-unit masks                         */  \
+  X(FLIGHT_SPEC, "flight_spec", 1, 0, 1)                   /* flight: both search attempts side by side                       */  \
+  X(FLIGHT_RESET, "flight_reset", 8, 1, 256)               /* flight: one-wave tickets per agent-tick, sparse reset           */  \
+  X(FLIGHT_BITS, "flight_bits", 16, 1, 256)                /* flight: ... occupancy bits                                      */  \
+  X(FLIGHT_MARKS, "flight_marks", 32, 1, 256)              /* flight: ... marks                                               */  \
+  X(FLIGHT_SPLAT, "flight_splat", 4, 1, 64)                /* flight: ... neighbour overlay                                   */
 enum {
 #define X(id, name, dflt, lo, hi) SOGM_TUNE_##id,
   SOGM_TUNING_TABLE(X)

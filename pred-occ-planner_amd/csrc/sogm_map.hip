@@ -1323,6 +1323,159 @@ extern "C" int sogm_debug_prestamp_prof(unsigned long long *out12_host, int rese
 }
 namespace sogm {
 #endif
+// ------------------------------------------------------------------------------------------------
+// Flight kernel M (sogm_flight_run; the flight is described in sogm_planner.hpp): an agent's map of its next tick, built
+// the moment the agent's previous tick is finished.  Per (agent, tick) one item of 1 + n_reset + n_bits + n_marks +
+// n_splat one-wave tickets, handed out in order (a ticket only ever waits for lower tickets of its item, or — the head — for
+// the swarm's tick k - 2):
+//   head    gate "every agent has finished tick k - 2" (the staleness rule's other half: table ver(k - 2) is complete);
+//           start state / map centre / stamp of tick k from the agent's executed record (k_tick_inputs' rule);
+//           candidate cylinders and cloud blocks of frame k around the new centre
+//   reset   the agent's grid back to zero through its mark log (k_reset_sectors' 2-lanes-per-sector form; an overflowed
+//           log: the whole grid), then the log restarts
+//   bits    occupancy bits of slice 0 from the listed cloud blocks
+//   marks   slice 0 + T - 1 future marks per occupied voxel, logged
+//   splat   the neighbours' records of table ver(k - 2), logged -> the agent goes to the search queue
+// Same device functions as the per-tick kernels: same cells.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void flight_reset_ticket(char *__restrict__ base, size_t agent_bytes, const unsigned *__restrict__ e,
+                                                    unsigned n, int cap, int first, int stride, int lane,
+                                                    unsigned long long *__restrict__ stat) {
+  const vfloat4 z = {0.f, 0.f, 0.f, 0.f};
+  if (n > (unsigned)cap) {  // overflowed log: this ticket's share of the whole grid (agent_bytes is a multiple of 32)
+    const size_t nv = agent_bytes / 16;
+    for (size_t i = (size_t)first * 64 + lane; i < nv; i += (size_t)stride * 64)
+      __builtin_nontemporal_store(z, reinterpret_cast<vfloat4 *>(base) + i);
+    return;
+  }
+  const int part = lane & 1, pair = lane >> 1;
+  unsigned  n_lines = 0;
+  for (size_t i0 = (size_t)first * 32; i0 < n; i0 += (size_t)stride * 32) {  // 32 entries per trip, two lanes each
+    const size_t   i    = i0 + pair;
+    const unsigned sct  = i < n ? e[i] : 0xFFFFFFFFu;
+    const unsigned prev = __shfl_up(sct, 2);
+    if (sct == 0xFFFFFFFFu || (pair > 0 && prev == sct)) continue;
+    const size_t off = (size_t)sct * 32 + 16 * part;
+    if (off + 16 <= agent_bytes) *reinterpret_cast<vfloat4 *>(base + off) = z;
+    if (part == 0) ++n_lines;
+  }
+  if (stat) {
+    for (int d = 32; d >= 1; d >>= 1) n_lines += (unsigned)__shfl_xor((int)n_lines, d, 64);
+    if (lane == 0 && n_lines) atomicAdd(stat + 2, (unsigned long long)n_lines * 32ull);
+  }
+}
+__global__ __launch_bounds__(64) void k_flight_map(GridGeom g, FlightCtl fl, FlightMapDev d, unsigned long long *reset_stat) {
+  __shared__ __attribute__((aligned(16))) SogmTrajRecord s_rec;
+  __shared__ double                                      s_hov[9];
+  __shared__ __attribute__((aligned(16))) CylCand        s_cand[PRESTAMP_CAND_LDS];
+  const int lane = threadIdx.x;
+  const int A    = fl.n_agents;
+  const int n_r = d.n_reset, n_b = d.n_bits, n_m = d.n_marks, n_s = d.n_splat;
+  const int per   = 1 + n_r + n_b + n_m + n_s;      // tickets per item
+  const int S     = per + 1;                        // stage counts per item (+1: the log restart between the two groups)
+  const int total = A * fl.n_ticks * per;
+  int      *err   = &fl.hdr[FL_ERR];
+  for (;;) {
+    const int t = flow_ticket(&fl.hdr[FL_M_TICKET]);
+    if (t >= total) break;
+    const int agent = fl_wait_item(fl.m_ring, fl.ring_mask, t / per, err);
+    if (agent < 0) break;
+    __threadfence();
+    const int          s    = t % per;
+    const int          k    = fl.tick_of[agent], kl = k - fl.first_tick;
+    const int          base = kl * S;
+    const FlightWorld &w    = d.worlds[kl];
+    long long         *ts   = fl.ts + (size_t)agent * 12;
+    CloudBlocks        cb   = d.cb;
+    cb.bounds = w.bounds;
+    cb.n_blocks = w.n_blocks;
+    cb.block_points = w.block_points;
+    cb.n_points = w.n_points;
+    char          *gbase = reinterpret_cast<char *>(d.grid) + (size_t)agent * d.agent_bytes;
+    const unsigned *lent = d.lg.entries + (size_t)agent * d.lg.cap;
+    if (s == 0) {
+      // ---- head ----
+      if (lane == 0) ts[8] = wall_clock64();
+      if (kl >= 2 && flow_wait_count(&fl.tick_done[kl - 2], A, err)) break;
+      if (lane == 0) ts[9] = wall_clock64();
+      constexpr int W   = (int)(sizeof(SogmTrajRecord) / 16);
+      const uint4  *src = reinterpret_cast<const uint4 *>(d.own + agent);
+      uint4        *dst = reinterpret_cast<uint4 *>(&s_rec);
+      for (int q = lane; q < W; q += 64) dst[q] = src[q];
+      if (lane < 9) s_hov[lane] = d.hover[agent * 9 + lane];
+      __syncthreads();
+      const double stamp = d.t0 + k * d.period;
+      if (lane == 0) {
+        tick_inputs_agent(s_rec, s_hov, agent, stamp, d.start_offset, d.hover, d.now, d.t_start, d.pva, d.poses);
+        d.stamps[agent] = stamp;
+      }
+      __threadfence();
+      __syncthreads();
+      cull_agent(g, w.cyl, w.n_cyl, d.poses[agent * 3], d.poses[agent * 3 + 1],
+                 (CylCand *)d.cand + (size_t)agent * SOGM_MAX_CYL_LDS, d.n_cand + agent, lane);
+      cull_blocks_agent(g, cb, agent, d.poses[agent * 3], d.poses[agent * 3 + 1], lane);
+      __threadfence();
+      if (lane == 0) atomicAdd(&fl.stage[agent], 1);
+      continue;
+    }
+    const int g1 = base + 1, g2 = g1 + n_r + n_b + 1, g3 = g2 + n_m;
+    if (s < 1 + n_r + n_b) {
+      // ---- reset / bits (both behind the head; neither touches what the other writes) ----
+      if (flow_wait_count(&fl.stage[agent], g1, err)) break;
+      if (s < 1 + n_r) {
+        const unsigned n = d.lg.n[agent];
+        if (s == 1 && lane == 0 && reset_stat) {
+          atomicAdd(reset_stat, (unsigned long long)(n > (unsigned)d.lg.cap ? (unsigned)d.lg.cap : n));
+          if (agent == 0) atomicAdd(reset_stat + 1, 1ull);
+        }
+        flight_reset_ticket(gbase, d.agent_bytes, lent, n, d.lg.cap, s - 1, n_r, lane, reset_stat);
+      } else {
+        stamp_bits_blocks(g, w.cloud, cb, agent, s - 1 - n_r, n_b, d.poses[agent * 3], d.poses[agent * 3 + 1],
+                          d.poses[agent * 3 + 2], d.bits + (size_t)agent * d.words, lane);
+      }
+      __threadfence();
+      int last = 0;
+      if (lane == 0) last = atomicAdd(&fl.stage[agent], 1) + 1 == g1 + n_r + n_b;
+      if (__builtin_amdgcn_readfirstlane(last)) {  // the group is complete: the log restarts, then the marks may append
+        if (lane == 0) {
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          d.lg.n[agent] = 0u;
+          __threadfence();
+          atomicAdd(&fl.stage[agent], 1);
+        }
+      }
+      continue;
+    }
+    if (s < 1 + n_r + n_b + n_m) {
+      // ---- marks ----
+      if (flow_wait_count(&fl.stage[agent], g2, err)) break;
+      stamp_marks_trips(g, d.grid, d.bits, d.words, w.cyl, w.n_cyl, d.poses, (const CylCand *)d.cand, d.n_cand, agent, d.lg,
+                        (s - 1 - n_r - n_b) * 256, n_m * 256, s_cand, PRESTAMP_CAND_LDS);
+      __syncthreads();  // (the next ticket's staging overwrites s_cand)
+      __threadfence();
+      if (lane == 0 && atomicAdd(&fl.stage[agent], 1) + 1 == g3) ts[10] = wall_clock64();
+      continue;
+    }
+    // ---- overlay of the neighbours' records of table ver(k - 2) ----
+    if (flow_wait_count(&fl.stage[agent], g3, err)) break;
+    if (d.tables && d.n_total > 0) {
+      const SogmTrajRecord *tab = d.tables + (size_t)((k - 2) & 3) * d.n_total;
+      const int items = d.n_total * g.T;
+      for (int i = (s - 1 - n_r - n_b - n_m) * 64 + lane; i < items; i += n_s * 64)
+        splat_item(g, d.grid, tab[i / g.T], agent, i % g.T, d.ego_ids, d.poses, d.stamps, d.body, d.n_body, d.lg);
+    }
+    __threadfence();
+    if (lane == 0 && atomicAdd(&fl.stage[agent], 1) + 1 == base + S) {  // the agent's map of tick k is complete
+      ts[11] = wall_clock64();
+      fl_publish(fl.s_ring, fl.ring_mask, &fl.hdr[FL_S_READY], agent);
+    }
+  }
+}
+int launch_flight_map(const GridGeom &g, const FlightCtl &fl, const FlightMapDev &d, int n_workgroups, hipStream_t st) {
+  hipLaunchKernelGGL(k_flight_map, dim3(n_workgroups), dim3(64), 0, st, g, fl, d, d.reset_stat);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 int launch_prestamp_flow(const GridGeom &g, const FlowCtl &fc, const PrestampDev &ps, int n_workgroups, int n_qp,
                          int n_finish, hipStream_t st) {
   hipLaunchKernelGGL(k_prestamp_gate, dim3(1), dim3(64), 0, st, fc.hdr, ps.gate_agents, n_qp, n_finish);

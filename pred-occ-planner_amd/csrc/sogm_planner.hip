@@ -295,6 +295,20 @@ void sogm_planner_destroy(sogm_planner *p) {
     if (p->ev_fdone[k]) (void)hipEventDestroy(p->ev_fdone[k]);
   }
   if (p->peek) (void)hipStreamDestroy(p->peek);
+  for (int k = 0; k < 4; ++k) {
+    if (p->fl_stream[k]) {
+      (void)hipStreamSynchronize(p->fl_stream[k]);
+      (void)hipStreamDestroy(p->fl_stream[k]);
+    }
+    if (p->fl_ev_done[k]) (void)hipEventDestroy(p->fl_ev_done[k]);
+  }
+  if (p->fl_ev_in) (void)hipEventDestroy(p->fl_ev_in);
+  if (p->h_fl_worlds) (void)hipHostFree(p->h_fl_worlds);
+  {
+    void *fp[] = {p->d_fl, p->d_fl_worlds, p->d_fl_pva, p->d_fl_tstart, p->d_fl_now, p->fl.ts, p->fl.acc};
+    for (void *q : fp)
+      if (q) (void)hipFree(q);
+  }
   if (p->ev_gate) (void)hipEventDestroy(p->ev_gate);
   if (p->ev_pdone) (void)hipEventDestroy(p->ev_pdone);
   if (p->h_flow_fail) (void)hipHostFree(p->h_flow_fail);
@@ -897,6 +911,281 @@ static int replan_impl(sogm_planner *p, const double *start_pva, const double *g
     SOGM_HIP_CHECK(hipEventRecord(p->ev_done[g], st));
     SOGM_HIP_CHECK(hipStreamWaitEvent(main, p->ev_done[g], 0));  // fan in
   }
+  return SOGM_OK;
+}
+
+
+}  // extern "C"
+// ---------------------------------------------------------------------------------------------------------------
+// sogm_flight_run (the flight is described in sogm_planner.hpp / sogm_abi.h)
+// ---------------------------------------------------------------------------------------------------------------
+// control block back to its start values: header / rings / counters 0, every agent's first map item published in agent
+// order, tick_of = first_tick, verdicts 0 (their tags are absolute tick numbers), the flight's log cleared (an agent-tick
+// that does not complete reports ok = 0 and an empty record)
+__global__ __launch_bounds__(256) void k_flight_reset(FlightCtl fl, int n_words, int *verdict, long long *acc, int *log_words,
+                                                      long long n_log_words) {
+  const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x, step = (long long)gridDim.x * blockDim.x;
+  for (long long i = i0; i < n_words; i += step) fl.hdr[i] = 0;  // header, rings, tick_done, tick_of, seg_done, stage: one block
+  for (long long i = i0; i < n_log_words; i += step) log_words[i] = 0;
+  for (long long i = i0; i < fl.n_agents; i += step) verdict[i] = 0;
+  for (long long i = i0; i < 8ll * fl.n_agents; i += step) acc[i] = 0;
+}
+__global__ __launch_bounds__(256) void k_flight_seed(FlightCtl fl) {
+  const int a = blockIdx.x * blockDim.x + threadIdx.x;
+  if (a < fl.n_agents) {
+    fl.tick_of[a] = fl.first_tick;
+    fl.m_ring[a]  = (1 << 16) | a;
+  }
+  if (a == 0) fl.hdr[FL_M_READY] = fl.n_agents;
+}
+__global__ void k_flight_report(const int *__restrict__ hdr, int *__restrict__ host_words) {
+  const int e = hdr[FL_ERR];
+  if (e != 0) {
+    host_words[0] = 100 + e;
+    host_words[1] = host_words[1] + 1;
+  }
+}
+
+// the 16-CU unit of a mask bit: two CUs per XCD whether bit i names XCD i / 32 or XCD i % 8 (tools/micro/cumask.hip)
+static int flight_unit_of(int i) { return ((i / 8) % 4) * 4 + ((i / 32 + i % 8) % 4); }
+
+static int flight_setup(sogm_planner *p) {
+  sogm_ctx *c = p->map;
+  const int A = c->n_agents;
+  if (p->d_fl) return SOGM_OK;
+  int ring = 1;
+  while (ring < 2 * A) ring <<= 1;
+  if (A >= (1 << 16)) return SOGM_ERR_INVALID_ARG;
+  const size_t words = FL_HDR + 5 * (size_t)ring + FLIGHT_MAX_TICKS + 3 * (size_t)A;
+  SOGM_HIP_CHECK(hipMalloc((void **)&p->d_fl, sizeof(int) * words));
+  int *q          = p->d_fl;
+  p->fl.hdr       = q;              q += FL_HDR;
+  p->fl.m_ring    = q;              q += ring;
+  p->fl.s_ring    = q;              q += ring;
+  p->fl.a_ring    = q;              q += ring;
+  p->fl.q_ring    = q;              q += ring;
+  p->fl.f_ring    = q;              q += ring;
+  p->fl.tick_done = q;              q += FLIGHT_MAX_TICKS;
+  p->fl.tick_of   = q;              q += A;
+  p->fl.seg_done  = q;              q += A;
+  p->fl.stage     = q;
+  p->fl.ring_mask = ring - 1;
+  p->fl.n_agents  = A;
+  SOGM_HIP_CHECK(hipMalloc((void **)&p->fl.ts, sizeof(long long) * 12 * (size_t)A));
+  SOGM_HIP_CHECK(hipMalloc((void **)&p->fl.acc, sizeof(long long) * 8 * (size_t)A));
+  SOGM_HIP_CHECK(hipMemset(p->fl.ts, 0, sizeof(long long) * 12 * (size_t)A));
+  SOGM_HIP_CHECK(hipMemset(p->fl.acc, 0, sizeof(long long) * 8 * (size_t)A));
+  SOGM_HIP_CHECK(hipMalloc((void **)&p->d_fl_worlds, sizeof(FlightWorld) * FLIGHT_MAX_TICKS));
+  SOGM_HIP_CHECK(hipHostMalloc((void **)&p->h_fl_worlds, sizeof(FlightWorld) * FLIGHT_MAX_TICKS, hipHostMallocDefault));
+  SOGM_HIP_CHECK(hipMalloc((void **)&p->d_fl_pva, sizeof(double) * 9 * (size_t)A));
+  SOGM_HIP_CHECK(hipMalloc((void **)&p->d_fl_tstart, sizeof(double) * (size_t)A));
+  SOGM_HIP_CHECK(hipMalloc((void **)&p->d_fl_now, sizeof(double) * (size_t)A));
+  // the four streams and their compute units: QP, search, map take flight_*_units units of 16 CUs, corridor + finish
+  // the rest; workgroups = what the partition holds at once (every workgroup of a flight kernel is resident from the
+  // start: nothing waits for a workgroup that is not running)
+  int n_cu = 256;
+  (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->device);
+  const int units_total = 16;
+  int       u[4] = {c->tune_i(SOGM_TUNE_FLIGHT_QP_UNITS), c->tune_i(SOGM_TUNE_FLIGHT_SEARCH_UNITS), 0,
+                    c->tune_i(SOGM_TUNE_FLIGHT_MAP_UNITS)};
+  u[2] = units_total - u[0] - u[1] - u[3];
+  if (u[2] < 1) {
+    sogm::set_error_text("sogm_flight_run: flight_qp_units + flight_search_units + flight_map_units must leave a unit for the corridor kernel");
+    return SOGM_ERR_INVALID_ARG;
+  }
+  const bool masks = c->tune_i(SOGM_TUNE_FLIGHT_MASKS) != 0;
+  int        first_unit = 0;
+  for (int k = 0; k < 4; ++k) {
+    uint32_t mask[16] = {0};
+    int      cus = 0;
+    for (int i = 0; i < n_cu && i < 512; ++i) {
+      const int un = flight_unit_of(i);
+      if (un >= first_unit && un < first_unit + u[k]) {
+        mask[i / 32] |= 1u << (i % 32);
+        ++cus;
+      }
+    }
+    first_unit += u[k];
+    p->fl_cus[k] = cus;
+    if (masks)
+      SOGM_HIP_CHECK(hipExtStreamCreateWithCUMask(&p->fl_stream[k], (uint32_t)((n_cu + 31) / 32), mask));
+    else
+      SOGM_HIP_CHECK(hipStreamCreateWithFlags(&p->fl_stream[k], hipStreamNonBlocking));
+    SOGM_HIP_CHECK(hipEventCreateWithFlags(&p->fl_ev_done[k], hipEventDisableTiming));
+  }
+  SOGM_HIP_CHECK(hipEventCreateWithFlags(&p->fl_ev_in, hipEventDisableTiming));
+  p->fl_wgs[0] = p->fl_cus[0];      // one QP workgroup per CU (a whole CU's LDS and registers)
+  p->fl_wgs[1] = p->fl_cus[1];      // one search workgroup per CU (124 KB of LDS)
+  p->fl_wgs[2] = 4 * p->fl_cus[2];  // corridor / finish waves: 39.8 KB of LDS, one per SIMD
+  p->fl_wgs[3] = 8 * p->fl_cus[3];  // map waves: two per SIMD
+  SOGM_HIP_CHECK(hipStreamSynchronize(nullptr));
+  return SOGM_OK;
+}
+
+extern "C" {
+int sogm_flight_run(sogm_planner *p, const SogmFlight *f, void *stream) {
+  if (!p || !f || f->n_ticks < 1 || f->n_ticks > FLIGHT_MAX_TICKS || f->first_tick < 0 || !f->worlds || !f->goals ||
+      !f->drone_ids || !f->hover_inout || !f->own_inout || !f->tables || !f->log_records || !f->log_ok || !(f->period > 0))
+    return SOGM_ERR_INVALID_ARG;
+  sogm_ctx *c = p->map;
+  const int A = c->n_agents;
+  if (f->n_total != A || f->agent0 != 0) {
+    sogm::set_error_text("sogm_flight_run: single process only (n_total == n_agents, agent0 == 0)");
+    return SOGM_ERR_INVALID_ARG;
+  }
+  if (!p->flow || !c->sparse || !c->d_body || c->n_body <= 0) return SOGM_ERR_STATE;
+  SOGM_HIP_CHECK(hipSetDevice(c->device));
+  hipStream_t main = (hipStream_t)stream;
+  if (int rc = sogm::join_prestamp(c, main)) return rc;
+  if (int rc = sogm::join_exchange(c, main)) return rc;
+  if (int rc = flight_setup(p)) return rc;
+  const size_t agent_bytes = (size_t)c->spec.T * (size_t)c->geom.V * c->cell_bytes();
+  if (agent_bytes % 32 != 0 || (reinterpret_cast<uintptr_t>(c->d_grid) & 31) != 0) {
+    sogm::set_error_text("sogm_flight_run: agent grids must be 32-byte aligned (V * T * cell bytes a multiple of 32)");
+    return SOGM_ERR_INVALID_ARG;
+  }
+  int max_blocks = 0;
+  for (int i = 0; i < f->n_ticks; ++i) {
+    const SogmWorld &w = f->worlds[i];
+    if (!w.cloud_xyz || !w.block_bounds || w.n_points < 0 || w.block_points < 64 || w.block_points > 4096 ||
+        w.n_blocks != (w.n_points + w.block_points - 1) / w.block_points || w.n_cyl < 0 || (w.n_cyl > 0 && !w.cylinders))
+      return SOGM_ERR_INVALID_ARG;
+    if (w.n_blocks > max_blocks) max_blocks = w.n_blocks;
+    p->h_fl_worlds[i] = FlightWorld{w.cloud_xyz, w.block_bounds, w.cylinders, w.n_points, w.n_blocks, w.block_points, w.n_cyl};
+  }
+  sogm::FlightMapDev md{};
+  {
+    SogmWorld big = f->worlds[0];  // (only its block count sizes the lists)
+    big.n_blocks  = max_blocks;
+    big.n_points  = max_blocks * big.block_points;
+    if (int rc = sogm::world_blocks(c, &big, &md.cb)) return rc;
+    md.cb.n_blocks = max_blocks;  // the row length of the lists for every frame of the flight
+  }
+  // the agent's single grid of the flight is the context's current one; it must be covered by its mark log
+  const int slot = sogm::cur_slot(c);
+  if (c->precleared && c->overlap >= 2) {  // (a pooled tick path left a spare grid queued: nothing to adopt here)
+  }
+  if (!c->tracked[slot] || !sogm::mark_log(c, slot).entries) {
+    if (int rc = sogm::launch_clear(c, main, c->d_grid, false)) return rc;  // dense, once; restarts the log
+    if (!c->tracked[slot]) {
+      sogm::set_error_text("sogm_flight_run: the current grid has no mark log (sogm_set_sparse_reset)");
+      return SOGM_ERR_STATE;
+    }
+  }
+  int words = 0;
+  {
+    sogm::PrestampDev tmp{};
+    if (int rc = sogm::prestamp_buffers(c, &tmp)) return rc;  // stamp scratch: bits, candidates
+    md.bits   = tmp.bits;
+    md.words  = tmp.words;
+    md.cand   = tmp.cand;
+    md.n_cand = tmp.n_cand;
+    words     = tmp.words;
+  }
+  (void)words;
+  FlightCtl fl   = p->fl;
+  fl.n_ticks     = f->n_ticks;
+  fl.first_tick  = f->first_tick;
+  md.grid        = (void *)c->d_grid;
+  md.worlds      = p->d_fl_worlds;
+  md.lg          = sogm::mark_log(c, slot);
+  md.own         = f->own_inout;
+  md.tables      = f->tables;
+  md.n_total     = f->n_total;
+  md.ego_ids     = f->drone_ids;
+  md.body        = c->d_body;
+  md.n_body      = c->n_body;
+  md.t0          = f->t0;
+  md.period      = f->period;
+  md.start_offset = f->replan_start_offset;
+  md.hover       = f->hover_inout;
+  md.now         = p->d_fl_now;
+  md.t_start     = p->d_fl_tstart;
+  md.pva         = p->d_fl_pva;
+  md.poses       = c->d_poses;
+  md.stamps      = c->d_stamps;
+  md.n_reset     = c->tune_i(SOGM_TUNE_FLIGHT_RESET);
+  md.n_bits      = c->tune_i(SOGM_TUNE_FLIGHT_BITS);
+  md.n_marks     = c->tune_i(SOGM_TUNE_FLIGHT_MARKS);
+  md.n_splat     = c->tune_i(SOGM_TUNE_FLIGHT_SPLAT);
+  md.agent_bytes = agent_bytes;
+  md.reset_stat  = c->d_reset_stat;
+  const MapView mv = view_of(c);
+  // frames + control block, in stream order on the caller's stream
+  SOGM_HIP_CHECK(hipMemcpyAsync(p->d_fl_worlds, p->h_fl_worlds, sizeof(FlightWorld) * (size_t)f->n_ticks, hipMemcpyHostToDevice, main));
+  const int       ring    = p->fl.ring_mask + 1;
+  const int       n_words = FL_HDR + 5 * ring + FLIGHT_MAX_TICKS + 3 * A;
+  const long long n_log   = (long long)f->n_ticks * A * (long long)(sizeof(SogmTrajRecord) / sizeof(int));
+  hipLaunchKernelGGL(k_flight_reset, dim3(256), dim3(256), 0, main, fl, n_words, p->aw.verdict, p->fl.acc,
+                     reinterpret_cast<int *>(f->log_records), n_log);
+  SOGM_HIP_CHECK(hipGetLastError());
+  SOGM_HIP_CHECK(hipMemsetAsync(f->log_ok, 0, sizeof(int32_t) * (size_t)f->n_ticks * A, main));
+  hipLaunchKernelGGL(k_flight_seed, dim3((A + 255) / 256), dim3(256), 0, main, fl);
+  SOGM_HIP_CHECK(hipGetLastError());
+  SOGM_HIP_CHECK(hipEventRecord(p->fl_ev_in, main));
+  for (int k = 0; k < 4; ++k) SOGM_HIP_CHECK(hipStreamWaitEvent(p->fl_stream[k], p->fl_ev_in, 0));
+  // QP first, then search (each wants whole CUs), then the one-wave kernels: with masks the order is immaterial
+  const int spec = c->tune_i(SOGM_TUNE_FLIGHT_SPEC) != 0 ? 1 : 0;
+  if (sogm::launch_flight_qp(p->pp, p->qs, p->qw, p->qc, fl, p->fl_wgs[0], p->d_fl_pva, p->d_goal, p->d_polys, p->d_nfaces,
+                             p->d_npoly, p->d_cpts, p->d_status, p->d_iters, p->fl_stream[0]) ||
+      sogm::launch_flight_search(mv, p->ap, p->pp.corridor_tau, astar_ws(p), fl, p->fl_wgs[1], p->d_fl_pva, f->goals,
+                                 p->d_fl_tstart, p->d_ret, p->d_route, p->d_route_len, p->route_cap, p->d_stats, spec,
+                                 p->fl_stream[1])) {
+    sogm::set_error("sogm_flight_run: launch", hipGetLastError());
+    (void)hipDeviceSynchronize();
+    return SOGM_ERR_HIP;
+  }
+  sogm::FlightLightDev ld{};
+  ld.start_pva   = p->d_fl_pva;
+  ld.t_start     = p->d_fl_tstart;
+  ld.route       = p->d_route;
+  ld.route_len   = p->d_route_len;
+  ld.route_cap   = p->route_cap;
+  ld.out_polys   = p->d_polys;
+  ld.out_nfaces  = p->d_nfaces;
+  ld.out_npoly   = p->d_npoly;
+  ld.out_goal    = p->d_goal;
+  ld.fin         = sogm::FinishArgs{p->pp.corridor_tau, p->d_ret, p->d_npoly, p->d_status, p->d_cpts, nullptr, f->n_total,
+                                    f->drone_ids, p->d_fl_now, p->d_fl_tstart, f->drone_ids, nullptr, nullptr, p->d_safe,
+                                    p->cw.counters, f->own_inout, nullptr};
+  ld.tables      = f->tables;
+  ld.n_total     = f->n_total;
+  ld.agent0      = f->agent0;
+  ld.log_records = f->log_records;
+  ld.log_ok      = f->log_ok;
+  if (sogm::launch_flight_light(mv, p->pp, p->cw, fl, ld, p->fl_wgs[2], p->fl_stream[2]) ||
+      sogm::launch_flight_map(c->geom, fl, md, p->fl_wgs[3], p->fl_stream[3])) {
+    sogm::set_error("sogm_flight_run: launch", hipGetLastError());
+    (void)hipDeviceSynchronize();
+    return SOGM_ERR_HIP;
+  }
+  for (int k = 0; k < 4; ++k) {
+    SOGM_HIP_CHECK(hipEventRecord(p->fl_ev_done[k], p->fl_stream[k]));
+    SOGM_HIP_CHECK(hipStreamWaitEvent(main, p->fl_ev_done[k], 0));
+  }
+  hipLaunchKernelGGL(k_flight_report, dim3(1), dim3(1), 0, main, (const int *)p->fl.hdr, p->h_flow_fail);
+  SOGM_HIP_CHECK(hipGetLastError());
+  c->updated             = 1;
+  c->cur_prestamped      = 0;
+  c->records_final_valid = 0;
+  c->n_stamps += f->n_ticks;
+  return SOGM_OK;
+}
+
+int sogm_flight_stats(sogm_planner *p, double *out_ms, int32_t *out_hdr) {
+  if (!p || !p->d_fl) return SOGM_ERR_INVALID_ARG;
+  SOGM_HIP_CHECK(hipSetDevice(p->map->device));
+  SOGM_HIP_CHECK(hipDeviceSynchronize());
+  const int A = p->map->n_agents;
+  if (out_ms) {
+    long long *tmp = new (std::nothrow) long long[8 * (size_t)A];
+    if (!tmp) return SOGM_ERR_INVALID_ARG;
+    const hipError_t e = hipMemcpy(tmp, p->fl.acc, sizeof(long long) * 8 * (size_t)A, hipMemcpyDeviceToHost);
+    for (int i = 0; i < 8 * A; ++i) out_ms[i] = (i % 8) == 7 ? (double)tmp[i] : (double)tmp[i] / 1.0e5;  // 100 MHz -> ms
+    delete[] tmp;
+    SOGM_HIP_CHECK(e);
+  }
+  if (out_hdr) SOGM_HIP_CHECK(hipMemcpy(out_hdr, p->fl.hdr, sizeof(int32_t) * FL_HDR, hipMemcpyDeviceToHost));
   return SOGM_OK;
 }
 

@@ -94,6 +94,159 @@ __device__ inline int flow_ticket(int *counter) {  // one ticket per wave, unifo
   return __builtin_amdgcn_readfirstlane(k);
 }
 #endif
+// ---------------------------------------------------------------------------------------------------------------
+// Flight (sogm_flight_run): n_ticks replan ticks of every agent in ONE set of launches, every agent on its own clock.
+// The reference's drones replan asynchronously, each reading whatever trajectories arrived last
+// (plan_manager/src/plan_manager.cpp:92-233, traj_coordinator/src/particles.cpp:179-190).  Here the RESULTS are
+// fixed by a staleness rule — agent a's tick k reads its own record of tick k - 1 and the neighbours' records as of
+// their tick k - 2 (table ver(k - 2)), and may start once every agent has finished tick k - 2 — and the SCHEDULE is free:
+// an agent whose chain is done goes straight on to its next tick while a straggler still solves its QP.
+// Four persistent kernels, each on a stream with its own compute units (hipExtStreamCreateWithCUMask: co-resident by
+// construction — no residency gates, no dispatch-order assumptions, four hardware queues):
+//   k_flight_map     one-wave workgroups: per (agent, tick) S tickets — head (gate on tick k - 2, start state from the own
+//                    record, cull of cylinders and cloud blocks of the tick's SogmWorld frame), sparse reset of the
+//                    agent's grid through its mark log, occupancy bits, marks, neighbour overlay -> s_ring
+//   k_flight_search  one workgroup per (agent, attempt) ticket: hybrid A* (both attempts side by side) -> a_ring
+//   k_flight_light   one-wave workgroups, role-less over two queues: finish (deconfliction, record, publication,
+//                    tick accounting, the agent's next item -> m_ring) before corridor segments (-> q_ring)
+//   k_flight_qp      one workgroup per CU: the Bezier QP -> f_ring
+// Hand-over: rings in HBM indexed by a monotonic position; a slot holds ((position / R + 1) << 16) | agent, so a reader
+// with ticket t takes its item when the slot's generation is t / R + 1 (R >= 2 A: an agent has one item in flight).
+// Per-agent buffers (start state, route, polytopes, control points, grid, mark log) are single: an agent's chain is
+// strictly sequential.  Swarm tables: a ring of four versions, ver(j) at slot j & 3.
+enum { FL_M_READY = 0, FL_M_TICKET, FL_S_READY, FL_S_TICKET, FL_A_READY, FL_C_TICKET, FL_Q_READY, FL_Q_TICKET,
+       FL_F_READY, FL_F_TICKET, FL_ERR, FL_FINISHED /* agent-ticks finished */, FL_HDR = 16 };
+#define FLIGHT_MAX_TICKS 64
+struct FlightWorld {  // one SogmWorld frame as the kernels read it
+  const float        *cloud, *bounds;
+  const SogmCylinder *cyl;
+  int                 n_points, n_blocks, block_points, n_cyl;
+};
+struct FlightCtl {
+  int *hdr;                                         // [FL_HDR]
+  int *m_ring, *s_ring, *a_ring, *q_ring, *f_ring;  // [ring_mask + 1] each
+  int  ring_mask;
+  int *tick_done;   // [FLIGHT_MAX_TICKS] agents that have finished tick first_tick + i
+  int *tick_of;     // [A] the tick the agent is in (absolute index)
+  int *seg_done;    // [A] cumulative corridor segment slots finished
+  int *stage;       // [A] cumulative map tickets finished
+  long long *ts;    // [A][12] stamps of the agent's current tick: 0 A* start, 1 A* done, 2 first corridor item, 3 corridors
+                    //         final, 4 QP start, 5 QP done, 6 finished, 7 -, 8 map head start, 9 gate passed, 10 marks done, 11 map ready
+  long long *acc;   // [A][8] sums over the flight (100 MHz ticks): gate wait, map, search queue + A*, corridors, QP queue + QP,
+                    //        finish, whole chain, ticks completed
+  int  n_agents, n_ticks, first_tick;
+};
+#ifdef __HIPCC__
+__device__ inline void fl_publish(int *ring, int mask, int *ready_n, int agent) {  // one lane; the item's data is written
+  __threadfence();
+  const int r = atomicAdd(ready_n, 1);
+  __hip_atomic_store(ring + (r & mask), (((r / (mask + 1)) + 1) << 16) | agent, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+// the agent at ring position `pos` (wave-uniform; bounded wait; -1 = the flight failed)
+__device__ inline int fl_wait_item(const int *ring, int mask, int pos, int *err) {
+  const int       want = (pos / (mask + 1)) + 1;
+  const long long t0   = wall_clock64();
+  for (;;) {
+    const int v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(ring + (pos & mask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    if ((v >> 16) == want) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      return v & 0xFFFF;
+    }
+    flow_pause();
+    if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0) return -1;
+    if (wall_clock64() - t0 > FLOW_TIMEOUT_TICKS) {
+      if ((threadIdx.x & 63) == 0) atomicExch(err, 12);
+      return -1;
+    }
+  }
+}
+// non-blocking claim of the next ticket of a queue whose items carry `per_item` tickets: the ticket number, or -1 when no
+// published item has an unclaimed ticket (wave-uniform; lane 0 does the compare-and-swap)
+__device__ inline int fl_try_claim(int *ticket, const int *ready_n, int per_item) {
+  int t = -1;
+  if ((threadIdx.x & 63) == 0) {
+    for (;;) {
+      const int cur = __hip_atomic_load(ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int rdy = __hip_atomic_load(ready_n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (cur >= rdy * per_item) break;
+      if (atomicCAS(ticket, cur, cur + 1) == cur) {
+        t = cur;
+        break;
+      }
+    }
+  }
+  return __builtin_amdgcn_readfirstlane(t);
+}
+#endif
+// the map role's arguments (csrc/sogm_map.hip, k_flight_map)
+struct FlightMapDev {
+  void                 *grid;          // the context's current grid (all agents)
+  unsigned             *bits;          // [A][words]
+  int                   words;
+  const FlightWorld    *worlds;        // dev [n_ticks]
+  CloudBlocks           cb;            // crop lists (bounds / counts per frame come from worlds[k])
+  void                 *cand;          // [A][SOGM_MAX_CYL_LDS] CylCand
+  int                  *n_cand;
+  MarkLog               lg;
+  const SogmTrajRecord *own;           // [A] executed records (latest wins)
+  const SogmTrajRecord *tables;        // [4][n_total] ring of swarm tables
+  int                   n_total;
+  const int32_t        *ego_ids;
+  const double         *body;
+  int                   n_body;
+  double                t0, period, start_offset;
+  double               *hover, *now, *t_start, *pva;
+  float                *poses;         // the context's map centres / stamps (queries read them)
+  double               *stamps;
+  int                   n_reset, n_bits, n_marks, n_splat;  // one-wave tickets per agent and tick
+  size_t                agent_bytes;
+  unsigned long long   *reset_stat;    // the context's reset statistics (sogm_sparse_reset_state / sogm_map_traffic), or null
+};
+int launch_flight_map(const GridGeom &g, const FlightCtl &fl, const FlightMapDev &d, int n_workgroups, hipStream_t st);
+// what finish_agent (csrc/sogm_corridor.hip) reads and writes for one agent
+struct FinishArgs {
+  double                corridor_tau;
+  const int32_t        *ret, *npoly, *status;
+  const double         *cpts;
+  const SogmTrajRecord *swarm;
+  int                   n_swarm;
+  const int32_t        *swarm_ego;
+  const double         *swarm_now, *t_start;
+  const int32_t        *drone_ids;
+  SogmTrajRecord       *out;
+  int32_t              *out_ok, *out_safe;
+  unsigned long long   *counters;
+  SogmTrajRecord       *pub_own, *pub_table;
+};
+// the light roles' arguments (k_flight_light): corridor stage buffers + the finishing role's
+struct FlightLightDev {
+  const double   *start_pva, *t_start, *route;
+  const int32_t  *route_len;
+  int             route_cap;
+  double         *out_polys;
+  int32_t        *out_nfaces, *out_npoly;
+  double         *out_goal;
+  FinishArgs      fin;          // swarm / pub_table / out / out_ok are set per tick from the fields below
+  SogmTrajRecord *tables;       // [4][n_total] ring of swarm tables (null: no deconfliction, no table)
+  int             n_total, agent0;
+  SogmTrajRecord *log_records;  // [n_ticks][A]
+  int32_t        *log_ok;       // [n_ticks][A]
+};
+struct CorridorWorkspace;
+int launch_flight_light(const MapView &m, const SogmPlannerParams &pp, const CorridorWorkspace &ws, const FlightCtl &fl,
+                        const FlightLightDev &d, int n_workgroups, hipStream_t st);
+struct AstarWorkspace;
+int launch_flight_search(const MapView &m, const SogmAstarParams &ap, double corridor_tau, const AstarWorkspace &wsp,
+                         const FlightCtl &fl, int n_workgroups, const double *start_pva, const double *goal,
+                         const double *t_start, int32_t *out_ret, double *out_route, int32_t *out_route_len, int route_cap,
+                         int32_t *out_stats, int spec, hipStream_t st);
+struct QpWorkspace;
+struct QpConst;
+int launch_flight_qp(const SogmPlannerParams &pp, const SogmQpSettings &qs, const QpWorkspace &ws, const QpConst &qc,
+                     const FlightCtl &fl, int n_workgroups, const double *start_pva, const double *goal_pv,
+                     const double *polys, const int32_t *nfaces, const int32_t *npoly, double *out_cpts,
+                     int32_t *out_status, int32_t *out_iters, hipStream_t st);
+
 // Arguments of the pre-stamp kernel (csrc/sogm_map.hip, k_prestamp_flow): the next tick's update inputs, the grid and
 // mark log it builds into, and where the next tick's start states go.
 struct PrestampDev {
@@ -242,4 +395,13 @@ struct sogm_planner {
   int search_mode;           // 0 the replan's two-call pattern, 1 / 2 one search with init_search true / false
   int spec_astar;            // dataflow replan: run the second search attempt speculatively beside the first
   hipStream_t peek;          // sogm_debug_flow_peek's private stream (created on first use)
+  // flight (sogm_flight_run): control block, per-agent tick inputs, frames, masked streams (all created on first use)
+  sogm::FlightCtl     fl;
+  int                *d_fl;          // header + rings + tick_done + tick_of + seg_done + stage
+  sogm::FlightWorld  *d_fl_worlds, *h_fl_worlds;  // [FLIGHT_MAX_TICKS] device / pinned staging
+  double             *d_fl_pva, *d_fl_tstart, *d_fl_now;
+  hipStream_t         fl_stream[4];  // QP, search, corridor + finish, map
+  hipEvent_t          fl_ev_in, fl_ev_done[4];
+  int                 fl_cus[4];     // compute units of each stream's mask
+  int                 fl_wgs[4];     // workgroups of each kernel
 };

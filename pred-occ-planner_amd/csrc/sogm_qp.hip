@@ -1736,12 +1736,43 @@ __global__ __launch_bounds__(QP_NT) void k_qp_flow(SogmPlannerParams pp, SogmQpS
   }
 }
 
+// Flight kernel Q (sogm_flight_run): as k_qp_flow, over the flight's rings — tickets run over every (agent, tick) of the
+// flight, the solved agent goes to the finish queue.
+__global__ __launch_bounds__(QP_NT) void k_flight_qp(SogmPlannerParams pp, SogmQpSettings qs, QpWorkspace ws, QpConst qc,
+                                                   FlightCtl fl, const double *start_pva, const double *goal_pv,
+                                                   const double *polys, const int32_t *nfaces, const int32_t *npoly,
+                                                   double *out_cpts, int32_t *out_status, int32_t *out_iters) {
+  __shared__ int s_agent;
+  const int total = fl.n_agents * fl.n_ticks;
+  for (;;) {
+    if (threadIdx.x < 64) {  // the first wave fetches the ticket and waits for its item (wave-uniform helpers)
+      int       a = -1;
+      const int k = flow_ticket(&fl.hdr[FL_Q_TICKET]);
+      if (k < total) a = fl_wait_item(fl.q_ring, fl.ring_mask, k, &fl.hdr[FL_ERR]);
+      if (threadIdx.x == 0) s_agent = a;
+    }
+    __syncthreads();
+    const int agent = __builtin_amdgcn_readfirstlane(s_agent);
+    if (agent < 0) break;  // no tickets left, or the flight failed
+    __threadfence();
+    if (threadIdx.x == 0) fl.ts[agent * 12 + 4] = wall_clock64();
+    qp_solve_agent(pp, qs, ws, qc, start_pva, goal_pv, polys, nfaces, npoly, out_cpts, out_status, out_iters, 0, agent);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      fl.ts[agent * 12 + 5] = wall_clock64();
+      fl_publish(fl.f_ring, fl.ring_mask, &fl.hdr[FL_F_READY], agent);
+    }
+    __syncthreads();
+  }
+}
+
 // Dynamic LDS k_qp may ask for: the CU's 160 KiB minus the kernel's static LDS (queried, not assumed).
 int qp_dynamic_lds_bytes() {
   hipFuncAttributes a, b;
   if (hipFuncGetAttributes(&a, (const void *)k_qp) != hipSuccess) return 128 * 1024;
   if (hipFuncGetAttributes(&b, (const void *)k_qp_flow) != hipSuccess) return 128 * 1024;
-  const long stat = (long)(a.sharedSizeBytes > b.sharedSizeBytes ? a.sharedSizeBytes : b.sharedSizeBytes);
+  long stat = (long)(a.sharedSizeBytes > b.sharedSizeBytes ? a.sharedSizeBytes : b.sharedSizeBytes);
+  if (hipFuncGetAttributes(&b, (const void *)k_flight_qp) == hipSuccess && (long)b.sharedSizeBytes > stat) stat = (long)b.sharedSizeBytes;
   const long dyn  = 160L * 1024 - stat;
   return (int)(dyn & ~255L);
 }
@@ -1775,6 +1806,20 @@ int launch_qp_flow(const SogmPlannerParams &pp, const SogmQpSettings &qs, const 
   }
   hipLaunchKernelGGL(k_qp_flow, dim3(n_workgroups), dim3(QP_NT), ws.dyn_lds_bytes, st, pp, qs, ws, qc, fc,
                      start_pva, goal_pv, polys, nfaces, npoly, out_cpts, out_status, out_iters, 0, n_agents);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int launch_flight_qp(const SogmPlannerParams &pp, const SogmQpSettings &qs, const QpWorkspace &ws, const QpConst &qc,
+                     const FlightCtl &fl, int n_workgroups, const double *start_pva, const double *goal_pv,
+                     const double *polys, const int32_t *nfaces, const int32_t *npoly, double *out_cpts,
+                     int32_t *out_status, int32_t *out_iters, hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void *)k_flight_qp, hipFuncAttributeMaxDynamicSharedMemorySize, ws.dyn_lds_bytes);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k_flight_qp, dim3(n_workgroups), dim3(QP_NT), ws.dyn_lds_bytes, st, pp, qs, ws, qc, fl, start_pva,
+                     goal_pv, polys, nfaces, npoly, out_cpts, out_status, out_iters);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

@@ -318,8 +318,13 @@ class SwarmTick:
     def __init__(self, grid="cfg2", agents_per_rank=None, rank=0, world=1, device=0, seed=0x5069,
                  spec=None, scene=None, dist=None, overlap_clear=True, deconflict=True, fsm=False,
                  double_buffer=None, grids=None, compute=None, exchange=None, prestamp=None, tuning=None,
-                 moving_world=None):
+                 moving_world=None, neighbour_lag=1):
         self.rank, self.world, self.dist = rank, world, dist
+        # neighbour_lag = 2: the overlay and isSafeAfterOpt of tick k read table ver(k - 2) instead of ver(k - 1) — the
+        # staleness rule of sogm_flight_run, flown here lock-step (one tick after the other) through the per-tick entry
+        # points: the reference path the flight's records are held to, bit for bit (single process, no fused publication)
+        self.neighbour_lag = int(neighbour_lag)
+        assert self.neighbour_lag in (1, 2)
         self.spec = spec if spec is not None else config.make_spec(grid)
         self.A_loc = agents_per_rank if agents_per_rank is not None else config.AGENTS.get(grid, 4)
         self.A_tot = self.A_loc * world
@@ -351,7 +356,8 @@ class SwarmTick:
         # publication inside the replan (default; SOGM_PUBLISH=0: the separate sogm_merge_latest launch): a single
         # process alternates between two swarm tables — the replan reads one (overlay, deconfliction) and its
         # finishing kernel fills the other for the next tick
-        self.publish = os.environ.get("SOGM_PUBLISH", "1") != "0" and hasattr(c, "set_publish") and not fsm
+        self.publish = (os.environ.get("SOGM_PUBLISH", "1") != "0" and hasattr(c, "set_publish") and not fsm
+                        and self.neighbour_lag == 1)
         self._tables = [self.all, torch.zeros_like(self.all)] if self.publish else None
         # pre-stamp (default; SOGM_PRESTAMP=0 or prestamp=False: off): every replan also builds the next tick's map and
         # start states, agent by agent as their records are published; the tick's inputs are double-buffered (the replan
@@ -469,8 +475,41 @@ class SwarmTick:
                 self.all = nxt   # what every agent executes after this tick: the next tick's table
             else:
                 self._exchange()
+        elif self.neighbour_lag == 2:
+            c.replan(self.pva, self.goals, self.t_start, self.new, self.ok)
+            c.merge_latest(self.new, self.ok, self.own, None)   # own = ver(k)'s rows
+            # self.all stays ver(k - 2) for this tick's readers; the next tick reads ver(k - 1) = the table of one tick ago
+            self._lag_prev, self.all = self.own.clone(), (self._lag_prev if getattr(self, "_lag_prev", None) is not None
+                                                          else torch.zeros_like(self.all))
+            if self.deconflict:
+                c.set_swarm(self.all, self.A_tot, self.now)
         else:
             c.replan(self.pva, self.goals, self.t_start, self.new, self.ok)
             self._publish()
         self.tick += 1
         return self.ok.clone()  # self.ok is rewritten by the next tick
+
+    # ---- flights: sogm_flight_run, every agent on its own clock ----
+    def fly(self, n_ticks):
+        """The next n_ticks ticks of every agent in ONE call (sogm_abi.h "Flight"): agent a's tick k starts when its own tick
+        k - 1 is finished and every agent has finished tick k - 2; it reads the neighbours' records of tick k - 2.  Needs
+        world frames (moving_world True / False) and a flight flown from tick 0 through fly() only.  Returns (ok [n, A]
+        int32, records uint8 [n, A, 2064]) device tensors — valid once the stream has run the flight."""
+        c = self.compute
+        assert getattr(c, "use_world", False), "fly() needs world frames (moving_world=True / False)"
+        assert self.world == 1 and not self.fsm
+        if not hasattr(self, "_fl_tables"):
+            assert self.tick == 0, "a flight starts at tick 0 (or continues a flight)"
+            self._fl_tables = torch.zeros((4, self.A_tot, _abi.TRAJ_RECORD_BYTES), dtype=torch.uint8, device="cuda")
+            self._fl_next = 0
+        assert self.tick == self._fl_next, "fly() continues flights only"
+        assert 1 <= n_ticks <= _abi.FLIGHT_MAX_TICKS
+        log_r = torch.zeros((n_ticks, self.A_loc, _abi.TRAJ_RECORD_BYTES), dtype=torch.uint8, device="cuda")
+        log_ok = torch.zeros((n_ticks, self.A_loc), dtype=torch.int32, device="cuda")
+        worlds = [c.world(self.tick + i) for i in range(n_ticks)]
+        self.planner.flight(worlds, self.tick, self.t0, TICK_PERIOD, REPLAN_START_TIME, self.goals, self.dev["ego_ids"],
+                            self.hover, self.own, self._fl_tables, log_r, log_ok)
+        self.tick += n_ticks
+        self._fl_next = self.tick
+        self.all = self._fl_tables[(self.tick - 1) & 3]   # ver(last tick): what every agent executes now
+        return log_ok, log_r

@@ -199,6 +199,28 @@ class SogmPlanner:
         self._prestamp = (cloud, cloud_range, cylinders, hover, now, t_start, pva, poses, world)
         check(lib().sogm_planner_set_prestamp(self._p, C.byref(ps)), "sogm_planner_set_prestamp")
 
+    # ---- sogm_flight_run: n ticks of every agent, each on its own clock ----
+    def flight(self, worlds, first_tick, t0, period, start_offset, goals, drone_ids, hover, own, tables, log_records,
+               log_ok):
+        """n = len(worlds) replan ticks of every agent in one call (sogm_abi.h "Flight"): `worlds` sogm.World frames of
+        ticks first_tick .. first_tick + n - 1, `tables` uint8 [4, A, 2064] (ver(j) at j & 3), `log_records` uint8
+        [n, A, 2064], `log_ok` int32 [n, A].  Asynchronous on the current stream."""
+        n = len(worlds)
+        arr = (_abi.SogmWorld * n)(*[w.c for w in worlds])
+        f = _abi.SogmFlight(n, int(first_tick), float(t0), float(period), float(start_offset), arr, goals.data_ptr(),
+                            drone_ids.data_ptr(), hover.data_ptr(), own.data_ptr(), tables.data_ptr(), self.A, 0,
+                            log_records.data_ptr(), log_ok.data_ptr())
+        self._flight_keep = (worlds, arr, goals, drone_ids, hover, own, tables, log_records, log_ok)
+        check(lib().sogm_flight_run(self._p, C.byref(f), _stream()), "sogm_flight_run")
+
+    def flight_stats(self):
+        """(per-agent sums [A, 8] in ms: _abi.FLIGHT_STAT_NAMES, control header [16]) of the last flight; synchronises"""
+        ms = np.zeros((self.A, 8), np.float64)
+        hdr = np.zeros((16,), np.int32)
+        check(lib().sogm_flight_stats(self._p, ms.ctypes.data_as(C.c_void_p), hdr.ctypes.data_as(C.c_void_p)),
+              "sogm_flight_stats")
+        return ms, hdr
+
     # ---- BaselinePlanner::replan ----
     def replan(self, start_pva, goal, t_start, drone_ids, out_records=None, out_ok=None):
         A, dev = self.A, start_pva.device

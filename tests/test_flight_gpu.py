@@ -1,0 +1,113 @@
+"""GPU: sogm_flight_run — n ticks of every agent in one call, every agent on its own clock (sogm_abi.h "Flight").
+
+The reference's drones replan asynchronously and read whatever trajectories arrived last
+(plan_manager/src/plan_manager.cpp:92-233, traj_coordinator/src/particles.cpp:179-190).  The flight fixes the RESULTS
+with a staleness rule (tick k reads the agent's own record of tick k - 1 and the neighbours' records of tick k - 2) and
+leaves the SCHEDULE free.  Checked here:
+  * the flight's per-tick records and ok flags equal, bit for bit, those of the same rule flown lock-step through the
+    per-tick entry points (sogm_update_world + sogm_replan, SwarmTick(neighbour_lag=2)) — whatever order the device ran
+    the agents in;
+  * that lock-step reference is held to the CPU oracle flown with the same rule, stage by stage (cells, A* pop order,
+    polytopes, QP);
+  * a flight continues a flight; the full-size swarm (128 agents, 200^3 x 20) flies with no failed tick."""
+import importlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _lockstep_lag2(driver, grid, A, n, **kw):
+    import torch
+    sw = driver.SwarmTick(grid, A, moving_world=True, prestamp=False, neighbour_lag=2, **kw)
+    oks, recs = [], []
+    for _ in range(n):
+        oks.append(sw.step().cpu().numpy().copy())
+        recs.append(sw.new.cpu().numpy().copy())
+    torch.cuda.synchronize()
+    assert sw.planner.flow_failures() == (0, 0)
+    own = sw.own.cpu().numpy().copy()
+    cnt = sw.planner.counters()
+    sw.close()
+    return np.stack(oks), np.stack(recs), own, cnt
+
+
+def _flight(driver, grid, A, chunks, **kw):
+    import torch
+    sw = driver.SwarmTick(grid, A, moving_world=True, prestamp=False, **kw)
+    oks, recs = [], []
+    for n in chunks:
+        ok, rec = sw.fly(n)
+        torch.cuda.synchronize()
+        ms, hdr = sw.planner.flight_stats()
+        assert hdr[10] == 0 and sw.planner.flow_failures() == (0, 0), (hdr.tolist(), sw.planner.flow_failures())
+        assert hdr[11] == A * n and (ms[:, 7] == n).all(), (hdr.tolist(), ms[:, 7])
+        oks.append(ok.cpu().numpy().copy())
+        recs.append(rec.cpu().numpy().copy())
+    own = sw.own.cpu().numpy().copy()
+    last = sw.all.cpu().numpy().copy()
+    cnt = sw.planner.counters()
+    sw.close()
+    return np.concatenate(oks), np.concatenate(recs), own, last, cnt, ms
+
+
+def test_flight_records_equal_the_lockstep_flight_with_the_same_staleness_rule(pop):
+    driver = importlib.import_module("pred-occ-planner_amd.driver")
+    K, A = 10, 6
+    ok_l, rec_l, own_l, cnt_l = _lockstep_lag2(driver, "parity", A, K)
+    ok_f, rec_f, own_f, last_f, cnt_f, ms = _flight(driver, "parity", A, [K])
+    assert ok_l.sum() > K * A // 3  # (a flight in which replans succeed)
+    assert np.array_equal(ok_f, ok_l), (ok_f, ok_l)
+    for k in range(K):
+        assert np.array_equal(rec_f[k], rec_l[k]), f"tick {k}: records differ in agents {np.flatnonzero((rec_f[k] != rec_l[k]).any(axis=1))}"
+    assert np.array_equal(own_f, own_l) and np.array_equal(last_f, own_l)
+    assert cnt_f == cnt_l
+    print("flight, per-agent ms per tick:", dict(zip(pop._abi.FLIGHT_STAT_NAMES, (ms[:, :7].sum(axis=0) / ms[:, 7].sum()).round(3))))
+
+
+def test_a_flight_continues_a_flight(pop):
+    driver = importlib.import_module("pred-occ-planner_amd.driver")
+    one = _flight(driver, "parity", 5, [9])
+    two = _flight(driver, "parity", 5, [1, 3, 5])
+    assert np.array_equal(one[0], two[0]) and np.array_equal(one[1], two[1])
+    assert np.array_equal(one[2], two[2]) and np.array_equal(one[3], two[3])
+
+
+def test_the_staleness_rule_flown_lockstep_against_the_oracle_stage_by_stage(pop, orc):
+    """the reference path of the first test against the CPU oracle under the same rule: every tick's map (this tick's frame,
+    overlay of table ver(k - 2)), A* pop order, polytopes and QP of every agent"""
+    driver = importlib.import_module("pred-occ-planner_amd.driver")
+    fp = importlib.import_module("test_full_size_parity")
+    sw = driver.SwarmTick("parity", 6, moving_world=True, prestamp=False, neighbour_lag=2)
+    acc = {}
+    for _ in range(7):
+        fp._sum(acc, fp._tick_with_parity(pop, orc, sw, list(range(6))))
+    print("staleness rule, lock-step vs oracle:", acc)
+    assert acc["agents"] == 42 and acc["qp_ok"] >= 18 and acc["fused_checked"] == 42
+    sw.close()
+
+
+def test_flight_with_and_without_masks_and_speculation_gives_the_same_records(pop):
+    """scheduling knobs must not change results: unmasked streams, sequential search attempts, other ticket counts"""
+    driver = importlib.import_module("pred-occ-planner_amd.driver")
+    base = _flight(driver, "parity", 6, [6])
+    for tuning in ({"flight_spec": 0}, {"flight_reset": 2, "flight_bits": 3, "flight_marks": 5, "flight_splat": 1},
+                   {"flight_qp_units": 2, "flight_search_units": 1, "flight_map_units": 6}):
+        other = _flight(driver, "parity", 6, [6], tuning=tuning)
+        assert np.array_equal(base[0], other[0]) and np.array_equal(base[1], other[1]), tuning
+
+
+def test_full_size_flight_equals_lockstep_rule(pop):
+    """BASELINE configs[2]'s swarm (128 agents, 200^3 x 20, moving world): six ticks in one flight against the same rule flown
+    lock-step — records and ok flags bit for bit, no failed tick, every agent-tick accounted for."""
+    driver = importlib.import_module("pred-occ-planner_amd.driver")
+    K, A = 6, 128
+    ok_l, rec_l, own_l, cnt_l = _lockstep_lag2(driver, "cfg2", A, K)
+    ok_f, rec_f, own_f, last_f, cnt_f, ms = _flight(driver, "cfg2", A, [K])
+    assert np.array_equal(ok_f, ok_l)
+    for k in range(K):
+        assert np.array_equal(rec_f[k], rec_l[k]), f"tick {k}: agents {np.flatnonzero((rec_f[k] != rec_l[k]).any(axis=1))}"
+    assert np.array_equal(own_f, own_l) and cnt_f == cnt_l
+    per = ms[:, :7].sum(axis=0) / ms[:, 7].sum()
+    print("cfg2 flight, mean ms per agent-tick:", dict(zip(pop._abi.FLIGHT_STAT_NAMES, per.round(3))), "ok", int(ok_f.sum()), "of", K * A)

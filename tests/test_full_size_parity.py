@@ -125,7 +125,12 @@ def _tick_with_parity(pop, orc, sw, agents, check_grid_cells=True):
             assert list(new[a].duration[:M]) == [pp.corridor_tau] * M and new[a].time_start == float(ts[a])
         stats["fused_checked"] += 1
     sw.own = driver.merge_latest(sw.new, sw.own, sw.ok)
-    driver.exchange_records(sw.own, sw.all, sw.dist, sw.world)
+    if getattr(sw, "neighbour_lag", 1) == 2:  # the flight's staleness rule: the next tick reads the table of ONE tick ago
+        import torch
+        prev = getattr(sw, "_lag_prev", None)
+        sw._lag_prev, sw.all = sw.own.clone(), (prev if prev is not None else torch.zeros_like(sw.all))
+    else:
+        driver.exchange_records(sw.own, sw.all, sw.dist, sw.world)
     sw.tick += 1
     return stats
 
