@@ -238,7 +238,9 @@ int sogm_set_resample(sogm_ctx *ctx, float replan_risk_rate, int num_resample, c
  *     "flight_search_units" (2), "flight_map_units" (4) — compute units in units of 16 for the QP / search / map kernels,
  *     the corridor + finish kernel takes the rest —, "flight_masks" (1; 0 = unmasked streams), "flight_spec" (1: both
  *     search attempts side by side), and per (agent, tick) one-wave tickets "flight_reset" (8), "flight_bits" (16),
- *     "flight_marks" (32), "flight_splat" (4).
+ *     "flight_marks" (32), "flight_splat" (4); "flight_admit" (48) agents whose map may be under construction at once, "flight_pace_us" (40) microseconds between two
+ *     admissions to the map stage (agents then reach every stage at a steady rate; 0 = unpaced), "flight_heads" (32)
+ *     admitting waves of the map kernel.
  * Not thread-safe against calls on the same context (like every other call).  Unknown key: SOGM_ERR_INVALID_ARG.
  * sogm_tuning_key(i) enumerates the keys (NULL past the last). */
 int         sogm_set_tuning(sogm_ctx *ctx, const char *key, double value);
@@ -860,7 +862,9 @@ typedef struct SogmFlight {
 int sogm_flight_run(sogm_planner *p, const SogmFlight *flight, void *stream);
 /* After a flight (synchronises): host out_ms[A][8] = per-agent sums over the last flight in ms {wait at the tick k - 2 gate,
  * map (reset + stamp + overlay), search (queue + A*), corridors (queue + FIRI), QP (queue + solve), finish, whole chain,
- * ticks completed}; host out_hdr[16] = the flight's control header (FL_* counters; [10] = error code, 0 = none). */
+ * ticks completed}; host out_hdr[32] = the flight's control counters ([4] = error code, 0 = none; [5] = agent-ticks
+ * finished; [16..24] = wave time of the map / corridor + finish kernels by activity, in units of 10 us: map workers idle,
+ * reset, bits, marks, overlay, heads, light waves idle, corridor segments, finish; [25..31] = descriptor counts). */
 int sogm_flight_stats(sogm_planner *p, double *out_ms_host, int32_t *out_hdr_host);
 int sogm_planner_counters(sogm_planner *p, int64_t *out_host, int reset);
 /* sogm_replan() chains its kernels per agent through device-side ready lists ("dataflow replan");

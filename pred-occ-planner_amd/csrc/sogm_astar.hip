@@ -1056,7 +1056,7 @@ __global__ __launch_bounds__(ASTAR_THREADS) void k_flight_search(
                                       &fl.hdr[FL_ERR], 0);
     if (mine && tid == ASTAR_MASTER) {
       fl.ts[agent * 12 + 1] = wall_clock64();
-      fl_publish(fl.a_ring, fl.ring_mask, &fl.hdr[FL_A_READY], agent);
+      wq_push(fl.lw, &fl.hdr[FL_LW_TAIL], ((unsigned)WK_CORRIDOR << 28) | (unsigned)agent, SOGM_MAX_PIECES);
     }
   }
 }

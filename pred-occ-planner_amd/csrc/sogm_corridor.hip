@@ -2165,26 +2165,38 @@ __global__ __launch_bounds__(64) void k_finish_flow(FlowCtl fc, FinishArgs f, in
   }
 }
 
-// Flight kernel L (sogm_flight_run): role-less one-wave workgroups over the flight's two light queues.  A wave claims —
-// without blocking: only tickets of published items are handed out — a finish item first (short, and it releases the
-// agent's next tick), else a corridor segment ticket; with neither it naps.  Corridor tickets: 16 per (agent, tick) as in
-// k_corridor_flow, the wave that completes an agent's last segment slot finalises its corridors and queues the QP.  Finish
-// items: finish_agent against table ver(k - 2), the record into ver(k) and the flight log, then the tick's accounting and
-// the agent's next map item.  The launch ends when every finish item has been claimed.
+// Flight kernel L (sogm_flight_run): role-less one-wave workgroups over the corridor + finish work queue.  A wave takes a
+// ticket (one atomicAdd), waits for the descriptor at that position and does what it says.  WK_CORRIDOR: one of the 16
+// segment slots of an agent whose search is done, as in k_corridor_flow; the wave that completes the agent's last slot
+// finalises its corridors and queues the QP.  WK_FINISH: finish_agent against table ver(k - 2), the record into ver(k) and
+// the flight log, then the tick's accounting and the agent's next map head.  17 descriptors per (agent, tick).
 __global__ __launch_bounds__(64) void k_flight_light(MapView m, SogmPlannerParams pp, CorridorWorkspace ws, FlightCtl fl,
                                                      FlightLightDev d) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int lane  = threadIdx.x;
-  const int total = fl.n_agents * fl.n_ticks;
-  int       naps  = 0;
+  const int      lane  = threadIdx.x;
+  const unsigned total = (unsigned)fl.n_agents * (unsigned)fl.n_ticks * (SOGM_MAX_PIECES + 1);
+  int           *err   = &fl.hdr[FL_ERR];
+  long long      c1_prev = 0;
+  int            kind_prev = 0;
   for (;;) {
-    if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&fl.hdr[FL_ERR], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0) break;
-    // ---- finish ----
-    int t = fl_try_claim(&fl.hdr[FL_F_TICKET], &fl.hdr[FL_F_READY], 1);
-    if (t >= 0) {
-      const int a = fl_wait_item(fl.f_ring, fl.ring_mask, t, &fl.hdr[FL_ERR]);
-      if (a < 0) break;
-      __threadfence();
+    const unsigned t = (unsigned)flow_ticket(&fl.hdr[FL_LW_HEAD]);
+    if (t >= total) break;
+    const long long c0   = wall_clock64();
+    const int       desc = wq_take(fl.lw, t, err);
+    if (desc < 0) break;
+    __threadfence();
+    const long long c1 = wall_clock64();
+    if (lane == 0) {  // wave time by activity (sogm_flight_stats)
+      if (c1_prev) {
+        atomicAdd(&fl.prof[kind_prev == WK_FINISH ? 8 : 7], (unsigned long long)(c0 - c1_prev));
+        atomicAdd(&fl.prof[kind_prev == WK_FINISH ? 15 : 14], 1ull);
+      }
+      atomicAdd(&fl.prof[6], (unsigned long long)(c1 - c0));
+    }
+    const int kind = desc >> 28, a = desc & 0xFFFF;
+    c1_prev   = c1;
+    kind_prev = kind;
+    if (kind == WK_FINISH) {
       const int k  = fl.tick_of[a];
       const int kl = k - fl.first_tick;
       FinishArgs f = d.fin;
@@ -2201,68 +2213,84 @@ __global__ __launch_bounds__(64) void k_flight_light(MapView m, SogmPlannerParam
         const long long now = wall_clock64();
         long long      *ts  = fl.ts + (size_t)a * 12, *acc = fl.acc + (size_t)a * 8;
         ts[6]               = now;
-        acc[0] += ts[9] - ts[8];    // gate wait
-        acc[1] += ts[11] - ts[9];   // map: reset + stamp + overlay
-        acc[2] += ts[1] - ts[11];   // search queue + A*
-        acc[3] += ts[3] - ts[1];    // corridor queue + corridors
-        acc[4] += ts[5] - ts[3];    // QP queue + QP
-        acc[5] += now - ts[5];      // finish queue + finish
-        acc[6] += now - ts[8];      // the whole chain
+        acc[0] += ts[9] - ts[8];                       // gate wait
+        acc[1] += (ts[11] - ts[7]) - (ts[9] - ts[8]);  // map: from the head's publication to the complete map
+        acc[2] += ts[1] - ts[11];                      // search queue + A*
+        acc[3] += ts[3] - ts[1];                       // corridor queue + corridors
+        acc[4] += ts[5] - ts[3];                       // QP queue + QP
+        acc[5] += now - ts[5];                         // finish queue + finish
+        acc[6] += now - ts[7];                         // the whole chain
         acc[7] += 1;
+        if (fl.ts_log) {
+          long long *lg = fl.ts_log + ((size_t)kl * fl.n_agents + a) * 12;
+          for (int q = 0; q < 12; ++q) lg[q] = ts[q];
+        }
         finish_count(f, a, (code & 1) != 0);
-        __hip_atomic_fetch_add(&fl.tick_done[kl], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        // The gate of the staleness rule — tick j may start once EVERY agent has finished tick j - 2 — is kept here, on the
+        // producer side: an agent whose next tick is still gated is PARKED, not queued, and the finish that completes
+        // the awaited tick releases the parked heads.  (A first version queued every head and let the admitting waves
+        // wait at the gate: a leader at the head of the admission FIFO then held back the laggards queued behind it — the
+        // very agents it was waiting for — and the swarm settled at two ticks of spread and 12 ms per tick.)
+        const int A_      = fl.n_agents;
+        const int done_kl = __hip_atomic_fetch_add(&fl.tick_done[kl], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) + 1;
         atomicAdd(&fl.hdr[FL_FINISHED], 1);
-        if (kl + 1 < fl.n_ticks) {  // the agent's next tick: its map item
+        if (kl + 1 < fl.n_ticks) {  // the agent's next tick: its map head, now or when tick k - 1 is complete
           fl.tick_of[a] = k + 1;
-          fl_publish(fl.m_ring, fl.ring_mask, &fl.hdr[FL_M_READY], a);
+          ts[7]         = now;
+          const bool open = kl < 1 || __hip_atomic_load(&fl.tick_done[kl - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= A_;
+          if (open) {
+            fl_publish(fl.m_ring, fl.ring_mask, &fl.hdr[FL_M_READY], a);
+          } else {
+            int      *lst  = fl.parked + (size_t)(kl + 1) * A_;
+            const int slot = atomicAdd(&fl.parked_n[kl + 1], 1);
+            __hip_atomic_store(&lst[slot], a, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            __threadfence();
+            // (the releaser may have scanned the list before this slot was written)
+            if (__hip_atomic_load(&fl.tick_done[kl - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= A_ &&
+                atomicCAS(&lst[slot], a, -2) == a)
+              fl_publish(fl.m_ring, fl.ring_mask, &fl.hdr[FL_M_READY], a);
+          }
+        }
+        if (done_kl == A_ && kl + 2 < fl.n_ticks) {  // tick k is complete: the heads of tick k + 2 parked so far may go
+          __threadfence();
+          int      *lst = fl.parked + (size_t)(kl + 2) * A_;
+          const int n   = __hip_atomic_load(&fl.parked_n[kl + 2], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+          for (int i = 0; i < n && i < A_; ++i) {
+            const int v = __hip_atomic_load(&lst[i], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+            if (v >= 0 && atomicCAS(&lst[i], v, -2) == v) fl_publish(fl.m_ring, fl.ring_mask, &fl.hdr[FL_M_READY], v);
+          }
         }
       }
-      naps = 0;
       continue;
     }
-    // ---- corridor segment ----
-    t = fl_try_claim(&fl.hdr[FL_C_TICKET], &fl.hdr[FL_A_READY], SOGM_MAX_PIECES);
-    if (t >= 0) {
-      const int agent = fl_wait_item(fl.a_ring, fl.ring_mask, t / SOGM_MAX_PIECES, &fl.hdr[FL_ERR]);
-      if (agent < 0) break;
-      __threadfence();
-      const int seg = t % SOGM_MAX_PIECES;
-      if (seg == 0 && lane == 0) fl.ts[agent * 12 + 2] = wall_clock64();
-      if (seg < d.route_len[agent] - 1) {
-        corridor_points_body<1>(m, pp, ws, d.start_pva, d.t_start, d.route, d.route_len, d.route_cap, agent, seg);
-        __threadfence_block();
-        __syncthreads();
-      }
-      corridor_segment_body<6, false>(m, pp, ws, d.start_pva, d.t_start, d.route, d.route_len, d.route_cap, agent, seg, smem,
-                                      FiriDirect{});
+    // ---- WK_CORRIDOR: segment slot `seg` of agent a ----
+    const int seg = (desc >> 16) & 0xFFF;
+    if (seg == 0 && lane == 0) fl.ts[a * 12 + 2] = wall_clock64();
+    if (seg < d.route_len[a] - 1) {
+      corridor_points_body<1>(m, pp, ws, d.start_pva, d.t_start, d.route, d.route_len, d.route_cap, a, seg);
+      __threadfence_block();
       __syncthreads();
+    }
+    corridor_segment_body<6, false>(m, pp, ws, d.start_pva, d.t_start, d.route, d.route_len, d.route_cap, a, seg, smem,
+                                    FiriDirect{});
+    __syncthreads();
+    __threadfence();
+    const int last = (flow_ticket(&fl.seg_done[a]) & (SOGM_MAX_PIECES - 1)) == SOGM_MAX_PIECES - 1;
+    if (last) {
       __threadfence();
-      const int last = (flow_ticket(&fl.seg_done[agent]) & (SOGM_MAX_PIECES - 1)) == SOGM_MAX_PIECES - 1;
-      if (last) {
-        __threadfence();
-        double       *s_lp   = (double *)smem;
-        double       *s_rows = s_lp + LP_WORK_DOUBLES;
-        int          *s_perm = (int *)(s_rows + LP_MAX_ROWS * 5);
-        SolverScratch sc{s_lp, s_perm, s_rows, nullptr};
-        corridor_finalize_body(pp, ws, d.start_pva, d.route, d.route_len, d.route_cap, d.out_polys, d.out_nfaces, d.out_npoly,
-                               d.out_goal, agent, sc);
-        __syncthreads();
-        if (lane == 0) {
-          fl.ts[agent * 12 + 3] = wall_clock64();
-          fl_publish(fl.q_ring, fl.ring_mask, &fl.hdr[FL_Q_READY], agent);
-        }
-      }
+      double       *s_lp   = (double *)smem;
+      double       *s_rows = s_lp + LP_WORK_DOUBLES;
+      int          *s_perm = (int *)(s_rows + LP_MAX_ROWS * 5);
+      SolverScratch sc{s_lp, s_perm, s_rows, nullptr};
+      corridor_finalize_body(pp, ws, d.start_pva, d.route, d.route_len, d.route_cap, d.out_polys, d.out_nfaces, d.out_npoly,
+                             d.out_goal, a, sc);
       __syncthreads();
-      naps = 0;
-      continue;
+      if (lane == 0) {
+        fl.ts[a * 12 + 3] = wall_clock64();
+        fl_publish(fl.q_ring, fl.ring_mask, &fl.hdr[FL_Q_READY], a);
+      }
     }
-    // ---- nothing to claim: done, or nap ----
-    if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&fl.hdr[FL_F_TICKET], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >= total) break;
-    flow_pause();
-    if (++naps > 400000) {  // ~3 s of naps with nothing to claim: the flight is stuck
-      if (lane == 0) atomicExch(&fl.hdr[FL_ERR], 13);
-      break;
-    }
+    __syncthreads();
   }
 }
 

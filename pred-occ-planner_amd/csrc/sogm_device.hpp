@@ -357,7 +357,10 @@ __device__ inline void bezier_pos(const SogmTrajRecord &r, double t, double out[
   X(FLIGHT_RESET, "flight_reset", 8, 1, 256)               /* flight: one-wave tickets per agent-tick, sparse reset           */  \
   X(FLIGHT_BITS, "flight_bits", 16, 1, 256)                /* flight: ... occupancy bits                                      */  \
   X(FLIGHT_MARKS, "flight_marks", 32, 1, 256)              /* flight: ... marks                                               */  \
-  X(FLIGHT_SPLAT, "flight_splat", 4, 1, 64)                /* flight: ... neighbour overlay                                   */
+  X(FLIGHT_SPLAT, "flight_splat", 4, 1, 64)                /* flight: ... neighbour overlay                                   */  \
+  X(FLIGHT_ADMIT, "flight_admit", 48, 1, 65536)            /* flight: agents whose map may be under construction at once      */  \
+  X(FLIGHT_PACE_US, "flight_pace_us", 40, 0, 100000)       /* flight: microseconds between two admissions to the map stage    */  \
+  X(FLIGHT_HEADS, "flight_heads", 32, 1, 4096)             /* flight: admitting waves of the map kernel                       */
 enum {
 #define X(id, name, dflt, lo, hi) SOGM_TUNE_##id,
   SOGM_TUNING_TABLE(X)

@@ -1325,9 +1325,11 @@ namespace sogm {
 #endif
 // ------------------------------------------------------------------------------------------------
 // Flight kernel M (sogm_flight_run; the flight is described in sogm_planner.hpp): an agent's map of its next tick, built
-// the moment the agent's previous tick is finished.  Per (agent, tick) one item of 1 + n_reset + n_bits + n_marks +
-// n_splat one-wave tickets, handed out in order (a ticket only ever waits for lower tickets of its item, or — the head — for
-// the swarm's tick k - 2):
+// the moment the agent's previous tick is finished.  Per (agent, tick) 1 + n_reset + n_bits + n_marks + n_splat one-wave
+// tickets in four phases; every phase is a queue of its own and a wave claims — never blocking — a ticket of the LATEST
+// phase that has one (a first version handed all tickets of an item out in order and let them wait for each other: 512
+// waves / 61 tickets = 8 items in flight, the swarm's maps took 17 ms per tick).  Only the head may wait: for the swarm's
+// tick k - 2.
 //   head    gate "every agent has finished tick k - 2" (the staleness rule's other half: table ver(k - 2) is complete);
 //           start state / map centre / stamp of tick k from the agent's executed record (k_tick_inputs' rule);
 //           candidate cylinders and cloud blocks of frame k around the new centre
@@ -1350,14 +1352,25 @@ __device__ __forceinline__ void flight_reset_ticket(char *__restrict__ base, siz
   }
   const int part = lane & 1, pair = lane >> 1;
   unsigned  n_lines = 0;
-  for (size_t i0 = (size_t)first * 32; i0 < n; i0 += (size_t)stride * 32) {  // 32 entries per trip, two lanes each
-    const size_t   i    = i0 + pair;
-    const unsigned sct  = i < n ? e[i] : 0xFFFFFFFFu;
-    const unsigned prev = __shfl_up(sct, 2);
-    if (sct == 0xFFFFFFFFu || (pair > 0 && prev == sct)) continue;
-    const size_t off = (size_t)sct * 32 + 16 * part;
-    if (off + 16 <= agent_bytes) *reinterpret_cast<vfloat4 *>(base + off) = z;
-    if (part == 0) ++n_lines;
+  // 32 entries per trip, two lanes each; EIGHT trips' entry loads are issued together (a trip by itself is one dependent
+  // load -> store pair: ~1 us per trip, 1.05 ms per ticket of 40 k entries in the first flights)
+  constexpr int U = 8;
+  const size_t  step = (size_t)stride * 32;
+  for (size_t i0 = (size_t)first * 32; i0 < n; i0 += U * step) {
+    unsigned sct[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const size_t i = i0 + u * step + pair;
+      sct[u]         = i < n ? e[i] : 0xFFFFFFFFu;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const unsigned prev = __shfl_up(sct[u], 2);
+      if (sct[u] == 0xFFFFFFFFu || (pair > 0 && prev == sct[u])) continue;
+      const size_t off = (size_t)sct[u] * 32 + 16 * part;
+      if (off + 16 <= agent_bytes) *reinterpret_cast<vfloat4 *>(base + off) = z;
+      if (part == 0) ++n_lines;
+    }
   }
   if (stat) {
     for (int d = 32; d >= 1; d >>= 1) n_lines += (unsigned)__shfl_xor((int)n_lines, d, 64);
@@ -1371,32 +1384,54 @@ __global__ __launch_bounds__(64) void k_flight_map(GridGeom g, FlightCtl fl, Fli
   const int lane = threadIdx.x;
   const int A    = fl.n_agents;
   const int n_r = d.n_reset, n_b = d.n_bits, n_m = d.n_marks, n_s = d.n_splat;
-  const int per   = 1 + n_r + n_b + n_m + n_s;      // tickets per item
-  const int S     = per + 1;                        // stage counts per item (+1: the log restart between the two groups)
-  const int total = A * fl.n_ticks * per;
-  int      *err   = &fl.hdr[FL_ERR];
-  for (;;) {
-    const int t = flow_ticket(&fl.hdr[FL_M_TICKET]);
-    if (t >= total) break;
-    const int agent = fl_wait_item(fl.m_ring, fl.ring_mask, t / per, err);
-    if (agent < 0) break;
-    __threadfence();
-    const int          s    = t % per;
-    const int          k    = fl.tick_of[agent], kl = k - fl.first_tick;
-    const int          base = kl * S;
-    const FlightWorld &w    = d.worlds[kl];
-    long long         *ts   = fl.ts + (size_t)agent * 12;
-    CloudBlocks        cb   = d.cb;
-    cb.bounds = w.bounds;
-    cb.n_blocks = w.n_blocks;
-    cb.block_points = w.block_points;
-    cb.n_points = w.n_points;
-    char          *gbase = reinterpret_cast<char *>(d.grid) + (size_t)agent * d.agent_bytes;
-    const unsigned *lent = d.lg.entries + (size_t)agent * d.lg.cap;
-    if (s == 0) {
-      // ---- head ----
+  const int S   = 1 + n_r + n_b + n_m + n_s;  // stage counts per (agent, tick); the per-agent stage counter is cumulative
+  const unsigned total = (unsigned)A * (unsigned)fl.n_ticks * (unsigned)(S - 1);  // descriptors of the work queue
+  int      *err = &fl.hdr[FL_ERR];
+  if ((int)blockIdx.x < d.n_head_wgs) {
+    // ---- admitting waves: heads, in the order the agents' previous ticks finished ----
+    const int items = A * fl.n_ticks;
+    for (;;) {
+      const int t = flow_ticket(&fl.hdr[FL_M_TICKET]);
+      if (t >= items) break;
+      const int agent = fl_wait_item(fl.m_ring, fl.ring_mask, t, err);
+      if (agent < 0) break;
+      __threadfence();
+      const int          k = fl.tick_of[agent], kl = k - fl.first_tick;
+      const FlightWorld &w = d.worlds[kl];
+      CloudBlocks        cb = d.cb;
+      cb.bounds       = w.bounds;
+      cb.n_blocks     = w.n_blocks;
+      cb.block_points = w.block_points;
+      cb.n_points     = w.n_points;
+      long long *ts = fl.ts + (size_t)agent * 12;
       if (lane == 0) ts[8] = wall_clock64();
+      // admission, in ticket order: at most n_admit maps under construction, and no faster than one agent per pace_ticks
+      // — agents then leave the map stage (and reach every later stage) at a steady rate instead of in a burst, which is
+      // what lets kernels with FIXED compute units all be busy at once: a swarm that moves in step serves one stage at a
+      // time and the tick becomes the SUM of the stages' times (measured: 12.9 ms = 5.6 map + 3.7 corridors + 3.4 QP).
+      {  // my turn: a tight poll — a handful of waves wait here, and the hand-over from head to head is the admission rate
+        const long long w0 = wall_clock64();
+        bool            bad = false;
+        while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&fl.hdr[FL_ADMITTED], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < t) {
+          __builtin_amdgcn_s_sleep(8);
+          if (wall_clock64() - w0 > FLOW_TIMEOUT_TICKS ||
+              __builtin_amdgcn_readfirstlane(__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0) {
+            if (lane == 0) atomicCAS(err, 0, 16);
+            bad = true;
+            break;
+          }
+        }
+        if (bad) break;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      }
+      if (flow_wait_count(&fl.hdr[FL_MAPS_DONE], t - d.n_admit + 1, err)) break;
       if (kl >= 2 && flow_wait_count(&fl.tick_done[kl - 2], A, err)) break;
+      if (lane == 0) {
+        long long *pc = reinterpret_cast<long long *>(&fl.hdr[FL_PACE_CLOCK]);
+        while (wall_clock64() - *pc < d.pace_ticks) __builtin_amdgcn_s_sleep(16);
+        *pc = wall_clock64();
+        __hip_atomic_store(&fl.hdr[FL_ADMITTED], t + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      }
       if (lane == 0) ts[9] = wall_clock64();
       constexpr int W   = (int)(sizeof(SogmTrajRecord) / 16);
       const uint4  *src = reinterpret_cast<const uint4 *>(d.own + agent);
@@ -1415,59 +1450,84 @@ __global__ __launch_bounds__(64) void k_flight_map(GridGeom g, FlightCtl fl, Fli
                  (CylCand *)d.cand + (size_t)agent * SOGM_MAX_CYL_LDS, d.n_cand + agent, lane);
       cull_blocks_agent(g, cb, agent, d.poses[agent * 3], d.poses[agent * 3 + 1], lane);
       __threadfence();
-      if (lane == 0) atomicAdd(&fl.stage[agent], 1);
-      continue;
+      if (lane == 0) {  // the agent's grid may be reset and its occupancy bits set (neither touches what the other writes)
+        atomicAdd(&fl.stage[agent], 1);
+        wq_push(fl.mw, &fl.hdr[FL_MW_TAIL], ((unsigned)WK_MAP_RESET << 28) | (unsigned)agent, n_r);
+        wq_push(fl.mw, &fl.hdr[FL_MW_TAIL], ((unsigned)WK_MAP_BITS << 28) | (unsigned)agent, n_b);
+      }
+      __syncthreads();
     }
-    const int g1 = base + 1, g2 = g1 + n_r + n_b + 1, g3 = g2 + n_m;
-    if (s < 1 + n_r + n_b) {
-      // ---- reset / bits (both behind the head; neither touches what the other writes) ----
-      if (flow_wait_count(&fl.stage[agent], g1, err)) break;
-      if (s < 1 + n_r) {
+    return;
+  }
+  long long c1_prev = 0;
+  int       kind_prev = 0;
+  for (;;) {
+    const unsigned t = (unsigned)flow_ticket(&fl.hdr[FL_MW_HEAD]);
+    if (t >= total) break;
+    const long long c0   = wall_clock64();
+    const int       desc = wq_take(fl.mw, t, err);
+    if (desc < 0) break;
+    __threadfence();
+    const long long c1 = wall_clock64();
+    if (lane == 0 && c1_prev) {
+      atomicAdd(&fl.prof[kind_prev], (unsigned long long)(c0 - c1_prev));  // the previous descriptor's work
+      atomicAdd(&fl.prof[8 + kind_prev], 1ull);
+    }
+    if (lane == 0) atomicAdd(&fl.prof[0], (unsigned long long)(c1 - c0));
+    const int          kind = desc >> 28, sub = (desc >> 16) & 0xFFF, agent = desc & 0xFFFF;
+    c1_prev   = c1;
+    kind_prev = kind;
+    const int          k = fl.tick_of[agent], kl = k - fl.first_tick;
+    const FlightWorld &w = d.worlds[kl];
+    CloudBlocks        cb = d.cb;
+    cb.bounds       = w.bounds;
+    cb.n_blocks     = w.n_blocks;
+    cb.block_points = w.block_points;
+    cb.n_points     = w.n_points;
+    long long     *ts  = fl.ts + (size_t)agent * 12;
+    const unsigned adr = (unsigned)agent;
+    if (kind == WK_MAP_RESET || kind == WK_MAP_BITS) {
+      if (kind == WK_MAP_RESET) {
         const unsigned n = d.lg.n[agent];
-        if (s == 1 && lane == 0 && reset_stat) {
+        if (sub == 0 && lane == 0 && reset_stat) {
           atomicAdd(reset_stat, (unsigned long long)(n > (unsigned)d.lg.cap ? (unsigned)d.lg.cap : n));
           if (agent == 0) atomicAdd(reset_stat + 1, 1ull);
         }
-        flight_reset_ticket(gbase, d.agent_bytes, lent, n, d.lg.cap, s - 1, n_r, lane, reset_stat);
+        flight_reset_ticket(reinterpret_cast<char *>(d.grid) + (size_t)agent * d.agent_bytes, d.agent_bytes,
+                            d.lg.entries + (size_t)agent * d.lg.cap, n, d.lg.cap, sub, n_r, lane, reset_stat);
       } else {
-        stamp_bits_blocks(g, w.cloud, cb, agent, s - 1 - n_r, n_b, d.poses[agent * 3], d.poses[agent * 3 + 1],
+        stamp_bits_blocks(g, w.cloud, cb, agent, sub, n_b, d.poses[agent * 3], d.poses[agent * 3 + 1],
                           d.poses[agent * 3 + 2], d.bits + (size_t)agent * d.words, lane);
       }
       __threadfence();
-      int last = 0;
-      if (lane == 0) last = atomicAdd(&fl.stage[agent], 1) + 1 == g1 + n_r + n_b;
-      if (__builtin_amdgcn_readfirstlane(last)) {  // the group is complete: the log restarts, then the marks may append
-        if (lane == 0) {
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-          d.lg.n[agent] = 0u;
-          __threadfence();
-          atomicAdd(&fl.stage[agent], 1);
-        }
+      if (lane == 0 && atomicAdd(&fl.stage[agent], 1) + 1 == kl * S + 1 + n_r + n_b) {
+        // the grid is clean and the bits are set: the log restarts, then the marks may append
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        d.lg.n[agent] = 0u;
+        wq_push(fl.mw, &fl.hdr[FL_MW_TAIL], ((unsigned)WK_MAP_MARKS << 28) | adr, n_m);
       }
-      continue;
-    }
-    if (s < 1 + n_r + n_b + n_m) {
-      // ---- marks ----
-      if (flow_wait_count(&fl.stage[agent], g2, err)) break;
+    } else if (kind == WK_MAP_MARKS) {
       stamp_marks_trips(g, d.grid, d.bits, d.words, w.cyl, w.n_cyl, d.poses, (const CylCand *)d.cand, d.n_cand, agent, d.lg,
-                        (s - 1 - n_r - n_b) * 256, n_m * 256, s_cand, PRESTAMP_CAND_LDS);
-      __syncthreads();  // (the next ticket's staging overwrites s_cand)
+                        sub * 256, n_m * 256, s_cand, PRESTAMP_CAND_LDS);
+      __syncthreads();  // (the next descriptor's staging overwrites s_cand)
       __threadfence();
-      if (lane == 0 && atomicAdd(&fl.stage[agent], 1) + 1 == g3) ts[10] = wall_clock64();
-      continue;
-    }
-    // ---- overlay of the neighbours' records of table ver(k - 2) ----
-    if (flow_wait_count(&fl.stage[agent], g3, err)) break;
-    if (d.tables && d.n_total > 0) {
-      const SogmTrajRecord *tab = d.tables + (size_t)((k - 2) & 3) * d.n_total;
-      const int items = d.n_total * g.T;
-      for (int i = (s - 1 - n_r - n_b - n_m) * 64 + lane; i < items; i += n_s * 64)
-        splat_item(g, d.grid, tab[i / g.T], agent, i % g.T, d.ego_ids, d.poses, d.stamps, d.body, d.n_body, d.lg);
-    }
-    __threadfence();
-    if (lane == 0 && atomicAdd(&fl.stage[agent], 1) + 1 == base + S) {  // the agent's map of tick k is complete
-      ts[11] = wall_clock64();
-      fl_publish(fl.s_ring, fl.ring_mask, &fl.hdr[FL_S_READY], agent);
+      if (lane == 0 && atomicAdd(&fl.stage[agent], 1) + 1 == kl * S + 1 + n_r + n_b + n_m) {
+        ts[10] = wall_clock64();
+        wq_push(fl.mw, &fl.hdr[FL_MW_TAIL], ((unsigned)WK_MAP_SPLAT << 28) | adr, n_s);
+      }
+    } else {  // WK_MAP_SPLAT: the neighbours' records of table ver(k - 2)
+      if (d.tables && d.n_total > 0) {
+        const SogmTrajRecord *tab = d.tables + (size_t)((k - 2) & 3) * d.n_total;
+        const int             n   = d.n_total * g.T;
+        for (int i = sub * 64 + lane; i < n; i += n_s * 64)
+          splat_item(g, d.grid, tab[i / g.T], agent, i % g.T, d.ego_ids, d.poses, d.stamps, d.body, d.n_body, d.lg);
+      }
+      __threadfence();
+      if (lane == 0 && atomicAdd(&fl.stage[agent], 1) + 1 == (kl + 1) * S) {  // the agent's map of tick k is complete
+        ts[11] = wall_clock64();
+        fl_publish(fl.s_ring, fl.ring_mask, &fl.hdr[FL_S_READY], agent);
+        atomicAdd(&fl.hdr[FL_MAPS_DONE], 1);  // one more agent may be admitted
+      }
     }
   }
 }

@@ -305,7 +305,7 @@ void sogm_planner_destroy(sogm_planner *p) {
   if (p->fl_ev_in) (void)hipEventDestroy(p->fl_ev_in);
   if (p->h_fl_worlds) (void)hipHostFree(p->h_fl_worlds);
   {
-    void *fp[] = {p->d_fl, p->d_fl_worlds, p->d_fl_pva, p->d_fl_tstart, p->d_fl_now, p->fl.ts, p->fl.acc};
+    void *fp[] = {p->d_fl, p->d_fl_worlds, p->d_fl_pva, p->d_fl_tstart, p->d_fl_now, p->fl.ts, p->fl.acc, p->fl.prof, p->fl.ts_log};
     for (void *q : fp)
       if (q) (void)hipFree(q);
   }
@@ -929,14 +929,17 @@ __global__ __launch_bounds__(256) void k_flight_reset(FlightCtl fl, int n_words,
   for (long long i = i0; i < n_log_words; i += step) log_words[i] = 0;
   for (long long i = i0; i < fl.n_agents; i += step) verdict[i] = 0;
   for (long long i = i0; i < 8ll * fl.n_agents; i += step) acc[i] = 0;
+  for (long long i = i0; i < 16; i += step) fl.prof[i] = 0ull;
 }
 __global__ __launch_bounds__(256) void k_flight_seed(FlightCtl fl) {
   const int a = blockIdx.x * blockDim.x + threadIdx.x;
   if (a < fl.n_agents) {
     fl.tick_of[a] = fl.first_tick;
-    fl.m_ring[a]  = (1 << 16) | a;
+    fl.m_ring[a]  = (1 << 16) | a;               // position a, generation 1: every agent's first head, in agent order
+    fl.ts[(size_t)a * 12 + 7] = wall_clock64();  // the head's publication
   }
   if (a == 0) fl.hdr[FL_M_READY] = fl.n_agents;
+  for (int i = a; i < FLIGHT_MAX_TICKS * fl.n_agents; i += (int)(gridDim.x * blockDim.x)) fl.parked[i] = -1;
 }
 __global__ void k_flight_report(const int *__restrict__ hdr, int *__restrict__ host_words) {
   const int e = hdr[FL_ERR];
@@ -956,25 +959,32 @@ static int flight_setup(sogm_planner *p) {
   int ring = 1;
   while (ring < 2 * A) ring <<= 1;
   if (A >= (1 << 16)) return SOGM_ERR_INVALID_ARG;
-  const size_t words = FL_HDR + 5 * (size_t)ring + FLIGHT_MAX_TICKS + 3 * (size_t)A;
+  const size_t words = FL_HDR + 3 * (size_t)ring + 4 * (size_t)FL_WQ_SLOTS + 2 * FLIGHT_MAX_TICKS + 3 * (size_t)A +
+                       (size_t)FLIGHT_MAX_TICKS * A;
   SOGM_HIP_CHECK(hipMalloc((void **)&p->d_fl, sizeof(int) * words));
   int *q          = p->d_fl;
   p->fl.hdr       = q;              q += FL_HDR;
-  p->fl.m_ring    = q;              q += ring;
   p->fl.s_ring    = q;              q += ring;
-  p->fl.a_ring    = q;              q += ring;
   p->fl.q_ring    = q;              q += ring;
-  p->fl.f_ring    = q;              q += ring;
+  p->fl.m_ring    = q;              q += ring;
+  if (ring & 1) q += 1;
+  p->fl.mw        = reinterpret_cast<unsigned long long *>(q);  q += 2 * FL_WQ_SLOTS;  // (FL_HDR and ring are even: 8-byte aligned)
+  p->fl.lw        = reinterpret_cast<unsigned long long *>(q);  q += 2 * FL_WQ_SLOTS;
   p->fl.tick_done = q;              q += FLIGHT_MAX_TICKS;
+  p->fl.parked_n  = q;              q += FLIGHT_MAX_TICKS;
   p->fl.tick_of   = q;              q += A;
   p->fl.seg_done  = q;              q += A;
-  p->fl.stage     = q;
+  p->fl.stage     = q;              q += A;
+  p->fl.parked    = q;
   p->fl.ring_mask = ring - 1;
   p->fl.n_agents  = A;
   SOGM_HIP_CHECK(hipMalloc((void **)&p->fl.ts, sizeof(long long) * 12 * (size_t)A));
   SOGM_HIP_CHECK(hipMalloc((void **)&p->fl.acc, sizeof(long long) * 8 * (size_t)A));
   SOGM_HIP_CHECK(hipMemset(p->fl.ts, 0, sizeof(long long) * 12 * (size_t)A));
   SOGM_HIP_CHECK(hipMemset(p->fl.acc, 0, sizeof(long long) * 8 * (size_t)A));
+  SOGM_HIP_CHECK(hipMalloc((void **)&p->fl.ts_log, sizeof(long long) * 12 * (size_t)A * FLIGHT_MAX_TICKS));
+  SOGM_HIP_CHECK(hipMalloc((void **)&p->fl.prof, sizeof(unsigned long long) * 16));
+  SOGM_HIP_CHECK(hipMemset(p->fl.prof, 0, sizeof(unsigned long long) * 16));
   SOGM_HIP_CHECK(hipMalloc((void **)&p->d_fl_worlds, sizeof(FlightWorld) * FLIGHT_MAX_TICKS));
   SOGM_HIP_CHECK(hipHostMalloc((void **)&p->h_fl_worlds, sizeof(FlightWorld) * FLIGHT_MAX_TICKS, hipHostMallocDefault));
   SOGM_HIP_CHECK(hipMalloc((void **)&p->d_fl_pva, sizeof(double) * 9 * (size_t)A));
@@ -1039,6 +1049,14 @@ int sogm_flight_run(sogm_planner *p, const SogmFlight *f, void *stream) {
   if (int rc = sogm::join_prestamp(c, main)) return rc;
   if (int rc = sogm::join_exchange(c, main)) return rc;
   if (int rc = flight_setup(p)) return rc;
+  {  // the work queues hold the descriptors of two ticks at most (an agent is at most one tick ahead of the slowest)
+    const long long per_tick = (long long)A * (1 + c->tune_i(SOGM_TUNE_FLIGHT_RESET) + c->tune_i(SOGM_TUNE_FLIGHT_BITS) +
+                                               c->tune_i(SOGM_TUNE_FLIGHT_MARKS) + c->tune_i(SOGM_TUNE_FLIGHT_SPLAT));
+    if (2 * per_tick > FL_WQ_SLOTS || 2ll * A * (SOGM_MAX_PIECES + 1) > FL_WQ_SLOTS) {
+      sogm::set_error_text("sogm_flight_run: agents x tickets per tick exceed the work queue (lower flight_marks / flight_bits)");
+      return SOGM_ERR_CAPACITY;
+    }
+  }
   const size_t agent_bytes = (size_t)c->spec.T * (size_t)c->geom.V * c->cell_bytes();
   if (agent_bytes % 32 != 0 || (reinterpret_cast<uintptr_t>(c->d_grid) & 31) != 0) {
     sogm::set_error_text("sogm_flight_run: agent grids must be 32-byte aligned (V * T * cell bytes a multiple of 32)");
@@ -1108,13 +1126,17 @@ int sogm_flight_run(sogm_planner *p, const SogmFlight *f, void *stream) {
   md.n_bits      = c->tune_i(SOGM_TUNE_FLIGHT_BITS);
   md.n_marks     = c->tune_i(SOGM_TUNE_FLIGHT_MARKS);
   md.n_splat     = c->tune_i(SOGM_TUNE_FLIGHT_SPLAT);
+  md.n_head_wgs  = c->tune_i(SOGM_TUNE_FLIGHT_HEADS) < p->fl_wgs[3] / 2 ? c->tune_i(SOGM_TUNE_FLIGHT_HEADS)
+                                                                        : (p->fl_wgs[3] / 2 > 0 ? p->fl_wgs[3] / 2 : 1);
+  md.n_admit     = c->tune_i(SOGM_TUNE_FLIGHT_ADMIT);
+  md.pace_ticks  = (int)(c->tune[SOGM_TUNE_FLIGHT_PACE_US] * 100.0);
   md.agent_bytes = agent_bytes;
   md.reset_stat  = c->d_reset_stat;
   const MapView mv = view_of(c);
   // frames + control block, in stream order on the caller's stream
   SOGM_HIP_CHECK(hipMemcpyAsync(p->d_fl_worlds, p->h_fl_worlds, sizeof(FlightWorld) * (size_t)f->n_ticks, hipMemcpyHostToDevice, main));
   const int       ring    = p->fl.ring_mask + 1;
-  const int       n_words = FL_HDR + 5 * ring + FLIGHT_MAX_TICKS + 3 * A;
+  const int       n_words = FL_HDR + 3 * ring + 4 * FL_WQ_SLOTS + 2 * FLIGHT_MAX_TICKS + 3 * A;  // (the parked lists: k_flight_seed)
   const long long n_log   = (long long)f->n_ticks * A * (long long)(sizeof(SogmTrajRecord) / sizeof(int));
   hipLaunchKernelGGL(k_flight_reset, dim3(256), dim3(256), 0, main, fl, n_words, p->aw.verdict, p->fl.acc,
                      reinterpret_cast<int *>(f->log_records), n_log);
@@ -1172,6 +1194,14 @@ int sogm_flight_run(sogm_planner *p, const SogmFlight *f, void *stream) {
   return SOGM_OK;
 }
 
+// diagnostics (tools/ only): every agent-tick's stamps of the last flight, [n_ticks][A][12] ticks of 10 ns
+int sogm_debug_flight_times(sogm_planner *p, long long *out_host, int n_ticks) {
+  if (!p || !p->d_fl || !out_host || n_ticks < 1 || n_ticks > FLIGHT_MAX_TICKS) return SOGM_ERR_INVALID_ARG;
+  SOGM_HIP_CHECK(hipDeviceSynchronize());
+  SOGM_HIP_CHECK(hipMemcpy(out_host, p->fl.ts_log, sizeof(long long) * 12 * (size_t)p->map->n_agents * n_ticks, hipMemcpyDeviceToHost));
+  return SOGM_OK;
+}
+
 int sogm_flight_stats(sogm_planner *p, double *out_ms, int32_t *out_hdr) {
   if (!p || !p->d_fl) return SOGM_ERR_INVALID_ARG;
   SOGM_HIP_CHECK(hipSetDevice(p->map->device));
@@ -1185,7 +1215,17 @@ int sogm_flight_stats(sogm_planner *p, double *out_ms, int32_t *out_hdr) {
     delete[] tmp;
     SOGM_HIP_CHECK(e);
   }
-  if (out_hdr) SOGM_HIP_CHECK(hipMemcpy(out_hdr, p->fl.hdr, sizeof(int32_t) * FL_HDR, hipMemcpyDeviceToHost));
+  if (out_hdr) {  // the counters, compacted (the device keeps them FL_STRIDE words apart)
+    int *tmp = new (std::nothrow) int[FL_HDR];
+    if (!tmp) return SOGM_ERR_INVALID_ARG;
+    const hipError_t e = hipMemcpy(tmp, p->fl.hdr, sizeof(int) * FL_HDR, hipMemcpyDeviceToHost);
+    for (int i = 0; i < 32; ++i) out_hdr[i] = i < FL_COUNTERS ? tmp[(size_t)i * FL_STRIDE] : 0;
+    delete[] tmp;
+    SOGM_HIP_CHECK(e);
+    unsigned long long prof[16];  // [16..31]: wave time by activity in units of 10 us (0-8), descriptor counts (9-15)
+    SOGM_HIP_CHECK(hipMemcpy(prof, p->fl.prof, sizeof(prof), hipMemcpyDeviceToHost));
+    for (int i = 0; i < 16; ++i) out_hdr[16 + i] = (int32_t)(i < 9 ? prof[i] / 1000ull : prof[i]);
+  }
   return SOGM_OK;
 }
 

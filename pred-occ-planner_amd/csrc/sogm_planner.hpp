@@ -103,19 +103,46 @@ __device__ inline int flow_ticket(int *counter) {  // one ticket per wave, unifo
 // an agent whose chain is done goes straight on to its next tick while a straggler still solves its QP.
 // Four persistent kernels, each on a stream with its own compute units (hipExtStreamCreateWithCUMask: co-resident by
 // construction — no residency gates, no dispatch-order assumptions, four hardware queues):
-//   k_flight_map     one-wave workgroups: per (agent, tick) S tickets — head (gate on tick k - 2, start state from the own
-//                    record, cull of cylinders and cloud blocks of the tick's SogmWorld frame), sparse reset of the
-//                    agent's grid through its mark log, occupancy bits, marks, neighbour overlay -> s_ring
-//   k_flight_search  one workgroup per (agent, attempt) ticket: hybrid A* (both attempts side by side) -> a_ring
-//   k_flight_light   one-wave workgroups, role-less over two queues: finish (deconfliction, record, publication,
-//                    tick accounting, the agent's next item -> m_ring) before corridor segments (-> q_ring)
-//   k_flight_qp      one workgroup per CU: the Bezier QP -> f_ring
-// Hand-over: rings in HBM indexed by a monotonic position; a slot holds ((position / R + 1) << 16) | agent, so a reader
-// with ticket t takes its item when the slot's generation is t / R + 1 (R >= 2 A: an agent has one item in flight).
+//   k_flight_map     a few admitting waves + role-less one-wave workgroups over ONE work queue of ready map work (a descriptor
+//                    is pushed when its prerequisites are complete, so no worker sits waiting on another).  The admitting
+//                    waves take agents in the order their previous tick finished and let `flight_admit` maps be under
+//                    construction at once: agents leave the map stage one after the other and stay spread over the stages
+//                    — a swarm whose agents all share every stage equally moves in step, and then every kernel's compute
+//                    units idle while another kernel's are busy.  Head (gate on
+//                    tick k - 2, start state from the own record, cull of cylinders and cloud blocks of the tick's
+//                    SogmWorld frame) -> sparse reset of the agent's grid through its mark log + occupancy bits -> marks
+//                    -> neighbour overlay -> s_ring
+//   k_flight_search  one workgroup per (agent, attempt) ticket: hybrid A* (both attempts side by side) -> 16 corridor descriptors
+//   k_flight_light   role-less one-wave workgroups over ONE work queue: corridor segments (-> q_ring) and finish items
+//                    (deconfliction, record, publication, tick accounting, the agent's next map head descriptor)
+//   k_flight_qp      one workgroup per CU: the Bezier QP -> a finish descriptor
+// Hand-over to the search and QP kernels: rings in HBM indexed by a monotonic position; a slot holds
+// ((position / R + 1) << 16) | agent, so a reader with ticket t takes its item when the slot's generation is t / R + 1
+// (R >= 2 A: an agent has one item in flight).  To the one-wave kernels: work queues (below).
 // Per-agent buffers (start state, route, polytopes, control points, grid, mark log) are single: an agent's chain is
 // strictly sequential.  Swarm tables: a ring of four versions, ver(j) at slot j & 3.
-enum { FL_M_READY = 0, FL_M_TICKET, FL_S_READY, FL_S_TICKET, FL_A_READY, FL_C_TICKET, FL_Q_READY, FL_Q_TICKET,
-       FL_F_READY, FL_F_TICKET, FL_ERR, FL_FINISHED /* agent-ticks finished */, FL_HDR = 16 };
+// Every counter of the header sits 4 KiB from the next: idle waves poll words of it, and with all of them in one 128-byte
+// line ~900 polling waves saturated that line's memory channel — every claim of every kernel queued behind the polls.
+#define FL_STRIDE 1024
+enum { FL_S_READY = 0 * FL_STRIDE, FL_S_TICKET = 1 * FL_STRIDE, FL_Q_READY = 2 * FL_STRIDE, FL_Q_TICKET = 3 * FL_STRIDE,
+       FL_ERR = 4 * FL_STRIDE, FL_FINISHED = 5 * FL_STRIDE /* agent-ticks finished */,
+       FL_MW_TAIL = 6 * FL_STRIDE, FL_MW_HEAD = 7 * FL_STRIDE,   // work queue of the map kernel: descriptors pushed / tickets taken
+       FL_LW_TAIL = 8 * FL_STRIDE, FL_LW_HEAD = 9 * FL_STRIDE,   // work queue of the corridor + finish kernel
+       FL_M_READY = 10 * FL_STRIDE, FL_M_TICKET = 11 * FL_STRIDE,  // map heads: agents whose previous tick is finished / admitted
+       FL_MAPS_DONE = 12 * FL_STRIDE,                               // maps completed (admission control)
+       FL_ADMITTED = 13 * FL_STRIDE,                                // heads admitted so far (they are admitted in ticket order)
+       FL_PACE_CLOCK = 14 * FL_STRIDE,                              // (two words) wall clock of the last admission
+       FL_COUNTERS = 15, FL_HDR = 15 * FL_STRIDE };
+// Work queues (map kernel, corridor + finish kernel): ONE FIFO of ready work per kernel.  A producer reserves positions with
+// one atomicAdd on the tail and stores a descriptor per position, tagged with the position's generation; a consumer takes a
+// ticket with one atomicAdd on the head and waits for ITS position (idle waves therefore poll distinct words).  Every
+// published descriptor is taken by the lowest waiting ticket, whatever its kind: no wave ever waits for work that depends
+// on work nobody is free to do.  (Two earlier forms: all tickets of an item handed out in order and waiting for each
+// other — 512 waves / 61 tickets = 8 maps in flight; a compare-and-swap claim per phase queue — hundreds of waves
+// retrying on one counter, the map stage took 5-28 ms per agent and got SLOWER with more waves or tickets.)
+// descriptor: kind << 28 | sub << 16 | agent
+enum { WK_MAP_HEAD = 0, WK_MAP_RESET = 1, WK_MAP_BITS = 2, WK_MAP_MARKS = 3, WK_MAP_SPLAT = 4, WK_CORRIDOR = 5, WK_FINISH = 6 };
+#define FL_WQ_SLOTS 131072  // per queue (a tick of 128 agents pushes 8-25 k map descriptors; at most two ticks are in flight)
 #define FLIGHT_MAX_TICKS 64
 struct FlightWorld {  // one SogmWorld frame as the kernels read it
   const float        *cloud, *bounds;
@@ -124,16 +151,24 @@ struct FlightWorld {  // one SogmWorld frame as the kernels read it
 };
 struct FlightCtl {
   int *hdr;                                         // [FL_HDR]
-  int *m_ring, *s_ring, *a_ring, *q_ring, *f_ring;  // [ring_mask + 1] each
+  int *s_ring, *q_ring, *m_ring;                    // [ring_mask + 1] each: maps ready for the search, corridors final for the QP,
+                                                    // agents whose previous tick is finished (map heads)
+  unsigned long long *mw, *lw;                      // [FL_WQ_SLOTS] work queues of the map / the corridor + finish kernel
   int  ring_mask;
   int *tick_done;   // [FLIGHT_MAX_TICKS] agents that have finished tick first_tick + i
+  int *parked_n;    // [FLIGHT_MAX_TICKS] heads of tick first_tick + i parked at the gate "tick i - 2 is complete" ...
+  int *parked;      // [FLIGHT_MAX_TICKS][A] ... the agents (-1 empty, -2 released)
   int *tick_of;     // [A] the tick the agent is in (absolute index)
   int *seg_done;    // [A] cumulative corridor segment slots finished
   int *stage;       // [A] cumulative map tickets finished
   long long *ts;    // [A][12] stamps of the agent's current tick: 0 A* start, 1 A* done, 2 first corridor item, 3 corridors
-                    //         final, 4 QP start, 5 QP done, 6 finished, 7 -, 8 map head start, 9 gate passed, 10 marks done, 11 map ready
+                    //         final, 4 QP start, 5 QP done, 6 finished, 7 map item published, 8 map head start, 9 gate passed, 10 marks done, 11 map ready
   long long *acc;   // [A][8] sums over the flight (100 MHz ticks): gate wait, map, search queue + A*, corridors, QP queue + QP,
                     //        finish, whole chain, ticks completed
+  long long *ts_log;         // [FLIGHT_MAX_TICKS][A][12] every agent-tick's stamps (sogm_debug_flight_times)
+  unsigned long long *prof;  // [16] wave time (100 MHz ticks) by activity, summed over the flight: 0 map workers idle (waiting
+                             //      for a descriptor), 1 reset, 2 bits, 3 marks, 4 overlay, 5 heads (incl. their waits),
+                             //      6 light waves idle, 7 corridor segments, 8 finish; 9.. descriptor counts of 1-4, 7, 8
   int  n_agents, n_ticks, first_tick;
 };
 #ifdef __HIPCC__
@@ -160,22 +195,36 @@ __device__ inline int fl_wait_item(const int *ring, int mask, int pos, int *err)
     }
   }
 }
-// non-blocking claim of the next ticket of a queue whose items carry `per_item` tickets: the ticket number, or -1 when no
-// published item has an unclaimed ticket (wave-uniform; lane 0 does the compare-and-swap)
-__device__ inline int fl_try_claim(int *ticket, const int *ready_n, int per_item) {
-  int t = -1;
-  if ((threadIdx.x & 63) == 0) {
-    for (;;) {
-      const int cur = __hip_atomic_load(ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const int rdy = __hip_atomic_load(ready_n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (cur >= rdy * per_item) break;
-      if (atomicCAS(ticket, cur, cur + 1) == cur) {
-        t = cur;
-        break;
-      }
+// work queue, producer side (ONE lane): `count` descriptors desc0, desc0 + (1 << 16), ... (consecutive `sub` fields)
+__device__ inline void wq_push(unsigned long long *wq, int *tail, unsigned desc0, int count) {
+  __threadfence();
+  const unsigned base = (unsigned)atomicAdd(tail, count);
+  for (int i = 0; i < count; ++i) {
+    const unsigned pos = base + (unsigned)i;
+    const unsigned long long v = ((unsigned long long)(pos / FL_WQ_SLOTS + 1u) << 32) | (desc0 + ((unsigned)i << 16));
+    __hip_atomic_store(wq + (pos % FL_WQ_SLOTS), v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+// work queue, consumer side (wave-uniform): the descriptor at position `pos` (bounded wait; -1 = the flight failed)
+__device__ inline int wq_take(const unsigned long long *wq, unsigned pos, int *err) {
+  const unsigned  want = pos / FL_WQ_SLOTS + 1u;
+  const long long t0   = wall_clock64();
+  int             naps = 0;
+  for (;;) {
+    const unsigned long long v  = __hip_atomic_load(wq + (pos % FL_WQ_SLOTS), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned           hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    if (hi == want) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      return (int)__builtin_amdgcn_readfirstlane((unsigned)v);
+    }
+    for (int i = 0; i <= (naps < 7 ? naps : 7); ++i) flow_pause();  // 14 us ... 110 us: an idle wave polls less and less
+    ++naps;
+    if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0) return -1;
+    if (wall_clock64() - t0 > FLOW_TIMEOUT_TICKS) {
+      if ((threadIdx.x & 63) == 0) atomicExch(err, 15);
+      return -1;
     }
   }
-  return __builtin_amdgcn_readfirstlane(t);
 }
 #endif
 // the map role's arguments (csrc/sogm_map.hip, k_flight_map)
@@ -199,6 +248,9 @@ struct FlightMapDev {
   float                *poses;         // the context's map centres / stamps (queries read them)
   double               *stamps;
   int                   n_reset, n_bits, n_marks, n_splat;  // one-wave tickets per agent and tick
+  int                   n_head_wgs;    // workgroups 0 .. n_head_wgs - 1 of the launch admit agents (heads), the rest work off the queue
+  int                   n_admit;       // agents whose map may be under construction at once
+  int                   pace_ticks;    // 100 MHz ticks between two admissions (0 = as fast as the heads run)
   size_t                agent_bytes;
   unsigned long long   *reset_stat;    // the context's reset statistics (sogm_sparse_reset_state / sogm_map_traffic), or null
 };

@@ -1760,7 +1760,7 @@ __global__ __launch_bounds__(QP_NT) void k_flight_qp(SogmPlannerParams pp, SogmQ
     __syncthreads();
     if (threadIdx.x == 0) {
       fl.ts[agent * 12 + 5] = wall_clock64();
-      fl_publish(fl.f_ring, fl.ring_mask, &fl.hdr[FL_F_READY], agent);
+      wq_push(fl.lw, &fl.hdr[FL_LW_TAIL], ((unsigned)WK_FINISH << 28) | (unsigned)agent, 1);
     }
     __syncthreads();
   }

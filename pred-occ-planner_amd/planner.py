@@ -214,9 +214,9 @@ class SogmPlanner:
         check(lib().sogm_flight_run(self._p, C.byref(f), _stream()), "sogm_flight_run")
 
     def flight_stats(self):
-        """(per-agent sums [A, 8] in ms: _abi.FLIGHT_STAT_NAMES, control header [16]) of the last flight; synchronises"""
+        """(per-agent sums [A, 8] in ms: _abi.FLIGHT_STAT_NAMES, control counters [32]) of the last flight; synchronises"""
         ms = np.zeros((self.A, 8), np.float64)
-        hdr = np.zeros((16,), np.int32)
+        hdr = np.zeros((32,), np.int32)
         check(lib().sogm_flight_stats(self._p, ms.ctypes.data_as(C.c_void_p), hdr.ctypes.data_as(C.c_void_p)),
               "sogm_flight_stats")
         return ms, hdr

@@ -35,14 +35,16 @@ def _lockstep_lag2(driver, grid, A, n, **kw):
 
 def _flight(driver, grid, A, chunks, **kw):
     import torch
+    pop_abi = importlib.import_module("pred-occ-planner_amd")._abi
     sw = driver.SwarmTick(grid, A, moving_world=True, prestamp=False, **kw)
     oks, recs = [], []
     for n in chunks:
         ok, rec = sw.fly(n)
         torch.cuda.synchronize()
         ms, hdr = sw.planner.flight_stats()
-        assert hdr[10] == 0 and sw.planner.flow_failures() == (0, 0), (hdr.tolist(), sw.planner.flow_failures())
-        assert hdr[11] == A * n and (ms[:, 7] == n).all(), (hdr.tolist(), ms[:, 7])
+        E, F = sw.planner._abi_idx = (pop_abi.FLIGHT_HDR_ERR, pop_abi.FLIGHT_HDR_FINISHED)
+        assert hdr[E] == 0 and sw.planner.flow_failures() == (0, 0), (hdr.tolist(), sw.planner.flow_failures())
+        assert hdr[F] == A * n and (ms[:, 7] == n).all(), (hdr.tolist(), ms[:, 7])
         oks.append(ok.cpu().numpy().copy())
         recs.append(rec.cpu().numpy().copy())
     own = sw.own.cpu().numpy().copy()
