@@ -43,6 +43,8 @@ def parse():
                     help="ticks of the block that runs the DENSE clear inside the tick (kernels[dense clear].in_tick; 0 = skip)")
     ap.add_argument("--sustained", type=int, default=300,
                     help="ticks of the sustained-flight block after the timed region (0 = skip)")
+    ap.add_argument("--no-variants", action="store_true", dest="no_variants",
+                    help="skip the labelled variants (pre-stamped lock-step, sogm_flight_run) and the cfg1 / cfg4 blocks")
     return ap.parse_args()
 
 
@@ -157,7 +159,7 @@ def cpu_baseline(pop, spec, scene, n_agents_sample):
                       f"{sum(oks)}/{n} succeeded, {dt:.1f} s wall"}
 
 
-def flow_chain(pop, sw):
+def flow_chain(pop, sw, absolute=False):
     """Per-agent stage times of the LAST dataflow replan (device timestamps, sogm_debug_flow_times): how the tick runs
     the stages — chained per agent — and which agent's chain ended it.  Synchronises."""
     import ctypes as C
@@ -182,7 +184,8 @@ def flow_chain(pop, sw):
                "us_per_iteration": float(st[q, 0] - st[q, 1] - st[q, 2] - st[q, 4]) / 100.0 / its,
                "register_resident": bool(st[q, 7] & 1), "rows_in_lds": bool(st[q, 7] & 2),
                "shader_clock_ghz": float(st[q, 11]) / max(float(st[q, 0]) * 10.0, 1.0)}
-    return {"slowest_qp": slow_qp,"astar_mean": float(d(0, 1).mean()), "astar_max": float(d(0, 1).max()),
+    extra = {"first_resident_s": float(t0) * 1e-8, "last_finish_s": float(ts[:, 6].max()) * 1e-8} if absolute else {}
+    return {**extra, "slowest_qp": slow_qp,"astar_mean": float(d(0, 1).mean()), "astar_max": float(d(0, 1).max()),
             "corridor_mean": float(d(2, 3).mean()), "corridor_max": float(d(2, 3).max()),
             "qp_mean": float(d(4, 5).mean()), "qp_max": float(d(4, 5).max()),
             "finish_mean": float(d(5, 6).mean()), "chain_mean": float(ms[:, 6].mean()), "chain_end": float(ms[:, 6].max()),
@@ -227,7 +230,7 @@ def main():
                           moving_world=moving)
     spec = sw.spec
     n_frames = args.warmup + args.steps + (3 + args.dense_ticks if args.dense_ticks > 0 else 0) + \
-        (3 + args.sustained if args.sustained > 0 else 0) + 8
+        (3 + args.sustained if args.sustained > 0 else 0) + (3 + args.steps) + 8
     t_up = time.perf_counter()
     sw.compute.prepare(0, n_frames)
     world_upload_s = time.perf_counter() - t_up
@@ -450,7 +453,9 @@ def main():
                    # where the timed replans ended + capacity limits hit (sogm_planner_counters)
                    "outcomes": outcomes,
                    "parallelism": f"agents sharded x{world}, 1 all-gather/tick",
-                   "tick_overlap": "lock-step (every agent's tick k ends before any agent's tick k + 1 starts)",
+                   "tick_overlap": "lock-step (every agent's tick k ends before any agent's tick k + 1 starts; overlay and "
+                                   "isSafeAfterOpt read the neighbours' records of tick k - 1) — variants.flight: per-agent overlap "
+                                   "under the staleness rule (sogm_flight_run)",
                    # which all-gather ran: "abi" = sogm_traj_allgather (RCCL behind the C ABI), "local" = one process
                    "exchange": exchange_kind,
                    "exchange_fallback_reason": sw.exchange.fallback_reason,
@@ -505,6 +510,8 @@ def main():
                               "tick_ms": dense_tick_ms,
                               "where": f"{args.dense_ticks} ticks with the sparse reset off (sogm_set_sparse_reset 0), after the timed region"}
         sw.map.set_profiling(False)
+    variants = {}
+    sparse_on, pool_mode = sparse["enabled"], sw.overlap_mode
     if args.sustained > 0:
         # sustained flight: the 20-step figure covers the first seconds (agents still far apart); keep flying —
         # the swarm converges on the centre, searches get longer — and time every tick (host-synchronised)
@@ -514,17 +521,46 @@ def main():
             for _ in range(3):  # untimed: every grid of the pool is cleared densely once before its log takes over
                 sw.step()
         sw.planner.counters(reset=True)
-        tick_ms, oks2 = [], []
+        # the device's wall clock against the host's (sogm_device_clock): the slowest tick is split with it
+        barrier()
+        offs = []
+        for _ in range(5):
+            h_a = time.perf_counter()
+            d_s, h_b = sw.map.device_clock()
+            offs.append((h_b - h_a, h_b - d_s))   # host = device + offset, measured at the call's return
+        clock_offset = min(offs)[1]
+        clock_err_ms = min(offs)[0] * 1e3
+        tick_ms, oks2, marks = [], [], []
         slowest = None
+        sw.map.map_traffic(reset=True)
         barrier()
         for _ in range(args.sustained):
             t1 = time.perf_counter()
             oks2.append(sw.step())
+            t_l = time.perf_counter()
             torch.cuda.synchronize()
-            tick_ms.append((time.perf_counter() - t1) * 1e3)
+            t2 = time.perf_counter()
+            tick_ms.append((t2 - t1) * 1e3)
             if slowest is None or tick_ms[-1] > slowest["tick_ms"]:  # (between two timed ticks: not in either)
-                slowest = dict(flow_chain(pop, sw) or {}, tick=sw.tick - 1, tick_ms=tick_ms[-1])
+                d_upd, d_rep = sw.map.tick_clock()
+                ch = flow_chain(pop, sw, absolute=True) or {}
+                split = None
+                if ch and d_upd > 0 and d_rep > 0:
+                    first_res, last_fin = ch.pop("first_resident_s"), ch.pop("last_finish_s")
+                    to_h = lambda d: d + clock_offset
+                    split = {"host_launch_until_first_kernel": (to_h(d_upd) - t1) * 1e3,
+                             "map_update_until_first_search_resident": (first_res - d_upd) * 1e3,
+                             "chain_first_search_to_last_finish": (last_fin - first_res) * 1e3,
+                             "last_finish_to_closing_kernel": (d_rep - last_fin) * 1e3,
+                             "closing_kernel_to_host_sync_return": (t2 - to_h(d_rep)) * 1e3,
+                             "host_launch_calls_ms": (t_l - t1) * 1e3,
+                             "clock_alignment_error_ms": clock_err_ms}
+                    split["sum"] = sum(v for k, v in split.items() if k not in ("host_launch_calls_ms", "clock_alignment_error_ms"))
+                slowest = dict(ch, tick=sw.tick - 1, tick_ms=tick_ms[-1], split_ms=split)
+            mv = sw.map.map_traffic(reset=True)   # (synchronises; between two timed ticks)
+            marks.append(int(mv["stamp_marks"]))
         tm = np.array(tick_ms)
+        mk = np.array(marks, np.float64)
         n_ok2 = int(torch.stack(oks2).sum().item())
         out["sustained"] = {"ticks": args.sustained, "flight_seconds": args.sustained * driver.TICK_PERIOD,
                             "first_tick": sw.tick - args.sustained,
@@ -534,8 +570,13 @@ def main():
                             "value_ok": n_ok2 * world / (tm.sum() * 1e-3),
                             "replans_ok_fraction": n_ok2 / float(sw.A_loc * args.sustained),
                             "outcomes_rank0": sw.planner.counters(reset=False),
-                            # the slowest tick accounted for: its critical agent's chain (device timestamps) — the part of
-                            # tick_ms the chain does not cover is host / launch time of that tick
+                            # the world keeps being stamped: cells marked per tick over the block (per-tick device crops
+                            # around the agents' current map centres; the frozen crops of round 4 decayed as agents left them)
+                            "stamp_marks_per_tick": {"first_tenth_mean": float(mk[:max(1, len(mk) // 10)].mean()),
+                                                     "last_tenth_mean": float(mk[-max(1, len(mk) // 10):].mean()),
+                                                     "min": float(mk.min()), "max": float(mk.max()), "mean": float(mk.mean())},
+                            # the slowest tick accounted for: host launch -> first kernel -> first search resident -> last
+                            # finish -> closing kernel -> host sync return (device stamps mapped onto the host clock)
                             "slowest_tick": slowest,
                             "note": "every tick host-synchronised (no overlap between ticks); rank 0's clock"}
         flow_code, flow_failed = sw.planner.flow_failures()
@@ -544,11 +585,132 @@ def main():
         c2 = sw.planner.counters(reset=True)
         if c2["corridor_capacity"] + c2["pieces_capacity"] + c2["deconflict_capacity"]:
             raise SystemExit(f"bench.py: capacity limits hit during the sustained block ({c2})")
+    scene_kept, seed_kept = sw.scene, None
+    sw.close()
+    sw = None
+    if not args.no_variants and world == 1 and moving and sparse_on and pool_mode >= 2:
+        # ---- labelled variant: the pre-stamp (round 4's headline path) on the moving world, a fresh swarm flying the SAME
+        # ticks as the headline.  The replan of tick k builds tick k + 1's map from frame k, the newest frame that exists while
+        # it runs: the update leaves the critical path, the map a tick plans on is one tick staler than the reference's.
+        torch.cuda.empty_cache()
+        pw = driver.SwarmTick(args.grid, A_loc, 0, 1, local, deconflict=not args.no_deconflict, moving_world=True, prestamp=True,
+                              scene=scene_kept)
+        if pw.prestamp:
+            pw.compute.prepare(0, args.warmup + args.steps + 1)
+            for _ in range(args.warmup):
+                pw.step()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            okv = [pw.step() for _ in range(args.steps)]
+            torch.cuda.synchronize()
+            dtv = time.perf_counter() - t1
+            if pw.planner.flow_failures()[1]:
+                raise SystemExit("bench.py: a tick of the pre-stamped variant failed on the device")
+            variants["prestamped_lockstep"] = {
+                "value": pw.A_tot * args.steps / dtv, "unit": "replans/s", "ms_per_step": dtv / args.steps * 1e3,
+                "replans_ok_fraction": int(torch.stack(okv).sum().item()) / float(pw.A_loc * args.steps),
+                "map_input_staleness_ticks": pw.map_input_staleness_ticks, "neighbour_record_staleness_ticks": 1,
+                "what": "lock-step tick whose replan also builds the NEXT tick's map (sogm_planner_set_prestamp) from the frame "
+                        "of the tick in flight: the update leaves the critical path, the map is one tick stale; same scene and "
+                        "ticks as the headline"}
+        pw.close()
+        pw = None
+    if not args.no_variants and world == 1 and moving:
+        # ---- labelled variant: sogm_flight_run — every agent on its own clock under the staleness rule (own record of tick
+        # k - 1, neighbours' of tick k - 2), a fresh swarm flying the SAME ticks as the headline (3 warm-up + 20 timed), then
+        # the same 300 ticks as the sustained block in flights of 20.  Same maps as the headline (staleness 0).
+        torch.cuda.empty_cache()
+        fw = driver.SwarmTick(args.grid, A_loc, 0, 1, local, deconflict=True, moving_world=True, prestamp=False, grids=1,
+                              scene=scene_kept)
+        n_fl = args.warmup + args.steps + (args.sustained if args.sustained > 0 else 0)
+        fw.compute.prepare(0, n_fl + 1)
+        fw.fly(args.warmup)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        okf, _ = fw.fly(args.steps) if args.steps <= pop._abi.FLIGHT_MAX_TICKS else (None, None)
+        torch.cuda.synchronize()
+        dtf = time.perf_counter() - t1
+        msf, hdr = fw.planner.flight_stats()
+        if hdr[pop._abi.FLIGHT_HDR_ERR] != 0 or fw.planner.flow_failures()[1]:
+            raise SystemExit(f"bench.py: the flight failed on the device (code {hdr[pop._abi.FLIGHT_HDR_ERR]})")
+        per = (msf[:, :7].sum(axis=0) / msf[:, 7].sum()).tolist()
+        fl = {"value": fw.A_tot * args.steps / dtf, "unit": "replans/s", "ms_per_step": dtf / args.steps * 1e3,
+              "replans_ok_fraction": int(okf.sum().item()) / float(fw.A_loc * args.steps),
+              "map_input_staleness_ticks": 0, "neighbour_record_staleness_ticks": 2,
+              "tick_overlap": "per agent: tick k starts when the agent's own tick k - 1 is finished and every agent has finished "
+                              "tick k - 2; it reads its own record of tick k - 1 and the neighbours' records of tick k - 2",
+              "per_agent_tick_ms": dict(zip(pop._abi.FLIGHT_STAT_NAMES[:7], per)),
+              "what": "sogm_flight_run: ONE call for all timed ticks, four persistent kernels on four CU-masked streams; "
+                      "records bit-identical to the same rule flown lock-step (tests/test_flight_gpu.py)"}
+        if args.sustained > 0:
+            per_flight, oks3, left = [], [], args.sustained
+            while left > 0:
+                n = min(20, left)
+                t1 = time.perf_counter()
+                ok_, _ = fw.fly(n)
+                torch.cuda.synchronize()
+                per_flight.append((time.perf_counter() - t1) * 1e3 / n)
+                oks3.append(ok_)
+                left -= n
+            _, hdr = fw.planner.flight_stats()
+            if hdr[pop._abi.FLIGHT_HDR_ERR] != 0:
+                raise SystemExit(f"bench.py: a sustained flight failed on the device (code {hdr[pop._abi.FLIGHT_HDR_ERR]})")
+            pf = np.array(per_flight)
+            fl["sustained"] = {"ticks": args.sustained, "flights_of": 20, "first_tick": args.warmup + args.steps,
+                               "ms_per_tick_mean": float(pf.mean()), "ms_per_tick_worst_flight": float(pf.max()),
+                               "ms_per_tick_best_flight": float(pf.min()),
+                               "value": fw.A_tot * args.sustained / (pf.sum() * 20 * 1e-3) if args.sustained % 20 == 0 else None,
+                               "replans_ok_fraction": int(torch.cat(oks3).sum().item()) / float(fw.A_loc * args.sustained)}
+        cf = fw.planner.counters(reset=True)
+        if cf["corridor_capacity"] + cf["pieces_capacity"] + cf["deconflict_capacity"]:
+            raise SystemExit(f"bench.py: capacity limits hit during the flights ({cf})")
+        variants["flight"] = fl
+        fw.close()
+        torch.cuda.empty_cache()
+    out["variants"] = variants
+    if not args.no_variants and world == 1 and args.grid == "cfg2":
+        # ---- the other BASELINE configurations that fit one GPU, driver-timed in the same run
+        cfgs = {}
+        try:
+            torch.cuda.empty_cache()
+            s4 = driver.SwarmTick("cfg4", pop.config.AGENTS["cfg4"], 0, 1, local, moving_world=True)
+            s4.compute.prepare(0, 16)
+            for _ in range(3):
+                s4.step()
+            torch.cuda.synchronize()
+            s4.map.set_profiling(slots=(0, 6))
+            s4.map.map_traffic(reset=True)
+            t1 = time.perf_counter()
+            ok4 = [s4.step() for _ in range(10)]
+            torch.cuda.synchronize()
+            dt4 = time.perf_counter() - t1
+            r_ms = np.array(s4.map.profile_read_all(0))
+            mv4 = s4.map.map_traffic(reset=True)
+            b4 = (4.0 * mv4["reset_entries"] + mv4["reset_bytes_zeroed"]) / max(int(mv4["resets"]), 1)
+            cfgs["cfg4"] = {"workload": f"BASELINE configs[4]: {s4.A_loc} agents, {s4.spec.L}x{s4.spec.W}x{s4.spec.H}x{s4.spec.T} SOGM, "
+                                        "fp16 occupancy cells (a single grid per agent: 207 GB), moving world, lock-step",
+                            "replans_per_s": s4.A_tot * 10 / dt4, "ms_per_step": dt4 / 10 * 1e3, "steps": 10,
+                            "replans_ok_fraction": int(torch.stack(ok4).sum().item()) / float(s4.A_loc * 10),
+                            "sogm_grids_per_agent": s4.overlap_mode if s4.overlap_mode >= 2 else 1,
+                            "roofline": {"bound": "hbm", "kernel": "k_reset_sectors (fp16 sectors of 16 cells)",
+                                         "bytes_per_launch": b4, "avg_launch_ms": float(r_ms.mean()) if len(r_ms) else None,
+                                         "achieved": (b4 / (r_ms.mean() * 1e-3) / 1e9) if len(r_ms) else None, "peak": PEAK,
+                                         "unit": "GB/s", "frac": (b4 / (r_ms.mean() * 1e-3) / 1e9 / PEAK) if len(r_ms) else None,
+                                         "launches_timed": int(len(r_ms))}}
+            if s4.planner.flow_failures()[1]:
+                raise SystemExit("bench.py: a cfg4 tick failed on the device")
+            s4.close()
+            torch.cuda.empty_cache()
+        except pop.SogmError as e:  # (e.g. HBM already held by another process: say so, do not invent a figure)
+            cfgs["cfg4"] = {"error": str(e)[:300]}
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        bench_dsp = importlib.import_module("bench_dsp")
+        cfgs["cfg1"] = bench_dsp.run("cfg1", None, 30, 5)
+        out["configs"] = cfgs
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(pop, spec, sw.scene, args.cpu_agents)
+        out["cpu_baseline"] = cpu_baseline(pop, spec, scene_kept, args.cpu_agents)
     else:
         out["cpu_baseline"] = None
-    sw.close()
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:

@@ -302,6 +302,14 @@ int sogm_profile_read_all(sogm_ctx *ctx, int slot, double *out_ms_host, int cap,
  */
 int sogm_set_overlap_clear(sogm_ctx *ctx, int mode);
 
+/* Where a tick's wall time goes (bench.py's sustained.slowest_tick).  sogm_device_clock runs a one-lane kernel on `stream`
+ * that reads the device's 100 MHz wall clock, synchronises the stream and returns the value: a host that brackets the call with
+ * its own clock learns the offset between the two clocks to within the synchronisation's return latency (also arms the
+ * stamps below).  sogm_tick_clock: host out[2] = that clock at the start of the last map update's first kernel and in the
+ * last sogm_replan's closing kernel (pinned memory, no synchronisation: read them after one). */
+int sogm_device_clock(sogm_ctx *ctx, int64_t *out_ticks_host, void *stream);
+int sogm_tick_clock(sogm_ctx *ctx, int64_t *out2_host);
+
 /* ------------------------------------------------------------------------------------------ */
 /* SOGM update                                                                                 */
 /* ------------------------------------------------------------------------------------------ */

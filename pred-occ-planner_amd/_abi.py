@@ -155,6 +155,8 @@ PROTOTYPES = {
     "sogm_update_gt": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
     "sogm_project_neighbours": (_i, [_vp, _vp, _i, _vp, _vp]),
     "sogm_update_gt_swarm": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp]),
+    "sogm_device_clock": (_i, [_vp, C.POINTER(C.c_int64), _vp]),
+    "sogm_tick_clock": (_i, [_vp, C.POINTER(C.c_int64)]),
     "sogm_cloud_block_bounds": (_i, [_vp, _i, _i, _vp, _vp]),
     "sogm_update_world": (_i, [_vp, C.POINTER(SogmWorld), _vp, _vp, _vp, _i, _vp, _vp]),
     "sogm_set_future_risk": (_i, [_vp, _vp, _vp, _vp, _vp]),

@@ -442,6 +442,8 @@ struct sogm_ctx {
   unsigned long long *d_reset_stat;  // [8]: {entries read, launches, bytes zeroed, -} of k_reset_sectors since the last
                                      // state query; {marks written, entries logged, -, -} of the stamp (sogm_map_traffic)
   long long      n_stamps;           // stamps launched since the last sogm_map_traffic reset (host count)
+  long long     *h_tick_clock;       // pinned, device-visible [4]: wall_clock64 (100 MHz) of {the last update's first kernel,
+                                     // the last replan's report, the last sogm_device_clock kernel, -} (sogm_tick_clock)
   // history of each pool slot since the pool was (re)built: resets through its log, dense clears (host-side launch
   // counts), and whether the CURRENT grid was built by a replan's pre-stamp (sogm_grid_history: lets a parity test
   // assert that the grid it compares went through k_reset_sectors and k_prestamp_flow)

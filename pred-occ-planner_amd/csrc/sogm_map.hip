@@ -310,8 +310,9 @@ __global__ __launch_bounds__(64) void k_cull_cylinders(GridGeom g, const SogmCyl
                                                        const float *__restrict__ poses, CylCand *__restrict__ cand,
                                                        int *__restrict__ n_cand, const double *__restrict__ stamps_in,
                                                        float *__restrict__ poses_out, double *__restrict__ stamps_out,
-                                                       CloudBlocks cb) {
+                                                       CloudBlocks cb, long long *__restrict__ tick_clock) {
   const int    agent = blockIdx.x, lane = threadIdx.x;
+  if (tick_clock && agent == 0 && lane == 0) tick_clock[0] = wall_clock64();  // the update's first kernel is running
   const float  q0 = poses[agent * 3], q1 = poses[agent * 3 + 1];
   if (lane < 3) poses_out[agent * 3 + lane] = poses[agent * 3 + lane];
   if (lane == 3) stamps_out[agent] = stamps_in[agent];
@@ -1708,7 +1709,8 @@ int world_blocks(sogm_ctx *c, const SogmWorld *w, CloudBlocks *out) {
     // (grown between ticks only: a frame with more blocks than any before; the old lists may still be read by a
     //  pre-stamp in flight, so everything drains first)
     SOGM_HIP_CHECK(hipDeviceSynchronize());
-    if (c->d_blk_list) (void)hipFree(c->d_blk_list);
+    if (c->h_tick_clock) (void)hipHostFree(c->h_tick_clock);
+  if (c->d_blk_list) (void)hipFree(c->d_blk_list);
     c->d_blk_list = nullptr;
     const int cap = (w->n_blocks + 1023) & ~1023;
     SOGM_HIP_CHECK(hipMalloc((void **)&c->d_blk_list, sizeof(int) * (size_t)cap * (size_t)c->n_agents));
@@ -2023,6 +2025,7 @@ void sogm_destroy(sogm_ctx *c) {
   if (c->d_cand) (void)hipFree(c->d_cand);
   if (c->d_stamp_bits) (void)hipFree(c->d_stamp_bits);
   if (c->d_ncand) (void)hipFree(c->d_ncand);
+  if (c->h_tick_clock) (void)hipHostFree(c->h_tick_clock);
   if (c->d_blk_list) (void)hipFree(c->d_blk_list);
   if (c->d_blk_n) (void)hipFree(c->d_blk_n);
   if (c->d_filter_cells) (void)hipFree(c->d_filter_cells);
@@ -2412,7 +2415,7 @@ static int update_gt_impl(sogm_ctx *c, const float *cloud_xyz, const int32_t *cl
   c->n_stamps++;
   prof_begin(c, SOGM_PROF_STAMP, st);
   hipLaunchKernelGGL(k_cull_cylinders, dim3(A), dim3(64), 0, st, c->geom, cylinders, n_cyl, poses,
-                     (CylCand *)c->d_cand, c->d_ncand, stamps, c->d_poses, c->d_stamps, cb);
+                     (CylCand *)c->d_cand, c->d_ncand, stamps, c->d_poses, c->d_stamps, cb, c->h_tick_clock);
   if (world)
     hipLaunchKernelGGL(k_stamp_bits_blocks, dim3(stamp_wgs, A), dim3(64), 0, st, c->geom, cloud_xyz, cb, c->d_poses,
                        c->d_stamp_bits, words);
@@ -2456,6 +2459,28 @@ int sogm_update_gt_swarm(sogm_ctx *c, const float *cloud_xyz, const int32_t *clo
   if (!c->d_body || c->n_body <= 0) return SOGM_ERR_STATE;
   return update_gt_impl(c, cloud_xyz, cloud_range, cylinders, n_cyl, poses, stamps, records, n_records, ego_ids,
                         true, (hipStream_t)stream);
+}
+
+__global__ void k_device_clock(long long *out) { *out = wall_clock64(); }
+int sogm_device_clock(sogm_ctx *c, int64_t *out_ticks, void *stream) {
+  if (!c || !out_ticks) return SOGM_ERR_INVALID_ARG;
+  SOGM_HIP_CHECK(hipSetDevice(c->device));
+  if (!c->h_tick_clock) {
+    SOGM_HIP_CHECK(hipHostMalloc((void **)&c->h_tick_clock, sizeof(long long) * 4, hipHostMallocMapped));
+    for (int i = 0; i < 4; ++i) c->h_tick_clock[i] = 0;
+  }
+  hipLaunchKernelGGL(k_device_clock, dim3(1), dim3(1), 0, (hipStream_t)stream, c->h_tick_clock + 2);
+  SOGM_HIP_CHECK(hipGetLastError());
+  SOGM_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+  *out_ticks = (int64_t) * (volatile long long *)(c->h_tick_clock + 2);
+  return SOGM_OK;
+}
+int sogm_tick_clock(sogm_ctx *c, int64_t *out2) {
+  if (!c || !out2) return SOGM_ERR_INVALID_ARG;
+  volatile long long *h = c->h_tick_clock;
+  out2[0] = h ? (int64_t)h[0] : 0;
+  out2[1] = h ? (int64_t)h[1] : 0;
+  return SOGM_OK;
 }
 
 int sogm_cloud_block_bounds(const float *cloud_xyz, int n_points, int block_points, float *out_bounds, void *stream) {

@@ -92,7 +92,9 @@ __global__ void k_pack_records(int A, double corridor_tau, const int32_t *ret, c
 // End of a dataflow replan (one lane, on the caller's stream after the fan-in): a wait of this tick timed out ->
 // remember the code and count the tick in pinned host memory, so the host can see failed ticks without a device
 // synchronisation (sogm_planner_flow_failures).
-__global__ void k_flow_report(const int *__restrict__ hdr, int *__restrict__ host_words, int *__restrict__ epoch_word) {
+__global__ void k_flow_report(const int *__restrict__ hdr, int *__restrict__ host_words, int *__restrict__ epoch_word,
+                              long long *__restrict__ tick_clock) {
+  if (tick_clock) tick_clock[1] = wall_clock64();  // the tick's last kernel (sogm_tick_clock)
   // the replan is over: the wide launch of the side-stream clear retires (sogm_ctx::clear_epoch_word), so that the
   // one-wave glue kernels between two replans (latest-wins merge, tick inputs, the stamp) find the memory pipeline
   // responsive; the narrow launch goes on
@@ -794,7 +796,7 @@ static int replan_flow(sogm_planner *p, const double *start_pva, const double *g
     hipStream_t rst = c->tune_i(SOGM_TUNE_PRESTAMP_STREAM) != 0 && c->pstream ? c->pstream : c->side;  // = pst above
     for (int k = 1; k < 4; ++k) SOGM_HIP_CHECK(hipStreamWaitEvent(rst, p->ev_fdone[k], 0));
     hipLaunchKernelGGL(k_flow_report, dim3(1), dim3(1), 0, rst, (const int *)p->d_flow, p->h_flow_fail,
-                       retire_p ? p->d_epoch : (int *)nullptr);
+                       retire_p ? p->d_epoch : (int *)nullptr, c->h_tick_clock);
     SOGM_HIP_CHECK(hipGetLastError());
     SOGM_HIP_CHECK(hipEventRecord(p->ev_pdone, rst));
     const int defer = c->tune_i(SOGM_TUNE_SPLAT_OVERLAP) != 0;  // 0: the caller's stream waits for the pre-stamp's end here
@@ -820,7 +822,7 @@ static int replan_flow(sogm_planner *p, const double *start_pva, const double *g
   const int retire = c->tune_i(SOGM_TUNE_CLEAR_RETIRE_AT_END);  // measured: tick -2 %, but the clear 14.5 -> 15.5 ms; off
   if (!reported) {
     hipLaunchKernelGGL(k_flow_report, dim3(1), dim3(1), 0, main, (const int *)p->d_flow, p->h_flow_fail,
-                       retire ? p->d_epoch : (int *)nullptr);
+                       retire ? p->d_epoch : (int *)nullptr, c->h_tick_clock);
     SOGM_HIP_CHECK(hipGetLastError());
   }
   return SOGM_OK;

@@ -385,6 +385,22 @@ class SwarmTick:
         self.distributed = dist is not None and (world > 1 or dist.is_initialized())
         self.exchange = exchange if exchange is not None else RecordExchange(c.ctx, dist, rank, world, device)
 
+    def set_prestamp(self, on):
+        """switch the pre-stamp on / off between two ticks of a flight (bench.py's labelled variant on the same swarm)"""
+        c = self.compute
+        on = bool(on) and self.publish and hasattr(c, "set_prestamp") and self.overlap_mode >= 2
+        if on and self._alt is None:
+            self._alt = (torch.zeros_like(self.pva), torch.zeros_like(self.t_start), torch.zeros_like(self.now),
+                         torch.zeros_like(self.poses))
+        if not on and self.prestamp:
+            torch.cuda.synchronize()
+            if c.prestamp_pending():   # a grid stamped for a tick that will now be built at its own start: drop it
+                self.map.prestamp_join()
+            self.planner.setPrestamp(None, None, None, 0, 0.0, 0.0, None, None, None, None)
+        self.prestamp = on
+        self.map_input_staleness_ticks = 1 if (on and self.moving_world is not None) else 0
+        return on
+
     def close(self):
         self.exchange.close()
         self.compute.close()

@@ -159,6 +159,20 @@ class SogmMap:
         return {"resets": out[0], "reset_entries": out[1], "reset_bytes_zeroed": out[2], "stamps": out[3],
                 "stamp_marks": out[4], "stamp_entries": out[5]}
 
+    def device_clock(self):
+        """(device wall clock in seconds, host perf_counter at the call's return): the device's 100 MHz clock read by a
+        kernel on the current stream, synchronised (sogm_device_clock)"""
+        import time
+        out = C.c_int64(0)
+        check(lib().sogm_device_clock(self._ctx, C.byref(out), _stream()), "sogm_device_clock")
+        return out.value * 1e-8, time.perf_counter()
+
+    def tick_clock(self):
+        """device clock (s) at the start of the last update's first kernel and in the last replan's closing kernel"""
+        out = (C.c_int64 * 2)()
+        check(lib().sogm_tick_clock(self._ctx, out), "sogm_tick_clock")
+        return out[0] * 1e-8, out[1] * 1e-8
+
     def grid_history(self):
         """How the current grid came to be: {slot, sparse_resets, dense_clears, prestamped} (sogm_grid_history)."""
         out = (C.c_int32 * 4)()

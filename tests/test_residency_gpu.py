@@ -79,3 +79,47 @@ def test_full_size_tick_with_four_queues_and_with_half_the_compute_units():
         assert f["digest"] == base["digest"], f"{name}: records / ok flags differ from the unconstrained flight"
     # the mask must have bitten: a masked run that is not slower did not restrict anything
     assert half["ms_per_tick"] > 1.15 * base["ms_per_tick"], (half["ms_per_tick"], base["ms_per_tick"])
+
+
+_FLIGHT_RUN = r"""
+import hashlib, importlib, json, os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.environ["SOGM_REPO"])
+pop = importlib.import_module("pred-occ-planner_amd")
+driver = importlib.import_module("pred-occ-planner_amd.driver")
+sw = driver.SwarmTick("cfg2", 128, moving_world=True, prestamp=False, grids=1)
+sw.compute.prepare(0, 16)
+sw.fly(3)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+ok, rec = sw.fly(10)
+torch.cuda.synchronize()
+ms = (time.perf_counter() - t0) / 10 * 1e3
+_, hdr = sw.planner.flight_stats()
+h = hashlib.sha256()
+h.update(rec.cpu().numpy().tobytes())
+h.update(ok.cpu().numpy().tobytes())
+print("FLIGHT " + json.dumps({"digest": h.hexdigest(), "ms_per_tick": ms, "err": int(hdr[pop._abi.FLIGHT_HDR_ERR]),
+                              "finished": int(hdr[pop._abi.FLIGHT_HDR_FINISHED]), "counters": sw.planner.counters()}))
+sw.close()
+"""
+
+
+def test_flight_runs_on_four_hardware_queues_at_full_speed():
+    """sogm_flight_run uses four streams (one per persistent kernel, each with its own compute units): ROCm's default of four
+    hardware queues is enough — same records, and a tick within x1.1 of the 32-queue flight (the per-tick dataflow replan,
+    nine streams, pays x1.3-1.4 there: the test above)."""
+    def fly(**env):
+        e = dict(os.environ, SOGM_REPO=ROOT, **env)
+        r = subprocess.run([sys.executable, "-c", _FLIGHT_RUN], env=e, capture_output=True, text=True, timeout=900)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("FLIGHT ")]
+        assert r.returncode == 0 and lines, (env, r.stdout[-1500:], r.stderr[-3000:])
+        return json.loads(lines[-1][7:])
+    base = fly(GPU_MAX_HW_QUEUES="32")
+    four = fly(GPU_MAX_HW_QUEUES="4")
+    print("flight: ms per tick — 32 hardware queues %.2f, four %.2f (x%.2f)" % (
+        base["ms_per_tick"], four["ms_per_tick"], four["ms_per_tick"] / base["ms_per_tick"]))
+    for f in (base, four):
+        assert f["err"] == 0 and f["finished"] == 1280, f
+    assert four["digest"] == base["digest"] and four["counters"] == base["counters"]
+    assert four["ms_per_tick"] <= 1.1 * base["ms_per_tick"], (four["ms_per_tick"], base["ms_per_tick"])

@@ -1,70 +1,85 @@
 """Timing of the perception half on BASELINE configs[1]: 16 agents, 100^3 x 15 SOGM, synthetic 640x480
-depth clouds -> filterPointCloud -> DSPMap::update -> publish (+ neighbour overlay).  Prints one JSON
-line with per-stage milliseconds (HIP events on the launch stream) and the particle-store counters."""
-import argparse, importlib, json, os, sys
+depth clouds -> filterPointCloud -> DSPMap::update -> publish (+ neighbour overlay).  run() returns (and the command line
+prints as one JSON line) per-stage milliseconds (HIP events on the launch stream), the roofline rating of the publish copy
+and the particle-store counters; bench.py calls run() for its configs.cfg1 block."""
+import argparse, importlib, json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-pop = importlib.import_module("pred-occ-planner_amd")
-sogm = importlib.import_module("pred-occ-planner_amd.sogm")
-dsp = importlib.import_module("pred-occ-planner_amd.dsp")
-ap = argparse.ArgumentParser()
-ap.add_argument("--grid", default="cfg1")
-ap.add_argument("--agents", type=int, default=None)
-ap.add_argument("--steps", type=int, default=30)
-ap.add_argument("--warmup", type=int, default=5)
-args = ap.parse_args()
-A = args.agents or pop.config.AGENTS[args.grid]
-spec = pop.config.make_spec(args.grid, map_kind=pop._abi.SOGM_MAP_RISKVOXEL)
-m = sogm.SogmMap(spec, A)
-g = dsp.DspMap(m, dsp.make_dsp_params(spec.T), dsp.make_tables(5))
-cap = 5000
-clouds = [pop.scene.make_depth_cloud(100 + a) for a in range(A)]
-n_pix = len(clouds[0])
-raw = sogm._dev(np.concatenate(clouds, axis=0), np.float32)
-rng = sogm._dev(np.stack([np.arange(A) * n_pix, (np.arange(A) + 1) * n_pix], axis=1), np.int32)
-labels = None  # velocityEstimationThread (clustering + association) runs on the GPU, in the update
-base = torch.arange(A, dtype=torch.int32, device="cuda") * cap
-quat = sogm._dev(np.tile(np.float32([1, 0, 0, 0]), (A, 1)), np.float32)
-recs = torch.zeros((A, pop._abi.TRAJ_RECORD_BYTES), dtype=torch.uint8, device="cuda")
-ego = torch.arange(A, dtype=torch.int32, device="cuda")
-ev = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(args.steps)]
-def tick(k, e=None):
-    pos = sogm._dev(np.tile(np.float32([0.03 * k, 0.0, 0.0]), (A, 1)), np.float32)
-    stamps = sogm._dev(np.full(A, 100.0 + k / 30.0), np.float64)
-    if e: e[0].record()
-    pts, cnt = m.filterPointCloud(raw, rng, 0.15, cap)
-    if e: e[1].record()
-    crange = torch.stack([base, base + cnt], dim=1).contiguous()
-    g.update(pts.view(-1, 3), labels, crange, pos, quat, stamps)
-    if e: e[2].record()
-    g.publish()
-    if e: e[3].record()
-    m.addOtherAgents(recs, A, ego)
-    if e: e[4].record()
-    return cnt
-for k in range(args.warmup):
-    tick(k)
-torch.cuda.synchronize()
-import time
-t0 = time.perf_counter()
-for k in range(args.steps):
-    cnt = tick(args.warmup + k, ev[k])
-torch.cuda.synchronize()
-dt = time.perf_counter() - t0
-ms = np.array([[e[i].elapsed_time(e[i + 1]) for i in range(4)] for e in ev])
-st, ob, c = g.download_state(0)
-V = m.V
-S = g.S
-b_dsp = 2 * V * S * 36 + V * (4 + spec.T) * 4 + V * spec.T * 4   # SURVEY 8d, per agent-update
-out = {"workload": f"{A} agents, {spec.L}x{spec.W}x{spec.H}x{spec.T} particle SOGM, {n_pix} depth points/agent/frame",
-       "updates_per_s": A * args.steps / dt, "ms_per_tick": dt / args.steps * 1e3,
-       "stage_ms": dict(zip(["filter", "dsp_update", "publish", "overlay"], ms.mean(axis=0).round(3).tolist())),
-       "filtered_points": cnt.cpu().numpy().tolist()[:4], "live_particles_agent0": int((st[:, :, 0] > 0.1).sum()),
-       "occupied_voxels_agent0": int((ob[:, 0] > spec.risk_threshold).sum()), "counters_agent0": c.tolist(),
-       # SURVEY 8d's per-update figure describes the reference's dense AoS sweep (every slot of every voxel read and
-       # written); the SoA / flag layout here touches 16 B per voxel plus the occupied lines, so dividing it by the
-       # update time is NOT an achieved-bandwidth figure (it exceeds the HBM peak).  Measured HBM bytes per kernel:
-       # profiles/r02_perception_rocprof.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command).
-       "reference_sweep_bytes_per_agent_update": b_dsp}
-print(json.dumps(out))
-g.close(); m.close()
+
+
+def run(grid="cfg1", agents=None, steps=30, warmup=5):
+    pop = importlib.import_module("pred-occ-planner_amd")
+    sogm = importlib.import_module("pred-occ-planner_amd.sogm")
+    dsp = importlib.import_module("pred-occ-planner_amd.dsp")
+    A = agents or pop.config.AGENTS[grid]
+    spec = pop.config.make_spec(grid, map_kind=pop._abi.SOGM_MAP_RISKVOXEL)
+    m = sogm.SogmMap(spec, A)
+    g = dsp.DspMap(m, dsp.make_dsp_params(spec.T), dsp.make_tables(5))
+    cap = 5000
+    clouds = [pop.scene.make_depth_cloud(100 + a) for a in range(A)]
+    n_pix = len(clouds[0])
+    raw = sogm._dev(np.concatenate(clouds, axis=0), np.float32)
+    rng = sogm._dev(np.stack([np.arange(A) * n_pix, (np.arange(A) + 1) * n_pix], axis=1), np.int32)
+    labels = None  # velocityEstimationThread (clustering + association) runs on the GPU, in the update
+    base = torch.arange(A, dtype=torch.int32, device="cuda") * cap
+    quat = sogm._dev(np.tile(np.float32([1, 0, 0, 0]), (A, 1)), np.float32)
+    recs = torch.zeros((A, pop._abi.TRAJ_RECORD_BYTES), dtype=torch.uint8, device="cuda")
+    ego = torch.arange(A, dtype=torch.int32, device="cuda")
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(steps)]
+
+    def tick(k, e=None):
+        pos = sogm._dev(np.tile(np.float32([0.03 * k, 0.0, 0.0]), (A, 1)), np.float32)
+        stamps = sogm._dev(np.full(A, 100.0 + k / 30.0), np.float64)
+        if e: e[0].record()
+        pts, cnt = m.filterPointCloud(raw, rng, 0.15, cap)
+        if e: e[1].record()
+        crange = torch.stack([base, base + cnt], dim=1).contiguous()
+        g.update(pts.view(-1, 3), labels, crange, pos, quat, stamps)
+        if e: e[2].record()
+        g.publish()
+        if e: e[3].record()
+        m.addOtherAgents(recs, A, ego)
+        if e: e[4].record()
+        return cnt
+
+    for k in range(warmup):
+        tick(k)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        cnt = tick(warmup + k, ev[k])
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ms = np.array([[e[i].elapsed_time(e[i + 1]) for i in range(4)] for e in ev])
+    st, ob, c = g.download_state(0)
+    V, S = m.V, g.S
+    b_dsp = 2 * V * S * 36 + V * (4 + spec.T) * 4 + V * spec.T * 4   # SURVEY 8d, per agent-update
+    pub_ms = float(ms[:, 2].mean())
+    pub_bytes = 2.0 * V * spec.T * 4 * A  # k_dsp_publish: the future-status accumulators read, the SOGM slabs written
+    out = {"workload": f"{A} agents, {spec.L}x{spec.W}x{spec.H}x{spec.T} particle SOGM, {n_pix} depth points/agent/frame "
+                       "(BASELINE configs[1]: filterPointCloud -> DSPMap::update incl. velocity estimation -> publish -> overlay)",
+           "agent_updates_per_s": A * steps / dt, "ms_per_frame": dt / steps * 1e3, "frames_timed": steps,
+           "stage_ms": dict(zip(["filter", "dsp_update", "publish", "overlay"], ms.mean(axis=0).round(3).tolist())),
+           "roofline": {"bound": "hbm", "kernel": "k_dsp_publish (future-status accumulators -> SOGM slabs, a straight copy)",
+                        "bytes_per_launch": pub_bytes, "avg_launch_ms": pub_ms, "achieved": pub_bytes / (pub_ms * 1e-3) / 1e9,
+                        "peak": 8000.0, "unit": "GB/s", "frac": pub_bytes / (pub_ms * 1e-3) / 1e9 / 8000.0,
+                        "timed_where": "HIP events on the launch stream around every publish of the timed frames"},
+           "filtered_points": cnt.cpu().numpy().tolist()[:4], "live_particles_agent0": int((st[:, :, 0] > 0.1).sum()),
+           "occupied_voxels_agent0": int((ob[:, 0] > spec.risk_threshold).sum()), "counters_agent0": c.tolist(),
+           # SURVEY 8d's per-update figure describes the reference's dense AoS sweep (every slot of every voxel read and
+           # written); the SoA / flag layout here touches 16 B per voxel plus the occupied lines, so dividing it by the
+           # update time is NOT an achieved-bandwidth figure (it exceeds the HBM peak).
+           "reference_sweep_bytes_per_agent_update": b_dsp}
+    g.close()
+    m.close()
+    return out
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--grid", default="cfg1")
+    ap.add_argument("--agents", type=int, default=None)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    a = ap.parse_args()
+    print(json.dumps(run(a.grid, a.agents, a.steps, a.warmup)))
