@@ -436,7 +436,7 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": ("f16" if spec.storage == 1 else "f32") + " occupancy / f64 planning",
+        "dtype": ("f16" if spec.storage & 1 else "f32") + " occupancy / f64 planning",
         "data": "synthetic",
         "config": {"workload": f"{sw.A_loc} agents/GPU x {world} GPU, {spec.L}x{spec.W}x{spec.H}x{spec.T} SOGM, "
                                f"sim_fkpcp-style moving cylinders, batched ADMM QP (BASELINE {'configs[4]' if args.grid == 'cfg4' else 'configs[2]'} per GPU)",
@@ -461,6 +461,7 @@ def main():
                    "exchange_fallback_reason": sw.exchange.fallback_reason,
                    "sogm_grids_per_agent": overlap_mode if overlap_mode >= 2 else 1,
                    "sogm_reset": "sparse (logged 32-byte sectors)" if sparse["enabled"] else "dense clear",
+                   "sogm_cell_order": "2x2x2 tiles" if spec.storage & 16 else "x-fastest rows",
                    # where the tick's map update runs: inside the previous replan, agent by agent as their records are
                    # published (sogm_planner_set_prestamp), or at the start of the tick
                    "map_update": ("pre-stamped by the previous replan" if sw.prestamp and sparse["enabled"]

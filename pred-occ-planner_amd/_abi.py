@@ -16,6 +16,7 @@ SOGM_MAP_FAKE = 0
 SOGM_MAP_RISKBASE = 1
 SOGM_MAP_RISKVOXEL = 2
 SOGM_STORE_F32, SOGM_STORE_F16 = 0, 1
+SOGM_LAYOUT_TILED = 16  # OR-ed into SogmSpec.storage: 2 x 2 x 2 cell tiles
 SOGM_DSP_MAX_T = 16
 
 SOGM_OK = 0

@@ -18,7 +18,7 @@ GRID_CONFIGS = {
 AGENTS = {"parity": 4, "cfg0": 1, "cfg1": 16, "cfg2": 128, "cfg4": 128}
 
 
-def make_spec(grid="parity", map_kind=SOGM_MAP_FAKE, clearance=0.45, time_resolution=0.2, storage=None):
+def make_spec(grid="parity", map_kind=SOGM_MAP_FAKE, clearance=0.45, time_resolution=0.2, storage=None, tiled=None):
     L, W, H, T = GRID_CONFIGS[grid] if isinstance(grid, str) else grid
     s = SogmSpec()
     s.L, s.W, s.H, s.T = L, W, H, T
@@ -34,6 +34,15 @@ def make_spec(grid="parity", map_kind=SOGM_MAP_FAKE, clearance=0.45, time_resolu
     s.map_kind = map_kind
     # BASELINE configs[4] (300^3 x 30, 128 agents) only fits 288 GB of HBM with fp16 occupancy cells
     s.storage = (1 if grid == "cfg4" else 0) if storage is None else storage
+    # cell order of a slice: 2 x 2 x 2 tiles (SOGM_LAYOUT_TILED; the default for fake-perception maps with even sizes: the
+    # stamp writes and the reset zeroes about half the sectors — 1.28 against 1.62 ms, 0.58 against 1.04 ms at 128 agents)
+    # or x-fastest rows (SOGM_LAYOUT=rows in the environment, A/B runs; odd sizes; an explicit `storage`).
+    if tiled is None:
+        import os
+        tiled = (os.environ.get("SOGM_LAYOUT", "tiled") == "tiled" and map_kind == SOGM_MAP_FAKE
+                 and not ((L | W | H) & 1) and storage is None)
+    if tiled:
+        s.storage |= 16
     return s
 
 

@@ -1179,10 +1179,11 @@ __device__ __forceinline__ void corridor_points_body(const MapView &m, const Sog
             const int y = ly + (c / nx) % ny;
             const int z = lz + c / (nx * ny);
             vi[q]       = x + y * g.L + z * g.L * g.W;
+            const int pi = g.phys(x, y, z);
             for (int j = js; j <= je; ++j) {
               const float thr = g.map_kind == SOGM_MAP_FAKE ? g.risk_threshold
                                                              : g.risk_threshold - g.decay_voxel * (float)j;
-              if (cell_ld(grid0, (size_t)j * g.V + vi[q], g.half) > thr) {
+              if (cell_ld(grid0, (size_t)j * g.V + pi, g.half) > thr) {
                 ++cnt[q];
                 mask[q] |= 1u << (j - js);
               }

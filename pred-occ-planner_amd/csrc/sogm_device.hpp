@@ -33,6 +33,7 @@ struct GridGeom {
   int   inf_step;     // (int)(clearance / res) in fp32 (risk_base.cpp:31)
   int   map_kind;
   int   half;         // 1: occupancy stored as __half (SOGM_STORE_F16), arithmetic stays fp32
+  int   tile;         // 1: the cells of a slice are stored in 2 x 2 x 2 tiles (SOGM_LAYOUT_TILED), see phys()
   // resample branch of ParticleATC::getParticlesWithRisk (sogm_set_resample; rate 0 = off, the shipped configurations)
   float        rs_rate;  // swarm/replan_risk_rate
   int          rs_n;     // swarm/num_resample
@@ -53,6 +54,39 @@ struct GridGeom {
     const int iy = (int)((y + ry) / res);
     const int iz = (int)((z + rz) / res);
     return iz * L * W + iy * L + ix;
+  }
+  // Where cell (x, y, z) of a slice lives.  Rows (tile = 0): z L W + y L + x, x fastest — a 32-byte sector is 8 cells of
+  // one x-row.  Tiles (tile = 1; L, W, H even): 2 x 2 x 2 cells = 8 fp32 cells = one sector, tiles in row order, inside a
+  // tile z, y, x.  Obstacle surfaces are thin shells in xy that run along z: an x-row sector catches 2.3 of a stamp's
+  // marks on average, a tile 4-5, so the stamp writes (and the reset zeroes) about half the sectors; the 5 x 5 window of
+  // the collision query at one height is nine 16-byte loads (3 x 3 tiles) instead of five to ten row loads.
+  __host__ __device__ inline int phys(int x, int y, int z) const {
+    if (!tile) return z * L * W + y * L + x;
+    return ((((z >> 1) * (W >> 1) + (y >> 1)) * (L >> 1) + (x >> 1)) << 3) | ((z & 1) << 2) | ((y & 1) << 1) | (x & 1);
+  }
+  // where the point (x, y, z) of the map frame (in range) is stored: getVoxelIndex's cell (map.h:169-174), or V when that
+  // index leaves the array (the reference's out-of-bounds case: a coordinate one ulp below +range).  No integer division
+  // on the common path.
+  __host__ __device__ inline int cell_of(float x, float y, float z) const {
+    const int ix = (int)((x + rx) / res);
+    const int iy = (int)((y + ry) / res);
+    const int iz = (int)((z + rz) / res);
+    if (tile && ix < L && iy < W && iz < H) return phys(ix, iy, iz);
+    const int v = iz * L * W + iy * L + ix;  // (rows; or an index component equal to its axis size: wraps like the reference's)
+    return v < V ? phys_of(v) : V;
+  }
+  // ... of a LOGICAL cell index (voxel_of's value — which may have wrapped into the next row / layer exactly as the
+  // reference's does — decomposed the way corner_of decomposes it)
+  __host__ __device__ inline int phys_of(int v) const {
+    if (!tile) return v;
+    return phys(v % L, (v / L) % W, v / (L * W));
+  }
+  // ... and back: the logical index of physical cell p
+  __host__ __device__ inline int logical_of(int p) const {
+    if (!tile) return p;
+    const int t = p >> 3, lt = L >> 1, wt = W >> 1;
+    const int x = ((t % lt) << 1) | (p & 1), y = (((t / lt) % wt) << 1) | ((p >> 1) & 1), z = ((t / (lt * wt)) << 1) | ((p >> 2) & 1);
+    return z * L * W + y * L + x;
   }
   // map.h:186-194 — voxel corner in the world frame
   __host__ __device__ inline void corner_of(int index, const float *pose, float &ox, float &oy,
@@ -87,7 +121,8 @@ inline GridGeom make_geom(const SogmSpec &s) {
   g.decay_voxel    = s.risk_thres_vox_decay;
   g.inf_step       = (int)(s.clearance / s.resolution);
   g.map_kind       = s.map_kind;
-  g.half           = s.storage == SOGM_STORE_F16 ? 1 : 0;
+  g.half           = (s.storage & 1) == SOGM_STORE_F16 ? 1 : 0;
+  g.tile           = (s.storage & SOGM_LAYOUT_TILED) ? 1 : 0;
   g.rs_rate        = 0.0f;
   g.rs_n           = 0;
   g.rs_z           = nullptr;
@@ -196,6 +231,58 @@ __device__ inline void window_gather(const char *base, const GridGeom &g, int ix
     }
   }
 }
+// The same window from a tiled slice (GridGeom::phys): the (2S+1)^2 cells at height iz lie in (S+1)^2 tiles at most; one
+// 16-byte load (8 bytes for fp16 cells) fetches a tile's four cells of that height, a tile is inside or outside the grid
+// as a whole, and a window cell picks its value with compile-time tile / cell indices selected by the parities of the
+// window's corner (no dynamically indexed registers).
+template <int S>
+__device__ inline void window_gather_tiled(const char *base, const GridGeom &g, int ix, int iy, int iz,
+                                           float (&v)[2 * S + 1][2 * S + 1]) {  // v[x][y]
+  constexpr int W = 2 * S + 1, NT = S + 1;
+  const int     x0 = ix - S, y0 = iy - S;
+  const bool    px = (x0 & 1) != 0, py = (y0 & 1) != 0;
+  const int     tx0 = x0 >> 1, ty0 = y0 >> 1;  // (arithmetic shift: floors for negative corners)
+  const int     lt = g.L >> 1, wt = g.W >> 1;
+  const unsigned zrow = (unsigned)(iz >> 1) * (unsigned)wt, zoff = (unsigned)(iz & 1) << 2;
+  float          t[NT][NT][4];  // [tile y][tile x][(y & 1) * 2 + (x & 1)]
+#pragma unroll
+  for (int tb = 0; tb < NT; ++tb) {
+    const int      ty   = ty0 + tb;
+    const unsigned tyok = (unsigned)ty < (unsigned)wt ? 0xFFFFFFFFu : 0u;
+    const unsigned row  = (zrow + (unsigned)min(max(ty, 0), wt - 1)) * (unsigned)lt;
+#pragma unroll
+    for (int ta = 0; ta < NT; ++ta) {
+      const int      tx  = tx0 + ta;
+      const unsigned ok  = tyok & ((unsigned)tx < (unsigned)lt ? 0xFFFFFFFFu : 0u);
+      const unsigned off = ((row + (unsigned)min(max(tx, 0), lt - 1)) << 3) + zoff;  // cells
+      if (g.half) {
+        const uint2 h = *reinterpret_cast<const uint2 *>(base + ((size_t)off << 1));
+        const __half2 a = *reinterpret_cast<const __half2 *>(&h.x), b = *reinterpret_cast<const __half2 *>(&h.y);
+        t[tb][ta][0] = __uint_as_float(__float_as_uint(__low2float(a)) & ok);
+        t[tb][ta][1] = __uint_as_float(__float_as_uint(__high2float(a)) & ok);
+        t[tb][ta][2] = __uint_as_float(__float_as_uint(__low2float(b)) & ok);
+        t[tb][ta][3] = __uint_as_float(__float_as_uint(__high2float(b)) & ok);
+      } else {
+        const uint4 q = *reinterpret_cast<const uint4 *>(base + ((size_t)off << 2));
+        t[tb][ta][0] = __uint_as_float(q.x & ok);
+        t[tb][ta][1] = __uint_as_float(q.y & ok);
+        t[tb][ta][2] = __uint_as_float(q.z & ok);
+        t[tb][ta][3] = __uint_as_float(q.w & ok);
+      }
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < W; ++a)
+#pragma unroll
+    for (int b = 0; b < W; ++b) {
+      // window cell (a, b) is cell (a + px, b + py) counted from the corner tile's origin
+      const float c00 = t[b >> 1][a >> 1][((b & 1) << 1) | (a & 1)];
+      const float c10 = t[b >> 1][(a + 1) >> 1][((b & 1) << 1) | ((a + 1) & 1)];
+      const float c01 = t[(b + 1) >> 1][a >> 1][(((b + 1) & 1) << 1) | (a & 1)];
+      const float c11 = t[(b + 1) >> 1][(a + 1) >> 1][(((b + 1) & 1) << 1) | ((a + 1) & 1)];
+      v[a][b]         = py ? (px ? c11 : c01) : (px ? c10 : c00);
+    }
+}
 template <int S>
 __device__ inline int window_replay(const float (&v)[2 * S + 1][2 * S + 1], float thr) {
   constexpr int W   = 2 * S + 1;
@@ -213,7 +300,10 @@ __device__ inline int window_replay(const float (&v)[2 * S + 1][2 * S + 1], floa
 template <int S>
 __device__ inline int window_sum_hits(const char *base, const GridGeom &g, int ix, int iy, int iz, float thr) {
   float v[2 * S + 1][2 * S + 1];
-  window_gather<S>(base, g, ix, iy, iz, v);
+  if (g.tile)
+    window_gather_tiled<S>(base, g, ix, iy, iz, v);
+  else
+    window_gather<S>(base, g, ix, iy, iz, v);
   return window_replay<S>(v, thr);
 }
 
@@ -258,7 +348,7 @@ __device__ inline int query_clear_idx(const MapView &m, int agent, double px, do
       for (int z = -zs; z <= zs; ++z) {
         const int qz = iz + z;
         if (!g.in_range(qx, qy, qz)) continue;
-        sum += cell_ld(sl, (size_t)qz * g.L * g.W + (size_t)qy * g.L + qx, g.half);
+        sum += cell_ld(sl, (size_t)g.phys(qx, qy, qz), g.half);
         if (sum > thr) return 1;
       }
     }
@@ -339,6 +429,7 @@ __device__ inline void bezier_pos(const SogmTrajRecord &r, double t, double out[
   X(RESET_UNROLL, "reset_unroll", 0, 0, 8)       /* sparse reset: 1 / 8 entries per trip; 0 = 1 under the replan, 8 alone */  \
   X(RESET_LATE, "reset_late", 1, 0, 1)           /* sparse reset: held back until every agent's corridors are final       */  \
   X(STAMP_WGS, "stamp_wgs", 256, 0, 4096)           /* stamp: one-wave workgroups per agent                                  */  \
+  X(STAMP_LDS_KB, "stamp_lds_kb", 0, 0, 64)              /* stamp: unused dynamic LDS per marks workgroup (bounds waves per CU) */  \
   X(SPLAT_WGS, "splat_wgs", 256, 0, 65536)           /* overlay launched under a pre-stamp's tail: workgroups                 */  \
   X(SPLAT_OVERLAP, "splat_overlap", 1, 0, 1)     /* 0: sogm_replan joins the pre-stamp's end itself                       */  \
   X(PRESTAMP_BITS, "prestamp_bits", 32, 0, 1024)    /* pre-stamp: one-wave tickets per agent, occupancy bits pass            */  \

@@ -1492,8 +1492,9 @@ __global__ __launch_bounds__(256) void k_dsp_occupancy(DspDev d) {
 }
 
 // ---- publish (:445-469 + risk_voxel.cpp:141-153) ---------------------------------------------------------
-__global__ __launch_bounds__(256) void k_dsp_publish(DspDev d, void *__restrict__ grid, int half, float thr,
+__global__ __launch_bounds__(256) void k_dsp_publish(DspDev d, void *__restrict__ grid, GridGeom gg, float thr,
                                                      float *__restrict__ poses, double *__restrict__ stamps) {
+  const int half = gg.half;
   const int a = blockIdx.y;
   const int v = blockIdx.x * 256 + threadIdx.x;
   DspAgent &s = d.ag[a];
@@ -1506,14 +1507,16 @@ __global__ __launch_bounds__(256) void k_dsp_publish(DspDev d, void *__restrict_
   if (v >= d.V) return;
   float *fut = d.fut + (size_t)a * d.T * d.V;
   char  *g   = reinterpret_cast<char *>(grid) + (size_t)a * d.T * d.V * (half ? 2 : 4);
+  const int pv = gg.phys_of(v);  // (rows: v itself, the straight copy; tiles: the cell's place in the slice)
   for (int t = 0; t < d.T; ++t) {
-    cell_st(g, (size_t)t * d.V + v, fut[(size_t)t * d.V + v], half);
+    cell_st(g, (size_t)t * d.V + pv, fut[(size_t)t * d.V + v], half);
     fut[(size_t)t * d.V + v] = 0.f;
   }
   if (d.occ[(size_t)a * 4 * d.V + v] > thr) atomicAdd(&s.n_occupied, 1);
 }
-__global__ void k_dsp_publish_ego(DspDev d, void *__restrict__ grid, int half, int inf_step,
+__global__ void k_dsp_publish_ego(DspDev d, void *__restrict__ grid, GridGeom gg, int inf_step,
                                   int32_t *__restrict__ out_n) {
+  const int half = gg.half;
   const int a = blockIdx.x;
   const int w = 2 * inf_step + 1;
   char     *g = reinterpret_cast<char *>(grid) + (size_t)a * d.T * d.V * (half ? 2 : 4);
@@ -1521,7 +1524,7 @@ __global__ void k_dsp_publish_ego(DspDev d, void *__restrict__ grid, int half, i
     const int x = k / (w * w) - inf_step, y = (k / w) % w - inf_step, z = k % w - inf_step;
     const int idx = z * d.L * d.W + y * d.L + x;  // getVoxelIndex(Vector3i) of the OFFSET (map.h:176)
     if (idx < 0 || idx >= d.V) continue;          // negative index = UB in the reference: skipped
-    for (int t = 0; t < 3 && t < d.T; ++t) cell_st(g, (size_t)t * d.V + idx, 0.f, half);
+    for (int t = 0; t < 3 && t < d.T; ++t) cell_st(g, (size_t)t * d.V + gg.phys_of(idx), 0.f, half);
   }
   if (threadIdx.x == 0) {
     if (out_n) out_n[a] = d.ag[a].n_occupied;
@@ -1802,8 +1805,8 @@ int sogm_dsp_publish(sogm_dsp *h, int32_t *out_n_occupied, void *stream) {
   }
   c->tracked[sogm::cur_slot(c)] = 0;  // every cell is written: the next reset of this grid is the dense clear
   hipLaunchKernelGGL(k_dsp_publish, dim3((unsigned)((d.V + 255) / 256), (unsigned)d.A), dim3(256), 0, st, d,
-                     (void *)c->d_grid, c->geom.half, c->geom.risk_threshold, c->d_poses, c->d_stamps);
-  hipLaunchKernelGGL(k_dsp_publish_ego, dim3((unsigned)d.A), dim3(128), 0, st, d, (void *)c->d_grid, c->geom.half, c->geom.inf_step,
+                     (void *)c->d_grid, c->geom, c->geom.risk_threshold, c->d_poses, c->d_stamps);
+  hipLaunchKernelGGL(k_dsp_publish_ego, dim3((unsigned)d.A), dim3(128), 0, st, d, (void *)c->d_grid, c->geom, c->geom.inf_step,
                      out_n_occupied);
   SOGM_HIP_CHECK(hipGetLastError());
   c->updated = 1;

@@ -351,7 +351,8 @@ __device__ __forceinline__ void stamp_bits_point(const GridGeom &g, const CropBo
   // voxel index is >= V and the reference writes outside risk_maps_.  Such marks are dropped, here and in the
   // oracle (x / y overflows inside the array wrap into the next row / layer exactly as the reference's do).
   if (v >= g.V) return;
-  __hip_atomic_fetch_or(mask + (v >> 5), 1u << (v & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const int p = g.phys_of(v);  // the mask is kept in the slice's storage order: neighbouring bits share a sector
+  __hip_atomic_fetch_or(mask + (p >> 5), 1u << (p & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // points first, first + stride, ... of [begin, end) (lane included in `first`)
 __device__ __forceinline__ void stamp_bits_range(const GridGeom &g, const float *__restrict__ cloud, int first, int end,
@@ -477,6 +478,11 @@ __device__ unsigned long long g_ps_prof[12];
 #define PS_CLK() 0ll
 #define PS_ADD(i, v) do { } while (0)
 #endif
+// CACHED: the slice loop keeps a group's sectors in registers between its store pass and its log pass (fewer
+// instructions: the persistent kernels, whose occupancy is two waves per SIMD anyway); otherwise it recomputes them in a
+// second pass (fewer registers: k_stamp_marks, whose scattered stores want every wave the CU can hold — 1.61 ms against
+// 1.76 for the cached form on the full machine).
+template <bool CACHED>
 __device__ __forceinline__ void stamp_marks_trips(const GridGeom &g, void *__restrict__ grid,
                                                   unsigned *__restrict__ bits, int words_per_agent,
                                                   const SogmCylinder *__restrict__ cyl, int n_cyl,
@@ -561,7 +567,7 @@ __device__ __forceinline__ void stamp_marks_trips(const GridGeom &g, void *__res
         ++n_marks;
       }
       float cx, cy, cz;
-      g.corner_of(v, pose, cx, cy, cz);
+      g.corner_of(g.logical_of(v), pose, cx, cy, cz);  // (v is the cell's position in the slice's storage order)
       float vx = 0.f, vy = 0.f;
       // GT velocity of the FIRST record containing the voxel (:127-154).  The walk is wave-uniform — every lane visits
       // the candidates in order until all lanes have their match — and takes the candidates four at a time: their loads
@@ -685,52 +691,121 @@ __device__ __forceinline__ void stamp_marks_trips(const GridGeom &g, void *__res
         const float fx = (cx + (vx * g.dt) * (float)k) - p0;
         const float fy = (cy + (vy * g.dt) * (float)k) - p1;
         const float fz = (cz + (0.0F * g.dt) * (float)k) - p2;
-        const int   fv = g.in_range(fx, fy, fz) ? g.voxel_of(fx, fy, fz) : g.V;
-        return fv < g.V ? fv : g.V;  // (index >= V: the reference's out-of-bounds case, see k_stamp_bits)
+        return g.in_range(fx, fy, fz) ? g.cell_of(fx, fy, fz) : g.V;
       };
-      // Mark log (sparse reset).  The lanes of a trip hold x-ordered voxels, so the marks of neighbouring lanes fall
-      // into the same 32-byte sector most of the time (8 fp32 cells), in slice 0 and — same velocity — in every later
-      // slice: a lane logs its sector only when it differs from its lower neighbour's, and marks outside the grid log
-      // nothing (60 % fewer entries than one per mark; the reset reads what is written here).  Pass 1 stores the
-      // marks and counts the entries slice by slice (lane k keeps the number of entries of the slices before k);
-      // ONE atomic reserves the wave's entries; pass 2 recomputes the sectors and writes them, slice after slice.
+      // Mark log (sparse reset).  The lanes of a trip hold neighbouring voxels of the slice's storage order, so the marks of
+      // neighbouring lanes fall into the same 32-byte sector most of the time, in slice 0 and — same velocity — in every
+      // later slice: a lane logs its sector only when no lane just below it holds the same one (rows: the lower neighbour;
+      // tiles: the lanes 1, 2 and 4 below — a moving obstacle's future cells straddle two tiles in alternation), and
+      // marks outside the grid log nothing.  One pass per group of eight slices: the marks are stored, the group's sectors and
+      // keep bits stay in registers, one atomic reserves the group's entries, then the sectors are written.  (Until round 5 a
+      // second pass recomputed every future cell — three IEEE divisions each — and every keep ballot: the stamp is bound by
+      // instruction issue, not by its stores.)
       const unsigned long long lt = lane ? (~0ull >> (64 - lane)) : 0ull;
-      unsigned                 pref = 0, run = 0;
+      // (the lanes below through DPP — v_mov_b32_dpp, no LDS round trip like __shfl_up: a lane with no source keeps the
+      //  sentinel.  wave_shr:1 crosses the rows of 16; row_shr:2 / :4 do not, so a row's first lanes keep a duplicate.)
       auto keep_of = [&](unsigned sector, bool in) -> unsigned long long {
-        const unsigned below = (unsigned)__shfl_up((int)sector, 1, 64);
-        return __ballot(active && in && (lane == 0 || below != sector));
+        constexpr int NONE = (int)0xFFFFFFFDu;
+        bool dup = (unsigned)__builtin_amdgcn_update_dpp(NONE, (int)sector, 0x138 /* wave_shr:1 */, 0xF, 0xF, false) == sector;
+        if (g.tile) {
+          dup = dup || (unsigned)__builtin_amdgcn_update_dpp(NONE, (int)sector, 0x112 /* row_shr:2 */, 0xF, 0xF, false) == sector;
+          dup = dup || (unsigned)__builtin_amdgcn_update_dpp(NONE, (int)sector, 0x114 /* row_shr:4 */, 0xF, 0xF, false) == sector;
+        }
+        return __ballot(active && in && !dup);
       };
-      {
-        const unsigned long long m = keep_of((unsigned)v >> esh, true);
-        run                        = (unsigned)__popcll(m);
-      }
-      for (int k = 1; k < g.T; ++k) {
-        const int    fv = future_cell(k);
-        const bool   in = fv < g.V;
-        const size_t ci = (size_t)k * g.V + (in ? fv : 0);
-        if (active && in) {
-          cell_st(base, ci, 1.0F, g.half);
-          ++n_marks;
+      // slices in groups of SG: a group's sectors and keep bits stay in registers between the store pass and the log pass
+      // (a cache of all T slices cost 40 registers and halved the occupancy of the waves that call this)
+      if constexpr (CACHED) {
+      constexpr int SG = 8;
+      unsigned     *lent = lg.entries ? lg.entries + (size_t)agent * lg.cap : nullptr;
+      // the log pass of group i runs after the store pass of group i + 1: the reservation's atomic has a group's worth of
+      // work to come back in
+      unsigned p_secs[SG], p_keep = 0, p_off = 0;
+      int      p_n = 0;  // slices of the pending group (0: none)
+      auto     flush = [&]() __attribute__((always_inline)) {
+        unsigned off = (unsigned)__shfl((int)p_off, 0, 64);
+#pragma unroll
+        for (int q = 0; q < SG; ++q)
+          if (q < p_n) {  // uniform
+            const bool               mine = ((p_keep >> q) & 1u) != 0;
+            const unsigned long long m    = __ballot(mine);
+            const unsigned           li   = off + (unsigned)__popcll(m & lt);
+            if (mine && li < (unsigned)lg.cap) lent[li] = p_secs[q];
+            off += (unsigned)__popcll(m);
+          }
+      };
+      for (int k0 = 0; k0 < g.T; k0 += SG) {  // uniform
+        unsigned secs[SG];
+        unsigned keepbits = 0, run = 0;
+#pragma unroll
+        for (int q = 0; q < SG; ++q) {
+          const int k = k0 + q;
+          secs[q]     = 0xFFFFFFFFu;
+          if (k < g.T) {  // uniform
+            const int    fv = k == 0 ? v : future_cell(k);
+            const bool   in = k == 0 ? true : fv < g.V;
+            const size_t ci = (size_t)k * g.V + (in ? fv : 0);
+            if (k != 0 && active && in) {  // (slice 0 was stored above)
+              cell_st(base, ci, 1.0F, g.half);
+              ++n_marks;
+            }
+            if (lent) {
+              secs[q]                    = in ? (unsigned)(ci >> esh) : 0xFFFFFFFFu;
+              const unsigned long long m = keep_of(secs[q], in);
+              keepbits |= (unsigned)((m >> lane) & 1ull) << q;
+              run += (unsigned)__popcll(m);
+            }
+          }
         }
-        if (lg.entries) {
-          const unsigned long long m = keep_of(in ? (unsigned)(ci >> esh) : 0xFFFFFFFFu, in);
-          if (lane == k) pref = run;
-          run += (unsigned)__popcll(m);
+        if (lent) {
+          unsigned off = 0;
+          if (lane == 0 && run) off = atomicAdd(lg.n + agent, run);  // (consumed one group later)
+          n_logged += run;
+          if (p_n) flush();
+#pragma unroll
+          for (int q = 0; q < SG; ++q) p_secs[q] = secs[q];
+          p_keep = keepbits;
+          p_off  = off;
+          p_n    = g.T - k0 < SG ? g.T - k0 : SG;
         }
       }
-      if (lg.entries) {
-        unsigned lbase = 0;
-        if (lane == 0) lbase = atomicAdd(lg.n + agent, run);
-        lbase          = (unsigned)__shfl((int)lbase, 0, 64);
-        n_logged += run;
-        unsigned *lent = lg.entries + (size_t)agent * lg.cap;
-        for (int k = 0; k < g.T; ++k) {
-          const int                fv  = k == 0 ? v : future_cell(k);
-          const bool               in  = fv < g.V;
-          const unsigned           sec = in ? (unsigned)(((size_t)k * g.V + fv) >> esh) : 0xFFFFFFFFu;
-          const unsigned long long m   = keep_of(sec, in);
-          const unsigned           li  = lbase + (unsigned)__shfl((int)pref, k, 64) + (unsigned)__popcll(m & lt);
-          if (((m >> lane) & 1ull) && li < (unsigned)lg.cap) lent[li] = sec;
+      if (lent && p_n) flush();
+      } else {
+        unsigned *lent = lg.entries ? lg.entries + (size_t)agent * lg.cap : nullptr;
+        unsigned  pref = 0, run = 0;
+        {
+          const unsigned long long m = keep_of((unsigned)v >> esh, true);
+          run                        = (unsigned)__popcll(m);
+        }
+        for (int k = 1; k < g.T; ++k) {
+          const int    fv = future_cell(k);
+          const bool   in = fv < g.V;
+          const size_t ci = (size_t)k * g.V + (in ? fv : 0);
+          if (active && in) {
+            cell_st(base, ci, 1.0F, g.half);
+            ++n_marks;
+          }
+          if (lent) {
+            const unsigned long long m = keep_of(in ? (unsigned)(ci >> esh) : 0xFFFFFFFFu, in);
+            if (lane == (k & 63)) pref = run;
+            run += (unsigned)__popcll(m);
+          }
+        }
+        if (lent && g.T <= 64) {
+          unsigned lbase = 0;
+          if (lane == 0) lbase = atomicAdd(lg.n + agent, run);
+          lbase          = (unsigned)__shfl((int)lbase, 0, 64);
+          n_logged += run;
+          for (int k = 0; k < g.T; ++k) {
+            const int                fv  = k == 0 ? v : future_cell(k);
+            const bool               in  = fv < g.V;
+            const unsigned           sec = in ? (unsigned)(((size_t)k * g.V + fv) >> esh) : 0xFFFFFFFFu;
+            const unsigned long long m   = keep_of(sec, in);
+            const unsigned           li  = lbase + (unsigned)__shfl((int)pref, k, 64) + (unsigned)__popcll(m & lt);
+            if (((m >> lane) & 1ull) && li < (unsigned)lg.cap) lent[li] = sec;
+          }
+        } else if (lent && lane == 0) {
+          atomicAdd(lg.n + agent, (unsigned)lg.cap + 1u);  // (T > 64: no log — the agent's next reset is the dense one)
         }
       }
       PS_ADD(6, PS_CLK() - ps_w1);
@@ -751,7 +826,7 @@ __global__ __launch_bounds__(64) void k_stamp_marks(GridGeom g, void *__restrict
                                                     const float *__restrict__ poses,
                                                     const CylCand *__restrict__ cand_all,
                                                     const int *__restrict__ n_cand, int agent0, MarkLog lg) {
-  stamp_marks_trips(g, grid, bits, words_per_agent, cyl, n_cyl, poses, cand_all, n_cand, (int)blockIdx.y + agent0, lg,
+  stamp_marks_trips<false>(g, grid, bits, words_per_agent, cyl, n_cyl, poses, cand_all, n_cand, (int)blockIdx.y + agent0, lg,
                     (int)blockIdx.x * 256, (int)gridDim.x * 256);
 }
 
@@ -819,8 +894,9 @@ __device__ inline void splat_item(const GridGeom &g, void *__restrict__ grid, co
         const float fx = (float)((p[0] + body[e * 3 + 0]) - q0);
         const float fy = (float)((p[1] + body[e * 3 + 1]) - q1);
         const float fz = (float)((p[2] + body[e * 3 + 2]) - q2);
-        const int   vx = g.in_range(fx, fy, fz) ? g.voxel_of(fx, fy, fz) : g.V;
-        const bool  in = vx < g.V;  // (index >= V: the reference's out-of-bounds case, see k_stamp_bits)
+        const int   vl = g.in_range(fx, fy, fz) ? g.voxel_of(fx, fy, fz) : g.V;
+        const bool  in = vl < g.V;  // (index >= V: the reference's out-of-bounds case, see k_stamp_bits)
+        const int   vx = in ? g.phys_of(vl) : g.V;
         if (in) cell_st(slab, vx, 1.0F, g.half);
         if (lent && lb + (unsigned)e < (unsigned)lg.cap) lent[lb + e] = in ? (unsigned)((tslab + vx) >> esh) : 0xFFFFFFFFu;
       }
@@ -829,7 +905,8 @@ __device__ inline void splat_item(const GridGeom &g, void *__restrict__ grid, co
       for (int k = 0; k < R.n_pieces; ++k) dur += R.duration[k];
       bezier_pos(R, dur, p);
       const float fx = (float)(p[0] - q0), fy = (float)(p[1] - q1), fz = (float)(p[2] - q2);
-      const int vx = g.in_range(fx, fy, fz) ? g.voxel_of(fx, fy, fz) : g.V;
+      const int vl = g.in_range(fx, fy, fz) ? g.voxel_of(fx, fy, fz) : g.V;
+      const int vx = vl < g.V ? g.phys_of(vl) : g.V;
       if (vx < g.V) {
         cell_st(slab, vx, 1.0F, g.half);
         if (lent) {
@@ -875,8 +952,9 @@ __device__ inline void splat_item(const GridGeom &g, void *__restrict__ grid, co
         const float fx = (float)((w0 + (double)nx) - q0);
         const float fy = (float)((w1 + (double)ny) - q1);
         const float fz = (float)((w2 + (double)nz) - q2);
-        const int   vx = g.in_range(fx, fy, fz) ? g.voxel_of(fx, fy, fz) : g.V;
-        const bool  in = vx < g.V;
+        const int   vl = g.in_range(fx, fy, fz) ? g.voxel_of(fx, fy, fz) : g.V;
+        const bool  in = vl < g.V;
+        const int   vx = in ? g.phys_of(vl) : g.V;
         const unsigned li = lb + (unsigned)(e * n + i);
         if (lent && li < (unsigned)lg.cap) lent[li] = in ? (unsigned)((tslab + vx) >> esh) : 0xFFFFFFFFu;
         if (in) cell_add(slab, vx, rk, g.half);  // (fractional weights: the sum depends on the order in the last bits)
@@ -889,8 +967,9 @@ __device__ inline void splat_item(const GridGeom &g, void *__restrict__ grid, co
     const float fx = (float)((p[0] + body[e * 3 + 0]) - q0);
     const float fy = (float)((p[1] + body[e * 3 + 1]) - q1);
     const float fz = (float)((p[2] + body[e * 3 + 2]) - q2);
-    const int   vx = g.in_range(fx, fy, fz) ? g.voxel_of(fx, fy, fz) : g.V;
-    const bool  in = vx < g.V;
+    const int   vl = g.in_range(fx, fy, fz) ? g.voxel_of(fx, fy, fz) : g.V;
+    const bool  in = vl < g.V;
+    const int   vx = in ? g.phys_of(vl) : g.V;
     if (lent && lb + (unsigned)e < (unsigned)lg.cap) lent[lb + e] = in ? (unsigned)((tslab + vx) >> esh) : 0xFFFFFFFFu;
     if (!in) continue;
     // += 1.0f per body particle; sums of 1.0 are exact in fp32 (and in fp16 up to 2048), so the order
@@ -1014,10 +1093,11 @@ __global__ __launch_bounds__(256) void k_obstacle_points(
       const int y = ly + (c / nx) % ny;
       const int z = lz + c / (nx * ny);
       vi          = x + y * g.L + z * g.L * g.W;
+      const int pi = g.phys(x, y, z);
       for (int j = js; j <= je; ++j) {
         const float thr =
             g.map_kind == SOGM_MAP_FAKE ? g.risk_threshold : g.risk_threshold - g.decay_voxel * (float)j;
-        if (cell_ld(grid0, (size_t)j * g.V + vi, g.half) > thr) {
+        if (cell_ld(grid0, (size_t)j * g.V + pi, g.half) > thr) {
           ++cnt;
           mask |= 1u << (j - js);
         }
@@ -1063,17 +1143,17 @@ __global__ __launch_bounds__(256) void k_obstacle_points(
 // ------------------------------------------------------------------------------------------------
 // layout converters ([T][V] slabs <-> reference [V][T])
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_slabs_to_vt(const void *__restrict__ slabs, int V, int T, int half,
-                                                     float *__restrict__ vt) {
+__global__ __launch_bounds__(256) void k_slabs_to_vt(const void *__restrict__ slabs, GridGeom g, float *__restrict__ vt) {
   const int v = blockIdx.x * blockDim.x + threadIdx.x;
-  if (v >= V) return;
-  for (int t = 0; t < T; ++t) vt[(size_t)v * T + t] = cell_ld(slabs, (size_t)t * V + v, half);
+  if (v >= g.V) return;
+  const int p = g.phys_of(v);
+  for (int t = 0; t < g.T; ++t) vt[(size_t)v * g.T + t] = cell_ld(slabs, (size_t)t * g.V + p, g.half);
 }
-__global__ __launch_bounds__(256) void k_vt_to_slabs(const float *__restrict__ vt, int V, int T, int half,
-                                                     void *__restrict__ slabs) {
+__global__ __launch_bounds__(256) void k_vt_to_slabs(const float *__restrict__ vt, GridGeom g, void *__restrict__ slabs) {
   const int v = blockIdx.x * blockDim.x + threadIdx.x;
-  if (v >= V) return;
-  for (int t = 0; t < T; ++t) cell_st(slabs, (size_t)t * V + v, vt[(size_t)v * T + t], half);
+  if (v >= g.V) return;
+  const int p = g.phys_of(v);
+  for (int t = 0; t < g.T; ++t) cell_st(slabs, (size_t)t * g.V + p, vt[(size_t)v * g.T + t], g.half);
 }
 
 // Bezier pos / vel / acc of a trajectory record at an absolute time (bernstein.cpp:25-59)
@@ -1298,7 +1378,7 @@ __global__ __launch_bounds__(64) void k_prestamp_flow(GridGeom g, FlowCtl fc, Pr
       if (flow_wait_count(&fc.stage[agent], 1 + n_bits, &fc.hdr[FLOW_ERR])) break;
       [[maybe_unused]] const long long ps_t2 = PS_CLK();
       PS_ADD(1, ps_t2 - ps_t1);
-      stamp_marks_trips(g, ps.grid, ps.bits, ps.words, ps.cyl, ps.n_cyl, ps.poses, (const CylCand *)ps.cand, ps.n_cand, agent, ps.lg,
+      stamp_marks_trips<true>(g, ps.grid, ps.bits, ps.words, ps.cyl, ps.n_cyl, ps.poses, (const CylCand *)ps.cand, ps.n_cand, agent, ps.lg,
                         (s - n_bits) * 256, n_marks * 256, s_cand, PRESTAMP_CAND_LDS);
       __syncthreads();  // (the next ticket's staging overwrites s_cand)
       // the agent's last marks ticket to finish declares its grid complete (the next update's overlay waits for it)
@@ -1508,7 +1588,7 @@ __global__ __launch_bounds__(64) void k_flight_map(GridGeom g, FlightCtl fl, Fli
         wq_push(fl.mw, &fl.hdr[FL_MW_TAIL], ((unsigned)WK_MAP_MARKS << 28) | adr, n_m);
       }
     } else if (kind == WK_MAP_MARKS) {
-      stamp_marks_trips(g, d.grid, d.bits, d.words, w.cyl, w.n_cyl, d.poses, (const CylCand *)d.cand, d.n_cand, agent, d.lg,
+      stamp_marks_trips<true>(g, d.grid, d.bits, d.words, w.cyl, w.n_cyl, d.poses, (const CylCand *)d.cand, d.n_cand, agent, d.lg,
                         sub * 256, n_m * 256, s_cand, PRESTAMP_CAND_LDS);
       __syncthreads();  // (the next descriptor's staging overwrites s_cand)
       __threadfence();
@@ -1943,7 +2023,8 @@ int sogm_create(const SogmSpec *spec, int n_agents, int device, sogm_ctx **out) 
   if (spec->map_kind != SOGM_MAP_FAKE && spec->map_kind != SOGM_MAP_RISKBASE &&
       spec->map_kind != SOGM_MAP_RISKVOXEL)
     return SOGM_ERR_INVALID_ARG;
-  if (spec->storage != SOGM_STORE_F32 && spec->storage != SOGM_STORE_F16) return SOGM_ERR_INVALID_ARG;
+  if ((spec->storage & ~(1 | SOGM_LAYOUT_TILED)) != 0) return SOGM_ERR_INVALID_ARG;
+  if ((spec->storage & SOGM_LAYOUT_TILED) && ((spec->L | spec->W | spec->H) & 1)) return SOGM_ERR_INVALID_ARG;  // whole tiles
   // one time slice is addressed with 32-bit byte offsets (window_sum_hits) and V is an int
   if ((unsigned long long)spec->L * spec->W * spec->H >= (1ull << 30)) {
     sogm::set_error_text("sogm_create: L * W * H must stay below 2^30 cells per time slice");
@@ -2423,7 +2504,10 @@ static int update_gt_impl(sogm_ctx *c, const float *cloud_xyz, const int32_t *cl
     hipLaunchKernelGGL(k_stamp_bits, dim3(stamp_wgs, A), dim3(64), 0, st, c->geom, cloud_xyz, cloud_range, c->d_poses,
                        c->d_stamp_bits, words, 0);
   const sogm::MarkLog lg = sogm::mark_log(c, sogm::cur_slot(c));
-  hipLaunchKernelGGL(k_stamp_marks, dim3(stamp_wgs, A), dim3(64), 0, st, c->geom, (void *)c->d_grid, c->d_stamp_bits,
+  // (dynamic LDS the kernel does not use bounds its waves per CU: the marks' scattered stores merge worse in L2 the more
+  //  waves interleave theirs — tuning key stamp_lds_kb, 160 / kb workgroups per CU)
+  const size_t marks_lds = (size_t)c->tune_i(SOGM_TUNE_STAMP_LDS_KB) * 1024;
+  hipLaunchKernelGGL(k_stamp_marks, dim3(stamp_wgs, A), dim3(64), marks_lds, st, c->geom, (void *)c->d_grid, c->d_stamp_bits,
                      words, cylinders, n_cyl, c->d_poses, (const CylCand *)c->d_cand, (const int *)c->d_ncand, 0, lg);
   prof_end(c, SOGM_PROF_STAMP, st);
   SOGM_HIP_CHECK(hipGetLastError());
@@ -2597,8 +2681,8 @@ int sogm_set_future_risk(sogm_ctx *c, const float *grid_vt, const float *poses,
   c->tracked[sogm::cur_slot(c)] = 0;  // every cell is written: the next reset of this grid is the dense clear
   c->cur_prestamped = 0;
   for (int a = 0; a < c->n_agents; ++a) {
-    hipLaunchKernelGGL(k_vt_to_slabs, dim3((V + 255) / 256), dim3(256), 0, st, grid_vt + a * per, V, T,
-                       c->geom.half, (void *)((char *)c->d_grid + a * per * c->cell_bytes()));
+    hipLaunchKernelGGL(k_vt_to_slabs, dim3((V + 255) / 256), dim3(256), 0, st, grid_vt + a * per, c->geom,
+                       (void *)((char *)c->d_grid + a * per * c->cell_bytes()));
   }
   SOGM_HIP_CHECK(hipGetLastError());
   c->updated = 1;
@@ -2612,8 +2696,8 @@ int sogm_download_reference_layout(sogm_ctx *c, int agent, float *out) {
   const size_t per = (size_t)V * T;
   SOGM_HIP_CHECK(hipDeviceSynchronize());
   hipLaunchKernelGGL(k_slabs_to_vt, dim3((V + 255) / 256), dim3(256), 0, 0,
-                     (const void *)((const char *)c->d_grid + (size_t)agent * per * c->cell_bytes()), V, T,
-                     c->geom.half, c->d_scratch_vt);
+                     (const void *)((const char *)c->d_grid + (size_t)agent * per * c->cell_bytes()), c->geom,
+                     c->d_scratch_vt);
   SOGM_HIP_CHECK(hipGetLastError());
   SOGM_HIP_CHECK(hipMemcpy(out, c->d_scratch_vt, per * sizeof(float), hipMemcpyDeviceToHost));
   return SOGM_OK;
