@@ -9,14 +9,14 @@ import importlib, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 driver = importlib.import_module("pred-occ-planner_amd.driver")
-sw = driver.SwarmTick("cfg2", 128, overlap_clear=False)
+sw = driver.SwarmTick("cfg2", 128, overlap_clear=False, moving_world=True, prestamp=False)  # (SOGM_LAYOUT=rows|tiled)
+print("cell order:", "2x2x2 tiles" if sw.spec.storage & 16 else "x-fastest rows")
 sw.map.set_profiling(True)
 entries, moved = [], []
 sw.map.map_traffic(reset=True)
 for k in range(6):  # update 0 clears densely (the grid is untracked), updates 1.. reset the logged sectors
     sw.compute.tick_inputs(sw.own, sw.t0, sw.hover, sw.now, sw.t_start, sw.pva, sw.poses)
-    sw.map.updateMapSwarm(sw.dev["cloud"], sw.dev["cloud_range"], sw.dev["cylinders"], sw.dev["n_cyl"], sw.poses, sw.now,
-                          sw.all, sw.A_tot, sw.dev["ego_ids"])
+    sw.compute.update_map(sw.poses, sw.now, sw.all, sw.A_tot, k)   # sogm_update_world: frame k, cropped on the device
     torch.cuda.synchronize()
     moved.append(sw.map.map_traffic(reset=True))  # (before the state query: that one restarts the reset's counters)
     st = sw.map.sparse_reset_state()

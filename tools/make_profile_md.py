@@ -1,8 +1,9 @@
-"""Assemble profiles/r04_end_rocprof.md and the PMC figures bench.py cites (profiles/r04_pmc_reset.json,
-r04_pmc_stamp.json, r04_pmc_traffic.json) from gpurun_out/profile/ (tools/make_profile.sh core + rest)."""
+"""Assemble profiles/r05_end_rocprof.md and the PMC figures bench.py cites (profiles/r05_pmc_reset.json,
+r05_pmc_stamp.json, r05_pmc_traffic.json) from gpurun_out/profile/ (tools/make_profile.sh core + rest)."""
 import json, os, re
 P = 'gpurun_out/profile/'
-R = 'r04'
+R = 'r05'
+KB = 1024.0
 
 
 def read(f, default=""):
@@ -19,62 +20,58 @@ def last_json(f):
     return "", None
 
 
-summ, tl, flow, qpt = read('summary.md'), read('timeline.txt'), read('flow.txt'), read('qp_time.txt')
-
-
-def pm(counter, kernel, last=False):
-    """(dispatches, mean KB of 1024 B) of a kernel's counter: from the first PMC pass that lists it, or the last one"""
+def pm(summ, counter, kernel, last=False):
+    """mean KB (of 1024 B) of a kernel's counter: from the first PMC pass of `summ` that lists it, or the last one"""
     m = re.findall(r"%s \| %s \| (\d+) \| ([\d.]+) \|" % (re.escape(kernel), counter), summ)
     if not m:
-        return 0, float('nan')
-    m = m[-1] if last else m[0]
-    return int(m[0]), float(m[1])
+        return float('nan')
+    return float((m[-1] if last else m[0])[1])
 
 
-KB = 1024.0
-# ---- sparse reset + stamp + overlay by themselves (tools/diag_reset_pmc.py under --pmc) -----------------------------
-_, fk_r = pm('FETCH_SIZE', 'k_reset_sectors<2, 1>')
-_, wk_r = pm('WRITE_SIZE', 'k_reset_sectors<2, 1>')
-_, fk_m = pm('FETCH_SIZE', 'k_stamp_marks')
-_, wk_m = pm('WRITE_SIZE', 'k_stamp_marks')
-_, fk_b = pm('FETCH_SIZE', 'k_stamp_bits')
-_, wk_b = pm('WRITE_SIZE', 'k_stamp_bits')
-ra = read('reset_alone_plain.txt')
-ent = [int(x) for x in re.search(r"log entries after each update: \[([\d, ]+)\]", ra).group(1).split(",")]
-reset_ms = [float(x) for x in re.search(r"reset launches[^:]*: \[([\d., ]+)\]", ra).group(1).split(",")]
-stamp_ms = [float(x) for x in re.search(r"stamp \(cull \+ bits \+ marks\) launches ms: \[([\d., ]+)\]", ra).group(1).split(",")]
-moved = json.loads(re.search(r"sogm_map_traffic\): (\[.*\])", ra).group(1))
+def map_pass(layout, summ):
+    """the sparse reset + stamp + overlay by themselves (tools/diag_reset_pmc.py under --pmc), one cell order"""
+    ra = read(f'reset_alone_{layout}.txt')
+    ent = [int(x) for x in re.search(r"log entries after each update: \[([\d, ]+)\]", ra).group(1).split(",")]
+    reset_ms = [float(x) for x in re.search(r"reset launches[^:]*: \[([\d., ]+)\]", ra).group(1).split(",")]
+    stamp_ms = [float(x) for x in re.search(r"stamp \(cull \+ bits \+ marks\) launches ms: \[([\d., ]+)\]", ra).group(1).split(",")]
+    moved = json.loads(re.search(r"sogm_map_traffic\): (\[.*\])", ra).group(1))
+    o = {"layout": layout, "reset_ms": sum(reset_ms[1:]) / len(reset_ms[1:]), "stamp_ms": sum(stamp_ms[1:]) / len(stamp_ms[1:]),
+         "entries_reset": sum(ent[:-1]) / len(ent[:-1]), "marks": moved[-1]["stamp_marks"], "stamp_entries": moved[-1]["stamp_entries"],
+         "zeroed": moved[-1]["reset_bytes_zeroed"]}
+    o["fk_r"], o["wk_r"] = pm(summ, 'FETCH_SIZE', 'k_reset_sectors<2, 1>'), pm(summ, 'WRITE_SIZE', 'k_reset_sectors<2, 1>')
+    o["fk_m"], o["wk_m"] = pm(summ, 'FETCH_SIZE', 'k_stamp_marks'), pm(summ, 'WRITE_SIZE', 'k_stamp_marks')
+    o["fk_b"], o["wk_b"] = pm(summ, 'FETCH_SIZE', 'k_stamp_bits_blocks'), pm(summ, 'WRITE_SIZE', 'k_stamp_bits_blocks')
+    # gfx950: FETCH_SIZE reports half of a coalesced streaming read (MI355X_MICROARCH guide, HBM / rocprofv3 section): x 2
+    o["reset_traffic"] = (2 * o["fk_r"] + o["wk_r"]) * KB
+    o["reset_counted"] = 4 * o["entries_reset"] + o["zeroed"]
+    o["stamp_alg"] = 4 * (o["marks"] + o["stamp_entries"])
+    o["stamp_traffic"] = (2 * o["fk_m"] + o["wk_m"]) * KB
+    return o
+
+
+summ, summ_rows = read('summary.md'), read('summary_rows.md')
+T, Rw = map_pass('tiled', summ), map_pass('rows', summ_rows)
 wide = read('reset_alone_wide.txt')
 wide_ms = [float(x) for x in re.search(r"reset launches[^:]*: \[([\d., ]+)\]", wide).group(1).split(",")] if wide else []
-ent_reset = sum(ent[:-1]) / len(ent[:-1])        # reset k reads the log update k-1 wrote
-marks = moved[-1]["stamp_marks"]
-s_entries = moved[-1]["stamp_entries"]
-zeroed = moved[-1]["reset_bytes_zeroed"]
-# gfx950: FETCH_SIZE reports half of a coalesced streaming read (MI355X_MICROARCH guide, HBM / rocprofv3 section): x 2
-reset_fetch, reset_write = 2 * fk_r * KB, wk_r * KB
-reset_traffic = reset_fetch + reset_write
-reset_counted = 4 * ent_reset + zeroed
-json.dump({"kernel": "k_reset_sectors (sparse reset of the SOGM, 2 lanes x 1 entry per trip: the variant the tick runs)",
+
+json.dump({"kernel": "k_reset_sectors (sparse reset of the SOGM, 2 lanes x 1 entry per trip: the variant the tick runs; 2x2x2 cell tiles)",
            "source": f"profiles/{R}_end_rocprof.md: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes of "
                      "`python tools/diag_reset_pmc.py` (128 agents 200x200x200x20, single grid, update = reset + stamp + overlay)",
-           "fetch_kb": fk_r, "write_kb": wk_r, "fetch_bytes_corrected": reset_fetch, "write_bytes": reset_write,
-           "entries_per_launch": ent_reset, "bytes_per_entry": reset_traffic / ent_reset,
-           "device_counted_bytes_per_launch": reset_counted, "counted_over_traffic": reset_counted / reset_traffic},
+           "fetch_kb": T["fk_r"], "write_kb": T["wk_r"], "fetch_bytes_corrected": 2 * T["fk_r"] * KB, "write_bytes": T["wk_r"] * KB,
+           "entries_per_launch": T["entries_reset"], "bytes_per_entry": T["reset_traffic"] / T["entries_reset"],
+           "device_counted_bytes_per_launch": T["reset_counted"], "counted_over_traffic": T["reset_counted"] / T["reset_traffic"]},
           open(f'profiles/{R}_pmc_reset.json', 'w'))
-stamp_alg = 4 * (marks + s_entries)
-stamp_traffic = (2 * fk_m + wk_m) * KB
-json.dump({"kernel": "k_stamp_marks (x-ordered marks + mark log)",
+json.dump({"kernel": "k_stamp_marks (marks + mark log; 2x2x2 cell tiles)",
            "source": f"profiles/{R}_end_rocprof.md (same passes as the reset)",
-           "fetch_kb": fk_m, "write_kb": wk_m, "bytes_per_launch": stamp_traffic, "marks": marks, "log_entries": s_entries,
-           "algorithmic_bytes_per_launch": stamp_alg, "sectors_logged": s_entries,
-           "sector_granular_minimum": 32 * s_entries + 4 * s_entries,
-           "k_stamp_bits": {"fetch_kb": fk_b, "write_kb": wk_b}},
+           "fetch_kb": T["fk_m"], "write_kb": T["wk_m"], "bytes_per_launch": T["stamp_traffic"], "marks": T["marks"],
+           "log_entries": T["stamp_entries"], "algorithmic_bytes_per_launch": T["stamp_alg"],
+           "k_stamp_bits_blocks": {"fetch_kb": T["fk_b"], "write_kb": T["wk_b"]},
+           "rows": {"bytes_per_launch": Rw["stamp_traffic"], "log_entries": Rw["stamp_entries"], "algorithmic_bytes_per_launch": Rw["stamp_alg"]}},
           open(f'profiles/{R}_pmc_stamp.json', 'w'))
-# ---- dense clear kernels (tools/diag_clear_pmc.py) ------------------------------------------------------------------
-_, fk_c = pm('FETCH_SIZE', 'k_clear_chunks<true>', last=True)
-_, wk_c = pm('WRITE_SIZE', 'k_clear_chunks<true>', last=True)
+fk_c, wk_c = pm(summ, 'FETCH_SIZE', 'k_clear_chunks<true>', last=True), pm(summ, 'WRITE_SIZE', 'k_clear_chunks<true>', last=True)
 plain_line, d = last_json('bench_plain.json')
-alg = d['roofline']['dense_equivalent']['bytes'] if 'dense_equivalent' in d['roofline'] else d['roofline']['bytes_per_launch']
+r, s, cb = d['roofline'], d.get('sustained') or {}, d.get('cpu_baseline') or {}
+alg = r['dense_equivalent']['bytes'] if 'dense_equivalent' in r else r['bytes_per_launch']
 dense_traffic = int((fk_c + wk_c) * KB)
 json.dump({"kernel": "k_clear_chunks (the in-tick dense SOGM clear)",
            "source": f"profiles/{R}_end_rocprof.md: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
@@ -82,14 +79,14 @@ json.dump({"kernel": "k_clear_chunks (the in-tick dense SOGM clear)",
            "fetch_kb": fk_c, "write_kb": wk_c, "bytes_per_launch": dense_traffic, "algorithmic_bytes_per_launch": alg},
           open(f'profiles/{R}_pmc_traffic.json', 'w'))
 
-r, s, cb = d['roofline'], d.get('sustained') or {}, d.get('cpu_baseline') or {}
-kern = {k['kernel'].split(' ')[0]: k for k in r.get('kernels', [])}
 kd = next((k for k in r.get('kernels', []) if k['kernel'].startswith('k_clear_slabs')), {})
 smi = lambda f: " / ".join(l.split(":", 1)[1].strip() if ":" in l else l.strip() for l in read(f).splitlines()
                            if any(k in l for k in ("sclk", "mclk", "Power (W)", "Temperature (Sensor junction)")))
-var = {}
-for name in ('dense', 'flow0', 'grids2', 'mode1', 'cfg4', 'trace'):
-    var[name] = last_json(f'bench_{name}.json')
+var = {name: last_json(f'bench_{name}.json') for name in ('rows', 'dense', 'flow0', 'trace')}
+ch, st, slow = d.get('chain_ms') or {}, cb.get('stages_ms') or {}, s.get('slowest_tick') or {}
+V = d.get('variants') or {}
+fl, ps = V.get('flight') or {}, V.get('prestamped_lockstep') or {}
+cfgs = d.get('configs') or {}
 
 
 def vrow(label, key):
@@ -101,38 +98,58 @@ def vrow(label, key):
     return f"| {label} | {v['value']:.0f} | {v['ms_per_step']:.2f} | {rr['avg_launch_ms']:.2f} (frac {rr['frac']:.3f}) | {sus} |"
 
 
-ch = d.get('chain_ms') or {}
-st = cb.get('stages_ms') or {}
-slow = s.get('slowest_tick') or {}
-md = f"""# Round 4 — rocprofv3 profile of `python bench.py` (MI355X, 128 agents, 200^3 x 20), numbers of record
+def lay_row(o):
+    return (f"| {o['layout']} | {o['stamp_ms']:.2f} ms | {o['marks']/1e6:.1f} M | {o['stamp_entries']/1e6:.1f} M | "
+            f"{o['stamp_traffic']/1e9:.3f} GB (FETCH x 2 {2*o['fk_m']*KB/1e9:.3f} + WRITE {o['wk_m']*KB/1e9:.3f}) | x {o['stamp_traffic']/o['stamp_alg']:.2f} | "
+            f"{o['reset_ms']:.3f} ms | {o['entries_reset']/1e6:.1f} M | {o['reset_traffic']/1e9:.3f} GB | {o['reset_counted']/o['reset_traffic']:.3f} |")
+
+
+rows_line, rows_d = var['rows']
+fl_rows = [json.loads(l[7:]) for l in read('flight_rows.txt').splitlines() if l.startswith('FLIGHT ')]
+fl_runs = [json.loads(l[7:]) for l in read('flight.txt').splitlines() if l.startswith('FLIGHT ')]
+md = f"""# Round 5 — rocprofv3 profile of `python bench.py` (MI355X, 128 agents, 200^3 x 20), numbers of record
 
 Collected by `tools/make_profile.sh core` and `... rest` on ONE GPU box (`cd /tmp && export TMPDIR=/tmp`), assembled by
 `tools/make_profile_md.py`:
-- `rocprofv3 --kernel-trace --stats -d … -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline --sustained 0 --dense-ticks 0`
+- `rocprofv3 --kernel-trace --stats -d … -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline --sustained 0 --dense-ticks 0 --no-variants`
 - separate PMC passes (no trace domains): `rocprofv3 --pmc FETCH_SIZE …` and `… --pmc WRITE_SIZE …` of
-  `SOGM_TUNING=reset_lanes=2,reset_unroll=1 python tools/diag_reset_pmc.py` (the sparse reset, the logging stamp and the
-  overlay by themselves: counter collection serialises kernels, under which the dataflow replan cannot run) and of
-  `SOGM_SPARSE_RESET=0 SOGM_TUNING=clear_early=1 python tools/diag_clear_pmc.py` (the in-tick dense clear kernels).
+  `SOGM_TUNING=reset_lanes=2,reset_unroll=1 python tools/diag_reset_pmc.py` under `SOGM_LAYOUT=tiled` and `=rows` (the sparse
+  reset, the logging stamp and the overlay by themselves, fed with the moving world's frames: counter collection serialises
+  kernels, under which the dataflow replan cannot run) and of `SOGM_SPARSE_RESET=0 SOGM_TUNING=clear_early=1 python
+  tools/diag_clear_pmc.py` (the in-tick dense clear kernels).
 The rocpd databases stay in gpurun_out/ (scratch); this file holds what is cited.
 
 **Box state** (`rocm-smi --showclocks --showpower --showtemp`; idle readings): before the default run:
-{smi('smi_before.txt')}; after it: {smi('smi_after.txt')}.  Boxes differ by several per cent (the same full-width clear:
-12.2–13.8 ms), so only figures of ONE box are compared with each other in DESIGN.md; code versions are compared on one
-box with `tools/micro/ab.sh` (`SOGM_LIB_PATH`).
+{smi('smi_before.txt')}; after it: {smi('smi_after.txt')}.  Boxes differ by several per cent, so only figures of ONE box
+are compared with each other.
 
-## Default run (`python bench.py`: 3 warm-up + 20 timed ticks, the dense-clear block, 300 host-synchronised ticks, CPU baseline)
+## Default run (`python bench.py`)
 
+**Headline** — lock-step tick through a moving world, map update at the start of the tick from that tick's frame
+(`map_input_staleness_ticks` {d['config'].get('map_input_staleness_ticks')}), cell order {d['config'].get('sogm_cell_order')}:
 **{d['value']:.0f} replans/s** ({d['ms_per_step']:.2f} ms per tick), {d['value_ok']:.0f} successful
 (`replans_ok_fraction` {d['config']['replans_ok_fraction']:.3f}; outcomes {json.dumps(d['config']['outcomes'])}).
-Sustained: {s.get('value', 0):.0f} replans/s over {s.get('ticks')} ticks (tick mean {s.get('tick_ms_mean', 0):.2f} / p50
-{s.get('tick_ms_p50', 0):.2f} / p99 {s.get('tick_ms_p99', 0):.2f} / max {s.get('tick_ms_max', 0):.2f} ms, ok
-{s.get('replans_ok_fraction', 0):.3f}); the slowest tick ({slow.get('tick_ms', 0):.2f} ms, tick {slow.get('tick')}): chain end
-{slow.get('chain_end', 0):.2f} ms, critical agent {slow.get('critical_agent')} = {json.dumps(slow.get('critical_chain'))} — an
-exhaustive A\\* search (both attempts NO_PATH) is what the long ticks are.
+
+**Variants** (fresh swarms flying the headline's ticks):
+- pre-stamped lock-step (map one tick stale): {ps.get('value', 0):.0f} replans/s, {ps.get('ms_per_step', 0):.2f} ms per tick;
+- **flight** (`sogm_flight_run`: per-agent overlap, own record of tick k − 1, neighbours' of tick k − 2; same maps as the
+  headline): **{fl.get('value', 0):.0f} replans/s, {fl.get('ms_per_step', 0):.2f} ms per tick**; per agent-tick (ms)
+  {json.dumps({k: round(v, 3) for k, v in (fl.get('per_agent_tick_ms') or {}).items()})}; its sustained block:
+  {json.dumps({k: (round(v, 2) if isinstance(v, float) else v) for k, v in (fl.get('sustained') or {}).items()})}.
+
+**Sustained** (lock-step, the next {s.get('ticks')} host-synchronised ticks): {s.get('value', 0):.0f} replans/s (tick mean
+{s.get('tick_ms_mean', 0):.2f} / p50 {s.get('tick_ms_p50', 0):.2f} / p99 {s.get('tick_ms_p99', 0):.2f} / max {s.get('tick_ms_max', 0):.2f} ms, ok
+{s.get('replans_ok_fraction', 0):.3f}); cells stamped per tick {json.dumps(s.get('stamp_marks_per_tick'))}.
+The slowest tick ({slow.get('tick_ms', 0):.2f} ms, tick {slow.get('tick')}) on ONE clock (`sogm_device_clock`), ms:
+{json.dumps({k: round(v, 3) for k, v in (slow.get('split_ms') or {}).items()})}; its critical agent {slow.get('critical_agent')} =
+{json.dumps(slow.get('critical_chain'))}.
 
 Per-agent chain of the last timed tick (device timestamps, ms): A\\* {ch.get('astar_mean', 0):.2f} mean / {ch.get('astar_max', 0):.2f} max,
 corridors {ch.get('corridor_mean', 0):.2f} / {ch.get('corridor_max', 0):.2f}, QP {ch.get('qp_mean', 0):.2f} / {ch.get('qp_max', 0):.2f}; mean chain
 {ch.get('chain_mean', 0):.2f}, chain end {ch.get('chain_end', 0):.2f} (critical agent {ch.get('critical_agent')}: {json.dumps(ch.get('critical_chain'))}).
+Other configurations in the same line: cfg4 {json.dumps({k: (round(v, 2) if isinstance(v, float) else v) for k, v in (cfgs.get('cfg4') or {}).items() if k not in ('roofline', 'workload')})},
+reset roofline {json.dumps((cfgs.get('cfg4') or {}).get('roofline'))}; cfg1 {(cfgs.get('cfg1') or {}).get('ms_per_frame', 0):.2f} ms per frame, stages
+{json.dumps((cfgs.get('cfg1') or {}).get('stage_ms'))}, `k_dsp_publish` {((cfgs.get('cfg1') or {}).get('roofline') or {}).get('frac', 0):.3f} of peak.
 CPU baseline (oracle "port"): {cb.get('value', 0):.1f} replans/s on {cb.get('cores')} of {cb.get('host_cores')} host cores;
 single-thread stage latencies of tick 0: SOGM update {st.get('sogm_update') or 0:.1f} ms, A\\* {st.get('astar') or 0:.2f} ms, corridors
 {st.get('corridor') or 0:.2f} ms, QP {st.get('qp') or 0:.1f} ms.
@@ -142,68 +159,59 @@ single-thread stage latencies of tick 0: SOGM update {st.get('sogm_update') or 0
 | kernel | time | bytes counted on the device / algorithmic | rate | of 8 TB/s | PMC traffic (FETCH x 2 + WRITE) | traffic / counted |
 |---|---|---|---|---|---|---|
 | `k_reset_sectors` inside the tick (n = {r.get('launches_timed')}) | {r['avg_launch_ms']:.3f} ms | {r['bytes_per_launch']/1e9:.3f} GB = 4 B x {r.get('log_entries_per_launch', 0)/1e6:.1f} M entries + {r.get('bytes_zeroed_per_launch', 0)/1e9:.3f} GB zeroed | {r['achieved']:.0f} GB/s | **{r['frac']:.3f}** | {(r.get('traffic') or 0)/1e9:.3f} GB (scaled per entry from the pass below) | {((r.get('traffic') or 0)/r['bytes_per_launch']):.3f} |
-| `k_reset_sectors` alone (PMC pass; launches {", ".join("%.3f" % x for x in reset_ms[1:])} ms) | {sum(reset_ms[1:])/len(reset_ms[1:]):.3f} ms | {reset_counted/1e9:.3f} GB = 4 B x {ent_reset/1e6:.1f} M + {zeroed/1e9:.3f} GB | {reset_counted/(sum(reset_ms[1:])/len(reset_ms[1:]))/1e6:.0f} GB/s | {reset_counted/(sum(reset_ms[1:])/len(reset_ms[1:]))/1e6/8000:.3f} | {reset_traffic/1e9:.3f} GB = {reset_fetch/1e9:.3f} + {reset_write/1e9:.3f} | {reset_traffic/reset_counted:.3f} |
-| the stamp alone (cull + bits + marks; launches {", ".join("%.2f" % x for x in stamp_ms[1:])} ms) | {sum(stamp_ms[1:])/len(stamp_ms[1:]):.2f} ms | {stamp_alg/1e9:.3f} GB = 4 B x ({marks/1e6:.1f} M marks + {s_entries/1e6:.1f} M log entries) | {stamp_alg/(sum(stamp_ms[1:])/len(stamp_ms[1:]))/1e6:.0f} GB/s | {stamp_alg/(sum(stamp_ms[1:])/len(stamp_ms[1:]))/1e6/8000:.3f} | `k_stamp_marks` {stamp_traffic/1e9:.3f} GB (FETCH {2*fk_m*KB/1e9:.3f} + WRITE {wk_m*KB/1e9:.3f}); `k_stamp_bits` WRITE {wk_b*KB/1e9:.2f} GB of device-scope atomics | {stamp_traffic/stamp_alg:.2f} |
+| `k_reset_sectors` alone (PMC pass) | {T['reset_ms']:.3f} ms | {T['reset_counted']/1e9:.3f} GB = 4 B x {T['entries_reset']/1e6:.1f} M + {T['zeroed']/1e9:.3f} GB | {T['reset_counted']/T['reset_ms']/1e6:.0f} GB/s | {T['reset_counted']/T['reset_ms']/1e6/8000:.3f} | {T['reset_traffic']/1e9:.3f} GB | {T['reset_traffic']/T['reset_counted']:.3f} |
+| the stamp alone (cull + bits + marks) | {T['stamp_ms']:.2f} ms | {T['stamp_alg']/1e9:.3f} GB = 4 B x ({T['marks']/1e6:.1f} M marks + {T['stamp_entries']/1e6:.1f} M log entries) | {T['stamp_alg']/T['stamp_ms']/1e6:.0f} GB/s | {T['stamp_alg']/T['stamp_ms']/1e6/8000:.3f} | `k_stamp_marks` {T['stamp_traffic']/1e9:.3f} GB; `k_stamp_bits_blocks` WRITE {T['wk_b']*KB/1e9:.2f} GB of device-scope atomics | {T['stamp_traffic']/T['stamp_alg']:.2f} |
 | dense clear alone (full width) | {min(kd.get('standalone', {}).get('launch_ms', [0])):.2f} ms | {alg/1e9:.2f} GB | {kd.get('standalone', {}).get('achieved', 0):.0f} GB/s | **{kd.get('standalone', {}).get('frac', 0):.3f}** | {dense_traffic/1e9:.2f} GB (`k_clear_chunks`) | {dense_traffic/alg:.4f} |
 | dense clear inside the tick (`sogm_set_sparse_reset 0`, {(kd.get('in_tick') or {}).get('launches_timed')} ticks) | {(kd.get('in_tick') or {}).get('avg_launch_ms', 0):.2f} ms | {alg/1e9:.2f} GB | {(kd.get('in_tick') or {}).get('achieved', 0):.0f} GB/s | **{(kd.get('in_tick') or {}).get('frac', 0):.3f}** (tick {(kd.get('in_tick') or {}).get('tick_ms', 0):.2f} ms) | — | — |
 
-Reading guide:
-- **The reset** is rated on what it moved: `sogm_map_traffic` counts, on the device and in the run, the log entries read
-  and the bytes of the stores issued; the PMC pass (reset alone, same variant) agrees within
-  {abs(reset_traffic/reset_counted - 1)*100:.1f} % (FETCH_SIZE doubled: gfx950 reports half of a coalesced streaming read).
-  It is a scatter of 32-byte stores behind a 4-byte index stream: latency-bound at ≈{reset_counted/(sum(reset_ms[1:])/len(reset_ms[1:]))/1e6/8000:.2f} of
-  the HBM peak, off the critical path (side stream, under the QP stage).  SURVEY 8(d)'s {alg/1e9:.2f} GB fill is not
-  executed; the kernel that does execute it is the dense clear (last two rows).
-- **Mark log**: this round the stamp logs a sector once per run of x-neighbouring marks instead of once per mark:
-  {s_entries/1e6:.1f} M entries per tick (round 3: 87.6 M), one per distinct sector.
-- **Stamp write amplification**: against "4 B per mark + 4 B per log entry" `k_stamp_marks` writes
-  x {stamp_traffic/stamp_alg:.2f}; but the {marks/1e6:.1f} M marks fall into {s_entries/1e6:.1f} M distinct 32-byte sectors
-  ({marks/s_entries:.2f} marks per sector: cylinder surfaces cross an x-row in two or three cells), and HBM writes whole
-  sectors: the sector-granular minimum is 32 B x sectors + 4 B x entries = {(36*s_entries)/1e9:.3f} GB, the counters show
-  {stamp_traffic/1e9:.3f} GB = x {stamp_traffic/(36*s_entries):.3f} of it.  Nothing is written twice; fewer bytes need a grid
-  layout in which a pillar's marks share sectors (z-fastest or blocked), which the A\\* window query pays for
-  (DESIGN 3.1).
-- In the dataflow replan the planner is five launches per tick; `k_corridor_flow`, `k_qp_flow`, `k_finish_flow`,
-  `k_prestamp_flow` are persistent (their durations span most of the tick by construction) — the per-agent chain is what
-  to read, not the kernel durations.
+## Cell order: x-fastest rows against 2 x 2 x 2 tiles (review item 6), same box
+
+Map kernels by themselves (`tools/diag_reset_pmc.py`, PMC passes per layout):
+
+| cell order | stamp | marks | log entries | `k_stamp_marks` traffic | traffic / (4 B per mark + 4 B per entry) | reset alone | entries read | reset traffic | counted / traffic |
+|---|---|---|---|---|---|---|---|---|---|
+{lay_row(Rw)}
+{lay_row(T)}
+
+Whole tick (`bench.py --no-variants --sustained 100`), rows against tiles: headline {(rows_d or {}).get('value', 0):.0f} vs {d['value']:.0f}
+replans/s ({(rows_d or {}).get('ms_per_step', 0):.2f} vs {d['ms_per_step']:.2f} ms); grouped stage launches after the timed region (each stage's
+slowest agent, ms) rows {json.dumps({k: round(v, 2) for k, v in ((rows_d or {}).get('stage_ms') or {}).items() if isinstance(v, float)})} vs tiles
+{json.dumps({k: round(v, 2) for k, v in (d.get('stage_ms') or {}).items() if isinstance(v, float)})}; chain A\\* mean
+{((rows_d or {}).get('chain_ms') or {}).get('astar_mean', 0):.3f} vs {ch.get('astar_mean', 0):.3f} ms.  Flights: rows
+{(fl_rows[0]['ms_per_tick'] if fl_rows else 0):.2f} vs tiles {(fl_runs[0]['ms_per_tick'] if fl_runs else 0):.2f} ms per tick.
+The search's 5 x 5 window is nine 16-byte loads under tiles (3 x 3 tiles at one height) against five to ten row loads:
+no regression; the corridor box scan gets faster (whole tiles per line).
 
 ## Variants on the same box
 
 | variant | replans/s | ms/tick | reset / clear ms | sustained replans/s (mean tick) |
 |---|---|---|---|---|
-| default: dataflow replan, 3 grids, sparse reset, pre-stamp | {d['value']:.0f} | {d['ms_per_step']:.2f} | {r['avg_launch_ms']:.2f} (frac {r['frac']:.3f}) | {s.get('value', 0):.0f} ({s.get('tick_ms_mean', 0):.2f} ms) |
+| default: lock-step, moving world, 3 grids, sparse reset, tiles | {d['value']:.0f} | {d['ms_per_step']:.2f} | {r['avg_launch_ms']:.2f} (frac {r['frac']:.3f}) | {s.get('value', 0):.0f} ({s.get('tick_ms_mean', 0):.2f} ms) |
+{vrow("x-fastest rows (`SOGM_LAYOUT=rows`)", 'rows')}
 {vrow("dense clear (`SOGM_SPARSE_RESET=0`)", 'dense')}
-{vrow("grouped streams (`SOGM_FLOW=0`), 3 grids", 'flow0')}
-{vrow("dataflow, 2 grids (`SOGM_GRIDS=2`)", 'grids2')}
-{vrow("single grid, reset in place (`SOGM_DOUBLE_BUFFER=0`)", 'mode1')}
-{vrow("BASELINE configs[4]: 300^3 x 30, fp16 cells", 'cfg4')}
+{vrow("grouped streams (`SOGM_FLOW=0`)", 'flow0')}
 
-Reduced residency (tests/test_residency_gpu.py, full-size tick, identical records): {read('residency.txt').strip() or '(not collected)'}
+Hardware queues / compute units (tests/test_residency_gpu.py, full-size, identical records):
+{read('residency.txt').strip() or '(not collected)'}
+
+## Flights (`tools/bench_flight.py 20`: 3 warm-up + 20 timed ticks per variant)
+
+```
+{read('flight.txt').strip()}
+```
+
+### timeline of a flight (`tools/diag_flight.py 20`)
+
+```
+{read('flight_timeline.txt').strip()}
+```
 
 {summ}
 
-## timeline of one tick (ms from the tick's first kernel)
+## per-agent chain of the dataflow replan (tools/diag_flow.py: in-kernel 100 MHz stamps, 12 ticks; frozen world, pre-stamped)
 
 ```
-{tl.strip()}
-```
-
-## per-agent chain of the dataflow replan (tools/diag_flow.py: in-kernel 100 MHz stamps, 12 ticks)
-
-```
-{flow.strip()}
-```
-
-## where the QP stage spends its time (tools/diag_qp_time.py: per-solve clock split inside `k_qp_flow`, 12 ticks)
-
-```
-{qpt.strip()}
-```
-
-## capacity limits over a 323-tick flight (tools/diag_capacity.py)
-
-```
-{read('capacity.txt').strip()}
+{read('flow.txt').strip()}
 ```
 
 ## bench.py JSON lines
@@ -220,24 +228,12 @@ Reduced residency (tests/test_residency_gpu.py, full-size tick, identical record
 {var['trace'][0]}
 ```
 
-- dense clear (`SOGM_SPARSE_RESET=0`):
+- x-fastest rows:
 
 ```
-{var['dense'][0]}
-```
-
-- grouped path (`SOGM_FLOW=0`):
-
-```
-{var['flow0'][0]}
-```
-
-- BASELINE configs[4]:
-
-```
-{var['cfg4'][0]}
+{rows_line}
 ```
 """
 open(f'profiles/{R}_end_rocprof.md', 'w').write(md)
-print(f"wrote profiles/{R}_end_rocprof.md", len(md), "bytes; reset counted/traffic", reset_counted / reset_traffic,
-      "stamp amplification", stamp_traffic / stamp_alg)
+print(f"wrote profiles/{R}_end_rocprof.md", len(md), "bytes; reset counted/traffic", T["reset_counted"] / T["reset_traffic"],
+      "stamp amplification tiles", T["stamp_traffic"] / T["stamp_alg"], "rows", Rw["stamp_traffic"] / Rw["stamp_alg"])
