@@ -702,6 +702,24 @@ def main():
                 raise SystemExit("bench.py: a cfg4 tick failed on the device")
             s4.close()
             torch.cuda.empty_cache()
+            # ... and as a flight (one grid per agent is all a flight needs: configs[4] cannot hold a second)
+            f4 = driver.SwarmTick("cfg4", pop.config.AGENTS["cfg4"], 0, 1, local, moving_world=True, prestamp=False, grids=1,
+                                  tuning={"flight_qp_units": 3, "flight_search_units": 1, "flight_map_units": 6})
+            f4.compute.prepare(0, 16)
+            f4.fly(3)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            okf4, _ = f4.fly(10)
+            torch.cuda.synchronize()
+            dtf4 = time.perf_counter() - t1
+            _, h4 = f4.planner.flight_stats()
+            if h4[pop._abi.FLIGHT_HDR_ERR] != 0:
+                raise SystemExit(f"bench.py: the cfg4 flight failed on the device (code {h4[pop._abi.FLIGHT_HDR_ERR]})")
+            cfgs["cfg4"]["flight"] = {"replans_per_s": f4.A_tot * 10 / dtf4, "ms_per_step": dtf4 / 10 * 1e3,
+                                      "replans_ok_fraction": int(okf4.sum().item()) / float(f4.A_loc * 10),
+                                      "what": "sogm_flight_run, same scene and ticks (map kernel on 96 CUs, QP 48, search 16)"}
+            f4.close()
+            torch.cuda.empty_cache()
         except pop.SogmError as e:  # (e.g. HBM already held by another process: say so, do not invent a figure)
             cfgs["cfg4"] = {"error": str(e)[:300]}
         sys.path.insert(0, os.path.join(ROOT, "tools"))

@@ -56,4 +56,4 @@ if __name__ == "__main__":
     variants = sys.argv[2:] or [""]
     for v in variants:
         tuning = {k: float(x) for k, x in (kv.split("=") for kv in v.split(",") if kv)}
-        print("FLIGHT " + json.dumps(run(tuning, ticks)), flush=True)
+        print("FLIGHT " + json.dumps(run(tuning, ticks, grid=os.environ.get("GRID", "cfg2"))), flush=True)

@@ -33,7 +33,7 @@ if [ "$PART" = core ]; then
   SOGM_SPARSE_RESET=0 SOGM_TUNING=clear_early=1 timeout 200 rocprofv3 --pmc WRITE_SIZE -d /tmp/prof_cwrite -- python $REPO/tools/diag_clear_pmc.py > $OUT/clear_alone.txt 2> $OUT/cwrite.err
   cd $REPO
   python tools/rocprof_summary.py "$(db /tmp/prof_trace)" "$(db /tmp/prof_rfetch_tiled)" "$(db /tmp/prof_rwrite_tiled)" "$(db /tmp/prof_cfetch)" "$(db /tmp/prof_cwrite)" > $OUT/summary.md 2> $OUT/summary.err
-  python tools/rocprof_summary.py "$(db /tmp/prof_rfetch_rows)" "$(db /tmp/prof_rwrite_rows)" > $OUT/summary_rows.md 2>> $OUT/summary.err
+  python tools/rocprof_summary.py - "$(db /tmp/prof_rfetch_rows)" "$(db /tmp/prof_rwrite_rows)" > $OUT/summary_rows.md 2>> $OUT/summary.err
   timeout 300 python tools/bench_flight.py 20 "" "flight_pace_us=0" "flight_admit=128" > $OUT/flight.txt 2>&1
   timeout 200 python tools/diag_flight.py 20 > $OUT/flight_timeline.txt 2>&1
   timeout 200 python tools/diag_flow.py 12 > $OUT/flow.txt 2>&1

@@ -180,7 +180,9 @@ slowest agent, ms) rows {json.dumps({k: round(v, 2) for k, v in ((rows_d or {}).
 {((rows_d or {}).get('chain_ms') or {}).get('astar_mean', 0):.3f} vs {ch.get('astar_mean', 0):.3f} ms.  Flights: rows
 {(fl_rows[0]['ms_per_tick'] if fl_rows else 0):.2f} vs tiles {(fl_runs[0]['ms_per_tick'] if fl_runs else 0):.2f} ms per tick.
 The search's 5 x 5 window is nine 16-byte loads under tiles (3 x 3 tiles at one height) against five to ten row loads:
-no regression; the corridor box scan gets faster (whole tiles per line).
+the search and the corridor box scan cost the same under both orders (the grouped A* launch — its slowest agent — differs
+by run-to-run noise); the stamp's HBM writes drop by a quarter (the marks fall into ~half as many sectors; the log keeps
+some duplicate entries where a moving obstacle's future cells alternate between two tiles) and the reset's time halves.
 
 ## Variants on the same box
 

@@ -9,8 +9,23 @@ def short(name):
     return n[-60:]
 
 
+def pmc_only():
+    for pmc in sys.argv[2:]:
+        c2 = sqlite3.connect(pmc).cursor()
+        print(f"\n## PMC pass {pmc.split('/')[-1]} (separate run, --pmc only)\n")
+        print("| kernel | counter | dispatches | mean value (KB) | mean duration us |")
+        print("|---|---|---|---|---|")
+        q = ("select kernel_name, counter_name, count(*), avg(value), avg(duration)/1000.0 from counters_collection "
+             "where kernel_name like '%sogm::%' group by kernel_name, counter_name")
+        for kn, cn, n, v, d in c2.execute(q):
+            print(f"| {short(kn)} | {cn} | {n} | {v:.1f} | {d:.1f} |")
+
+
 def main():
     trace = sys.argv[1]
+    if trace == "-":  # PMC passes only
+        pmc_only()
+        return
     con = sqlite3.connect(trace)
     cur = con.cursor()
     print("## kernel-trace stats (rocprofv3 --kernel-trace --stats), durations in ms\n")
