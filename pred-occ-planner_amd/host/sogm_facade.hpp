@@ -174,6 +174,21 @@ class RiskMap {
     check(sogm_update_gt_swarm(ctx_, cloud_xyz, cloud_range, cyl, n_cyl, poses, stamps, records, n_records, ego_ids, st),
           "sogm_update_gt_swarm");
   }
+  // updateMap from one sensor frame (MapBase::cloudCallback -> updateMap with the states groundTruthStateCallback
+  // delivered, map.cpp:170-171, fake_particle_risk_voxel.cpp:244-264): the PassThrough crop (:88-104) runs on the device
+  // around each agent's map centre.  `bounds`: xy bounds of the cloud's blocks of `block_points` points — blockBounds()
+  // computes them on the device, once per frame.  records = nullptr: no overlay.
+  static void blockBounds(const float *cloud_xyz, int n_points, int block_points, float *bounds, hipStream_t st = nullptr) {
+    check(sogm_cloud_block_bounds(cloud_xyz, n_points, block_points, bounds, st), "sogm_cloud_block_bounds");
+  }
+  static SogmWorld world(const float *cloud_xyz, int n_points, const float *bounds, int block_points,
+                         const SogmCylinder *cyl, int n_cyl) {
+    return SogmWorld{cloud_xyz, bounds, cyl, n_points, (n_points + block_points - 1) / block_points, block_points, n_cyl};
+  }
+  void updateWorld(const SogmWorld &frame, const float *poses, const double *stamps, const SogmTrajRecord *records = nullptr,
+                   int n_records = 0, const int32_t *ego_ids = nullptr, hipStream_t st = nullptr) {
+    check(sogm_update_world(ctx_, &frame, poses, stamps, records, n_records, ego_ids, st), "sogm_update_world");
+  }
   // The update of a tick whose map the previous replan pre-stamped (Planner::setPrestamp): grid swap + overlay
   bool prestampPending() const { return sogm_prestamp_pending(ctx_) != 0; }
   void prestampJoin(void *stream = nullptr) { check(sogm_prestamp_join(ctx_, stream), "sogm_prestamp_join"); }
@@ -336,6 +351,16 @@ class Planner {
   }
   void setPrestamp(const SogmPrestamp *next_tick) {
     check(sogm_planner_set_prestamp(p_, next_tick), "sogm_planner_set_prestamp");
+  }
+  // n ticks of every agent in one call, every agent on its own clock (the reference's drones each run their own FSM,
+  // plan_manager.cpp:92-233): sogm_flight_run, see sogm_abi.h "Flight".  Returns the device's verdict after a
+  // synchronisation when `wait` is set: false = a device-side wait timed out (sogm_flight_stats hdr[4]).
+  bool flight(const SogmFlight &f, hipStream_t st = nullptr, bool wait = false) {
+    check(sogm_flight_run(p_, &f, st), "sogm_flight_run");
+    if (!wait) return true;
+    int32_t hdr[32];
+    check(sogm_flight_stats(p_, nullptr, hdr), "sogm_flight_stats");
+    return hdr[4] == 0;
   }
   // bool BaselinePlanner::replan(t, start_pos, start_vel, start_acc, goal_pos) — batched
   void replan(const double *start_pva, const double *goal, const double *t_start, const int32_t *drone_ids,

@@ -3,6 +3,7 @@
 // points, search, corridors, optimisation, replan — on a two-agent scene with one pillar between them.
 #include <cmath>
 #include <cstdio>
+#include <cstring>
 #include <vector>
 
 #include "sogm_facade.hpp"
@@ -107,6 +108,54 @@ int main() {
   REQUIRE(recordFromMsg(msg, back) && back.n_pieces == rec[0].n_pieces);
   // the second agent now sees the first one's trajectory in its map
   map.addOtherAgents(d_rec.data(), A, d_ids.data());
+  // ---- ABI version 5: per-update sensor frames and flights through the facade ----------------------------------------
+  static_assert(sizeof(SogmWorld) == 3 * sizeof(void *) + 4 * sizeof(int32_t), "SogmWorld layout (the Python binding mirrors it)");
+  static_assert(sizeof(SogmFlight) == 2 * 4 + 3 * 8 + 6 * sizeof(void *) + 2 * 4 + 2 * sizeof(void *), "SogmFlight layout");
+  REQUIRE(sogm_abi_version() == SOGM_ABI_VERSION);
+  {
+    // the same frame through sogm_update_world (device-side crop through the block index): same answers
+    RiskMap map2(spec, A);
+    map2.setCoordinator(body);
+    const int BP = 64, nb = (n_pts + BP - 1) / BP;
+    DevBuf<float> d_bounds((size_t)nb * 4);
+    RiskMap::blockBounds(d_cloud.data(), n_pts, BP, d_bounds.data());
+    const SogmWorld frame = RiskMap::world(d_cloud.data(), n_pts, d_bounds.data(), BP, d_cyl.data(), 1);
+    map2.updateWorld(frame, d_poses.data(), d_stamps.data());
+    REQUIRE(map2.getClearOcccupancy(0, {-0.45, 0.0, 1.0}, 0.0) == 1);
+    REQUIRE(map2.getClearOcccupancy(0, {-2.0, 1.5, 1.0}, 0.3) == 0);
+    std::vector<Vec3> pts2;
+    map2.getObstaclePoints(0, pts2, 100.0, 100.3, {-1.0, -1.0, 0.5}, {1.0, 1.0, 1.5});
+    REQUIRE(pts2.size() == pts.size());
+    for (size_t i = 0; i < pts.size(); ++i) REQUIRE(pts2[i] == pts[i]);
+    // a flight of four ticks: both agents cross the pillar's neighbourhood, every agent on its own clock
+    Planner planner2(map2, ap, pp, qs);
+    const int K = 4;
+    std::vector<SogmWorld> frames(K, frame);  // (a static world: the same frame for every tick)
+    const double hover0[18] = {-3, 0.1, 1, 0, 0, 0, 0, 0, 0, 3, -0.1, 1, 0, 0, 0, 0, 0, 0};
+    DevBuf<double> d_hover, d_goal3;
+    const double goal3[6] = {3, 0.1, 1, -3, -0.1, 1};
+    d_hover.put(hover0, 18); d_goal3.put(goal3, 6);
+    DevBuf<SogmTrajRecord> d_own(A), d_tables((size_t)4 * A), d_log((size_t)K * A);
+    DevBuf<int32_t> d_logok((size_t)K * A);
+    std::vector<SogmTrajRecord> zero((size_t)4 * A);
+    std::memset(zero.data(), 0, sizeof(SogmTrajRecord) * zero.size());
+    d_tables.put(zero.data(), zero.size()); d_own.put(zero.data(), A);
+    SogmFlight f{};
+    f.n_ticks = K; f.first_tick = 0; f.t0 = 100.0; f.period = 0.1; f.replan_start_offset = 0.02; f.worlds = frames.data();
+    f.goals = d_goal3.data(); f.drone_ids = d_ids.data(); f.hover_inout = d_hover.data(); f.own_inout = d_own.data();
+    f.tables = d_tables.data(); f.n_total = A; f.agent0 = 0; f.log_records = d_log.data(); f.log_ok = d_logok.data();
+    REQUIRE(planner2.flight(f, nullptr, /*wait*/ true));
+    std::vector<int32_t> lok((size_t)K * A);
+    std::vector<SogmTrajRecord> lrec((size_t)K * A);
+    d_logok.get(lok.data(), lok.size()); d_log.get(lrec.data(), lrec.size());
+    int n_ok = 0;
+    for (int i = 0; i < K * A; ++i) n_ok += lok[i];
+    REQUIRE(n_ok >= K);                                   // (replans succeed)
+    REQUIRE(lok[0] == 1 && lrec[0].n_pieces >= 1 && lrec[0].drone_id == 0);
+    REQUIRE(std::fabs(lrec[0].cpts[0] - (-3.0)) < 2e-3);  // tick 0 starts where the agent hovers
+    for (int k = 0; k < K; ++k) REQUIRE(lrec[(size_t)k * A + 1].drone_id == 1 && std::fabs(lrec[(size_t)k * A].time_start - (100.02 + 0.1 * k)) < 1e-9);
+    std::printf("flight through the facade: %d of %d agent-ticks ok\n", n_ok, K * A);
+  }
   std::printf("facade gpu ok: A* ret %d/%d, %d/%d pieces, QP status %d, %zu obstacle points\n", ret[0], ret[1], np[0], np[1],
               st[0], pts.size());
   return 0;
