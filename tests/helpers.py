@@ -28,6 +28,21 @@ def hard_cases(pop, A, seed, field=7.0):
     return sc, pva
 
 
+def pocket_cloud(pose, half_width, depth, back=0.6, step=0.1):
+    """Static wall points (no cylinder record: velocity zero) forming a U-shaped pocket that opens towards -x around `pose`:
+    a front wall at x = pose.x + depth and two side walls at y = pose.y +- half_width reaching back to x = pose.x - back,
+    floor to ceiling.  A search towards +x has to explore the pocket before it backs out: hundreds of expansions
+    (tests/golden/make_astar_fixture.py, tests/test_astar_independent.py)."""
+    zs = np.arange(0.05, 3.0, step)
+    ys = np.arange(-half_width, half_width + 1e-6, step)
+    xs = np.arange(-back, depth + 1e-6, step)
+    front = np.stack(np.meshgrid([depth], ys, zs, indexing="ij"), -1).reshape(-1, 3)
+    left = np.stack(np.meshgrid(xs, [-half_width], zs, indexing="ij"), -1).reshape(-1, 3)
+    right = np.stack(np.meshgrid(xs, [half_width], zs, indexing="ij"), -1).reshape(-1, 3)
+    pts = np.concatenate([front, left, right]) + np.asarray(pose, np.float64)[None, :] * np.array([1.0, 1.0, 0.0])
+    return pts.astype(np.float32)
+
+
 def oracle_grids(pop, orc, spec, sc, recs):
     cyl = pop.scene.cylinders_to_struct(sc["cylinders"])
     body = pop.scene.body_particles()
