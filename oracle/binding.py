@@ -209,6 +209,11 @@ def firi(bd, pc, a, b, iterations=2, max_faces=64, r=None):
     return (hp[:max(n, 0)].copy() if n <= max_faces else hp.copy()), n, r
 
 
+def lbfgs_set_max_iterations(k):
+    """test knob: lbfgs_parameter_t::max_iterations of the MVIE's optimiser (0 = the reference's unlimited default)"""
+    lib().orc_lbfgs_set_max_iterations(int(k))
+
+
 def mvie(hpoly, R, p, r):
     h = np.ascontiguousarray(hpoly, np.float64)
     R = np.ascontiguousarray(R, np.float64).copy()

@@ -165,6 +165,11 @@ int lineSearchLO(const MvieData &D, double x[9], double &f, double g[9], double 
   }
 }
 
+// lbfgs_parameter_t::max_iterations (lbfgs.hpp:68-74; firi.hpp leaves it at its default 0 = unlimited).  A TEST knob
+// (orc_lbfgs_set_max_iterations): with the iteration count capped, two readings of the optimiser can be compared after
+// 1, 2, 5 ... iterations, before rounding differences in the cost function have been amplified by the line searches.
+int g_lbfgs_max_iterations = 0;
+
 // lbfgs.hpp lbfgs_optimize with the parameters of firi.hpp:191-199
 int lbfgsMVIE(const MvieData &D, double x[9], double &fout) {
   const int    n = 9, m = 18, past = 3;
@@ -216,6 +221,10 @@ int lbfgsMVIE(const MvieData &D, double x[9], double &fout) {
         }
       }
       pf[k % past] = fx;
+      if (g_lbfgs_max_iterations != 0 && g_lbfgs_max_iterations <= k) {
+        ret = -8;  // LBFGSERR_MAXIMUMITERATION (lbfgs.hpp:597-602)
+        break;
+      }
       ++k;
       for (int i = 0; i < n; ++i) {
         lm_s[end][i] = x[i] - xp[i];
@@ -581,6 +590,8 @@ int orc_firi(const double *bd, int n_bd, const double *pc, int n_pc, const doubl
              const double b[3], int iterations, double *hpoly, int max_faces, double r[3]) {
   return firi(bd, n_bd, pc, n_pc, a, b, iterations, hpoly, max_faces, r);
 }
+
+void orc_lbfgs_set_max_iterations(int k) { g_lbfgs_max_iterations = k > 0 ? k : 0; }
 
 int orc_mvie(const double *hpoly, int m, double Rio[9], double p[3], double r[3]) {
   M3 R;
