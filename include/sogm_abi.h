@@ -247,6 +247,12 @@ int sogm_set_resample(sogm_ctx *ctx, float replan_risk_rate, int num_resample, c
  *     "flight_marks" (32), "flight_splat" (4); "flight_admit" (48) agents whose map may be under construction at once, "flight_pace_us" (40) microseconds between two
  *     admissions to the map stage (agents then reach every stage at a steady rate; 0 = unpaced), "flight_heads" (32)
  *     admitting waves of the map kernel.
+ *   sogm_update_world, experimental (measured, not adopted: profiles/EXPERIMENTS.md round 5):  "update_flow" (0; 1 = the
+ *     maps are built agent by agent on a stream of the context's own — one persistent launch over one-wave tickets, per
+ *     agent occupancy bits -> marks -> overlay, agents in the order of their previous chain's length — and sogm_replan's
+ *     searches start per agent as their map completes; every other reader of the grid joins the flow's end by itself;
+ *     identical cells and records), with "update_bits" (16), "update_marks" (64), "update_splat" (40) tickets per agent,
+ *     "update_wgs" (0 = 16 per CU), "update_chunk" (1) tickets per claim, "update_cached" (0), "update_order" (1).
  * Not thread-safe against calls on the same context (like every other call).  Unknown key: SOGM_ERR_INVALID_ARG.
  * sogm_tuning_key(i) enumerates the keys (NULL past the last). */
 int         sogm_set_tuning(sogm_ctx *ctx, const char *key, double value);

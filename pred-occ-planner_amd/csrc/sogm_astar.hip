@@ -1016,6 +1016,32 @@ __global__ __launch_bounds__(ASTAR_THREADS) void k_astar(
       fc.ts[agent * 8 + 0] = wall_clock64();
     }
   }
+  if (fc.map_ready) {
+    // update flow: this tick's maps are being built beside this launch, agent by agent — wait for this agent's (bounded
+    // like every wait of the tick: a flow that does not deliver fails the tick, code 16)
+    __shared__ int s_map_ok;
+    if (tid == 0) {
+      const long long t0 = wall_clock64();
+      int             ok = 0;
+      for (;;) {
+        if (__hip_atomic_load(fc.map_ready + agent, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == fc.map_epoch) {
+          ok = 1;
+          break;
+        }
+        if (__hip_atomic_load(&fc.hdr[FLOW_ERR], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+        if (wall_clock64() - t0 > FLOW_TIMEOUT_TICKS) {
+          atomicExch(&fc.hdr[FLOW_ERR], 16);
+          break;
+        }
+        __builtin_amdgcn_s_sleep(32);  // ~1 us: the wait is on the tick's critical path
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      s_map_ok = ok;
+      if (!second) fc.ts[agent * 8 + 0] = wall_clock64();  // the search starts now
+    }
+    __syncthreads();
+    if (!s_map_ok) return;
+  }
   const bool mine = astar_search_wg(m, ap, corridor_tau, wsp, start_pva, goal, t_start, out_ret, out_route, out_route_len,
                                     route_cap, out_stats, out_trace, trace_cap, agent, second, spec, 0,
                                     fc.hdr ? &fc.hdr[FLOW_ERR] : nullptr, search_mode);

@@ -451,7 +451,15 @@ __device__ inline void bezier_pos(const SogmTrajRecord &r, double t, double out[
   X(FLIGHT_SPLAT, "flight_splat", 4, 1, 64)                /* flight: ... neighbour overlay                                   */  \
   X(FLIGHT_ADMIT, "flight_admit", 48, 1, 65536)            /* flight: agents whose map may be under construction at once      */  \
   X(FLIGHT_PACE_US, "flight_pace_us", 40, 0, 100000)       /* flight: microseconds between two admissions to the map stage    */  \
-  X(FLIGHT_HEADS, "flight_heads", 32, 1, 4096)             /* flight: admitting waves of the map kernel                       */
+  X(FLIGHT_HEADS, "flight_heads", 32, 1, 4096)             /* flight: admitting waves of the map kernel                       */  \
+  X(UPDATE_FLOW, "update_flow", 0, 0, 1)                   /* sogm_update_world builds the maps agent by agent on a stream of its own; sogm_replan's searches start per agent */ \
+  X(UPDATE_BITS, "update_bits", 16, 1, 256)                /* update flow: one-wave tickets per agent, occupancy bits         */  \
+  X(UPDATE_MARKS, "update_marks", 64, 1, 256)              /* update flow: ... marks                                          */  \
+  X(UPDATE_SPLAT, "update_splat", 40, 1, 64)               /* update flow: ... neighbour overlay                              */  \
+  X(UPDATE_WGS, "update_wgs", 0, 0, 65536)                 /* update flow: one-wave workgroups; 0 = 16 per CU                 */  \
+  X(UPDATE_CHUNK, "update_chunk", 1, 1, 64)                /* update flow: consecutive tickets per claim                      */  \
+  X(UPDATE_CACHED, "update_cached", 0, 0, 1)               /* update flow: the marks' register-cached single-pass form        */  \
+  X(UPDATE_ORDER, "update_order", 1, 0, 1)                 /* update flow: agents in the order of their previous chain's length, longest first */
 enum {
 #define X(id, name, dflt, lo, hi) SOGM_TUNE_##id,
   SOGM_TUNING_TABLE(X)
@@ -567,6 +575,18 @@ struct sogm_ctx {
   // sogm_update_gt*, which discards the grid and clears the stamp's bitmask)
   volatile int         *ps_fail_host;
   int                   ps_fail_seen;
+  // update flow (tuning key update_flow): sogm_update_world leaves the caller's stream after the cull and builds the
+  // maps agent by agent on `ustream` (k_update_flow: tickets, per agent bits -> marks -> overlay); the agent's last ticket
+  // stores map_epoch into d_map_ready[agent].  sogm_replan's searches are launched beside it and wait per agent; every
+  // other reader or writer of the current grid joins the flow's end first (join_update).
+  hipStream_t    ustream;
+  hipEvent_t     ev_uin, ev_udone;
+  int            update_pending;
+  int            map_epoch;
+  int           *d_map_ready;      // [A]
+  int           *d_update_ctl;     // [8 + A]: {ticket, error, -...} + per-agent progress counters
+  long long     *d_update_ts;      // [A][4] diagnostics (sogm_debug_update_flow_times)
+  int           *d_update_order;   // [A] agents in the order the flow takes them (identity until a replan ranks them)
   double         tune[SOGM_TUNE_N];  // sogm_set_tuning; defaults from SOGM_TUNING_TABLE at sogm_create
   int            tune_i(int k) const { return (int)tune[k]; }
   int            profiling;   // bit k: slot k is timed (sogm_set_profiling: all, sogm_set_profiling_slots: a choice)
@@ -627,6 +647,14 @@ inline int join_prestamp(sogm_ctx *c, hipStream_t st) {
     c->pdone_pending = 0;
   }
   c->ps_stage = nullptr;
+  return SOGM_OK;
+}
+// the caller's stream waits for the end of an update flow still building the current grid
+inline int join_update(sogm_ctx *c, hipStream_t st) {
+  if (c->update_pending) {
+    if (hipStreamWaitEvent(st, c->ev_udone, 0) != hipSuccess) return SOGM_ERR_HIP;
+    c->update_pending = 0;
+  }
   return SOGM_OK;
 }
 inline int join_exchange(sogm_ctx *c, hipStream_t st) {

@@ -1799,6 +1799,7 @@ int sogm_dsp_publish(sogm_dsp *h, int32_t *out_n_occupied, void *stream) {
   sogm_ctx   *c  = h->map;
   hipStream_t st = (hipStream_t)stream;
   SOGM_HIP_CHECK(hipSetDevice(c->device));
+  if (int rc = sogm::join_update(c, st)) return rc;
   if (c->precleared) {  // a pending side-stream clear must not race the copy
     int rc = sogm::adopt_preclear(c, st);
     if (rc) return rc;

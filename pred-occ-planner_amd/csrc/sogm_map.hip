@@ -1789,8 +1789,7 @@ int world_blocks(sogm_ctx *c, const SogmWorld *w, CloudBlocks *out) {
     // (grown between ticks only: a frame with more blocks than any before; the old lists may still be read by a
     //  pre-stamp in flight, so everything drains first)
     SOGM_HIP_CHECK(hipDeviceSynchronize());
-    if (c->h_tick_clock) (void)hipHostFree(c->h_tick_clock);
-  if (c->d_blk_list) (void)hipFree(c->d_blk_list);
+    if (c->d_blk_list) (void)hipFree(c->d_blk_list);
     c->d_blk_list = nullptr;
     const int cap = (w->n_blocks + 1023) & ~1023;
     SOGM_HIP_CHECK(hipMalloc((void **)&c->d_blk_list, sizeof(int) * (size_t)cap * (size_t)c->n_agents));
@@ -2124,6 +2123,16 @@ void sogm_destroy(sogm_ctx *c) {
     (void)hipStreamSynchronize(c->pstream);
     (void)hipStreamDestroy(c->pstream);
   }
+  if (c->ustream) {
+    (void)hipStreamSynchronize(c->ustream);
+    (void)hipStreamDestroy(c->ustream);
+  }
+  if (c->ev_uin) (void)hipEventDestroy(c->ev_uin);
+  if (c->ev_udone) (void)hipEventDestroy(c->ev_udone);
+  if (c->d_map_ready) (void)hipFree(c->d_map_ready);
+  if (c->d_update_ctl) (void)hipFree(c->d_update_ctl);
+  if (c->d_update_order) (void)hipFree(c->d_update_order);
+  if (c->d_update_ts) (void)hipFree(c->d_update_ts);
   if (c->ev_side2_go) (void)hipEventDestroy(c->ev_side2_go);
   if (c->ev_side2_done) (void)hipEventDestroy(c->ev_side2_done);
   if (c->ev_grid_free) (void)hipEventDestroy(c->ev_grid_free);
@@ -2151,6 +2160,10 @@ int64_t sogm_grid_bytes(const sogm_ctx *c) {
 }
 float *sogm_grid_ptr(sogm_ctx *c) {
   if (!c) return nullptr;
+  if (c->update_pending) {  // an update flow still building this grid: the pointer is handed out complete
+    (void)hipStreamSynchronize(c->ustream);
+    c->update_pending = 0;
+  }
   c->tracked[sogm::cur_slot(c)] = 0;  // the caller may write cells the mark log does not see
   return c->d_grid;
 }
@@ -2297,11 +2310,42 @@ int sogm_map_traffic(sogm_ctx *c, int64_t *out, int reset) {
 int sogm_debug_copy_grid(sogm_ctx *c, int agent, void *dst_dev, void *stream) {
   if (!c || !dst_dev || agent < 0 || agent >= c->n_agents) return SOGM_ERR_INVALID_ARG;
   const size_t bytes = (size_t)c->spec.T * (size_t)c->geom.V * c->cell_bytes();
+  if (int rc = sogm::join_update(c, (hipStream_t)stream)) return rc;
   SOGM_HIP_CHECK(hipMemcpyAsync(dst_dev, (const char *)c->d_grid + (size_t)agent * bytes, bytes, hipMemcpyDeviceToDevice,
                                 (hipStream_t)stream));
   return SOGM_OK;
 }
 
+enum { UF_ERR = 1024, UF_STAGE = 2048, UF_STAGE_STRIDE = 32 };  // the update flow's control words (k_update_flow)
+// diagnostics (tools/ only): the update flow's control words after a device synchronisation —
+// out = {epoch, pending, ticket, error, ...ctl[2..7], stage[A], map_ready[A]}
+int sogm_debug_update_flow(sogm_ctx *c, int32_t *out, int cap) {
+  if (!c || !out || cap < 10 + 2 * c->n_agents) return SOGM_ERR_INVALID_ARG;
+  SOGM_HIP_CHECK(hipSetDevice(c->device));
+  (void)hipDeviceSynchronize();
+  const int A = c->n_agents;
+  out[0]      = c->map_epoch;
+  out[1]      = c->update_pending;
+  if (!c->d_update_ctl) return SOGM_ERR_STATE;
+  {
+    std::vector<int> w((size_t)(UF_STAGE + UF_STAGE_STRIDE * A));
+    SOGM_HIP_CHECK(hipMemcpy(w.data(), c->d_update_ctl, sizeof(int) * w.size(), hipMemcpyDeviceToHost));
+    out[2] = w[0];
+    out[3] = w[UF_ERR];
+    for (int a = 0; a < A; ++a) out[10 + a] = w[(size_t)(UF_STAGE + UF_STAGE_STRIDE * a)];
+  }
+  SOGM_HIP_CHECK(hipMemcpy(out + 10 + A, c->d_map_ready, sizeof(int) * A, hipMemcpyDeviceToHost));
+  return SOGM_OK;
+}
+// ... and its per-agent stamps [A][4] (100 MHz wall clock) + the order it took the agents in [A]
+int sogm_debug_update_flow_times(sogm_ctx *c, int64_t *out_ts, int32_t *out_order) {
+  if (!c || !out_ts || !out_order || !c->d_update_ts) return SOGM_ERR_INVALID_ARG;
+  SOGM_HIP_CHECK(hipSetDevice(c->device));
+  (void)hipDeviceSynchronize();
+  SOGM_HIP_CHECK(hipMemcpy(out_ts, c->d_update_ts, sizeof(long long) * 4 * c->n_agents, hipMemcpyDeviceToHost));
+  SOGM_HIP_CHECK(hipMemcpy(out_order, c->d_update_order, sizeof(int) * c->n_agents, hipMemcpyDeviceToHost));
+  return SOGM_OK;
+}
 int sogm_grid_history(sogm_ctx *c, int32_t *out) {
   if (!c || !out) return SOGM_ERR_INVALID_ARG;
   const int slot = sogm::cur_slot(c);
@@ -2315,6 +2359,10 @@ int sogm_grid_history(sogm_ctx *c, int32_t *out) {
 int sogm_set_overlap_clear(sogm_ctx *c, int mode) {
   if (!c || mode < 0 || mode > 3) return SOGM_ERR_INVALID_ARG;
   SOGM_HIP_CHECK(hipSetDevice(c->device));
+  if (c->update_pending) {
+    (void)hipDeviceSynchronize();
+    c->update_pending = 0;
+  }
   if (c->precleared || c->n_ready || c->n_dirty) {
     // pre-clears may be in flight: let them finish and forget them (the next update clears its grid itself)
     (void)hipDeviceSynchronize();
@@ -2442,6 +2490,117 @@ int sogm_set_body_particles(sogm_ctx *c, const double *xyz, int n) {
 
 static int clear_grid(sogm_ctx *c, hipStream_t st) { return sogm::reset_slot(c, st, sogm::cur_slot(c), c->d_grid, false); }
 
+// ---- update flow (tuning key update_flow): the maps of a lock-step tick agent by agent ----
+// One persistent launch of one-wave workgroups over tickets; an agent's tickets are consecutive (bits, marks, overlay) and
+// agents are taken in `order` (the previous tick's longest chains first), so the first agents' maps are complete after the
+// latency of ONE ticket chain instead of after four kernels over the whole swarm; the agent's last ticket stores the
+// epoch into map_ready[agent] (release), which sogm_replan's search workgroups wait for.  A ticket only ever waits for
+// tickets of its own agent, all of which are held by resident or earlier waves: no residency assumption beyond one agent's
+// worth of waves.  Same cells, same log as the four kernels (tests/test_update_flow_gpu.py).
+struct UpdateFlowDev {
+  void                 *grid;
+  unsigned             *bits;
+  int                   words;
+  const float          *cloud;
+  CloudBlocks           cb;
+  const SogmCylinder   *cyl;
+  int                   n_cyl;
+  const void           *cand;
+  const int            *n_cand;
+  MarkLog               lg;
+  const float          *poses;   // the context's copies (filed by k_cull_cylinders, the launch before)
+  const double         *stamps;
+  const SogmTrajRecord *rec;
+  int                   n_rec;
+  const int32_t        *ego_ids;
+  const double         *body;
+  int                   n_body;
+  int                   n_agents, n_bits, n_marks, n_splat;
+  int                  *ctl;      // ticket, error and per-agent progress words (UF_* below)
+  int                   chunk;    // consecutive tickets per claim
+  long long            *ts;       // [A][4] wall clock: first ticket claimed, bits complete, marks complete, map ready (diagnostics)
+  int                  *map_ready;
+  int                   epoch;
+  const int            *order;
+};
+// (no LDS: the replan's corridor workgroups, resident beside this kernel and waiting for routes, hold every CU's LDS)
+// Control words, each on a line of its own (thousands of waves claim tickets, bump and poll them — in one 128-byte line that
+// line's memory channel is the bottleneck, as the flight's header showed): ticket at ctl[0], error at ctl[UF_ERR], the
+// per-agent progress counters at ctl[UF_STAGE + 32 agent].
+extern "C++" {
+template <bool CACHED>
+__global__ __launch_bounds__(64) void k_update_flow(GridGeom g, UpdateFlowDev u) {
+  const int lane  = threadIdx.x;
+  const int per   = u.n_bits + u.n_marks + u.n_splat;
+  const int total = u.n_agents * per;
+  int      *err   = u.ctl + UF_ERR;
+  for (;;) {
+    int t0 = 0;
+    if (lane == 0) t0 = atomicAdd(&u.ctl[0], u.chunk);  // a chunk of consecutive tickets per claim
+    t0 = __builtin_amdgcn_readfirstlane(t0);
+    if (t0 >= total) break;
+    for (int t = t0; t < t0 + u.chunk && t < total; ++t) {
+      const int agent = u.order[t / per];
+      const int s     = t % per;
+      int      *stage = u.ctl + UF_STAGE + UF_STAGE_STRIDE * agent;
+      bool      last  = false;
+      if (s == 0 && lane == 0) u.ts[agent * 4] = wall_clock64();
+      if (s < u.n_bits) {
+        stamp_bits_blocks(g, u.cloud, u.cb, agent, s, u.n_bits, u.poses[agent * 3], u.poses[agent * 3 + 1],
+                          u.poses[agent * 3 + 2], u.bits + (size_t)agent * u.words, lane);
+        __threadfence();
+        if (lane == 0 && atomicAdd(stage, 1) + 1 == u.n_bits) u.ts[agent * 4 + 1] = wall_clock64();
+      } else if (s < u.n_bits + u.n_marks) {
+        if (flow_wait_count(stage, u.n_bits, err)) return;
+        stamp_marks_trips<CACHED>(g, u.grid, u.bits, u.words, u.cyl, u.n_cyl, u.poses, (const CylCand *)u.cand, u.n_cand,
+                                  agent, u.lg, (s - u.n_bits) * 256, u.n_marks * 256);
+        __threadfence();
+        if (lane == 0) {
+          const int n = atomicAdd(stage, 1) + 1;
+          last        = n == per;
+          if (n == u.n_bits + u.n_marks) u.ts[agent * 4 + 2] = wall_clock64();
+        }
+      } else {
+        if (flow_wait_count(stage, u.n_bits + u.n_marks, err)) return;  // stores of 1.0 first, the additions after them
+        const int n = u.n_rec * g.T;
+        for (int i = (s - u.n_bits - u.n_marks) * 64 + lane; i < n; i += u.n_splat * 64)
+          splat_item(g, u.grid, u.rec[i / g.T], agent, i % g.T, u.ego_ids, u.poses, u.stamps, u.body, u.n_body, u.lg);
+        __threadfence();
+        if (lane == 0) last = atomicAdd(stage, 1) + 1 == per;
+      }
+      if (last) {
+        u.ts[agent * 4 + 3] = wall_clock64();
+        __hip_atomic_store(&u.map_ready[agent], u.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
+}
+}  // extern "C++"
+__global__ void k_iota(int *p, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = i;
+}
+namespace sogm {
+// stream, events and words of the update flow (first use)
+static int update_flow_setup(sogm_ctx *c) {
+  if (c->ustream) return SOGM_OK;
+  const int A = c->n_agents;
+  SOGM_HIP_CHECK(sogm::create_stream_partitioned(&c->ustream, 0));
+  SOGM_HIP_CHECK(hipEventCreateWithFlags(&c->ev_uin, hipEventDisableTiming));
+  SOGM_HIP_CHECK(hipEventCreateWithFlags(&c->ev_udone, hipEventDisableTiming));
+  SOGM_HIP_CHECK(hipMalloc((void **)&c->d_map_ready, sizeof(int) * A));
+  SOGM_HIP_CHECK(hipMalloc((void **)&c->d_update_ctl, sizeof(int) * (size_t)(UF_STAGE + UF_STAGE_STRIDE * A)));
+  SOGM_HIP_CHECK(hipMalloc((void **)&c->d_update_order, sizeof(int) * A));
+  SOGM_HIP_CHECK(hipMalloc((void **)&c->d_update_ts, sizeof(long long) * 4 * A));
+  SOGM_HIP_CHECK(hipMemset(c->d_update_ts, 0, sizeof(long long) * 4 * A));
+  SOGM_HIP_CHECK(hipMemset(c->d_map_ready, 0, sizeof(int) * A));
+  hipLaunchKernelGGL(k_iota, dim3((A + 255) / 256), dim3(256), 0, nullptr, c->d_update_order, A);
+  SOGM_HIP_CHECK(hipGetLastError());
+  SOGM_HIP_CHECK(hipStreamSynchronize(nullptr));  // (null-stream work is not ordered with the non-blocking streams)
+  return SOGM_OK;
+}
+}  // namespace sogm
+
 // updateMap for every agent; with `records` (sogm_update_gt_swarm) the neighbour overlay follows in the same call
 static int update_gt_impl(sogm_ctx *c, const float *cloud_xyz, const int32_t *cloud_range,
                           const SogmCylinder *cylinders, int n_cyl, const float *poses, const double *stamps,
@@ -2452,6 +2611,7 @@ static int update_gt_impl(sogm_ctx *c, const float *cloud_xyz, const int32_t *cl
   if (world)
     if (int rc = sogm::world_blocks(c, world, &cb)) return rc;
   const int A = c->n_agents;
+  if (int rc = sogm::join_update(c, st)) return rc;    // an update flow of the previous tick nobody joined
   if (int rc = sogm::join_prestamp(c, st)) return rc;  // a pre-stamp of the last replan may still be running
   if (fused)
     if (int rc = sogm::join_exchange(c, st)) return rc;  // records may come from an all-gather in flight
@@ -2497,6 +2657,57 @@ static int update_gt_impl(sogm_ctx *c, const float *cloud_xyz, const int32_t *cl
   prof_begin(c, SOGM_PROF_STAMP, st);
   hipLaunchKernelGGL(k_cull_cylinders, dim3(A), dim3(64), 0, st, c->geom, cylinders, n_cyl, poses,
                      (CylCand *)c->d_cand, c->d_ncand, stamps, c->d_poses, c->d_stamps, cb, c->h_tick_clock);
+  if (world && c->tune_i(SOGM_TUNE_UPDATE_FLOW) != 0) {
+    // the maps agent by agent on the flow's stream; the caller's stream goes on (sogm_replan's searches wait per agent,
+    // everything else joins the flow's end: sogm::join_update)
+    if (int rc = sogm::update_flow_setup(c)) return rc;
+    UpdateFlowDev u{};
+    u.grid    = (void *)c->d_grid;
+    u.bits    = c->d_stamp_bits;
+    u.words   = words;
+    u.cloud   = cloud_xyz;
+    u.cb      = cb;
+    u.cyl     = cylinders;
+    u.n_cyl   = n_cyl;
+    u.cand    = c->d_cand;
+    u.n_cand  = c->d_ncand;
+    u.lg      = sogm::mark_log(c, sogm::cur_slot(c));
+    u.poses   = c->d_poses;
+    u.stamps  = c->d_stamps;
+    u.rec     = records;
+    u.n_rec   = fused ? n_records : 0;
+    u.ego_ids = ego_ids;
+    u.body    = c->d_body;
+    u.n_body  = c->n_body;
+    u.n_agents = A;
+    u.n_bits   = c->tune_i(SOGM_TUNE_UPDATE_BITS);
+    u.n_marks  = c->tune_i(SOGM_TUNE_UPDATE_MARKS);
+    u.n_splat  = u.n_rec > 0 ? c->tune_i(SOGM_TUNE_UPDATE_SPLAT) : 0;
+    u.ctl      = c->d_update_ctl;
+    u.ts       = c->d_update_ts;
+    u.chunk    = c->tune_i(SOGM_TUNE_UPDATE_CHUNK) > 0 ? c->tune_i(SOGM_TUNE_UPDATE_CHUNK) : 1;
+    u.map_ready = c->d_map_ready;
+    u.epoch     = ++c->map_epoch;
+    u.order     = c->d_update_order;
+    int n_cu = 256;
+    (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->device);
+    int wgs = c->tune_i(SOGM_TUNE_UPDATE_WGS) > 0 ? c->tune_i(SOGM_TUNE_UPDATE_WGS) : 16 * n_cu;
+    const int total = A * (u.n_bits + u.n_marks + u.n_splat);
+    if (wgs > total) wgs = total;
+    SOGM_HIP_CHECK(hipEventRecord(c->ev_uin, st));
+    SOGM_HIP_CHECK(hipStreamWaitEvent(c->ustream, c->ev_uin, 0));
+    SOGM_HIP_CHECK(hipMemsetAsync(c->d_update_ctl, 0, sizeof(int) * (size_t)(UF_STAGE + UF_STAGE_STRIDE * A), c->ustream));
+    if (c->tune_i(SOGM_TUNE_UPDATE_CACHED))
+      hipLaunchKernelGGL(k_update_flow<true>, dim3(wgs), dim3(64), 0, c->ustream, c->geom, u);
+    else
+      hipLaunchKernelGGL(k_update_flow<false>, dim3(wgs), dim3(64), 0, c->ustream, c->geom, u);
+    SOGM_HIP_CHECK(hipGetLastError());
+    prof_end(c, SOGM_PROF_STAMP, c->ustream);
+    SOGM_HIP_CHECK(hipEventRecord(c->ev_udone, c->ustream));
+    c->update_pending = 1;
+    c->updated        = 1;
+    return SOGM_OK;
+  }
   if (world)
     hipLaunchKernelGGL(k_stamp_bits_blocks, dim3(stamp_wgs, A), dim3(64), 0, st, c->geom, cloud_xyz, cb, c->d_poses,
                        c->d_stamp_bits, words);
@@ -2602,6 +2813,7 @@ int sogm_update_prestamped(sogm_ctx *c, const SogmTrajRecord *records, int n_rec
   }
   SOGM_HIP_CHECK(hipSetDevice(c->device));
   hipStream_t st = (hipStream_t)stream;
+  if (int rc = sogm::join_update(c, st)) return rc;
   if (n_records > 0)
     if (int rc = sogm::join_exchange(c, st)) return rc;  // records may come from an all-gather in flight
   if (int rc = sogm::adopt_preclear(c, st, false)) return rc;  // the pre-stamped grid becomes the current one
@@ -2651,6 +2863,7 @@ int sogm_project_neighbours(sogm_ctx *c, const SogmTrajRecord *records, int n_re
   if (!c->d_body || c->n_body <= 0) return SOGM_ERR_STATE;
   if (n_records == 0) return SOGM_OK;
   SOGM_HIP_CHECK(hipSetDevice(c->device));
+  if (int rc = sogm::join_update(c, (hipStream_t)stream)) return rc;
   if (int rc = sogm::join_exchange(c, (hipStream_t)stream)) return rc;  // records may come from an all-gather in flight
   const long long total = (long long)c->n_agents * n_records * c->spec.T;
   const int       nblk  = (int)((total + 255) / 256);
@@ -2668,6 +2881,7 @@ int sogm_set_future_risk(sogm_ctx *c, const float *grid_vt, const float *poses,
   if (!c || !grid_vt || !poses || !stamps) return SOGM_ERR_INVALID_ARG;
   SOGM_HIP_CHECK(hipSetDevice(c->device));
   hipStream_t st = (hipStream_t)stream;
+  if (int rc = sogm::join_update(c, st)) return rc;
   SOGM_HIP_CHECK(hipMemcpyAsync(c->d_poses, poses, sizeof(float) * 3 * c->n_agents,
                                 hipMemcpyDeviceToDevice, st));
   SOGM_HIP_CHECK(hipMemcpyAsync(c->d_stamps, stamps, sizeof(double) * c->n_agents,
@@ -2754,6 +2968,7 @@ int sogm_traj_safe(sogm_ctx *c, const SogmTrajRecord *records, const double *t_n
   if (!c || !records || !t_now || !out_safe) return SOGM_ERR_INVALID_ARG;
   if (!c->updated) return SOGM_ERR_STATE;
   SOGM_HIP_CHECK(hipSetDevice(c->device));
+  if (int rc = sogm::join_update(c, (hipStream_t)stream)) return rc;
   hipLaunchKernelGGL(k_traj_safe, dim3((c->n_agents + 63) / 64), dim3(64), 0, (hipStream_t)stream, view_of(c),
                      records, t_now, check_duration, out_safe);
   SOGM_HIP_CHECK(hipGetLastError());
@@ -2766,6 +2981,7 @@ int sogm_query_clear(sogm_ctx *c, const int32_t *agent_idx, const double *pos_xy
   if (!c->updated) return SOGM_ERR_STATE;
   if (n_q == 0) return SOGM_OK;
   SOGM_HIP_CHECK(hipSetDevice(c->device));
+  if (int rc = sogm::join_update(c, (hipStream_t)stream)) return rc;
   hipLaunchKernelGGL(k_query_clear, dim3((n_q + 255) / 256), dim3(256), 0, (hipStream_t)stream,
                      view_of(c), agent_idx, pos_xyz, t, t_is_index, n_q, out);
   SOGM_HIP_CHECK(hipGetLastError());
@@ -2781,6 +2997,7 @@ int sogm_obstacle_points(sogm_ctx *c, const int32_t *agent_idx, const double *bo
   if (!c->updated) return SOGM_ERR_STATE;
   if (n_b == 0) return SOGM_OK;
   SOGM_HIP_CHECK(hipSetDevice(c->device));
+  if (int rc = sogm::join_update(c, (hipStream_t)stream)) return rc;
   hipLaunchKernelGGL(k_obstacle_points, dim3(n_b), dim3(256), 0, (hipStream_t)stream, view_of(c),
                      agent_idx, box_lo, box_hi, t0, t1, out_pts, out_counts, cap);
   SOGM_HIP_CHECK(hipGetLastError());

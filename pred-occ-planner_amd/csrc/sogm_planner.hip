@@ -335,6 +335,7 @@ int sogm_astar_search(sogm_planner *p, const double *start_pva, const double *go
   if (!p->map->updated) return SOGM_ERR_STATE;
   SOGM_HIP_CHECK(hipSetDevice(p->map->device));
   hipStream_t st = (hipStream_t)stream;
+  if (int rc0 = sogm::join_update(p->map, st)) return rc0;
   prof_begin(p->map, SOGM_PROF_ASTAR, st);
   int rc = launch_astar(view_of(p->map), p->ap, p->pp.corridor_tau, astar_ws(p), p->sel_count,
                         start_pva, goal, t_start, out_ret, out_route, out_route_len, route_cap,
@@ -356,6 +357,7 @@ int sogm_corridor_generate(sogm_planner *p, const double *start_pva, const doubl
   if (!p->map->updated) return SOGM_ERR_STATE;
   SOGM_HIP_CHECK(hipSetDevice(p->map->device));
   hipStream_t st = (hipStream_t)stream;
+  if (int rc0 = sogm::join_update(p->map, st)) return rc0;
   prof_begin(p->map, SOGM_PROF_CORRIDOR, st);
   int rc = launch_corridor(view_of(p->map), p->pp, p->cw, p->sel_count, start_pva, t_start,
                            route, route_len, route_cap, out_polys, out_nfaces, out_npoly, out_goal,
@@ -628,6 +630,24 @@ __global__ __launch_bounds__(256) void k_flow_reset(int *hdr, int n_hdr, int *re
   for (int i = i0; i < n_rec; i += step) records[i] = 0;
 }
 
+// order[rank] = agent, rank = the number of agents whose chain of this tick (search start -> finished) was longer (ties:
+// lower index first); by == 0: identity
+__global__ void k_update_rank(const long long *__restrict__ ts, int *__restrict__ order, int n, int by) {
+  for (int a = threadIdx.x; a < n; a += blockDim.x) {
+    if (!by) {
+      order[a] = a;
+      continue;
+    }
+    const long long da = ts[a * 8 + 6] - ts[a * 8 + 0];
+    int             r  = 0;
+    for (int b = 0; b < n; ++b) {
+      const long long db = ts[b * 8 + 6] - ts[b * 8 + 0];
+      r += (db > da || (db == da && b < a)) ? 1 : 0;
+    }
+    order[r] = a;
+  }
+}
+
 static int replan_flow(sogm_planner *p, const double *start_pva, const double *goal, const double *t_start,
                        const int32_t *drone_ids, SogmTrajRecord *out_records, int32_t *out_ok, void *stream) {
   sogm_ctx     *c    = p->map;
@@ -653,8 +673,13 @@ static int replan_flow(sogm_planner *p, const double *start_pva, const double *g
   SOGM_HIP_CHECK(hipEventRecord(p->ev_in, main));
   for (int k = 0; k < 4; ++k) SOGM_HIP_CHECK(hipStreamWaitEvent(p->fstream[k], p->ev_in, 0));
   prof_begin(c, SOGM_PROF_ASTAR, sA);
+  // an update flow still building this tick's maps (sogm_update_world with update_flow): the searches are launched beside
+  // it and every search workgroup waits for ITS agent's map; the caller's stream joins the flow's end at the fan-in
+  sogm::FlowCtl fca = p->fc;
+  fca.map_ready = c->update_pending ? c->d_map_ready : nullptr;
+  fca.map_epoch = c->map_epoch;
   if (launch_astar(mv, p->ap, p->pp.corridor_tau, astar_ws(p), A, start_pva, goal, t_start, p->d_ret, p->d_route,
-                   p->d_route_len, p->route_cap, p->d_stats, nullptr, 0, sA, 0, &p->fc, spec ? 8 : 0)) {
+                   p->d_route_len, p->route_cap, p->d_stats, nullptr, 0, sA, 0, &fca, spec ? 8 : 0)) {
     sogm::set_error("sogm_replan: k_astar", hipGetLastError());
     return SOGM_ERR_HIP;
   }
@@ -682,6 +707,9 @@ static int replan_flow(sogm_planner *p, const double *start_pva, const double *g
     return SOGM_ERR_HIP;
   }
   prof_end(c, SOGM_PROF_CORRIDOR, sC);
+  // (a QP workgroup takes a whole CU — registers and LDS — from the moment it is resident, and the first corridors are
+  //  final long after an update flow has ended: the QP kernel is dispatched behind the flow's end, not beside it)
+  if (c->update_pending) SOGM_HIP_CHECK(hipStreamWaitEvent(sQ, c->ev_udone, 0));
   prof_begin(c, SOGM_PROF_QP, sQ);
   if (sogm::launch_qp_flow(p->pp, p->qs, p->qw, p->qc, p->fc, A, wg_q, start_pva, p->d_goal, p->d_polys, p->d_nfaces,
                            p->d_npoly, p->d_cpts, p->d_status, p->d_iters, sQ)) {
@@ -788,6 +816,13 @@ static int replan_flow(sogm_planner *p, const double *start_pva, const double *g
     SOGM_HIP_CHECK(hipEventRecord(p->ev_fdone[k], p->fstream[k]));
     SOGM_HIP_CHECK(hipStreamWaitEvent(main, p->ev_fdone[k], 0));  // fan in
   }
+  if (int rc = sogm::join_update(c, main)) return rc;  // (complete long ago: every search waited for its agent's map)
+  if (c->d_update_order && c->tune_i(SOGM_TUNE_UPDATE_FLOW) != 0) {
+    // the next update flow takes the agents in the order of this tick's chain lengths, longest first (a schedule only)
+    hipLaunchKernelGGL(k_update_rank, dim3(1), dim3(256), 0, main, (const long long *)p->fc.ts, c->d_update_order, A,
+                       c->tune_i(SOGM_TUNE_UPDATE_ORDER));
+    SOGM_HIP_CHECK(hipGetLastError());
+  }
   bool reported = false;
   if (c->prestamp_slot >= 0) {
     // the tick's report behind the pre-stamp on ITS stream (the last kernel of the tick to end), so that the caller's
@@ -835,6 +870,7 @@ static int replan_impl(sogm_planner *p, const double *start_pva, const double *g
   hipStream_t main = (hipStream_t)stream;
   const int   A = c->n_agents, G = p->n_groups;
   const MapView mv = view_of(c);
+  if (int rc = sogm::join_update(c, main)) return rc;
   for (int g = 0; g < G; ++g)
     if (!p->gstream[g]) SOGM_HIP_CHECK(sogm::create_stream_partitioned(&p->gstream[g], 1));
   // the swarm's records (deconfliction) may come from an all-gather still in flight on the exchange stream
@@ -1048,6 +1084,7 @@ int sogm_flight_run(sogm_planner *p, const SogmFlight *f, void *stream) {
   if (!p->flow || !c->sparse || !c->d_body || c->n_body <= 0) return SOGM_ERR_STATE;
   SOGM_HIP_CHECK(hipSetDevice(c->device));
   hipStream_t main = (hipStream_t)stream;
+  if (int rc = sogm::join_update(c, main)) return rc;
   if (int rc = sogm::join_prestamp(c, main)) return rc;
   if (int rc = sogm::join_exchange(c, main)) return rc;
   if (int rc = flight_setup(p)) return rc;

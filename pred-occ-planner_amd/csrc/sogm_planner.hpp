@@ -66,6 +66,8 @@ struct FlowCtl {
                   //        (diagnostics, always written)
   int *p_ready;   // [A] agents in publication order (null: nobody consumes it)
   int *stage;     // [A]
+  const int *map_ready;  // [A] update flow: the agent's map is complete when this holds map_epoch (null: it is already)
+  int        map_epoch;
 };
 #ifdef __HIPCC__
 // hand-over primitives of the persistent kernels: a ticket per wave, a bounded wait for a published slot

@@ -1,22 +1,23 @@
-"""Timeline of one tick from a rocprofv3 kernel trace (rocpd .db): start offset / duration of every SOGM kernel."""
-import glob, sqlite3, sys
-db = glob.glob(sys.argv[1] + "/**/*.db", recursive=True)[0]
-cur = sqlite3.connect(db).cursor()
-rows = cur.execute("select name, start, end from kernels order by start").fetchall()
-# a tick starts at each k_stamp_cloud
-mark = "k_tick_inputs" if any("k_tick_inputs" in r[0] for r in rows) else "k_stamp_cloud"
-if any("k_prestamp_flow" in r[0] for r in rows):  # pre-stamped ticks have no k_tick_inputs: a tick = replan to replan
-    mark = "k_flow_reset"
-stamps = [i for i, r in enumerate(rows) if mark in r[0]]
-k = len(stamps) // 2  # a tick from the middle of the timed region (the run ends with stage-pass updates)
-a, b = stamps[k], stamps[k + 1]
-t0 = rows[a][1]
-print(f"tick length {(rows[b][1] - t0) / 1e6:.2f} ms")
-show_all = len(sys.argv) > 2 and sys.argv[2] == "--all"  # every kernel, incl. the host framework's small ones
-for name, s, e in rows[a:b]:
-    n = name.split("(")[0].split("::")[-1][:28]
-    if show_all:
-        n = name.replace("void ", "")[:60]
-        print(f"{n:60s} start {(s - t0) / 1e6:7.3f}  dur {(e - s) / 1e6:7.3f}  end {(e - t0) / 1e6:7.3f}")
-    elif (e - s) > 150e3 or "k_" in n:
-        print(f"{n:28s} start {(s - t0) / 1e6:7.2f}  dur {(e - s) / 1e6:7.2f}  end {(e - t0) / 1e6:7.2f}")
+#!/usr/bin/env python
+"""Kernel timeline of the last lock-step ticks in a rocprofv3 --kernel-trace database: every kernel between two
+k_cull_cylinders launches (the update's first kernel), start and end in ms after that launch's start.
+    python tools/tick_timeline.py <results.db> [ticks from the end, default 2]"""
+import sqlite3
+import sys
+
+con = sqlite3.connect(sys.argv[1])
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+cols = [d[0] for d in con.execute("select * from kernels limit 1").description]
+q = "queue_id" if "queue_id" in cols else ("stream_id" if "stream_id" in cols else "0")
+rows = con.execute(f"select name, start, end, {q}, vgpr_count, accum_vgpr_count, lds_size, grid_x * grid_y * grid_z / (workgroup_x * workgroup_y * workgroup_z), workgroup_x from kernels order by start").fetchall()
+culls = [i for i, r in enumerate(rows) if r[0].startswith("k_cull_cylinders")]
+for j in range(max(0, len(culls) - n - 1), len(culls) - 1):
+    i0, i1 = culls[j], culls[j + 1]
+    t0 = rows[i0][1]
+    # kernels launched shortly before the cull belong to the tick too (sogm_tick_inputs)
+    k = i0
+    while k > 0 and t0 - rows[k - 1][1] < 100000:
+        k -= 1
+    print(f"--- tick starting at kernel {i0}: {(rows[i1][1] - t0) / 1e6:.3f} ms until the next update")
+    for name, s, e, qq, vg, ag, lds, wgs, wx in rows[k:i1]:
+        print(f"  {(s - t0) / 1e6:8.3f} -> {(e - t0) / 1e6:8.3f}  ({(e - s) / 1e3:8.1f} us)  q{qq}  {wgs:6d} x {wx:4d}  vgpr {vg}+{ag} lds {lds:6d}  {name[:60]}")
