@@ -429,6 +429,7 @@ __device__ inline void bezier_pos(const SogmTrajRecord &r, double t, double out[
   X(RESET_UNROLL, "reset_unroll", 0, 0, 8)       /* sparse reset: 1 / 8 entries per trip; 0 = 1 under the replan, 8 alone */  \
   X(RESET_LATE, "reset_late", 1, 0, 1)           /* sparse reset: held back until every agent's corridors are final       */  \
   X(STAMP_WGS, "stamp_wgs", 256, 0, 4096)           /* stamp: one-wave workgroups per agent                                  */  \
+  X(STAMP_BITS_WGS, "stamp_bits_wgs", 0, 0, 4096)   /* stamp: one-wave workgroups per agent of the occupancy-bits pass; 0 = stamp_wgs */  \
   X(STAMP_LDS_KB, "stamp_lds_kb", 0, 0, 64)              /* stamp: unused dynamic LDS per marks workgroup (bounds waves per CU) */  \
   X(SPLAT_WGS, "splat_wgs", 256, 0, 65536)           /* overlay launched under a pre-stamp's tail: workgroups                 */  \
   X(SPLAT_OVERLAP, "splat_overlap", 1, 0, 1)     /* 0: sogm_replan joins the pre-stamp's end itself                       */  \
