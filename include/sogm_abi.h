@@ -233,7 +233,7 @@ int sogm_set_resample(sogm_ctx *ctx, float replan_risk_rate, int num_resample, c
  * SOGM_SPARSE_RESET, SOGM_FLOW and SOGM_RCCL_LIB).  Keys (defaults in parentheses):
  *   read by sogm_planner_create (set them before):  "groups" (2) agent groups of the grouped-stream replan,
  *     "spec_astar" (1) speculative second search, "clear_gate_frac" (1.0);
- *   read at every call:  "qp_wgs" (0 = half the CUs) persistent QP workgroups, "stamp_wgs" (256), "stamp_bits_wgs" (0 = stamp_wgs), "stamp_lds_kb" (0), "splat_wgs" (256),
+ *   read at every call:  "qp_wgs" (0 = half the CUs) persistent QP workgroups, "stamp_wgs" (256), "stamp_bits_wgs" (0 = stamp_wgs), "stamp_cached" (0), "stamp_lds_log" (1), "stamp_lds_kb" (0), "splat_wgs" (256),
  *     "splat_overlap" (1), "reset_wgs" (32), "reset_lanes" (0 = auto: 2 under the replan, 4 alone), "reset_unroll"
  *     (0 = auto: 1 / 8), "reset_late" (1), "prestamp_bits" (32), "prestamp_marks" (64), "prestamp_wgs" (0 = 8 per CU), "prestamp_stream" (1), "prestamp_gate_frac" (0.9: the pre-stamp of the next map starts when that share of the agents' corridors is final — an event recorded behind a gate kernel on the resets' stream; 1.0: when all are),
  *     "prestamp_late_agents" (8), "prestamp_late_bits" (128), "prestamp_late_marks" (256), and the dense clear's

@@ -39,6 +39,22 @@ struct GridGeom {
   int          rs_n;     // swarm/num_resample
   const float *rs_z;     // injected standard-normal table, device
   int          rs_nz;
+  // a / res, correctly rounded.  The compiler's IEEE fp32 division is a dozen instructions (scaling, reciprocal iterations,
+  // fix-up, two mode switches) and the stamp computes two or three per mark, the search three per query.  For the one
+  // resolution the reference ships (VOXEL_RESOLUTION 0.15, a compile-time constant of map_parameters.h) the three-instruction
+  // sequence q0 = a * RN(1/res), e = fma(-res, q0, a) (exact), q = fma(e, RN(1/res), q0) gives RN(a / res) for EVERY
+  // float a with |a| in [2^-20, 64] (checked exhaustively, tests/test_fast_division.py; below that both truncate to 0):
+  // used for that resolution and that range only, the true division everywhere else.
+  float inv_res;
+  int   fast_div;
+  __host__ __device__ inline float div_res(float a) const {
+    if (fast_div && fabsf(a) < 64.0F) {
+      const float q0 = a * inv_res;
+      const float e  = fmaf(-res, q0, a);
+      return fmaf(e, inv_res, q0);
+    }
+    return a / res;
+  }
 
   // map.h:153-157 — strict inequalities
   __host__ __device__ inline bool in_range(float x, float y, float z) const {
@@ -50,9 +66,9 @@ struct GridGeom {
   }
   // map.h:169-174 — fp32 add, fp32 divide, truncation
   __host__ __device__ inline int voxel_of(float x, float y, float z) const {
-    const int ix = (int)((x + rx) / res);
-    const int iy = (int)((y + ry) / res);
-    const int iz = (int)((z + rz) / res);
+    const int ix = (int)div_res(x + rx);
+    const int iy = (int)div_res(y + ry);
+    const int iz = (int)div_res(z + rz);
     return iz * L * W + iy * L + ix;
   }
   // Where cell (x, y, z) of a slice lives.  Rows (tile = 0): z L W + y L + x, x fastest — a 32-byte sector is 8 cells of
@@ -68,9 +84,12 @@ struct GridGeom {
   // index leaves the array (the reference's out-of-bounds case: a coordinate one ulp below +range).  No integer division
   // on the common path.
   __host__ __device__ inline int cell_of(float x, float y, float z) const {
-    const int ix = (int)((x + rx) / res);
-    const int iy = (int)((y + ry) / res);
-    const int iz = (int)((z + rz) / res);
+    return cell_of_xy(x, y, (int)div_res(z + rz));
+  }
+  // ... with the z index computed by the caller (the stamp's future marks keep their voxel's z: once per voxel)
+  __host__ __device__ inline int cell_of_xy(float x, float y, int iz) const {
+    const int ix = (int)div_res(x + rx);
+    const int iy = (int)div_res(y + ry);
     if (tile && ix < L && iy < W && iz < H) return phys(ix, iy, iz);
     const int v = iz * L * W + iy * L + ix;  // (rows; or an index component equal to its axis size: wraps like the reference's)
     return v < V ? phys_of(v) : V;
@@ -127,6 +146,8 @@ inline GridGeom make_geom(const SogmSpec &s) {
   g.rs_n           = 0;
   g.rs_z           = nullptr;
   g.rs_nz          = 0;
+  g.inv_res        = (float)(1.0 / (double)s.resolution);
+  g.fast_div       = s.resolution == 0.15F && g.inv_res == 6.666666507720947F ? 1 : 0;
   // RiskVoxel::getClearOcccupancy (risk_voxel.cpp:399-423) compares the K-cell sum with the fixed
   // map/risk_threshold_astar: the RiskBase rule with risk_threshold_region = that value and no decay.
   // It inherits MapBase::getObstaclePoints (map.cpp:480-518): fixed risk_threshold as well.
@@ -321,9 +342,9 @@ __device__ inline int query_clear_idx(const MapView &m, int agent, double px, do
   }
   const float *pose = m.poses + agent * 3;
   const float  fx = (float)px - pose[0], fy = (float)py - pose[1], fz = (float)pz - pose[2];
-  const int    ix = (int)((fx + g.rx) / g.res);
-  const int    iy = (int)((fy + g.ry) / g.res);
-  const int    iz = (int)((fz + g.rz) / g.res);
+  const int    ix = (int)g.div_res(fx + g.rx);
+  const int    iy = (int)g.div_res(fy + g.ry);
+  const int    iz = (int)g.div_res(fz + g.rz);
   if (!g.in_range(ix, iy, iz)) return -1;
   const void  *sl  = m.slab(agent, t);
   const int    s   = g.inf_step;
@@ -430,6 +451,8 @@ __device__ inline void bezier_pos(const SogmTrajRecord &r, double t, double out[
   X(RESET_LATE, "reset_late", 1, 0, 1)           /* sparse reset: held back until every agent's corridors are final       */  \
   X(STAMP_WGS, "stamp_wgs", 256, 0, 4096)           /* stamp: one-wave workgroups per agent                                  */  \
   X(STAMP_BITS_WGS, "stamp_bits_wgs", 0, 0, 4096)   /* stamp: one-wave workgroups per agent of the occupancy-bits pass; 0 = stamp_wgs */  \
+  X(STAMP_LDS_LOG, "stamp_lds_log", 1, 0, 1)        /* stamp: the marks' log pass reads the sectors back from LDS instead of recomputing them */  \
+  X(STAMP_CACHED, "stamp_cached", 0, 0, 1)          /* stamp: the marks' register-cached single-pass slice loops (the persistent kernels' form) */  \
   X(STAMP_LDS_KB, "stamp_lds_kb", 0, 0, 64)              /* stamp: unused dynamic LDS per marks workgroup (bounds waves per CU) */  \
   X(SPLAT_WGS, "splat_wgs", 256, 0, 65536)           /* overlay launched under a pre-stamp's tail: workgroups                 */  \
   X(SPLAT_OVERLAP, "splat_overlap", 1, 0, 1)     /* 0: sogm_replan joins the pre-stamp's end itself                       */  \

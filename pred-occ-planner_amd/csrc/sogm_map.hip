@@ -558,7 +558,7 @@ __device__ __forceinline__ void stamp_marks_trips(const GridGeom &g, void *__res
                                                   const CylCand *__restrict__ cand_all,
                                                   const int *__restrict__ n_cand, int agent, const MarkLog &lg,
                                                   int w_first, int w_stride, CylCand *cand_lds = nullptr,
-                                                  int cand_lds_cap = 0) {
+                                                  int cand_lds_cap = 0, unsigned *lds_secs = nullptr) {
   const int      kept   = n_cand[agent];
   const bool     culled = kept <= SOGM_MAX_CYL_LDS;
   const int      n_lds  = culled ? kept : 0;
@@ -755,11 +755,15 @@ __device__ __forceinline__ void stamp_marks_trips(const GridGeom &g, void *__res
       PS_ADD(5, ps_w1 - ps_w0);
       PS_ADD(8, 1);
       // the cell of slice k this voxel marks (g.V: none — outside the grid, or the reference's out-of-bounds index)
+      // (the z velocity is zero — (cz + (0.0F * dt) * k) - p2 is the same number for every k — so the z part of the range
+      //  test and the z index are the voxel's own, computed once: one division and four comparisons less per mark)
+      const float fzc = (cz + 0.0F) - p2;
+      const bool  zin = fzc > -g.rz && fzc < g.rz;
+      const int   izc = (int)g.div_res(fzc + g.rz);
       auto future_cell = [&](int k) -> int {
         const float fx = (cx + (vx * g.dt) * (float)k) - p0;
         const float fy = (cy + (vy * g.dt) * (float)k) - p1;
-        const float fz = (cz + (0.0F * g.dt) * (float)k) - p2;
-        return g.in_range(fx, fy, fz) ? g.cell_of(fx, fy, fz) : g.V;
+        return zin && fx > -g.rx && fx < g.rx && fy > -g.ry && fy < g.ry ? g.cell_of_xy(fx, fy, izc) : g.V;
       };
       // Mark log (sparse reset).  The lanes of a trip hold neighbouring voxels of the slice's storage order, so the marks of
       // neighbouring lanes fall into the same 32-byte sector most of the time, in slice 0 and — same velocity — in every
@@ -841,9 +845,14 @@ __device__ __forceinline__ void stamp_marks_trips(const GridGeom &g, void *__res
       } else {
         unsigned *lent = lg.entries ? lg.entries + (size_t)agent * lg.cap : nullptr;
         unsigned  pref = 0, run = 0;
+        // lds_secs ([T][64] words of the wave's LDS; k_stamp_marks): the store pass leaves every slice's sector there — or
+        // NOT_KEPT for a lane that does not log it — and the log pass reads it back instead of recomputing the future cell
+        // and the keep ballot (half of the slice loops' instructions: the kernel is bound by instruction issue)
+        constexpr unsigned NOT_KEPT = 0xFFFFFFFEu;
         {
           const unsigned long long m = keep_of((unsigned)v >> esh, true);
           run                        = (unsigned)__popcll(m);
+          if (lds_secs) lds_secs[lane] = ((m >> lane) & 1ull) ? (unsigned)v >> esh : NOT_KEPT;
         }
         for (int k = 1; k < g.T; ++k) {
           const int    fv = future_cell(k);
@@ -857,6 +866,7 @@ __device__ __forceinline__ void stamp_marks_trips(const GridGeom &g, void *__res
             const unsigned long long m = keep_of(in ? (unsigned)(ci >> esh) : 0xFFFFFFFFu, in);
             if (lane == (k & 63)) pref = run;
             run += (unsigned)__popcll(m);
+            if (lds_secs) lds_secs[k * 64 + lane] = ((m >> lane) & 1ull) ? (unsigned)(ci >> esh) : NOT_KEPT;
           }
         }
         if (lent && g.T <= 64) {
@@ -864,6 +874,15 @@ __device__ __forceinline__ void stamp_marks_trips(const GridGeom &g, void *__res
           if (lane == 0) lbase = atomicAdd(lg.n + agent, run);
           lbase          = (unsigned)__shfl((int)lbase, 0, 64);
           n_logged += run;
+          if (lds_secs) {
+            for (int k = 0; k < g.T; ++k) {
+              const unsigned           sec  = lds_secs[k * 64 + lane];  // (this lane's own word: no cross-lane hazard)
+              const bool               mine = sec != NOT_KEPT;
+              const unsigned long long m    = __ballot(mine);
+              const unsigned           li   = lbase + (unsigned)__shfl((int)pref, k, 64) + (unsigned)__popcll(m & lt);
+              if (mine && li < (unsigned)lg.cap) lent[li] = sec;
+            }
+          } else
           for (int k = 0; k < g.T; ++k) {
             const int                fv  = k == 0 ? v : future_cell(k);
             const bool               in  = fv < g.V;
@@ -893,9 +912,20 @@ __global__ __launch_bounds__(64) void k_stamp_marks(GridGeom g, void *__restrict
                                                     const SogmCylinder *__restrict__ cyl, int n_cyl,
                                                     const float *__restrict__ poses,
                                                     const CylCand *__restrict__ cand_all,
-                                                    const int *__restrict__ n_cand, int agent0, MarkLog lg) {
+                                                    const int *__restrict__ n_cand, int agent0, MarkLog lg, int lds_log) {
+  extern __shared__ unsigned s_marks_secs[];  // [T][64] when the launch provides it (lds_log != 0)
   stamp_marks_trips<false>(g, grid, bits, words_per_agent, cyl, n_cyl, poses, cand_all, n_cand, (int)blockIdx.y + agent0, lg,
-                    (int)blockIdx.x * 256, (int)gridDim.x * 256);
+                           (int)blockIdx.x * 256, (int)gridDim.x * 256, nullptr, 0, lds_log ? s_marks_secs : nullptr);
+}
+// (the register-cached single-pass form of the slice loops: tuning key stamp_cached)
+__global__ __launch_bounds__(64) void k_stamp_marks_cached(GridGeom g, void *__restrict__ grid,
+                                                           unsigned *__restrict__ bits, int words_per_agent,
+                                                           const SogmCylinder *__restrict__ cyl, int n_cyl,
+                                                           const float *__restrict__ poses,
+                                                           const CylCand *__restrict__ cand_all,
+                                                           const int *__restrict__ n_cand, int agent0, MarkLog lg) {
+  stamp_marks_trips<true>(g, grid, bits, words_per_agent, cyl, n_cyl, poses, cand_all, n_cand, (int)blockIdx.y + agent0, lg,
+                          (int)blockIdx.x * 256, (int)gridDim.x * 256);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2787,8 +2817,18 @@ static int update_gt_impl(sogm_ctx *c, const float *cloud_xyz, const int32_t *cl
   // (dynamic LDS the kernel does not use bounds its waves per CU: the marks' scattered stores merge worse in L2 the more
   //  waves interleave theirs — tuning key stamp_lds_kb, 160 / kb workgroups per CU)
   const size_t marks_lds = (size_t)c->tune_i(SOGM_TUNE_STAMP_LDS_KB) * 1024;
-  hipLaunchKernelGGL(k_stamp_marks, dim3(stamp_wgs, A), dim3(64), marks_lds, st, c->geom, (void *)c->d_grid, c->d_stamp_bits,
-                     words, cylinders, n_cyl, c->d_poses, (const CylCand *)c->d_cand, (const int *)c->d_ncand, 0, lg);
+  if (c->tune_i(SOGM_TUNE_STAMP_CACHED))
+    hipLaunchKernelGGL(k_stamp_marks_cached, dim3(stamp_wgs, A), dim3(64), marks_lds, st, c->geom, (void *)c->d_grid,
+                       c->d_stamp_bits, words, cylinders, n_cyl, c->d_poses, (const CylCand *)c->d_cand,
+                       (const int *)c->d_ncand, 0, lg);
+  else
+  {
+    // the log pass's sector cache: T x 64 words of LDS per (one-wave) workgroup, in front of the tuning aid's padding
+    const int    lds_log = lg.entries && c->spec.T <= 64 && c->tune_i(SOGM_TUNE_STAMP_LDS_LOG) ? 1 : 0;
+    const size_t lds     = marks_lds + (lds_log ? sizeof(unsigned) * 64 * (size_t)c->spec.T : 0);
+    hipLaunchKernelGGL(k_stamp_marks, dim3(stamp_wgs, A), dim3(64), lds, st, c->geom, (void *)c->d_grid, c->d_stamp_bits,
+                       words, cylinders, n_cyl, c->d_poses, (const CylCand *)c->d_cand, (const int *)c->d_ncand, 0, lg, lds_log);
+  }
   prof_end(c, SOGM_PROF_STAMP, st);
   SOGM_HIP_CHECK(hipGetLastError());
   if (fused && n_records > 0) {
