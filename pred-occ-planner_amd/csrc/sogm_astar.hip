@@ -1008,6 +1008,23 @@ __global__ __launch_bounds__(ASTAR_THREADS) void k_astar(
   const int  tid    = threadIdx.x;
   // dataflow replan: tell the gate kernel that this workgroup holds its CU resources (the corridor kernel's
   // waiting workgroups must not be dispatched before every search is resident, or they could starve it)
+  if (fc.reset_gen) {
+    // dataflow replan: the control block's reset runs on another stream (under the map update, normally long done): wait
+    // for its generation word before touching the block; then this agent's outputs back to "failed, empty record"
+    if (tid == 0) {
+      const long long t0 = wall_clock64();
+      while (__hip_atomic_load(fc.reset_gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != fc.reset_epoch) {
+        if (wall_clock64() - t0 > FLOW_TIMEOUT_TICKS) break;  // (the finishing kernel's own timeout fails the tick)
+        __builtin_amdgcn_s_sleep(32);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+    if (!second) {
+      if (tid == 0) fc.out_ok[agent] = 0;
+      for (int i = tid; i < fc.rec_words; i += ASTAR_THREADS) fc.out_records[(size_t)agent * fc.rec_words + i] = 0;
+    }
+  }
   if (fc.hdr && tid == 0) {
     atomicAdd(&fc.hdr[FLOW_A_RESIDENT], 1);
     if (!second) {

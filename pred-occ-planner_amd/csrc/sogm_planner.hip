@@ -212,7 +212,8 @@ int sogm_planner_create(sogm_ctx *map, const SogmAstarParams *astar, const SogmP
     const char *ef = getenv("SOGM_FLOW");  // (one of the library's three environment switches)
     p->flow        = ef ? atoi(ef) != 0 : 1;
     // layout: header, seg_done[A], stage[A] (zeroed per replan), then the four ready lists (-1 per replan)
-    if (e == hipSuccess) e = hipMalloc((void **)&p->d_flow, sizeof(int) * (FLOW_HDR + 6 * (size_t)A));
+    if (e == hipSuccess) e = hipMalloc((void **)&p->d_flow, sizeof(int) * (FLOW_HDR + 6 * (size_t)A + 1));  // (+ the reset's generation word)
+    if (e == hipSuccess) e = hipMemset(p->d_flow, 0, sizeof(int) * (FLOW_HDR + 6 * (size_t)A + 1));
     p->fc.hdr      = p->d_flow;
     p->fc.seg_done = p->d_flow + FLOW_HDR;
     p->fc.stage    = p->fc.seg_done + A;
@@ -612,22 +613,23 @@ int sogm_planner_set_swarm(sogm_planner *p, const SogmTrajRecord *records, int n
 // verdicts 0, ok 0, records empty.
 // epoch_word (dense clear's gate, sogm_device.hpp): this replan's epoch, written by the block that reset the counters
 // and after them.
-__global__ __launch_bounds__(256) void k_flow_reset(int *hdr, int n_hdr, int *ready, int n_ready, int *verdict,
-                                                    int n_verdict, int32_t *ok, int n_ok, int *records, int n_rec,
-                                                    int *epoch_word, int epoch) {
-  const int i0 = (int)(blockIdx.x * blockDim.x + threadIdx.x), step = (int)(gridDim.x * blockDim.x);
-  if (blockIdx.x == 0) {
-    for (int i = (int)threadIdx.x; i < n_hdr; i += (int)blockDim.x) hdr[i] = 0;
-    __threadfence();
-    __syncthreads();
-    if (epoch_word && threadIdx.x == 0)
-      __hip_atomic_store(epoch_word, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-  }
+// ONE workgroup, on the corridor stream, launched before the searches and run under the map update (it only touches the
+// planner's own words): when everything is back to its start value the generation word gets this replan's number — the
+// search workgroups wait for it in their prologue (no event between the update's last kernel and k_astar on the caller's
+// stream: the record's marker cost 55 us there) and zero their agent's ok / record themselves.
+__global__ __launch_bounds__(1024) void k_flow_reset(int *hdr, int n_hdr, int *ready, int n_ready, int *verdict,
+                                                     int n_verdict, int *epoch_word, int epoch, int *gen_word, int gen) {
+  const int i0 = (int)threadIdx.x, step = (int)blockDim.x;
+  for (int i = i0; i < n_hdr; i += step) hdr[i] = 0;
   for (int i = i0; i < n_ready; i += step) ready[i] = -1;
   if (verdict)
     for (int i = i0; i < n_verdict; i += step) verdict[i] = 0;
-  for (int i = i0; i < n_ok; i += step) ok[i] = 0;
-  for (int i = i0; i < n_rec; i += step) records[i] = 0;
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (epoch_word) __hip_atomic_store(epoch_word, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(gen_word, gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
 }
 
 // order[rank] = agent, rank = the number of agents whose chain of this tick (search start -> finished) was longer (ties:
@@ -664,26 +666,46 @@ static int replan_flow(sogm_planner *p, const double *start_pva, const double *g
   // k_finish_flow writes ok / the record of every agent whose chain completes; an agent whose chain does NOT (a wait
   // timed out, FLOW_ERR) must report ok = 0 and an empty record, not the previous tick's
   const bool spec = p->spec_astar != 0;
-  hipLaunchKernelGGL(k_flow_reset, dim3(64), dim3(256), 0, main, p->d_flow, FLOW_HDR + 2 * A, p->fc.a_ready, 4 * A,
-                     spec ? p->aw.verdict : nullptr, A, out_ok, A, reinterpret_cast<int *>(out_records),
-                     (int)(sizeof(SogmTrajRecord) / sizeof(int)) * A,
+  // The reset on the corridor stream: behind the previous replan's report (that stream's last kernel: below) and, in the
+  // pre-stamping variant, behind the pre-stamp's end; the waiting kernels of THIS replan follow it on the same stream or
+  // behind ev_gate.  The readers of the swarm table on those streams wait for an all-gather in flight themselves.
+  SOGM_HIP_CHECK(hipStreamWaitEvent(sC, p->ev_pdone, 0));  // (never recorded, or long complete, without a pre-stamp: no wait)
+  if (c->cur_prestamped) {
+    // a grid adopted by sogm_update_prestamped: its overlay (on the caller's stream) waits per agent on the control
+    // block's stage words — the reset must not run under it.  An event on the caller's stream, as before (this variant pays
+    // the marker in front of its searches)
+    SOGM_HIP_CHECK(hipEventRecord(p->ev_gate, main));
+    SOGM_HIP_CHECK(hipStreamWaitEvent(sC, p->ev_gate, 0));
+  }
+  int *gen_word = p->d_flow + FLOW_HDR + 6 * (size_t)A;
+  ++p->reset_epoch;
+  hipLaunchKernelGGL(k_flow_reset, dim3(1), dim3(1024), 0, sC, p->d_flow, FLOW_HDR + 2 * A, p->fc.a_ready, 4 * A,
+                     spec ? p->aw.verdict : nullptr, A,
                      c->overlap >= 2 && c->clear_gate ? c->clear_epoch_word : nullptr,
-                     c->overlap >= 2 && c->clear_gate ? sogm::next_clear_epoch(c) : 0);
+                     c->overlap >= 2 && c->clear_gate ? sogm::next_clear_epoch(c) : 0, gen_word, p->reset_epoch);
   SOGM_HIP_CHECK(hipGetLastError());
-  SOGM_HIP_CHECK(hipEventRecord(p->ev_in, main));
-  for (int k = 0; k < 4; ++k) SOGM_HIP_CHECK(hipStreamWaitEvent(p->fstream[k], p->ev_in, 0));
+  if (c->exchange_pending)
+    for (int k = 1; k < 4; ++k) SOGM_HIP_CHECK(hipStreamWaitEvent(p->fstream[k], c->ev_xdone, 0));
   prof_begin(c, SOGM_PROF_ASTAR, sA);
   // an update flow still building this tick's maps (sogm_update_world with update_flow): the searches are launched beside
   // it and every search workgroup waits for ITS agent's map; the caller's stream joins the flow's end at the fan-in
   sogm::FlowCtl fca = p->fc;
   fca.map_ready = c->update_pending ? c->d_map_ready : nullptr;
   fca.map_epoch = c->map_epoch;
+  fca.reset_gen   = gen_word;
+  fca.reset_epoch = p->reset_epoch;
+  fca.out_ok      = out_ok;
+  fca.out_records = reinterpret_cast<int *>(out_records);
+  fca.rec_words   = (int)(sizeof(SogmTrajRecord) / sizeof(int));
   if (launch_astar(mv, p->ap, p->pp.corridor_tau, astar_ws(p), A, start_pva, goal, t_start, p->d_ret, p->d_route,
                    p->d_route_len, p->route_cap, p->d_stats, nullptr, 0, sA, 0, &fca, spec ? 8 : 0)) {
     sogm::set_error("sogm_replan: k_astar", hipGetLastError());
     return SOGM_ERR_HIP;
   }
   prof_end(c, SOGM_PROF_ASTAR, sA);
+  // "the searches are launched" for the side-stream work that starts from here (spare grids' clears, the pre-stamp):
+  // recorded BEHIND k_astar — in front of it the record's marker held the searches back by 55 us
+  SOGM_HIP_CHECK(hipEventRecord(p->ev_in, main));
   if (sogm::launch_flow_gate(p->fc, spec ? 2 * A : A, sC)) return SOGM_ERR_HIP;
   SOGM_HIP_CHECK(hipEventRecord(p->ev_gate, sC));
   SOGM_HIP_CHECK(hipStreamWaitEvent(sQ, p->ev_gate, 0));
@@ -812,10 +834,21 @@ static int replan_flow(sogm_planner *p, const double *start_pva, const double *g
     c->ps_fail_host = p->h_flow_fail;  // sogm_update_prestamped refuses the grid if this replan turns out to have failed
     c->ps_fail_seen = p->h_flow_fail ? p->h_flow_fail[1] : 0;
   }
-  for (int k = 0; k < 4; ++k) {
-    SOGM_HIP_CHECK(hipEventRecord(p->ev_fdone[k], p->fstream[k]));
-    SOGM_HIP_CHECK(hipStreamWaitEvent(main, p->ev_fdone[k], 0));  // fan in
+  // fan-in.  Without a pre-stamp the tick's report runs on the corridor stream behind the QP and finishing kernels, so that
+  // the NEXT replan's reset — same stream — is ordered behind it without an event on the caller's stream
+  const bool report_on_sc = !(c->prestamp_slot >= 0);
+  for (int k = 0; k < 4; ++k)
+    if (k != 1) SOGM_HIP_CHECK(hipEventRecord(p->ev_fdone[k], p->fstream[k]));
+  if (report_on_sc) {
+    SOGM_HIP_CHECK(hipStreamWaitEvent(sC, p->ev_fdone[2], 0));
+    SOGM_HIP_CHECK(hipStreamWaitEvent(sC, p->ev_fdone[3], 0));
+    const int retire_c = c->tune_i(SOGM_TUNE_CLEAR_RETIRE_AT_END);
+    hipLaunchKernelGGL(k_flow_report, dim3(1), dim3(1), 0, sC, (const int *)p->d_flow, p->h_flow_fail,
+                       retire_c ? p->d_epoch : (int *)nullptr, c->h_tick_clock);
+    SOGM_HIP_CHECK(hipGetLastError());
   }
+  SOGM_HIP_CHECK(hipEventRecord(p->ev_fdone[1], sC));
+  for (int k = 0; k < 4; ++k) SOGM_HIP_CHECK(hipStreamWaitEvent(main, p->ev_fdone[k], 0));
   if (int rc = sogm::join_update(c, main)) return rc;  // (complete long ago: every search waited for its agent's map)
   if (c->d_update_order && c->tune_i(SOGM_TUNE_UPDATE_FLOW) != 0) {
     // the next update flow takes the agents in the order of this tick's chain lengths, longest first (a schedule only)
@@ -823,7 +856,7 @@ static int replan_flow(sogm_planner *p, const double *start_pva, const double *g
                        c->tune_i(SOGM_TUNE_UPDATE_ORDER));
     SOGM_HIP_CHECK(hipGetLastError());
   }
-  bool reported = false;
+  bool reported = report_on_sc;
   if (c->prestamp_slot >= 0) {
     // the tick's report behind the pre-stamp on ITS stream (the last kernel of the tick to end), so that the caller's
     // stream goes from the fan-in straight to the next tick's first kernel instead of through one more launch

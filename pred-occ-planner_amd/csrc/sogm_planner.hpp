@@ -68,6 +68,13 @@ struct FlowCtl {
   int *stage;     // [A]
   const int *map_ready;  // [A] update flow: the agent's map is complete when this holds map_epoch (null: it is already)
   int        map_epoch;
+  // the control block's reset runs on the corridor stream, early (under the map update); the searches wait for its
+  // generation word in their prologue and zero their agent's outputs there (k_astar; null: nothing to wait for)
+  const int *reset_gen;
+  int        reset_epoch;
+  int32_t   *out_ok;       // [A] this replan's outputs, zeroed per agent by its first search workgroup
+  int       *out_records;  // [A][rec_words]
+  int        rec_words;
 };
 #ifdef __HIPCC__
 // hand-over primitives of the persistent kernels: a ticket per wave, a bounded wait for a published slot
@@ -443,6 +450,7 @@ struct sogm_planner {
   SogmWorld      ps_world;
   hipEvent_t     ev_gate, ev_fdone[4];
   int           *d_epoch;      // device word: the clear epoch of the replan in flight (sogm_ctx::clear_epoch_word)
+  int            reset_epoch;  // generation of the control block's reset (k_flow_reset writes it into d_flow's last word)
   int           *h_flow_fail;  // pinned, device-visible: {last FLOW_ERR code, ticks that failed} (k_flow_report)
   // per-object use of the per-stage entries (sogm_planner_select_agents / _set_search_mode)
   int sel_first, sel_count;  // agents the per-stage entries process; (0, A) by default
