@@ -465,6 +465,11 @@ __device__ __forceinline__ void stamp_bits_wave4(const GridGeom &g, const CropBo
   }
 }
 // listed blocks first, first + stride, ... of the agent (one wave per call; a block's points are taken 64 at a time)
+// WAVE_DEDUPE: the word-level de-duplication over the 256 points in flight (k_stamp_bits_blocks: 32768 short-lived waves
+// hide its ~10 us of dependent cross-lane steps per block, and the atomics' count is that kernel's cost); the persistent
+// kernels, where a ticket walks dozens of blocks one after the other, only drop the bit of the predecessor lane (one DPP
+// move: with the leader loop the flight's bits stage took 775 instead of 146 wave-ms per tick)
+template <bool WAVE_DEDUPE = false>
 __device__ __forceinline__ void stamp_bits_blocks(const GridGeom &g, const float *__restrict__ cloud, const CloudBlocks &cb,
                                                   int agent, int first, int stride, float p0, float p1, float p2,
                                                   unsigned *__restrict__ mask, int lane) {
@@ -488,7 +493,17 @@ __device__ __forceinline__ void stamp_bits_blocks(const GridGeom &g, const float
       // consecutive points of a block are neighbours along z, 0.10 m apart in 0.15 m voxels: a lane whose bit is its
       // predecessor's leaves the OR to it (the ORs are device-scope atomics that execute at the memory side: their count
       // is what the pass costs)
-      stamp_bits_wave4(g, box, px, py, pz, mask, lane);
+      if constexpr (WAVE_DEDUPE) {
+        stamp_bits_wave4(g, box, px, py, pz, mask, lane);
+      } else {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int p    = stamp_bit_of(g, box, px[u], py[u], pz[u]);
+          const int prev = __builtin_amdgcn_update_dpp(-2, p, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
+          if (p >= 0 && prev != p)
+            __hip_atomic_fetch_or(mask + (p >> 5), 1u << (p & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
     }
     for (; j < end; j += 64) stamp_bits_point(g, box, cloud[(size_t)j * 3], cloud[(size_t)j * 3 + 1], cloud[(size_t)j * 3 + 2], mask);
   }
@@ -509,8 +524,8 @@ __global__ __launch_bounds__(64) void k_stamp_bits_blocks(GridGeom g, const floa
                                                           int words_per_agent) {
   const int    agent = blockIdx.y;
   const float *pose  = poses + agent * 3;
-  stamp_bits_blocks(g, cloud, cb, agent, (int)blockIdx.x, (int)gridDim.x, pose[0], pose[1], pose[2],
-                    bits + (size_t)agent * words_per_agent, (int)threadIdx.x);
+  stamp_bits_blocks<true>(g, cloud, cb, agent, (int)blockIdx.x, (int)gridDim.x, pose[0], pose[1], pose[2],
+                          bits + (size_t)agent * words_per_agent, (int)threadIdx.x);
 }
 // xy bounds of every block of `block_points` consecutive points (sogm_cloud_block_bounds): one wave per block
 __global__ __launch_bounds__(64) void k_block_bounds(const float *__restrict__ cloud, int n_points, int block_points,
