@@ -859,8 +859,11 @@ int sogm_update_prestamped(sogm_ctx *ctx, const SogmTrajRecord *records, int n_r
  * and ver(first_tick - 2) must hold the swarm's records of those ticks (a fresh flight: the initial table — empty or hover
  * records — in both); on return ver(first_tick + n_ticks - 1) and ver(first_tick + n_ticks - 2) are complete, i.e. a
  * following call with first_tick advanced by n_ticks continues the flight.  Needs the sparse reset (the agent's single grid is
- * reset through its mark log at the start of each of its ticks), body particles, 32-byte aligned agent grids; single
- * process (n_total == n_agents: every row of the tables is written by this call's agents).  Four persistent kernels on
+ * reset through its mark log at the start of each of its ticks), body particles, 32-byte aligned agent grids.
+ * Several ranks (n_total > n_agents: the batch is rows agent0 .. agent0 + n_agents - 1, the other rows belong to other
+ * ranks): a call flies at most TWO ticks — ticks k and k + 1 read ver(k - 2) and ver(k - 1), which the host completes
+ * between two calls by all-gathering every rank's rows of the versions the previous call finished (sogm_traj_allgather, in
+ * place); same records as one process flying all agents (tests/test_exchange_gpu.py).  Four persistent kernels on
  * four streams with disjoint compute-unit masks (tuning keys flight_*_units, 16 CUs per unit); asynchronous: `stream`
  * waits for the flight's end.  SOGM_ERR_STATE if the planner was created without the dataflow path.
  */

@@ -1110,8 +1110,11 @@ int sogm_flight_run(sogm_planner *p, const SogmFlight *f, void *stream) {
     return SOGM_ERR_INVALID_ARG;
   sogm_ctx *c = p->map;
   const int A = c->n_agents;
-  if (f->n_total != A || f->agent0 != 0) {
-    sogm::set_error_text("sogm_flight_run: single process only (n_total == n_agents, agent0 == 0)");
+  if (f->n_total < A || f->agent0 < 0 || f->agent0 + A > f->n_total) return SOGM_ERR_INVALID_ARG;
+  if (f->n_total != A && f->n_ticks > 2) {
+    // several ranks: the rows of the OTHER ranks' agents in ver(k - 2) must be complete before tick k starts, and only
+    // the host can put them there (an all-gather of the finished versions between two calls): two ticks per call at most
+    sogm::set_error_text("sogm_flight_run: with n_total > n_agents (other ranks' rows in the tables) a call flies at most two ticks");
     return SOGM_ERR_INVALID_ARG;
   }
   if (!p->flow || !c->sparse || !c->d_body || c->n_body <= 0) return SOGM_ERR_STATE;

@@ -513,7 +513,9 @@ class SwarmTick:
         int32, records uint8 [n, A, 2064]) device tensors — valid once the stream has run the flight."""
         c = self.compute
         assert getattr(c, "use_world", False), "fly() needs world frames (moving_world=True / False)"
-        assert self.world == 1 and not self.fsm
+        assert not self.fsm
+        if self.world > 1:
+            return self._fly_ranks(n_ticks)
         if not hasattr(self, "_fl_tables"):
             assert self.tick == 0, "a flight starts at tick 0 (or continues a flight)"
             self._fl_tables = torch.zeros((4, self.A_tot, _abi.TRAJ_RECORD_BYTES), dtype=torch.uint8, device="cuda")
@@ -528,4 +530,49 @@ class SwarmTick:
         self.tick += n_ticks
         self._fl_next = self.tick
         self.all = self._fl_tables[(self.tick - 1) & 3]   # ver(last tick): what every agent executes now
+        return log_ok, log_r
+
+    def _fly_ranks(self, n_ticks):
+        """fly() over several ranks: tick k reads the OTHER ranks' records of tick k - 2, which only an all-gather between
+        two calls can deliver — so the flight goes in calls of two ticks (k, k + 1 read ver(k - 2), ver(k - 1): both
+        complete before the call), each followed by the all-gather of the two versions it finished (this rank's rows of
+        ver(k), ver(k + 1) to every rank).  Same records as one process flying all agents."""
+        c = self.compute
+        lo, hi = shard_bounds(self.rank, self.world, self.A_loc)
+        if not hasattr(self, "_fl_tables"):
+            assert self.tick == 0, "a flight starts at tick 0 (or continues a flight)"
+            self._fl_tables = torch.zeros((4, self.A_tot, _abi.TRAJ_RECORD_BYTES), dtype=torch.uint8, device="cuda")
+            self._fl_next = 0
+        assert self.tick == self._fl_next, "fly() continues flights only"
+        log_r = torch.zeros((n_ticks, self.A_loc, _abi.TRAJ_RECORD_BYTES), dtype=torch.uint8, device="cuda")
+        log_ok = torch.zeros((n_ticks, self.A_loc), dtype=torch.int32, device="cuda")
+        done = 0
+        while done < n_ticks:
+            n = min(2, n_ticks - done)
+            worlds = [c.world(self.tick + i) for i in range(n)]
+            # (flight_guard: a test that runs several ranks as threads on ONE device serialises their calls with it — two
+            #  flights at once would fight for the same compute-unit partitions, each holding what the other's kernels need)
+            guard = getattr(self, "flight_guard", None)
+            if guard is not None:
+                guard.acquire()
+            try:
+                self.planner.flight(worlds, self.tick, self.t0, TICK_PERIOD, REPLAN_START_TIME, self.goals, self.dev["ego_ids"],
+                                    self.hover, self.own, self._fl_tables, log_r[done:done + n], log_ok[done:done + n],
+                                    n_total=self.A_tot, agent0=lo)
+                if guard is not None:
+                    torch.cuda.current_stream().synchronize()
+            finally:
+                if guard is not None:
+                    guard.release()
+            for k in range(self.tick, self.tick + n):
+                tab = self._fl_tables[k & 3]
+                if self.exchange.active:
+                    self.exchange.all_gather(tab[lo:hi], tab)     # in place: this rank's rows are where they belong
+                    self.exchange.wait()
+                else:
+                    exchange_records(tab[lo:hi].clone(), tab, self.dist, self.world)
+            self.tick += n
+            done += n
+        self._fl_next = self.tick
+        self.all = self._fl_tables[(self.tick - 1) & 3]
         return log_ok, log_r

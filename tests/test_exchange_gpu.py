@@ -256,3 +256,71 @@ def test_two_rank_flight_on_one_gpu_matches_the_single_process_flight(pop, tmp_p
     env = dict(os.environ, SOGM_RCCL_LIB=str(so), SOGM_REPO=root)
     r = subprocess.run([sys.executable, "-c", _TWO_RANK_FLIGHT], env=env, capture_output=True, text=True, timeout=500)
     assert r.returncode == 0 and "two-rank flight ok" in r.stdout, (r.stdout[-3000:], r.stderr[-3000:])
+
+
+_TWO_RANK_CHUNKED_FLIGHT = _TWO_RANK_FLIGHT[:_TWO_RANK_FLIGHT.index("dist = ThreadDist(WORLD)")] + r"""
+dist = ThreadDist(WORLD)
+GUARD = threading.Lock()
+res, errs = {}, []
+def run(rank):
+    try:
+        tls.rank = rank
+        torch.cuda.set_device(0)
+        with torch.cuda.stream(torch.cuda.Stream()):
+            sw = driver.SwarmTick("parity", A_LOC, rank, WORLD, 0, dist=dist, moving_world=True, prestamp=False)
+            sw.flight_guard = GUARD
+            assert sw.exchange.active and sw.distributed
+            ok_l, rec_l = sw.fly(TICKS)
+            torch.cuda.current_stream().synchronize()
+            res[rank] = (ok_l.cpu().numpy().copy(), rec_l.cpu().numpy().copy(), sw.all.cpu().numpy().copy(),
+                         sw.own.cpu().numpy().copy())
+            dist.bar.wait()          # nobody destroys its communicator while the other is still in a collective
+            sw.close()
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        errs.append((rank, traceback.format_exc()))
+        try: dist.bar.abort()
+        except Exception: pass
+ts = [threading.Thread(target=run, args=(r,), daemon=True) for r in range(WORLD)]
+[t.start() for t in ts]
+[t.join(240) for t in ts]
+if errs or any(t.is_alive() for t in ts):
+    print("FAILED", errs, [t.is_alive() for t in ts], flush=True)
+    os._exit(3)
+# the same flight in one process, one six-tick call
+sw = driver.SwarmTick("parity", A_LOC * WORLD, moving_world=True, prestamp=False)
+ok_r, rec_r = sw.fly(TICKS)
+torch.cuda.synchronize()
+ok_r, rec_r, tab_r, own_r = ok_r.cpu().numpy(), rec_r.cpu().numpy(), sw.all.cpu().numpy().copy(), sw.own.cpu().numpy().copy()
+sw.close()
+assert ok_r.sum() >= 2 * TICKS
+for r in range(WORLD):
+    lo, hi = r * A_LOC, (r + 1) * A_LOC
+    assert np.array_equal(res[r][0], ok_r[:, lo:hi]), ("ok flags differ", r)
+    for k in range(TICKS):
+        assert np.array_equal(res[r][1][k], rec_r[k, lo:hi]), ("per-tick records differ", r, k)
+    assert np.array_equal(res[r][2], tab_r), ("last table differs", r)
+    assert np.array_equal(res[r][3], own_r[lo:hi])
+print("two-rank chunked flight ok", ok_r.sum(axis=1).tolist())
+"""
+
+
+@pytest.mark.own_device
+def test_two_rank_flight_run_in_two_tick_calls_matches_the_single_process_flight(pop, tmp_path):
+    """sogm_flight_run over several ranks (review item: the N > 1 stand-in on the flight kernels): two SwarmTick ranks as two
+    host threads on one GPU fly 6 ticks through `fly()` — calls of two ticks with n_total = 8, agent0 = 0 / 4, each
+    followed by the all-gather (stand-in RCCL behind the C ABI, in place) of the two table versions it finished — and
+    must log, tick by tick, exactly the records of ONE process flying all 8 agents in a single six-tick call: the
+    staleness rule (own record k - 1, neighbours' k - 2) makes the schedule free, the ranks included.  (The two ranks'
+    calls are serialised by a lock: two flights at once on ONE device hold each other's compute-unit partitions.)"""
+    import os
+    import subprocess
+    import sys
+    assert "class ThreadDist" in _TWO_RANK_CHUNKED_FLIGHT
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = tmp_path / "libfake_rccl.so"
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-std=c++17", "-shared", "-fPIC",
+                           os.path.join(root, "tests", "fake_rccl.cpp"), "-o", str(so)])
+    env = dict(os.environ, SOGM_RCCL_LIB=str(so), SOGM_REPO=root)
+    r = subprocess.run([sys.executable, "-c", _TWO_RANK_CHUNKED_FLIGHT], env=env, capture_output=True, text=True, timeout=500)
+    assert r.returncode == 0 and "two-rank chunked flight ok" in r.stdout, (r.stdout[-3000:], r.stderr[-3000:])
