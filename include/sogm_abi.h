@@ -842,7 +842,12 @@ int sogm_prestamp_pending(const sogm_ctx *ctx);
  * next sogm_update_* / sogm_replan call.  No-op otherwise. */
 int sogm_prestamp_join(sogm_ctx *ctx, void *stream);
 /* The update of a pre-stamped tick: adopts the grid, its map centres and stamps, then adds the neighbour overlay
- * (records may be NULL with n_records = 0). */
+ * (records may be NULL with n_records = 0).  A grid whose pre-stamping replan FAILED is refused (SOGM_ERR_STATE: build the
+ * map with sogm_update_gt* / sogm_update_world instead) — decided on two levels: while the pre-stamp is still running the
+ * overlay waits per agent on the device and writes nothing once that replan's error word is set (the tick is then
+ * reported as failed by sogm_planner_flow_failures); the HOST check (the failure count against its value when the pre-stamp
+ * was queued) sees a failure only once the failing replan's report has run, i.e. it is exact after a synchronisation of
+ * the stream and best-effort for a host that pipelines ticks without one. */
 int sogm_update_prestamped(sogm_ctx *ctx, const SogmTrajRecord *records, int n_records, const int32_t *ego_ids,
                            void *stream);
 /*
