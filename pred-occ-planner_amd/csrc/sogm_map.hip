@@ -432,15 +432,16 @@ __device__ __forceinline__ void stamp_bits_wave(const GridGeom &g, const CropBox
 }
 // ... and for the 256 points a wave has in flight (four per lane): the columns of a block lie side by side, 0.10 m apart,
 // so their bits share words across the four sets as well
+// (called by ALL 64 lanes — the wave OR reads lane 63 —; `valid` bit u = the lane's point u exists)
 __device__ __forceinline__ void stamp_bits_wave4(const GridGeom &g, const CropBox &box, const float (&px)[4],
                                                  const float (&py)[4], const float (&pz)[4], unsigned *__restrict__ mask,
-                                                 int lane) {
+                                                 int lane, unsigned valid) {
   int                w[4];
   unsigned           bit[4];
   unsigned long long todo[4];
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
-    const int p = stamp_bit_of(g, box, px[u], py[u], pz[u]);
+    const int p = ((valid >> u) & 1u) ? stamp_bit_of(g, box, px[u], py[u], pz[u]) : -1;
     w[u]        = p >= 0 ? p >> 5 : -1;
     bit[u]      = p >= 0 ? 1u << (p & 31) : 0u;
     todo[u]     = __ballot(p >= 0);
@@ -459,8 +460,17 @@ __device__ __forceinline__ void stamp_bits_wave4(const GridGeom &g, const CropBo
       b |= mine ? bit[u] : 0u;
       todo[u] &= ~__ballot(mine);
     }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) b |= (unsigned)__shfl_xor((int)b, d, 64);
+    // OR over the wave with DPP (row_shr 1, 2, 4, 8: lane 15 of every row holds its row; row_bcast 15 / 31: lane 63 holds
+    // the wave) — seven instructions instead of six ds_bpermute round trips with their address arithmetic: the bits pass
+    // is bound by instruction issue (80 % of the slots), and this loop is most of it
+    int x = (int)b;
+    x |= __builtin_amdgcn_update_dpp(0, x, 0x111 /* row_shr:1 */, 0xF, 0xF, true);
+    x |= __builtin_amdgcn_update_dpp(0, x, 0x112 /* row_shr:2 */, 0xF, 0xF, true);
+    x |= __builtin_amdgcn_update_dpp(0, x, 0x114 /* row_shr:4 */, 0xF, 0xF, true);
+    x |= __builtin_amdgcn_update_dpp(0, x, 0x118 /* row_shr:8 */, 0xF, 0xF, true);
+    x |= __builtin_amdgcn_update_dpp(0, x, 0x142 /* row_bcast:15 */, 0xA, 0xF, true);
+    x |= __builtin_amdgcn_update_dpp(0, x, 0x143 /* row_bcast:31 */, 0xC, 0xF, true);
+    b = (unsigned)__builtin_amdgcn_readlane(x, 63);
     if (lane == 0) __hip_atomic_fetch_or(mask + wv, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
@@ -480,6 +490,23 @@ __device__ __forceinline__ void stamp_bits_blocks(const GridGeom &g, const float
     const int b   = list[i];
     const int beg = b * cb.block_points;
     const int end = beg + cb.block_points < cb.n_points ? beg + cb.block_points : cb.n_points;
+    if constexpr (WAVE_DEDUPE) {
+      for (int jb = beg; jb < end; jb += 256) {  // uniform trips of 256 points: every lane takes part in the wave OR
+        float    px[4], py[4], pz[4];
+        unsigned valid = 0u;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int idx = jb + lane + u * 64;
+          valid |= (idx < end ? 1u : 0u) << u;
+          const size_t q = (size_t)(idx < end ? idx : end - 1) * 3;
+          px[u] = cloud[q];
+          py[u] = cloud[q + 1];
+          pz[u] = cloud[q + 2];
+        }
+        stamp_bits_wave4(g, box, px, py, pz, mask, lane, valid);
+      }
+      continue;
+    }
     int       j   = beg + lane;
     for (; j + 192 < end; j += 256) {  // four points of this lane in flight
       float px[4], py[4], pz[4];
@@ -493,16 +520,12 @@ __device__ __forceinline__ void stamp_bits_blocks(const GridGeom &g, const float
       // consecutive points of a block are neighbours along z, 0.10 m apart in 0.15 m voxels: a lane whose bit is its
       // predecessor's leaves the OR to it (the ORs are device-scope atomics that execute at the memory side: their count
       // is what the pass costs)
-      if constexpr (WAVE_DEDUPE) {
-        stamp_bits_wave4(g, box, px, py, pz, mask, lane);
-      } else {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int p    = stamp_bit_of(g, box, px[u], py[u], pz[u]);
-          const int prev = __builtin_amdgcn_update_dpp(-2, p, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
-          if (p >= 0 && prev != p)
-            __hip_atomic_fetch_or(mask + (p >> 5), 1u << (p & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+      for (int u = 0; u < 4; ++u) {
+        const int p    = stamp_bit_of(g, box, px[u], py[u], pz[u]);
+        const int prev = __builtin_amdgcn_update_dpp(-2, p, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
+        if (p >= 0 && prev != p)
+          __hip_atomic_fetch_or(mask + (p >> 5), 1u << (p & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
     for (; j < end; j += 64) stamp_bits_point(g, box, cloud[(size_t)j * 3], cloud[(size_t)j * 3 + 1], cloud[(size_t)j * 3 + 2], mask);
