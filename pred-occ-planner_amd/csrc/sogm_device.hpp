@@ -47,6 +47,9 @@ struct GridGeom {
   // used for that resolution and that range only, the true division everywhere else.
   float inv_res;
   int   fast_div;
+  // largest |offset| of the body particles per axis (sogm_set_body_particles; +inf until they are set): the overlay skips
+  // a neighbour whose centre is farther outside the map than that — all of its particles are (splat_item)
+  float body_ext[3];
   __host__ __device__ inline float div_res(float a) const {
     if (fast_div && fabsf(a) < 64.0F) {
       const float q0 = a * inv_res;
@@ -146,6 +149,7 @@ inline GridGeom make_geom(const SogmSpec &s) {
   g.rs_n           = 0;
   g.rs_z           = nullptr;
   g.rs_nz          = 0;
+  g.body_ext[0] = g.body_ext[1] = g.body_ext[2] = INFINITY;
   g.inv_res        = (float)(1.0 / (double)s.resolution);
   g.fast_div       = s.resolution == 0.15F && g.inv_res == 6.666666507720947F ? 1 : 0;
   // RiskVoxel::getClearOcccupancy (risk_voxel.cpp:399-423) compares the K-cell sum with the fixed
