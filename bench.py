@@ -363,11 +363,14 @@ def main():
     st_gbps, st_frac = rate(stamp_alg, stamp_ms)
     pmc_stamp = committed("r05_pmc_stamp.json") or committed("r04_pmc_stamp.json")
     k_stamp = {"kernel": "k_cull_cylinders + k_stamp_bits + k_stamp_marks (the stamp; stage pass after the timed region, "
-                         "machine to itself — inside the tick it runs as k_prestamp_flow under the replan)",
+                         "machine to itself — inside the headline tick the same kernels run at its start, on the critical path; in the "
+                         "pre-stamped variant as k_prestamp_flow under the replan)",
                "launch_ms": stamp_ms, "marks": marks, "log_entries": s_entries,
                "algorithmic_bytes": stamp_alg, "achieved": st_gbps, "frac": st_frac,
                "note": "algorithmic bytes = 4 B per marked cell + 4 B per log entry; a mark costs HBM a 32-byte sector "
-                       "unless its x-neighbours share it: traffic / algorithmic is the write amplification",
+                       "unless the cells of its 2 x 2 x 2 tile (rows: its x-neighbours) share it: traffic / algorithmic is the write "
+                       "amplification; neither pass is HBM-bound (bits: the count of its memory-side atomic ORs, marks: "
+                       "instruction issue — DESIGN.md 3.1)",
                "traffic": (pmc_stamp or {}).get("bytes_per_launch"),
                "write_amplification": ((pmc_stamp["bytes_per_launch"] / pmc_stamp["algorithmic_bytes_per_launch"])
                                        if pmc_stamp and pmc_stamp.get("algorithmic_bytes_per_launch") else None),
