@@ -246,7 +246,11 @@ int sogm_set_resample(sogm_ctx *ctx, float replan_risk_rate, int num_resample, c
  *     search attempts side by side), and per (agent, tick) one-wave tickets "flight_reset" (8), "flight_bits" (16),
  *     "flight_marks" (32), "flight_splat" (4); "flight_admit" (48) agents whose map may be under construction at once, "flight_pace_us" (40) microseconds between two
  *     admissions to the map stage (agents then reach every stage at a steady rate; 0 = unpaced), "flight_heads" (32)
- *     admitting waves of the map kernel.
+ *     admitting waves of the map kernel; "flight_urgent" (8): an agent among the last n finishers of a tick — the agents the
+ *     swarm waits for at the next gate — builds the map of its next tick through a lane of its own (four of the heads, no
+ *     admission order / pace / window; "flight_urgent_waves" (128) of the map workers serve that lane only, and its maps are cut into "flight_urgent_fine" (4)
+ *     times more tickets; 0 = no such lane).
+ *     None of these keys changes a cell or a record.
  *   sogm_update_world, experimental (measured, not adopted: profiles/EXPERIMENTS.md round 5):  "update_flow" (0; 1 = the
  *     maps are built agent by agent on a stream of the context's own — one persistent launch over one-wave tickets, per
  *     agent occupancy bits -> marks -> overlay, agents in the order of their previous chain's length — and sogm_replan's

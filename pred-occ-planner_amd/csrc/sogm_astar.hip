@@ -1093,12 +1093,12 @@ __global__ __launch_bounds__(ASTAR_THREADS) void k_flight_search(
     if (agent < 0) break;
     const int second = spec ? (t & 1) : 0;
     const int k      = fl.tick_of[agent];
-    if (tid == 0 && !second) fl.ts[agent * 12 + 0] = wall_clock64();
+    if (tid == 0 && !second) fl.ts[agent * FL_TS + 0] = wall_clock64();
     const bool mine = astar_search_wg(m, ap, corridor_tau, wsp, start_pva, goal, t_start, out_ret, out_route, out_route_len,
                                       route_cap, out_stats, nullptr, 0, agent, second, spec != 0, 4 * (k + 1),
                                       &fl.hdr[FL_ERR], 0);
     if (mine && tid == ASTAR_MASTER) {
-      fl.ts[agent * 12 + 1] = wall_clock64();
+      fl.ts[agent * FL_TS + 1] = wall_clock64();
       wq_push(fl.lw, &fl.hdr[FL_LW_TAIL], ((unsigned)WK_CORRIDOR << 28) | (unsigned)agent, SOGM_MAX_PIECES);
     }
   }

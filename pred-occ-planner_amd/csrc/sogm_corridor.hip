@@ -2212,7 +2212,7 @@ __global__ __launch_bounds__(64) void k_flight_light(MapView m, SogmPlannerParam
       __threadfence();  // the record (own, ver(k), log) is out before the tick counts as finished
       if (lane == 0) {
         const long long now = wall_clock64();
-        long long      *ts  = fl.ts + (size_t)a * 12, *acc = fl.acc + (size_t)a * 8;
+        long long      *ts  = fl.ts + (size_t)a * FL_TS, *acc = fl.acc + (size_t)a * 8;
         ts[6]               = now;
         acc[0] += ts[9] - ts[8];                       // gate wait
         acc[1] += (ts[11] - ts[7]) - (ts[9] - ts[8]);  // map: from the head's publication to the complete map
@@ -2223,8 +2223,8 @@ __global__ __launch_bounds__(64) void k_flight_light(MapView m, SogmPlannerParam
         acc[6] += now - ts[7];                         // the whole chain
         acc[7] += 1;
         if (fl.ts_log) {
-          long long *lg = fl.ts_log + ((size_t)kl * fl.n_agents + a) * 12;
-          for (int q = 0; q < 12; ++q) lg[q] = ts[q];
+          long long *lg = fl.ts_log + ((size_t)kl * fl.n_agents + a) * FL_TS;
+          for (int q = 0; q < FL_TS; ++q) lg[q] = ts[q];
         }
         finish_count(f, a, (code & 1) != 0);
         // The gate of the staleness rule — tick j may start once EVERY agent has finished tick j - 2 — is kept here, on the
@@ -2239,7 +2239,12 @@ __global__ __launch_bounds__(64) void k_flight_light(MapView m, SogmPlannerParam
           fl.tick_of[a] = k + 1;
           ts[7]         = now;
           const bool open = kl < 1 || __hip_atomic_load(&fl.tick_done[kl - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= A_;
-          if (open) {
+          // one of the last finishers of its tick (and so not gated): its next map goes through the urgent lane
+          const bool urgent = open && fl.n_urgent > 0 && done_kl > A_ - fl.n_urgent;
+          fl.urgent[a]      = urgent ? 1 : 0;
+          if (urgent) {
+            fl_publish(fl.u_ring, fl.ring_mask, &fl.hdr[FL_U_READY], a);
+          } else if (open) {
             fl_publish(fl.m_ring, fl.ring_mask, &fl.hdr[FL_M_READY], a);
           } else {
             int      *lst  = fl.parked + (size_t)(kl + 1) * A_;
@@ -2266,7 +2271,7 @@ __global__ __launch_bounds__(64) void k_flight_light(MapView m, SogmPlannerParam
     }
     // ---- WK_CORRIDOR: segment slot `seg` of agent a ----
     const int seg = (desc >> 16) & 0xFFF;
-    if (seg == 0 && lane == 0) fl.ts[a * 12 + 2] = wall_clock64();
+    if (seg == 0 && lane == 0) fl.ts[a * FL_TS + 2] = wall_clock64();
     if (seg < d.route_len[a] - 1) {
       corridor_points_body<1>(m, pp, ws, d.start_pva, d.t_start, d.route, d.route_len, d.route_cap, a, seg);
       __threadfence_block();
@@ -2287,7 +2292,7 @@ __global__ __launch_bounds__(64) void k_flight_light(MapView m, SogmPlannerParam
                              d.out_goal, a, sc);
       __syncthreads();
       if (lane == 0) {
-        fl.ts[a * 12 + 3] = wall_clock64();
+        fl.ts[a * FL_TS + 3] = wall_clock64();
         fl_publish(fl.q_ring, fl.ring_mask, &fl.hdr[FL_Q_READY], a);
       }
     }

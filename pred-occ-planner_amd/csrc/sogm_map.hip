@@ -1605,17 +1605,24 @@ __global__ __launch_bounds__(64) void k_flight_map(GridGeom g, FlightCtl fl, Fli
   __shared__ __attribute__((aligned(16))) CylCand        s_cand[PRESTAMP_CAND_LDS];
   const int lane = threadIdx.x;
   const int A    = fl.n_agents;
-  const int n_r = d.n_reset, n_b = d.n_bits, n_m = d.n_marks, n_s = d.n_splat;
-  const int S   = 1 + n_r + n_b + n_m + n_s;  // stage counts per (agent, tick); the per-agent stage counter is cumulative
-  const unsigned total = (unsigned)A * (unsigned)fl.n_ticks * (unsigned)(S - 1);  // descriptors of the work queue
+  // this wave's lane: the urgent heads / workers come first in their groups; the urgent lane cuts a map into finer tickets
+  // (a map's latency is the sum of its phases' longest tickets — 0.25 reset + 0.3 marks + 0.17 overlay ms with the plain
+  // lane's counts even on idle workers — and the urgent lane exists for latency)
+  const bool urgent = (int)blockIdx.x < d.n_head_wgs ? (int)blockIdx.x < d.n_uhead_wgs
+                                                     : (int)blockIdx.x - d.n_head_wgs < d.n_uwork_wgs;
+  const int n_r = urgent ? d.un_reset : d.n_reset, n_b = urgent ? d.un_bits : d.n_bits;
+  const int n_m = urgent ? d.un_marks : d.n_marks, n_s = urgent ? d.un_splat : d.n_splat;
+  const int S   = 1 + n_r + n_b + n_m + n_s;  // stage counts per (agent, tick); the agent's stage counter restarts at its head
   int      *err = &fl.hdr[FL_ERR];
+  const int all = A * fl.n_ticks;  // agent-ticks of the flight: every lane of this kernel ends when FL_FINISHED reaches it
   if ((int)blockIdx.x < d.n_head_wgs) {
-    // ---- admitting waves: heads, in the order the agents' previous ticks finished ----
-    const int items = A * fl.n_ticks;
+    // ---- admitting waves: heads, in the order the agents' previous ticks finished; the first n_uhead_wgs serve the
+    // urgent ring: no admission order, no pace, no window (the gate is open for an agent that is behind) ----
+    unsigned long long *const wq      = urgent ? fl.uw : fl.mw;
+    int *const                wq_tail = &fl.hdr[urgent ? FL_UW_TAIL : FL_MW_TAIL];
     for (;;) {
-      const int t = flow_ticket(&fl.hdr[FL_M_TICKET]);
-      if (t >= items) break;
-      const int agent = fl_wait_item(fl.m_ring, fl.ring_mask, t, err);
+      const int t     = flow_ticket(&fl.hdr[urgent ? FL_U_TICKET : FL_M_TICKET]);
+      const int agent = fl_wait_item_end(urgent ? fl.u_ring : fl.m_ring, fl.ring_mask, t, err, &fl.hdr[FL_FINISHED], all, !urgent);
       if (agent < 0) break;
       __threadfence();
       const int          k = fl.tick_of[agent], kl = k - fl.first_tick;
@@ -1625,13 +1632,13 @@ __global__ __launch_bounds__(64) void k_flight_map(GridGeom g, FlightCtl fl, Fli
       cb.n_blocks     = w.n_blocks;
       cb.block_points = w.block_points;
       cb.n_points     = w.n_points;
-      long long *ts = fl.ts + (size_t)agent * 12;
+      long long *ts = fl.ts + (size_t)agent * FL_TS;
       if (lane == 0) ts[8] = wall_clock64();
       // admission, in ticket order: at most n_admit maps under construction, and no faster than one agent per pace_ticks
       // — agents then leave the map stage (and reach every later stage) at a steady rate instead of in a burst, which is
       // what lets kernels with FIXED compute units all be busy at once: a swarm that moves in step serves one stage at a
       // time and the tick becomes the SUM of the stages' times (measured: 12.9 ms = 5.6 map + 3.7 corridors + 3.4 QP).
-      {  // my turn: a tight poll — a handful of waves wait here, and the hand-over from head to head is the admission rate
+      if (!urgent) {  // my turn: a tight poll — a handful of waves wait here, and the hand-over from head to head is the admission rate
         const long long w0 = wall_clock64();
         bool            bad = false;
         while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&fl.hdr[FL_ADMITTED], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < t) {
@@ -1646,9 +1653,9 @@ __global__ __launch_bounds__(64) void k_flight_map(GridGeom g, FlightCtl fl, Fli
         if (bad) break;
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       }
-      if (flow_wait_count(&fl.hdr[FL_MAPS_DONE], t - d.n_admit + 1, err)) break;
+      if (!urgent && flow_wait_count(&fl.hdr[FL_MAPS_DONE], t - d.n_admit + 1, err)) break;
       if (kl >= 2 && flow_wait_count(&fl.tick_done[kl - 2], A, err)) break;
-      if (lane == 0) {
+      if (!urgent && lane == 0) {
         long long *pc = reinterpret_cast<long long *>(&fl.hdr[FL_PACE_CLOCK]);
         while (wall_clock64() - *pc < d.pace_ticks) __builtin_amdgcn_s_sleep(16);
         *pc = wall_clock64();
@@ -1673,21 +1680,25 @@ __global__ __launch_bounds__(64) void k_flight_map(GridGeom g, FlightCtl fl, Fli
       cull_blocks_agent(g, cb, agent, d.poses[agent * 3], d.poses[agent * 3 + 1], lane);
       __threadfence();
       if (lane == 0) {  // the agent's grid may be reset and its occupancy bits set (neither touches what the other writes)
-        atomicAdd(&fl.stage[agent], 1);
-        wq_push(fl.mw, &fl.hdr[FL_MW_TAIL], ((unsigned)WK_MAP_RESET << 28) | (unsigned)agent, n_r);
-        wq_push(fl.mw, &fl.hdr[FL_MW_TAIL], ((unsigned)WK_MAP_BITS << 28) | (unsigned)agent, n_b);
+        ts[12] = wall_clock64();
+        atomicExch(&fl.stage[agent], 1);  // (the agent's previous map is complete: nobody else touches the counter now)
+        wq_push(wq, wq_tail, ((unsigned)WK_MAP_RESET << 28) | (unsigned)agent, n_r);
+        wq_push(wq, wq_tail, ((unsigned)WK_MAP_BITS << 28) | (unsigned)agent, n_b);
       }
       __syncthreads();
     }
     return;
   }
+  // ---- workers: the first n_uwork_wgs of them on the urgent queue, the others on the plain one; a map stays in the lane
+  // its head put it in (a worker pushes the next phase's descriptors into its own queue) ----
+  unsigned long long *const wq      = urgent ? fl.uw : fl.mw;
+  int *const                wq_tail = &fl.hdr[urgent ? FL_UW_TAIL : FL_MW_TAIL];
   long long c1_prev = 0;
   int       kind_prev = 0;
   for (;;) {
-    const unsigned t = (unsigned)flow_ticket(&fl.hdr[FL_MW_HEAD]);
-    if (t >= total) break;
+    const unsigned t = (unsigned)flow_ticket(&fl.hdr[urgent ? FL_UW_HEAD : FL_MW_HEAD]);
     const long long c0   = wall_clock64();
-    const int       desc = wq_take(fl.mw, t, err);
+    const int       desc = wq_take_end(wq, t, err, &fl.hdr[FL_FINISHED], all, !urgent);
     if (desc < 0) break;
     __threadfence();
     const long long c1 = wall_clock64();
@@ -1706,7 +1717,7 @@ __global__ __launch_bounds__(64) void k_flight_map(GridGeom g, FlightCtl fl, Fli
     cb.n_blocks     = w.n_blocks;
     cb.block_points = w.block_points;
     cb.n_points     = w.n_points;
-    long long     *ts  = fl.ts + (size_t)agent * 12;
+    long long     *ts  = fl.ts + (size_t)agent * FL_TS;
     const unsigned adr = (unsigned)agent;
     if (kind == WK_MAP_RESET || kind == WK_MAP_BITS) {
       if (kind == WK_MAP_RESET) {
@@ -1722,20 +1733,21 @@ __global__ __launch_bounds__(64) void k_flight_map(GridGeom g, FlightCtl fl, Fli
                           d.poses[agent * 3 + 2], d.bits + (size_t)agent * d.words, lane);
       }
       __threadfence();
-      if (lane == 0 && atomicAdd(&fl.stage[agent], 1) + 1 == kl * S + 1 + n_r + n_b) {
+      if (lane == 0 && atomicAdd(&fl.stage[agent], 1) + 1 == 1 + n_r + n_b) {
         // the grid is clean and the bits are set: the log restarts, then the marks may append
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         d.lg.n[agent] = 0u;
-        wq_push(fl.mw, &fl.hdr[FL_MW_TAIL], ((unsigned)WK_MAP_MARKS << 28) | adr, n_m);
+        ts[13]        = wall_clock64();
+        wq_push(wq, wq_tail, ((unsigned)WK_MAP_MARKS << 28) | adr, n_m);
       }
     } else if (kind == WK_MAP_MARKS) {
       stamp_marks_trips<true>(g, d.grid, d.bits, d.words, w.cyl, w.n_cyl, d.poses, (const CylCand *)d.cand, d.n_cand, agent, d.lg,
                         sub * 256, n_m * 256, s_cand, PRESTAMP_CAND_LDS);
       __syncthreads();  // (the next descriptor's staging overwrites s_cand)
       __threadfence();
-      if (lane == 0 && atomicAdd(&fl.stage[agent], 1) + 1 == kl * S + 1 + n_r + n_b + n_m) {
+      if (lane == 0 && atomicAdd(&fl.stage[agent], 1) + 1 == 1 + n_r + n_b + n_m) {
         ts[10] = wall_clock64();
-        wq_push(fl.mw, &fl.hdr[FL_MW_TAIL], ((unsigned)WK_MAP_SPLAT << 28) | adr, n_s);
+        wq_push(wq, wq_tail, ((unsigned)WK_MAP_SPLAT << 28) | adr, n_s);
       }
     } else {  // WK_MAP_SPLAT: the neighbours' records of table ver(k - 2)
       if (d.tables && d.n_total > 0) {
@@ -1745,10 +1757,10 @@ __global__ __launch_bounds__(64) void k_flight_map(GridGeom g, FlightCtl fl, Fli
           splat_item(g, d.grid, tab[i / g.T], agent, i % g.T, d.ego_ids, d.poses, d.stamps, d.body, d.n_body, d.lg);
       }
       __threadfence();
-      if (lane == 0 && atomicAdd(&fl.stage[agent], 1) + 1 == (kl + 1) * S) {  // the agent's map of tick k is complete
+      if (lane == 0 && atomicAdd(&fl.stage[agent], 1) + 1 == S) {  // the agent's map of tick k is complete
         ts[11] = wall_clock64();
         fl_publish(fl.s_ring, fl.ring_mask, &fl.hdr[FL_S_READY], agent);
-        atomicAdd(&fl.hdr[FL_MAPS_DONE], 1);  // one more agent may be admitted
+        if (!urgent) atomicAdd(&fl.hdr[FL_MAPS_DONE], 1);  // one more agent may be admitted (the window counts the plain lane's maps)
       }
     }
   }

@@ -1007,7 +1007,7 @@ __global__ __launch_bounds__(256) void k_flight_seed(FlightCtl fl) {
   if (a < fl.n_agents) {
     fl.tick_of[a] = fl.first_tick;
     fl.m_ring[a]  = (1 << 16) | a;               // position a, generation 1: every agent's first head, in agent order
-    fl.ts[(size_t)a * 12 + 7] = wall_clock64();  // the head's publication
+    fl.ts[(size_t)a * FL_TS + 7] = wall_clock64();  // the head's publication
   }
   if (a == 0) fl.hdr[FL_M_READY] = fl.n_agents;
   for (int i = a; i < FLIGHT_MAX_TICKS * fl.n_agents; i += (int)(gridDim.x * blockDim.x)) fl.parked[i] = -1;
@@ -1030,7 +1030,7 @@ static int flight_setup(sogm_planner *p) {
   int ring = 1;
   while (ring < 2 * A) ring <<= 1;
   if (A >= (1 << 16)) return SOGM_ERR_INVALID_ARG;
-  const size_t words = FL_HDR + 3 * (size_t)ring + 4 * (size_t)FL_WQ_SLOTS + 2 * FLIGHT_MAX_TICKS + 3 * (size_t)A +
+  const size_t words = FL_HDR + 4 * (size_t)ring + 6 * (size_t)FL_WQ_SLOTS + 2 * FLIGHT_MAX_TICKS + 4 * (size_t)A +
                        (size_t)FLIGHT_MAX_TICKS * A;
   SOGM_HIP_CHECK(hipMalloc((void **)&p->d_fl, sizeof(int) * words));
   int *q          = p->d_fl;
@@ -1038,22 +1038,24 @@ static int flight_setup(sogm_planner *p) {
   p->fl.s_ring    = q;              q += ring;
   p->fl.q_ring    = q;              q += ring;
   p->fl.m_ring    = q;              q += ring;
-  if (ring & 1) q += 1;
-  p->fl.mw        = reinterpret_cast<unsigned long long *>(q);  q += 2 * FL_WQ_SLOTS;  // (FL_HDR and ring are even: 8-byte aligned)
+  p->fl.u_ring    = q;              q += ring;
+  p->fl.mw        = reinterpret_cast<unsigned long long *>(q);  q += 2 * FL_WQ_SLOTS;  // (FL_HDR and 4 x ring are even: 8-byte aligned)
   p->fl.lw        = reinterpret_cast<unsigned long long *>(q);  q += 2 * FL_WQ_SLOTS;
+  p->fl.uw        = reinterpret_cast<unsigned long long *>(q);  q += 2 * FL_WQ_SLOTS;
   p->fl.tick_done = q;              q += FLIGHT_MAX_TICKS;
   p->fl.parked_n  = q;              q += FLIGHT_MAX_TICKS;
   p->fl.tick_of   = q;              q += A;
   p->fl.seg_done  = q;              q += A;
   p->fl.stage     = q;              q += A;
+  p->fl.urgent    = q;              q += A;
   p->fl.parked    = q;
   p->fl.ring_mask = ring - 1;
   p->fl.n_agents  = A;
-  SOGM_HIP_CHECK(hipMalloc((void **)&p->fl.ts, sizeof(long long) * 12 * (size_t)A));
+  SOGM_HIP_CHECK(hipMalloc((void **)&p->fl.ts, sizeof(long long) * FL_TS * (size_t)A));
   SOGM_HIP_CHECK(hipMalloc((void **)&p->fl.acc, sizeof(long long) * 8 * (size_t)A));
-  SOGM_HIP_CHECK(hipMemset(p->fl.ts, 0, sizeof(long long) * 12 * (size_t)A));
+  SOGM_HIP_CHECK(hipMemset(p->fl.ts, 0, sizeof(long long) * FL_TS * (size_t)A));
   SOGM_HIP_CHECK(hipMemset(p->fl.acc, 0, sizeof(long long) * 8 * (size_t)A));
-  SOGM_HIP_CHECK(hipMalloc((void **)&p->fl.ts_log, sizeof(long long) * 12 * (size_t)A * FLIGHT_MAX_TICKS));
+  SOGM_HIP_CHECK(hipMalloc((void **)&p->fl.ts_log, sizeof(long long) * FL_TS * (size_t)A * FLIGHT_MAX_TICKS));
   SOGM_HIP_CHECK(hipMalloc((void **)&p->fl.prof, sizeof(unsigned long long) * 16));
   SOGM_HIP_CHECK(hipMemset(p->fl.prof, 0, sizeof(unsigned long long) * 16));
   SOGM_HIP_CHECK(hipMalloc((void **)&p->d_fl_worlds, sizeof(FlightWorld) * FLIGHT_MAX_TICKS));
@@ -1203,6 +1205,25 @@ int sogm_flight_run(sogm_planner *p, const SogmFlight *f, void *stream) {
   md.n_splat     = c->tune_i(SOGM_TUNE_FLIGHT_SPLAT);
   md.n_head_wgs  = c->tune_i(SOGM_TUNE_FLIGHT_HEADS) < p->fl_wgs[3] / 2 ? c->tune_i(SOGM_TUNE_FLIGHT_HEADS)
                                                                         : (p->fl_wgs[3] / 2 > 0 ? p->fl_wgs[3] / 2 : 1);
+  // the urgent lane (sogm_planner.hpp): a few heads and a share of the workers, none with flight_urgent = 0
+  fl.n_urgent    = c->tune_i(SOGM_TUNE_FLIGHT_URGENT) < A ? c->tune_i(SOGM_TUNE_FLIGHT_URGENT) : A - 1;
+  if (fl.n_urgent < 0) fl.n_urgent = 0;
+  md.n_uhead_wgs = 0;
+  md.n_uwork_wgs = 0;
+  {
+    const int fine = c->tune_i(SOGM_TUNE_FLIGHT_URGENT_FINE);
+    auto      cut  = [fine](int n, int hi) { return n * fine < hi ? n * fine : hi; };
+    md.un_reset = cut(md.n_reset, 256);
+    md.un_bits  = cut(md.n_bits, 256) > 2 * md.n_bits ? 2 * md.n_bits : cut(md.n_bits, 256);  // (bits tickets are short already)
+    md.un_marks = cut(md.n_marks, 256);
+    md.un_splat = cut(md.n_splat, 64);
+  }
+  if (fl.n_urgent > 0) {
+    const int workers = p->fl_wgs[3] - md.n_head_wgs;
+    md.n_uhead_wgs = md.n_head_wgs >= 8 ? 4 : md.n_head_wgs / 2;
+    md.n_uwork_wgs = c->tune_i(SOGM_TUNE_FLIGHT_URGENT_WAVES) < workers / 2 ? c->tune_i(SOGM_TUNE_FLIGHT_URGENT_WAVES) : workers / 2;
+    if (md.n_uhead_wgs < 1 || md.n_uwork_wgs < 1) fl.n_urgent = 0, md.n_uhead_wgs = 0, md.n_uwork_wgs = 0;
+  }
   md.n_admit     = c->tune_i(SOGM_TUNE_FLIGHT_ADMIT);
   md.pace_ticks  = (int)(c->tune[SOGM_TUNE_FLIGHT_PACE_US] * 100.0);
   md.agent_bytes = agent_bytes;
@@ -1211,7 +1232,7 @@ int sogm_flight_run(sogm_planner *p, const SogmFlight *f, void *stream) {
   // frames + control block, in stream order on the caller's stream
   SOGM_HIP_CHECK(hipMemcpyAsync(p->d_fl_worlds, p->h_fl_worlds, sizeof(FlightWorld) * (size_t)f->n_ticks, hipMemcpyHostToDevice, main));
   const int       ring    = p->fl.ring_mask + 1;
-  const int       n_words = FL_HDR + 3 * ring + 4 * FL_WQ_SLOTS + 2 * FLIGHT_MAX_TICKS + 3 * A;  // (the parked lists: k_flight_seed)
+  const int       n_words = FL_HDR + 4 * ring + 6 * FL_WQ_SLOTS + 2 * FLIGHT_MAX_TICKS + 4 * A;  // (the parked lists: k_flight_seed)
   const long long n_log   = (long long)f->n_ticks * A * (long long)(sizeof(SogmTrajRecord) / sizeof(int));
   hipLaunchKernelGGL(k_flight_reset, dim3(256), dim3(256), 0, main, fl, n_words, p->aw.verdict, p->fl.acc,
                      reinterpret_cast<int *>(f->log_records), n_log);
@@ -1269,11 +1290,11 @@ int sogm_flight_run(sogm_planner *p, const SogmFlight *f, void *stream) {
   return SOGM_OK;
 }
 
-// diagnostics (tools/ only): every agent-tick's stamps of the last flight, [n_ticks][A][12] ticks of 10 ns
+// diagnostics (tools/ only): every agent-tick's stamps of the last flight, [n_ticks][A][FL_TS] ticks of 10 ns
 int sogm_debug_flight_times(sogm_planner *p, long long *out_host, int n_ticks) {
   if (!p || !p->d_fl || !out_host || n_ticks < 1 || n_ticks > FLIGHT_MAX_TICKS) return SOGM_ERR_INVALID_ARG;
   SOGM_HIP_CHECK(hipDeviceSynchronize());
-  SOGM_HIP_CHECK(hipMemcpy(out_host, p->fl.ts_log, sizeof(long long) * 12 * (size_t)p->map->n_agents * n_ticks, hipMemcpyDeviceToHost));
+  SOGM_HIP_CHECK(hipMemcpy(out_host, p->fl.ts_log, sizeof(long long) * FL_TS * (size_t)p->map->n_agents * n_ticks, hipMemcpyDeviceToHost));
   return SOGM_OK;
 }
 
@@ -1294,7 +1315,7 @@ int sogm_flight_stats(sogm_planner *p, double *out_ms, int32_t *out_hdr) {
     int *tmp = new (std::nothrow) int[FL_HDR];
     if (!tmp) return SOGM_ERR_INVALID_ARG;
     const hipError_t e = hipMemcpy(tmp, p->fl.hdr, sizeof(int) * FL_HDR, hipMemcpyDeviceToHost);
-    for (int i = 0; i < 32; ++i) out_hdr[i] = i < FL_COUNTERS ? tmp[(size_t)i * FL_STRIDE] : 0;
+    for (int i = 0; i < 32; ++i) out_hdr[i] = i < 15 ? tmp[(size_t)i * FL_STRIDE] : 0;  // (the urgent lane's four: not reported)
     delete[] tmp;
     SOGM_HIP_CHECK(e);
     unsigned long long prof[16];  // [16..31]: wave time by activity in units of 10 us (0-8), descriptor counts (9-15)

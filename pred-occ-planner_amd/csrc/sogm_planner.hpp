@@ -141,7 +141,17 @@ enum { FL_S_READY = 0 * FL_STRIDE, FL_S_TICKET = 1 * FL_STRIDE, FL_Q_READY = 2 *
        FL_MAPS_DONE = 12 * FL_STRIDE,                               // maps completed (admission control)
        FL_ADMITTED = 13 * FL_STRIDE,                                // heads admitted so far (they are admitted in ticket order)
        FL_PACE_CLOCK = 14 * FL_STRIDE,                              // (two words) wall clock of the last admission
-       FL_COUNTERS = 15, FL_HDR = 15 * FL_STRIDE };
+       FL_U_READY = 15 * FL_STRIDE, FL_U_TICKET = 16 * FL_STRIDE,   // urgent lane (below): heads published / taken
+       FL_UW_TAIL = 17 * FL_STRIDE, FL_UW_HEAD = 18 * FL_STRIDE,    // urgent lane: map descriptors pushed / tickets taken
+       FL_COUNTERS = 19, FL_HDR = 19 * FL_STRIDE };
+// The urgent lane of the map kernel.  The flight's rate is the rate of its SLOWEST agent's own chain (tools/diag_flight.py:
+// the critical path follows one agent with long corridors / QPs for many ticks in a row), and that agent — always behind,
+// never gated — queued like everybody else: behind a burst of leaders the gate had just released (up to 1.3 ms in the
+// in-order admission, 0.4 ms for a free head wave) and then shared the map workers with ~24 other maps (1.0 ms for a map
+// that takes 0.3 by itself).  The leaders have slack by definition, the laggards have none: an agent that finishes tick k
+// among the last `flight_urgent` of the swarm builds the map of its tick k + 1 through a lane of its own — `u_ring` ->
+// urgent heads (no admission order, no pace, no window) -> work queue `uw` -> workers that serve nothing else.  The cells,
+// records and logs do not depend on the schedule (the staleness rule fixes every input).
 // Work queues (map kernel, corridor + finish kernel): ONE FIFO of ready work per kernel.  A producer reserves positions with
 // one atomicAdd on the tail and stores a descriptor per position, tagged with the position's generation; a consumer takes a
 // ticket with one atomicAdd on the head and waits for ITS position (idle waves therefore poll distinct words).  Every
@@ -151,6 +161,7 @@ enum { FL_S_READY = 0 * FL_STRIDE, FL_S_TICKET = 1 * FL_STRIDE, FL_Q_READY = 2 *
 // retrying on one counter, the map stage took 5-28 ms per agent and got SLOWER with more waves or tickets.)
 // descriptor: kind << 28 | sub << 16 | agent
 enum { WK_MAP_HEAD = 0, WK_MAP_RESET = 1, WK_MAP_BITS = 2, WK_MAP_MARKS = 3, WK_MAP_SPLAT = 4, WK_CORRIDOR = 5, WK_FINISH = 6 };
+#define FL_TS 16            // stamps per agent-tick (FlightCtl::ts)
 #define FL_WQ_SLOTS 131072  // per queue (a tick of 128 agents pushes 8-25 k map descriptors; at most two ticks are in flight)
 #define FLIGHT_MAX_TICKS 64
 struct FlightWorld {  // one SogmWorld frame as the kernels read it
@@ -160,21 +171,25 @@ struct FlightWorld {  // one SogmWorld frame as the kernels read it
 };
 struct FlightCtl {
   int *hdr;                                         // [FL_HDR]
-  int *s_ring, *q_ring, *m_ring;                    // [ring_mask + 1] each: maps ready for the search, corridors final for the QP,
-                                                    // agents whose previous tick is finished (map heads)
-  unsigned long long *mw, *lw;                      // [FL_WQ_SLOTS] work queues of the map / the corridor + finish kernel
+  int *s_ring, *q_ring, *m_ring, *u_ring;           // [ring_mask + 1] each: maps ready for the search, corridors final for the QP,
+                                                    // agents whose previous tick is finished (map heads; u_ring: the urgent ones)
+  unsigned long long *mw, *lw, *uw;                 // [FL_WQ_SLOTS] work queues of the map / the corridor + finish kernel / the
+                                                    // map kernel's urgent lane
   int  ring_mask;
+  int *urgent;      // [A] 1: the agent's current tick goes through the urgent lane
+  int  n_urgent;    // an agent among the last n_urgent finishers of a tick is urgent in its next one (0: no urgent lane)
   int *tick_done;   // [FLIGHT_MAX_TICKS] agents that have finished tick first_tick + i
   int *parked_n;    // [FLIGHT_MAX_TICKS] heads of tick first_tick + i parked at the gate "tick i - 2 is complete" ...
   int *parked;      // [FLIGHT_MAX_TICKS][A] ... the agents (-1 empty, -2 released)
   int *tick_of;     // [A] the tick the agent is in (absolute index)
   int *seg_done;    // [A] cumulative corridor segment slots finished
   int *stage;       // [A] cumulative map tickets finished
-  long long *ts;    // [A][12] stamps of the agent's current tick: 0 A* start, 1 A* done, 2 first corridor item, 3 corridors
-                    //         final, 4 QP start, 5 QP done, 6 finished, 7 map item published, 8 map head start, 9 gate passed, 10 marks done, 11 map ready
+  long long *ts;    // [A][FL_TS] stamps of the agent's current tick: 0 A* start, 1 A* done, 2 first corridor item, 3 corridors
+                    //         final, 4 QP start, 5 QP done, 6 finished, 7 map item published, 8 map head start, 9 gate passed, 10 marks done, 11 map ready,
+                    //         12 head done (reset / bits tickets queued), 13 grid reset and bits set (marks tickets queued)
   long long *acc;   // [A][8] sums over the flight (100 MHz ticks): gate wait, map, search queue + A*, corridors, QP queue + QP,
                     //        finish, whole chain, ticks completed
-  long long *ts_log;         // [FLIGHT_MAX_TICKS][A][12] every agent-tick's stamps (sogm_debug_flight_times)
+  long long *ts_log;         // [FLIGHT_MAX_TICKS][A][FL_TS] every agent-tick's stamps (sogm_debug_flight_times)
   unsigned long long *prof;  // [16] wave time (100 MHz ticks) by activity, summed over the flight: 0 map workers idle (waiting
                              //      for a descriptor), 1 reset, 2 bits, 3 marks, 4 overlay, 5 heads (incl. their waits),
                              //      6 light waves idle, 7 corridor segments, 8 finish; 9.. descriptor counts of 1-4, 7, 8
@@ -199,6 +214,30 @@ __device__ inline int fl_wait_item(const int *ring, int mask, int pos, int *err)
     flow_pause();
     if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0) return -1;
     if (wall_clock64() - t0 > FLOW_TIMEOUT_TICKS) {
+      if ((threadIdx.x & 63) == 0) atomicExch(err, 12);
+      return -1;
+    }
+  }
+}
+// the same for the map kernel's lanes, whose item counts are not known in advance (an agent-tick goes through the plain or
+// the urgent lane): -2 once every agent-tick of the flight is finished; `timed` = false: no time limit of its own (the
+// urgent lane may see no item for a whole flight; a stalled flight ends through the other waiters' limits and `err`)
+__device__ inline int fl_wait_item_end(const int *ring, int mask, int pos, int *err, const int *finished, int all, bool timed) {
+  const int       want = (pos / (mask + 1)) + 1;
+  const long long t0   = wall_clock64();
+  for (;;) {
+    const int v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(ring + (pos & mask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    if ((v >> 16) == want) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      return v & 0xFFFF;
+    }
+    if (timed)
+      flow_pause();
+    else
+      __builtin_amdgcn_s_sleep(127);  // (the few urgent heads poll every 3.4 us)
+    if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(finished, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >= all) return -2;
+    if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0) return -1;
+    if (timed && wall_clock64() - t0 > FLOW_TIMEOUT_TICKS) {
       if ((threadIdx.x & 63) == 0) atomicExch(err, 12);
       return -1;
     }
@@ -235,6 +274,36 @@ __device__ inline int wq_take(const unsigned long long *wq, unsigned pos, int *e
     }
   }
 }
+// the same with the end-of-flight exit (see fl_wait_item_end): -2 = every agent-tick is finished
+__device__ inline int wq_take_end(const unsigned long long *wq, unsigned pos, int *err, const int *finished, int all, bool timed) {
+  const unsigned  want = pos / FL_WQ_SLOTS + 1u;
+  const long long t0   = wall_clock64();
+  int             naps = 0;
+  for (;;) {
+    const unsigned long long v  = __hip_atomic_load(wq + (pos % FL_WQ_SLOTS), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned           hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    if (hi == want) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      return (int)__builtin_amdgcn_readfirstlane((unsigned)v);
+    }
+    if (timed) {
+      for (int i = 0; i <= (naps < 7 ? naps : 7); ++i) flow_pause();  // 14 us ... 110 us: an idle wave polls less and less
+    } else {
+      __builtin_amdgcn_s_sleep(127);  // 3.4 us: the urgent lane exists for latency, and few waves poll it
+    }
+    ++naps;
+    if ((naps & (timed ? 1 : 7)) == 0 &&
+        __builtin_amdgcn_readfirstlane(__hip_atomic_load(finished, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >= all)
+      return -2;
+    if ((timed || (naps & 7) == 0) &&
+        __builtin_amdgcn_readfirstlane(__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0)
+      return -1;
+    if (timed && wall_clock64() - t0 > FLOW_TIMEOUT_TICKS) {
+      if ((threadIdx.x & 63) == 0) atomicExch(err, 15);
+      return -1;
+    }
+  }
+}
 #endif
 // the map role's arguments (csrc/sogm_map.hip, k_flight_map)
 struct FlightMapDev {
@@ -257,7 +326,10 @@ struct FlightMapDev {
   float                *poses;         // the context's map centres / stamps (queries read them)
   double               *stamps;
   int                   n_reset, n_bits, n_marks, n_splat;  // one-wave tickets per agent and tick
+  int                   un_reset, un_bits, un_marks, un_splat;  // ... of a map in the urgent lane
   int                   n_head_wgs;    // workgroups 0 .. n_head_wgs - 1 of the launch admit agents (heads), the rest work off the queue
+  int                   n_uhead_wgs;   // the first n_uhead_wgs of the heads serve the urgent ring
+  int                   n_uwork_wgs;   // the first n_uwork_wgs of the workers serve the urgent queue
   int                   n_admit;       // agents whose map may be under construction at once
   int                   pace_ticks;    // 100 MHz ticks between two admissions (0 = as fast as the heads run)
   size_t                agent_bytes;

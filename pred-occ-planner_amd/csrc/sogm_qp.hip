@@ -1755,11 +1755,11 @@ __global__ __launch_bounds__(QP_NT) void k_flight_qp(SogmPlannerParams pp, SogmQ
     const int agent = __builtin_amdgcn_readfirstlane(s_agent);
     if (agent < 0) break;  // no tickets left, or the flight failed
     __threadfence();
-    if (threadIdx.x == 0) fl.ts[agent * 12 + 4] = wall_clock64();
+    if (threadIdx.x == 0) fl.ts[agent * FL_TS + 4] = wall_clock64();
     qp_solve_agent(pp, qs, ws, qc, start_pva, goal_pv, polys, nfaces, npoly, out_cpts, out_status, out_iters, 0, agent);
     __syncthreads();
     if (threadIdx.x == 0) {
-      fl.ts[agent * 12 + 5] = wall_clock64();
+      fl.ts[agent * FL_TS + 5] = wall_clock64();
       wq_push(fl.lw, &fl.hdr[FL_LW_TAIL], ((unsigned)WK_FINISH << 28) | (unsigned)agent, 1);
     }
     __syncthreads();

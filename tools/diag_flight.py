@@ -23,7 +23,7 @@ sw.fly(3)
 torch.cuda.synchronize()
 sw.fly(ticks)
 torch.cuda.synchronize()
-ts = np.zeros((ticks, A, 12), np.int64)
+ts = np.zeros((ticks, A, 16), np.int64)
 lib = pop.lib()
 lib.sogm_debug_flight_times.restype = C.c_int
 lib.sogm_debug_flight_times.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
@@ -57,4 +57,57 @@ for t in T[::3]:
     q = ((ms[:, :, 3] <= t) & (t < ms[:, :, 5])).sum()
     f = ((ms[:, :, 5] <= t) & (t < ms[:, :, 6])).sum()
     print(f"{t:6.1f} {w:7d} {m:5d} {s:6d} {c:8d} {q:5d} {f:6d}")
+# The critical path of the flight: walk back from the last finish.  An agent-tick starts either at the agent's own previous
+# finish (edge "own") or when tick k - 2 is complete (edge "gate": its last finisher); what follows is the agent-tick's
+# chain, split into waiting for admission, map, search, corridors, QP, finish.
+QP_ITERS = sw.planner.last_qp_iterations() if hasattr(sw.planner, "last_qp_iterations") else None
+k, a = ticks - 1, int(np.argmax(ms[ticks - 1, :, 6]))
+path = []
+while k >= 0:
+    pub, hs, adm, mr = ms[k, a, 7], ms[k, a, 8], ms[k, a, 9], ms[k, a, 11]
+    seg = {"tick": k, "agent": a, "parked": hs - pub, "admission": adm - hs, "map": mr - adm, "search": ms[k, a, 1] - mr,
+           "corridor": ms[k, a, 3] - ms[k, a, 1], "qp": ms[k, a, 5] - ms[k, a, 3], "finish": ms[k, a, 6] - ms[k, a, 5]}
+    gate_open = ms[k - 2, :, 6].max() if k >= 2 else -1.0
+    if k >= 2 and gate_open >= pub - 1e-3:   # the head was parked until the gate opened: go to the last finisher of k - 2
+        seg["edge"] = "gate"
+        seg["parked"] = hs - gate_open
+        path.append(seg)
+        a = int(np.argmax(ms[k - 2, :, 6]))
+        k -= 2
+    else:
+        seg["edge"] = "own"
+        path.append(seg)
+        k -= 1
+path.reverse()
+print("critical path (edge = how the agent-tick was reached; ms):")
+tot = {}
+for s_ in path:
+    print("  tick %2d agent %3d via %-4s parked %.2f adm %.2f map %.2f A* %.2f corr %.2f qp %.2f fin %.2f" % (
+        s_["tick"], s_["agent"], s_["edge"], s_["parked"], s_["admission"], s_["map"], s_["search"], s_["corridor"], s_["qp"], s_["finish"]))
+    for key in ("parked", "admission", "map", "search", "corridor", "qp", "finish"):
+        tot[key] = tot.get(key, 0.0) + s_[key]
+print("critical path totals (ms):", {k_: round(v, 2) for k_, v in tot.items()}, "sum", round(sum(tot.values()), 2),
+      "own edges", sum(1 for s_ in path if s_["edge"] == "own"), "gate edges", sum(1 for s_ in path if s_["edge"] == "gate"))
+# agent-ticks that went through the urgent lane (no admission wait, head at once) against the others: the map's phases
+adm_w = ms[:, :, 9] - ms[:, :, 8]
+urg = (adm_w < 0.004) & (ms[:, :, 8] - ms[:, :, 7] < 0.06)
+urg[0] = False
+for name, sel in (("urgent lane", urg), ("plain lane", ~urg)):
+    if sel.sum() == 0:
+        continue
+    h_d = (ms[:, :, 12] - ms[:, :, 9])[sel]
+    r_b = (ms[:, :, 13] - ms[:, :, 12])[sel]
+    mk = (ms[:, :, 10] - ms[:, :, 13])[sel]
+    print(f"{name}: head {h_d.mean():.3f} (p90 {np.percentile(h_d, 90):.3f})  reset + bits {r_b.mean():.3f} (p90 {np.percentile(r_b, 90):.3f})  marks {mk.mean():.3f} (p90 {np.percentile(mk, 90):.3f})")
+    a_m = (ms[:, :, 10] - ms[:, :, 9])[sel]
+    m_r = (ms[:, :, 11] - ms[:, :, 10])[sel]
+    print(f"{name}: {int(sel.sum())} agent-ticks; admitted -> marksDone mean {a_m.mean():.3f} p50 {np.percentile(a_m, 50):.3f} p90 {np.percentile(a_m, 90):.3f} max {a_m.max():.3f};"
+          f" marksDone -> mapReady mean {m_r.mean():.3f} p90 {np.percentile(m_r, 90):.3f} max {m_r.max():.3f}")
+# how many urgent maps are under construction at once, sampled at every urgent admission
+ua, ur = np.sort(ms[:, :, 9][urg]), np.sort(ms[:, :, 11][urg])
+if len(ua):
+    conc = [int((ua <= t).sum() - (ur <= t).sum()) for t in ua]
+    print("urgent maps under construction at an urgent admission: mean %.1f p90 %d max %d" % (np.mean(conc), np.percentile(conc, 90), max(conc)))
+last = [int(np.argmax(ms[k_, :, 6])) for k_ in range(ticks)]
+print("last finisher per tick:", last)
 sw.close()
