@@ -248,8 +248,9 @@ int sogm_set_resample(sogm_ctx *ctx, float replan_risk_rate, int num_resample, c
  *     admissions to the map stage (agents then reach every stage at a steady rate; 0 = unpaced), "flight_heads" (32)
  *     admitting waves of the map kernel; "flight_urgent" (8): an agent among the last n finishers of a tick — the agents the
  *     swarm waits for at the next gate — builds the map of its next tick through a lane of its own (four of the heads, no
- *     admission order / pace / window; "flight_urgent_waves" (128) of the map workers serve that lane only, and its maps are cut into "flight_urgent_fine" (4)
- *     times more tickets; 0 = no such lane).
+ *     admission order / pace / window; a work queue of its own that the first "flight_urgent_waves" (4096 = all) map workers
+ *     look at before they take plain work and while they wait for it; its maps are cut into "flight_urgent_fine" (4) times
+ *     more tickets; 0 = no such lane).
  *     None of these keys changes a cell or a record.
  *   sogm_update_world, experimental (measured, not adopted: profiles/EXPERIMENTS.md round 5):  "update_flow" (0; 1 = the
  *     maps are built agent by agent on a stream of the context's own — one persistent launch over one-wave tickets, per

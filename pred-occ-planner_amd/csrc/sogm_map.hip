@@ -1605,19 +1605,15 @@ __global__ __launch_bounds__(64) void k_flight_map(GridGeom g, FlightCtl fl, Fli
   __shared__ __attribute__((aligned(16))) CylCand        s_cand[PRESTAMP_CAND_LDS];
   const int lane = threadIdx.x;
   const int A    = fl.n_agents;
-  // this wave's lane: the urgent heads / workers come first in their groups; the urgent lane cuts a map into finer tickets
-  // (a map's latency is the sum of its phases' longest tickets — 0.25 reset + 0.3 marks + 0.17 overlay ms with the plain
-  // lane's counts even on idle workers — and the urgent lane exists for latency)
-  const bool urgent = (int)blockIdx.x < d.n_head_wgs ? (int)blockIdx.x < d.n_uhead_wgs
-                                                     : (int)blockIdx.x - d.n_head_wgs < d.n_uwork_wgs;
-  const int n_r = urgent ? d.un_reset : d.n_reset, n_b = urgent ? d.un_bits : d.n_bits;
-  const int n_m = urgent ? d.un_marks : d.n_marks, n_s = urgent ? d.un_splat : d.n_splat;
-  const int S   = 1 + n_r + n_b + n_m + n_s;  // stage counts per (agent, tick); the agent's stage counter restarts at its head
+  // (the urgent lane cuts a map into finer tickets: a map's latency is the sum of its phases' longest tickets — 0.25 reset +
+  //  0.3 marks + 0.17 overlay ms with the plain lane's counts even on idle workers — and the urgent lane exists for latency)
   int      *err = &fl.hdr[FL_ERR];
   const int all = A * fl.n_ticks;  // agent-ticks of the flight: every lane of this kernel ends when FL_FINISHED reaches it
   if ((int)blockIdx.x < d.n_head_wgs) {
     // ---- admitting waves: heads, in the order the agents' previous ticks finished; the first n_uhead_wgs serve the
     // urgent ring: no admission order, no pace, no window (the gate is open for an agent that is behind) ----
+    const bool urgent = (int)blockIdx.x < d.n_uhead_wgs;
+    const int  n_r = urgent ? d.un_reset : d.n_reset, n_b = urgent ? d.un_bits : d.n_bits;
     unsigned long long *const wq      = urgent ? fl.uw : fl.mw;
     int *const                wq_tail = &fl.hdr[urgent ? FL_UW_TAIL : FL_MW_TAIL];
     for (;;) {
@@ -1689,17 +1685,78 @@ __global__ __launch_bounds__(64) void k_flight_map(GridGeom g, FlightCtl fl, Fli
     }
     return;
   }
-  // ---- workers: the first n_uwork_wgs of them on the urgent queue, the others on the plain one; a map stays in the lane
-  // its head put it in (a worker pushes the next phase's descriptors into its own queue) ----
-  unsigned long long *const wq      = urgent ? fl.uw : fl.mw;
-  int *const                wq_tail = &fl.hdr[urgent ? FL_UW_TAIL : FL_MW_TAIL];
+  // ---- workers.  Every worker holds a ticket of the plain queue, as before; the first n_uwork_wgs of them look at the urgent
+  // queue first — before they take a plain descriptor and while they wait for one — and claim an urgent descriptor that is
+  // THERE with a compare-and-swap on the queue's head (never a ticket for one that is not: a worker must not be lost to the
+  // plain lane waiting for urgent work; the claim is tried once per look, so the waves do not spin on the counter).  A
+  // first version gave the urgent lane 128 workers of its own: they idled most of the time, which a flight whose map
+  // kernel is the bottleneck paid for (300^3 x 30: 11.5 -> 13.7 ms per tick).  A map stays in the lane its head put it in:
+  // the next phase's descriptors go into the queue the finished one came from. ----
+  const bool ulane = (int)blockIdx.x - d.n_head_wgs < d.n_uwork_wgs;
+  bool       have_plain = false;
+  unsigned   plain_t    = 0;
+  int        seen_uh    = 0;
   long long c1_prev = 0;
   int       kind_prev = 0;
   for (;;) {
-    const unsigned t = (unsigned)flow_ticket(&fl.hdr[urgent ? FL_UW_HEAD : FL_MW_HEAD]);
     const long long c0   = wall_clock64();
-    const int       desc = wq_take_end(wq, t, err, &fl.hdr[FL_FINISHED], all, !urgent);
+    int             desc = -1;
+    bool            urgent = false;
+    for (int naps = 0;;) {
+      if (ulane) {
+        const int ut = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&fl.hdr[FL_UW_TAIL], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        if (ut - seen_uh > 0) {
+          const int h = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&fl.hdr[FL_UW_HEAD], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+          seen_uh     = h;
+          if (ut - h > 0) {
+            int got = 0;
+            if (lane == 0) {
+              int e = h;
+              got   = __hip_atomic_compare_exchange_strong(&fl.hdr[FL_UW_HEAD], &e, h + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                           __HIP_MEMORY_SCOPE_AGENT) ? 1 : 0;
+            }
+            if (__builtin_amdgcn_readfirstlane(got)) {  // position h is reserved by its producer: the descriptor is there or about to be
+              desc   = wq_take_end(fl.uw, (unsigned)h, err, &fl.hdr[FL_FINISHED], all, false);
+              urgent = true;
+              break;
+            }
+          }
+        }
+      }
+      if (!have_plain) {
+        plain_t    = (unsigned)flow_ticket(&fl.hdr[FL_MW_HEAD]);
+        have_plain = true;
+      }
+      {
+        const unsigned long long v  = __hip_atomic_load(fl.mw + (plain_t % FL_WQ_SLOTS), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned           hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+        if (hi == plain_t / FL_WQ_SLOTS + 1u) {
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          desc       = (int)__builtin_amdgcn_readfirstlane((unsigned)v);
+          have_plain = false;
+          break;
+        }
+      }
+      // 14 us ... 110 us: an idle wave polls less and less (a worker that also serves the urgent lane: 14 ... 28 us)
+      for (int i = 0; i <= (naps < (ulane ? 1 : 7) ? naps : (ulane ? 1 : 7)); ++i) flow_pause();
+      ++naps;
+      if ((naps & 1) == 0 &&
+          __builtin_amdgcn_readfirstlane(__hip_atomic_load(&fl.hdr[FL_FINISHED], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >= all) {
+        desc = -2;
+        break;
+      }
+      if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0) break;
+      if (wall_clock64() - c0 > FLOW_TIMEOUT_TICKS) {
+        if (lane == 0) atomicExch(err, 15);
+        break;
+      }
+    }
     if (desc < 0) break;
+    const int n_r = urgent ? d.un_reset : d.n_reset, n_b = urgent ? d.un_bits : d.n_bits;
+    const int n_m = urgent ? d.un_marks : d.n_marks, n_s = urgent ? d.un_splat : d.n_splat;
+    const int S   = 1 + n_r + n_b + n_m + n_s;  // stage counts per (agent, tick); the agent's stage counter restarts at its head
+    unsigned long long *const wq      = urgent ? fl.uw : fl.mw;
+    int *const                wq_tail = &fl.hdr[urgent ? FL_UW_TAIL : FL_MW_TAIL];
     __threadfence();
     const long long c1 = wall_clock64();
     if (lane == 0 && c1_prev) {

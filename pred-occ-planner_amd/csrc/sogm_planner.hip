@@ -1221,7 +1221,7 @@ int sogm_flight_run(sogm_planner *p, const SogmFlight *f, void *stream) {
   if (fl.n_urgent > 0) {
     const int workers = p->fl_wgs[3] - md.n_head_wgs;
     md.n_uhead_wgs = md.n_head_wgs >= 8 ? 4 : md.n_head_wgs / 2;
-    md.n_uwork_wgs = c->tune_i(SOGM_TUNE_FLIGHT_URGENT_WAVES) < workers / 2 ? c->tune_i(SOGM_TUNE_FLIGHT_URGENT_WAVES) : workers / 2;
+    md.n_uwork_wgs = c->tune_i(SOGM_TUNE_FLIGHT_URGENT_WAVES) < workers ? c->tune_i(SOGM_TUNE_FLIGHT_URGENT_WAVES) : workers;
     if (md.n_uhead_wgs < 1 || md.n_uwork_wgs < 1) fl.n_urgent = 0, md.n_uhead_wgs = 0, md.n_uwork_wgs = 0;
   }
   md.n_admit     = c->tune_i(SOGM_TUNE_FLIGHT_ADMIT);

@@ -150,8 +150,9 @@ enum { FL_S_READY = 0 * FL_STRIDE, FL_S_TICKET = 1 * FL_STRIDE, FL_Q_READY = 2 *
 // in-order admission, 0.4 ms for a free head wave) and then shared the map workers with ~24 other maps (1.0 ms for a map
 // that takes 0.3 by itself).  The leaders have slack by definition, the laggards have none: an agent that finishes tick k
 // among the last `flight_urgent` of the swarm builds the map of its tick k + 1 through a lane of its own — `u_ring` ->
-// urgent heads (no admission order, no pace, no window) -> work queue `uw` -> workers that serve nothing else.  The cells,
-// records and logs do not depend on the schedule (the staleness rule fixes every input).
+// urgent heads (no admission order, no pace, no window) -> work queue `uw`, which the workers look at before they take
+// plain work and while they wait for it, in finer tickets.  The cells, records and logs do not depend on the schedule
+// (the staleness rule fixes every input).
 // Work queues (map kernel, corridor + finish kernel): ONE FIFO of ready work per kernel.  A producer reserves positions with
 // one atomicAdd on the tail and stores a descriptor per position, tagged with the position's generation; a consumer takes a
 // ticket with one atomicAdd on the head and waits for ITS position (idle waves therefore poll distinct words).  Every
@@ -329,7 +330,7 @@ struct FlightMapDev {
   int                   un_reset, un_bits, un_marks, un_splat;  // ... of a map in the urgent lane
   int                   n_head_wgs;    // workgroups 0 .. n_head_wgs - 1 of the launch admit agents (heads), the rest work off the queue
   int                   n_uhead_wgs;   // the first n_uhead_wgs of the heads serve the urgent ring
-  int                   n_uwork_wgs;   // the first n_uwork_wgs of the workers serve the urgent queue
+  int                   n_uwork_wgs;   // the first n_uwork_wgs of the workers look at the urgent queue first
   int                   n_admit;       // agents whose map may be under construction at once
   int                   pace_ticks;    // 100 MHz ticks between two admissions (0 = as fast as the heads run)
   size_t                agent_bytes;

@@ -91,11 +91,16 @@ def test_the_staleness_rule_flown_lockstep_against_the_oracle_stage_by_stage(pop
 
 
 def test_flight_with_and_without_masks_and_speculation_gives_the_same_records(pop):
-    """scheduling knobs must not change results: unmasked streams, sequential search attempts, other ticket counts"""
+    """scheduling knobs must not change results: unmasked streams, sequential search attempts, other ticket counts, the
+    urgent lane"""
     driver = importlib.import_module("pred-occ-planner_amd.driver")
     base = _flight(driver, "parity", 6, [6])
     for tuning in ({"flight_spec": 0}, {"flight_reset": 2, "flight_bits": 3, "flight_marks": 5, "flight_splat": 1},
-                   {"flight_qp_units": 2, "flight_search_units": 1, "flight_map_units": 6}):
+                   {"flight_qp_units": 2, "flight_search_units": 1, "flight_map_units": 6},
+                   # the urgent lane of the map kernel: none, a few agents with the plain ticket counts, nearly all
+                   # agents with the finest tickets on a handful of workers
+                   {"flight_urgent": 0}, {"flight_urgent": 2, "flight_urgent_fine": 1},
+                   {"flight_urgent": 5, "flight_urgent_waves": 7, "flight_urgent_fine": 16}):
         other = _flight(driver, "parity", 6, [6], tuning=tuning)
         assert np.array_equal(base[0], other[0]) and np.array_equal(base[1], other[1]), tuning
 
