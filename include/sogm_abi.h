@@ -250,7 +250,9 @@ int sogm_set_resample(sogm_ctx *ctx, float replan_risk_rate, int num_resample, c
  *     swarm waits for at the next gate — builds the map of its next tick through a lane of its own (four of the heads, no
  *     admission order / pace / window; a work queue of its own that the first "flight_urgent_waves" (4096 = all) map workers
  *     look at before they take plain work and while they wait for it; its maps are cut into "flight_urgent_fine" (4) times
- *     more tickets; 0 = no such lane).
+ *     more tickets; 0 = no such lane); "flight_gate_pace_us" (40): the staleness rule's gate — tick k reads the neighbours'
+ *     records of tick k - 2 — sits in front of a map's overlay, the only phase that reads them: an agent builds the rest of its
+ *     next map while it waits, and the finish that opens a gate queues the waiting overlays this many microseconds apart.
  *     None of these keys changes a cell or a record.
  *   sogm_update_world, experimental (measured, not adopted: profiles/EXPERIMENTS.md round 5):  "update_flow" (0; 1 = the
  *     maps are built agent by agent on a stream of the context's own — one persistent launch over one-wave tickets, per

@@ -2175,6 +2175,15 @@ __global__ __launch_bounds__(64) void k_flight_light(MapView m, SogmPlannerParam
                                                      FlightLightDev d) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int      lane  = threadIdx.x;
+  // ONE FIFO of 17 descriptors per agent-tick (16 corridor segments + the finish); a worker whose ticket lies beyond the
+  // flight's last descriptor leaves at once.  (Tried at the end of round 5 and taken back: a second, priority queue for the
+  // finishes — 50 us of work that end an agent's tick; in the FIFO they wait 0.1-0.2 ms behind corridor segments — which
+  // every worker looked at first and whose descriptor count per queue is not known in advance, so that the idle workers
+  // stayed resident until the call's end.  Single-process flights: records identical, finish 0.2 -> 0.05 ms per agent-tick,
+  // tick 6.99 -> 6.83 ms.  The two-rank flight of tests/test_exchange_gpu.py (two-tick calls): from the second call on two
+  // corridor segments per call stayed unprocessed for 3 s — with every exit rule tried (finished count, epoch word, both
+  // queues' known totals), with the queue's head / tail never reset, and NOT with all but 64 of the idle workers leaving
+  // early.  Unexplained; profiles/EXPERIMENTS.md.)
   const unsigned total = (unsigned)fl.n_agents * (unsigned)fl.n_ticks * (SOGM_MAX_PIECES + 1);
   int           *err   = &fl.hdr[FL_ERR];
   long long      c1_prev = 0;
@@ -2214,8 +2223,8 @@ __global__ __launch_bounds__(64) void k_flight_light(MapView m, SogmPlannerParam
         const long long now = wall_clock64();
         long long      *ts  = fl.ts + (size_t)a * FL_TS, *acc = fl.acc + (size_t)a * 8;
         ts[6]               = now;
-        acc[0] += ts[9] - ts[8];                       // gate wait
-        acc[1] += (ts[11] - ts[7]) - (ts[9] - ts[8]);  // map: from the head's publication to the complete map
+        acc[0] += ts[14] - ts[10];                       // gate wait: the overlay parked behind the finished marks
+        acc[1] += (ts[11] - ts[7]) - (ts[14] - ts[10]);  // map: from the head's publication to the complete map, less that
         acc[2] += ts[1] - ts[11];                      // search queue + A*
         acc[3] += ts[3] - ts[1];                       // corridor queue + corridors
         acc[4] += ts[5] - ts[3];                       // QP queue + QP
@@ -2227,43 +2236,41 @@ __global__ __launch_bounds__(64) void k_flight_light(MapView m, SogmPlannerParam
           for (int q = 0; q < FL_TS; ++q) lg[q] = ts[q];
         }
         finish_count(f, a, (code & 1) != 0);
-        // The gate of the staleness rule — tick j may start once EVERY agent has finished tick j - 2 — is kept here, on the
-        // producer side: an agent whose next tick is still gated is PARKED, not queued, and the finish that completes
-        // the awaited tick releases the parked heads.  (A first version queued every head and let the admitting waves
-        // wait at the gate: a leader at the head of the admission FIFO then held back the laggards queued behind it — the
-        // very agents it was waiting for — and the swarm settled at two ticks of spread and 12 ms per tick.)
+        // The gate of the staleness rule — tick j reads table ver(j - 2), so every agent must have finished tick j - 2 — sits
+        // in FRONT OF THE OVERLAY, the only phase of a map that reads the table (k_flight_map): an agent goes on to its next
+        // map head at once and builds reset / bits / marks while it waits; the overlay of a map that reaches the gate early
+        // is PARKED there, not queued, and the finish that completes the awaited tick queues the parked overlays.  (First
+        // version: the whole head parked at the gate.  A gate then released a burst of 20-60 heads into the admission order
+        // and the map workers at once, and the laggards arriving just then — the very agents the next gate waits for —
+        // queued behind it: parked + admission + map 1.9 ms per tick of the flight's critical path.)
         const int A_      = fl.n_agents;
         const int done_kl = __hip_atomic_fetch_add(&fl.tick_done[kl], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) + 1;
-        atomicAdd(&fl.hdr[FL_FINISHED], 1);
-        if (kl + 1 < fl.n_ticks) {  // the agent's next tick: its map head, now or when tick k - 1 is complete
+        if (atomicAdd(&fl.hdr[FL_FINISHED], 1) + 1 == A_ * fl.n_ticks)  // the call's last agent-tick: the map kernel's waves may go
+          __hip_atomic_store(&fl.hdr[FL_END], fl.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        if (kl + 1 < fl.n_ticks) {  // the agent's next tick: its map head, now
           fl.tick_of[a] = k + 1;
           ts[7]         = now;
-          const bool open = kl < 1 || __hip_atomic_load(&fl.tick_done[kl - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= A_;
-          // one of the last finishers of its tick (and so not gated): its next map goes through the urgent lane
-          const bool urgent = open && fl.n_urgent > 0 && done_kl > A_ - fl.n_urgent;
+          // one of the last finishers of its tick: its next map goes through the urgent lane
+          const bool urgent = fl.n_urgent > 0 && done_kl > A_ - fl.n_urgent;
           fl.urgent[a]      = urgent ? 1 : 0;
-          if (urgent) {
-            fl_publish(fl.u_ring, fl.ring_mask, &fl.hdr[FL_U_READY], a);
-          } else if (open) {
-            fl_publish(fl.m_ring, fl.ring_mask, &fl.hdr[FL_M_READY], a);
-          } else {
-            int      *lst  = fl.parked + (size_t)(kl + 1) * A_;
-            const int slot = atomicAdd(&fl.parked_n[kl + 1], 1);
-            __hip_atomic_store(&lst[slot], a, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-            __threadfence();
-            // (the releaser may have scanned the list before this slot was written)
-            if (__hip_atomic_load(&fl.tick_done[kl - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= A_ &&
-                atomicCAS(&lst[slot], a, -2) == a)
-              fl_publish(fl.m_ring, fl.ring_mask, &fl.hdr[FL_M_READY], a);
-          }
+          fl_publish(urgent ? fl.u_ring : fl.m_ring, fl.ring_mask, &fl.hdr[urgent ? FL_U_READY : FL_M_READY], a);
         }
-        if (done_kl == A_ && kl + 2 < fl.n_ticks) {  // tick k is complete: the heads of tick k + 2 parked so far may go
+        if (done_kl == A_ && kl + 2 < fl.n_ticks) {  // tick k is complete: the overlays of tick k + 2 parked so far may go
           __threadfence();
           int      *lst = fl.parked + (size_t)(kl + 2) * A_;
           const int n   = __hip_atomic_load(&fl.parked_n[kl + 2], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
           for (int i = 0; i < n && i < A_; ++i) {
             const int v = __hip_atomic_load(&lst[i], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-            if (v >= 0 && atomicCAS(&lst[i], v, -2) == v) fl_publish(fl.m_ring, fl.ring_mask, &fl.hdr[FL_M_READY], v);
+            if (v >= 0 && atomicCAS(&lst[i], v, -2) == v) {
+              const bool u                 = fl.urgent[v] != 0;
+              if (fl.gate_pace_ticks > 0 && i > 0) {
+                const long long p0 = wall_clock64();
+                while (wall_clock64() - p0 < fl.gate_pace_ticks) __builtin_amdgcn_s_sleep(32);
+              }
+              fl.ts[(size_t)v * FL_TS + 14] = wall_clock64();
+              wq_push(u ? fl.uw : fl.mw, &fl.hdr[u ? FL_UW_TAIL : FL_MW_TAIL], ((unsigned)WK_MAP_SPLAT << 28) | (unsigned)v,
+                      u ? fl.un_splat : fl.n_splat);
+            }
           }
         }
       }

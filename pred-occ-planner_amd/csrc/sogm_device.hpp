@@ -483,6 +483,7 @@ __device__ inline void bezier_pos(const SogmTrajRecord &r, double t, double out[
   X(FLIGHT_URGENT, "flight_urgent", 8, 0, 65536)           /* flight: the last n finishers of a tick build their next map in the urgent lane; 0 = none */ \
   X(FLIGHT_URGENT_WAVES, "flight_urgent_waves", 4096, 1, 4096) /* flight: map workers that look at the urgent queue first (all of them by default) */ \
   X(FLIGHT_URGENT_FINE, "flight_urgent_fine", 4, 1, 16)    /* flight: the urgent lane's maps in this many times more tickets  */  \
+  X(FLIGHT_GATE_PACE_US, "flight_gate_pace_us", 40, 0, 100000) /* flight: microseconds between two overlays a gate releases     */  \
   X(UPDATE_FLOW, "update_flow", 0, 0, 1)                   /* sogm_update_world builds the maps agent by agent on a stream of its own; sogm_replan's searches start per agent */ \
   X(UPDATE_BITS, "update_bits", 16, 1, 256)                /* update flow: one-wave tickets per agent, occupancy bits         */  \
   X(UPDATE_MARKS, "update_marks", 64, 1, 256)              /* update flow: ... marks                                          */  \

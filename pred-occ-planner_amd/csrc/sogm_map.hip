@@ -1608,7 +1608,7 @@ __global__ __launch_bounds__(64) void k_flight_map(GridGeom g, FlightCtl fl, Fli
   // (the urgent lane cuts a map into finer tickets: a map's latency is the sum of its phases' longest tickets — 0.25 reset +
   //  0.3 marks + 0.17 overlay ms with the plain lane's counts even on idle workers — and the urgent lane exists for latency)
   int      *err = &fl.hdr[FL_ERR];
-  const int all = A * fl.n_ticks;  // agent-ticks of the flight: every lane of this kernel ends when FL_FINISHED reaches it
+  // (every lane of this kernel ends when the call's last finish has stored the call's epoch in hdr[FL_END])
   if ((int)blockIdx.x < d.n_head_wgs) {
     // ---- admitting waves: heads, in the order the agents' previous ticks finished; the first n_uhead_wgs serve the
     // urgent ring: no admission order, no pace, no window (the gate is open for an agent that is behind) ----
@@ -1618,7 +1618,7 @@ __global__ __launch_bounds__(64) void k_flight_map(GridGeom g, FlightCtl fl, Fli
     int *const                wq_tail = &fl.hdr[urgent ? FL_UW_TAIL : FL_MW_TAIL];
     for (;;) {
       const int t     = flow_ticket(&fl.hdr[urgent ? FL_U_TICKET : FL_M_TICKET]);
-      const int agent = fl_wait_item_end(urgent ? fl.u_ring : fl.m_ring, fl.ring_mask, t, err, &fl.hdr[FL_FINISHED], all, !urgent);
+      const int agent = fl_wait_item_end(urgent ? fl.u_ring : fl.m_ring, fl.ring_mask, t, err, &fl.hdr[FL_END], fl.epoch, !urgent);
       if (agent < 0) break;
       __threadfence();
       const int          k = fl.tick_of[agent], kl = k - fl.first_tick;
@@ -1650,7 +1650,6 @@ __global__ __launch_bounds__(64) void k_flight_map(GridGeom g, FlightCtl fl, Fli
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       }
       if (!urgent && flow_wait_count(&fl.hdr[FL_MAPS_DONE], t - d.n_admit + 1, err)) break;
-      if (kl >= 2 && flow_wait_count(&fl.tick_done[kl - 2], A, err)) break;
       if (!urgent && lane == 0) {
         long long *pc = reinterpret_cast<long long *>(&fl.hdr[FL_PACE_CLOCK]);
         while (wall_clock64() - *pc < d.pace_ticks) __builtin_amdgcn_s_sleep(16);
@@ -1693,64 +1692,15 @@ __global__ __launch_bounds__(64) void k_flight_map(GridGeom g, FlightCtl fl, Fli
   // kernel is the bottleneck paid for (300^3 x 30: 11.5 -> 13.7 ms per tick).  A map stays in the lane its head put it in:
   // the next phase's descriptors go into the queue the finished one came from. ----
   const bool ulane = (int)blockIdx.x - d.n_head_wgs < d.n_uwork_wgs;
-  bool       have_plain = false;
-  unsigned   plain_t    = 0;
-  int        seen_uh    = 0;
+  WqWorker   ww;
   long long c1_prev = 0;
   int       kind_prev = 0;
   for (;;) {
-    const long long c0   = wall_clock64();
-    int             desc = -1;
+    const long long c0     = wall_clock64();
     bool            urgent = false;
-    for (int naps = 0;;) {
-      if (ulane) {
-        const int ut = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&fl.hdr[FL_UW_TAIL], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        if (ut - seen_uh > 0) {
-          const int h = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&fl.hdr[FL_UW_HEAD], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-          seen_uh     = h;
-          if (ut - h > 0) {
-            int got = 0;
-            if (lane == 0) {
-              int e = h;
-              got   = __hip_atomic_compare_exchange_strong(&fl.hdr[FL_UW_HEAD], &e, h + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
-                                                           __HIP_MEMORY_SCOPE_AGENT) ? 1 : 0;
-            }
-            if (__builtin_amdgcn_readfirstlane(got)) {  // position h is reserved by its producer: the descriptor is there or about to be
-              desc   = wq_take_end(fl.uw, (unsigned)h, err, &fl.hdr[FL_FINISHED], all, false);
-              urgent = true;
-              break;
-            }
-          }
-        }
-      }
-      if (!have_plain) {
-        plain_t    = (unsigned)flow_ticket(&fl.hdr[FL_MW_HEAD]);
-        have_plain = true;
-      }
-      {
-        const unsigned long long v  = __hip_atomic_load(fl.mw + (plain_t % FL_WQ_SLOTS), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned           hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-        if (hi == plain_t / FL_WQ_SLOTS + 1u) {
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-          desc       = (int)__builtin_amdgcn_readfirstlane((unsigned)v);
-          have_plain = false;
-          break;
-        }
-      }
-      // 14 us ... 110 us: an idle wave polls less and less (a worker that also serves the urgent lane: 14 ... 28 us)
-      for (int i = 0; i <= (naps < (ulane ? 1 : 7) ? naps : (ulane ? 1 : 7)); ++i) flow_pause();
-      ++naps;
-      if ((naps & 1) == 0 &&
-          __builtin_amdgcn_readfirstlane(__hip_atomic_load(&fl.hdr[FL_FINISHED], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >= all) {
-        desc = -2;
-        break;
-      }
-      if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0) break;
-      if (wall_clock64() - c0 > FLOW_TIMEOUT_TICKS) {
-        if (lane == 0) atomicExch(err, 15);
-        break;
-      }
-    }
+    // (a worker that also serves the urgent lane naps 14 ... 28 us between two looks, the others up to 110)
+    const int desc = wq_take2(fl.mw, &fl.hdr[FL_MW_HEAD], fl.uw, &fl.hdr[FL_UW_TAIL], &fl.hdr[FL_UW_HEAD], ww, ulane, ulane ? 1 : 7,
+                              err, &fl.hdr[FL_END], fl.epoch, urgent);
     if (desc < 0) break;
     const int n_r = urgent ? d.un_reset : d.n_reset, n_b = urgent ? d.un_bits : d.n_bits;
     const int n_m = urgent ? d.un_marks : d.n_marks, n_s = urgent ? d.un_splat : d.n_splat;
@@ -1803,8 +1753,27 @@ __global__ __launch_bounds__(64) void k_flight_map(GridGeom g, FlightCtl fl, Fli
       __syncthreads();  // (the next descriptor's staging overwrites s_cand)
       __threadfence();
       if (lane == 0 && atomicAdd(&fl.stage[agent], 1) + 1 == 1 + n_r + n_b + n_m) {
-        ts[10] = wall_clock64();
-        wq_push(wq, wq_tail, ((unsigned)WK_MAP_SPLAT << 28) | adr, n_s);
+        const long long now = wall_clock64();
+        ts[10] = now;
+        if (!urgent) atomicAdd(&fl.hdr[FL_MAPS_DONE], 1);  // one more agent may be admitted (a map at the gate holds no worker)
+        // the gate of the staleness rule: the overlay reads table ver(k - 2) — every agent must have finished tick k - 2.
+        // Early: the overlay is parked, and the finish that completes that tick queues it (k_flight_light).
+        const bool open = kl < 2 || __hip_atomic_load(&fl.tick_done[kl - 2], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= A;
+        if (open) {
+          ts[14] = now;
+          wq_push(wq, wq_tail, ((unsigned)WK_MAP_SPLAT << 28) | adr, n_s);
+        } else {
+          int      *lst  = fl.parked + (size_t)kl * A;
+          const int slot = atomicAdd(&fl.parked_n[kl], 1);
+          __hip_atomic_store(&lst[slot], agent, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+          __threadfence();
+          // (the releaser may have scanned the list before this slot was written)
+          if (__hip_atomic_load(&fl.tick_done[kl - 2], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= A &&
+              atomicCAS(&lst[slot], agent, -2) == agent) {
+            ts[14] = wall_clock64();
+            wq_push(wq, wq_tail, ((unsigned)WK_MAP_SPLAT << 28) | adr, n_s);
+          }
+        }
       }
     } else {  // WK_MAP_SPLAT: the neighbours' records of table ver(k - 2)
       if (d.tables && d.n_total > 0) {
@@ -1817,7 +1786,6 @@ __global__ __launch_bounds__(64) void k_flight_map(GridGeom g, FlightCtl fl, Fli
       if (lane == 0 && atomicAdd(&fl.stage[agent], 1) + 1 == S) {  // the agent's map of tick k is complete
         ts[11] = wall_clock64();
         fl_publish(fl.s_ring, fl.ring_mask, &fl.hdr[FL_S_READY], agent);
-        if (!urgent) atomicAdd(&fl.hdr[FL_MAPS_DONE], 1);  // one more agent may be admitted (the window counts the plain lane's maps)
       }
     }
   }

@@ -996,7 +996,15 @@ static int replan_impl(sogm_planner *p, const double *start_pva, const double *g
 __global__ __launch_bounds__(256) void k_flight_reset(FlightCtl fl, int n_words, int *verdict, long long *acc, int *log_words,
                                                       long long n_log_words) {
   const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x, step = (long long)gridDim.x * blockDim.x;
-  for (long long i = i0; i < n_words; i += step) fl.hdr[i] = 0;  // header, rings, tick_done, tick_of, seg_done, stage: one block
+  // header, rings, plain queues, tick_done, tick_of, seg_done, stage: one block.  NOT the head / tail words of the urgent
+  // queue: its consumers decide "a descriptor is there" by LOADING tail and head (every other hand-over of the flight is a
+  // read-modify-write or a generation-tagged slot), so the queue runs on over the planner's life instead of restarting
+  // with every call: positions only grow (modulo 2^32; a slot's generation tag follows its position), and a value a
+  // consumer reads late can only be LOWER than the true one — it then looks again — never claim a descriptor that
+  // does not exist yet.
+  for (long long i = i0; i < n_words; i += step)
+    if (i != FL_UW_TAIL && i != FL_UW_HEAD) fl.hdr[i] = 0;
+  if (i0 == 0) fl.hdr[FL_UW_HEAD] = fl.hdr[FL_UW_TAIL];  // (descriptors an aborted call left behind are skipped)
   for (long long i = i0; i < n_log_words; i += step) log_words[i] = 0;
   for (long long i = i0; i < fl.n_agents; i += step) verdict[i] = 0;
   for (long long i = i0; i < 8ll * fl.n_agents; i += step) acc[i] = 0;
@@ -1031,8 +1039,9 @@ static int flight_setup(sogm_planner *p) {
   while (ring < 2 * A) ring <<= 1;
   if (A >= (1 << 16)) return SOGM_ERR_INVALID_ARG;
   const size_t words = FL_HDR + 4 * (size_t)ring + 6 * (size_t)FL_WQ_SLOTS + 2 * FLIGHT_MAX_TICKS + 4 * (size_t)A +
-                       (size_t)FLIGHT_MAX_TICKS * A;
+                       (size_t)FLIGHT_MAX_TICKS * A + 2;
   SOGM_HIP_CHECK(hipMalloc((void **)&p->d_fl, sizeof(int) * words));
+  SOGM_HIP_CHECK(hipMemset(p->d_fl, 0, sizeof(int) * words));  // (once: the urgent / priority queues start empty at position 0)
   int *q          = p->d_fl;
   p->fl.hdr       = q;              q += FL_HDR;
   p->fl.s_ring    = q;              q += ring;
@@ -1041,14 +1050,16 @@ static int flight_setup(sogm_planner *p) {
   p->fl.u_ring    = q;              q += ring;
   p->fl.mw        = reinterpret_cast<unsigned long long *>(q);  q += 2 * FL_WQ_SLOTS;  // (FL_HDR and 4 x ring are even: 8-byte aligned)
   p->fl.lw        = reinterpret_cast<unsigned long long *>(q);  q += 2 * FL_WQ_SLOTS;
-  p->fl.uw        = reinterpret_cast<unsigned long long *>(q);  q += 2 * FL_WQ_SLOTS;
   p->fl.tick_done = q;              q += FLIGHT_MAX_TICKS;
   p->fl.parked_n  = q;              q += FLIGHT_MAX_TICKS;
   p->fl.tick_of   = q;              q += A;
   p->fl.seg_done  = q;              q += A;
   p->fl.stage     = q;              q += A;
   p->fl.urgent    = q;              q += A;
-  p->fl.parked    = q;
+  p->fl.parked    = q;              q += (size_t)FLIGHT_MAX_TICKS * A;
+  // (behind everything a call resets: the urgent / priority queues and their head / tail words are NOT reset — below)
+  if ((q - p->d_fl) & 1) q += 1;
+  p->fl.uw        = reinterpret_cast<unsigned long long *>(q);  q += 2 * FL_WQ_SLOTS;
   p->fl.ring_mask = ring - 1;
   p->fl.n_agents  = A;
   SOGM_HIP_CHECK(hipMalloc((void **)&p->fl.ts, sizeof(long long) * FL_TS * (size_t)A));
@@ -1218,6 +1229,11 @@ int sogm_flight_run(sogm_planner *p, const SogmFlight *f, void *stream) {
     md.un_marks = cut(md.n_marks, 256);
     md.un_splat = cut(md.n_splat, 64);
   }
+  fl.gate_pace_ticks = (int)(c->tune[SOGM_TUNE_FLIGHT_GATE_PACE_US] * 100.0);
+  p->fl_epoch = p->fl_epoch >= 0x7ffffff0 ? 1 : p->fl_epoch + 1;  // (never 0: the zeroed word)
+  fl.epoch    = p->fl_epoch;
+  fl.n_splat  = md.n_splat;
+  fl.un_splat = md.un_splat;
   if (fl.n_urgent > 0) {
     const int workers = p->fl_wgs[3] - md.n_head_wgs;
     md.n_uhead_wgs = md.n_head_wgs >= 8 ? 4 : md.n_head_wgs / 2;
@@ -1232,7 +1248,7 @@ int sogm_flight_run(sogm_planner *p, const SogmFlight *f, void *stream) {
   // frames + control block, in stream order on the caller's stream
   SOGM_HIP_CHECK(hipMemcpyAsync(p->d_fl_worlds, p->h_fl_worlds, sizeof(FlightWorld) * (size_t)f->n_ticks, hipMemcpyHostToDevice, main));
   const int       ring    = p->fl.ring_mask + 1;
-  const int       n_words = FL_HDR + 4 * ring + 6 * FL_WQ_SLOTS + 2 * FLIGHT_MAX_TICKS + 4 * A;  // (the parked lists: k_flight_seed)
+  const int       n_words = FL_HDR + 4 * ring + 4 * FL_WQ_SLOTS + 2 * FLIGHT_MAX_TICKS + 4 * A;  // (the parked lists: k_flight_seed)
   const long long n_log   = (long long)f->n_ticks * A * (long long)(sizeof(SogmTrajRecord) / sizeof(int));
   hipLaunchKernelGGL(k_flight_reset, dim3(256), dim3(256), 0, main, fl, n_words, p->aw.verdict, p->fl.acc,
                      reinterpret_cast<int *>(f->log_records), n_log);

@@ -117,10 +117,10 @@ __device__ inline int flow_ticket(int *counter) {  // one ticket per wave, unifo
 //                    waves take agents in the order their previous tick finished and let `flight_admit` maps be under
 //                    construction at once: agents leave the map stage one after the other and stay spread over the stages
 //                    — a swarm whose agents all share every stage equally moves in step, and then every kernel's compute
-//                    units idle while another kernel's are busy.  Head (gate on
-//                    tick k - 2, start state from the own record, cull of cylinders and cloud blocks of the tick's
-//                    SogmWorld frame) -> sparse reset of the agent's grid through its mark log + occupancy bits -> marks
-//                    -> neighbour overlay -> s_ring
+//                    units idle while another kernel's are busy.  Head (start state from the own record, cull of
+//                    cylinders and cloud blocks of the tick's SogmWorld frame) -> sparse reset of the agent's grid through its
+//                    mark log + occupancy bits -> marks -> [gate: every agent has finished tick k - 2] -> neighbour overlay
+//                    (the only phase that reads table ver(k - 2)) -> s_ring
 //   k_flight_search  one workgroup per (agent, attempt) ticket: hybrid A* (both attempts side by side) -> 16 corridor descriptors
 //   k_flight_light   role-less one-wave workgroups over ONE work queue: corridor segments (-> q_ring) and finish items
 //                    (deconfliction, record, publication, tick accounting, the agent's next map head descriptor)
@@ -143,7 +143,8 @@ enum { FL_S_READY = 0 * FL_STRIDE, FL_S_TICKET = 1 * FL_STRIDE, FL_Q_READY = 2 *
        FL_PACE_CLOCK = 14 * FL_STRIDE,                              // (two words) wall clock of the last admission
        FL_U_READY = 15 * FL_STRIDE, FL_U_TICKET = 16 * FL_STRIDE,   // urgent lane (below): heads published / taken
        FL_UW_TAIL = 17 * FL_STRIDE, FL_UW_HEAD = 18 * FL_STRIDE,    // urgent lane: map descriptors pushed / tickets taken
-       FL_COUNTERS = 19, FL_HDR = 19 * FL_STRIDE };
+       FL_END = 19 * FL_STRIDE,                                     // the epoch of the call whose last agent-tick is finished
+       FL_COUNTERS = 20, FL_HDR = 20 * FL_STRIDE };
 // The urgent lane of the map kernel.  The flight's rate is the rate of its SLOWEST agent's own chain (tools/diag_flight.py:
 // the critical path follows one agent with long corridors / QPs for many ticks in a row), and that agent — always behind,
 // never gated — queued like everybody else: behind a burst of leaders the gate had just released (up to 1.3 ms in the
@@ -179,15 +180,24 @@ struct FlightCtl {
   int  ring_mask;
   int *urgent;      // [A] 1: the agent's current tick goes through the urgent lane
   int  n_urgent;    // an agent among the last n_urgent finishers of a tick is urgent in its next one (0: no urgent lane)
+  int  n_splat, un_splat;  // overlay tickets of a map in the plain / the urgent lane (the finish that opens a gate queues them)
+  int  epoch;              // this call's number (never 0, never repeated while the planner lives): the waves whose work has
+                           // no known count leave when hdr[FL_END] holds it — a word the call's last finish stores, compared for
+                           // EQUALITY, so that a value left by an earlier call can end nothing (the counters are zeroed by a
+                           // kernel before the flight's kernels start, but a poll is a load, and "FINISHED >= all" would
+                           // hold for the previous call's final count)
+  int  gate_pace_ticks;    // 100 MHz ticks between two overlays that a gate releases (they reach the search and the corridors
+                           // one after the other instead of as a burst)
   int *tick_done;   // [FLIGHT_MAX_TICKS] agents that have finished tick first_tick + i
-  int *parked_n;    // [FLIGHT_MAX_TICKS] heads of tick first_tick + i parked at the gate "tick i - 2 is complete" ...
+  int *parked_n;    // [FLIGHT_MAX_TICKS] maps of tick first_tick + i whose overlay is parked at the gate "tick i - 2 is complete" ...
   int *parked;      // [FLIGHT_MAX_TICKS][A] ... the agents (-1 empty, -2 released)
   int *tick_of;     // [A] the tick the agent is in (absolute index)
   int *seg_done;    // [A] cumulative corridor segment slots finished
   int *stage;       // [A] cumulative map tickets finished
   long long *ts;    // [A][FL_TS] stamps of the agent's current tick: 0 A* start, 1 A* done, 2 first corridor item, 3 corridors
                     //         final, 4 QP start, 5 QP done, 6 finished, 7 map item published, 8 map head start, 9 gate passed, 10 marks done, 11 map ready,
-                    //         12 head done (reset / bits tickets queued), 13 grid reset and bits set (marks tickets queued)
+                    //         12 head done (reset / bits tickets queued), 13 grid reset and bits set (marks tickets queued),
+                    //         14 overlay tickets queued (the gate "tick k - 2 is complete" lies between 10 and 14)
   long long *acc;   // [A][8] sums over the flight (100 MHz ticks): gate wait, map, search queue + A*, corridors, QP queue + QP,
                     //        finish, whole chain, ticks completed
   long long *ts_log;         // [FLIGHT_MAX_TICKS][A][FL_TS] every agent-tick's stamps (sogm_debug_flight_times)
@@ -221,9 +231,9 @@ __device__ inline int fl_wait_item(const int *ring, int mask, int pos, int *err)
   }
 }
 // the same for the map kernel's lanes, whose item counts are not known in advance (an agent-tick goes through the plain or
-// the urgent lane): -2 once every agent-tick of the flight is finished; `timed` = false: no time limit of its own (the
+// the urgent lane): -2 once the call's last agent-tick is finished (hdr[FL_END] == epoch); `timed` = false: no time limit of its own (the
 // urgent lane may see no item for a whole flight; a stalled flight ends through the other waiters' limits and `err`)
-__device__ inline int fl_wait_item_end(const int *ring, int mask, int pos, int *err, const int *finished, int all, bool timed) {
+__device__ inline int fl_wait_item_end(const int *ring, int mask, int pos, int *err, const int *end_word, int epoch, bool timed) {
   const int       want = (pos / (mask + 1)) + 1;
   const long long t0   = wall_clock64();
   for (;;) {
@@ -236,10 +246,10 @@ __device__ inline int fl_wait_item_end(const int *ring, int mask, int pos, int *
       flow_pause();
     else
       __builtin_amdgcn_s_sleep(127);  // (the few urgent heads poll every 3.4 us)
-    if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(finished, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >= all) return -2;
+    if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(end_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == epoch) return -2;
     if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0) return -1;
     if (timed && wall_clock64() - t0 > FLOW_TIMEOUT_TICKS) {
-      if ((threadIdx.x & 63) == 0) atomicExch(err, 12);
+      if ((threadIdx.x & 63) == 0) atomicExch(err, 17);
       return -1;
     }
   }
@@ -276,7 +286,7 @@ __device__ inline int wq_take(const unsigned long long *wq, unsigned pos, int *e
   }
 }
 // the same with the end-of-flight exit (see fl_wait_item_end): -2 = every agent-tick is finished
-__device__ inline int wq_take_end(const unsigned long long *wq, unsigned pos, int *err, const int *finished, int all, bool timed) {
+__device__ inline int wq_take_end(const unsigned long long *wq, unsigned pos, int *err, const int *end_word, int epoch, bool timed) {
   const unsigned  want = pos / FL_WQ_SLOTS + 1u;
   const long long t0   = wall_clock64();
   int             naps = 0;
@@ -294,12 +304,73 @@ __device__ inline int wq_take_end(const unsigned long long *wq, unsigned pos, in
     }
     ++naps;
     if ((naps & (timed ? 1 : 7)) == 0 &&
-        __builtin_amdgcn_readfirstlane(__hip_atomic_load(finished, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >= all)
+        __builtin_amdgcn_readfirstlane(__hip_atomic_load(end_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == epoch)
       return -2;
     if ((timed || (naps & 7) == 0) &&
         __builtin_amdgcn_readfirstlane(__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0)
       return -1;
     if (timed && wall_clock64() - t0 > FLOW_TIMEOUT_TICKS) {
+      if ((threadIdx.x & 63) == 0) atomicExch(err, 15);
+      return -1;
+    }
+  }
+}
+// A worker of a kernel with a plain FIFO and a priority queue.  It holds a ticket of the plain queue, as wq_take's callers do,
+// and looks at the priority queue first — before it takes its plain descriptor and while it waits for it — claiming a
+// priority descriptor that is THERE with a compare-and-swap on that queue's head (never a ticket for one that is not: a
+// worker must not be lost to the plain queue waiting for priority work; one try per look, so the waves do not spin on the
+// counter).  Returns the descriptor (>= 0; `prio` says from which queue), -2 once every agent-tick of the flight is finished
+// (the queues' item counts are not known in advance), -1 if the flight failed.  Wave-uniform.
+struct WqWorker {
+  bool     have_plain = false;
+  unsigned plain_t    = 0;
+  int      seen_ph    = 0;
+};
+__device__ inline int wq_take2(const unsigned long long *plain, int *plain_head, const unsigned long long *prioq, int *prio_tail,
+                               int *prio_head, WqWorker &w, bool look, int max_naps, int *err, const int *end_word, int epoch,
+                               bool &prio) {
+  const long long t0 = wall_clock64();
+  prio               = false;
+  for (int naps = 0;;) {
+    if (look) {
+      const int pt = __builtin_amdgcn_readfirstlane(__hip_atomic_load(prio_tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      if (pt - w.seen_ph > 0) {
+        const int h = __builtin_amdgcn_readfirstlane(__hip_atomic_load(prio_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        w.seen_ph   = h;
+        if (pt - h > 0) {
+          int got = 0;
+          if ((threadIdx.x & 63) == 0) {
+            int e = h;
+            got   = __hip_atomic_compare_exchange_strong(prio_head, &e, h + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                         __HIP_MEMORY_SCOPE_AGENT) ? 1 : 0;
+          }
+          if (__builtin_amdgcn_readfirstlane(got)) {  // position h is reserved by its producer: the descriptor is there or about to be
+            prio = true;
+            return wq_take_end(prioq, (unsigned)h, err, end_word, epoch, false);
+          }
+        }
+      }
+    }
+    if (!w.have_plain) {
+      w.plain_t    = (unsigned)flow_ticket(plain_head);
+      w.have_plain = true;
+    }
+    {
+      const unsigned long long v  = __hip_atomic_load(plain + (w.plain_t % FL_WQ_SLOTS), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned           hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+      if (hi == w.plain_t / FL_WQ_SLOTS + 1u) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        w.have_plain = false;
+        return (int)__builtin_amdgcn_readfirstlane((unsigned)v);
+      }
+    }
+    for (int i = 0; i <= (naps < max_naps ? naps : max_naps); ++i) flow_pause();  // 14 us ... an idle wave polls less and less
+    ++naps;
+    if ((naps & 1) == 0 &&
+        __builtin_amdgcn_readfirstlane(__hip_atomic_load(end_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == epoch)
+      return -2;
+    if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0) return -1;
+    if (wall_clock64() - t0 > FLOW_TIMEOUT_TICKS) {
       if ((threadIdx.x & 63) == 0) atomicExch(err, 15);
       return -1;
     }
@@ -539,4 +610,5 @@ struct sogm_planner {
   hipEvent_t          fl_ev_in, fl_ev_done[4];
   int                 fl_cus[4];     // compute units of each stream's mask
   int                 fl_wgs[4];     // workgroups of each kernel
+  int                 fl_epoch = 0;  // number of the last sogm_flight_run call (FlightCtl::epoch)
 };

@@ -31,8 +31,8 @@ assert lib.sogm_debug_flight_times(sw.planner._p, ts.ctypes.data_as(C.c_void_p),
 t0 = ts[:, :, 7].min()
 ms = (ts - t0) / 1e5
 names = ["A*start", "A*done", "corr1st", "corrFinal", "QPstart", "QPdone", "finished", "published", "headStart", "admitted",
-         "marksDone", "mapReady"]
-order = [7, 8, 9, 10, 11, 0, 1, 2, 3, 4, 5, 6]
+         "marksDone", "mapReady", "headDone", "bitsDone", "splatQueued"]
+order = [7, 8, 9, 10, 14, 11, 0, 1, 2, 3, 4, 5, 6]
 print("flight of", ticks, "ticks:", round(ms[:, :, 6].max(), 2), "ms =", round(ms[:, :, 6].max() / ticks, 2), "ms per tick")
 print("mean interval between consecutive stamps (ms):")
 for a, b in zip(order[:-1], order[1:]):
@@ -64,27 +64,31 @@ QP_ITERS = sw.planner.last_qp_iterations() if hasattr(sw.planner, "last_qp_itera
 k, a = ticks - 1, int(np.argmax(ms[ticks - 1, :, 6]))
 path = []
 while k >= 0:
-    pub, hs, adm, mr = ms[k, a, 7], ms[k, a, 8], ms[k, a, 9], ms[k, a, 11]
-    seg = {"tick": k, "agent": a, "parked": hs - pub, "admission": adm - hs, "map": mr - adm, "search": ms[k, a, 1] - mr,
-           "corridor": ms[k, a, 3] - ms[k, a, 1], "qp": ms[k, a, 5] - ms[k, a, 3], "finish": ms[k, a, 6] - ms[k, a, 5]}
+    pub, hs, adm, mk, sp, mr = ms[k, a, 7], ms[k, a, 8], ms[k, a, 9], ms[k, a, 10], ms[k, a, 14], ms[k, a, 11]
+    seg = {"tick": k, "agent": a, "parked": hs - pub, "admission": adm - hs, "map": (mk - adm) + (mr - sp), "gate": 0.0,
+           "search": ms[k, a, 1] - mr, "corridor": ms[k, a, 3] - ms[k, a, 1], "qp": ms[k, a, 5] - ms[k, a, 3],
+           "finish": ms[k, a, 6] - ms[k, a, 5]}
     gate_open = ms[k - 2, :, 6].max() if k >= 2 else -1.0
-    if k >= 2 and gate_open >= pub - 1e-3:   # the head was parked until the gate opened: go to the last finisher of k - 2
+    if k >= 2 and gate_open > mk + 1e-3:   # the overlay was parked until the gate opened: go to the last finisher of k - 2
         seg["edge"] = "gate"
-        seg["parked"] = hs - gate_open
+        seg["parked"] = seg["admission"] = 0.0
+        seg["gate"] = sp - gate_open           # hand-over from the finish that opened the gate
+        seg["map"] = mr - sp                   # (only the overlay is on the path)
         path.append(seg)
         a = int(np.argmax(ms[k - 2, :, 6]))
         k -= 2
     else:
         seg["edge"] = "own"
+        seg["gate"] = sp - mk
         path.append(seg)
         k -= 1
 path.reverse()
 print("critical path (edge = how the agent-tick was reached; ms):")
 tot = {}
 for s_ in path:
-    print("  tick %2d agent %3d via %-4s parked %.2f adm %.2f map %.2f A* %.2f corr %.2f qp %.2f fin %.2f" % (
-        s_["tick"], s_["agent"], s_["edge"], s_["parked"], s_["admission"], s_["map"], s_["search"], s_["corridor"], s_["qp"], s_["finish"]))
-    for key in ("parked", "admission", "map", "search", "corridor", "qp", "finish"):
+    print("  tick %2d agent %3d via %-4s parked %.2f adm %.2f map %.2f gate %.2f A* %.2f corr %.2f qp %.2f fin %.2f" % (
+        s_["tick"], s_["agent"], s_["edge"], s_["parked"], s_["admission"], s_["map"], s_["gate"], s_["search"], s_["corridor"], s_["qp"], s_["finish"]))
+    for key in ("parked", "admission", "map", "gate", "search", "corridor", "qp", "finish"):
         tot[key] = tot.get(key, 0.0) + s_[key]
 print("critical path totals (ms):", {k_: round(v, 2) for k_, v in tot.items()}, "sum", round(sum(tot.values()), 2),
       "own edges", sum(1 for s_ in path if s_["edge"] == "own"), "gate edges", sum(1 for s_ in path if s_["edge"] == "gate"))
