@@ -218,6 +218,18 @@ def main():
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    # configs[3]'s rank share (tools/bench_rank_share.py): the ring neighbours of the rank this GPU will play fly in child
+    # processes NOW, before this process holds a hardware queue (they exit before the first tick here); their per-tick rows
+    # are replayed in the configs block at the end
+    share_rows, share_err = None, None
+    if world == 1 and not launched and not args.no_variants and args.grid == "cfg2" and args.agents is None:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        rank_share = importlib.import_module("bench_rank_share")
+        try:
+            import tempfile
+            share_rows = rank_share.neighbour_rows(tempfile.mkdtemp(prefix="sogm_rows_"))
+        except Exception as e:  # noqa: BLE001  (the headline does not depend on it: say so in the block instead)
+            share_err = str(e)[-400:]
     A_loc = args.agents if args.agents is not None else pop.config.AGENTS[args.grid]
     # The world moves: every tick's update takes that tick's sensor frame (scene.WorldTimeline: cylinders advanced by v dt,
     # their cloud points with them) and crops it on the device around the agent's current map centre.  All frames of the
@@ -733,6 +745,13 @@ def main():
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         bench_dsp = importlib.import_module("bench_dsp")
         cfgs["cfg1"] = bench_dsp.run("cfg1", None, 30, 5)
+        if share_rows is not None:
+            try:
+                cfgs["cfg3_rank_share"] = rank_share.run(rows_file=share_rows)
+            except Exception as e:  # noqa: BLE001
+                cfgs["cfg3_rank_share"] = {"error": str(e)[-400:]}
+        elif share_err is not None:
+            cfgs["cfg3_rank_share"] = {"error": share_err}
         out["configs"] = cfgs
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(pop, spec, scene_kept, args.cpu_agents)

@@ -114,6 +114,53 @@ class RecordExchange:
             self.handle = None
 
 
+class LoopbackHub:
+    """Several ranks of ONE swarm flown by one process on one device, one rank after the other within a tick (bench.py's
+    configs[3] rank share; tests/test_rank_share_gpu.py): stands where the collective stands.  Each rank's SwarmTick
+    gets hub.exchange(rank); its all_gather() only STAGES the rank's rows, and hub.commit() — called once every
+    co-simulated rank has stepped tick k — writes every staged row block into every rank's table.  So the table a rank
+    reads during tick k is ver(k - 1) of all co-simulated ranks, exactly what the all-gather leaves behind
+    (plan_manager.cpp:364-399 -> particles.cpp:131-191, one tick stale); rows of ranks that are not co-simulated stay
+    empty records ("nothing received from that drone yet")."""
+
+    def __init__(self, world, agents_per_rank):
+        self.world, self.A_loc, self.staged = world, agents_per_rank, {}
+
+    def exchange(self, rank):
+        return _LoopbackExchange(self, rank)
+
+    def commit(self, replayed=None):
+        """`replayed`: {rank: rows} of ranks that are not flown live this time — their rows of this tick from an earlier
+        pass (tools/bench_rank_share.py: one process cannot hold three planners' streams without sharing hardware
+        queues, so one ring neighbour flies live and the other is replayed)."""
+        rows = {s: own for s, (own, _) in self.staged.items()}
+        rows.update(replayed or {})
+        for _, (_, table) in self.staged.items():
+            for s, own in rows.items():
+                lo, hi = shard_bounds(s, self.world, self.A_loc)
+                table[lo:hi].copy_(own)
+        self.staged = {}
+
+
+class _LoopbackExchange:
+    active, fallback_reason = True, None
+
+    def __init__(self, hub, rank):
+        self.hub, self.rank = hub, rank
+
+    def info(self):
+        return {"ranks": self.hub.world, "rank": self.rank}
+
+    def all_gather(self, own, all_records):
+        self.hub.staged[self.rank] = (own, all_records)
+
+    def wait(self):
+        pass
+
+    def close(self):
+        pass
+
+
 def merge_latest(new, old, ok):
     """latest-wins per drone (particles.cpp:179-190); a failed replan keeps the previous trajectory
     (the FSM keeps executing it, plan_manager.cpp:176-196)."""
