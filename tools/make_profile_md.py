@@ -149,7 +149,10 @@ corridors {ch.get('corridor_mean', 0):.2f} / {ch.get('corridor_max', 0):.2f}, QP
 {ch.get('chain_mean', 0):.2f}, chain end {ch.get('chain_end', 0):.2f} (critical agent {ch.get('critical_agent')}: {json.dumps(ch.get('critical_chain'))}).
 Other configurations in the same line: cfg4 {json.dumps({k: (round(v, 2) if isinstance(v, float) else v) for k, v in (cfgs.get('cfg4') or {}).items() if k not in ('roofline', 'workload')})},
 reset roofline {json.dumps((cfgs.get('cfg4') or {}).get('roofline'))}; cfg1 {(cfgs.get('cfg1') or {}).get('ms_per_frame', 0):.2f} ms per frame, stages
-{json.dumps((cfgs.get('cfg1') or {}).get('stage_ms'))}, `k_dsp_publish` {((cfgs.get('cfg1') or {}).get('roofline') or {}).get('frac', 0):.3f} of peak.
+{json.dumps((cfgs.get('cfg1') or {}).get('stage_ms'))}, `k_dsp_publish` {((cfgs.get('cfg1') or {}).get('roofline') or {}).get('frac', 0):.3f} of peak;
+cfg3's rank share (rank 0 of 8: 64 of 512 agents, 512-row table, ring neighbours' rows replayed; tools/bench_rank_share.py)
+{json.dumps({k: (round(v, 2) if isinstance(v, float) else v) for k, v in (cfgs.get('cfg3_rank_share') or {}).items() if k in ('ms_per_step', 'ms_p50', 'ms_max', 'rank_replans_per_s', 'replans_ok_fraction', 'other_ranks_rows_in_table', 'projected_cfg3_replans_per_s', 'error')})}
+— the last figure is a PROJECTION (x 8, no all-gather in it).
 CPU baseline (oracle "port"): {cb.get('value', 0):.1f} replans/s on {cb.get('cores')} of {cb.get('host_cores')} host cores;
 single-thread stage latencies of tick 0: SOGM update {st.get('sogm_update') or 0:.1f} ms, A\\* {st.get('astar') or 0:.2f} ms, corridors
 {st.get('corridor') or 0:.2f} ms, QP {st.get('qp') or 0:.1f} ms.
