@@ -151,7 +151,7 @@ def neighbour_rows(tmpdir, grid="cfg2", agents_per_rank=64, world=8, timed_rank=
     todo = [(prv, None, f1), (nxt, f1, f2)] if neighbours >= 2 and world > 2 else [(nxt, None, f2)]
     for log, rep, out in todo:
         cmd = base + ["--log", str(log), "--out", out] + (["--rows", rep] if rep else [])
-        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
         if r.returncode != 0:
             raise RuntimeError(f"bench_rank_share: logging pass failed: {r.stderr[-1500:]}")
     return f2
