@@ -1,0 +1,68 @@
+"""getObstaclePoints (the box scan that feeds FIRI) against an INDEPENDENT restatement written from the reference text
+(tests/golden/make_obstacle_points_fixture.py -> obstacle_points_independent.json; plan_env/src/map.cpp:463-530,
+plan_env/src/risk_base.cpp:295-337, map.h:186-194) on the independent map's grids: count, order and every coordinate (SHA-256
+of the fp64 points) of 14 boxes x 3 poses x 2 map kinds — boxes beyond the map, windows beyond the last slice (the
+reference's inclusive slice loop reads risk_maps_[i][T]), the whole map.  CPU: the C++ oracle.  GPU: sogm_obstacle_points
+directly, not through the oracle."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FX = json.load(open(os.path.join(ROOT, "tests", "golden", "obstacle_points_independent.json")))
+CAP = 450000
+KINDS = (("base", 0), ("risk", 1))     # SOGM_MAP_FAKE (MapBase's scan), SOGM_MAP_RISKBASE (decayed threshold)
+
+
+def _scene(pop):
+    sc = pop.scene.make_scene(FX["agents"], 4.95, seed=FX["seed"], moving=True)
+    return sc, pop.scene.cylinders_to_struct(sc["cylinders"])
+
+
+def _check(name, a, b, box, pts, n):
+    want = box[name]
+    assert n == want["n"], (name, a, b, n, want["n"])
+    assert hashlib.sha256(np.ascontiguousarray(pts[:n]).tobytes()).hexdigest() == want["sha256"], (name, a, b, "a point differs")
+    assert pts[:4].tolist() == want["first"]
+
+
+def test_oracle_box_scan_equals_the_independent_restatement(pop, orc):
+    sc, cyl = _scene(pop)
+    total = 0
+    for a, case in enumerate(FX["cases"]):
+        pose = np.float32(case["pose"])
+        for name, kind in KINDS:
+            spec = pop.config.make_spec("parity", map_kind=kind)
+            assert [spec.L, spec.W, spec.H, spec.T] == FX["grid"]
+            g = orc.update_gt(pop.config.make_spec("parity"), sc["cloud"], cyl, len(sc["cylinders"]), pose)
+            for b, box in enumerate(case["boxes"]):
+                pts, n = orc.obstacle_points(spec, g, pose, case["stamp"], box["t0"], box["t1"], box["lc"], box["hc"], CAP)
+                _check(name, a, b, box, pts, n)
+                total += n
+    assert total > 1000000
+
+
+@pytest.mark.gpu
+def test_kernel_box_scan_equals_the_independent_restatement(pop):
+    import importlib
+    sogm = importlib.import_module("pred-occ-planner_amd.sogm")
+    sc, _ = _scene(pop)
+    A = FX["agents"]
+    sc = dict(sc)
+    sc["poses"] = np.float32([c["pose"] for c in FX["cases"]])
+    sc["stamps"] = np.float64([c["stamp"] for c in FX["cases"]])
+    for name, kind in KINDS:
+        spec = pop.config.make_spec("parity", map_kind=kind)
+        dev = sogm.upload_scene(sc)
+        m = sogm.SogmMap(spec, A)
+        m.updateMap(dev["cloud"], dev["cloud_range"], dev["cylinders"], dev["n_cyl"], dev["poses"], dev["stamps"])
+        for a, case in enumerate(FX["cases"]):
+            for b, box in enumerate(case["boxes"]):
+                pts, cnt = m.getObstaclePoints(sogm._dev(np.int32([a])), sogm._dev(np.float64([box["lc"]]), np.float64),
+                                               sogm._dev(np.float64([box["hc"]]), np.float64), sogm._dev(np.float64([box["t0"]]), np.float64),
+                                               sogm._dev(np.float64([box["t1"]]), np.float64), CAP)
+                _check(name, a, b, box, pts[0].cpu().numpy(), int(cnt[0].item()))
+        m.close()
