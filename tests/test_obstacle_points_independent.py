@@ -26,7 +26,7 @@ def _check(name, a, b, box, pts, n):
     want = box[name]
     assert n == want["n"], (name, a, b, n, want["n"])
     assert hashlib.sha256(np.ascontiguousarray(pts[:n]).tobytes()).hexdigest() == want["sha256"], (name, a, b, "a point differs")
-    assert pts[:4].tolist() == want["first"]
+    assert pts[:min(n, 4)].tolist() == want["first"]
 
 
 def test_oracle_box_scan_equals_the_independent_restatement(pop, orc):
