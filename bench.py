@@ -89,7 +89,7 @@ def cpu_baseline(pop, spec, scene, n_agents_sample):
     ap, pp, qs = pop.config.make_astar_params(), pop.config.make_planner_params(True), pop.config.make_qp_settings()
     cyl = pop.scene.cylinders_to_struct(scene["cylinders"])
     recs = pop.scene.straight_records(scene)
-    body = pop.scene.body_particles()
+    body = pop.scene.received_body_particles()
     A = scene["n_agents"]
     # every host core, one agent-replan per thread (SURVEY §8 d); each in-flight agent holds its own SOGM
     # (V*T*4 B = 640 MB at 200^3 x 20) — bounded by the host's RAM, not by a constant

@@ -277,7 +277,11 @@ int sogm_map_traffic(sogm_ctx *ctx, int64_t *out_host, int reset);
 int sogm_grid_history(sogm_ctx *ctx, int32_t *out_host);
 
 /* Body particles of one drone: ParticleATC::initEgoParticles (particles.cpp:62-87).
- * host: xyz[n*3] offsets (fp64).  Every drone of the swarm uses the same set. */
+ * host: xyz[n*3] offsets (fp64).  Every drone of the swarm uses the same set.
+ * The overlay places ANOTHER drone's particles, and those reach a ParticleATC through particlesCallback
+ * (particles.cpp:89-108) as geometry_msgs/Polygon points — Point32, i.e. float32 coordinates cast back to double.  A host
+ * that wants the reference's cells to the last bit passes the offsets as received ((double)(float)x; the Python mirror's
+ * scene.received_body_particles does); the library uses what it is given. */
 int sogm_set_body_particles(sogm_ctx *ctx, const double *xyz_host, int n);
 
 /* Per-kernel timing with HIP events recorded on the caller's stream around each launch (used by

@@ -139,6 +139,8 @@ class RiskMap {
   int       agents() const { return n_; }
 
   // ParticleATC::initEgoParticles + setCoordinator (risk_base.h:62-65)
+  // (pass the particles as ANOTHER drone's ParticleATC holds them: particlesCallback reads Point32 coordinates —
+  //  (double)(float)x — particles.cpp:89-108; the library uses what it is given)
   void setCoordinator(const std::vector<Vec3> &body_particles) {
     check(sogm_set_body_particles(ctx_, body_particles[0].data(), (int)body_particles.size()), "set_body");
   }

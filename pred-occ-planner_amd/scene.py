@@ -49,6 +49,13 @@ def body_particles(size=(0.4, 0.4, 0.45)):
     return np.asarray(out, dtype=np.float64)
 
 
+def received_body_particles(size=(0.4, 0.4, 0.45)):
+    """What a ParticleATC holds for ANOTHER drone (the only particles the neighbour overlay and isSafeAfterOpt place):
+    particlesCallback (traj_coordinator/src/particles.cpp:89-108) copies them from a geometry_msgs/PolygonStamped, whose
+    points are geometry_msgs/Point32 — the sender's fp64 ego particles rounded to float32 and cast back to double."""
+    return body_particles(size).astype(np.float32).astype(np.float64)
+
+
 def cylinders_to_struct(cyl):
     """(n, 5) float64 rows {x, y, w, vx, vy} -> ctypes array of SogmCylinder (type 3, height 4)."""
     arr = (SogmCylinder * max(len(cyl), 1))()

@@ -13,7 +13,7 @@ import torch
 
 from . import _abi
 from ._abi import check, lib
-from .scene import body_particles, struct_to_numpy
+from .scene import received_body_particles, struct_to_numpy
 
 
 def _dev(x, dtype=None, device="cuda"):
@@ -41,7 +41,7 @@ class SogmMap:
         self._ctx = C.c_void_p()
         torch.cuda.set_device(device)
         check(lib().sogm_create(C.byref(spec), n_agents, device, C.byref(self._ctx)), "sogm_create")
-        self.body = body_particles(drone_size)
+        self.body = received_body_particles(drone_size)   # as another drone's ParticleATC receives them (Point32)
         check(lib().sogm_set_body_particles(
             self._ctx, self.body.ctypes.data_as(C.POINTER(C.c_double)), len(self.body)),
             "sogm_set_body_particles")

@@ -45,7 +45,7 @@ def pocket_cloud(pose, half_width, depth, back=0.6, step=0.1):
 
 def oracle_grids(pop, orc, spec, sc, recs):
     cyl = pop.scene.cylinders_to_struct(sc["cylinders"])
-    body = pop.scene.body_particles()
+    body = pop.scene.received_body_particles()
     out = []
     A = sc["n_agents"]
     for a in range(A):
@@ -94,7 +94,7 @@ class OracleCompute:
         self.ap, self.pp, self.qs = (pop.config.make_astar_params(), pop.config.make_planner_params(True),
                                      pop.config.make_qp_settings())
         self.cyl = pop.scene.cylinders_to_struct(scene["cylinders"])
-        self.body = pop.scene.body_particles()
+        self.body = pop.scene.received_body_particles()
         self.grids, self.swarm, self.pub = [None] * (hi - lo), None, None
         self.overlay_sums = []   # (tick stamp, agent, sum of the SOGM, hash of the occupied cells) per agent-update
 

@@ -63,7 +63,7 @@ def test_neighbour_overlay_validity_chain(pop, orc):
     (getParticlesWithRisk returns false on empty waypoints, particles.cpp:353-356)."""
     s = pop.config.make_spec("parity")
     sc = pop.scene.make_scene(2, 4.95, seed=3, circle_radius=2.0)
-    body = pop.scene.body_particles()
+    body = pop.scene.received_body_particles()
     V = s.L * s.W * s.H
     recs = pop.scene.straight_records(sc, t_start=sc["stamps"][0] + 0.1)  # starts after slice 0
     g = np.zeros((V, s.T), np.float32)

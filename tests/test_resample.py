@@ -26,7 +26,7 @@ def _table(n_body, n, seed=7):
 
 def test_oracle_resample_conserves_the_weight_per_particle(pop, orc):
     spec, sc, recs = _scene(pop)
-    body = pop.scene.body_particles()
+    body = pop.scene.received_body_particles()
     z = _table(len(body), 10)
     cyl = pop.scene.cylinders_to_struct(sc["cylinders"])
     plain = orc.update_gt(spec, sc["cloud"], cyl, len(sc["cylinders"]), sc["poses"][0])
