@@ -195,6 +195,71 @@ def flow_chain(pop, sw, absolute=False):
             "what": "device timestamps of the dataflow replan's persistent kernels, first search resident = 0"}
 
 
+def _r(x, nd=2):
+    return None if x is None else round(float(x), nd)
+
+
+def compact_line(out):
+    """The ONE JSON line bench.py prints.  Everything measured goes to a file (profiles/bench_last_detail.json here, copied to
+    gpurun_out/ when that exists); the line keeps the contract's keys, the roofline and cpu_baseline objects without their
+    prose, and ENDS with `summary` (< 1200 characters): a driver that keeps only the last 2000 characters of the line still
+    holds every number DESIGN.md section 6 quotes."""
+    detail_paths = []
+    for d in ("profiles", "gpurun_out"):
+        dd = os.path.join(ROOT, d)
+        if os.path.isdir(dd):
+            try:
+                with open(os.path.join(dd, "bench_last_detail.json"), "w") as f:
+                    json.dump(out, f, indent=1)
+                detail_paths.append(os.path.join(d, "bench_last_detail.json"))
+            except OSError:
+                pass
+    g = lambda o, *ks: (g(o.get(ks[0]), *ks[1:]) if len(ks) > 1 else o.get(ks[0])) if isinstance(o, dict) else None
+    ro, cb, cfg = out.get("roofline") or {}, out.get("cpu_baseline"), dict(out.get("config") or {})
+    for k in ("world", "tick_overlap"):  # prose: in the detail file
+        cfg.pop(k, None)
+    line = {k: out[k] for k in ("metric", "value", "value_ok", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
+                                "higher_is_better", "scaling", "vs_baseline", "dtype", "data") if k in out}
+    line["config"] = cfg
+    if "multi_gpu" in out:
+        line["multi_gpu"] = out["multi_gpu"]
+    line["detail_file"] = detail_paths
+    line["roofline"] = {k: ro.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_frac",
+                                               "achieved_distinct", "frac_distinct", "bytes_per_launch", "avg_launch_ms",
+                                               "launches_timed", "bytes_counted", "timed_where") if k in ro}
+    line["cpu_baseline"] = ({k: cb.get(k) for k in ("value", "unit", "cores", "host_cores", "kind", "sample")} if cb else None)
+    v, cf, su, ch = out.get("variants") or {}, out.get("configs") or {}, out.get("sustained") or {}, out.get("chain_ms") or {}
+    fl, ks = v.get("flight") or {}, {k.get("kernel", "")[:8]: k for k in ro.get("kernels", []) if isinstance(k, dict)}
+    stamp = next((k for n, k in ks.items() if n.startswith("k_cull")), {})
+    line["summary"] = {
+        "headline": {"v": _r(out.get("value"), 0), "ms": _r(out.get("ms_per_step")), "ok": _r(g(out, "config", "replans_ok_fraction"), 4)},
+        "lockstep_sustained": {"v": _r(su.get("value"), 0), "p50": _r(su.get("tick_ms_p50")), "p99": _r(su.get("tick_ms_p99")),
+                               "max": _r(su.get("tick_ms_max")), "ok": _r(su.get("replans_ok_fraction"), 4),
+                               "ticks": su.get("ticks")} if su else None,
+        "prestamped": {"v": _r(g(v, "prestamped_lockstep", "value"), 0), "ms": _r(g(v, "prestamped_lockstep", "ms_per_step"))},
+        "flight": {"v": _r(fl.get("value"), 0), "ms": _r(fl.get("ms_per_step")), "ok": _r(fl.get("replans_ok_fraction"), 4),
+                   "sust_v": _r(g(fl, "sustained", "value"), 0), "sust_ok": _r(g(fl, "sustained", "replans_ok_fraction"), 7),
+                   "sust_worst_ms": _r(g(fl, "sustained", "ms_per_tick_worst_flight")),
+                   "sust_best_ms": _r(g(fl, "sustained", "ms_per_tick_best_flight")),
+                   "map_gate_ms": _r((g(fl, "per_agent_tick_ms", "map") or 0) + (g(fl, "per_agent_tick_ms", "gate_wait") or 0))
+                   if fl.get("per_agent_tick_ms") else None,
+                   "flights": fl.get("flights"), "flights_failed": fl.get("flights_failed")} if fl else None,
+        "chain_ms": {"astar": _r(ch.get("astar_mean")), "corr": _r(ch.get("corridor_mean")), "corr_max": _r(ch.get("corridor_max")),
+                     "qp": _r(ch.get("qp_mean")), "qp_max": _r(ch.get("qp_max")), "mean": _r(ch.get("chain_mean")),
+                     "end": _r(ch.get("chain_end")), "qp_us_it": _r(g(ch, "slowest_qp", "us_per_iteration"), 3)} if ch else None,
+        "reset": {"ms": _r(ro.get("avg_launch_ms"), 3), "frac": _r(ro.get("frac"), 3), "traffic_frac": _r(ro.get("traffic_frac"), 3),
+                  "frac_distinct": _r(ro.get("frac_distinct"), 3)},
+        "stamp_ms": _r(stamp.get("launch_ms"), 3),
+        "cfg4": {"v": _r(g(cf, "cfg4", "replans_per_s"), 0), "flight_v": _r(g(cf, "cfg4", "flight", "replans_per_s"), 0),
+                 "flights_failed": g(cf, "cfg4", "flight", "flights_failed"), "err": (g(cf, "cfg4", "error") or "")[:60] or None},
+        "cfg1_ms_frame": _r(g(cf, "cfg1", "ms_per_frame")),
+        "cfg3_share": {"ms": _r(g(cf, "cfg3_rank_share", "ms_per_step")),
+                       "proj_v": _r(g(cf, "cfg3_rank_share", "projected_cfg3_replans_per_s"), 0)},
+        "cpu": {"v": _r(cb.get("value"), 1), "cores": cb.get("cores")} if cb else None,
+    }
+    return line
+
+
 def main():
     args = parse()
     import torch
@@ -640,48 +705,70 @@ def main():
                               scene=scene_kept)
         n_fl = args.warmup + args.steps + (args.sustained if args.sustained > 0 else 0)
         fw.compute.prepare(0, n_fl + 1)
-        fw.fly(args.warmup)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        okf, _ = fw.fly(args.steps) if args.steps <= pop._abi.FLIGHT_MAX_TICKS else (None, None)
-        torch.cuda.synchronize()
-        dtf = time.perf_counter() - t1
+        # EVERY flight is checked when it ends: the device's error word (k_flight_reset zeroes it at the start of the next
+        # call), the finished count (every agent-tick of the call) and the planner's cumulative failure word.  A flight that
+        # timed out on the device fails the variant: no value is reported for it, only what happened.
+        fl_log = {"flights": 0, "flights_failed": 0, "failed_word": fw.planner.flow_failures()[1], "errors": []}
+
+        def fly_checked(n, label):
+            t_ = time.perf_counter()
+            ok_, _ = fw.fly(n)
+            torch.cuda.synchronize()
+            secs = time.perf_counter() - t_
+            _, h_ = fw.planner.flight_stats()
+            code_, failed_ = fw.planner.flow_failures()
+            fin_ = int(h_[pop._abi.FLIGHT_HDR_FINISHED])
+            fl_log["flights"] += 1
+            bad = h_[pop._abi.FLIGHT_HDR_ERR] != 0 or fin_ != fw.A_loc * n or failed_ != fl_log["failed_word"]
+            fl_log["failed_word"] = failed_
+            if bad:
+                fl_log["flights_failed"] += 1
+                fl_log["errors"].append({"flight": label, "ticks": n, "device_error": int(h_[pop._abi.FLIGHT_HDR_ERR]),
+                                         "agent_ticks_finished": fin_, "agent_ticks": fw.A_loc * n,
+                                         "ms_per_tick": secs / n * 1e3})
+            return ok_, secs, bad
+
+        fly_checked(args.warmup, "warm-up")
+        okf, dtf, bad_timed = fly_checked(args.steps, "timed") if args.steps <= pop._abi.FLIGHT_MAX_TICKS else (None, None, True)
         msf, hdr = fw.planner.flight_stats()
-        if hdr[pop._abi.FLIGHT_HDR_ERR] != 0 or fw.planner.flow_failures()[1]:
-            raise SystemExit(f"bench.py: the flight failed on the device (code {hdr[pop._abi.FLIGHT_HDR_ERR]})")
-        per = (msf[:, :7].sum(axis=0) / msf[:, 7].sum()).tolist()
-        fl = {"value": fw.A_tot * args.steps / dtf, "unit": "replans/s", "ms_per_step": dtf / args.steps * 1e3,
-              "replans_ok_fraction": int(okf.sum().item()) / float(fw.A_loc * args.steps),
+        per = (msf[:, :7].sum(axis=0) / max(msf[:, 7].sum(), 1.0)).tolist()
+        fl = {"unit": "replans/s",
               "map_input_staleness_ticks": 0, "neighbour_record_staleness_ticks": 2,
               "tick_overlap": "per agent: tick k starts when the agent's own tick k - 1 is finished and every agent has finished "
                               "tick k - 2; it reads its own record of tick k - 1 and the neighbours' records of tick k - 2",
-              "per_agent_tick_ms": dict(zip(pop._abi.FLIGHT_STAT_NAMES[:7], per)),
               "what": "sogm_flight_run: ONE call for all timed ticks, four persistent kernels on four CU-masked streams; "
                       "records bit-identical to the same rule flown lock-step (tests/test_flight_gpu.py)"}
-        if args.sustained > 0:
+        if not bad_timed and not fl_log["flights_failed"]:
+            fl.update({"value": fw.A_tot * args.steps / dtf, "ms_per_step": dtf / args.steps * 1e3,
+                       "replans_ok_fraction": int(okf.sum().item()) / float(fw.A_loc * args.steps),
+                       "per_agent_tick_ms": dict(zip(pop._abi.FLIGHT_STAT_NAMES[:7], per))})
+        if args.sustained > 0 and not fl_log["flights_failed"]:
             # (flights of 60 ticks: every call starts with the whole swarm in step and ends with a drain behind its last
             #  straggler, which a longer flight spreads over more ticks; sogm_flight_run takes up to 64)
             FL_N = min(60, pop._abi.FLIGHT_MAX_TICKS)
             per_flight, n_flight, oks3, left = [], [], [], args.sustained
             while left > 0:
                 n = min(FL_N, left)
-                t1 = time.perf_counter()
-                ok_, _ = fw.fly(n)
-                torch.cuda.synchronize()
-                per_flight.append((time.perf_counter() - t1) * 1e3 / n)
+                ok_, secs, bad = fly_checked(n, f"sustained {len(per_flight)}")
+                per_flight.append(secs * 1e3 / n)
                 n_flight.append(n)
                 oks3.append(ok_)
                 left -= n
-            _, hdr = fw.planner.flight_stats()
-            if hdr[pop._abi.FLIGHT_HDR_ERR] != 0:
-                raise SystemExit(f"bench.py: a sustained flight failed on the device (code {hdr[pop._abi.FLIGHT_HDR_ERR]})")
+                if bad:
+                    break  # (the records behind an aborted flight are not the flight's)
             pf = np.array(per_flight)
             total_ms = float((pf * np.array(n_flight)).sum())
-            fl["sustained"] = {"ticks": args.sustained, "flights_of": FL_N, "first_tick": args.warmup + args.steps,
-                               "ms_per_tick_mean": total_ms / args.sustained, "ms_per_tick_worst_flight": float(pf.max()),
-                               "ms_per_tick_best_flight": float(pf.min()),
-                               "value": fw.A_tot * args.sustained / (total_ms * 1e-3),
-                               "replans_ok_fraction": int(torch.cat(oks3).sum().item()) / float(fw.A_loc * args.sustained)}
+            sus = {"ticks": args.sustained, "flights_of": FL_N, "first_tick": args.warmup + args.steps,
+                   "ms_per_tick_worst_flight": float(pf.max()), "ms_per_tick_best_flight": float(pf.min())}
+            if not fl_log["flights_failed"]:
+                sus.update({"ms_per_tick_mean": total_ms / args.sustained,
+                            "value": fw.A_tot * args.sustained / (total_ms * 1e-3),
+                            "replans_ok_fraction": int(torch.cat(oks3).sum().item()) / float(fw.A_loc * args.sustained)})
+            fl["sustained"] = sus
+        fl["flights"], fl["flights_failed"] = fl_log["flights"], fl_log["flights_failed"]
+        if fl_log["flights_failed"]:
+            fl["error"] = {"what": "a flight timed out on the device (3 s bounded waits): the variant reports no value",
+                           "failed": fl_log["errors"]}
         cf = fw.planner.counters(reset=True)
         if cf["corridor_capacity"] + cf["pieces_capacity"] + cf["deconflict_capacity"]:
             raise SystemExit(f"bench.py: capacity limits hit during the flights ({cf})")
@@ -733,11 +820,15 @@ def main():
             torch.cuda.synchronize()
             dtf4 = time.perf_counter() - t1
             _, h4 = f4.planner.flight_stats()
-            if h4[pop._abi.FLIGHT_HDR_ERR] != 0:
-                raise SystemExit(f"bench.py: the cfg4 flight failed on the device (code {h4[pop._abi.FLIGHT_HDR_ERR]})")
-            cfgs["cfg4"]["flight"] = {"replans_per_s": f4.A_tot * 10 / dtf4, "ms_per_step": dtf4 / 10 * 1e3,
-                                      "replans_ok_fraction": int(okf4.sum().item()) / float(f4.A_loc * 10),
-                                      "what": "sogm_flight_run, same scene and ticks (map kernel on 96 CUs, QP 48, search 16)"}
+            if (h4[pop._abi.FLIGHT_HDR_ERR] != 0 or int(h4[pop._abi.FLIGHT_HDR_FINISHED]) != f4.A_loc * 10
+                    or f4.planner.flow_failures()[1]):
+                cfgs["cfg4"]["flight"] = {"error": f"the flight timed out on the device (code {int(h4[pop._abi.FLIGHT_HDR_ERR])}, "
+                                                   f"{int(h4[pop._abi.FLIGHT_HDR_FINISHED])} of {f4.A_loc * 10} agent-ticks finished)",
+                                          "flights_failed": 1}
+            else:
+                cfgs["cfg4"]["flight"] = {"replans_per_s": f4.A_tot * 10 / dtf4, "ms_per_step": dtf4 / 10 * 1e3,
+                                          "replans_ok_fraction": int(okf4.sum().item()) / float(f4.A_loc * 10), "flights_failed": 0,
+                                          "what": "sogm_flight_run, same scene and ticks (map kernel on 96 CUs, QP 48, search 16)"}
             f4.close()
             torch.cuda.empty_cache()
         except pop.SogmError as e:  # (e.g. HBM already held by another process: say so, do not invent a figure)
@@ -758,7 +849,7 @@ def main():
     else:
         out["cpu_baseline"] = None
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(compact_line(out)))
     if dist is not None:
         dist.destroy_process_group()
 

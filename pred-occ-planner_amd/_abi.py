@@ -122,7 +122,7 @@ class SogmFlight(C.Structure):
 
 
 FLIGHT_MAX_TICKS = 64
-FLIGHT_HDR_ERR, FLIGHT_HDR_FINISHED = 4, 5  # sogm_flight_stats out_hdr indices
+FLIGHT_HDR_ERR, FLIGHT_HDR_FINISHED, FLIGHT_HDR_LATE_WGS = 4, 5, 15  # sogm_flight_stats out_hdr indices
 FLIGHT_STAT_NAMES = ("gate_wait", "map", "search", "corridor", "qp", "finish", "chain", "ticks")
 TRAJ_RECORD_BYTES = C.sizeof(SogmTrajRecord)  # 2064
 CYLINDER_BYTES = C.sizeof(SogmCylinder)  # 96

@@ -1083,6 +1083,7 @@ __global__ __launch_bounds__(ASTAR_THREADS) void k_flight_search(
   const int tid   = threadIdx.x;
   const int per   = spec ? 2 : 1;
   const int total = fl.n_agents * fl.n_ticks * per;
+  fl_wg_started(fl, 1);
   for (;;) {
     __syncthreads();  // (s_item of the previous trip has been read by everybody)
     if (tid == 0) s_item = atomicAdd(&fl.hdr[FL_S_TICKET], 1);

@@ -1323,7 +1323,7 @@ __device__ __forceinline__ void corridor_segment_body(const MapView &m, const So
   const long long tk0 = wall_clock64();
   const int M = DIRECT ? fd.n_bd : 6;
   if (lane == 0) {
-    for (int k = 0; k < 16; ++k) dbg[k] = 0;
+    for (int k = 0; k < 12; ++k) dbg[k] = 0;  // (12-15: the flight's own stamps of this slot, k_flight_light)
     if constexpr (DIRECT) {
       for (int i = 0; i < 4 * M; ++i) s_bd[i] = fd.bd[(size_t)prob * M * 4 + i];
       for (int k = 0; k < 3; ++k) {
@@ -2186,6 +2186,7 @@ __global__ __launch_bounds__(64) void k_flight_light(MapView m, SogmPlannerParam
   // early.  Unexplained; profiles/EXPERIMENTS.md.)
   const unsigned total = (unsigned)fl.n_agents * (unsigned)fl.n_ticks * (SOGM_MAX_PIECES + 1);
   int           *err   = &fl.hdr[FL_ERR];
+  fl_wg_started(fl, 2);
   long long      c1_prev = 0;
   int            kind_prev = 0;
   for (;;) {
@@ -2279,14 +2280,25 @@ __global__ __launch_bounds__(64) void k_flight_light(MapView m, SogmPlannerParam
     // ---- WK_CORRIDOR: segment slot `seg` of agent a ----
     const int seg = (desc >> 16) & 0xFFF;
     if (seg == 0 && lane == 0) fl.ts[a * FL_TS + 2] = wall_clock64();
+    // diagnostics (sogm_debug_corridor_stats, tools/soak_flight.py): when this slot's descriptor was taken, its obstacle points
+    // were out, its segment was done, and on which compute unit (HW_ID | XCC_ID << 32)
+    long long *sdbg = ws.seg_dbg + ((size_t)a * SOGM_MAX_PIECES + seg) * 16;
+    if (lane == 0) {
+      sdbg[12] = c1;
+      sdbg[13] = 0;
+      sdbg[14] = 0;
+      sdbg[15] = (long long)(unsigned)__builtin_amdgcn_s_getreg(63492) | ((long long)(unsigned)__builtin_amdgcn_s_getreg(63508) << 32);
+    }
     if (seg < d.route_len[a] - 1) {
       corridor_points_body<1>(m, pp, ws, d.start_pva, d.t_start, d.route, d.route_len, d.route_cap, a, seg);
       __threadfence_block();
       __syncthreads();
     }
+    if (lane == 0) sdbg[13] = wall_clock64();
     corridor_segment_body<6, false>(m, pp, ws, d.start_pva, d.t_start, d.route, d.route_len, d.route_cap, a, seg, smem,
                                     FiriDirect{});
     __syncthreads();
+    if (lane == 0) sdbg[14] = wall_clock64();
     __threadfence();
     const int last = (flow_ticket(&fl.seg_done[a]) & (SOGM_MAX_PIECES - 1)) == SOGM_MAX_PIECES - 1;
     if (last) {

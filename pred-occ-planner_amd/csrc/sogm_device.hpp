@@ -11,7 +11,7 @@
 #include <new>
 #include <stdint.h>
 
-#include "../../include/sogm_abi.h"
+#include "../../include/sogm_abi_debug.h"  // (includes sogm_abi.h: the library defines both headers' entry points)
 #include "../../include/sogm_detmath.h"
 
 namespace sogm {
@@ -43,7 +43,8 @@ struct GridGeom {
   // fix-up, two mode switches) and the stamp computes two or three per mark, the search three per query.  For the one
   // resolution the reference ships (VOXEL_RESOLUTION 0.15, a compile-time constant of map_parameters.h) the three-instruction
   // sequence q0 = a * RN(1/res), e = fma(-res, q0, a) (exact), q = fma(e, RN(1/res), q0) gives RN(a / res) for EVERY
-  // float a with |a| in [2^-20, 64] (checked exhaustively, tests/test_fast_division.py; below that both truncate to 0):
+  // float a with |a| in [2^-20, 64) (checked for EVERY such float on the device, tests/test_fast_division.py::test_every_float_on_the_device
+  // — sogm_debug_div_check —, and on the CPU for a sample + every float near a voxel boundary; below that both truncate to 0):
   // used for that resolution and that range only, the true division everywhere else.
   float inv_res;
   int   fast_div;
@@ -484,6 +485,8 @@ __device__ inline void bezier_pos(const SogmTrajRecord &r, double t, double out[
   X(FLIGHT_URGENT_WAVES, "flight_urgent_waves", 4096, 1, 4096) /* flight: map workers that look at the urgent queue first (all of them by default) */ \
   X(FLIGHT_URGENT_FINE, "flight_urgent_fine", 4, 1, 16)    /* flight: the urgent lane's maps in this many times more tickets  */  \
   X(FLIGHT_GATE_PACE_US, "flight_gate_pace_us", 40, 0, 100000) /* flight: microseconds between two overlays a gate releases     */  \
+  X(FLIGHT_LIGHT_PER_CU, "flight_light_per_cu", 4, 1, 4)   /* flight: corridor + finish waves per compute unit of their partition (4 = every SIMD) */ \
+  X(FLIGHT_MAP_PER_CU, "flight_map_per_cu", 8, 1, 8)       /* flight: map waves per compute unit of their partition            */ \
   X(UPDATE_FLOW, "update_flow", 0, 0, 1)                   /* sogm_update_world builds the maps agent by agent on a stream of its own; sogm_replan's searches start per agent */ \
   X(UPDATE_BITS, "update_bits", 16, 1, 256)                /* update flow: one-wave tickets per agent, occupancy bits         */  \
   X(UPDATE_MARKS, "update_marks", 64, 1, 256)              /* update flow: ... marks                                          */  \
@@ -706,8 +709,11 @@ int  queue_spare_clears(sogm_ctx *c, hipEvent_t after);
 struct CloudBlocks {
   const float *bounds;  // [n_blocks][4] {xmin, xmax, ymin, ymax}; null = the caller's per-agent {begin, end} ranges are used
   int          n_blocks, block_points, n_points;
-  int         *list;    // [A][n_blocks] ids of the blocks that intersect the agent's window, ascending
+  int         *list;    // [A][row] ids of the blocks that intersect the agent's window, ascending
   int         *n_list;  // [A]
+  int          row;     // row length of `list` (>= n_blocks).  NOT n_blocks itself: a flight's agents are on different ticks at
+                        // once, their frames may hold different block counts, and they share the lists — a row stride that
+                        // followed the frame would let one agent's head overwrite a list another agent's bits tickets read
 };
 // the context's crop lists sized for `w` (grown on demand; stream-ordered)
 int world_blocks(sogm_ctx *c, const SogmWorld *w, CloudBlocks *out);

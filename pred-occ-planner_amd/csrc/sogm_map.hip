@@ -392,7 +392,7 @@ __device__ __forceinline__ void stamp_bits_range(const GridGeom &g, const float 
 __device__ __forceinline__ void cull_blocks_agent(const GridGeom &g, const CloudBlocks &cb, int agent, float q0, float q1,
                                                   int lane) {
   const float lox = q0 - g.rx, hix = q0 + g.rx, loy = q1 - g.ry, hiy = q1 + g.ry;
-  int        *out = cb.list + (size_t)agent * cb.n_blocks;
+  int        *out = cb.list + (size_t)agent * cb.row;
   int         kept = 0;
   for (int b0 = 0; b0 < cb.n_blocks; b0 += 64) {
     const int b    = b0 + lane;
@@ -484,7 +484,7 @@ __device__ __forceinline__ void stamp_bits_blocks(const GridGeom &g, const float
                                                   int agent, int first, int stride, float p0, float p1, float p2,
                                                   unsigned *__restrict__ mask, int lane) {
   const CropBox box(g, p0, p1, p2);
-  const int    *list = cb.list + (size_t)agent * cb.n_blocks;
+  const int    *list = cb.list + (size_t)agent * cb.row;
   const int     n    = cb.n_list[agent];
   for (int i = first; i < n; i += stride) {  // uniform
     const int b   = list[i];
@@ -930,7 +930,9 @@ __device__ __forceinline__ void stamp_marks_trips(const GridGeom &g, void *__res
             if (((m >> lane) & 1ull) && li < (unsigned)lg.cap) lent[li] = sec;
           }
         } else if (lent && lane == 0) {
-          atomicAdd(lg.n + agent, (unsigned)lg.cap + 1u);  // (T > 64: no log — the agent's next reset is the dense one)
+          // (T > 64: no log — the agent's next reset is the dense one.  A saturating mark: an add per trip could carry the
+          //  unsigned counter past 2^32 and back under `cap`, and the next sparse reset would trust an empty log)
+          atomicMax(lg.n + agent, (unsigned)lg.cap + 1u);
         }
       }
       PS_ADD(6, PS_CLK() - ps_w1);
@@ -1608,6 +1610,7 @@ __global__ __launch_bounds__(64) void k_flight_map(GridGeom g, FlightCtl fl, Fli
   // (the urgent lane cuts a map into finer tickets: a map's latency is the sum of its phases' longest tickets — 0.25 reset +
   //  0.3 marks + 0.17 overlay ms with the plain lane's counts even on idle workers — and the urgent lane exists for latency)
   int      *err = &fl.hdr[FL_ERR];
+  fl_wg_started(fl, 3);
   // (every lane of this kernel ends when the call's last finish has stored the call's epoch in hdr[FL_END])
   if ((int)blockIdx.x < d.n_head_wgs) {
     // ---- admitting waves: heads, in the order the agents' previous ticks finished; the first n_uhead_wgs serve the
@@ -1961,6 +1964,9 @@ int prestamp_buffers(sogm_ctx *c, PrestampDev *d) {
   return SOGM_OK;
 }
 
+// Growing stalls the host for as long as the device needs to drain (hipDeviceSynchronize + hipFree + hipMalloc): callers
+// reach it before they launch anything of their tick — sogm_update_world / sogm_update_gt_swarm at their top,
+// sogm_planner_set_prestamp (so that sogm_replan's own call below never grows), sogm_flight_run before its first launch.
 int world_blocks(sogm_ctx *c, const SogmWorld *w, CloudBlocks *out) {
   SOGM_HIP_CHECK(hipSetDevice(c->device));
   if (w->n_blocks > c->blk_cap || !c->d_blk_n) {  // (also the first frame of all, even an empty one: the counts exist)
@@ -1974,8 +1980,8 @@ int world_blocks(sogm_ctx *c, const SogmWorld *w, CloudBlocks *out) {
     if (!c->d_blk_n) SOGM_HIP_CHECK(hipMalloc((void **)&c->d_blk_n, sizeof(int) * (size_t)c->n_agents));
     c->blk_cap = cap;
   }
-  // (the lists are packed with this frame's block count as the row length: a row never exceeds n_blocks <= blk_cap)
-  *out = CloudBlocks{w->block_bounds, w->n_blocks, w->block_points, w->n_points, c->d_blk_list, c->d_blk_n};
+  // (rows of blk_cap entries whatever the frame holds: a row never exceeds n_blocks <= blk_cap)
+  *out = CloudBlocks{w->block_bounds, w->n_blocks, w->block_points, w->n_points, c->d_blk_list, c->d_blk_n, c->blk_cap};
   return SOGM_OK;
 }
 
@@ -2491,6 +2497,50 @@ int sogm_debug_copy_grid(sogm_ctx *c, int agent, void *dst_dev, void *stream) {
   if (int rc = sogm::join_update(c, (hipStream_t)stream)) return rc;
   SOGM_HIP_CHECK(hipMemcpyAsync(dst_dev, (const char *)c->d_grid + (size_t)agent * bytes, bytes, hipMemcpyDeviceToDevice,
                                 (hipStream_t)stream));
+  return SOGM_OK;
+}
+
+}  // extern "C"
+// every float whose bit pattern lies in [bits_lo, bits_hi) and its negative: GridGeom::div_res against the IEEE division
+__global__ __launch_bounds__(256) void k_div_check(sogm::GridGeom g, unsigned bits_lo, unsigned bits_hi, unsigned long long *out) {
+  const unsigned long long n    = (unsigned long long)(bits_hi - bits_lo);
+  const unsigned long long step = (unsigned long long)gridDim.x * blockDim.x;
+  unsigned                 bad = 0, first = 0xFFFFFFFFu;
+  for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += step) {
+    const unsigned b = bits_lo + (unsigned)i;
+    const float    a = __uint_as_float(b);
+    const float    q = g.div_res(a), t = a / g.res, qn = g.div_res(-a), tn = (-a) / g.res;
+    if (__float_as_uint(q) != __float_as_uint(t) || __float_as_uint(qn) != __float_as_uint(tn)) {
+      ++bad;
+      if (b < first) first = b;
+    }
+  }
+  if (bad) {
+    atomicAdd(out, (unsigned long long)bad);
+    atomicMin(out + 1, (unsigned long long)first);
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) out[2] = (unsigned long long)g.fast_div;
+}
+extern "C" {
+// diagnostics (tests/ only): GridGeom::div_res — the three-instruction fp32 division the stamp and the search use — against
+// the IEEE division, on the device, for EVERY float in [lo, hi) and its negative.  out3_host = {mismatches, bit pattern of the
+// first one (2^64 - 1 if none), whether the context uses the fast sequence at all (its resolution is 0.15f)}
+int sogm_debug_div_check(sogm_ctx *c, float lo, float hi, unsigned long long *out3_host) {
+  if (!c || !out3_host || !(lo > 0.0f) || !(hi > lo)) return SOGM_ERR_INVALID_ARG;
+  SOGM_HIP_CHECK(hipSetDevice(c->device));
+  unsigned long long *d = nullptr;
+  SOGM_HIP_CHECK(hipMalloc((void **)&d, 3 * sizeof(unsigned long long)));
+  const unsigned long long init[3] = {0ull, ~0ull, 0ull};
+  SOGM_HIP_CHECK(hipMemcpy(d, init, sizeof(init), hipMemcpyHostToDevice));
+  unsigned bl, bh;
+  std::memcpy(&bl, &lo, 4);
+  std::memcpy(&bh, &hi, 4);
+  hipLaunchKernelGGL(k_div_check, dim3(4096), dim3(256), 0, nullptr, c->geom, bl, bh, d);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (e == hipSuccess) e = hipMemcpy(out3_host, d, sizeof(init), hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  SOGM_HIP_CHECK(e);
   return SOGM_OK;
 }
 

@@ -583,7 +583,13 @@ int sogm_planner_set_prestamp(sogm_planner *p, const SogmPrestamp *ps) {
   p->ps.cyl          = w ? w->cylinders : ps->cylinders;
   p->ps.n_cyl        = w ? w->n_cyl : ps->n_cyl;
   p->ps_world_on     = w ? 1 : 0;
-  if (w) p->ps_world = *w;
+  if (w) {
+    p->ps_world = *w;
+    // the crop lists grow HERE if this frame holds more blocks than any before it (world_blocks then drains the device and
+    // re-allocates): between two calls of the tick, never inside sogm_replan with the tick's persistent kernels queued
+    sogm::CloudBlocks sized{};
+    if (int rc = sogm::world_blocks(p->map, w, &sized)) return rc;
+  }
   p->ps.stamp        = ps->next_stamp;
   p->ps.start_offset = ps->replan_start_offset;
   p->ps.hover        = ps->hover_inout;
@@ -1009,6 +1015,7 @@ __global__ __launch_bounds__(256) void k_flight_reset(FlightCtl fl, int n_words,
   for (long long i = i0; i < fl.n_agents; i += step) verdict[i] = 0;
   for (long long i = i0; i < 8ll * fl.n_agents; i += step) acc[i] = 0;
   for (long long i = i0; i < 16; i += step) fl.prof[i] = 0ull;
+  for (long long i = i0; i < 8 * FL_WG_LOG; i += step) fl.wg_start[i] = 0;
 }
 __global__ __launch_bounds__(256) void k_flight_seed(FlightCtl fl) {
   const int a = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1028,8 +1035,92 @@ __global__ void k_flight_report(const int *__restrict__ hdr, int *__restrict__ h
   }
 }
 
-// the 16-CU unit of a mask bit: two CUs per XCD whether bit i names XCD i / 32 or XCD i % 8 (tools/micro/cumask.hip)
+// the 16-CU unit of a mask bit: two CUs per XCD whether bit i names XCD i / 32 or XCD i % 8 (tools/micro/cumask.hip).
+// unit = 4 * shader engine + r: the compute units of one shader engine (of every XCD) whose index is congruent r mod 4.
 static int flight_unit_of(int i) { return ((i / 8) % 4) * 4 + ((i / 32 + i % 8) % 4); }
+
+// Which units each of the four kernels gets.  The workgroup dispatcher hands the workgroups of a launch to the shader
+// engines of its compute-unit mask in strict ROTATION: when one engine's units are full the dispatch stops, whatever room the
+// other engines have (measured, tools/diag_flight_residency.py: a mask with four units in one engine and eight in another
+// held 16 + 16 one-wave workgroups per XCD, not 16 + 32 — 120 of the round-5 corridor kernel's 384 workgroups sat in the
+// dispatcher for the whole flight).  A workgroup that is not running is harmless until the hardware scheduler saves and
+// restores the process's queues (any queue created or destroyed on the device, by any process, does that): the waiting
+// workgroups then start in the slots the save freed, one per XCD ahead of the restored waves, and the wave that lost its slot
+// stays saved until somebody leaves — the 3-second stalls of round 5.  So: every kernel's mask holds the SAME number of units
+// in every shader engine it touches, and a launch has exactly as many workgroups as that mask holds at once
+// (engines x smallest engine share): every workgroup is resident from the first microsecond, nothing waits in a dispatcher.
+// grid[se][r] = kernel that owns unit 4 se + r (-1 free).  Kernels 0, 1, 3 (QP, search, map) are placed by a small search —
+// fewest engines first — such that the rest (kernel 2, corridor + finish) is balanced too; if no such layout exists the most
+// balanced one is kept and the launch is cut to what is resident.
+struct FlightLayout {
+  int grid[4][4];
+  int resident_units[4];  // engines touched x smallest share, in units
+};
+static int layout_rest_score(const int grid[4][4]) {  // units of the rest that are resident under the rotation
+  int touched = 0, smallest = 5;
+  for (int se = 0; se < 4; ++se) {
+    int n = 0;
+    for (int r = 0; r < 4; ++r) n += grid[se][r] < 0;
+    if (n > 0) {
+      ++touched;
+      if (n < smallest) smallest = n;
+    }
+  }
+  return touched ? touched * smallest : 0;
+}
+static void layout_search(int grid[4][4], const int want[4], const int order[3], int depth, int rest_units, int *best_score,
+                          int best[4][4]) {
+  if (depth == 3) {
+    const int sc = layout_rest_score(grid);
+    if (sc > *best_score) {
+      *best_score = sc;
+      std::memcpy(best, grid, sizeof(int) * 16);
+    }
+    return;
+  }
+  const int k = order[depth], u = want[k];
+  for (int n_se = 1; n_se <= 4 && *best_score < rest_units; ++n_se) {
+    if (u % n_se != 0 || u / n_se > 4) continue;
+    const int per = u / n_se;
+    for (int set = 1; set < 16 && *best_score < rest_units; ++set) {
+      if (__builtin_popcount((unsigned)set) != n_se) continue;
+      int  saved[4][4];
+      bool ok = true;
+      std::memcpy(saved, grid, sizeof(saved));
+      for (int se = 0; se < 4 && ok; ++se) {
+        if (!((set >> se) & 1)) continue;
+        int got = 0;
+        for (int r = 0; r < 4 && got < per; ++r)
+          if (grid[se][r] < 0) grid[se][r] = k, ++got;
+        ok = got == per;
+      }
+      if (ok) layout_search(grid, want, order, depth + 1, rest_units, best_score, best);
+      std::memcpy(grid, saved, sizeof(saved));
+    }
+  }
+}
+static FlightLayout flight_layout(const int want[4]) {
+  FlightLayout L;
+  int          grid[4][4], best_score = -1;
+  for (int i = 0; i < 16; ++i) (&grid[0][0])[i] = -1, (&L.grid[0][0])[i] = -1;
+  const int order[3] = {0, 3, 1};  // QP and map (whole engines when they can have them), then the search
+  layout_search(grid, want, order, 0, want[2], &best_score, L.grid);
+  for (int i = 0; i < 16; ++i)
+    if ((&L.grid[0][0])[i] < 0) (&L.grid[0][0])[i] = 2;
+  for (int k = 0; k < 4; ++k) {
+    int touched = 0, smallest = 5;
+    for (int se = 0; se < 4; ++se) {
+      int n = 0;
+      for (int r = 0; r < 4; ++r) n += L.grid[se][r] == k;
+      if (n > 0) {
+        ++touched;
+        if (n < smallest) smallest = n;
+      }
+    }
+    L.resident_units[k] = touched ? touched * smallest : 0;
+  }
+  return L;
+}
 
 static int flight_setup(sogm_planner *p) {
   sogm_ctx *c = p->map;
@@ -1067,6 +1158,7 @@ static int flight_setup(sogm_planner *p) {
   SOGM_HIP_CHECK(hipMemset(p->fl.ts, 0, sizeof(long long) * FL_TS * (size_t)A));
   SOGM_HIP_CHECK(hipMemset(p->fl.acc, 0, sizeof(long long) * 8 * (size_t)A));
   SOGM_HIP_CHECK(hipMalloc((void **)&p->fl.ts_log, sizeof(long long) * FL_TS * (size_t)A * FLIGHT_MAX_TICKS));
+  SOGM_HIP_CHECK(hipMalloc((void **)&p->fl.wg_start, sizeof(long long) * 8 * FL_WG_LOG));
   SOGM_HIP_CHECK(hipMalloc((void **)&p->fl.prof, sizeof(unsigned long long) * 16));
   SOGM_HIP_CHECK(hipMemset(p->fl.prof, 0, sizeof(unsigned long long) * 16));
   SOGM_HIP_CHECK(hipMalloc((void **)&p->d_fl_worlds, sizeof(FlightWorld) * FLIGHT_MAX_TICKS));
@@ -1087,20 +1179,21 @@ static int flight_setup(sogm_planner *p) {
     sogm::set_error_text("sogm_flight_run: flight_qp_units + flight_search_units + flight_map_units must leave a unit for the corridor kernel");
     return SOGM_ERR_INVALID_ARG;
   }
-  const bool masks = c->tune_i(SOGM_TUNE_FLIGHT_MASKS) != 0;
-  int        first_unit = 0;
+  const bool         masks = c->tune_i(SOGM_TUNE_FLIGHT_MASKS) != 0;
+  const FlightLayout L     = flight_layout(u);
   for (int k = 0; k < 4; ++k) {
     uint32_t mask[16] = {0};
     int      cus = 0;
     for (int i = 0; i < n_cu && i < 512; ++i) {
       const int un = flight_unit_of(i);
-      if (un >= first_unit && un < first_unit + u[k]) {
+      if (L.grid[un / 4][un % 4] == k) {
         mask[i / 32] |= 1u << (i % 32);
         ++cus;
       }
     }
-    first_unit += u[k];
-    p->fl_cus[k] = cus;
+    // compute units that hold workgroups from the start: the dispatcher's rotation over the mask's shader engines stops at
+    // the smallest engine share (flight_layout balances the shares; an unbalanced rest is cut here)
+    p->fl_cus[k] = masks ? cus * L.resident_units[k] / (u[k] > 0 ? u[k] : 1) : cus;
     if (masks)
       SOGM_HIP_CHECK(hipExtStreamCreateWithCUMask(&p->fl_stream[k], (uint32_t)((n_cu + 31) / 32), mask));
     else
@@ -1110,8 +1203,8 @@ static int flight_setup(sogm_planner *p) {
   SOGM_HIP_CHECK(hipEventCreateWithFlags(&p->fl_ev_in, hipEventDisableTiming));
   p->fl_wgs[0] = p->fl_cus[0];      // one QP workgroup per CU (a whole CU's LDS and registers)
   p->fl_wgs[1] = p->fl_cus[1];      // one search workgroup per CU (124 KB of LDS)
-  p->fl_wgs[2] = 4 * p->fl_cus[2];  // corridor / finish waves: 39.8 KB of LDS, one per SIMD
-  p->fl_wgs[3] = 8 * p->fl_cus[3];  // map waves: two per SIMD
+  p->fl_wgs[2] = c->tune_i(SOGM_TUNE_FLIGHT_LIGHT_PER_CU) * p->fl_cus[2];  // corridor / finish waves: 39.8 KB of LDS, one per SIMD
+  p->fl_wgs[3] = c->tune_i(SOGM_TUNE_FLIGHT_MAP_PER_CU) * p->fl_cus[3];    // map waves: two per SIMD
   SOGM_HIP_CHECK(hipStreamSynchronize(nullptr));
   return SOGM_OK;
 }
@@ -1165,7 +1258,7 @@ int sogm_flight_run(sogm_planner *p, const SogmFlight *f, void *stream) {
     big.n_blocks  = max_blocks;
     big.n_points  = max_blocks * big.block_points;
     if (int rc = sogm::world_blocks(c, &big, &md.cb)) return rc;
-    md.cb.n_blocks = max_blocks;  // the row length of the lists for every frame of the flight
+    md.cb.n_blocks = max_blocks;  // (per frame in the kernel; the lists' row length is md.cb.row = the context's capacity)
   }
   // the agent's single grid of the flight is the context's current one; it must be covered by its mark log
   const int slot = sogm::cur_slot(c);
@@ -1314,6 +1407,45 @@ int sogm_debug_flight_times(sogm_planner *p, long long *out_host, int n_ticks) {
   return SOGM_OK;
 }
 
+// diagnostics (tools/ only): the control block of the last flight as it stands — out_words = [FL_COUNTERS header counters]
+// [FLIGHT_MAX_TICKS tick_done][FLIGHT_MAX_TICKS parked_n][A tick_of][A seg_done][A stage][A urgent], out_ts = [A][FL_TS]
+// stamps of every agent's current tick.  What a stalled flight looked like when it was aborted.
+int sogm_debug_flight_dump(sogm_planner *p, int32_t *out_words, int cap_words, long long *out_ts) {
+  if (!p || !p->d_fl || !out_words) return SOGM_ERR_INVALID_ARG;
+  const int A = p->map->n_agents;
+  if (cap_words < FL_COUNTERS + 2 * FLIGHT_MAX_TICKS + 4 * A) return SOGM_ERR_INVALID_ARG;
+  SOGM_HIP_CHECK(hipSetDevice(p->map->device));
+  SOGM_HIP_CHECK(hipDeviceSynchronize());
+  for (int i = 0; i < FL_COUNTERS; ++i)
+    SOGM_HIP_CHECK(hipMemcpy(out_words + i, p->fl.hdr + (size_t)i * FL_STRIDE, sizeof(int), hipMemcpyDeviceToHost));
+  int32_t *o = out_words + FL_COUNTERS;
+  SOGM_HIP_CHECK(hipMemcpy(o, p->fl.tick_done, sizeof(int) * FLIGHT_MAX_TICKS, hipMemcpyDeviceToHost));
+  o += FLIGHT_MAX_TICKS;
+  SOGM_HIP_CHECK(hipMemcpy(o, p->fl.parked_n, sizeof(int) * FLIGHT_MAX_TICKS, hipMemcpyDeviceToHost));
+  o += FLIGHT_MAX_TICKS;
+  SOGM_HIP_CHECK(hipMemcpy(o, p->fl.tick_of, sizeof(int) * (size_t)A, hipMemcpyDeviceToHost));
+  o += A;
+  SOGM_HIP_CHECK(hipMemcpy(o, p->fl.seg_done, sizeof(int) * (size_t)A, hipMemcpyDeviceToHost));
+  o += A;
+  SOGM_HIP_CHECK(hipMemcpy(o, p->fl.stage, sizeof(int) * (size_t)A, hipMemcpyDeviceToHost));
+  o += A;
+  SOGM_HIP_CHECK(hipMemcpy(o, p->fl.urgent, sizeof(int) * (size_t)A, hipMemcpyDeviceToHost));
+  if (out_ts) SOGM_HIP_CHECK(hipMemcpy(out_ts, p->fl.ts, sizeof(long long) * FL_TS * (size_t)A, hipMemcpyDeviceToHost));
+  return SOGM_OK;
+}
+
+// diagnostics (tools/, tests/): when every workgroup of the last flight's four kernels started — out_host [8][4096]: [0..3] wall-clock
+// ticks (100 MHz; 0 = the workgroup never ran), [4..7] where it started (HW_ID | XCC_ID << 32), out_wgs_host[4] the launched counts (QP, search, corridor + finish, map)
+int sogm_debug_flight_wg_starts(sogm_planner *p, long long *out_host, int32_t *out_wgs_host) {
+  if (!p || !p->d_fl || !out_host) return SOGM_ERR_INVALID_ARG;
+  SOGM_HIP_CHECK(hipSetDevice(p->map->device));
+  SOGM_HIP_CHECK(hipDeviceSynchronize());
+  SOGM_HIP_CHECK(hipMemcpy(out_host, p->fl.wg_start, sizeof(long long) * 8 * FL_WG_LOG, hipMemcpyDeviceToHost));
+  if (out_wgs_host)
+    for (int k = 0; k < 4; ++k) out_wgs_host[k] = p->fl_wgs[k];
+  return SOGM_OK;
+}
+
 int sogm_flight_stats(sogm_planner *p, double *out_ms, int32_t *out_hdr) {
   if (!p || !p->d_fl) return SOGM_ERR_INVALID_ARG;
   SOGM_HIP_CHECK(hipSetDevice(p->map->device));
@@ -1334,6 +1466,27 @@ int sogm_flight_stats(sogm_planner *p, double *out_ms, int32_t *out_hdr) {
     for (int i = 0; i < 32; ++i) out_hdr[i] = i < 15 ? tmp[(size_t)i * FL_STRIDE] : 0;  // (the urgent lane's four: not reported)
     delete[] tmp;
     SOGM_HIP_CHECK(e);
+    {  // [15]: workgroups of the four kernels that were NOT resident from the start (first instruction > 1 ms after the
+       // flight's first workgroup): must be 0 — the liveness argument (flight_layout) and tests/test_flight_gpu.py hold it
+      long long *ws = new (std::nothrow) long long[4 * FL_WG_LOG];
+      if (!ws) return SOGM_ERR_INVALID_ARG;
+      const hipError_t e2 = hipMemcpy(ws, p->fl.wg_start, sizeof(long long) * 4 * FL_WG_LOG, hipMemcpyDeviceToHost);
+      long long first = 0;
+      int       late  = 0;
+      for (int k = 0; k < 4; ++k)
+        for (int b = 0; b < p->fl_wgs[k] && b < FL_WG_LOG; ++b) {
+          const long long v = ws[(size_t)k * FL_WG_LOG + b];
+          if (v > 0 && (first == 0 || v < first)) first = v;
+        }
+      for (int k = 0; k < 4; ++k)
+        for (int b = 0; b < p->fl_wgs[k] && b < FL_WG_LOG; ++b) {
+          const long long v = ws[(size_t)k * FL_WG_LOG + b];
+          if (v == 0 || v - first > 100000) ++late;
+        }
+      delete[] ws;
+      SOGM_HIP_CHECK(e2);
+      out_hdr[15] = late;
+    }
     unsigned long long prof[16];  // [16..31]: wave time by activity in units of 10 us (0-8), descriptor counts (9-15)
     SOGM_HIP_CHECK(hipMemcpy(prof, p->fl.prof, sizeof(prof), hipMemcpyDeviceToHost));
     for (int i = 0; i < 16; ++i) out_hdr[16 + i] = (int32_t)(i < 9 ? prof[i] / 1000ull : prof[i]);

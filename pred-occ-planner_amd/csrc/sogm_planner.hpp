@@ -110,8 +110,10 @@ __device__ inline int flow_ticket(int *counter) {  // one ticket per wave, unifo
 // fixed by a staleness rule — agent a's tick k reads its own record of tick k - 1 and the neighbours' records as of
 // their tick k - 2 (table ver(k - 2)), and may start once every agent has finished tick k - 2 — and the SCHEDULE is free:
 // an agent whose chain is done goes straight on to its next tick while a straggler still solves its QP.
-// Four persistent kernels, each on a stream with its own compute units (hipExtStreamCreateWithCUMask: co-resident by
-// construction — no residency gates, no dispatch-order assumptions, four hardware queues):
+// Four persistent kernels, each on a stream with its own compute units (hipExtStreamCreateWithCUMask; every mask balanced over
+// the shader engines it touches and every launch exactly as large as its mask holds — flight_layout in sogm_planner.hip: all
+// workgroups resident from the first microsecond, which is also what lets a flight survive the hardware scheduler's queue
+// save / restore; no residency gates, no dispatch-order assumptions, four hardware queues):
 //   k_flight_map     a few admitting waves + role-less one-wave workgroups over ONE work queue of ready map work (a descriptor
 //                    is pushed when its prerequisites are complete, so no worker sits waiting on another).  The admitting
 //                    waves take agents in the order their previous tick finished and let `flight_admit` maps be under
@@ -204,9 +206,21 @@ struct FlightCtl {
   unsigned long long *prof;  // [16] wave time (100 MHz ticks) by activity, summed over the flight: 0 map workers idle (waiting
                              //      for a descriptor), 1 reset, 2 bits, 3 marks, 4 overlay, 5 heads (incl. their waits),
                              //      6 light waves idle, 7 corridor segments, 8 finish; 9.. descriptor counts of 1-4, 7, 8
+  long long *wg_start;       // [8][FL_WG_LOG] ([4..7]: where, HW_ID | XCC_ID << 32) wall clock at which workgroup b of kernel k (0 QP, 1 search, 2 corridor + finish, 3 map)
+                             //      executed its first instruction in this call (0: never) — the residency evidence of
+                             //      sogm_debug_flight_wg_starts: a workgroup that starts late was NOT resident from the start
   int  n_agents, n_ticks, first_tick;
 };
+#define FL_WG_LOG 4096
 #ifdef __HIPCC__
+__device__ inline void fl_wg_started(const FlightCtl &fl, int kernel) {
+  if (threadIdx.x == 0 && fl.wg_start && blockIdx.x < FL_WG_LOG) {
+    fl.wg_start[(size_t)kernel * FL_WG_LOG + blockIdx.x] = wall_clock64();
+    // where: HW_ID (wave / SIMD / CU / SH / SE) | XCC_ID << 32
+    fl.wg_start[(size_t)(4 + kernel) * FL_WG_LOG + blockIdx.x] =
+        (long long)(unsigned)__builtin_amdgcn_s_getreg(63492) | ((long long)(unsigned)__builtin_amdgcn_s_getreg(63508) << 32);
+  }
+}
 __device__ inline void fl_publish(int *ring, int mask, int *ready_n, int agent) {  // one lane; the item's data is written
   __threadfence();
   const int r = atomicAdd(ready_n, 1);

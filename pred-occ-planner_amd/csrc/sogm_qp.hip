@@ -1744,6 +1744,7 @@ __global__ __launch_bounds__(QP_NT) void k_flight_qp(SogmPlannerParams pp, SogmQ
                                                    double *out_cpts, int32_t *out_status, int32_t *out_iters) {
   __shared__ int s_agent;
   const int total = fl.n_agents * fl.n_ticks;
+  fl_wg_started(fl, 0);
   for (;;) {
     if (threadIdx.x < 64) {  // the first wave fetches the ticket and waits for its item (wave-uniform helpers)
       int       a = -1;

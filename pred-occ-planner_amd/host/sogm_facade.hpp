@@ -159,8 +159,10 @@ class RiskMap {
   void setResample(float replan_risk_rate, int num_resample, const float *normal_table_dev, int n_table) {
     check(sogm_set_resample(ctx_, replan_risk_rate, num_resample, normal_table_dev, n_table), "sogm_set_resample");
   }
-  // a tuning knob of this context (sogm_abi.h "Tuning knobs")
+#ifdef SOGM_ABI_DEBUG_H
+  // a tuning knob of this context (include/sogm_abi_debug.h "Tuning knobs"; there when that header was included first)
   void setTuning(const char *key, double value) { check(sogm_set_tuning(ctx_, key, value), "sogm_set_tuning"); }
+#endif
   void setSparseReset(bool on, int log_capacity_per_agent = 0) {
     check(sogm_set_sparse_reset(ctx_, on ? 1 : 0, log_capacity_per_agent), "sogm_set_sparse_reset");
   }
@@ -362,7 +364,7 @@ class Planner {
     if (!wait) return true;
     int32_t hdr[32];
     check(sogm_flight_stats(p_, nullptr, hdr), "sogm_flight_stats");
-    return hdr[4] == 0;
+    return hdr[4] == 0 && hdr[15] == 0;  // no time-out, and every workgroup of the flight was resident from the start
   }
   // bool BaselinePlanner::replan(t, start_pos, start_vel, start_acc, goal_pos) — batched
   void replan(const double *start_pva, const double *goal, const double *t_start, const int32_t *drone_ids,

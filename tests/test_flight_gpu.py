@@ -9,7 +9,16 @@ leaves the SCHEDULE free.  Checked here:
     the agents in;
   * that lock-step reference is held to the CPU oracle flown with the same rule, stage by stage (cells, A* pop order,
     polytopes, QP);
-  * a flight continues a flight; the full-size swarm (128 agents, 200^3 x 20) flies with no failed tick."""
+  * a flight continues a flight; the full-size swarm (128 agents, 200^3 x 20) flies with no failed tick;
+  * LIVENESS (round 6).  Round 5's driver box lost one 60-tick flight of five to the 3 s device time-out.  Cause: the
+    corridor kernel's compute-unit mask held four units in one shader engine and eight in another, the workgroup
+    dispatcher rotates over a mask's engines and stops at the first full one, so 120 of its 384 workgroups waited in the
+    dispatcher for the whole flight; whenever the hardware scheduler saved and restored the process's queues (any queue
+    created or destroyed on the device does that) they started in the freed slots ahead of the restored waves, and a
+    saved wave per XCD stayed saved until the other kernels left.  Held here: every workgroup of every flight starts
+    within 1 ms (hdr[15] == 0, asserted after EVERY flight of this file), full-size flights survive a queue being
+    created and destroyed in their middle with identical records, and 5 x 60 full-size ticks after a lock-step swarm has
+    lived in the process end with no error and the lock-step rule's ok fraction."""
 import importlib
 
 import numpy as np
@@ -45,6 +54,9 @@ def _flight(driver, grid, A, chunks, **kw):
         E, F = sw.planner._abi_idx = (pop_abi.FLIGHT_HDR_ERR, pop_abi.FLIGHT_HDR_FINISHED)
         assert hdr[E] == 0 and sw.planner.flow_failures() == (0, 0), (hdr.tolist(), sw.planner.flow_failures())
         assert hdr[F] == A * n and (ms[:, 7] == n).all(), (hdr.tolist(), ms[:, 7])
+        # every workgroup of the four kernels was running from the start (sogm_flight_stats hdr[15] = workgroups that started
+        # more than 1 ms late): what the flight's liveness under a queue save / restore rests on (csrc flight_layout)
+        assert hdr[pop_abi.FLIGHT_HDR_LATE_WGS] == 0, hdr.tolist()
         oks.append(ok.cpu().numpy().copy())
         recs.append(rec.cpu().numpy().copy())
     own = sw.own.cpu().numpy().copy()
@@ -118,3 +130,94 @@ def test_full_size_flight_equals_lockstep_rule(pop):
     assert np.array_equal(own_f, own_l) and cnt_f == cnt_l
     per = ms[:, :7].sum(axis=0) / ms[:, 7].sum()
     print("cfg2 flight, mean ms per agent-tick:", dict(zip(pop._abi.FLIGHT_STAT_NAMES, per.round(3))), "ok", int(ok_f.sum()), "of", K * A)
+
+
+def _poke_queue(delay_s):
+    """create and destroy a CU-masked stream (= a new hardware queue: the scheduler unmaps and remaps every queue of the
+    process, compute waves are saved and restored) `delay_s` from now, on a thread of its own"""
+    import ctypes as C
+    import threading
+    import time
+    path = next(m.split()[-1] for m in open("/proc/self/maps") if "libamdhip64" in m)
+    h = C.CDLL(path)
+    h.hipExtStreamCreateWithCUMask.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+    h.hipStreamDestroy.argtypes = [C.c_void_p]
+    res = {}
+
+    def run():
+        time.sleep(delay_s)
+        st = C.c_void_p()
+        mask = (C.c_uint32 * 8)(1, 0, 0, 0, 0, 0, 0, 0)
+        res["create"] = h.hipExtStreamCreateWithCUMask(C.byref(st), 8, mask)
+        res["destroy"] = h.hipStreamDestroy(st) if res["create"] == 0 else -1
+
+    th = threading.Thread(target=run)
+    th.start()
+    return th, res
+
+
+def test_full_size_flight_survives_a_queue_save_and_restore_with_identical_records(pop):
+    """A run-list change in the middle of a flight (here: this process creates and destroys a masked stream 60 / 150 / 250 ms
+    into 60-tick flights; on the round-5 layout the FIRST such flight timed out, tools/diag_flight_preempt.py) must cost a
+    flight nothing but time: no error, every agent-tick finished, and the records of the undisturbed flight, bit for bit."""
+    import torch
+    driver = importlib.import_module("pred-occ-planner_amd.driver")
+    A, n = 128, 60
+    calm = _flight(driver, "cfg2", A, [3, n, n])
+    sw = driver.SwarmTick("cfg2", A, moving_world=True, prestamp=False, grids=1)
+    sw.compute.prepare(0, 3 + 2 * n + 1)
+    oks, recs = [], []
+    for chunk, delay in ((3, None), (n, 0.06), (n, 0.25)):
+        th = _poke_queue(delay) if delay is not None else None
+        ok, rec = sw.fly(chunk)
+        torch.cuda.synchronize()
+        if th is not None:
+            th[0].join()
+            assert th[1] == {"create": 0, "destroy": 0}, th[1]
+        _, hdr = sw.planner.flight_stats()
+        assert hdr[pop._abi.FLIGHT_HDR_ERR] == 0 and hdr[pop._abi.FLIGHT_HDR_FINISHED] == A * chunk, hdr.tolist()
+        assert hdr[pop._abi.FLIGHT_HDR_LATE_WGS] == 0 and sw.planner.flow_failures() == (0, 0), hdr.tolist()
+        oks.append(ok.cpu().numpy().copy())
+        recs.append(rec.cpu().numpy().copy())
+    own = sw.own.cpu().numpy().copy()
+    sw.close()
+    assert np.array_equal(np.concatenate(oks), calm[0]) and np.array_equal(np.concatenate(recs), calm[1])
+    assert np.array_equal(own, calm[2])
+
+
+def test_soak_five_flights_of_sixty_after_a_lockstep_swarm_lived_in_the_process(pop):
+    """bench.py's sequence: a lock-step swarm (three grids, nine streams) flown and closed, then a fresh
+    flight swarm flying 3 + 20 + 5 x 60 full-size ticks — every flight checked when it ends: no error, every agent-tick
+    finished, no late workgroup, worst flight within 1.5 x of the best; the ok fraction equals the same rule flown lock-step."""
+    import time
+    import torch
+    driver = importlib.import_module("pred-occ-planner_amd.driver")
+    A, chunks = 128, [3, 20, 60, 60, 60, 60, 60]
+    head = driver.SwarmTick("cfg2", A, moving_world=True)
+    head.compute.prepare(0, 13)
+    for _ in range(12):
+        head.step()
+    torch.cuda.synchronize()
+    assert head.planner.flow_failures() == (0, 0)
+    scene = head.scene
+    head.close()
+    torch.cuda.empty_cache()
+    sw = driver.SwarmTick("cfg2", A, moving_world=True, prestamp=False, grids=1, scene=scene)
+    sw.compute.prepare(0, sum(chunks) + 1)
+    n_ok, per_tick = 0, []
+    for n in chunks:
+        t0 = time.perf_counter()
+        ok, _ = sw.fly(n)
+        torch.cuda.synchronize()
+        per_tick.append((time.perf_counter() - t0) / n * 1e3)
+        _, hdr = sw.planner.flight_stats()
+        assert hdr[pop._abi.FLIGHT_HDR_ERR] == 0 and hdr[pop._abi.FLIGHT_HDR_FINISHED] == A * n, (n, hdr.tolist())
+        assert hdr[pop._abi.FLIGHT_HDR_LATE_WGS] == 0 and sw.planner.flow_failures() == (0, 0), (n, hdr.tolist())
+        n_ok += int(ok.sum().item())
+    sw.close()
+    torch.cuda.empty_cache()
+    sixty = per_tick[2:]
+    assert max(sixty) <= 1.5 * min(sixty), per_tick
+    ok_l, _, _, _ = _lockstep_lag2(driver, "cfg2", A, sum(chunks), scene=scene, grids=1)
+    assert n_ok == int(ok_l.sum()), (n_ok, int(ok_l.sum()))
+    print("soak: ms per tick of the seven flights", [round(x, 2) for x in per_tick], "ok fraction", n_ok / (A * sum(chunks)))
