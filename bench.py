@@ -366,6 +366,19 @@ def main():
     moved = sw.map.map_traffic(reset=True)      # device-side counts of the timed region: what the resets and stamps moved
     sparse = sw.map.sparse_reset_state()        # (after it: this call restarts the reset's own counters)
     chain = flow_chain(pop, sw)                 # the last timed tick's per-agent stage times (dataflow replan)
+    # distinct 32-byte sectors among the entries of the CURRENT grid's mark log (the last timed tick's map): duplicates are
+    # zeroed twice by the reset and merge in the L2, so the honest HBM denominator is 4 B x entries + 32 B x DISTINCT sectors
+    log_distinct = None
+    if sparse["enabled"]:
+        import ctypes as _C
+        d3 = (_C.c_uint64 * 3)()
+        fn = pop.lib().sogm_debug_log_distinct
+        fn.restype, fn.argtypes = _C.c_int, [_C.c_void_p, _C.c_void_p]
+        if fn(sw.map.ctx, d3) == 0 and d3[0] > 0:
+            log_distinct = {"entries": int(d3[0]), "distinct_sectors": int(d3[1]), "ratio": d3[1] / d3[0],
+                            "agents_overflowed": int(d3[2]),
+                            "what": "the last timed tick's map: valid entries of its mark logs and the distinct sectors "
+                                    "among them (sogm_debug_log_distinct: test-and-set over a throw-away bitmap, untimed)"}
     sw.map.set_profiling(True)  # restart the rings for the stage pass below
     # stage pass on the state of the last tick (map must be live: rebuild it without the pre-clear)
     overlap_mode = sw.overlap_mode
@@ -464,16 +477,28 @@ def main():
         achieved, frac = rate(reset_bytes, avg[0])
         pmc = committed("r05_pmc_reset.json") or committed("r04_pmc_reset.json")
         traffic = pmc["bytes_per_entry"] * entries if pmc and "bytes_per_entry" in pmc else None
+        # rated on DISTINCT sectors: 4 B per entry read + 32 B per distinct sector written
+        distinct_bytes = (4.0 * entries + 32.0 * entries * log_distinct["ratio"]) if log_distinct else None
+        achieved_distinct, frac_distinct = rate(distinct_bytes, avg[0]) if distinct_bytes else (None, None)
         k_reset = {"kernel": "k_reset_sectors (sparse reset of the grid the update swapped out; side stream, under the replan's QP stage)",
                    "avg_launch_ms": float(avg[0]), "launches_timed": n_clear, "log_entries_per_launch": entries,
                    "bytes_zeroed_per_launch": zeroed, "bytes_per_launch": reset_bytes, "achieved": achieved, "frac": frac,
-                   "traffic": traffic, "standalone": reset_alone,
+                   "traffic": traffic, "standalone": reset_alone, "log_distinct": log_distinct,
+                   "bytes_distinct_per_launch": distinct_bytes, "achieved_distinct": achieved_distinct,
+                   "frac_distinct": frac_distinct,
+                   "counted_over_traffic": (reset_bytes / traffic) if traffic else None,
+                   "distinct_over_traffic": (distinct_bytes / traffic) if traffic and distinct_bytes else None,
                    "traffic_frac": (traffic / (avg[0] * 1e-3) / 1e9 / PEAK) if traffic else None,
                    "traffic_source": "profiles/r05_pmc_reset.json: rocprofv3 --pmc FETCH_SIZE (doubled, gfx950 streaming-read "
                                      "correction) + WRITE_SIZE per log entry, scaled by this run's entry count" if traffic else None}
         roofline = {"bound": "hbm", "kernel": k_reset["kernel"],
                     "achieved": achieved, "peak": PEAK, "unit": "GB/s", "frac": frac,
                     "traffic": traffic, "traffic_source": k_reset["traffic_source"],
+                    "traffic_frac": k_reset["traffic_frac"],
+                    # the same launch rated on 4 B x entries + 32 B x DISTINCT sectors (the log holds duplicates the stamp's
+                    # wave-local lookback cannot see; they are zeroed twice and merge in the L2)
+                    "achieved_distinct": achieved_distinct, "frac_distinct": frac_distinct,
+                    "bytes_distinct_per_launch": distinct_bytes, "log_distinct": log_distinct,
                     "bytes_per_launch": reset_bytes, "log_entries_per_launch": entries,
                     "bytes_zeroed_per_launch": zeroed,
                     "avg_launch_ms": float(avg[0]), "launches_timed": n_clear, "sparse_resets": n_res,

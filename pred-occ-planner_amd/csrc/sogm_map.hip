@@ -2522,6 +2522,71 @@ __global__ __launch_bounds__(256) void k_div_check(sogm::GridGeom g, unsigned bi
   if (blockIdx.x == 0 && threadIdx.x == 0) out[2] = (unsigned long long)g.fast_div;
 }
 extern "C" {
+// diagnostics (bench.py, tools/): how many DISTINCT 32-byte sectors the current grid's mark log names.  The log holds one entry
+// per mark the wave-local lookback could not merge (sogm_map.hip, stamp_marks_trips) — marks of different waves in one sector
+// are logged once each, the reset zeroes such a sector more than once and the stores merge in the L2 — so "4 B x entries +
+// 32 B x entries" over-counts what HBM moves; 4 B x entries + 32 B x DISTINCT sectors is the honest denominator.  A
+// test-and-set over a throw-away bitmap (one bit per sector and agent), outside any timed region: a returning atomic per
+// entry at 25-30 G/s would cost the stamp more than the duplicates cost the reset.
+}  // extern "C"
+__global__ __launch_bounds__(256) void k_log_distinct(sogm::MarkLog lg, int n_agents, unsigned *bitmap, size_t words_per_agent,
+                                                      unsigned long long *out) {
+  const int agent = blockIdx.y;
+  if (agent >= n_agents) return;
+  const unsigned  n = lg.n[agent] > (unsigned)lg.cap ? (unsigned)lg.cap : lg.n[agent];
+  const unsigned *e = lg.entries + (size_t)agent * lg.cap;
+  unsigned       *bm = bitmap + (size_t)agent * words_per_agent;
+  unsigned long long ent = 0, dis = 0;
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const unsigned sec = e[i];
+    if (sec == 0xFFFFFFFFu || (size_t)(sec >> 5) >= words_per_agent) continue;
+    ++ent;
+    const unsigned bit = 1u << (sec & 31);
+    if (!(atomicOr(bm + (sec >> 5), bit) & bit)) ++dis;
+  }
+  for (int d = 32; d >= 1; d >>= 1) {
+    ent += __shfl_xor(ent, d, 64);
+    dis += __shfl_xor(dis, d, 64);
+  }
+  if ((threadIdx.x & 63) == 0 && ent) {
+    atomicAdd(out, ent);
+    atomicAdd(out + 1, dis);
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0 && lg.n[agent] > (unsigned)lg.cap) atomicAdd(out + 2, 1ull);
+}
+extern "C" {
+// host out3 = {valid entries of the current grid's mark logs (all agents), distinct sectors among them, agents whose log
+// overflowed (their reset is dense: not counted)}.  Synchronises; allocates and frees V T / 64 bytes per agent.
+int sogm_debug_log_distinct(sogm_ctx *c, unsigned long long *out3_host) {
+  if (!c || !out3_host) return SOGM_ERR_INVALID_ARG;
+  SOGM_HIP_CHECK(hipSetDevice(c->device));
+  SOGM_HIP_CHECK(hipDeviceSynchronize());
+  const int     slot = sogm::cur_slot(c);
+  sogm::MarkLog lg   = c->sparse ? sogm::mark_log(c, slot) : sogm::MarkLog{nullptr, nullptr, 0, nullptr};
+  out3_host[0] = out3_host[1] = out3_host[2] = 0;
+  if (!lg.entries || !c->tracked[slot]) return SOGM_ERR_STATE;
+  const size_t cells_per_sector = 32 / c->cell_bytes();
+  const size_t sectors = ((size_t)c->spec.T * (size_t)c->geom.V + cells_per_sector - 1) / cells_per_sector;
+  const size_t words   = (sectors + 31) / 32;
+  unsigned           *bm = nullptr;
+  unsigned long long *d  = nullptr;
+  SOGM_HIP_CHECK(hipMalloc((void **)&bm, sizeof(unsigned) * words * (size_t)c->n_agents));
+  hipError_t e = hipMalloc((void **)&d, 3 * sizeof(unsigned long long));
+  if (e == hipSuccess) e = hipMemset(bm, 0, sizeof(unsigned) * words * (size_t)c->n_agents);
+  if (e == hipSuccess) e = hipMemset(d, 0, 3 * sizeof(unsigned long long));
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_log_distinct, dim3(64, c->n_agents), dim3(256), 0, nullptr, lg, c->n_agents, bm, words, d);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (e == hipSuccess) e = hipMemcpy(out3_host, d, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+  (void)hipFree(bm);
+  if (d) (void)hipFree(d);
+  SOGM_HIP_CHECK(e);
+  return SOGM_OK;
+}
+
 // diagnostics (tests/ only): GridGeom::div_res — the three-instruction fp32 division the stamp and the search use — against
 // the IEEE division, on the device, for EVERY float in [lo, hi) and its negative.  out3_host = {mismatches, bit pattern of the
 // first one (2^64 - 1 if none), whether the context uses the fast sequence at all (its resolution is 0.15f)}

@@ -50,3 +50,27 @@ def test_every_float_near_a_voxel_boundary_truncates_like_the_true_division():
     # values below 2^-20 truncate to voxel 0 either way
     tiny = np.float32([0.0, 1e-30, 1e-12, 2.0 ** -21, -1e-12])
     assert np.all(_div_res(tiny).astype(np.int32) == 0) and np.all((tiny / D).astype(np.int32) == 0)
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_every_float_on_the_device():
+    """EVERY float of [2^-20, 64) and its negative through GridGeom::div_res on the device (the hardware's own fused
+    multiply-adds, no emulation) against the device's IEEE division: 0 mismatches (sogm_debug_div_check; 4.4e8 operands)."""
+    import ctypes as C
+    import importlib
+    pop = importlib.import_module("pred-occ-planner_amd")
+    sogm = importlib.import_module("pred-occ-planner_amd.sogm")
+    lib = pop.lib()
+    lib.sogm_debug_div_check.restype = C.c_int
+    lib.sogm_debug_div_check.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_void_p]
+    m = sogm.SogmMap(pop.config.make_spec("parity"), 1)
+    out = (C.c_uint64 * 3)()
+    assert lib.sogm_debug_div_check(m.ctx, 2.0 ** -20, 64.0, out) == 0
+    assert out[2] == 1, "the parity grid's resolution (0.15f) must take the fast sequence"
+    assert out[0] == 0, f"{out[0]} mismatches, first at bit pattern {out[1]:#x}"
+    # ... and the range it is NOT used for stays the true division by construction
+    assert lib.sogm_debug_div_check(m.ctx, 64.0, 1.0e6, out) == 0 and out[0] == 0
+    m.close()

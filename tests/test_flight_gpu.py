@@ -221,3 +221,32 @@ def test_soak_five_flights_of_sixty_after_a_lockstep_swarm_lived_in_the_process(
     ok_l, _, _, _ = _lockstep_lag2(driver, "cfg2", A, sum(chunks), scene=scene, grids=1)
     assert n_ok == int(ok_l.sum()), (n_ok, int(ok_l.sum()))
     print("soak: ms per tick of the seven flights", [round(x, 2) for x in per_tick], "ok fraction", n_ok / (A * sum(chunks)))
+
+
+def test_flight_through_frames_of_different_sizes(pop, monkeypatch):
+    """agents of one flight are on ticks k and k + 1 at once; when those frames hold different numbers of
+    256-point blocks, the per-agent crop lists — one buffer for the whole flight — must keep ONE row stride (CloudBlocks::row,
+    the context's capacity), not the frame's block count: with the frame's count as the stride an agent's head overwrote the
+    list another agent's bits tickets were still reading, and obstacles went missing from a map.  Every frame here drops a
+    different number of trailing cloud points (block counts differ by up to 6); the flight must still equal the same rule
+    flown lock-step, where one tick runs at a time."""
+    scene_mod = importlib.import_module("pred-occ-planner_amd.scene")
+    driver = importlib.import_module("pred-occ-planner_amd.driver")
+    plain = scene_mod.WorldTimeline.frame
+    blocks = set()
+
+    def ragged(self, k):
+        f = plain(self, k)
+        n = len(f["cloud"]) - 530 * ((k * 7) % 4)
+        blocks.add((max(n, 256) + 255) // 256)
+        return {"cloud": np.ascontiguousarray(f["cloud"][:max(n, 256)]), "cylinders": f["cylinders"]}
+
+    monkeypatch.setattr(scene_mod.WorldTimeline, "frame", ragged)
+    K, A = 9, 6
+    ok_l, rec_l, own_l, cnt_l = _lockstep_lag2(driver, "parity", A, K)
+    ok_f, rec_f, own_f, last_f, cnt_f, ms = _flight(driver, "parity", A, [K])
+    assert len(blocks) >= 3, blocks   # (the frames really differ in their block counts)
+    assert np.array_equal(ok_f, ok_l), (ok_f, ok_l)
+    for k in range(K):
+        assert np.array_equal(rec_f[k], rec_l[k]), f"tick {k}: agents {np.flatnonzero((rec_f[k] != rec_l[k]).any(axis=1))}"
+    assert np.array_equal(own_f, own_l) and cnt_f == cnt_l
