@@ -800,6 +800,57 @@ def main():
         variants["flight"] = fl
         fw.close()
         torch.cuda.empty_cache()
+    if not args.no_variants and world > 1 and moving and args.steps <= pop._abi.FLIGHT_MAX_TICKS:
+        # ---- labelled variant on N > 1 ranks: the flight with the exchange BEHIND the call (SogmFlight::nccl_comm): every rank
+        # flies warm-up + timed ticks in ONE sogm_flight_run each, the per-tick all-gathers of the table versions are queued
+        # on the exchange stream behind device-side waits — no host step between ticks.  Verified like the lock-step line:
+        # every rank's own clock, error word, finished count, late workgroups; one failed rank fails the variant.  Every rank
+        # runs the same sequence of collectives whatever happens to it (a rank that raised still joins the all_gather below).
+        err_txt, dtf, okf, hdr = None, 0.0, None, None
+        fw = None
+        try:
+            torch.cuda.empty_cache()
+            fw = driver.SwarmTick(args.grid, A_loc, rank, world, local, dist=dist, deconflict=True, moving_world=True,
+                                  prestamp=False, grids=1, scene=scene_kept)
+            if not fw.exchange.active:
+                raise RuntimeError(f"the exchange is not the ABI's ({fw.exchange.fallback_reason})")
+            fw.compute.prepare(0, args.warmup + args.steps + 1)
+            fw.planner.flight_prepare(len(scene_kept["cloud"]))
+            barrier()
+            fw.fly(args.warmup)
+            barrier()
+            t1 = time.perf_counter()
+            okf, _ = fw.fly(args.steps)
+            barrier()
+            dtf = time.perf_counter() - t1
+            _, hdr = fw.planner.flight_stats()
+            if (hdr[pop._abi.FLIGHT_HDR_ERR] != 0 or int(hdr[pop._abi.FLIGHT_HDR_FINISHED]) != fw.A_loc * args.steps
+                    or hdr[pop._abi.FLIGHT_HDR_LATE_WGS] != 0 or fw.planner.flow_failures()[1]):
+                err_txt = (f"rank {rank}: device error {int(hdr[pop._abi.FLIGHT_HDR_ERR])}, "
+                           f"{int(hdr[pop._abi.FLIGHT_HDR_FINISHED])} of {fw.A_loc * args.steps} agent-ticks, "
+                           f"{int(hdr[pop._abi.FLIGHT_HDR_LATE_WGS])} late workgroups")
+        except Exception as e:  # noqa: BLE001
+            err_txt = f"rank {rank}: {str(e)[-300:]}"
+        mine = [dtf, float(int(okf.sum().item())) if okf is not None and err_txt is None else -1.0, 0.0 if err_txt is None else 1.0]
+        allr = [None] * world
+        dist.all_gather_object(allr, (mine, err_txt))
+        failed = [e for _, e in allr if e]
+        fl = {"unit": "replans/s", "ranks": world, "neighbour_record_staleness_ticks": 2,
+              "what": "sogm_flight_run on every rank, ONE call for all timed ticks, the per-tick all-gather of the table versions "
+                      "queued behind the call on the exchange stream (SogmFlight::nccl_comm): no host step between ticks",
+              "rank_ms_per_step": [m[0] / args.steps * 1e3 for m, _ in allr], "flights_failed": len(failed)}
+        if failed:
+            fl["error"] = failed
+        else:
+            dmax = max(m[0] for m, _ in allr)
+            fl.update({"value": A_loc * world * args.steps / dmax, "ms_per_step": dmax / args.steps * 1e3,
+                       "replans_ok_fraction": sum(m[1] for m, _ in allr) / float(A_loc * world * args.steps)})
+        variants["flight"] = fl
+        if fw is not None:
+            try:
+                fw.close()
+            except Exception:  # noqa: BLE001
+                pass
     out["variants"] = variants
     if not args.no_variants and world == 1 and args.grid == "cfg2":
         # ---- the other BASELINE configurations that fit one GPU, driver-timed in the same run

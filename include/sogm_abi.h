@@ -179,10 +179,11 @@ typedef struct sogm_ctx sogm_ctx;
 /* ------------------------------------------------------------------------------------------ */
 /* ABI version of this header; bumps on any change of a signature OR of the size of a buffer an entry point writes
  * (version 5: sogm_sparse_reset_state writes out[8] and sogm_profile_read SOGM_PROF_N = 8 doubles, where version 4's
- * first revision wrote 7; SogmWorld / the world-frame update entries / the flight entries were added).  A host
+ * first revision wrote 7; SogmWorld / the world-frame update entries / the flight entries were added; version 6: SogmFlight
+ * gained nccl_comm, sogm_flight_stats reports hdr[15], the profiling / tuning / debug entries moved to sogm_abi_debug.h).  A host
  * compares sogm_abi_version() with the SOGM_ABI_VERSION it was compiled against before any other call: the Python
  * binding and host/sogm_facade.hpp refuse a library of another version. */
-#define SOGM_ABI_VERSION 5
+#define SOGM_ABI_VERSION 6
 int         sogm_abi_version(void);
 /* Text of the last HIP error seen by this thread ("" if none). */
 const char *sogm_last_error(void);
@@ -775,9 +776,17 @@ int sogm_update_prestamped(sogm_ctx *ctx, const SogmTrajRecord *records, int n_r
  * following call with first_tick advanced by n_ticks continues the flight.  Needs the sparse reset (the agent's single grid is
  * reset through its mark log at the start of each of its ticks), body particles, 32-byte aligned agent grids.
  * Several ranks (n_total > n_agents: the batch is rows agent0 .. agent0 + n_agents - 1, the other rows belong to other
- * ranks): a call flies at most TWO ticks — ticks k and k + 1 read ver(k - 2) and ver(k - 1), which the host completes
- * between two calls by all-gathering every rank's rows of the versions the previous call finished (sogm_traj_allgather, in
- * place); same records as one process flying all agents (tests/test_exchange_gpu.py).  Four persistent kernels on
+ * ranks).  With `nccl_comm` set (an ncclComm_t, e.g. sogm_comm_handle) the exchange runs BEHIND the call, no host step
+ * between ticks: for every tick j of the call the library queues, on the context's exchange stream, a one-lane kernel that
+ * waits until every LOCAL agent has finished tick j, the in-place ncclAllGather of this rank's rows of ver(j)
+ * (tables[(j & 3) * n_total + agent0], n_agents records), and a one-lane kernel that marks ver(j) complete and queues the
+ * overlays of tick j + 2 parked at the gate; the gate of tick k's overlay is then "the all-gather of ver(k - 2) has completed
+ * here" — the same staleness rule, so the records equal those of one process flying all agents.  Every rank passes the same
+ * n_ticks (the collectives are matched one to one); a rank whose flight failed still runs all of its collectives.  The
+ * call's last two versions are complete when the exchange stream has drained: `stream` waits for it as for the flight.
+ * Without `nccl_comm` a call flies at most TWO ticks — ticks k and k + 1 read ver(k - 2) and ver(k - 1), which the host
+ * completes between two calls by all-gathering every rank's rows of the versions the previous call finished
+ * (sogm_traj_allgather, in place).  Both forms: tests/test_exchange_gpu.py (two ranks on one GPU, stand-in RCCL).  Four persistent kernels on
  * four streams with disjoint compute-unit masks (tuning keys flight_*_units, 16 CUs per unit); asynchronous: `stream`
  * waits for the flight's end.  SOGM_ERR_STATE if the planner was created without the dataflow path.
  */
@@ -795,12 +804,21 @@ typedef struct SogmFlight {
   int32_t          n_total, agent0;
   SogmTrajRecord  *log_records;          /* dev [n_ticks][A] every tick's sogm_replan-style output record ... */
   int32_t         *log_ok;               /* dev [n_ticks][A] ... and ok flag */
+  void            *nccl_comm;            /* several ranks: the communicator of the exchange behind the call (see above); NULL:
+                                            one process owns every row, or the host all-gathers between calls of two ticks */
 } SogmFlight;
 int sogm_flight_run(sogm_planner *p, const SogmFlight *flight, void *stream);
+/* Optional: creates the flight's control block and its five streams (four masked ones + the exchange stream), runs an empty
+ * kernel on each, so that their hardware queues exist before any flight is in the air, and allocates what the first
+ * sogm_flight_run would allocate (crop lists for frames of up to max_cloud_points points, the stamp's scratch) — the first
+ * call otherwise synchronises the DEVICE while it grows them.  For a host that flies several planners in ONE process (a
+ * second planner's first call would wait for the first planner's flight to end).  Reads the flight_* tuning keys like the
+ * first sogm_flight_run would.  Synchronises. */
+int sogm_flight_prepare(sogm_planner *p, int max_cloud_points);
 /* After a flight (synchronises): host out_ms[A][8] = per-agent sums over the last flight in ms {wait at the tick k - 2 gate,
  * map (reset + stamp + overlay), search (queue + A*), corridors (queue + FIRI), QP (queue + solve), finish, whole chain,
  * ticks completed}; host out_hdr[32] = the flight's control counters ([4] = error code, 0 = none; [5] = agent-ticks
- * finished; [15] = workgroups of the flight's four kernels that were NOT running within 1 ms of its first workgroup — must be
+ * finished; [15] = workgroups of the flight's four kernels that were NOT running within 1 ms of their kernel's first workgroup — must be
  * 0: every kernel's compute-unit mask holds the same number of units in every shader engine it touches and a launch has
  * exactly the workgroups that mask holds at once, so nothing waits in a dispatcher that a queue save / restore could start
  * ahead of a restored wave (DESIGN.md 3.1 "Liveness of the flight"); [16..24] = wave time of the map / corridor + finish kernels by activity, in units of 10 us: map workers idle,

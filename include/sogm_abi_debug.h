@@ -42,6 +42,10 @@ int sogm_sparse_reset_state(sogm_ctx *ctx, int32_t *out_host);
  *     more tickets; 0 = no such lane); "flight_gate_pace_us" (40): the staleness rule's gate — tick k reads the neighbours'
  *     records of tick k - 2 — sits in front of a map's overlay, the only phase that reads them: an agent builds the rest of its
  *     next map while it waits, and the finish that opens a gate queues the waiting overlays this many microseconds apart;
+ *     "flight_engines" (4), "flight_engine_first" (0): the shader engines (of every XCD) the flight's kernels share — a flight on
+ *     half of them leaves the other half to a second flight on the same device (two ranks as two threads: tests) —,
+ *     "flight_exchange_units" (0): units given to NO kernel, room for a collective's own kernels beside a multi-rank flight
+ *     (the Python driver sets 1 when torch.distributed runs over more than one rank: untested on hardware);
  *     "flight_light_per_cu" (4), "flight_map_per_cu" (8): one-wave workgroups of the corridor + finish / the map kernel per
  *     compute unit of their partition (what a unit holds at once; fewer leaves slack).  Whatever the unit counts, every
  *     kernel's mask gets the same number of units in every shader engine it touches and a launch exactly the workgroups

@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # (SOGM_LIB_PATH: another build of the same ABI, for same-box A/B runs of two library versions — tools/micro/ab.sh)
 LIB_PATH = os.environ.get("SOGM_LIB_PATH") or os.path.join(_HERE, "libsogm_hip.so")
 
-SOGM_ABI_VERSION = 5  # include/sogm_abi.h; load_library() refuses a library of another version
+SOGM_ABI_VERSION = 6  # include/sogm_abi.h; load_library() refuses a library of another version
 SOGM_MAX_PIECES = 16
 SOGM_MAP_FAKE = 0
 SOGM_MAP_RISKBASE = 1
@@ -118,7 +118,7 @@ class SogmFlight(C.Structure):
                 ("replan_start_offset", C.c_double), ("worlds", C.POINTER(SogmWorld)), ("goals", C.c_void_p),
                 ("drone_ids", C.c_void_p), ("hover_inout", C.c_void_p), ("own_inout", C.c_void_p),
                 ("tables", C.c_void_p), ("n_total", C.c_int32), ("agent0", C.c_int32), ("log_records", C.c_void_p),
-                ("log_ok", C.c_void_p)]
+                ("log_ok", C.c_void_p), ("nccl_comm", C.c_void_p)]
 
 
 FLIGHT_MAX_TICKS = 64
@@ -197,6 +197,7 @@ PROTOTYPES = {
     "sogm_update_prestamped": (_i, [_vp, _vp, _i, _vp, _vp]),
     "sogm_planner_counters": (_i, [_vp, C.POINTER(C.c_int64), _i]),
     "sogm_flight_run": (_i, [_vp, C.POINTER(SogmFlight), _vp]),
+    "sogm_flight_prepare": (_i, [_vp, _i]),
     "sogm_flight_stats": (_i, [_vp, _vp, _vp]),
     "sogm_planner_set_swarm": (_i, [_vp, _vp, _i, _vp, _vp]),
     "sogm_traj_allgather": (_i, [_vp, _vp, _vp, _i, _vp, _vp]),

@@ -2256,24 +2256,9 @@ __global__ __launch_bounds__(64) void k_flight_light(MapView m, SogmPlannerParam
           fl.urgent[a]      = urgent ? 1 : 0;
           fl_publish(urgent ? fl.u_ring : fl.m_ring, fl.ring_mask, &fl.hdr[urgent ? FL_U_READY : FL_M_READY], a);
         }
-        if (done_kl == A_ && kl + 2 < fl.n_ticks) {  // tick k is complete: the overlays of tick k + 2 parked so far may go
-          __threadfence();
-          int      *lst = fl.parked + (size_t)(kl + 2) * A_;
-          const int n   = __hip_atomic_load(&fl.parked_n[kl + 2], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-          for (int i = 0; i < n && i < A_; ++i) {
-            const int v = __hip_atomic_load(&lst[i], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-            if (v >= 0 && atomicCAS(&lst[i], v, -2) == v) {
-              const bool u                 = fl.urgent[v] != 0;
-              if (fl.gate_pace_ticks > 0 && i > 0) {
-                const long long p0 = wall_clock64();
-                while (wall_clock64() - p0 < fl.gate_pace_ticks) __builtin_amdgcn_s_sleep(32);
-              }
-              fl.ts[(size_t)v * FL_TS + 14] = wall_clock64();
-              wq_push(u ? fl.uw : fl.mw, &fl.hdr[u ? FL_UW_TAIL : FL_MW_TAIL], ((unsigned)WK_MAP_SPLAT << 28) | (unsigned)v,
-                      u ? fl.un_splat : fl.n_splat);
-            }
-          }
-        }
+        // tick k is complete: the overlays of tick k + 2 parked so far may go.  (Several ranks with the exchange behind the
+        // call: the gate is the all-gather of ver(k), and the kernel behind that collective releases them — k_flight_xsignal.)
+        if (done_kl == A_ && kl + 2 < fl.n_ticks && !fl.xready) fl_gate_release(fl, kl + 2);
       }
       continue;
     }

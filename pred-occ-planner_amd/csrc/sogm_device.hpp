@@ -485,6 +485,9 @@ __device__ inline void bezier_pos(const SogmTrajRecord &r, double t, double out[
   X(FLIGHT_URGENT_WAVES, "flight_urgent_waves", 4096, 1, 4096) /* flight: map workers that look at the urgent queue first (all of them by default) */ \
   X(FLIGHT_URGENT_FINE, "flight_urgent_fine", 4, 1, 16)    /* flight: the urgent lane's maps in this many times more tickets  */  \
   X(FLIGHT_GATE_PACE_US, "flight_gate_pace_us", 40, 0, 100000) /* flight: microseconds between two overlays a gate releases     */  \
+  X(FLIGHT_ENGINES, "flight_engines", 4, 1, 4)             /* flight: shader engines (of every XCD) the four kernels share ... */ \
+  X(FLIGHT_ENGINE_FIRST, "flight_engine_first", 0, 0, 3)   /* flight: ... starting with this one (two flights side by side on one device: tests) */ \
+  X(FLIGHT_EXCHANGE_UNITS, "flight_exchange_units", 0, 0, 4) /* flight: 16-CU units left to NO kernel (room for the collective's kernels beside a multi-rank flight) */ \
   X(FLIGHT_LIGHT_PER_CU, "flight_light_per_cu", 4, 1, 4)   /* flight: corridor + finish waves per compute unit of their partition (4 = every SIMD) */ \
   X(FLIGHT_MAP_PER_CU, "flight_map_per_cu", 8, 1, 8)       /* flight: map waves per compute unit of their partition            */ \
   X(UPDATE_FLOW, "update_flow", 0, 0, 1)                   /* sogm_update_world builds the maps agent by agent on a stream of its own; sogm_replan's searches start per agent */ \
@@ -692,6 +695,12 @@ inline int join_update(sogm_ctx *c, hipStream_t st) {
   }
   return SOGM_OK;
 }
+// csrc/sogm_exchange.hip: the context's exchange stream (created on first use), a raw all-gather queued on it in ITS order (no
+// event from a caller's stream: the caller has queued whatever the collective must wait for on that stream itself), and the
+// completion mark consumers join through join_exchange
+int exchange_stream(sogm_ctx *c, hipStream_t *out);
+int exchange_allgather_raw(sogm_ctx *c, void *nccl_comm, const void *send, void *recv, size_t bytes_per_rank);
+int exchange_mark_pending(sogm_ctx *c);
 inline int join_exchange(sogm_ctx *c, hipStream_t st) {
   if (c->exchange_pending && hipStreamWaitEvent(st, c->ev_xdone, 0) != hipSuccess) return SOGM_ERR_HIP;
   return SOGM_OK;

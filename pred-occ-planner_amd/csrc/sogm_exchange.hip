@@ -81,6 +81,45 @@ int rccl_fail(const char *what, ncclResult_t r) {
 
 }  // namespace
 
+namespace sogm {
+int exchange_stream(sogm_ctx *ctx, hipStream_t *out) {
+  if (!ctx->xstream) {
+    // A stream with a compute-unit mask — here: every unit — gets a hardware queue of its OWN (plain streams share a pool of
+    // GPU_MAX_HW_QUEUES queues).  The exchange stream carries kernels that WAIT (k_flight_xwait of a multi-rank flight: until a
+    // tick is complete) and collectives that wait for their peers: whatever shared their queue would wait with them — with two
+    // ranks in one process (tests) that was the other rank's control-block reset, and the flights stalled.
+    int n_cu = 256;
+    (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, ctx->device);
+    uint32_t mask[16];
+    for (int i = 0; i < 16; ++i) mask[i] = 0xFFFFFFFFu;
+    if (hipExtStreamCreateWithCUMask(&ctx->xstream, (uint32_t)((n_cu + 31) / 32 < 16 ? (n_cu + 31) / 32 : 16), mask) != hipSuccess) {
+      (void)hipGetLastError();
+      SOGM_HIP_CHECK(hipStreamCreateWithFlags(&ctx->xstream, hipStreamNonBlocking));
+    }
+    SOGM_HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_xin, hipEventDisableTiming));
+    SOGM_HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_xdone, hipEventDisableTiming));
+  }
+  if (out) *out = ctx->xstream;
+  return SOGM_OK;
+}
+int exchange_allgather_raw(sogm_ctx *ctx, void *nccl_comm, const void *send, void *recv, size_t bytes_per_rank) {
+  RcclApi *a = rccl();
+  if (!a) {
+    sogm::set_error_text("all-gather: librccl.so.1 could not be loaded");
+    return SOGM_ERR_COMM;
+  }
+  if (int rc = exchange_stream(ctx, nullptr)) return rc;
+  const ncclResult_t r = a->AllGather(send, recv, bytes_per_rank, ncclUint8, (ncclComm_t)nccl_comm, ctx->xstream);
+  if (r != ncclSuccess) return rccl_fail("ncclAllGather", r);
+  return SOGM_OK;
+}
+int exchange_mark_pending(sogm_ctx *ctx) {
+  SOGM_HIP_CHECK(hipEventRecord(ctx->ev_xdone, ctx->xstream));
+  ctx->exchange_pending = 1;
+  return SOGM_OK;
+}
+}  // namespace sogm
+
 struct sogm_comm {
   ncclComm_t comm;
   int        rank, world, device;
@@ -162,11 +201,7 @@ int sogm_traj_allgather(sogm_ctx *ctx, void *nccl_comm, const SogmTrajRecord *lo
     return SOGM_ERR_COMM;
   }
   SOGM_HIP_CHECK(hipSetDevice(ctx->device));
-  if (!ctx->xstream) {
-    SOGM_HIP_CHECK(hipStreamCreateWithFlags(&ctx->xstream, hipStreamNonBlocking));
-    SOGM_HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_xin, hipEventDisableTiming));
-    SOGM_HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_xdone, hipEventDisableTiming));
-  }
+  if (int rc = sogm::exchange_stream(ctx, nullptr)) return rc;
   // the local records are final once everything queued on the caller's stream so far has run; every earlier
   // reader of all_records was queued on (or joined to) that stream as well
   if (ctx->records_final_valid && ctx->records_final_ptr == local_records) {

@@ -1761,7 +1761,7 @@ __global__ __launch_bounds__(64) void k_flight_map(GridGeom g, FlightCtl fl, Fli
         if (!urgent) atomicAdd(&fl.hdr[FL_MAPS_DONE], 1);  // one more agent may be admitted (a map at the gate holds no worker)
         // the gate of the staleness rule: the overlay reads table ver(k - 2) — every agent must have finished tick k - 2.
         // Early: the overlay is parked, and the finish that completes that tick queues it (k_flight_light).
-        const bool open = kl < 2 || __hip_atomic_load(&fl.tick_done[kl - 2], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= A;
+        const bool open = fl_gate_open(fl, kl);
         if (open) {
           ts[14] = now;
           wq_push(wq, wq_tail, ((unsigned)WK_MAP_SPLAT << 28) | adr, n_s);
@@ -1771,8 +1771,7 @@ __global__ __launch_bounds__(64) void k_flight_map(GridGeom g, FlightCtl fl, Fli
           __hip_atomic_store(&lst[slot], agent, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
           __threadfence();
           // (the releaser may have scanned the list before this slot was written)
-          if (__hip_atomic_load(&fl.tick_done[kl - 2], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= A &&
-              atomicCAS(&lst[slot], agent, -2) == agent) {
+          if (fl_gate_open(fl, kl) && atomicCAS(&lst[slot], agent, -2) == agent) {
             ts[14] = wall_clock64();
             wq_push(wq, wq_tail, ((unsigned)WK_MAP_SPLAT << 28) | adr, n_s);
           }

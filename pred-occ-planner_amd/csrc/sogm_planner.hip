@@ -1027,6 +1027,24 @@ __global__ __launch_bounds__(256) void k_flight_seed(FlightCtl fl) {
   if (a == 0) fl.hdr[FL_M_READY] = fl.n_agents;
   for (int i = a; i < FLIGHT_MAX_TICKS * fl.n_agents; i += (int)(gridDim.x * blockDim.x)) fl.parked[i] = -1;
 }
+// the exchange behind a multi-rank flight (sogm_flight_run with SogmFlight::nccl_comm), on the exchange stream, per tick i of the
+// call: k_flight_xwait -> ncclAllGather(rows of ver(first_tick + i)) -> k_flight_xsignal
+__global__ void k_flight_xwait(FlightCtl fl, int i) {  // every local agent has finished tick i: its rows of the version are final
+  if (threadIdx.x != 0) return;
+  while (__hip_atomic_load(&fl.tick_done[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < fl.n_agents) {
+    // (no limit of its own: every wait INSIDE the flight is bounded and sets the error word, which ends this one — the
+    //  collective behind it still runs, its peers are waiting in theirs)
+    if (__hip_atomic_load(&fl.hdr[FL_ERR], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+    flow_pause();
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+__global__ void k_flight_xsignal(FlightCtl fl, int i) {  // every rank's rows of ver(first_tick + i) are here
+  if (threadIdx.x != 0) return;
+  __threadfence();
+  __hip_atomic_store(&fl.xready[i], fl.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  if (i + 2 < fl.n_ticks) fl_gate_release(fl, i + 2);
+}
 __global__ void k_flight_report(const int *__restrict__ hdr, int *__restrict__ host_words) {
   const int e = hdr[FL_ERR];
   if (e != 0) {
@@ -1060,7 +1078,7 @@ static int layout_rest_score(const int grid[4][4]) {  // units of the rest that 
   int touched = 0, smallest = 5;
   for (int se = 0; se < 4; ++se) {
     int n = 0;
-    for (int r = 0; r < 4; ++r) n += grid[se][r] < 0;
+    for (int r = 0; r < 4; ++r) n += grid[se][r] == -1;
     if (n > 0) {
       ++touched;
       if (n < smallest) smallest = n;
@@ -1091,7 +1109,7 @@ static void layout_search(int grid[4][4], const int want[4], const int order[3],
         if (!((set >> se) & 1)) continue;
         int got = 0;
         for (int r = 0; r < 4 && got < per; ++r)
-          if (grid[se][r] < 0) grid[se][r] = k, ++got;
+          if (grid[se][r] == -1) grid[se][r] = k, ++got;
         ok = got == per;
       }
       if (ok) layout_search(grid, want, order, depth + 1, rest_units, best_score, best);
@@ -1099,14 +1117,23 @@ static void layout_search(int grid[4][4], const int want[4], const int order[3],
     }
   }
 }
-static FlightLayout flight_layout(const int want[4]) {
+// engines [se0, se0 + n_se) are the flight's (the others belong to nobody here: -2); `reserved` units of them stay free of any
+// kernel (-3), taken from the highest engine's highest classes first
+static FlightLayout flight_layout(const int want[4], int se0 = 0, int n_se = 4, int reserved = 0) {
   FlightLayout L;
   int          grid[4][4], best_score = -1;
   for (int i = 0; i < 16; ++i) (&grid[0][0])[i] = -1, (&L.grid[0][0])[i] = -1;
+  for (int se = 0; se < 4; ++se)
+    if (se < se0 || se >= se0 + n_se)
+      for (int r = 0; r < 4; ++r) grid[se][r] = -2;
+  for (int se = se0 + n_se - 1, left = reserved; se >= se0 && left > 0; --se)
+    for (int r = 3; r >= 0 && left > 0; --r)
+      if (grid[se][r] == -1) grid[se][r] = -3, --left;
+  std::memcpy(L.grid, grid, sizeof(grid));
   const int order[3] = {0, 3, 1};  // QP and map (whole engines when they can have them), then the search
   layout_search(grid, want, order, 0, want[2], &best_score, L.grid);
   for (int i = 0; i < 16; ++i)
-    if ((&L.grid[0][0])[i] < 0) (&L.grid[0][0])[i] = 2;
+    if ((&L.grid[0][0])[i] == -1) (&L.grid[0][0])[i] = 2;
   for (int k = 0; k < 4; ++k) {
     int touched = 0, smallest = 5;
     for (int se = 0; se < 4; ++se) {
@@ -1129,7 +1156,7 @@ static int flight_setup(sogm_planner *p) {
   int ring = 1;
   while (ring < 2 * A) ring <<= 1;
   if (A >= (1 << 16)) return SOGM_ERR_INVALID_ARG;
-  const size_t words = FL_HDR + 4 * (size_t)ring + 6 * (size_t)FL_WQ_SLOTS + 2 * FLIGHT_MAX_TICKS + 4 * (size_t)A +
+  const size_t words = FL_HDR + 4 * (size_t)ring + 6 * (size_t)FL_WQ_SLOTS + 3 * FLIGHT_MAX_TICKS + 4 * (size_t)A +
                        (size_t)FLIGHT_MAX_TICKS * A + 2;
   SOGM_HIP_CHECK(hipMalloc((void **)&p->d_fl, sizeof(int) * words));
   SOGM_HIP_CHECK(hipMemset(p->d_fl, 0, sizeof(int) * words));  // (once: the urgent / priority queues start empty at position 0)
@@ -1143,6 +1170,7 @@ static int flight_setup(sogm_planner *p) {
   p->fl.lw        = reinterpret_cast<unsigned long long *>(q);  q += 2 * FL_WQ_SLOTS;
   p->fl.tick_done = q;              q += FLIGHT_MAX_TICKS;
   p->fl.parked_n  = q;              q += FLIGHT_MAX_TICKS;
+  p->fl_xready    = q;              q += FLIGHT_MAX_TICKS;
   p->fl.tick_of   = q;              q += A;
   p->fl.seg_done  = q;              q += A;
   p->fl.stage     = q;              q += A;
@@ -1171,7 +1199,10 @@ static int flight_setup(sogm_planner *p) {
   // start: nothing waits for a workgroup that is not running)
   int n_cu = 256;
   (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->device);
-  const int units_total = 16;
+  int n_se = c->tune_i(SOGM_TUNE_FLIGHT_ENGINES), se0 = c->tune_i(SOGM_TUNE_FLIGHT_ENGINE_FIRST);
+  if (se0 + n_se > 4) n_se = 4 - se0;
+  const int reserved    = c->tune_i(SOGM_TUNE_FLIGHT_EXCHANGE_UNITS);
+  const int units_total = 4 * n_se - reserved;
   int       u[4] = {c->tune_i(SOGM_TUNE_FLIGHT_QP_UNITS), c->tune_i(SOGM_TUNE_FLIGHT_SEARCH_UNITS), 0,
                     c->tune_i(SOGM_TUNE_FLIGHT_MAP_UNITS)};
   u[2] = units_total - u[0] - u[1] - u[3];
@@ -1180,7 +1211,7 @@ static int flight_setup(sogm_planner *p) {
     return SOGM_ERR_INVALID_ARG;
   }
   const bool         masks = c->tune_i(SOGM_TUNE_FLIGHT_MASKS) != 0;
-  const FlightLayout L     = flight_layout(u);
+  const FlightLayout L     = flight_layout(u, se0, n_se, reserved);
   for (int k = 0; k < 4; ++k) {
     uint32_t mask[16] = {0};
     int      cus = 0;
@@ -1209,6 +1240,12 @@ static int flight_setup(sogm_planner *p) {
   return SOGM_OK;
 }
 
+#ifdef SOGM_FLIGHT_TRACE
+#include <chrono>
+#define FL_TRACE(what) std::fprintf(stderr, "FLTRACE %p %s %.3f ms\n", (void *)p, what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count())
+#else
+#define FL_TRACE(what) (void)0
+#endif
 extern "C" {
 int sogm_flight_run(sogm_planner *p, const SogmFlight *f, void *stream) {
   if (!p || !f || f->n_ticks < 1 || f->n_ticks > FLIGHT_MAX_TICKS || f->first_tick < 0 || !f->worlds || !f->goals ||
@@ -1217,10 +1254,11 @@ int sogm_flight_run(sogm_planner *p, const SogmFlight *f, void *stream) {
   sogm_ctx *c = p->map;
   const int A = c->n_agents;
   if (f->n_total < A || f->agent0 < 0 || f->agent0 + A > f->n_total) return SOGM_ERR_INVALID_ARG;
-  if (f->n_total != A && f->n_ticks > 2) {
-    // several ranks: the rows of the OTHER ranks' agents in ver(k - 2) must be complete before tick k starts, and only
-    // the host can put them there (an all-gather of the finished versions between two calls): two ticks per call at most
-    sogm::set_error_text("sogm_flight_run: with n_total > n_agents (other ranks' rows in the tables) a call flies at most two ticks");
+  const bool xchg = f->n_total != A && f->nccl_comm != nullptr;  // the exchange runs behind the call (k_flight_xwait / xsignal)
+  if (f->n_total != A && !xchg && f->n_ticks > 2) {
+    // several ranks, no communicator: the rows of the OTHER ranks' agents in ver(k - 2) must be complete before tick k starts,
+    // and only the host can put them there (an all-gather of the finished versions between two calls): two ticks per call
+    sogm::set_error_text("sogm_flight_run: with n_total > n_agents (other ranks' rows in the tables) and no nccl_comm a call flies at most two ticks");
     return SOGM_ERR_INVALID_ARG;
   }
   if (!p->flow || !c->sparse || !c->d_body || c->n_body <= 0) return SOGM_ERR_STATE;
@@ -1283,6 +1321,7 @@ int sogm_flight_run(sogm_planner *p, const SogmFlight *f, void *stream) {
   }
   (void)words;
   FlightCtl fl   = p->fl;
+  fl.xready      = xchg ? p->fl_xready : nullptr;
   fl.n_ticks     = f->n_ticks;
   fl.first_tick  = f->first_tick;
   md.grid        = (void *)c->d_grid;
@@ -1341,7 +1380,7 @@ int sogm_flight_run(sogm_planner *p, const SogmFlight *f, void *stream) {
   // frames + control block, in stream order on the caller's stream
   SOGM_HIP_CHECK(hipMemcpyAsync(p->d_fl_worlds, p->h_fl_worlds, sizeof(FlightWorld) * (size_t)f->n_ticks, hipMemcpyHostToDevice, main));
   const int       ring    = p->fl.ring_mask + 1;
-  const int       n_words = FL_HDR + 4 * ring + 4 * FL_WQ_SLOTS + 2 * FLIGHT_MAX_TICKS + 4 * A;  // (the parked lists: k_flight_seed)
+  const int       n_words = FL_HDR + 4 * ring + 4 * FL_WQ_SLOTS + 3 * FLIGHT_MAX_TICKS + 4 * A;  // (the parked lists: k_flight_seed)
   const long long n_log   = (long long)f->n_ticks * A * (long long)(sizeof(SogmTrajRecord) / sizeof(int));
   hipLaunchKernelGGL(k_flight_reset, dim3(256), dim3(256), 0, main, fl, n_words, p->aw.verdict, p->fl.acc,
                      reinterpret_cast<int *>(f->log_records), n_log);
@@ -1351,6 +1390,7 @@ int sogm_flight_run(sogm_planner *p, const SogmFlight *f, void *stream) {
   SOGM_HIP_CHECK(hipGetLastError());
   SOGM_HIP_CHECK(hipEventRecord(p->fl_ev_in, main));
   for (int k = 0; k < 4; ++k) SOGM_HIP_CHECK(hipStreamWaitEvent(p->fl_stream[k], p->fl_ev_in, 0));
+  FL_TRACE("waits queued");
   // QP first, then search (each wants whole CUs), then the one-wave kernels: with masks the order is immaterial
   const int spec = c->tune_i(SOGM_TUNE_FLIGHT_SPEC) != 0 ? 1 : 0;
   if (sogm::launch_flight_qp(p->pp, p->qs, p->qw, p->qc, fl, p->fl_wgs[0], p->d_fl_pva, p->d_goal, p->d_polys, p->d_nfaces,
@@ -1362,6 +1402,7 @@ int sogm_flight_run(sogm_planner *p, const SogmFlight *f, void *stream) {
     (void)hipDeviceSynchronize();
     return SOGM_ERR_HIP;
   }
+  FL_TRACE("qp + search launched");
   sogm::FlightLightDev ld{};
   ld.start_pva   = p->d_fl_pva;
   ld.t_start     = p->d_fl_tstart;
@@ -1386,6 +1427,34 @@ int sogm_flight_run(sogm_planner *p, const SogmFlight *f, void *stream) {
     (void)hipDeviceSynchronize();
     return SOGM_ERR_HIP;
   }
+  FL_TRACE("light + map launched");
+  if (xchg) {
+    // The exchange behind the call: per tick [wait: every local agent has finished it] -> in-place all-gather of this rank's
+    // rows of its table version -> [mark the version complete, queue the overlays parked at its gate], all queued now, on the
+    // context's exchange stream, behind the control block's reset.  Every rank queues the same n_ticks collectives; a rank
+    // whose flight fails still runs them (the waiting kernel gives up on the error word), so no peer hangs in a collective.
+    hipStream_t xs = nullptr;
+    if (int rc = sogm::exchange_stream(c, &xs)) return rc;
+    SOGM_HIP_CHECK(hipStreamWaitEvent(xs, p->fl_ev_in, 0));
+    int rc_x = SOGM_OK;
+    for (int i = 0; i < f->n_ticks; ++i) {
+      const int       k   = f->first_tick + i;
+      SogmTrajRecord *tab = f->tables + (size_t)(k & 3) * f->n_total;
+      hipLaunchKernelGGL(k_flight_xwait, dim3(1), dim3(64), 0, xs, fl, i);
+      if (rc_x == SOGM_OK)  // (after a failed collective the remaining ones are not attempted: the communicator is broken)
+        rc_x = sogm::exchange_allgather_raw(c, f->nccl_comm, tab + f->agent0, tab, sizeof(SogmTrajRecord) * (size_t)A);
+      hipLaunchKernelGGL(k_flight_xsignal, dim3(1), dim3(64), 0, xs, fl, i);
+      if (i == 0) FL_TRACE("first collective queued");
+    }
+    FL_TRACE("collectives queued");
+    SOGM_HIP_CHECK(hipGetLastError());
+    if (int rc = sogm::exchange_mark_pending(c)) return rc;
+    if (int rc = sogm::join_exchange(c, main)) return rc;  // the call's last versions are complete when `stream` goes on
+    if (rc_x != SOGM_OK) {
+      (void)hipDeviceSynchronize();
+      return rc_x;
+    }
+  }
   for (int k = 0; k < 4; ++k) {
     SOGM_HIP_CHECK(hipEventRecord(p->fl_ev_done[k], p->fl_stream[k]));
     SOGM_HIP_CHECK(hipStreamWaitEvent(main, p->fl_ev_done[k], 0));
@@ -1396,6 +1465,50 @@ int sogm_flight_run(sogm_planner *p, const SogmFlight *f, void *stream) {
   c->cur_prestamped      = 0;
   c->records_final_valid = 0;
   c->n_stamps += f->n_ticks;
+  return SOGM_OK;
+}
+
+}  // extern "C"
+__global__ void k_flight_touch(int *word) {
+  if (threadIdx.x == 0 && word) atomicAdd(word, 0);
+}
+extern "C" {
+// Creates what the first sogm_flight_run would create — control block, the four masked streams, the exchange stream — and
+// runs one empty kernel on each, so that their hardware queues EXIST before any flight is in the air, and allocates what the
+// first sogm_flight_run would allocate (crop lists for frames of up to max_cloud_points points, the stamp's scratch): that
+// first call otherwise synchronises the DEVICE while it grows them.  A host that flies several planners in one process (two
+// ranks on one device: tests) calls this for each of them before the first flight — the second rank's first call would
+// otherwise wait for the first rank's flight to end, which waits for the second rank's rows.  Optional otherwise.  Synchronises.
+int sogm_flight_prepare(sogm_planner *p, int max_cloud_points) {
+  if (!p || max_cloud_points < 0) return SOGM_ERR_INVALID_ARG;
+  SOGM_HIP_CHECK(hipSetDevice(p->map->device));
+  if (int rc = flight_setup(p)) return rc;
+  {  // everything a first sogm_flight_run would allocate — and synchronise the DEVICE for: the per-agent crop lists for
+     // frames of up to max_cloud_points points (blocks of 256), the stamp's scratch
+    SogmWorld big{};
+    big.block_points = 256;
+    big.n_points     = max_cloud_points;
+    big.n_blocks     = (max_cloud_points + 255) / 256;
+    sogm::CloudBlocks cb{};
+    if (int rc = sogm::world_blocks(p->map, &big, &cb)) return rc;
+    sogm::PrestampDev tmp{};
+    if (p->map->sparse) {
+      if (int rc = sogm::prestamp_buffers(p->map, &tmp)) return rc;
+      // the current grid's mark log (its creation ends with a null-stream memset and synchronisation, which waits for every
+      // BLOCKING stream of the process — masked streams are — i.e. for another planner's flight) and the one dense clear that
+      // puts the grid under its log
+      sogm_ctx *c    = p->map;
+      const int slot = sogm::cur_slot(c);
+      if (!c->tracked[slot] || !sogm::mark_log(c, slot).entries)
+        if (int rc = sogm::launch_clear(c, nullptr, c->d_grid, false)) return rc;
+    }
+  }
+  hipStream_t xs = nullptr;
+  if (int rc = sogm::exchange_stream(p->map, &xs)) return rc;
+  for (int k = 0; k < 4; ++k) hipLaunchKernelGGL(k_flight_touch, dim3(1), dim3(64), 0, p->fl_stream[k], (int *)nullptr);
+  hipLaunchKernelGGL(k_flight_touch, dim3(1), dim3(64), 0, xs, (int *)nullptr);
+  SOGM_HIP_CHECK(hipGetLastError());
+  SOGM_HIP_CHECK(hipDeviceSynchronize());
   return SOGM_OK;
 }
 
@@ -1471,18 +1584,18 @@ int sogm_flight_stats(sogm_planner *p, double *out_ms, int32_t *out_hdr) {
       long long *ws = new (std::nothrow) long long[4 * FL_WG_LOG];
       if (!ws) return SOGM_ERR_INVALID_ARG;
       const hipError_t e2 = hipMemcpy(ws, p->fl.wg_start, sizeof(long long) * 4 * FL_WG_LOG, hipMemcpyDeviceToHost);
-      long long first = 0;
-      int       late  = 0;
-      for (int k = 0; k < 4; ++k)
+      int late = 0;
+      for (int k = 0; k < 4; ++k) {  // per kernel: against ITS first workgroup (the four launches may start a millisecond apart)
+        long long first = 0;
         for (int b = 0; b < p->fl_wgs[k] && b < FL_WG_LOG; ++b) {
           const long long v = ws[(size_t)k * FL_WG_LOG + b];
           if (v > 0 && (first == 0 || v < first)) first = v;
         }
-      for (int k = 0; k < 4; ++k)
         for (int b = 0; b < p->fl_wgs[k] && b < FL_WG_LOG; ++b) {
           const long long v = ws[(size_t)k * FL_WG_LOG + b];
           if (v == 0 || v - first > 100000) ++late;
         }
+      }
       delete[] ws;
       SOGM_HIP_CHECK(e2);
       out_hdr[15] = late;

@@ -193,6 +193,11 @@ struct FlightCtl {
   int *tick_done;   // [FLIGHT_MAX_TICKS] agents that have finished tick first_tick + i
   int *parked_n;    // [FLIGHT_MAX_TICKS] maps of tick first_tick + i whose overlay is parked at the gate "tick i - 2 is complete" ...
   int *parked;      // [FLIGHT_MAX_TICKS][A] ... the agents (-1 empty, -2 released)
+  int *xready;      // [FLIGHT_MAX_TICKS] several ranks with the exchange behind the call (SogmFlight::nccl_comm): == epoch once the
+                    // all-gather of table ver(first_tick + i) — every rank's rows — has completed here; null: one process owns
+                    // every row.  The gate of tick k's overlay is then xready[k - 2] instead of tick_done[k - 2] (which the
+                    // collective itself waited for), and the parked overlays are released by the kernel behind the collective
+                    // on the exchange stream (k_flight_xsignal) instead of by the finish that completes the tick.
   int *tick_of;     // [A] the tick the agent is in (absolute index)
   int *seg_done;    // [A] cumulative corridor segment slots finished
   int *stage;       // [A] cumulative map tickets finished
@@ -241,6 +246,34 @@ __device__ inline int fl_wait_item(const int *ring, int mask, int pos, int *err)
     if (wall_clock64() - t0 > FLOW_TIMEOUT_TICKS) {
       if ((threadIdx.x & 63) == 0) atomicExch(err, 12);
       return -1;
+    }
+  }
+}
+// the gate of the staleness rule in front of tick kl's overlay (kl relative to first_tick): is table ver(kl - 2) complete?
+__device__ inline bool fl_gate_open(const FlightCtl &fl, int kl) {
+  if (kl < 2) return true;  // (versions of an earlier call: complete before this call's kernels started)
+  if (fl.xready) return __hip_atomic_load(&fl.xready[kl - 2], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == fl.epoch;
+  return __hip_atomic_load(&fl.tick_done[kl - 2], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= fl.n_agents;
+}
+// table ver(kl - 2) has just become complete: queue the overlays of tick kl that were parked at the gate so far (ONE lane;
+// the parking side re-checks the gate after it has written its slot: list + compare-and-swap on both sides)
+__device__ inline void wq_push(unsigned long long *wq, int *tail, unsigned desc0, int count);
+__device__ inline void fl_gate_release(const FlightCtl &fl, int kl) {
+  const int A_ = fl.n_agents;
+  __threadfence();
+  int      *lst = fl.parked + (size_t)kl * A_;
+  const int n   = __hip_atomic_load(&fl.parked_n[kl], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+  for (int i = 0; i < n && i < A_; ++i) {
+    const int v = __hip_atomic_load(&lst[i], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+    if (v >= 0 && atomicCAS(&lst[i], v, -2) == v) {
+      const bool u = fl.urgent[v] != 0;
+      if (fl.gate_pace_ticks > 0 && i > 0) {
+        const long long p0 = wall_clock64();
+        while (wall_clock64() - p0 < fl.gate_pace_ticks) __builtin_amdgcn_s_sleep(32);
+      }
+      fl.ts[(size_t)v * FL_TS + 14] = wall_clock64();
+      wq_push(u ? fl.uw : fl.mw, &fl.hdr[u ? FL_UW_TAIL : FL_MW_TAIL], ((unsigned)WK_MAP_SPLAT << 28) | (unsigned)v,
+              u ? fl.un_splat : fl.n_splat);
     }
   }
 }
@@ -625,4 +658,5 @@ struct sogm_planner {
   int                 fl_cus[4];     // compute units of each stream's mask
   int                 fl_wgs[4];     // workgroups of each kernel
   int                 fl_epoch = 0;  // number of the last sogm_flight_run call (FlightCtl::epoch)
+  int                *fl_xready = nullptr;  // [FLIGHT_MAX_TICKS] FlightCtl::xready of a multi-rank flight
 };

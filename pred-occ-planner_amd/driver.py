@@ -378,6 +378,12 @@ class SwarmTick:
         half = (self.spec.L // 2) * 0.15
         self.scene = scene if scene is not None else scene_mod.make_scene(self.A_tot, half, seed=seed)
         lo, hi = shard_bounds(rank, world, self.A_loc)
+        if world > 1 and compute is None and dist is not None and "flight_engines" not in (tuning or {}) \
+                and "flight_exchange_units" not in (tuning or {}):
+            # several ranks, one GPU each: a flight's four kernels fill every compute unit, and the collective queued behind the
+            # call (SogmFlight::nccl_comm) runs kernels of its own — one 16-CU unit is left to no kernel (the map kernel gives it
+            # up) so that they find room.  NOT measured on hardware: no multi-GPU box.
+            tuning = dict(tuning or {}, flight_exchange_units=1, flight_map_units=3)
         self.compute = compute if compute is not None else HipCompute(
             self.spec, self.scene, lo, hi, device, overlap_clear, double_buffer, grids, tuning, moving_world)
         c = self.compute
@@ -593,6 +599,19 @@ class SwarmTick:
         assert self.tick == self._fl_next, "fly() continues flights only"
         log_r = torch.zeros((n_ticks, self.A_loc, _abi.TRAJ_RECORD_BYTES), dtype=torch.uint8, device="cuda")
         log_ok = torch.zeros((n_ticks, self.A_loc), dtype=torch.int32, device="cuda")
+        if self.exchange.active and os.environ.get("SOGM_FLIGHT_EXCHANGE", "device") == "device":
+            # the exchange behind the call (SogmFlight::nccl_comm): ONE call for all ticks — per tick a device-side wait, the
+            # in-place all-gather of this rank's rows and the release of the next-but-one tick's overlays are queued on the
+            # context's exchange stream; no host step between ticks, every rank passes the same n_ticks
+            assert 1 <= n_ticks <= _abi.FLIGHT_MAX_TICKS
+            worlds = [c.world(self.tick + i) for i in range(n_ticks)]
+            self.planner.flight(worlds, self.tick, self.t0, TICK_PERIOD, REPLAN_START_TIME, self.goals, self.dev["ego_ids"],
+                                self.hover, self.own, self._fl_tables, log_r, log_ok, n_total=self.A_tot, agent0=lo,
+                                comm=self.exchange.handle)
+            self.tick += n_ticks
+            self._fl_next = self.tick
+            self.all = self._fl_tables[(self.tick - 1) & 3]
+            return log_ok, log_r
         done = 0
         while done < n_ticks:
             n = min(2, n_ticks - done)

@@ -201,19 +201,26 @@ class SogmPlanner:
 
     # ---- sogm_flight_run: n ticks of every agent, each on its own clock ----
     def flight(self, worlds, first_tick, t0, period, start_offset, goals, drone_ids, hover, own, tables, log_records,
-               log_ok, n_total=None, agent0=0):
+               log_ok, n_total=None, agent0=0, comm=None):
         """n = len(worlds) replan ticks of every agent in one call (sogm_abi.h "Flight"): `worlds` sogm.World frames of
         ticks first_tick .. first_tick + n - 1, `tables` uint8 [4, n_total, 2064] (ver(j) at j & 3; this planner's agents
         are rows agent0 .. agent0 + A; with n_total > A the other rows are the caller's to fill between calls and n <= 2),
-        `log_records` uint8 [n, A, 2064], `log_ok` int32 [n, A].  Asynchronous on the current stream."""
+        `log_records` uint8 [n, A, 2064], `log_ok` int32 [n, A].  `comm` (an ncclComm_t handle, e.g. sogm_comm_handle):
+        several ranks with the exchange behind the call — no limit of two ticks, every rank passes the same n.
+        Asynchronous on the current stream."""
         n = len(worlds)
         arr = (_abi.SogmWorld * n)(*[w.c for w in worlds])
         f = _abi.SogmFlight(n, int(first_tick), float(t0), float(period), float(start_offset), arr, goals.data_ptr(),
                             drone_ids.data_ptr(), hover.data_ptr(), own.data_ptr(), tables.data_ptr(),
                             self.A if n_total is None else int(n_total), int(agent0),
-                            log_records.data_ptr(), log_ok.data_ptr())
+                            log_records.data_ptr(), log_ok.data_ptr(), comm)
         self._flight_keep = (worlds, arr, goals, drone_ids, hover, own, tables, log_records, log_ok)
         check(lib().sogm_flight_run(self._p, C.byref(f), _stream()), "sogm_flight_run")
+
+    def flight_prepare(self, max_cloud_points=0):
+        """the flight's streams, their hardware queues and its buffers (crop lists for frames of up to max_cloud_points points),
+        created now (sogm_flight_prepare): before several planners of one process fly at once"""
+        check(lib().sogm_flight_prepare(self._p, int(max_cloud_points)), "sogm_flight_prepare")
 
     def flight_stats(self):
         """(per-agent sums [A, 8] in ms: _abi.FLIGHT_STAT_NAMES, control counters [32]) of the last flight; synchronises"""

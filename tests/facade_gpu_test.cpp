@@ -108,9 +108,9 @@ int main() {
   REQUIRE(recordFromMsg(msg, back) && back.n_pieces == rec[0].n_pieces);
   // the second agent now sees the first one's trajectory in its map
   map.addOtherAgents(d_rec.data(), A, d_ids.data());
-  // ---- ABI version 5: per-update sensor frames and flights through the facade ----------------------------------------
+  // ---- ABI version 5 (6: SogmFlight::nccl_comm): per-update sensor frames and flights through the facade ----------------------------------------
   static_assert(sizeof(SogmWorld) == 3 * sizeof(void *) + 4 * sizeof(int32_t), "SogmWorld layout (the Python binding mirrors it)");
-  static_assert(sizeof(SogmFlight) == 2 * 4 + 3 * 8 + 6 * sizeof(void *) + 2 * 4 + 2 * sizeof(void *), "SogmFlight layout");
+  static_assert(sizeof(SogmFlight) == 2 * 4 + 3 * 8 + 6 * sizeof(void *) + 2 * 4 + 3 * sizeof(void *), "SogmFlight layout");
   REQUIRE(sogm_abi_version() == SOGM_ABI_VERSION);
   {
     // the same frame through sogm_update_world (device-side crop through the block index): same answers

@@ -48,7 +48,7 @@ def test_struct_sizes_match_header(pop):
 
 def test_abi_version_and_device_count(pop):
     lib = pop.lib()
-    assert lib.sogm_abi_version() == pop._abi.SOGM_ABI_VERSION == 5
+    assert lib.sogm_abi_version() == pop._abi.SOGM_ABI_VERSION == 6
     assert lib.sogm_device_count() >= 0
 
 

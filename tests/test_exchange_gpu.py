@@ -321,6 +321,98 @@ def test_two_rank_flight_run_in_two_tick_calls_matches_the_single_process_flight
     so = tmp_path / "libfake_rccl.so"
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-std=c++17", "-shared", "-fPIC",
                            os.path.join(root, "tests", "fake_rccl.cpp"), "-o", str(so)])
-    env = dict(os.environ, SOGM_RCCL_LIB=str(so), SOGM_REPO=root)
+    env = dict(os.environ, SOGM_RCCL_LIB=str(so), SOGM_REPO=root, SOGM_FLIGHT_EXCHANGE="host")
     r = subprocess.run([sys.executable, "-c", _TWO_RANK_CHUNKED_FLIGHT], env=env, capture_output=True, text=True, timeout=500)
     assert r.returncode == 0 and "two-rank chunked flight ok" in r.stdout, (r.stdout[-3000:], r.stderr[-3000:])
+
+
+# Two ranks, ONE sogm_flight_run call of 20 ticks each, the exchange behind the call (SogmFlight::nccl_comm): per tick a
+# device-side wait, the in-place all-gather of the rank's rows (stand-in RCCL) and the release of the overlays parked at the
+# gate run on each context's exchange stream — no host step between ticks.  Both flights are in the air AT ONCE on one GPU:
+# each takes two of the four shader engines (tuning keys flight_engines / flight_engine_first; 2 + 2 + 2 + 2 units).
+_TWO_RANK_DEVICE_EXCHANGE_FLIGHT = _TWO_RANK_FLIGHT[:_TWO_RANK_FLIGHT.index("dist = ThreadDist(WORLD)")] + r"""
+TICKS = 20
+dist = ThreadDist(WORLD)
+res, errs = {}, []
+# Two ranks in ONE process share the pool of hardware queues, and a rank's stream holds a barrier packet for the whole length
+# of its flight (the call's closing kernel waits for the four kernels): the OTHER rank's stream must not sit in the same
+# queue behind it — each thread's stream is therefore created with a compute-unit mask (every unit), which gives it a
+# hardware queue of its own.  (One rank per process, the deployment, has no such neighbour.)
+torch.cuda.init()
+_hip = C.CDLL(next(m.split()[-1] for m in open("/proc/self/maps") if "libamdhip64" in m))
+_hip.hipExtStreamCreateWithCUMask.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+def own_queue_stream():
+    st, mask = C.c_void_p(), (C.c_uint32 * 8)(*([0xFFFFFFFF] * 8))
+    assert _hip.hipExtStreamCreateWithCUMask(C.byref(st), 8, mask) == 0
+    return torch.cuda.ExternalStream(st.value)
+def run(rank):
+    try:
+        tls.rank = rank
+        torch.cuda.set_device(0)
+        with torch.cuda.stream(own_queue_stream()):
+            tuning = {"flight_engines": 2, "flight_engine_first": 2 * rank, "flight_qp_units": 2, "flight_search_units": 2,
+                      "flight_map_units": 2}
+            sw = driver.SwarmTick("parity", A_LOC, rank, WORLD, 0, dist=dist, moving_world=True, prestamp=False, tuning=tuning)
+            assert sw.exchange.active and sw.distributed
+            sw.compute.prepare(0, TICKS + 1)     # the sensor frames, uploaded (a pageable upload synchronises)
+            sw.planner.flight_prepare(len(sw.scene["cloud"]))   # queues and buffers of both flights exist before either is in the air
+            dist.bar.wait()
+            ok_l, rec_l = sw.fly(TICKS)          # ONE call: n_total = 8, agent0 = 4 rank, comm = the stand-in's
+            torch.cuda.current_stream().synchronize()
+            ms, hdr = sw.planner.flight_stats()
+            assert hdr[pop._abi.FLIGHT_HDR_ERR] == 0 and hdr[pop._abi.FLIGHT_HDR_FINISHED] == A_LOC * TICKS, hdr.tolist()
+            assert hdr[pop._abi.FLIGHT_HDR_LATE_WGS] == 0, hdr.tolist()
+            res[rank] = (ok_l.cpu().numpy().copy(), rec_l.cpu().numpy().copy(), sw.all.cpu().numpy().copy(),
+                         sw.own.cpu().numpy().copy(), sw._fl_tables.cpu().numpy().copy())
+            dist.bar.wait()          # nobody destroys its communicator while the other is still in a collective
+            sw.close()
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        errs.append((rank, traceback.format_exc()))
+        try: dist.bar.abort()
+        except Exception: pass
+ts = [threading.Thread(target=run, args=(r,), daemon=True) for r in range(WORLD)]
+[t.start() for t in ts]
+[t.join(240) for t in ts]
+if errs or any(t.is_alive() for t in ts):
+    print("FAILED", errs, [t.is_alive() for t in ts], flush=True)
+    os._exit(3)
+# the same flight in one process, one twenty-tick call
+sw = driver.SwarmTick("parity", A_LOC * WORLD, moving_world=True, prestamp=False)
+ok_r, rec_r = sw.fly(TICKS)
+torch.cuda.synchronize()
+ok_r, rec_r, tab_r, own_r = ok_r.cpu().numpy(), rec_r.cpu().numpy(), sw.all.cpu().numpy().copy(), sw.own.cpu().numpy().copy()
+ring_r = sw._fl_tables.cpu().numpy().copy()
+sw.close()
+assert ok_r.sum() >= 2 * TICKS
+for r in range(WORLD):
+    lo, hi = r * A_LOC, (r + 1) * A_LOC
+    assert np.array_equal(res[r][0], ok_r[:, lo:hi]), ("ok flags differ", r)
+    for k in range(TICKS):
+        assert np.array_equal(res[r][1][k], rec_r[k, lo:hi]), ("per-tick records differ", r, k)
+    assert np.array_equal(res[r][2], tab_r), ("last table differs", r)
+    assert np.array_equal(res[r][3], own_r[lo:hi])
+    assert np.array_equal(res[r][4], ring_r), ("the ring of table versions differs", r)   # every rank holds every row of every version
+print("two-rank device-exchange flight ok", ok_r.sum(axis=1).tolist())
+"""
+
+
+@pytest.mark.own_device
+def test_two_rank_flight_with_the_exchange_behind_the_call_matches_the_single_process_flight(pop, tmp_path):
+    """a multi-rank flight that does not go back to the host every two ticks.  Two SwarmTick ranks as two
+    host threads on one GPU each fly 20 ticks in ONE sogm_flight_run call (n_total = 8, agent0 = 0 / 4, nccl_comm = the
+    stand-in RCCL's communicator); the table versions are exchanged by collectives queued behind the call, the gate of tick
+    k's overlay is the all-gather of ver(k - 2).  Records, ok flags, own records, the last table and the whole ring of four
+    versions equal ONE process flying all 8 agents in a single call.  (Reference: the drones never wait for each other and
+    read whatever arrived last, plan_manager.cpp:92-233, particles.cpp:179-190.)"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = tmp_path / "libfake_rccl.so"
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-std=c++17", "-shared", "-fPIC",
+                           os.path.join(root, "tests", "fake_rccl.cpp"), "-o", str(so)])
+    env = dict(os.environ, SOGM_RCCL_LIB=str(so), SOGM_REPO=root)
+    r = subprocess.run([sys.executable, "-c", _TWO_RANK_DEVICE_EXCHANGE_FLIGHT], env=env, capture_output=True, text=True,
+                       timeout=500)
+    assert r.returncode == 0 and "two-rank device-exchange flight ok" in r.stdout, (r.stdout[-3000:], r.stderr[-3000:])
