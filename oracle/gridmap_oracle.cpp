@@ -36,7 +36,11 @@ struct GM {
   bool   has_first_depth = false, local_updated = false;
   int    lb_min[3], lb_max[3];
   std::vector<double> proj;  // xyz
-  std::queue<int>     cache;  // addresses (the reference queues Vector3i ids)
+  struct Queued { int a, id[3]; };
+  std::queue<Queued>  cache;  // the reference queues the Vector3i id of a voxel's FIRST touch of the frame (:199-201): kept with
+                              // its address — an id with a component outside the map (a ray voxel below the ground plane:
+                              // z = -1) reaches, through the unchecked flat address, the top cell of the neighbouring row, and
+                              // the fusion judges `in_local` on that ID (:430-433), not on the cell the address decodes to
   int N() const { return nv[0] * nv[1] * nv[2]; }
 };
 
@@ -62,7 +66,7 @@ int setCacheOccupancy(GM &g, const double p[3], int occ) {
   const int a = addr(g, id[0], id[1], id[2]);
   if (a < 0 || a >= g.N()) return -1;  // out of bounds = UB in the reference; not emulated
   g.cnt_hm[a] += 1;
-  if (g.cnt_hm[a] == 1) g.cache.push(a);
+  if (g.cnt_hm[a] == 1) g.cache.push(GM::Queued{a, {id[0], id[1], id[2]}});
   if (occ == 1) g.cnt_hit[a] += 1;
   return a;
 }
@@ -258,9 +262,9 @@ void raycastProcess(GM &g, const double cam[3]) {
   boundIndex(g, min_id);
   boundIndex(g, max_id);
   while (!g.cache.empty()) {
-    const int a = g.cache.front();
+    const GM::Queued q = g.cache.front();
     g.cache.pop();
-    const int ix = a / (g.nv[1] * g.nv[2]), iy = (a / g.nv[2]) % g.nv[1], iz = a % g.nv[2];
+    const int a = q.a, ix = q.id[0], iy = q.id[1], iz = q.id[2];
     const int    hm = (int16_t)g.cnt_hm[a], hit = (int16_t)g.cnt_hit[a];  // `short` counters (grid_map.h)
     const double upd = hit >= hm - hit ? g.hit_log : g.miss_log;
     g.cnt_hit[a] = g.cnt_hm[a] = 0;

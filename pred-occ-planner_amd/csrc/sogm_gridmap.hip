@@ -56,6 +56,8 @@ struct GmDev {
   int     *cnt_hm, *cnt_hit;  // [A][N]
   unsigned long long *rayend, *own[2];  // [A][N] epoch-tagged keys
   int     *touched;   // [A][N]
+  unsigned long long *first_trav;  // [A][N] epoch-tagged: the earliest TRAVERSAL touch of the address this frame — (ray << 12 |
+                                   // step << 1 | its id had a component outside the map) — k_gm_count / k_gm_fuse
   double  *pt;        // [A][n_samples][3] ray end (world)
   int     *end_vox;   // [A][n_samples]  (-1: sample dropped)
   int     *stop[2];   // [A][n_samples] steps walked in the previous / current round
@@ -415,10 +417,22 @@ __global__ __launch_bounds__(256) void k_gm_count(GmDev d) {
   rc.set(st, en);
   const int                 fr  = s.dedup ? gm_final_round(s) : 0;
   const unsigned long long *own = d.own[fr & 1] + (size_t)a * d.N;
-  int c[3];
+  int c[3], step = 0;
   while (rc.step(c)) {
     const double tmp[3] = {(c[0] + 0.5) * d.res, (c[1] + 0.5) * d.res, (c[2] + 0.5) * d.res};
     const int    ad     = gm_touch(d, s, a, tmp, 0);
+    if (ad >= 0) {
+      // The reference queues the Vector3i ID of a voxel's first touch of the frame and judges `in_local` on that id (:199-201,
+      // :430-433).  An id with a component outside the map — a ray voxel below the ground plane has z = -1 — reaches, through
+      // the unchecked flat address, a cell of the neighbouring row: if that touch is the address's FIRST of the frame, the cell
+      // counts as "outside the local range".  Sequential order = (ray, step); kept as an epoch-tagged maximum of its complement.
+      int id[3];
+      gm_pos_to_index(d, tmp, id);
+      const unsigned wrapped = (id[0] < 0 || id[0] >= d.nv[0] || id[1] < 0 || id[1] >= d.nv[1] || id[2] < 0 || id[2] >= d.nv[2]) ? 1u : 0u;
+      const unsigned v = ((unsigned)i << 12) | ((unsigned)(step < 2047 ? step : 2047) << 1) | wrapped;
+      atomicMax(&d.first_trav[(size_t)a * d.N + ad], ((unsigned long long)(unsigned)s.raycast_num << 32) | (unsigned long long)(0xffffffffu - v));
+    }
+    ++step;
     if (ad < 0 || !s.dedup) continue;
     const int o = gm_key_ray(own[ad], s.raycast_num, fr + 1);
     if (o >= 0 && o < i) break;
@@ -485,8 +499,20 @@ __global__ __launch_bounds__(256) void k_gm_fuse(GmDev d) {
       continue;
     }
     const int ix = ad / (d.nv[1] * d.nv[2]), iy = (ad / d.nv[2]) % d.nv[1], iz = ad % d.nv[2];
-    const bool in_local = ix >= s.upd_min[0] && ix <= s.upd_max[0] && iy >= s.upd_min[1] && iy <= s.upd_max[1] &&
-                          iz >= s.upd_min[2] && iz <= s.upd_max[2];
+    // whose id was queued for this address: the first touch of the frame in (ray, step) order.  Ray-END touches are of points
+    // inside the map (their ids are the cell's own) and a ray's end touch precedes its traversal; a traversal touch may have
+    // come through an id outside the map (k_gm_count): such an id is never inside [upd_min, upd_max]
+    bool first_is_wrapped = false;
+    {
+      const unsigned long long kt = d.first_trav[at];
+      if ((unsigned)(kt >> 32) == (unsigned)s.raycast_num) {
+        const unsigned v = 0xffffffffu - (unsigned)(kt & 0xffffffffu);
+        const int      j_end = gm_key_ray(d.rayend[at], s.raycast_num, 0);
+        first_is_wrapped = (v & 1u) != 0 && !(j_end >= 0 && j_end <= (int)(v >> 12));
+      }
+    }
+    const bool in_local = !first_is_wrapped && ix >= s.upd_min[0] && ix <= s.upd_max[0] && iy >= s.upd_min[1] &&
+                          iy <= s.upd_max[1] && iz >= s.upd_min[2] && iz <= s.upd_max[2];
     if (!in_local) o = d.cmin_log;
     d.occ[at] = fmin(fmax(o + upd, d.cmin_log), d.cmax_log);
   }
@@ -662,6 +688,7 @@ int sogm_gridmap_create(const SogmGridMapParams *P, int n_agents, int device, so
   bad |= alloc((void **)&d.own[0], A * N * 8);
   bad |= alloc((void **)&d.own[1], A * N * 8);
   bad |= alloc((void **)&d.touched, A * N * sizeof(int));
+  bad |= alloc((void **)&d.first_trav, A * N * 8);
   bad |= alloc((void **)&d.pt, A * NS * 3 * sizeof(double));
   bad |= alloc((void **)&d.end_vox, A * NS * sizeof(int));
   bad |= alloc((void **)&d.stop[0], A * NS * sizeof(int));
@@ -698,6 +725,7 @@ int sogm_gridmap_create(const SogmGridMapParams *P, int n_agents, int device, so
   if (e == hipSuccess) e = hipMemset(d.rayend, 0, A * N * 8);
   if (e == hipSuccess) e = hipMemset(d.own[0], 0, A * N * 8);
   if (e == hipSuccess) e = hipMemset(d.own[1], 0, A * N * 8);
+  if (e == hipSuccess) e = hipMemset(d.first_trav, 0, A * N * 8);
   if (e == hipSuccess) {
     hipLaunchKernelGGL(k_gm_fill_f64, dim3(2048), dim3(256), 0, 0, d.occ, A * N, d.unk);
     e = hipDeviceSynchronize();
