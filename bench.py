@@ -439,7 +439,7 @@ def main():
 
     # ---- the dense clear: the kernel that does SURVEY 8(d)'s work (first use of a grid, dense writers, SOGM_SPARSE_RESET=0)
     sa_gbps, sa_frac = rate(grid_bytes, min(standalone_clear_ms))
-    pmc_dense = committed("r05_pmc_traffic.json") or committed("r04_pmc_traffic.json")
+    pmc_dense = committed("r06_pmc_traffic.json") or committed("r05_pmc_traffic.json")
     k_dense = {"kernel": "k_clear_slabs / k_clear_chunks (dense clear: V*T*4 B per agent-update, SURVEY 8(d))",
                "bytes_per_launch": grid_bytes,
                "standalone": {"where": "full width, machine to itself, stage pass after the timed region",
@@ -451,7 +451,7 @@ def main():
     marks, s_entries = int(stamp_moved["stamp_marks"]), int(stamp_moved["stamp_entries"])
     stamp_alg = 4 * marks + 4 * s_entries
     st_gbps, st_frac = rate(stamp_alg, stamp_ms)
-    pmc_stamp = committed("r05_pmc_stamp.json") or committed("r04_pmc_stamp.json")
+    pmc_stamp = committed("r06_pmc_stamp.json") or committed("r05_pmc_stamp.json")
     k_stamp = {"kernel": "k_cull_cylinders + k_stamp_bits + k_stamp_marks (the stamp; stage pass after the timed region, "
                          "machine to itself — inside the headline tick the same kernels run at its start, on the critical path; in the "
                          "pre-stamped variant as k_prestamp_flow under the replan)",
@@ -464,7 +464,7 @@ def main():
                "traffic": (pmc_stamp or {}).get("bytes_per_launch"),
                "write_amplification": ((pmc_stamp["bytes_per_launch"] / pmc_stamp["algorithmic_bytes_per_launch"])
                                        if pmc_stamp and pmc_stamp.get("algorithmic_bytes_per_launch") else None),
-               "traffic_source": "profiles/r05_pmc_stamp.json (committed rocprofv3 --pmc passes of the same cell order, not measured in this run)"
+               "traffic_source": "profiles/r06_pmc_stamp.json (r05 until it exists; committed rocprofv3 --pmc passes of the same cell order, not measured in this run)"
                                  if pmc_stamp else None}
     if sparse["enabled"] and moved["resets"] > 0:
         # The map is no longer rebuilt by filling V x T cells: the reset zeroes the lines named by the mark log (DESIGN
@@ -475,7 +475,7 @@ def main():
         zeroed = moved["reset_bytes_zeroed"] / n_res
         reset_bytes = 4.0 * entries + zeroed
         achieved, frac = rate(reset_bytes, avg[0])
-        pmc = committed("r05_pmc_reset.json") or committed("r04_pmc_reset.json")
+        pmc = committed("r06_pmc_reset.json") or committed("r05_pmc_reset.json")
         traffic = pmc["bytes_per_entry"] * entries if pmc and "bytes_per_entry" in pmc else None
         # rated on DISTINCT sectors: 4 B per entry read + 32 B per distinct sector written
         distinct_bytes = (4.0 * entries + 32.0 * entries * log_distinct["ratio"]) if log_distinct else None
@@ -489,7 +489,7 @@ def main():
                    "counted_over_traffic": (reset_bytes / traffic) if traffic else None,
                    "distinct_over_traffic": (distinct_bytes / traffic) if traffic and distinct_bytes else None,
                    "traffic_frac": (traffic / (avg[0] * 1e-3) / 1e9 / PEAK) if traffic else None,
-                   "traffic_source": "profiles/r05_pmc_reset.json: rocprofv3 --pmc FETCH_SIZE (doubled, gfx950 streaming-read "
+                   "traffic_source": "profiles/r06_pmc_reset.json (r05 until it exists): rocprofv3 --pmc FETCH_SIZE (doubled, gfx950 streaming-read "
                                      "correction) + WRITE_SIZE per log entry, scaled by this run's entry count" if traffic else None}
         roofline = {"bound": "hbm", "kernel": k_reset["kernel"],
                     "achieved": achieved, "peak": PEAK, "unit": "GB/s", "frac": frac,

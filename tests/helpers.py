@@ -228,3 +228,14 @@ def gridmap_fixture_frames(n=9):
         cam, R = pop.scene.camera_pose(-3.0 + 0.02 * k, 0.05 * np.sin(0.4 * k), 1.0 + 0.005 * k, 0.04 * np.sin(0.5 * k))
         out.append((img, cam, R))
     return out
+
+
+
+def dsp_fixture_inputs(n_updates=4, seed=7):
+    """the injected tables (Gaussian position / velocity noise, rand()) and a synthetic sensor sequence with labels for
+    tests/golden/make_dsp_fixture.py and tests/test_dsp_independent.py"""
+    pop = importlib.import_module("pred-occ-planner_amd")
+    dsp = importlib.import_module("pred-occ-planner_amd.dsp")
+    tables = dsp.make_tables(11, n_gauss=1 << 18, n_rand=1 << 12)
+    seq = pop.scene.make_dsp_sequence(seed, n_updates, half=(66 * 0.15 / 2, 66 * 0.15 / 2, 20 * 0.15 / 2))
+    return tables, seq

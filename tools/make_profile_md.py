@@ -1,8 +1,8 @@
-"""Assemble profiles/r05_end_rocprof.md and the PMC figures bench.py cites (profiles/r05_pmc_reset.json,
-r05_pmc_stamp.json, r05_pmc_traffic.json) from gpurun_out/profile/ (tools/make_profile.sh core + rest)."""
+"""Assemble profiles/r06_end_rocprof.md and the PMC figures bench.py cites (profiles/r06_pmc_reset.json,
+r06_pmc_stamp.json, r06_pmc_traffic.json) from gpurun_out/profile/ (tools/make_profile.sh core + rest)."""
 import json, os, re
 P = 'gpurun_out/profile/'
-R = 'r05'
+R = 'r06'
 KB = 1024.0
 
 
@@ -14,9 +14,12 @@ def read(f, default=""):
 
 
 def last_json(f):
+    """(the ONE line bench.py printed, everything it measured): since round 6 the line is compact and the full dictionary is
+    in the detail file make_profile.sh copies beside it"""
     for line in reversed(read(f).strip().splitlines()):
         if line.startswith('{'):
-            return line, json.loads(line)
+            det = read(f.replace('.json', '_detail.json'))
+            return line, (json.loads(det) if det.strip().startswith('{') else json.loads(line))
     return "", None
 
 
@@ -107,7 +110,7 @@ def lay_row(o):
 rows_line, rows_d = var['rows']
 fl_rows = [json.loads(l[7:]) for l in read('flight_rows.txt').splitlines() if l.startswith('FLIGHT ')]
 fl_runs = [json.loads(l[7:]) for l in read('flight.txt').splitlines() if l.startswith('FLIGHT ')]
-md = f"""# Round 5 — rocprofv3 profile of `python bench.py` (MI355X, 128 agents, 200^3 x 20), numbers of record
+md = f"""# Round 6 — rocprofv3 profile of `python bench.py` (MI355X, 128 agents, 200^3 x 20), numbers of record
 
 Collected by `tools/make_profile.sh core` and `... rest` on ONE GPU box (`cd /tmp && export TMPDIR=/tmp`), assembled by
 `tools/make_profile_md.py`:
