@@ -371,12 +371,13 @@ def main():
     log_distinct = None
     if sparse["enabled"]:
         import ctypes as _C
-        d3 = (_C.c_uint64 * 3)()
+        d3 = (_C.c_uint64 * 6)()
         fn = pop.lib().sogm_debug_log_distinct
         fn.restype, fn.argtypes = _C.c_int, [_C.c_void_p, _C.c_void_p]
         if fn(sw.map.ctx, d3) == 0 and d3[0] > 0:
             log_distinct = {"entries": int(d3[0]), "distinct_sectors": int(d3[1]), "ratio": d3[1] / d3[0],
                             "agents_overflowed": int(d3[2]),
+                            "duplicates_within_log_positions": {"8": int(d3[3]), "63": int(d3[4]), "1023": int(d3[5])},
                             "what": "the last timed tick's map: valid entries of its mark logs and the distinct sectors "
                                     "among them (sogm_debug_log_distinct: test-and-set over a throw-away bitmap, untimed)"}
     sw.map.set_profiling(True)  # restart the rings for the stage pass below

@@ -820,6 +820,12 @@ __device__ __forceinline__ void stamp_marks_trips(const GridGeom &g, void *__res
         if (g.tile) {
           dup = dup || (unsigned)__builtin_amdgcn_update_dpp(NONE, (int)sector, 0x112 /* row_shr:2 */, 0xF, 0xF, false) == sector;
           dup = dup || (unsigned)__builtin_amdgcn_update_dpp(NONE, (int)sector, 0x114 /* row_shr:4 */, 0xF, 0xF, false) == sector;
+#ifdef SOGM_LOOKBACK_FULL
+          dup = dup || (unsigned)__builtin_amdgcn_update_dpp(NONE, (int)sector, 0x113 /* row_shr:3 */, 0xF, 0xF, false) == sector;
+          dup = dup || (unsigned)__builtin_amdgcn_update_dpp(NONE, (int)sector, 0x115 /* row_shr:5 */, 0xF, 0xF, false) == sector;
+          dup = dup || (unsigned)__builtin_amdgcn_update_dpp(NONE, (int)sector, 0x116 /* row_shr:6 */, 0xF, 0xF, false) == sector;
+          dup = dup || (unsigned)__builtin_amdgcn_update_dpp(NONE, (int)sector, 0x117 /* row_shr:7 */, 0xF, 0xF, false) == sector;
+#endif
         }
         return __ballot(active && in && !dup);
       };
@@ -2535,34 +2541,52 @@ __global__ __launch_bounds__(256) void k_log_distinct(sogm::MarkLog lg, int n_ag
   const unsigned  n = lg.n[agent] > (unsigned)lg.cap ? (unsigned)lg.cap : lg.n[agent];
   const unsigned *e = lg.entries + (size_t)agent * lg.cap;
   unsigned       *bm = bitmap + (size_t)agent * words_per_agent;
-  unsigned long long ent = 0, dis = 0;
+  unsigned long long ent = 0, dis = 0, near8 = 0, near63 = 0, near1k = 0;
   for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const unsigned sec = e[i];
     if (sec == 0xFFFFFFFFu || (size_t)(sec >> 5) >= words_per_agent) continue;
     ++ent;
     const unsigned bit = 1u << (sec & 31);
     if (!(atomicOr(bm + (sec >> 5), bit) & bit)) ++dis;
+    // where the duplicates sit: an equal entry among the previous 8 / 63 / 1023 positions of the log (a wave appends its
+    // entries as one block: "within 63" ~ what a wave-wide de-duplication could remove, "within 1023" a workgroup-wide one)
+    bool d8 = false, d63 = false, d1k = false;
+    for (unsigned b = 1; b <= 1023 && b <= i; ++b)
+      if (e[i - b] == sec) {
+        d1k = true;
+        if (b <= 63) d63 = true;
+        if (b <= 8) d8 = true;
+        break;
+      }
+    near8 += d8, near63 += d63, near1k += d1k;
   }
   for (int d = 32; d >= 1; d >>= 1) {
     ent += __shfl_xor(ent, d, 64);
     dis += __shfl_xor(dis, d, 64);
+    near8 += __shfl_xor(near8, d, 64);
+    near63 += __shfl_xor(near63, d, 64);
+    near1k += __shfl_xor(near1k, d, 64);
   }
   if ((threadIdx.x & 63) == 0 && ent) {
     atomicAdd(out, ent);
     atomicAdd(out + 1, dis);
+    atomicAdd(out + 3, near8);
+    atomicAdd(out + 4, near63);
+    atomicAdd(out + 5, near1k);
   }
   if (blockIdx.x == 0 && threadIdx.x == 0 && lg.n[agent] > (unsigned)lg.cap) atomicAdd(out + 2, 1ull);
 }
 extern "C" {
-// host out3 = {valid entries of the current grid's mark logs (all agents), distinct sectors among them, agents whose log
-// overflowed (their reset is dense: not counted)}.  Synchronises; allocates and frees V T / 64 bytes per agent.
+// host out[6] = {valid entries of the current grid's mark logs (all agents), distinct sectors among them, agents whose log
+// overflowed (their reset is dense: not counted), entries with an equal entry among the previous 8 / 63 / 1023 log positions}.
+// Synchronises; allocates and frees V T / 64 bytes per agent.
 int sogm_debug_log_distinct(sogm_ctx *c, unsigned long long *out3_host) {
   if (!c || !out3_host) return SOGM_ERR_INVALID_ARG;
   SOGM_HIP_CHECK(hipSetDevice(c->device));
   SOGM_HIP_CHECK(hipDeviceSynchronize());
   const int     slot = sogm::cur_slot(c);
   sogm::MarkLog lg   = c->sparse ? sogm::mark_log(c, slot) : sogm::MarkLog{nullptr, nullptr, 0, nullptr};
-  out3_host[0] = out3_host[1] = out3_host[2] = 0;
+  for (int i = 0; i < 6; ++i) out3_host[i] = 0;
   if (!lg.entries || !c->tracked[slot]) return SOGM_ERR_STATE;
   const size_t cells_per_sector = 32 / c->cell_bytes();
   const size_t sectors = ((size_t)c->spec.T * (size_t)c->geom.V + cells_per_sector - 1) / cells_per_sector;
@@ -2570,16 +2594,16 @@ int sogm_debug_log_distinct(sogm_ctx *c, unsigned long long *out3_host) {
   unsigned           *bm = nullptr;
   unsigned long long *d  = nullptr;
   SOGM_HIP_CHECK(hipMalloc((void **)&bm, sizeof(unsigned) * words * (size_t)c->n_agents));
-  hipError_t e = hipMalloc((void **)&d, 3 * sizeof(unsigned long long));
+  hipError_t e = hipMalloc((void **)&d, 6 * sizeof(unsigned long long));
   if (e == hipSuccess) e = hipMemset(bm, 0, sizeof(unsigned) * words * (size_t)c->n_agents);
-  if (e == hipSuccess) e = hipMemset(d, 0, 3 * sizeof(unsigned long long));
+  if (e == hipSuccess) e = hipMemset(d, 0, 6 * sizeof(unsigned long long));
   if (e == hipSuccess) e = hipDeviceSynchronize();
   if (e == hipSuccess) {
     hipLaunchKernelGGL(k_log_distinct, dim3(64, c->n_agents), dim3(256), 0, nullptr, lg, c->n_agents, bm, words, d);
     e = hipGetLastError();
   }
   if (e == hipSuccess) e = hipDeviceSynchronize();
-  if (e == hipSuccess) e = hipMemcpy(out3_host, d, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(out3_host, d, 6 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
   (void)hipFree(bm);
   if (d) (void)hipFree(d);
   SOGM_HIP_CHECK(e);
