@@ -323,6 +323,12 @@ int osqpDense(const double *Pin, const double *qin, const double *Ain, const dou
   // still hold Ax - z and Px + q + A'y in SCALED form after update_info; OSQP 1.0 names them scaled_prim_res /
   // scaled_dual_res), with the scaled norms of z, Ax, q, A'y, Px
   double sc_pr = 0, sc_dr = 0, sc_nAx = 0, sc_nz = 0, sc_nPx = 0, sc_nAty = 0, sc_nq = 0;
+  // OSQP unscales its residual norms by MULTIPLYING with the stored reciprocals of the scaling (scaling.c: Dinv, Einv =
+  // vec_ew_recipr(D), (E) once; auxil.c compute_pri_res / compute_dua_res / is_primal_infeasible: vec_scaled_norm_inf(Einv, .),
+  // (Dinv, .)).  Until round 6 this restatement divided by E and D: the same number up to the last bit, not the same bits.
+  Vec Einv(m), Dinv(n);
+  for (int i = 0; i < m; ++i) Einv[i] = 1.0 / E[i];
+  for (int j = 0; j < n; ++j) Dinv[j] = 1.0 / D[j];
   auto residuals = [&](double eps_abs, double eps_rel, bool &prim_ok, bool &dual_ok) {
     double pr = 0, nAx = 0, nz = 0;
     sc_pr = sc_nAx = sc_nz = 0;
@@ -330,9 +336,9 @@ int osqpDense(const double *Pin, const double *qin, const double *Ain, const dou
       double s = 0;
       for (int j = 0; j < n; ++j) s += A[(size_t)i * n + j] * x[j];
       Ax[i] = s;
-      pr    = std::max(pr, std::fabs((s - z[i]) / E[i]));
-      nAx   = std::max(nAx, std::fabs(s / E[i]));
-      nz    = std::max(nz, std::fabs(z[i] / E[i]));
+      pr    = std::max(pr, std::fabs(Einv[i] * (s - z[i])));
+      nAx   = std::max(nAx, std::fabs(Einv[i] * s));
+      nz    = std::max(nz, std::fabs(Einv[i] * z[i]));
       sc_pr  = std::max(sc_pr, std::fabs(s - z[i]));
       sc_nAx = std::max(sc_nAx, std::fabs(s));
       sc_nz  = std::max(sc_nz, std::fabs(z[i]));
@@ -345,10 +351,10 @@ int osqpDense(const double *Pin, const double *qin, const double *Ain, const dou
       for (int i = 0; i < m; ++i) a += A[(size_t)i * n + j] * y[i];
       Px[j]  = s;
       Aty[j] = a;
-      dr     = std::max(dr, std::fabs((s + q[j] + a) / D[j]));
-      nPx    = std::max(nPx, std::fabs(s / D[j]));
-      nAty   = std::max(nAty, std::fabs(a / D[j]));
-      nq     = std::max(nq, std::fabs(q[j] / D[j]));
+      dr     = std::max(dr, std::fabs(Dinv[j] * (s + q[j] + a)));
+      nPx    = std::max(nPx, std::fabs(Dinv[j] * s));
+      nAty   = std::max(nAty, std::fabs(Dinv[j] * a));
+      nq     = std::max(nq, std::fabs(Dinv[j] * q[j]));
       sc_dr   = std::max(sc_dr, std::fabs(s + q[j] + a));
       sc_nPx  = std::max(sc_nPx, std::fabs(s));
       sc_nAty = std::max(sc_nAty, std::fabs(a));
@@ -386,7 +392,7 @@ int osqpDense(const double *Pin, const double *qin, const double *Ain, const dou
     for (int j = 0; j < n; ++j) {
       double s = 0;
       for (int i = 0; i < m; ++i) s += A[(size_t)i * n + j] * dy[i];
-      na = std::max(na, std::fabs(s / D[j]));
+      na = std::max(na, std::fabs(Dinv[j] * s));
     }
     return na < eps_inf * ndy;
   };

@@ -948,9 +948,10 @@ __device__ __forceinline__ void qp_solve_agent(const SogmPlannerParams &pp, cons
         if (c >= 0) s += R.gval[(size_t)r * QP_ELL + k] * s_x[c];
       }
       const double e = R.gE[r], z = R.gz[r];
-      m[0]           = dmax(m[0], dabs((s - z) / e));
-      m[1]           = dmax(m[1], dabs(s / e));
-      m[2]           = dmax(m[2], dabs(z / e));
+      const double ei = 1.0 / e;  // OSQP's Einv (scaling.c: vec_ew_recipr): the norms MULTIPLY by it (auxil.c)
+      m[0]           = dmax(m[0], dabs(ei * (s - z)));
+      m[1]           = dmax(m[1], dabs(ei * s));
+      m[2]           = dmax(m[2], dabs(ei * z));
       m[6]           = dmax(m[6], dabs(s - z));
       m[7]           = dmax(m[7], dabs(s));
       m[8]           = dmax(m[8], dabs(z));
@@ -964,9 +965,10 @@ __device__ __forceinline__ void qp_solve_agent(const SogmPlannerParams &pp, cons
       ax += v[1] * s_x[c0 + 1];
       ax += v[2] * s_x[c0 + 2];
       const double e = R.sE[s], z = R.sz[s];
-      m[0]           = dmax(m[0], dabs((ax - z) / e));
-      m[1]           = dmax(m[1], dabs(ax / e));
-      m[2]           = dmax(m[2], dabs(z / e));
+      const double ei = 1.0 / e;
+      m[0]           = dmax(m[0], dabs(ei * (ax - z)));
+      m[1]           = dmax(m[1], dabs(ei * ax));
+      m[2]           = dmax(m[2], dabs(ei * z));
       m[6]           = dmax(m[6], dabs(ax - z));
       m[7]           = dmax(m[7], dabs(ax));
       m[8]           = dmax(m[8], dabs(z));
@@ -978,10 +980,10 @@ __device__ __forceinline__ void qp_solve_agent(const SogmPlannerParams &pp, cons
       const int     b0 = (j / 15) * 15;
       for (int k = 0; k < 15; ++k) s += Pb[k] * s_x[b0 + k];
       const double a  = col_sum_y(j);
-      const double dj = s_D[j];
-      m[3]            = dmax(m[3], dabs((s + a) / dj));
-      m[4]            = dmax(m[4], dabs(s / dj));
-      m[5]            = dmax(m[5], dabs(a / dj));
+      const double dj = 1.0 / s_D[j];  // Dinv
+      m[3]            = dmax(m[3], dabs(dj * (s + a)));
+      m[4]            = dmax(m[4], dabs(dj * s));
+      m[5]            = dmax(m[5], dabs(dj * a));
       m[9]            = dmax(m[9], dabs(s + a));
       m[10]           = dmax(m[10], dabs(s));
       m[11]           = dmax(m[11], dabs(a));
@@ -1178,7 +1180,7 @@ __device__ __forceinline__ void qp_solve_agent(const SogmPlannerParams &pp, cons
         for (int i = 0; i < fj_n; ++i) a = __builtin_fma(fv[60 * i], fy[20 * i], a);
         a += dpp_quad(a, 0xB1);
         a += dpp_quad(a, 0x4E);
-        na = dabs(a / s_D[j]);
+        na = dabs((1.0 / s_D[j]) * a);
       }
     } else {
       for (int j = tid; j < n; j += QP_NT) {
@@ -1192,7 +1194,7 @@ __device__ __forceinline__ void qp_solve_agent(const SogmPlannerParams &pp, cons
           const int sr = sbase + 5 * f;
           a += R.sval[(size_t)sr * 3 + pd] * R.sdy[sr];
         }
-        na = dmax(na, dabs(a / s_D[j]));
+        na = dmax(na, dabs((1.0 / s_D[j]) * a));
       }
     }
     na = block_max(na, s_red);
@@ -1222,8 +1224,9 @@ __device__ __forceinline__ void qp_solve_agent(const SogmPlannerParams &pp, cons
       for (int k = 0; k < QP_ELL; ++k) ax += gv(k) * xg[k];  // absent entries are 0 * x[0]
       if (grow) {
         const double r_ = dabs(ax - g_z), n_ = dmax(dabs(ax), dabs(g_z));
-        v[0] = f32 ? (double)((float)r_ / (float)e) : r_ / e;
-        v[1] = f32 ? (double)((float)n_ / (float)e) : n_ / e;
+        const double ei = 1.0 / e;  // OSQP's Einv: the norms multiply by the stored reciprocal (one division per row)
+        v[0] = f32 ? (double)((float)r_ / (float)e) : ei * r_;
+        v[1] = f32 ? (double)((float)n_ / (float)e) : ei * n_;
         v[2] = r_;
         v[3] = n_;
         v[8] = dabs(e * d);
@@ -1246,8 +1249,9 @@ __device__ __forceinline__ void qp_solve_agent(const SogmPlannerParams &pp, cons
           const double d  = dr_ > 0.0 ? dr_ : 0.0;  // projection onto the polar of the recession cone
           R.sdy[sr]       = d;
           const double r_ = dabs(ax - s_zr(u)), n_ = dmax(dabs(ax), dabs(s_zr(u)));
-          v[0] = dmax(v[0], f32 ? (double)((float)r_ / (float)e) : r_ / e);
-          v[1] = dmax(v[1], f32 ? (double)((float)n_ / (float)e) : n_ / e);
+          const double ei = 1.0 / e;
+          v[0] = dmax(v[0], f32 ? (double)((float)r_ / (float)e) : ei * r_);
+          v[1] = dmax(v[1], f32 ? (double)((float)n_ / (float)e) : ei * n_);
           v[2] = dmax(v[2], r_);
           v[3] = dmax(v[3], n_);
           v[8] = dmax(v[8], dabs(e * d));
@@ -1283,10 +1287,10 @@ __device__ __forceinline__ void qp_solve_agent(const SogmPlannerParams &pp, cons
       s_ += dpp_quad(s_, 0x4E);
       a_ += dpp_quad(a_, 0x4E);
       if (q == 0) {
-        const double dj = s_D[j];
+        const double dj = s_D[j], di = 1.0 / dj;  // Dinv
         const double r_ = dabs(s_ + a_), n_ = dmax(dabs(s_), dabs(a_));
-        v[4] = f32 ? (double)((float)r_ / (float)dj) : r_ / dj;
-        v[5] = f32 ? (double)((float)n_ / (float)dj) : n_ / dj;
+        v[4] = f32 ? (double)((float)r_ / (float)dj) : di * r_;
+        v[5] = f32 ? (double)((float)n_ / (float)dj) : di * n_;
         v[6] = r_;
         v[7] = n_;
       }
