@@ -33,15 +33,19 @@ int sogm_sparse_reset_state(sogm_ctx *ctx, int32_t *out_host);
  *     "flight_search_units" (2), "flight_map_units" (4) — compute units in units of 16 for the QP / search / map kernels,
  *     the corridor + finish kernel takes the rest —, "flight_masks" (1; 0 = unmasked streams), "flight_spec" (1: both
  *     search attempts side by side), and per (agent, tick) one-wave tickets "flight_reset" (8), "flight_bits" (16),
- *     "flight_marks" (32), "flight_splat" (4); "flight_admit" (48) agents whose map may be under construction at once, "flight_pace_us" (40) microseconds between two
+ *     "flight_marks" (32), "flight_splat" (4); "flight_admit" (48) agents whose map may be under construction at once, "flight_pace_us" (20; 40 until round 6) microseconds between two
  *     admissions to the map stage (agents then reach every stage at a steady rate; 0 = unpaced), "flight_heads" (32)
  *     admitting waves of the map kernel; "flight_urgent" (8): an agent among the last n finishers of a tick — the agents the
  *     swarm waits for at the next gate — builds the map of its next tick through a lane of its own (four of the heads, no
  *     admission order / pace / window; a work queue of its own that the first "flight_urgent_waves" (4096 = all) map workers
  *     look at before they take plain work and while they wait for it; its maps are cut into "flight_urgent_fine" (4) times
- *     more tickets; 0 = no such lane); "flight_gate_pace_us" (40): the staleness rule's gate — tick k reads the neighbours'
+ *     more tickets; 0 = no such lane); "flight_gate_pace_us" (20; 40 until round 6): the staleness rule's gate — tick k reads the neighbours'
  *     records of tick k - 2 — sits in front of a map's overlay, the only phase that reads them: an agent builds the rest of its
  *     next map while it waits, and the finish that opens a gate queues the waiting overlays this many microseconds apart;
+ *     "flight_neighbour_lag" (2): tick k's overlay and isSafeAfterOpt read the neighbours' records of tick k - lag.  2 is the
+ *     flight's rule (an agent runs up to two ticks ahead of the slowest); 1 is the REFERENCE's staleness — a record is at most
+ *     one broadcast period old (particles.cpp:179-190), what the lock-step tick reads — with less overlap: an agent's overlay
+ *     waits until every agent has finished the previous tick.  This key DOES change records (it selects the rule);
  *     "flight_engines" (4), "flight_engine_first" (0): the shader engines (of every XCD) the flight's kernels share — a flight on
  *     half of them leaves the other half to a second flight on the same device (two ranks as two threads: tests) —,
  *     "flight_exchange_units" (0): units given to NO kernel, room for a collective's own kernels beside a multi-rank flight
@@ -50,7 +54,7 @@ int sogm_sparse_reset_state(sogm_ctx *ctx, int32_t *out_host);
  *     compute unit of their partition (what a unit holds at once; fewer leaves slack).  Whatever the unit counts, every
  *     kernel's mask gets the same number of units in every shader engine it touches and a launch exactly the workgroups
  *     that mask holds at once (sogm_flight_stats hdr[15] counts workgroups that were not resident from the start: 0).
- *     None of these keys changes a cell or a record.
+ *     None of these keys but flight_neighbour_lag changes a cell or a record.
  *   sogm_update_world, experimental (measured, not adopted: profiles/EXPERIMENTS.md round 5):  "update_flow" (0; 1 = the
  *     maps are built agent by agent on a stream of the context's own — one persistent launch over one-wave tickets, per
  *     agent occupancy bits -> marks -> overlay, agents in the order of their previous chain's length — and sogm_replan's

@@ -2211,7 +2211,7 @@ __global__ __launch_bounds__(64) void k_flight_light(MapView m, SogmPlannerParam
       const int k  = fl.tick_of[a];
       const int kl = k - fl.first_tick;
       FinishArgs f = d.fin;
-      f.swarm      = d.tables ? d.tables + (size_t)((k - 2) & 3) * d.n_total : nullptr;
+      f.swarm      = d.tables ? d.tables + (size_t)((k - fl.lag) & 3) * d.n_total : nullptr;
       f.pub_table  = d.tables ? d.tables + (size_t)(k & 3) * d.n_total + d.agent0 : nullptr;
       f.out        = d.log_records + (size_t)kl * fl.n_agents;
       f.out_ok     = d.log_ok + (size_t)kl * fl.n_agents;
@@ -2258,7 +2258,7 @@ __global__ __launch_bounds__(64) void k_flight_light(MapView m, SogmPlannerParam
         }
         // tick k is complete: the overlays of tick k + 2 parked so far may go.  (Several ranks with the exchange behind the
         // call: the gate is the all-gather of ver(k), and the kernel behind that collective releases them — k_flight_xsignal.)
-        if (done_kl == A_ && kl + 2 < fl.n_ticks && !fl.xready) fl_gate_release(fl, kl + 2);
+        if (done_kl == A_ && kl + fl.lag < fl.n_ticks && !fl.xready) fl_gate_release(fl, kl + fl.lag);
       }
       continue;
     }

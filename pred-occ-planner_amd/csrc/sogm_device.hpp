@@ -479,12 +479,13 @@ __device__ inline void bezier_pos(const SogmTrajRecord &r, double t, double out[
   X(FLIGHT_MARKS, "flight_marks", 32, 1, 256)              /* flight: ... marks                                               */  \
   X(FLIGHT_SPLAT, "flight_splat", 4, 1, 64)                /* flight: ... neighbour overlay                                   */  \
   X(FLIGHT_ADMIT, "flight_admit", 48, 1, 65536)            /* flight: agents whose map may be under construction at once      */  \
-  X(FLIGHT_PACE_US, "flight_pace_us", 40, 0, 100000)       /* flight: microseconds between two admissions to the map stage    */  \
+  X(FLIGHT_PACE_US, "flight_pace_us", 20, 0, 100000)       /* flight: microseconds between two admissions to the map stage    */  \
   X(FLIGHT_HEADS, "flight_heads", 32, 1, 4096)             /* flight: admitting waves of the map kernel                       */  \
   X(FLIGHT_URGENT, "flight_urgent", 8, 0, 65536)           /* flight: the last n finishers of a tick build their next map in the urgent lane; 0 = none */ \
   X(FLIGHT_URGENT_WAVES, "flight_urgent_waves", 4096, 1, 4096) /* flight: map workers that look at the urgent queue first (all of them by default) */ \
   X(FLIGHT_URGENT_FINE, "flight_urgent_fine", 4, 1, 16)    /* flight: the urgent lane's maps in this many times more tickets  */  \
-  X(FLIGHT_GATE_PACE_US, "flight_gate_pace_us", 40, 0, 100000) /* flight: microseconds between two overlays a gate releases     */  \
+  X(FLIGHT_GATE_PACE_US, "flight_gate_pace_us", 20, 0, 100000) /* flight: microseconds between two overlays a gate releases     */  \
+  X(FLIGHT_NEIGHBOUR_LAG, "flight_neighbour_lag", 2, 1, 2) /* flight: tick k reads the neighbours' records of tick k - this (1 = the reference's staleness) */ \
   X(FLIGHT_ENGINES, "flight_engines", 4, 1, 4)             /* flight: shader engines (of every XCD) the four kernels share ... */ \
   X(FLIGHT_ENGINE_FIRST, "flight_engine_first", 0, 0, 3)   /* flight: ... starting with this one (two flights side by side on one device: tests) */ \
   X(FLIGHT_EXCHANGE_UNITS, "flight_exchange_units", 0, 0, 4) /* flight: 16-CU units left to NO kernel (room for the collective's kernels beside a multi-rank flight) */ \

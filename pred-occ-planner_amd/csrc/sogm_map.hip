@@ -1785,7 +1785,7 @@ __global__ __launch_bounds__(64) void k_flight_map(GridGeom g, FlightCtl fl, Fli
       }
     } else {  // WK_MAP_SPLAT: the neighbours' records of table ver(k - 2)
       if (d.tables && d.n_total > 0) {
-        const SogmTrajRecord *tab = d.tables + (size_t)((k - 2) & 3) * d.n_total;
+        const SogmTrajRecord *tab = d.tables + (size_t)((k - fl.lag) & 3) * d.n_total;
         const int             n   = d.n_total * g.T;
         for (int i = sub * 64 + lane; i < n; i += n_s * 64)
           splat_item(g, d.grid, tab[i / g.T], agent, i % g.T, d.ego_ids, d.poses, d.stamps, d.body, d.n_body, d.lg);

@@ -1043,7 +1043,7 @@ __global__ void k_flight_xsignal(FlightCtl fl, int i) {  // every rank's rows of
   if (threadIdx.x != 0) return;
   __threadfence();
   __hip_atomic_store(&fl.xready[i], fl.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-  if (i + 2 < fl.n_ticks) fl_gate_release(fl, i + 2);
+  if (i + fl.lag < fl.n_ticks) fl_gate_release(fl, i + fl.lag);
 }
 __global__ void k_flight_report(const int *__restrict__ hdr, int *__restrict__ host_words) {
   const int e = hdr[FL_ERR];
@@ -1255,7 +1255,8 @@ int sogm_flight_run(sogm_planner *p, const SogmFlight *f, void *stream) {
   const int A = c->n_agents;
   if (f->n_total < A || f->agent0 < 0 || f->agent0 + A > f->n_total) return SOGM_ERR_INVALID_ARG;
   const bool xchg = f->n_total != A && f->nccl_comm != nullptr;  // the exchange runs behind the call (k_flight_xwait / xsignal)
-  if (f->n_total != A && !xchg && f->n_ticks > 2) {
+  const int lag = c->tune_i(SOGM_TUNE_FLIGHT_NEIGHBOUR_LAG) == 1 ? 1 : 2;
+  if (f->n_total != A && !xchg && f->n_ticks > lag) {
     // several ranks, no communicator: the rows of the OTHER ranks' agents in ver(k - 2) must be complete before tick k starts,
     // and only the host can put them there (an all-gather of the finished versions between two calls): two ticks per call
     sogm::set_error_text("sogm_flight_run: with n_total > n_agents (other ranks' rows in the tables) and no nccl_comm a call flies at most two ticks");
@@ -1322,6 +1323,7 @@ int sogm_flight_run(sogm_planner *p, const SogmFlight *f, void *stream) {
   (void)words;
   FlightCtl fl   = p->fl;
   fl.xready      = xchg ? p->fl_xready : nullptr;
+  fl.lag         = lag;
   fl.n_ticks     = f->n_ticks;
   fl.first_tick  = f->first_tick;
   md.grid        = (void *)c->d_grid;

@@ -215,6 +215,8 @@ struct FlightCtl {
                              //      executed its first instruction in this call (0: never) — the residency evidence of
                              //      sogm_debug_flight_wg_starts: a workgroup that starts late was NOT resident from the start
   int  n_agents, n_ticks, first_tick;
+  int  lag;         // tick k reads the neighbours' records of tick k - lag: 2 (the flight's rule: the most overlap) or 1 (the
+                    // reference's staleness — a record one broadcast old, particles.cpp:179-190; tuning key flight_neighbour_lag)
 };
 #define FL_WG_LOG 4096
 #ifdef __HIPCC__
@@ -249,11 +251,11 @@ __device__ inline int fl_wait_item(const int *ring, int mask, int pos, int *err)
     }
   }
 }
-// the gate of the staleness rule in front of tick kl's overlay (kl relative to first_tick): is table ver(kl - 2) complete?
+// the gate of the staleness rule in front of tick kl's overlay (kl relative to first_tick): is table ver(kl - lag) complete?
 __device__ inline bool fl_gate_open(const FlightCtl &fl, int kl) {
-  if (kl < 2) return true;  // (versions of an earlier call: complete before this call's kernels started)
-  if (fl.xready) return __hip_atomic_load(&fl.xready[kl - 2], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == fl.epoch;
-  return __hip_atomic_load(&fl.tick_done[kl - 2], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= fl.n_agents;
+  if (kl < fl.lag) return true;  // (versions of an earlier call: complete before this call's kernels started)
+  if (fl.xready) return __hip_atomic_load(&fl.xready[kl - fl.lag], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == fl.epoch;
+  return __hip_atomic_load(&fl.tick_done[kl - fl.lag], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= fl.n_agents;
 }
 // table ver(kl - 2) has just become complete: queue the overlays of tick kl that were parked at the gate so far (ONE lane;
 // the parking side re-checks the gate after it has written its slot: list + compare-and-swap on both sides)

@@ -27,9 +27,9 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def _lockstep_lag2(driver, grid, A, n, **kw):
+def _lockstep_lag2(driver, grid, A, n, lag=2, **kw):
     import torch
-    sw = driver.SwarmTick(grid, A, moving_world=True, prestamp=False, neighbour_lag=2, **kw)
+    sw = driver.SwarmTick(grid, A, moving_world=True, prestamp=False, neighbour_lag=lag, **kw)
     oks, recs = [], []
     for _ in range(n):
         oks.append(sw.step().cpu().numpy().copy())
@@ -250,3 +250,22 @@ def test_flight_through_frames_of_different_sizes(pop, monkeypatch):
     for k in range(K):
         assert np.array_equal(rec_f[k], rec_l[k]), f"tick {k}: agents {np.flatnonzero((rec_f[k] != rec_l[k]).any(axis=1))}"
     assert np.array_equal(own_f, own_l) and cnt_f == cnt_l
+
+
+def test_flight_with_the_references_staleness_equals_the_lockstep_tick(pop):
+    """VERDICT r05 missing #5: the reference's drones read records that are at most ONE broadcast old
+    (traj_coordinator/src/particles.cpp:179-190); the flight's default rule reads them two ticks old.  With
+    `flight_neighbour_lag` = 1 tick k's overlay and isSafeAfterOpt read table ver(k - 1) — an agent still builds the reset, bits
+    and marks of its next map while it waits for the swarm's previous tick — and the records must equal the ordinary lock-step
+    tick's (sogm_update_world + sogm_replan, the bench's headline rule), bit for bit: parity grid and 128 x 200^3 x 20."""
+    driver = importlib.import_module("pred-occ-planner_amd.driver")
+    for grid, A, K in (("parity", 6, 10), ("cfg2", 128, 6)):
+        ok_l, rec_l, own_l, cnt_l = _lockstep_lag2(driver, grid, A, K, lag=1)
+        ok_f, rec_f, own_f, last_f, cnt_f, ms = _flight(driver, grid, A, [K], tuning={"flight_neighbour_lag": 1})
+        assert ok_l.sum() > K * A // 3
+        assert np.array_equal(ok_f, ok_l), (grid, ok_f.sum(axis=1), ok_l.sum(axis=1))
+        for k in range(K):
+            assert np.array_equal(rec_f[k], rec_l[k]), f"{grid} tick {k}: agents {np.flatnonzero((rec_f[k] != rec_l[k]).any(axis=1))}"
+        assert np.array_equal(own_f, own_l) and cnt_f == cnt_l
+        print(grid, "flight with the reference's staleness, mean ms per agent-tick:",
+              dict(zip(pop._abi.FLIGHT_STAT_NAMES, (ms[:, :7].sum(axis=0) / ms[:, 7].sum()).round(3))))
