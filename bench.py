@@ -43,6 +43,8 @@ def parse():
                     help="ticks of the block that runs the DENSE clear inside the tick (kernels[dense clear].in_tick; 0 = skip)")
     ap.add_argument("--sustained", type=int, default=300,
                     help="ticks of the sustained-flight block after the timed region (0 = skip)")
+    ap.add_argument("--watchdog", type=float, default=240.0,
+                    help="N > 1: seconds the sections after the headline may take before rank 0 prints the line without them (0 = off)")
     ap.add_argument("--no-variants", action="store_true", dest="no_variants",
                     help="skip the labelled variants (pre-stamped lock-step, sogm_flight_run) and the cfg1 / cfg4 blocks")
     return ap.parse_args()
@@ -199,6 +201,40 @@ def _r(x, nd=2):
     return None if x is None else round(float(x), nd)
 
 
+class PostHeadlineWatchdog:
+    """N > 1 only.  Once the headline of the line is measured, nothing after it may cost the line: if the sections behind it
+    (dense ticks, sustained ticks, the multi-rank flight — none of which has run on more than one REAL GPU before the driver's
+    first scaling run) do not finish within `seconds`, rank 0 prints the line with what it has, `watchdog` naming the section
+    that hung, and every rank leaves with os._exit (a rank stuck inside a collective cannot be joined).  The other ranks
+    leave a little later than rank 0 so that its line is out before their end of the communicator goes away."""
+
+    def __init__(self, out, rank, seconds):
+        import threading
+        self.out, self.rank, self.section, self.done = out, rank, "start", False
+        self.t = threading.Timer(seconds + (0 if rank == 0 else 15), self.fire)
+        self.t.daemon = True
+        self.t.start()
+
+    def fire(self):
+        if self.done:
+            return
+        if self.rank == 0:
+            self.out["watchdog"] = f"the sections after the headline did not finish in time; hung in: {self.section}"
+            self.out.setdefault("variants", {})
+            if self.section == "flight":
+                self.out["variants"]["flight"] = {"error": ["watchdog: the multi-rank flight did not return"], "flights_failed": 1}
+            self.out.setdefault("cpu_baseline", None)
+            try:
+                print(json.dumps(compact_line(self.out)), flush=True)
+            finally:
+                os._exit(0)
+        os._exit(0)
+
+    def cancel(self):
+        self.done = True
+        self.t.cancel()
+
+
 def compact_line(out):
     """The ONE JSON line bench.py prints.  Everything measured goes to a file (profiles/bench_last_detail.json here, copied to
     gpurun_out/ when that exists); the line keeps the contract's keys, the roofline and cpu_baseline objects without their
@@ -223,6 +259,8 @@ def compact_line(out):
     line["config"] = cfg
     if "multi_gpu" in out:
         line["multi_gpu"] = out["multi_gpu"]
+    if "watchdog" in out:
+        line["watchdog"] = out["watchdog"]
     line["detail_file"] = detail_paths
     line["roofline"] = {k: ro.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_frac",
                                                "achieved_distinct", "frac_distinct", "bytes_per_launch", "avg_launch_ms",
@@ -243,7 +281,9 @@ def compact_line(out):
                    "sust_best_ms": _r(g(fl, "sustained", "ms_per_tick_best_flight")),
                    "map_gate_ms": _r((g(fl, "per_agent_tick_ms", "map") or 0) + (g(fl, "per_agent_tick_ms", "gate_wait") or 0))
                    if fl.get("per_agent_tick_ms") else None,
-                   "flights": fl.get("flights"), "flights_failed": fl.get("flights_failed")} if fl else None,
+                   "flights": fl.get("flights"), "flights_failed": fl.get("flights_failed"),
+                   **({"ranks": fl.get("ranks")} if fl.get("ranks") else {}),
+                   **({"err": json.dumps(fl["error"])[:100]} if fl.get("error") else {})} if fl else None,
         "chain_ms": {"astar": _r(ch.get("astar_mean")), "corr": _r(ch.get("corridor_mean")), "corr_max": _r(ch.get("corridor_max")),
                      "qp": _r(ch.get("qp_mean")), "qp_max": _r(ch.get("qp_max")), "mean": _r(ch.get("chain_mean")),
                      "end": _r(ch.get("chain_end")), "qp_us_it": _r(g(ch, "slowest_qp", "us_per_iteration"), 3)} if ch else None,
@@ -597,6 +637,9 @@ def main():
                             "exchange": exchange_kind}
         if any(int(t[1].item()) != world for t in allr):
             raise SystemExit(f"bench.py: ncclCommCount != {world} on some rank: {out['multi_gpu']}")
+    dog = PostHeadlineWatchdog(out, rank, args.watchdog) if world > 1 and args.watchdog > 0 else None
+    if dog:
+        dog.section = "dense ticks"
     # ---- the dense clear INSIDE the tick (sparse reset off): the fill of SURVEY 8(d) as the tick used to run it
     sw.map.set_overlap_clear(overlap_mode != 0, grids=(overlap_mode if overlap_mode >= 2 else 1))
     if sparse["enabled"] and args.dense_ticks > 0:
@@ -619,6 +662,8 @@ def main():
         sw.map.set_profiling(False)
     variants = {}
     sparse_on, pool_mode = sparse["enabled"], sw.overlap_mode
+    if dog:
+        dog.section = "sustained lock-step ticks"
     if args.sustained > 0:
         # sustained flight: the 20-step figure covers the first seconds (agents still far apart); keep flying —
         # the swarm converges on the centre, searches get longer — and time every tick (host-synchronised)
@@ -801,6 +846,8 @@ def main():
         variants["flight"] = fl
         fw.close()
         torch.cuda.empty_cache()
+    if dog:
+        dog.section = "flight"
     if not args.no_variants and world > 1 and moving and args.steps <= pop._abi.FLIGHT_MAX_TICKS:
         # ---- labelled variant on N > 1 ranks: the flight with the exchange BEHIND the call (SogmFlight::nccl_comm): every rank
         # flies warm-up + timed ticks in ONE sogm_flight_run each, the per-tick all-gathers of the table versions are queued
@@ -925,6 +972,8 @@ def main():
         out["cpu_baseline"] = cpu_baseline(pop, spec, scene_kept, args.cpu_agents)
     else:
         out["cpu_baseline"] = None
+    if dog:
+        dog.cancel()
     if rank == 0:
         print(json.dumps(compact_line(out)))
     if dist is not None:

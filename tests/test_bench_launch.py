@@ -97,3 +97,43 @@ def test_the_printed_line_ends_with_a_compact_summary(bench, tmp_path, monkeypat
                                                                                   "ms_per_tick_best_flight": 8.1}}
     s = bench.compact_line(_fake_out(bad))["summary"]["flight"]
     assert s["v"] is None and s["sust_v"] is None and s["flights_failed"] == 1 and s["sust_worst_ms"] == 52.0
+
+
+def test_a_hung_section_after_the_headline_does_not_cost_the_line(tmp_path):
+    """N > 1: the sections behind the headline have never run on more than one real GPU.  If one of them hangs (a rank stuck in a
+    collective), rank 0 still prints the line — headline intact, the hung section named, the flight counted as failed — and
+    the process leaves by itself with exit code 0."""
+    import json
+    import subprocess
+
+    (tmp_path / "profiles").mkdir()
+    code = f"""
+import importlib.util, sys, time
+sys.path.insert(0, {os.path.join(ROOT, 'tests')!r})
+spec = importlib.util.spec_from_file_location("bench_mod", {os.path.join(ROOT, 'bench.py')!r})
+m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
+from test_bench_launch import _fake_out
+m.ROOT = {str(tmp_path)!r}
+out = _fake_out(None)
+for k in ("sustained", "variants", "configs", "cpu_baseline"):
+    out.pop(k)
+out["n_gpus"] = 8
+dog = m.PostHeadlineWatchdog(out, 0, 0.3)
+dog.section = "flight"
+time.sleep(30)          # "stuck in a collective"
+print("NOT REACHED")
+"""
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=25)
+    assert r.returncode == 0, r.stderr[-500:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and "NOT REACHED" not in r.stdout
+    line = json.loads(lines[0])
+    assert line["value"] == 14644.88 and line["n_gpus"] == 8 and "flight" in line["watchdog"]
+    assert line["summary"]["flight"]["flights_failed"] == 1 and line["summary"]["flight"]["v"] is None
+    # a rank other than 0 leaves silently (later than rank 0); a cancelled watchdog does nothing
+    code2 = code.replace("PostHeadlineWatchdog(out, 0, 0.3)", "PostHeadlineWatchdog(out, 1, -14.7)")
+    r = subprocess.run([sys.executable, "-c", code2], capture_output=True, text=True, timeout=25)
+    assert r.returncode == 0 and r.stdout.strip() == ""
+    code3 = code.replace("time.sleep(30)", "dog.cancel(); time.sleep(1)")
+    r = subprocess.run([sys.executable, "-c", code3], capture_output=True, text=True, timeout=25)
+    assert r.returncode == 0 and r.stdout.strip() == "NOT REACHED"
