@@ -268,7 +268,8 @@ __device__ __forceinline__ void qp_solve_agent(const SogmPlannerParams &pp, cons
   const size_t head1 = ((size_t)n * (QP_BW + 1) + (size_t)M * 225) * sizeof(double);
   const size_t head4 = (size_t)M * 225 * 4 * sizeof(double);
   const size_t k1_bytes = (size_t)n * (QP_BW + 1) * sizeof(double);
-  const bool   fast  = use_blocks && G <= 256 && S <= 1024 &&
+  // (the check of the register-resident path stages y through factor()'s block area: it must hold one double per row and 320 partial results)
+  const bool   fast  = use_blocks && G <= 256 && S <= 1024 && (size_t)(G + S) + 320 <= (size_t)M * 675 &&
                     head4 + rows_hot_bytes(G, S) <= (size_t)ws.dyn_lds_bytes;
   const size_t head        = fast ? head4 : head1;
   const size_t rows_al     = (rows_bytes(G, S) + 15) & ~(size_t)15;
@@ -1111,7 +1112,28 @@ __device__ __forceinline__ void qp_solve_agent(const SogmPlannerParams &pp, cons
       if (grow) h_gw[t] = g_rho * g_z - g_y;
     }
   };
-  // registers -> row storage, for the residual / termination code that reads it
+  // The termination check's view of y: the column quads' A^T y reads every row's y, which lives in the row lanes'
+  // registers.  It is staged through LDS — factor()'s block area (s_Dv ..), dead between two factorisations — and not
+  // through the row storage: for the largest problems (8 pieces) the cold row arrays sit in HBM scratch, and a check
+  // paid a store + fence + dependent L2 loads per face for it (the column loop was a chain of L2 round trips).
+  double *const c_sy = (double *)qp_smem + (size_t)M * 225;  // [S] safety rows' y (FAST only: == s_Dv)
+  double *const c_gy = c_sy + S;                             // [G] general rows' y
+  double *const c_red = c_gy + G;                            // [32][10] the check's row-level partial reductions
+  auto fast_stage_y = [&]() __attribute__((always_inline)) {
+    const int t = launder(tid);
+    if (grole) {
+      if (grow) c_gy[t] = g_y;
+    } else {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int sr = (t - 256) + 256 * u;
+        if (sr < S) c_sy[sr] = s_yr(u);
+      }
+    }
+    if (ccol && (t & 3) == 0) s_x[t >> 2] = xj;
+    __syncthreads();
+  };
+  // registers -> row storage: before a refactorisation (set_rho() and fast_load() read z and y from there)
   auto fast_spill = [&]() __attribute__((always_inline)) {
     const int t = launder(tid);
     if (grole) {
@@ -1176,8 +1198,21 @@ __device__ __forceinline__ void qp_solve_agent(const SogmPlannerParams &pp, cons
       if (ccol) {  // A^T dy on the column quads, as the dual norms above
         const int     j = tid >> 2;
         double        a = __builtin_fma(cv[1], R.gdy[cr[1]], cv[0] * R.gdy[cr[0]]);
-        const double *fv = R.sval + fj_sv, *fy = R.sdy + fj_sw;
-        for (int i = 0; i < fj_n; ++i) a = __builtin_fma(fv[60 * i], fy[20 * i], a);
+        const double *fvp = h_sv + fj_sv, *fyp = R.sdy + fj_sw;
+        const double *fv0 = fvp, *fy0 = fyp;
+#pragma unroll 1
+        for (int i0 = 0; i0 < fj_n; i0 += 4, fvp += 240, fyp += 80) {  // four faces per round trip (delta_y may sit in HBM scratch)
+          double av[4], bv[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const bool ok = i0 + u < fj_n;
+            av[u]         = *(ok ? fvp + 60 * u : fv0);
+            bv[u]         = *(ok ? fyp + 20 * u : fy0);
+            bv[u]         = ok ? bv[u] : 0.0;
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) a = __builtin_fma(av[u], bv[u], a);
+        }
         a += dpp_quad(a, 0xB1);
         a += dpp_quad(a, 0x4E);
         na = dabs((1.0 / s_D[j]) * a);
@@ -1210,6 +1245,11 @@ __device__ __forceinline__ void qp_solve_agent(const SogmPlannerParams &pp, cons
   auto fast_residuals = [&]() __attribute__((always_inline)) {
     const int  t = launder(tid), lane = t & 63, wave = t >> 6;
     const bool f32 = qs.residual_fp32 != 0;  // BASELINE configs[4]: residual norms / reductions in fp32
+    // |x| as the operand modifier and max as v_max_f64: written as "x < 0 ? -x : x" / "a > b ? a : b" each cost a compare
+    // and two selects per use, ~50 a row slot (they differ from these in the sign of a zero and in which NaN survives:
+    // neither reaches a threshold test)
+    auto fab = [](double x) __attribute__((always_inline)) { return __builtin_fabs(x); };
+    auto fmx = [](double a, double b) __attribute__((always_inline)) { return __builtin_fmax(a, b); };
     double    v[10];
 #pragma unroll
     for (int k = 0; k < 10; ++k) v[k] = 0.0;
@@ -1223,24 +1263,33 @@ __device__ __forceinline__ void qp_solve_agent(const SogmPlannerParams &pp, cons
 #pragma unroll
       for (int k = 0; k < QP_ELL; ++k) ax += gv(k) * xg[k];  // absent entries are 0 * x[0]
       if (grow) {
-        const double r_ = dabs(ax - g_z), n_ = dmax(dabs(ax), dabs(g_z));
+        const double r_ = fab(ax - g_z), n_ = fmx(fab(ax), fab(g_z));
         const double ei = 1.0 / e;  // OSQP's Einv: the norms multiply by the stored reciprocal (one division per row)
         v[0] = f32 ? (double)((float)r_ / (float)e) : ei * r_;
         v[1] = f32 ? (double)((float)n_ / (float)e) : ei * n_;
         v[2] = r_;
         v[3] = n_;
-        v[8] = dabs(e * d);
+        v[8] = fab(e * d);
         v[9] = g_hi * (d > 0 ? d : 0) + g_lo * (d < 0 ? d : 0);
       }
     } else {
+      // every slot's E and delta_y first: behind the store of a projected delta_y the next slot's loads could not be
+      // moved up (the compiler cannot tell the arrays apart), and with the cold rows in HBM scratch each slot then
+      // cost an L2 round trip of its own
+      double se[4], sd[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int sr = (t - 256) + 256 * u, sc = sr < S ? sr : 0;
+        se[u] = R.sE[sc];
+        sd[u] = R.sdy[sc];
+      }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         if (256 * u >= S) continue;  // workgroup-uniform
         const int    sr = (t - 256) + 256 * u;
         const bool   ok = sr < S;
-        const int    sc = ok ? sr : 0;
         const double x0 = s_x[s_c(u)], x1 = s_x[s_c(u) + 1], x2 = s_x[s_c(u) + 2];
-        const double e = R.sE[sc], dr_ = R.sdy[sc];
+        const double e = se[u], dr_ = sd[u];
         double       ax = 0.0;
         ax += sv(u, 0) * x0;
         ax += sv(u, 1) * x1;
@@ -1248,13 +1297,13 @@ __device__ __forceinline__ void qp_solve_agent(const SogmPlannerParams &pp, cons
         if (ok) {
           const double d  = dr_ > 0.0 ? dr_ : 0.0;  // projection onto the polar of the recession cone
           R.sdy[sr]       = d;
-          const double r_ = dabs(ax - s_zr(u)), n_ = dmax(dabs(ax), dabs(s_zr(u)));
+          const double r_ = fab(ax - s_zr(u)), n_ = fmx(fab(ax), fab(s_zr(u)));
           const double ei = 1.0 / e;
-          v[0] = dmax(v[0], f32 ? (double)((float)r_ / (float)e) : ei * r_);
-          v[1] = dmax(v[1], f32 ? (double)((float)n_ / (float)e) : ei * n_);
-          v[2] = dmax(v[2], r_);
-          v[3] = dmax(v[3], n_);
-          v[8] = dmax(v[8], dabs(e * d));
+          v[0] = fmx(v[0], f32 ? (double)((float)r_ / (float)e) : ei * r_);
+          v[1] = fmx(v[1], f32 ? (double)((float)n_ / (float)e) : ei * n_);
+          v[2] = fmx(v[2], r_);
+          v[3] = fmx(v[3], n_);
+          v[8] = fmx(v[8], fab(e * d));
           v[9] += s_hi(u) * d;
         }
       }
@@ -1274,10 +1323,25 @@ __device__ __forceinline__ void qp_solve_agent(const SogmPlannerParams &pp, cons
         xk[u]       = s_x[b0 + kk];
       }
 #pragma unroll
-      for (int e = 0; e < 2; ++e) yg[e] = R.gy[cr[e]];
+      for (int e = 0; e < 2; ++e) yg[e] = c_gy[cr[e]];
       double        s_ = 0.0, a_ = 0.0;
-      const double *fv = R.sval + fj_sv, *fy = R.sy + fj_sw;
-      for (int i = 0; i < fj_n; ++i) a_ = __builtin_fma(fv[60 * i], fy[20 * i], a_);
+      {  // the faces' terms in face order, eight independent LDS reads per round trip (as the iteration's A^T w)
+        const double *fvp = h_sv + fj_sv, *fyp = c_sy + fj_sw;
+        const double *fv0 = fvp, *zero = s_xt + 127;  // s_xt is zero beyond n
+#pragma unroll 1
+        for (int i0 = 0; i0 < fj_n; i0 += 4, fvp += 240, fyp += 80) {
+          double a[4], b[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const bool ok = i0 + u < fj_n;
+            a[u]          = *(ok ? fvp + 60 * u : fv0);
+            b[u]          = *(ok ? fyp + 20 * u : zero);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) a_ = __builtin_fma(a[u], b[u], a_);  // (an absent face adds v * 0)
+        }
+      }
 #pragma unroll
       for (int u = 0; u < 4; ++u) s_ = __builtin_fma(q + 4 * u < 15 ? pk[u] : 0.0, xk[u], s_);
 #pragma unroll
@@ -1288,7 +1352,7 @@ __device__ __forceinline__ void qp_solve_agent(const SogmPlannerParams &pp, cons
       a_ += dpp_quad(a_, 0x4E);
       if (q == 0) {
         const double dj = s_D[j], di = 1.0 / dj;  // Dinv
-        const double r_ = dabs(s_ + a_), n_ = dmax(dabs(s_), dabs(a_));
+        const double r_ = fab(s_ + a_), n_ = fmx(fab(s_), fab(a_));
         v[4] = f32 ? (double)((float)r_ / (float)dj) : di * r_;
         v[5] = f32 ? (double)((float)n_ / (float)dj) : di * n_;
         v[6] = r_;
@@ -1300,33 +1364,56 @@ __device__ __forceinline__ void qp_solve_agent(const SogmPlannerParams &pp, cons
       for (int k = 0; k < 9; ++k) {
         float fv = (float)v[k];
         if ((double)fv < v[k]) fv = __int_as_float(__float_as_int(fv) + 1);  // next float up (v >= 0, finite)
-        v[k] = (double)wave_max_dpp_f(fv);
+        v[k] = (double)fv;  // (the maximum of floats is the same number whichever width carries it)
       }
-    } else {
-#pragma unroll
-      for (int k = 0; k < 9; ++k) v[k] = wave_max_dpp(v[k]);
     }
-    v[9] = wave_sum_dpp(v[9]);
-    if (lane == 0) {
+    // Ten reductions over 512 lanes: inside each 16-lane row on the DPP path (two quad permutes, row_half_mirror,
+    // row_mirror), then ONE LDS round over the 32 row results of the workgroup (c_red, behind the staged y) instead of
+    // four readlanes + three operations per value and wave: 40 lanes — value k, waves 2 p and 2 p + 1 — fold eight rows
+    // each and meet through two quad permutes.  The bound product keeps its summation tree: rows (r0 + r16) + (r32 + r48)
+    // per wave, waves ((w0 + w1) + (w2 + w3)) + ((w4 + w5) + (w6 + w7)).
 #pragma unroll
-      for (int k = 0; k < 10; ++k) s_red12[wave * 12 + k] = v[k];
+    for (int k = 0; k < 9; ++k) {
+      double x = v[k];
+      x        = __builtin_fmax(x, dpp_ctrl_t<0xB1>(x));
+      x        = __builtin_fmax(x, dpp_ctrl_t<0x4E>(x));
+      x        = __builtin_fmax(x, dpp_ctrl_t<0x141>(x));
+      v[k]     = __builtin_fmax(x, dpp_ctrl_t<0x140>(x));
+    }
+    {
+      double x = v[9];
+      x += dpp_ctrl_t<0xB1>(x);
+      x += dpp_ctrl_t<0x4E>(x);
+      x += dpp_ctrl_t<0x141>(x);
+      v[9] = x + dpp_ctrl_t<0x140>(x);
+    }
+    if ((lane & 15) == 0) {
+      double *o = c_red + (wave * 4 + (lane >> 4)) * 10;
+#pragma unroll
+      for (int k = 0; k < 10; ++k) o[k] = v[k];
     }
     __syncthreads();
-    if (t < 10) {
-      double r_;
-      if (t == 9) {
-        r_ = ((s_red12[9] + s_red12[21]) + (s_red12[33] + s_red12[45])) + ((s_red12[57] + s_red12[69]) + (s_red12[81] + s_red12[93]));
+    if (t < 40) {  // (wave 0)
+      const int     k = t >> 2, pq = t & 3;
+      const double *o = c_red + (size_t)(8 * pq) * 10 + k;  // rows 8 pq .. 8 pq + 7: waves 2 pq, 2 pq + 1
+      double        r_;
+      if (k == 9) {
+        r_ = ((o[0] + o[10]) + (o[20] + o[30])) + ((o[40] + o[50]) + (o[60] + o[70]));
+        r_ += dpp_quad(r_, 0xB1);
+        r_ += dpp_quad(r_, 0x4E);
       } else {
-        r_ = s_red12[t];
-        for (int w = 1; w < QP_NT / 64; ++w) r_ = dmax(r_, s_red12[12 * w + t]);
+        r_ = __builtin_fmax(__builtin_fmax(__builtin_fmax(o[0], o[10]), __builtin_fmax(o[20], o[30])),
+                            __builtin_fmax(__builtin_fmax(o[40], o[50]), __builtin_fmax(o[60], o[70])));
+        r_ = __builtin_fmax(r_, dpp_quad(r_, 0xB1));
+        r_ = __builtin_fmax(r_, dpp_quad(r_, 0x4E));
       }
       // slots: pr 0 | max(nAx, nz) 1 | sc_pr 8 | max(sc_nAx, sc_nz) 9 | dr 3 | max(nPx, nAty) 4 | sc_dr 11 |
       // max(sc_nPx, sc_nAty) 12 | ||dy|| 7 | bound product 15
-      const int slot = t == 0 ? 0 : t == 1 ? 1 : t == 2 ? 8 : t == 3 ? 9 : t == 4 ? 3 : t == 5 ? 4 : t == 6 ? 11 : t == 7 ? 12 : t == 8 ? 7 : 15;
-      s_sc[slot] = t == 4 ? r_ * cinv : r_;
+      const int slot = k == 0 ? 0 : k == 1 ? 1 : k == 2 ? 8 : k == 3 ? 9 : k == 4 ? 3 : k == 5 ? 4 : k == 6 ? 11 : k == 7 ? 12 : k == 8 ? 7 : 15;
+      if (pq == 0) s_sc[slot] = k == 4 ? r_ * cinv : r_;
     }
-    if (t >= 10 && t < 16)  // the partners of the pair maxima, and ||q|| = 0
-      s_sc[t == 10 ? 2 : t == 11 ? 5 : t == 12 ? 6 : t == 13 ? 10 : t == 14 ? 13 : 14] = 0.0;
+    if (t >= 64 && t < 70)  // the partners of the pair maxima, and ||q|| = 0 (a lane of wave 1)
+      s_sc[t == 64 ? 2 : t == 65 ? 5 : t == 66 ? 6 : t == 67 ? 10 : t == 68 ? 13 : 14] = 0.0;
     __syncthreads();
   };
 
@@ -1547,7 +1634,7 @@ __device__ __forceinline__ void qp_solve_agent(const SogmPlannerParams &pp, cons
       const long long dbg_c0 = wall_clock64();
       ++dbg_ncheck;
       if constexpr (FAST) {
-        fast_spill();
+        fast_stage_y();
         const long long dbg_c1 = wall_clock64();
         dbg_k1 += dbg_c1 - dbg_c0;
         fast_residuals();
@@ -1588,6 +1675,7 @@ __device__ __forceinline__ void qp_solve_agent(const SogmPlannerParams &pp, cons
           ++dbg_nrefac;
           rho_cur  = rho_new;
           rinv_cur = 1.0 / rho_cur;
+          if constexpr (FAST) fast_spill();  // z, y: set_rho() and fast_load() read them from the row storage
           set_rho();
           if (!factor()) {
             status   = -7;
@@ -1605,7 +1693,7 @@ __device__ __forceinline__ void qp_solve_agent(const SogmPlannerParams &pp, cons
     }
     if (!finished) {  // max_iter reached
       if constexpr (FAST) {
-        fast_spill();
+        fast_stage_y();
         fast_residuals();
       } else {
         residuals();
