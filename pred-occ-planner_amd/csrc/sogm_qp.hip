@@ -678,18 +678,18 @@ __device__ __forceinline__ void qp_solve_agent(const SogmPlannerParams &pp, cons
         for (int p = 0; p < 15; ++p) {
           const double *A_ = s_T[cur];
           const double  d  = A_[p * 16];  // every lane reads the pivot: the failure test is workgroup-uniform
+          // (the lane's pivot-column and pivot-row entries are read WITH the pivot, whether or not the lane is on the
+          //  pivot's row or column: read inside the branch they were issued behind the division — read, divide, read,
+          //  multiply-add, store, barrier as one chain per sweep; er, ec < 15 for every lane)
+          const double arp = A_[er * 15 + p], apc = A_[p * 15 + ec];
           if (!(d > 0.0)) {
             if (tid == 0) s_flag = 0;
             break;
           }
           if (el) {
             const double inv = 1.0 / d;
-            if (er != p && ec != p)
-              a = __builtin_fma(-(A_[er * 15 + p] * A_[p * 15 + ec]), inv, a);
-            else if (er == p && ec == p)
-              a = -inv;
-            else
-              a = a * inv;
+            const double gen = __builtin_fma(-(arp * apc), inv, a);
+            a                = (er != p && ec != p) ? gen : (er == p && ec == p) ? -inv : a * inv;
             s_T[cur ^ 1][tid] = a;
           }
           cur ^= 1;
