@@ -469,27 +469,35 @@ __device__ __forceinline__ void qp_solve_agent(const SogmPlannerParams &pp, cons
   const int sbase = s_off[pi] + pk, nface = s_nf[pi];                   \
   (void)pd;
 
+  const long long dbg_s1 = wall_clock64() - dbg_t0;
   // ---- 3. Ruiz equilibration with cost scaling (OSQP scale_data)
   double c_scale = 1.0;
+  // (maxima of |.|: the operand modifier and v_max_f64 — the values are finite, a maximum does not depend on the order
+  //  its candidates are visited in, so a column's entries are split over a lane quad and meet through two DPP steps;
+  //  every product, square root and division is the one the plain loops of OSQP's scale_data perform)
   for (int it = 0; it < qs.scaling_iters; ++it) {
-    for (int j = tid; j < n; j += QP_NT) {
+    for (int jq = launder(tid); jq < 4 * n; jq += QP_NT) {  // four lanes per column (a quad is in or out as a whole)
+      const int     j = jq >> 2, q = jq & 3;
       double        mx = 0;
       const double *Pb = s_P + (j / 15) * 225;
       const int     jj = j % 15;
-      for (int i = 0; i < 15; ++i) mx = dmax(mx, dabs(Pb[i * 15 + jj]));
-      for (int a = s_cptr[j]; a < s_cptr[j + 1]; ++a) {
+      for (int i = q; i < 15; i += 4) mx = __builtin_fmax(mx, __builtin_fabs(Pb[i * 15 + jj]));
+      for (int a = s_cptr[j] + q; a < s_cptr[j + 1]; a += 4) {
         const int e = R.cidx[a];
-        mx          = dmax(mx, dabs(R.gval[(size_t)(e >> 3) * QP_ELL + (e & 7)]));
+        mx          = __builtin_fmax(mx, __builtin_fabs(R.gval[(size_t)(e >> 3) * QP_ELL + (e & 7)]));
       }
       COL_DECODE(j)
-      for (int f = 0; f < nface; ++f) mx = dmax(mx, dabs(R.sval[(size_t)(sbase + 5 * f) * 3 + pd]));
-      s_Dt[j] = 1.0 / sogm_det::sqrt_rn(limit_scaling(mx));
+      for (int f = q; f < nface; f += 4)
+        mx = __builtin_fmax(mx, __builtin_fabs(R.sval[(size_t)(sbase + 5 * f) * 3 + pd]));
+      mx = __builtin_fmax(mx, dpp_quad(mx, 0xB1));
+      mx = __builtin_fmax(mx, dpp_quad(mx, 0x4E));
+      if (q == 0) s_Dt[j] = 1.0 / sogm_det::sqrt_rn(limit_scaling(mx));
     }
     __syncthreads();
     for (int r = tid; r < G; r += QP_NT) {
       double mx = 0;
       for (int k = 0; k < QP_ELL; ++k)
-        if (R.gcol[(size_t)r * QP_ELL + k] >= 0) mx = dmax(mx, dabs(R.gval[(size_t)r * QP_ELL + k]));
+        if (R.gcol[(size_t)r * QP_ELL + k] >= 0) mx = __builtin_fmax(mx, __builtin_fabs(R.gval[(size_t)r * QP_ELL + k]));
       const double et = 1.0 / sogm_det::sqrt_rn(limit_scaling(mx));
       for (int k = 0; k < QP_ELL; ++k) {
         const int c = R.gcol[(size_t)r * QP_ELL + k];
@@ -498,13 +506,10 @@ __device__ __forceinline__ void qp_solve_agent(const SogmPlannerParams &pp, cons
       R.gE[r] *= et;
     }
     for (int s = tid; s < S; s += QP_NT) {
-      int i = 0;
-      while (i + 1 < M && s >= s_off[i + 1]) ++i;
-      const int    k  = (s - s_off[i]) % 5;
       double      *v  = R.sval + (size_t)s * 3;
-      const double mx = dmax(dmax(dabs(v[0]), dabs(v[1])), dabs(v[2]));
+      const double mx = __builtin_fmax(__builtin_fmax(__builtin_fabs(v[0]), __builtin_fabs(v[1])), __builtin_fabs(v[2]));
       const double et = 1.0 / sogm_det::sqrt_rn(limit_scaling(mx));
-      const int    c0 = i * 15 + k * 3;
+      const int    c0 = R.sc0[s];  // piece * 15 + point * 3 (assembled once: not searched for in every pass)
       v[0] *= et * s_Dt[c0];
       v[1] *= et * s_Dt[c0 + 1];
       v[2] *= et * s_Dt[c0 + 2];
@@ -516,12 +521,15 @@ __device__ __forceinline__ void qp_solve_agent(const SogmPlannerParams &pp, cons
     }
     for (int j = tid; j < n; j += QP_NT) s_D[j] *= s_Dt[j];
     __syncthreads();
-    for (int j = tid; j < n; j += QP_NT) {
+    for (int jq = launder(tid); jq < 4 * n; jq += QP_NT) {
+      const int     j = jq >> 2, q = jq & 3;
       double        mx = 0;
       const double *Pb = s_P + (j / 15) * 225;
       const int     jj = j % 15;
-      for (int i = 0; i < 15; ++i) mx = dmax(mx, dabs(Pb[i * 15 + jj]));
-      s_cn[j] = mx;
+      for (int i = q; i < 15; i += 4) mx = __builtin_fmax(mx, __builtin_fabs(Pb[i * 15 + jj]));
+      mx = __builtin_fmax(mx, dpp_quad(mx, 0xB1));
+      mx = __builtin_fmax(mx, dpp_quad(mx, 0x4E));
+      if (q == 0) s_cn[j] = mx;
     }
     __syncthreads();
     if (tid == 0) {
@@ -545,6 +553,7 @@ __device__ __forceinline__ void qp_solve_agent(const SogmPlannerParams &pp, cons
   for (int s = tid; s < S; s += QP_NT) R.su[s] *= R.sE[s];
   const double cinv = 1.0 / c_scale;
   __syncthreads();
+  const long long dbg_s2 = wall_clock64() - dbg_t0;
 
   // ---- helpers -----------------------------------------------------------------------------------
   double rho_cur = qs.rho;  // safety rows are one-sided inequalities: their rho is rho_cur itself
@@ -1419,6 +1428,7 @@ __device__ __forceinline__ void qp_solve_agent(const SogmPlannerParams &pp, cons
 
   set_rho();
   if constexpr (FAST) build_K1();
+  const long long dbg_s3 = wall_clock64() - dbg_t0;
   bool chol_ok = factor();
   const long long dbg_setup = wall_clock64() - dbg_t0;
   int  status = -2, iter = 0;
@@ -1726,6 +1736,9 @@ __device__ __forceinline__ void qp_solve_agent(const SogmPlannerParams &pp, cons
       o[12] = dbg_k1;  // checks: the spill of the row state | the residual pass (the rest of o[4]: tests, certificate)
       o[13] = dbg_k2;  // shader clocks of the whole solve (o[0]: the same span in 10 ns ticks)
       o[0] = wall_clock64() - dbg_t0;
+      // set-up split, three 20-bit fields of 10 ns ticks since the start: assembly + CSC done | Ruiz scaling done | rho + K1 done
+      // (o[1] - the third: the first factorisation and the load of the row state)
+      o[14] = dbg_s1 | (dbg_s2 << 20) | (dbg_s3 << 40);
       o[1] = dbg_setup;
       o[2] = dbg_refac;
       o[3] = dbg_nrefac;

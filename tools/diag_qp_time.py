@@ -17,6 +17,7 @@ lib.sogm_debug_qp_stats.argtypes = [C.c_void_p, C.c_void_p]
 tot = np.zeros(8)
 fac = np.zeros(4)
 chk = np.zeros(3)
+stp = np.zeros(5)
 for k in range(ticks):
     sw.step()
     torch.cuda.synchronize()
@@ -29,6 +30,9 @@ for k in range(ticks):
     tot[:4] += us[ok].sum(0); tot[4] += plain[ok].sum(); tot[5] += it[ok].sum(); tot[6] += st[ok, 3].sum(); tot[7] += st[ok, 5].sum()
     fac[:3] += st[ok, 8:11].sum(0) / 100.0; fac[3] += (st[ok, 3] + 1).sum()
     chk[:2] += st[ok, 12:14].sum(0) / 100.0; chk[2] += st[ok, 5].sum()
+    w = st[ok, 14]
+    s1, s2, s3 = (w & 0xFFFFF) / 100.0, ((w >> 20) & 0xFFFFF) / 100.0, ((w >> 40) & 0xFFFFF) / 100.0
+    stp += np.array([s1.sum(), (s2 - s1).sum(), (s3 - s2).sum(), (st[ok, 1] / 100.0 - s3).sum(), ok.sum()])
     if k % every:
         continue
     order = np.argsort(-us[:, 0])[:8]
@@ -41,3 +45,4 @@ print(f"all solves of {ticks} ticks: set-up {tot[1]/tot[0]:.1%}, refactorisation
 print(f"shader clock during the solves of the last tick: {np.median(st[ok, 11] / (st[ok, 0] * 10.0)):.2f} GHz (median over agents)")
 print(f"factor() phases, us per factorisation: block assembly {fac[0]/fac[3]:.1f}, forward sweeps {fac[1]/fac[3]:.1f}, backward rows + registers {fac[2]/fac[3]:.1f}")
 print(f"checks, us each: spill of the row state {chk[0]/chk[2]:.2f}, residual pass {chk[1]/chk[2]:.2f}, tests / certificate {tot[3]/tot[7] - (chk[0]+chk[1])/chk[2]:.2f}")
+print(f"set-up, us per solve: assembly + CSC {stp[0]/stp[4]:.1f}, Ruiz scaling {stp[1]/stp[4]:.1f}, rho + K1 {stp[2]/stp[4]:.1f}, first factorisation + load {stp[3]/stp[4]:.1f}")
