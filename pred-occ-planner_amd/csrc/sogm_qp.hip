@@ -472,16 +472,31 @@ __device__ __forceinline__ void qp_solve_agent(const SogmPlannerParams &pp, cons
   const long long dbg_s1 = wall_clock64() - dbg_t0;
   // ---- 3. Ruiz equilibration with cost scaling (OSQP scale_data)
   double c_scale = 1.0;
-  // (maxima of |.|: the operand modifier and v_max_f64 — the values are finite, a maximum does not depend on the order
-  //  its candidates are visited in, so a column's entries are split over a lane quad and meet through two DPP steps;
-  //  every product, square root and division is the one the plain loops of OSQP's scale_data perform)
+  // Restated for the device without changing one rounding:
+  //  * maxima of |.| with the operand modifier and v_max_f64 (finite values); a maximum does not depend on the order of
+  //    its candidates, so a column's entries are split over a lane quad and meet through two DPP steps;
+  //  * the cost scaling's P <- c P is applied by the NEXT pass's P <- (c P) (d_r d_c) — the same two products per
+  //    entry in the same order (a last sweep after the loop) — and the P part of the next pass's column norm is
+  //    fl(c * cn_j) without reading P again: x -> fl(c x) is monotone for c > 0, so the largest entry stays the largest;
+  //  * the quad that owns column j scales P's column j and takes its norm in one phase.
+  // Three barriers per pass instead of five; every product, square root and division is one OSQP's scale_data performs.
+  auto p_colmax = [&](int j, int q) __attribute__((always_inline)) -> double {
+    const double *Pb = s_P + (j / 15) * 225 + j % 15;
+    double        mx = 0;
+    for (int i = q; i < 15; i += 4) mx = __builtin_fmax(mx, __builtin_fabs(Pb[i * 15]));
+    mx = __builtin_fmax(mx, dpp_quad(mx, 0xB1));
+    return __builtin_fmax(mx, dpp_quad(mx, 0x4E));
+  };
+  for (int jq = launder(tid); jq < 4 * n; jq += QP_NT) {  // (a quad is in or out of a trip as a whole)
+    const double mx = p_colmax(jq >> 2, jq & 3);
+    if ((jq & 3) == 0) s_cn[jq >> 2] = mx;
+  }
+  double ct_prev = 1.0;  // the previous pass's c, not yet applied to s_P (x 1.0 is exact)
+  __syncthreads();
   for (int it = 0; it < qs.scaling_iters; ++it) {
-    for (int jq = launder(tid); jq < 4 * n; jq += QP_NT) {  // four lanes per column (a quad is in or out as a whole)
-      const int     j = jq >> 2, q = jq & 3;
-      double        mx = 0;
-      const double *Pb = s_P + (j / 15) * 225;
-      const int     jj = j % 15;
-      for (int i = q; i < 15; i += 4) mx = __builtin_fmax(mx, __builtin_fabs(Pb[i * 15 + jj]));
+    for (int jq = launder(tid); jq < 4 * n; jq += QP_NT) {
+      const int j = jq >> 2, q = jq & 3;
+      double    mx = q == 0 ? s_cn[j] * ct_prev : 0.0;  // max |c P(:, j)|
       for (int a = s_cptr[j] + q; a < s_cptr[j + 1]; a += 4) {
         const int e = R.cidx[a];
         mx          = __builtin_fmax(mx, __builtin_fabs(R.gval[(size_t)(e >> 3) * QP_ELL + (e & 7)]));
@@ -515,21 +530,22 @@ __device__ __forceinline__ void qp_solve_agent(const SogmPlannerParams &pp, cons
       v[2] *= et * s_Dt[c0 + 2];
       R.sE[s] *= et;
     }
-    for (int i = tid; i < M * 225; i += QP_NT) {
-      const int b = i / 225, rr = (i % 225) / 15, cc = i % 15;
-      s_P[i] *= s_Dt[b * 15 + rr] * s_Dt[b * 15 + cc];
-    }
-    for (int j = tid; j < n; j += QP_NT) s_D[j] *= s_Dt[j];
-    __syncthreads();
-    for (int jq = launder(tid); jq < 4 * n; jq += QP_NT) {
-      const int     j = jq >> 2, q = jq & 3;
+    for (int jq = launder(tid); jq < 4 * n; jq += QP_NT) {  // P(:, j) <- (c_prev P(:, j)) (d_r d_j), and its norm
+      const int     j = jq >> 2, q = jq & 3, b15 = (j / 15) * 15;
+      double       *Pb = s_P + (j / 15) * 225 + j % 15;
+      const double  dj = s_Dt[j];
       double        mx = 0;
-      const double *Pb = s_P + (j / 15) * 225;
-      const int     jj = j % 15;
-      for (int i = q; i < 15; i += 4) mx = __builtin_fmax(mx, __builtin_fabs(Pb[i * 15 + jj]));
+      for (int i = q; i < 15; i += 4) {
+        const double v = (Pb[i * 15] * ct_prev) * (s_Dt[b15 + i] * dj);
+        Pb[i * 15]     = v;
+        mx             = __builtin_fmax(mx, __builtin_fabs(v));
+      }
       mx = __builtin_fmax(mx, dpp_quad(mx, 0xB1));
       mx = __builtin_fmax(mx, dpp_quad(mx, 0x4E));
-      if (q == 0) s_cn[j] = mx;
+      if (q == 0) {
+        s_cn[j] = mx;
+        s_D[j] *= dj;
+      }
     }
     __syncthreads();
     if (tid == 0) {
@@ -541,11 +557,10 @@ __device__ __forceinline__ void qp_solve_agent(const SogmPlannerParams &pp, cons
       s_sc[0]       = 1.0 / c_temp;
     }
     __syncthreads();
-    const double ct = s_sc[0];
-    for (int i = tid; i < M * 225; i += QP_NT) s_P[i] *= ct;
-    c_scale *= ct;
-    __syncthreads();
+    ct_prev = s_sc[0];
+    c_scale *= ct_prev;
   }
+  for (int i = tid; i < M * 225; i += QP_NT) s_P[i] *= ct_prev;  // the last pass's c
   for (int r = tid; r < G; r += QP_NT) {
     R.gl[r] *= R.gE[r];
     R.gu[r] *= R.gE[r];
