@@ -698,27 +698,32 @@ __device__ __forceinline__ void qp_solve_agent(const SogmPlannerParams &pp, cons
         if (el) s_T[1][tid] = a;
         __syncthreads();
         int cur = 1;
+        // A sweep is bound by the LDS instructions the workgroup issues, and only 225 lanes hold an entry: waves 4-7 skip
+        // the body and meet the others at the barrier (a non-positive pivot therefore cannot end the loop early: it is
+        // remembered, the sweeps run on — on values nobody reads — and the flag is set behind the loop).
+        // (The lane's pivot-column and pivot-row entries are read WITH the pivot, whether or not the lane is on the
+        //  pivot's row or column: read inside that branch they were issued behind the division — read, divide, read,
+        //  multiply-add, store, barrier as one chain per sweep; er, ec < 15 for every lane.)
+        const bool act = tid < 256;  // wave-uniform
+        bool       bad = false;
 #pragma unroll 1
         for (int p = 0; p < 15; ++p) {
-          const double *A_ = s_T[cur];
-          const double  d  = A_[p * 16];  // every lane reads the pivot: the failure test is workgroup-uniform
-          // (the lane's pivot-column and pivot-row entries are read WITH the pivot, whether or not the lane is on the
-          //  pivot's row or column: read inside the branch they were issued behind the division — read, divide, read,
-          //  multiply-add, store, barrier as one chain per sweep; er, ec < 15 for every lane)
-          const double arp = A_[er * 15 + p], apc = A_[p * 15 + ec];
-          if (!(d > 0.0)) {
-            if (tid == 0) s_flag = 0;
-            break;
-          }
-          if (el) {
-            const double inv = 1.0 / d;
-            const double gen = __builtin_fma(-(arp * apc), inv, a);
-            a                = (er != p && ec != p) ? gen : (er == p && ec == p) ? -inv : a * inv;
-            s_T[cur ^ 1][tid] = a;
+          if (act) {
+            const double *A_  = s_T[cur];
+            const double  d   = A_[p * 16];
+            const double  arp = A_[er * 15 + p], apc = A_[p * 15 + ec];
+            bad               = bad || !(d > 0.0);
+            if (el) {
+              const double inv = 1.0 / d;
+              const double gen = __builtin_fma(-(arp * apc), inv, a);
+              a                = (er != p && ec != p) ? gen : (er == p && ec == p) ? -inv : a * inv;
+              s_T[cur ^ 1][tid] = a;
+            }
           }
           cur ^= 1;
           __syncthreads();
         }
+        if (bad && tid == 0) s_flag = 0;
         if (el) s_Dv[i * 225 + tid] = -a;  // inv(S_i)
         __syncthreads();
         if (!s_flag) break;  // uniform
