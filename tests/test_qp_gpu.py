@@ -109,9 +109,9 @@ def _box_chain(M, nf, max_faces, rng, tau_len=0.3):
 # (pieces, faces per polytope): 12 x 6 -> general path (no block factor), rows in LDS;
 # 8 x 30 -> S = 1200 rows: general path, row storage in HBM scratch;
 # 8 x 25 -> S = 1000: register-resident iteration with the cold row data in HBM scratch;
-# 5 x 40 -> S = 1000 with few pieces; 3 x 6 -> the common small case; 16 x 5 -> the most pieces the ABI takes (n = 240: the
+# 5 x 40 -> S = 1000 with few pieces; 3 x 6 -> the common small case; 16 x 6 -> the most pieces the ABI takes (n = 240: the
 # set-up's column quads take two trips)
-@pytest.mark.parametrize("M,nf", [(12, 6), (8, 30), (8, 25), (5, 40), (3, 6), (16, 5)])
+@pytest.mark.parametrize("M,nf", [(12, 6), (8, 30), (8, 25), (5, 40), (3, 6), (16, 6)])
 def test_qp_solver_paths_match_oracle(pop, orc, M, nf):
     import torch
     sogm = importlib.import_module("pred-occ-planner_amd.sogm")
