@@ -560,8 +560,20 @@ __device__ __forceinline__ double costMVIE(const MvieData &D, const double *x, d
   wave_lds_sync();
   double sum = 0.0;
   if (lane < 10) {
+    // the running sum in face order, its LDS reads four at a time (read one, wait, add one was a chain of LDS latencies
+    // as long as the number of faces the ellipsoid touches); a row beyond n re-reads row n - 1 and is not added
     const double *src = terms + lane;
-    for (int r = 0; r < n; ++r) sum += src[r * 10];
+    for (int r = 0; r < n; r += 4) {
+      double t4[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) t4[u] = src[(r + u < n ? r + u : n - 1) * 10];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const double t = sum + t4[u];
+        sum            = r + u < n ? t : sum;
+      }
+    }
   }
   wave_lds_sync();  // the next evaluation overwrites `terms`
   double acc[10];
@@ -801,20 +813,37 @@ __device__ __forceinline__ int lbfgsMVIE(const MvieData &D, double *x, double *l
           return acc;
         };
 #undef LBFGS_BC
+        // (the next entry's two elements are read while the current entry's chain — product, ordered sum, division, update —
+        //  runs: the address does not depend on it, and read at the top of its own trip the LDS latency stood in front of
+        //  every entry.  The read past the last entry of a loop is of a valid slot and unused.)
+        int    jn = j == 0 ? m - 1 : j - 1;
+        double ns = lm_s[jn * n + ql], ny = lm_y[jn * n + ql];
+        double hsq = 0.0, hyq = 0.0;
         for (int i = 0; i < bound; ++i) {
-          j = j == 0 ? m - 1 : j - 1;
-          const double hsq = lm_s[j * n + ql], hyq = lm_y[j * n + ql];
+          j   = jn;
+          hsq = ns;
+          hyq = ny;
+          jn  = j == 0 ? m - 1 : j - 1;
+          ns  = lm_s[jn * n + ql];
+          ny  = lm_y[jn * n + ql];
           const double alpha = ordered_sum(hsq * dl) / lane_f64(ys_keep, j);
           if (lane == j) al_keep = alpha;  // lm_alpha[j]
           dl += (-alpha) * hyq;
         }
         dl *= ys / yy;
+        jn = j;  // the second loop starts at the entry the first one ended with: its elements are still in hsq / hyq
+        ns = hsq;
+        ny = hyq;
         for (int i = 0; i < bound; ++i) {
-          const double hsq = lm_s[j * n + ql], hyq = lm_y[j * n + ql];
+          j   = jn;
+          hsq = ns;
+          hyq = ny;
+          jn  = j + 1 == m ? 0 : j + 1;
+          ns  = lm_s[jn * n + ql];
+          ny  = lm_y[jn * n + ql];
           const double beta = ordered_sum(hyq * dl) / lane_f64(ys_keep, j);
           const double al   = lane_f64(al_keep, j);
           dl += (al - beta) * hsq;
-          j = j + 1 == m ? 0 : j + 1;
         }
 #pragma unroll
         for (int q = 0; q < n; ++q) d[q] = lane_f64(dl, q);
