@@ -494,17 +494,64 @@ __device__ inline double lane_f64(double v, int l) {  // value of lane l (l wave
   hi     = __builtin_amdgcn_readlane(hi, l);
   return __hiloint2double(hi, lo);
 }
-// one face's terms of cost and gradient (firi.hpp:105-122); false when smoothedL1 rejects the face
+// N independent IEEE fp64 divisions x[i] / y[i], stage by stage: the instruction sequence the compiler expands "x / y" to
+// (v_div_scale of the denominator and of the numerator, v_rcp, two Newton steps on the reciprocal, the quotient, its
+// residual, v_div_fmas, v_div_fixup — LLVM's LowerFDIV64), so every quotient has the bits of the plain division; written
+// out because the expansion passes its scale flag through VCC, which makes the compiler emit N divisions as N chains of
+// thirteen dependent instructions one after the other — on a wave that is alone on its SIMD and issues in order, N times
+// ~110 cycles.  Stage-wise the chains overlap (the flags live in ordinary scalar registers until their v_div_fmas).
+template <int N>
+__device__ __forceinline__ void div_n(const double (&x)[N], const double (&y)[N], double (&q)[N]) {
+  double s0[N], s1[N], r[N], e[N], m[N];
+  bool   fl[N], unused;
+#pragma unroll
+  for (int i = 0; i < N; ++i) s0[i] = __builtin_amdgcn_div_scale(x[i], y[i], false, &unused);  // the denominator, scaled
+#pragma unroll
+  for (int i = 0; i < N; ++i) r[i] = __builtin_amdgcn_rcp(s0[i]);
+#pragma unroll
+  for (int i = 0; i < N; ++i) s1[i] = __builtin_amdgcn_div_scale(x[i], y[i], true, &fl[i]);  // the numerator, scaled
+#pragma unroll
+  for (int i = 0; i < N; ++i) e[i] = __builtin_fma(-s0[i], r[i], 1.0);
+#pragma unroll
+  for (int i = 0; i < N; ++i) r[i] = __builtin_fma(r[i], e[i], r[i]);
+#pragma unroll
+  for (int i = 0; i < N; ++i) e[i] = __builtin_fma(-s0[i], r[i], 1.0);
+#pragma unroll
+  for (int i = 0; i < N; ++i) r[i] = __builtin_fma(r[i], e[i], r[i]);
+#pragma unroll
+  for (int i = 0; i < N; ++i) m[i] = s1[i] * r[i];
+#pragma unroll
+  for (int i = 0; i < N; ++i) e[i] = __builtin_fma(-s0[i], m[i], s1[i]);
+#pragma unroll
+  for (int i = 0; i < N; ++i) q[i] = __builtin_amdgcn_div_fixup(__builtin_amdgcn_div_fmas(e[i], r[i], m[i], fl[i]), y[i], x[i]);
+}
+
+// one face's terms of cost and gradient (firi.hpp:105-122); false when smoothedL1 rejects the face.  The face's five
+// divisions — A L / ||A L|| and the two of smoothedL1's cubic branch (firi.hpp's x / mu and 3 (mu - x / 2) / mu, evaluated
+// whether or not the branch is the lane's: some lane of the wave takes it) — go through div_n together.
 __device__ inline bool mvie_face(const double a[3], const double L[3][3], const double *p,
                                  double smoothEps, double t[10]) {
   double AL[3];
   for (int j = 0; j < 3; ++j) AL[j] = (a[0] * L[0][j] + a[1] * L[1][j]) + a[2] * L[2][j];
   const double normAL = sogm_det::sqrt_rn((AL[0] * AL[0] + AL[1] * AL[1]) + AL[2] * AL[2]);
-  const double adj[3] = {AL[0] / normAL, AL[1] / normAL, AL[2] / normAL};
   const double Ap     = (a[0] * p[0] + a[1] * p[1]) + a[2] * p[2];
   const double viola  = (normAL + Ap) - 1.0;
+  const double mu = smoothEps, mumxd2 = mu - 0.5 * viola;
+  const double nx[5] = {AL[0], AL[1], AL[2], viola, 3.0 * mumxd2}, ny[5] = {normAL, normAL, normAL, mu, mu};
+  double       qd[5];
+  div_n<5>(nx, ny, qd);
+  const double adj[3] = {qd[0], qd[1], qd[2]};
   double       c, dc;
-  if (!smoothedL1(smoothEps, viola, c, dc)) return false;
+  // smoothedL1(mu, viola, c, dc) with its two quotients taken from above
+  if (viola < 0.0) return false;
+  if (viola > mu) {
+    c  = viola - 0.5 * mu;
+    dc = 1.0;
+  } else {
+    const double xdmu = qd[3], sqrxdmu = xdmu * xdmu;
+    c  = mumxd2 * sqrxdmu * xdmu;
+    dc = sqrxdmu * ((-0.5) * xdmu + qd[4]);
+  }
   t[0]                = c;
   const double vec[3] = {dc * a[0], dc * a[1], dc * a[2]};
   for (int j = 0; j < 3; ++j) t[1 + j] = vec[j];
