@@ -143,6 +143,7 @@ int sogm_planner_create(sogm_ctx *map, const SogmAstarParams *astar, const SogmP
   if (e == hipSuccess) e = hipMalloc(&p->aw.hkeys, 8 * (size_t)hc * A * 2);
   if (e == hipSuccess) e = hipMalloc((void **)&p->aw.verdict, sizeof(int) * A);
   if (e == hipSuccess) e = hipMalloc((void **)&p->aw.dbg, sizeof(long long) * 8 * A);
+  if (e == hipSuccess) e = hipMemset(p->aw.dbg, 0, sizeof(long long) * 8 * A);
   if (e == hipSuccess) e = hipMalloc((void **)&p->d_ret, sizeof(int32_t) * A);
   if (e == hipSuccess) e = hipMalloc((void **)&p->d_route_len, sizeof(int32_t) * A);
   if (e == hipSuccess) e = hipMalloc((void **)&p->d_stats, sizeof(int32_t) * 4 * A);
@@ -163,6 +164,8 @@ int sogm_planner_create(sogm_ctx *map, const SogmAstarParams *astar, const SogmP
     if (e == hipSuccess) e = hipMalloc((void **)&p->cw.seg_state, sizeof(int32_t) * slots);
     if (e == hipSuccess) e = hipMalloc((void **)&p->cw.seg_npts, sizeof(int32_t) * slots);
     if (e == hipSuccess) e = hipMalloc((void **)&p->cw.seg_dbg, sizeof(long long) * 16 * slots);
+    // (slots no segment ever ran in are read by sogm_debug_corridor_stats as well: zero, not whatever the allocation held)
+    if (e == hipSuccess) e = hipMemset(p->cw.seg_dbg, 0, sizeof(long long) * 16 * slots);
     if (e == hipSuccess) e = hipMalloc((void **)&p->cw.counters, sizeof(unsigned long long) * SOGM_CNT_N);
     if (e == hipSuccess) e = hipMemset(p->cw.counters, 0, sizeof(unsigned long long) * SOGM_CNT_N);
     // QP row storage fallback (rows normally live in LDS)
